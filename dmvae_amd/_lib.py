@@ -1,0 +1,54 @@
+"""ctypes binding of libdmvae_hip.so (the C ABI declared in include/dmvae_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (or ``make -C dmvae_amd/csrc``).
+Loading fails loudly: there is no Python/CPU fallback for any entry point.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdmvae_hip.so")
+
+
+class ConvDesc(Structure):
+    """struct dmvae_conv_desc (include/dmvae_hip.h)."""
+    _fields_ = [("n", c_int32), ("h", c_int32), ("w", c_int32), ("cin", c_int32), ("cout", c_int32),
+                ("ks", c_int32), ("upsample", c_int32), ("act", c_int32), ("out_f32", c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/dmvae_hip.h declares
+SIGNATURES = {
+    "dmvae_last_error": (c_char_p, []),
+    "dmvae_abi_version": (c_int, []),
+    "dmvae_conv2d_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_void_p]),
+}
+
+_lib = None
+
+
+class DmvaeHipError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DmvaeHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C dmvae_amd/csrc` (there is no CPU fallback)")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().dmvae_last_error()
+        raise DmvaeHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,17 @@
+// C-ABI plumbing: thread-local error string + version.
+#include "common.h"
+#include "dmvae_hip.h"
+#include <cstdarg>
+#include <cstdio>
+
+static thread_local char g_err[512] = "";
+
+void dmvae_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* dmvae_last_error(void) { return g_err; }
+extern "C" int dmvae_abi_version(void) { return 1; }

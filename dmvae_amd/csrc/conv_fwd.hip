@@ -1,0 +1,226 @@
+// Implicit-GEMM convolution forward for NHWC bf16 activations on gfx950 (MI355X).
+//
+// Replaces the vendor conv the reference reaches through nn.Conv2d in
+// models/flux_ae.py:63,65,67 (ResnetBlock), :32-35 (AttnBlock 1x1), :101 (Upsample conv,
+// with the nearest-x2 of :104 folded into the gather), :274/:237 (conv_in / conv_out) and
+// the nn.Linear GEMMs of models/vae.py:58-62 (ks=1, H=W=1).  The same kernel computes
+// dgrad of a stride-1 conv when handed tap-flipped / transposed weights.
+//
+//   D[cout][pixel] = sum_{tap, ci} Wt[cout][tap][ci] * X[pixel (+) tap][ci]
+//
+// Tile 128 (cout) x 128 (pixels) x BK (ci chunk of one tap); 4 waves in 2x2, each wave a
+// 64x64 sub-tile = 2x2 v_mfma_f32_32x32x16_bf16 accumulators.  Operand tiles are DMA'd
+// straight into LDS with global_load_lds (16 B/lane); the XOR bank swizzle is applied on
+// the per-lane *source* address (LDS image stays lane-linear) and again on the ds_read_b128
+// fragment reads.  Padding pixels / out-of-range rows source a device zero page.
+#include "common.h"
+#include "dmvae_hip.h"
+
+namespace dmvae_conv_fwd {
+
+struct ConvArgs {
+  const bf16* x;      // [N, Hi, Wi, Cin]
+  const bf16* w;      // [Cout, T, Cin]
+  const float* bias;  // [Cout] or null
+  const bf16* res;    // [N, Ho, Wo, Cout] or null
+  void* y;            // [N, Ho, Wo, Cout] bf16 or f32
+  int N, Hi, Wi, Cin, Ho, Wo, Cout;
+  int ks, ups, act, M;
+};
+
+constexpr int TM = 128;  // cout rows per tile  (MFMA "A" operand)
+constexpr int TP = 128;  // pixel rows per tile (MFMA "B" operand)
+
+template <int BK>
+struct Geo {
+  static constexpr int CPR = BK / 8;         // 16-B chunks per LDS row
+  static constexpr int RPB = 16 / CPR;       // rows per 256-B bank row
+  static constexpr int ROWB = BK * 2;        // bytes per LDS row
+  static constexpr int TILEB = 128 * ROWB;   // bytes per operand tile
+  static constexpr int LPW = TILEB / 1024 / 4;  // wave-loads per wave per tile
+  __device__ static __forceinline__ int swz(int row) { return (row / RPB) % CPR; }
+};
+
+template <int BK, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
+  using G = Geo<BK>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // stage s: W tile at s*2*TILEB, P tile at s*2*TILEB + TILEB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * TP;   // first pixel
+  const int n0 = blockIdx.y * TM;   // first cout
+  const int T = a.ks * a.ks;
+  const int nchunk = a.Cin / BK;
+  const int S = T * nchunk;
+  const bf16* zero = reinterpret_cast<const bf16*>(dmvae_zero_page);
+
+  // --- per-thread load rows -------------------------------------------------------------
+  int prow_n[G::LPW], prow_y[G::LPW], prow_x[G::LPW];
+  const bf16* wrow[G::LPW];
+  int csrc[G::LPW];  // source chunk (elements) for this lane in each of its rows
+#pragma unroll
+  for (int j = 0; j < G::LPW; j++) {
+    const int p = (wave * G::LPW + j) * 64 + lane;
+    const int row = p / G::CPR, cp = p % G::CPR;
+    csrc[j] = (cp ^ G::swz(row)) * 8;
+    const int m = m0 + row;
+    if (m < a.M) {
+      const int hw = a.Ho * a.Wo;
+      const int n = m / hw, r = m - n * hw;
+      prow_n[j] = n; prow_y[j] = r / a.Wo; prow_x[j] = r - prow_y[j] * a.Wo;
+    } else { prow_n[j] = -1; prow_y[j] = 0; prow_x[j] = 0; }
+    const int co = n0 + row;
+    wrow[j] = co < a.Cout ? a.w + (size_t)co * T * a.Cin : nullptr;
+  }
+
+  auto stage = [&](int s, int buf) {
+    const int tap = s / nchunk, ch = s - tap * nchunk;
+    const int ky = a.ks == 3 ? tap / 3 - 1 : 0, kx = a.ks == 3 ? tap % 3 - 1 : 0;
+    char* wt = smem + buf * 2 * G::TILEB;
+    char* pt = wt + G::TILEB;
+#pragma unroll
+    for (int j = 0; j < G::LPW; j++) {
+      const int q = wave * G::LPW + j;
+      const bf16* src = wrow[j] ? wrow[j] + (size_t)tap * a.Cin + ch * BK + csrc[j] : zero;
+      __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(wt + q * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < G::LPW; j++) {
+      const int q = wave * G::LPW + j;
+      const bf16* src = zero;
+      int iy = prow_y[j] + ky, ix = prow_x[j] + kx;
+      if (prow_n[j] >= 0 && iy >= 0 && iy < a.Ho && ix >= 0 && ix < a.Wo) {
+        if (a.ups) { iy >>= 1; ix >>= 1; }
+        src = a.x + ((size_t)(prow_n[j] * a.Hi + iy) * a.Wi + ix) * a.Cin + ch * BK + csrc[j];
+      }
+      __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(pt + q * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // fragment read offsets (bytes within a tile), per kk step add chunk XOR
+  int wro[2], pro[2], wsw[2], psw[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int rw = wm * 64 + i * 32 + (lane & 31);
+    const int rp = wn * 64 + i * 32 + (lane & 31);
+    wro[i] = rw * G::ROWB; wsw[i] = G::swz(rw);
+    pro[i] = rp * G::ROWB; psw[i] = G::swz(rp);
+  }
+  const int kg = lane >> 5;
+
+  stage(0, 0);
+  for (int s = 0; s < S; s++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < S) stage(s + 1, (s + 1) & 1);
+    const char* wt = smem + (s & 1) * 2 * G::TILEB;
+    const char* pt = wt + G::TILEB;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; kk++) {
+      const int c = kk * 2 + kg;
+      bf16x8 wf[2], pf[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        wf[i] = *reinterpret_cast<const bf16x8*>(wt + wro[i] + ((c ^ wsw[i]) << 4));
+        pf[i] = *reinterpret_cast<const bf16x8*>(pt + pro[i] + ((c ^ psw[i]) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], pf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // --- epilogue: lane owns pixel (l&31) and 4-cout quads ---------------------------------
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int m = m0 + wn * 64 + j * 32 + (lane & 31);
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int cb = n0 + wm * 64 + i * 32 + 8 * q + 4 * kg;
+        if (cb >= a.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * q + e];
+        if (a.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + cb);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += b[e];
+        }
+        const size_t off = (size_t)m * a.Cout + cb;
+        if (a.res) {
+          const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.res + off);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += (float)r[e];
+        }
+        if (a.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = v[e] * sigmoidf_(v[e]);
+        } else if (a.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if (OUT_F32) {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + off) = o;
+        } else {
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.y) + off) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int BK, bool F32>
+int launch(const ConvArgs& a, hipStream_t st) {
+  dim3 grid((a.M + TP - 1) / TP, (a.Cout + TM - 1) / TM);
+  const int lds = 2 * 2 * Geo<BK>::TILEB;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_kernel<BK, F32>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_fwd_kernel<BK, F32>), grid, dim3(256), lds, st, a);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace dmvae_conv_fwd
+using namespace dmvae_conv_fwd;
+
+extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* bias, const void* residual,
+                                     void* y, const dmvae_conv_desc* d, hipStream_t stream) {
+  DMVAE_CHECK_ARG(x && w && y && d, "conv2d_nhwc_fwd: null pointer");
+  DMVAE_CHECK_ARG(d->ks == 1 || d->ks == 3, "conv2d_nhwc_fwd: ks must be 1 or 3 (got %d)", d->ks);
+  DMVAE_CHECK_ARG(d->cin > 0 && d->cin % 32 == 0, "conv2d_nhwc_fwd: Cin must be a positive multiple of 32 (got %d)", d->cin);
+  DMVAE_CHECK_ARG(d->cout > 0 && d->cout % 4 == 0, "conv2d_nhwc_fwd: Cout must be a positive multiple of 4 (got %d)", d->cout);
+  DMVAE_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0, "conv2d_nhwc_fwd: empty shape");
+  DMVAE_CHECK_ARG(d->act >= 0 && d->act <= 2, "conv2d_nhwc_fwd: bad activation code %d", d->act);
+  ConvArgs a;
+  a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.res = (const bf16*)residual; a.y = y;
+  a.N = d->n; a.Hi = d->h; a.Wi = d->w; a.Cin = d->cin; a.Cout = d->cout;
+  a.ups = d->upsample ? 1 : 0;
+  a.Ho = a.ups ? 2 * d->h : d->h; a.Wo = a.ups ? 2 * d->w : d->w;
+  a.ks = d->ks; a.act = d->act;
+  const long long M = (long long)a.N * a.Ho * a.Wo;
+  DMVAE_CHECK_ARG(M < (1ll << 31) / 4, "conv2d_nhwc_fwd: too many pixels");
+  a.M = (int)M;
+  const bool f32 = d->out_f32 != 0;
+  if (a.Cin % 64 == 0) return f32 ? launch<64, true>(a, stream) : launch<64, false>(a, stream);
+  return f32 ? launch<32, true>(a, stream) : launch<32, false>(a, stream);
+}

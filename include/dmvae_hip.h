@@ -1,0 +1,57 @@
+/* dmvae_hip.h -- C ABI of libdmvae_hip.so, the MI355X (gfx950) kernels behind the DMVAE
+ * training hot path.
+ *
+ * The reference (sen-ye/dmvae) is pure PyTorch and has no FFI of its own: the device work below
+ * is what its nn.Module.forward()/autograd reaches through ATen (cuDNN conv, cuBLAS GEMM, native
+ * GroupNorm, SDPA, elementwise loss ops).  Each entry point cites the reference call site whose
+ * device work it replaces.  The binding a maintainer adds is a ctypes stub;
+ * dmvae_amd/_lib.py is that stub.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers owned by the caller (PyTorch's caching allocator); kernels
+ *    never allocate, free or synchronise; every call is enqueued on `stream`.
+ *  - activations are NHWC ("channels last") bf16 unless stated; reductions / statistics are f32.
+ *  - return 0 on success, negative errno-style code on failure (-22 bad argument, -5 launch
+ *    failure); dmvae_last_error() returns a thread-local message.  Nothing throws or exits.
+ *  - one process per GPU; calls may come from the autograd engine thread.
+ */
+#ifndef DMVAE_HIP_H
+#define DMVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* dmvae_stream_t; /* == hipStream_t */
+
+const char* dmvae_last_error(void);
+/* ABI version; bumped when a signature changes. */
+int dmvae_abi_version(void);
+
+/* ---- convolution / GEMM (MFMA-bound) -------------------------------------------------------- */
+
+typedef struct dmvae_conv_desc {
+  int32_t n, h, w;   /* input batch, height, width (pre-upsample) */
+  int32_t cin, cout;
+  int32_t ks;        /* 1 or 3 (3 => padding 1, stride 1) */
+  int32_t upsample;  /* 1: nearest x2 of the input folded into the gather (flux_ae.py:103-107) */
+  int32_t act;       /* epilogue: 0 none, 1 SiLU (vae.py:60), 2 ReLU (lpips.py VGG trunk) */
+  int32_t out_f32;   /* 1: y is float32 (parity / final layers), else bf16 */
+} dmvae_conv_desc;
+
+/* y[n,ho,wo,cout] = act( conv(x, w) + bias + residual ).
+ * x: [n,h,w,cin] bf16; w: [cout, ks*ks, cin] bf16 (tap-major, see dmvae_pack_conv_weight);
+ * bias: [cout] f32 or NULL; residual: [n,ho,wo,cout] bf16 or NULL.
+ * Replaces nn.Conv2d at models/flux_ae.py:32-35,63,65,67,101,237,274 and nn.Linear at
+ * models/vae.py:58-62 (ks=1,h=w=1,n=tokens).  dgrad of a stride-1 conv is this same call with
+ * the weights packed by dmvae_pack_conv_weight(..., for_dgrad=1). */
+int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* bias, const void* residual, void* y,
+                          const dmvae_conv_desc* d, dmvae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMVAE_HIP_H */
