@@ -24,6 +24,8 @@ SIGNATURES = {
     "dmvae_last_error": (c_char_p, []),
     "dmvae_abi_version": (c_int, []),
     "dmvae_conv2d_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_void_p]),
+    "dmvae_conv2d_nhwc_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
+    "dmvae_conv2d_nhwc_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(ConvDesc), c_int, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,264 @@
+// Weight-gradient of the NHWC bf16 convolution on gfx950 (MI355X).
+//
+// Replaces the cuDNN wgrad autograd reaches for nn.Conv2d at models/flux_ae.py:32-35,63,65,67,
+// 101,237,274 (and nn.Linear at models/vae.py:58-62 with ks=1).
+//
+//   dW[co][tap][ci] = sum_p dy[p][co] * a[p (+) tap][ci]        (reduction over pixels)
+//
+// Both operands are channel-contiguous in HBM while the reduction runs over pixels, so the MFMA
+// fragments (8 consecutive k per lane) are produced with the gfx950 LDS transpose read
+// ds_read_b64_tr_b16: LDS holds [pixel][channel] tiles exactly as DMA'd (global_load_lds, 16 B
+// per lane), and each 16-lane group reads a [4 pixels][16 channels] block transposed.
+// The 64-B segment XOR swizzle (segment ^= pixel&3) is applied on the DMA source address and
+// on the transpose read, making the four pixel rows of a block hit distinct bank quarters.
+//
+// Split-K over pixel ranges: each workgroup owns one (cout-tile, cin-tile, tap) and a pixel
+// range, and writes an f32 slab; dmvae_conv_wgrad's second kernel reduces the slabs in a fixed
+// order (deterministic, no float atomics) into the PyTorch weight layout [cout][cin][kh][kw].
+#include "common.h"
+#include "dmvae_hip.h"
+
+namespace dmvae_conv_wgrad {
+
+struct WgradArgs {
+  const bf16* dy;  // [M, Cout]
+  const bf16* a;   // [N, Hi, Wi, Cin]
+  float* slab;     // [splits][Cout][T][Cin]
+  int N, Hi, Wi, Cin, Ho, Wo, Cout;
+  int ks, ups, M, kchunk;  // kchunk: pixels per split (multiple of 64)
+};
+
+constexpr int BKP = 64;              // pixels per K step
+constexpr int TILEB = BKP * 256;     // bytes per operand tile ([64][128] bf16)
+
+__device__ __forceinline__ s16x4 tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int T = a.ks * a.ks;
+  const int ci_tiles = (a.Cin + 127) / 128;
+  int t = blockIdx.y;
+  const int tap = t % T; t /= T;
+  const int ci0 = (t % ci_tiles) * 128;
+  const int co0 = (t / ci_tiles) * 128;
+  const int ky = a.ks == 3 ? tap / 3 - 1 : 0, kx = a.ks == 3 ? tap % 3 - 1 : 0;
+  const int k0 = blockIdx.x * a.kchunk;
+  const int k1 = min(k0 + a.kchunk, a.M);
+  const int S = (k1 - k0 + BKP - 1) / BKP;
+  const bf16* zero = reinterpret_cast<const bf16*>(dmvae_zero_page);
+
+  // per-thread load rows: load q = wave*4+j covers pixel rows 4q..4q+3, lane -> row 4q+lane/16,
+  // physical chunk lane%16; logical chunk = swizzle^-1 (an involution)
+  int pn[4], py[4], px[4];
+  const int cphys = lane & 15;
+  int clog[4];
+  bool co_ok[4], ci_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int row = (wave * 4 + j) * 4 + (lane >> 4);
+    clog[j] = ((((cphys >> 2) ^ (row & 3)) << 2) | (cphys & 3)) * 8;  // element offset in the 128-ch row
+    co_ok[j] = co0 + clog[j] < a.Cout;
+    ci_ok[j] = ci0 + clog[j] < a.Cin;
+    const int p = k0 + row;
+    const int hw = a.Ho * a.Wo;
+    const int n = p / hw, r = p - n * hw;
+    pn[j] = n; py[j] = r / a.Wo; px[j] = r - py[j] * a.Wo;
+  }
+
+  auto stage = [&](int s, int buf) {
+    char* dt = smem + buf * 2 * TILEB;
+    char* at = dt + TILEB;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int q = wave * 4 + j;
+      const int p = k0 + s * BKP + q * 4 + (lane >> 4);
+      const bf16* src = (p < k1 && co_ok[j]) ? a.dy + (size_t)p * a.Cout + co0 + clog[j] : zero;
+      __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(dt + q * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int q = wave * 4 + j;
+      const int p = k0 + s * BKP + q * 4 + (lane >> 4);
+      const bf16* src = zero;
+      int iy = py[j] + ky, ix = px[j] + kx;
+      if (p < k1 && ci_ok[j] && iy >= 0 && iy < a.Ho && ix >= 0 && ix < a.Wo) {
+        if (a.ups) { iy >>= 1; ix >>= 1; }
+        src = a.a + ((size_t)(pn[j] * a.Hi + iy) * a.Wi + ix) * a.Cin + ci0 + clog[j];
+      }
+      __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(at + q * 1024), 16, 0, 0);
+      // advance this row by one K step (64 pixels)
+      px[j] += BKP;
+      while (px[j] >= a.Wo) { px[j] -= a.Wo; if (++py[j] == a.Ho) { py[j] = 0; pn[j]++; } }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // transpose-read addressing: lane supplies the address of 4 contiguous channels of one pixel row
+  const int g = (lane >> 4) & 1, kq = lane >> 5, rr = (lane & 15) >> 2, qq = lane & 3;
+  int choff_d[2], choff_a[2];  // byte offset inside the 64-B segment + segment index
+  int seg_d[2], seg_a[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int chd = wm * 64 + i * 32 + 16 * g + 4 * qq;
+    const int cha = wn * 64 + i * 32 + 16 * g + 4 * qq;
+    seg_d[i] = chd >> 5; choff_d[i] = (chd & 31) * 2;
+    seg_a[i] = cha >> 5; choff_a[i] = (cha & 31) * 2;
+  }
+
+  if (S > 0) stage(0, 0);
+  for (int s = 0; s < S; s++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < S) stage(s + 1, (s + 1) & 1);
+    const char* dt = smem + (s & 1) * 2 * TILEB;
+    const char* at = dt + TILEB;
+#pragma unroll
+    for (int kk = 0; kk < BKP / 16; kk++) {
+      union { bf16x8 v; s16x4 h[2]; } df[2], af[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int row = kk * 16 + kq * 8 + h * 4 + rr;  // row & 3 == rr
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          df[i].h[h] = tr_read(dt + row * 256 + ((seg_d[i] ^ rr) << 6) + choff_d[i]);
+          af[i].h[h] = tr_read(at + row * 256 + ((seg_a[i] ^ rr) << 6) + choff_a[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[i].v, af[j].v, acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // slab store: lane owns ci = (l&31), 16 couts per block
+  float* slab = a.slab + (size_t)blockIdx.x * a.Cout * T * a.Cin;
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
+    if (ci >= a.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+        if (co < a.Cout) slab[((size_t)co * T + tap) * a.Cin + ci] = acc[i][j][r];
+      }
+  }
+}
+
+// out[co][ci][tap] (PyTorch [cout][cin][kh][kw]) = (accumulate ? out : 0) + sum_s slab[s][co][tap][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int splits, int Cout, int T,
+                                    int Cin, int accumulate) {
+  const size_t total = (size_t)Cout * T * Cin;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; k++) s += slab[(size_t)k * total + i];
+    const int ci = i % Cin;
+    const size_t r = i / Cin;
+    const int tap = r % T;
+    const size_t co = r / T;
+    const size_t o = (co * Cin + ci) * T + tap;
+    out[o] = accumulate ? out[o] + s : s;
+  }
+}
+
+// db[c] (+)= sum_p dy[p][c]; one block per 64-channel slice x pixel range, two-stage.
+__global__ void colsum_partial_kernel(const bf16* __restrict__ dy, float* __restrict__ part, int M, int C, int rows_per_block) {
+  __shared__ float sh[4][64];
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int p0 = blockIdx.x * rows_per_block, p1 = min(p0 + rows_per_block, M);
+  float s = 0.f;
+  if (c < C)
+    for (int p = p0 + w; p < p1; p += 4) s += (float)dy[(size_t)p * C + c];
+  sh[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < C) part[(size_t)blockIdx.x * C + c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int C, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < nparts; k++) s += part[(size_t)k * C + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+static int pick_splits(int M, int tiles) {
+  // aim for ~1024 workgroups, at least 8 K steps each
+  int want = (1024 + tiles - 1) / tiles;
+  int maxs = (M + 8 * BKP - 1) / (8 * BKP);
+  int s = want < maxs ? want : maxs;
+  return s < 1 ? 1 : s;
+}
+
+}  // namespace dmvae_conv_wgrad
+using namespace dmvae_conv_wgrad;
+
+extern "C" size_t dmvae_conv2d_nhwc_wgrad_workspace(const dmvae_conv_desc* d) {
+  if (!d) return 0;
+  const int T = d->ks * d->ks;
+  const long long M = (long long)d->n * d->h * d->w * (d->upsample ? 4 : 1);
+  const int tiles = ((d->cout + 127) / 128) * ((d->cin + 127) / 128) * T;
+  const int splits = pick_splits((int)M, tiles);
+  size_t slab = (size_t)splits * d->cout * T * d->cin * sizeof(float);
+  size_t colsum = (size_t)1024 * d->cout * sizeof(float);
+  return slab + colsum;
+}
+
+extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, void* dbias, void* workspace,
+                                       size_t workspace_bytes, const dmvae_conv_desc* d, int accumulate,
+                                       hipStream_t stream) {
+  DMVAE_CHECK_ARG(dy && a && dw && d && workspace, "conv2d_nhwc_wgrad: null pointer");
+  DMVAE_CHECK_ARG(d->ks == 1 || d->ks == 3, "conv2d_nhwc_wgrad: ks must be 1 or 3");
+  DMVAE_CHECK_ARG(d->cin > 0 && d->cin % 8 == 0 && d->cout > 0 && d->cout % 8 == 0,
+                  "conv2d_nhwc_wgrad: Cin and Cout must be positive multiples of 8 (got %d, %d)", d->cin, d->cout);
+  DMVAE_CHECK_ARG(workspace_bytes >= dmvae_conv2d_nhwc_wgrad_workspace(d), "conv2d_nhwc_wgrad: workspace too small");
+  WgradArgs w;
+  w.dy = (const bf16*)dy; w.a = (const bf16*)a; w.slab = (float*)workspace;
+  w.N = d->n; w.Hi = d->h; w.Wi = d->w; w.Cin = d->cin; w.Cout = d->cout; w.ks = d->ks;
+  w.ups = d->upsample ? 1 : 0;
+  w.Ho = w.ups ? 2 * d->h : d->h; w.Wo = w.ups ? 2 * d->w : d->w;
+  const long long M = (long long)w.N * w.Ho * w.Wo;
+  DMVAE_CHECK_ARG(M > 0 && M < (1ll << 31) / 4, "conv2d_nhwc_wgrad: bad pixel count");
+  w.M = (int)M;
+  const int T = w.ks * w.ks;
+  const int tiles = ((w.Cout + 127) / 128) * ((w.Cin + 127) / 128) * T;
+  int splits = pick_splits(w.M, tiles);
+  w.kchunk = (((w.M + splits - 1) / splits) + BKP - 1) / BKP * BKP;
+  splits = (w.M + w.kchunk - 1) / w.kchunk;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wgrad_kernel, dim3(splits, tiles), dim3(256), 4 * TILEB, stream, w);
+  DMVAE_CHECK_LAUNCH();
+  const size_t total = (size_t)w.Cout * T * w.Cin;
+  int rb = (int)((total + 255) / 256); if (rb > 2048) rb = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, w.slab, (float*)dw, splits, w.Cout, T, w.Cin, accumulate);
+  DMVAE_CHECK_LAUNCH();
+  if (dbias) {
+    float* part = w.slab + (size_t)splits * total;
+    int nparts = (w.M + 255) / 256; if (nparts > 1024) nparts = 1024;
+    const int rpb = (w.M + nparts - 1) / nparts;
+    nparts = (w.M + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nparts, (w.Cout + 63) / 64), dim3(256), 0, stream, w.dy, part, w.M, w.Cout, rpb);
+    DMVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((w.Cout + 255) / 256), dim3(256), 0, stream, part, (float*)dbias, nparts, w.Cout, accumulate);
+    DMVAE_CHECK_LAUNCH();
+  }
+  return 0;
+}

@@ -51,6 +51,17 @@ typedef struct dmvae_conv_desc {
 int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* bias, const void* residual, void* y,
                           const dmvae_conv_desc* d, dmvae_stream_t stream);
 
+/* Weight/bias gradient of the conv above (reduction over pixels, split-K, deterministic).
+ * dy: [n,ho,wo,cout] bf16; a: the conv's bf16 input [n,h,w,cin] (pre-upsample when d->upsample);
+ * dw: [cout][cin][ks][ks] f32 (PyTorch nn.Conv2d.weight layout); dbias: [cout] f32 or NULL.
+ * accumulate=1 adds into dw/dbias (autograd .grad accumulation), 0 overwrites.
+ * workspace: >= dmvae_conv2d_nhwc_wgrad_workspace(d) bytes, caller-owned.  d->act/out_f32 ignored.
+ * Replaces autograd's conv/linear weight-gradient for the call sites listed at conv2d_nhwc_fwd. */
+size_t dmvae_conv2d_nhwc_wgrad_workspace(const dmvae_conv_desc* d);
+int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, void* dbias, void* workspace,
+                            size_t workspace_bytes, const dmvae_conv_desc* d, int accumulate,
+                            dmvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
