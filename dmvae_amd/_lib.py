@@ -25,6 +25,10 @@ SIGNATURES = {
     "dmvae_abi_version": (c_int, []),
     "dmvae_conv2d_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_void_p]),
     "dmvae_conv2d_nhwc_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
+    "dmvae_groupnorm_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dmvae_groupnorm_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "dmvae_groupnorm_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dmvae_groupnorm_bwd": (c_int, [c_void_p] * 10 + [c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_conv2d_nhwc_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(ConvDesc), c_int, c_void_p]),
 }
 

@@ -1,0 +1,338 @@
+// GroupNorm(32 groups, eps) [+ swish] on NHWC bf16 activations: statistics, apply, and backward.
+//
+// Replaces nn.GroupNorm + swish at models/flux_ae.py:21-22,28,38,62,64,71-76,236,266-267 (the
+// reference runs them as separate fp32 ATen kernels under autocast).  HBM-bound: coalesced 16-B
+// loads (8 channels per lane), per-thread f32 accumulation, LDS block reduce, fixed-order final
+// combine in f64 (deterministic; no atomics).
+//
+//   stats   : x -> (mean, rstd) per (image, group)                       reads 2 B/elem
+//   apply   : a = act(x_hat*gamma+beta) -> bf16                           reads 2, writes 2 B/elem
+//   bwd     : (da, x) -> A[n,c]=sum dy, B[n,c]=sum dy*x_hat   (reduce)    reads 4 B/elem
+//             dx = rstd*(dy*gamma - (s1 + x_hat*s2)/m) [+ dres] (apply)   reads 4(+2), writes 2
+//             with dy = da * swish'(x_hat*gamma+beta)
+#include "common.h"
+#include "dmvae_hip.h"
+
+namespace dmvae_gn {
+
+struct Geom {
+  int HW, C, G, cpg, tp_shift, rows, ppc, nchunk;
+};
+
+__device__ __forceinline__ void load8(const bf16* p, float (&v)[8]) {
+  const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; e++) v[e] = (float)t[e];
+}
+__device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
+  bf16x8 t;
+#pragma unroll
+  for (int e = 0; e < 8; e++) t[e] = (bf16)v[e];
+  *reinterpret_cast<bf16x8*>(p) = t;
+}
+
+// Reduce per-thread 2x8 channel accumulators over the block's pixel rows and write
+// part[((n*nchunk+chunk)*C + c)*2 + {0,1}].
+__device__ __forceinline__ void block_reduce_store(float (&s0)[8], float (&s1)[8], float* part, const Geom& g, int lane_c,
+                                                   int prow, bool active) {
+  __shared__ float red[256 * 16];
+  const int tp = 1 << g.tp_shift;
+  float* mine = red + (prow * tp + lane_c) * 16;
+#pragma unroll
+  for (int e = 0; e < 8; e++) { mine[e] = s0[e]; mine[8 + e] = s1[e]; }
+  __syncthreads();
+  // thread t < C handles channel t (may need two rounds when C > 256)
+  for (int c = threadIdx.x; c < g.C; c += 256) {
+    const int lc = c >> 3, e = c & 7;
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < g.rows; r++) {
+      const float* q = red + (r * tp + lc) * 16;
+      a += q[e]; b += q[8 + e];
+    }
+    float* o = part + ((size_t)(blockIdx.y * g.nchunk + blockIdx.x) * g.C + c) * 2;
+    o[0] = a; o[1] = b;
+  }
+  (void)active;
+}
+
+__global__ __launch_bounds__(256) void stats_partial_kernel(const bf16* __restrict__ x, float* __restrict__ part, Geom g) {
+  const int tp = 1 << g.tp_shift;
+  const int lane_c = threadIdx.x & (tp - 1), prow = threadIdx.x >> g.tp_shift;
+  const bool active = lane_c * 8 < g.C;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * g.ppc, p1 = min(p0 + g.ppc, g.HW);
+  float s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { s[e] = 0.f; ss[e] = 0.f; }
+  if (active) {
+    const bf16* base = x + (size_t)n * g.HW * g.C + lane_c * 8;
+    for (int p = p0 + prow; p < p1; p += g.rows) {
+      float v[8];
+      load8(base + (size_t)p * g.C, v);
+#pragma unroll
+      for (int e = 0; e < 8; e++) { s[e] += v[e]; ss[e] += v[e] * v[e]; }
+    }
+  }
+  block_reduce_store(s, ss, part, g, lane_c, prow, active);
+}
+
+// one wave per (n, group): combine partials in f64
+__global__ void stats_final_kernel(const float* __restrict__ part, float* __restrict__ stats, Geom g, int N, float eps) {
+  const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wid >= N * g.G) return;
+  const int n = wid / g.G, grp = wid % g.G;
+  double s = 0.0, ss = 0.0;
+  const int items = g.nchunk * g.cpg;
+  for (int i = lane; i < items; i += 64) {
+    const int ch = i / g.cpg, c = grp * g.cpg + i % g.cpg;
+    const float* q = part + ((size_t)(n * g.nchunk + ch) * g.C + c) * 2;
+    s += q[0]; ss += q[1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+  if (lane == 0) {
+    const double cnt = (double)g.cpg * g.HW;
+    const double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    if (var < 0) var = 0;
+    stats[wid * 2] = (float)mean;
+    stats[wid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+template <bool SWISH>
+__global__ __launch_bounds__(256) void apply_kernel(const bf16* __restrict__ x, const float* __restrict__ stats,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    bf16* __restrict__ y, Geom g) {
+  const int tp = 1 << g.tp_shift;
+  const int lane_c = threadIdx.x & (tp - 1), prow = threadIdx.x >> g.tp_shift;
+  if (lane_c * 8 >= g.C) return;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * g.ppc, p1 = min(p0 + g.ppc, g.HW);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const int c = lane_c * 8 + e;
+    const float* st = stats + ((size_t)n * g.G + c / g.cpg) * 2;
+    sc[e] = st[1] * gamma[c];
+    sh[e] = beta[c] - st[0] * sc[e];
+  }
+  const size_t base = (size_t)n * g.HW * g.C + lane_c * 8;
+  for (int p = p0 + prow; p < p1; p += g.rows) {
+    float v[8];
+    load8(x + base + (size_t)p * g.C, v);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float t = v[e] * sc[e] + sh[e];
+      v[e] = SWISH ? t * sigmoidf_(t) : t;
+    }
+    store8(y + base + (size_t)p * g.C, v);
+  }
+}
+
+template <bool SWISH>
+__global__ __launch_bounds__(256) void bwd_partial_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x,
+                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ part, Geom g) {
+  const int tp = 1 << g.tp_shift;
+  const int lane_c = threadIdx.x & (tp - 1), prow = threadIdx.x >> g.tp_shift;
+  const bool active = lane_c * 8 < g.C;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * g.ppc, p1 = min(p0 + g.ppc, g.HW);
+  float A[8], B[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { A[e] = 0.f; B[e] = 0.f; }
+  if (active) {
+    float mu[8], rs[8], ga[8], be[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int c = lane_c * 8 + e;
+      const float* st = stats + ((size_t)n * g.G + c / g.cpg) * 2;
+      mu[e] = st[0]; rs[e] = st[1]; ga[e] = gamma[c]; be[e] = beta[c];
+    }
+    const size_t base = (size_t)n * g.HW * g.C + lane_c * 8;
+    for (int p = p0 + prow; p < p1; p += g.rows) {
+      float v[8], d[8];
+      load8(x + base + (size_t)p * g.C, v);
+      load8(da + base + (size_t)p * g.C, d);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float xh = (v[e] - mu[e]) * rs[e];
+        float dy = d[e];
+        if (SWISH) {
+          const float t = xh * ga[e] + be[e];
+          const float sg = sigmoidf_(t);
+          dy *= sg * (1.f + t * (1.f - sg));
+        }
+        A[e] += dy; B[e] += dy * xh;
+      }
+    }
+  }
+  block_reduce_store(A, B, part, g, lane_c, prow, active);
+}
+
+// AB[n][c][2] = sum over chunks (f64 combine); then S[n][g][2] = sum_{c in g} gamma_c*(A,B)
+__global__ void bwd_final_kernel(const float* __restrict__ part, const float* __restrict__ gamma, float* __restrict__ AB,
+                                 float* __restrict__ S, Geom g, int N) {
+  // one wave per (n, group)
+  const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wid >= N * g.G) return;
+  const int n = wid / g.G, grp = wid % g.G;
+  double s1 = 0.0, s2 = 0.0;
+  for (int ci = 0; ci < g.cpg; ci++) {
+    const int c = grp * g.cpg + ci;
+    double a = 0.0, b = 0.0;
+    for (int ch = lane; ch < g.nchunk; ch += 64) {
+      const float* q = part + ((size_t)(n * g.nchunk + ch) * g.C + c) * 2;
+      a += q[0]; b += q[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if (lane == 0) { AB[((size_t)n * g.C + c) * 2] = (float)a; AB[((size_t)n * g.C + c) * 2 + 1] = (float)b; }
+    s1 += (double)gamma[c] * a; s2 += (double)gamma[c] * b;
+  }
+  if (lane == 0) { S[wid * 2] = (float)s1; S[wid * 2 + 1] = (float)s2; }
+}
+
+// dgamma[c] (+)= sum_n B[n][c]; dbeta[c] (+)= sum_n A[n][c]
+__global__ void bwd_param_kernel(const float* __restrict__ AB, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C,
+                                 int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int n = 0; n < N; n++) { a += AB[((size_t)n * C + c) * 2]; b += AB[((size_t)n * C + c) * 2 + 1]; }
+  dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)a;
+  dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)b;
+}
+
+template <bool SWISH>
+__global__ __launch_bounds__(256) void bwd_apply_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x,
+                                                        const bf16* __restrict__ dres, const float* __restrict__ stats,
+                                                        const float* __restrict__ S, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16* __restrict__ dx, Geom g) {
+  const int tp = 1 << g.tp_shift;
+  const int lane_c = threadIdx.x & (tp - 1), prow = threadIdx.x >> g.tp_shift;
+  if (lane_c * 8 >= g.C) return;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * g.ppc, p1 = min(p0 + g.ppc, g.HW);
+  const float inv_m = 1.0f / ((float)g.cpg * (float)g.HW);
+  float mu[8], rs[8], ga[8], be[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const int c = lane_c * 8 + e;
+    const size_t gi = ((size_t)n * g.G + c / g.cpg) * 2;
+    mu[e] = stats[gi]; rs[e] = stats[gi + 1]; ga[e] = gamma[c]; be[e] = beta[c];
+    s1[e] = S[gi] * inv_m; s2[e] = S[gi + 1] * inv_m;
+  }
+  const size_t base = (size_t)n * g.HW * g.C + lane_c * 8;
+  for (int p = p0 + prow; p < p1; p += g.rows) {
+    float v[8], d[8], o[8];
+    load8(x + base + (size_t)p * g.C, v);
+    load8(da + base + (size_t)p * g.C, d);
+    if (dres) load8(dres + base + (size_t)p * g.C, o);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float xh = (v[e] - mu[e]) * rs[e];
+      float dy = d[e];
+      if (SWISH) {
+        const float t = xh * ga[e] + be[e];
+        const float sg = sigmoidf_(t);
+        dy *= sg * (1.f + t * (1.f - sg));
+      }
+      const float r = rs[e] * (dy * ga[e] - s1[e] - xh * s2[e]);
+      o[e] = dres ? o[e] + r : r;
+    }
+    store8(dx + base + (size_t)p * g.C, o);
+  }
+}
+
+static int make_geom(Geom& g, int N, int HW, int C, int G) {
+  if (C <= 0 || C % 8 != 0 || C > 512 || G <= 0 || C % G != 0 || HW <= 0 || N <= 0) return -1;
+  g.HW = HW; g.C = C; g.G = G; g.cpg = C / G;
+  int tp = 1, sh = 0;
+  while (tp < C / 8) { tp <<= 1; sh++; }
+  g.tp_shift = sh; g.rows = 256 / tp;
+  // chunks per image: target ~2048 blocks overall, >= 4 row-iterations per block, <= 64
+  int nchunk = (2048 + N - 1) / N;
+  const int maxc = (HW + g.rows * 4 - 1) / (g.rows * 4);
+  if (nchunk > maxc) nchunk = maxc;
+  if (nchunk > 64) nchunk = 64;
+  if (nchunk < 1) nchunk = 1;
+  g.ppc = (HW + nchunk - 1) / nchunk;
+  g.nchunk = (HW + g.ppc - 1) / g.ppc;
+  return 0;
+}
+
+}  // namespace dmvae_gn
+using namespace dmvae_gn;
+
+extern "C" size_t dmvae_groupnorm_workspace(int n, int hw, int c, int groups) {
+  Geom g;
+  if (make_geom(g, n, hw, c, groups)) return 0;
+  // partials + AB + S
+  return ((size_t)n * g.nchunk * c * 2 + (size_t)n * c * 2 + (size_t)n * groups * 2) * sizeof(float);
+}
+
+extern "C" int dmvae_groupnorm_stats(const void* x, void* stats, void* workspace, size_t workspace_bytes, int n, int hw, int c,
+                                     int groups, float eps, hipStream_t stream) {
+  Geom g;
+  DMVAE_CHECK_ARG(x && stats && workspace, "groupnorm_stats: null pointer");
+  DMVAE_CHECK_ARG(make_geom(g, n, hw, c, groups) == 0, "groupnorm_stats: unsupported shape n=%d hw=%d c=%d groups=%d", n, hw, c, groups);
+  DMVAE_CHECK_ARG(workspace_bytes >= dmvae_groupnorm_workspace(n, hw, c, groups), "groupnorm_stats: workspace too small");
+  hipLaunchKernelGGL(stats_partial_kernel, dim3(g.nchunk, n), dim3(256), 0, stream, (const bf16*)x, (float*)workspace, g);
+  DMVAE_CHECK_LAUNCH();
+  const int waves = n * groups;
+  hipLaunchKernelGGL(stats_final_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, (const float*)workspace, (float*)stats, g, n, eps);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_groupnorm_apply(const void* x, const void* stats, const void* gamma, const void* beta, void* y, int n, int hw,
+                                     int c, int groups, int swish, hipStream_t stream) {
+  Geom g;
+  DMVAE_CHECK_ARG(x && stats && gamma && beta && y, "groupnorm_apply: null pointer");
+  DMVAE_CHECK_ARG(make_geom(g, n, hw, c, groups) == 0, "groupnorm_apply: unsupported shape n=%d hw=%d c=%d groups=%d", n, hw, c, groups);
+  if (swish)
+    hipLaunchKernelGGL(apply_kernel<true>, dim3(g.nchunk, n), dim3(256), 0, stream, (const bf16*)x, (const float*)stats,
+                       (const float*)gamma, (const float*)beta, (bf16*)y, g);
+  else
+    hipLaunchKernelGGL(apply_kernel<false>, dim3(g.nchunk, n), dim3(256), 0, stream, (const bf16*)x, (const float*)stats,
+                       (const float*)gamma, (const float*)beta, (bf16*)y, g);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_groupnorm_bwd(const void* da, const void* x, const void* dres, const void* stats, const void* gamma,
+                                   const void* beta, void* dx, void* dgamma, void* dbeta, void* workspace, size_t workspace_bytes,
+                                   int n, int hw, int c, int groups, int swish, int accumulate, hipStream_t stream) {
+  Geom g;
+  DMVAE_CHECK_ARG(da && x && stats && gamma && beta && dx && workspace, "groupnorm_bwd: null pointer");
+  DMVAE_CHECK_ARG(make_geom(g, n, hw, c, groups) == 0, "groupnorm_bwd: unsupported shape n=%d hw=%d c=%d groups=%d", n, hw, c, groups);
+  DMVAE_CHECK_ARG(workspace_bytes >= dmvae_groupnorm_workspace(n, hw, c, groups), "groupnorm_bwd: workspace too small");
+  float* part = (float*)workspace;
+  float* AB = part + (size_t)n * g.nchunk * c * 2;
+  float* S = AB + (size_t)n * c * 2;
+  const dim3 grid(g.nchunk, n);
+  if (swish)
+    hipLaunchKernelGGL(bwd_partial_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)x, (const float*)stats,
+                       (const float*)gamma, (const float*)beta, part, g);
+  else
+    hipLaunchKernelGGL(bwd_partial_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)x, (const float*)stats,
+                       (const float*)gamma, (const float*)beta, part, g);
+  DMVAE_CHECK_LAUNCH();
+  const int waves = n * groups;
+  hipLaunchKernelGGL(bwd_final_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, part, (const float*)gamma, AB, S, g, n);
+  DMVAE_CHECK_LAUNCH();
+  if (dgamma && dbeta) {
+    hipLaunchKernelGGL(bwd_param_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, AB, (float*)dgamma, (float*)dbeta, n, c, accumulate);
+    DMVAE_CHECK_LAUNCH();
+  }
+  if (swish)
+    hipLaunchKernelGGL(bwd_apply_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)x, (const bf16*)dres,
+                       (const float*)stats, S, (const float*)gamma, (const float*)beta, (bf16*)dx, g);
+  else
+    hipLaunchKernelGGL(bwd_apply_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)x, (const bf16*)dres,
+                       (const float*)stats, S, (const float*)gamma, (const float*)beta, (bf16*)dx, g);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}

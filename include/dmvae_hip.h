@@ -62,6 +62,30 @@ int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, void* dbias
                             size_t workspace_bytes, const dmvae_conv_desc* d, int accumulate,
                             dmvae_stream_t stream);
 
+/* ---- GroupNorm(+swish) on NHWC bf16 (HBM-bound) --------------------------------------------- */
+
+/* Workspace bytes needed by groupnorm_stats / groupnorm_bwd for x: [n, hw, c]; 0 if unsupported
+ * (c must be a multiple of 8 and <= 512, c % groups == 0). */
+size_t dmvae_groupnorm_workspace(int n, int hw, int c, int groups);
+
+/* stats[n][groups][2] = (mean, rstd) over (hw, c/groups) of x [n,hw,c] bf16, f32 accumulation.
+ * Replaces the statistics half of nn.GroupNorm(32, C, eps=1e-6) (models/flux_ae.py:28,62,64,236). */
+int dmvae_groupnorm_stats(const void* x, void* stats, void* workspace, size_t workspace_bytes, int n, int hw,
+                          int c, int groups, float eps, dmvae_stream_t stream);
+
+/* y = act((x-mean)*rstd*gamma+beta) as bf16; act = swish (x*sigmoid(x), flux_ae.py:21-22) when
+ * swish!=0, identity otherwise (AttnBlock.norm, flux_ae.py:38). gamma/beta: [c] f32. */
+int dmvae_groupnorm_apply(const void* x, const void* stats, const void* gamma, const void* beta, void* y,
+                          int n, int hw, int c, int groups, int swish, dmvae_stream_t stream);
+
+/* Backward of y=act(GN(x)): given da=dL/dy (bf16), x, stats, gamma, beta computes
+ * dx (bf16) = GN/swish backward [+ dres when dres != NULL, fusing the residual-branch add],
+ * dgamma/dbeta ([c] f32, accumulate!=0 adds) -- both may be NULL to skip. */
+int dmvae_groupnorm_bwd(const void* da, const void* x, const void* dres, const void* stats, const void* gamma,
+                        const void* beta, void* dx, void* dgamma, void* dbeta, void* workspace,
+                        size_t workspace_bytes, int n, int hw, int c, int groups, int swish, int accumulate,
+                        dmvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
