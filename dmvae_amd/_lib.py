@@ -25,6 +25,26 @@ SIGNATURES = {
     "dmvae_abi_version": (c_int, []),
     "dmvae_conv2d_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_void_p]),
     "dmvae_conv2d_nhwc_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
+    "dmvae_gemm_nt_batched": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_longlong] * 3 + [c_int, c_int, c_void_p]),
+    "dmvae_gemm_tn_batched_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dmvae_gemm_tn_batched": (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 4 + [c_longlong] * 3 + [c_float, c_int, c_void_p]),
+    "dmvae_softmax_rows_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "dmvae_softmax_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "dmvae_transpose_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dmvae_pack_conv_weight": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "dmvae_sumpool2x2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dmvae_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dmvae_nhwc_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dmvae_silu_fwd": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dmvae_silu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dmvae_loss_workspace": (c_size_t, []),
+    "dmvae_l1_mse": (c_int, [c_void_p] * 5 + [c_size_t, c_size_t, c_float, c_float, c_void_p]),
+    "dmvae_lpips_diff": (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "dmvae_dmd_pre": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
+    "dmvae_dmd_post": (c_int, [c_void_p] * 10 + [c_size_t, c_int, c_int, c_float, c_int, c_void_p]),
+    "dmvae_kl_mmd": (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
+    "dmvae_grad_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_int, c_void_p]),
+    "dmvae_adamw_ema_step": (c_int, [c_void_p] * 6 + [c_size_t] + [c_float] * 5 + [c_int, c_float, c_void_p]),
     "dmvae_groupnorm_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dmvae_groupnorm_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dmvae_groupnorm_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -26,6 +26,7 @@ struct ConvArgs {
   void* y;            // [N, Ho, Wo, Cout] bf16 or f32
   int N, Hi, Wi, Cin, Ho, Wo, Cout;
   int ks, ups, act, M;
+  long long x_bs, w_bs, y_bs;  // element strides per blockIdx.z (batched GEMM); 0 otherwise
 };
 
 constexpr int TM = 128;  // cout rows per tile  (MFMA "A" operand)
@@ -54,6 +55,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
   const int nchunk = a.Cin / BK;
   const int S = T * nchunk;
   const bf16* zero = reinterpret_cast<const bf16*>(dmvae_zero_page);
+  a.x += (size_t)blockIdx.z * a.x_bs;
+  a.w += (size_t)blockIdx.z * a.w_bs;
+  if (a.res) a.res += (size_t)blockIdx.z * a.y_bs;
+  a.y = OUT_F32 ? (void*)(reinterpret_cast<float*>(a.y) + (size_t)blockIdx.z * a.y_bs)
+                : (void*)(reinterpret_cast<bf16*>(a.y) + (size_t)blockIdx.z * a.y_bs);
 
   // --- per-thread load rows -------------------------------------------------------------
   int prow_n[G::LPW], prow_y[G::LPW], prow_x[G::LPW];
@@ -186,8 +192,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
 }
 
 template <int BK, bool F32>
-int launch(const ConvArgs& a, hipStream_t st) {
-  dim3 grid((a.M + TP - 1) / TP, (a.Cout + TM - 1) / TM);
+int launch(const ConvArgs& a, hipStream_t st, int batch = 1) {
+  dim3 grid((a.M + TP - 1) / TP, (a.Cout + TM - 1) / TM, batch);
   const int lds = 2 * 2 * Geo<BK>::TILEB;
   static bool attr_done = false;
   if (!attr_done) {
@@ -217,10 +223,26 @@ extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* b
   a.ups = d->upsample ? 1 : 0;
   a.Ho = a.ups ? 2 * d->h : d->h; a.Wo = a.ups ? 2 * d->w : d->w;
   a.ks = d->ks; a.act = d->act;
+  a.x_bs = a.w_bs = a.y_bs = 0;
   const long long M = (long long)a.N * a.Ho * a.Wo;
   DMVAE_CHECK_ARG(M < (1ll << 31) / 4, "conv2d_nhwc_fwd: too many pixels");
   a.M = (int)M;
   const bool f32 = d->out_f32 != 0;
   if (a.Cin % 64 == 0) return f32 ? launch<64, true>(a, stream) : launch<64, false>(a, stream);
   return f32 ? launch<32, true>(a, stream) : launch<32, false>(a, stream);
+}
+
+// C[b][m][n] = act( sum_k A[b][m][k] * B[b][n][k] + bias[n] + R[b][m][n] ), all row-major bf16 (C bf16 or f32).
+extern "C" int dmvae_gemm_nt_batched(const void* A, const void* B, const void* bias, const void* R, void* C, int M, int N,
+                                     int K, int batch, long long a_bs, long long b_bs, long long c_bs, int act, int out_f32,
+                                     hipStream_t stream) {
+  DMVAE_CHECK_ARG(A && B && C, "gemm_nt_batched: null pointer");
+  DMVAE_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && K > 0 && K % 32 == 0 && batch > 0 && batch < 65536,
+                  "gemm_nt_batched: need N%%4==0, K%%32==0 (M=%d N=%d K=%d batch=%d)", M, N, K, batch);
+  ConvArgs a;
+  a.x = (const bf16*)A; a.w = (const bf16*)B; a.bias = (const float*)bias; a.res = (const bf16*)R; a.y = C;
+  a.N = 1; a.Hi = 1; a.Wi = M; a.Ho = 1; a.Wo = M; a.Cin = K; a.Cout = N; a.ks = 1; a.ups = 0; a.act = act; a.M = M;
+  a.x_bs = a_bs; a.w_bs = b_bs; a.y_bs = c_bs;
+  if (K % 64 == 0) return out_f32 ? launch<64, true>(a, stream, batch) : launch<64, false>(a, stream, batch);
+  return out_f32 ? launch<32, true>(a, stream, batch) : launch<32, false>(a, stream, batch);
 }

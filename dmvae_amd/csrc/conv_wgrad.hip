@@ -26,6 +26,7 @@ struct WgradArgs {
   float* slab;     // [splits][Cout][T][Cin]
   int N, Hi, Wi, Cin, Ho, Wo, Cout;
   int ks, ups, M, kchunk;  // kchunk: pixels per split (multiple of 64)
+  long long dy_bs, a_bs, slab_bs;  // per blockIdx.z element strides (batched TN GEMM); 0 otherwise
 };
 
 constexpr int BKP = 64;              // pixels per K step
@@ -50,6 +51,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   const int k1 = min(k0 + a.kchunk, a.M);
   const int S = (k1 - k0 + BKP - 1) / BKP;
   const bf16* zero = reinterpret_cast<const bf16*>(dmvae_zero_page);
+  a.dy += (size_t)blockIdx.z * a.dy_bs;
+  a.a += (size_t)blockIdx.z * a.a_bs;
+  a.slab += (size_t)blockIdx.z * a.slab_bs;
 
   // per-thread load rows: load q = wave*4+j covers pixel rows 4q..4q+3, lane -> row 4q+lane/16,
   // physical chunk lane%16; logical chunk = swizzle^-1 (an involution)
@@ -160,6 +164,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 }
 
 // out[co][ci][tap] (PyTorch [cout][cin][kh][kw]) = (accumulate ? out : 0) + sum_s slab[s][co][tap][ci]
+// batched TN GEMM epilogue: out[b][co][ci] (bf16 or f32) = alpha * sum_s slab[b][s][co][ci]
+template <typename OutT>
+__global__ void tn_reduce_kernel(const float* __restrict__ slab, OutT* __restrict__ out, int splits, size_t total,
+                                 long long slab_bs, long long out_bs, float alpha) {
+  slab += (size_t)blockIdx.y * slab_bs;
+  out += (size_t)blockIdx.y * out_bs;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; k++) s += slab[(size_t)k * total + i];
+    out[i] = (OutT)(alpha * s);
+  }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int splits, int Cout, int T,
                                     int Cin, int accumulate) {
   const size_t total = (size_t)Cout * T * Cin;
@@ -234,6 +251,7 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
   const long long M = (long long)w.N * w.Ho * w.Wo;
   DMVAE_CHECK_ARG(M > 0 && M < (1ll << 31) / 4, "conv2d_nhwc_wgrad: bad pixel count");
   w.M = (int)M;
+  w.dy_bs = w.a_bs = w.slab_bs = 0;
   const int T = w.ks * w.ks;
   const int tiles = ((w.Cout + 127) / 128) * ((w.Cin + 127) / 128) * T;
   int splits = pick_splits(w.M, tiles);
@@ -260,5 +278,43 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
     hipLaunchKernelGGL(colsum_final_kernel, dim3((w.Cout + 255) / 256), dim3(256), 0, stream, part, (float*)dbias, nparts, w.Cout, accumulate);
     DMVAE_CHECK_LAUNCH();
   }
+  return 0;
+}
+
+// C[b][m][n] = alpha * sum_k A[b][k][m] * B[b][k][n]   (A: [K][M], B: [K][N] row-major bf16; C bf16 or f32)
+extern "C" size_t dmvae_gemm_tn_batched_workspace(int M, int N, int K, int batch) {
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int splits = pick_splits(K, tiles * batch);
+  return (size_t)batch * splits * M * N * sizeof(float);
+}
+extern "C" int dmvae_gemm_tn_batched(const void* A, const void* B, void* C, void* workspace, size_t workspace_bytes, int M, int N,
+                                     int K, int batch, long long a_bs, long long b_bs, long long c_bs, float alpha, int out_f32,
+                                     hipStream_t stream) {
+  DMVAE_CHECK_ARG(A && B && C && workspace, "gemm_tn_batched: null pointer");
+  DMVAE_CHECK_ARG(M > 0 && M % 8 == 0 && N > 0 && N % 8 == 0 && K > 0 && batch > 0 && batch < 65536,
+                  "gemm_tn_batched: need M%%8==0, N%%8==0 (M=%d N=%d K=%d batch=%d)", M, N, K, batch);
+  DMVAE_CHECK_ARG(workspace_bytes >= dmvae_gemm_tn_batched_workspace(M, N, K, batch), "gemm_tn_batched: workspace too small");
+  WgradArgs w;
+  w.dy = (const bf16*)A; w.a = (const bf16*)B; w.slab = (float*)workspace;
+  w.N = 1; w.Hi = 1; w.Wi = K; w.Ho = 1; w.Wo = K; w.Cin = N; w.Cout = M; w.ks = 1; w.ups = 0; w.M = K;
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int splits = pick_splits(K, tiles * batch);
+  w.kchunk = (((K + splits - 1) / splits) + BKP - 1) / BKP * BKP;
+  splits = (K + w.kchunk - 1) / w.kchunk;
+  const size_t total = (size_t)M * N;
+  w.dy_bs = a_bs; w.a_bs = b_bs; w.slab_bs = (long long)splits * total;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wgrad_kernel, dim3(splits, tiles, batch), dim3(256), 4 * TILEB, stream, w);
+  DMVAE_CHECK_LAUNCH();
+  int rb = (int)((total + 255) / 256); if (rb > 1024) rb = 1024;
+  if (out_f32)
+    hipLaunchKernelGGL(tn_reduce_kernel<float>, dim3(rb, batch), dim3(256), 0, stream, w.slab, (float*)C, splits, total, w.slab_bs, c_bs, alpha);
+  else
+    hipLaunchKernelGGL(tn_reduce_kernel<bf16>, dim3(rb, batch), dim3(256), 0, stream, w.slab, (bf16*)C, splits, total, w.slab_bs, c_bs, alpha);
+  DMVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -1,0 +1,221 @@
+// Layout, packing and small elementwise kernels around the conv/GEMM hot path (all HBM-bound).
+#include "common.h"
+#include "dmvae_hip.h"
+
+namespace dmvae_misc {
+
+// ---- conv weight packing -------------------------------------------------------------------
+// src: f32 [cout][cin][T] (PyTorch).  mode 0 (forward):  dst bf16 [cout_pad][T][cin_pad], dst[co][t][ci] = src[co][ci][t]
+//                                     mode 1 (dgrad):    dst bf16 [cin_pad][T][cout_pad], dst[ci][T-1-t][co] = src[co][ci][t]
+__global__ void pack_weight_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int cout, int cin, int T, int rows_pad,
+                                   int cols_pad, int mode) {
+  const size_t total = (size_t)rows_pad * T * cols_pad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int col = i % cols_pad;
+    const size_t r = i / cols_pad;
+    const int t = r % T;
+    const int row = r / T;
+    float v = 0.f;
+    if (mode == 0) {
+      if (row < cout && col < cin) v = src[((size_t)row * cin + col) * T + t];
+    } else {
+      if (row < cin && col < cout) v = src[((size_t)col * cin + row) * T + (T - 1 - t)];
+    }
+    dst[i] = (bf16)v;
+  }
+}
+
+// ---- 2x2 sum pool (backward of nearest x2 upsample, flux_ae.py:104) ---------------------------
+__global__ void sumpool2x2_kernel(const bf16* __restrict__ dy, bf16* __restrict__ dx, int N, int H, int W, int C) {
+  const int c8 = C / 8;
+  const size_t total = (size_t)N * H * W * c8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = i % c8;
+    size_t r = i / c8;
+    const int x = r % W; r /= W;
+    const int y = r % H;
+    const int n = r / H;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dyy = 0; dyy < 2; dyy++)
+#pragma unroll
+      for (int dxx = 0; dxx < 2; dxx++) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + (((size_t)n * 2 * H + 2 * y + dyy) * 2 * W + 2 * x + dxx) * C + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] += (float)v[e];
+      }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = (bf16)acc[e];
+    *reinterpret_cast<bf16x8*>(dx + i * 8) = o;
+  }
+}
+
+// ---- image layout: NCHW f32 <-> NHWC (channel-padded) ----------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int N, int C, int HW, int Cpad) {
+  const size_t total = (size_t)N * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, p = i % HW;
+    for (int c = 0; c < Cpad; c++) dst[i * Cpad + c] = (bf16)(c < C ? src[(n * C + c) * HW + p] : 0.f);
+  }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int N, int C, int HW, int Cpad) {
+  const size_t total = (size_t)N * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, p = i % HW;
+    for (int c = 0; c < C; c++) dst[(n * C + c) * HW + p] = (float)src[i * Cpad + c];
+  }
+}
+
+// ---- SiLU on bf16 (vae.py:60) ------------------------------------------------------------------
+__global__ void silu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const bf16x8 v = reinterpret_cast<const bf16x8*>(x)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { const float t = (float)v[e]; o[e] = (bf16)(t * sigmoidf_(t)); }
+    reinterpret_cast<bf16x8*>(y)[i] = o;
+  }
+}
+__global__ void silu_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, bf16* __restrict__ dx, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const bf16x8 v = reinterpret_cast<const bf16x8*>(x)[i];
+    const bf16x8 d = reinterpret_cast<const bf16x8*>(dy)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float t = (float)v[e], sg = sigmoidf_(t);
+      o[e] = (bf16)((float)d[e] * sg * (1.f + t * (1.f - sg)));
+    }
+    reinterpret_cast<bf16x8*>(dx)[i] = o;
+  }
+}
+
+// ---- row softmax for the decoder self-attention (flux_ae.py:47, S=1024) ------------------------
+// P[r][:] = softmax(scale * S[r][:]) ; one wave per row, f32 in, bf16 out.
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ s, bf16* __restrict__ p, int rows, int cols,
+                                                          float scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* sr = s + (size_t)row * cols;
+  float m = -INFINITY;
+  for (int c = lane; c < cols; c += 64) m = fmaxf(m, sr[c] * scale);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float sum = 0.f;
+  for (int c = lane; c < cols; c += 64) sum += __expf(sr[c] * scale - m);
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  bf16* pr = p + (size_t)row * cols;
+  for (int c = lane; c < cols; c += 64) pr[c] = (bf16)(__expf(sr[c] * scale - m) * inv);
+}
+// dS[r][:] = scale * P .* (dP - sum(dP .* P)) ; dP f32, P bf16, dS bf16
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dp, const bf16* __restrict__ p,
+                                                          bf16* __restrict__ ds, int rows, int cols, float scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* dr = dp + (size_t)row * cols;
+  const bf16* pr = p + (size_t)row * cols;
+  float dot = 0.f;
+  for (int c = lane; c < cols; c += 64) dot += dr[c] * (float)pr[c];
+  dot = wave_sum(dot);
+  bf16* o = ds + (size_t)row * cols;
+  for (int c = lane; c < cols; c += 64) o[c] = (bf16)(scale * (float)pr[c] * (dr[c] - dot));
+}
+
+// ---- bf16 [rows][cols] -> [cols][rows] batched transpose (attention K/V operands) ----------------
+__global__ void transpose_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int rows, int cols) {
+  __shared__ bf16 tile[32][33];
+  src += (size_t)blockIdx.z * rows * cols;
+  dst += (size_t)blockIdx.z * rows * cols;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[j][threadIdx.x] = src[(size_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) dst[(size_t)c * rows + r] = tile[threadIdx.x][j];
+  }
+}
+
+static inline int grid_for(size_t n, int block = 256, int cap = 4096) {
+  size_t g = (n + block - 1) / block;
+  return (int)(g > (size_t)cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace dmvae_misc
+using namespace dmvae_misc;
+
+extern "C" int dmvae_pack_conv_weight(const void* w, void* out, int cout, int cin, int ks, int rows_pad, int cols_pad,
+                                      int for_dgrad, hipStream_t stream) {
+  DMVAE_CHECK_ARG(w && out && cout > 0 && cin > 0 && (ks == 1 || ks == 3), "pack_conv_weight: bad argument");
+  DMVAE_CHECK_ARG(rows_pad >= (for_dgrad ? cin : cout) && cols_pad >= (for_dgrad ? cout : cin), "pack_conv_weight: padding smaller than shape");
+  const int T = ks * ks;
+  const size_t total = (size_t)rows_pad * T * cols_pad;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)w, (bf16*)out, cout, cin, T, rows_pad,
+                     cols_pad, for_dgrad ? 1 : 0);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_sumpool2x2_nhwc(const void* dy, void* dx, int n, int h, int w, int c, hipStream_t stream) {
+  DMVAE_CHECK_ARG(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "sumpool2x2_nhwc: bad argument (c must be a multiple of 8)");
+  hipLaunchKernelGGL(sumpool2x2_kernel, dim3(grid_for((size_t)n * h * w * (c / 8))), dim3(256), 0, stream, (const bf16*)dy, (bf16*)dx, n, h, w, c);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_nchw_f32_to_nhwc_bf16(const void* src, void* dst, int n, int c, int hw, int c_pad, hipStream_t stream) {
+  DMVAE_CHECK_ARG(src && dst && n > 0 && c > 0 && hw > 0 && c_pad >= c, "nchw_f32_to_nhwc_bf16: bad argument");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)n * hw)), dim3(256), 0, stream, (const float*)src, (bf16*)dst, n, c, hw, c_pad);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_nhwc_to_nchw_f32(const void* src, void* dst, int n, int c, int hw, int c_pad, int src_f32, hipStream_t stream) {
+  DMVAE_CHECK_ARG(src && dst && n > 0 && c > 0 && hw > 0 && c_pad >= c, "nhwc_to_nchw_f32: bad argument");
+  if (src_f32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for((size_t)n * hw)), dim3(256), 0, stream, (const float*)src, (float*)dst, n, c, hw, c_pad);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(grid_for((size_t)n * hw)), dim3(256), 0, stream, (const bf16*)src, (float*)dst, n, c, hw, c_pad);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_silu_fwd(const void* x, void* y, size_t n, hipStream_t stream) {
+  DMVAE_CHECK_ARG(x && y && n % 8 == 0, "silu_fwd: element count must be a multiple of 8");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(silu_fwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, n / 8);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int dmvae_silu_bwd(const void* x, const void* dy, void* dx, size_t n, hipStream_t stream) {
+  DMVAE_CHECK_ARG(x && dy && dx && n % 8 == 0, "silu_bwd: element count must be a multiple of 8");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16*)x, (const bf16*)dy, (bf16*)dx, n / 8);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_softmax_rows_fwd(const void* s, void* p, int rows, int cols, float scale, hipStream_t stream) {
+  DMVAE_CHECK_ARG(s && p && rows > 0 && cols > 0, "softmax_rows_fwd: bad argument");
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)s, (bf16*)p, rows, cols, scale);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int dmvae_softmax_rows_bwd(const void* dp, const void* p, void* ds, int rows, int cols, float scale, hipStream_t stream) {
+  DMVAE_CHECK_ARG(dp && p && ds && rows > 0 && cols > 0, "softmax_rows_bwd: bad argument");
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)dp, (const bf16*)p, (bf16*)ds, rows, cols, scale);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_transpose_bf16(const void* src, void* dst, int batch, int rows, int cols, hipStream_t stream) {
+  DMVAE_CHECK_ARG(src && dst && batch > 0 && batch < 65536 && rows > 0 && cols > 0, "transpose_bf16: bad argument");
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, batch), dim3(32, 8), 0, stream, (const bf16*)src, (bf16*)dst, rows, cols);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}

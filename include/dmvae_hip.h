@@ -86,6 +86,97 @@ int dmvae_groupnorm_bwd(const void* da, const void* x, const void* dres, const v
                         size_t workspace_bytes, int n, int hw, int c, int groups, int swish, int accumulate,
                         dmvae_stream_t stream);
 
+/* ---- batched GEMMs on the same MFMA cores (decoder self-attention, flux_ae.py:37-49) --------- */
+
+/* C[b][m][n] = act( sum_k A[b][m][k]*B[b][n][k] + bias[n] + R[b][m][n] ); row-major bf16, both
+ * operands K-contiguous; *_bs are element strides between batch items (0 = shared operand);
+ * C/R share c_bs.  K%32==0, N%4==0.  act as in dmvae_conv_desc; out_f32 selects C's type. */
+int dmvae_gemm_nt_batched(const void* A, const void* B, const void* bias, const void* R, void* C, int M, int N,
+                          int K, int batch, long long a_bs, long long b_bs, long long c_bs, int act, int out_f32,
+                          dmvae_stream_t stream);
+
+/* C[b][m][n] = alpha * sum_k A[b][k][m]*B[b][k][n]  (A:[K][M], B:[K][N] row-major bf16; the
+ * reduction dim is the slow one -> LDS transpose reads).  M%8==0, N%8==0.  Split-K, deterministic. */
+size_t dmvae_gemm_tn_batched_workspace(int M, int N, int K, int batch);
+int dmvae_gemm_tn_batched(const void* A, const void* B, void* C, void* workspace, size_t workspace_bytes, int M,
+                          int N, int K, int batch, long long a_bs, long long b_bs, long long c_bs, float alpha,
+                          int out_f32, dmvae_stream_t stream);
+
+/* P = softmax(scale*S) per row (S f32 [rows][cols] -> P bf16), and its backward
+ * dS = scale * P .* (dP - rowsum(dP .* P)) (dP f32, dS bf16).  F.scaled_dot_product_attention's
+ * softmax at flux_ae.py:47 (single head, scale = 1/sqrt(C)). */
+int dmvae_softmax_rows_fwd(const void* s, void* p, int rows, int cols, float scale, dmvae_stream_t stream);
+int dmvae_softmax_rows_bwd(const void* dp, const void* p, void* ds, int rows, int cols, float scale,
+                           dmvae_stream_t stream);
+/* dst[b][c][r] = src[b][r][c], bf16 */
+int dmvae_transpose_bf16(const void* src, void* dst, int batch, int rows, int cols, dmvae_stream_t stream);
+
+/* ---- layout / packing ------------------------------------------------------------------------- */
+
+/* nn.Conv2d.weight f32 [cout][cin][ks][ks] -> bf16 kernel operand.
+ * for_dgrad=0: out[rows_pad=cout..][ks*ks][cols_pad=cin..], out[co][t][ci]       = w[co][ci][t]
+ * for_dgrad=1: out[rows_pad=cin..][ks*ks][cols_pad=cout..], out[ci][T-1-t][co]   = w[co][ci][t]
+ * (tap-flipped transpose: conv2d_nhwc_fwd on dy with this operand is the input gradient).
+ * Padding rows/cols are zero-filled. */
+int dmvae_pack_conv_weight(const void* w, void* out, int cout, int cin, int ks, int rows_pad, int cols_pad,
+                           int for_dgrad, dmvae_stream_t stream);
+/* dx[n,h,w,c] = sum of the 2x2 block of dy[n,2h,2w,c]: backward of F.interpolate(scale=2,'nearest')
+ * (flux_ae.py:104).  bf16, c%8==0. */
+int dmvae_sumpool2x2_nhwc(const void* dy, void* dx, int n, int h, int w, int c, dmvae_stream_t stream);
+/* image layout conversion at the Decoder boundary (reference tensors are NCHW f32). */
+int dmvae_nchw_f32_to_nhwc_bf16(const void* src, void* dst, int n, int c, int hw, int c_pad, dmvae_stream_t stream);
+int dmvae_nhwc_to_nchw_f32(const void* src, void* dst, int n, int c, int hw, int c_pad, int src_f32,
+                           dmvae_stream_t stream);
+/* SiLU on bf16 (nn.SiLU in the bottleneck MLP, vae.py:60) and its backward. n%8==0. */
+int dmvae_silu_fwd(const void* x, void* y, size_t n, dmvae_stream_t stream);
+int dmvae_silu_bwd(const void* x, const void* dy, void* dx, size_t n, dmvae_stream_t stream);
+
+/* ---- losses (HBM-bound reductions) ------------------------------------------------------------- */
+
+size_t dmvae_loss_workspace(void);
+
+/* out2 = { mean|recon-images|, mean (recon-images)^2 } over n f32 elements (F.l1_loss, F.mse_loss,
+ * train_tokenizer.py:180-181).  grad (optional, f32 [n]) = w1*sign(d)/n + w2*2d/n. */
+int dmvae_l1_mse(const void* recon, const void* images, void* grad, void* out2, void* workspace,
+                 size_t workspace_bytes, size_t n, float w1, float w2, dmvae_stream_t stream);
+
+/* One LPIPS level (utils/lpips.py:86-94): out[0] (+)= mean_{n,hw} sum_c w_c (f0/(|f0|+1e-10) -
+ * f1/(|f1|+1e-10))^2 for NHWC bf16 features [n][hw][c].  df1 (optional bf16) = gscale * d(sum)/d f1. */
+int dmvae_lpips_diff(const void* f0, const void* f1, const void* lin_w, void* df1, void* out, void* workspace,
+                     size_t workspace_bytes, int n, int hw, int c, float gscale, int accumulate,
+                     dmvae_stream_t stream);
+
+/* DMD score-gradient loss (train_dmd.py:204-230; toy_example_2d/dmd.py:349-360), f32 [batch][per_sample]:
+ * pre : xt = t*x1 + (1-t)*x0                                       (ICPlan, path.py:114-136)
+ * post: CFG combine, pred = xt + v*(1-t), grad = (p_real-p_student)/mean|p_real| (weight_factor!=0),
+ *       nan_to_num; out2 = { 0.5*mean(grad^2), mean_b ||grad_b|| }; dlatents = grad/numel. */
+int dmvae_dmd_pre(const void* x1, const void* x0, const void* t, void* xt, int batch, int per_sample,
+                  dmvae_stream_t stream);
+int dmvae_dmd_post(const void* x1, const void* xt, const void* t, const void* v_teacher, const void* v_teacher_u,
+                   const void* v_student, const void* v_student_u, void* dlatents, void* out2, void* workspace,
+                   size_t workspace_bytes, int batch, int per_sample, float cfg, int weight_factor,
+                   dmvae_stream_t stream);
+
+/* Build-defined (no reference counterpart): per-latent KL of batch moments vs N(0,1) and batched
+ * RBF-mixture MMD^2 between z[g] ([n][32] f32) and y[g] ([m][32] f32), fused in one pass over z.
+ * kl: [33] f32 (32 channels + their mean); mmd: [groups] f32;
+ * dz (optional): w_kl * d mean(kl)/dz + w_mmd * d mean(mmd)/dz.  workspace >= (groups*64+64)*4 B. */
+int dmvae_kl_mmd(const void* z, const void* y, void* kl, void* mmd, void* dz, void* workspace,
+                 size_t workspace_bytes, int groups, int n, int m, int d, float w_kl, float w_mmd,
+                 dmvae_stream_t stream);
+
+/* ---- optimiser tail on flat f32 buffers (train_tokenizer.py:140-150,382,415-419) ---------------- */
+
+/* norm_out3 = { ||g||_2, min(1, max_norm/(norm+1e-6)), sum of squares }; accumulate_prev!=0 adds the
+ * previous call's sum of squares (norm over several buffers).  workspace >= 8 KiB. */
+int dmvae_grad_norm(const void* grads, void* norm_out3, void* workspace, size_t workspace_bytes, size_t n,
+                    float max_norm, int accumulate_prev, dmvae_stream_t stream);
+/* p,m,v (and ema when non-NULL) updated in place: g*=clip (norm_out3[1], NULL = no clip); decoupled
+ * weight decay; bias-corrected Adam (torch.optim.AdamW semantics); ema = ema*decay + p*(1-decay). */
+int dmvae_adamw_ema_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, void* ema,
+                         const void* norm_out3, size_t n, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int step, float ema_decay, dmvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

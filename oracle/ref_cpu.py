@@ -1,0 +1,441 @@
+"""CPU oracle: a functional restatement of the reference's DMVAE hot path (PyTorch CPU, fp32/fp64).
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``dmvae_amd/`` imports this file; only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may.  The product path has no
+CPU fallback.
+
+Pinning: every function here is checked against golden vectors captured by importing the
+reference's own modules in the build container (``oracle/capture_golden.py`` ->
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py``).  The reference ships no tests or
+fixtures of its own, so those captured outputs are the pin.  The KL / MMD
+functions have NO reference counterpart: they are this build's own
+specification and their parity is *unpinned*.
+
+All functions take parameters as a flat ``dict[str, Tensor]`` keyed exactly like the reference's
+``state_dict()`` and use the reference's NCHW layout.  ``q`` is an optional rounding hook applied
+at the points where the HIP path stores bf16 (conv/GEMM operands and outputs); ``q=None`` is the
+plain fp32 algorithm.
+
+Reference files followed (all under /root/reference):
+  models/flux_ae.py:21-107,184-278   models/vae.py:10-98          utils/lpips.py:81-162
+  train_tokenizer.py:134-150,179-204  train_dmd.py:204-230,408-416
+  diffusion/transport/transport.py:105-164, path.py:5-136, utils.py:12-16
+  models/dinov2.py + models/dino_layers/{block,attention,layer_scale,mlp,patch_embed}.py
+  toy_example_2d/dmd.py:320-360, toy_example_2d/sshpae.py:29-71
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+P = Dict[str, Tensor]
+Q = Optional[Callable[[Tensor], Tensor]]
+
+
+# --------------------------------------------------------------------------------------------
+# rounding hooks
+# --------------------------------------------------------------------------------------------
+class _Bf16RoundSTE(torch.autograd.Function):
+    """Round to bf16 in forward AND round the incoming gradient in backward (the HIP path stores
+    activations and activation-gradients as bf16 at the same tensor sites)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _Bf16RoundFwdOnly(torch.autograd.Function):
+    """Round to bf16 in forward, identity gradient (weights: f32 master, bf16 shadow copy)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def bf16_round(x: Tensor) -> Tensor:
+    return _Bf16RoundSTE.apply(x)
+
+
+def bf16_round_weight(x: Tensor) -> Tensor:
+    return _Bf16RoundFwdOnly.apply(x)
+
+
+def _q(q: Q, x: Tensor) -> Tensor:
+    return x if q is None else q(x)
+
+
+def _qw(q: Q, w: Tensor) -> Tensor:
+    return w if q is None else bf16_round_weight(w)
+
+
+# --------------------------------------------------------------------------------------------
+# models/flux_ae.py
+# --------------------------------------------------------------------------------------------
+def swish(x: Tensor) -> Tensor:
+    """flux_ae.py:21-22"""
+    return x * torch.sigmoid(x)
+
+
+def group_norm(x: Tensor, weight: Tensor, bias: Tensor, groups: int = 32, eps: float = 1e-6) -> Tensor:
+    """nn.GroupNorm(32, C, eps=1e-6, affine=True) (flux_ae.py:28,62,64,236), biased variance."""
+    n, c = x.shape[:2]
+    xg = x.reshape(n, groups, -1)
+    mean = xg.mean(dim=2, keepdim=True)
+    var = ((xg - mean) ** 2).mean(dim=2, keepdim=True)
+    xh = ((xg - mean) / torch.sqrt(var + eps)).reshape(x.shape)
+    shape = [1, c] + [1] * (x.dim() - 2)
+    return xh * weight.reshape(shape) + bias.reshape(shape)
+
+
+def conv2d(x: Tensor, p: P, name: str, q: Q = None, stride: int = 1, padding: int = 1, round_out: bool = True) -> Tensor:
+    y = F.conv2d(_q(q, x), _qw(q, p[name + ".weight"]), p[name + ".bias"], stride=stride, padding=padding)
+    return _q(q, y) if round_out else y
+
+
+def resnet_block(x: Tensor, p: P, pre: str, q: Q = None) -> Tensor:
+    """flux_ae.py:69-82.  bf16 sites of the HIP path: conv inputs (after GN+swish), conv1 output,
+    shortcut output, block output (conv2 + bias + residual rounded once)."""
+    cin, cout = p[pre + "conv1.weight"].shape[1], p[pre + "conv1.weight"].shape[0]
+    h = swish(group_norm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"]))
+    h = conv2d(h, p, pre + "conv1", q)
+    h = swish(group_norm(h, p[pre + "norm2.weight"], p[pre + "norm2.bias"]))
+    h = conv2d(h, p, pre + "conv2", q, round_out=False)
+    if cin != cout:
+        x = conv2d(x, p, pre + "nin_shortcut", q, padding=0)
+    return _q(q, x + h)
+
+
+def attn_block(x: Tensor, p: P, pre: str, q: Q = None) -> Tensor:
+    """flux_ae.py:37-52: GN -> q,k,v 1x1 -> single-head SDPA over (h w) tokens with d=C -> proj -> +x."""
+    b, c, hh, ww = x.shape
+    h_ = group_norm(x, p[pre + "norm.weight"], p[pre + "norm.bias"])
+    qq = conv2d(h_, p, pre + "q", q, padding=0)
+    kk = conv2d(h_, p, pre + "k", q, padding=0)
+    vv = conv2d(h_, p, pre + "v", q, padding=0)
+    qt = qq.reshape(b, c, hh * ww).transpose(1, 2)  # b (h w) c
+    kt = kk.reshape(b, c, hh * ww).transpose(1, 2)
+    vt = vv.reshape(b, c, hh * ww).transpose(1, 2)
+    s = torch.matmul(qt, kt.transpose(1, 2)) * (1.0 / math.sqrt(c))
+    pr = torch.softmax(s, dim=-1)
+    o = torch.matmul(_q(q, pr), vt)  # HIP path stores P as bf16 before P.V
+    o = _q(q, o).transpose(1, 2).reshape(b, c, hh, ww)
+    o = conv2d(o, p, pre + "proj_out", q, padding=0, round_out=False)
+    return _q(q, x + o)
+
+
+def upsample(x: Tensor, p: P, pre: str, q: Q = None) -> Tensor:
+    """flux_ae.py:103-107: nearest x2 then conv3x3."""
+    x = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    return conv2d(x, p, pre + "conv", q)
+
+
+def downsample(x: Tensor, p: P, pre: str, q: Q = None) -> Tensor:
+    """flux_ae.py:91-95: pad (0,1,0,1) then conv3x3 stride 2 pad 0."""
+    x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0.0)
+    return conv2d(x, p, pre + "conv", q, stride=2, padding=0)
+
+
+def decoder_forward(z: Tensor, p: P, pre: str = "", q: Q = None, num_resolutions: int = 4, num_res_blocks: int = 2,
+                    final_f32: bool = True) -> Tensor:
+    """flux_ae.py:239-269 with post_init's conv_in = Sequential(Upsample(z), Conv3x3) (:271-275).
+    z: [B,256,C] tokens (hard-coded 16x16, :244-245) or [B,C,h,w]."""
+    if z.dim() == 3:
+        b, t, c = z.shape
+        assert t == 256, "reference hard-codes a 16x16 token grid (flux_ae.py:245)"
+        z = z.reshape(b, 16, 16, c).permute(0, 3, 1, 2)
+    h = upsample(_q(q, z), p, pre + "conv_in.0.", q)
+    h = conv2d(h, p, pre + "conv_in.1", q)
+    h = resnet_block(h, p, pre + "mid.block_1.", q)
+    h = attn_block(h, p, pre + "mid.attn_1.", q)
+    h = resnet_block(h, p, pre + "mid.block_2.", q)
+    for lvl in reversed(range(num_resolutions)):
+        for blk in range(num_res_blocks + 1):
+            h = resnet_block(h, p, f"{pre}up.{lvl}.block.{blk}.", q)
+        if lvl != 0:
+            h = upsample(h, p, f"{pre}up.{lvl}.upsample.", q)
+    h = swish(group_norm(h, p[pre + "norm_out.weight"], p[pre + "norm_out.bias"]))
+    return conv2d(h, p, pre + "conv_out", q, round_out=not final_f32)
+
+
+def encoder_forward(x: Tensor, p: P, pre: str = "", q: Q = None, num_resolutions: int = 4, num_res_blocks: int = 2) -> Tensor:
+    """flux_ae.py:160-181 (defined but never instantiated by the reference scripts; same kernels)."""
+    h = conv2d(x, p, pre + "conv_in", q)
+    for lvl in range(num_resolutions):
+        for blk in range(num_res_blocks):
+            h = resnet_block(h, p, f"{pre}down.{lvl}.block.{blk}.", q)
+        if lvl != num_resolutions - 1:
+            h = downsample(h, p, f"{pre}down.{lvl}.downsample.", q)
+    h = resnet_block(h, p, pre + "mid.block_1.", q)
+    h = attn_block(h, p, pre + "mid.attn_1.", q)
+    h = resnet_block(h, p, pre + "mid.block_2.", q)
+    h = swish(group_norm(h, p[pre + "norm_out.weight"], p[pre + "norm_out.bias"]))
+    return conv2d(h, p, pre + "conv_out", q)
+
+
+# --------------------------------------------------------------------------------------------
+# models/vae.py
+# --------------------------------------------------------------------------------------------
+def linear(x: Tensor, p: P, name: str, q: Q = None, round_out: bool = True) -> Tensor:
+    y = F.linear(_q(q, x), _qw(q, p[name + ".weight"]), p.get(name + ".bias"))
+    return _q(q, y) if round_out else y
+
+
+def mlp_forward(x: Tensor, p: P, pre: str = "bottle_neck.", q: Q = None) -> Tensor:
+    """vae.py:56-65: Linear -> SiLU -> Linear."""
+    h = linear(x, p, pre + "mlp.0", q)
+    return linear(F.silu(h), p, pre + "mlp.2", q)
+
+
+def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
+    mean = x.mean(dim=-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps) * w + b
+
+
+def vit_forward_features(x: Tensor, p: P, pre: str = "encoder.model.", num_heads: int = 16, patch: int = 16, q: Q = None) -> Tensor:
+    """DINOv2 ViT forward_features -> [B, 1+N, C] (cls first), following models/dinov2.py:224-262 and
+    dino_layers/{patch_embed.py:68-81, block.py:89-115, attention.py:56-69, layer_scale.py:26, mlp.py:34-39}.
+    timm's `vit_*_patch14_dinov2` uses the same algebra and the same parameter sub-names."""
+    w = p[pre + "patch_embed.proj.weight"]
+    t = F.conv2d(_q(q, x), _qw(q, w), p[pre + "patch_embed.proj.bias"], stride=patch)
+    b, c = t.shape[:2]
+    t = _q(q, t.flatten(2).transpose(1, 2))
+    t = torch.cat([p[pre + "cls_token"].expand(b, -1, -1), t], dim=1) + p[pre + "pos_embed"]
+    depth = 1 + max(int(k[len(pre) + 7:].split(".")[0]) for k in p if k.startswith(pre + "blocks."))
+    hd = c // num_heads
+    for i in range(depth):
+        bp = f"{pre}blocks.{i}."
+        h = layer_norm(t, p[bp + "norm1.weight"], p[bp + "norm1.bias"])
+        qkv = linear(h, p, bp + "attn.qkv", q).reshape(b, -1, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
+        att = torch.softmax((qkv[0] * hd ** -0.5) @ qkv[1].transpose(-2, -1), dim=-1)
+        h = (att @ qkv[2]).transpose(1, 2).reshape(b, -1, c)
+        h = linear(h, p, bp + "attn.proj", q)
+        t = t + h * p[bp + "ls1.gamma"]
+        h = layer_norm(t, p[bp + "norm2.weight"], p[bp + "norm2.bias"])
+        h = linear(F.gelu(linear(h, p, bp + "mlp.fc1", q)), p, bp + "mlp.fc2", q)
+        t = t + h * p[bp + "ls2.gamma"]
+    return layer_norm(t, p[pre + "norm.weight"], p[pre + "norm.bias"])
+
+
+def dino_encoder_forward(x: Tensor, p: P, pre: str = "encoder.", num_heads: int = 16, q: Q = None) -> Tensor:
+    """vae.py:52-53 with Denormalize/Normalize (:10-31): x in [-1,1] -> ImageNet-normalised -> ViT -> drop cls."""
+    x = x * p[pre + "de_scale.std"] + p[pre + "de_scale.mean"]
+    x = (x - p[pre + "scale.mean"]) / p[pre + "scale.std"]
+    return vit_forward_features(x, p, pre + "model.", num_heads=num_heads, q=q)[:, 1:]
+
+
+def vae_forward(x: Tensor, p: P, num_heads: int = 16, q: Q = None, return_latent: bool = False):
+    """vae.py:90-98."""
+    tok = dino_encoder_forward(x, p, num_heads=num_heads, q=q)
+    lat = mlp_forward(tok, p, q=q)
+    rec = decoder_forward(lat, p, pre="decoder.", q=q).float()
+    return (rec, lat) if return_latent else rec
+
+
+# --------------------------------------------------------------------------------------------
+# utils/lpips.py
+# --------------------------------------------------------------------------------------------
+LPIPS_SHIFT = (-0.030, -0.088, -0.188)
+LPIPS_SCALE = (0.458, 0.448, 0.450)
+VGG_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512)
+VGG_TAPS = (3, 8, 15, 22, 29)  # relu1_2, relu2_2, relu3_3, relu4_3, relu5_3 (lpips.py:126-135)
+
+
+def vgg16_features(x: Tensor, p: P, pre: str = "net.", q: Q = None) -> List[Tensor]:
+    """torchvision VGG16 'D' features sliced as lpips.py:116-153; returns the five tapped activations.
+    Parameter names follow the reference's slices: net.slice{1..5}.{idx}.{weight,bias}."""
+    outs, idx, h = [], 0, x
+    bounds = (4, 9, 16, 23, 30)
+    for v in VGG_CFG:
+        sl = 1 + sum(idx >= bnd for bnd in bounds)
+        if v == "M":
+            h = F.max_pool2d(h, 2, 2)
+            idx += 1
+        else:
+            name = f"{pre}slice{sl}.{idx}"
+            h = F.relu(F.conv2d(_q(q, h), _qw(q, p[name + ".weight"]), p[name + ".bias"], padding=1))
+            h = _q(q, h)
+            idx += 2
+        if idx - 1 in VGG_TAPS:
+            outs.append(h)
+    return outs
+
+
+def lpips_from_feats(f0: Sequence[Tensor], f1: Sequence[Tensor], lin_w: Sequence[Tensor], eps: float = 1e-10) -> Tensor:
+    """lpips.py:86-94,156-162: sum_l mean_hw( w_l . (f0/|f0| - f1/|f1|)^2 ), then mean over batch -> scalar."""
+    val = 0.0
+    for a, b, w in zip(f0, f1, lin_w):
+        na = a / (torch.sqrt((a ** 2).sum(dim=1, keepdim=True)) + eps)
+        nb = b / (torch.sqrt((b ** 2).sum(dim=1, keepdim=True)) + eps)
+        d = (na - nb) ** 2
+        val = val + (d * w.reshape(1, -1, 1, 1)).sum(dim=1, keepdim=True).mean(dim=(2, 3), keepdim=True)
+    return val.mean()
+
+
+def lpips_forward(inp: Tensor, tgt: Tensor, p: P, q: Q = None) -> Tensor:
+    """lpips.py:81-94 (ScalingLayer :97-104)."""
+    shift = torch.tensor(LPIPS_SHIFT, dtype=inp.dtype).reshape(1, 3, 1, 1)
+    scale = torch.tensor(LPIPS_SCALE, dtype=inp.dtype).reshape(1, 3, 1, 1)
+    f0 = vgg16_features((inp - shift) / scale, p, q=q)
+    f1 = vgg16_features((tgt - shift) / scale, p, q=q)
+    lin = [p[f"lin{k}.model.1.weight"].reshape(-1) for k in range(5)]
+    return lpips_from_feats(f0, f1, lin)
+
+
+# --------------------------------------------------------------------------------------------
+# train_tokenizer.py / train_dmd.py losses
+# --------------------------------------------------------------------------------------------
+def l1_mse(recon: Tensor, images: Tensor) -> Tuple[Tensor, Tensor]:
+    """train_tokenizer.py:180-181."""
+    d = recon - images
+    return d.abs().mean(), (d * d).mean()
+
+
+def forward_generator(images: Tensor, recon: Tensor, lpips_p: P, l1_w: float = 1.0, l2_w: float = 0.0,
+                      lpips_w: float = 1.0, q: Q = None):
+    """train_tokenizer.py:179-190 with the discriminator branch off (step < disc_start_step)."""
+    l1, l2 = l1_mse(recon, images)
+    lp = lpips_forward(images, recon, lpips_p, q=q)
+    rec = l1 * l1_w + l2 * l2_w + lp * lpips_w
+    return rec, {"L1": l1, "L2": l2, "LPIPS": lp, "rec_loss": rec}
+
+
+def expand_t(t: Tensor, x: Tensor) -> Tensor:
+    return t.reshape(t.shape[0], *([1] * (x.dim() - 1)))
+
+
+def transport_plan(t: Tensor, x0: Tensor, x1: Tensor) -> Tuple[Tensor, Tensor]:
+    """ICPlan (path.py:18-27,114-136): alpha=t, sigma=1-t -> xt = t*x1 + (1-t)*x0, ut = x1 - x0."""
+    te = expand_t(t, x1)
+    return te * x1 + (1 - te) * x0, x1 - x0
+
+
+def transport_loss(model_out: Tensor, t: Tensor, x0: Tensor, x1: Tensor) -> Tensor:
+    """transport.py:134-143: mean_flat((model_output - ut)^2) per sample."""
+    _, ut = transport_plan(t, x0, x1)
+    return ((model_out - ut) ** 2).flatten(1).mean(dim=1)
+
+
+def dmd_loss(latents: Tensor, t: Tensor, x0: Tensor, v_teacher: Tensor, v_student: Tensor,
+             v_teacher_u: Optional[Tensor] = None, v_student_u: Optional[Tensor] = None, cfg: float = 1.0,
+             weight_factor: bool = True):
+    """train_dmd.py:204-230 with (t, x0) and the four model outputs injected.  `t` is already mapped
+    into [t0, t1].  weight_factor=False gives the toy variant (toy_example_2d/dmd.py:349-360).
+    Returns loss, dmd_gradient_norm, grad (the detached score-gradient; dloss/dlatents = grad/numel)."""
+    xt, _ = transport_plan(t, x0, latents)
+    vt, vs = v_teacher, v_student
+    if cfg > 1:
+        vt = vt + (cfg - 1) * (vt - v_teacher_u)
+        vs = vs + (cfg - 1) * (vs - v_student_u)
+    om = expand_t(1 - t, xt)
+    pred_t = xt + vt * om
+    pred_s = xt + vs * om
+    p_real = latents - pred_t
+    p_student = latents - pred_s
+    grad = p_real - p_student
+    if weight_factor:
+        grad = grad / p_real.abs().mean(dim=tuple(range(1, latents.dim())), keepdim=True)
+    grad = torch.nan_to_num(grad).detach()
+    loss = 0.5 * F.mse_loss(latents, (latents - grad).detach(), reduction="mean")
+    gnorm = torch.norm(grad.flatten(1), dim=1).mean()
+    return loss, gnorm, grad
+
+
+def latents_to_spatial(tokens: Tensor) -> Tensor:
+    """train_dmd.py:408-416 (p=1): [B, h*w, C] -> [B, C, h, w], a pure permutation (bit-exact)."""
+    b, t, c = tokens.shape
+    h = int(t ** 0.5)
+    assert h * h == t
+    return tokens.reshape(b, h, h, c).permute(0, 3, 1, 2).contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# optimiser tail (train_tokenizer.py:140-150,382-392,415-419)
+# --------------------------------------------------------------------------------------------
+def clip_grad_norm(grads: Sequence[Tensor], max_norm: float = 1.0, eps: float = 1e-6) -> Tuple[Tensor, List[Tensor]]:
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    coef = torch.clamp(max_norm / (total + eps), max=1.0)
+    return total, [g * coef for g in grads]
+
+
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.95,
+               eps: float = 1e-8, wd: float = 0.005):
+    """torch.optim.AdamW semantics (decoupled decay, bias correction, eps added after sqrt(v_hat))."""
+    p = p * (1 - lr * wd)
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    p = p - (lr / bc1) * m / denom
+    return p, m, v
+
+
+def ema_update(ema: Tensor, p: Tensor, decay: float = 0.9999) -> Tensor:
+    return ema * decay + p * (1 - decay)
+
+
+def warmup_lr(step: int, base_lr: float, warmup_steps: int = 1000) -> float:
+    """LambdaLR of train_tokenizer.py:385-392: linear warm-up then constant."""
+    return base_lr * min(1.0, (step + 1) / warmup_steps) if warmup_steps > 0 else base_lr
+
+
+# --------------------------------------------------------------------------------------------
+# Build-defined distribution-matching statistics (NO reference counterpart: parity unpinned)
+# --------------------------------------------------------------------------------------------
+def kl_moment(z: Tensor) -> Tuple[Tensor, Tensor]:
+    """Per-latent-channel KL( N(mu_c, sigma_c^2) || N(0,1) ) with batch moments over (B*T):
+    0.5*(mu^2 + var - 1 - ln var), biased variance.  z: [B,T,C] -> (per-channel [C], mean scalar)."""
+    zz = z.reshape(-1, z.shape[-1]).double()
+    mu = zz.mean(dim=0)
+    var = ((zz - mu) ** 2).mean(dim=0)
+    kl = 0.5 * (mu * mu + var - 1.0 - torch.log(var))
+    return kl.to(z.dtype), kl.mean().to(z.dtype)
+
+
+MMD_BANDWIDTH_MULTS = (0.5, 1.0, 2.0, 4.0, 8.0)
+
+
+def mmd_rbf(x: Tensor, y: Tensor) -> Tensor:
+    """Biased RBF-mixture MMD^2 per group.  x: [G,n,d], y: [G,m,d] -> [G].
+    k(a,b) = mean_j exp(-|a-b|^2 / (2 * mult_j * d));  MMD^2 = mean k(x,x) + mean k(y,y) - 2 mean k(x,y)."""
+    d = x.shape[-1]
+
+    def kmean(a, b):
+        d2 = (a.double().unsqueeze(2) - b.double().unsqueeze(1)).pow(2).sum(-1)
+        k = sum(torch.exp(-d2 / (2.0 * m * d)) for m in MMD_BANDWIDTH_MULTS) / len(MMD_BANDWIDTH_MULTS)
+        return k.mean(dim=(1, 2))
+
+    return (kmean(x, x) + kmean(y, y) - 2 * kmean(x, y)).to(x.dtype)
+
+
+# --------------------------------------------------------------------------------------------
+# toy_example_2d/sshpae.py
+# --------------------------------------------------------------------------------------------
+def sshape_sample(n: int, seed: int = 42, thickness: float = 0.06, diffusion: float = 0.03, amplitude: float = 0.85,
+                  vertical_scale: float = 0.85, skew: float = 0.15) -> np.ndarray:
+    """SShapeDistribution2D(random_state=seed, flip_y=True).sample(n)[0] (sshpae.py:29-71)."""
+    rng = np.random.default_rng(seed)
+    t = rng.uniform(-1.0, 1.0, size=n)
+    pts = np.stack([amplitude * np.sin(np.pi * t), vertical_scale * t - skew * np.sin(2 * np.pi * t)], axis=1)
+    tang = np.stack([amplitude * np.pi * np.cos(np.pi * t), vertical_scale - 2 * np.pi * skew * np.cos(2 * np.pi * t)], axis=1)
+    tang /= np.linalg.norm(tang, axis=1, keepdims=True) + 1e-8
+    ang = np.arctan2(tang[:, 0], -tang[:, 1])
+    rad = rng.normal(0.0, thickness, size=n)
+    pts[:, 0] += rad * np.cos(ang)
+    pts[:, 1] += rad * np.sin(ang)
+    pts += rng.normal(0.0, (diffusion * (0.4 + 0.6 * np.abs(t)))[:, None])
+    pts[:, 1] *= -1
+    return np.clip(pts, -1.0, 1.0)
