@@ -1,0 +1,202 @@
+"""torch.autograd.Functions that orchestrate the HIP kernels for one reference module each.
+
+Granularity follows models/flux_ae.py: one Function per ResnetBlock (:69-82), AttnBlock (:37-52),
+Upsample (:103-107), plain conv (:237,274), norm_out+swish+conv_out (:266-268) and the bottleneck
+MLP (models/vae.py:56-65).  Forward and backward are hand-scheduled sequences of C-ABI calls
+(dmvae_amd.ops); nothing here computes on the CPU.  Internal activations are NHWC bf16.
+
+What each backward saves: the block input, the GroupNorm statistics, and the bf16 post-norm
+activations `a = swish(GN(x))` that the forward materialised anyway (they are the wgrad operand).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .ops import bf16, f32
+
+_EPOCH = [0]   # bumped by optimisers that update weights through raw pointers
+_PACK_CACHE = {}
+
+
+def bump_weight_epoch() -> None:
+    _EPOCH[0] += 1
+
+
+def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad: int = 0) -> torch.Tensor:
+    """bf16 kernel operand of an f32 conv/linear weight, cached until the weight changes."""
+    key = (w.data_ptr(), tuple(w.shape), for_dgrad, rows_pad, cols_pad)
+    ver = (w._version, _EPOCH[0])
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    p = ops.pack_conv_weight(w.detach().contiguous(), for_dgrad, rows_pad, cols_pad)
+    _PACK_CACHE[key] = (ver, p)
+    return p
+
+
+def _gn_swish(x, gw, gb, swish=True):
+    st = ops.groupnorm_stats(x)
+    return st, ops.groupnorm_apply(x, st, gw, gb, swish)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class ResnetBlockFn(torch.autograd.Function):
+    """x + conv2(swish(GN(conv1(swish(GN(x)))))) with optional 1x1 shortcut (flux_ae.py:69-82)."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, sw, sb):
+        st1, a1 = _gn_swish(x, n1w, n1b)
+        h1 = ops.conv2d_nhwc(a1, packed(c1w), c1b, ks=3)
+        st2, a2 = _gn_swish(h1, n2w, n2b)
+        xs = x if sw is None else ops.conv2d_nhwc(x, packed(sw), sb, ks=1)
+        y = ops.conv2d_nhwc(a2, packed(c2w), c2b, residual=xs, ks=3)
+        ctx.save_for_backward(x, st1, a1, h1, st2, a2, n1w, n1b, c1w, n2w, n2b, c2w, sw)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st1, a1, h1, st2, a2, n1w, n1b, c1w, n2w, n2b, c2w, sw = ctx.saved_tensors
+        dy = _c(dy)
+        dc2w, dc2b = ops.conv2d_nhwc_wgrad(dy, a2, 3)
+        da2 = ops.conv2d_nhwc(dy, packed(c2w, True), ks=3)
+        dh1, dn2w, dn2b = ops.groupnorm_bwd(da2, h1, st2, n2w, n2b, True)
+        dc1w, dc1b = ops.conv2d_nhwc_wgrad(dh1, a1, 3)
+        da1 = ops.conv2d_nhwc(dh1, packed(c1w, True), ks=3)
+        if sw is None:
+            dxs, dsw, dsb = dy, None, None
+        else:
+            dsw, dsb = ops.conv2d_nhwc_wgrad(dy, x, 1)
+            dxs = ops.conv2d_nhwc(dy, packed(sw, True), ks=1)
+        dx, dn1w, dn1b = ops.groupnorm_bwd(da1, x, st1, n1w, n1b, True, dres=dxs)
+        return dx, dn1w, dn1b, dc1w, dc1b, dn2w, dn2b, dc2w, dc2b, dsw, dsb
+
+
+class AttnBlockFn(torch.autograd.Function):
+    """x + proj_out(SDPA(q,k,v)) over (h w) tokens, single head, d = C (flux_ae.py:37-52)."""
+
+    @staticmethod
+    def forward(ctx, x, nw, nb, qw, qb, kw, kb, vw, vb, pw, pb):
+        n, h, w, c = x.shape
+        s = h * w
+        st, hn = _gn_swish(x, nw, nb, swish=False)
+        q = ops.conv2d_nhwc(hn, packed(qw), qb, ks=1).view(n, s, c)
+        k = ops.conv2d_nhwc(hn, packed(kw), kb, ks=1).view(n, s, c)
+        v = ops.conv2d_nhwc(hn, packed(vw), vb, ks=1).view(n, s, c)
+        scale = float(c) ** -0.5
+        p = ops.softmax_rows(ops.gemm_nt(q, k, out_f32=True), scale)          # [n, s, s] bf16
+        o = ops.gemm_nt(p, ops.transpose_last2(v))                            # [n, s, c]
+        y = ops.conv2d_nhwc(o.view(n, h, w, c), packed(pw), pb, residual=x, ks=1)
+        ctx.save_for_backward(x, st, hn, q, k, v, p, o, nw, nb, qw, kw, vw, pw)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st, hn, q, k, v, p, o, nw, nb, qw, kw, vw, pw = ctx.saved_tensors
+        n, h, w, c = x.shape
+        s = h * w
+        dy = _c(dy)
+        dpw, dpb = ops.conv2d_nhwc_wgrad(dy, o.view(n, h, w, c), 1)
+        do = ops.conv2d_nhwc(dy, packed(pw, True), ks=1).view(n, s, c)
+        dp = ops.gemm_nt(do, v, out_f32=True)                                  # dP[q][key] = do[q].v[key]
+        ds = ops.softmax_rows_bwd(dp, p, ctx.scale)                            # bf16, includes the scale
+        dv = ops.gemm_tn(p, do)                                                # [n, key, c]
+        dq = ops.gemm_nt(ds, ops.transpose_last2(k))                           # [n, q, c]
+        dk = ops.gemm_tn(ds, q)                                                # [n, key, c]
+        dq4, dk4, dv4 = dq.view(n, h, w, c), dk.view(n, h, w, c), dv.view(n, h, w, c)
+        dqw, dqb = ops.conv2d_nhwc_wgrad(dq4, hn, 1)
+        dkw, dkb = ops.conv2d_nhwc_wgrad(dk4, hn, 1)
+        dvw, dvb = ops.conv2d_nhwc_wgrad(dv4, hn, 1)
+        dh = ops.conv2d_nhwc(dq4, packed(qw, True), ks=1)
+        dh = ops.conv2d_nhwc(dk4, packed(kw, True), residual=dh, ks=1)
+        dh = ops.conv2d_nhwc(dv4, packed(vw, True), residual=dh, ks=1)
+        dx, dnw, dnb = ops.groupnorm_bwd(dh, x, st, nw, nb, False, dres=dy)
+        return dx, dnw, dnb, dqw, dqb, dkw, dkb, dvw, dvb, dpw, dpb
+
+
+class ConvFn(torch.autograd.Function):
+    """Plain conv (3x3 pad 1 or 1x1), optionally on the nearest-x2 upsampled input (flux_ae.py:103-107)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, ks, upsample):
+        y = ops.conv2d_nhwc(x, packed(w), b, ks=ks, upsample=upsample)
+        ctx.save_for_backward(x, w)
+        ctx.ks, ctx.upsample = ks, upsample
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dw, db = ops.conv2d_nhwc_wgrad(dy, x, ctx.ks, upsample=ctx.upsample)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_nhwc(dy, packed(w, True), ks=ctx.ks)
+            if ctx.upsample:
+                dx = ops.sumpool2x2(dx)
+        return dx, dw, db, None, None
+
+
+class NormConvOutFn(torch.autograd.Function):
+    """conv_out(swish(norm_out(h))) -> NCHW f32 image (flux_ae.py:266-268).  Cout (3) is padded to 4 for the
+    forward store and to 32 for the bf16 gradient operand."""
+
+    @staticmethod
+    def forward(ctx, x, nw, nb, cw, cb):
+        cout = cw.shape[0]
+        st, a = _gn_swish(x, nw, nb)
+        cbp = torch.zeros(4, dtype=f32, device=x.device)
+        cbp[:cout] = cb
+        y4 = ops.conv2d_nhwc(a, packed(cw, False, rows_pad=4), cbp, ks=3, out_f32=True)
+        ctx.save_for_backward(x, st, a, nw, nb, cw)
+        return ops.nhwc_to_nchw_f32(y4, cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st, a, nw, nb, cw = ctx.saved_tensors
+        cout = cw.shape[0]
+        dyp = ops.nchw_to_nhwc_bf16(_c(dy.float()), c_pad=32)
+        dwp, dbp = ops.conv2d_nhwc_wgrad(dyp, a, 3)
+        da = ops.conv2d_nhwc(dyp, packed(cw, True, cols_pad=32), ks=3)
+        dx, dnw, dnb = ops.groupnorm_bwd(da, x, st, nw, nb, True)
+        return dx, dnw, dnb, dwp[:cout].contiguous(), dbp[:cout].contiguous()
+
+
+class MLPFn(torch.autograd.Function):
+    """Linear -> SiLU -> Linear on tokens (models/vae.py:56-65); x [M, Cin] bf16."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w2, b2):
+        h = ops.gemm_nt(x, packed(w0).view(w0.shape[0], w0.shape[1]), b0)
+        a = ops.silu(h)
+        y = ops.gemm_nt(a, packed(w2).view(w2.shape[0], w2.shape[1]), b2)
+        ctx.save_for_backward(x, h, a, w0, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, a, w0, w2 = ctx.saved_tensors
+        dy = _c(dy)
+        m = x.shape[0]
+        dw2, db2 = ops.conv2d_nhwc_wgrad(dy.view(1, 1, m, -1), a.view(1, 1, m, -1), 1)
+        da = ops.gemm_nt(dy, packed(w2, True).view(w2.shape[1], w2.shape[0]))
+        dh = ops.silu_bwd(h, da)
+        dw0, db0 = ops.conv2d_nhwc_wgrad(dh.view(1, 1, m, -1), x.view(1, 1, m, -1), 1)
+        dx = ops.gemm_nt(dh, packed(w0, True).view(w0.shape[1], w0.shape[0])) if ctx.needs_input_grad[0] else None
+        return dx, dw0.view(w0.shape), db0, dw2.view(w2.shape), db2
+
+
+def to_nhwc_bf16(x: torch.Tensor) -> torch.Tensor:
+    """NCHW (any float dtype) -> NHWC bf16 contiguous, differentiable (boundary plumbing)."""
+    return x.permute(0, 2, 3, 1).contiguous().to(bf16)
+
+
+def to_nchw(x: torch.Tensor, dtype=None) -> torch.Tensor:
+    y = x.permute(0, 3, 1, 2).contiguous()
+    return y if dtype is None else y.to(dtype)

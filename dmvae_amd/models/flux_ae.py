@@ -1,0 +1,229 @@
+"""Drop-in counterparts of the reference's models/flux_ae.py modules, computing on MI355X HIP kernels.
+
+Same class names, constructor arguments, ``forward`` signatures and ``state_dict`` keys as the
+reference (AttnBlock :25-52, ResnetBlock :55-82, Downsample :85-95, Upsample :98-107, Encoder
+:110-181, Decoder :184-278).  Parameters live in ordinary nn.Conv2d / nn.GroupNorm holders created in
+the reference's order (so a fixed seed gives the reference's initial weights and checkpoints load
+with strict=True), but ``forward`` never calls them: it dispatches to dmvae_amd.functional.
+
+Public ``forward`` takes/returns NCHW like the reference; ``forward_nhwc`` is the internal
+channels-last bf16 path the Decoder chains without layout round-trips.
+"""
+from dataclasses import dataclass
+
+import torch
+from torch import Tensor, nn
+
+from .. import functional as Fn
+
+
+@dataclass
+class AutoEncoderParams:
+    resolution: int
+    in_channels: int
+    ch: int
+    out_ch: int
+    ch_mult: list
+    num_res_blocks: int
+    z_channels: int
+    scale_factor: float
+    shift_factor: float
+
+
+def swish(x: Tensor) -> Tensor:
+    return x * torch.sigmoid(x)
+
+
+def _gn(c):
+    return nn.GroupNorm(num_groups=32, num_channels=c, eps=1e-6, affine=True)
+
+
+class _NCHWAdapter(nn.Module):
+    def forward(self, x: Tensor) -> Tensor:
+        return Fn.to_nchw(self.forward_nhwc(Fn.to_nhwc_bf16(x)), x.dtype if x.dtype != torch.float64 else torch.float32)
+
+
+class AttnBlock(_NCHWAdapter):
+    def __init__(self, in_channels: int):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = _gn(in_channels)
+        self.q = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+        self.k = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+        self.v = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+        self.proj_out = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+
+    def forward_nhwc(self, x: Tensor) -> Tensor:
+        return Fn.AttnBlockFn.apply(x, self.norm.weight, self.norm.bias, self.q.weight, self.q.bias, self.k.weight, self.k.bias,
+                                    self.v.weight, self.v.bias, self.proj_out.weight, self.proj_out.bias)
+
+
+class ResnetBlock(_NCHWAdapter):
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.in_channels = in_channels
+        out_channels = in_channels if out_channels is None else out_channels
+        self.out_channels = out_channels
+        self.norm1 = _gn(in_channels)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.norm2 = _gn(out_channels)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        if self.in_channels != self.out_channels:
+            self.nin_shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
+
+    def forward_nhwc(self, x: Tensor) -> Tensor:
+        sc = getattr(self, "nin_shortcut", None)
+        return Fn.ResnetBlockFn.apply(x, self.norm1.weight, self.norm1.bias, self.conv1.weight, self.conv1.bias, self.norm2.weight,
+                                      self.norm2.bias, self.conv2.weight, self.conv2.bias, None if sc is None else sc.weight,
+                                      None if sc is None else sc.bias)
+
+
+class Downsample(_NCHWAdapter):
+    """pad (0,1,0,1) + conv3x3 stride 2 (reference :85-95).  Only used by the reference's never-instantiated
+    Encoder; the stride-2 kernel is not built yet, so forward raises (no silent fallback)."""
+
+    def __init__(self, in_channels: int):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
+
+    def forward_nhwc(self, x: Tensor) -> Tensor:
+        raise NotImplementedError("stride-2 Downsample has no HIP kernel yet (reference Encoder is dead code; see DESIGN.md)")
+
+
+class Upsample(_NCHWAdapter):
+    def __init__(self, in_channels: int):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+
+    def forward_nhwc(self, x: Tensor) -> Tensor:
+        return Fn.ConvFn.apply(x, self.conv.weight, self.conv.bias, 3, True)
+
+
+class _Conv3x3(nn.Conv2d):
+    """nn.Conv2d parameter holder whose forward runs the HIP kernel on NHWC bf16 (used inside Sequential conv_in)."""
+
+    def forward_nhwc(self, x: Tensor) -> Tensor:
+        return Fn.ConvFn.apply(x, self.weight, self.bias, self.kernel_size[0], False)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return Fn.to_nchw(self.forward_nhwc(Fn.to_nhwc_bf16(x)), x.dtype)
+
+
+class Encoder(nn.Module):
+    def __init__(self, resolution: int, in_channels: int, ch: int, ch_mult: list, num_res_blocks: int, z_channels: int):
+        super().__init__()
+        self.ch = ch
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution = resolution
+        self.in_channels = in_channels
+        self.conv_in = _Conv3x3(in_channels, self.ch, kernel_size=3, stride=1, padding=1)
+        curr_res = resolution
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.in_ch_mult = in_ch_mult
+        self.down = nn.ModuleList()
+        block_in = self.ch
+        for i_level in range(self.num_resolutions):
+            block = nn.ModuleList()
+            attn = nn.ModuleList()
+            block_in = ch * in_ch_mult[i_level]
+            block_out = ch * ch_mult[i_level]
+            for _ in range(self.num_res_blocks):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out))
+                block_in = block_out
+            down = nn.Module()
+            down.block = block
+            down.attn = attn
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in)
+                curr_res = curr_res // 2
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.norm_out = _gn(block_in)
+        self.conv_out = _Conv3x3(block_in, z_channels * 2, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, x: Tensor) -> Tensor:
+        h = self.conv_in.forward_nhwc(Fn.to_nhwc_bf16(x))
+        for i_level in range(self.num_resolutions):
+            for i_block in range(self.num_res_blocks):
+                h = self.down[i_level].block[i_block].forward_nhwc(h)
+            if i_level != self.num_resolutions - 1:
+                h = self.down[i_level].downsample.forward_nhwc(h)
+        h = self.mid.block_1.forward_nhwc(h)
+        h = self.mid.attn_1.forward_nhwc(h)
+        h = self.mid.block_2.forward_nhwc(h)
+        raise NotImplementedError("Encoder tail (norm_out + conv_out to 2*z) is not wired: the reference never instantiates Encoder")
+
+
+class Decoder(nn.Module):
+    def __init__(self, ch: int, out_ch: int, ch_mult: list, num_res_blocks: int, in_channels: int, resolution: int, z_channels: int):
+        super().__init__()
+        self.ch = ch
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution = resolution
+        self.in_channels = in_channels
+        self.ffactor = 2 ** (self.num_resolutions - 1)
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        self.block_in = block_in
+        curr_res = resolution // 2 ** (self.num_resolutions - 1)
+        self.z_shape = (1, z_channels, curr_res, curr_res)
+        self.conv_in = _Conv3x3(z_channels, block_in, kernel_size=3, stride=1, padding=1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block = nn.ModuleList()
+            attn = nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(self.num_res_blocks + 1):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out))
+                block_in = block_out
+            up = nn.Module()
+            up.block = block
+            up.attn = attn
+            if i_level != 0:
+                up.upsample = Upsample(block_in)
+                curr_res = curr_res * 2
+            self.up.insert(0, up)
+        self.norm_out = _gn(block_in)
+        self.conv_out = nn.Conv2d(block_in, out_ch, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, z: Tensor, grad_ckpt=False) -> Tensor:
+        """z: [B, 256, C] tokens (the reference hard-codes the 16x16 grid, :244-245) or NCHW [B, C, h, w].
+        Returns the NCHW image; f32 (the reference returns bf16 under autocast and VAE.forward casts to float)."""
+        if z.ndim == 3:
+            b, t, c = z.shape
+            if t != 256:
+                raise ValueError("Decoder expects 256 tokens (16x16) like the reference (flux_ae.py:245)")
+            h = z.reshape(b, 16, 16, c).to(torch.bfloat16).contiguous()      # tokens are already channels-last
+        else:
+            h = Fn.to_nhwc_bf16(z)
+        if isinstance(self.conv_in, nn.Sequential):
+            for m in self.conv_in:
+                h = m.forward_nhwc(h)
+        else:
+            h = self.conv_in.forward_nhwc(h)
+        h = self.mid.block_1.forward_nhwc(h)
+        h = self.mid.attn_1.forward_nhwc(h)
+        h = self.mid.block_2.forward_nhwc(h)
+        for i_level in reversed(range(self.num_resolutions)):
+            for i_block in range(self.num_res_blocks + 1):
+                h = self.up[i_level].block[i_block].forward_nhwc(h)
+            if i_level != 0:
+                h = self.up[i_level].upsample.forward_nhwc(h)
+        return Fn.NormConvOutFn.apply(h, self.norm_out.weight, self.norm_out.bias, self.conv_out.weight, self.conv_out.bias)
+
+    def post_init(self, z_channels):
+        self.conv_in = nn.Sequential(
+            Upsample(z_channels),
+            _Conv3x3(z_channels, self.block_in, kernel_size=3, stride=1, padding=1),
+        )
+
+    def get_last_layer(self):
+        return self.conv_out.weight

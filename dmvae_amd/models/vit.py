@@ -1,0 +1,119 @@
+"""DINOv2 ViT encoder with timm's `vit_{base,large}_patch14_dinov2` parameter names, in stock PyTorch-ROCm.
+
+The reference builds this through the third-party `timm.create_model(..., pretrained=True)` (models/vae.py:47-50),
+which is not installed here and needs the network.  The block algebra follows the reference's vendored
+models/dinov2.py + models/dino_layers (LayerNorm eps 1e-6, MHA, LayerScale, GELU MLP); sub-module names match timm
+(blocks.N.{norm1,attn.qkv,attn.proj,ls1.gamma,norm2,mlp.fc1,mlp.fc2,ls2.gamma}) so reference `vae.pt` files load.
+This is a SURVEY.md section-8(f) "next" row: hipBLASLt GEMMs + explicit matmul/softmax attention (no Triton, no SDPA).
+Frozen / no-grad in the tokenizer stage (train_tokenizer.py:295-297).
+"""
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim, bias=True)
+
+    def forward(self, x):
+        b, n, c = x.shape
+        hd = c // self.num_heads
+        qkv = self.qkv(x).reshape(b, n, 3, self.num_heads, hd).permute(2, 0, 3, 1, 4)
+        att = torch.softmax((qkv[0] * hd ** -0.5) @ qkv[1].transpose(-2, -1), dim=-1)
+        return self.proj((att.to(qkv[2].dtype) @ qkv[2]).transpose(1, 2).reshape(b, n, c))
+
+
+class _LayerScale(nn.Module):
+    def __init__(self, dim, init_values=1e-5):
+        super().__init__()
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+    def forward(self, x):
+        return x * self.gamma
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, init_values=1e-5):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim, num_heads)
+        self.ls1 = _LayerScale(dim, init_values)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.ls2 = _LayerScale(dim, init_values)
+
+    def forward(self, x):
+        x = x + self.ls1(self.attn(self.norm1(x)))
+        return x + self.ls2(self.mlp(self.norm2(x)))
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class DinoV2ViT(nn.Module):
+    num_prefix_tokens = 1
+
+    def __init__(self, embed_dim=1024, depth=24, num_heads=16, patch_size=16, img_size=256, in_chans=3):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.patch_embed = _PatchEmbed(patch_size, in_chans, embed_dim)
+        n = (img_size // patch_size) ** 2
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n + 1, embed_dim))
+        self.blocks = nn.ModuleList([_Block(embed_dim, num_heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.normal_(self.cls_token, std=1e-6)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+
+    def forward_features(self, x):
+        x = self.patch_embed(x)
+        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1).to(x.dtype), x], dim=1) + self.pos_embed.to(x.dtype)
+        for blk in self.blocks:
+            x = blk(x)
+        return self.norm(x)
+
+
+_ARCH = {
+    "vit_base_patch14_dinov2.lvd142m": dict(embed_dim=768, depth=12, num_heads=12),
+    "vit_large_patch14_dinov2.lvd142m": dict(embed_dim=1024, depth=24, num_heads=16),
+}
+
+
+def create_model(name, pretrained=True, patch_size=16, img_size=256, **kw):
+    """Offline stand-in for timm.models.create_model (vae.py:48-50).  No network here, so `pretrained` weights cannot be
+    fetched: the model is randomly initialised; load a reference `vae.pt` (which contains encoder.model.*) for real weights."""
+    if name not in _ARCH:
+        raise ValueError(f"unknown encoder {name!r}; known: {sorted(_ARCH)}")
+    if pretrained:
+        warnings.warn("timm pretrained DINOv2 weights are not available offline; encoder is randomly initialised "
+                      "(load a vae.pt checkpoint for trained weights)", stacklevel=2)
+    cfg = dict(_ARCH[name])
+    cfg.update(kw)
+    return DinoV2ViT(patch_size=patch_size, img_size=img_size, **cfg)

@@ -1,0 +1,339 @@
+"""Thin tensor-level wrappers over the C ABI (include/dmvae_hip.h).
+
+Every function takes CUDA(HIP) tensors, validates dtype/contiguity, launches on the current stream
+and returns freshly allocated outputs.  No function here has a CPU path: CPU tensors raise.
+Activations are NHWC bf16 ``[N, H, W, C]``.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+bf16 = torch.bfloat16
+f32 = torch.float32
+
+ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.DmvaeHipError(f"{name}: expected a GPU tensor; dmvae_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+_WS = {}
+
+
+def workspace(nbytes: int, device, slot: str = "main") -> torch.Tensor:
+    """Persistent per-(device, stream, slot) scratch buffer, grown on demand (never shrinks)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream(), slot)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+# ---- conv / GEMM ------------------------------------------------------------------------------
+def pack_conv_weight(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad: int = 0) -> torch.Tensor:
+    """f32 [cout, cin, ks, ks] (or [out, in] for Linear) -> bf16 [rows, ks*ks, cols] kernel operand."""
+    w = _req(w, f32, "weight")
+    if w.dim() == 2:
+        cout, cin, ks = w.shape[0], w.shape[1], 1
+    else:
+        cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+    rows, cols = (cin, cout) if for_dgrad else (cout, cin)
+    rows_pad, cols_pad = max(rows_pad, rows), max(cols_pad, cols)
+    out = torch.empty(rows_pad, ks * ks, cols_pad, dtype=bf16, device=w.device)
+    check(_lib.lib().dmvae_pack_conv_weight(w.data_ptr(), out.data_ptr(), cout, cin, ks, rows_pad, cols_pad, int(for_dgrad), _stream()),
+          "pack_conv_weight")
+    return out
+
+
+def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None, ks: int = 3, upsample: bool = False, act: int = ACT_NONE,
+                out_f32: bool = False) -> torch.Tensor:
+    """y = act(conv(x, w) + bias + residual); x [N,H,W,Cin] bf16, w_packed [Cout, ks*ks, Cin] bf16."""
+    x = _req(x, bf16, "x")
+    w_packed = _req(w_packed, bf16, "w_packed")
+    n, h, w_, cin = x.shape
+    cout = w_packed.shape[0]
+    assert w_packed.shape[1] == ks * ks and w_packed.shape[2] == cin, (w_packed.shape, ks, cin)
+    ho, wo = (2 * h, 2 * w_) if upsample else (h, w_)
+    y = torch.empty(n, ho, wo, cout, dtype=f32 if out_f32 else bf16, device=x.device)
+    if bias is not None:
+        _req(bias, f32, "bias")
+    if residual is not None:
+        _req(residual, bf16, "residual")
+        assert residual.shape == y.shape
+    d = ConvDesc(n, h, w_, cin, cout, ks, int(upsample), act, int(out_f32))
+    check(_lib.lib().dmvae_conv2d_nhwc_fwd(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(), ctypes.byref(d),
+                                           _stream()), "conv2d_nhwc_fwd")
+    return y
+
+
+def conv2d_nhwc_wgrad(dy: torch.Tensor, a: torch.Tensor, ks: int, upsample: bool = False, need_bias: bool = True,
+                      dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None,
+                      accumulate: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """dW [Cout,Cin,ks,ks] f32 and db [Cout] f32 from dy [N,Ho,Wo,Cout] and the conv input a [N,H,W,Cin] (bf16)."""
+    dy = _req(dy, bf16, "dy")
+    a = _req(a, bf16, "a")
+    n, h, w_, cin = a.shape
+    cout = dy.shape[-1]
+    d = ConvDesc(n, h, w_, cin, cout, ks, int(upsample), 0, 0)
+    L = _lib.lib()
+    wsb = L.dmvae_conv2d_nhwc_wgrad_workspace(ctypes.byref(d))
+    ws = workspace(wsb, a.device)
+    dw = dw_out if dw_out is not None else torch.empty(cout, cin, ks, ks, dtype=f32, device=a.device)
+    db = (db_out if db_out is not None else torch.empty(cout, dtype=f32, device=a.device)) if need_bias else None
+    check(L.dmvae_conv2d_nhwc_wgrad(dy.data_ptr(), a.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel(), ctypes.byref(d),
+                                    int(accumulate), _stream()), "conv2d_nhwc_wgrad")
+    return dw, db
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+            act: int = ACT_NONE, out_f32: bool = False) -> torch.Tensor:
+    """C[..., m, n] = act(A[..., m, k] @ B[..., n, k]^T + bias + residual).  A/B bf16; a 2-D operand is shared by the batch."""
+    a = _req(a, bf16, "A")
+    b = _req(b, bf16, "B")
+    batch = a.shape[0] if a.dim() == 3 else (b.shape[0] if b.dim() == 3 else 1)
+    m, k = a.shape[-2:]
+    n = b.shape[-2]
+    assert b.shape[-1] == k
+    shape = (batch, m, n) if (a.dim() == 3 or b.dim() == 3) else (m, n)
+    c = torch.empty(shape, dtype=f32 if out_f32 else bf16, device=a.device)
+    if residual is not None:
+        _req(residual, bf16, "residual")
+    check(_lib.lib().dmvae_gemm_nt_batched(a.data_ptr(), b.data_ptr(), _ptr(bias), _ptr(residual), c.data_ptr(), m, n, k, batch,
+                                           m * k if a.dim() == 3 else 0, n * k if b.dim() == 3 else 0, m * n, act, int(out_f32), _stream()),
+          "gemm_nt_batched")
+    return c
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, out_f32: bool = False) -> torch.Tensor:
+    """C[b] = alpha * A[b]^T @ B[b] with A [batch, K, M], B [batch, K, N] bf16 (reduction over the slow dim)."""
+    a = _req(a, bf16, "A")
+    b = _req(b, bf16, "B")
+    assert a.dim() == 3 and b.dim() == 3 and a.shape[:2] == b.shape[:2]
+    batch, k, m = a.shape
+    n = b.shape[2]
+    L = _lib.lib()
+    wsb = L.dmvae_gemm_tn_batched_workspace(m, n, k, batch)
+    ws = workspace(wsb, a.device)
+    c = torch.empty(batch, m, n, dtype=f32 if out_f32 else bf16, device=a.device)
+    check(L.dmvae_gemm_tn_batched(a.data_ptr(), b.data_ptr(), c.data_ptr(), ws.data_ptr(), ws.numel(), m, n, k, batch, k * m, k * n, m * n,
+                                  float(alpha), int(out_f32), _stream()), "gemm_tn_batched")
+    return c
+
+
+def softmax_rows(s: torch.Tensor, scale: float) -> torch.Tensor:
+    s = _req(s, f32, "S")
+    p = torch.empty(s.shape, dtype=bf16, device=s.device)
+    check(_lib.lib().dmvae_softmax_rows_fwd(s.data_ptr(), p.data_ptr(), s.numel() // s.shape[-1], s.shape[-1], float(scale), _stream()), "softmax_rows_fwd")
+    return p
+
+
+def softmax_rows_bwd(dp: torch.Tensor, p: torch.Tensor, scale: float) -> torch.Tensor:
+    dp = _req(dp, f32, "dP")
+    p = _req(p, bf16, "P")
+    ds = torch.empty_like(p)
+    check(_lib.lib().dmvae_softmax_rows_bwd(dp.data_ptr(), p.data_ptr(), ds.data_ptr(), p.numel() // p.shape[-1], p.shape[-1], float(scale), _stream()),
+          "softmax_rows_bwd")
+    return ds
+
+
+def transpose_last2(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x, bf16, "x")
+    assert x.dim() == 3
+    out = torch.empty(x.shape[0], x.shape[2], x.shape[1], dtype=bf16, device=x.device)
+    check(_lib.lib().dmvae_transpose_bf16(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.shape[2], _stream()), "transpose_bf16")
+    return out
+
+
+# ---- GroupNorm ----------------------------------------------------------------------------------
+def groupnorm_stats(x: torch.Tensor, groups: int = 32, eps: float = 1e-6) -> torch.Tensor:
+    x = _req(x, bf16, "x")
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    L = _lib.lib()
+    wsb = L.dmvae_groupnorm_workspace(n, hw, c, groups)
+    if wsb == 0:
+        raise ValueError(f"groupnorm: unsupported shape {tuple(x.shape)} with {groups} groups")
+    ws = workspace(wsb, x.device)
+    stats = torch.empty(n, groups, 2, dtype=f32, device=x.device)
+    check(L.dmvae_groupnorm_stats(x.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws.numel(), n, hw, c, groups, float(eps), _stream()), "groupnorm_stats")
+    return stats
+
+
+def groupnorm_apply(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, swish: bool, groups: int = 32) -> torch.Tensor:
+    x = _req(x, bf16, "x")
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    y = torch.empty_like(x)
+    check(_lib.lib().dmvae_groupnorm_apply(x.data_ptr(), _req(stats, f32, "stats").data_ptr(), _req(gamma, f32, "gamma").data_ptr(),
+                                           _req(beta, f32, "beta").data_ptr(), y.data_ptr(), n, hw, c, groups, int(swish), _stream()), "groupnorm_apply")
+    return y
+
+
+def groupnorm_bwd(da: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, swish: bool,
+                  dres: Optional[torch.Tensor] = None, groups: int = 32, need_param_grads: bool = True):
+    da = _req(da, bf16, "da")
+    x = _req(x, bf16, "x")
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    L = _lib.lib()
+    wsb = L.dmvae_groupnorm_workspace(n, hw, c, groups)
+    ws = workspace(wsb, x.device)
+    dx = torch.empty_like(x)
+    dg = torch.empty(c, dtype=f32, device=x.device) if need_param_grads else None
+    db = torch.empty(c, dtype=f32, device=x.device) if need_param_grads else None
+    if dres is not None:
+        _req(dres, bf16, "dres")
+    check(L.dmvae_groupnorm_bwd(da.data_ptr(), x.data_ptr(), _ptr(dres), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dx.data_ptr(),
+                                _ptr(dg), _ptr(db), ws.data_ptr(), ws.numel(), n, hw, c, groups, int(swish), 0, _stream()), "groupnorm_bwd")
+    return dx, dg, db
+
+
+# ---- layout / elementwise ---------------------------------------------------------------------------
+def sumpool2x2(dy: torch.Tensor) -> torch.Tensor:
+    dy = _req(dy, bf16, "dy")
+    n, h2, w2, c = dy.shape
+    dx = torch.empty(n, h2 // 2, w2 // 2, c, dtype=bf16, device=dy.device)
+    check(_lib.lib().dmvae_sumpool2x2_nhwc(dy.data_ptr(), dx.data_ptr(), n, h2 // 2, w2 // 2, c, _stream()), "sumpool2x2_nhwc")
+    return dx
+
+
+def nchw_to_nhwc_bf16(x: torch.Tensor, c_pad: int = 0) -> torch.Tensor:
+    x = _req(x, f32, "x")
+    n, c, h, w = x.shape
+    c_pad = max(c_pad, c)
+    out = torch.empty(n, h, w, c_pad, dtype=bf16, device=x.device)
+    check(_lib.lib().dmvae_nchw_f32_to_nhwc_bf16(x.data_ptr(), out.data_ptr(), n, c, h * w, c_pad, _stream()), "nchw_f32_to_nhwc_bf16")
+    return out
+
+
+def nhwc_to_nchw_f32(x: torch.Tensor, c: int) -> torch.Tensor:
+    assert x.dtype in (bf16, f32) and x.is_cuda and x.is_contiguous()
+    n, h, w, c_pad = x.shape
+    out = torch.empty(n, c, h, w, dtype=f32, device=x.device)
+    check(_lib.lib().dmvae_nhwc_to_nchw_f32(x.data_ptr(), out.data_ptr(), n, c, h * w, c_pad, int(x.dtype == f32), _stream()), "nhwc_to_nchw_f32")
+    return out
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x, bf16, "x")
+    y = torch.empty_like(x)
+    check(_lib.lib().dmvae_silu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "silu_fwd")
+    return y
+
+
+def silu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    x = _req(x, bf16, "x")
+    dy = _req(dy, bf16, "dy")
+    dx = torch.empty_like(x)
+    check(_lib.lib().dmvae_silu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream()), "silu_bwd")
+    return dx
+
+
+# ---- losses ---------------------------------------------------------------------------------------
+def _loss_ws(device) -> torch.Tensor:
+    return workspace(_lib.lib().dmvae_loss_workspace(), device, slot="loss")
+
+
+def l1_mse(recon: torch.Tensor, images: torch.Tensor, w1: float = 1.0, w2: float = 0.0, need_grad: bool = True):
+    """-> (out2 = [L1, MSE] device tensor, grad wrt recon of w1*L1 + w2*MSE or None)."""
+    recon = _req(recon, f32, "recon")
+    images = _req(images, f32, "images")
+    assert recon.shape == images.shape
+    ws = _loss_ws(recon.device)
+    out = torch.empty(2, dtype=f32, device=recon.device)
+    grad = torch.empty_like(recon) if need_grad else None
+    check(_lib.lib().dmvae_l1_mse(recon.data_ptr(), images.data_ptr(), _ptr(grad), out.data_ptr(), ws.data_ptr(), ws.numel(), recon.numel(),
+                                  float(w1), float(w2), _stream()), "l1_mse")
+    return out, grad
+
+
+def lpips_diff(f0: torch.Tensor, f1: torch.Tensor, lin_w: torch.Tensor, out: torch.Tensor, gscale: float, need_grad: bool, accumulate: bool):
+    """One LPIPS level on NHWC bf16 features; accumulates the level value into out[0]; returns d/d f1 (bf16) or None."""
+    f0 = _req(f0, bf16, "f0")
+    f1 = _req(f1, bf16, "f1")
+    n, c = f0.shape[0], f0.shape[-1]
+    hw = f0.numel() // (n * c)
+    ws = _loss_ws(f0.device)
+    df1 = torch.empty_like(f1) if need_grad else None
+    check(_lib.lib().dmvae_lpips_diff(f0.data_ptr(), f1.data_ptr(), _req(lin_w, f32, "lin_w").data_ptr(), _ptr(df1), out.data_ptr(), ws.data_ptr(),
+                                      ws.numel(), n, hw, c, float(gscale), int(accumulate), _stream()), "lpips_diff")
+    return df1
+
+
+def dmd_pre(x1: torch.Tensor, x0: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    x1 = _req(x1, f32, "x1")
+    x0 = _req(x0, f32, "x0")
+    t = _req(t, f32, "t")
+    xt = torch.empty_like(x1)
+    b = x1.shape[0]
+    check(_lib.lib().dmvae_dmd_pre(x1.data_ptr(), x0.data_ptr(), t.data_ptr(), xt.data_ptr(), b, x1.numel() // b, _stream()), "dmd_pre")
+    return xt
+
+
+def dmd_post(x1, xt, t, v_teacher, v_student, v_teacher_u=None, v_student_u=None, cfg: float = 1.0, weight_factor: bool = True):
+    """-> (out2 = [loss, dmd_gradient_norm], dlatents = grad/numel)."""
+    for name, v in (("x1", x1), ("xt", xt), ("t", t), ("v_teacher", v_teacher), ("v_student", v_student)):
+        _req(v, f32, name)
+    b = x1.shape[0]
+    ws = _loss_ws(x1.device)
+    out = torch.empty(2, dtype=f32, device=x1.device)
+    dl = torch.empty_like(x1)
+    check(_lib.lib().dmvae_dmd_post(x1.data_ptr(), xt.data_ptr(), t.data_ptr(), v_teacher.data_ptr(), _ptr(v_teacher_u), v_student.data_ptr(),
+                                    _ptr(v_student_u), dl.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), b, x1.numel() // b, float(cfg),
+                                    int(weight_factor), _stream()), "dmd_post")
+    return out, dl
+
+
+def kl_mmd(z: torch.Tensor, y: torch.Tensor, w_kl: float = 1.0, w_mmd: float = 1.0, need_grad: bool = True):
+    """z [G,n,32], y [G,m,32] f32 -> (kl [33] (32 per-latent + mean), mmd [G], dz or None)."""
+    z = _req(z, f32, "z")
+    y = _req(y, f32, "y")
+    g, n, d = z.shape
+    m = y.shape[1]
+    ws = workspace((g * 64 + 64) * 4, z.device, slot="loss")
+    kl = torch.empty(d + 1, dtype=f32, device=z.device)
+    mmd = torch.empty(g, dtype=f32, device=z.device)
+    dz = torch.empty_like(z) if need_grad else None
+    check(_lib.lib().dmvae_kl_mmd(z.data_ptr(), y.data_ptr(), kl.data_ptr(), mmd.data_ptr(), _ptr(dz), ws.data_ptr(), ws.numel(), g, n, m, d,
+                                  float(w_kl), float(w_mmd), _stream()), "kl_mmd")
+    return kl, mmd, dz
+
+
+# ---- optimiser tail -----------------------------------------------------------------------------
+def grad_norm(flat_grads: torch.Tensor, max_norm: float, norm_out: Optional[torch.Tensor] = None, accumulate_prev: bool = False) -> torch.Tensor:
+    g = _req(flat_grads, f32, "grads")
+    ws = workspace(8192, g.device, slot="opt")
+    out = norm_out if norm_out is not None else torch.zeros(3, dtype=f32, device=g.device)
+    check(_lib.lib().dmvae_grad_norm(g.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), g.numel(), float(max_norm), int(accumulate_prev), _stream()),
+          "grad_norm")
+    return out
+
+
+def adamw_ema_step(p, g, m, v, ema, norm_out, lr, beta1, beta2, eps, wd, step, ema_decay):
+    for name, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _req(t, f32, name)
+    check(_lib.lib().dmvae_adamw_ema_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(ema), _ptr(norm_out), p.numel(), float(lr),
+                                          float(beta1), float(beta2), float(eps), float(wd), int(step), float(ema_decay), _stream()), "adamw_ema_step")

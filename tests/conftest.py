@@ -1,0 +1,47 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+class Golden(dict):
+    def t(self, k, dtype=torch.float32):
+        return torch.from_numpy(np.asarray(self[k])).to(dtype)
+
+    def sub(self, prefix):
+        return {k[len(prefix):]: torch.from_numpy(np.asarray(v)) for k, v in self.items() if k.startswith(prefix)}
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
+        return Golden({k: z[k] for k in z.files})
+
+
+@pytest.fixture
+def golden():
+    return load_golden
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
