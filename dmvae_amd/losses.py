@@ -1,0 +1,92 @@
+"""Loss assembly of the DMVAE train step on the HIP kernels: the build's counterpart of
+VAELossFunction.forward_generator (train_tokenizer.py:179-204, train_dmd.py:233-262) and
+compute_distribution_matching_loss (train_dmd.py:204-230; toy_example_2d/dmd.py:349-360), plus the build-defined
+KL / MMD statistics (no reference counterpart, weights default to 0)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+def latents_to_spatial(tokens: torch.Tensor) -> torch.Tensor:
+    """[B, h*w, C] -> [B, C, h, w] (train_dmd.py:408-416, p = 1): a pure permutation, bit-exact."""
+    b, t, c = tokens.shape
+    h = int(t ** 0.5)
+    assert h * h == t
+    return tokens.reshape(b, h, h, c).permute(0, 3, 1, 2).contiguous()
+
+
+class _L1MSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, recon, images, w1, w2):
+        out, grad = ops.l1_mse(recon.contiguous(), images.contiguous(), w1, w2, need_grad=True)
+        ctx.save_for_backward(grad)
+        ctx.w = (w1, w2)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        # grad was built for w1*L1 + w2*L2; the caller combines exactly that, so upstream grads are (w1*g, w2*g)
+        (grad,) = ctx.saved_tensors
+        w1, w2 = ctx.w
+        g = g1 / w1 if w1 != 0 else (g2 / w2 if w2 != 0 else torch.zeros_like(g1))
+        return grad * g, None, None, None
+
+
+def l1_mse(recon: torch.Tensor, images: torch.Tensor, w1: float = 1.0, w2: float = 0.0):
+    """(L1, L2) as in F.l1_loss / F.mse_loss; differentiable w.r.t. recon for the combination w1*L1 + w2*L2."""
+    return _L1MSE.apply(recon, images, float(w1), float(w2))
+
+
+class _DMDLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, latents, xt, t, vt, vs, vtu, vsu, cfg, weight_factor):
+        out, dl = ops.dmd_post(latents.contiguous(), xt, t, vt, vs, vtu, vsu, cfg=cfg, weight_factor=weight_factor)
+        ctx.save_for_backward(dl)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g, _):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None, None, None, None, None, None, None
+
+
+def dmd_make_xt(latents: torch.Tensor, x0: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """xt = t*x1 + (1-t)*x0 (ICPlan.plan, diffusion/transport/path.py:114-136)."""
+    return ops.dmd_pre(latents.detach().float().contiguous(), x0.float().contiguous(), t.float().contiguous())
+
+
+def dmd_loss(latents, xt, t, v_teacher, v_student, v_teacher_u=None, v_student_u=None, cfg: float = 1.0, weight_factor: bool = True):
+    """-> (loss, log tensor [dmd_loss, dmd_gradient_norm]); gradient reaches `latents` only (dL/dlatents = grad/numel)."""
+    f = lambda v: None if v is None else v.detach().float().contiguous()
+    loss, log = _DMDLoss.apply(latents.float(), f(xt), f(t), f(v_teacher), f(v_student), f(v_teacher_u), f(v_student_u), float(cfg),
+                               bool(weight_factor))
+    return loss, log
+
+
+class _KLMMD(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, y, w_kl, w_mmd):
+        kl, mmd, dz = ops.kl_mmd(z.contiguous(), y.contiguous(), w_kl, w_mmd, need_grad=True)
+        ctx.save_for_backward(dz)
+        ctx.mark_non_differentiable(kl, mmd)
+        return w_kl * kl[-1] + w_mmd * mmd.mean(), kl, mmd
+
+    @staticmethod
+    def backward(ctx, g, _a, _b):
+        (dz,) = ctx.saved_tensors
+        return dz * g, None, None, None
+
+
+def kl_mmd_loss(latent_tokens: torch.Tensor, prior: Optional[torch.Tensor] = None, w_kl: float = 1.0, w_mmd: float = 1.0,
+                generator: Optional[torch.Generator] = None):
+    """Build-defined distribution-matching statistics on latent tokens [B, T, 32] (per-rank statistics under DP):
+    returns (w_kl*mean_c KL_c + w_mmd*mean_g MMD^2_g, per-latent KL [33], per-image MMD^2 [B])."""
+    z = latent_tokens.float()
+    if prior is None:
+        prior = torch.randn(z.shape, device=z.device, dtype=torch.float32, generator=generator)
+    return _KLMMD.apply(z, prior.float(), float(w_kl), float(w_mmd))
