@@ -18,7 +18,6 @@ from . import ops
 from .ops import bf16, f32
 
 _EPOCH = [0]   # bumped by optimisers that update weights through raw pointers
-_PACK_CACHE = {}
 
 
 def bump_weight_epoch() -> None:
@@ -26,14 +25,22 @@ def bump_weight_epoch() -> None:
 
 
 def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad: int = 0) -> torch.Tensor:
-    """bf16 kernel operand of an f32 conv/linear weight, cached until the weight changes."""
-    key = (w.data_ptr(), tuple(w.shape), for_dgrad, rows_pad, cols_pad)
-    ver = (w._version, _EPOCH[0])
-    hit = _PACK_CACHE.get(key)
+    """bf16 kernel operand of an f32 conv/linear weight, cached ON the parameter object until the weight changes
+    (in-place updates bump ``_version``; raw-pointer optimisers call bump_weight_epoch)."""
+    cache = getattr(w, "_dmvae_packed", None)
+    if cache is None:
+        cache = {}
+        try:
+            w._dmvae_packed = cache
+        except AttributeError:      # non-leaf views etc.: no caching
+            pass
+    key = (for_dgrad, rows_pad, cols_pad)
+    ver = (w.data_ptr(), w._version, _EPOCH[0])
+    hit = cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
     p = ops.pack_conv_weight(w.detach().contiguous(), for_dgrad, rows_pad, cols_pad)
-    _PACK_CACHE[key] = (ver, p)
+    cache[key] = (ver, p)
     return p
 
 

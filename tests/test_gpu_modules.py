@@ -1,0 +1,166 @@
+"""Module-level parity (-m gpu): the drop-in nn.Modules (dmvae_amd.models) vs (a) the golden vectors captured from the
+reference's own modules and (b) the CPU oracle evaluated with bf16 rounding at the HIP path's storage points.
+
+Tolerances (relative to the tensor's max-abs):
+  * vs oracle-with-bf16-sites: 1e-2 -- both sides round activations to bf16 at the same sites, so differences are
+    f32 accumulation order plus rare 1-ulp bf16 flips (2^-8) that propagate;
+  * vs the reference's pure-f32 goldens: 3e-2 -- bf16 autocast-level agreement (the reference itself trains under
+    autocast(bf16), train_tokenizer.py:410).
+The 1e-4 f32 bar is enforced per kernel on identical inputs in test_gpu_kernels.py."""
+import warnings
+
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import ref_cpu as R
+from oracle.detweights import det_tensor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+Q = R.bf16_round
+TOL_Q, TOL_REF = 1e-2, 3e-2
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _load(mod, params):
+    sd = mod.state_dict()
+    for k in sd:
+        if k in params:
+            sd[k] = params[k].to(sd[k].dtype)
+    mod.load_state_dict(sd, strict=True)
+    return mod.to(DEV)
+
+
+def _run_block(mod, g, oracle_fn):
+    p = g.sub("p.")
+    _load(mod, p)
+    x = g.t("x").to(DEV).requires_grad_(True)
+    y = mod(x)
+    y.backward(g.t("dy").to(DEV))
+    # oracle with bf16 storage sites
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xo = g.t("x").requires_grad_(True)
+    yo = oracle_fn(Q(xo), po, "", Q)
+    yo.backward(Q(g.t("dy")))
+    assert rel_err(y.float().cpu(), yo.detach()) < TOL_Q
+    assert rel_err(y.float().cpu(), g.t("y")) < TOL_REF
+    assert rel_err(x.grad.cpu(), xo.grad) < TOL_Q
+    assert rel_err(x.grad.cpu(), g.t("dx")) < TOL_REF
+    for n, prm in mod.named_parameters():
+        ref, orc = g.t("g." + n), po[n].grad
+        if ref.abs().max() < 1e-4:      # exactly-zero gradients (see test_oracle_golden): noise on both sides
+            assert prm.grad.abs().max() < 1e-2
+            continue
+        assert rel_err(prm.grad.cpu(), orc) < TOL_Q, n
+        assert rel_err(prm.grad.cpu(), ref) < TOL_REF, n
+
+
+@pytest.mark.parametrize("name,cin,cout", [("resblock_same", 64, 64), ("resblock_short", 128, 64)])
+def test_resnet_block(name, cin, cout):
+    from dmvae_amd.models.flux_ae import ResnetBlock
+    _run_block(ResnetBlock(cin, cout), load_golden(name), R.resnet_block)
+
+
+def test_attn_block():
+    from dmvae_amd.models.flux_ae import AttnBlock
+    _run_block(AttnBlock(64), load_golden("attnblock"), R.attn_block)
+
+
+def test_upsample():
+    from dmvae_amd.models.flux_ae import Upsample
+    _run_block(Upsample(32), load_golden("upsample"), R.upsample)
+
+
+def test_mlp():
+    from dmvae_amd.models.vae import MLP
+    g = load_golden("mlp")
+    mod = _load(MLP(64, 32, hidden_dim=128), g.sub("p."))
+    x = g.t("x").to(DEV).requires_grad_(True)
+    y = mod(x)
+    y.backward(g.t("dy").to(DEV))
+    assert rel_err(y.float().cpu(), g.t("y")) < TOL_REF
+    assert rel_err(x.grad.cpu(), g.t("dx")) < TOL_REF
+    for n, prm in mod.named_parameters():
+        assert rel_err(prm.grad.cpu(), g.t("g." + n)) < TOL_REF, n
+
+
+def _decoder(ch, seed):
+    from dmvae_amd.models.flux_ae import Decoder
+    dec = Decoder(ch=ch, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_channels=3, resolution=256, z_channels=16)
+    dec.post_init(z_channels=32)
+    params = {k: det_tensor(k, v.shape, seed) for k, v in dec.state_dict().items()}
+    return _load(dec, params), params
+
+
+def test_decoder_small_fwd_bwd():
+    g = load_golden("decoder_small")
+    dec, params = _decoder(32, 12)
+    z = g.t("z").to(DEV).requires_grad_(True)
+    y = dec(z)
+    assert y.dtype == torch.float32 and y.shape == (2, 3, 64, 64)
+    y.backward(g.t("dy").to(DEV))
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    zo = g.t("z").requires_grad_(True)
+    yo = R.decoder_forward(zo, po, q=Q)
+    yo.backward(g.t("dy"))
+    # 40 convs / 30 GroupNorms deep: a single 1-ulp bf16 flip early on perturbs thousands of downstream sums and
+    # re-rolls their rounding, so two correct bf16 pipelines decorrelate to the bf16 noise floor (measured stage by
+    # stage with tools/probes/t_dec.py; single blocks match the bf16-site oracle bit-for-bit, see _run_block).
+    # Criterion: the HIP path must be as close to the reference's f32 result as the bf16-site oracle is.
+    def floor(hip, orc, ref, what, slack=1.5, abs_floor=1e-3):
+        e_hip, e_orc = rel_l2(hip, ref), rel_l2(orc, ref)
+        print(f"decoder_small {what}: rel-L2 to f32 reference -- HIP {e_hip:.2e}, bf16-site oracle {e_orc:.2e}")
+        assert e_hip < slack * e_orc + abs_floor, what
+    floor(y.cpu(), yo.detach(), g.t("y"), "y")
+    floor(z.grad.cpu(), zo.grad, g.t("dz"), "dz")
+    for n, prm in dec.named_parameters():
+        if "g." + n in g and g["gn." + n][0] > 1e-3:
+            floor(prm.grad.cpu(), po[n].grad, g.t("g." + n), "grad " + n)
+        gn = g["gn." + n][0]
+        if gn > 1e-3:   # every parameter: gradient norm within 5% of the reference's
+            assert abs(prm.grad.double().norm().item() - gn) < 5e-2 * gn, n
+
+
+def test_decoder_full_b1_tokens():
+    g = load_golden("decoder_full_b1")
+    dec, _ = _decoder(128, 22)
+    with torch.no_grad():
+        y = dec(g.t("z").to(DEV))
+    assert y.shape == (1, 3, 256, 256)
+    assert rel_err(y[0, :, ::8, ::8].cpu(), g.t("y_slice")) < TOL_REF
+    assert abs(y.double().abs().sum().item() - g["y_sum"][1]) < 2e-2 * g["y_sum"][1]
+
+
+def test_vae_forward_tiny_and_api():
+    from test_oracle_golden import vae_tiny_params
+    g = load_golden("vae_forward_tiny")
+    p, vae = vae_tiny_params()
+    vae.load_state_dict(p, strict=True)
+    vae = vae.to(DEV)
+    x = (torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(32)) * 2 - 1).to(DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        rec, lat = vae(x, return_latent=True)
+    assert rec.dtype == torch.float32 and lat.shape == (1, 256, 32)
+    assert rel_err(lat.float().cpu(), g.t("latent")) < TOL_REF
+    assert rel_err(rec[0, :, ::8, ::8].cpu(), g.t("rec_slice")) < TOL_REF
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert torch.equal(vae.encode(x), lat)
+        assert torch.equal(vae.decode(lat).float(), rec)
+    # get_last_layer must be a leaf usable with autograd.grad(retain_graph=True) (train_tokenizer.py:194-196)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        rec = vae(x)
+    last = vae.decoder.get_last_layer()
+    g1 = torch.autograd.grad(rec.abs().mean(), last, retain_graph=True)[0]
+    g2 = torch.autograd.grad((rec ** 2).mean(), last, retain_graph=True)[0]
+    assert g1.shape == last.shape and g2.shape == last.shape and g1.norm() > 0 and g2.norm() > 0
+
+
+def test_cpu_tensor_fails_loudly():
+    from dmvae_amd import _lib, ops
+    with pytest.raises(_lib.DmvaeHipError):
+        ops.groupnorm_stats(torch.zeros(1, 4, 4, 32, dtype=torch.bfloat16))
