@@ -1,0 +1,141 @@
+"""torch.distributed plumbing for the data-parallel DMVAE step: one process per GPU, RCCL over xGMI
+(backend string "nccl" IS RCCL on PyTorch-ROCm), gloo on CPU for tests.
+
+Mirrors the parts of the reference's utils/dist.py the hot path touches (init_distributed_mode :228-239,
+allreduce/barrier :106-170 degrade to no-ops when uninitialised) and replaces DistributedDataParallel
+(train_tokenizer.py:302) by `FlatGradSync`: all trainable parameters' gradients live in ONE flat f32 buffer laid
+out in backward-completion order; contiguous buckets are all-reduced asynchronously on RCCL's stream as soon as
+their last gradient has been accumulated, overlapping the rest of backward.  A few large collectives instead of
+DDP's 25 MB default: xGMI is point-to-point, per-link bound, so fewer/larger messages amortise launch + sync.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as tdist
+
+__all__ = ["init_distributed_mode", "initialized", "get_rank", "get_world_size", "get_local_rank", "barrier", "allreduce",
+           "is_master", "FlatGradSync"]
+
+_initialized = False
+_rank, _world, _local_rank = 0, 1, 0
+
+
+def init_distributed_mode(backend: Optional[str] = None, timeout_minutes: int = 30) -> None:
+    """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the env (torchrun).  No env -> single process, collectives are no-ops."""
+    global _initialized, _rank, _world, _local_rank
+    if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        if torch.cuda.is_available():
+            torch.cuda.set_device(0)
+        return
+    _rank, _world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    _local_rank = int(os.environ.get("LOCAL_RANK", _rank))
+    use_gpu = torch.cuda.is_available()
+    if use_gpu:
+        torch.cuda.set_device(_local_rank % torch.cuda.device_count())
+    if backend is None:
+        backend = "nccl" if use_gpu else "gloo"
+    if not tdist.is_initialized():
+        kw = {}
+        if use_gpu and backend == "nccl":
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        tdist.init_process_group(backend=backend, timeout=datetime.timedelta(minutes=timeout_minutes), **kw)
+    _initialized = True
+
+
+def initialized() -> bool:
+    return _initialized
+
+
+def get_rank() -> int:
+    return _rank
+
+
+def get_world_size() -> int:
+    return _world
+
+
+def get_local_rank() -> int:
+    return _local_rank
+
+
+def is_master() -> bool:
+    return _rank == 0
+
+
+def barrier() -> None:
+    if _initialized:
+        tdist.barrier()
+
+
+def allreduce(t: torch.Tensor, async_op: bool = False, op=None):
+    if _initialized:
+        return tdist.all_reduce(t, op=op or tdist.ReduceOp.SUM, async_op=async_op)
+    return None
+
+
+class FlatGradSync:
+    """Bucketed asynchronous gradient averaging over a flat gradient buffer.
+
+    params   : trainable parameters in the order their gradients become ready in backward (first-ready first);
+               their .grad are views into `flat_grad` in that same order.
+    The hook on each parameter fires after its gradient has been accumulated; when every parameter of a bucket
+    has fired, the bucket's slice is divided by world_size and all-reduced (SUM) with async_op=True.
+    `wait()` must be called before the optimiser reads the gradients.
+    """
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], flat_grad: torch.Tensor, offsets: Sequence[int],
+                 bucket_bytes: int = 64 << 20):
+        self.flat_grad = flat_grad
+        self.world = get_world_size()
+        self.enabled = initialized() and self.world > 1
+        self.buckets: List[List[int]] = []      # [start, end, n_params]
+        self.param_bucket: List[int] = []
+        cur_start, cur_n = 0, 0
+        for i, p in enumerate(params):
+            self.param_bucket.append(len(self.buckets))
+            cur_n += 1
+            end = offsets[i] + p.numel()
+            if (end - cur_start) * 4 >= bucket_bytes or i == len(params) - 1:
+                self.buckets.append([cur_start, end, cur_n])
+                cur_start, cur_n = end, 0
+        self._pending = [b[2] for b in self.buckets]
+        self._works = []
+        self._handles = []
+        if self.enabled:
+            for i, p in enumerate(params):
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def _make_hook(self, i):
+        def hook(_p):
+            b = self.param_bucket[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        sl = self.flat_grad[s:e]
+        sl.div_(self.world)
+        self._works.append(tdist.all_reduce(sl, op=tdist.ReduceOp.SUM, async_op=True))
+
+    def wait(self) -> None:
+        """Block the current stream until every bucket's all-reduce has completed; re-arm for the next backward."""
+        if not self.enabled:
+            return
+        for b, left in enumerate(self._pending):      # parameters that received no gradient this step
+            if left > 0:
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        self._works.clear()
+        self._pending = [b[2] for b in self.buckets]
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles.clear()

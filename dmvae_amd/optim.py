@@ -1,0 +1,67 @@
+"""Flat-buffer optimiser tail: clip_grad_norm_(1.0) + AdamW(betas=(.9,.95), eps=1e-8, wd=.005) + EMA + LambdaLR warm-up
+(train_tokenizer.py:140-150,382-392,415-419,437) as two HIP launches over one contiguous f32 parameter buffer.
+
+`FlatParams.flatten` re-homes the given parameters (and their .grad) as views into flat buffers, in the order given
+(use backward-completion order so FlatGradSync's buckets fill front to back).  state_dict()/load_state_dict() of the
+owning module keep working: the views are ordinary nn.Parameters."""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+
+from . import functional as Fn
+from . import ops
+
+
+class FlatParams:
+    def __init__(self, params: Sequence[torch.nn.Parameter], with_ema: bool = True):
+        self.params: List[torch.nn.Parameter] = list(params)
+        assert all(p.dtype == torch.float32 for p in self.params)
+        dev = self.params[0].device
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4          # keep every tensor 16-B aligned
+        self.numel = n
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, off in zip(self.params, self.offsets):
+            self.flat[off:off + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + p.numel()].view(p.shape)
+            p.grad = self.grad[off:off + p.numel()].view(p.shape)
+        self.ema = self.flat.clone() if with_ema else None
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def ema_state(self):
+        """name-less list of EMA tensors aligned with self.params (views)."""
+        return [self.ema[off:off + p.numel()].view(p.shape) for p, off in zip(self.params, self.offsets)]
+
+
+class FlatAdamWEMA:
+    def __init__(self, fp: FlatParams, lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.005, max_norm=1.0, ema_decay=0.9999,
+                 warmup_steps=1000):
+        self.fp = fp
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.max_norm, self.ema_decay, self.warmup_steps = max_norm, ema_decay, warmup_steps
+        self.exp_avg = torch.zeros_like(fp.flat)
+        self.exp_avg_sq = torch.zeros_like(fp.flat)
+        self.norm = torch.zeros(3, dtype=torch.float32, device=fp.flat.device)   # [norm, clip coef, sumsq] stays on device
+        self.t = 0
+
+    def current_lr(self) -> float:
+        """LambdaLR(lambda s: min(1, (s+1)/warmup)) evaluated at the scheduler step count (train_tokenizer.py:385-392)."""
+        if self.warmup_steps <= 0:
+            return self.lr
+        return self.lr * min(1.0, (self.t + 1) / self.warmup_steps)
+
+    def step(self):
+        lr = self.current_lr()
+        self.t += 1
+        ops.grad_norm(self.fp.grad, self.max_norm, norm_out=self.norm)
+        ops.adamw_ema_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.fp.ema, self.norm if self.max_norm > 0 else None,
+                           lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, self.ema_decay)
+        Fn.bump_weight_epoch()      # weights changed through raw pointers: invalidate the packed bf16 operands
+        return self.norm            # device tensor; no host sync

@@ -1,0 +1,116 @@
+"""Step harness: the build's counterpart of the reference's tokenizer / DMD train-step bodies
+(train_tokenizer.py:403-437 and train_dmd.py:506-575, loss assembly :179-204 / :204-262).
+
+`TokenizerTrainer.step(images)` = VAE forward (frozen ViT encoder under bf16 autocast, bottleneck MLP and decoder on the
+HIP kernels) -> L1 (+L2) + LPIPS (+ build-defined KL/MMD, weight 0 by default) -> backward -> [bucketed RCCL
+all-reduce overlapped with backward] -> clip + AdamW + EMA (two launches on flat buffers).  The discriminator branch
+(step >= disc_start_step = 5000) is a SURVEY.md 8(f) "next" row and is not part of this step.  No per-step host sync:
+the log scalars stay in one device tensor; call `read_log()` when you want them.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Dict, Optional
+
+import torch
+
+from . import dist, losses
+from .models.vae import VAE
+from .optim import FlatAdamWEMA, FlatParams
+from .utils.lpips import LPIPS
+
+
+def backward_order_params(vae: VAE):
+    """Trainable parameters (decoder + bottleneck) in the order their gradients complete in backward."""
+    dec = vae.decoder
+    order = [dec.conv_out, dec.norm_out]
+    for lvl in range(dec.num_resolutions):                 # up[0] is the highest resolution: last in forward, first in backward
+        if hasattr(dec.up[lvl], "upsample"):
+            order.append(dec.up[lvl].upsample)
+        order += list(reversed(list(dec.up[lvl].block)))
+    order += [dec.mid.block_2, dec.mid.attn_1, dec.mid.block_1, dec.conv_in, vae.bottle_neck]
+    params, seen = [], set()
+    for m in order:
+        for p in m.parameters():
+            if id(p) not in seen and p.requires_grad:
+                seen.add(id(p))
+                params.append(p)
+    return params
+
+
+class TokenizerTrainer:
+    def __init__(self, vae: VAE, lpips: Optional[LPIPS], lr: float = 1e-4, l1: float = 1.0, l2: float = 0.0, lpips_w: float = 1.0,
+                 kl_w: float = 0.0, mmd_w: float = 0.0, warmup_steps: int = 1000, ema_decay: float = 0.9999, max_norm: float = 1.0,
+                 bucket_bytes: int = 64 << 20):
+        self.vae, self.lpips = vae, lpips
+        self.w = dict(l1=l1, l2=l2, lpips=lpips_w, kl=kl_w, mmd=mmd_w)
+        vae.encoder.eval()
+        for p in vae.encoder.parameters():                 # train_tokenizer.py:295-297
+            p.requires_grad_(False)
+        params = backward_order_params(vae)
+        n_train = sum(p.numel() for p in vae.parameters() if p.requires_grad)
+        assert n_train == sum(p.numel() for p in params), "parameter ordering lost a trainable parameter"
+        self.fp = FlatParams(params, with_ema=True)
+        self.opt = FlatAdamWEMA(self.fp, lr=lr, warmup_steps=warmup_steps, ema_decay=ema_decay, max_norm=max_norm)
+        self.sync = dist.FlatGradSync(params, self.fp.grad, self.fp.offsets, bucket_bytes=bucket_bytes)
+        self.log = torch.zeros(8, dtype=torch.float32, device=self.fp.flat.device)
+        self.global_step = 0
+
+    def step(self, images: torch.Tensor) -> torch.Tensor:
+        vae, w = self.vae, self.w
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.no_grad():
+                tokens = vae.encoder(images)
+            latent = vae.bottle_neck(tokens)
+            recon = vae.decoder(latent).float()
+            l1, l2 = losses.l1_mse(recon, images, w["l1"], w["l2"])
+            loss = l1 * w["l1"] + l2 * w["l2"]
+            lp = None
+            if self.lpips is not None and w["lpips"] != 0:
+                lp = self.lpips(images, recon)
+                loss = loss + lp * w["lpips"]
+            kl = None
+            if w["kl"] != 0 or w["mmd"] != 0:
+                dm, kl, mmd = losses.kl_mmd_loss(latent, w_kl=w["kl"], w_mmd=w["mmd"])
+                loss = loss + dm
+        loss.backward()
+        self.sync.wait()
+        norm = self.opt.step()
+        self.fp.zero_grad()
+        with torch.no_grad():
+            self.log[0], self.log[1], self.log[3] = l1.detach(), l2.detach(), loss.detach()
+            if lp is not None:
+                self.log[2] = lp.detach()
+            self.log[4] = norm[0]
+            if kl is not None:
+                self.log[5], self.log[6] = kl[-1], mmd.mean()
+        self.global_step += 1
+        return loss.detach()
+
+    def read_log(self) -> Dict[str, float]:
+        v = self.log.tolist()       # the single D2H sync
+        return {"L1": v[0], "L2": v[1], "LPIPS": v[2], "rec_loss": v[3], "vae_norm": v[4], "KL": v[5], "MMD": v[6]}
+
+    def checkpoint(self) -> dict:
+        """vae.pt layout of the reference (train_tokenizer.py:440-450): vae_wo_ddp + vae_ema state_dicts."""
+        sd = {k: v.detach().clone() for k, v in self.vae.state_dict().items()}
+        ema = dict(sd)
+        names = {id(p): n for n, p in self.vae.named_parameters()}
+        for p, e in zip(self.fp.params, self.fp.ema_state()):
+            ema[names[id(p)]] = e.detach().clone()
+        return {"vae_wo_ddp": sd, "vae_ema": ema, "steps": self.global_step}
+
+
+def build_tokenizer_trainer(device="cuda", z_channels=32, model_size="large", seed=42, lpips_ckpt=None, **kw) -> TokenizerTrainer:
+    """Random-init model in the reference's constructor order under torch.manual_seed(seed)."""
+    torch.manual_seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae = VAE(z_channels=z_channels, model_size=model_size).to(device)
+    lp = LPIPS(ckpt_path=lpips_ckpt).eval().requires_grad_(False).to(device)
+    lp = lp.to(memory_format=torch.channels_last)
+    if lpips_ckpt is None:          # no trunk / lin weights offline: deterministic positive lin weights
+        with torch.no_grad():
+            for lin in (lp.lin0, lp.lin1, lp.lin2, lp.lin3, lp.lin4):
+                lin.model[-1].weight.fill_(1.0 / lin.model[-1].weight.shape[1])
+    return TokenizerTrainer(vae, lp, **kw)
