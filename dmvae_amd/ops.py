@@ -40,6 +40,10 @@ def _ptr(t: Optional[torch.Tensor]):
 
 _WS = {}
 
+# bench.py sets this to a list to time the dominant kernel with HIP events on the launch stream:
+# entries are (name, start_event, end_event, algorithmic_flops)
+KERNEL_TIMING = None
+
 
 def workspace(nbytes: int, device, slot: str = "main") -> torch.Tensor:
     """Persistent per-(device, stream, slot) scratch buffer, grown on demand (never shrinks)."""
@@ -84,8 +88,16 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
         _req(residual, bf16, "residual")
         assert residual.shape == y.shape
     d = ConvDesc(n, h, w_, cin, cout, ks, int(upsample), act, int(out_f32))
+    timing = KERNEL_TIMING
+    if timing is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_lib.lib().dmvae_conv2d_nhwc_fwd(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(), ctypes.byref(d),
                                            _stream()), "conv2d_nhwc_fwd")
+    if timing is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        timing.append(("conv_fwd_kernel", e0, e1, 2.0 * n * ho * wo * cout * cin * ks * ks))
     return y
 
 
