@@ -1,0 +1,112 @@
+"""CPU: host-side mirror of the reference interface -- constructor/RNG parity, state_dict layout, checkpoint layout,
+flat-buffer optimiser plumbing, loud failure without a GPU."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def _ck_equal(mod, g):
+    for k, v in mod.state_dict().items():
+        ck = g["ck." + k]
+        assert abs(v.double().sum().item() - ck[0]) < 1e-9 and abs(v.double().abs().sum().item() - ck[1]) < 1e-9, k
+
+
+def test_fixed_seed_init_reproduces_reference_decoder():
+    """torch.manual_seed + the reference's constructor / post_init / init_weights order (models/vae.py:81-88) gives the
+    reference's initial weights bit-for-bit (checksums captured from the reference modules)."""
+    from dmvae_amd.models import flux_ae
+    from dmvae_amd.models.init_param import init_weights
+    g = load_golden("decoder_small")
+    torch.manual_seed(11)
+    dec = flux_ae.Decoder(ch=32, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_channels=3, resolution=64, z_channels=16)
+    dec.post_init(z_channels=32)
+    init_weights(dec, 0.02)
+    _ck_equal(dec, g)
+    g = load_golden("decoder_full_b1")
+    torch.manual_seed(21)
+    dec = flux_ae.Decoder(ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_channels=3, resolution=256, z_channels=16)
+    dec.post_init(z_channels=32)
+    init_weights(dec.conv_in, 0.02)
+    init_weights(dec, 0.02)
+    _ck_equal(dec, g)
+    assert list(dec.state_dict().keys()) == list(g["keys"])
+    assert sum(p.numel() for p in dec.parameters()) == int(g["n_params"]) == 49628451
+
+
+def _tiny_vae():
+    from dmvae_amd.models.vae import VAE
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=64, depth=1, num_heads=4))
+
+
+def test_vae_checkpoint_layout_roundtrip(tmp_path):
+    """vae.pt = {'vae_wo_ddp': sd, 'vae_ema': sd} (train_tokenizer.py:440-450); load_pretrained picks by `ema` (vae.py:110-121)."""
+    a, b = _tiny_vae(), _tiny_vae()
+    sd = a.state_dict()
+    ema = {k: v + 1 for k, v in sd.items()}
+    path = tmp_path / "vae.pt"
+    torch.save({"vae_wo_ddp": sd, "vae_ema": ema, "steps": 3}, path)
+    b.load_pretrained(str(path), ema=False)
+    assert all(torch.equal(b.state_dict()[k], sd[k]) for k in sd)
+    b.load_pretrained(str(path), ema=True)
+    assert all(torch.equal(b.state_dict()[k], ema[k]) for k in sd)
+    b.load_pretrained(str(tmp_path / "missing.pt"))          # reference behaviour: warn and return silently
+    import copy
+    c = copy.deepcopy(a)                                       # EMA copies (train_tokenizer.py:397)
+    assert all(torch.equal(c.state_dict()[k], sd[k]) for k in sd)
+    assert a.decoder.get_last_layer() is a.decoder.conv_out.weight and a.bottle_neck.get_last_layer() is a.bottle_neck.mlp[-1].weight
+
+
+def test_flat_params_and_backward_order():
+    from dmvae_amd.optim import FlatParams
+    from dmvae_amd.train import backward_order_params
+    vae = _tiny_vae()
+    for p in vae.encoder.parameters():
+        p.requires_grad_(False)
+    before = {k: v.clone() for k, v in vae.state_dict().items()}
+    params = backward_order_params(vae)
+    assert sum(p.numel() for p in params) == sum(p.numel() for p in vae.parameters() if p.requires_grad)
+    assert params[0] is vae.decoder.conv_out.weight and params[-1] is vae.bottle_neck.mlp[2].bias
+    fp = FlatParams(params)
+    assert all(torch.equal(vae.state_dict()[k], before[k]) for k in before)       # values preserved
+    fp.flat.mul_(2.0)                                                              # params are views of the flat buffer
+    assert torch.equal(vae.decoder.conv_out.weight, before["decoder.conv_out.weight"] * 2)
+    vae.decoder.conv_out.weight.grad.add_(1.0)
+    assert fp.grad[: vae.decoder.conv_out.weight.numel()].eq(1).all()
+    vae.load_state_dict(before)                                                    # load_state_dict copies into the views
+    assert torch.equal(fp.flat[: params[0].numel()].view(params[0].shape), before["decoder.conv_out.weight"])
+    assert all(o % 4 == 0 for o in fp.offsets)
+
+
+def test_lambda_lr_warmup_matches_reference_schedule():
+    from dmvae_amd.optim import FlatAdamWEMA, FlatParams
+    p = torch.nn.Parameter(torch.zeros(8))
+    opt = FlatAdamWEMA(FlatParams([p]), lr=1e-4, warmup_steps=1000)
+    sched = torch.optim.lr_scheduler.LambdaLR(torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-4), lambda s: min(1.0, (s + 1) / 1000))
+    for t in (0, 1, 10, 998, 999, 1000, 5000):
+        opt.t = t
+        sched.last_epoch = t
+        assert opt.current_lr() == pytest.approx(1e-4 * min(1.0, (t + 1) / 1000))
+
+
+def test_forward_without_gpu_raises_not_falls_back():
+    from dmvae_amd import _lib
+    from dmvae_amd.models.flux_ae import ResnetBlock
+    with pytest.raises((_lib.DmvaeHipError, RuntimeError)):
+        ResnetBlock(32, 32)(torch.zeros(1, 32, 4, 4))
+
+
+def test_product_does_not_import_oracle():
+    import os
+    import re
+    from conftest import ROOT
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "dmvae_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
