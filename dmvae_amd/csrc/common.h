@@ -30,3 +30,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// XCD-aware block order (MI355X: 8 XCDs with private L2s; the dispatcher places flat block b on XCD b % 8).
+// Maps the flat dispatch index to a logical work index such that each XCD walks ONE contiguous range of logical
+// indices in dispatch order, so blocks that are neighbours in logical order share an L2.  Bijective for any total.
+// Placement is a speed assumption only; results do not depend on it.
+__device__ __forceinline__ unsigned xcd_remap(unsigned flat, unsigned total) {
+  const unsigned q = total >> 3, r = total & 7u, x = flat & 7u;
+  const unsigned start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return start + (flat >> 3);
+}

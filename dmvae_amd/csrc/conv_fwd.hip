@@ -15,6 +15,7 @@
 // fragment reads.  Padding pixels / out-of-range rows source a device zero page.
 #include "common.h"
 #include "dmvae_hip.h"
+#include <cstdlib>
 
 namespace dmvae_conv_fwd {
 
@@ -25,7 +26,7 @@ struct ConvArgs {
   const bf16* res;    // [N, Ho, Wo, Cout] or null
   void* y;            // [N, Ho, Wo, Cout] bf16 or f32
   int N, Hi, Wi, Cin, Ho, Wo, Cout;
-  int ks, ups, act, M;
+  int ks, ups, act, M, ctiles, korder;
   long long x_bs, w_bs, y_bs;  // element strides per blockIdx.z (batched GEMM); 0 otherwise
 };
 
@@ -49,8 +50,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
   // stage s: W tile at s*2*TILEB, P tile at s*2*TILEB + TILEB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * TP;   // first pixel
-  const int n0 = blockIdx.y * TM;   // first cout
+  // flat grid, XCD-aware: cout tiles of one pixel tile are adjacent (they share the activation tile in L2) and each
+  // XCD walks a contiguous range of pixel tiles (3x3 halo rows are shared in the same L2)
+  const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (int)(wid / a.ctiles) * TP;   // first pixel
+  const int n0 = (int)(wid % a.ctiles) * TM;   // first cout
   const int T = a.ks * a.ks;
   const int nchunk = a.Cin / BK;
   const int S = T * nchunk;
@@ -81,7 +85,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
   }
 
   auto stage = [&](int s, int buf) {
-    const int tap = s / nchunk, ch = s - tap * nchunk;
+    // channel chunk outer, tap inner: the 9 taps re-read (shifted) the same activation lines back to back -> L2 hits
+    const int ch = a.korder ? s / T : s % nchunk, tap = a.korder ? s - ch * T : s / nchunk;
     const int ky = a.ks == 3 ? tap / 3 - 1 : 0, kx = a.ks == 3 ? tap % 3 - 1 : 0;
     char* wt = smem + buf * 2 * G::TILEB;
     char* pt = wt + G::TILEB;
@@ -192,8 +197,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
 }
 
 template <int BK, bool F32>
-int launch(const ConvArgs& a, hipStream_t st, int batch = 1) {
-  dim3 grid((a.M + TP - 1) / TP, (a.Cout + TM - 1) / TM, batch);
+int launch(const ConvArgs& a_in, hipStream_t st, int batch = 1) {
+  ConvArgs a = a_in;
+  a.ctiles = (a.Cout + TM - 1) / TM;
+  { const char* e = getenv("DMVAE_KORDER"); a.korder = e ? atoi(e) : 1; }
+  dim3 grid(((a.M + TP - 1) / TP) * a.ctiles, 1, batch);
   const int lds = 2 * 2 * Geo<BK>::TILEB;
   static bool attr_done = false;
   if (!attr_done) {
@@ -209,6 +217,9 @@ int launch(const ConvArgs& a, hipStream_t st, int batch = 1) {
 }  // namespace dmvae_conv_fwd
 using namespace dmvae_conv_fwd;
 
+int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void* residual, void* y, const dmvae_conv_desc* d,
+                      hipStream_t stream);  // conv_pp.hip; returns 1 when it declines the shape
+
 extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* bias, const void* residual,
                                      void* y, const dmvae_conv_desc* d, hipStream_t stream) {
   DMVAE_CHECK_ARG(x && w && y && d, "conv2d_nhwc_fwd: null pointer");
@@ -217,6 +228,10 @@ extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* b
   DMVAE_CHECK_ARG(d->cout > 0 && d->cout % 4 == 0, "conv2d_nhwc_fwd: Cout must be a positive multiple of 4 (got %d)", d->cout);
   DMVAE_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0, "conv2d_nhwc_fwd: empty shape");
   DMVAE_CHECK_ARG(d->act >= 0 && d->act <= 2, "conv2d_nhwc_fwd: bad activation code %d", d->act);
+  {
+    const int r = dmvae_conv_pp_try(x, w, bias, residual, y, d, stream);  // large shapes: the ping-pong kernel
+    if (r <= 0) return r;
+  }
   ConvArgs a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.res = (const bf16*)residual; a.y = y;
   a.N = d->n; a.Hi = d->h; a.Wi = d->w; a.Cin = d->cin; a.Cout = d->cout;

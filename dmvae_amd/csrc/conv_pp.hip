@@ -1,0 +1,323 @@
+// Implicit-GEMM convolution (forward and, with flipped weights, dgrad) for NHWC bf16 on gfx950 -- "ping-pong" kernel.
+//
+// Same contract as conv_fwd.hip (nn.Conv2d at models/flux_ae.py:32-35,63,65,67,101,237,274; nn.Linear at
+// models/vae.py:58-62), restructured around what the PMC counters of the first kernel showed (profiles/
+// r1_conv_fwd_v1_pmc.txt): 17 non-MFMA instructions per MFMA (64-bit im2col address math every K step), one K step of
+// prefetch, and 64 FLOP per staged byte.  Here:
+//
+//   * tile 256(cout) x 256(pixels) or 128 x 512, 8 waves, each wave 8 accumulators of 32x32 (128x64 or 64x128):
+//     102-128 FLOP per byte staged through LDS instead of 64;
+//   * K tile = 32 channels of one tap (64-B LDS rows, XOR-swizzled 16-B chunks, conflict-free ds_read_b128), NBUF-deep
+//     LDS ring filled by LDS-DMA (buffer_load_dwordx4 ... lds) NBUF-1 tiles ahead, counted s_waitcnt vmcnt(N) -- the
+//     queue is never drained inside the loop;
+//   * im2col addressing is a per-lane 32-bit voffset fixed for the whole kernel (per tap: one select against a
+//     precomputed 9-bit validity mask) plus a wave-uniform soffset; zero padding and ragged edges come from the
+//     buffer descriptor's out-of-range rule (returns 0), verified on hardware by tools/probes/probe_buflds.hip;
+//   * the two waves that share a SIMD (w and w+4) alternate roles every interval: one issues its 12 ds_read_b128 +
+//     LDS-DMA while the other runs its 16 MFMAs under s_setprio(1); two s_barrier per K tile keep the roles in step.
+//
+// Hazards (B_k = k-th workgroup barrier; group 0 = waves 0-3, group 1 = waves 4-7, one barrier behind):
+//   RAW  tile t+1 is read after B_{2t+2}; every wave waits (vmcnt) for its own pieces of t+1 at the end of its LOAD(t),
+//        i.e. before B_{2t+1} (group 0) / B_{2t+2} (group 1).
+//   WAR  the slot of tile t-1 is re-filled by DMA issued after B_{2t}; its last ds_reads (group 1, LOAD(t-1)) are
+//        retired by lgkmcnt(0) before B_{2t}.
+#include "common.h"
+#include "dmvae_hip.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace dmvae_conv_pp {
+
+struct Args {
+  const bf16* x;      // [N, Hi, Wi, Cin]
+  const bf16* w;      // [Cout, T, Cin]
+  const float* bias;  // [Cout] or null
+  const bf16* res;    // [N, Ho, Wo, Cout] or null
+  void* y;            // [N, Ho, Wo, Cout] bf16 or f32
+  int N, Hi, Wi, Cin, Ho, Wo, Cout;
+  int ks, act, M, ctiles;
+};
+
+constexpr unsigned SENT = 0x80000000u;  // voffset beyond any descriptor's num_records -> the DMA writes zeros
+
+__device__ __forceinline__ int swz64(int row) { return (row >> 2) & 3; }  // 64-B rows: 4 rows per 256-B bank row
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool OUT_F32>
+__global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
+#if __HIP_DEVICE_COMPILE__  // the host pass only needs the launch stub (hipcc drops the stub when it cannot digest the gfx950 body)
+  constexpr int BM = TM / WM / 32, BP = TP / WP / 32;  // 32x32 accumulator blocks per wave
+  constexpr int TILE_A = TM * 64, TILE_B = TP * 64, SLOT = TILE_A + TILE_B;
+  constexpr int NPA = TM / 128, NPB = TP / 128;  // 1-KiB DMA pieces per wave per K tile
+  constexpr int NP = NPA + NPB;
+  constexpr int PF = NBUF - 1;  // prefetch distance in K tiles
+  static_assert(WM * WP == 8 && BM * BP == 8, "8 waves x 8 accumulators");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int wm = wave / WP, wp = wave % WP;
+  const int T = a.ks * a.ks;
+  const int nchunk = a.Cin >> 5;
+  const int nK = T * nchunk;
+
+  const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (int)(wid / a.ctiles) * TP;  // first pixel
+  const int n0 = (int)(wid % a.ctiles) * TM;  // first cout
+
+  // ---- descriptors ---------------------------------------------------------------------------------------------
+  const unsigned wbytes = (unsigned)a.Cout * T * a.Cin * 2u;
+  const unsigned xbytes = (unsigned)a.N * a.Hi * a.Wi * a.Cin * 2u;
+  const unsigned shift = (!UPS && a.ks == 3) ? (unsigned)(a.Wi + 1) * a.Cin * 2u : 0u;  // makes every tap offset >= 0
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, wbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.x) - shift), 0, xbytes + shift, 0x00020000);
+
+  // ---- per-lane DMA sources (fixed for the whole kernel) ----------------------------------------------------------
+  unsigned voffA[NPA];
+#pragma unroll
+  for (int p = 0; p < NPA; p++) {
+    const int row = (wave * NPA + p) * 16 + (lane >> 2);
+    const int co = n0 + row;
+    const int c = (lane & 3) ^ swz64(row);  // logical 16-B chunk this lane fetches (LDS image stays lane-linear)
+    voffA[p] = co < a.Cout ? (unsigned)co * T * a.Cin * 2u + c * 16u : SENT;
+  }
+  unsigned ctrB[NPB], maskB[NPB], selB[NPB];
+  unsigned rowo[UPS ? NPB : 1][3], colo[UPS ? NPB : 1][3];
+#pragma unroll
+  for (int p = 0; p < NPB; p++) {
+    const int row = (wave * NPB + p) * 16 + (lane >> 2);
+    const int m = m0 + row;
+    const int c = (lane & 3) ^ swz64(row);
+    unsigned mask = 0;
+    ctrB[p] = 0;
+    if (m < a.M) {
+      const int hw = a.Ho * a.Wo;
+      const int n = m / hw, r = m - n * hw;
+      const int y = r / a.Wo, x = r - y * a.Wo;
+      if (a.ks == 3) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+          for (int kx = 0; kx < 3; kx++) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            if (yy >= 0 && yy < a.Ho && xx >= 0 && xx < a.Wo) mask |= 1u << (ky * 3 + kx);
+          }
+      } else {
+        mask = 1;
+      }
+      if (UPS) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int yy = min(max(y + k - 1, 0), a.Ho - 1) >> 1, xx = min(max(x + k - 1, 0), a.Wo - 1) >> 1;
+          rowo[UPS ? p : 0][k] = (unsigned)((n * a.Hi + yy) * a.Wi) * a.Cin * 2u + c * 16u;
+          colo[UPS ? p : 0][k] = (unsigned)xx * a.Cin * 2u;
+        }
+        if (a.ks != 3) ctrB[p] = rowo[UPS ? p : 0][1] + colo[UPS ? p : 0][1];
+      } else {
+        ctrB[p] = (unsigned)((n * a.Hi + y) * a.Wi + x) * a.Cin * 2u + c * 16u;
+      }
+    }
+    maskB[p] = mask;
+    selB[p] = SENT;
+  }
+
+  // ---- fragment read offsets (bytes inside a slot) ------------------------------------------------------------------
+  const int kg = lane >> 5;
+  int aoff[2][BM], boff[2][BP];  // [kk]: the second 16-channel step sits 32 B away in the XOR sense
+#pragma unroll
+  for (int i = 0; i < BM; i++) {
+    const int row = wm * (TM / WM) + i * 32 + (lane & 31);
+    aoff[0][i] = row * 64 + ((kg ^ swz64(row)) << 4);
+    aoff[1][i] = aoff[0][i] ^ 32;
+  }
+#pragma unroll
+  for (int j = 0; j < BP; j++) {
+    const int row = wp * (TP / WP) + j * 32 + (lane & 31);
+    boff[0][j] = TILE_A + row * 64 + ((kg ^ swz64(row)) << 4);
+    boff[1][j] = boff[0][j] ^ 32;
+  }
+
+  f32x16 acc[BM][BP];
+#pragma unroll
+  for (int i = 0; i < BM; i++)
+#pragma unroll
+    for (int j = 0; j < BP; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // ---- DMA issue state (wave-uniform): tile `it` = (tap it_tap, channel chunk it_ch) ------------------------------------
+  int it = 0, it_tap = 0, it_ch = 0;
+  unsigned soffB_tap = 0;
+  auto new_tap = [&]() {
+    const int ky = a.ks == 3 ? it_tap / 3 : 1, kx = a.ks == 3 ? it_tap - (it_tap / 3) * 3 : 1;
+    soffB_tap = (!UPS && a.ks == 3) ? (unsigned)(ky * a.Wi + kx) * a.Cin * 2u : 0u;
+#pragma unroll
+    for (int p = 0; p < NPB; p++) {
+      unsigned v = ctrB[p];
+      if (UPS && a.ks == 3) {
+        const unsigned ro = ky == 0 ? rowo[UPS ? p : 0][0] : (ky == 1 ? rowo[UPS ? p : 0][1] : rowo[UPS ? p : 0][2]);
+        const unsigned co = kx == 0 ? colo[UPS ? p : 0][0] : (kx == 1 ? colo[UPS ? p : 0][1] : colo[UPS ? p : 0][2]);
+        v = ro + co;
+      }
+      selB[p] = ((maskB[p] >> it_tap) & 1u) ? v : SENT;
+    }
+  };
+  // issue this wave's pieces of tile `it` into the ring slot at byte offset `slot` (wave-uniform); past the last tile issue
+  // all-zero pieces so that the vmcnt bookkeeping stays uniform (an out-of-range piece moves no memory)
+  auto issue = [&](int slot) {
+    const bool live = it < nK;
+    if (live && it_ch == 0) new_tap();
+    const unsigned soA = (unsigned)(it_tap * a.Cin + it_ch * 32) * 2u;
+    const unsigned soB = soffB_tap + (unsigned)it_ch * 64u;
+#pragma unroll
+    for (int p = 0; p < NPA; p++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + slot + (wave * NPA + p) * 1024), 16, live ? voffA[p] : SENT, soA, 0, 0);
+#pragma unroll
+    for (int p = 0; p < NPB; p++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + TILE_A + (wave * NPB + p) * 1024), 16, live ? selB[p] : SENT, soB, 0, 0);
+    it++;
+    if (++it_ch == nchunk) { it_ch = 0; it_tap++; }
+  };
+
+  // ---- prologue ---------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int u = 0; u < PF; u++) issue(u * SLOT);
+  wait_vmcnt<(PF - 1) * NP>();
+  __builtin_amdgcn_s_barrier();                // B_0: everybody's pieces of tile 0 have landed
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger group 1 by one interval
+
+  // ---- main loop ------------------------------------------------------------------------------------------------------
+  bf16x8 af[2][BM], bfr[2][BP];
+  int slot_rd = 0, slot_wr = PF * SLOT;
+#pragma unroll 1
+  for (int t = 0; t < nK; t++) {
+    // LOAD interval
+    const char* sb = smem + slot_rd;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+#pragma unroll
+      for (int j = 0; j < BP; j++) bfr[kk][j] = *reinterpret_cast<const bf16x8*>(sb + boff[kk][j]);
+#pragma unroll
+      for (int i = 0; i < BM; i++) af[kk][i] = *reinterpret_cast<const bf16x8*>(sb + aoff[kk][i]);
+    }
+    issue(slot_wr);
+    slot_rd = slot_rd + SLOT == NBUF * SLOT ? 0 : slot_rd + SLOT;
+    slot_wr = slot_wr + SLOT == NBUF * SLOT ? 0 : slot_wr + SLOT;
+    wait_vmcnt<(PF - 1) * NP>();  // own pieces of the NEXT tile have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // COMPUTE interval
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+      for (int i = 0; i < BM; i++)
+#pragma unroll
+        for (int j = 0; j < BP; j++)  // in-place accumulate in the AGPR half of the register file
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[kk][i]), "v"(bfr[kk][j]));
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // matches group 1's extra barrier
+  wait_vmcnt<0>();                             // the trailing all-zero pieces
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA (inline asm, invisible to the hazard recognizer) -> accumulator reads
+
+  // ---- epilogue: lane owns pixel (l&31) of each pixel block and 4-cout quads ----------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < BP; j++) {
+    const int m = m0 + wp * (TP / WP) + j * 32 + (lane & 31);
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int i = 0; i < BM; i++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int cb = n0 + wm * (TM / WM) + i * 32 + 8 * q + 4 * kg;
+        if (cb >= a.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * q + e];
+        if (a.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + cb);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += b[e];
+        }
+        const size_t off = (size_t)m * a.Cout + cb;
+        if (a.res) {
+          const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.res + off);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += (float)r[e];
+        }
+        if (a.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = v[e] * sigmoidf_(v[e]);
+        } else if (a.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if (OUT_F32) {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + off) = o;
+        } else {
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.y) + off) = o;
+        }
+      }
+    }
+  }
+#endif
+}
+
+template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32>
+int launch(Args a, hipStream_t st) {
+  a.ctiles = (a.Cout + TM - 1) / TM;
+  const unsigned grid = (unsigned)((a.M + TP - 1) / TP) * a.ctiles;
+  constexpr int lds = NBUF * (TM + TP) * 64;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32>), dim3(grid), dim3(512), lds, st, a);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+template <bool UPS, bool F32>
+int pick(const Args& a, hipStream_t st) {
+  if (a.Cout <= 128) return launch<128, 512, 2, 4, 3, UPS, F32>(a, st);
+  return launch<256, 256, 2, 4, 4, UPS, F32>(a, st);
+}
+
+}  // namespace dmvae_conv_pp
+
+// Entry used by dmvae_conv2d_nhwc_fwd (conv_fwd.hip) for the shapes this kernel covers; returns 1 when it declines.
+int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void* residual, void* y, const dmvae_conv_desc* d,
+                      hipStream_t stream) {
+  using namespace dmvae_conv_pp;
+  static const bool disabled = [] { const char* e = getenv("DMVAE_CONV_V1"); return e && atoi(e) != 0; }();
+  if (disabled) return 1;
+  const int ups = d->upsample ? 1 : 0;
+  const long long M = (long long)d->n * d->h * d->w * (ups ? 4 : 1);
+  const long long xbytes = (long long)d->n * d->h * d->w * d->cin * 2;
+  const long long wbytes = (long long)d->cout * d->ks * d->ks * d->cin * 2;
+  if (d->cin % 32 != 0 || d->cout < 64 || M < 16384 || xbytes + (1ll << 22) >= (1ll << 31) || wbytes >= (1ll << 31)) return 1;
+  Args a;
+  a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.res = (const bf16*)residual; a.y = y;
+  a.N = d->n; a.Hi = d->h; a.Wi = d->w; a.Cin = d->cin; a.Cout = d->cout;
+  a.Ho = ups ? 2 * d->h : d->h; a.Wo = ups ? 2 * d->w : d->w;
+  a.ks = d->ks; a.act = d->act; a.M = (int)M; a.ctiles = 0;
+  const bool f32 = d->out_f32 != 0;
+  if (ups) return f32 ? pick<true, true>(a, stream) : pick<true, false>(a, stream);
+  return f32 ? pick<false, true>(a, stream) : pick<false, false>(a, stream);
+}

@@ -26,6 +26,7 @@ struct WgradArgs {
   float* slab;     // [splits][Cout][T][Cin]
   int N, Hi, Wi, Cin, Ho, Wo, Cout;
   int ks, ups, M, kchunk;  // kchunk: pixels per split (multiple of 64)
+  int ntiles;              // (cout-tile, cin-tile, tap) combinations per pixel range
   long long dy_bs, a_bs, slab_bs;  // per blockIdx.z element strides (batched TN GEMM); 0 otherwise
 };
 
@@ -42,12 +43,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int T = a.ks * a.ks;
   const int ci_tiles = (a.Cin + 127) / 128;
-  int t = blockIdx.y;
+  // flat grid, XCD-aware: all (cout-tile, cin-tile, tap) blocks of one pixel range are adjacent in dispatch order and
+  // each XCD owns a contiguous run of pixel ranges, so the dy / activation tiles are fetched into one L2 once
+  const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = (int)(wid / a.ntiles);
+  int t = (int)(wid % a.ntiles);
   const int tap = t % T; t /= T;
   const int ci0 = (t % ci_tiles) * 128;
   const int co0 = (t / ci_tiles) * 128;
   const int ky = a.ks == 3 ? tap / 3 - 1 : 0, kx = a.ks == 3 ? tap % 3 - 1 : 0;
-  const int k0 = blockIdx.x * a.kchunk;
+  const int k0 = split * a.kchunk;
   const int k1 = min(k0 + a.kchunk, a.M);
   const int S = (k1 - k0 + BKP - 1) / BKP;
   const bf16* zero = reinterpret_cast<const bf16*>(dmvae_zero_page);
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   }
 
   // slab store: lane owns ci = (l&31), 16 couts per block
-  float* slab = a.slab + (size_t)blockIdx.x * a.Cout * T * a.Cin;
+  float* slab = a.slab + (size_t)split * a.Cout * T * a.Cin;
 #pragma unroll
   for (int j = 0; j < 2; j++) {
     const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
@@ -192,25 +197,46 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   }
 }
 
-// db[c] (+)= sum_p dy[p][c]; one block per 64-channel slice x pixel range, two-stage.
-__global__ void colsum_partial_kernel(const bf16* __restrict__ dy, float* __restrict__ part, int M, int C, int rows_per_block) {
-  __shared__ float sh[4][64];
-  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
-  const int w = threadIdx.x >> 6;
+// db[c] (+)= sum_p dy[p][c].  HBM-bound: 16-B loads (8 channels per lane), tp channel-lanes x (256/tp) pixel rows per
+// block iteration, f32 accumulation, LDS block reduce, fixed-order second stage (deterministic).
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ dy, float* __restrict__ part, int M, int C,
+                                                             int tp_shift, int rows_per_block) {
+  __shared__ float red[256 * 8];
+  const int tp = 1 << tp_shift, rows = 256 >> tp_shift;
+  const int lc = threadIdx.x & (tp - 1), prow = threadIdx.x >> tp_shift;
+  const int c0 = (blockIdx.y * tp + lc) * 8;
   const int p0 = blockIdx.x * rows_per_block, p1 = min(p0 + rows_per_block, M);
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < C)
+    for (int p = p0 + prow; p < p1; p += rows) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + (size_t)p * C + c0);
+#pragma unroll
+      for (int e = 0; e < 8; e++) s[e] += (float)v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[(prow * tp + lc) * 8 + e] = s[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < tp * 8; c += 256) {
+    float a = 0.f;
+    for (int r = 0; r < rows; r++) a += red[(r * tp + (c >> 3)) * 8 + (c & 7)];
+    const int cg = blockIdx.y * tp * 8 + c;
+    if (cg < C) part[(size_t)blockIdx.x * C + cg] = a;
+  }
+}
+// 64 channels per block, 4 lanes per channel stride over the partials
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int C,
+                                                           int accumulate) {
+  __shared__ float sh[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), kl = threadIdx.x >> 6;
   float s = 0.f;
   if (c < C)
-    for (int p = p0 + w; p < p1; p += 4) s += (float)dy[(size_t)p * C + c];
-  sh[w][threadIdx.x & 63] = s;
+    for (int k = kl; k < nparts; k += 4) s += part[(size_t)k * C + c];
+  sh[kl][threadIdx.x & 63] = s;
   __syncthreads();
-  if (w == 0 && c < C) part[(size_t)blockIdx.x * C + c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-}
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int C, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int k = 0; k < nparts; k++) s += part[(size_t)k * C + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (kl == 0 && c < C) {
+    const float t = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 static int pick_splits(int M, int tiles) {
@@ -262,7 +288,8 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
     attr_done = true;
   }
-  hipLaunchKernelGGL(wgrad_kernel, dim3(splits, tiles), dim3(256), 4 * TILEB, stream, w);
+  w.ntiles = tiles;
+  hipLaunchKernelGGL(wgrad_kernel, dim3(splits * tiles), dim3(256), 4 * TILEB, stream, w);
   DMVAE_CHECK_LAUNCH();
   const size_t total = (size_t)w.Cout * T * w.Cin;
   int rb = (int)((total + 255) / 256); if (rb > 2048) rb = 2048;
@@ -270,12 +297,18 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
   DMVAE_CHECK_LAUNCH();
   if (dbias) {
     float* part = w.slab + (size_t)splits * total;
-    int nparts = (w.M + 255) / 256; if (nparts > 1024) nparts = 1024;
+    int tp = 1, tps = 0;
+    while (tp < 64 && tp * 8 < w.Cout) { tp <<= 1; tps++; }
+    const int rows = 256 / tp;
+    int nparts = (w.M + rows * 8 - 1) / (rows * 8);   // >= 8 row iterations per block
+    if (nparts > 512) nparts = 512;
+    if (nparts < 1) nparts = 1;
     const int rpb = (w.M + nparts - 1) / nparts;
     nparts = (w.M + rpb - 1) / rpb;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nparts, (w.Cout + 63) / 64), dim3(256), 0, stream, w.dy, part, w.M, w.Cout, rpb);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nparts, (w.Cout + tp * 8 - 1) / (tp * 8)), dim3(256), 0, stream, w.dy, part, w.M,
+                       w.Cout, tps, rpb);
     DMVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((w.Cout + 255) / 256), dim3(256), 0, stream, part, (float*)dbias, nparts, w.Cout, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((w.Cout + 63) / 64), dim3(256), 0, stream, part, (float*)dbias, nparts, w.Cout, accumulate);
     DMVAE_CHECK_LAUNCH();
   }
   return 0;
@@ -308,7 +341,8 @@ extern "C" int dmvae_gemm_tn_batched(const void* A, const void* B, void* C, void
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
     attr_done = true;
   }
-  hipLaunchKernelGGL(wgrad_kernel, dim3(splits, tiles, batch), dim3(256), 4 * TILEB, stream, w);
+  w.ntiles = tiles;
+  hipLaunchKernelGGL(wgrad_kernel, dim3(splits * tiles, 1, batch), dim3(256), 4 * TILEB, stream, w);
   DMVAE_CHECK_LAUNCH();
   int rb = (int)((total + 255) / 256); if (rb > 1024) rb = 1024;
   if (out_f32)

@@ -20,6 +20,21 @@ from .optim import FlatAdamWEMA, FlatParams
 from .utils.lpips import LPIPS
 
 
+def frozen_bf16_shadow(module: torch.nn.Module) -> torch.nn.Module:
+    """Copy of a FROZEN module whose Linear/Conv2d weights+biases are stored in bf16 -- exactly the values autocast(bf16)
+    would cast them to on every call (the reference re-casts the frozen ViT / VGG weights each step under autocast,
+    train_tokenizer.py:295-297,410-411).  Norm / LayerScale / embedding parameters stay f32 like under autocast.  The owner
+    module (and its state_dict / checkpoint) is untouched."""
+    import copy
+    sh = copy.deepcopy(module).eval().requires_grad_(False)
+    for m in sh.modules():
+        if isinstance(m, (torch.nn.Linear, torch.nn.Conv2d)):
+            m.weight.data = m.weight.data.to(torch.bfloat16)
+            if m.bias is not None:
+                m.bias.data = m.bias.data.to(torch.bfloat16)
+    return sh
+
+
 def backward_order_params(vae: VAE):
     """Trainable parameters (decoder + bottleneck) in the order their gradients complete in backward."""
     dec = vae.decoder
@@ -55,19 +70,29 @@ class TokenizerTrainer:
         self.sync = dist.FlatGradSync(params, self.fp.grad, self.fp.offsets, bucket_bytes=bucket_bytes)
         self.log = torch.zeros(8, dtype=torch.float32, device=self.fp.flat.device)
         self.global_step = 0
+        self.refresh_frozen_shadows()
+
+    def refresh_frozen_shadows(self) -> None:
+        """(Re)build the bf16 shadows of the frozen encoder and LPIPS trunk; call after loading new weights into them."""
+        self._enc = frozen_bf16_shadow(self.vae.encoder)
+        self._lpips = None
+        if self.lpips is not None:
+            import copy
+            self._lpips = copy.deepcopy(self.lpips).eval().requires_grad_(False)      # lin weights stay f32 (kernel operand)
+            self._lpips.net = frozen_bf16_shadow(self.lpips.net).to(memory_format=torch.channels_last)
 
     def step(self, images: torch.Tensor) -> torch.Tensor:
         vae, w = self.vae, self.w
         with torch.autocast("cuda", dtype=torch.bfloat16):
             with torch.no_grad():
-                tokens = vae.encoder(images)
+                tokens = self._enc(images)
             latent = vae.bottle_neck(tokens)
             recon = vae.decoder(latent).float()
             l1, l2 = losses.l1_mse(recon, images, w["l1"], w["l2"])
             loss = l1 * w["l1"] + l2 * w["l2"]
             lp = None
             if self.lpips is not None and w["lpips"] != 0:
-                lp = self.lpips(images, recon)
+                lp = self._lpips(images, recon)
                 loss = loss + lp * w["lpips"]
             kl = None
             if w["kl"] != 0 or w["mmd"] != 0:

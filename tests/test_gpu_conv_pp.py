@@ -1,0 +1,79 @@
+"""Parity of the large-shape ("ping-pong") conv kernel, csrc/conv_pp.hip, through the same C-ABI entry point
+(dmvae_conv2d_nhwc_fwd dispatches to it for M >= 16384 pixels, Cout >= 64, Cin % 32 == 0).  Reference: fp64 conv on
+the same bf16-rounded operands (F.conv2d on CPU), as for the small-shape kernel in test_gpu_kernels.py.  Covers both
+tile configurations (128x512, 256x256), ragged pixel / cout edges, image-border masks with non-power-of-two widths,
+Cin = 32 (one chunk per tap), the folded nearest-x2 upsample, 1x1, and the dgrad use (tap-flipped weights)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from test_gpu_kernels import _conv_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+CASES = [  # N, H, W, Cin, Cout, ks, ups
+    (1, 128, 128, 64, 128, 3, 0),    # 128x512 tiles
+    (1, 128, 128, 64, 192, 3, 0),    # 256x256 tiles, ragged cout
+    (2, 96, 100, 32, 64, 3, 0),      # ragged pixel count, W not a power of two, one chunk per tap
+    (1, 64, 64, 64, 128, 3, 1),      # folded nearest-x2 upsample
+    (1, 64, 72, 96, 320, 3, 1),      # upsample, 256-wide tiles, ragged cout, Cin = 3 chunks
+    (1, 128, 128, 128, 256, 1, 0),   # 1x1
+    (3, 80, 80, 160, 96, 3, 0),      # several images per tile row range
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("act", [0, 1])
+def test_conv_pp_fwd(case, act):
+    from dmvae_amd import ops
+    n, h, w_, cin, cout, ks, ups = case
+    g = torch.Generator(device="cpu").manual_seed(11 + cin + cout)
+    x = torch.randn(n, h, w_, cin, generator=g).to(DEV).to(BF)
+    w = (torch.randn(cout, cin, ks, ks, generator=g) * 0.05).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    ho, wo = (2 * h, 2 * w_) if ups else (h, w_)
+    r = torch.randn(n, ho, wo, cout, generator=g).to(DEV).to(BF)
+    wp = ops.pack_conv_weight(w)
+    ref = _conv_ref(x, w.to(BF), b, r, ks, ups, act)
+    y32 = ops.conv2d_nhwc(x, wp, b, r, ks=ks, upsample=bool(ups), act=act, out_f32=True)
+    assert rel_err(y32.cpu(), ref) < 1e-5
+    y16 = ops.conv2d_nhwc(x, wp, b, r, ks=ks, upsample=bool(ups), act=act)
+    assert torch.equal(y16, y32.to(BF))
+    y0 = ops.conv2d_nhwc(x, wp, None, None, ks=ks, upsample=bool(ups), act=0, out_f32=True)     # no bias / residual
+    assert rel_err(y0.cpu(), _conv_ref(x, w.to(BF), None, None, ks, ups, 0)) < 1e-5
+
+
+@pytest.mark.parametrize("case", [(1, 128, 128, 64, 128, 3), (2, 96, 100, 96, 64, 3), (1, 128, 128, 256, 128, 1)])
+def test_conv_pp_dgrad(case):
+    """dx = conv(dy, flipped/transposed weights): the same kernel with dmvae_pack_conv_weight(for_dgrad=1)."""
+    from dmvae_amd import ops
+    n, h, w_, cin, cout, ks = case
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(n, h, w_, cout, generator=g).to(DEV).to(BF)
+    w = (torch.randn(cout, cin, ks, ks, generator=g) * 0.05).to(DEV)
+    xr = torch.zeros(n, cin, h, w_, dtype=torch.double, requires_grad=True)
+    F.conv2d(xr, w.to(BF).float().cpu().double(), None, padding=ks // 2).backward(dy.float().cpu().double().permute(0, 3, 1, 2))
+    dx = ops.conv2d_nhwc(dy, ops.pack_conv_weight(w, for_dgrad=True), ks=ks, out_f32=True)
+    assert rel_err(dx.cpu(), xr.grad.permute(0, 2, 3, 1)) < 1e-5
+
+
+def test_conv_pp_is_deterministic_and_linear():
+    """Full-size property checks (BASELINE config shape 128->128 @ 256x256, batch 4): run-to-run bit equality and
+    conv(x1 + x2) == conv(x1) + conv(x2) in f32 up to accumulation order."""
+    from dmvae_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x1 = torch.randn(4, 256, 256, 128, generator=g).to(DEV).to(BF)
+    x2 = (torch.randn(4, 256, 256, 128, generator=g) * 2).to(DEV).to(BF)
+    xs = (x1.float() + x2.float()).to(BF)
+    exact = xs.float() == x1.float() + x2.float()        # keep only positions where the bf16 sum is exact
+    x1 = torch.where(exact, x1, torch.zeros_like(x1)); x2 = torch.where(exact, x2, torch.zeros_like(x2))
+    xs = (x1.float() + x2.float()).to(BF)
+    wp = ops.pack_conv_weight((torch.randn(128, 128, 3, 3, generator=g) * 0.05).to(DEV))
+    ya = ops.conv2d_nhwc(xs, wp, ks=3, out_f32=True)
+    yb = ops.conv2d_nhwc(xs, wp, ks=3, out_f32=True)
+    assert torch.equal(ya, yb)
+    ysum = ops.conv2d_nhwc(x1, wp, ks=3, out_f32=True) + ops.conv2d_nhwc(x2, wp, ks=3, out_f32=True)
+    assert rel_err(ya, ysum) < 1e-5
