@@ -250,9 +250,19 @@ static int pick_splits(int M, int tiles) {
 }  // namespace dmvae_conv_wgrad
 using namespace dmvae_conv_wgrad;
 
+// conv_wgrad_pp.hip: the ping-pong kernel for the large layers (plan returns 0 when it does not cover the shape)
+int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_out, int* cfg_out);
+int dmvae_wgrad_pp_launch(const void* dy, const void* act, float* slab, const dmvae_conv_desc* d, int splits, int kchunk, int cfg,
+                          hipStream_t stream);
+
 extern "C" size_t dmvae_conv2d_nhwc_wgrad_workspace(const dmvae_conv_desc* d) {
   if (!d) return 0;
   const int T = d->ks * d->ks;
+  {
+    int sp, kc, cfg;
+    if ((d->ks == 1 || d->ks == 3) && dmvae_wgrad_pp_plan(d, &sp, &kc, &cfg))
+      return (size_t)sp * d->cout * T * d->cin * sizeof(float) + (size_t)1024 * d->cout * sizeof(float);
+  }
   const long long M = (long long)d->n * d->h * d->w * (d->upsample ? 4 : 1);
   const int tiles = ((d->cout + 127) / 128) * ((d->cin + 127) / 128) * T;
   const int splits = pick_splits((int)M, tiles);
@@ -281,16 +291,22 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
   const int T = w.ks * w.ks;
   const int tiles = ((w.Cout + 127) / 128) * ((w.Cin + 127) / 128) * T;
   int splits = pick_splits(w.M, tiles);
-  w.kchunk = (((w.M + splits - 1) / splits) + BKP - 1) / BKP * BKP;
-  splits = (w.M + w.kchunk - 1) / w.kchunk;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
-    attr_done = true;
+  int pp_kchunk = 0, pp_cfg = 0;
+  if (dmvae_wgrad_pp_plan(d, &splits, &pp_kchunk, &pp_cfg)) {
+    const int rc = dmvae_wgrad_pp_launch(dy, a, w.slab, d, splits, pp_kchunk, pp_cfg, stream);
+    if (rc) return rc;
+  } else {
+    w.kchunk = (((w.M + splits - 1) / splits) + BKP - 1) / BKP * BKP;
+    splits = (w.M + w.kchunk - 1) / w.kchunk;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
+      attr_done = true;
+    }
+    w.ntiles = tiles;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(splits * tiles), dim3(256), 4 * TILEB, stream, w);
+    DMVAE_CHECK_LAUNCH();
   }
-  w.ntiles = tiles;
-  hipLaunchKernelGGL(wgrad_kernel, dim3(splits * tiles), dim3(256), 4 * TILEB, stream, w);
-  DMVAE_CHECK_LAUNCH();
   const size_t total = (size_t)w.Cout * T * w.Cin;
   int rb = (int)((total + 255) / 256); if (rb > 2048) rb = 2048;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, w.slab, (float*)dw, splits, w.Cout, T, w.Cin, accumulate);

@@ -1,0 +1,323 @@
+// Weight gradient of the NHWC bf16 convolution on gfx950 -- "ping-pong" kernel for the large decoder layers.
+//
+// Same contract as conv_wgrad.hip (autograd's conv / linear weight gradient for nn.Conv2d at models/flux_ae.py:32-35,
+// 63,65,67,101 and nn.Linear at models/vae.py:58-62):
+//
+//   dW[co][tap][ci] = sum_p dy[p][co] * a[p (+) tap][ci]                  (reduction over pixels, split-K, deterministic)
+//
+// GEMM view: M = cout, N = (tap, cin) flattened in column groups of 128 channels, K = pixels.  Both operands are
+// channel-contiguous while the reduction runs over pixels, so LDS holds [32 pixels][128 channels] sub-tiles exactly as
+// DMA'd and the MFMA fragments come from the gfx950 transpose read ds_read_b64_tr_b16 (64-B segment XOR swizzle keyed
+// on pixel & 3, applied on the DMA source address and on the read -- same image as conv_wgrad.hip, hardware-checked by
+// tools/probes/probe_tr16.hip).
+//
+// Structure = conv_pp.hip: 8 waves, each 128x64 (or 64x96) of the 256x256 (or 128x384) output tile, a 4-deep LDS ring
+// filled by LDS-DMA through buffer descriptors three K tiles ahead (counted vmcnt), the two waves of a SIMD alternating
+// LOAD / COMPUTE intervals between two s_barrier per K tile.  The 128x384 configuration serves Cout or Cin = 128: its
+// three column groups are three different taps (or tap x cin-half), so a 128-channel layer still stages ~96 FLOP/B.
+//
+// A K tile is 32 consecutive pixels of one image row (the host only selects this kernel when W % 32 == 0), so the
+// zero-padding test is wave-uniform except for the first / last pixel of a row: per-lane sources are fixed for the
+// whole kernel and only the wave-uniform soffset advances.
+#include "common.h"
+#include "dmvae_hip.h"
+#include <cstdlib>
+
+namespace dmvae_wgrad_pp {
+
+struct Args {
+  const bf16* dy;  // [M, Cout]
+  const bf16* a;   // [N, Hi, Wi, Cin]
+  float* slab;     // [splits][Cout][T][Cin]
+  int N, Hi, Wi, Cin, Ho, Wo, Cout;
+  int ks, ups, M, kchunk;  // kchunk: pixels per split (multiple of 32)
+  int mtiles, ntiles, ngroups, gpt;  // gpt: 128-channel column groups per cin row (Cin / 128)
+};
+
+constexpr unsigned SENT = 0x80000000u;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ s16x4 tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+// GA / GB: 128-channel sub-tiles of the dy / activation operand per block; waves WM x WN.
+template <int GA, int GB, int WM, int WN>
+__global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int TM = GA * 128, TN = GB * 128;
+  constexpr int BM = TM / WM / 32, BN = TN / WN / 32;
+  constexpr int SUB = 32 * 256;  // bytes of one [32 px][128 ch] sub-tile
+  constexpr int SLOT = (GA + GB) * SUB;
+  constexpr int NBUF = 4, PF = 3;
+  constexpr int NPA = GA, NPB = GB;  // 1-KiB pieces per wave per K tile (8 pieces per sub-tile, 8 waves)
+  constexpr int NP = NPA + NPB;
+  static_assert(WM * WN == 8, "8 waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int wm = wave / WN, wn = wave % WN;
+  const int T = a.ks * a.ks;
+
+  const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = a.mtiles * a.ntiles;
+  const int split = (int)(wid / tiles);
+  const int tile = (int)(wid % tiles);
+  const int co0 = (tile / a.ntiles) * TM;
+  const int g0 = (tile % a.ntiles) * GB;  // first column group of this block
+  const int k0 = split * a.kchunk;
+  const int k1 = min(k0 + a.kchunk, a.M);
+  const int nK = (k1 - k0) >> 5;
+
+  // ---- descriptors: dy is linear in the pixel index; the activation base is shifted so every tap offset is >= 0 -------
+  const unsigned dybytes = (unsigned)a.M * a.Cout * 2u;
+  const unsigned abytes = (unsigned)a.N * a.Hi * a.Wi * a.Cin * 2u;
+  const unsigned shift = (!a.ups && a.ks == 3) ? (unsigned)(a.Wi + 1) * a.Cin * 2u : 0u;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, dybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.a) - shift), 0, abytes + shift, 0x00020000);
+
+  // ---- per-lane DMA sources ----------------------------------------------------------------------------------------------
+  // piece pb (0 .. 8*G-1): sub-tile pb / 8, pixel rows 4*(pb % 8) .. +3; lane -> row + lane/16, physical 16-B chunk lane%16
+  const int cphys = lane & 15;
+  unsigned voffA[NPA];
+#pragma unroll
+  for (int p = 0; p < NPA; p++) {
+    const int pb = wave * NPA + p;
+    const int sub = pb >> 3, row = (pb & 7) * 4 + (lane >> 4);
+    const int clog = ((((cphys >> 2) ^ (row & 3)) << 2) | (cphys & 3)) * 8;
+    const int co = co0 + sub * 128 + clog;
+    voffA[p] = co < a.Cout ? (unsigned)(row * a.Cout + co) * 2u : SENT;
+  }
+  unsigned voffB[NPB], voffBL[NPB], voffBR[NPB];  // plain / first pixel of a row masked / last pixel masked
+  int kyB[NPB], kxB[NPB];                           // tap of the piece's column group (wave-uniform)
+  unsigned tapoB[NPB];                              // wave-uniform byte offset of the tap (+ shift), non-upsampled case
+  int rowB[NPB];
+#pragma unroll
+  for (int p = 0; p < NPB; p++) {
+    const int pb = wave * NPB + p;
+    const int sub = pb >> 3, row = (pb & 7) * 4 + (lane >> 4);
+    const int clog = ((((cphys >> 2) ^ (row & 3)) << 2) | (cphys & 3)) * 8;
+    const int g = g0 + sub;
+    const int tap = g / a.gpt, ci = (g - tap * a.gpt) * 128 + clog;
+    const bool ok = g < a.ngroups;
+    kyB[p] = a.ks == 3 ? tap / 3 : 1;
+    kxB[p] = a.ks == 3 ? tap - (tap / 3) * 3 : 1;
+    tapoB[p] = (!a.ups && a.ks == 3) ? (unsigned)(kyB[p] * a.Wi + kxB[p]) * a.Cin * 2u : 0u;
+    rowB[p] = row;
+    const unsigned v = a.ups ? (unsigned)ci * 2u : (unsigned)(row * a.Cin + ci) * 2u;
+    voffB[p] = ok ? v : SENT;
+    voffBL[p] = (ok && row != 0) ? v : SENT;
+    voffBR[p] = (ok && row != 31) ? v : SENT;
+  }
+
+  // ---- fragment read addresses (bytes inside a slot): one per 32-row block, (kk, h) are immediates --------------------------
+  const int g16 = (lane >> 4) & 1, kq = lane >> 5, rr = (lane & 15) >> 2, qq = lane & 3;
+  int aoff[BM], boff[BN];
+#pragma unroll
+  for (int i = 0; i < BM; i++) {
+    const int ch = wm * (TM / WM) + i * 32 + 16 * g16 + 4 * qq;  // channel inside the TM-wide operand
+    const int sub = ch >> 7, c = ch & 127;
+    aoff[i] = sub * SUB + (kq * 8 + rr) * 256 + ((((c >> 5) ^ rr)) << 6) + (c & 31) * 2;
+  }
+#pragma unroll
+  for (int j = 0; j < BN; j++) {
+    const int ch = wn * (TN / WN) + j * 32 + 16 * g16 + 4 * qq;
+    const int sub = ch >> 7, c = ch & 127;
+    boff[j] = GA * SUB + sub * SUB + (kq * 8 + rr) * 256 + ((((c >> 5) ^ rr)) << 6) + (c & 31) * 2;
+  }
+
+  f32x16 acc[BM][BN];
+#pragma unroll
+  for (int i = 0; i < BM; i++)
+#pragma unroll
+    for (int j = 0; j < BN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // ---- DMA issue state: tile `it` starts at pixel pt = (n, y, x0), all wave-uniform -----------------------------------------
+  int it = 0;
+  int pt = k0;
+  int px0, py, pn;
+  {
+    const int hw = a.Ho * a.Wo;
+    pn = k0 / hw;
+    const int r = k0 - pn * hw;
+    py = r / a.Wo;
+    px0 = r - py * a.Wo;
+  }
+  auto issue = [&](int slot) {
+    const bool live = it < nK;
+    const unsigned soA = (unsigned)pt * a.Cout * 2u;
+#pragma unroll
+    for (int p = 0; p < NPA; p++) {
+      const int pb = wave * NPA + p;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + slot + pb * 1024), 16, live ? voffA[p] : SENT, soA, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < NPB; p++) {
+      const int pb = wave * NPB + p;
+      const int yy = py + kyB[p] - 1;
+      const bool yok = (unsigned)yy < (unsigned)a.Ho;
+      const bool edgeL = kxB[p] == 0 && px0 == 0, edgeR = kxB[p] == 2 && px0 + 32 == a.Wo;
+      unsigned v = edgeL ? voffBL[p] : (edgeR ? voffBR[p] : voffB[p]);
+      unsigned so;
+      if (a.ups) {
+        const int xx = px0 + rowB[p] + kxB[p] - 1;  // masked lanes never use it
+        v = v == SENT ? SENT : v + (unsigned)(xx >> 1) * a.Cin * 2u;
+        so = (unsigned)((pn * a.Hi + (yy >> 1)) * a.Wi) * a.Cin * 2u;
+      } else {
+        so = (unsigned)pt * a.Cin * 2u + tapoB[p];
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + GA * SUB + pb * 1024), 16, (live && yok) ? v : SENT, yok ? so : 0u, 0, 0);
+    }
+    it++;
+    pt += 32;
+    px0 += 32;
+    if (px0 == a.Wo) {
+      px0 = 0;
+      if (++py == a.Ho) { py = 0; pn++; }
+    }
+  };
+
+#pragma unroll
+  for (int u = 0; u < PF; u++) issue(u * SLOT);
+  wait_vmcnt<(PF - 1) * NP>();
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+
+  union Frag { bf16x8 v; s16x4 h[2]; };
+  Frag af[2][BM], bfr[2][BN];
+  int slot_rd = 0, slot_wr = PF * SLOT;
+#pragma unroll 1
+  for (int t = 0; t < nK; t++) {
+    const char* sb = smem + slot_rd;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+#pragma unroll
+      for (int j = 0; j < BN; j++) {
+        bfr[kk][j].h[0] = tr_read(sb + boff[j] + kk * 4096);
+        bfr[kk][j].h[1] = tr_read(sb + boff[j] + kk * 4096 + 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < BM; i++) {
+        af[kk][i].h[0] = tr_read(sb + aoff[i] + kk * 4096);
+        af[kk][i].h[1] = tr_read(sb + aoff[i] + kk * 4096 + 1024);
+      }
+    }
+    issue(slot_wr);
+    slot_rd = slot_rd + SLOT == NBUF * SLOT ? 0 : slot_rd + SLOT;
+    slot_wr = slot_wr + SLOT == NBUF * SLOT ? 0 : slot_wr + SLOT;
+    wait_vmcnt<(PF - 1) * NP>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+      for (int i = 0; i < BM; i++)
+#pragma unroll
+        for (int j = 0; j < BN; j++)
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[kk][i].v), "v"(bfr[kk][j].v));
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  wait_vmcnt<0>();
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+  // ---- slab store: lane owns column (l & 31) of each N block, 16 couts per accumulator ------------------------------------------
+  float* slab = a.slab + (size_t)split * a.Cout * T * a.Cin;
+#pragma unroll
+  for (int j = 0; j < BN; j++) {
+    const int nn = wn * (TN / WN) + j * 32 + (lane & 31);  // column inside the block's TN
+    const int g = g0 + (nn >> 7);
+    if (g >= a.ngroups) continue;
+    const int tap = g / a.gpt, ci = (g - tap * a.gpt) * 128 + (nn & 127);
+#pragma unroll
+    for (int i = 0; i < BM; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int co = co0 + wm * (TM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+        if (co < a.Cout) slab[((size_t)co * T + tap) * a.Cin + ci] = acc[i][j][r];
+      }
+  }
+#endif
+}
+
+template <int GA, int GB, int WM, int WN>
+int launch(const Args& a, int splits, hipStream_t st) {
+  constexpr int lds = 4 * (GA + GB) * 32 * 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_kernel<GA, GB, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((wgrad_pp_kernel<GA, GB, WM, WN>), dim3((unsigned)(splits * a.mtiles * a.ntiles)), dim3(512), lds, st, a);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace dmvae_wgrad_pp
+
+// Plan shared by the workspace query and the launch: returns 0 when the ping-pong kernel does not cover the shape.
+int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_out, int* cfg_out) {
+  static const bool disabled = [] { const char* e = getenv("DMVAE_WGRAD_V1"); return e && atoi(e) != 0; }();
+  if (disabled) return 0;
+  const int ups = d->upsample ? 1 : 0;
+  const int wo = ups ? 2 * d->w : d->w;
+  const long long M = (long long)d->n * d->h * d->w * (ups ? 4 : 1);
+  if (d->cin % 128 != 0 || d->cout % 128 != 0 || wo % 32 != 0 || M < 8192) return 0;
+  if ((long long)M * d->cout * 2 >= (1ll << 31) || (long long)d->n * d->h * d->w * d->cin * 2 + (1ll << 22) >= (1ll << 31)) return 0;
+  const int T = d->ks * d->ks;
+  const int ngroups = T * (d->cin / 128);
+  int cfg, mtiles, ntiles;
+  if (d->cout % 256 == 0 && (d->cin / 128) % 2 == 0) { cfg = 0; mtiles = d->cout / 256; ntiles = ngroups / 2; }
+  else { cfg = 1; mtiles = d->cout / 128; ntiles = (ngroups + 2) / 3; }
+  const int tiles = mtiles * ntiles;
+  // fill the 256 CUs with whole blocks (1 block per CU): the fewest rounds that still leave >= 16 K tiles per split
+  const int ktiles = (int)(M / 32);
+  int best = 1;
+  double best_eff = 0;
+  for (int s = 1; s <= ktiles / 16 && s * tiles <= 4096; s++) {
+    const int blocks = s * tiles;
+    const int rounds = (blocks + 255) / 256;
+    const int kt = (ktiles + s - 1) / s;  // K tiles per split (critical path per block)
+    const double eff = (double)ktiles * tiles / ((double)rounds * 256 * kt) / (1.0 + 24.0 / kt);  // useful / provisioned, with a fixed per-block cost
+    if (eff > best_eff * 1.0001) { best_eff = eff; best = s; }
+  }
+  const int kt = (ktiles + best - 1) / best;
+  *kchunk_out = kt * 32;
+  *splits_out = (ktiles + kt - 1) / kt;
+  *cfg_out = cfg;
+  return 1;
+}
+
+int dmvae_wgrad_pp_launch(const void* dy, const void* act, float* slab, const dmvae_conv_desc* d, int splits, int kchunk, int cfg,
+                          hipStream_t stream) {
+  using namespace dmvae_wgrad_pp;
+  Args a;
+  a.dy = (const bf16*)dy; a.a = (const bf16*)act; a.slab = slab;
+  a.N = d->n; a.Hi = d->h; a.Wi = d->w; a.Cin = d->cin; a.Cout = d->cout; a.ks = d->ks;
+  a.ups = d->upsample ? 1 : 0;
+  a.Ho = a.ups ? 2 * d->h : d->h; a.Wo = a.ups ? 2 * d->w : d->w;
+  a.M = a.N * a.Ho * a.Wo;
+  a.kchunk = kchunk;
+  a.gpt = d->cin / 128;
+  a.ngroups = d->ks * d->ks * a.gpt;
+  if (cfg == 0) {
+    a.mtiles = d->cout / 256; a.ntiles = a.ngroups / 2;
+    return launch<2, 2, 2, 4>(a, splits, stream);
+  }
+  a.mtiles = d->cout / 128; a.ntiles = (a.ngroups + 2) / 3;
+  return launch<1, 3, 2, 4>(a, splits, stream);
+}

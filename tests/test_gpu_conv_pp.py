@@ -77,3 +77,37 @@ def test_conv_pp_is_deterministic_and_linear():
     assert torch.equal(ya, yb)
     ysum = ops.conv2d_nhwc(x1, wp, ks=3, out_f32=True) + ops.conv2d_nhwc(x2, wp, ks=3, out_f32=True)
     assert rel_err(ya, ysum) < 1e-5
+
+
+WGRAD_CASES = [  # N, H, W, Cin, Cout, ks, ups  -- shapes the ping-pong wgrad kernel (csrc/conv_wgrad_pp.hip) covers
+    (1, 128, 128, 128, 128, 3, 0),   # 128x384 tiles: three taps per block
+    (2, 64, 64, 256, 256, 3, 0),     # 256x256 tiles
+    (1, 96, 96, 256, 128, 3, 0),     # Cout 128 with two cin halves per tap; H*W not a power of two
+    (2, 32, 32, 512, 512, 3, 0),     # 2x2 output tiles x 9 taps
+    (1, 64, 64, 256, 256, 3, 1),     # folded nearest-x2 upsample (activation is pre-upsample)
+    (1, 64, 64, 128, 128, 3, 1),
+    (1, 128, 128, 256, 128, 1, 0),   # 1x1 with a partially filled column-group triple
+    (1, 128, 64, 512, 256, 1, 0),    # 1x1, 256x256 tiles, W = 64
+    (1, 1, 8192, 1024, 256, 1, 0),   # Linear layer as a 1x1 conv over tokens (MLP wgrad)
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_pp_wgrad(case):
+    from dmvae_amd import ops
+    n, h, w_, cin, cout, ks, ups = case
+    g = torch.Generator().manual_seed(7 + cin)
+    ho, wo = (2 * h, 2 * w_) if ups else (h, w_)
+    a = torch.randn(n, h, w_, cin, generator=g).to(DEV).to(BF)
+    dy = torch.randn(n, ho, wo, cout, generator=g).to(DEV).to(BF)
+    # reference on the GPU in fp64 (same bf16-rounded operands); conv_transpose-free formulation via autograd
+    xr = a.double().permute(0, 3, 1, 2)
+    if ups:
+        xr = xr.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    wr = torch.zeros(cout, cin, ks, ks, dtype=torch.double, device=DEV, requires_grad=True)
+    br = torch.zeros(cout, dtype=torch.double, device=DEV, requires_grad=True)
+    F.conv2d(xr, wr, br, padding=ks // 2).backward(dy.double().permute(0, 3, 1, 2))
+    dw, db = ops.conv2d_nhwc_wgrad(dy, a, ks, upsample=bool(ups))
+    assert rel_err(dw, wr.grad) < 1e-5 and rel_err(db, br.grad) < 1e-5
+    dw2, _ = ops.conv2d_nhwc_wgrad(dy, a, ks, upsample=bool(ups))
+    assert torch.equal(dw, dw2)                       # deterministic split-K (fixed-order slab reduction)
