@@ -6,7 +6,7 @@
 Step = VAE forward (frozen ViT-L/16 encoder, bottleneck MLP, conv decoder) + L1 + LPIPS + backward + bucketed RCCL
 gradient all-reduce + clip + AdamW + EMA, bf16 compute, local batch 32 (train_tokenizer.py, config C2 of SURVEY.md 8),
 synthetic images, random-init weights of the reference architecture (no network for data / checkpoints).
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (implicit-GEMM conv forward/dgrad, MFMA-bound),
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (implicit-GEMM conv forward/dgrad, csrc/conv_pp.hip, MFMA-bound),
 timed with HIP events on its launch stream inside the timed region; `cpu_baseline` is the CPU oracle
 (oracle/ref_cpu.py, "port") running the same step at batch 1 on the host cores (rank 0, N=1 only).
 """
@@ -25,7 +25,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/M
 LOCAL_BATCH = 32
 
 
-def cpu_baseline(seconds_budget=40.0):
+def cpu_baseline(seconds_budget=30.0):
     """One fp32 tokenizer step (fwd + L1 + LPIPS + backward) of the CPU oracle at batch 1, all host cores."""
     import warnings
     from oracle import ref_cpu as R
@@ -57,7 +57,7 @@ def cpu_baseline(seconds_budget=40.0):
         loss.backward()
         n += 1
         dt = time.time() - t0
-        if dt > seconds_budget * 0.5 or n >= 2:
+        if dt > seconds_budget * 0.5 or n >= 8:
             break
     return {"value": round(n / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": f"{n} step(s) at batch 1 of the same tokenizer step (fp32, oracle/ref_cpu.py: ViT-L fwd + MLP + decoder fwd/bwd + L1 + LPIPS), "
@@ -119,7 +119,7 @@ def main():
                                "AdamW + EMA, ImageNet-256-shaped synthetic batch, random-init weights",
                    "local_batch": args.batch, "global_batch": world * args.batch, "image": "3x256x256", "z_channels": 32,
                    "parallelism": f"dp{world}", "loss_after_run": round(log["rec_loss"], 5)},
-        "roofline": {"bound": "mfma", "kernel": "dmvae_conv_fwd::conv_fwd_kernel (decoder conv forward + dgrad)",
+        "roofline": {"bound": "mfma", "kernel": "dmvae_conv_pp::conv_pp_kernel (decoder conv forward + dgrad launches through dmvae_conv2d_nhwc_fwd)",
                      "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                      "launches": len(timing), "avg_launch_us": round(k_ms * 1e3 / max(1, len(timing)), 2),
