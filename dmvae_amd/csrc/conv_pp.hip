@@ -35,12 +35,27 @@ struct Args {
   const bf16* res;    // [N, Ho, Wo, Cout] or null
   void* y;            // [N, Ho, Wo, Cout] bf16 or f32
   int N, Hi, Wi, Cin, Ho, Wo, Cout;
-  int ks, act, M, ctiles;
+  int ks, act, M, ctiles, total;  // total = pixel tiles x cout tiles
+  int stagger;                    // start delay per group of CUs, units of 64 cycles (0 = off)
+  unsigned long long* dbg;  // optional per-block s_memtime stamps (dmvae_debug_timing), null in production
 };
 
 constexpr unsigned SENT = 0x80000000u;  // voffset beyond any descriptor's num_records -> the DMA writes zeros
 
 __device__ __forceinline__ int swz64(int row) { return (row >> 2) & 3; }  // 64-B rows: 4 rows per 256-B bank row
+
+// q = m / d, r = m % d for 0 <= m < 2^24 (exact in f32) via one reciprocal and a +-1 fix-up; plain division otherwise
+__device__ __forceinline__ void divmod_small(int m, int d, float inv_d, bool small, int& q, int& r) {
+  if (small) {
+    q = (int)((float)m * inv_d);
+    r = m - q * d;
+    if (r < 0) { q--; r += d; }
+    if (r >= d) { q++; r -= d; }
+  } else {
+    q = m / d;
+    r = m - q * d;
+  }
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -66,10 +81,6 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   const int nchunk = a.Cin >> 5;
   const int nK = T * nchunk;
 
-  const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (int)(wid / a.ctiles) * TP;  // first pixel
-  const int n0 = (int)(wid % a.ctiles) * TM;  // first cout
-
   // ---- descriptors ---------------------------------------------------------------------------------------------
   const unsigned wbytes = (unsigned)a.Cout * T * a.Cin * 2u;
   const unsigned xbytes = (unsigned)a.N * a.Hi * a.Wi * a.Cin * 2u;
@@ -78,7 +89,24 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   const __amdgpu_buffer_rsrc_t rB =
       __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.x) - shift), 0, xbytes + shift, 0x00020000);
 
-  // ---- per-lane DMA sources (fixed for the whole kernel) ----------------------------------------------------------
+  // Persistent blocks: one per CU, each walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  Re-dispatching a 512-thread
+  // workgroup costs ~2 k cycles per XCD-serialised launch (measured 8-13 k cycle gaps between consecutive 76 k-cycle blocks
+  // of a CU, tools/probes/time_conv_pp.py); gridDim.x is a multiple of 8, so a block's tiles stay on one XCD's contiguous
+  // range of the XCD-aware order.
+  if (a.stagger > 0) {  // de-phase the CUs of an XCD so that their epilogue store bursts do not coincide
+    const int g = (blockIdx.x >> 3) & 7;
+    for (int i = 0; i < g * a.stagger; i++) __builtin_amdgcn_s_sleep(1);
+  }
+  for (unsigned work = blockIdx.x; work < (unsigned)a.total; work += gridDim.x) {
+  const unsigned wid = xcd_remap(work, a.total);
+  const int m0 = (int)(wid / a.ctiles) * TP;  // first pixel
+  const int n0 = (int)(wid % a.ctiles) * TM;  // first cout
+  auto stamp = [&](int k) {
+    if (a.dbg && tid == 0) a.dbg[(size_t)work * 8 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
+
+  // ---- per-lane DMA sources (fixed for the whole tile) ------------------------------------------------------------
   unsigned voffA[NPA];
 #pragma unroll
   for (int p = 0; p < NPA; p++) {
@@ -87,6 +115,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     const int c = (lane & 3) ^ swz64(row);  // logical 16-B chunk this lane fetches (LDS image stays lane-linear)
     voffA[p] = co < a.Cout ? (unsigned)co * T * a.Cin * 2u + c * 16u : SENT;
   }
+  const int hw = a.Ho * a.Wo;
+  const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)a.Wo;
+  const bool small_m = a.M < (1 << 24);
   unsigned ctrB[NPB], maskB[NPB], selB[NPB];
   unsigned rowo[UPS ? NPB : 1][3], colo[UPS ? NPB : 1][3];
 #pragma unroll
@@ -97,17 +128,13 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     unsigned mask = 0;
     ctrB[p] = 0;
     if (m < a.M) {
-      const int hw = a.Ho * a.Wo;
-      const int n = m / hw, r = m - n * hw;
-      const int y = r / a.Wo, x = r - y * a.Wo;
-      if (a.ks == 3) {
-#pragma unroll
-        for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-          for (int kx = 0; kx < 3; kx++) {
-            const int yy = y + ky - 1, xx = x + kx - 1;
-            if (yy >= 0 && yy < a.Ho && xx >= 0 && xx < a.Wo) mask |= 1u << (ky * 3 + kx);
-          }
+      int n, r, y, x;
+      divmod_small(m, hw, inv_hw, small_m, n, r);
+      divmod_small(r, a.Wo, inv_wo, small_m, y, x);
+      if (a.ks == 3) {  // bit ky*3+kx set when the tap stays inside the image
+        const unsigned rm = (y > 0 ? 0x007u : 0u) | 0x038u | (y < a.Ho - 1 ? 0x1C0u : 0u);
+        const unsigned cm = (x > 0 ? 0x049u : 0u) | 0x092u | (x < a.Wo - 1 ? 0x124u : 0u);
+        mask = rm & cm;
       } else {
         mask = 1;
       }
@@ -186,10 +213,12 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   };
 
   // ---- prologue ---------------------------------------------------------------------------------------------------
+  stamp(1);
 #pragma unroll
   for (int u = 0; u < PF; u++) issue(u * SLOT);
   wait_vmcnt<(PF - 1) * NP>();
   __builtin_amdgcn_s_barrier();                // B_0: everybody's pieces of tile 0 have landed
+  stamp(2);
   if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger group 1 by one interval
 
   // ---- main loop ------------------------------------------------------------------------------------------------------
@@ -214,7 +243,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    // COMPUTE interval
+    // COMPUTE interval (issuing the DMA from here, in the MFMA shadow, measured 5-8 % slower than from the LOAD interval)
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; kk++)
@@ -228,60 +257,93 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
+  stamp(3);
   if (grp == 0) __builtin_amdgcn_s_barrier();  // matches group 1's extra barrier
   wait_vmcnt<0>();                             // the trailing all-zero pieces
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA (inline asm, invisible to the hazard recognizer) -> accumulator reads
 
-  // ---- epilogue: lane owns pixel (l&31) of each pixel block and 4-cout quads ----------------------------------------------------
+  // ---- epilogue: accumulators -> LDS (f32, per-wave region) -> whole pixel rows, 16-B coalesced stores --------------------------
+  // The MFMA layout gives a lane 4 couts of one pixel: storing that directly touches 32 cache lines per instruction.  Staged
+  // through LDS each store instruction writes RPI full pixel rows of the wave's BM*32 couts instead.  Measured (s_memtime
+  // stamps, tools/probes/time_conv_pp.py): 11-13 k cycles per 128 KB tile = the CU's ~12 B/clk store-issue rate, independent
+  // of what other CUs do (de-phasing the CUs changes nothing) -- 12-14 % of a tile; hiding it needs a second resident tile.
+  __builtin_amdgcn_s_barrier();  // every wave's trailing DMA has landed: the ring is free
+  {
+    constexpr int CW = BM * 32;             // couts per wave
+    constexpr int ROWB = CW * 4 + 16;       // padded f32 row (bank-conflict-free ds_write_b128)
+    constexpr int LPR = CW / 8, RPI = 64 / LPR;
+    char* reg = smem + wave * (32 * ROWB);
+    const int px_w = lane & 31;
+    const int cl = lane % LPR, rg = lane / LPR;
+    const int cb = n0 + wm * (TM / WM) + cl * 8;  // this lane's 8 couts in the read phase
+    const bool c_ok = cb < a.Cout;
+    float bias8[8];
 #pragma unroll
-  for (int j = 0; j < BP; j++) {
-    const int m = m0 + wp * (TP / WP) + j * 32 + (lane & 31);
-    if (m >= a.M) continue;
+    for (int e = 0; e < 8; e++) bias8[e] = (a.bias && c_ok) ? a.bias[cb + e] : 0.f;
 #pragma unroll
-    for (int i = 0; i < BM; i++) {
+    for (int j = 0; j < BP; j++) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int cb = n0 + wm * (TM / WM) + i * 32 + 8 * q + 4 * kg;
-        if (cb >= a.Cout) continue;
-        float v[4];
+      for (int i = 0; i < BM; i++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * q + e];
-        if (a.bias) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + cb);
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += b[e];
+        for (int q = 0; q < 4; q++) {
+          f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          *reinterpret_cast<f32x4*>(reg + px_w * ROWB + (i * 32 + 8 * q + 4 * kg) * 4) = v;
         }
-        const size_t off = (size_t)m * a.Cout + cb;
-        if (a.res) {
-          const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.res + off);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS ops are ordered; the region is private to the wave
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += (float)r[e];
-        }
-        if (a.act == 1) {
+      for (int it2 = 0; it2 < 32 / RPI; it2++) {
+        const int px = it2 * RPI + rg;
+        const int m = m0 + wp * (TP / WP) + j * 32 + px;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + px * ROWB + cl * 32);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + px * ROWB + cl * 32 + 16);
+        if (m < a.M && c_ok) {
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = v[e] * sigmoidf_(v[e]);
-        } else if (a.act == 2) {
+          for (int e = 0; e < 8; e++) v[e] += bias8[e];
+          const size_t off = (size_t)m * a.Cout + cb;
+          if (a.res) {
+            const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(a.res + off);
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
-        }
-        if (OUT_F32) {
-          f32x4 o = {v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + off) = o;
-        } else {
-          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.y) + off) = o;
+            for (int e = 0; e < 8; e++) v[e] += (float)r8[e];
+          }
+          if (a.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = v[e] * sigmoidf_(v[e]);
+          } else if (a.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          if (OUT_F32) {
+            float* yo = reinterpret_cast<float*>(a.y) + off;
+            *reinterpret_cast<f32x4*>(yo) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(yo + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          } else {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (bf16)v[e];
+            // non-temporal: the tile is next read by a later kernel, after far more than an L2 of other traffic
+            __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.y) + off));
+          }
         }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads retired before the next block overwrites the region
     }
   }
+  stamp(4);
+  if (a.dbg) { wait_vmcnt<0>(); stamp(5); }
+  __builtin_amdgcn_s_barrier();  // staging reads done before the next tile's DMA reuses the LDS
+  }  // persistent tile loop
 #endif
 }
 
 template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32>
 int launch(Args a, hipStream_t st) {
   a.ctiles = (a.Cout + TM - 1) / TM;
-  const unsigned grid = (unsigned)((a.M + TP - 1) / TP) * a.ctiles;
-  constexpr int lds = NBUF * (TM + TP) * 64;
+  a.total = ((a.M + TP - 1) / TP) * a.ctiles;
+  static const int persist = [] { const char* e = getenv("DMVAE_PP_GRID"); return e ? atoi(e) : 256; }();  // 0: one block per tile
+  const unsigned grid = (persist > 0 && a.total > persist) ? (unsigned)persist : (unsigned)a.total;
+  constexpr int ring = NBUF * (TM + TP) * 64, epi = 8 * 32 * ((TM / WM) * 4 + 16);
+  constexpr int lds = ring > epi ? ring : epi;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32>),
@@ -295,13 +357,16 @@ int launch(Args a, hipStream_t st) {
 
 template <bool UPS, bool F32>
 int pick(const Args& a, hipStream_t st) {
-  if (a.Cout <= 128) return launch<128, 512, 2, 4, 3, UPS, F32>(a, st);
+  if (a.Cout <= 128) return launch<128, 512, 2, 4, 4, UPS, F32>(a, st);  // 160 KiB of LDS: the whole CU
   return launch<256, 256, 2, 4, 4, UPS, F32>(a, st);
 }
 
 }  // namespace dmvae_conv_pp
 
 // Entry used by dmvae_conv2d_nhwc_fwd (conv_fwd.hip) for the shapes this kernel covers; returns 1 when it declines.
+static unsigned long long* g_dbg = nullptr;
+extern "C" void dmvae_debug_timing(void* buf) { g_dbg = (unsigned long long*)buf; }  // diagnostics only (tools/probes/time_conv_pp.py)
+
 int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void* residual, void* y, const dmvae_conv_desc* d,
                       hipStream_t stream) {
   using namespace dmvae_conv_pp;
@@ -311,12 +376,13 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
   const long long M = (long long)d->n * d->h * d->w * (ups ? 4 : 1);
   const long long xbytes = (long long)d->n * d->h * d->w * d->cin * 2;
   const long long wbytes = (long long)d->cout * d->ks * d->ks * d->cin * 2;
-  if (d->cin % 32 != 0 || d->cout < 64 || M < 16384 || xbytes + (1ll << 22) >= (1ll << 31) || wbytes >= (1ll << 31)) return 1;
+  if (d->cin % 32 != 0 || d->cout < 64 || d->cout % 8 != 0 || M < 16384 || xbytes + (1ll << 22) >= (1ll << 31) || wbytes >= (1ll << 31)) return 1;
   Args a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.res = (const bf16*)residual; a.y = y;
   a.N = d->n; a.Hi = d->h; a.Wi = d->w; a.Cin = d->cin; a.Cout = d->cout;
   a.Ho = ups ? 2 * d->h : d->h; a.Wo = ups ? 2 * d->w : d->w;
-  a.ks = d->ks; a.act = d->act; a.M = (int)M; a.ctiles = 0;
+  a.ks = d->ks; a.act = d->act; a.M = (int)M; a.ctiles = 0; a.dbg = g_dbg;
+  { static const int stag = [] { const char* e = getenv("DMVAE_PP_STAGGER"); return e ? atoi(e) : 0; }(); a.stagger = stag; }
   const bool f32 = d->out_f32 != 0;
   if (ups) return f32 ? pick<true, true>(a, stream) : pick<true, false>(a, stream);
   return f32 ? pick<false, true>(a, stream) : pick<false, false>(a, stream);
