@@ -64,6 +64,53 @@ def cpu_baseline(seconds_budget=30.0):
                       f"{dt:.1f} s on {threads} threads"}
 
 
+def kl_mmd_roofline(dev):
+    """The build-defined KL + MMD op, timed with HIP events on its launch stream:
+    (1) the fused call at the step's real shape (B=32 images x 256 latent tokens x 32 channels vs 256 prior samples);
+    (2) the HBM-bound part alone -- the KL moment pass + its gradient -- on a tensor larger than the 256 MB Infinity Cache;
+    (3) the pairwise (VALU/exp-bound) kernel at a large batch.  Algorithmic bytes: z and y read once, dz written once (fused call);
+    z read by the moment pass, z read + dz written by the gradient pass (KL-only)."""
+    from dmvae_amd import ops
+    HBM_PEAK = 8000.0
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3     # us
+
+    out = {}
+    z = torch.randn(32, 256, 32, device=dev) * 0.7 + 0.2
+    y = torch.randn(32, 256, 32, device=dev)
+    us = timed(lambda: ops.kl_mmd(z, y, need_grad=True), 50)
+    byt = 3 * z.numel() * 4
+    pairs = 32 * 3 * 256 * 256
+    out["fused_B32"] = {"shape": "G=32 n=m=256 d=32, value+grad", "us_per_call": round(us, 1), "algorithmic_MB": round(byt / 1e6, 2),
+                        "achieved_GBps": round(byt / us / 1e3, 1), "hbm_frac": round(byt / us / 1e3 / HBM_PEAK, 4),
+                        "Gpair_per_s": round(pairs / us / 1e3, 1), "bound": "valu/exp + launch (5 launches), not HBM: see DESIGN.md 3.4"}
+    zl = torch.randn(8192, 256, 32, device=dev)       # 268 MB
+    us = timed(lambda: ops.kl_mmd(zl, None, need_grad=True), 10)
+    byt = 3 * zl.numel() * 4
+    out["kl_pass_268MB"] = {"shape": "G=8192 n=256 d=32, KL moments + gradient only", "us_per_call": round(us, 1),
+                            "algorithmic_MB": round(byt / 1e6, 1), "achieved_GBps": round(byt / us / 1e3, 1),
+                            "hbm_frac": round(byt / us / 1e3 / HBM_PEAK, 4), "bound": "hbm"}
+    del zl
+    zb = torch.randn(1024, 256, 32, device=dev)
+    yb = torch.randn(1024, 256, 32, device=dev)
+    us = timed(lambda: ops.kl_mmd(zb, yb, need_grad=True), 5)
+    byt = 3 * zb.numel() * 4
+    pairs = 1024 * 3 * 256 * 256
+    out["fused_B1024"] = {"shape": "G=1024 n=m=256 d=32, value+grad", "us_per_call": round(us, 1), "algorithmic_MB": round(byt / 1e6, 1),
+                          "achieved_GBps": round(byt / us / 1e3, 1), "hbm_frac": round(byt / us / 1e3 / HBM_PEAK, 4),
+                          "Gpair_per_s": round(pairs / us / 1e3, 1), "bound": "valu/exp"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,6 +172,8 @@ def main():
                      "launches": len(timing), "avg_launch_us": round(k_ms * 1e3 / max(1, len(timing)), 2),
                      "share_of_step": round(k_ms / (dt * 1e3), 3)},
     }
+    if world == 1:
+        out["kl_mmd"] = kl_mmd_roofline(dev)
     if world == 1 and not args.no_cpu_baseline:
         del tr, images
         torch.cuda.empty_cache()

@@ -42,6 +42,7 @@ SIGNATURES = {
     "dmvae_lpips_diff": (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dmvae_dmd_pre": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "dmvae_dmd_post": (c_int, [c_void_p] * 10 + [c_size_t, c_int, c_int, c_float, c_int, c_void_p]),
+    "dmvae_kl_mmd_workspace": (c_size_t, [c_int, c_int, c_int]),
     "dmvae_kl_mmd": (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "dmvae_grad_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_int, c_void_p]),
     "dmvae_adamw_ema_step": (c_int, [c_void_p] * 6 + [c_size_t] + [c_float] * 5 + [c_int, c_float, c_void_p]),

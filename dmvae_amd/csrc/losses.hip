@@ -183,86 +183,80 @@ __global__ void dmd_final_kernel(const float* __restrict__ out_s, float* __restr
   if (threadIdx.x == 0) { out[0] = (float)(0.5 * a * inv_numel); out[1] = (float)(c / B); }
 }
 
-// ---- fused per-latent KL moments + batched RBF-mixture MMD (build-defined) ---------------------------
-// One block per group g (image): X_g = z[g] [n][d] (d == 32), Y_g = y[g] [m][d].
-//   mom[g][c][0..1] = sum_r z, sum_r z^2   (KL batch moments, finalised by kl_final_kernel)
-//   mmd[g] = mean k(x,x) + mean k(y,y) - 2 mean k(x,y),  k = mean_j exp(-|a-b|^2/(2*mult_j*d)), mult = {.5,1,2,4,8}
-// Each thread owns one x row in registers (n <= 256) and streams y (and x) rows from LDS.
+// ---- per-latent KL of batch moments + batched RBF-mixture MMD (build-defined) -------------------------
+//   kl[c]  = 0.5*(mu_c^2 + var_c - 1 - ln var_c), moments over all G*n rows of z [G][n][32]          (HBM-bound pass)
+//   mmd[g] = mean k(x,x) + mean k(y,y) - 2 mean k(x,y),  k(a,b) = mean_j exp(-|a-b|^2 / (2*mult_j*d)), mult = {.5,1,2,4,8}
+//   dz     = w_kl * d mean_c(kl_c)/dz + w_mmd * d mean_g(mmd_g)/dz
+// Roofline note: compulsory traffic is (G*n + G*m + G*n)*32*4 B, but the pair work is G*(n^2+nm+m^2) kernel
+// evaluations of ~46-78 VALU lane-ops each: at n = m = 256 the kernel is VALU/exp-bound, not HBM-bound; only the moments
+// pass (and MMD with small groups) can approach the HBM roofline.
+//
+// Launches: kl_moments (grid-stride, 16-B loads) -> kl_final -> mmd_pair (one workgroup per (group, pair-type, 128-row
+// tile)) -> kl_mmd_final.  Everything is fixed-order (no float atomics): run-to-run bit-exact.
 constexpr int MMD_D = 32;
-__device__ __forceinline__ float rbf_mix(float d2, float inv16d) {
-  // mult 8 -> exp(-d2/(16 d)); each halving of the bandwidth squares the kernel value
-  const float e8 = __expf(-d2 * inv16d);
-  const float e4 = e8 * e8, e2 = e4 * e4, e1 = e2 * e2, eh = e1 * e1;
-  return 0.2f * (e8 + e4 + e2 + e1 + eh);
-}
-__global__ __launch_bounds__(256) void kl_mmd_kernel(const float* __restrict__ z, const float* __restrict__ y,
-                                                     float* __restrict__ mom, float* __restrict__ mmd, int n, int m) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* xs = sm;                 // [n][33]
-  float* ys = sm + (size_t)n * 33;  // [m][33]
-  __shared__ float sh[4];
-  const int g = blockIdx.x;
-  const float* zg = z + (size_t)g * n * MMD_D;
-  const float* yg = y + (size_t)g * m * MMD_D;
-  for (int i = threadIdx.x; i < n * MMD_D; i += 256) xs[(i >> 5) * 33 + (i & 31)] = zg[i];
-  for (int i = threadIdx.x; i < m * MMD_D; i += 256) ys[(i >> 5) * 33 + (i & 31)] = yg[i];
+constexpr int MMD_ROWS = 128;   // rows per workgroup: 2 per lane
+constexpr int MMD_CCH = 256;    // columns staged in LDS per chunk
+constexpr int MMD_NQ = 4;       // column slices = waves per workgroup (2 workgroups share a CU: one stages / reduces while the other computes)
+
+// part[b][c][0..1] = sum, sum of squares over the block's rows; z viewed as [R][32]
+__global__ __launch_bounds__(256) void kl_moments_kernel(const float* __restrict__ z, float* __restrict__ part, size_t R) {
+  __shared__ float red[32][8][8];
+  const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3;  // 8 lanes x float4 per row, 32 rows per sweep
+  float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * 32;
+  size_t r = (size_t)blockIdx.x * 32 + rl;
+  for (; r + 3 * stride < R; r += 4 * stride) {  // four independent 16-B loads in flight per lane
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + (r + u * stride) * MMD_D + cq * 4));
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) { s[e] += v[u][e]; ss[e] += v[u][e] * v[u][e]; }
+  }
+  for (; r < R; r += stride) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(z + r * MMD_D + cq * 4);
+#pragma unroll
+    for (int e = 0; e < 4; e++) { s[e] += v[e]; ss[e] += v[e] * v[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) { red[rl][cq][e] = s[e]; red[rl][cq][4 + e] = ss[e]; }
   __syncthreads();
-  // KL moments: thread c<32 handles channel c (column sums over n rows); 8 row-slices x 32 channels
-  {
-    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    float s = 0.f, ss = 0.f;
-    for (int r = sl; r < n; r += 8) { const float v = xs[r * 33 + c]; s += v; ss += v * v; }
-    __shared__ float ms[8][32][2];
-    ms[sl][c][0] = s; ms[sl][c][1] = ss;
-    __syncthreads();
-    if (threadIdx.x < 32) {
-      float a = 0.f, b = 0.f;
-      for (int k = 0; k < 8; k++) { a += ms[k][c][0]; b += ms[k][c][1]; }
-      mom[((size_t)g * MMD_D + c) * 2] = a; mom[((size_t)g * MMD_D + c) * 2 + 1] = b;
-    }
+  if (threadIdx.x < 64) {
+    const int c = threadIdx.x & 31, w = threadIdx.x >> 5;  // channel, 0: sum / 1: sum of squares
+    float a = 0.f;
+    for (int r = 0; r < 32; r++) a += red[r][c >> 2][w * 4 + (c & 3)];
+    part[((size_t)blockIdx.x * MMD_D + c) * 2 + w] = a;
   }
-  const float inv16d = 1.f / (16.f * MMD_D);
-  float kxx = 0.f, kxy = 0.f, kyy = 0.f;
-  const int i = threadIdx.x;
-  float xi[MMD_D], yi[MMD_D];
-  if (i < n) {
-#pragma unroll
-    for (int e = 0; e < MMD_D; e++) xi[e] = xs[i * 33 + e];
-    for (int j = 0; j < n; j++) {
-      float d2 = 0.f;
-#pragma unroll
-      for (int e = 0; e < MMD_D; e++) { const float d = xi[e] - xs[j * 33 + e]; d2 += d * d; }
-      kxx += rbf_mix(d2, inv16d);
-    }
-    for (int j = 0; j < m; j++) {
-      float d2 = 0.f;
-#pragma unroll
-      for (int e = 0; e < MMD_D; e++) { const float d = xi[e] - ys[j * 33 + e]; d2 += d * d; }
-      kxy += rbf_mix(d2, inv16d);
-    }
-  }
-  if (i < m) {
-#pragma unroll
-    for (int e = 0; e < MMD_D; e++) yi[e] = ys[i * 33 + e];
-    for (int j = 0; j < m; j++) {
-      float d2 = 0.f;
-#pragma unroll
-      for (int e = 0; e < MMD_D; e++) { const float d = yi[e] - ys[j * 33 + e]; d2 += d * d; }
-      kyy += rbf_mix(d2, inv16d);
-    }
-  }
-  kxx = block_sum_256(kxx, sh);
-  kxy = block_sum_256(kxy, sh);
-  kyy = block_sum_256(kyy, sh);
-  if (threadIdx.x == 0) mmd[g] = kxx / ((float)n * n) + kyy / ((float)m * m) - 2.f * kxy / ((float)n * m);
 }
-// kl[c] = 0.5*(mu^2 + var - 1 - ln var) from moments over all G*n rows; kl[C] = mean_c ; also stats[c] = (mu, var)
-__global__ void kl_final_kernel(const float* __restrict__ mom, float* __restrict__ kl, float* __restrict__ stats, int G, double rows) {
-  const int c = threadIdx.x;  // 32 threads... launched with 64
+
+// kl[c] from the moment partials; kl[32] = mean_c; stats[c] = (mu, var).  1024 threads: 16 strided part-lanes per (channel,
+// moment), four independent loads in flight each (a serial loop over 2048 partials costs > 100 us of pure load latency)
+__global__ __launch_bounds__(1024) void kl_final_kernel(const float* __restrict__ mom, float* __restrict__ kl, float* __restrict__ stats,
+                                                        int nparts, double rows) {
+  __shared__ double sh[16][64];
+  const int cm = threadIdx.x & 63, pl = threadIdx.x >> 6;  // cm = channel*2 + moment (the partials' inner layout)
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int g = pl;
+  for (; g + 48 < nparts; g += 64) {
+    const float v0 = mom[(size_t)g * 64 + cm], v1 = mom[(size_t)(g + 16) * 64 + cm], v2 = mom[(size_t)(g + 32) * 64 + cm],
+                v3 = mom[(size_t)(g + 48) * 64 + cm];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; g < nparts; g += 16) a0 += mom[(size_t)g * 64 + cm];
+  sh[pl][cm] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double t = 0.0;
+    for (int k = 0; k < 16; k++) t += sh[k][threadIdx.x];
+    sh[0][threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int c = threadIdx.x;
   double v = 0.0;
   if (c < MMD_D) {
-    double s = 0.0, ss = 0.0;
-    for (int g = 0; g < G; g++) { s += mom[((size_t)g * MMD_D + c) * 2]; ss += mom[((size_t)g * MMD_D + c) * 2 + 1]; }
+    const double s = sh[0][2 * c], ss = sh[0][2 * c + 1];
     const double mu = s / rows;
     double var = ss / rows - mu * mu;
     if (var < 1e-30) var = 1e-30;
@@ -274,48 +268,184 @@ __global__ void kl_final_kernel(const float* __restrict__ mom, float* __restrict
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   if (c == 0) kl[MMD_D] = (float)(v / MMD_D);
 }
-// dz[g][i][:] = w_kl * d(mean_c kl_c)/dz + w_mmd * d(mean_g mmd_g)/dz
-__global__ __launch_bounds__(256) void kl_mmd_bwd_kernel(const float* __restrict__ z, const float* __restrict__ y,
-                                                         const float* __restrict__ stats, float* __restrict__ dz, int n, int m,
-                                                         int G, float w_kl, float w_mmd) {
+
+// One workgroup = (group g, pair type, 128-row tile).  type 0: rows x / cols x (value + gradient), 1: rows x / cols y (value +
+// gradient), 2: rows y / cols y (value).  Lane l of every wave holds rows l and l+64 of the tile in registers; wave q sweeps
+// column slice q of the LDS-staged column chunk with wave-uniform (broadcast) ds_read_b128.
+//   d2 = |a|^2 + |b|^2 - 2 a.b      k = mean_j e_j,  e_8 = exp(-d2/(16 d)), e_4 = e_8^2, ... (each halving of the bandwidth squares)
+//   w  = mean_j e_j / (mult_j d)    (so that dk/da = -w (a - b));  per row: S = sum k, SW = sum w, SB = sum w b
+// Outputs: ksum[g][tile] = sum of k over the tile (fixed order), gpart[type][g][row][:] = a*SW - SB = sum_j w (a - b_j).
+template <bool GRAD>
+__global__ __launch_bounds__(256, 2) void mmd_pair_kernel(const float* __restrict__ z, const float* __restrict__ y, float* __restrict__ ksum,
+                                                       float* __restrict__ gpart, int n, int m, int tiles_x, int tiles_y) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* xs = sm;
-  float* ys = sm + (size_t)n * 33;
-  const int g = blockIdx.x;
-  const float* zg = z + (size_t)g * n * MMD_D;
-  const float* yg = y + (size_t)g * m * MMD_D;
-  for (int i = threadIdx.x; i < n * MMD_D; i += 256) xs[(i >> 5) * 33 + (i & 31)] = zg[i];
-  for (int i = threadIdx.x; i < m * MMD_D; i += 256) ys[(i >> 5) * 33 + (i & 31)] = yg[i];
-  __syncthreads();
-  const int i = threadIdx.x;
-  if (i >= n) return;
-  const float inv16d = 1.f / (16.f * MMD_D);
-  float xi[MMD_D], gr[MMD_D];
+  float* cols = sm;                          // [MMD_CCH][32]
+  float* cnorm = sm + MMD_CCH * MMD_D;       // [MMD_CCH]
+  constexpr int SCR = 2 * MMD_ROWS * 34 > MMD_CCH * MMD_D + MMD_CCH ? 2 * MMD_ROWS * 34 : MMD_CCH * MMD_D + MMD_CCH;
+  float* sc = sm + SCR;                      // [MMD_NQ] tile-sum scalars, above both uses of the region below
+  float* red = sm;                           // [2][MMD_ROWS][34] gradient scratch, aliases cols/cnorm once the sweep is over
+  const int g = blockIdx.y, tile = blockIdx.x;
+  const int type = tile < tiles_x ? 0 : (tile < 2 * tiles_x ? 1 : 2);
+  const int rt = type == 0 ? tile : (type == 1 ? tile - tiles_x : tile - 2 * tiles_x);
+  const float* rsrc = type == 2 ? y + (size_t)g * m * MMD_D : z + (size_t)g * n * MMD_D;
+  const float* csrc = type == 0 ? z + (size_t)g * n * MMD_D : y + (size_t)g * m * MMD_D;
+  const int nrows = type == 2 ? m : n, ncols = type == 0 ? n : m;
+  const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r0 = rt * MMD_ROWS + lane, r1 = r0 + 64;
+
+  float a0[MMD_D], a1[MMD_D], na0 = 0.f, na1 = 0.f;
 #pragma unroll
-  for (int e = 0; e < MMD_D; e++) { xi[e] = xs[i * 33 + e]; gr[e] = 0.f; }
-  // d k(a,b)/da = -(a-b) * sum_j (1/5) k_j / (mult_j * d) ; with mult = 8,4,2,1,.5
-  const float cxx = 2.f / ((float)n * n), cxy = -2.f / ((float)n * m);
-  for (int pass = 0; pass < 2; pass++) {
-    const float* os = pass == 0 ? xs : ys;
-    const int cnt = pass == 0 ? n : m;
-    const float coef = pass == 0 ? cxx : cxy;
-    for (int j = 0; j < cnt; j++) {
-      float d[MMD_D], d2 = 0.f;
+  for (int e4 = 0; e4 < MMD_D / 4; e4++) {
+    const f32x4 v0 = r0 < nrows ? *reinterpret_cast<const f32x4*>(rsrc + (size_t)r0 * MMD_D + e4 * 4) : f32x4{0, 0, 0, 0};
+    const f32x4 v1 = r1 < nrows ? *reinterpret_cast<const f32x4*>(rsrc + (size_t)r1 * MMD_D + e4 * 4) : f32x4{0, 0, 0, 0};
 #pragma unroll
-      for (int e = 0; e < MMD_D; e++) { d[e] = xi[e] - os[j * 33 + e]; d2 += d[e] * d[e]; }
-      const float e8 = __expf(-d2 * inv16d);
-      const float e4 = e8 * e8, e2 = e4 * e4, e1 = e2 * e2, eh = e1 * e1;
-      const float kp = -0.2f * (e8 * 0.125f + e4 * 0.25f + e2 * 0.5f + e1 + eh * 2.f) / (float)MMD_D * coef;
-#pragma unroll
-      for (int e = 0; e < MMD_D; e++) gr[e] += kp * d[e];
+    for (int e = 0; e < 4; e++) {
+      a0[e4 * 4 + e] = v0[e]; a1[e4 * 4 + e] = v1[e];
+      na0 += v0[e] * v0[e]; na1 += v1[e] * v1[e];
     }
   }
-  const double rows = (double)G * n;
+  float s0 = 0.f, s1 = 0.f, sw0 = 0.f, sw1 = 0.f;
+  float sb0[GRAD ? MMD_D : 1], sb1[GRAD ? MMD_D : 1];
+  if (GRAD) {
 #pragma unroll
-  for (int e = 0; e < MMD_D; e++) {
-    const float mu = stats[e * 2], var = stats[e * 2 + 1];
-    const float dkl = (mu + (1.f - 1.f / var) * (xi[e] - mu)) / (float)rows / (float)MMD_D;
-    dz[((size_t)g * n + i) * MMD_D + e] = w_kl * dkl + w_mmd * gr[e] / (float)G;
+    for (int e = 0; e < MMD_D; e++) { sb0[GRAD ? e : 0] = 0.f; sb1[GRAD ? e : 0] = 0.f; }
+  }
+  const float inv16d = 1.f / (16.f * MMD_D), invd = 1.f / (float)MMD_D;
+
+  for (int c0 = 0; c0 < ncols; c0 += MMD_CCH) {
+    const int cc = min(MMD_CCH, ncols - c0);
+    // stage the column chunk: 8 lanes x float4 per column row, squared norms by an 8-lane shuffle
+    for (int i = threadIdx.x; i < MMD_CCH * 8; i += 256) {
+      const int j = i >> 3, e4 = i & 7;
+      f32x4 v = {0, 0, 0, 0};
+      if (j < cc) v = *reinterpret_cast<const f32x4*>(csrc + (size_t)(c0 + j) * MMD_D + e4 * 4);
+      *reinterpret_cast<f32x4*>(cols + j * MMD_D + e4 * 4) = v;
+      float p = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+      p += __shfl_xor(p, 1, 64); p += __shfl_xor(p, 2, 64); p += __shfl_xor(p, 4, 64);
+      if (e4 == 0) cnorm[j] = p;
+    }
+    __syncthreads();
+    const int cpw = MMD_CCH / MMD_NQ;
+    const int j1 = min(cc, (q + 1) * cpw);
+    // software-pipelined column fetch: column j+1 is in flight (LDS broadcast reads) while column j is evaluated
+    f32x4 bq[MMD_D / 4];
+    float nbq = 0.f;
+    {
+      const int jf = min(q * cpw, MMD_CCH - 1);
+#pragma unroll
+      for (int e4 = 0; e4 < MMD_D / 4; e4++) bq[e4] = *reinterpret_cast<const f32x4*>(cols + jf * MMD_D + e4 * 4);
+      nbq = cnorm[jf];
+    }
+    for (int j = q * cpw; j < j1; j++) {
+      float b[MMD_D];
+#pragma unroll
+      for (int e4 = 0; e4 < MMD_D / 4; e4++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) b[e4 * 4 + e] = bq[e4][e];
+      const float nb = nbq;
+      {
+        const int jn = min(j + 1, MMD_CCH - 1);  // wave-uniform address: LDS broadcast
+#pragma unroll
+        for (int e4 = 0; e4 < MMD_D / 4; e4++) bq[e4] = *reinterpret_cast<const f32x4*>(cols + jn * MMD_D + e4 * 4);
+        nbq = cnorm[jn];
+      }
+      float d0a = 0.f, d0b = 0.f, d1a = 0.f, d1b = 0.f;  // two partial chains per row for ILP
+#pragma unroll
+      for (int e = 0; e < MMD_D; e += 2) {
+        d0a = fmaf(a0[e], b[e], d0a); d0b = fmaf(a0[e + 1], b[e + 1], d0b);
+        d1a = fmaf(a1[e], b[e], d1a); d1b = fmaf(a1[e + 1], b[e + 1], d1b);
+      }
+      const float q0 = fmaxf(na0 + nb - 2.f * (d0a + d0b), 0.f), q1 = fmaxf(na1 + nb - 2.f * (d1a + d1b), 0.f);
+      const float e8 = __expf(-q0 * inv16d), f8 = __expf(-q1 * inv16d);
+      const float e4 = e8 * e8, e2 = e4 * e4, e1 = e2 * e2, eh = e1 * e1;
+      const float f4 = f8 * f8, f2 = f4 * f4, f1 = f2 * f2, fh = f1 * f1;
+      s0 += 0.2f * (e8 + e4 + e2 + e1 + eh);
+      s1 += 0.2f * (f8 + f4 + f2 + f1 + fh);
+      if (GRAD) {
+        const float w0 = 0.2f * invd * (0.125f * e8 + 0.25f * e4 + 0.5f * e2 + e1 + 2.f * eh);
+        const float w1 = 0.2f * invd * (0.125f * f8 + 0.25f * f4 + 0.5f * f2 + f1 + 2.f * fh);
+        sw0 += w0; sw1 += w1;
+#pragma unroll
+        for (int e = 0; e < MMD_D; e++) { sb0[GRAD ? e : 0] = fmaf(w0, b[e], sb0[GRAD ? e : 0]); sb1[GRAD ? e : 0] = fmaf(w1, b[e], sb1[GRAD ? e : 0]); }
+      }
+    }
+    __syncthreads();
+  }
+  if (r0 >= nrows) s0 = 0.f;
+  if (r1 >= nrows) s1 = 0.f;
+  // ---- tile sum of k: wave shuffle, then the 8 waves in fixed order ---------------------------------------------------------------
+  float st = wave_sum(s0 + s1);
+  if (lane == 0) sc[q] = st;
+  // ---- per-row gradient sums across the 4 column slices: two scratch slots, two fixed-order rounds ---------------------------------
+  if (GRAD && type != 2) {
+    float* slot = red + (size_t)(q & 1) * MMD_ROWS * 34;
+    if (q < 2) {
+#pragma unroll
+      for (int e = 0; e < MMD_D; e++) { slot[lane * 34 + e] = sb0[GRAD ? e : 0]; slot[(lane + 64) * 34 + e] = sb1[GRAD ? e : 0]; }
+      slot[lane * 34 + 32] = sw0; slot[(lane + 64) * 34 + 32] = sw1;
+    }
+    __syncthreads();
+    if (q >= 2) {
+#pragma unroll
+      for (int e = 0; e < MMD_D; e++) { slot[lane * 34 + e] += sb0[GRAD ? e : 0]; slot[(lane + 64) * 34 + e] += sb1[GRAD ? e : 0]; }
+      slot[lane * 34 + 32] += sw0; slot[(lane + 64) * 34 + 32] += sw1;
+    }
+    __syncthreads();
+    const int r = threadIdx.x >> 1, ch = threadIdx.x & 1;  // row, channel half
+    const int rg = rt * MMD_ROWS + r;
+    if (rg < nrows) {
+      const float* s0p = red + r * 34;
+      const float* s1p = red + (size_t)MMD_ROWS * 34 + r * 34;
+      const float SW = s0p[32] + s1p[32];
+      const float* ar = rsrc + (size_t)rg * MMD_D + ch * 16;
+      float* o = gpart + (((size_t)type * gridDim.y + g) * n + rg) * MMD_D + ch * 16;
+#pragma unroll
+      for (int e = 0; e < 16; e++) o[e] = ar[e] * SW - (s0p[ch * 16 + e] + s1p[ch * 16 + e]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < MMD_NQ; k++) t += sc[k];
+    ksum[(size_t)g * gridDim.x + tile] = t;
+  }
+}
+
+// mmd[g] from the tile sums (grid.x = G, 64 threads); dz from the gradient partials (grid-stride over G*n*8 float4s)
+__global__ void mmd_final_kernel(const float* __restrict__ ksum, float* __restrict__ mmd, int n, int m, int tiles_x, int tiles_y) {
+  const int g = blockIdx.x, nt = 2 * tiles_x + tiles_y;
+  if (threadIdx.x != 0) return;
+  double kxx = 0, kxy = 0, kyy = 0;
+  for (int t = 0; t < tiles_x; t++) { kxx += ksum[(size_t)g * nt + t]; kxy += ksum[(size_t)g * nt + tiles_x + t]; }
+  for (int t = 0; t < tiles_y; t++) kyy += ksum[(size_t)g * nt + 2 * tiles_x + t];
+  mmd[g] = (float)(kxx / ((double)n * n) + kyy / ((double)m * m) - 2.0 * kxy / ((double)n * m));
+}
+__global__ __launch_bounds__(256) void kl_mmd_grad_kernel(const float* __restrict__ z, const float* __restrict__ gpart,
+                                                          const float* __restrict__ stats, float* __restrict__ dz, int G, int n, int m,
+                                                          float w_kl, float w_mmd) {
+  const size_t total4 = (size_t)G * n * (MMD_D / 4);
+  const float rows = (float)G * (float)n;
+  // d mmd_g / dx_i = -(2/n^2) * gp_xx[i] + (2/(n m)) * gp_xy[i]   with gp = sum_j w (a - b_j)
+  const float cxx = -2.f / ((float)n * (float)n) * w_mmd / (float)G, cxy = 2.f / ((float)n * (float)m) * w_mmd / (float)G;
+  const float* gxx = gpart;
+  const float* gxy = gpart + (size_t)G * n * MMD_D;
+  // blockDim * gridDim is a multiple of 8, so a thread always owns the same channel quad: hoist its moments
+  const int c4 = (int)(threadIdx.x & 7) * 4;
+  float mu[4], slope[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    mu[e] = stats[(c4 + e) * 2];
+    slope[e] = 1.f - 1.f / stats[(c4 + e) * 2 + 1];
+  }
+  const float kscale = w_kl / rows / (float)MMD_D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z) + i);
+    f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+    if (gpart) { a = reinterpret_cast<const f32x4*>(gxx)[i]; b = reinterpret_cast<const f32x4*>(gxy)[i]; }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e] = kscale * (mu[e] + slope[e] * (x[e] - mu[e])) + cxx * a[e] + cxy * b[e];
+    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dz) + i);
   }
 }
 
@@ -389,28 +519,68 @@ extern "C" int dmvae_dmd_post(const void* x1, const void* xt, const void* t, con
   return 0;
 }
 
+static inline void kl_mmd_plan(int groups, int n, int m, int* tx, int* ty, int* nmom) {
+  *tx = (n + MMD_ROWS - 1) / MMD_ROWS;
+  *ty = (m + MMD_ROWS - 1) / MMD_ROWS;
+  size_t R = (size_t)groups * n;
+  size_t nb = (R + 255) / 256;  // >= 8 row sweeps per block
+  *nmom = (int)(nb > 2048 ? 2048 : (nb < 1 ? 1 : nb));
+}
+// layout (floats): mom[nmom][32][2] | stats[64] | ksum[G][2tx+ty] | gpart[2][G][n][32]
+extern "C" size_t dmvae_kl_mmd_workspace(int groups, int n, int m) {
+  if (groups <= 0 || n <= 0 || m < 0) return 0;
+  int tx, ty, nmom;
+  kl_mmd_plan(groups, n, m, &tx, &ty, &nmom);
+  return ((size_t)nmom * MMD_D * 2 + 64 + (size_t)groups * (2 * tx + ty) + (size_t)2 * groups * n * MMD_D) * sizeof(float);
+}
+
 extern "C" int dmvae_kl_mmd(const void* z, const void* y, void* kl, void* mmd, void* dz, void* workspace, size_t workspace_bytes,
                             int groups, int n, int m, int d, float w_kl, float w_mmd, hipStream_t stream) {
-  DMVAE_CHECK_ARG(z && y && kl && mmd && workspace, "kl_mmd: null pointer");
+  const bool kl_only = m == 0;  // m = 0 (y, mmd may be NULL): the KL moment pass and its gradient alone
+  DMVAE_CHECK_ARG(z && kl && workspace && (kl_only || (y && mmd)), "kl_mmd: null pointer");
   DMVAE_CHECK_ARG(d == MMD_D, "kl_mmd: latent width must be %d (got %d)", MMD_D, d);
-  DMVAE_CHECK_ARG(groups > 0 && n > 0 && n <= 256 && m > 0 && m <= 256, "kl_mmd: need 0 < n,m <= 256 per group");
-  const size_t need = ((size_t)groups * MMD_D * 2 + MMD_D * 2) * sizeof(float);
-  DMVAE_CHECK_ARG(workspace_bytes >= need, "kl_mmd: workspace too small (need %zu bytes)", need);
+  DMVAE_CHECK_ARG(groups > 0 && groups <= 65535 && n > 0 && m >= 0, "kl_mmd: need 0 < groups <= 65535, n > 0, m >= 0");
+  const size_t need = dmvae_kl_mmd_workspace(groups, n, m);
+  DMVAE_CHECK_ARG(workspace_bytes >= need, "kl_mmd: workspace too small (need %zu bytes, see dmvae_kl_mmd_workspace)", need);
+  int tx, ty, nmom;
+  kl_mmd_plan(groups, n, m, &tx, &ty, &nmom);
   float* mom = (float*)workspace;
-  float* stats = mom + (size_t)groups * MMD_D * 2;
-  const size_t lds = (size_t)(n + m) * 33 * sizeof(float);
+  float* stats = mom + (size_t)nmom * MMD_D * 2;
+  float* ksum = stats + 64;
+  float* gpart = ksum + (size_t)groups * (2 * tx + ty);
+  hipLaunchKernelGGL(kl_moments_kernel, dim3(nmom), dim3(256), 0, stream, (const float*)z, mom, (size_t)groups * n);
+  DMVAE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(1024), 0, stream, mom, (float*)kl, stats, nmom, (double)groups * n);
+  DMVAE_CHECK_LAUNCH();
+  // cols + norms + tile scalars; the gradient scratch (2 x 128 x 34 floats = 34.8 KB) aliases cols + norms, the scalars sit above both
+  if (kl_only) {
+    if (dz) {
+      size_t nb = ((size_t)groups * n * 8 + 255) / 256; if (nb > 4096) nb = 4096;
+      hipLaunchKernelGGL(kl_mmd_grad_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)z, (const float*)nullptr, stats, (float*)dz, groups, n, 1, w_kl, 0.f);
+      DMVAE_CHECK_LAUNCH();
+    }
+    return 0;
+  }
+  const size_t lds_v = (size_t)(2 * MMD_ROWS * 34 + 8) * sizeof(float) > (size_t)(MMD_CCH * MMD_D + MMD_CCH + 8) * sizeof(float)
+                           ? (size_t)(2 * MMD_ROWS * 34 + 8) * sizeof(float) : (size_t)(MMD_CCH * MMD_D + MMD_CCH + 8) * sizeof(float);
+  const size_t lds_g = lds_v;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kl_mmd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 33 * 4);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kl_mmd_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 33 * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mmd_pair_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mmd_pair_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kl_mmd_kernel, dim3(groups), dim3(256), lds, stream, (const float*)z, (const float*)y, mom, (float*)mmd, n, m);
+  const dim3 grid(2 * tx + ty, groups);
+  if (dz)
+    hipLaunchKernelGGL(mmd_pair_kernel<true>, grid, dim3(256), lds_g, stream, (const float*)z, (const float*)y, ksum, gpart, n, m, tx, ty);
+  else
+    hipLaunchKernelGGL(mmd_pair_kernel<false>, grid, dim3(256), lds_v, stream, (const float*)z, (const float*)y, ksum, gpart, n, m, tx, ty);
   DMVAE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(64), 0, stream, mom, (float*)kl, stats, groups, (double)groups * n);
+  hipLaunchKernelGGL(mmd_final_kernel, dim3(groups), dim3(64), 0, stream, ksum, (float*)mmd, n, m, tx, ty);
   DMVAE_CHECK_LAUNCH();
   if (dz) {
-    hipLaunchKernelGGL(kl_mmd_bwd_kernel, dim3(groups), dim3(256), lds, stream, (const float*)z, (const float*)y, stats, (float*)dz, n, m, groups, w_kl, w_mmd);
+    size_t nb = ((size_t)groups * n * 8 + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(kl_mmd_grad_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)z, gpart, stats, (float*)dz, groups, n, m, w_kl, w_mmd);
     DMVAE_CHECK_LAUNCH();
   }
   return 0;

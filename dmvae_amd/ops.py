@@ -319,18 +319,21 @@ def dmd_post(x1, xt, t, v_teacher, v_student, v_teacher_u=None, v_student_u=None
     return out, dl
 
 
-def kl_mmd(z: torch.Tensor, y: torch.Tensor, w_kl: float = 1.0, w_mmd: float = 1.0, need_grad: bool = True):
-    """z [G,n,32], y [G,m,32] f32 -> (kl [33] (32 per-latent + mean), mmd [G], dz or None)."""
+def kl_mmd(z: torch.Tensor, y: Optional[torch.Tensor], w_kl: float = 1.0, w_mmd: float = 1.0, need_grad: bool = True):
+    """z [G,n,32], y [G,m,32] f32 -> (kl [33] (32 per-latent + mean), mmd [G], dz or None).  y=None: KL pass only (mmd is None)."""
     z = _req(z, f32, "z")
-    y = _req(y, f32, "y")
     g, n, d = z.shape
-    m = y.shape[1]
-    ws = workspace((g * 64 + 64) * 4, z.device, slot="loss")
+    m = 0
+    if y is not None:
+        y = _req(y, f32, "y")
+        m = y.shape[1]
+    L = _lib.lib()
+    ws = workspace(L.dmvae_kl_mmd_workspace(g, n, m), z.device, slot="klmmd")
     kl = torch.empty(d + 1, dtype=f32, device=z.device)
-    mmd = torch.empty(g, dtype=f32, device=z.device)
+    mmd = torch.empty(g, dtype=f32, device=z.device) if y is not None else None
     dz = torch.empty_like(z) if need_grad else None
-    check(_lib.lib().dmvae_kl_mmd(z.data_ptr(), y.data_ptr(), kl.data_ptr(), mmd.data_ptr(), _ptr(dz), ws.data_ptr(), ws.numel(), g, n, m, d,
-                                  float(w_kl), float(w_mmd), _stream()), "kl_mmd")
+    check(L.dmvae_kl_mmd(z.data_ptr(), _ptr(y), kl.data_ptr(), _ptr(mmd), _ptr(dz), ws.data_ptr(), ws.numel(), g, n, m, d,
+                         float(w_kl), float(w_mmd), _stream()), "kl_mmd")
     return kl, mmd, dz
 
 

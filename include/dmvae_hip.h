@@ -160,7 +160,10 @@ int dmvae_dmd_post(const void* x1, const void* xt, const void* t, const void* v_
 /* Build-defined (no reference counterpart): per-latent KL of batch moments vs N(0,1) and batched
  * RBF-mixture MMD^2 between z[g] ([n][32] f32) and y[g] ([m][32] f32), fused in one pass over z.
  * kl: [33] f32 (32 channels + their mean); mmd: [groups] f32;
- * dz (optional): w_kl * d mean(kl)/dz + w_mmd * d mean(mmd)/dz.  workspace >= (groups*64+64)*4 B. */
+ * dz (optional): w_kl * d mean(kl)/dz + w_mmd * d mean(mmd)/dz.  Any n, m > 0 (128-row tiles, 256-column LDS chunks);
+ * workspace >= dmvae_kl_mmd_workspace(groups, n, m) bytes.  m = 0 (y, mmd may be NULL) runs the KL moment pass and its
+ * gradient alone.  Deterministic (fixed-order reductions). */
+size_t dmvae_kl_mmd_workspace(int groups, int n, int m);
 int dmvae_kl_mmd(const void* z, const void* y, void* kl, void* mmd, void* dz, void* workspace,
                  size_t workspace_bytes, int groups, int n, int m, int d, float w_kl, float w_mmd,
                  dmvae_stream_t stream);

@@ -247,6 +247,28 @@ def test_kl_mmd_vs_spec():
     assert rel_err(mxy.cpu(), myx.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(3, 300, 520), (5, 64, 8), (2, 129, 257)])
+def test_kl_mmd_ragged_tiles_and_chunks(shape):
+    """Row tiles (128) and column chunks (256) with ragged edges; KL-only mode (m = 0)."""
+    ops = _ops()
+    g, n, m = shape
+    gen = torch.Generator().manual_seed(5)
+    z = torch.randn(g, n, 32, generator=gen) * 1.3 - 0.1
+    y = torch.randn(g, m, 32, generator=gen)
+    kl, mmd, dz = ops.kl_mmd(z.to(DEV), y.to(DEV), w_kl=1.0, w_mmd=0.5)
+    zr = z.double().requires_grad_(True)
+    klr, klm = R.kl_moment(zr)
+    mr = R.mmd_rbf(zr, y.double())
+    (klm + 0.5 * mr.mean()).backward()
+    assert rel_err(kl[:32].cpu(), klr) < 1e-4 and rel_err(mmd.cpu(), mr) < 1e-4 and rel_err(dz.cpu(), zr.grad) < 1e-4
+    kl2, none, dz2 = ops.kl_mmd(z.to(DEV), None, w_kl=1.0)
+    zr2 = z.double().requires_grad_(True)
+    R.kl_moment(zr2)[1].backward()
+    assert none is None and torch.equal(kl2, kl) and rel_err(dz2.cpu(), zr2.grad) < 1e-5
+    kl3, mmd3, dz3 = ops.kl_mmd(z.to(DEV), y.to(DEV), w_kl=1.0, w_mmd=0.5)
+    assert torch.equal(dz3, dz) and torch.equal(mmd3, mmd)          # deterministic
+
+
 def test_adamw_ema_golden():
     ops = _ops()
     g = load_golden("opt_tail")
