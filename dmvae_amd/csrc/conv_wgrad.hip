@@ -252,8 +252,8 @@ using namespace dmvae_conv_wgrad;
 
 // conv_wgrad_pp.hip: the ping-pong kernel for the large layers (plan returns 0 when it does not cover the shape)
 int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_out, int* cfg_out);
-int dmvae_wgrad_pp_launch(const void* dy, const void* act, float* slab, const dmvae_conv_desc* d, int splits, int kchunk, int cfg,
-                          hipStream_t stream);
+int dmvae_wgrad_pp_launch(const void* dy, const void* act, float* slab, float* bslab, const dmvae_conv_desc* d, int splits, int kchunk,
+                          int cfg, hipStream_t stream);
 
 extern "C" size_t dmvae_conv2d_nhwc_wgrad_workspace(const dmvae_conv_desc* d) {
   if (!d) return 0;
@@ -261,7 +261,7 @@ extern "C" size_t dmvae_conv2d_nhwc_wgrad_workspace(const dmvae_conv_desc* d) {
   {
     int sp, kc, cfg;
     if ((d->ks == 1 || d->ks == 3) && dmvae_wgrad_pp_plan(d, &sp, &kc, &cfg))
-      return (size_t)sp * d->cout * T * d->cin * sizeof(float) + (size_t)1024 * d->cout * sizeof(float);
+      return (size_t)sp * d->cout * T * d->cin * sizeof(float) + (size_t)4096 * d->cout * sizeof(float);  // + [splits*ntiles <= 4096][cout] bias partials
   }
   const long long M = (long long)d->n * d->h * d->w * (d->upsample ? 4 : 1);
   const int tiles = ((d->cout + 127) / 128) * ((d->cin + 127) / 128) * T;
@@ -291,10 +291,14 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
   const int T = w.ks * w.ks;
   const int tiles = ((w.Cout + 127) / 128) * ((w.Cin + 127) / 128) * T;
   int splits = pick_splits(w.M, tiles);
-  int pp_kchunk = 0, pp_cfg = 0;
+  int pp_kchunk = 0, pp_cfg = 0, pp_ntiles = 1;
+  bool bias_fused = false;
   if (dmvae_wgrad_pp_plan(d, &splits, &pp_kchunk, &pp_cfg)) {
-    const int rc = dmvae_wgrad_pp_launch(dy, a, w.slab, d, splits, pp_kchunk, pp_cfg, stream);
+    const size_t tot = (size_t)w.Cout * T * w.Cin;
+    const int rc = dmvae_wgrad_pp_launch(dy, a, w.slab, dbias ? w.slab + (size_t)splits * tot : nullptr, d, splits, pp_kchunk, pp_cfg, stream);
     if (rc) return rc;
+    bias_fused = dbias != nullptr;
+    { const int ng = T * (d->cin / 128); pp_ntiles = pp_cfg == 0 ? ng / 2 : (ng + 2) / 3; }
   } else {
     w.kchunk = (((w.M + splits - 1) / splits) + BKP - 1) / BKP * BKP;
     splits = (w.M + w.kchunk - 1) / w.kchunk;
@@ -311,7 +315,11 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
   int rb = (int)((total + 255) / 256); if (rb > 2048) rb = 2048;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, w.slab, (float*)dw, splits, w.Cout, T, w.Cin, accumulate);
   DMVAE_CHECK_LAUNCH();
-  if (dbias) {
+  if (bias_fused) {  // the ping-pong kernel left per-split column sums of dy behind the weight slabs
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((w.Cout + 63) / 64), dim3(256), 0, stream, w.slab + (size_t)splits * total, (float*)dbias,
+                       splits * pp_ntiles, w.Cout, accumulate);
+    DMVAE_CHECK_LAUNCH();
+  } else if (dbias) {
     float* part = w.slab + (size_t)splits * total;
     int tp = 1, tps = 0;
     while (tp < 64 && tp * 8 < w.Cout) { tp <<= 1; tps++; }

@@ -29,6 +29,7 @@ struct Args {
   const bf16* dy;  // [M, Cout]
   const bf16* a;   // [N, Hi, Wi, Cin]
   float* slab;     // [splits][Cout][T][Cin]
+  float* bslab;    // [splits][Cout] bias-gradient partials (column sums of dy) or null
   int N, Hi, Wi, Cin, Ho, Wo, Cout;
   int ks, ups, M, kchunk;  // kchunk: pixels per split (multiple of 32)
   int mtiles, ntiles, ngroups, gpt;  // gpt: 128-channel column groups per cin row (Cin / 128)
@@ -132,6 +133,20 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     boff[j] = GA * SUB + sub * SUB + (kq * 8 + rr) * 256 + ((((c >> 5) ^ rr)) << 6) + (c & 31) * 2;
   }
 
+  // Bias gradient (column sums of dy) rides along on the matrix pipe: dy fragment x all-ones fragment, in the wave whose N
+  // index equals the cout block.  The ntiles blocks that share a (split, cout tile) take the K tiles round-robin, so every
+  // block does 1/ntiles of it (one block doing all of it would set the critical path of a single-round launch) -- instead of
+  // a second 2 B/elem pass over dy.
+  const int my_nt = tile % a.ntiles;
+  const bool do_bias = a.bslab != nullptr && wn < BM;
+  int bias_cnt = my_nt;
+  f32x16 accb;
+#pragma unroll
+  for (int r = 0; r < 16; r++) accb[r] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; e++) ones[e] = (bf16)1.0f;
+
   f32x16 acc[BM][BN];
 #pragma unroll
   for (int i = 0; i < BM; i++)
@@ -226,6 +241,17 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #pragma unroll
         for (int j = 0; j < BN; j++)
           asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[kk][i].v), "v"(bfr[kk][j].v));
+    const bool bias_now = do_bias && bias_cnt == 0;
+    bias_cnt = bias_cnt == 0 ? a.ntiles - 1 : bias_cnt - 1;
+    if (bias_now) {
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+        for (int i = 0; i < BM; i++)
+          if (i == wn)  // accumulator pinned to VGPRs ("+v"): the 128 AGPRs of the main accumulators are left exactly as they are
+            // s_nop: the compiler rematerialises `ones` with v_mov right before the statement and pads nothing for inline asm
+            asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accb) : "v"(af[kk][i].v), "v"(ones));
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -235,6 +261,13 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   wait_vmcnt<0>();
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
+  if (do_bias && (lane & 31) == 0) {  // every column of accb holds the same sums: column 0 lives in lanes 0 and 32
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int co = co0 + wm * (TM / WM) + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+      if (co < a.Cout) a.bslab[((size_t)split * a.ntiles + my_nt) * a.Cout + co] = accb[r];
+    }
+  }
   // ---- slab store: lane owns column (l & 31) of each N block, 16 couts per accumulator ------------------------------------------
   float* slab = a.slab + (size_t)split * a.Cout * T * a.Cin;
 #pragma unroll
@@ -302,11 +335,11 @@ int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_o
   return 1;
 }
 
-int dmvae_wgrad_pp_launch(const void* dy, const void* act, float* slab, const dmvae_conv_desc* d, int splits, int kchunk, int cfg,
-                          hipStream_t stream) {
+int dmvae_wgrad_pp_launch(const void* dy, const void* act, float* slab, float* bslab, const dmvae_conv_desc* d, int splits, int kchunk,
+                          int cfg, hipStream_t stream) {
   using namespace dmvae_wgrad_pp;
   Args a;
-  a.dy = (const bf16*)dy; a.a = (const bf16*)act; a.slab = slab;
+  a.dy = (const bf16*)dy; a.a = (const bf16*)act; a.slab = slab; a.bslab = bslab;
   a.N = d->n; a.Hi = d->h; a.Wi = d->w; a.Cin = d->cin; a.Cout = d->cout; a.ks = d->ks;
   a.ups = d->upsample ? 1 : 0;
   a.Ho = a.ups ? 2 * d->h : d->h; a.Wo = a.ups ? 2 * d->w : d->w;
