@@ -44,6 +44,11 @@ def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad
     return p
 
 
+def _dst(param):
+    """Destination view for a parameter's gradient when its owner enabled direct flat-buffer gradients (optim.FlatParams)."""
+    return getattr(param, "_dmvae_grad_view", None) if param is not None else None
+
+
 def _gn_swish(x, gw, gb, swish=True):
     st = ops.groupnorm_stats(x)
     return st, ops.groupnorm_apply(x, st, gw, gb, swish)
@@ -64,23 +69,25 @@ class ResnetBlockFn(torch.autograd.Function):
         xs = x if sw is None else ops.conv2d_nhwc(x, packed(sw), sb, ks=1)
         y = ops.conv2d_nhwc(a2, packed(c2w), c2b, residual=xs, ks=3)
         ctx.save_for_backward(x, st1, a1, h1, st2, a2, n1w, n1b, c1w, n2w, n2b, c2w, sw)
+        ctx.bias_params = (c1b, c2b, sb)     # only for their gradient destinations
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, st1, a1, h1, st2, a2, n1w, n1b, c1w, n2w, n2b, c2w, sw = ctx.saved_tensors
         dy = _c(dy)
-        dc2w, dc2b = ops.conv2d_nhwc_wgrad(dy, a2, 3)
+        c1b, c2b, sb = ctx.bias_params
+        dc2w, dc2b = ops.conv2d_nhwc_wgrad(dy, a2, 3, dw_out=_dst(c2w), db_out=_dst(c2b))
         da2 = ops.conv2d_nhwc(dy, packed(c2w, True), ks=3)
-        dh1, dn2w, dn2b = ops.groupnorm_bwd(da2, h1, st2, n2w, n2b, True)
-        dc1w, dc1b = ops.conv2d_nhwc_wgrad(dh1, a1, 3)
+        dh1, dn2w, dn2b = ops.groupnorm_bwd(da2, h1, st2, n2w, n2b, True, dg_out=_dst(n2w), db_out=_dst(n2b))
+        dc1w, dc1b = ops.conv2d_nhwc_wgrad(dh1, a1, 3, dw_out=_dst(c1w), db_out=_dst(c1b))
         da1 = ops.conv2d_nhwc(dh1, packed(c1w, True), ks=3)
         if sw is None:
             dxs, dsw, dsb = dy, None, None
         else:
-            dsw, dsb = ops.conv2d_nhwc_wgrad(dy, x, 1)
+            dsw, dsb = ops.conv2d_nhwc_wgrad(dy, x, 1, dw_out=_dst(sw), db_out=_dst(sb))
             dxs = ops.conv2d_nhwc(dy, packed(sw, True), ks=1)
-        dx, dn1w, dn1b = ops.groupnorm_bwd(da1, x, st1, n1w, n1b, True, dres=dxs)
+        dx, dn1w, dn1b = ops.groupnorm_bwd(da1, x, st1, n1w, n1b, True, dres=dxs, dg_out=_dst(n1w), db_out=_dst(n1b))
         return dx, dn1w, dn1b, dc1w, dc1b, dn2w, dn2b, dc2w, dc2b, dsw, dsb
 
 
@@ -100,6 +107,7 @@ class AttnBlockFn(torch.autograd.Function):
         o = ops.gemm_nt(p, ops.transpose_last2(v))                            # [n, s, c]
         y = ops.conv2d_nhwc(o.view(n, h, w, c), packed(pw), pb, residual=x, ks=1)
         ctx.save_for_backward(x, st, hn, q, k, v, p, o, nw, nb, qw, kw, vw, pw)
+        ctx.bias_params = (qb, kb, vb, pb)
         ctx.scale = scale
         return y
 
@@ -109,7 +117,8 @@ class AttnBlockFn(torch.autograd.Function):
         n, h, w, c = x.shape
         s = h * w
         dy = _c(dy)
-        dpw, dpb = ops.conv2d_nhwc_wgrad(dy, o.view(n, h, w, c), 1)
+        qb, kb, vb, pb = ctx.bias_params
+        dpw, dpb = ops.conv2d_nhwc_wgrad(dy, o.view(n, h, w, c), 1, dw_out=_dst(pw), db_out=_dst(pb))
         do = ops.conv2d_nhwc(dy, packed(pw, True), ks=1).view(n, s, c)
         dp = ops.gemm_nt(do, v, out_f32=True)                                  # dP[q][key] = do[q].v[key]
         ds = ops.softmax_rows_bwd(dp, p, ctx.scale)                            # bf16, includes the scale
@@ -117,13 +126,13 @@ class AttnBlockFn(torch.autograd.Function):
         dq = ops.gemm_nt(ds, ops.transpose_last2(k))                           # [n, q, c]
         dk = ops.gemm_tn(ds, q)                                                # [n, key, c]
         dq4, dk4, dv4 = dq.view(n, h, w, c), dk.view(n, h, w, c), dv.view(n, h, w, c)
-        dqw, dqb = ops.conv2d_nhwc_wgrad(dq4, hn, 1)
-        dkw, dkb = ops.conv2d_nhwc_wgrad(dk4, hn, 1)
-        dvw, dvb = ops.conv2d_nhwc_wgrad(dv4, hn, 1)
+        dqw, dqb = ops.conv2d_nhwc_wgrad(dq4, hn, 1, dw_out=_dst(qw), db_out=_dst(qb))
+        dkw, dkb = ops.conv2d_nhwc_wgrad(dk4, hn, 1, dw_out=_dst(kw), db_out=_dst(kb))
+        dvw, dvb = ops.conv2d_nhwc_wgrad(dv4, hn, 1, dw_out=_dst(vw), db_out=_dst(vb))
         dh = ops.conv2d_nhwc(dq4, packed(qw, True), ks=1)
         dh = ops.conv2d_nhwc(dk4, packed(kw, True), residual=dh, ks=1)
         dh = ops.conv2d_nhwc(dv4, packed(vw, True), residual=dh, ks=1)
-        dx, dnw, dnb = ops.groupnorm_bwd(dh, x, st, nw, nb, False, dres=dy)
+        dx, dnw, dnb = ops.groupnorm_bwd(dh, x, st, nw, nb, False, dres=dy, dg_out=_dst(nw), db_out=_dst(nb))
         return dx, dnw, dnb, dqw, dqb, dkw, dkb, dvw, dvb, dpw, dpb
 
 
@@ -134,14 +143,14 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, w, b, ks, upsample):
         y = ops.conv2d_nhwc(x, packed(w), b, ks=ks, upsample=upsample)
         ctx.save_for_backward(x, w)
-        ctx.ks, ctx.upsample = ks, upsample
+        ctx.ks, ctx.upsample, ctx.bias_param = ks, upsample, b
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = _c(dy)
-        dw, db = ops.conv2d_nhwc_wgrad(dy, x, ctx.ks, upsample=ctx.upsample)
+        dw, db = ops.conv2d_nhwc_wgrad(dy, x, ctx.ks, upsample=ctx.upsample, dw_out=_dst(w), db_out=_dst(ctx.bias_param))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_nhwc(dy, packed(w, True), ks=ctx.ks)
@@ -162,6 +171,7 @@ class NormConvOutFn(torch.autograd.Function):
         cbp[:cout] = cb
         y4 = ops.conv2d_nhwc(a, packed(cw, False, rows_pad=4), cbp, ks=3, out_f32=True)
         ctx.save_for_backward(x, st, a, nw, nb, cw)
+        ctx.bias_param = cb
         return ops.nhwc_to_nchw_f32(y4, cout)
 
     @staticmethod
@@ -171,7 +181,12 @@ class NormConvOutFn(torch.autograd.Function):
         dyp = ops.nchw_to_nhwc_bf16(_c(dy.float()), c_pad=32)
         dwp, dbp = ops.conv2d_nhwc_wgrad(dyp, a, 3)
         da = ops.conv2d_nhwc(dyp, packed(cw, True, cols_pad=32), ks=3)
-        dx, dnw, dnb = ops.groupnorm_bwd(da, x, st, nw, nb, True)
+        dx, dnw, dnb = ops.groupnorm_bwd(da, x, st, nw, nb, True, dg_out=_dst(nw), db_out=_dst(nb))
+        dcw, dcb = _dst(cw), _dst(ctx.bias_param)
+        if dcw is not None:
+            dcw.copy_(dwp[:cout])
+            dcb.copy_(dbp[:cout])
+            return dx, dnw, dnb, dcw, dcb
         return dx, dnw, dnb, dwp[:cout].contiguous(), dbp[:cout].contiguous()
 
 
@@ -184,6 +199,7 @@ class MLPFn(torch.autograd.Function):
         a = ops.silu(h)
         y = ops.gemm_nt(a, packed(w2).view(w2.shape[0], w2.shape[1]), b2)
         ctx.save_for_backward(x, h, a, w0, w2)
+        ctx.bias_params = (b0, b2)
         return y
 
     @staticmethod
@@ -191,10 +207,12 @@ class MLPFn(torch.autograd.Function):
         x, h, a, w0, w2 = ctx.saved_tensors
         dy = _c(dy)
         m = x.shape[0]
-        dw2, db2 = ops.conv2d_nhwc_wgrad(dy.view(1, 1, m, -1), a.view(1, 1, m, -1), 1)
+        b0, b2 = ctx.bias_params
+        v4 = lambda t: None if t is None else t.view(t.shape[0], t.shape[1], 1, 1)
+        dw2, db2 = ops.conv2d_nhwc_wgrad(dy.view(1, 1, m, -1), a.view(1, 1, m, -1), 1, dw_out=v4(_dst(w2)), db_out=_dst(b2))
         da = ops.gemm_nt(dy, packed(w2, True).view(w2.shape[1], w2.shape[0]))
         dh = ops.silu_bwd(h, da)
-        dw0, db0 = ops.conv2d_nhwc_wgrad(dh.view(1, 1, m, -1), x.view(1, 1, m, -1), 1)
+        dw0, db0 = ops.conv2d_nhwc_wgrad(dh.view(1, 1, m, -1), x.view(1, 1, m, -1), 1, dw_out=v4(_dst(w0)), db_out=_dst(b0))
         dx = ops.gemm_nt(dh, packed(w0, True).view(w0.shape[1], w0.shape[0])) if ctx.needs_input_grad[0] else None
         return dx, dw0.view(w0.shape), db0, dw2.view(w2.shape), db2
 

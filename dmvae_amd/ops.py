@@ -205,7 +205,8 @@ def groupnorm_apply(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, b
 
 
 def groupnorm_bwd(da: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, swish: bool,
-                  dres: Optional[torch.Tensor] = None, groups: int = 32, need_param_grads: bool = True):
+                  dres: Optional[torch.Tensor] = None, groups: int = 32, need_param_grads: bool = True,
+                  dg_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None):
     da = _req(da, bf16, "da")
     x = _req(x, bf16, "x")
     n, c = x.shape[0], x.shape[-1]
@@ -214,8 +215,8 @@ def groupnorm_bwd(da: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma:
     wsb = L.dmvae_groupnorm_workspace(n, hw, c, groups)
     ws = workspace(wsb, x.device)
     dx = torch.empty_like(x)
-    dg = torch.empty(c, dtype=f32, device=x.device) if need_param_grads else None
-    db = torch.empty(c, dtype=f32, device=x.device) if need_param_grads else None
+    dg = (dg_out if dg_out is not None else torch.empty(c, dtype=f32, device=x.device)) if need_param_grads else None
+    db = (db_out if db_out is not None else torch.empty(c, dtype=f32, device=x.device)) if need_param_grads else None
     if dres is not None:
         _req(dres, bf16, "dres")
     check(L.dmvae_groupnorm_bwd(da.data_ptr(), x.data_ptr(), _ptr(dres), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dx.data_ptr(),

@@ -35,6 +35,22 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
 
+    def enable_direct_grads(self) -> None:
+        """The HIP backward Functions (dmvae_amd.functional) then WRITE each parameter gradient straight into its slice of the
+        flat buffer and hand that view to autograd, instead of returning a fresh tensor that AccumulateGrad adds into `.grad`
+        (193 small add kernels + one memset per step for the tokenizer).  Requires every parameter to receive exactly one
+        gradient per backward (true for the decoder / bottleneck); call `begin_step()` before each backward."""
+        for p, off in zip(self.params, self.offsets):
+            p._dmvae_grad_view = self.grad[off:off + p.numel()].view(p.shape)
+        self.direct = True
+
+    def begin_step(self) -> None:
+        if getattr(self, "direct", False):
+            for p in self.params:
+                p.grad = None          # autograd adopts the returned flat-buffer view (no accumulation kernel)
+        else:
+            self.zero_grad()
+
     def ema_state(self):
         """name-less list of EMA tensors aligned with self.params (views)."""
         return [self.ema[off:off + p.numel()].view(p.shape) for p, off in zip(self.params, self.offsets)]

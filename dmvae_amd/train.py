@@ -66,6 +66,7 @@ class TokenizerTrainer:
         n_train = sum(p.numel() for p in vae.parameters() if p.requires_grad)
         assert n_train == sum(p.numel() for p in params), "parameter ordering lost a trainable parameter"
         self.fp = FlatParams(params, with_ema=True)
+        self.fp.enable_direct_grads()
         self.opt = FlatAdamWEMA(self.fp, lr=lr, warmup_steps=warmup_steps, ema_decay=ema_decay, max_norm=max_norm)
         self.sync = dist.FlatGradSync(params, self.fp.grad, self.fp.offsets, bucket_bytes=bucket_bytes)
         self.log = torch.zeros(8, dtype=torch.float32, device=self.fp.flat.device)
@@ -83,6 +84,7 @@ class TokenizerTrainer:
 
     def step(self, images: torch.Tensor) -> torch.Tensor:
         vae, w = self.vae, self.w
+        self.fp.begin_step()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             with torch.no_grad():
                 tokens = self._enc(images)
@@ -101,7 +103,6 @@ class TokenizerTrainer:
         loss.backward()
         self.sync.wait()
         norm = self.opt.step()
-        self.fp.zero_grad()
         with torch.no_grad():
             self.log[0], self.log[1], self.log[3] = l1.detach(), l2.detach(), loss.detach()
             if lp is not None:
