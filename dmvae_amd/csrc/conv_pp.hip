@@ -303,8 +303,13 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
           const size_t off = (size_t)m * a.Cout + cb;
           if (a.res) {
             const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(a.res + off);
+            if (a.act == 3) {  // ReLU-backward gate: `res` is the saved activation, not an addend
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] += (float)r8[e];
+              for (int e = 0; e < 8; e++) v[e] = (float)r8[e] > 0.f ? v[e] : 0.f;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; e++) v[e] += (float)r8[e];
+            }
           }
           if (a.act == 1) {
 #pragma unroll

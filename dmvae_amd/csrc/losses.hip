@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256) void lpips_diff_kernel(const bf16* __restrict_
     float g[8], v = 0.f, gdot = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-      const float d = a[e] * ia - b[e] * ib;
+#pragma clang fp contract(off)  // a*ia - b*ib must not become fma(a, ia, -(b*ib)): LPIPS(x, x) has to be exactly 0
+      const float pa = a[e] * ia, pb = b[e] * ib;
+      const float d = pa - pb;
       v += wv[e] * d * d;
       g[e] = -2.f * wv[e] * d;      // dL/d n1_c
       gdot += g[e] * b[e];

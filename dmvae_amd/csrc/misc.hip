@@ -51,6 +51,84 @@ __global__ void sumpool2x2_kernel(const bf16* __restrict__ dy, bf16* __restrict_
   }
 }
 
+// ---- 2x2 max pool on NHWC bf16 (VGG16 trunk of LPIPS, utils/lpips.py:116-153) and its backward fused with the ReLU mask ----------
+__global__ void maxpool2x2_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int N, int H, int W, int C) {
+  const int c8 = C / 8;
+  const size_t total = (size_t)N * H * W * c8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = i % c8;
+    size_t r = i / c8;
+    const int xo = r % W; r /= W;
+    const int yo = r % H;
+    const int n = r / H;
+    const bf16* base = x + (((size_t)n * 2 * H + 2 * yo) * 2 * W + 2 * xo) * C + cc * 8;
+    bf16x8 m = *reinterpret_cast<const bf16x8*>(base);
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + ((size_t)(k >> 1) * 2 * W + (k & 1)) * C);
+#pragma unroll
+      for (int e = 0; e < 8; e++) m[e] = (float)v[e] > (float)m[e] ? v[e] : m[e];
+    }
+    *reinterpret_cast<bf16x8*>(y + i * 8) = m;
+  }
+}
+// dx[pos] = x[pos] > 0 ? (pos == argmax of its window ? dpool : 0) + extra[pos] : 0, argmax = first maximum in scan order
+// (F.max_pool2d backward), x = the post-ReLU activation that was pooled.  dpool / extra may be null.
+__global__ void maxpool2x2_relu_bwd_kernel(const bf16* __restrict__ dpool, const bf16* __restrict__ x, const bf16* __restrict__ extra,
+                                           bf16* __restrict__ dx, int N, int H, int W, int C) {
+  const int c8 = C / 8;
+  const size_t total = (size_t)N * H * W * c8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = i % c8;
+    size_t r = i / c8;
+    const int xo = r % W; r /= W;
+    const int yo = r % H;
+    const int n = r / H;
+    const size_t b0 = (((size_t)n * 2 * H + 2 * yo) * 2 * W + 2 * xo) * C + cc * 8;
+    bf16x8 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const bf16x8*>(x + b0 + ((size_t)(k >> 1) * 2 * W + (k & 1)) * C);
+    bf16x8 g;
+#pragma unroll
+    for (int e = 0; e < 8; e++) g[e] = (bf16)0.f;
+    if (dpool) g = *reinterpret_cast<const bf16x8*>(dpool + i * 8);
+    int arg[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      float m = (float)v[0][e];
+      arg[e] = 0;
+#pragma unroll
+      for (int k = 1; k < 4; k++)
+        if ((float)v[k][e] > m) { m = (float)v[k][e]; arg[e] = k; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const size_t off = b0 + ((size_t)(k >> 1) * 2 * W + (k & 1)) * C;
+      bf16x8 ex;
+#pragma unroll
+      for (int e = 0; e < 8; e++) ex[e] = (bf16)0.f;
+      if (extra) ex = *reinterpret_cast<const bf16x8*>(extra + off);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float t = (arg[e] == k ? (float)g[e] : 0.f) + (float)ex[e];
+        o[e] = (float)v[k][e] > 0.f ? (bf16)t : (bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(dx + off) = o;
+    }
+  }
+}
+// dx = y > 0 ? dy : 0 (ReLU backward from the saved output), bf16
+__global__ void relu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, bf16* __restrict__ dx, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const bf16x8 d = reinterpret_cast<const bf16x8*>(dy)[i], v = reinterpret_cast<const bf16x8*>(y)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = (float)v[e] > 0.f ? d[e] : (bf16)0.f;
+    reinterpret_cast<bf16x8*>(dx)[i] = o;
+  }
+}
+
 // ---- image layout: NCHW f32 <-> NHWC (channel-padded) ----------------------------------------
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int N, int C, int HW, int Cpad) {
   const size_t total = (size_t)N * HW;
@@ -164,6 +242,28 @@ extern "C" int dmvae_pack_conv_weight(const void* w, void* out, int cout, int ci
 extern "C" int dmvae_sumpool2x2_nhwc(const void* dy, void* dx, int n, int h, int w, int c, hipStream_t stream) {
   DMVAE_CHECK_ARG(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "sumpool2x2_nhwc: bad argument (c must be a multiple of 8)");
   hipLaunchKernelGGL(sumpool2x2_kernel, dim3(grid_for((size_t)n * h * w * (c / 8))), dim3(256), 0, stream, (const bf16*)dy, (bf16*)dx, n, h, w, c);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_maxpool2x2_nhwc(const void* x, void* y, int n, int h, int w, int c, hipStream_t stream) {
+  DMVAE_CHECK_ARG(x && y && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "maxpool2x2_nhwc: bad argument (c must be a multiple of 8)");
+  hipLaunchKernelGGL(maxpool2x2_kernel, dim3(grid_for((size_t)n * h * w * (c / 8))), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, n, h, w, c);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int dmvae_maxpool2x2_relu_bwd_nhwc(const void* dpool, const void* x, const void* extra, void* dx, int n, int h, int w, int c,
+                                              hipStream_t stream) {
+  DMVAE_CHECK_ARG(x && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "maxpool2x2_relu_bwd_nhwc: bad argument (c must be a multiple of 8)");
+  hipLaunchKernelGGL(maxpool2x2_relu_bwd_kernel, dim3(grid_for((size_t)n * h * w * (c / 8))), dim3(256), 0, stream, (const bf16*)dpool,
+                     (const bf16*)x, (const bf16*)extra, (bf16*)dx, n, h, w, c);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int dmvae_relu_bwd(const void* dy, const void* y, void* dx, size_t n, hipStream_t stream) {
+  DMVAE_CHECK_ARG(dy && y && dx && n % 8 == 0, "relu_bwd: element count must be a multiple of 8");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)y, (bf16*)dx, n / 8);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -46,7 +46,11 @@ def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad
 
 def _dst(param):
     """Destination view for a parameter's gradient when its owner enabled direct flat-buffer gradients (optim.FlatParams)."""
-    return getattr(param, "_dmvae_grad_view", None) if param is not None else None
+    if param is None:
+        return None
+    v = getattr(param, "_dmvae_grad_view", None)
+    # a FRESH view object per use: AccumulateGrad adopts a gradient without copying only if nobody else holds its TensorImpl
+    return None if v is None else v.view(v.shape)
 
 
 def _gn_swish(x, gw, gb, swish=True):

@@ -17,7 +17,7 @@ from ._lib import ConvDesc, check
 bf16 = torch.bfloat16
 f32 = torch.float32
 
-ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_RELU_GATE = 0, 1, 2, 3
 
 
 def _stream() -> int:
@@ -230,6 +230,35 @@ def sumpool2x2(dy: torch.Tensor) -> torch.Tensor:
     n, h2, w2, c = dy.shape
     dx = torch.empty(n, h2 // 2, w2 // 2, c, dtype=bf16, device=dy.device)
     check(_lib.lib().dmvae_sumpool2x2_nhwc(dy.data_ptr(), dx.data_ptr(), n, h2 // 2, w2 // 2, c, _stream()), "sumpool2x2_nhwc")
+    return dx
+
+
+def maxpool2x2(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x, bf16, "x")
+    n, h2, w2, c = x.shape
+    y = torch.empty(n, h2 // 2, w2 // 2, c, dtype=bf16, device=x.device)
+    check(_lib.lib().dmvae_maxpool2x2_nhwc(x.data_ptr(), y.data_ptr(), n, h2 // 2, w2 // 2, c, _stream()), "maxpool2x2_nhwc")
+    return y
+
+
+def maxpool2x2_relu_bwd(dpool: Optional[torch.Tensor], x: torch.Tensor, extra: Optional[torch.Tensor]) -> torch.Tensor:
+    """dx = x > 0 ? route(dpool to the first maximum of each 2x2 window of x) + extra : 0."""
+    x = _req(x, bf16, "x")
+    n, h2, w2, c = x.shape
+    for name, t in (("dpool", dpool), ("extra", extra)):
+        if t is not None:
+            _req(t, bf16, name)
+    dx = torch.empty_like(x)
+    check(_lib.lib().dmvae_maxpool2x2_relu_bwd_nhwc(_ptr(dpool), x.data_ptr(), _ptr(extra), dx.data_ptr(), n, h2 // 2, w2 // 2, c, _stream()),
+          "maxpool2x2_relu_bwd_nhwc")
+    return dx
+
+
+def relu_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    dy = _req(dy, bf16, "dy")
+    y = _req(y, bf16, "y")
+    dx = torch.empty_like(dy)
+    check(_lib.lib().dmvae_relu_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), _stream()), "relu_bwd")
     return dx
 
 

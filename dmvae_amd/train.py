@@ -76,11 +76,7 @@ class TokenizerTrainer:
     def refresh_frozen_shadows(self) -> None:
         """(Re)build the bf16 shadows of the frozen encoder and LPIPS trunk; call after loading new weights into them."""
         self._enc = frozen_bf16_shadow(self.vae.encoder)
-        self._lpips = None
-        if self.lpips is not None:
-            import copy
-            self._lpips = copy.deepcopy(self.lpips).eval().requires_grad_(False)      # lin weights stay f32 (kernel operand)
-            self._lpips.net = frozen_bf16_shadow(self.lpips.net).to(memory_format=torch.channels_last)
+        self._lpips = self.lpips          # LPIPS runs on the HIP conv kernels with cached bf16 operands: no shadow needed
 
     def step(self, images: torch.Tensor) -> torch.Tensor:
         vae, w = self.vae, self.w
@@ -134,7 +130,6 @@ def build_tokenizer_trainer(device="cuda", z_channels=32, model_size="large", se
         warnings.simplefilter("ignore")
         vae = VAE(z_channels=z_channels, model_size=model_size).to(device)
     lp = LPIPS(ckpt_path=lpips_ckpt).eval().requires_grad_(False).to(device)
-    lp = lp.to(memory_format=torch.channels_last)
     if lpips_ckpt is None:          # no trunk / lin weights offline: deterministic positive lin weights
         with torch.no_grad():
             for lin in (lp.lin0, lp.lin1, lp.lin2, lp.lin3, lp.lin4):

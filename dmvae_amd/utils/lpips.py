@@ -4,9 +4,10 @@ vgg16 :116-153): same class names, state_dict keys (net.slice{1..5}.{idx}.*, lin
 
 The feature-difference reduction (normalize_tensor, diff^2, 1x1 lin, spatial mean, level sum, batch mean;
 :86-94,156-162) runs in the fused HIP kernel dmvae_lpips_diff (forward value + gradient w.r.t. the second
-argument's features in one pass over NHWC bf16 features).  The VGG16 trunk itself is a SURVEY.md 8(f) "next" row:
-stock PyTorch-ROCm convs in channels-last bf16 (torchvision is not installed here, so the 'D' layer list is built
-locally; pretrained trunk weights must be loaded from a checkpoint -- they are not downloadable offline)."""
+argument's features in one pass over NHWC bf16 features).  The VGG16 trunk runs on the same
+implicit-GEMM conv kernel as the decoder (ReLU epilogue, NHWC bf16, both LPIPS branches batched as one pass), with HIP
+2x2 max pools; its backward is hand-scheduled (`_VggLpips`).  torchvision is not installed here, so the 'D' layer list is built
+locally; pretrained trunk weights must be loaded from a checkpoint -- they are not downloadable offline."""
 import torch
 import torch.nn as nn
 
@@ -68,38 +69,78 @@ class vgg16(nn.Module):
         return outs
 
 
-class _LpipsDiff(torch.autograd.Function):
-    """sum_l mean_{n,hw} sum_c w_c (f0_hat - f1_hat)^2 over the five levels; gradient flows to feats1 only
-    (the reference calls lpips(images, recon): the first argument carries no graph)."""
+class _VggLpips(torch.autograd.Function):
+    """LPIPS(input, target) on the HIP kernels: ScalingLayer -> VGG16 trunk (both branches batched as one N = 2B pass through
+    the implicit-GEMM conv kernel with a ReLU epilogue, 2x2 max pools) -> fused feature-diff reduction per tapped level.
+    Backward (w.r.t. `target` only -- the reference calls lpips(images, recon), the first argument carries no graph) walks
+    the trunk in reverse on the target half: conv input-gradients with the ReLU gate fused into the producing conv's epilogue
+    or into the max-pool backward.  Replaces utils/lpips.py:81-94,116-153 (MIOpen convs / ATen pools in the reference)."""
 
     @staticmethod
-    def forward(ctx, lin_ws, *feats):
-        k = len(feats) // 2
-        f0s, f1s = feats[:k], feats[k:]
-        out = torch.zeros(1, dtype=torch.float32, device=f0s[0].device)
-        need = any(f.requires_grad for f in f1s)
-        grads = []
-        for i in range(k):
-            a = f0s[i].detach().permute(0, 2, 3, 1)
-            b = f1s[i].detach().permute(0, 2, 3, 1)
-            a = a.to(torch.bfloat16).contiguous()
-            b = b.to(torch.bfloat16).contiguous()
-            n, hw = a.shape[0], a.shape[1] * a.shape[2]
-            g = ops.lpips_diff(a, b, lin_ws[i], out, 1.0 / (hw * n), need, accumulate=i > 0)
-            grads.append(g)
-        ctx.k = k
-        ctx.dtypes = [f.dtype for f in f1s]
-        ctx.save_for_backward(*[g for g in grads if g is not None])
-        ctx.need = need
+    def forward(ctx, inp, tgt, mod):
+        from .. import functional as Fn
+        b = inp.shape[0]
+        shift, scale = mod.scaling_layer.shift, mod.scaling_layer.scale
+        x = torch.cat([(inp.detach().float() - shift) / scale, (tgt.detach().float() - shift) / scale], 0).contiguous()
+        h = ops.nchw_to_nhwc_bf16(x, c_pad=32)                       # [2B, H, W, 32] (3 real channels)
+        need = tgt.requires_grad
+        lin_ws = [l.model[-1].weight.detach().reshape(-1).float().contiguous() for l in (mod.lin0, mod.lin1, mod.lin2, mod.lin3, mod.lin4)]
+        out = torch.zeros(1, dtype=torch.float32, device=inp.device)
+        convs = [m for sl in (mod.net.slice1, mod.net.slice2, mod.net.slice3, mod.net.slice4, mod.net.slice5) for m in sl if isinstance(m, nn.Conv2d)]
+        tape, ci, level = [], 0, 0                                    # tape: ("conv", conv, y_tgt_half, df1 | None) / ("pool",)
+        taps = {1, 3, 6, 9, 12}                                        # conv indices whose ReLU output is an LPIPS feature
+        for v in _CFG:
+            if v == "M":
+                h = ops.maxpool2x2(h)
+                tape.append(("pool",))
+                continue
+            conv = convs[ci]
+            wp = Fn.packed(conv.weight, False, 0, 32 if conv.weight.shape[1] < 32 else 0)
+            h = ops.conv2d_nhwc(h, wp, conv.bias.detach().float(), ks=3, act=ops.ACT_RELU)
+            df1 = None
+            if ci in taps:
+                n, hh, ww, _ = h.shape
+                df1 = ops.lpips_diff(h[:b], h[b:], lin_ws[level], out, 1.0 / (hh * ww * b), need, accumulate=level > 0)
+                level += 1
+            tape.append(("conv", conv, h[b:] if need else None, df1))
+            ci += 1
+        ctx.tape, ctx.need, ctx.scale = tape, need, scale
         return out[0]
 
     @staticmethod
     def backward(ctx, gout):
-        k = ctx.k
         if not ctx.need:
-            return (None,) * (1 + 2 * k)
-        grads = [(g.permute(0, 3, 1, 2) * gout).to(dt) for g, dt in zip(ctx.saved_tensors, ctx.dtypes)]
-        return (None,) + (None,) * k + tuple(grads)
+            return None, None, None
+        from .. import functional as Fn
+        tape = ctx.tape
+        d = None            # gradient w.r.t. the input of the layer above (bf16 NHWC, target half), already ReLU-gated where due
+        pending_pool = False
+        for k in range(len(tape) - 1, -1, -1):
+            e = tape[k]
+            if e[0] == "pool":
+                pending_pool = True
+                continue
+            _, conv, y, df1 = e
+            if d is None:                                   # topmost conv (relu5_3): only the feature gradient arrives
+                dpre = ops.relu_bwd(df1, y)
+            elif pending_pool:                              # conv -> relu -> [tap] -> pool: un-pool + feature gradient + ReLU gate
+                dpre = ops.maxpool2x2_relu_bwd(d, y, df1)
+            else:
+                dpre = d                                    # gate was fused into the dgrad conv that produced d
+            pending_pool = False
+            # input gradient of this conv; if the layer below is conv+ReLU directly, gate by its saved output in the epilogue
+            below = tape[k - 1] if k > 0 else None
+            cin = conv.weight.shape[1]
+            wd = Fn.packed(conv.weight, True, 4 if cin < 4 else 0, 0)
+            if below is None:
+                dimg = ops.conv2d_nhwc(dpre, wd, ks=3, out_f32=True)                      # [B, H, W, 4]
+                g = ops.nhwc_to_nchw_f32(dimg, cin) / ctx.scale * gout
+                return None, g, None
+            if below[0] == "conv":
+                d = ops.conv2d_nhwc(dpre, wd, residual=below[2], ks=3, act=ops.ACT_RELU_GATE)
+            else:
+                d = ops.conv2d_nhwc(dpre, wd, ks=3)
+        raise AssertionError("unreachable")
 
 
 class LPIPS(nn.Module):
@@ -122,12 +163,6 @@ class LPIPS(nn.Module):
         self.load_state_dict(torch.load(ckpt_path, map_location=torch.device("cpu"), weights_only=True), strict=False)
 
     def forward(self, input, target):
-        in0, in1 = self.scaling_layer(input), self.scaling_layer(target)
-        in0 = in0.contiguous(memory_format=torch.channels_last)
-        in1 = in1.contiguous(memory_format=torch.channels_last)
-        with torch.no_grad():
-            outs0 = self.net(in0)
-        outs1 = self.net(in1)
-        lins = [self.lin0, self.lin1, self.lin2, self.lin3, self.lin4]
-        ws = [l.model[-1].weight.detach().reshape(-1).float().contiguous() for l in lins]
-        return _LpipsDiff.apply(ws, *outs0, *outs1)
+        if not (input.is_cuda and target.is_cuda):
+            raise ops._lib.DmvaeHipError("LPIPS: expected GPU tensors; dmvae_amd has no CPU path")
+        return _VggLpips.apply(input, target, self)

@@ -38,7 +38,8 @@ typedef struct dmvae_conv_desc {
   int32_t cin, cout;
   int32_t ks;        /* 1 or 3 (3 => padding 1, stride 1) */
   int32_t upsample;  /* 1: nearest x2 of the input folded into the gather (flux_ae.py:103-107) */
-  int32_t act;       /* epilogue: 0 none, 1 SiLU (vae.py:60), 2 ReLU (lpips.py VGG trunk) */
+  int32_t act;       /* epilogue: 0 none, 1 SiLU (vae.py:60), 2 ReLU (lpips.py VGG trunk), 3 ReLU-backward mask: `residual` is
+                        not added but gates the result, y = residual > 0 ? conv + bias : 0 (input gradient through conv+ReLU) */
   int32_t out_f32;   /* 1: y is float32 (parity / final layers), else bf16 */
 } dmvae_conv_desc;
 
@@ -123,6 +124,14 @@ int dmvae_pack_conv_weight(const void* w, void* out, int cout, int cin, int ks, 
 /* dx[n,h,w,c] = sum of the 2x2 block of dy[n,2h,2w,c]: backward of F.interpolate(scale=2,'nearest')
  * (flux_ae.py:104).  bf16, c%8==0. */
 int dmvae_sumpool2x2_nhwc(const void* dy, void* dx, int n, int h, int w, int c, dmvae_stream_t stream);
+/* VGG16 trunk of LPIPS (utils/lpips.py:116-153; nn.MaxPool2d(2,2) and the ReLU backward), NHWC bf16, c%8==0:
+ * y[n,h,w,c] = max of the 2x2 window of x[n,2h,2w,c];
+ * dx = x > 0 ? route(dpool -> first maximum of its window) + extra : 0   (dpool [n,h,w,c] and extra [n,2h,2w,c] may be NULL);
+ * relu_bwd: dx = y > 0 ? dy : 0. */
+int dmvae_maxpool2x2_nhwc(const void* x, void* y, int n, int h, int w, int c, dmvae_stream_t stream);
+int dmvae_maxpool2x2_relu_bwd_nhwc(const void* dpool, const void* x, const void* extra, void* dx, int n, int h, int w, int c,
+                                   dmvae_stream_t stream);
+int dmvae_relu_bwd(const void* dy, const void* y, void* dx, size_t n, dmvae_stream_t stream);
 /* image layout conversion at the Decoder boundary (reference tensors are NCHW f32). */
 int dmvae_nchw_f32_to_nhwc_bf16(const void* src, void* dst, int n, int c, int hw, int c_pad, dmvae_stream_t stream);
 int dmvae_nhwc_to_nchw_f32(const void* src, void* dst, int n, int c, int hw, int c_pad, int src_f32,
