@@ -130,7 +130,21 @@ __global__ void relu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restr
 }
 
 // ---- image layout: NCHW f32 <-> NHWC (channel-padded) ----------------------------------------
+// one thread per (pixel, 8-channel chunk): plane reads are coalesced across pixels, the 16-B store is contiguous in NHWC
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int N, int C, int HW, int Cpad) {
+  const int c8 = Cpad / 8;
+  const size_t total = (size_t)N * HW * c8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c8) * 8;
+    const size_t px = i / c8;
+    const size_t n = px / HW, p = px % HW;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = (bf16)(ch + e < C ? src[(n * C + ch + e) * HW + p] : 0.f);
+    *reinterpret_cast<bf16x8*>(dst + px * Cpad + ch) = o;
+  }
+}
+__global__ void nchw_to_nhwc_scalar_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int N, int C, int HW, int Cpad) {
   const size_t total = (size_t)N * HW;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t n = i / HW, p = i % HW;
@@ -270,7 +284,10 @@ extern "C" int dmvae_relu_bwd(const void* dy, const void* y, void* dx, size_t n,
 
 extern "C" int dmvae_nchw_f32_to_nhwc_bf16(const void* src, void* dst, int n, int c, int hw, int c_pad, hipStream_t stream) {
   DMVAE_CHECK_ARG(src && dst && n > 0 && c > 0 && hw > 0 && c_pad >= c, "nchw_f32_to_nhwc_bf16: bad argument");
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)n * hw)), dim3(256), 0, stream, (const float*)src, (bf16*)dst, n, c, hw, c_pad);
+  if (c_pad % 8 == 0)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)n * hw * (c_pad / 8))), dim3(256), 0, stream, (const float*)src, (bf16*)dst, n, c, hw, c_pad);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_scalar_kernel, dim3(grid_for((size_t)n * hw)), dim3(256), 0, stream, (const float*)src, (bf16*)dst, n, c, hw, c_pad);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -24,9 +24,10 @@ def bump_weight_epoch() -> None:
     _EPOCH[0] += 1
 
 
-def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad: int = 0) -> torch.Tensor:
+def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad: int = 0, frozen: bool = False) -> torch.Tensor:
     """bf16 kernel operand of an f32 conv/linear weight, cached ON the parameter object until the weight changes
-    (in-place updates bump ``_version``; raw-pointer optimisers call bump_weight_epoch)."""
+    (in-place updates bump ``_version``; raw-pointer optimisers call bump_weight_epoch, which `frozen` weights -- not owned
+    by any optimiser, e.g. the LPIPS trunk -- ignore)."""
     cache = getattr(w, "_dmvae_packed", None)
     if cache is None:
         cache = {}
@@ -35,7 +36,7 @@ def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad
         except AttributeError:      # non-leaf views etc.: no caching
             pass
     key = (for_dgrad, rows_pad, cols_pad)
-    ver = (w.data_ptr(), w._version, _EPOCH[0])
+    ver = (w.data_ptr(), w._version, -1 if frozen else _EPOCH[0])
     hit = cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]

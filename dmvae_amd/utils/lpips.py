@@ -95,7 +95,7 @@ class _VggLpips(torch.autograd.Function):
                 tape.append(("pool",))
                 continue
             conv = convs[ci]
-            wp = Fn.packed(conv.weight, False, 0, 32 if conv.weight.shape[1] < 32 else 0)
+            wp = Fn.packed(conv.weight, False, 0, 32 if conv.weight.shape[1] < 32 else 0, frozen=True)
             h = ops.conv2d_nhwc(h, wp, conv.bias.detach().float(), ks=3, act=ops.ACT_RELU)
             df1 = None
             if ci in taps:
@@ -131,7 +131,7 @@ class _VggLpips(torch.autograd.Function):
             # input gradient of this conv; if the layer below is conv+ReLU directly, gate by its saved output in the epilogue
             below = tape[k - 1] if k > 0 else None
             cin = conv.weight.shape[1]
-            wd = Fn.packed(conv.weight, True, 4 if cin < 4 else 0, 0)
+            wd = Fn.packed(conv.weight, True, 4 if cin < 4 else 0, 0, frozen=True)
             if below is None:
                 dimg = ops.conv2d_nhwc(dpre, wd, ks=3, out_f32=True)                      # [B, H, W, 4]
                 g = ops.nhwc_to_nchw_f32(dimg, cin) / ctx.scale * gout
