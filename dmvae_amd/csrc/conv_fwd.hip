@@ -225,6 +225,7 @@ using namespace dmvae_conv_fwd;
 int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void* residual, void* y, const dmvae_conv_desc* d,
                       hipStream_t stream);  // conv_pp.hip; returns 1 when it declines the shape
 
+
 extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* bias, const void* residual,
                                      void* y, const dmvae_conv_desc* d, hipStream_t stream) {
   DMVAE_CHECK_ARG(x && w && y && d, "conv2d_nhwc_fwd: null pointer");

@@ -90,38 +90,33 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.x) - shift), 0, xbytes + shift, 0x00020000);
 
   // Persistent blocks: one per CU, each walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  Re-dispatching a 512-thread
-  // workgroup costs ~2 k cycles per XCD-serialised launch (measured 8-13 k cycle gaps between consecutive 76 k-cycle blocks
-  // of a CU, tools/probes/time_conv_pp.py); gridDim.x is a multiple of 8, so a block's tiles stay on one XCD's contiguous
-  // range of the XCD-aware order.
-  if (a.stagger > 0) {  // de-phase the CUs of an XCD so that their epilogue store bursts do not coincide
-    const int g = (blockIdx.x >> 3) & 7;
-    for (int i = 0; i < g * a.stagger; i++) __builtin_amdgcn_s_sleep(1);
-  }
-  for (unsigned work = blockIdx.x; work < (unsigned)a.total; work += gridDim.x) {
-  const unsigned wid = xcd_remap(work, a.total);
-  const int m0 = (int)(wid / a.ctiles) * TP;  // first pixel
-  const int n0 = (int)(wid % a.ctiles) * TM;  // first cout
-  auto stamp = [&](int k) {
-    if (a.dbg && tid == 0) a.dbg[(size_t)work * 8 + k] = __builtin_amdgcn_s_memtime();
-  };
-  stamp(0);
-
-  // ---- per-lane DMA sources (fixed for the whole tile) ------------------------------------------------------------
-  unsigned voffA[NPA];
-#pragma unroll
-  for (int p = 0; p < NPA; p++) {
-    const int row = (wave * NPA + p) * 16 + (lane >> 2);
-    const int co = n0 + row;
-    const int c = (lane & 3) ^ swz64(row);  // logical 16-B chunk this lane fetches (LDS image stays lane-linear)
-    voffA[p] = co < a.Cout ? (unsigned)co * T * a.Cin * 2u + c * 16u : SENT;
-  }
+  // workgroup costs ~2 k cycles per XCD-serialised launch (tools/probes/time_conv_pp.py); gridDim.x is a multiple of 8, so a
+  // block's tiles stay on one XCD's contiguous range of the XCD-aware order.  The per-tile address setup and the DMA of the
+  // NEXT tile's first two K tiles are issued before the epilogue of the current tile, so the first-tile latency (3-8 k
+  // cycles) hides under the store-bound epilogue (11-13 k cycles); the epilogue stages through ring slots 2.. for that.
   const int hw = a.Ho * a.Wo;
   const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)a.Wo;
   const bool small_m = a.M < (1 << 24);
+  int m0 = 0, n0 = 0;  // tile whose DMA sources are currently set up
+  unsigned voffA[NPA];
   unsigned ctrB[NPB], maskB[NPB], selB[NPB];
   unsigned rowo[UPS ? NPB : 1][3], colo[UPS ? NPB : 1][3];
+  int it = 0, it_tap = 0, it_ch = 0;  // DMA issue state (wave-uniform): tile `it` = (tap it_tap, channel chunk it_ch)
+  unsigned soffB_tap = 0;
+  auto setup = [&](unsigned work) {
+    const unsigned wid = xcd_remap(work, a.total);
+    m0 = (int)(wid / a.ctiles) * TP;  // first pixel
+    n0 = (int)(wid % a.ctiles) * TM;  // first cout
+    it = it_tap = it_ch = 0;
 #pragma unroll
-  for (int p = 0; p < NPB; p++) {
+    for (int p = 0; p < NPA; p++) {
+      const int row = (wave * NPA + p) * 16 + (lane >> 2);
+      const int co = n0 + row;
+      const int c = (lane & 3) ^ swz64(row);  // logical 16-B chunk this lane fetches (LDS image stays lane-linear)
+      voffA[p] = co < a.Cout ? (unsigned)co * T * a.Cin * 2u + c * 16u : SENT;
+    }
+#pragma unroll
+    for (int p = 0; p < NPB; p++) {
     const int row = (wave * NPB + p) * 16 + (lane >> 2);
     const int m = m0 + row;
     const int c = (lane & 3) ^ swz64(row);
@@ -153,6 +148,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     maskB[p] = mask;
     selB[p] = SENT;
   }
+  };
 
   // ---- fragment read offsets (bytes inside a slot) ------------------------------------------------------------------
   const int kg = lane >> 5;
@@ -171,16 +167,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   }
 
   f32x16 acc[BM][BP];
-#pragma unroll
-  for (int i = 0; i < BM; i++)
-#pragma unroll
-    for (int j = 0; j < BP; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  // ---- DMA issue state (wave-uniform): tile `it` = (tap it_tap, channel chunk it_ch) ------------------------------------
-  int it = 0, it_tap = 0, it_ch = 0;
-  unsigned soffB_tap = 0;
   auto new_tap = [&]() {
     const int ky = a.ks == 3 ? it_tap / 3 : 1, kx = a.ks == 3 ? it_tap - (it_tap / 3) * 3 : 1;
     soffB_tap = (!UPS && a.ks == 3) ? (unsigned)(ky * a.Wi + kx) * a.Cin * 2u : 0u;
@@ -212,13 +199,26 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     if (++it_ch == nchunk) { it_ch = 0; it_tap++; }
   };
 
-  // ---- prologue ---------------------------------------------------------------------------------------------------
-  stamp(1);
+  // ---- persistent tile loop ---------------------------------------------------------------------------------------------
+  auto stamp = [&](unsigned work, int k) {
+    if (a.dbg && tid == 0) a.dbg[(size_t)work * 8 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(blockIdx.x, 0);
+  setup(blockIdx.x);
+  stamp(blockIdx.x, 1);
 #pragma unroll
   for (int u = 0; u < PF; u++) issue(u * SLOT);
+  for (unsigned work = blockIdx.x; work < (unsigned)a.total;) {
+  const int m0c = m0, n0c = n0;  // the tile being computed (setup() moves m0 / n0 on to the next one before the epilogue)
+#pragma unroll
+  for (int i = 0; i < BM; i++)
+#pragma unroll
+    for (int j = 0; j < BP; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
   wait_vmcnt<(PF - 1) * NP>();
   __builtin_amdgcn_s_barrier();                // B_0: everybody's pieces of tile 0 have landed
-  stamp(2);
+  stamp(work, 2);
   if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger group 1 by one interval
 
   // ---- main loop ------------------------------------------------------------------------------------------------------
@@ -257,86 +257,104 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
-  stamp(3);
+  stamp(work, 3);
   if (grp == 0) __builtin_amdgcn_s_barrier();  // matches group 1's extra barrier
   wait_vmcnt<0>();                             // the trailing all-zero pieces
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA (inline asm, invisible to the hazard recognizer) -> accumulator reads
 
   // ---- epilogue: accumulators -> LDS (f32, per-wave region) -> whole pixel rows, 16-B coalesced stores --------------------------
   // The MFMA layout gives a lane 4 couts of one pixel: storing that directly touches 32 cache lines per instruction.  Staged
-  // through LDS each store instruction writes RPI full pixel rows of the wave's BM*32 couts instead.  Measured (s_memtime
-  // stamps, tools/probes/time_conv_pp.py): 11-13 k cycles per 128 KB tile = the CU's ~12 B/clk store-issue rate, independent
-  // of what other CUs do (de-phasing the CUs changes nothing) -- 12-14 % of a tile; hiding it needs a second resident tile.
-  __builtin_amdgcn_s_barrier();  // every wave's trailing DMA has landed: the ring is free
+  // through LDS each store instruction writes RPI rows of CWH contiguous couts instead.  Measured (s_memtime stamps,
+  // tools/probes/time_conv_pp.py): 11-13 k cycles per 128 KB tile = the CU's store-issue rate (~75 cycles per
+  // global_store_dwordx4 wave-instruction), independent of what other CUs do -- so the next tile's setup and first DMA are
+  // started first and fly underneath it (staging uses ring slots 2.. in half-cout passes to leave slots 0-1 to that DMA).
+  __builtin_amdgcn_s_barrier();  // every wave's trailing DMA has landed and all fragment reads are done: the ring is free
+  const unsigned next = work + gridDim.x;
+  const bool has_next = next < (unsigned)a.total;
+  if (has_next) {
+    stamp(next, 0);
+    setup(next);
+    stamp(next, 1);
+    issue(0);
+    issue(SLOT);
+  }
   {
-    constexpr int CW = BM * 32;             // couts per wave
-    constexpr int ROWB = CW * 4 + 16;       // padded f32 row (bank-conflict-free ds_write_b128)
-    constexpr int LPR = CW / 8, RPI = 64 / LPR;
-    char* reg = smem + wave * (32 * ROWB);
+    constexpr int EH = BM / 2;               // cout blocks per staging pass
+    constexpr int CWH = EH * 32;             // couts per wave per pass
+    constexpr int ROWB = CWH * 4 + 16;       // padded f32 row (bank-conflict-free ds_write_b128)
+    constexpr int LPR = CWH / 8, RPI = 64 / LPR;
+    char* reg = smem + 2 * SLOT + wave * (32 * ROWB);
     const int px_w = lane & 31;
     const int cl = lane % LPR, rg = lane / LPR;
-    const int cb = n0 + wm * (TM / WM) + cl * 8;  // this lane's 8 couts in the read phase
-    const bool c_ok = cb < a.Cout;
-    float bias8[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) bias8[e] = (a.bias && c_ok) ? a.bias[cb + e] : 0.f;
+    for (int hh = 0; hh < 2; hh++) {
+      const int cb = n0c + wm * (TM / WM) + hh * CWH + cl * 8;  // this lane's 8 couts in the read phase
+      const bool c_ok = cb < a.Cout;
+      float bias8[8];
 #pragma unroll
-    for (int j = 0; j < BP; j++) {
+      for (int e = 0; e < 8; e++) bias8[e] = (a.bias && c_ok) ? a.bias[cb + e] : 0.f;
 #pragma unroll
-      for (int i = 0; i < BM; i++)
+      for (int j = 0; j < BP; j++) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-          *reinterpret_cast<f32x4*>(reg + px_w * ROWB + (i * 32 + 8 * q + 4 * kg) * 4) = v;
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS ops are ordered; the region is private to the wave
+        for (int i = 0; i < EH; i++)
 #pragma unroll
-      for (int it2 = 0; it2 < 32 / RPI; it2++) {
-        const int px = it2 * RPI + rg;
-        const int m = m0 + wp * (TP / WP) + j * 32 + px;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + px * ROWB + cl * 32);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + px * ROWB + cl * 32 + 16);
-        if (m < a.M && c_ok) {
-          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          for (int q = 0; q < 4; q++) {
+            const f32x16& t = acc[hh * EH + i][j];
+            f32x4 v = {t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(reg + px_w * ROWB + (i * 32 + 8 * q + 4 * kg) * 4) = v;
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS ops are ordered; the region is private to the wave
 #pragma unroll
-          for (int e = 0; e < 8; e++) v[e] += bias8[e];
-          const size_t off = (size_t)m * a.Cout + cb;
-          if (a.res) {
-            const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(a.res + off);
-            if (a.act == 3) {  // ReLU-backward gate: `res` is the saved activation, not an addend
+        for (int it2 = 0; it2 < 32 / RPI; it2++) {
+          const int px = it2 * RPI + rg;
+          const int m = m0c + wp * (TP / WP) + j * 32 + px;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + px * ROWB + cl * 32);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + px * ROWB + cl * 32 + 16);
+          if (m < a.M && c_ok) {
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-              for (int e = 0; e < 8; e++) v[e] = (float)r8[e] > 0.f ? v[e] : 0.f;
+            for (int e = 0; e < 8; e++) v[e] += bias8[e];
+            const size_t off = (size_t)m * a.Cout + cb;
+            if (a.res) {
+              const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(a.res + off);
+              if (a.act == 3) {  // ReLU-backward gate: `res` is the saved activation, not an addend
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = (float)r8[e] > 0.f ? v[e] : 0.f;
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] += (float)r8[e];
+              }
+            }
+            if (a.act == 1) {
+#pragma unroll
+              for (int e = 0; e < 8; e++) v[e] = v[e] * sigmoidf_(v[e]);
+            } else if (a.act == 2) {
+#pragma unroll
+              for (int e = 0; e < 8; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            if (OUT_F32) {
+              float* yo = reinterpret_cast<float*>(a.y) + off;
+              *reinterpret_cast<f32x4*>(yo) = f32x4{v[0], v[1], v[2], v[3]};
+              *reinterpret_cast<f32x4*>(yo + 4) = f32x4{v[4], v[5], v[6], v[7]};
             } else {
+              bf16x8 o;
 #pragma unroll
-              for (int e = 0; e < 8; e++) v[e] += (float)r8[e];
+              for (int e = 0; e < 8; e++) o[e] = (bf16)v[e];
+              // non-temporal: the tile is next read by a later kernel, after far more than an L2 of other traffic
+              __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.y) + off));
             }
           }
-          if (a.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = v[e] * sigmoidf_(v[e]);
-          } else if (a.act == 2) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
-          }
-          if (OUT_F32) {
-            float* yo = reinterpret_cast<float*>(a.y) + off;
-            *reinterpret_cast<f32x4*>(yo) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(yo + 4) = f32x4{v[4], v[5], v[6], v[7]};
-          } else {
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; e++) o[e] = (bf16)v[e];
-            // non-temporal: the tile is next read by a later kernel, after far more than an L2 of other traffic
-            __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.y) + off));
-          }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads retired before the next block overwrites the region
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads retired before the next block overwrites the region
     }
   }
-  stamp(4);
-  if (a.dbg) { wait_vmcnt<0>(); stamp(5); }
-  __builtin_amdgcn_s_barrier();  // staging reads done before the next tile's DMA reuses the LDS
+  stamp(work, 4);
+  wait_vmcnt<0>();               // the epilogue's stores share vmcnt with the two prefetched K tiles: drain both
+  stamp(work, 5);
+  __builtin_amdgcn_s_barrier();  // staging reads done before ring slots 2.. are refilled
+  if (has_next) issue(2 * SLOT);
+  work = next;
   }  // persistent tile loop
 #endif
 }
@@ -347,7 +365,7 @@ int launch(Args a, hipStream_t st) {
   a.total = ((a.M + TP - 1) / TP) * a.ctiles;
   static const int persist = [] { const char* e = getenv("DMVAE_PP_GRID"); return e ? atoi(e) : 256; }();  // 0: one block per tile
   const unsigned grid = (persist > 0 && a.total > persist) ? (unsigned)persist : (unsigned)a.total;
-  constexpr int ring = NBUF * (TM + TP) * 64, epi = 8 * 32 * ((TM / WM) * 4 + 16);
+  constexpr int ring = NBUF * (TM + TP) * 64, epi = 2 * (TM + TP) * 64 + 8 * 32 * ((TM / WM / 2) * 4 + 16);
   constexpr int lds = ring > epi ? ring : epi;
   static bool attr_done = false;
   if (!attr_done) {

@@ -6,7 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from dmvae_amd import ops, _lib
 L = _lib.lib()
+DB = False
 L.dmvae_debug_timing.argtypes = [ctypes.c_void_p]
+
+set_dbg = L.dmvae_debug_timing
 SHAPES = [("512>512@32", 32, 32, 32, 512, 512, 3), ("128>128@256", 32, 256, 256, 128, 128, 3), ("256>256@128", 32, 128, 128, 256, 256, 3)]
 for name, n, h, w, cin, cout, ks in SHAPES:
     x = torch.randn(n, h, w, cin, device="cuda").to(torch.bfloat16)
@@ -14,10 +17,10 @@ for name, n, h, w, cin, cout, ks in SHAPES:
     b = torch.randn(cout, device="cuda")
     for _ in range(2): ops.conv2d_nhwc(x, wt, b, ks=ks)
     buf = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")
-    L.dmvae_debug_timing(buf.data_ptr())
+    set_dbg(buf.data_ptr())
     ops.conv2d_nhwc(x, wt, b, ks=ks)
     torch.cuda.synchronize()
-    L.dmvae_debug_timing(None)
+    set_dbg(None)
     t = buf.view(-1, 8).cpu().double()
     nb = int((t[:, 0] != 0).sum())
     t = t[:nb]
