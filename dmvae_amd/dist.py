@@ -27,7 +27,8 @@ _rank, _world, _local_rank = 0, 1, 0
 def init_distributed_mode(backend: Optional[str] = None, timeout_minutes: int = 30) -> None:
     """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the env (torchrun).  No env -> single process, collectives are no-ops."""
     global _initialized, _rank, _world, _local_rank
-    if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    force = os.environ.get("DMVAE_FORCE_DIST", "0") != "0"   # diagnostics: run the collective path on a single rank
+    if "RANK" not in os.environ or (int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not force):
         if torch.cuda.is_available():
             torch.cuda.set_device(0)
         return
@@ -91,7 +92,7 @@ class FlatGradSync:
                  bucket_bytes: int = 64 << 20):
         self.flat_grad = flat_grad
         self.world = get_world_size()
-        self.enabled = initialized() and self.world > 1
+        self.enabled = initialized() and (self.world > 1 or os.environ.get("DMVAE_FORCE_DIST", "0") != "0")
         self.buckets: List[List[int]] = []      # [start, end, n_params]
         self.param_bucket: List[int] = []
         cur_start, cur_n = 0, 0

@@ -294,6 +294,36 @@ def silu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     return dx
 
 
+# ---- frozen ViT encoder, elementwise ---------------------------------------------------------------------
+def layernorm_bf16(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """LayerNorm over the last dim of an f32 tensor, bf16 result (what autocast feeds the next Linear)."""
+    x = _req(x, f32, "x")
+    c = x.shape[-1]
+    y = torch.empty(x.shape, dtype=bf16, device=x.device)
+    check(_lib.lib().dmvae_layernorm_f32_bf16(x.data_ptr(), _req(gamma, f32, "gamma").data_ptr(), _req(beta, f32, "beta").data_ptr(), y.data_ptr(),
+                                              x.numel() // c, c, float(eps), _stream()), "layernorm_f32_bf16")
+    return y
+
+
+def softmax_rows_bf16(s: torch.Tensor, scale: float) -> torch.Tensor:
+    """softmax(scale * s) over the last dim, bf16 in / bf16 out, f32 inside."""
+    s = _req(s, bf16, "S")
+    p = torch.empty_like(s)
+    check(_lib.lib().dmvae_softmax_rows_bf16(s.data_ptr(), p.data_ptr(), s.numel() // s.shape[-1], s.shape[-1], float(scale), _stream()), "softmax_rows_bf16")
+    return p
+
+
+def scale_residual_(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor) -> torch.Tensor:
+    """x (f32, in place) += gamma * y (bf16): LayerScale + residual add."""
+    x = _req(x, f32, "x")
+    y = _req(y, bf16, "y")
+    assert x.shape == y.shape
+    c = x.shape[-1]
+    check(_lib.lib().dmvae_scale_residual_f32(x.data_ptr(), y.data_ptr(), _req(gamma, f32, "gamma").data_ptr(), x.numel() // c, c, _stream()),
+          "scale_residual_f32")
+    return x
+
+
 # ---- losses ---------------------------------------------------------------------------------------
 def _loss_ws(device) -> torch.Tensor:
     return workspace(_lib.lib().dmvae_loss_workspace(), device, slot="loss")

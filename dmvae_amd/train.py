@@ -78,12 +78,21 @@ class TokenizerTrainer:
         self._enc = frozen_bf16_shadow(self.vae.encoder)
         self._lpips = self.lpips          # LPIPS runs on the HIP conv kernels with cached bf16 operands: no shadow needed
 
+    def _encode(self, images: torch.Tensor) -> torch.Tensor:
+        """Frozen encoder forward (DINOEncoder.forward, models/vae.py:52-53) on the bf16 shadow; widths the HIP LayerNorm covers
+        take the fused elementwise path, anything else the stock module."""
+        enc = self._enc
+        if enc.model.embed_dim % 256 == 0 and enc.model.embed_dim <= 1536:
+            from .models.vit_fast import frozen_forward_features
+            return frozen_forward_features(enc.model, enc.scale(enc.de_scale(images)))[:, enc.model.num_prefix_tokens:]
+        return enc(images)
+
     def step(self, images: torch.Tensor) -> torch.Tensor:
         vae, w = self.vae, self.w
         self.fp.begin_step()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             with torch.no_grad():
-                tokens = self._enc(images)
+                tokens = self._encode(images)
             latent = vae.bottle_neck(tokens)
             recon = vae.decoder(latent).float()
             l1, l2 = losses.l1_mse(recon, images, w["l1"], w["l2"])

@@ -140,6 +140,17 @@ int dmvae_nhwc_to_nchw_f32(const void* src, void* dst, int n, int c, int hw, int
 int dmvae_silu_fwd(const void* x, void* y, size_t n, dmvae_stream_t stream);
 int dmvae_silu_bwd(const void* x, const void* dy, void* dx, size_t n, dmvae_stream_t stream);
 
+/* ---- frozen ViT encoder forward, elementwise part (models/vae.py:52-53; timm / dino_layers block algebra) ------------------- */
+
+/* y[rows][c] (bf16) = LayerNorm(x[rows][c] f32; gamma, beta f32, eps): nn.LayerNorm under autocast (f32) + the bf16 cast in front
+ * of the following Linear.  c in {256, 512, ..., 1536}. */
+int dmvae_layernorm_f32_bf16(const void* x, const void* gamma, const void* beta, void* y, int rows, int c, float eps,
+                             dmvae_stream_t stream);
+/* x[rows][c] (f32, in place) += gamma[c] * y[rows][c] (bf16): LayerScale (dino_layers/layer_scale.py:15-26) + residual add. c%8==0. */
+int dmvae_scale_residual_f32(void* x, const void* y, const void* gamma, size_t rows, int c, dmvae_stream_t stream);
+/* p[rows][cols] (bf16) = softmax(scale * s[rows][cols]) with bf16 scores, f32 inside; cols <= 512 (encoder attention, S = 257). */
+int dmvae_softmax_rows_bf16(const void* s, void* p, size_t rows, int cols, float scale, dmvae_stream_t stream);
+
 /* ---- losses (HBM-bound reductions) ------------------------------------------------------------- */
 
 size_t dmvae_loss_workspace(void);

@@ -53,3 +53,34 @@ def test_direct_flat_grads_match_autograd_accumulation():
     assert losses[-1] < losses[0]
     log = c.read_log()
     assert log["L1"] > 0 and log["LPIPS"] > 0 and log["vae_norm"] > 0
+
+
+def test_frozen_vit_fast_path_matches_stock_module():
+    """csrc/vit.hip kernels (LayerNorm -> bf16, LayerScale + residual) inside the frozen-encoder forward vs the stock module under
+    autocast, and each kernel vs its fp64 definition."""
+    from dmvae_amd import ops
+    from dmvae_amd.models.vit import DinoV2ViT
+    from dmvae_amd.models.vit_fast import frozen_forward_features
+    from dmvae_amd.train import frozen_bf16_shadow
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(37, 1024, generator=g) * 2 + 0.5).cuda()
+    gam, bet = torch.randn(1024, generator=g).cuda(), torch.randn(1024, generator=g).cuda()
+    y = ops.layernorm_bf16(x, gam, bet, 1e-6)
+    ref = torch.nn.functional.layer_norm(x.double(), (1024,), gam.double(), bet.double(), 1e-6)
+    assert torch.equal(y, ref.float().to(torch.bfloat16)) or (y.float() - ref.float()).abs().max() < 2e-2
+    assert ((y.double() - ref).abs() / (ref.abs() + 1)).max() < 5e-3
+    r = torch.randn(37, 1024, generator=g).cuda()
+    yb = torch.randn(37, 1024, generator=g).cuda().to(torch.bfloat16)
+    want = r.double() + gam.double() * yb.double()
+    ops.scale_residual_(r, yb, gam)
+    assert (r.double() - want).abs().max() < 1e-5
+    torch.manual_seed(0)
+    vit = DinoV2ViT(embed_dim=256, depth=2, num_heads=4, patch_size=16, img_size=64).cuda().eval()
+    with torch.no_grad():
+        for blk in vit.blocks:
+            blk.ls1.gamma.fill_(0.5); blk.ls2.gamma.fill_(0.5)
+    img = torch.randn(3, 3, 64, 64, generator=g).cuda()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        want = vit.forward_features(img).float()
+    got = frozen_forward_features(frozen_bf16_shadow(vit), img).float()
+    assert ((got - want).norm() / want.norm()).item() < 2e-2
