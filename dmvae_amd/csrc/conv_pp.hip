@@ -399,7 +399,8 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
   const long long M = (long long)d->n * d->h * d->w * (ups ? 4 : 1);
   const long long xbytes = (long long)d->n * d->h * d->w * d->cin * 2;
   const long long wbytes = (long long)d->cout * d->ks * d->ks * d->cin * 2;
-  if (d->cin % 32 != 0 || d->cout < 64 || d->cout % 8 != 0 || M < 16384 || xbytes + (1ll << 22) >= (1ll << 31) || wbytes >= (1ll << 31)) return 1;
+  static const long long min_m = [] { const char* e = getenv("DMVAE_PP_MINM"); return e ? atoll(e) : 16384ll; }();
+  if (d->cin % 32 != 0 || d->cout < 64 || d->cout % 8 != 0 || M < min_m || xbytes + (1ll << 22) >= (1ll << 31) || wbytes >= (1ll << 31)) return 1;
   Args a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.res = (const bf16*)residual; a.y = y;
   a.N = d->n; a.Hi = d->h; a.Wi = d->w; a.Cin = d->cin; a.Cout = d->cout;

@@ -124,3 +124,154 @@ extern "C" int dmvae_softmax_rows_bf16(const void* s, void* p, size_t rows, int 
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- fused multi-head self-attention of the encoder (timm Attention / dino_layers/attention.py:56-69; head dim 64, S <= 288) ------
+// qkv: [B][S][3][H][64] bf16 (the qkv Linear's output as it lies in memory), out: [B][S][H*64] bf16.
+// One workgroup per (batch, head): K ([key][d], 128-B rows, 16-B chunks XOR-swizzled by key & 7) and V ([key][128-slot rows] with
+// the 64-B segment swizzle of the wgrad kernels, so the same ds_read_b64_tr_b16 addressing applies) are staged in LDS once; each
+// wave walks 32-query blocks:  S^T = K Q^T on the matrix cores (so a lane owns one query column and softmax needs no
+// cross-lane traffic beyond one swap with lane^32), f32 softmax with the 1/sum folded into P, P -> bf16 A-fragments by
+// v_permlane32_swap, O = P V with V fragments from the LDS transpose read.  Nothing of size S x S ever reaches HBM.
+namespace dmvae_vit {
+
+constexpr int ATT_D = 64, ATT_KB = 9, ATT_KEYS = ATT_KB * 32;  // keys padded to 288
+
+__device__ __forceinline__ s16x4 tr_read_v(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  bf16x2 t = {(bf16)a, (bf16)b};
+  return *reinterpret_cast<unsigned*>(&t);
+}
+
+__global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int S, int H, float scale) {
+#if __HIP_DEVICE_COMPILE__
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ks = smem;                       // [288][128 B]
+  char* vs = smem + ATT_KEYS * 128;      // [288][256 B] (channels 0..63 used)
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int C = H * ATT_D;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16* base = qkv + (size_t)b * S * 3 * C + h * ATT_D;
+  // ---- stage K and V: 8 lanes x 16 B per key row -----------------------------------------------------------------------------------
+  for (int i = tid; i < ATT_KEYS * 8; i += 256) {
+    const int key = i >> 3, c = i & 7;
+    uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+    if (key < S) {
+      kv = *reinterpret_cast<const uint4*>(base + ((size_t)key * 3 + 1) * C + c * 8);
+      vv = *reinterpret_cast<const uint4*>(base + ((size_t)key * 3 + 2) * C + c * 8);
+    }
+    *reinterpret_cast<uint4*>(ks + key * 128 + ((c ^ (key & 7)) << 4)) = kv;
+    // V: channel chunk c (8 channels) -> 64-B segment c >> 2, swizzled by key & 3; 16-B slot c & 3 inside it
+    *reinterpret_cast<uint4*>(vs + key * 256 + ((((c >> 2) ^ (key & 3))) << 6) + ((c & 3) << 4)) = vv;
+  }
+  __syncthreads();
+  const int kg = lane >> 5, ql = lane & 31;
+  // V transpose-read addressing (see conv_wgrad_pp.hip): lane supplies 4 channels of one key row
+  const int g16 = (lane >> 4) & 1, rr = (lane & 15) >> 2, qq = lane & 3;
+  int voff[2];
+#pragma unroll
+  for (int db = 0; db < 2; db++) {
+    const int ch = db * 32 + 16 * g16 + 4 * qq;
+    voff[db] = (kg * 8 + rr) * 256 + ((((ch >> 5) ^ rr)) << 6) + (ch & 31) * 2;
+  }
+  for (int qb = wave; qb * 32 < S; qb += 4) {
+    const int q = qb * 32 + ql;
+    // Q fragments (B operand of the swapped product): 8 d's per lane per 16-step
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      uint4 t = {0, 0, 0, 0};
+      if (q < S) t = *reinterpret_cast<const uint4*>(base + (size_t)q * 3 * C + kk * 16 + kg * 8);
+      qf[kk] = *reinterpret_cast<bf16x8*>(&t);
+    }
+    // ---- S^T = K Q^T: acc[kb][r] = score(key = kb*32 + (r&3) + 8*(r>>2) + 4*kg, query q) ------------------------------------------
+    f32x16 st[ATT_KB];
+#pragma unroll
+    for (int kb = 0; kb < ATT_KB; kb++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) st[kb][r] = 0.f;
+      const int key = kb * 32 + ql;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + key * 128 + ((((kk * 2 + kg)) ^ (key & 7)) << 4));
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kb], 0, 0, 0);
+      }
+    }
+    // ---- softmax over keys (this lane + lane^32 own the column) ------------------------------------------------------------------
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < ATT_KB; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        const float v = key < S ? st[kb][r] * scale : -INFINITY;
+        st[kb][r] = v;
+        m = fmaxf(m, v);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < ATT_KB; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { const float e = __expf(st[kb][r] - m); st[kb][r] = e; sum += e; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    // ---- O = P V ---------------------------------------------------------------------------------------------------------------------
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) o[db][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < ATT_KB; kb++) {
+#pragma unroll
+      for (int half = 0; half < 2; half++) {  // 16-key step: registers r = half*8 .. half*8+7 of this block
+        unsigned p0 = pack_bf16(st[kb][half * 8 + 0] * inv, st[kb][half * 8 + 1] * inv);
+        unsigned p1 = pack_bf16(st[kb][half * 8 + 2] * inv, st[kb][half * 8 + 3] * inv);
+        unsigned p2 = pack_bf16(st[kb][half * 8 + 4] * inv, st[kb][half * 8 + 5] * inv);
+        unsigned p3 = pack_bf16(st[kb][half * 8 + 6] * inv, st[kb][half * 8 + 7] * inv);
+        // lanes < 32 hold keys {0-3, 8-11} of the step, lanes >= 32 {4-7, 12-15}: the A fragment wants {0-7} / {8-15}
+        auto s0 = __builtin_amdgcn_permlane32_swap(p0, p2, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(p1, p3, false, false);
+        union { unsigned u[4]; bf16x8 v; } pa;
+        pa.u[0] = s0[0]; pa.u[1] = s1[0]; pa.u[2] = s0[1]; pa.u[3] = s1[1];
+        const int ksn = kb * 2 + half;
+#pragma unroll
+        for (int db = 0; db < 2; db++) {
+          union { bf16x8 v; s16x4 hlf[2]; } vf;
+          vf.hlf[0] = tr_read_v(vs + ksn * 4096 + voff[db]);
+          vf.hlf[1] = tr_read_v(vs + ksn * 4096 + voff[db] + 1024);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.v, vf.v, o[db], 0, 0, 0);
+        }
+      }
+    }
+    // ---- store: rows q = qb*32 + (r&3) + 8*(r>>2) + 4*kg, column d = db*32 + (lane & 31) -----------------------------------------------
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int qo = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (qo < S) out[((size_t)b * S + qo) * C + h * ATT_D + db * 32 + ql] = (bf16)o[db][r];
+      }
+  }
+#endif
+}
+
+}  // namespace dmvae_vit
+
+extern "C" int dmvae_attention_qkv_bf16(const void* qkv, void* out, int batch, int seq, int heads, int head_dim, float scale,
+                                        hipStream_t stream) {
+  using namespace dmvae_vit;
+  DMVAE_CHECK_ARG(qkv && out && batch > 0 && heads > 0 && seq > 0, "attention_qkv_bf16: bad argument");
+  DMVAE_CHECK_ARG(head_dim == ATT_D && seq <= ATT_KEYS, "attention_qkv_bf16: needs head_dim 64 and seq <= 288 (got %d, %d)", head_dim, seq);
+  constexpr int lds = ATT_KEYS * 128 + ATT_KEYS * 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(attention_kernel, dim3(batch * heads), dim3(256), lds, stream, (const bf16*)qkv, (bf16*)out, seq, heads, scale);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}

@@ -313,6 +313,16 @@ def softmax_rows_bf16(s: torch.Tensor, scale: float) -> torch.Tensor:
     return p
 
 
+def attention_qkv(qkv: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """Fused multi-head self-attention on the qkv Linear's output [B, S, 3*heads*64] (bf16) -> [B, S, heads*64]."""
+    qkv = _req(qkv, bf16, "qkv")
+    b, s, c3 = qkv.shape
+    c = c3 // 3
+    out = torch.empty(b, s, c, dtype=bf16, device=qkv.device)
+    check(_lib.lib().dmvae_attention_qkv_bf16(qkv.data_ptr(), out.data_ptr(), b, s, heads, c // heads, float(scale), _stream()), "attention_qkv_bf16")
+    return out
+
+
 def scale_residual_(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor) -> torch.Tensor:
     """x (f32, in place) += gamma * y (bf16): LayerScale + residual add."""
     x = _req(x, f32, "x")

@@ -150,6 +150,10 @@ int dmvae_layernorm_f32_bf16(const void* x, const void* gamma, const void* beta,
 int dmvae_scale_residual_f32(void* x, const void* y, const void* gamma, size_t rows, int c, dmvae_stream_t stream);
 /* p[rows][cols] (bf16) = softmax(scale * s[rows][cols]) with bf16 scores, f32 inside; cols <= 512 (encoder attention, S = 257). */
 int dmvae_softmax_rows_bf16(const void* s, void* p, size_t rows, int cols, float scale, dmvae_stream_t stream);
+/* out[b][s][h*64+d] = softmax_k(scale * q.k) v for qkv [b][s][3][h][64] bf16 (the qkv Linear's output layout): the encoder's
+ * multi-head self-attention (timm Attention; dino_layers/attention.py:56-69) fused in one kernel.  head_dim 64, seq <= 288. */
+int dmvae_attention_qkv_bf16(const void* qkv, void* out, int batch, int seq, int heads, int head_dim, float scale,
+                             dmvae_stream_t stream);
 
 /* ---- losses (HBM-bound reductions) ------------------------------------------------------------- */
 

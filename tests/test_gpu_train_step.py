@@ -84,3 +84,19 @@ def test_frozen_vit_fast_path_matches_stock_module():
         want = vit.forward_features(img).float()
     got = frozen_forward_features(frozen_bf16_shadow(vit), img).float()
     assert ((got - want).norm() / want.norm()).item() < 2e-2
+
+
+@pytest.mark.parametrize("shape", [(2, 257, 16), (3, 65, 4), (1, 288, 2), (2, 17, 3)])
+def test_fused_encoder_attention_vs_reference(shape):
+    from dmvae_amd import ops
+    b, s, h = shape
+    c = h * 64
+    g = torch.Generator().manual_seed(s)
+    qkv = (torch.randn(b, s, 3 * c, generator=g) * 1.5).cuda().to(torch.bfloat16)
+    out = ops.attention_qkv(qkv, h, 64 ** -0.5)
+    t = qkv.double().reshape(b, s, 3, h, 64).permute(2, 0, 3, 1, 4)
+    att = torch.softmax(t[0] @ t[1].transpose(-2, -1) * 64 ** -0.5, dim=-1)
+    ref = (att @ t[2]).transpose(1, 2).reshape(b, s, c)
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2e-2 * ref.abs().max().item() + 1e-3, err     # P and O are rounded to bf16 once each
+    assert torch.equal(out, ops.attention_qkv(qkv, h, 64 ** -0.5))
