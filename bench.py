@@ -151,8 +151,14 @@ def main():
     log = tr.read_log()
     if rank != 0:
         return
-    k_ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in timing)
-    k_flop = sum(f for *_, f in timing)
+    DOMINANT = "conv_pp_kernel<256, 256, 2, 4, 4, false, false>"
+    per = {}
+    for label, e0, e1, fl in timing:
+        a = per.setdefault(label, [0.0, 0.0, 0])
+        a[0] += e0.elapsed_time(e1); a[1] += fl; a[2] += 1
+    k_ms, k_flop, k_n = per.get(DOMINANT, [0.0, 0.0, 0])
+    all_ms = sum(a[0] for a in per.values())
+    all_flop = sum(a[1] for a in per.values())
     achieved = k_flop / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     out = {
         "metric": "images/sec DMVAE train step @256x256",
@@ -166,11 +172,13 @@ def main():
                                "AdamW + EMA, ImageNet-256-shaped synthetic batch, random-init weights",
                    "local_batch": args.batch, "global_batch": world * args.batch, "image": "3x256x256", "z_channels": 32,
                    "parallelism": f"dp{world}", "loss_after_run": round(log["rec_loss"], 5)},
-        "roofline": {"bound": "mfma", "kernel": "dmvae_conv_pp::conv_pp_kernel (decoder conv forward + dgrad launches through dmvae_conv2d_nhwc_fwd)",
+        "roofline": {"bound": "mfma", "kernel": "dmvae_conv_pp::" + DOMINANT + " (conv forward / input-gradient, Cout >= 256; decoder + LPIPS trunk)",
                      "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                     "launches": len(timing), "avg_launch_us": round(k_ms * 1e3 / max(1, len(timing)), 2),
-                     "share_of_step": round(k_ms / (dt * 1e3), 3)},
+                     "launches": k_n, "avg_launch_us": round(k_ms * 1e3 / max(1, k_n), 2),
+                     "share_of_step": round(k_ms / (dt * 1e3), 3),
+                     "all_conv_fwd_dgrad_launches": {"launches": len(timing), "achieved_TFLOPs": round(all_flop / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,
+                                                     "share_of_step": round(all_ms / (dt * 1e3), 3)}},
     }
     if world == 1:
         out["kl_mmd"] = kl_mmd_roofline(dev)

@@ -295,6 +295,15 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       for (int e = 0; e < 8; e++) bias8[e] = (a.bias && c_ok) ? a.bias[cb + e] : 0.f;
 #pragma unroll
       for (int j = 0; j < BP; j++) {
+        // residual / gate operand of this pass: issued up front so the loads fly under the LDS transpose below
+        bf16x8 r8s[32 / RPI];
+        if (a.res) {
+#pragma unroll
+          for (int it2 = 0; it2 < 32 / RPI; it2++) {
+            const int m = m0c + wp * (TP / WP) + j * 32 + it2 * RPI + rg;
+            if (m < a.M && c_ok) r8s[it2] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(a.res + (size_t)m * a.Cout + cb));
+          }
+        }
 #pragma unroll
         for (int i = 0; i < EH; i++)
 #pragma unroll
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
             for (int e = 0; e < 8; e++) v[e] += bias8[e];
             const size_t off = (size_t)m * a.Cout + cb;
             if (a.res) {
-              const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(a.res + off);
+              const bf16x8 r8 = r8s[it2];
               if (a.act == 3) {  // ReLU-backward gate: `res` is the saved activation, not an addend
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = (float)r8[e] > 0.f ? v[e] : 0.f;

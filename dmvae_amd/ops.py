@@ -97,7 +97,14 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
     if timing is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        timing.append(("conv_fwd_kernel", e0, e1, 2.0 * n * ho * wo * cout * cin * ks * ks))
+        # which kernel dmvae_conv2d_nhwc_fwd dispatched to (csrc/conv_pp.hip::dmvae_conv_pp_try), so that the bench's per-kernel
+        # average can be checked against rocprofv3's per-kernel-name average
+        if cin % 32 == 0 and cout >= 64 and cout % 8 == 0 and n * ho * wo >= 16384:
+            label = "conv_pp_kernel<%s, %s, %s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", "true" if upsample else "false",
+                                                     "true" if out_f32 else "false")
+        else:
+            label = "conv_fwd_kernel"
+        timing.append((label, e0, e1, 2.0 * n * ho * wo * cout * cin * ks * ks))
     return y
 
 

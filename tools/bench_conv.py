@@ -35,6 +35,15 @@ for name, n, h, w, cin, cout, ks, ups in SHAPES:
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         out += f"  fwd {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF/s"
+    if "res" in which:
+        r = torch.randn(n, ho, wo, cout, device="cuda").to(torch.bfloat16)
+        for _ in range(2): ops.conv2d_nhwc(x, wt, b, r, ks=ks, upsample=bool(ups))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps): ops.conv2d_nhwc(x, wt, b, r, ks=ks, upsample=bool(ups))
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        out += f"  fwd+residual {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF/s"
     if "wgrad" in which:
         for _ in range(2): ops.conv2d_nhwc_wgrad(dy, x, ks, upsample=bool(ups))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
