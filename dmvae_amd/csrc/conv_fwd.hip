@@ -101,8 +101,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
       const int q = wave * G::LPW + j;
       const bf16* src = zero;
       int iy = prow_y[j] + ky, ix = prow_x[j] + kx;
-      if (prow_n[j] >= 0 && iy >= 0 && iy < a.Ho && ix >= 0 && ix < a.Wo) {
-        if (a.ups) { iy >>= 1; ix >>= 1; }
+      bool ok = prow_n[j] >= 0 && iy >= 0 && iy < a.Ho && ix >= 0 && ix < a.Wo;
+      if (a.ups == 3) {  // stride 2 over the (0,1,0,1)-padded input: tap (ky+1, kx+1) of output pixel (y, x) reads (2y+ky+1, 2x+kx+1)
+        iy += prow_y[j] + 1; ix += prow_x[j] + 1;
+        ok = prow_n[j] >= 0 && iy < a.Hi && ix < a.Wi;
+      } else if (a.ups == 2) {  // zero-insertion x2: only odd positions carry data
+        ok = ok && (iy & 1) && (ix & 1);
+      }
+      if (ok) {
+        if (a.ups == 1 || a.ups == 2) { iy >>= 1; ix >>= 1; }
         src = a.x + ((size_t)(prow_n[j] * a.Hi + iy) * a.Wi + ix) * a.Cin + ch * BK + csrc[j];
       }
       __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(pt + q * 1024), 16, 0, 0);
@@ -241,8 +248,12 @@ extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* b
   ConvArgs a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.res = (const bf16*)residual; a.y = y;
   a.N = d->n; a.Hi = d->h; a.Wi = d->w; a.Cin = d->cin; a.Cout = d->cout;
-  a.ups = d->upsample ? 1 : 0;
-  a.Ho = a.ups ? 2 * d->h : d->h; a.Wo = a.ups ? 2 * d->w : d->w;
+  DMVAE_CHECK_ARG(d->upsample >= 0 && d->upsample <= 2 && (d->stride == 0 || d->stride == 1 || d->stride == 2),
+                  "conv2d_nhwc_fwd: bad upsample (%d) / stride (%d)", d->upsample, d->stride);
+  DMVAE_CHECK_ARG(d->stride != 2 || (d->ks == 3 && !d->upsample && d->h % 2 == 0 && d->w % 2 == 0),
+                  "conv2d_nhwc_fwd: stride 2 needs ks=3, no upsample, even h and w");
+  a.ups = d->stride == 2 ? 3 : d->upsample;   // gather mode: 0 plain, 1 nearest x2, 2 zero-insertion x2, 3 stride 2
+  a.Ho = a.ups == 3 ? d->h / 2 : (a.ups ? 2 * d->h : d->h); a.Wo = a.ups == 3 ? d->w / 2 : (a.ups ? 2 * d->w : d->w);
   a.ks = d->ks; a.act = d->act;
   a.x_bs = a.w_bs = a.y_bs = 0;
   const long long M = (long long)a.N * a.Ho * a.Wo;

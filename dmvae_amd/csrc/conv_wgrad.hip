@@ -94,8 +94,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
       const int p = k0 + s * BKP + q * 4 + (lane >> 4);
       const bf16* src = zero;
       int iy = py[j] + ky, ix = px[j] + kx;
-      if (p < k1 && ci_ok[j] && iy >= 0 && iy < a.Ho && ix >= 0 && ix < a.Wo) {
-        if (a.ups) { iy >>= 1; ix >>= 1; }
+      bool ok = iy >= 0 && iy < a.Ho && ix >= 0 && ix < a.Wo;
+      if (a.ups == 3) {  // stride-2 Downsample conv: output pixel (y, x), tap (ky+1, kx+1) pairs with input (2y+ky+1, 2x+kx+1)
+        iy += py[j] + 1; ix += px[j] + 1;
+        ok = iy < a.Hi && ix < a.Wi;
+      }
+      if (p < k1 && ci_ok[j] && ok) {
+        if (a.ups == 1) { iy >>= 1; ix >>= 1; }
         src = a.a + ((size_t)(pn[j] * a.Hi + iy) * a.Wi + ix) * a.Cin + ci0 + clog[j];
       }
       __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(at + q * 1024), 16, 0, 0);
@@ -263,7 +268,7 @@ extern "C" size_t dmvae_conv2d_nhwc_wgrad_workspace(const dmvae_conv_desc* d) {
     if ((d->ks == 1 || d->ks == 3) && dmvae_wgrad_pp_plan(d, &sp, &kc, &cfg))
       return (size_t)sp * d->cout * T * d->cin * sizeof(float) + (size_t)4096 * d->cout * sizeof(float);  // + [splits*ntiles <= 4096][cout] bias partials
   }
-  const long long M = (long long)d->n * d->h * d->w * (d->upsample ? 4 : 1);
+  const long long M = d->stride == 2 ? (long long)d->n * (d->h / 2) * (d->w / 2) : (long long)d->n * d->h * d->w * (d->upsample ? 4 : 1);
   const int tiles = ((d->cout + 127) / 128) * ((d->cin + 127) / 128) * T;
   const int splits = pick_splits((int)M, tiles);
   size_t slab = (size_t)splits * d->cout * T * d->cin * sizeof(float);
@@ -282,8 +287,11 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
   WgradArgs w;
   w.dy = (const bf16*)dy; w.a = (const bf16*)a; w.slab = (float*)workspace;
   w.N = d->n; w.Hi = d->h; w.Wi = d->w; w.Cin = d->cin; w.Cout = d->cout; w.ks = d->ks;
-  w.ups = d->upsample ? 1 : 0;
-  w.Ho = w.ups ? 2 * d->h : d->h; w.Wo = w.ups ? 2 * d->w : d->w;
+  DMVAE_CHECK_ARG(d->upsample == 0 || d->upsample == 1, "conv2d_nhwc_wgrad: upsample must be 0 or 1");
+  DMVAE_CHECK_ARG(d->stride != 2 || (d->ks == 3 && !d->upsample && d->h % 2 == 0 && d->w % 2 == 0),
+                  "conv2d_nhwc_wgrad: stride 2 needs ks=3, no upsample, even h and w");
+  w.ups = d->stride == 2 ? 3 : d->upsample;   // gather mode: 0 plain, 1 nearest x2, 3 stride 2
+  w.Ho = w.ups == 3 ? d->h / 2 : (w.ups ? 2 * d->h : d->h); w.Wo = w.ups == 3 ? d->w / 2 : (w.ups ? 2 * d->w : d->w);
   const long long M = (long long)w.N * w.Ho * w.Wo;
   DMVAE_CHECK_ARG(M > 0 && M < (1ll << 31) / 4, "conv2d_nhwc_wgrad: bad pixel count");
   w.M = (int)M;

@@ -164,6 +164,76 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class DownsampleFn(torch.autograd.Function):
+    """Downsample conv (flux_ae.py:85-95): F.pad(x, (0,1,0,1)) then conv3x3 stride 2, as one strided gather in the conv
+    kernel.  Its input gradient is the stride-1 dgrad conv over dy zero-inserted at odd positions (desc.upsample = 2)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        y = ops.conv2d_nhwc(x, packed(w), b, ks=3, stride=2)
+        ctx.save_for_backward(x, w)
+        ctx.bias_param = b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dw, db = ops.conv2d_nhwc_wgrad(dy, x, 3, stride=2, dw_out=_dst(w), db_out=_dst(ctx.bias_param))
+        dx = ops.conv2d_nhwc(dy, packed(w, True), ks=3, upsample=2) if ctx.needs_input_grad[0] else None
+        return dx, dw, db
+
+
+class ConvInFn(torch.autograd.Function):
+    """conv3x3 on an NCHW f32 image whose channel count is not a multiple of 32 (Encoder.conv_in, flux_ae.py:127): channels are
+    zero-padded to 32 on the way into NHWC bf16."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        cin = x.shape[1]
+        xp = ops.nchw_to_nhwc_bf16(_c(x.float()), c_pad=32)
+        y = ops.conv2d_nhwc(xp, packed(w, False, cols_pad=32), b, ks=3)
+        ctx.save_for_backward(xp, w)
+        ctx.bias_param, ctx.cin = b, cin
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, w = ctx.saved_tensors
+        dy = _c(dy)
+        dwp, db = ops.conv2d_nhwc_wgrad(dy, xp, 3, db_out=_dst(ctx.bias_param))
+        dw = _dst(w)
+        if dw is not None:
+            dw.copy_(dwp[:, :ctx.cin])
+        else:
+            dw = dwp[:, :ctx.cin].contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.nhwc_to_nchw_f32(ops.conv2d_nhwc(dy, packed(w, True, rows_pad=32), ks=3), ctx.cin)
+        return dx, dw, db
+
+
+class NormSwishConvFn(torch.autograd.Function):
+    """conv3x3(swish(GroupNorm(x))) with an NHWC bf16 result (Encoder tail, flux_ae.py:178-180)."""
+
+    @staticmethod
+    def forward(ctx, x, nw, nb, cw, cb):
+        st, a = _gn_swish(x, nw, nb)
+        y = ops.conv2d_nhwc(a, packed(cw), cb, ks=3)
+        ctx.save_for_backward(x, st, a, nw, nb, cw)
+        ctx.bias_param = cb
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st, a, nw, nb, cw = ctx.saved_tensors
+        dy = _c(dy)
+        dcw, dcb = ops.conv2d_nhwc_wgrad(dy, a, 3, dw_out=_dst(cw), db_out=_dst(ctx.bias_param))
+        da = ops.conv2d_nhwc(dy, packed(cw, True), ks=3)
+        dx, dnw, dnb = ops.groupnorm_bwd(da, x, st, nw, nb, True, dg_out=_dst(nw), db_out=_dst(nb))
+        return dx, dnw, dnb, dcw, dcb
+
+
 class NormConvOutFn(torch.autograd.Function):
     """conv_out(swish(norm_out(h))) -> NCHW f32 image (flux_ae.py:266-268).  Cout (3) is padded to 4 for the
     forward store and to 32 for the bf16 gradient operand."""

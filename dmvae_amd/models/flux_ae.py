@@ -79,15 +79,14 @@ class ResnetBlock(_NCHWAdapter):
 
 
 class Downsample(_NCHWAdapter):
-    """pad (0,1,0,1) + conv3x3 stride 2 (reference :85-95).  Only used by the reference's never-instantiated
-    Encoder; the stride-2 kernel is not built yet, so forward raises (no silent fallback)."""
+    """pad (0,1,0,1) + conv3x3 stride 2 (reference :85-95): one strided gather in the HIP conv kernel."""
 
     def __init__(self, in_channels: int):
         super().__init__()
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
 
     def forward_nhwc(self, x: Tensor) -> Tensor:
-        raise NotImplementedError("stride-2 Downsample has no HIP kernel yet (reference Encoder is dead code; see DESIGN.md)")
+        return Fn.DownsampleFn.apply(x, self.conv.weight, self.conv.bias)
 
 
 class Upsample(_NCHWAdapter):
@@ -146,16 +145,23 @@ class Encoder(nn.Module):
         self.conv_out = _Conv3x3(block_in, z_channels * 2, kernel_size=3, stride=1, padding=1)
 
     def forward(self, x: Tensor) -> Tensor:
-        h = self.conv_in.forward_nhwc(Fn.to_nhwc_bf16(x))
+        """Reference :160-181 (downsampling stack -> mid -> norm_out/swish/conv_out), NCHW in, NCHW [B, 2*z, H/2^(L-1), W/2^(L-1)] out."""
+        if self.in_channels % 32:
+            h = Fn.ConvInFn.apply(x, self.conv_in.weight, self.conv_in.bias)
+        else:
+            h = self.conv_in.forward_nhwc(Fn.to_nhwc_bf16(x))
         for i_level in range(self.num_resolutions):
             for i_block in range(self.num_res_blocks):
                 h = self.down[i_level].block[i_block].forward_nhwc(h)
+                if len(self.down[i_level].attn) > 0:      # never populated by the reference ctor (:139 builds an empty list)
+                    h = self.down[i_level].attn[i_block].forward_nhwc(h)
             if i_level != self.num_resolutions - 1:
                 h = self.down[i_level].downsample.forward_nhwc(h)
         h = self.mid.block_1.forward_nhwc(h)
         h = self.mid.attn_1.forward_nhwc(h)
         h = self.mid.block_2.forward_nhwc(h)
-        raise NotImplementedError("Encoder tail (norm_out + conv_out to 2*z) is not wired: the reference never instantiates Encoder")
+        h = Fn.NormSwishConvFn.apply(h, self.norm_out.weight, self.norm_out.bias, self.conv_out.weight, self.conv_out.bias)
+        return Fn.to_nchw(h, x.dtype if x.dtype != torch.float64 else torch.float32)
 
 
 class Decoder(nn.Module):

@@ -72,22 +72,24 @@ def pack_conv_weight(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0
 
 
 def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor] = None,
-                residual: Optional[torch.Tensor] = None, ks: int = 3, upsample: bool = False, act: int = ACT_NONE,
-                out_f32: bool = False) -> torch.Tensor:
-    """y = act(conv(x, w) + bias + residual); x [N,H,W,Cin] bf16, w_packed [Cout, ks*ks, Cin] bf16."""
+                residual: Optional[torch.Tensor] = None, ks: int = 3, upsample=False, act: int = ACT_NONE,
+                out_f32: bool = False, stride: int = 1) -> torch.Tensor:
+    """y = act(conv(x, w) + bias + residual); x [N,H,W,Cin] bf16, w_packed [Cout, ks*ks, Cin] bf16.
+    upsample: False/0 none, True/1 nearest x2 folded into the gather, 2 zero-insertion x2 (dgrad of the stride-2 conv);
+    stride 2: the Downsample conv (input padded bottom/right by one, flux_ae.py:85-95)."""
     x = _req(x, bf16, "x")
     w_packed = _req(w_packed, bf16, "w_packed")
     n, h, w_, cin = x.shape
     cout = w_packed.shape[0]
     assert w_packed.shape[1] == ks * ks and w_packed.shape[2] == cin, (w_packed.shape, ks, cin)
-    ho, wo = (2 * h, 2 * w_) if upsample else (h, w_)
+    ho, wo = (2 * h, 2 * w_) if upsample else ((h // 2, w_ // 2) if stride == 2 else (h, w_))
     y = torch.empty(n, ho, wo, cout, dtype=f32 if out_f32 else bf16, device=x.device)
     if bias is not None:
         _req(bias, f32, "bias")
     if residual is not None:
         _req(residual, bf16, "residual")
         assert residual.shape == y.shape
-    d = ConvDesc(n, h, w_, cin, cout, ks, int(upsample), act, int(out_f32))
+    d = ConvDesc(n, h, w_, cin, cout, ks, int(upsample), act, int(out_f32), stride)
     timing = KERNEL_TIMING
     if timing is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -99,7 +101,7 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
         e1.record()
         # which kernel dmvae_conv2d_nhwc_fwd dispatched to (csrc/conv_pp.hip::dmvae_conv_pp_try), so that the bench's per-kernel
         # average can be checked against rocprofv3's per-kernel-name average
-        if cin % 32 == 0 and cout >= 64 and cout % 8 == 0 and n * ho * wo >= 16384:
+        if cin % 32 == 0 and cout >= 64 and cout % 8 == 0 and n * ho * wo >= 16384 and int(upsample) < 2 and stride != 2:
             label = "conv_pp_kernel<%s, %s, %s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", "true" if upsample else "false",
                                                      "true" if out_f32 else "false")
         else:
@@ -110,13 +112,13 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
 
 def conv2d_nhwc_wgrad(dy: torch.Tensor, a: torch.Tensor, ks: int, upsample: bool = False, need_bias: bool = True,
                       dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None,
-                      accumulate: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                      accumulate: bool = False, stride: int = 1) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """dW [Cout,Cin,ks,ks] f32 and db [Cout] f32 from dy [N,Ho,Wo,Cout] and the conv input a [N,H,W,Cin] (bf16)."""
     dy = _req(dy, bf16, "dy")
     a = _req(a, bf16, "a")
     n, h, w_, cin = a.shape
     cout = dy.shape[-1]
-    d = ConvDesc(n, h, w_, cin, cout, ks, int(upsample), 0, 0)
+    d = ConvDesc(n, h, w_, cin, cout, ks, int(upsample), 0, 0, stride)
     L = _lib.lib()
     wsb = L.dmvae_conv2d_nhwc_wgrad_workspace(ctypes.byref(d))
     ws = workspace(wsb, a.device)

@@ -36,11 +36,15 @@ int dmvae_abi_version(void);
 typedef struct dmvae_conv_desc {
   int32_t n, h, w;   /* input batch, height, width (pre-upsample) */
   int32_t cin, cout;
-  int32_t ks;        /* 1 or 3 (3 => padding 1, stride 1) */
-  int32_t upsample;  /* 1: nearest x2 of the input folded into the gather (flux_ae.py:103-107) */
+  int32_t ks;        /* 1 or 3 (3 => padding 1, stride 1 unless `stride` says otherwise) */
+  int32_t upsample;  /* 1: nearest x2 of the input folded into the gather (flux_ae.py:103-107);
+                        2: zero-insertion x2 (input pixel (y,x) sits at output position (2y+1,2x+1), zeros elsewhere): with
+                           for_dgrad-packed weights this is the input gradient of the stride-2 Downsample conv below */
   int32_t act;       /* epilogue: 0 none, 1 SiLU (vae.py:60), 2 ReLU (lpips.py VGG trunk), 3 ReLU-backward mask: `residual` is
                         not added but gates the result, y = residual > 0 ? conv + bias : 0 (input gradient through conv+ReLU) */
   int32_t out_f32;   /* 1: y is float32 (parity / final layers), else bf16 */
+  int32_t stride;    /* 0 or 1: stride 1.  2: the Downsample conv of flux_ae.py:85-95 -- input zero-padded by one row/column at the
+                        bottom/right only, 3x3, stride 2, no other padding: y is [n, h/2, w/2, cout] (h, w even; ks=3, upsample=0) */
 } dmvae_conv_desc;
 
 /* y[n,ho,wo,cout] = act( conv(x, w) + bias + residual ).

@@ -59,6 +59,49 @@ def test_conv_fwd(case, act):
     assert torch.equal(y16, y32.to(BF))        # bf16 store == RNE of the f32 result, bit-exact
 
 
+S2_CASES = [(2, 6, 6, 32, 32), (1, 20, 28, 96, 72), (3, 16, 16, 64, 128), (1, 64, 64, 128, 128), (1, 2, 2, 32, 8)]  # N, H, W, Cin, Cout
+
+
+@pytest.mark.parametrize("case", S2_CASES)
+def test_conv_stride2_fwd_dgrad_wgrad(case):
+    """Downsample conv (flux_ae.py:85-95): F.pad(x, (0,1,0,1)) + conv3x3 stride 2, its input gradient (the stride-1 dgrad conv
+    over dy zero-inserted at odd positions, desc.upsample = 2) and its weight / bias gradient (desc.stride = 2), against fp64
+    autograd on the same bf16-rounded operands."""
+    ops = _ops()
+    n, h, w_, cin, cout = case
+    g = torch.Generator().manual_seed(31 + cin + h)
+    x = torch.randn(n, h, w_, cin, generator=g).to(DEV).to(BF)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    dy = torch.randn(n, h // 2, w_ // 2, cout, generator=g).to(DEV).to(BF)
+    xr = x.float().cpu().double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.to(BF).float().cpu().double().requires_grad_(True)
+    br = b.cpu().double().requires_grad_(True)
+    yr = F.conv2d(F.pad(xr, (0, 1, 0, 1)), wr, br, stride=2)
+    yr.backward(dy.float().cpu().double().permute(0, 3, 1, 2))
+    y32 = ops.conv2d_nhwc(x, ops.pack_conv_weight(w), b, ks=3, stride=2, out_f32=True)
+    assert y32.shape == (n, h // 2, w_ // 2, cout)
+    assert rel_err(y32.cpu(), yr.detach().permute(0, 2, 3, 1)) < 1e-5
+    assert torch.equal(ops.conv2d_nhwc(x, ops.pack_conv_weight(w), b, ks=3, stride=2), y32.to(BF))
+    if cout % 32 == 0:     # dy is the dgrad conv's Cin
+        dx = ops.conv2d_nhwc(dy, ops.pack_conv_weight(w, for_dgrad=True), ks=3, upsample=2, out_f32=True)
+        assert dx.shape == (n, h, w_, cin)
+        assert rel_err(dx.cpu(), xr.grad.permute(0, 2, 3, 1)) < 1e-5
+    dw, db = ops.conv2d_nhwc_wgrad(dy, x, 3, stride=2)
+    assert rel_err(dw.cpu(), wr.grad) < 1e-5
+    assert rel_err(db.cpu(), br.grad) < 1e-5
+    dw2, db2 = ops.conv2d_nhwc_wgrad(dy, x, 3, stride=2)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)          # deterministic split-K
+
+
+def test_conv_stride2_rejects_odd_sizes():
+    ops = _ops()
+    from dmvae_amd._lib import DmvaeHipError
+    x = torch.zeros(1, 5, 6, 32, device=DEV, dtype=BF)
+    with pytest.raises(DmvaeHipError):
+        ops.conv2d_nhwc(x, torch.zeros(32, 9, 32, device=DEV, dtype=BF), ks=3, stride=2)
+
+
 @pytest.mark.parametrize("case", CONV_CASES[:8] + [(2, 16, 16, 32, 512, 3, 0), (2, 3, 3, 40, 24, 3, 0)])
 def test_conv_wgrad_and_dgrad(case):
     ops = _ops()

@@ -76,6 +76,66 @@ def test_upsample():
     _run_block(Upsample(32), load_golden("upsample"), R.upsample)
 
 
+def test_downsample():
+    from dmvae_amd.models.flux_ae import Downsample
+    _run_block(Downsample(32), load_golden("downsample"), R.downsample)
+
+
+def test_flux_encoder_small_fwd_bwd():
+    """flux_ae.Encoder (reference :110-181; never instantiated by its scripts, so the golden is its only pin): forward against the
+    captured output, forward + every gradient against the bf16-site oracle."""
+    from dmvae_amd.models.flux_ae import Encoder
+    g = load_golden("flux_encoder_small")
+    p = g.sub("p.")
+    enc = _load(Encoder(resolution=16, in_channels=32, ch=32, ch_mult=[1, 2], num_res_blocks=1, z_channels=16), p)
+    x = g.t("x").to(DEV).requires_grad_(True)
+    y = enc(x)
+    assert y.shape == (1, 32, 8, 8)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+    y.backward(dy.to(DEV))
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xo = g.t("x").requires_grad_(True)
+    yo = R.encoder_forward(Q(xo), po, q=Q, num_resolutions=2, num_res_blocks=1)
+    yo.backward(Q(dy))
+    # exact (f32, no rounding sites) gradients tell which parameters have identically-zero gradients: with ch = 32 every GroupNorm
+    # group is a single channel, so a conv bias feeding a GroupNorm is removed by the mean subtraction
+    pe = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    R.encoder_forward(g.t("x"), pe, num_resolutions=2, num_res_blocks=1).backward(dy)
+    assert rel_err(y.float().cpu(), g.t("y")) < TOL_REF
+    assert rel_err(y.float().cpu(), yo.detach()) < 2 * TOL_Q      # 9 convs / 8 GroupNorms deep
+    assert rel_err(x.grad.cpu(), xo.grad) < 3 * TOL_Q
+    checked = 0
+    for n, prm in enc.named_parameters():
+        assert prm.grad is not None, n
+        if pe[n].grad.abs().max() < 1e-4:
+            assert prm.grad.abs().max() < 5e-2, n                 # bf16 noise on both sides
+            continue
+        assert rel_err(prm.grad.cpu(), po[n].grad) < 3 * TOL_Q, n
+        checked += 1
+    assert checked >= 40
+
+
+def test_flux_encoder_rgb_input():
+    """in_channels = 3 (the reference's AutoEncoderParams default): conv_in pads the image to 32 channels on the way to NHWC."""
+    from dmvae_amd.models.flux_ae import Encoder
+    enc = Encoder(resolution=32, in_channels=3, ch=32, ch_mult=[1, 2], num_res_blocks=1, z_channels=16)
+    params = {k: det_tensor(k, v.shape, 17) for k, v in enc.state_dict().items()}
+    _load(enc, params)
+    x = (torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(DEV).requires_grad_(True)
+    y = enc(x)
+    assert y.shape == (2, 32, 16, 16) and y.dtype == torch.float32
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(4))
+    y.backward(dy.to(DEV))
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo = x.detach().cpu().requires_grad_(True)
+    yo = R.encoder_forward(xo, po, q=Q, num_resolutions=2, num_res_blocks=1)
+    yo.backward(Q(dy))
+    assert rel_err(y.cpu(), yo.detach()) < 2 * TOL_Q
+    assert rel_err(x.grad.cpu(), xo.grad) < 3 * TOL_Q
+    for n in ("conv_in.weight", "conv_in.bias", "down.0.downsample.conv.weight", "conv_out.weight", "norm_out.weight"):
+        assert rel_err(dict(enc.named_parameters())[n].grad.cpu(), po[n].grad) < 3 * TOL_Q, n
+
+
 def test_mlp():
     from dmvae_amd.models.vae import MLP
     g = load_golden("mlp")
