@@ -36,6 +36,9 @@ SIGNATURES = {
     "dmvae_maxpool2x2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_maxpool2x2_relu_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dmvae_leaky_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
+    "dmvae_im2col_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "dmvae_col2im_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "dmvae_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_nhwc_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_silu_fwd": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -57,6 +60,8 @@ SIGNATURES = {
     "dmvae_groupnorm_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dmvae_groupnorm_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_groupnorm_bwd": (c_int, [c_void_p] * 10 + [c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dmvae_groupnorm_bwd_reduce": (c_int, [c_void_p] * 9 + [c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dmvae_groupnorm_bwd_apply": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dmvae_conv2d_nhwc_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(ConvDesc), c_int, c_void_p]),
 }
 

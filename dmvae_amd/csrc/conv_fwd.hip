@@ -195,6 +195,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
         } else if (a.act == 2) {
 #pragma unroll
           for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        } else if (a.act == 4) {  // LeakyReLU(0.2), models/patchgan.py:125
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
         }
         if (OUT_F32) {
           f32x4 o = {v[0], v[1], v[2], v[3]};
@@ -240,7 +243,7 @@ extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* b
   DMVAE_CHECK_ARG(d->cin > 0 && d->cin % 32 == 0, "conv2d_nhwc_fwd: Cin must be a positive multiple of 32 (got %d)", d->cin);
   DMVAE_CHECK_ARG(d->cout > 0 && d->cout % 4 == 0, "conv2d_nhwc_fwd: Cout must be a positive multiple of 4 (got %d)", d->cout);
   DMVAE_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0, "conv2d_nhwc_fwd: empty shape");
-  DMVAE_CHECK_ARG(d->act >= 0 && d->act <= 3 && (d->act != 3 || residual), "conv2d_nhwc_fwd: bad activation code %d", d->act);
+  DMVAE_CHECK_ARG(d->act >= 0 && d->act <= 4 && (d->act != 3 || residual), "conv2d_nhwc_fwd: bad activation code %d", d->act);
   {
     const int r = dmvae_conv_pp_try(x, w, bias, residual, y, d, stream);  // large shapes: the ping-pong kernel
     if (r <= 0) return r;

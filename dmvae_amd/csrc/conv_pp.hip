@@ -340,6 +340,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
             } else if (a.act == 2) {
 #pragma unroll
               for (int e = 0; e < 8; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            } else if (a.act == 4) {
+#pragma unroll
+              for (int e = 0; e < 8; e++) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
             }
             if (OUT_F32) {
               float* yo = reinterpret_cast<float*>(a.y) + off;

@@ -100,7 +100,7 @@ __global__ void stats_final_kernel(const float* __restrict__ part, float* __rest
   }
 }
 
-template <bool SWISH>
+template <int ACT>
 __global__ __launch_bounds__(256) void apply_kernel(const bf16* __restrict__ x, const float* __restrict__ stats,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     bf16* __restrict__ y, Geom g) {
@@ -124,13 +124,13 @@ __global__ __launch_bounds__(256) void apply_kernel(const bf16* __restrict__ x, 
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const float t = v[e] * sc[e] + sh[e];
-      v[e] = SWISH ? t * sigmoidf_(t) : t;
+      v[e] = ACT == 1 ? t * sigmoidf_(t) : (ACT == 2 ? (t > 0.f ? t : 0.2f * t) : t);
     }
     store8(y + base + (size_t)p * g.C, v);
   }
 }
 
-template <bool SWISH>
+template <int ACT>
 __global__ __launch_bounds__(256) void bwd_partial_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x,
                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ part, Geom g) {
@@ -159,10 +159,12 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const bf16* __restrict
       for (int e = 0; e < 8; e++) {
         const float xh = (v[e] - mu[e]) * rs[e];
         float dy = d[e];
-        if (SWISH) {
+        if (ACT == 1) {
           const float t = xh * ga[e] + be[e];
           const float sg = sigmoidf_(t);
           dy *= sg * (1.f + t * (1.f - sg));
+        } else if (ACT == 2) {
+          dy = xh * ga[e] + be[e] > 0.f ? dy : 0.2f * dy;
         }
         A[e] += dy; B[e] += dy * xh;
       }
@@ -205,17 +207,17 @@ __global__ void bwd_param_kernel(const float* __restrict__ AB, float* __restrict
   dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)b;
 }
 
-template <bool SWISH>
+template <int ACT>
 __global__ __launch_bounds__(256) void bwd_apply_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x,
                                                         const bf16* __restrict__ dres, const float* __restrict__ stats,
                                                         const float* __restrict__ S, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, bf16* __restrict__ dx, Geom g) {
+                                                        const float* __restrict__ beta, bf16* __restrict__ dx, Geom g, float inv_count) {
   const int tp = 1 << g.tp_shift;
   const int lane_c = threadIdx.x & (tp - 1), prow = threadIdx.x >> g.tp_shift;
   if (lane_c * 8 >= g.C) return;
   const int n = blockIdx.y;
   const int p0 = blockIdx.x * g.ppc, p1 = min(p0 + g.ppc, g.HW);
-  const float inv_m = 1.0f / ((float)g.cpg * (float)g.HW);
+  const float inv_m = inv_count > 0.f ? inv_count : 1.0f / ((float)g.cpg * (float)g.HW);
   float mu[8], rs[8], ga[8], be[8], s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; e++) {
@@ -234,10 +236,12 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const bf16* __restrict__
     for (int e = 0; e < 8; e++) {
       const float xh = (v[e] - mu[e]) * rs[e];
       float dy = d[e];
-      if (SWISH) {
+      if (ACT == 1) {
         const float t = xh * ga[e] + be[e];
         const float sg = sigmoidf_(t);
         dy *= sg * (1.f + t * (1.f - sg));
+      } else if (ACT == 2) {
+        dy = xh * ga[e] + be[e] > 0.f ? dy : 0.2f * dy;
       }
       const float r = rs[e] * (dy * ga[e] - s1[e] - xh * s2[e]);
       o[e] = dres ? o[e] + r : r;
@@ -252,11 +256,11 @@ static int make_geom(Geom& g, int N, int HW, int C, int G) {
   int tp = 1, sh = 0;
   while (tp < C / 8) { tp <<= 1; sh++; }
   g.tp_shift = sh; g.rows = 256 / tp;
-  // chunks per image: target ~2048 blocks overall, >= 4 row-iterations per block, <= 64
+  // chunks per image: target ~2048 blocks overall, >= 4 row-iterations per block
   int nchunk = (2048 + N - 1) / N;
   const int maxc = (HW + g.rows * 4 - 1) / (g.rows * 4);
   if (nchunk > maxc) nchunk = maxc;
-  if (nchunk > 64) nchunk = 64;
+  if (nchunk > 2048) nchunk = 2048;   // N >= 32 (every decoder shape): <= 64 chunks per image; a single "image" (BatchNorm use) still fills the chip
   if (nchunk < 1) nchunk = 1;
   g.ppc = (HW + nchunk - 1) / nchunk;
   g.nchunk = (HW + g.ppc - 1) / g.ppc;
@@ -288,51 +292,73 @@ extern "C" int dmvae_groupnorm_stats(const void* x, void* stats, void* workspace
 }
 
 extern "C" int dmvae_groupnorm_apply(const void* x, const void* stats, const void* gamma, const void* beta, void* y, int n, int hw,
-                                     int c, int groups, int swish, hipStream_t stream) {
+                                     int c, int groups, int act, hipStream_t stream) {
   Geom g;
   DMVAE_CHECK_ARG(x && stats && gamma && beta && y, "groupnorm_apply: null pointer");
+  DMVAE_CHECK_ARG(act >= 0 && act <= 2, "groupnorm_apply: act must be 0 (none), 1 (swish) or 2 (LeakyReLU 0.2)");
   DMVAE_CHECK_ARG(make_geom(g, n, hw, c, groups) == 0, "groupnorm_apply: unsupported shape n=%d hw=%d c=%d groups=%d", n, hw, c, groups);
-  if (swish)
-    hipLaunchKernelGGL(apply_kernel<true>, dim3(g.nchunk, n), dim3(256), 0, stream, (const bf16*)x, (const float*)stats,
-                       (const float*)gamma, (const float*)beta, (bf16*)y, g);
-  else
-    hipLaunchKernelGGL(apply_kernel<false>, dim3(g.nchunk, n), dim3(256), 0, stream, (const bf16*)x, (const float*)stats,
-                       (const float*)gamma, (const float*)beta, (bf16*)y, g);
+  const dim3 grid(g.nchunk, n);
+#define DMVAE_GN_APPLY(A) hipLaunchKernelGGL(apply_kernel<A>, grid, dim3(256), 0, stream, (const bf16*)x, (const float*)stats, \
+                                             (const float*)gamma, (const float*)beta, (bf16*)y, g)
+  if (act == 1) DMVAE_GN_APPLY(1); else if (act == 2) DMVAE_GN_APPLY(2); else DMVAE_GN_APPLY(0);
+#undef DMVAE_GN_APPLY
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+// Reduction half of the backward: sums[n][groups][2] = (sum g, sum g*x_hat) with g = da*act'(.)*gamma, plus dgamma / dbeta.
+extern "C" int dmvae_groupnorm_bwd_reduce(const void* da, const void* x, const void* stats, const void* gamma, const void* beta,
+                                          void* sums, void* dgamma, void* dbeta, void* workspace, size_t workspace_bytes, int n, int hw,
+                                          int c, int groups, int act, int accumulate, hipStream_t stream) {
+  Geom g;
+  DMVAE_CHECK_ARG(da && x && stats && gamma && beta && sums && workspace, "groupnorm_bwd_reduce: null pointer");
+  DMVAE_CHECK_ARG(act >= 0 && act <= 2, "groupnorm_bwd_reduce: act must be 0, 1 or 2");
+  DMVAE_CHECK_ARG(make_geom(g, n, hw, c, groups) == 0, "groupnorm_bwd_reduce: unsupported shape n=%d hw=%d c=%d groups=%d", n, hw, c, groups);
+  DMVAE_CHECK_ARG(workspace_bytes >= dmvae_groupnorm_workspace(n, hw, c, groups), "groupnorm_bwd_reduce: workspace too small");
+  float* part = (float*)workspace;
+  float* AB = part + (size_t)n * g.nchunk * c * 2;
+  const dim3 grid(g.nchunk, n);
+#define DMVAE_GN_PART(A) hipLaunchKernelGGL(bwd_partial_kernel<A>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)x, \
+                                            (const float*)stats, (const float*)gamma, (const float*)beta, part, g)
+  if (act == 1) DMVAE_GN_PART(1); else if (act == 2) DMVAE_GN_PART(2); else DMVAE_GN_PART(0);
+#undef DMVAE_GN_PART
+  DMVAE_CHECK_LAUNCH();
+  const int waves = n * groups;
+  hipLaunchKernelGGL(bwd_final_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, part, (const float*)gamma, AB, (float*)sums, g, n);
+  DMVAE_CHECK_LAUNCH();
+  if (dgamma && dbeta) {
+    hipLaunchKernelGGL(bwd_param_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, AB, (float*)dgamma, (float*)dbeta, n, c, accumulate);
+    DMVAE_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+// Elementwise half: dx = rstd*(g - (s1 + x_hat*s2)*inv_count) [+ dres]; inv_count <= 0 selects 1/(hw*c/groups).
+extern "C" int dmvae_groupnorm_bwd_apply(const void* da, const void* x, const void* dres, const void* stats, const void* sums,
+                                         const void* gamma, const void* beta, void* dx, int n, int hw, int c, int groups, int act,
+                                         float inv_count, hipStream_t stream) {
+  Geom g;
+  DMVAE_CHECK_ARG(da && x && stats && sums && gamma && beta && dx, "groupnorm_bwd_apply: null pointer");
+  DMVAE_CHECK_ARG(act >= 0 && act <= 2, "groupnorm_bwd_apply: act must be 0, 1 or 2");
+  DMVAE_CHECK_ARG(make_geom(g, n, hw, c, groups) == 0, "groupnorm_bwd_apply: unsupported shape n=%d hw=%d c=%d groups=%d", n, hw, c, groups);
+  const dim3 grid(g.nchunk, n);
+#define DMVAE_GN_BAPPLY(A) hipLaunchKernelGGL(bwd_apply_kernel<A>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)x, (const bf16*)dres, \
+                                              (const float*)stats, (const float*)sums, (const float*)gamma, (const float*)beta, (bf16*)dx, g, inv_count)
+  if (act == 1) DMVAE_GN_BAPPLY(1); else if (act == 2) DMVAE_GN_BAPPLY(2); else DMVAE_GN_BAPPLY(0);
+#undef DMVAE_GN_BAPPLY
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int dmvae_groupnorm_bwd(const void* da, const void* x, const void* dres, const void* stats, const void* gamma,
                                    const void* beta, void* dx, void* dgamma, void* dbeta, void* workspace, size_t workspace_bytes,
-                                   int n, int hw, int c, int groups, int swish, int accumulate, hipStream_t stream) {
+                                   int n, int hw, int c, int groups, int act, int accumulate, hipStream_t stream) {
   Geom g;
   DMVAE_CHECK_ARG(da && x && stats && gamma && beta && dx && workspace, "groupnorm_bwd: null pointer");
   DMVAE_CHECK_ARG(make_geom(g, n, hw, c, groups) == 0, "groupnorm_bwd: unsupported shape n=%d hw=%d c=%d groups=%d", n, hw, c, groups);
   DMVAE_CHECK_ARG(workspace_bytes >= dmvae_groupnorm_workspace(n, hw, c, groups), "groupnorm_bwd: workspace too small");
-  float* part = (float*)workspace;
-  float* AB = part + (size_t)n * g.nchunk * c * 2;
-  float* S = AB + (size_t)n * c * 2;
-  const dim3 grid(g.nchunk, n);
-  if (swish)
-    hipLaunchKernelGGL(bwd_partial_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)x, (const float*)stats,
-                       (const float*)gamma, (const float*)beta, part, g);
-  else
-    hipLaunchKernelGGL(bwd_partial_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)x, (const float*)stats,
-                       (const float*)gamma, (const float*)beta, part, g);
-  DMVAE_CHECK_LAUNCH();
-  const int waves = n * groups;
-  hipLaunchKernelGGL(bwd_final_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, part, (const float*)gamma, AB, S, g, n);
-  DMVAE_CHECK_LAUNCH();
-  if (dgamma && dbeta) {
-    hipLaunchKernelGGL(bwd_param_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, AB, (float*)dgamma, (float*)dbeta, n, c, accumulate);
-    DMVAE_CHECK_LAUNCH();
-  }
-  if (swish)
-    hipLaunchKernelGGL(bwd_apply_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)x, (const bf16*)dres,
-                       (const float*)stats, S, (const float*)gamma, (const float*)beta, (bf16*)dx, g);
-  else
-    hipLaunchKernelGGL(bwd_apply_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)x, (const bf16*)dres,
-                       (const float*)stats, S, (const float*)gamma, (const float*)beta, (bf16*)dx, g);
-  DMVAE_CHECK_LAUNCH();
-  return 0;
+  float* S = (float*)workspace + (size_t)n * g.nchunk * c * 2 + (size_t)n * c * 2;
+  int rc = dmvae_groupnorm_bwd_reduce(da, x, stats, gamma, beta, S, dgamma, dbeta, workspace, workspace_bytes, n, hw, c, groups, act, accumulate, stream);
+  if (rc) return rc;
+  return dmvae_groupnorm_bwd_apply(da, x, dres, stats, S, gamma, beta, dx, n, hw, c, groups, act, 0.f, stream);
 }

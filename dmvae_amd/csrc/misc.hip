@@ -119,12 +119,74 @@ __global__ void maxpool2x2_relu_bwd_kernel(const bf16* __restrict__ dpool, const
   }
 }
 // dx = y > 0 ? dy : 0 (ReLU backward from the saved output), bf16
-__global__ void relu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, bf16* __restrict__ dx, size_t n8) {
+__global__ void relu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, bf16* __restrict__ dx, size_t n8, float slope) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
     const bf16x8 d = reinterpret_cast<const bf16x8*>(dy)[i], v = reinterpret_cast<const bf16x8*>(y)[i];
     bf16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = (float)v[e] > 0.f ? d[e] : (bf16)0.f;
+    for (int e = 0; e < 8; e++) o[e] = (float)v[e] > 0.f ? d[e] : (bf16)(slope * (float)d[e]);
+    reinterpret_cast<bf16x8*>(dx)[i] = o;
+  }
+}
+
+// ---- im2col / col2im for the PatchGAN convs (models/patchgan.py:125-147: 4x4, stride 2 or 1, padding 1) --------------------------
+// col[n, oy, ox, (ky*ks + kx)*C + c] = x[n, oy*stride - pad + ky, ox*stride - pad + kx, c] (0 outside): the conv becomes the
+// [M, ks*ks*C] x [Cout, ks*ks*C]^T GEMM of the 1x1 path.  One thread per (output pixel, tap, 8 channels): 16-B loads and stores.
+__global__ void im2col_kernel(const bf16* __restrict__ x, bf16* __restrict__ col, int N, int H, int W, int C, int Ho, int Wo, int ks,
+                              int stride, int pad) {
+  const int c8 = C / 8, T = ks * ks;
+  const size_t total = (size_t)N * Ho * Wo * T * c8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = i % c8;
+    size_t r = i / c8;
+    const int t = r % T; r /= T;
+    const int ox = r % Wo; r /= Wo;
+    const int oy = r % Ho;
+    const int n = r / Ho;
+    const int iy = oy * stride - pad + t / ks, ix = ox * stride - pad + t % ks;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (bf16)0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const bf16x8*>(x + (((size_t)n * H + iy) * W + ix) * C + cc * 8);
+    reinterpret_cast<bf16x8*>(col)[i] = v;
+  }
+}
+
+// Adjoint as a gather (deterministic): dx[n, iy, ix, c] = sum over the taps (ky, kx) whose window covers (iy, ix) of
+// dcol[n, (iy + pad - ky)/stride, (ix + pad - kx)/stride, (ky*ks + kx)*C + c]; f32 accumulation, one bf16 rounding.
+template <typename TIN>
+__global__ void col2im_kernel(const TIN* __restrict__ dcol, bf16* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo, int ks,
+                              int stride, int pad) {
+  const int c8 = C / 8, T = ks * ks;
+  const size_t total = (size_t)N * H * W * c8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = i % c8;
+    size_t r = i / c8;
+    const int ix = r % W; r /= W;
+    const int iy = r % H;
+    const int n = r / H;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int ky = 0; ky < ks; ky++) {
+      const int ty = iy + pad - ky;
+      if (ty < 0 || ty % stride != 0 || ty / stride >= Ho) continue;
+      for (int kx = 0; kx < ks; kx++) {
+        const int tx = ix + pad - kx;
+        if (tx < 0 || tx % stride != 0 || tx / stride >= Wo) continue;
+        const TIN* src = dcol + ((((size_t)n * Ho + ty / stride) * Wo + tx / stride) * T + ky * ks + kx) * C + cc * 8;
+        if constexpr (sizeof(TIN) == 4) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { acc[e] += lo[e]; acc[4 + e] += hi[e]; }
+        } else {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+#pragma unroll
+          for (int e = 0; e < 8; e++) acc[e] += (float)v[e];
+        }
+      }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = (bf16)acc[e];
     reinterpret_cast<bf16x8*>(dx)[i] = o;
   }
 }
@@ -243,7 +305,7 @@ using namespace dmvae_misc;
 
 extern "C" int dmvae_pack_conv_weight(const void* w, void* out, int cout, int cin, int ks, int rows_pad, int cols_pad,
                                       int for_dgrad, hipStream_t stream) {
-  DMVAE_CHECK_ARG(w && out && cout > 0 && cin > 0 && (ks == 1 || ks == 3), "pack_conv_weight: bad argument");
+  DMVAE_CHECK_ARG(w && out && cout > 0 && cin > 0 && ks >= 1 && ks <= 7, "pack_conv_weight: bad argument");
   DMVAE_CHECK_ARG(rows_pad >= (for_dgrad ? cin : cout) && cols_pad >= (for_dgrad ? cout : cin), "pack_conv_weight: padding smaller than shape");
   const int T = ks * ks;
   const size_t total = (size_t)rows_pad * T * cols_pad;
@@ -277,7 +339,42 @@ extern "C" int dmvae_maxpool2x2_relu_bwd_nhwc(const void* dpool, const void* x, 
 extern "C" int dmvae_relu_bwd(const void* dy, const void* y, void* dx, size_t n, hipStream_t stream) {
   DMVAE_CHECK_ARG(dy && y && dx && n % 8 == 0, "relu_bwd: element count must be a multiple of 8");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)y, (bf16*)dx, n / 8);
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)y, (bf16*)dx, n / 8, 0.f);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int dmvae_leaky_relu_bwd(const void* dy, const void* y, void* dx, size_t n, float slope, hipStream_t stream) {
+  DMVAE_CHECK_ARG(dy && y && dx && n % 8 == 0 && slope >= 0.f, "leaky_relu_bwd: element count must be a multiple of 8, slope >= 0");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)y, (bf16*)dx, n / 8, slope);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+static bool im2col_geom(int h, int w, int ks, int stride, int pad, int* ho, int* wo) {
+  if (ks < 1 || ks > 7 || stride < 1 || stride > 4 || pad < 0 || pad >= ks) return false;
+  *ho = (h + 2 * pad - ks) / stride + 1; *wo = (w + 2 * pad - ks) / stride + 1;
+  return h + 2 * pad >= ks && w + 2 * pad >= ks;
+}
+extern "C" int dmvae_im2col_nhwc(const void* x, void* col, int n, int h, int w, int c, int ks, int stride, int pad, hipStream_t stream) {
+  int ho, wo;
+  DMVAE_CHECK_ARG(x && col && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && im2col_geom(h, w, ks, stride, pad, &ho, &wo),
+                  "im2col_nhwc: bad argument (c must be a multiple of 8; ks 1..7, stride 1..4, pad < ks)");
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((size_t)n * ho * wo * ks * ks * (c / 8))), dim3(256), 0, stream, (const bf16*)x, (bf16*)col, n, h, w, c,
+                     ho, wo, ks, stride, pad);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int dmvae_col2im_nhwc(const void* dcol, void* dx, int n, int h, int w, int c, int ks, int stride, int pad, int in_f32,
+                                 hipStream_t stream) {
+  int ho, wo;
+  DMVAE_CHECK_ARG(dcol && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && im2col_geom(h, w, ks, stride, pad, &ho, &wo),
+                  "col2im_nhwc: bad argument (c must be a multiple of 8; ks 1..7, stride 1..4, pad < ks)");
+  const dim3 grid(grid_for((size_t)n * h * w * (c / 8)));
+  if (in_f32)
+    hipLaunchKernelGGL(col2im_kernel<float>, grid, dim3(256), 0, stream, (const float*)dcol, (bf16*)dx, n, h, w, c, ho, wo, ks, stride, pad);
+  else
+    hipLaunchKernelGGL(col2im_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)dcol, (bf16*)dx, n, h, w, c, ho, wo, ks, stride, pad);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -24,7 +24,8 @@ def bump_weight_epoch() -> None:
     _EPOCH[0] += 1
 
 
-def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad: int = 0, frozen: bool = False) -> torch.Tensor:
+def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad: int = 0, frozen: bool = False,
+           transposed: bool = False) -> torch.Tensor:
     """bf16 kernel operand of an f32 conv/linear weight, cached ON the parameter object until the weight changes
     (in-place updates bump ``_version``; raw-pointer optimisers call bump_weight_epoch, which `frozen` weights -- not owned
     by any optimiser, e.g. the LPIPS trunk -- ignore)."""
@@ -35,12 +36,14 @@ def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad
             w._dmvae_packed = cache
         except AttributeError:      # non-leaf views etc.: no caching
             pass
-    key = (for_dgrad, rows_pad, cols_pad)
+    key = (for_dgrad, rows_pad, cols_pad, transposed)
     ver = (w.data_ptr(), w._version, -1 if frozen else _EPOCH[0])
     hit = cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
     p = ops.pack_conv_weight(w.detach().contiguous(), for_dgrad, rows_pad, cols_pad)
+    if transposed:       # [rows][taps*cols] -> [taps*cols][rows]: the B operand of the im2col convs' input-gradient GEMM
+        p = p.view(p.shape[0], -1).t().contiguous()
     cache[key] = (ver, p)
     return p
 
@@ -232,6 +235,121 @@ class NormSwishConvFn(torch.autograd.Function):
         da = ops.conv2d_nhwc(dy, packed(cw, True), ks=3)
         dx, dnw, dnb = ops.groupnorm_bwd(da, x, st, nw, nb, True, dg_out=_dst(nw), db_out=_dst(nb))
         return dx, dnw, dnb, dcw, dcb
+
+
+class ImageToNhwcFn(torch.autograd.Function):
+    """NCHW f32 image -> NHWC bf16 with the channel count zero-padded to c_pad (boundary of the discriminator / VGG trunk)."""
+
+    @staticmethod
+    def forward(ctx, x, c_pad):
+        ctx.c = x.shape[1]
+        return ops.nchw_to_nhwc_bf16(_c(x.float()), c_pad=c_pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.nhwc_to_nchw_f32(_c(dy), ctx.c), None
+
+
+class ConvIm2colFn(torch.autograd.Function):
+    """nn.Conv2d(kernel k, stride s, padding p) on NHWC bf16 as im2col + GEMM (models/patchgan.py:125-147: k=4, s=2|1, p=1).
+    x: [N,H,W,Cp] with Cp >= w.shape[1] zero-padded channels; act: ops.ACT_NONE | ops.ACT_LEAKY fused into the GEMM epilogue.
+    out_f32: logits layer -- the single output channel is computed in a 4-row padded GEMM and returned as [N,Ho,Wo,1] f32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, act, out_f32):
+        cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+        n, h, wd, cp = x.shape
+        col = ops.im2col(x, ks, stride, pad)
+        ho, wo, k = col.shape[1], col.shape[2], col.shape[3]
+        m = n * ho * wo
+        rows = cout if cout % 4 == 0 else (cout + 3) // 4 * 4
+        wp = packed(w, False, rows_pad=rows, cols_pad=cp).view(rows, 1, k)
+        bp = b
+        if b is not None and rows != cout:
+            bp = torch.zeros(rows, dtype=f32, device=x.device)
+            bp[:cout] = b
+        y = ops.conv2d_nhwc(col.view(1, 1, m, k), wp, bp, ks=1, act=act, out_f32=out_f32).view(n, ho, wo, rows)
+        if rows != cout:
+            y = y[..., :cout].contiguous()
+        ctx.save_for_backward(x, w, y if act == ops.ACT_LEAKY else None)
+        ctx.cfg = (stride, pad, act, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, act, b = ctx.cfg
+        cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+        n, h, wd, cp = x.shape
+        ho, wo = dy.shape[1], dy.shape[2]
+        m, k = n * ho * wo, ks * ks * cp
+        dy = _c(dy)
+        if act == ops.ACT_LEAKY:
+            dy = ops.leaky_relu_bwd(dy, y)
+        cpad = cout if cout % 32 == 0 else (cout + 31) // 32 * 32     # dy is the K operand of both gradient GEMMs
+        if cpad != cout or dy.dtype != bf16:
+            dyp = torch.zeros(n, ho, wo, cpad, dtype=bf16, device=dy.device)
+            dyp[..., :cout] = dy
+            dy = dyp
+        col = ops.im2col(x, ks, stride, pad)                             # recomputed: 16x the activation, not worth keeping
+        dwp, dbp = ops.conv2d_nhwc_wgrad(dy.view(1, 1, m, cpad), col.view(1, 1, m, k), 1, need_bias=b is not None)
+        del col
+        dw = dwp.view(cpad, ks * ks, cp)[:cout, :, :cin].permute(0, 2, 1).reshape(cout, cin, ks, ks)
+        dst = _dst(w)
+        if dst is not None:
+            dst.copy_(dw)
+            dw = dst
+        else:
+            dw = dw.contiguous()
+        db = None
+        if b is not None:
+            db = _dst(b)
+            if db is not None:
+                db.copy_(dbp[:cout])
+            else:
+                db = dbp[:cout].contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = packed(w, False, rows_pad=cpad, cols_pad=cp, transposed=True)          # [k, cpad]
+            dcol = ops.gemm_nt(dy.view(m, cpad), wt, out_f32=True)     # f32: the taps are summed before the one bf16 rounding
+            dx = ops.col2im(dcol.view(n, ho, wo, k), h, wd, ks, stride, pad)
+        return dx, dw, db, None, None, None, None
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """act(BatchNorm(x)) on NHWC bf16 with caller-provided per-channel statistics (models/patchgan.py:134-145): the GroupNorm
+    kernels with one "image" of N*H*W pixels and one channel per group.  `stats` [1,C,2] = (mean, rstd): batch statistics
+    (combined over ranks for SyncBatchNorm) when `batch_stats`, the running estimates otherwise.  In the first case the backward
+    all-reduces the two per-channel sums over `group` like torch.nn.SyncBatchNorm; in the second the statistics are constants."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, stats, act, batch_stats, count, group):
+        c = x.shape[-1]
+        y = ops.groupnorm_apply(x.view(1, -1, c), stats, gamma, beta, act, groups=c).view(x.shape)
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.cfg = (act, batch_stats, count, group)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        act, batch_stats, count, group = ctx.cfg
+        c = x.shape[-1]
+        dy3, x3 = _c(dy).view(1, -1, c), x.view(1, -1, c)
+        need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dg = db = None
+        if batch_stats or need_p:
+            sums, dg, db = ops.groupnorm_bwd_reduce(dy3, x3, stats, gamma, beta, act, groups=c, need_param_grads=need_p,
+                                                    dg_out=_dst(gamma) if need_p else None, db_out=_dst(beta) if need_p else None)
+        if batch_stats:
+            if group is not None:
+                import torch.distributed as tdist
+                tdist.all_reduce(sums, group=group)
+        else:
+            sums = torch.zeros(1, c, 2, dtype=f32, device=x.device)
+        dx = ops.groupnorm_bwd_apply(dy3, x3, stats, sums, gamma, beta, act, groups=c, inv_count=1.0 / count).view(x.shape) \
+            if ctx.needs_input_grad[0] else None
+        return dx, dg, db, None, None, None, None, None
 
 
 class NormConvOutFn(torch.autograd.Function):

@@ -17,7 +17,7 @@ from ._lib import ConvDesc, check
 bf16 = torch.bfloat16
 f32 = torch.float32
 
-ACT_NONE, ACT_SILU, ACT_RELU, ACT_RELU_GATE = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_RELU_GATE, ACT_LEAKY = 0, 1, 2, 3, 4
 
 
 def _stream() -> int:
@@ -233,7 +233,72 @@ def groupnorm_bwd(da: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma:
     return dx, dg, db
 
 
+def groupnorm_bwd_reduce(da: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: int,
+                         groups: int = 32, need_param_grads: bool = True, dg_out: Optional[torch.Tensor] = None,
+                         db_out: Optional[torch.Tensor] = None):
+    """Reduction half of groupnorm_bwd: sums [n, groups, 2] = (sum g, sum g*x_hat), plus dgamma / dbeta."""
+    da = _req(da, bf16, "da")
+    x = _req(x, bf16, "x")
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    L = _lib.lib()
+    ws = workspace(L.dmvae_groupnorm_workspace(n, hw, c, groups), x.device)
+    sums = torch.empty(n, groups, 2, dtype=f32, device=x.device)
+    dg = (dg_out if dg_out is not None else torch.empty(c, dtype=f32, device=x.device)) if need_param_grads else None
+    db = (db_out if db_out is not None else torch.empty(c, dtype=f32, device=x.device)) if need_param_grads else None
+    check(L.dmvae_groupnorm_bwd_reduce(da.data_ptr(), x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(),
+                                       _ptr(dg), _ptr(db), ws.data_ptr(), ws.numel(), n, hw, c, groups, int(act), 0, _stream()), "groupnorm_bwd_reduce")
+    return sums, dg, db
+
+
+def groupnorm_bwd_apply(da: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, sums: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                        act: int, groups: int = 32, inv_count: float = 0.0, dres: Optional[torch.Tensor] = None) -> torch.Tensor:
+    da = _req(da, bf16, "da")
+    x = _req(x, bf16, "x")
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    dx = torch.empty_like(x)
+    check(_lib.lib().dmvae_groupnorm_bwd_apply(da.data_ptr(), x.data_ptr(), _ptr(dres), stats.data_ptr(), _req(sums, f32, "sums").data_ptr(),
+                                               gamma.data_ptr(), beta.data_ptr(), dx.data_ptr(), n, hw, c, groups, int(act), float(inv_count),
+                                               _stream()), "groupnorm_bwd_apply")
+    return dx
+
+
 # ---- layout / elementwise ---------------------------------------------------------------------------
+def _im2col_out(h, w, ks, stride, pad):
+    return (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+
+
+def im2col(x: torch.Tensor, ks: int, stride: int, pad: int) -> torch.Tensor:
+    """[N,H,W,C] bf16 -> [N,Ho,Wo,ks*ks*C] (tap-major, zero padding): the PatchGAN convs as GEMMs (models/patchgan.py:125-147)."""
+    x = _req(x, bf16, "x")
+    n, h, w, c = x.shape
+    ho, wo = _im2col_out(h, w, ks, stride, pad)
+    col = torch.empty(n, ho, wo, ks * ks * c, dtype=bf16, device=x.device)
+    check(_lib.lib().dmvae_im2col_nhwc(x.data_ptr(), col.data_ptr(), n, h, w, c, ks, stride, pad, _stream()), "im2col_nhwc")
+    return col
+
+
+def col2im(dcol: torch.Tensor, h: int, w: int, ks: int, stride: int, pad: int) -> torch.Tensor:
+    """Adjoint of im2col: [N,Ho,Wo,ks*ks*C] -> [N,H,W,C]."""
+    assert dcol.dtype in (bf16, f32) and dcol.is_cuda and dcol.is_contiguous()
+    n, ho, wo, k = dcol.shape
+    c = k // (ks * ks)
+    assert (ho, wo) == _im2col_out(h, w, ks, stride, pad) and c * ks * ks == k
+    dx = torch.empty(n, h, w, c, dtype=bf16, device=dcol.device)
+    check(_lib.lib().dmvae_col2im_nhwc(dcol.data_ptr(), dx.data_ptr(), n, h, w, c, ks, stride, pad, int(dcol.dtype == f32), _stream()), "col2im_nhwc")
+    return dx
+
+
+def leaky_relu_bwd(dy: torch.Tensor, y: torch.Tensor, slope: float = 0.2) -> torch.Tensor:
+    dy = _req(dy, bf16, "dy")
+    y = _req(y, bf16, "y")
+    dx = torch.empty_like(dy)
+    check(_lib.lib().dmvae_leaky_relu_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), float(slope), _stream()), "leaky_relu_bwd")
+    return dx
+
+
+
 def sumpool2x2(dy: torch.Tensor) -> torch.Tensor:
     dy = _req(dy, bf16, "dy")
     n, h2, w2, c = dy.shape

@@ -41,7 +41,8 @@ typedef struct dmvae_conv_desc {
                         2: zero-insertion x2 (input pixel (y,x) sits at output position (2y+1,2x+1), zeros elsewhere): with
                            for_dgrad-packed weights this is the input gradient of the stride-2 Downsample conv below */
   int32_t act;       /* epilogue: 0 none, 1 SiLU (vae.py:60), 2 ReLU (lpips.py VGG trunk), 3 ReLU-backward mask: `residual` is
-                        not added but gates the result, y = residual > 0 ? conv + bias : 0 (input gradient through conv+ReLU) */
+                        not added but gates the result, y = residual > 0 ? conv + bias : 0 (input gradient through conv+ReLU);
+                        4 LeakyReLU(0.2) (models/patchgan.py:125) */
   int32_t out_f32;   /* 1: y is float32 (parity / final layers), else bf16 */
   int32_t stride;    /* 0 or 1: stride 1.  2: the Downsample conv of flux_ae.py:85-95 -- input zero-padded by one row/column at the
                         bottom/right only, 3x3, stride 2, no other padding: y is [n, h/2, w/2, cout] (h, w even; ks=3, upsample=0) */
@@ -78,18 +79,30 @@ size_t dmvae_groupnorm_workspace(int n, int hw, int c, int groups);
 int dmvae_groupnorm_stats(const void* x, void* stats, void* workspace, size_t workspace_bytes, int n, int hw,
                           int c, int groups, float eps, dmvae_stream_t stream);
 
-/* y = act((x-mean)*rstd*gamma+beta) as bf16; act = swish (x*sigmoid(x), flux_ae.py:21-22) when
- * swish!=0, identity otherwise (AttnBlock.norm, flux_ae.py:38). gamma/beta: [c] f32. */
+/* y = act((x-mean)*rstd*gamma+beta) as bf16; act: 0 identity (AttnBlock.norm, flux_ae.py:38), 1 swish (x*sigmoid(x),
+ * flux_ae.py:21-22), 2 LeakyReLU(0.2).  gamma/beta: [c] f32.
+ * With n=1, hw=N*H*W, groups=c this is nn.BatchNorm2d / nn.SyncBatchNorm (+LeakyReLU) of models/patchgan.py:134-145 on an
+ * NHWC tensor: `stats` then holds the per-channel (mean, rstd) -- batch statistics in training (combined over ranks by the
+ * caller for SyncBatchNorm), (running_mean, 1/sqrt(running_var+eps)) in eval. */
 int dmvae_groupnorm_apply(const void* x, const void* stats, const void* gamma, const void* beta, void* y,
-                          int n, int hw, int c, int groups, int swish, dmvae_stream_t stream);
+                          int n, int hw, int c, int groups, int act, dmvae_stream_t stream);
 
 /* Backward of y=act(GN(x)): given da=dL/dy (bf16), x, stats, gamma, beta computes
- * dx (bf16) = GN/swish backward [+ dres when dres != NULL, fusing the residual-branch add],
- * dgamma/dbeta ([c] f32, accumulate!=0 adds) -- both may be NULL to skip. */
+ * dx (bf16) = GN/act backward [+ dres when dres != NULL, fusing the residual-branch add],
+ * dgamma/dbeta ([c] f32, accumulate!=0 adds) -- both may be NULL to skip.  = bwd_reduce followed by bwd_apply. */
 int dmvae_groupnorm_bwd(const void* da, const void* x, const void* dres, const void* stats, const void* gamma,
                         const void* beta, void* dx, void* dgamma, void* dbeta, void* workspace,
-                        size_t workspace_bytes, int n, int hw, int c, int groups, int swish, int accumulate,
+                        size_t workspace_bytes, int n, int hw, int c, int groups, int act, int accumulate,
                         dmvae_stream_t stream);
+/* The two halves, for callers that own the statistics (SyncBatchNorm: all-reduce `sums` over ranks in between and pass
+ * inv_count = 1 / global element count; eval-mode BatchNorm: skip the reduce and pass zero sums).
+ * sums: [n][groups][2] f32 = (sum g, sum g*x_hat), g = da*act'(.)*gamma.  inv_count <= 0 selects 1/(hw*c/groups). */
+int dmvae_groupnorm_bwd_reduce(const void* da, const void* x, const void* stats, const void* gamma, const void* beta,
+                               void* sums, void* dgamma, void* dbeta, void* workspace, size_t workspace_bytes, int n,
+                               int hw, int c, int groups, int act, int accumulate, dmvae_stream_t stream);
+int dmvae_groupnorm_bwd_apply(const void* da, const void* x, const void* dres, const void* stats, const void* sums,
+                              const void* gamma, const void* beta, void* dx, int n, int hw, int c, int groups, int act,
+                              float inv_count, dmvae_stream_t stream);
 
 /* ---- batched GEMMs on the same MFMA cores (decoder self-attention, flux_ae.py:37-49) --------- */
 
@@ -128,6 +141,16 @@ int dmvae_pack_conv_weight(const void* w, void* out, int cout, int cin, int ks, 
 /* dx[n,h,w,c] = sum of the 2x2 block of dy[n,2h,2w,c]: backward of F.interpolate(scale=2,'nearest')
  * (flux_ae.py:104).  bf16, c%8==0. */
 int dmvae_sumpool2x2_nhwc(const void* dy, void* dx, int n, int h, int w, int c, dmvae_stream_t stream);
+/* PatchGAN convs (models/patchgan.py:125-147: nn.Conv2d(k=4, stride 2 or 1, padding 1)) as im2col + the 1x1 GEMM path:
+ * col[n,oy,ox,(ky*ks+kx)*c + ci] = x[n, oy*stride-pad+ky, ox*stride-pad+kx, ci] (zero outside), ho = (h+2*pad-ks)/stride+1;
+ * col2im is its adjoint (f32 accumulation over the overlapping taps, gather form: deterministic; dcol bf16, or f32 when
+ * in_f32 -- the GEMM's f32 result summed without an intermediate rounding, as a direct dgrad conv would).  bf16 x/col/dx, c%8==0.
+ * The weight operand [cout][ks*ks][c] comes from dmvae_pack_conv_weight (ks up to 7). */
+int dmvae_im2col_nhwc(const void* x, void* col, int n, int h, int w, int c, int ks, int stride, int pad, dmvae_stream_t stream);
+int dmvae_col2im_nhwc(const void* dcol, void* dx, int n, int h, int w, int c, int ks, int stride, int pad, int in_f32,
+                      dmvae_stream_t stream);
+/* dx = y > 0 ? dy : slope*dy  (nn.LeakyReLU(0.2) backward from the saved OUTPUT, patchgan.py:125,136,144). bf16, n%8==0. */
+int dmvae_leaky_relu_bwd(const void* dy, const void* y, void* dx, size_t n, float slope, dmvae_stream_t stream);
 /* VGG16 trunk of LPIPS (utils/lpips.py:116-153; nn.MaxPool2d(2,2) and the ReLU backward), NHWC bf16, c%8==0:
  * y[n,h,w,c] = max of the 2x2 window of x[n,2h,2w,c];
  * dx = x > 0 ? route(dpool -> first maximum of its window) + extra : 0   (dpool [n,h,w,c] and extra [n,2h,2w,c] may be NULL);

@@ -37,3 +37,19 @@ def det_fill_(module_or_sd, base_seed: int, prefix: str = "", skip=()):
             continue
         p.copy_(det_tensor(prefix + name, p.shape, base_seed).to(p.dtype))
     return module_or_sd
+
+
+@torch.no_grad()
+def det_fill_patchgan_(sd, base_seed: int):
+    """In-place fill of an NLayerDiscriminator state_dict (models/patchgan.py key layout main.{idx}.*): conv weights / biases and
+    BatchNorm shifts from det_tensor, BatchNorm scales around 1, running variances in [0.5, ...), counters untouched."""
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        if k.endswith("running_var"):
+            v.copy_(0.5 + det_tensor(k, v.shape, base_seed).abs() * 5)
+        elif v.dim() == 1 and k.endswith("weight"):                  # BatchNorm scale (conv weights are 4-D)
+            v.copy_(1.0 + det_tensor(k, v.shape, base_seed))
+        else:
+            v.copy_(det_tensor(k, v.shape, base_seed))
+    return sd

@@ -22,6 +22,7 @@ Reference files followed (all under /root/reference):
   diffusion/transport/transport.py:105-164, path.py:5-136, utils.py:12-16
   models/dinov2.py + models/dino_layers/{block,attention,layer_scale,mlp,patch_embed}.py
   toy_example_2d/dmd.py:320-360, toy_example_2d/sshpae.py:29-71
+  models/patchgan.py:99-151  utils/diffaug.py:43-114  train_tokenizer.py:190-227 (discriminator branch)
 """
 from __future__ import annotations
 
@@ -311,6 +312,126 @@ def forward_generator(images: Tensor, recon: Tensor, lpips_p: P, l1_w: float = 1
     lp = lpips_forward(images, recon, lpips_p, q=q)
     rec = l1 * l1_w + l2 * l2_w + lp * lpips_w
     return rec, {"L1": l1, "L2": l2, "LPIPS": lp, "rec_loss": rec}
+
+
+# --------------------------------------------------------------------------------------------
+# models/patchgan.py, utils/diffaug.py and the discriminator branch of train_tokenizer.py
+# --------------------------------------------------------------------------------------------
+def batch_norm(x: Tensor, w: Tensor, b: Tensor, running_mean: Tensor, running_var: Tensor, training: bool, momentum: float = 0.1,
+               eps: float = 1e-5):
+    """nn.BatchNorm2d == nn.SyncBatchNorm on one rank (patchgan.py:113-115).  Returns (y, running_mean', running_var')."""
+    if training:
+        mean = x.mean(dim=(0, 2, 3))
+        var = x.var(dim=(0, 2, 3), unbiased=False)
+        n = x.numel() // x.shape[1]
+        new_rm = (1 - momentum) * running_mean + momentum * mean.detach()
+        new_rv = (1 - momentum) * running_var + momentum * var.detach() * (n / max(n - 1, 1))
+    else:
+        mean, var, new_rm, new_rv = running_mean, running_var, running_mean, running_var
+    sh = (1, -1, 1, 1)
+    y = (x - mean.reshape(sh)) / torch.sqrt(var.reshape(sh) + eps) * w.reshape(sh) + b.reshape(sh)
+    return y, new_rm, new_rv
+
+
+def patchgan_forward(x: Tensor, p: P, pre: str = "main.", q: Q = None, training: bool = True, n_layers: int = 3):
+    """NLayerDiscriminator.forward (patchgan.py:99-151): conv4x4 s2 + LeakyReLU; (n_layers-1) x [conv4x4 s2, BN, LeakyReLU];
+    [conv4x4 s1, BN, LeakyReLU]; conv4x4 s1 -> 1 channel.  bf16 sites of the HIP path: every conv input / weight, every conv
+    output except the f32 logits, every BN+LeakyReLU output.  Returns (logits, {buffer name: updated running statistic})."""
+    new_buf: Dict[str, Tensor] = {}
+    h = F.conv2d(_q(q, x), _qw(q, p[pre + "0.weight"]), p[pre + "0.bias"], stride=2, padding=1)
+    h = _q(q, F.leaky_relu(h, 0.2))
+    idx = 2
+    for layer in range(1, n_layers + 1):
+        stride = 2 if layer < n_layers else 1
+        h = _q(q, F.conv2d(_q(q, h), _qw(q, p[f"{pre}{idx}.weight"]), p.get(f"{pre}{idx}.bias"), stride=stride, padding=1))
+        bn = f"{pre}{idx + 1}."
+        h, rm, rv = batch_norm(h, p[bn + "weight"], p[bn + "bias"], p[bn + "running_mean"], p[bn + "running_var"], training)
+        new_buf[bn + "running_mean"], new_buf[bn + "running_var"] = rm, rv
+        h = _q(q, F.leaky_relu(h, 0.2))
+        idx += 3
+    return F.conv2d(_q(q, h), _qw(q, p[f"{pre}{idx}.weight"]), p[f"{pre}{idx}.bias"], stride=1, padding=1), new_buf
+
+
+def diffaug(x: Tensor, rand01: Tensor, trans: bool = True, color: bool = True, cut: bool = True, cutout: float = 0.2) -> Tensor:
+    """DiffAug.aug (diffaug.py:43-114) with the blur warm-up off (every reference call site passes schedule 0) and the random draws
+    injected: rand01 [7, B] are the values of torch.rand(7, B, 1, 1) (:69), (trans, color, cut) the outcome of torch.rand(3) <= prob
+    (:66).  Translation by up to 1/8 of the size with zero fill; brightness, per-pixel saturation, per-image contrast; one zeroed
+    rectangle of `cutout` x size, clamped at the border."""
+    x = x.float()
+    B, C, H, W = x.shape
+    r = rand01.reshape(7, B).to(x.dtype)
+    if trans:
+        dh, dw = round(H * 0.125), round(W * 0.125)
+        th = torch.floor(r[0] * (2 * dh + 1)).long() - dh
+        tw = torch.floor(r[1] * (2 * dw + 1)).long() - dw
+        ys = torch.arange(H).view(1, H, 1) + th.view(B, 1, 1)            # source row of output row h
+        xs = torch.arange(W).view(1, 1, W) + tw.view(B, 1, 1)
+        ok = ((ys >= 0) & (ys < H) & (xs >= 0) & (xs < W)).unsqueeze(1)
+        bi = torch.arange(B).view(B, 1, 1).expand(B, H, W)
+        g = x.permute(0, 2, 3, 1)[bi, ys.clamp(0, H - 1).expand(B, H, W), xs.clamp(0, W - 1).expand(B, H, W)].permute(0, 3, 1, 2)
+        x = torch.where(ok, g, torch.zeros_like(g))
+    if color:
+        x = x + (r[2].view(B, 1, 1, 1) - 0.5)
+        m = x.mean(dim=1, keepdim=True)
+        x = (x - m) * (r[3].view(B, 1, 1, 1) * 2) + m
+        m = x.mean(dim=(1, 2, 3), keepdim=True)
+        x = (x - m) * (r[4].view(B, 1, 1, 1) + 0.5) + m
+    if cut:
+        ch, cw = round(H * cutout), round(W * cutout)
+        oh = torch.floor(r[5] * (H + (1 - ch % 2))).long()
+        ow = torch.floor(r[6] * (W + (1 - cw % 2))).long()
+        mask = torch.ones(B, H, W, dtype=x.dtype)
+        for b in range(B):
+            hh = (torch.arange(ch) + oh[b] - ch // 2).clamp(0, H - 1)
+            ww = (torch.arange(cw) + ow[b] - cw // 2).clamp(0, W - 1)
+            mask[b][hh.view(-1, 1), ww.view(1, -1)] = 0
+        x = x * mask.unsqueeze(1)
+    return x
+
+
+def hinge_d_loss(logits_real: Tensor, logits_fake: Tensor) -> Tensor:
+    """train_tokenizer.py:214."""
+    return 0.5 * (F.relu(1.0 - logits_real).mean() + F.relu(1.0 + logits_fake).mean())
+
+
+def forward_discriminator(images: Tensor, recon: Tensor, disc_p: P, rand01_a: Tensor, rand01_b: Tensor, bcr_weight: float,
+                          cutout_a: float = 0.2, cutout_b: float = 0.2, q: Q = None):
+    """VAELossFunction.forward_discriminator (train_tokenizer.py:207-227): hinge loss on D(aug([images; recon])) plus the balanced
+    consistency term bcr * mse(D(strong_aug(.)), D(aug(.))); the discriminator is in train mode for both passes (BatchNorm uses batch
+    statistics and updates its running estimates twice).  Returns (loss, log, buffers after both passes)."""
+    bs = images.shape[0]
+    both = torch.cat([images, recon], dim=0)
+    logits, buf1 = patchgan_forward(diffaug(both, rand01_a, cutout=cutout_a), disc_p, q=q, training=True)
+    logits = logits.float()
+    lr, lf = logits[:bs], logits[bs:]
+    d_loss = hinge_d_loss(lr, lf)
+    p2 = dict(disc_p)
+    p2.update(buf1)
+    logits2, buf2 = patchgan_forward(diffaug(both, rand01_b, cutout=cutout_b), p2, q=q, training=True)
+    bcr = F.mse_loss(logits2.float(), logits) * bcr_weight
+    acc_real = (lr.detach() > 0).float().mean() * 100
+    acc_fake = (lf.detach() < 0).float().mean() * 100
+    log = {"d_loss": d_loss.detach(), "bcr_loss": bcr.detach(), "acc_real": acc_real, "acc_fake": acc_fake, "acc_mean": (acc_real + acc_fake) * 0.5}
+    return d_loss + bcr, log, buf2
+
+
+def adaptive_disc_weight(rec_loss: Tensor, g_loss: Tensor, last_layer: Tensor, disc_weight: float) -> Tensor:
+    """train_tokenizer.py:194-198: disc_weight * clamp(|d rec / d last| / (|d g / d last| + 1e-6), 0, 1e4)."""
+    gr = torch.autograd.grad(rec_loss, last_layer, retain_graph=True)[0]
+    gd = torch.autograd.grad(g_loss, last_layer, retain_graph=True)[0]
+    return disc_weight * (gr.norm() / (gd.norm() + 1e-6)).clamp(0.0, 1e4).detach()
+
+
+def forward_generator_gan(images: Tensor, recon: Tensor, lpips_p: P, disc_p: P, last_layer: Tensor, rand01: Tensor, disc_weight: float = 0.5,
+                          l1_w: float = 1.0, l2_w: float = 0.0, lpips_w: float = 1.0, cutout: float = 0.2, q: Q = None):
+    """train_tokenizer.py:179-204 with the discriminator branch on (step >= disc_start_step): the discriminator is in eval mode
+    (running statistics), g = -mean D(aug(recon)), total = rec + adaptive_weight * g."""
+    rec, log = forward_generator(images, recon, lpips_p, l1_w, l2_w, lpips_w, q)
+    logits, _ = patchgan_forward(diffaug(recon, rand01, cutout=cutout), disc_p, q=q, training=False)
+    g_loss = -logits.float().mean()
+    w = adaptive_disc_weight(rec, g_loss, last_layer, disc_weight)
+    log = dict(log, d_weight=w)
+    return rec + g_loss * w, log
 
 
 def expand_t(t: Tensor, x: Tensor) -> Tensor:

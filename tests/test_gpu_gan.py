@@ -1,0 +1,124 @@
+"""Discriminator branch on the HIP kernels (-m gpu): the drop-in NLayerDiscriminator (im2col + MFMA GEMM convs, BatchNorm on the
+GroupNorm kernels), DiffAug and the GAN loss terms, against the fixtures captured from the reference and the CPU oracle evaluated
+with bf16 rounding at the HIP path's storage points.  Tolerances as in test_gpu_modules.py."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rel_err
+from oracle import ref_cpu as R
+from test_oracle_gan import patchgan_params
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+Q = R.bf16_round
+TOL_Q, TOL_REF = 1e-2, 3e-2
+
+
+def _disc(params):
+    from dmvae_amd.models.patchgan import NLayerDiscriminator
+    d = NLayerDiscriminator()
+    sd = d.state_dict()
+    for k in sd:
+        if k in params:
+            sd[k] = params[k].clone()
+    d.load_state_dict(sd, strict=True)
+    return d.to(DEV)
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 16, 64, 4, 2, 1), (1, 9, 11, 8, 32, 4, 1, 1), (3, 16, 16, 8, 64, 4, 2, 1), (1, 7, 7, 24, 8, 3, 1, 0),
+                                  (2, 64, 64, 64, 128, 4, 2, 1)])
+def test_im2col_col2im(case):
+    """im2col against F.unfold (bit-exact: pure data movement) and col2im against its autograd adjoint (f32 sum of <= 16 bf16 values,
+    one rounding)."""
+    from dmvae_amd import ops
+    n, h, w, c, _, ks, stride, pad = case
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, h, w, c, generator=g).to(DEV).to(BF)
+    col = ops.im2col(x, ks, stride, pad)
+    xr = x.float().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    u = F.unfold(xr, ks, padding=pad, stride=stride)                                  # [n, c*ks*ks, L], channel-major rows
+    ho, wo = col.shape[1], col.shape[2]
+    ref = u.view(n, c, ks * ks, ho, wo).permute(0, 3, 4, 2, 1).reshape(n, ho, wo, ks * ks * c)
+    assert torch.equal(col.float().cpu(), ref.detach())
+    dcol = torch.randn(col.shape, generator=g).to(DEV).to(BF)
+    dx = ops.col2im(dcol, h, w, ks, stride, pad)
+    ref.backward(dcol.float().cpu(), retain_graph=True)
+    assert rel_err(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1)) < 4e-3              # one bf16 rounding of the f32 sum
+    dcol32 = torch.randn(col.shape, generator=g).to(DEV)                               # f32 input: the GEMM's unrounded result
+    xr.grad = None
+    ref.backward(dcol32.cpu())
+    assert rel_err(ops.col2im(dcol32, h, w, ks, stride, pad).float().cpu(), xr.grad.permute(0, 2, 3, 1)) < 4e-3
+
+
+def test_patchgan_eval_and_train():
+    g = load_golden("patchgan_small")
+    p = patchgan_params(g, int(g["seed"]))
+    disc = _disc(p)
+    assert [k for k in disc.state_dict()] == [str(k) for k in g["keys"]]
+    x = g.t("x").to(DEV)
+    disc.eval()
+    with torch.no_grad():
+        y_eval = disc(x)
+    assert y_eval.shape == (2, 1, 6, 6) and y_eval.dtype == torch.float32
+    with torch.no_grad():
+        yo_eval, _ = R.patchgan_forward(g.t("x"), p, q=Q, training=False)
+    assert rel_err(y_eval.cpu(), yo_eval) < TOL_Q
+    assert rel_err(y_eval.cpu(), g.t("y_eval")) < TOL_REF
+    # training step: batch statistics, running-estimate update, all gradients
+    disc.train()
+    xg = x.clone().requires_grad_(True)
+    y = disc(xg)
+    y.backward(g.t("dy").to(DEV))
+    po = {k: (v.clone().requires_grad_(True) if "running" not in k else v.clone()) for k, v in p.items()}
+    xo = g.t("x").requires_grad_(True)
+    yo, buf = R.patchgan_forward(xo, po, q=Q, training=True)
+    yo.backward(Q(g.t("dy")))                    # the logit gradient enters the HIP path as a bf16 GEMM operand
+    assert rel_err(y.cpu(), yo.detach()) < TOL_Q
+    assert rel_err(y.detach().cpu(), g.t("y")) < TOL_REF
+    assert rel_err(xg.grad.cpu(), xo.grad) < 3 * TOL_Q          # 5 convs / 3 BatchNorms deep (cf. test_flux_encoder_small_fwd_bwd)
+    # against the reference's f32 result: 5 convs / 3 small-batch BatchNorms / LeakyReLU kinks amplify bf16 rounding (both for this
+    # path and for the bf16-site oracle), so the criterion is test_gpu_modules.py::test_decoder_small_fwd_bwd's -- the HIP path must be
+    # as close to the f32 reference as the bf16-site oracle is
+    def floor(hip, orc, ref, what, slack=1.5, abs_floor=1e-3):
+        rl2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+        e_hip, e_orc = rl2(hip, ref), rl2(orc, ref)
+        print(f"patchgan {what}: rel-L2 to f32 reference -- HIP {e_hip:.2e}, bf16-site oracle {e_orc:.2e}")
+        assert e_hip < slack * e_orc + abs_floor, what
+    floor(xg.grad.cpu(), xo.grad, g.t("dx"), "dx")
+    sd = disc.state_dict()
+    for k, v in buf.items():
+        assert rel_err(sd[k].cpu(), g.t("buf1." + k)) < 5e-3, k
+    assert int(sd["main.3.num_batches_tracked"]) == int(g["buf1.main.3.num_batches_tracked"]) == 1
+    for n, prm in disc.named_parameters():
+        ref_norm = g["gn." + n][0]
+        if ref_norm < 1e-3:                                   # main.2/5/8.bias: exact zeros in f32, bf16 noise here
+            assert prm.grad.abs().max() < 2e-2, n
+            continue
+        # rel-L2, not max-abs: a pre-activation within bf16 noise of the LeakyReLU kink takes slope 1 on one side and 0.2 on the other,
+        # which moves single gradient entries by ~10 % of the maximum while the tensor as a whole agrees to 1.5 % (tools/probes/dbg_patchgan.py)
+        assert ((prm.grad.cpu().double() - po[n].grad.double()).norm() / po[n].grad.double().norm()).item() < 3 * TOL_Q, n
+        assert abs(prm.grad.double().norm().item() - ref_norm) < 3e-2 * ref_norm, n
+        if "g." + n in g:
+            floor(prm.grad.cpu(), po[n].grad, g.t("g." + n), "grad " + n)
+
+
+def test_patchgan_full_size_shapes_and_determinism():
+    """256x256 inputs, batch 8 (the discriminator step sees [images; recon]): logits [B,1,30,30]; two identical steps give identical
+    logits and gradients (split-K reductions are ordered)."""
+    from dmvae_amd.models.patchgan import NLayerDiscriminator, weights_init
+    torch.manual_seed(0)
+    disc = NLayerDiscriminator().apply(weights_init).to(DEV)
+    x = (torch.rand(8, 3, 256, 256, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
+    outs = []
+    for _ in range(2):
+        disc.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        y = disc(xg)
+        assert y.shape == (8, 1, 30, 30)
+        F.relu(1.0 - y).mean().backward()
+        outs.append((y.detach().clone(), xg.grad.clone(), disc.main[0].weight.grad.clone(), disc.main[8].weight.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.isfinite(outs[0][1]).all() and outs[0][1].abs().max() > 0
