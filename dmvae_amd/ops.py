@@ -290,6 +290,31 @@ def col2im(dcol: torch.Tensor, h: int, w: int, ks: int, stride: int, pad: int) -
     return dx
 
 
+def _diffaug_args(x, rand01, flags, cutout):
+    assert x.dtype == f32 and x.is_cuda and x.is_contiguous() and x.dim() == 4
+    b, c, h, w = x.shape
+    rand01 = _req(rand01, f32, "rand01")
+    assert rand01.numel() == 7 * b
+    ws = torch.empty(b, dtype=f32, device=x.device)
+    # Python round() on the same float expressions as utils/diffaug.py:73-75,92-94
+    return rand01, ws, (b, c, h, w, int(flags), round(h * 0.125), round(w * 0.125), round(h * cutout), round(w * cutout))
+
+
+def diffaug(x: torch.Tensor, rand01: torch.Tensor, flags: int = 7, cutout: float = 0.2) -> torch.Tensor:
+    """DiffAug forward on an NCHW f32 batch; flags: 1 translate | 2 colour | 4 cut-out; rand01 [7, B] device f32."""
+    rand01, ws, a = _diffaug_args(x, rand01, flags, cutout)
+    y = torch.empty_like(x)
+    check(_lib.lib().dmvae_diffaug_fwd(x.data_ptr(), rand01.data_ptr(), y.data_ptr(), ws.data_ptr(), *a, _stream()), "diffaug_fwd")
+    return y
+
+
+def diffaug_bwd(dy: torch.Tensor, rand01: torch.Tensor, flags: int = 7, cutout: float = 0.2) -> torch.Tensor:
+    rand01, ws, a = _diffaug_args(dy, rand01, flags, cutout)
+    dx = torch.empty_like(dy)
+    check(_lib.lib().dmvae_diffaug_bwd(dy.data_ptr(), rand01.data_ptr(), dx.data_ptr(), ws.data_ptr(), *a, _stream()), "diffaug_bwd")
+    return dx
+
+
 def leaky_relu_bwd(dy: torch.Tensor, y: torch.Tensor, slope: float = 0.2) -> torch.Tensor:
     dy = _req(dy, bf16, "dy")
     y = _req(y, bf16, "y")

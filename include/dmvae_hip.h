@@ -151,6 +151,15 @@ int dmvae_col2im_nhwc(const void* dcol, void* dx, int n, int h, int w, int c, in
                       dmvae_stream_t stream);
 /* dx = y > 0 ? dy : slope*dy  (nn.LeakyReLU(0.2) backward from the saved OUTPUT, patchgan.py:125,136,144). bf16, n%8==0. */
 int dmvae_leaky_relu_bwd(const void* dy, const void* y, void* dx, size_t n, float slope, dmvae_stream_t stream);
+/* DiffAug (utils/diffaug.py:43-114) on NCHW f32 images [b,c<=8,h,w], blur warm-up off (schedule 0 at every reference call site):
+ * translate by th,tw = floor(r0|r1*(2*delta+1)) - delta with zero fill; brightness r2-0.5, per-pixel saturation 2*r3, per-image
+ * contrast r4+0.5; zero the cut_h x cut_w rectangle centred at floor(r5|r6*(size+1-cut%2)), clamped at the border.
+ * rand01: device f32 [7][b] = torch.rand(7,b,1,1) (:69); flags: bit 0 translate, bit 1 colour, bit 2 cut-out (torch.rand(3) <= prob,
+ * :66); delta_* = round(size*0.125), cut_* = round(size*cutout) (:73-75,:92-94).  workspace: b floats.  bwd is the exact adjoint. */
+int dmvae_diffaug_fwd(const void* x, const void* rand01, void* y, void* workspace, int b, int c, int h, int w, int flags,
+                      int delta_h, int delta_w, int cut_h, int cut_w, dmvae_stream_t stream);
+int dmvae_diffaug_bwd(const void* dy, const void* rand01, void* dx, void* workspace, int b, int c, int h, int w, int flags,
+                      int delta_h, int delta_w, int cut_h, int cut_w, dmvae_stream_t stream);
 /* VGG16 trunk of LPIPS (utils/lpips.py:116-153; nn.MaxPool2d(2,2) and the ReLU backward), NHWC bf16, c%8==0:
  * y[n,h,w,c] = max of the 2x2 window of x[n,2h,2w,c];
  * dx = x > 0 ? route(dpool -> first maximum of its window) + extra : 0   (dpool [n,h,w,c] and extra [n,2h,2w,c] may be NULL);

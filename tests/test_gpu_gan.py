@@ -122,3 +122,56 @@ def test_patchgan_full_size_shapes_and_determinism():
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert torch.isfinite(outs[0][1]).all() and outs[0][1].abs().max() > 0
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_diffaug_kernels(tag):
+    """Fused DiffAug against the fixtures captured from the reference's DiffAug.aug (translation / cut-out bit-exact, colour to f32
+    summation order) and against its captured input gradient."""
+    from dmvae_amd import ops
+    g = load_golden("diffaug")
+    x = g.t(f"{tag}.x").to(DEV)
+    for name, flags in (("trans", 1), ("color", 2), ("cut", 4), ("all", 7)):
+        y = ops.diffaug(x, g.t(f"{tag}.{name}.rand01").to(DEV), flags, 0.2)
+        ref = g.t(f"{tag}.{name}.y")
+        if name in ("trans", "cut"):
+            assert torch.equal(y.cpu(), ref), name
+        else:
+            assert rel_err(y.cpu(), ref) < 2e-6, name
+            assert torch.equal(y.cpu() == 0, ref == 0) or name == "color"
+    dx = ops.diffaug_bwd(g.t(f"{tag}.all.dy").to(DEV), g.t(f"{tag}.all.rand01").to(DEV), 7, 0.2)
+    assert rel_err(dx.cpu(), g.t(f"{tag}.all.dx")) < 1e-5
+    assert torch.equal(dx.cpu() == 0, g.t(f"{tag}.all.dx") == 0)
+    if tag == "a":
+        y = ops.diffaug(x, g.t("a.edge.rand01").to(DEV), 7, 0.2)
+        assert rel_err(y.cpu(), g.t("a.edge.y")) < 2e-6 and torch.equal(y.cpu() == 0, g.t("a.edge.y") == 0)
+
+
+def test_diffaug_module_rng_and_adjoint():
+    """The drop-in DiffAug consumes the RNG streams like the reference (torch.rand(3) on the CPU generator, torch.rand(7,B,1,1) on the
+    device generator) and its backward is the exact adjoint of its forward: <aug(x), dy> == <x, aug^T(dy)> up to the constant offset the
+    brightness term adds (checked through a difference of two inputs)."""
+    from dmvae_amd.utils.diffaug import DiffAug
+    x1 = (torch.rand(6, 3, 64, 48, generator=torch.Generator().manual_seed(5)) * 2 - 1).to(DEV)
+    x2 = (torch.rand(6, 3, 64, 48, generator=torch.Generator().manual_seed(6)) * 2 - 1).to(DEV)
+    dy = torch.randn(6, 3, 64, 48, generator=torch.Generator().manual_seed(7)).to(DEV)
+    outs = []
+    for x in (x1, x2):
+        torch.manual_seed(123)
+        xg = x.clone().requires_grad_(True)
+        y = DiffAug(prob=1.0, cutout=0.3).aug(xg)
+        y.backward(dy)
+        outs.append((y.detach(), xg.grad))
+    assert torch.equal(outs[0][1], outs[1][1])                       # the map is affine: the adjoint does not depend on x
+    lhs = ((outs[0][0] - outs[1][0]).double() * dy.double()).sum()
+    rhs = ((x1 - x2).double() * outs[0][1].double()).sum()
+    assert abs(lhs.item() - rhs.item()) < 1e-6 * max(1.0, abs(lhs.item()))
+    torch.manual_seed(123)
+    cpu_flags = torch.rand(3)                                         # same draws as the module made
+    dev_draws = torch.rand(7, 6, 1, 1, device=DEV)
+    y_ref = R.diffaug(x1.cpu(), dev_draws.view(7, 6).cpu(), cutout=0.3)
+    assert bool((cpu_flags <= 1.0).all())
+    assert rel_err(outs[0][0].cpu(), y_ref) < 2e-6
+    assert DiffAug(prob=0.0).aug(x1) is x1
+    with pytest.raises(NotImplementedError):
+        DiffAug().aug(x1, 0.5)
