@@ -90,3 +90,42 @@ def kl_mmd_loss(latent_tokens: torch.Tensor, prior: Optional[torch.Tensor] = Non
     if prior is None:
         prior = torch.randn(z.shape, device=z.device, dtype=torch.float32, generator=generator)
     return _KLMMD.apply(z, prior.float(), float(w_kl), float(w_mmd))
+
+
+# ---- adversarial branch (train_tokenizer.py:190-227) -------------------------------------------------------------------------------
+def generator_gan_term(rec_loss: torch.Tensor, recon: torch.Tensor, disc: torch.nn.Module, daug, last_layer: torch.Tensor,
+                       disc_weight: float = 0.5):
+    """VAELossFunction.forward_generator's discriminator branch (train_tokenizer.py:190-203): the discriminator is frozen and in eval
+    mode (BatchNorm running statistics), g = -mean D(aug(recon)); the adaptive weight is disc_weight * clamp(|d rec/d last| /
+    (|d g/d last| + 1e-6), 0, 1e4) at the decoder's last layer.  Returns (rec_loss + d_weight * g, d_weight).
+
+    With direct flat-buffer gradients (optim.FlatParams.enable_direct_grads) each autograd.grad call leaves its result in
+    `last_layer`'s gradient slot, so each is reduced to its norm before the next call overwrites the slot (same stream: the order
+    holds); the caller's final backward rewrites the slot with the full gradient."""
+    disc.eval()
+    for p in disc.parameters():
+        p.requires_grad_(False)
+    g_loss = -disc(daug.aug(recon, 0)).float().mean()
+    n_rec = torch.autograd.grad(rec_loss, last_layer, retain_graph=True)[0].detach().norm()
+    n_gan = torch.autograd.grad(g_loss, last_layer, retain_graph=True)[0].detach().norm()
+    d_weight = (n_rec / (n_gan + 1e-6)).clamp_(0.0, 1e4) * disc_weight
+    return rec_loss + g_loss * d_weight, d_weight
+
+
+def discriminator_loss(images: torch.Tensor, recon: torch.Tensor, disc: torch.nn.Module, daug, bcr_strong_aug, bcr_weight: float = 1.0):
+    """VAELossFunction.forward_discriminator (train_tokenizer.py:207-227): hinge loss on D(aug([images; recon])) plus
+    bcr_weight * mse(D(strong_aug(.)), D(aug(.))), the discriminator in train mode for both passes.  Returns (loss, log) with the log
+    entries as device scalars (no host sync): d_loss, bcr_loss, acc_real, acc_fake."""
+    for p in disc.parameters():
+        p.requires_grad_(True)
+    disc.train()
+    bs = images.shape[0]
+    both = torch.cat([images, recon], dim=0)
+    logits = disc(daug.aug(both, 0.0)).float()
+    lr_, lf_ = logits[:bs], logits[bs:]
+    d_loss = 0.5 * (torch.relu(1.0 - lr_).mean() + torch.relu(1.0 + lf_).mean())
+    logits2 = disc(bcr_strong_aug.aug(both, 0.0)).float()
+    l_bcr = torch.nn.functional.mse_loss(logits2, logits) * bcr_weight
+    log = {"d_loss": d_loss.detach(), "bcr_loss": l_bcr.detach(), "acc_real": (lr_.detach() > 0).float().mean() * 100,
+           "acc_fake": (lf_.detach() < 0).float().mean() * 100}
+    return d_loss + l_bcr, log

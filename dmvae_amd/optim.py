@@ -68,10 +68,11 @@ class FlatAdamWEMA:
         self.t = 0
 
     def current_lr(self) -> float:
-        """LambdaLR(lambda s: min(1, (s+1)/warmup)) evaluated at the scheduler step count (train_tokenizer.py:385-392)."""
-        if self.warmup_steps <= 0:
-            return self.lr
-        return self.lr * min(1.0, (self.t + 1) / self.warmup_steps)
+        """The reference's LambdaLR (train_tokenizer.py:385-392): lr_lambda(s) = s / warmup if s < warmup else 1, evaluated at the
+        number of completed steps -- the first optimiser step runs at lr 0."""
+        if self.t < self.warmup_steps:
+            return self.lr * (self.t / self.warmup_steps)
+        return self.lr
 
     def step(self):
         lr = self.current_lr()

@@ -380,16 +380,23 @@ def main():
     tok = rn(2, 256, 32)
     save("latents_to_spatial", tokens=tok, spatial=train_dmd.latents_to_spatial(tok))
 
-    # ---- G11 opt_tail: clip + AdamW + EMA, 3 steps with LambdaLR warm-up ------------------------
+    # ---- G11 opt_tail: clip + AdamW + EMA, 6 steps with LambdaLR warm-up ------------------------
     torch.manual_seed(51)
     net = nn.Sequential(nn.Linear(16, 32), nn.SiLU(), nn.Linear(32, 8))
     import copy
     ema = copy.deepcopy(net)
     opt = torch.optim.AdamW(net.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.005)
-    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, (s + 1) / 1000))
+    warm = 4        # the reference's lr_lambda (train_tokenizer.py:385-389) with a short warm-up: lr = 0, 1/4, 2/4, 3/4, 1, 1 x base
+
+    def lr_lambda(step):
+        if step < warm:
+            return step / warm
+        return 1.0
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda)
     p0 = {k: v.clone() for k, v in net.state_dict().items()}
-    grads_hist, norms = [], []
-    for it in range(3):
+    grads_hist, norms, lrs = [], [], []
+    for it in range(6):
+        lrs.append(opt.param_groups[0]["lr"])
         for p_ in net.parameters():
             p_.grad = 3.0 * torch.randn(p_.shape, generator=g)
         grads_hist.append([p_.grad.clone() for p_ in net.parameters()])
@@ -398,9 +405,9 @@ def main():
         opt.zero_grad()
         sched.step()
         train_tokenizer.update_ema(ema, net)
-    save("opt_tail", norms=np.array(norms), **{"p0." + k: v for k, v in p0.items()},
+    save("opt_tail", norms=np.array(norms), lrs=np.array(lrs), warmup_steps=np.array(warm), **{"p0." + k: v for k, v in p0.items()},
          **{f"g{it}.{i}": gr for it, gl in enumerate(grads_hist) for i, gr in enumerate(gl)},
-         **{"p3." + k: v for k, v in sd_np(net).items()}, **{"ema3." + k: v for k, v in sd_np(ema).items()})
+         **{"p6." + k: v for k, v in sd_np(net).items()}, **{"ema6." + k: v for k, v in sd_np(ema).items()})
 
     # ---- G13 sshape ----------------------------------------------------------------------------
     ss = _load("sshpae", REF + "/toy_example_2d/sshpae.py")

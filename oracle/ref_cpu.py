@@ -509,8 +509,9 @@ def ema_update(ema: Tensor, p: Tensor, decay: float = 0.9999) -> Tensor:
 
 
 def warmup_lr(step: int, base_lr: float, warmup_steps: int = 1000) -> float:
-    """LambdaLR of train_tokenizer.py:385-392: linear warm-up then constant."""
-    return base_lr * min(1.0, (step + 1) / warmup_steps) if warmup_steps > 0 else base_lr
+    """LambdaLR of train_tokenizer.py:385-392, lr_lambda(step) = step / warmup if step < warmup else 1: the learning rate in force
+    for optimiser step number `step` (0-based) -- the very first step runs at lr 0."""
+    return base_lr * (step / warmup_steps if step < warmup_steps else 1.0)
 
 
 # --------------------------------------------------------------------------------------------

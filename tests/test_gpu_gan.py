@@ -175,3 +175,88 @@ def test_diffaug_module_rng_and_adjoint():
     assert DiffAug(prob=0.0).aug(x1) is x1
     with pytest.raises(NotImplementedError):
         DiffAug().aug(x1, 0.5)
+
+
+class _RandQueue:
+    """torch.rand returns the queued tensors (moved to the requested device) instead of drawing: replays the fixture's draws through the
+    drop-in DiffAug, which consumes torch.rand(3) then torch.rand(7, B, 1, 1, device=...) like the reference."""
+
+    def __init__(self, queued):
+        self.queue = list(queued)
+
+    def __enter__(self):
+        self._orig = torch.rand
+
+        def rand(*size, **kw):
+            t = self.queue.pop(0)
+            return t.to(kw["device"]) if "device" in kw else t
+        torch.rand = rand
+        return self
+
+    def __exit__(self, *a):
+        torch.rand = self._orig
+        assert not self.queue
+
+
+def test_gan_loss_terms_vs_reference_fixture():
+    """losses.generator_gan_term / discriminator_loss against train_tokenizer.VAELossFunction.forward_generator (discriminator branch on)
+    and forward_discriminator, captured with a conv stand-in for the decoder's last layer (oracle/capture_golden_gan.py)."""
+    from dmvae_amd import losses
+    from dmvae_amd.utils.diffaug import DiffAug
+    from dmvae_amd.utils.lpips import LPIPS
+    from test_oracle_golden import lpips_params
+    g = load_golden("gan_losses")
+    lp = LPIPS().eval().requires_grad_(False)
+    sd = lp.state_dict()
+    for k, v in lpips_params(g).items():
+        sd[k] = v.reshape(sd[k].shape)
+    lp.load_state_dict(sd)
+    lp = lp.to(DEV)
+    disc_p = patchgan_params(g, int(g["disc_seed"]))
+    disc = _disc(disc_p)
+    img, feat = g.t("images").to(DEV), g.t("feat").to(DEV)
+    last = g.t("last").to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        recon = (F.conv2d(feat, last, padding=1) + 0.9 * img).float()
+        l1, l2 = losses.l1_mse(recon, img, 1.0, 0.0)
+        rec_loss = l1 + lp(img, recon)
+        B = img.shape[0]
+        with _RandQueue([torch.zeros(3), g.t("gen_rand01").view(7, B, 1, 1)]):
+            total, d_weight = losses.generator_gan_term(rec_loss, recon, disc, DiffAug(prob=1.0, cutout=0.2), last, 0.5)
+    assert not disc.training and all(not p.requires_grad for p in disc.parameters())
+    assert abs(rec_loss.item() - float(g["gen_rec_loss"])) < 2e-2 * float(g["gen_rec_loss"])
+    assert abs(d_weight.item() - float(g["d_weight"])) < 8e-2 * float(g["d_weight"])          # ratio of two bf16-path gradient norms
+    assert abs(total.item() - float(g["gen_loss"])) < 3e-2 * abs(float(g["gen_loss"]))
+    total.backward()
+    rl2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
+    assert rl2(last.grad.cpu(), g.t("g_last")) < 8e-2
+    # bf16-site oracle on the same draws: tighter
+    lpo = lpips_params(g)
+    lo = g.t("last").requires_grad_(True)
+    ro = F.conv2d(g.t("feat"), lo, padding=1) + 0.9 * g.t("images")
+    to, logo = R.forward_generator_gan(g.t("images"), ro, lpo, disc_p, lo, g.t("gen_rand01"), 0.5, q=Q)
+    assert abs(d_weight.item() - logo["d_weight"].item()) < 5e-2 * logo["d_weight"].item()
+    assert abs(total.item() - to.item()) < 2e-2 * abs(to.item())
+    # discriminator step terms (bcr weight 4, strong cut-out 0.5 as captured); buffers continue from the generator pass
+    draws = [torch.zeros(3), g.t("d_rand01_a").view(7, 2 * B, 1, 1), torch.zeros(3), g.t("d_rand01_b").view(7, 2 * B, 1, 1)]
+    with torch.autocast("cuda", dtype=torch.bfloat16), _RandQueue(draws):
+        d_total, dlog = losses.discriminator_loss(img, g.t("recon").to(DEV), disc, DiffAug(prob=1.0, cutout=0.2), DiffAug(prob=1, cutout=0.5), 4.0)
+    assert disc.training
+    assert abs(d_total.item() - float(g["d_total"])) < 3e-2 * abs(float(g["d_total"]))
+    assert abs(dlog["d_loss"].item() - float(g["dlog.d_loss"])) < 2e-2 * float(g["dlog.d_loss"])
+    assert abs(dlog["bcr_loss"].item() - float(g["dlog.bcr_loss"])) < 8e-2 * float(g["dlog.bcr_loss"]) + 1e-3
+    # 72 logits per half: one sign flip of a near-zero logit under bf16 = 1.4 points
+    assert abs(dlog["acc_real"].item() - float(g["dlog.acc_real"])) <= 3.0 and abs(dlog["acc_fake"].item() - float(g["dlog.acc_fake"])) <= 3.0
+    d_total.backward()
+    sd = disc.state_dict()
+    for k, v in g.sub("buf2.").items():
+        if "num_batches" in k:
+            assert int(sd[k]) == int(v) == 2, k                 # two training-mode passes
+        else:
+            assert rel_err(sd[k].cpu(), v) < 1e-2, k
+    for n, prm in disc.named_parameters():
+        gn = g["dgn." + n][0]
+        if gn > 1e-3:
+            assert abs(prm.grad.double().norm().item() - gn) < 6e-2 * gn, n
+    for k, v in g.sub("dg.").items():
+        assert rl2(dict(disc.named_parameters())[k].grad.cpu(), v) < 0.12, k

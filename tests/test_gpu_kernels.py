@@ -319,15 +319,15 @@ def test_adamw_ema_golden():
     sizes = [g["p0." + n].size for n in names]
     flat = torch.cat([g.t("p0." + n).flatten() for n in names]).to(DEV)
     ema, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
-    for it in range(3):
+    for it in range(6):
         gr = torch.cat([g.t(f"g{it}.{i}").flatten() for i in range(4)]).to(DEV)
         norm = ops.grad_norm(gr, 1.0)
         assert abs(norm[0].item() - float(g["norms"][it])) < 1e-5 * float(g["norms"][it])
-        ops.adamw_ema_step(flat, gr, m, v, ema, norm, R.warmup_lr(it, 1e-4, 1000), 0.9, 0.95, 1e-8, 0.005, it + 1, 0.9999)
+        ops.adamw_ema_step(flat, gr, m, v, ema, norm, R.warmup_lr(it, 1e-4, int(g["warmup_steps"])), 0.9, 0.95, 1e-8, 0.005, it + 1, 0.9999)
     off = 0
     for n, sz in zip(names, sizes):
-        assert rel_err(flat[off:off + sz].cpu(), g.t("p3." + n).flatten()) < 1e-6
-        assert rel_err(ema[off:off + sz].cpu(), g.t("ema3." + n).flatten()) < 1e-6
+        assert rel_err(flat[off:off + sz].cpu(), g.t("p6." + n).flatten()) < 1e-6
+        assert rel_err(ema[off:off + sz].cpu(), g.t("ema6." + n).flatten()) < 1e-6
         off += sz
 
 

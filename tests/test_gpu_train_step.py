@@ -45,7 +45,7 @@ def test_direct_flat_grads_match_autograd_accumulation():
     assert all(p.grad is not None for p in a.fp.params)
     c, d = _trainer(True), _trainer(False)
     losses = []
-    for _ in range(3):
+    for _ in range(6):          # warm-up of 2: the reference's schedule runs step 0 at lr 0, step 1 at half the rate
         lc, ld = c.step(images), d.step(images)
         assert abs(lc.item() - ld.item()) < 1e-3 * abs(ld.item())
         losses.append(lc.item())
@@ -100,3 +100,42 @@ def test_fused_encoder_attention_vs_reference(shape):
     err = (out.double() - ref).abs().max().item()
     assert err < 2e-2 * ref.abs().max().item() + 1e-3, err     # P and O are rounded to bf16 once each
     assert torch.equal(out, ops.attention_qkv(qkv, h, 64 ** -0.5))
+
+
+def test_step_with_discriminator_branch():
+    """Steady-state step of train_tokenizer.py (global_step >= disc_start_step): generator term with the adaptive weight, then the
+    discriminator update.  Checks the wiring -- the branch switches on at disc_start_step, both optimisers move their parameters, the
+    discriminator is left in train mode with trainable parameters, BatchNorm counters advance by two per step, the log entries are
+    finite and the checkpoint carries disc_wo_ddp -- and run-to-run determinism given the same RNG seeds."""
+    from dmvae_amd.models.init_param import init_weights
+    from dmvae_amd.models.patchgan import NLayerDiscriminator
+
+    def run():
+        tr = _trainer(True)
+        torch.manual_seed(11)
+        disc = NLayerDiscriminator()
+        init_weights(disc, 0.02)
+        from dmvae_amd.train import TokenizerTrainer
+        tr = TokenizerTrainer(tr.vae, tr.lpips, warmup_steps=2, disc=disc.cuda(), disc_start_step=1, disc_weight=0.5)
+        g = torch.Generator(device="cuda").manual_seed(0)
+        images = torch.rand(2, 3, 256, 256, device="cuda", generator=g) * 2 - 1
+        d0 = tr.dfp.flat.clone()
+        tr.step(images)                                   # step 0: branch off
+        assert torch.equal(tr.dfp.flat, d0) and int(disc.main[3].num_batches_tracked) == 0 and tr.read_log()["d_weight"] == 0.0
+        torch.manual_seed(5)
+        out = []
+        for _ in range(3):                                # steps 1..3: branch on (lr: 0.5x at step 1 of the warm-up, then 1x)
+            out.append(tr.step(images).item())
+        return tr, disc, d0, out
+
+    tr, disc, d0, out = run()
+    log, dlog = tr.read_log(), tr.read_disc_log()
+    assert all(map(lambda v: v == v and abs(v) < 1e6, list(log.values()) + list(dlog.values())))
+    assert log["d_weight"] > 0 and dlog["d_loss"] > 0 and dlog["disc_norm"] > 0 and 0 <= dlog["acc_mean"] <= 100
+    assert not torch.equal(tr.dfp.flat, d0)                                    # the discriminator optimiser moved its parameters
+    assert disc.training and all(p.requires_grad for p in disc.parameters())
+    assert int(disc.main[3].num_batches_tracked) == 6                           # two training-mode passes per discriminator step
+    ck = tr.checkpoint()
+    assert set(ck["disc_wo_ddp"].keys()) == set(disc.state_dict().keys()) and "vae_ema" in ck
+    tr2, _, _, out2 = run()
+    assert out == out2 and torch.equal(tr.fp.flat, tr2.fp.flat) and torch.equal(tr.dfp.flat, tr2.dfp.flat)

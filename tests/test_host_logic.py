@@ -87,11 +87,16 @@ def test_lambda_lr_warmup_matches_reference_schedule():
     from dmvae_amd.optim import FlatAdamWEMA, FlatParams
     p = torch.nn.Parameter(torch.zeros(8))
     opt = FlatAdamWEMA(FlatParams([p]), lr=1e-4, warmup_steps=1000)
-    sched = torch.optim.lr_scheduler.LambdaLR(torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-4), lambda s: min(1.0, (s + 1) / 1000))
-    for t in (0, 1, 10, 998, 999, 1000, 5000):
+    sgd = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+    sched = torch.optim.lr_scheduler.LambdaLR(sgd, lambda s: s / 1000 if s < 1000 else 1.0)     # train_tokenizer.py:386-391
+    for t in range(1003):
         opt.t = t
-        sched.last_epoch = t
-        assert opt.current_lr() == pytest.approx(1e-4 * min(1.0, (t + 1) / 1000))
+        assert opt.current_lr() == pytest.approx(sgd.param_groups[0]["lr"], rel=1e-12, abs=0), t
+        sgd.step()
+        sched.step()
+    assert opt.current_lr() == 1e-4
+    opt.t = 0
+    assert opt.current_lr() == 0.0                       # the reference's first step runs at lr 0
 
 
 def test_forward_without_gpu_raises_not_falls_back():

@@ -254,16 +254,18 @@ def test_opt_tail():
     ema = [x.clone() for x in p]
     m = [torch.zeros_like(x) for x in p]
     v = [torch.zeros_like(x) for x in p]
-    for it in range(3):
+    warm = int(g["warmup_steps"])
+    for it in range(6):
         grads = [g.t(f"g{it}.{i}") for i in range(4)]
         norm, grads = R.clip_grad_norm(grads, 1.0)
         assert abs(norm.item() - float(g["norms"][it])) < 1e-5 * float(g["norms"][it])
-        lr = R.warmup_lr(it, 1e-4, 1000)
+        lr = R.warmup_lr(it, 1e-4, warm)
+        assert lr == pytest.approx(float(g["lrs"][it]), rel=1e-12, abs=0)      # the reference's own LambdaLR sequence (lr 0 at step 0)
         for i in range(4):
             p[i], m[i], v[i] = R.adamw_step(p[i], grads[i], m[i], v[i], it + 1, lr)
             ema[i] = R.ema_update(ema[i], p[i])
     for i, n in enumerate(names):
-        assert rel_err(p[i], g.t("p3." + n)) < 1e-6 and rel_err(ema[i], g.t("ema3." + n)) < 1e-6
+        assert rel_err(p[i], g.t("p6." + n)) < 1e-6 and rel_err(ema[i], g.t("ema6." + n)) < 1e-6
 
 
 def test_sshape():
