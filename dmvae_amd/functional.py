@@ -311,7 +311,9 @@ class ConvIm2colFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             wt = packed(w, False, rows_pad=cpad, cols_pad=cp, transposed=True)          # [k, cpad]
-            dcol = ops.gemm_nt(dy.view(m, cpad), wt, out_f32=True)     # f32: the taps are summed before the one bf16 rounding
+            # f32 result: the taps are summed before the one bf16 rounding.  Through the conv entry point (1x1) so that large
+            # shapes get the ping-pong kernel.
+            dcol = ops.conv2d_nhwc(dy.view(1, 1, m, cpad), wt.view(k, 1, cpad), ks=1, out_f32=True)
             dx = ops.col2im(dcol.view(n, ho, wo, k), h, wd, ks, stride, pad)
         return dx, dw, db, None, None, None, None
 
