@@ -151,7 +151,7 @@ def main():
     log = tr.read_log()
     if rank != 0:
         return
-    DOMINANT = "conv_pp_kernel<256, 256, 2, 4, 4, false, false>"
+    DOMINANT = "conv_pp_kernel<256, 256, 2, 4, 4, false, false, true>"
     per = {}
     for label, e0, e1, fl in timing:
         a = per.setdefault(label, [0.0, 0.0, 0])
@@ -160,6 +160,18 @@ def main():
     all_ms = sum(a[0] for a in per.values())
     all_flop = sum(a[1] for a in per.values())
     achieved = k_flop / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure is the one collected over
+    # this same command by tools/pmc_step_traffic.sh (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied)
+    # and committed under profiles/; null when the committed profile is for a different kernel
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_conv_pp_traffic.json")) as f:
+            tp = json.load(f)
+        if tp.get("kernel") == DOMINANT and args.batch == LOCAL_BATCH:
+            traffic = int(tp["hbm_MB_per_launch"] * 1e6)
+            traffic_src = "profiles/r1_conv_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, %d launches; FETCH_SIZE x2 per MI355X_MICROARCH.md)" % tp["launches_profiled"]
+    except (OSError, ValueError, KeyError):
+        pass
     out = {
         "metric": "images/sec DMVAE train step @256x256",
         "value": round(world * args.batch * args.steps / dt, 2),
@@ -174,7 +186,8 @@ def main():
                    "parallelism": f"dp{world}", "loss_after_run": round(log["rec_loss"], 5)},
         "roofline": {"bound": "mfma", "kernel": "dmvae_conv_pp::" + DOMINANT + " (conv forward / input-gradient, Cout >= 256; decoder + LPIPS trunk)",
                      "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                     "traffic_source": traffic_src,
                      "launches": k_n, "avg_launch_us": round(k_ms * 1e3 / max(1, k_n), 2),
                      "share_of_step": round(k_ms / (dt * 1e3), 3),
                      "all_conv_fwd_dgrad_launches": {"launches": len(timing), "achieved_TFLOPs": round(all_flop / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,

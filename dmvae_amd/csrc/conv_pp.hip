@@ -62,7 +62,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool OUT_F32>
+template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool OUT_F32, bool KO>
 __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__  // the host pass only needs the launch stub (hipcc drops the stub when it cannot digest the gfx950 body)
   constexpr int BM = TM / WM / 32, BP = TP / WP / 32;  // 32x32 accumulator blocks per wave
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   // all-zero pieces so that the vmcnt bookkeeping stays uniform (an out-of-range piece moves no memory)
   auto issue = [&](int slot) {
     const bool live = it < nK;
-    if (live && it_ch == 0) new_tap();
+    if (live && (KO || it_ch == 0)) new_tap();
     const unsigned soA = (unsigned)(it_tap * a.Cin + it_ch * 32) * 2u;
     const unsigned soB = soffB_tap + (unsigned)it_ch * 64u;
 #pragma unroll
@@ -196,7 +196,11 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     for (int p = 0; p < NPB; p++)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + TILE_A + (wave * NPB + p) * 1024), 16, live ? selB[p] : SENT, soB, 0, 0);
     it++;
-    if (++it_ch == nchunk) { it_ch = 0; it_tap++; }
+    if (KO) {  // channel chunk outer, tap inner: the nine taps of a chunk re-read (shifted) the same activation lines back to back
+      if (++it_tap == T) { it_tap = 0; it_ch++; }
+    } else {
+      if (++it_ch == nchunk) { it_ch = 0; it_tap++; }
+    }
   };
 
   // ---- persistent tile loop ---------------------------------------------------------------------------------------------
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #endif
 }
 
-template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32>
+template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32, bool KO>
 int launch(Args a, hipStream_t st) {
   a.ctiles = (a.Cout + TM - 1) / TM;
   a.total = ((a.M + TP - 1) / TP) * a.ctiles;
@@ -381,19 +385,30 @@ int launch(Args a, hipStream_t st) {
   constexpr int lds = ring > epi ? ring : epi;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32>), dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO>), dim3(grid), dim3(512), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
 
+// KO (last template argument) = K-tile order: false = tap outer / channel chunk inner, true = chunk outer / tap inner.  With the taps
+// inner the nine shifted re-reads of a 32-channel chunk follow each other within ~10 us and hit in the XCD's L2; with the taps outer each
+// tap streams the whole channel depth of the pixel tile (256 KB per CU at Cin = 512) and the next tap finds nothing of it left:
+// FETCH_SIZE per launch 9.0x vs 2.2x the compulsory bytes at 512->512 @128^2 (profiles/r1_conv_hbm_traffic.txt).  The folded-upsample
+// variant keeps the taps outer (its per-tap source selection is too costly to redo every K tile).
 template <bool UPS, bool F32>
 int pick(const Args& a, hipStream_t st) {
-  if (a.Cout <= 128) return launch<128, 512, 2, 4, 4, UPS, F32>(a, st);  // 160 KiB of LDS: the whole CU
-  return launch<256, 256, 2, 4, 4, UPS, F32>(a, st);
+  static const bool ko = [] { const char* e = getenv("DMVAE_PP_KORDER"); return e ? atoi(e) != 0 : true; }();
+  if constexpr (UPS) {
+    if (a.Cout <= 128) return launch<128, 512, 2, 4, 4, UPS, F32, false>(a, st);
+    return launch<256, 256, 2, 4, 4, UPS, F32, false>(a, st);
+  } else {
+    if (a.Cout <= 128) return ko ? launch<128, 512, 2, 4, 4, UPS, F32, true>(a, st) : launch<128, 512, 2, 4, 4, UPS, F32, false>(a, st);  // 160 KiB of LDS: the whole CU
+    return ko ? launch<256, 256, 2, 4, 4, UPS, F32, true>(a, st) : launch<256, 256, 2, 4, 4, UPS, F32, false>(a, st);
+  }
 }
 
 }  // namespace dmvae_conv_pp

@@ -7,6 +7,7 @@ Activations are NHWC bf16 ``[N, H, W, C]``.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -43,6 +44,7 @@ _WS = {}
 # bench.py sets this to a list to time the dominant kernel with HIP events on the launch stream:
 # entries are (name, start_event, end_event, algorithmic_flops)
 KERNEL_TIMING = None
+_PP_KORDER = "false" if os.environ.get("DMVAE_PP_KORDER", "1") == "0" else "true"   # csrc/conv_pp.hip::pick
 
 
 def workspace(nbytes: int, device, slot: str = "main") -> torch.Tensor:
@@ -102,8 +104,8 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
         # which kernel dmvae_conv2d_nhwc_fwd dispatched to (csrc/conv_pp.hip::dmvae_conv_pp_try), so that the bench's per-kernel
         # average can be checked against rocprofv3's per-kernel-name average
         if cin % 32 == 0 and cout >= 64 and cout % 8 == 0 and n * ho * wo >= 16384 and int(upsample) < 2 and stride != 2:
-            label = "conv_pp_kernel<%s, %s, %s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", "true" if upsample else "false",
-                                                     "true" if out_f32 else "false")
+            label = "conv_pp_kernel<%s, %s, %s, %s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", "true" if upsample else "false",
+                                                         "true" if out_f32 else "false", "false" if upsample else _PP_KORDER)
         else:
             label = "conv_fwd_kernel"
         timing.append((label, e0, e1, 2.0 * n * ho * wo * cout * cin * ks * ks))
