@@ -207,10 +207,19 @@ __global__ __launch_bounds__(256) void kl_moments_kernel(const float* __restrict
   float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
   const size_t stride = (size_t)gridDim.x * 32;
   size_t r = (size_t)blockIdx.x * 32 + rl;
+  // The gradient pass walks z from its end right after this one; the last ~192 MB are therefore read with plain loads (they stay in the
+  // 256 MB Infinity Cache for it), everything before with streaming loads (faster, and it would be evicted anyway).
+  const size_t keep_rows = ((size_t)192 << 20) / (MMD_D * sizeof(float));
+  const size_t nt_rows = R > keep_rows ? R - keep_rows : 0;
   for (; r + 3 * stride < R; r += 4 * stride) {  // four independent 16-B loads in flight per lane
     f32x4 v[4];
+    if (r + 3 * stride < nt_rows) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + (r + u * stride) * MMD_D + cq * 4));
+      for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + (r + u * stride) * MMD_D + cq * 4));
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const f32x4*>(z + (r + u * stride) * MMD_D + cq * 4);
+    }
 #pragma unroll
     for (int u = 0; u < 4; u++)
 #pragma unroll
@@ -432,7 +441,9 @@ __global__ __launch_bounds__(256) void kl_mmd_grad_kernel(const float* __restric
   const float* gxx = gpart;
   const float* gxy = gpart + (size_t)G * n * MMD_D;
   // blockDim * gridDim is a multiple of 8, so a thread always owns the same channel quad: hoist its moments
-  const int c4 = (int)(threadIdx.x & 7) * 4;
+  // The tensor is walked from its END: the moments pass has just streamed z front to back, so the tail is what the 256 MB Infinity
+  // Cache still holds; total4 is a multiple of 8, so thread t then owns channel quad 7 - (t & 7) throughout.
+  const int c4 = (7 - (int)(threadIdx.x & 7)) * 4;
   float mu[4], slope[4];
 #pragma unroll
   for (int e = 0; e < 4; e++) {
@@ -440,7 +451,8 @@ __global__ __launch_bounds__(256) void kl_mmd_grad_kernel(const float* __restric
     slope[e] = 1.f - 1.f / stats[(c4 + e) * 2 + 1];
   }
   const float kscale = w_kl / rows / (float)MMD_D;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total4; j += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = total4 - 1 - j;
     const f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z) + i);
     f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
     if (gpart) { a = reinterpret_cast<const f32x4*>(gxx)[i]; b = reinterpret_cast<const f32x4*>(gxy)[i]; }
