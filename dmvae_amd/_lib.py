@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdmvae_hip.so")
 class ConvDesc(Structure):
     """struct dmvae_conv_desc (include/dmvae_hip.h)."""
     _fields_ = [("n", c_int32), ("h", c_int32), ("w", c_int32), ("cin", c_int32), ("cout", c_int32),
-                ("ks", c_int32), ("upsample", c_int32), ("act", c_int32), ("out_f32", c_int32), ("stride", c_int32)]
+                ("ks", c_int32), ("upsample", c_int32), ("act", c_int32), ("out_f32", c_int32), ("stride", c_int32), ("transposed", c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/dmvae_hip.h declares

@@ -26,7 +26,11 @@ struct ConvArgs {
   const bf16* res;    // [N, Ho, Wo, Cout] or null
   void* y;            // [N, Ho, Wo, Cout] bf16 or f32
   int N, Hi, Wi, Cin, Ho, Wo, Cout;
-  int ks, ups, act, M, ctiles, korder;
+  int ks, act, M, ctiles, korder;
+  // gather: tap (ky, kx) in [0, ks)^2 of output pixel (y, x) reads t = (y*so - pd + ky, x*so - pd + kx); sd = 1: source pixel t;
+  // sd = 2, fl = 1: source t >> 1 (nearest x2 upsample folded in); sd = 2, fl = 0: source t / 2 for even t only (zero insertion: the
+  // input gradient of a stride-2 conv); anything outside [0, Hi) x [0, Wi) reads zero
+  int so, pd, sd, fl;
   long long x_bs, w_bs, y_bs;  // element strides per blockIdx.z (batched GEMM); 0 otherwise
 };
 
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
   auto stage = [&](int s, int buf) {
     // channel chunk outer, tap inner: the 9 taps re-read (shifted) the same activation lines back to back -> L2 hits
     const int ch = a.korder ? s / T : s % nchunk, tap = a.korder ? s - ch * T : s / nchunk;
-    const int ky = a.ks == 3 ? tap / 3 - 1 : 0, kx = a.ks == 3 ? tap % 3 - 1 : 0;
+    const int ky = tap / a.ks, kx = tap - ky * a.ks;
     char* wt = smem + buf * 2 * G::TILEB;
     char* pt = wt + G::TILEB;
 #pragma unroll
@@ -100,18 +104,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     for (int j = 0; j < G::LPW; j++) {
       const int q = wave * G::LPW + j;
       const bf16* src = zero;
-      int iy = prow_y[j] + ky, ix = prow_x[j] + kx;
-      bool ok = prow_n[j] >= 0 && iy >= 0 && iy < a.Ho && ix >= 0 && ix < a.Wo;
-      if (a.ups == 3) {  // stride 2 over the (0,1,0,1)-padded input: tap (ky+1, kx+1) of output pixel (y, x) reads (2y+ky+1, 2x+kx+1)
-        iy += prow_y[j] + 1; ix += prow_x[j] + 1;
-        ok = prow_n[j] >= 0 && iy < a.Hi && ix < a.Wi;
-      } else if (a.ups == 2) {  // zero-insertion x2: only odd positions carry data
-        ok = ok && (iy & 1) && (ix & 1);
+      int iy = prow_y[j] * a.so - a.pd + ky, ix = prow_x[j] * a.so - a.pd + kx;
+      bool ok = prow_n[j] >= 0 && iy >= 0 && ix >= 0;
+      if (a.sd == 2) {
+        if (!a.fl) ok = ok && !((iy | ix) & 1);
+        iy >>= 1; ix >>= 1;
       }
-      if (ok) {
-        if (a.ups == 1 || a.ups == 2) { iy >>= 1; ix >>= 1; }
-        src = a.x + ((size_t)(prow_n[j] * a.Hi + iy) * a.Wi + ix) * a.Cin + ch * BK + csrc[j];
-      }
+      if (ok && iy < a.Hi && ix < a.Wi) src = a.x + ((size_t)(prow_n[j] * a.Hi + iy) * a.Wi + ix) * a.Cin + ch * BK + csrc[j];
       __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(pt + q * 1024), 16, 0, 0);
     }
   };
@@ -235,11 +234,50 @@ using namespace dmvae_conv_fwd;
 int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void* residual, void* y, const dmvae_conv_desc* d,
                       hipStream_t stream);  // conv_pp.hip; returns 1 when it declines the shape
 
+// Output size and gather parameters (see ConvArgs) of a conv descriptor; shared with conv_wgrad.hip.  Returns non-zero for combinations
+// that are not built.
+//   ks 1                      : so 1, pd 0
+//   ks 3, stride 1            : so 1, pd 1  [upsample 1: nearest x2, sd 2 fl 1, output 2h x 2w]
+//   ks 3, stride 2            : Downsample conv, input padded bottom/right only (flux_ae.py:85-95): so 2, pd 0, output h/2 x w/2
+//   ks 3, upsample 2          : its input gradient = zero insertion: so 1, pd 2, sd 2, output 2h x 2w   (also: ks 3, stride 2, transposed)
+//   ks 4, stride 1|2          : PatchGAN convs, padding 1 (patchgan.py:125-147): so = stride, pd 1, output (h + 2 - 4)/stride + 1
+//   ks 4, stride 1|2, transposed : their input gradients: so 1, pd 2, sd = stride, output (h - 1)*stride + 2
+int dmvae_conv_geometry(const dmvae_conv_desc* d, int* ho, int* wo, int* so, int* pd, int* sd, int* fl) {
+  const int stride = d->stride == 2 ? 2 : 1;
+  if (d->stride < 0 || d->stride > 2 || d->upsample < 0 || d->upsample > 2 || d->transposed < 0 || d->transposed > 1) return 1;
+  *so = 1; *pd = 0; *sd = 1; *fl = 0; *ho = d->h; *wo = d->w;
+  if (d->ks == 1) return (stride != 1 || d->upsample || d->transposed) ? 1 : 0;
+  if (d->ks == 3) {
+    *pd = 1;
+    if (d->transposed) {
+      if (stride != 2 || d->upsample) return 1;
+      *pd = 2; *sd = 2; *ho = 2 * d->h; *wo = 2 * d->w;
+      return 0;
+    }
+    if (stride == 2) {
+      if (d->upsample || d->h % 2 || d->w % 2) return 1;
+      *so = 2; *pd = 0; *ho = d->h / 2; *wo = d->w / 2;
+      return 0;
+    }
+    if (d->upsample == 1) { *sd = 2; *fl = 1; *ho = 2 * d->h; *wo = 2 * d->w; }
+    if (d->upsample == 2) { *pd = 2; *sd = 2; *ho = 2 * d->h; *wo = 2 * d->w; }
+    return 0;
+  }
+  if (d->ks == 4) {
+    if (d->upsample) return 1;
+    if (d->transposed) { *pd = 2; *sd = stride; *ho = (d->h - 1) * stride + 2; *wo = (d->w - 1) * stride + 2; return 0; }
+    if (d->h + 2 < 4 || d->w + 2 < 4) return 1;
+    *so = stride; *pd = 1; *ho = (d->h + 2 - 4) / stride + 1; *wo = (d->w + 2 - 4) / stride + 1;
+    return 0;
+  }
+  return 1;
+}
+
 
 extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* bias, const void* residual,
                                      void* y, const dmvae_conv_desc* d, hipStream_t stream) {
   DMVAE_CHECK_ARG(x && w && y && d, "conv2d_nhwc_fwd: null pointer");
-  DMVAE_CHECK_ARG(d->ks == 1 || d->ks == 3, "conv2d_nhwc_fwd: ks must be 1 or 3 (got %d)", d->ks);
+  DMVAE_CHECK_ARG(d->ks == 1 || d->ks == 3 || d->ks == 4, "conv2d_nhwc_fwd: ks must be 1, 3 or 4 (got %d)", d->ks);
   DMVAE_CHECK_ARG(d->cin > 0 && d->cin % 32 == 0, "conv2d_nhwc_fwd: Cin must be a positive multiple of 32 (got %d)", d->cin);
   DMVAE_CHECK_ARG(d->cout > 0 && d->cout % 4 == 0, "conv2d_nhwc_fwd: Cout must be a positive multiple of 4 (got %d)", d->cout);
   DMVAE_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0, "conv2d_nhwc_fwd: empty shape");
@@ -251,12 +289,13 @@ extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* b
   ConvArgs a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.res = (const bf16*)residual; a.y = y;
   a.N = d->n; a.Hi = d->h; a.Wi = d->w; a.Cin = d->cin; a.Cout = d->cout;
-  DMVAE_CHECK_ARG(d->upsample >= 0 && d->upsample <= 2 && (d->stride == 0 || d->stride == 1 || d->stride == 2),
-                  "conv2d_nhwc_fwd: bad upsample (%d) / stride (%d)", d->upsample, d->stride);
-  DMVAE_CHECK_ARG(d->stride != 2 || (d->ks == 3 && !d->upsample && d->h % 2 == 0 && d->w % 2 == 0),
-                  "conv2d_nhwc_fwd: stride 2 needs ks=3, no upsample, even h and w");
-  a.ups = d->stride == 2 ? 3 : d->upsample;   // gather mode: 0 plain, 1 nearest x2, 2 zero-insertion x2, 3 stride 2
-  a.Ho = a.ups == 3 ? d->h / 2 : (a.ups ? 2 * d->h : d->h); a.Wo = a.ups == 3 ? d->w / 2 : (a.ups ? 2 * d->w : d->w);
+  {
+    int ho, wo;
+    DMVAE_CHECK_ARG(dmvae_conv_geometry(d, &ho, &wo, &a.so, &a.pd, &a.sd, &a.fl) == 0,
+                    "conv2d_nhwc_fwd: unsupported combination ks=%d stride=%d upsample=%d transposed=%d h=%d w=%d", d->ks, d->stride,
+                    d->upsample, d->transposed, d->h, d->w);
+    a.Ho = ho; a.Wo = wo;
+  }
   a.ks = d->ks; a.act = d->act;
   a.x_bs = a.w_bs = a.y_bs = 0;
   const long long M = (long long)a.N * a.Ho * a.Wo;
@@ -276,7 +315,7 @@ extern "C" int dmvae_gemm_nt_batched(const void* A, const void* B, const void* b
                   "gemm_nt_batched: need N%%4==0, K%%32==0 (M=%d N=%d K=%d batch=%d)", M, N, K, batch);
   ConvArgs a;
   a.x = (const bf16*)A; a.w = (const bf16*)B; a.bias = (const float*)bias; a.res = (const bf16*)R; a.y = C;
-  a.N = 1; a.Hi = 1; a.Wi = M; a.Ho = 1; a.Wo = M; a.Cin = K; a.Cout = N; a.ks = 1; a.ups = 0; a.act = act; a.M = M;
+  a.N = 1; a.Hi = 1; a.Wi = M; a.Ho = 1; a.Wo = M; a.Cin = K; a.Cout = N; a.ks = 1; a.so = 1; a.pd = 0; a.sd = 1; a.fl = 0; a.act = act; a.M = M;
   a.x_bs = a_bs; a.w_bs = b_bs; a.y_bs = c_bs;
   if (K % 64 == 0) return out_f32 ? launch<64, true>(a, stream, batch) : launch<64, false>(a, stream, batch);
   return out_f32 ? launch<32, true>(a, stream, batch) : launch<32, false>(a, stream, batch);

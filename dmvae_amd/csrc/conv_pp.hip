@@ -422,7 +422,7 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
   using namespace dmvae_conv_pp;
   static const bool disabled = [] { const char* e = getenv("DMVAE_CONV_V1"); return e && atoi(e) != 0; }();
   if (disabled) return 1;
-  if (d->upsample == 2 || d->stride == 2) return 1;  // zero-insertion / stride-2 gathers: the general kernel (conv_fwd.hip)
+  if (d->upsample == 2 || d->stride == 2 || d->ks == 4 || d->transposed) return 1;  // strided / zero-insertion / 4x4 gathers: the general kernel (conv_fwd.hip)
   const int ups = d->upsample ? 1 : 0;
   const long long M = (long long)d->n * d->h * d->w * (ups ? 4 : 1);
   const long long xbytes = (long long)d->n * d->h * d->w * d->cin * 2;

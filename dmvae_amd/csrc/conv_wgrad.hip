@@ -25,7 +25,8 @@ struct WgradArgs {
   const bf16* a;   // [N, Hi, Wi, Cin]
   float* slab;     // [splits][Cout][T][Cin]
   int N, Hi, Wi, Cin, Ho, Wo, Cout;
-  int ks, ups, M, kchunk;  // kchunk: pixels per split (multiple of 64)
+  int ks, M, kchunk;       // kchunk: pixels per split (multiple of 64)
+  int so, pd, sd, fl;      // gather of the conv being differentiated, as in conv_fwd.hip::ConvArgs (forward kinds only)
   int ntiles;              // (cout-tile, cin-tile, tap) combinations per pixel range
   long long dy_bs, a_bs, slab_bs;  // per blockIdx.z element strides (batched TN GEMM); 0 otherwise
 };
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   const int tap = t % T; t /= T;
   const int ci0 = (t % ci_tiles) * 128;
   const int co0 = (t / ci_tiles) * 128;
-  const int ky = a.ks == 3 ? tap / 3 - 1 : 0, kx = a.ks == 3 ? tap % 3 - 1 : 0;
+  const int ky = tap / a.ks, kx = tap - ky * a.ks;
   const int k0 = split * a.kchunk;
   const int k1 = min(k0 + a.kchunk, a.M);
   const int S = (k1 - k0 + BKP - 1) / BKP;
@@ -93,16 +94,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
       const int q = wave * 4 + j;
       const int p = k0 + s * BKP + q * 4 + (lane >> 4);
       const bf16* src = zero;
-      int iy = py[j] + ky, ix = px[j] + kx;
-      bool ok = iy >= 0 && iy < a.Ho && ix >= 0 && ix < a.Wo;
-      if (a.ups == 3) {  // stride-2 Downsample conv: output pixel (y, x), tap (ky+1, kx+1) pairs with input (2y+ky+1, 2x+kx+1)
-        iy += py[j] + 1; ix += px[j] + 1;
-        ok = iy < a.Hi && ix < a.Wi;
-      }
-      if (p < k1 && ci_ok[j] && ok) {
-        if (a.ups == 1) { iy >>= 1; ix >>= 1; }
-        src = a.a + ((size_t)(pn[j] * a.Hi + iy) * a.Wi + ix) * a.Cin + ci0 + clog[j];
-      }
+      int iy = py[j] * a.so - a.pd + ky, ix = px[j] * a.so - a.pd + kx;
+      bool ok = p < k1 && ci_ok[j] && iy >= 0 && ix >= 0;
+      if (a.sd == 2) { iy >>= 1; ix >>= 1; }   // nearest x2 upsample folded in (the only sd = 2 kind that has a weight gradient here)
+      if (ok && iy < a.Hi && ix < a.Wi) src = a.a + ((size_t)(pn[j] * a.Hi + iy) * a.Wi + ix) * a.Cin + ci0 + clog[j];
       __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(at + q * 1024), 16, 0, 0);
       // advance this row by one K step (64 pixels)
       px[j] += BKP;
@@ -257,6 +252,7 @@ using namespace dmvae_conv_wgrad;
 
 // conv_wgrad_pp.hip: the ping-pong kernel for the large layers (plan returns 0 when it does not cover the shape)
 int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_out, int* cfg_out);
+int dmvae_conv_geometry(const dmvae_conv_desc* d, int* ho, int* wo, int* so, int* pd, int* sd, int* fl);  // conv_fwd.hip
 int dmvae_wgrad_pp_launch(const void* dy, const void* act, float* slab, float* bslab, const dmvae_conv_desc* d, int splits, int kchunk,
                           int cfg, hipStream_t stream);
 
@@ -268,7 +264,9 @@ extern "C" size_t dmvae_conv2d_nhwc_wgrad_workspace(const dmvae_conv_desc* d) {
     if ((d->ks == 1 || d->ks == 3) && dmvae_wgrad_pp_plan(d, &sp, &kc, &cfg))
       return (size_t)sp * d->cout * T * d->cin * sizeof(float) + (size_t)4096 * d->cout * sizeof(float);  // + [splits*ntiles <= 4096][cout] bias partials
   }
-  const long long M = d->stride == 2 ? (long long)d->n * (d->h / 2) * (d->w / 2) : (long long)d->n * d->h * d->w * (d->upsample ? 4 : 1);
+  int ho = 0, wo = 0, g0, g1, g2, g3;
+  if (dmvae_conv_geometry(d, &ho, &wo, &g0, &g1, &g2, &g3)) return 0;
+  const long long M = (long long)d->n * ho * wo;
   const int tiles = ((d->cout + 127) / 128) * ((d->cin + 127) / 128) * T;
   const int splits = pick_splits((int)M, tiles);
   size_t slab = (size_t)splits * d->cout * T * d->cin * sizeof(float);
@@ -280,18 +278,16 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
                                        size_t workspace_bytes, const dmvae_conv_desc* d, int accumulate,
                                        hipStream_t stream) {
   DMVAE_CHECK_ARG(dy && a && dw && d && workspace, "conv2d_nhwc_wgrad: null pointer");
-  DMVAE_CHECK_ARG(d->ks == 1 || d->ks == 3, "conv2d_nhwc_wgrad: ks must be 1 or 3");
+  DMVAE_CHECK_ARG(d->ks == 1 || d->ks == 3 || d->ks == 4, "conv2d_nhwc_wgrad: ks must be 1, 3 or 4");
   DMVAE_CHECK_ARG(d->cin > 0 && d->cin % 8 == 0 && d->cout > 0 && d->cout % 8 == 0,
                   "conv2d_nhwc_wgrad: Cin and Cout must be positive multiples of 8 (got %d, %d)", d->cin, d->cout);
   DMVAE_CHECK_ARG(workspace_bytes >= dmvae_conv2d_nhwc_wgrad_workspace(d), "conv2d_nhwc_wgrad: workspace too small");
   WgradArgs w;
   w.dy = (const bf16*)dy; w.a = (const bf16*)a; w.slab = (float*)workspace;
   w.N = d->n; w.Hi = d->h; w.Wi = d->w; w.Cin = d->cin; w.Cout = d->cout; w.ks = d->ks;
-  DMVAE_CHECK_ARG(d->upsample == 0 || d->upsample == 1, "conv2d_nhwc_wgrad: upsample must be 0 or 1");
-  DMVAE_CHECK_ARG(d->stride != 2 || (d->ks == 3 && !d->upsample && d->h % 2 == 0 && d->w % 2 == 0),
-                  "conv2d_nhwc_wgrad: stride 2 needs ks=3, no upsample, even h and w");
-  w.ups = d->stride == 2 ? 3 : d->upsample;   // gather mode: 0 plain, 1 nearest x2, 3 stride 2
-  w.Ho = w.ups == 3 ? d->h / 2 : (w.ups ? 2 * d->h : d->h); w.Wo = w.ups == 3 ? d->w / 2 : (w.ups ? 2 * d->w : d->w);
+  DMVAE_CHECK_ARG(!d->transposed && d->upsample != 2 && dmvae_conv_geometry(d, &w.Ho, &w.Wo, &w.so, &w.pd, &w.sd, &w.fl) == 0,
+                  "conv2d_nhwc_wgrad: unsupported combination ks=%d stride=%d upsample=%d transposed=%d h=%d w=%d", d->ks, d->stride,
+                  d->upsample, d->transposed, d->h, d->w);
   const long long M = (long long)w.N * w.Ho * w.Wo;
   DMVAE_CHECK_ARG(M > 0 && M < (1ll << 31) / 4, "conv2d_nhwc_wgrad: bad pixel count");
   w.M = (int)M;
@@ -361,7 +357,7 @@ extern "C" int dmvae_gemm_tn_batched(const void* A, const void* B, void* C, void
   DMVAE_CHECK_ARG(workspace_bytes >= dmvae_gemm_tn_batched_workspace(M, N, K, batch), "gemm_tn_batched: workspace too small");
   WgradArgs w;
   w.dy = (const bf16*)A; w.a = (const bf16*)B; w.slab = (float*)workspace;
-  w.N = 1; w.Hi = 1; w.Wi = K; w.Ho = 1; w.Wo = K; w.Cin = N; w.Cout = M; w.ks = 1; w.ups = 0; w.M = K;
+  w.N = 1; w.Hi = 1; w.Wi = K; w.Ho = 1; w.Wo = K; w.Cin = N; w.Cout = M; w.ks = 1; w.so = 1; w.pd = 0; w.sd = 1; w.fl = 0; w.M = K;
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   int splits = pick_splits(K, tiles * batch);
   w.kchunk = (((K + splits - 1) / splits) + BKP - 1) / BKP * BKP;

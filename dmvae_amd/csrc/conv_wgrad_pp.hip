@@ -306,7 +306,7 @@ int launch(const Args& a, int splits, hipStream_t st) {
 int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_out, int* cfg_out) {
   static const bool disabled = [] { const char* e = getenv("DMVAE_WGRAD_V1"); return e && atoi(e) != 0; }();
   if (disabled) return 0;
-  if (d->stride == 2 || d->upsample == 2) return 0;  // stride-2 gather: the general kernel (conv_wgrad.hip)
+  if (d->stride == 2 || d->upsample == 2 || d->ks == 4 || d->transposed) return 0;  // strided / 4x4 gathers: the general kernel (conv_wgrad.hip)
   const int ups = d->upsample ? 1 : 0;
   const int wo = ups ? 2 * d->w : d->w;
   const long long M = (long long)d->n * d->h * d->w * (ups ? 4 : 1);

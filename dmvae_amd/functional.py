@@ -250,58 +250,49 @@ class ImageToNhwcFn(torch.autograd.Function):
         return ops.nhwc_to_nchw_f32(_c(dy), ctx.c), None
 
 
-class ConvIm2colFn(torch.autograd.Function):
-    """nn.Conv2d(kernel k, stride s, padding p) on NHWC bf16 as im2col + GEMM (models/patchgan.py:125-147: k=4, s=2|1, p=1).
-    x: [N,H,W,Cp] with Cp >= w.shape[1] zero-padded channels; act: ops.ACT_NONE | ops.ACT_LEAKY fused into the GEMM epilogue.
-    out_f32: logits layer -- the single output channel is computed in a 4-row padded GEMM and returned as [N,Ho,Wo,1] f32."""
+class ConvK4Fn(torch.autograd.Function):
+    """nn.Conv2d(kernel 4, stride 1|2, padding 1) on NHWC bf16 (models/patchgan.py:125-147) as a strided 16-tap gather in the implicit-GEMM
+    conv kernel -- no im2col tensor.  x: [N,H,W,Cp] with Cp >= w.shape[1] zero-padded channels (Cp % 32 == 0); act: ops.ACT_NONE |
+    ops.ACT_LEAKY fused into the epilogue.  out_f32: logits layer -- the single output channel is computed with 4 padded rows and
+    returned as [N,Ho,Wo,1] f32.  Backward: weight gradient from the same gather (desc.stride), input gradient as the transposed gather
+    (desc.transposed; dy's channels zero-padded to a multiple of 32 as the reduction dimension)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, out_f32):
-        cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
-        n, h, wd, cp = x.shape
-        col = ops.im2col(x, ks, stride, pad)
-        ho, wo, k = col.shape[1], col.shape[2], col.shape[3]
-        m = n * ho * wo
+    def forward(ctx, x, w, b, stride, act, out_f32):
+        cout, cin = w.shape[0], w.shape[1]
+        cp = x.shape[-1]
         rows = cout if cout % 4 == 0 else (cout + 3) // 4 * 4
-        wp = packed(w, False, rows_pad=rows, cols_pad=cp).view(rows, 1, k)
         bp = b
         if b is not None and rows != cout:
             bp = torch.zeros(rows, dtype=f32, device=x.device)
             bp[:cout] = b
-        y = ops.conv2d_nhwc(col.view(1, 1, m, k), wp, bp, ks=1, act=act, out_f32=out_f32).view(n, ho, wo, rows)
+        y = ops.conv2d_nhwc(x, packed(w, False, rows_pad=rows, cols_pad=cp), bp, ks=4, stride=stride, act=act, out_f32=out_f32)
         if rows != cout:
             y = y[..., :cout].contiguous()
         ctx.save_for_backward(x, w, y if act == ops.ACT_LEAKY else None)
-        ctx.cfg = (stride, pad, act, b)
+        ctx.cfg = (stride, act, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
-        stride, pad, act, b = ctx.cfg
-        cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+        stride, act, b = ctx.cfg
+        cout, cin = w.shape[0], w.shape[1]
         n, h, wd, cp = x.shape
-        ho, wo = dy.shape[1], dy.shape[2]
-        m, k = n * ho * wo, ks * ks * cp
         dy = _c(dy)
         if act == ops.ACT_LEAKY:
             dy = ops.leaky_relu_bwd(dy, y)
-        cpad = cout if cout % 32 == 0 else (cout + 31) // 32 * 32     # dy is the K operand of both gradient GEMMs
+        cpad = cout if cout % 32 == 0 else (cout + 31) // 32 * 32
         if cpad != cout or dy.dtype != bf16:
-            dyp = torch.zeros(n, ho, wo, cpad, dtype=bf16, device=dy.device)
+            dyp = torch.zeros(dy.shape[0], dy.shape[1], dy.shape[2], cpad, dtype=bf16, device=dy.device)
             dyp[..., :cout] = dy
             dy = dyp
-        col = ops.im2col(x, ks, stride, pad)                             # recomputed: 16x the activation, not worth keeping
-        dwp, dbp = ops.conv2d_nhwc_wgrad(dy.view(1, 1, m, cpad), col.view(1, 1, m, k), 1, need_bias=b is not None)
-        del col
-        dw = dwp.view(cpad, ks * ks, cp)[:cout, :, :cin].permute(0, 2, 1).reshape(cout, cin, ks, ks)
-        dst = _dst(w)
-        if dst is not None:
-            dst.copy_(dw)
-            dw = dst
+        dwp, dbp = ops.conv2d_nhwc_wgrad(dy, x, 4, stride=stride, need_bias=b is not None)       # [cpad, cp, 4, 4]
+        dw, db = _dst(w), None
+        if dw is not None:
+            dw.copy_(dwp[:cout, :cin])
         else:
-            dw = dw.contiguous()
-        db = None
+            dw = dwp[:cout, :cin].contiguous()
         if b is not None:
             db = _dst(b)
             if db is not None:
@@ -310,12 +301,12 @@ class ConvIm2colFn(torch.autograd.Function):
                 db = dbp[:cout].contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            wt = packed(w, False, rows_pad=cpad, cols_pad=cp, transposed=True)          # [k, cpad]
-            # f32 result: the taps are summed before the one bf16 rounding.  Through the conv entry point (1x1) so that large
-            # shapes get the ping-pong kernel.
-            dcol = ops.conv2d_nhwc(dy.view(1, 1, m, cpad), wt.view(k, 1, cpad), ks=1, out_f32=True)
-            dx = ops.col2im(dcol.view(n, ho, wo, k), h, wd, ks, stride, pad)
-        return dx, dw, db, None, None, None, None
+            dx = ops.conv2d_nhwc(dy, packed(w, True, rows_pad=cp, cols_pad=cpad), ks=4, stride=stride, transposed=True)
+            if dx.shape[1] != h or dx.shape[2] != wd:      # (h - 2) % stride != 0: the conv never read the last row / column
+                full = torch.zeros_like(x)
+                full[:, :dx.shape[1], :dx.shape[2]] = dx[:, :h, :wd]
+                dx = full
+        return dx, dw, db, None, None, None
 
 
 class BatchNormActFn(torch.autograd.Function):

@@ -2,8 +2,8 @@
 same constructor, ``state_dict`` keys (``main.{0,2,3,5,6,8,9,11}.*`` incl. the BatchNorm running statistics) and
 ``forward(input, grad_ckpt=False) -> [B, 1, 30, 30]`` logits for 256x256 inputs.
 
-The five 4x4 convolutions (stride 2,2,2,1,1, padding 1) run as im2col + the MFMA GEMM path of the conv kernel with the bias
-and the first LeakyReLU(0.2) in its epilogue; BatchNorm / SyncBatchNorm + LeakyReLU run on the GroupNorm kernels (one
+The five 4x4 convolutions (stride 2,2,2,1,1, padding 1) are strided 16-tap gathers in the implicit-GEMM conv kernel (forward, weight
+gradient, and the transposed gather for the input gradient) with the bias and the first LeakyReLU(0.2) in the epilogue; BatchNorm / SyncBatchNorm + LeakyReLU run on the GroupNorm kernels (one
 "image" of N*H*W pixels, one channel per group) with the cross-rank combination of the statistics done the way
 torch.nn.SyncBatchNorm does it (all-gather of per-rank mean / var / count forward, all-reduce of the two per-channel sums
 backward).  ``ActNorm`` (reference :5-87) is never enabled by the reference's scripts (`use_actnorm=False` everywhere) and is
@@ -84,7 +84,7 @@ class NLayerDiscriminator(nn.Module):
 
     def forward(self, input, grad_ckpt=False):
         mods = list(self.main)
-        h = Fn.ImageToNhwcFn.apply(input, max(8, (input.shape[1] + 7) // 8 * 8))
+        h = Fn.ImageToNhwcFn.apply(input, (input.shape[1] + 31) // 32 * 32)      # channels zero-padded to the conv kernel's 32-channel K step
         i = 0
         while i < len(mods):
             conv = mods[i]
@@ -92,8 +92,8 @@ class NLayerDiscriminator(nn.Module):
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             last = nxt is None
             fuse_act = isinstance(nxt, nn.LeakyReLU)
-            h = Fn.ConvIm2colFn.apply(h, conv.weight, conv.bias, conv.stride[0], conv.padding[0],
-                                      ops.ACT_LEAKY if fuse_act else ops.ACT_NONE, last)
+            assert conv.kernel_size == (4, 4) and conv.padding == (1, 1) and conv.stride[0] in (1, 2)
+            h = Fn.ConvK4Fn.apply(h, conv.weight, conv.bias, conv.stride[0], ops.ACT_LEAKY if fuse_act else ops.ACT_NONE, last)
             i += 2 if fuse_act else 1
             if isinstance(nxt, nn.modules.batchnorm._BatchNorm):
                 act = 2 if isinstance(mods[i + 1] if i + 1 < len(mods) else None, nn.LeakyReLU) else 0

@@ -73,25 +73,35 @@ def pack_conv_weight(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0
     return out
 
 
+def conv_out_size(h: int, w: int, ks: int, upsample: int = 0, stride: int = 1, transposed: bool = False):
+    """Output height / width of dmvae_conv2d_nhwc_fwd for a descriptor (csrc/conv_fwd.hip::dmvae_conv_geometry)."""
+    if ks == 4:
+        return ((h - 1) * stride + 2, (w - 1) * stride + 2) if transposed else ((h - 2) // stride + 1, (w - 2) // stride + 1)
+    if upsample or transposed:
+        return 2 * h, 2 * w
+    return (h // 2, w // 2) if stride == 2 else (h, w)
+
+
 def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None, ks: int = 3, upsample=False, act: int = ACT_NONE,
-                out_f32: bool = False, stride: int = 1) -> torch.Tensor:
+                out_f32: bool = False, stride: int = 1, transposed: bool = False) -> torch.Tensor:
     """y = act(conv(x, w) + bias + residual); x [N,H,W,Cin] bf16, w_packed [Cout, ks*ks, Cin] bf16.
-    upsample: False/0 none, True/1 nearest x2 folded into the gather, 2 zero-insertion x2 (dgrad of the stride-2 conv);
-    stride 2: the Downsample conv (input padded bottom/right by one, flux_ae.py:85-95)."""
+    upsample: False/0 none, True/1 nearest x2 folded into the gather, 2 zero-insertion x2 (dgrad of the stride-2 3x3 conv);
+    stride 2 with ks 3: the Downsample conv (input padded bottom/right by one, flux_ae.py:85-95); ks 4 (stride 1 | 2, padding 1): the
+    PatchGAN convs (patchgan.py:125-147); transposed: the input gradient of the ks-4 conv with that stride (w_packed packed for_dgrad)."""
     x = _req(x, bf16, "x")
     w_packed = _req(w_packed, bf16, "w_packed")
     n, h, w_, cin = x.shape
     cout = w_packed.shape[0]
     assert w_packed.shape[1] == ks * ks and w_packed.shape[2] == cin, (w_packed.shape, ks, cin)
-    ho, wo = (2 * h, 2 * w_) if upsample else ((h // 2, w_ // 2) if stride == 2 else (h, w_))
+    ho, wo = conv_out_size(h, w_, ks, int(upsample), stride, transposed)
     y = torch.empty(n, ho, wo, cout, dtype=f32 if out_f32 else bf16, device=x.device)
     if bias is not None:
         _req(bias, f32, "bias")
     if residual is not None:
         _req(residual, bf16, "residual")
         assert residual.shape == y.shape
-    d = ConvDesc(n, h, w_, cin, cout, ks, int(upsample), act, int(out_f32), stride)
+    d = ConvDesc(n, h, w_, cin, cout, ks, int(upsample), act, int(out_f32), stride, int(transposed))
     timing = KERNEL_TIMING
     if timing is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -103,7 +113,7 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
         e1.record()
         # which kernel dmvae_conv2d_nhwc_fwd dispatched to (csrc/conv_pp.hip::dmvae_conv_pp_try), so that the bench's per-kernel
         # average can be checked against rocprofv3's per-kernel-name average
-        if cin % 32 == 0 and cout >= 64 and cout % 8 == 0 and n * ho * wo >= 16384 and int(upsample) < 2 and stride != 2:
+        if cin % 32 == 0 and cout >= 64 and cout % 8 == 0 and n * ho * wo >= 16384 and int(upsample) < 2 and stride != 2 and ks != 4 and not transposed:
             label = "conv_pp_kernel<%s, %s, %s, %s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", "true" if upsample else "false",
                                                          "true" if out_f32 else "false", "false" if upsample else _PP_KORDER)
         else:
@@ -120,7 +130,7 @@ def conv2d_nhwc_wgrad(dy: torch.Tensor, a: torch.Tensor, ks: int, upsample: bool
     a = _req(a, bf16, "a")
     n, h, w_, cin = a.shape
     cout = dy.shape[-1]
-    d = ConvDesc(n, h, w_, cin, cout, ks, int(upsample), 0, 0, stride)
+    d = ConvDesc(n, h, w_, cin, cout, ks, int(upsample), 0, 0, stride, 0)
     L = _lib.lib()
     wsb = L.dmvae_conv2d_nhwc_wgrad_workspace(ctypes.byref(d))
     ws = workspace(wsb, a.device)

@@ -36,7 +36,8 @@ int dmvae_abi_version(void);
 typedef struct dmvae_conv_desc {
   int32_t n, h, w;   /* input batch, height, width (pre-upsample) */
   int32_t cin, cout;
-  int32_t ks;        /* 1 or 3 (3 => padding 1, stride 1 unless `stride` says otherwise) */
+  int32_t ks;        /* 1, 3 (padding 1, stride 1 unless `stride` says otherwise) or 4 (padding 1, stride 1 or 2: the PatchGAN
+                        convs, models/patchgan.py:125-147; y is [n, (h-2)/stride+1, (w-2)/stride+1, cout]) */
   int32_t upsample;  /* 1: nearest x2 of the input folded into the gather (flux_ae.py:103-107);
                         2: zero-insertion x2 (input pixel (y,x) sits at output position (2y+1,2x+1), zeros elsewhere): with
                            for_dgrad-packed weights this is the input gradient of the stride-2 Downsample conv below */
@@ -46,6 +47,9 @@ typedef struct dmvae_conv_desc {
   int32_t out_f32;   /* 1: y is float32 (parity / final layers), else bf16 */
   int32_t stride;    /* 0 or 1: stride 1.  2: the Downsample conv of flux_ae.py:85-95 -- input zero-padded by one row/column at the
                         bottom/right only, 3x3, stride 2, no other padding: y is [n, h/2, w/2, cout] (h, w even; ks=3, upsample=0) */
+  int32_t transposed;/* 1 (ks 4, or ks 3 with stride 2): x is the OUTPUT gradient [n,h,w,cin] of the conv described by (ks, stride) and y its
+                        input gradient [n, (h-1)*stride+2, ..., cout] (ks 4) / [n, 2h, 2w, cout] (ks 3); weights packed with for_dgrad=1.
+                        Forward entry point only. */
 } dmvae_conv_desc;
 
 /* y[n,ho,wo,cout] = act( conv(x, w) + bias + residual ).

@@ -94,6 +94,54 @@ def test_conv_stride2_fwd_dgrad_wgrad(case):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)          # deterministic split-K
 
 
+K4_CASES = [(2, 8, 8, 32, 64, 2), (1, 9, 11, 32, 32, 1), (3, 16, 16, 64, 128, 2), (1, 7, 10, 96, 8, 1), (2, 64, 64, 64, 128, 2), (2, 33, 32, 256, 512, 1),
+            (1, 12, 10, 32, 4, 1)]  # N, H, W, Cin, Cout, stride
+
+
+@pytest.mark.parametrize("case", K4_CASES)
+def test_conv_k4_fwd_dgrad_wgrad(case):
+    """4x4 conv, padding 1, stride 1 | 2 (models/patchgan.py:125-147) as a gather in the conv kernels: forward, the transposed gather for
+    the input gradient, and the weight / bias gradient, against fp64 autograd on the same bf16-rounded operands; forward also against the
+    im2col + GEMM formulation (an independent route through other kernels)."""
+    ops = _ops()
+    n, h, w_, cin, cout, stride = case
+    g = torch.Generator().manual_seed(41 + cin + h)
+    x = torch.randn(n, h, w_, cin, generator=g).to(DEV).to(BF)
+    w = (torch.randn(cout, cin, 4, 4, generator=g) * 0.05).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    ho, wo = (h - 2) // stride + 1, (w_ - 2) // stride + 1
+    dy = torch.randn(n, ho, wo, cout, generator=g).to(DEV).to(BF)
+    xr = x.float().cpu().double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.to(BF).float().cpu().double().requires_grad_(True)
+    br = b.cpu().double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=1)
+    yr.backward(dy.float().cpu().double().permute(0, 3, 1, 2))
+    wp = ops.pack_conv_weight(w)
+    assert wp.shape == (cout, 16, cin)
+    y32 = ops.conv2d_nhwc(x, wp, b, ks=4, stride=stride, out_f32=True)
+    assert y32.shape == (n, ho, wo, cout)
+    assert rel_err(y32.cpu(), yr.detach().permute(0, 2, 3, 1)) < 1e-5
+    for act in (0, 4):
+        ya = ops.conv2d_nhwc(x, wp, b, ks=4, stride=stride, act=act)
+        want = y32 if act == 0 else torch.where(y32 > 0, y32, 0.2 * y32)
+        assert torch.equal(ya, want.to(BF))
+    col = ops.im2col(x, 4, stride, 1)
+    y_col = ops.conv2d_nhwc(col.view(1, 1, n * ho * wo, 16 * cin), wp.view(cout, 1, 16 * cin), b, ks=1, out_f32=True).view(n, ho, wo, cout)
+    assert rel_err(y32, y_col) < 1e-5
+    if cout % 32 == 0:
+        dx = ops.conv2d_nhwc(dy, ops.pack_conv_weight(w, for_dgrad=True), ks=4, stride=stride, transposed=True, out_f32=True)
+        hh, ww = (ho - 1) * stride + 2, (wo - 1) * stride + 2
+        assert dx.shape == (n, hh, ww, cin)
+        ref = xr.grad.permute(0, 2, 3, 1)
+        assert rel_err(dx.cpu(), ref[:, :hh, :ww]) < 1e-5
+        assert ref[:, hh:].abs().max() == 0 if hh < h else True           # rows the strided conv never read
+    if cout % 8 == 0:
+        dw, db = ops.conv2d_nhwc_wgrad(dy, x, 4, stride=stride)
+        assert dw.shape == (cout, cin, 4, 4)
+        assert rel_err(dw.cpu(), wr.grad) < 1e-5
+        assert rel_err(db.cpu(), br.grad) < 1e-5
+
+
 def test_conv_stride2_rejects_odd_sizes():
     ops = _ops()
     from dmvae_amd._lib import DmvaeHipError
