@@ -27,6 +27,18 @@ def weights_init(m):
         nn.init.constant_(m.bias.data, 0)
 
 
+def sync_batch_stats(mean: torch.Tensor, var: torch.Tensor, count: int, group=None):
+    """Combine per-rank per-channel (mean, biased variance, element count) into the statistics of the union of all ranks' batches, the
+    way torch.nn.SyncBatchNorm does (ranks may hold different counts): one all-reduce of [sum x, sum x^2, n].  Returns (mean, var, n)."""
+    c = mean.numel()
+    packed = torch.cat([mean * count, (var + mean * mean) * count, torch.full((1,), float(count), device=mean.device, dtype=mean.dtype)])
+    torch.distributed.all_reduce(packed, group=group)
+    total = packed[-1]
+    g_mean = packed[:c] / total
+    g_var = (packed[c:2 * c] / total - g_mean * g_mean).clamp_min_(0.0)
+    return g_mean, g_var, int(round(total.item()))
+
+
 def _bn_stats(bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor):
     """Per-channel (mean, rstd) [1,C,2], whether they are batch statistics, the global element count and the process group to
     reduce the backward sums over.  Training: batch statistics (over all ranks for SyncBatchNorm) and the running-estimate update
@@ -46,11 +58,7 @@ def _bn_stats(bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor):
         if isinstance(bn, nn.SyncBatchNorm) and torch.distributed.is_available() and torch.distributed.is_initialized() \
                 and torch.distributed.get_world_size(bn.process_group) > 1:
             group = bn.process_group if bn.process_group is not None else torch.distributed.group.WORLD
-            packed = torch.cat([mean * count, (var + mean * mean) * count, torch.full((1,), float(count), device=x.device)])
-            torch.distributed.all_reduce(packed, group=group)
-            total = int(round(packed[-1].item()))
-            mean = packed[:c] / packed[-1]
-            var = (packed[c:2 * c] / packed[-1] - mean * mean).clamp_min_(0.0)
+            mean, var, total = sync_batch_stats(mean, var, count, group)
             st = torch.stack([mean, torch.rsqrt(var + bn.eps)], dim=1).view(1, c, 2).contiguous()
         if bn.training and bn.track_running_stats:
             bn.num_batches_tracked += 1

@@ -72,3 +72,36 @@ def test_single_process_is_noop():
     t = torch.ones(3)
     assert dist.allreduce(t) is None or True
     dist.barrier()
+
+
+def _bn_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from dmvae_amd import dist
+    from dmvae_amd.models.patchgan import sync_batch_stats
+    dist.init_distributed_mode(backend="gloo")
+    sizes = [5, 9]                                           # ranks hold different batch sizes
+    xs = [torch.randn(sizes[r], 16, 6, 7, generator=torch.Generator().manual_seed(7 + r)) * (1 + r) + r for r in range(world)]
+    x = xs[rank]
+    mean, var = x.mean(dim=(0, 2, 3)), x.var(dim=(0, 2, 3), unbiased=False)
+    g_mean, g_var, n = sync_batch_stats(mean, var, x.numel() // 16)
+    allx = torch.cat(xs, dim=0)
+    ok = (n == allx.numel() // 16 and torch.allclose(g_mean, allx.mean(dim=(0, 2, 3)), rtol=1e-5, atol=1e-6)
+          and torch.allclose(g_var, allx.var(dim=(0, 2, 3), unbiased=False), rtol=1e-4, atol=1e-6))
+    dist.barrier()
+    q.put((rank, ok))
+    torch.distributed.destroy_process_group()
+
+
+def test_sync_batchnorm_statistics_two_ranks_gloo():
+    """The cross-rank combination used by the discriminator's SyncBatchNorm (models/patchgan.py:113-115 in the reference) equals the
+    statistics of the concatenated batch, with unequal per-rank batch sizes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
