@@ -445,6 +445,53 @@ def scale_residual_(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor) -> to
     return x
 
 
+def layernorm_bwd_(dx_io: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-6, need_param_grads: bool = True,
+                   dg_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """dx_io (f32, in place) += LayerNorm backward of dy (bf16) at input x (f32); returns (dgamma, dbeta) or (None, None)."""
+    dx_io = _req(dx_io, f32, "dx_io")
+    dy = _req(dy, bf16, "dy")
+    x = _req(x, f32, "x")
+    c = x.shape[-1]
+    rows = x.numel() // c
+    L = _lib.lib()
+    ws = workspace(L.dmvae_vit_bwd_workspace(c), x.device)
+    dg = (dg_out if dg_out is not None else torch.empty(c, dtype=f32, device=x.device)) if need_param_grads else None
+    db = (db_out if db_out is not None else torch.empty(c, dtype=f32, device=x.device)) if need_param_grads else None
+    check(L.dmvae_layernorm_bwd_f32(dy.data_ptr(), x.data_ptr(), _req(gamma, f32, "gamma").data_ptr(), dx_io.data_ptr(), _ptr(dg), _ptr(db),
+                                    ws.data_ptr(), ws.numel(), rows, c, float(eps), int(accumulate), _stream()), "layernorm_bwd_f32")
+    return dg, db
+
+
+def layerscale_bwd(dt: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, dg_out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """For r = x + gamma * y: returns (dy = gamma * dt as bf16, dgamma = sum_rows dt * y)."""
+    dt = _req(dt, f32, "dt")
+    y = _req(y, bf16, "y")
+    c = y.shape[-1]
+    rows = y.numel() // c
+    L = _lib.lib()
+    ws = workspace(L.dmvae_vit_bwd_workspace(c), y.device)
+    dy = torch.empty_like(y)
+    dg = dg_out if dg_out is not None else torch.empty(c, dtype=f32, device=y.device)
+    check(L.dmvae_layerscale_bwd(dt.data_ptr(), y.data_ptr(), _req(gamma, f32, "gamma").data_ptr(), dy.data_ptr(), dg.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), rows, c, int(accumulate), _stream()), "layerscale_bwd")
+    return dy, dg
+
+
+def gelu(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x, bf16, "x")
+    y = torch.empty_like(x)
+    check(_lib.lib().dmvae_gelu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "gelu_fwd")
+    return y
+
+
+def gelu_bwd(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    dy = _req(dy, bf16, "dy")
+    x = _req(x, bf16, "x")
+    dx = torch.empty_like(x)
+    check(_lib.lib().dmvae_gelu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), _stream()), "gelu_bwd")
+    return dx
+
+
 # ---- losses ---------------------------------------------------------------------------------------
 def _loss_ws(device) -> torch.Tensor:
     return workspace(_lib.lib().dmvae_loss_workspace(), device, slot="loss")

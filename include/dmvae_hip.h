@@ -195,6 +195,20 @@ int dmvae_softmax_rows_bf16(const void* s, void* p, size_t rows, int cols, float
 int dmvae_attention_qkv_bf16(const void* qkv, void* out, int batch, int seq, int heads, int head_dim, float scale,
                              dmvae_stream_t stream);
 
+/* Backward side of the same encoder block, for the stages where the encoder trains (train_dmd.py:349,519).  Residual stream f32,
+ * Linear operands / results bf16 (autocast).  workspace: dmvae_vit_bwd_workspace(c) bytes.
+ * layernorm_bwd: dx_io[rows][c] (f32, the residual-stream gradient) += LayerNorm backward of dy (bf16) at input x (f32);
+ *   dgamma / dbeta ([c] f32, both or neither; accumulate != 0 adds).  c as for layernorm_f32_bf16.
+ * layerscale_bwd: for r = x + gamma * y: dy = gamma * dt (bf16), dgamma (+)= sum_rows dt * y.  c = 8 * a divisor of 256.
+ * gelu: exact erf form (nn.GELU() default), bf16 in / out, f32 inside; bwd takes the pre-activation x.  n % 8 == 0. */
+size_t dmvae_vit_bwd_workspace(int c);
+int dmvae_layernorm_bwd_f32(const void* dy, const void* x, const void* gamma, void* dx_io, void* dgamma, void* dbeta, void* workspace,
+                            size_t workspace_bytes, int rows, int c, float eps, int accumulate, dmvae_stream_t stream);
+int dmvae_layerscale_bwd(const void* dt, const void* y, const void* gamma, void* dy, void* dgamma, void* workspace,
+                         size_t workspace_bytes, int rows, int c, int accumulate, dmvae_stream_t stream);
+int dmvae_gelu_fwd(const void* x, void* y, size_t n, dmvae_stream_t stream);
+int dmvae_gelu_bwd(const void* dy, const void* x, void* dx, size_t n, dmvae_stream_t stream);
+
 /* ---- losses (HBM-bound reductions) ------------------------------------------------------------- */
 
 size_t dmvae_loss_workspace(void);
