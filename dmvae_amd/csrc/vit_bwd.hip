@@ -17,7 +17,7 @@
 
 namespace dmvae_vit_bwd {
 
-constexpr int LN_MAX_BLOCKS = 512;
+constexpr int LN_MAX_BLOCKS = 256;
 
 // One wave per row, rows dealt round-robin to the grid's waves; C = SWEEPS * 256.
 // part: [gridDim.x][2][C] -- per-block sums of dy * x_hat (dgamma) and dy (dbeta).
@@ -85,16 +85,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
   }
 }
 
-// out[j][c] (+)= sum_b part[b][j][c], j < nj: fixed order, f64 accumulation
-__global__ void colsum_parts_kernel(const float* __restrict__ part, float* __restrict__ o0, float* __restrict__ o1, int nblk, int nj, int C,
-                                    int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nj * C) return;
-  const int j = i / C, c = i - j * C;
-  double a = 0.0;
-  for (int b = 0; b < nblk; b++) a += (double)part[((size_t)b * nj + j) * C + c];
-  float* o = j == 0 ? o0 : o1;
-  o[c] = (accumulate ? o[c] : 0.f) + (float)a;
+// out[j][c] (+)= sum_b part[b][j][c], j < nj.  Block = 64 consecutive columns x 4 interleaved partial groups (coalesced 256-B rows,
+// nblk/4 serial loads per thread), combined in a fixed order: deterministic.
+__global__ __launch_bounds__(256) void colsum_parts_kernel(const float* __restrict__ part, float* __restrict__ o0, float* __restrict__ o1, int nblk,
+                                                           int nj, int C, int accumulate) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  const int total = nj * C;
+  float a = 0.f;
+  if (col < total) {
+    const int j = col / C, c = col - j * C;
+    for (int b = grp; b < nblk; b += 4) a += part[((size_t)b * nj + j) * C + c];
+  }
+  red[grp][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (grp == 0 && col < total) {
+    const int j = col / C, c = col - j * C;
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float* o = j == 0 ? o0 : o1;
+    o[c] = (accumulate ? o[c] : 0.f) + v;
+  }
 }
 
 // dy = gamma * dt (bf16); part[blk][c] = sum over the block's rows of dt * y.  One thread owns 8 channels; blockDim 256 = (C/8 lanes)
@@ -185,7 +195,7 @@ extern "C" int dmvae_layernorm_bwd_f32(const void* dy, const void* x, const void
 #undef DMVAE_LNB
   DMVAE_CHECK_LAUNCH();
   if (dgamma && dbeta) {
-    hipLaunchKernelGGL(colsum_parts_kernel, dim3((2 * c + 255) / 256), dim3(256), 0, stream, (const float*)workspace, (float*)dgamma, (float*)dbeta,
+    hipLaunchKernelGGL(colsum_parts_kernel, dim3((2 * c + 63) / 64), dim3(256), 0, stream, (const float*)workspace, (float*)dgamma, (float*)dbeta,
                        nblk, 2, c, accumulate);
     DMVAE_CHECK_LAUNCH();
   }
@@ -202,7 +212,7 @@ extern "C" int dmvae_layerscale_bwd(const void* dt, const void* y, const void* g
   hipLaunchKernelGGL(layerscale_bwd_kernel, dim3(nblk), dim3(256), (size_t)rpb * c * sizeof(float), stream, (const float*)dt, (const bf16*)y,
                      (const float*)gamma, (bf16*)dy, (float*)workspace, rows, c);
   DMVAE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_parts_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, (const float*)workspace, (float*)dgamma, (float*)dgamma, nblk, 1, c,
+  hipLaunchKernelGGL(colsum_parts_kernel, dim3((c + 63) / 64), dim3(256), 0, stream, (const float*)workspace, (float*)dgamma, (float*)dgamma, nblk, 1, c,
                      accumulate);
   DMVAE_CHECK_LAUNCH();
   return 0;

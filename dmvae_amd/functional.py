@@ -403,6 +403,131 @@ class MLPFn(torch.autograd.Function):
         return dx, dw0.view(w0.shape), db0, dw2.view(w2.shape), db2
 
 
+# ---- trainable ViT encoder block (timm VisionTransformer block reached through models/vae.py:47-53; stages with a trainable encoder:
+# train_dmd.py:349,519) ------------------------------------------------------------------------------------------------------------
+def _bf(w: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of an f32 Linear parameter -- what autocast(bf16) feeds the GEMM -- cached until the parameter changes."""
+    cache = getattr(w, "_dmvae_bf16", None)
+    ver = (w.data_ptr(), w._version, _EPOCH[0])
+    if cache is not None and cache[0] == ver:
+        return cache[1]
+    v = w.detach().to(bf16)
+    try:
+        w._dmvae_bf16 = (ver, v)
+    except AttributeError:
+        pass
+    return v
+
+
+def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Tensor, need_dx: bool = True):
+    """Gradients of y = x @ w^T + b for bf16 operands [rows, .]: dW and db from the split-K weight-gradient kernel (f32 results, bias
+    gradient fused on the matrix pipe; the 1x1 case of the conv wgrad) when its shape constraints hold, else a library GEMM + column sum;
+    dx = dy @ w as a library GEMM (hipBLASLt through torch.matmul, bf16 like the reference's autocast backward)."""
+    rows, cout = dy2.shape
+    cin = x2.shape[1]
+    if cin % 8 == 0 and cout % 8 == 0:
+        dst_w = _dst(w)
+        dw, db = ops.conv2d_nhwc_wgrad(dy2.view(1, 1, rows, cout), x2.view(1, 1, rows, cin), 1,
+                                       dw_out=None if dst_w is None else dst_w.view(cout, cin, 1, 1), db_out=_dst(b))
+        dw = dw.view(cout, cin)
+    else:
+        dw, db = (dy2.t() @ x2).float(), dy2.float().sum(0)
+    return (dy2 @ _bf(w)) if need_dx else None, dw, db
+
+
+def _attention_bwd(qkv: torch.Tensor, do: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """d(qkv) of multi-head self-attention from the qkv Linear's output [B,S,3*C] and d(out) [B,S,C] (bf16): the probabilities are
+    recomputed (QK^T GEMM + f32 softmax, keys padded to a multiple of 32 and masked), then the four GEMMs of the decoder AttnBlock's
+    backward per (batch, head) as batched launches.  Head dim 64."""
+    b, s, c3 = qkv.shape
+    c = c3 // 3
+    hd = c // heads
+    sp = (s + 31) // 32 * 32
+    bh = b * heads
+    buf = torch.zeros(3, bh, sp, hd, dtype=bf16, device=qkv.device)
+    buf[:, :, :s] = qkv.view(b, s, 3, heads, hd).permute(2, 0, 3, 1, 4).reshape(3, bh, s, hd)
+    q, k, v = buf[0], buf[1], buf[2]
+    dop = torch.zeros(bh, sp, hd, dtype=bf16, device=qkv.device)
+    dop[:, :s] = do.view(b, s, heads, hd).permute(0, 2, 1, 3).reshape(bh, s, hd)
+    sc = ops.gemm_nt(q, k, out_f32=True)                       # [bh, sp, sp]
+    if sp != s:
+        sc[:, :, s:] = float("-inf")                           # padded keys
+    p = ops.softmax_rows(sc, scale)
+    dp = ops.gemm_nt(dop, v, out_f32=True)
+    ds = ops.softmax_rows_bwd(dp, p, scale)
+    dv = ops.gemm_tn(p, dop)                                   # [bh, key, hd]
+    dq = ops.gemm_nt(ds, ops.transpose_last2(k))
+    dk = ops.gemm_tn(ds, q)
+    out = torch.stack([dq[:, :s], dk[:, :s], dv[:, :s]], dim=0).view(3, b, heads, s, hd).permute(1, 3, 0, 2, 4)
+    return out.reshape(b, s, c3).contiguous()
+
+
+class VitBlockFn(torch.autograd.Function):
+    """One pre-norm transformer block on the f32 residual stream t [B,S,C]:
+        t += ls1 * proj(MHA(LN1(t)));  t += ls2 * fc2(GELU(fc1(LN2(t))))
+    with bf16 Linear operands / results (autocast semantics).  Forward = the frozen path's kernels (LayerNorm -> bf16, fused attention,
+    LayerScale + residual) plus the HIP GELU; backward = csrc/vit_bwd.hip kernels, the GEMM-composed attention backward and library
+    GEMMs for the Linear layers."""
+
+    @staticmethod
+    def forward(ctx, t, n1w, n1b, qkvw, qkvb, pw, pb, ls1, n2w, n2b, f1w, f1b, f2w, f2b, ls2, heads, eps):
+        import torch.nn.functional as F
+        b, s, c = t.shape
+        hd = c // heads
+        hn1 = ops.layernorm_bf16(t, n1w, n1b, eps)
+        qkv = F.linear(hn1, _bf(qkvw), _bf(qkvb))
+        o = ops.attention_qkv(qkv, heads, hd ** -0.5)
+        o2 = F.linear(o, _bf(pw), _bf(pb))
+        t_mid = ops.scale_residual_(t.clone(), o2, ls1)
+        hn2 = ops.layernorm_bf16(t_mid, n2w, n2b, eps)
+        h1 = F.linear(hn2, _bf(f1w), _bf(f1b))
+        g = ops.gelu(h1)
+        o3 = F.linear(g, _bf(f2w), _bf(f2b))
+        t_out = ops.scale_residual_(t_mid.clone(), o3, ls2)
+        ctx.save_for_backward(t, hn1, qkv, o, o2, t_mid, hn2, h1, g, o3, n1w, qkvw, pw, ls1, n2w, f1w, f2w, ls2)
+        ctx.others = (n1b, qkvb, pb, n2b, f1b, f2b, heads, eps)
+        return t_out
+
+    @staticmethod
+    def backward(ctx, dt_out):
+        t, hn1, qkv, o, o2, t_mid, hn2, h1, g, o3, n1w, qkvw, pw, ls1, n2w, f1w, f2w, ls2 = ctx.saved_tensors
+        n1b, qkvb, pb, n2b, f1b, f2b, heads, eps = ctx.others
+        b, s, c = t.shape
+        rows = b * s
+        dt = dt_out.float().clone()                                   # becomes d(t_mid), then d(t)
+        # MLP branch
+        do3, dls2 = ops.layerscale_bwd(dt, o3, ls2, dg_out=_dst(ls2))
+        dg, df2w, df2b = _lin_grads(do3.view(rows, c), g.view(rows, -1), f2w, f2b)
+        dh1 = ops.gelu_bwd(dg.view_as(h1), h1)
+        dhn2, df1w, df1b = _lin_grads(dh1.view(rows, -1), hn2.view(rows, c), f1w, f1b)
+        dn2w, dn2b = ops.layernorm_bwd_(dt, dhn2.view(b, s, c), t_mid, n2w, eps, dg_out=_dst(n2w), db_out=_dst(n2b))
+        # attention branch
+        do2, dls1 = ops.layerscale_bwd(dt, o2, ls1, dg_out=_dst(ls1))
+        do, dpw, dpb = _lin_grads(do2.view(rows, c), o.view(rows, c), pw, pb)
+        dqkv = _attention_bwd(qkv, do.view(b, s, c), heads, (c // heads) ** -0.5)
+        dhn1, dqkvw, dqkvb = _lin_grads(dqkv.view(rows, 3 * c), hn1.view(rows, c), qkvw, qkvb)
+        dn1w, dn1b = ops.layernorm_bwd_(dt, dhn1.view(b, s, c), t, n1w, eps, dg_out=_dst(n1w), db_out=_dst(n1b))
+        return dt, dn1w, dn1b, dqkvw, dqkvb, dpw, dpb, dls1, dn2w, dn2b, df1w, df1b, df2w, df2b, dls2, None, None
+
+
+class LayerNormBf16Fn(torch.autograd.Function):
+    """LayerNorm of the f32 residual stream with a bf16 result (the encoder's final norm feeding the bottleneck MLP)."""
+
+    @staticmethod
+    def forward(ctx, t, w, b, eps):
+        ctx.save_for_backward(t, w)
+        ctx.others = (b, eps)
+        return ops.layernorm_bf16(t, w, b, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        t, w = ctx.saved_tensors
+        b, eps = ctx.others
+        dt = torch.zeros_like(t)
+        dw, db = ops.layernorm_bwd_(dt, _c(dy).to(bf16), t, w, eps, dg_out=_dst(w), db_out=_dst(b))
+        return dt, dw, db, None
+
+
 def to_nhwc_bf16(x: torch.Tensor) -> torch.Tensor:
     """NCHW (any float dtype) -> NHWC bf16 contiguous, differentiable (boundary plumbing)."""
     return x.permute(0, 2, 3, 1).contiguous().to(bf16)

@@ -4,8 +4,10 @@ The reference builds this through the third-party `timm.create_model(..., pretra
 which is not installed here and needs the network.  The block algebra follows the reference's vendored
 models/dinov2.py + models/dino_layers (LayerNorm eps 1e-6, MHA, LayerScale, GELU MLP); sub-module names match timm
 (blocks.N.{norm1,attn.qkv,attn.proj,ls1.gamma,norm2,mlp.fc1,mlp.fc2,ls2.gamma}) so reference `vae.pt` files load.
-This is a SURVEY.md section-8(f) "next" row: hipBLASLt GEMMs + explicit matmul/softmax attention (no Triton, no SDPA).
-Frozen / no-grad in the tokenizer stage (train_tokenizer.py:295-297).
+SURVEY.md section-8(f) rank 3.  Three ways through it: frozen (tokenizer stage, train_tokenizer.py:295-297) -> the step harness runs
+`vit_fast.frozen_forward_features` on a bf16 shadow; trainable on the GPU at a width the kernels cover -> `vit_fast.trainable_forward_features`
+(autograd Functions over csrc/vit.hip + vit_bwd.hip, library GEMMs for the Linear layers); anything else (CPU construction / state_dict
+work, unusual widths) -> the stock PyTorch modules below, which also define the parameter names.
 """
 import math
 import warnings
@@ -93,6 +95,14 @@ class DinoV2ViT(nn.Module):
                 nn.init.zeros_(m.bias)
 
     def forward_features(self, x):
+        if x.is_cuda and torch.is_grad_enabled() and self.pos_embed.requires_grad:
+            from .vit_fast import hip_path_supported, trainable_forward_features
+            if hip_path_supported(self, self.pos_embed.shape[1]):
+                return trainable_forward_features(self, x)        # trainable encoder on the HIP kernels (csrc/vit.hip, vit_bwd.hip)
+        return self.forward_features_stock(x)
+
+    def forward_features_stock(self, x):
+        """The stock PyTorch route (parameter-name definition; CPU; widths the kernels do not cover; the parity reference in the tests)."""
         x = self.patch_embed(x)
         x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1).to(x.dtype), x], dim=1) + self.pos_embed.to(x.dtype)
         for blk in self.blocks:

@@ -10,12 +10,24 @@ import torch.nn.functional as F
 from .. import ops
 
 
+def patch_embed_gemm(vit, x: torch.Tensor) -> torch.Tensor:
+    """PatchEmbed (Conv2d(kernel = stride = patch), dino_layers/patch_embed.py) as what it is -- one GEMM over non-overlapping patches:
+    [B,3,H,W] -> [B, N, 3*p*p] (channel, row, column order = the conv weight's) @ W^T + b.  Differentiable (views + a library GEMM); avoids
+    MIOpen's convolution search (minutes on the first backward call) and its atomically-accumulated, run-to-run different weight gradient."""
+    w = vit.patch_embed.proj.weight
+    b_, c, hh, ww = x.shape
+    p = w.shape[-1]
+    assert hh % p == 0 and ww % p == 0, "image size must be a multiple of the patch size"
+    patches = x.view(b_, c, hh // p, p, ww // p, p).permute(0, 2, 4, 1, 3, 5).reshape(b_, (hh // p) * (ww // p), c * p * p)
+    return F.linear(patches.to(torch.bfloat16), w.view(w.shape[0], -1).to(torch.bfloat16), vit.patch_embed.proj.bias.to(torch.bfloat16))
+
+
 @torch.no_grad()
 def frozen_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
     """vit: a DinoV2ViT whose Linear / Conv2d weights are bf16 (train.frozen_bf16_shadow); x: [B,3,H,W] f32, already normalised.
     Returns the final-norm tokens [B, 1+N, C] in bf16 (what the bottleneck MLP consumes)."""
     bf = torch.bfloat16
-    t = vit.patch_embed(x.to(bf)).float()
+    t = patch_embed_gemm(vit, x).float()
     t = torch.cat([vit.cls_token.expand(t.shape[0], -1, -1).float(), t], dim=1) + vit.pos_embed.float()
     t = t.contiguous()                                   # f32 residual stream [B, S, C]
     b, s, c = t.shape
@@ -37,3 +49,26 @@ def frozen_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
         o = F.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias)
         ops.scale_residual_(t, o, blk.ls2.gamma)
     return ops.layernorm_bf16(t, vit.norm.weight, vit.norm.bias, vit.norm.eps)
+
+
+def hip_path_supported(vit, seq_len: int) -> bool:
+    """Shapes the encoder kernels cover: width a multiple of 256 up to 1536 with 8 * (a divisor of 256) channels (LayerNorm / LayerScale
+    kernels), head dim 64, at most 288 tokens (fused attention)."""
+    c = vit.embed_dim
+    nh = vit.blocks[0].attn.num_heads
+    return c % 256 == 0 and c <= 1536 and 256 % (c // 8) == 0 and c // nh == 64 and seq_len <= 288
+
+
+def trainable_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
+    """`DinoV2ViT.forward_features` with gradients, for the stages where the encoder trains (train_dmd.py:349,519): patch embedding
+    (one GEMM over patches), class token and position embedding through stock autograd, every transformer block as one `VitBlockFn` on the f32
+    residual stream, the final LayerNorm as `LayerNormBf16Fn`.  Same arithmetic as the module under autocast(bf16)."""
+    from ..functional import LayerNormBf16Fn, VitBlockFn
+    t = patch_embed_gemm(vit, x)
+    t = torch.cat([vit.cls_token.expand(t.shape[0], -1, -1).float(), t.float()], dim=1) + vit.pos_embed.float()
+    t = t.contiguous()
+    for blk in vit.blocks:
+        t = VitBlockFn.apply(t, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.attn.proj.bias,
+                             blk.ls1.gamma, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight,
+                             blk.mlp.fc2.bias, blk.ls2.gamma, blk.attn.num_heads, blk.norm1.eps)
+    return LayerNormBf16Fn.apply(t, vit.norm.weight, vit.norm.bias, vit.norm.eps)

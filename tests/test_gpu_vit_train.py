@@ -51,3 +51,95 @@ def test_layerscale_bwd_and_gelu(rows, c):
     assert rel_err(ops.gelu(x).float(), F.gelu(xr.detach())) < 4e-3                       # bf16 result
     assert (ops.gelu(x).float() - F.gelu(x.float()).to(BF).float()).abs().max() <= 2 ** -7 * F.gelu(x.float()).abs().max()
     assert rel_err(ops.gelu_bwd(d, x).float(), xr.grad) < 4e-3
+
+
+def _vit(embed_dim, depth, heads, img, seed=0):
+    from dmvae_amd.models.vit import DinoV2ViT
+    torch.manual_seed(seed)
+    vit = DinoV2ViT(embed_dim=embed_dim, depth=depth, num_heads=heads, patch_size=16, img_size=img).to(DEV)
+    with torch.no_grad():
+        for blk in vit.blocks:                      # LayerScale at O(1) so that both branches matter; non-trivial norms / biases
+            blk.ls1.gamma.uniform_(0.5, 1.5); blk.ls2.gamma.uniform_(0.5, 1.5)
+        for n, p in vit.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.1)
+            if "norm" in n and n.endswith("weight"):
+                p.uniform_(0.7, 1.3)
+            if n.endswith("fc1.weight") or n.endswith("fc2.weight") or n.endswith("qkv.weight") or n.endswith("proj.weight"):
+                p.mul_(2.5)
+        vit.cls_token.normal_(0, 0.5)
+        vit.pos_embed.normal_(0, 0.5)
+    return vit
+
+
+def _rl2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def test_trainable_encoder_matches_stock_autocast():
+    """forward_features with gradients on the HIP kernels vs the stock PyTorch modules under autocast(bf16) on the same weights: tokens,
+    input gradient and every parameter gradient (rel-L2: bf16 activations on both sides, different rounding sites inside attention)."""
+    import copy
+    from dmvae_amd.models import vit_fast
+    vit = _vit(256, 2, 4, 64)
+    ref = copy.deepcopy(vit)
+    assert vit_fast.hip_path_supported(vit, vit.pos_embed.shape[1])
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 3, 64, 64, generator=g).to(DEV)
+    dy = torch.randn(3, 17, 256, generator=g).to(DEV)
+    xa = x.clone().requires_grad_(True)
+    ya = vit.forward_features(xa)                                   # dispatches to the HIP path (trainable, CUDA, supported width)
+    assert ya.dtype == BF and ya.shape == (3, 17, 256)
+    (ya.float() * dy).sum().backward()
+    xb = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=BF):
+        yb = ref.forward_features_stock(xb)
+        (yb.float() * dy).sum().backward()
+    assert _rl2(ya.float(), yb.float()) < 1e-2
+    assert _rl2(xa.grad, xb.grad) < 3e-2
+    pa, pb = dict(vit.named_parameters()), dict(ref.named_parameters())
+    for n in pa:
+        assert pa[n].grad is not None, n
+        assert _rl2(pa[n].grad, pb[n].grad) < 3e-2, (n, _rl2(pa[n].grad, pb[n].grad))
+    # fp32 stock module (no autocast): the bf16 path stays within the bf16 noise floor of the exact gradients
+    ref32 = copy.deepcopy(ref)
+    ref32.zero_grad()
+    xc = x.clone().requires_grad_(True)
+    (ref32.forward_features_stock(xc) * dy).sum().backward()
+    e_hip = max(_rl2(pa[n].grad, dict(ref32.named_parameters())[n].grad) for n in pa)
+    e_stock = max(_rl2(pb[n].grad, dict(ref32.named_parameters())[n].grad) for n in pa)
+    assert e_hip < 1.5 * e_stock + 5e-3, (e_hip, e_stock)
+
+
+def test_trainable_encoder_full_width_is_deterministic():
+    """ViT-L width (1024, 16 heads, 257 tokens), two blocks, batch 4: finite gradients everywhere, identical on a second run."""
+    vit = _vit(1024, 2, 16, 256, seed=3)
+    x = torch.randn(4, 3, 256, 256, generator=torch.Generator().manual_seed(2)).to(DEV)
+    outs = []
+    for _ in range(2):
+        vit.zero_grad(set_to_none=True)
+        xa = x.clone().requires_grad_(True)
+        y = vit.forward_features(xa)
+        assert y.shape == (4, 257, 1024)
+        y.float().square().mean().backward()
+        outs.append([y.detach().clone(), xa.grad.clone()] + [p.grad.clone() for p in vit.parameters()])
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert all(o.abs().max() > 0 for o in outs[0])
+
+
+def test_vae_forward_with_trainable_encoder():
+    """VAE.forward(freeze_encoder=False): gradients reach the encoder through the bottleneck MLP and the sliced token view."""
+    import warnings
+    from dmvae_amd.models.vae import VAE
+    torch.manual_seed(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=256, depth=1, num_heads=4)).to(DEV)
+    x = (torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(DEV)
+    rec = vae(x)
+    assert rec.shape == (2, 3, 256, 256)
+    (rec - x).abs().mean().backward()
+    g = vae.encoder.model.blocks[0].attn.qkv.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
+    assert vae.encoder.model.pos_embed.grad is not None and vae.encoder.model.patch_embed.proj.weight.grad is not None
