@@ -292,6 +292,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     const int cl = lane % LPR, rg = lane / LPR;
 #pragma unroll
     for (int hh = 0; hh < 2; hh++) {
+      if (n0c + wm * (TM / WM) + hh * CWH >= a.Cout) continue;  // this wave's couts of the pass are all padding (wave-uniform; e.g. Cout = 64 on the 128-row tile)
       const int cb = n0c + wm * (TM / WM) + hh * CWH + cl * 8;  // this lane's 8 couts in the read phase
       const bool c_ok = cb < a.Cout;
       float bias8[8];
