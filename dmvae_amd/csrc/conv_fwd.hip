@@ -47,18 +47,26 @@ struct Geo {
   __device__ static __forceinline__ int swz(int row) { return (row / RPB) % CPR; }
 };
 
-template <int BK, bool OUT_F32>
+// TMk x TPk: cout x pixel tile.  128 x 128 (2 x 2 waves of 64 x 64) is the general shape; 32 x 256 (1 x 4 waves of 32 x 64, BK = 64 only)
+// serves layers with a handful of output channels (conv_out 128 -> 3, the first VGG layer's input gradient 64 -> 3), where the 128-row
+// tile spends 32x the useful matrix work on padding.
+template <int BK, bool OUT_F32, int TMk = 128, int TPk = 128>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
   using G = Geo<BK>;
+  constexpr int WVM = TMk >= 128 ? 2 : 1, WVN = 4 / WVM;         // wave grid
+  constexpr int IM = TMk / WVM / 32, JN = TPk / WVN / 32;          // 32 x 32 accumulator blocks per wave
+  constexpr int WTILE = TMk * G::ROWB, PTILE = TPk * G::ROWB, STAGE = WTILE + PTILE;
+  constexpr int LW = WTILE / 1024 / 4, LP = PTILE / 1024 / 4;      // wave-loads per wave per tile
+  static_assert(LW >= 1 && LP >= 1 && IM >= 1 && JN >= 1, "tile too small for four waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // stage s: W tile at s*2*TILEB, P tile at s*2*TILEB + TILEB
+  // stage s: W tile at s*STAGE, P tile at s*STAGE + WTILE
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WVM == 2 ? wave >> 1 : 0, wn = WVM == 2 ? wave & 1 : wave;
   // flat grid, XCD-aware: cout tiles of one pixel tile are adjacent (they share the activation tile in L2) and each
   // XCD walks a contiguous range of pixel tiles (3x3 halo rows are shared in the same L2)
   const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (int)(wid / a.ctiles) * TP;   // first pixel
-  const int n0 = (int)(wid % a.ctiles) * TM;   // first cout
+  const int m0 = (int)(wid / a.ctiles) * TPk;   // first pixel
+  const int n0 = (int)(wid % a.ctiles) * TMk;   // first cout
   const int T = a.ks * a.ks;
   const int nchunk = a.Cin / BK;
   const int S = T * nchunk;
@@ -70,39 +78,45 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
                 : (void*)(reinterpret_cast<bf16*>(a.y) + (size_t)blockIdx.z * a.y_bs);
 
   // --- per-thread load rows -------------------------------------------------------------
-  int prow_n[G::LPW], prow_y[G::LPW], prow_x[G::LPW];
-  const bf16* wrow[G::LPW];
-  int csrc[G::LPW];  // source chunk (elements) for this lane in each of its rows
+  int prow_n[LP], prow_y[LP], prow_x[LP];
+  const bf16* wrow[LW];
+  int csrcW[LW], csrcP[LP];  // source chunk (elements) for this lane in each of its rows
 #pragma unroll
-  for (int j = 0; j < G::LPW; j++) {
-    const int p = (wave * G::LPW + j) * 64 + lane;
+  for (int j = 0; j < LW; j++) {
+    const int p = (wave * LW + j) * 64 + lane;
     const int row = p / G::CPR, cp = p % G::CPR;
-    csrc[j] = (cp ^ G::swz(row)) * 8;
+    csrcW[j] = (cp ^ G::swz(row)) * 8;
+    const int co = n0 + row;
+    wrow[j] = co < a.Cout ? a.w + (size_t)co * T * a.Cin : nullptr;
+  }
+#pragma unroll
+  for (int j = 0; j < LP; j++) {
+    const int p = (wave * LP + j) * 64 + lane;
+    const int row = p / G::CPR, cp = p % G::CPR;
+    csrcP[j] = (cp ^ G::swz(row)) * 8;
     const int m = m0 + row;
     if (m < a.M) {
       const int hw = a.Ho * a.Wo;
       const int n = m / hw, r = m - n * hw;
       prow_n[j] = n; prow_y[j] = r / a.Wo; prow_x[j] = r - prow_y[j] * a.Wo;
     } else { prow_n[j] = -1; prow_y[j] = 0; prow_x[j] = 0; }
-    const int co = n0 + row;
-    wrow[j] = co < a.Cout ? a.w + (size_t)co * T * a.Cin : nullptr;
   }
 
   auto stage = [&](int s, int buf) {
     // channel chunk outer, tap inner: the 9 taps re-read (shifted) the same activation lines back to back -> L2 hits
     const int ch = a.korder ? s / T : s % nchunk, tap = a.korder ? s - ch * T : s / nchunk;
     const int ky = tap / a.ks, kx = tap - ky * a.ks;
-    char* wt = smem + buf * 2 * G::TILEB;
-    char* pt = wt + G::TILEB;
+    char* wt = smem + buf * STAGE;
+    char* pt = wt + WTILE;
 #pragma unroll
-    for (int j = 0; j < G::LPW; j++) {
-      const int q = wave * G::LPW + j;
-      const bf16* src = wrow[j] ? wrow[j] + (size_t)tap * a.Cin + ch * BK + csrc[j] : zero;
+    for (int j = 0; j < LW; j++) {
+      const int q = wave * LW + j;
+      const bf16* src = wrow[j] ? wrow[j] + (size_t)tap * a.Cin + ch * BK + csrcW[j] : zero;
       __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(wt + q * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < G::LPW; j++) {
-      const int q = wave * G::LPW + j;
+    for (int j = 0; j < LP; j++) {
+      const int q = wave * LP + j;
       const bf16* src = zero;
       int iy = prow_y[j] * a.so - a.pd + ky, ix = prow_x[j] * a.so - a.pd + kx;
       bool ok = prow_n[j] >= 0 && iy >= 0 && ix >= 0;
@@ -110,27 +124,30 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
         if (!a.fl) ok = ok && !((iy | ix) & 1);
         iy >>= 1; ix >>= 1;
       }
-      if (ok && iy < a.Hi && ix < a.Wi) src = a.x + ((size_t)(prow_n[j] * a.Hi + iy) * a.Wi + ix) * a.Cin + ch * BK + csrc[j];
+      if (ok && iy < a.Hi && ix < a.Wi) src = a.x + ((size_t)(prow_n[j] * a.Hi + iy) * a.Wi + ix) * a.Cin + ch * BK + csrcP[j];
       __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(pt + q * 1024), 16, 0, 0);
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[IM][JN];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < IM; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < JN; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   // fragment read offsets (bytes within a tile), per kk step add chunk XOR
-  int wro[2], pro[2], wsw[2], psw[2];
+  int wro[IM], pro[JN], wsw[IM], psw[JN];
 #pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int rw = wm * 64 + i * 32 + (lane & 31);
-    const int rp = wn * 64 + i * 32 + (lane & 31);
+  for (int i = 0; i < IM; i++) {
+    const int rw = wm * (IM * 32) + i * 32 + (lane & 31);
     wro[i] = rw * G::ROWB; wsw[i] = G::swz(rw);
-    pro[i] = rp * G::ROWB; psw[i] = G::swz(rp);
+  }
+#pragma unroll
+  for (int j = 0; j < JN; j++) {
+    const int rp = wn * (JN * 32) + j * 32 + (lane & 31);
+    pro[j] = rp * G::ROWB; psw[j] = G::swz(rp);
   }
   const int kg = lane >> 5;
 
@@ -139,35 +156,34 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (s + 1 < S) stage(s + 1, (s + 1) & 1);
-    const char* wt = smem + (s & 1) * 2 * G::TILEB;
-    const char* pt = wt + G::TILEB;
+    const char* wt = smem + (s & 1) * STAGE;
+    const char* pt = wt + WTILE;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; kk++) {
       const int c = kk * 2 + kg;
-      bf16x8 wf[2], pf[2];
+      bf16x8 wf[IM], pf[JN];
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
-        wf[i] = *reinterpret_cast<const bf16x8*>(wt + wro[i] + ((c ^ wsw[i]) << 4));
-        pf[i] = *reinterpret_cast<const bf16x8*>(pt + pro[i] + ((c ^ psw[i]) << 4));
-      }
+      for (int i = 0; i < IM; i++) wf[i] = *reinterpret_cast<const bf16x8*>(wt + wro[i] + ((c ^ wsw[i]) << 4));
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+      for (int j = 0; j < JN; j++) pf[j] = *reinterpret_cast<const bf16x8*>(pt + pro[j] + ((c ^ psw[j]) << 4));
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+      for (int i = 0; i < IM; i++)
+#pragma unroll
+        for (int j = 0; j < JN; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], pf[j], acc[i][j], 0, 0, 0);
     }
   }
 
   // --- epilogue: lane owns pixel (l&31) and 4-cout quads ---------------------------------
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int m = m0 + wn * 64 + j * 32 + (lane & 31);
+  for (int j = 0; j < JN; j++) {
+    const int m = m0 + wn * (JN * 32) + j * 32 + (lane & 31);
     if (m >= a.M) continue;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < IM; i++) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int cb = n0 + wm * 64 + i * 32 + 8 * q + 4 * kg;
+        const int cb = n0 + wm * (IM * 32) + i * 32 + 8 * q + 4 * kg;
         if (cb >= a.Cout) continue;
         float v[4];
 #pragma unroll
@@ -210,20 +226,20 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
   }
 }
 
-template <int BK, bool F32>
+template <int BK, bool F32, int TMk = 128, int TPk = 128>
 int launch(const ConvArgs& a_in, hipStream_t st, int batch = 1) {
   ConvArgs a = a_in;
-  a.ctiles = (a.Cout + TM - 1) / TM;
+  a.ctiles = (a.Cout + TMk - 1) / TMk;
   { const char* e = getenv("DMVAE_KORDER"); a.korder = e ? atoi(e) : 1; }
-  dim3 grid(((a.M + TP - 1) / TP) * a.ctiles, 1, batch);
-  const int lds = 2 * 2 * Geo<BK>::TILEB;
+  dim3 grid(((a.M + TPk - 1) / TPk) * a.ctiles, 1, batch);
+  const int lds = 2 * (TMk + TPk) * Geo<BK>::ROWB;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_kernel<BK, F32>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_kernel<BK, F32, TMk, TPk>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_fwd_kernel<BK, F32>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_fwd_kernel<BK, F32, TMk, TPk>), grid, dim3(256), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -302,6 +318,9 @@ extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* b
   DMVAE_CHECK_ARG(M < (1ll << 31) / 4, "conv2d_nhwc_fwd: too many pixels");
   a.M = (int)M;
   const bool f32 = d->out_f32 != 0;
+  static const bool narrow_ok = [] { const char* e = getenv("DMVAE_CONV_NARROW"); return e ? atoi(e) != 0 : true; }();
+  if (narrow_ok && a.Cout <= 32 && a.Cin % 64 == 0 && a.M >= 4096)   // a handful of output channels: 32-row cout tile
+    return f32 ? launch<64, true, 32, 256>(a, stream) : launch<64, false, 32, 256>(a, stream);
   if (a.Cin % 64 == 0) return f32 ? launch<64, true>(a, stream) : launch<64, false>(a, stream);
   return f32 ? launch<32, true>(a, stream) : launch<32, false>(a, stream);
 }

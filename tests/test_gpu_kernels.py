@@ -37,6 +37,8 @@ CONV_CASES = [  # N, H, W, Cin, Cout, ks, ups
     (2, 8, 8, 64, 64, 3, 0), (2, 8, 8, 64, 128, 3, 0), (1, 16, 16, 128, 64, 3, 0), (3, 5, 7, 32, 32, 3, 0),
     (2, 8, 8, 64, 64, 1, 0), (1, 32, 32, 512, 512, 3, 0), (2, 4, 4, 32, 96, 3, 1), (1, 8, 8, 64, 256, 1, 0),
     (1, 1, 1, 32, 4, 3, 0), (1, 2, 130, 64, 36, 3, 0),
+    # a handful of output channels on >= 4096 pixels: the 32 x 256 tile of the general kernel
+    (2, 64, 64, 128, 4, 3, 0), (1, 70, 90, 64, 12, 3, 0), (1, 64, 64, 64, 32, 3, 1), (1, 64, 65, 64, 4, 1, 0),
 ]
 
 
