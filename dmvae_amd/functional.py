@@ -11,6 +11,7 @@ activations `a = swish(GN(x))` that the forward materialised anyway (they are th
 from __future__ import annotations
 
 from typing import Optional
+import os
 
 import torch
 
@@ -364,8 +365,21 @@ class NormConvOutFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, st, a, nw, nb, cw = ctx.saved_tensors
         cout = cw.shape[0]
-        dyp = ops.nchw_to_nhwc_bf16(_c(dy.float()), c_pad=32)
-        dwp, dbp = ops.conv2d_nhwc_wgrad(dyp, a, 3)
+        dyf = _c(dy.float())
+        dyp = ops.nchw_to_nhwc_bf16(dyf, c_pad=32)                 # the input-gradient conv's reduction dimension: 32-channel K steps
+        if cout <= 8 and a.numel() // a.shape[-1] >= 16384 and os.environ.get("DMVAE_CONVOUT_IM2COL", "1") != "0":
+            # With 3 output channels a 128-row weight-gradient tile is 98 % padding (1.4 ms at B = 32).  Instead: im2col of the GRADIENT
+            # (8 padded channels x 9 taps = 72 columns, col[q][t*8+co] = dy[q + off(t)][co]) and ONE 1x1 weight-gradient GEMM against `a`:
+            #   G[(t, co)][ci] = sum_q dy[q + off(t)][co] * a[q][ci]  =  dW[co][ci][8 - t]   (the tap seen from the other side),
+            # and the centre tap's column sums are the bias gradient.
+            n_, h_, w_, c_ = a.shape
+            m_ = n_ * h_ * w_
+            col = ops.im2col(ops.nchw_to_nhwc_bf16(dyf, c_pad=8), 3, 1, 1)
+            g_, gb = ops.conv2d_nhwc_wgrad(col.view(1, 1, m_, 72), a.view(1, 1, m_, c_), 1)
+            dwp = g_.view(9, 8, c_).flip(0).permute(1, 2, 0).reshape(8, c_, 3, 3)
+            dbp = gb.view(9, 8)[4]
+        else:
+            dwp, dbp = ops.conv2d_nhwc_wgrad(dyp, a, 3)
         da = ops.conv2d_nhwc(dyp, packed(cw, True, cols_pad=32), ks=3)
         dx, dnw, dnb = ops.groupnorm_bwd(da, x, st, nw, nb, True, dg_out=_dst(nw), db_out=_dst(nb))
         dcw, dcb = _dst(cw), _dst(ctx.bias_param)

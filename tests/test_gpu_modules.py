@@ -224,3 +224,25 @@ def test_cpu_tensor_fails_loudly():
     from dmvae_amd import _lib, ops
     with pytest.raises(_lib.DmvaeHipError):
         ops.groupnorm_stats(torch.zeros(1, 4, 4, 32, dtype=torch.bfloat16))
+
+
+def test_conv_out_weight_gradient_via_gradient_im2col():
+    """NormConvOutFn's weight / bias gradient for >= 16384 pixels comes from im2col of the output gradient + one 1x1 weight-gradient GEMM
+    (functional.py); it must equal the direct 3x3 weight-gradient kernel on the same operands (f32 accumulation on both sides)."""
+    from dmvae_amd import functional as Fn, ops
+    g = torch.Generator().manual_seed(9)
+    n, h, w_, c = 2, 96, 100, 128
+    x = torch.randn(n, h, w_, c, generator=g).to(DEV).to(torch.bfloat16).requires_grad_(True)
+    nw, nb = (1 + 0.2 * torch.randn(c, generator=g)).to(DEV).requires_grad_(True), (0.1 * torch.randn(c, generator=g)).to(DEV).requires_grad_(True)
+    cw = (0.05 * torch.randn(3, c, 3, 3, generator=g)).to(DEV).requires_grad_(True)
+    cb = (0.1 * torch.randn(3, generator=g)).to(DEV).requires_grad_(True)
+    y = Fn.NormConvOutFn.apply(x, nw, nb, cw, cb)
+    assert y.shape == (n, 3, h, w_) and y.dtype == torch.float32
+    dy = torch.randn(y.shape, generator=g).to(DEV)
+    y.backward(dy)
+    st = ops.groupnorm_stats(x.detach())
+    a = ops.groupnorm_apply(x.detach(), st, nw.detach(), nb.detach(), True)
+    dyp = ops.nchw_to_nhwc_bf16(dy, c_pad=32)
+    dw_ref, db_ref = ops.conv2d_nhwc_wgrad(dyp, a, 3)
+    assert rel_err(cw.grad, dw_ref[:3]) < 1e-5
+    assert rel_err(cb.grad, db_ref[:3]) < 1e-5
