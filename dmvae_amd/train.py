@@ -182,6 +182,150 @@ class TokenizerTrainer:
         return out
 
 
+def backward_order_params_full(vae: VAE):
+    """Every trainable parameter of the VAE, decoder / bottleneck first (backward_order_params), then the encoder's blocks last-to-first and
+    its embeddings -- the order their gradients complete when the encoder trains too (train_dmd.py:519)."""
+    params = backward_order_params(vae)
+    seen = {id(p) for p in params}
+    enc = vae.encoder.model
+    order = [enc.norm] + list(reversed(list(enc.blocks))) + [enc.patch_embed]
+    for m in order:
+        for p in m.parameters():
+            if id(p) not in seen and p.requires_grad:
+                seen.add(id(p))
+                params.append(p)
+    for p in vae.parameters():
+        if id(p) not in seen and p.requires_grad:
+            seen.add(id(p))
+            params.append(p)
+    return params
+
+
+class DMDTrainer:
+    """Step harness of the distribution-matching stage (train_dmd.py:506-575): every `vae_train_every`-th step the whole VAE (encoder
+    included, :519) trains on  rec_loss [+ adversarial term] + dmd_weight * DMD loss (:233-262, :204-230), then -- every step -- the student
+    velocity model trains on the flow-matching loss of the current latents (transport.training_losses, transport.py:119-164).
+
+    `teacher` / `student` are callables `f(xt [B,C,h,w], t [B], labels [B]) -> velocity` (the reference's LightningDiT; SURVEY.md 8(f) rank 3 --
+    not rebuilt here, any nn.Module works).  The VAE side runs on the HIP kernels: trainable ViT encoder (functional.VitBlockFn), bottleneck,
+    decoder, LPIPS, `losses.dmd_loss` (csrc/losses.hip::dmd_*).  The student is updated with torch.optim.AdamW like the reference's
+    optimizer_sit (:473).  The reference keeps no EMA in this stage."""
+
+    def __init__(self, vae: VAE, lpips: Optional[LPIPS], teacher, student, lr: float = 1e-4, diff_lr: float = 1e-4, wd: float = 0.005,
+                 l1: float = 1.0, l2: float = 0.0, lpips_w: float = 1.0, dmd_weight: float = 5.0, dmd_cfg_scale: float = 5.0, num_classes: int = 1000,
+                 t0: float = 0.0, t1: float = 1.0, latent_mean: float = 0.0, latent_scale: float = 1.0, vae_train_every: int = 5,
+                 time_dist_shift: float = 1.0, warmup_steps: int = 1000, max_norm: float = 1.0, bucket_bytes: int = 64 << 20):
+        self.vae, self.lpips, self.teacher, self.student = vae, lpips, teacher, student
+        self.w = dict(l1=l1, l2=l2, lpips=lpips_w)
+        self.dmd_weight, self.cfg, self.num_classes = dmd_weight, dmd_cfg_scale, num_classes
+        self.t0, self.t1, self.latent_mean, self.latent_scale = t0, t1, latent_mean, latent_scale
+        self.vae_train_every, self.time_dist_shift, self.max_norm = vae_train_every, time_dist_shift, max_norm
+        for p in vae.parameters():
+            p.requires_grad_(True)                                         # train_dmd.py:519
+        params = backward_order_params_full(vae)
+        assert sum(p.numel() for p in params) == sum(p.numel() for p in vae.parameters())
+        # gradients reach the embeddings through stock autograd and the blocks through the HIP Functions: both accumulate into the flat
+        # buffer's views (no direct writes in this harness)
+        self.fp = FlatParams(params, with_ema=False)
+        self.opt = FlatAdamWEMA(self.fp, lr=lr, weight_decay=wd, warmup_steps=warmup_steps, max_norm=max_norm)
+        self.sync = dist.FlatGradSync(params, self.fp.grad, self.fp.offsets, bucket_bytes=bucket_bytes)
+        sp = [p for p in student.parameters()] if hasattr(student, "parameters") else []
+        self.sopt = torch.optim.AdamW(sp, lr=diff_lr, weight_decay=wd, betas=(0.9, 0.95), eps=1e-8) if sp else None
+        self.ssched = torch.optim.lr_scheduler.LambdaLR(self.sopt, lambda s: s / warmup_steps if s < warmup_steps else 1.0) if sp else None
+        self.log = torch.zeros(10, dtype=torch.float32, device=self.fp.flat.device)
+        self.global_step = 0
+
+    def _sample(self, x1: torch.Tensor):
+        """Transport.sample (transport.py:105-116): x0 on the device generator, t on the CPU generator, optional time shift."""
+        x0 = torch.randn_like(x1)
+        t = torch.rand((x1.shape[0],)).to(x1)
+        s = self.time_dist_shift
+        t = 1 - s * (1 - t) / (1 + (s - 1) * (1 - t))
+        return t, x0
+
+    def _dmd(self, latents: torch.Tensor, labels: torch.Tensor):
+        """compute_distribution_matching_loss (train_dmd.py:204-230)."""
+        t, x0 = self._sample(latents)
+        t = (t * (self.t1 - self.t0) + self.t0)
+        xt = losses.dmd_make_xt(latents, x0, t)
+        with torch.no_grad():
+            vt, vs = self.teacher(xt, t, labels), self.student(xt, t, labels)
+            vtu = vsu = None
+            if self.cfg > 1:
+                un = torch.ones_like(labels) * self.num_classes
+                vtu, vsu = self.teacher(xt, t, un), self.student(xt, t, un)
+        return losses.dmd_loss(latents, xt, t, vt, vs, vtu, vsu, cfg=self.cfg)
+
+    def step(self, images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        vae, w = self.vae, self.w
+        vae_turn = self.global_step % self.vae_train_every == 0
+        for p in getattr(self.student, "parameters", lambda: [])():
+            p.requires_grad_(False)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if vae_turn:
+                self.fp.begin_step()
+                vae.train()
+                recon, z = vae(images, return_latent=True)
+            else:
+                with torch.no_grad():
+                    z = vae.bottle_neck(vae.encoder(images))
+                    recon = None
+            latents = losses.latents_to_spatial((z.float() - self.latent_mean) * self.latent_scale)
+            if vae_turn:
+                l1, l2 = losses.l1_mse(recon, images, w["l1"], w["l2"])
+                loss = l1 * w["l1"] + l2 * w["l2"]
+                lp = None
+                if self.lpips is not None and w["lpips"] != 0:
+                    lp = self.lpips(images, recon)
+                    loss = loss + lp * w["lpips"]
+                rec_loss = loss
+                dlog = None
+                if self.dmd_weight > 0:
+                    dmd, dlog = self._dmd(latents, labels)
+                    loss = loss + dmd * self.dmd_weight
+        if vae_turn:
+            loss.backward()
+            self.sync.wait()
+            norm = self.opt.step()
+            with torch.no_grad():
+                self.log[0], self.log[1], self.log[3], self.log[4] = l1.detach(), l2.detach(), rec_loss.detach(), norm[0]
+                if lp is not None:
+                    self.log[2] = lp.detach()
+                if dlog is not None:
+                    self.log[5], self.log[6] = dlog[0], dlog[1]
+        # student turn (every step): flow-matching loss on the current latents (transport.training_losses)
+        sloss = None
+        if self.sopt is not None:
+            for p in self.student.parameters():
+                p.requires_grad_(True)
+            x1 = latents.detach()
+            t, x0 = self._sample(x1)
+            te = t.view(-1, *([1] * (x1.dim() - 1)))
+            xt, ut = te * x1 + (1 - te) * x0, x1 - x0                    # ICPlan.plan (path.py:114-136)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = self.student(xt, t, labels)
+                sloss = ((out.float() - ut) ** 2).flatten(1).mean(1).mean()
+            sloss.backward()
+            if dist.initialized() and dist.get_world_size() > 1:
+                for p in self.student.parameters():
+                    if p.grad is not None:
+                        p.grad.div_(dist.get_world_size())
+                        dist.allreduce(p.grad)
+            snorm = torch.nn.utils.clip_grad_norm_(self.student.parameters(), self.max_norm)
+            self.sopt.step()
+            self.sopt.zero_grad(set_to_none=True)
+            self.ssched.step()
+            with torch.no_grad():
+                self.log[7], self.log[8] = sloss.detach(), snorm
+        self.global_step += 1
+        return (loss if vae_turn else sloss).detach()
+
+    def read_log(self) -> Dict[str, float]:
+        v = self.log.tolist()
+        return {"L1": v[0], "L2": v[1], "LPIPS": v[2], "rec_loss": v[3], "vae_norm": v[4], "dmd_loss": v[5], "dmd_gradient_norm": v[6],
+                "diffusion_loss": v[7], "sit_norm": v[8]}
+
+
 def build_tokenizer_trainer(device="cuda", z_channels=32, model_size="large", seed=42, lpips_ckpt=None, **kw) -> TokenizerTrainer:
     """Random-init model in the reference's constructor order under torch.manual_seed(seed)."""
     torch.manual_seed(seed)

@@ -139,3 +139,62 @@ def test_step_with_discriminator_branch():
     assert set(ck["disc_wo_ddp"].keys()) == set(disc.state_dict().keys()) and "vae_ema" in ck
     tr2, _, _, out2 = run()
     assert out == out2 and torch.equal(tr.fp.flat, tr2.fp.flat) and torch.equal(tr.dfp.flat, tr2.dfp.flat)
+
+
+class _TinyVelocity(torch.nn.Module):
+    """Stand-in for the reference's LightningDiT (f(xt, t, labels) -> velocity): per-pixel MLP over channels with a label / time embedding."""
+
+    def __init__(self, c=32, ncls=10):
+        super().__init__()
+        self.emb = torch.nn.Embedding(ncls + 1, c)
+        self.f1, self.f2 = torch.nn.Linear(c, 64), torch.nn.Linear(64, c)
+
+    def forward(self, xt, t, y):
+        h = xt.permute(0, 2, 3, 1) + self.emb(y)[:, None, None, :] * t.view(-1, 1, 1, 1).to(xt.dtype)
+        return self.f2(torch.nn.functional.silu(self.f1(h))).permute(0, 3, 1, 2)
+
+
+def test_dmd_stage_step_harness():
+    """train_dmd.py's step structure on the HIP path with a pluggable velocity model: VAE turn every `vae_train_every` steps (whole VAE trainable,
+    encoder included: gradients through functional.VitBlockFn; DMD loss with CFG through losses.dmd_loss), student turn every step; turn pattern,
+    finiteness, every parameter group moves, run-to-run determinism under fixed seeds."""
+    from dmvae_amd.models.vae import VAE
+    from dmvae_amd.train import DMDTrainer
+    from dmvae_amd.utils.lpips import LPIPS
+
+    def run():
+        torch.manual_seed(21)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=256, depth=1, num_heads=4)).cuda()
+        with torch.no_grad():
+            vae.encoder.model.blocks[0].ls1.gamma.fill_(1.0); vae.encoder.model.blocks[0].ls2.gamma.fill_(1.0)
+        lp = LPIPS().eval().requires_grad_(False).cuda()
+        with torch.no_grad():
+            for lin in (lp.lin0, lp.lin1, lp.lin2, lp.lin3, lp.lin4):
+                lin.model[-1].weight.fill_(1.0 / lin.model[-1].weight.shape[1])
+        teacher, student = _TinyVelocity().cuda().requires_grad_(False), _TinyVelocity().cuda()
+        tr = DMDTrainer(vae, lp, teacher, student, dmd_weight=5.0, dmd_cfg_scale=2.0, num_classes=10, vae_train_every=2, warmup_steps=2)
+        g = torch.Generator(device="cuda").manual_seed(0)
+        images = torch.rand(2, 3, 256, 256, device="cuda", generator=g) * 2 - 1
+        labels = torch.tensor([3, 7], device="cuda")
+        torch.manual_seed(5)
+        snaps = []
+        for _ in range(5):
+            tr.step(images, labels)
+            snaps.append((tr.fp.flat.clone(), torch.cat([p.detach().flatten() for p in student.parameters()]).clone()))
+        return tr, snaps
+
+    tr, snaps = run()
+    log = tr.read_log()
+    assert all(v == v and abs(v) < 1e6 for v in log.values()), log
+    assert log["dmd_loss"] > 0 and log["dmd_gradient_norm"] > 0 and log["diffusion_loss"] > 0 and log["vae_norm"] > 0
+    # lr warm-up: step 0 runs at lr 0 for both optimisers; VAE turns are steps 0, 2, 4; the student trains every step
+    vae_moved = [not torch.equal(snaps[i][0], snaps[i - 1][0]) for i in range(1, 5)]
+    stu_moved = [not torch.equal(snaps[i][1], snaps[i - 1][1]) for i in range(1, 5)]
+    assert vae_moved == [False, True, False, True], vae_moved
+    assert stu_moved == [True, True, True, True], stu_moved
+    enc_w = tr.vae.encoder.model.blocks[0].attn.qkv.weight
+    assert enc_w.grad is not None and enc_w.grad.abs().max() > 0                       # the encoder trains in this stage
+    tr2, snaps2 = run()
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(snaps, snaps2))
