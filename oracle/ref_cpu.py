@@ -23,6 +23,7 @@ Reference files followed (all under /root/reference):
   models/dinov2.py + models/dino_layers/{block,attention,layer_scale,mlp,patch_embed}.py
   toy_example_2d/dmd.py:320-360, toy_example_2d/sshpae.py:29-71
   models/patchgan.py:99-151  utils/diffaug.py:43-114  train_tokenizer.py:190-227 (discriminator branch)
+  diffusion/lightningdit/{lightningdit.py:27-421, rms_norm.py:34-76, swiglu_ffn.py:15-36, pos_embed.py:37-41,96-135}
 """
 from __future__ import annotations
 
@@ -312,6 +313,64 @@ def forward_generator(images: Tensor, recon: Tensor, lpips_p: P, l1_w: float = 1
     lp = lpips_forward(images, recon, lpips_p, q=q)
     rec = l1 * l1_w + l2 * l2_w + lp * lpips_w
     return rec, {"L1": l1, "L2": l2, "LPIPS": lp, "rec_loss": rec}
+
+
+# --------------------------------------------------------------------------------------------
+# diffusion/lightningdit: the LightningDiT velocity model (teacher / student of train_dmd.py)
+# --------------------------------------------------------------------------------------------
+def rms_norm(x: Tensor, w: Tensor, eps: float = 1e-6, q: Q = None) -> Tensor:
+    """rms_norm.py:52-76: normalise in f32, cast back to the input's dtype (a bf16 rounding site when the input is bf16), then scale."""
+    xf = x.float()
+    return _q(q, xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)) * w
+
+
+def rope_2d(t: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
+    """pos_embed.py:37-41,135: t * cos + rotate_half(t) * sin with (x0, x1) -> (-x1, x0) on consecutive feature pairs."""
+    r = t.reshape(*t.shape[:-1], -1, 2)
+    rot = torch.stack((-r[..., 1], r[..., 0]), dim=-1).reshape(t.shape)
+    return t * cos + rot * sin
+
+
+def lightningdit_forward(x: Tensor, t: Tensor, y: Tensor, p: P, num_heads: int, patch_size: int = 1, q: Q = None) -> Tensor:
+    """LightningDiT.forward in eval mode (lightningdit.py:390-421) for the configuration train_dmd.py builds (RMSNorm, QK-norm, RoPE, SwiGLU,
+    shift + scale + gate adaLN; :289-294 defaults).  p: state_dict.  bf16 sites (`q`) = where autocast(bf16) rounds in the reference and where
+    the HIP inference path stores bf16: every Linear's input and output, the per-head q/k after normalisation, the SwiGLU gate and product,
+    the gated branch output before it joins the f32 residual stream."""
+    b, c_in, hh, ww = x.shape
+    hid = p["pos_embed"].shape[-1]
+    hd = hid // num_heads
+    lin = lambda v, name: _q(q, F.linear(_q(q, v), _qw(q, p[name + ".weight"]), p[name + ".bias"]))
+    # patch embedding: Conv2d(kernel = stride = patch) == Linear over (c, ky, kx) patches, tokens row-major
+    w = p["x_embedder.proj.weight"]
+    pt = x.reshape(b, c_in, hh // patch_size, patch_size, ww // patch_size, patch_size).permute(0, 2, 4, 1, 3, 5).reshape(b, -1, c_in * patch_size ** 2)
+    h = _q(q, F.linear(_q(q, pt), _qw(q, w.reshape(w.shape[0], -1)), p["x_embedder.proj.bias"])) + p["pos_embed"]
+    half = 128
+    freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    temb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    temb = lin(F.silu(lin(temb, "t_embedder.mlp.0")), "t_embedder.mlp.2")
+    c = temb + p["y_embedder.embedding_table.weight"][y]
+    cos, sin = p["feat_rope.freqs_cos"], p["feat_rope.freqs_sin"]
+    nblk = 1 + max(int(k.split(".")[1]) for k in p if k.startswith("blocks."))
+    for i in range(nblk):
+        pre = f"blocks.{i}."
+        sh_a, sc_a, g_a, sh_m, sc_m, g_m = lin(F.silu(c), pre + "adaLN_modulation.1").chunk(6, dim=1)
+        a = rms_norm(h, p[pre + "norm1.weight"]) * (1 + sc_a.unsqueeze(1)) + sh_a.unsqueeze(1)
+        qkv = lin(a, pre + "attn.qkv").reshape(b, -1, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
+        qq = rope_2d(rms_norm(qkv[0], p[pre + "attn.q_norm.weight"], q=q), cos, sin)
+        kk = rope_2d(rms_norm(qkv[1], p[pre + "attn.k_norm.weight"], q=q), cos, sin)
+        att = torch.softmax((_q(q, qq) @ _q(q, kk).transpose(-2, -1)) * hd ** -0.5, dim=-1)
+        o = _q(q, _q(q, att) @ qkv[2]).transpose(1, 2).reshape(b, -1, hid)
+        h = h + _q(q, g_a.unsqueeze(1) * lin(o, pre + "attn.proj"))
+        a = rms_norm(h, p[pre + "norm2.weight"]) * (1 + sc_m.unsqueeze(1)) + sh_m.unsqueeze(1)
+        x1, x2 = lin(a, pre + "mlp.w12").chunk(2, dim=-1)
+        h = h + _q(q, g_m.unsqueeze(1) * lin(_q(q, _q(q, F.silu(x1)) * x2), pre + "mlp.w3"))
+    sh, sc = lin(F.silu(c), "final_layer.adaLN_modulation.1").chunk(2, dim=1)
+    a = rms_norm(h, p["final_layer.norm_final.weight"]) * (1 + sc.unsqueeze(1)) + sh.unsqueeze(1)
+    o = lin(a, "final_layer.linear")
+    gh = hh // patch_size
+    c_out = o.shape[-1] // patch_size ** 2
+    return o.reshape(b, gh, gh, patch_size, patch_size, c_out).permute(0, 5, 1, 3, 2, 4).reshape(b, c_out, hh, ww)
 
 
 # --------------------------------------------------------------------------------------------
