@@ -1,0 +1,73 @@
+"""Inference forward of LightningDiT on the HIP kernels (csrc/dit.hip) -- the route `LightningDiT.forward` takes when no gradient is needed
+(the teacher's and the student's evaluations inside the DMD loss, train_dmd.py:211-217: four DiT-XL/1 forwards per VAE turn).
+
+Same arithmetic as `forward_stock` under autocast(bf16), with bf16 rounding at the sites where the reference's autocast graph rounds (see
+csrc/dit.hip); per block: 1 fused RMSNorm+modulate, qkv GEMM, 1 fused QK-norm+RoPE+head split, attention as batched QK^T GEMM / f32 softmax /
+PV GEMM (head dims 64 and 72 alike: the K step pads to 96), proj GEMM, 1 gated residual, RMSNorm+modulate, w12 GEMM, SwiGLU gate, w3 GEMM,
+gated residual.  The tiny per-sample pieces (timestep / label embedding, adaLN Linear) stay stock PyTorch under autocast."""
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+
+_BF = torch.bfloat16
+
+
+def supported(model, x: torch.Tensor) -> bool:
+    from .lightningdit import RMSNorm, SwiGLUFFN
+    if not (x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == _BF):
+        return False
+    blk = model.blocks[0]
+    c, hd = model.hidden_size, model.hidden_size // model.num_heads
+    tokens = model.x_embedder.num_patches
+    return (model.use_rope and model.use_rmsnorm and isinstance(blk.attn.q_norm, RMSNorm) and isinstance(blk.mlp, SwiGLUFFN) and not blk.wo_shift
+            and c % 8 == 0 and c <= 2048 and hd % 2 == 0 and hd <= 128 and tokens % 32 == 0 and blk.mlp.w3.in_features % 8 == 0
+            and x.shape[-1] * x.shape[-2] == tokens * model.patch_size ** 2)
+
+
+def _bf(p):
+    """bf16 copy of a parameter, cached until it changes (functional._bf: in-place optimiser updates bump `_version`) -- the frozen teacher
+    converts its 675 M parameters once, not on each of its two evaluations per step."""
+    from ..functional import _bf as cached
+    return cached(p)
+
+
+def _attention(qkv, blk, rope, heads):
+    b, n, c3 = qkv.shape
+    c = c3 // 3
+    d = c // heads
+    q, k, v = ops.qknorm_rope(qkv, blk.attn.q_norm.weight, blk.attn.k_norm.weight, rope.freqs_cos, rope.freqs_sin, heads, blk.attn.q_norm.eps)
+    p = ops.softmax_rows(ops.gemm_nt(q, k, out_f32=True), d ** -0.5)            # [B*H, N, N] bf16
+    o = ops.gemm_nt(p, ops.transpose_last2(v))                                  # [B*H, N, D]
+    return o.view(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, c)
+
+
+@torch.no_grad()
+def forward_inference(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """x [B,C,H,W], t [B], y [B] -> velocity [B,C_out,H,W] in bf16 (what the stock modules return under autocast)."""
+    b, cin, hh, ww = x.shape
+    ps, c, heads = model.patch_size, model.hidden_size, model.num_heads
+    w = model.x_embedder.proj.weight
+    patches = x.view(b, cin, hh // ps, ps, ww // ps, ps).permute(0, 2, 4, 1, 3, 5).reshape(b, -1, cin * ps * ps)
+    h = F.linear(patches.to(_BF), _bf(w).view(w.shape[0], -1), _bf(model.x_embedder.proj.bias)).float() + model.pos_embed
+    h = h.contiguous()
+    n = h.shape[1]
+    cvec = model.t_embedder(t) + model.y_embedder(y, False)                     # stock modules under the caller's autocast: [B, C] f32
+    sc = F.silu(cvec)
+    for blk in model.blocks:
+        lin = blk.adaLN_modulation[1]
+        mod = F.linear(sc.to(_BF), _bf(lin.weight), _bf(lin.bias)).contiguous()  # [B, 6C]: shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp
+        a = ops.rmsnorm_modulate(h, blk.norm1.weight, mod, 0, c, blk.norm1.eps)
+        qkv = F.linear(a, _bf(blk.attn.qkv.weight), _bf(blk.attn.qkv.bias))
+        o = F.linear(_attention(qkv, blk, model.feat_rope, heads), _bf(blk.attn.proj.weight), _bf(blk.attn.proj.bias))
+        ops.gated_residual_(h, o, mod, 2 * c)
+        a = ops.rmsnorm_modulate(h, blk.norm2.weight, mod, 3 * c, 4 * c, blk.norm2.eps)
+        g = ops.swiglu(F.linear(a, _bf(blk.mlp.w12.weight), _bf(blk.mlp.w12.bias)))
+        ops.gated_residual_(h, F.linear(g, _bf(blk.mlp.w3.weight), _bf(blk.mlp.w3.bias)), mod, 5 * c)
+    fl = model.final_layer
+    mod = F.linear(sc.to(_BF), _bf(fl.adaLN_modulation[1].weight), _bf(fl.adaLN_modulation[1].bias)).contiguous()   # [B, 2C]: shift | scale
+    a = ops.rmsnorm_modulate(h, fl.norm_final.weight, mod, 0, c, fl.norm_final.eps)
+    out = model.unpatchify(F.linear(a, _bf(fl.linear.weight), _bf(fl.linear.bias)))
+    if model.learn_sigma:
+        out, _ = out.chunk(2, dim=1)
+    return out

@@ -492,6 +492,52 @@ def gelu_bwd(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return dx
 
 
+# ---- LightningDiT inference path (csrc/dit.hip) -------------------------------------------------------
+def rmsnorm_modulate(x: torch.Tensor, w: torch.Tensor, mod: torch.Tensor, shift_off: int, scale_off: int, eps: float = 1e-6) -> torch.Tensor:
+    """bf16( RMSNorm(x [B,N,C] f32; w) * bf16(1 + scale[b]) + shift[b] ); mod [B, k*C] bf16 holds the adaLN chunks at the given element offsets."""
+    x = _req(x, f32, "x")
+    mod = _req(mod, bf16, "mod")
+    b, n, c = x.shape
+    y = torch.empty(b, n, c, dtype=bf16, device=x.device)
+    check(_lib.lib().dmvae_rmsnorm_modulate_bf16(x.data_ptr(), _req(w, f32, "w").data_ptr(), mod.data_ptr(), y.data_ptr(), b * n, n, c, mod.shape[1],
+                                                 int(shift_off), int(scale_off), float(eps), _stream()), "rmsnorm_modulate_bf16")
+    return y
+
+
+def qknorm_rope(qkv: torch.Tensor, qw: torch.Tensor, kw: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, eps: float = 1e-6):
+    """qkv [B,N,3*H*D] bf16 -> (q, k [B*H, N, Dp] with Dp = D rounded up to 32, v [B*H, N, D]): per-head RMSNorm * weight + 2-D RoPE on q and k."""
+    qkv = _req(qkv, bf16, "qkv")
+    b, n, c3 = qkv.shape
+    d = c3 // 3 // heads
+    dp = (d + 31) // 32 * 32
+    q = torch.empty(b * heads, n, dp, dtype=bf16, device=qkv.device)
+    k = torch.empty_like(q)
+    v = torch.empty(b * heads, n, d, dtype=bf16, device=qkv.device)
+    check(_lib.lib().dmvae_qknorm_rope_bf16(qkv.data_ptr(), _req(qw, f32, "qw").data_ptr(), _req(kw, f32, "kw").data_ptr(), _req(cos, f32, "cos").data_ptr(),
+                                            _req(sin, f32, "sin").data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), b, n, heads, d, dp, float(eps),
+                                            _stream()), "qknorm_rope_bf16")
+    return q, k, v
+
+
+def swiglu(x12: torch.Tensor) -> torch.Tensor:
+    x12 = _req(x12, bf16, "x12")
+    hid = x12.shape[-1] // 2
+    out = torch.empty(*x12.shape[:-1], hid, dtype=bf16, device=x12.device)
+    check(_lib.lib().dmvae_swiglu_bf16(x12.data_ptr(), out.data_ptr(), x12.numel() // (2 * hid), hid, _stream()), "swiglu_bf16")
+    return out
+
+
+def gated_residual_(x: torch.Tensor, y: torch.Tensor, mod: torch.Tensor, gate_off: int) -> torch.Tensor:
+    """x [B,N,C] (f32, in place) += bf16(gate[b] * y); gate = mod[:, gate_off : gate_off + C]."""
+    x = _req(x, f32, "x")
+    y = _req(y, bf16, "y")
+    mod = _req(mod, bf16, "mod")
+    b, n, c = x.shape
+    check(_lib.lib().dmvae_gated_residual_f32(x.data_ptr(), y.data_ptr(), mod.data_ptr(), b * n, n, c, mod.shape[1], int(gate_off), _stream()),
+          "gated_residual_f32")
+    return x
+
+
 # ---- losses ---------------------------------------------------------------------------------------
 def _loss_ws(device) -> torch.Tensor:
     return workspace(_lib.lib().dmvae_loss_workspace(), device, slot="loss")

@@ -209,6 +209,23 @@ int dmvae_layerscale_bwd(const void* dt, const void* y, const void* gamma, void*
 int dmvae_gelu_fwd(const void* x, void* y, size_t n, dmvae_stream_t stream);
 int dmvae_gelu_bwd(const void* dy, const void* x, void* dx, size_t n, dmvae_stream_t stream);
 
+/* ---- LightningDiT inference path (diffusion/lightningdit/lightningdit.py:175-273; teacher / student evaluations of the DMD loss,
+ * train_dmd.py:211-217).  Residual stream f32, Linear operands / results bf16; rounding sites follow the reference's autocast graph.
+ * mod: the adaLN Linear's output [B][mod_stride] bf16; *_off: element offsets of the shift / scale / gate chunks inside a row.
+ * rmsnorm_modulate: y = bf16( RMSNorm(x; w, eps) * bf16(1 + scale[b]) + shift[b] ), shift_off < 0: no shift (`wo_shift`).  c % 4 == 0, c <= 2048.
+ * qknorm_rope: qkv [B][N][3][H][D] bf16 -> q, k: per-head RMSNorm (bf16 result) * weight, 2-D rotary embedding with the [N][D] cos / sin
+ *   tables (pos_embed.py:96-135), bf16, head-major [B*H][N][Dp] zero-padded to Dp >= D; v copied head-major [B*H][N][D].  D even, Dp <= 128.
+ * swiglu: out[rows][hidden] = bf16( bf16(silu(x1)) * x2 ), x12 = [x1 | x2] (swiglu_ffn.py:31-36).  hidden % 8 == 0.
+ * gated_residual: x[rows][c] (f32) += bf16( gate[b] * y ).  c % 8 == 0. */
+int dmvae_rmsnorm_modulate_bf16(const void* x, const void* w, const void* mod, void* y, int rows, int rows_per_sample, int c, int mod_stride,
+                                int shift_off, int scale_off, float eps, dmvae_stream_t stream);
+int dmvae_qknorm_rope_bf16(const void* qkv, const void* q_weight, const void* k_weight, const void* cos_table, const void* sin_table,
+                           void* q_out, void* k_out, void* v_out, int batch, int seq, int heads, int head_dim, int head_dim_padded, float eps,
+                           dmvae_stream_t stream);
+int dmvae_swiglu_bf16(const void* x12, void* out, size_t rows, int hidden, dmvae_stream_t stream);
+int dmvae_gated_residual_f32(void* x, const void* y, const void* mod, size_t rows, int rows_per_sample, int c, int mod_stride, int gate_off,
+                             dmvae_stream_t stream);
+
 /* ---- losses (HBM-bound reductions) ------------------------------------------------------------- */
 
 size_t dmvae_loss_workspace(void);

@@ -355,18 +355,18 @@ def lightningdit_forward(x: Tensor, t: Tensor, y: Tensor, p: P, num_heads: int, 
     for i in range(nblk):
         pre = f"blocks.{i}."
         sh_a, sc_a, g_a, sh_m, sc_m, g_m = lin(F.silu(c), pre + "adaLN_modulation.1").chunk(6, dim=1)
-        a = rms_norm(h, p[pre + "norm1.weight"]) * (1 + sc_a.unsqueeze(1)) + sh_a.unsqueeze(1)
+        a = rms_norm(h, p[pre + "norm1.weight"]) * _q(q, 1 + sc_a.unsqueeze(1)) + sh_a.unsqueeze(1)      # `1 + scale` is itself a bf16 tensor under autocast
         qkv = lin(a, pre + "attn.qkv").reshape(b, -1, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
         qq = rope_2d(rms_norm(qkv[0], p[pre + "attn.q_norm.weight"], q=q), cos, sin)
         kk = rope_2d(rms_norm(qkv[1], p[pre + "attn.k_norm.weight"], q=q), cos, sin)
         att = torch.softmax((_q(q, qq) @ _q(q, kk).transpose(-2, -1)) * hd ** -0.5, dim=-1)
         o = _q(q, _q(q, att) @ qkv[2]).transpose(1, 2).reshape(b, -1, hid)
         h = h + _q(q, g_a.unsqueeze(1) * lin(o, pre + "attn.proj"))
-        a = rms_norm(h, p[pre + "norm2.weight"]) * (1 + sc_m.unsqueeze(1)) + sh_m.unsqueeze(1)
+        a = rms_norm(h, p[pre + "norm2.weight"]) * _q(q, 1 + sc_m.unsqueeze(1)) + sh_m.unsqueeze(1)
         x1, x2 = lin(a, pre + "mlp.w12").chunk(2, dim=-1)
         h = h + _q(q, g_m.unsqueeze(1) * lin(_q(q, _q(q, F.silu(x1)) * x2), pre + "mlp.w3"))
     sh, sc = lin(F.silu(c), "final_layer.adaLN_modulation.1").chunk(2, dim=1)
-    a = rms_norm(h, p["final_layer.norm_final.weight"]) * (1 + sc.unsqueeze(1)) + sh.unsqueeze(1)
+    a = rms_norm(h, p["final_layer.norm_final.weight"]) * _q(q, 1 + sc.unsqueeze(1)) + sh.unsqueeze(1)
     o = lin(a, "final_layer.linear")
     gh = hh // patch_size
     c_out = o.shape[-1] // patch_size ** 2

@@ -1,0 +1,121 @@
+"""LightningDiT inference path on the HIP kernels (-m gpu): csrc/dit.hip kernels against their definitions, the fast forward against the
+fixtures captured from the reference, the CPU oracle with bf16 rounding at the autocast sites, and the stock modules under autocast(bf16)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rel_err
+from oracle import ref_cpu as R
+from test_oracle_dit import CFGS, build
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+Q = R.bf16_round
+
+
+def _rl2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("c,n", [(1152, 256), (128, 64), (144, 64), (2048, 32)])
+def test_dit_elementwise_kernels(c, n):
+    from dmvae_amd import ops
+    g = torch.Generator().manual_seed(c)
+    b = 3
+    x = (torch.randn(b, n, c, generator=g) * 2).to(DEV)
+    w = (1 + 0.3 * torch.randn(c, generator=g)).to(DEV)
+    mod = (0.5 * torch.randn(b, 6 * c, generator=g)).to(DEV).to(BF)
+    y = ops.rmsnorm_modulate(x, w, mod, 0, c)
+    xd = x.double()
+    nrm = xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-6) * w.double()
+    ref = nrm * (1 + mod[:, c:2 * c].float()).to(BF).double().unsqueeze(1) + mod[:, :c].double().unsqueeze(1)
+    assert (y.double() - ref).abs().max() <= 2 ** -7 * ref.abs().max()          # one bf16 rounding of the f32 result
+    assert _rl2(y, ref) < 3e-3
+    y2 = ops.rmsnorm_modulate(x, w, mod, -1, 4 * c)                              # no shift
+    ref2 = nrm * (1 + mod[:, 4 * c:5 * c].float()).to(BF).double().unsqueeze(1)
+    assert _rl2(y2, ref2) < 3e-3
+    # gated residual
+    yb = torch.randn(b, n, c, generator=g).to(DEV).to(BF)
+    want = x.double() + (mod[:, 2 * c:3 * c].unsqueeze(1) * yb).double()        # bf16 * bf16 -> bf16 product, like the reference's autocast graph
+    ops.gated_residual_(x, yb, mod, 2 * c)
+    assert (x.double() - want).abs().max() < 1e-5
+    # swiglu
+    hid = 3072 if c == 1152 else 2 * c
+    x12 = torch.randn(b * n, 2 * hid, generator=g).to(DEV).to(BF)
+    want = F.silu(x12[:, :hid]) * x12[:, hid:]                                   # bf16 silu, then bf16 product
+    assert torch.equal(ops.swiglu(x12), want) or (ops.swiglu(x12).float() - want.float()).abs().max() <= 2 ** -7 * want.float().abs().max()
+
+
+@pytest.mark.parametrize("heads,d", [(16, 72), (2, 64), (3, 32)])
+def test_qknorm_rope_kernel(heads, d):
+    from dmvae_amd import ops
+    from dmvae_amd.models.lightningdit import RMSNorm, VisionRotaryEmbeddingFast
+    g = torch.Generator().manual_seed(d)
+    b, side = 2, 8
+    n = side * side
+    qkv = torch.randn(b, n, 3 * heads * d, generator=g).to(DEV).to(BF)
+    rope = VisionRotaryEmbeddingFast(dim=d // 2, pt_seq_len=side).to(DEV)
+    qn, kn = RMSNorm(d).to(DEV), RMSNorm(d).to(DEV)
+    with torch.no_grad():
+        qn.weight.uniform_(0.5, 1.5); kn.weight.uniform_(0.5, 1.5)
+    q, k, v = ops.qknorm_rope(qkv, qn.weight.detach(), kn.weight.detach(), rope.freqs_cos, rope.freqs_sin, heads)
+    dp = (d + 31) // 32 * 32
+    assert q.shape == (b * heads, n, dp) and v.shape == (b * heads, n, d)
+    q5 = qkv.view(b, n, 3, heads, d).permute(2, 0, 3, 1, 4)
+    with torch.no_grad():
+        qr, kr = rope(qn(q5[0])).to(BF), rope(kn(q5[1])).to(BF)                  # bf16 in -> RMSNorm rounds to bf16, weight / RoPE in f32, bf16 at SDPA
+    assert (q[..., :d].float() - qr.reshape(b * heads, n, d).float()).abs().max() <= 2 ** -7 * qr.float().abs().max()
+    assert _rl2(q[..., :d], qr.reshape(b * heads, n, d)) < 2e-3 and _rl2(k[..., :d], kr.reshape(b * heads, n, d)) < 2e-3
+    assert torch.equal(v, q5[2].reshape(b * heads, n, d))
+    if dp > d:
+        assert float(q[..., d:].abs().max()) == 0.0 and float(k[..., d:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("tag", ["dit_small_hd64", "dit_small_hd72"])
+def test_lightningdit_fast_forward_vs_fixture_oracle_and_stock(tag):
+    g = load_golden(tag)
+    m = build(tag, g).to(DEV)
+    x, t, y = g.t("x").to(DEV), g.t("t").to(DEV), torch.from_numpy(np.asarray(g["y"])).to(DEV)
+    for p in m.parameters():
+        p.requires_grad_(False)                                                  # the teacher's state (train_dmd.py:372-373)
+    with torch.autocast("cuda", dtype=BF):
+        out = m(x, t, y)                                                          # dispatches to lightningdit_fast.forward_inference
+        ref_stock = m.forward_stock(x, t, y)
+    assert out.dtype == BF and out.shape == x.shape
+    with torch.no_grad():
+        yo = R.lightningdit_forward(g.t("x"), g.t("t"), torch.from_numpy(np.asarray(g["y"])), {k: v.cpu() for k, v in m.state_dict().items()},
+                                    CFGS[tag]["num_heads"], CFGS[tag]["patch_size"], q=Q)
+    e_fast, e_stock, e_orc = _rl2(out.float().cpu(), g.t("out")), _rl2(ref_stock.float().cpu(), g.t("out")), _rl2(yo, g.t("out"))
+    print(f"{tag}: rel-L2 to the f32 reference -- HIP path {e_fast:.2e}, stock autocast {e_stock:.2e}, bf16-site oracle {e_orc:.2e}")
+    assert _rl2(out.float().cpu(), yo) < 2e-2                                    # same rounding sites, different accumulation order
+    assert e_fast < 1.5 * max(e_stock, e_orc) + 2e-3                              # as close to the f32 reference as the reference's own autocast run
+    # with gradients enabled and trainable parameters the module takes the stock route (the student's training turn)
+    for p in m.parameters():
+        p.requires_grad_(True)
+    with torch.autocast("cuda", dtype=BF):
+        o2 = m(x, t, y)
+    assert o2.requires_grad
+    with torch.no_grad(), torch.autocast("cuda", dtype=BF):
+        assert torch.equal(m(x, t, y), out)                                       # no_grad: fast path again, deterministic
+
+
+def test_lightningdit_xl1_fast_forward_shapes_and_determinism():
+    """DiT-XL/1 at the DMD stage's shape (B = 16, 32 x 16 x 16 latents, head dim 72): finite, deterministic, close to the stock modules."""
+    from dmvae_amd.models.lightningdit import LightningDiT_models
+    from oracle.detweights import det_fill_
+    torch.manual_seed(0)
+    m = LightningDiT_models["LightningDiT-XL/1"](input_size=16, in_channels=32, num_classes=1000).to(DEV).eval().requires_grad_(False)
+    with torch.no_grad():
+        for blk in m.blocks:                                                      # the reference zero-initialises these: give the blocks something to do
+            blk.adaLN_modulation[1].weight.normal_(0, 0.02); blk.adaLN_modulation[1].bias.normal_(0, 0.3)
+        m.final_layer.linear.weight.normal_(0, 0.02); m.final_layer.adaLN_modulation[1].bias.normal_(0, 0.3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(16, 32, 16, 16, generator=g).to(DEV)
+    t, y = torch.rand(16, generator=g).to(DEV), torch.randint(0, 1001, (16,), generator=g).to(DEV)
+    with torch.autocast("cuda", dtype=BF):
+        a, b = m(x, t, y), m(x, t, y)
+        s = m.forward_stock(x, t, y)
+    assert a.shape == (16, 32, 16, 16) and torch.isfinite(a).all() and torch.equal(a, b)
+    assert _rl2(a.float(), s.float()) < 3e-2
