@@ -267,8 +267,14 @@ class DMDTrainer:
                 vae.train()
                 recon, z = vae(images, return_latent=True)
             else:
-                with torch.no_grad():
-                    z = vae.bottle_neck(vae.encoder(images))
+                with torch.no_grad():                               # student-only step: the latents are all that is needed (train_dmd.py:520-523)
+                    enc = vae.encoder
+                    from .models import vit_fast
+                    if vit_fast.hip_path_supported(enc.model, enc.model.pos_embed.shape[1]):
+                        tok = vit_fast.trainable_forward_features(enc.model, enc.scale(enc.de_scale(images)))[:, enc.model.num_prefix_tokens:]
+                    else:
+                        tok = enc(images)
+                    z = vae.bottle_neck(tok)
                     recon = None
             latents = losses.latents_to_spatial((z.float() - self.latent_mean) * self.latent_scale)
             if vae_turn:
