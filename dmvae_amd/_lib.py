@@ -57,6 +57,11 @@ SIGNATURES = {
     "dmvae_rmsnorm_modulate_bf16": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float, c_void_p]),
     "dmvae_qknorm_rope_bf16": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),
     "dmvae_swiglu_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "dmvae_dit_bwd_workspace": (c_size_t, [c_int, c_int]),
+    "dmvae_gated_residual_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "dmvae_swiglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "dmvae_rmsnorm_modulate_bwd": (c_int, [c_void_p] * 8 + [c_size_t] + [c_int] * 6 + [c_float, c_int, c_void_p]),
+    "dmvae_qknorm_rope_bwd": (c_int, [c_void_p] * 12 + [c_size_t] + [c_int] * 5 + [c_float, c_int, c_void_p]),
     "dmvae_gated_residual_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_loss_workspace": (c_size_t, []),
     "dmvae_l1_mse": (c_int, [c_void_p] * 5 + [c_size_t, c_size_t, c_float, c_float, c_void_p]),

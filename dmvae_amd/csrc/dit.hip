@@ -134,6 +134,232 @@ __global__ void gated_residual_kernel(float* __restrict__ x, const bf16* __restr
   }
 }
 
+// ---- backward side (the student's training turn, train_dmd.py:565-575) --------------------------------------------------------------------
+// Gradients are bf16 where the forward tensor is bf16 and f32 on the residual stream; per-sample reductions (d shift / d scale / d gate of the
+// adaLN chunks) and per-channel reductions (norm weights) are two-stage with a fixed order.
+
+// gated residual x_out = x + bf16(gate[b] * y):  dy = bf16(gate[b] * dx_out),  dgate[b][c] = sum_n dx_out * y.   grid (C/256, B); block = 32 channel
+// octets x 8 token lanes
+__global__ __launch_bounds__(256) void gated_residual_bwd_kernel(const float* __restrict__ dx, const bf16* __restrict__ y, const bf16* __restrict__ mod,
+                                                                 bf16* __restrict__ dy, float* __restrict__ dmod, int N, int C, int stride, int gate_off) {
+  __shared__ float red[8][256];
+  const int b = blockIdx.y, oc = threadIdx.x & 31, tl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 256 + oc * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < C) {
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(mod + (size_t)b * stride + gate_off + c);
+    for (int n = tl; n < N; n += 8) {
+      const size_t off = ((size_t)b * N + n) * C + c;
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(dx + off), d1 = *reinterpret_cast<const f32x4*>(dx + off + 4);
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + off);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        o[e] = (bf16)((float)g[e] * d0[e]); o[4 + e] = (bf16)((float)g[4 + e] * d1[e]);
+        acc[e] += d0[e] * (float)v[e]; acc[4 + e] += d1[e] * (float)v[4 + e];
+      }
+      *reinterpret_cast<bf16x8*>(dy + off) = o;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[tl][oc * 8 + e] = acc[e];
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < C) {
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; q++) a += red[q][threadIdx.x];
+    dmod[(size_t)b * stride + gate_off + cc] = a;
+  }
+}
+
+__device__ __forceinline__ float silu_grad_(float x) { const float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
+
+// h = bf16(bf16(silu(x1)) * x2):  dx1 = dh * x2 * silu'(x1),  dx2 = dh * bf16(silu(x1))
+__global__ void swiglu_bwd_kernel(const bf16* __restrict__ dh, const bf16* __restrict__ x12, bf16* __restrict__ dx12, size_t rows, int hid8) {
+  const size_t total = rows * hid8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / hid8;
+    const int c = (int)(i - r * hid8);
+    const size_t o1 = (r * 2 * hid8 + c) * 8, o2 = (r * 2 * hid8 + hid8 + c) * 8;
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(x12 + o1), b = *reinterpret_cast<const bf16x8*>(x12 + o2);
+    const bf16x8 d = reinterpret_cast<const bf16x8*>(dh)[i];
+    bf16x8 g1, g2;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float x = (float)a[e], dv = (float)d[e];
+      g1[e] = (bf16)(dv * (float)b[e] * silu_grad_(x));
+      g2[e] = (bf16)(dv * (float)(bf16)(x * sigmoidf_(x)));
+    }
+    *reinterpret_cast<bf16x8*>(dx12 + o1) = g1;
+    *reinterpret_cast<bf16x8*>(dx12 + o2) = g2;
+  }
+}
+
+// a = bf16( n * w * m + shift ),  n = x * rs,  m = bf16(1 + scale[b]):
+//   dx += rs * (g - n * mean(g * n)),  g = da * w * m;   dshift[b] = sum_n da;   dscale[b] = sum_n da * n * w;   dw = sum_rows da * m * n.
+// grid (BPS, B): the block's 4 waves walk the rows of sample b; part: [B][BPS][3][C] (dshift, dscale, dw contributions of the block)
+constexpr int RM_BPS = 8;
+__global__ __launch_bounds__(256) void rmsnorm_modulate_bwd_kernel(const bf16* __restrict__ da, const float* __restrict__ x, const float* __restrict__ w,
+                                                                   const bf16* __restrict__ mod, float* __restrict__ dx_io, float* __restrict__ part,
+                                                                   int N, int C, int stride, int scale_off, float eps) {
+  extern __shared__ float red[];  // [4 waves][3][C]
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  f32x4 gw[MAX_SWEEPS], gm[MAX_SWEEPS], a0[MAX_SWEEPS], a1[MAX_SWEEPS], a2[MAX_SWEEPS];
+#pragma unroll
+  for (int k = 0; k < MAX_SWEEPS; k++) {
+    const int c = k * 256 + lane * 4;
+    a0[k] = f32x4{0, 0, 0, 0}; a1[k] = f32x4{0, 0, 0, 0}; a2[k] = f32x4{0, 0, 0, 0};
+    if (c < C) {
+      gw[k] = *reinterpret_cast<const f32x4*>(w + c);
+      const bf16x4 sc = *reinterpret_cast<const bf16x4*>(mod + (size_t)b * stride + scale_off + c);
+#pragma unroll
+      for (int e = 0; e < 4; e++) gm[k][e] = (float)(bf16)(1.f + (float)sc[e]);
+    }
+  }
+  for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
+    const size_t row = (size_t)b * N + n;
+    f32x4 v[MAX_SWEEPS], g[MAX_SWEEPS];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAX_SWEEPS; k++) {
+      const int c = k * 256 + lane * 4;
+      if (c < C) {
+        v[k] = *reinterpret_cast<const f32x4*>(x + row * C + c);
+        ss += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
+      }
+    }
+    const float rs = rsqrtf(wave_sum(ss) / (float)C + eps);
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAX_SWEEPS; k++) {
+      const int c = k * 256 + lane * 4;
+      if (c < C) {
+        const bf16x4 d = *reinterpret_cast<const bf16x4*>(da + row * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float nh = v[k][e] * rs, dv = (float)d[e];
+          v[k][e] = nh;
+          g[k][e] = dv * gw[k][e] * gm[k][e];
+          s2 += g[k][e] * nh;
+          a0[k][e] += dv; a1[k][e] += dv * nh * gw[k][e]; a2[k][e] += dv * gm[k][e] * nh;
+        }
+      }
+    }
+    const float m2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int k = 0; k < MAX_SWEEPS; k++) {
+      const int c = k * 256 + lane * 4;
+      if (c < C) {
+        f32x4 o = *reinterpret_cast<const f32x4*>(dx_io + row * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] += rs * (g[k][e] - v[k][e] * m2);
+        *reinterpret_cast<f32x4*>(dx_io + row * C + c) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAX_SWEEPS; k++) {
+    const int c = k * 256 + lane * 4;
+    if (c < C) {
+      *reinterpret_cast<f32x4*>(&red[(wave * 3 + 0) * C + c]) = a0[k];
+      *reinterpret_cast<f32x4*>(&red[(wave * 3 + 1) * C + c]) = a1[k];
+      *reinterpret_cast<f32x4*>(&red[(wave * 3 + 2) * C + c]) = a2[k];
+    }
+  }
+  __syncthreads();
+  float* po = part + ((size_t)b * gridDim.x + blockIdx.x) * 3 * C;
+  for (int i = threadIdx.x; i < 3 * C; i += 256)
+    po[i] = (red[0 * 3 * C + i] + red[1 * 3 * C + i]) + (red[2 * 3 * C + i] + red[3 * 3 * C + i]);
+}
+// second stage: dmod[b][shift_off + c] = sum_blk part[b][blk][0][c] (skipped when shift_off < 0), dmod[b][scale_off + c] = ... [1] ...;
+// dw[c] (+)= sum_b sum_blk part[b][blk][2][c]
+__global__ void rmsnorm_modulate_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dmod, float* __restrict__ dw, int B, int bps, int C,
+                                                  int stride, int shift_off, int scale_off, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float wsum = 0.f;
+  for (int b = 0; b < B; b++) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < bps; k++) {
+      const float* q = part + ((size_t)b * bps + k) * 3 * C;
+      s0 += q[c]; s1 += q[C + c]; wsum += q[2 * C + c];
+    }
+    if (shift_off >= 0) dmod[(size_t)b * stride + shift_off + c] = s0;
+    dmod[(size_t)b * stride + scale_off + c] = s1;
+  }
+  if (dw) dw[c] = (accumulate ? dw[c] : 0.f) + wsum;
+}
+
+// Backward of qknorm_rope: dq', dk' [B*H][N][Dp] bf16 (w.r.t. the rotated, normalised q / k), dv [B*H][N][D] -> dqkv [B][N][3][H][D] bf16 and the
+// per-block partial sums of the two norm weights' gradients, part [gridDim.x][2][D].
+__global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16* __restrict__ dq, const bf16* __restrict__ dk, const bf16* __restrict__ dv,
+                                                              const bf16* __restrict__ qkv, const float* __restrict__ qw, const float* __restrict__ kw,
+                                                              const float* __restrict__ cosb, const float* __restrict__ sinb, bf16* __restrict__ dqkv,
+                                                              float* __restrict__ part, int tokens, int N, int H, int D, int Dp, float eps) {
+  __shared__ float red[4][4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool live = 2 * lane < D;
+  float gq0 = 0.f, gq1 = 0.f, gk0 = 0.f, gk1 = 0.f;     // weight-gradient accumulators of this lane's feature pair
+  float wq0 = 0.f, wq1 = 0.f, wk0 = 0.f, wk1 = 0.f;
+  if (live) { wq0 = qw[2 * lane]; wq1 = qw[2 * lane + 1]; wk0 = kw[2 * lane]; wk1 = kw[2 * lane + 1]; }
+  for (int tok = blockIdx.x * 4 + wave; tok < tokens; tok += gridDim.x * 4) {
+    const int b = tok / N, n = tok - b * N;
+    float c0 = 0.f, s0 = 0.f, c1 = 0.f, s1 = 0.f;
+    if (live) {
+      c0 = cosb[(size_t)n * D + 2 * lane]; c1 = cosb[(size_t)n * D + 2 * lane + 1];
+      s0 = sinb[(size_t)n * D + 2 * lane]; s1 = sinb[(size_t)n * D + 2 * lane + 1];
+    }
+    const bf16* base = qkv + (size_t)tok * 3 * H * D;
+    bf16* dbase = dqkv + (size_t)tok * 3 * H * D;
+    for (int h = 0; h < H; h++) {
+      const size_t o = ((size_t)(b * H + h) * N + n);
+      float q0 = 0.f, q1 = 0.f, k0 = 0.f, k1 = 0.f, dq0 = 0.f, dq1 = 0.f, dk0 = 0.f, dk1 = 0.f;
+      bf16x2 dvv = {(bf16)0.f, (bf16)0.f};
+      if (live) {
+        const bf16x2 a = *reinterpret_cast<const bf16x2*>(base + (size_t)h * D + 2 * lane);
+        const bf16x2 c = *reinterpret_cast<const bf16x2*>(base + (size_t)(H + h) * D + 2 * lane);
+        q0 = (float)a[0]; q1 = (float)a[1]; k0 = (float)c[0]; k1 = (float)c[1];
+        const bf16x2 ga = *reinterpret_cast<const bf16x2*>(dq + o * Dp + 2 * lane);
+        const bf16x2 gc = *reinterpret_cast<const bf16x2*>(dk + o * Dp + 2 * lane);
+        dvv = *reinterpret_cast<const bf16x2*>(dv + o * D + 2 * lane);
+        // transpose of the pair rotation: out0 = a0*c0 - a1*s0, out1 = a1*c1 + a0*s1
+        dq0 = (float)ga[0] * c0 + (float)ga[1] * s1; dq1 = (float)ga[1] * c1 - (float)ga[0] * s0;
+        dk0 = (float)gc[0] * c0 + (float)gc[1] * s1; dk1 = (float)gc[1] * c1 - (float)gc[0] * s0;
+      }
+      const float rq = rsqrtf(wave_sum(q0 * q0 + q1 * q1) / (float)D + eps);
+      const float rk = rsqrtf(wave_sum(k0 * k0 + k1 * k1) / (float)D + eps);
+      const float nq0 = q0 * rq, nq1 = q1 * rq, nk0 = k0 * rk, nk1 = k1 * rk;
+      gq0 += dq0 * (float)(bf16)nq0; gq1 += dq1 * (float)(bf16)nq1; gk0 += dk0 * (float)(bf16)nk0; gk1 += dk1 * (float)(bf16)nk1;
+      const float eq0 = dq0 * wq0, eq1 = dq1 * wq1, ek0 = dk0 * wk0, ek1 = dk1 * wk1;       // d(normalised)
+      const float mq = wave_sum(eq0 * nq0 + eq1 * nq1) / (float)D, mk = wave_sum(ek0 * nk0 + ek1 * nk1) / (float)D;
+      if (live) {
+        const bf16x2 oq = {(bf16)(rq * (eq0 - nq0 * mq)), (bf16)(rq * (eq1 - nq1 * mq))};
+        const bf16x2 ok = {(bf16)(rk * (ek0 - nk0 * mk)), (bf16)(rk * (ek1 - nk1 * mk))};
+        *reinterpret_cast<bf16x2*>(dbase + (size_t)h * D + 2 * lane) = oq;
+        *reinterpret_cast<bf16x2*>(dbase + (size_t)(H + h) * D + 2 * lane) = ok;
+        *reinterpret_cast<bf16x2*>(dbase + (size_t)(2 * H + h) * D + 2 * lane) = dvv;
+      }
+    }
+  }
+  red[wave][0][lane] = gq0; red[wave][1][lane] = gq1; red[wave][2][lane] = gk0; red[wave][3][lane] = gk1;
+  __syncthreads();
+  if (threadIdx.x < 2 * D) {            // part[blk][0][d] = dq_weight, part[blk][1][d] = dk_weight
+    const int which = threadIdx.x / D, d = threadIdx.x - which * D;
+    const int slot = which * 2 + (d & 1), ln = d >> 1;
+    part[((size_t)blockIdx.x * 2 + which) * D + d] = (red[0][slot][ln] + red[1][slot][ln]) + (red[2][slot][ln] + red[3][slot][ln]);
+  }
+}
+__global__ void colsum2_kernel(const float* __restrict__ part, float* __restrict__ o0, float* __restrict__ o1, int nblk, int D, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * D) return;
+  const int which = i / D, d = i - which * D;
+  float a = 0.f;
+  for (int b = 0; b < nblk; b++) a += part[((size_t)b * 2 + which) * D + d];
+  float* o = which ? o1 : o0;
+  o[d] = (accumulate ? o[d] : 0.f) + a;
+}
+
 static inline int grid_for(size_t n, int block = 256, int cap = 4096) {
   size_t g = (n + block - 1) / block;
   return (int)(g > (size_t)cap ? cap : (g < 1 ? 1 : g));
@@ -184,6 +410,75 @@ extern "C" int dmvae_gated_residual_f32(void* x, const void* y, const void* mod,
   if (rows == 0) return 0;
   hipLaunchKernelGGL(gated_residual_kernel, dim3(grid_for(rows * (size_t)(c / 8))), dim3(256), 0, stream, (float*)x, (const bf16*)y, (const bf16*)mod, rows,
                      c / 8, rows_per_sample, mod_stride, gate_off);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- backward entry points -----------------------------------------------------------------------------------------------------------
+extern "C" size_t dmvae_dit_bwd_workspace(int batch, int c) {
+  const size_t a = (size_t)batch * RM_BPS * 3 * (size_t)c * sizeof(float), b = (size_t)1024 * 2 * 128 * sizeof(float);
+  return a > b ? a : b;
+}
+
+extern "C" int dmvae_gated_residual_bwd(const void* dx, const void* y, const void* mod, void* dy, void* dmod, int batch, int seq, int c, int mod_stride,
+                                        int gate_off, hipStream_t stream) {
+  DMVAE_CHECK_ARG(dx && y && mod && dy && dmod && batch > 0 && seq > 0 && c > 0 && c % 8 == 0 && gate_off >= 0 && gate_off % 8 == 0 &&
+                      mod_stride % 8 == 0 && gate_off + c <= mod_stride, "gated_residual_bwd: bad argument");
+  hipLaunchKernelGGL(gated_residual_bwd_kernel, dim3((c + 255) / 256, batch), dim3(256), 0, stream, (const float*)dx, (const bf16*)y, (const bf16*)mod,
+                     (bf16*)dy, (float*)dmod, seq, c, mod_stride, gate_off);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_swiglu_bwd(const void* dh, const void* x12, void* dx12, size_t rows, int hidden, hipStream_t stream) {
+  DMVAE_CHECK_ARG(dh && x12 && dx12 && hidden > 0 && hidden % 8 == 0, "swiglu_bwd: hidden width must be a multiple of 8 (got %d)", hidden);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (size_t)(hidden / 8))), dim3(256), 0, stream, (const bf16*)dh, (const bf16*)x12, (bf16*)dx12,
+                     rows, hidden / 8);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_rmsnorm_modulate_bwd(const void* da, const void* x, const void* w, const void* mod, void* dx_io, void* dmod, void* dw,
+                                          void* workspace, size_t workspace_bytes, int batch, int seq, int c, int mod_stride, int shift_off,
+                                          int scale_off, float eps, int accumulate, hipStream_t stream) {
+  DMVAE_CHECK_ARG(da && x && w && mod && dx_io && dmod && workspace && batch > 0 && seq > 0, "rmsnorm_modulate_bwd: bad argument");
+  DMVAE_CHECK_ARG(c % 4 == 0 && c >= 4 && c <= MAX_SWEEPS * 256, "rmsnorm_modulate_bwd: width must be a multiple of 4 up to 2048 (got %d)", c);
+  DMVAE_CHECK_ARG(scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride,
+                  "rmsnorm_modulate_bwd: modulation offsets must be multiples of 4 inside the row");
+  DMVAE_CHECK_ARG(workspace_bytes >= dmvae_dit_bwd_workspace(batch, c), "rmsnorm_modulate_bwd: workspace too small");
+  const size_t lds = (size_t)4 * 3 * c * sizeof(float);
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_modulate_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(rmsnorm_modulate_bwd_kernel, dim3(RM_BPS, batch), dim3(256), lds, stream, (const bf16*)da, (const float*)x, (const float*)w,
+                     (const bf16*)mod, (float*)dx_io, (float*)workspace, seq, c, mod_stride, scale_off, eps);
+  DMVAE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rmsnorm_modulate_bwd_final_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, (const float*)workspace, (float*)dmod, (float*)dw,
+                     batch, RM_BPS, c, mod_stride, shift_off, scale_off, accumulate);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_qknorm_rope_bwd(const void* dq, const void* dk, const void* dv, const void* qkv, const void* q_weight, const void* k_weight,
+                                     const void* cos_table, const void* sin_table, void* dqkv, void* dq_weight, void* dk_weight, void* workspace,
+                                     size_t workspace_bytes, int batch, int seq, int heads, int head_dim, int head_dim_padded, float eps, int accumulate,
+                                     hipStream_t stream) {
+  DMVAE_CHECK_ARG(dq && dk && dv && qkv && q_weight && k_weight && cos_table && sin_table && dqkv && dq_weight && dk_weight && workspace && batch > 0 &&
+                      seq > 0 && heads > 0, "qknorm_rope_bwd: bad argument");
+  DMVAE_CHECK_ARG(head_dim % 2 == 0 && head_dim >= 2 && head_dim_padded >= head_dim && head_dim_padded <= 128,
+                  "qknorm_rope_bwd: head dim must be even, padded head dim <= 128 (got %d, %d)", head_dim, head_dim_padded);
+  const int tokens = batch * seq;
+  int nblk = (tokens + 3) / 4; if (nblk > 1024) nblk = 1024;
+  DMVAE_CHECK_ARG(workspace_bytes >= (size_t)nblk * 2 * head_dim * sizeof(float), "qknorm_rope_bwd: workspace too small");
+  hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (const bf16*)qkv,
+                     (const float*)q_weight, (const float*)k_weight, (const float*)cos_table, (const float*)sin_table, (bf16*)dqkv, (float*)workspace,
+                     tokens, seq, heads, head_dim, head_dim_padded, eps);
+  DMVAE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum2_kernel, dim3((2 * head_dim + 255) / 256), dim3(256), 0, stream, (const float*)workspace, (float*)dq_weight, (float*)dk_weight,
+                     nblk, head_dim, accumulate);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -123,10 +123,16 @@ class TimestepEmbedder(nn.Module):
         self.frequency_embedding_size = frequency_embedding_size
         self.mlp = nn.Sequential(nn.Linear(frequency_embedding_size, hidden_size), nn.SiLU(), nn.Linear(hidden_size, hidden_size))
 
+    _FREQS = {}     # (half, max_period, device) -> table: computed on the CPU like the reference (:122-124), moved once (hipGraph-capturable afterwards)
+
     @staticmethod
     def timestep_embedding(t, dim, max_period=10000):
         half = dim // 2
-        freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(t.device)
+        key = (half, max_period, str(t.device))
+        freqs = TimestepEmbedder._FREQS.get(key)
+        if freqs is None:
+            freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(t.device)
+            TimestepEmbedder._FREQS[key] = freqs
         args = t[:, None].float() * freqs[None]
         emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
         if dim % 2:

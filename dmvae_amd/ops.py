@@ -538,6 +538,55 @@ def gated_residual_(x: torch.Tensor, y: torch.Tensor, mod: torch.Tensor, gate_of
     return x
 
 
+def gated_residual_bwd(dx: torch.Tensor, y: torch.Tensor, mod: torch.Tensor, dmod: torch.Tensor, gate_off: int) -> torch.Tensor:
+    """-> dy = bf16(gate[b] * dx); fills dmod[:, gate_off : gate_off + C] (f32) with sum_n dx * y."""
+    dx = _req(dx, f32, "dx"); y = _req(y, bf16, "y"); mod = _req(mod, bf16, "mod"); dmod = _req(dmod, f32, "dmod")
+    b, n, c = dx.shape
+    dy = torch.empty_like(y)
+    check(_lib.lib().dmvae_gated_residual_bwd(dx.data_ptr(), y.data_ptr(), mod.data_ptr(), dy.data_ptr(), dmod.data_ptr(), b, n, c, mod.shape[1],
+                                              int(gate_off), _stream()), "gated_residual_bwd")
+    return dy
+
+
+def swiglu_bwd(dh: torch.Tensor, x12: torch.Tensor) -> torch.Tensor:
+    dh = _req(dh, bf16, "dh"); x12 = _req(x12, bf16, "x12")
+    hid = x12.shape[-1] // 2
+    dx12 = torch.empty_like(x12)
+    check(_lib.lib().dmvae_swiglu_bwd(dh.data_ptr(), x12.data_ptr(), dx12.data_ptr(), x12.numel() // (2 * hid), hid, _stream()), "swiglu_bwd")
+    return dx12
+
+
+def rmsnorm_modulate_bwd_(dx_io: torch.Tensor, da: torch.Tensor, x: torch.Tensor, w: torch.Tensor, mod: torch.Tensor, dmod: torch.Tensor,
+                          shift_off: int, scale_off: int, eps: float = 1e-6, dw_out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """dx_io (f32, in place) += backward of rmsnorm_modulate at x; fills the shift / scale chunks of dmod; returns dw [C] f32."""
+    dx_io = _req(dx_io, f32, "dx_io"); da = _req(da, bf16, "da"); x = _req(x, f32, "x"); mod = _req(mod, bf16, "mod"); dmod = _req(dmod, f32, "dmod")
+    b, n, c = x.shape
+    L = _lib.lib()
+    ws = workspace(L.dmvae_dit_bwd_workspace(b, c), x.device)
+    dw = dw_out if dw_out is not None else torch.empty(c, dtype=f32, device=x.device)
+    check(L.dmvae_rmsnorm_modulate_bwd(da.data_ptr(), x.data_ptr(), _req(w, f32, "w").data_ptr(), mod.data_ptr(), dx_io.data_ptr(), dmod.data_ptr(),
+                                       dw.data_ptr(), ws.data_ptr(), ws.numel(), b, n, c, mod.shape[1], int(shift_off), int(scale_off), float(eps),
+                                       int(accumulate), _stream()), "rmsnorm_modulate_bwd")
+    return dw
+
+
+def qknorm_rope_bwd(dq, dk, dv, qkv, qw, kw, cos, sin, heads: int, eps: float = 1e-6, dqw_out=None, dkw_out=None, accumulate: bool = False):
+    """-> (dqkv [B,N,3*H*D] bf16, dq_weight [D], dk_weight [D])."""
+    dq = _req(dq, bf16, "dq"); dk = _req(dk, bf16, "dk"); dv = _req(dv, bf16, "dv"); qkv = _req(qkv, bf16, "qkv")
+    b, n, c3 = qkv.shape
+    d = c3 // 3 // heads
+    dp = dq.shape[-1]
+    L = _lib.lib()
+    ws = workspace(L.dmvae_dit_bwd_workspace(b, c3 // 3), qkv.device)
+    dqkv = torch.empty_like(qkv)
+    dqw = dqw_out if dqw_out is not None else torch.empty(d, dtype=f32, device=qkv.device)
+    dkw = dkw_out if dkw_out is not None else torch.empty(d, dtype=f32, device=qkv.device)
+    check(L.dmvae_qknorm_rope_bwd(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), qkv.data_ptr(), _req(qw, f32, "qw").data_ptr(), _req(kw, f32, "kw").data_ptr(),
+                                  _req(cos, f32, "cos").data_ptr(), _req(sin, f32, "sin").data_ptr(), dqkv.data_ptr(), dqw.data_ptr(), dkw.data_ptr(),
+                                  ws.data_ptr(), ws.numel(), b, n, heads, d, dp, float(eps), int(accumulate), _stream()), "qknorm_rope_bwd")
+    return dqkv, dqw, dkw
+
+
 # ---- losses ---------------------------------------------------------------------------------------
 def _loss_ws(device) -> torch.Tensor:
     return workspace(_lib.lib().dmvae_loss_workspace(), device, slot="loss")

@@ -225,6 +225,25 @@ int dmvae_qknorm_rope_bf16(const void* qkv, const void* q_weight, const void* k_
 int dmvae_swiglu_bf16(const void* x12, void* out, size_t rows, int hidden, dmvae_stream_t stream);
 int dmvae_gated_residual_f32(void* x, const void* y, const void* mod, size_t rows, int rows_per_sample, int c, int mod_stride, int gate_off,
                              dmvae_stream_t stream);
+/* Backward side of the four kernels above (the student's training turn, train_dmd.py:565-575).  dmod: f32 [B][mod_stride], each call fills the
+ * chunk(s) it owns (d shift / d scale / d gate = sums over the sample's tokens).  workspace: dmvae_dit_bwd_workspace(batch, c) bytes.
+ * gated_residual_bwd: dy = bf16(gate[b] * dx), dmod[gate] = sum_n dx * y.
+ * swiglu_bwd: dx12 = [dh * x2 * silu'(x1) | dh * bf16(silu(x1))].
+ * rmsnorm_modulate_bwd: dx_io (f32) += RMSNorm backward of da * w * bf16(1 + scale); dmod[shift] = sum_n da (skipped when shift_off < 0),
+ *   dmod[scale] = sum_n da * n * w, dw (+)= sum_rows da * bf16(1 + scale) * n   (dw may be NULL).
+ * qknorm_rope_bwd: (dq, dk [B*H][N][Dp], dv [B*H][N][D]) -> dqkv [B][N][3][H][D] bf16 through the transposed rotation and the per-head RMSNorm;
+ *   dq_weight / dk_weight [D] f32 (accumulate != 0 adds). */
+size_t dmvae_dit_bwd_workspace(int batch, int c);
+int dmvae_gated_residual_bwd(const void* dx, const void* y, const void* mod, void* dy, void* dmod, int batch, int seq, int c, int mod_stride,
+                             int gate_off, dmvae_stream_t stream);
+int dmvae_swiglu_bwd(const void* dh, const void* x12, void* dx12, size_t rows, int hidden, dmvae_stream_t stream);
+int dmvae_rmsnorm_modulate_bwd(const void* da, const void* x, const void* w, const void* mod, void* dx_io, void* dmod, void* dw, void* workspace,
+                               size_t workspace_bytes, int batch, int seq, int c, int mod_stride, int shift_off, int scale_off, float eps,
+                               int accumulate, dmvae_stream_t stream);
+int dmvae_qknorm_rope_bwd(const void* dq, const void* dk, const void* dv, const void* qkv, const void* q_weight, const void* k_weight,
+                          const void* cos_table, const void* sin_table, void* dqkv, void* dq_weight, void* dk_weight, void* workspace,
+                          size_t workspace_bytes, int batch, int seq, int heads, int head_dim, int head_dim_padded, float eps, int accumulate,
+                          dmvae_stream_t stream);
 
 /* ---- losses (HBM-bound reductions) ------------------------------------------------------------- */
 

@@ -119,3 +119,75 @@ def test_lightningdit_xl1_fast_forward_shapes_and_determinism():
         s = m.forward_stock(x, t, y)
     assert a.shape == (16, 32, 16, 16) and torch.isfinite(a).all() and torch.equal(a, b)
     assert _rl2(a.float(), s.float()) < 3e-2
+
+
+@pytest.mark.parametrize("c,n", [(1152, 256), (128, 64), (144, 40)])
+def test_dit_backward_kernels(c, n):
+    """gated_residual_bwd, swiglu_bwd and rmsnorm_modulate_bwd against fp64 autograd of their forward definitions (straight-through at the
+    forward's bf16 rounding sites)."""
+    from dmvae_amd import ops
+    g = torch.Generator().manual_seed(c + n)
+    b = 3
+    x = (torch.randn(b, n, c, generator=g) * 2).to(DEV)
+    w = (1 + 0.3 * torch.randn(c, generator=g)).to(DEV)
+    mod = (0.5 * torch.randn(b, 6 * c, generator=g)).to(DEV).to(BF)
+    da = torch.randn(b, n, c, generator=g).to(DEV).to(BF)
+    dres = torch.randn(b, n, c, generator=g).to(DEV)
+    # rmsnorm_modulate
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    shr, scr = mod[:, :c].double().requires_grad_(True), mod[:, c:2 * c].double().requires_grad_(True)
+    nrm = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6) * wr
+    m_ = (1 + scr)
+    m_ = m_ + ((1 + mod[:, c:2 * c].float()).to(BF).double() - m_).detach()                 # forward value = bf16(1 + scale), gradient straight through
+    (nrm * m_.unsqueeze(1) + shr.unsqueeze(1)).backward(da.double())
+    dmod = torch.zeros(b, 6 * c, device=DEV)
+    dx = dres.clone()
+    dw = ops.rmsnorm_modulate_bwd_(dx, da, x, w, mod, dmod, 0, c)
+    assert rel_err(dx, dres.double() + xr.grad) < 2e-6
+    assert rel_err(dw, wr.grad) < 1e-5
+    assert rel_err(dmod[:, :c], shr.grad) < 1e-5 and rel_err(dmod[:, c:2 * c], scr.grad) < 1e-5
+    assert float(dmod[:, 2 * c:].abs().max()) == 0.0
+    # gated residual
+    y = torch.randn(b, n, c, generator=g).to(DEV).to(BF)
+    dmod2 = torch.zeros(b, 6 * c, device=DEV)
+    dy = ops.gated_residual_bwd(dres, y, mod, dmod2, 2 * c)
+    assert torch.equal(dy, (mod[:, 2 * c:3 * c].float().unsqueeze(1) * dres).to(BF))
+    assert rel_err(dmod2[:, 2 * c:3 * c], (dres.double() * y.double()).sum(1)) < 1e-5
+    # swiglu
+    hid = 2 * c
+    x12 = torch.randn(b * n, 2 * hid, generator=g).to(DEV).to(BF)
+    dh = torch.randn(b * n, hid, generator=g).to(DEV).to(BF)
+    xr = x12.double().requires_grad_(True)
+    (F.silu(xr[:, :hid]) * xr[:, hid:]).backward(dh.double())
+    assert _rl2(ops.swiglu_bwd(dh, x12), xr.grad) < 4e-3
+
+
+@pytest.mark.parametrize("heads,d", [(16, 72), (2, 64)])
+def test_qknorm_rope_bwd_kernel(heads, d):
+    from dmvae_amd import ops
+    from dmvae_amd.models.lightningdit import RMSNorm, VisionRotaryEmbeddingFast
+    g = torch.Generator().manual_seed(d + 1)
+    b, side = 2, 8
+    n = side * side
+    qkv = torch.randn(b, n, 3 * heads * d, generator=g).to(DEV).to(BF)
+    rope = VisionRotaryEmbeddingFast(dim=d // 2, pt_seq_len=side).to(DEV).double()
+    qn, kn = RMSNorm(d).to(DEV).double(), RMSNorm(d).to(DEV).double()
+    with torch.no_grad():
+        qn.weight.uniform_(0.5, 1.5); kn.weight.uniform_(0.5, 1.5)
+    dp = (d + 31) // 32 * 32
+    dq = torch.zeros(b * heads, n, dp, device=DEV, dtype=BF); dk = torch.zeros_like(dq)
+    dq[..., :d] = torch.randn(b * heads, n, d, generator=g).to(DEV).to(BF); dk[..., :d] = torch.randn(b * heads, n, d, generator=g).to(DEV).to(BF)
+    dv = torch.randn(b * heads, n, d, generator=g).to(DEV).to(BF)
+    x = qkv.double().requires_grad_(True)
+    q5 = x.view(b, n, 3, heads, d).permute(2, 0, 3, 1, 4)
+
+    def norm_ste(t, mod_):      # RMSNorm with the forward's bf16 rounding of the normalised value (rms_norm.py:75), gradient straight through
+        nh = t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-6)
+        return (nh + (nh.float().to(BF).double() - nh).detach()) * mod_.weight
+    qq, kk = rope(norm_ste(q5[0], qn)), rope(norm_ste(q5[1], kn))
+    loss = (qq.reshape(b * heads, n, d) * dq[..., :d].double()).sum() + (kk.reshape(b * heads, n, d) * dk[..., :d].double()).sum() + \
+        (q5[2].reshape(b * heads, n, d) * dv.double()).sum()
+    loss.backward()
+    dqkv, dqw, dkw = ops.qknorm_rope_bwd(dq, dk, dv, qkv, qn.weight.detach().float(), kn.weight.detach().float(), rope.freqs_cos.float(), rope.freqs_sin.float(), heads)
+    assert _rl2(dqkv, x.grad) < 4e-3                                             # bf16 result
+    assert _rl2(dqw, qn.weight.grad) < 2e-3 and _rl2(dkw, kn.weight.grad) < 2e-3   # the forward's bf16-rounded normalised value enters the weight gradient
