@@ -542,6 +542,87 @@ class LayerNormBf16Fn(torch.autograd.Function):
         return dt, dw, db, None
 
 
+# ---- LightningDiT block with gradients (the student's training turn, train_dmd.py:565-575) -------------------------------------------
+class DitBlockFn(torch.autograd.Function):
+    """LightningDiTBlock.forward (lightningdit.py:236-250) on the f32 residual stream h [B,N,C] with the adaLN chunks `mod` [B,6C] (bf16, computed by
+    stock autograd outside): forward = the inference path's kernels (csrc/dit.hip), backward = their backward kernels, the GEMM-composed
+    attention backward and `_lin_grads` for the four Linear layers.  Returns the new residual stream; gradients flow to h, mod and all block
+    parameters."""
+
+    @staticmethod
+    def forward(ctx, h, mod, n1w, qkvw, qkvb, qnw, knw, pw, pb, n2w, w12w, w12b, w3w, w3b, cos, sin, heads, eps):
+        import torch.nn.functional as F
+        b, n, c = h.shape
+        d = c // heads
+        mod = _c(mod)
+        a1 = ops.rmsnorm_modulate(h, n1w, mod, 0, c, eps)
+        qkv = F.linear(a1, _bf(qkvw), _bf(qkvb))
+        q, k, v = ops.qknorm_rope(qkv, qnw, knw, cos, sin, heads, eps)
+        p = ops.softmax_rows(ops.gemm_nt(q, k, out_f32=True), d ** -0.5)
+        o = ops.gemm_nt(p, ops.transpose_last2(v)).view(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, c)
+        o2 = F.linear(o, _bf(pw), _bf(pb))
+        h_mid = ops.gated_residual_(h.clone(), o2, mod, 2 * c)
+        a2 = ops.rmsnorm_modulate(h_mid, n2w, mod, 3 * c, 4 * c, eps)
+        x12 = F.linear(a2, _bf(w12w), _bf(w12b))
+        g = ops.swiglu(x12)
+        o3 = F.linear(g, _bf(w3w), _bf(w3b))
+        h_out = ops.gated_residual_(h_mid.clone(), o3, mod, 5 * c)
+        ctx.save_for_backward(h, mod, a1, qkv, q, k, v, p, o, o2, h_mid, a2, x12, g, o3, n1w, qkvw, qnw, knw, pw, n2w, w12w, w3w, cos, sin)
+        ctx.others = (qkvb, pb, w12b, w3b, heads, eps)
+        return h_out
+
+    @staticmethod
+    def backward(ctx, dh_out):
+        import torch.nn.functional as F
+        h, mod, a1, qkv, q, k, v, p, o, o2, h_mid, a2, x12, g, o3, n1w, qkvw, qnw, knw, pw, n2w, w12w, w3w, cos, sin = ctx.saved_tensors
+        qkvb, pb, w12b, w3b, heads, eps = ctx.others
+        b, n, c = h.shape
+        d, rows = c // heads, b * n
+        dp_ = q.shape[-1]
+        dt = dh_out.float().clone()                                 # becomes d(h_mid), then d(h)
+        dmod = torch.zeros(b, mod.shape[1], dtype=f32, device=h.device)
+        # MLP branch
+        do3 = ops.gated_residual_bwd(dt, o3, mod, dmod, 5 * c)
+        dg, dw3, db3 = _lin_grads(do3.view(rows, c), g.view(rows, -1), w3w, w3b)
+        dx12 = ops.swiglu_bwd(dg.view_as(g), x12)
+        da2, dw12, db12 = _lin_grads(dx12.view(rows, -1), a2.view(rows, c), w12w, w12b)
+        dn2w = ops.rmsnorm_modulate_bwd_(dt, da2.view(b, n, c), h_mid, n2w, mod, dmod, 3 * c, 4 * c, eps, dw_out=_dst(n2w))
+        # attention branch
+        do2 = ops.gated_residual_bwd(dt, o2, mod, dmod, 2 * c)
+        do, dpw, dpb = _lin_grads(do2.view(rows, c), o.view(rows, c), pw, pb)
+        do_h = do.view(b, n, heads, d).permute(0, 2, 1, 3).reshape(b * heads, n, d)
+        pad = dp_ - d                                                   # head dim padded to the GEMM kernel's 32-wide K step (72 -> 96)
+        do_p, v_p = (F.pad(do_h, (0, pad)), F.pad(v, (0, pad))) if pad else (do_h.contiguous(), v)
+        ds = ops.softmax_rows_bwd(ops.gemm_nt(do_p, v_p, out_f32=True), p, d ** -0.5)
+        dv = ops.gemm_tn(p, do_h.contiguous())                          # [B*H, key, D]
+        dq = ops.gemm_nt(ds, ops.transpose_last2(k))                    # [B*H, N, Dp]
+        dk = ops.gemm_tn(ds, q)
+        dqkv, dqnw, dknw = ops.qknorm_rope_bwd(dq, dk, dv, qkv, qnw, knw, cos, sin, heads, eps, dqw_out=_dst(qnw), dkw_out=_dst(knw))
+        da1, dqkvw, dqkvb = _lin_grads(dqkv.view(rows, 3 * c), a1.view(rows, c), qkvw, qkvb)
+        dn1w = ops.rmsnorm_modulate_bwd_(dt, da1.view(b, n, c), h, n1w, mod, dmod, 0, c, eps, dw_out=_dst(n1w))
+        return (dt, dmod.to(mod.dtype), dn1w, dqkvw, dqkvb, dqnw, dknw, dpw, dpb, dn2w, dw12, db12, dw3, db3, None, None, None, None)
+
+
+class RmsnormModulateFn(torch.autograd.Function):
+    """bf16( RMSNorm(h) * bf16(1 + scale) + shift ) with gradients to h, the norm weight and the adaLN chunks (FinalLayer, lightningdit.py:266-273)."""
+
+    @staticmethod
+    def forward(ctx, h, w, mod, shift_off, scale_off, eps):
+        mod = _c(mod)
+        ctx.save_for_backward(h, w, mod)
+        ctx.cfg = (shift_off, scale_off, eps)
+        return ops.rmsnorm_modulate(h, w, mod, shift_off, scale_off, eps)
+
+    @staticmethod
+    def backward(ctx, da):
+        h, w, mod = ctx.saved_tensors
+        shift_off, scale_off, eps = ctx.cfg
+        dt = torch.zeros_like(h)
+        dmod = torch.zeros(mod.shape, dtype=f32, device=h.device)
+        dw = ops.rmsnorm_modulate_bwd_(dt, _c(da).to(bf16), h, w, mod, dmod, shift_off, scale_off, eps, dw_out=_dst(w))
+        return dt, dw, dmod.to(mod.dtype), None, None, None
+
+
 def to_nhwc_bf16(x: torch.Tensor) -> torch.Tensor:
     """NCHW (any float dtype) -> NHWC bf16 contiguous, differentiable (boundary plumbing)."""
     return x.permute(0, 2, 3, 1).contiguous().to(bf16)

@@ -7,8 +7,10 @@ Two routes through `forward`:
   * no gradients needed (the four teacher / student evaluations inside the DMD loss, train_dmd.py:211-217; sampling) on a GPU at a shape
     the kernels cover -> `lightningdit_fast.forward_inference`: RMSNorm + adaLN modulate, QK-norm + RoPE, SwiGLU gate and the gated
     residual on HIP kernels (csrc/dit.hip), GEMMs through the library, attention on the conv kernel's batched-GEMM path;
-  * otherwise (the student's own training turn, CPU, unusual shapes) -> the stock PyTorch modules below, which also define the parameters.
-SURVEY.md 8(f) rank 3; forward only -- the student's backward runs through stock autograd."""
+  * gradients needed (the student's own training turn, train_dmd.py:565-575) on such a GPU shape -> `lightningdit_fast.forward_train`: one autograd
+    Function per block (`functional.DitBlockFn`) over the same kernels and their backward counterparts;
+  * otherwise (CPU, no autocast, unusual shapes) -> the stock PyTorch modules below, which also define the parameters.
+SURVEY.md 8(f) rank 3."""
 from __future__ import annotations
 
 import math
@@ -281,9 +283,11 @@ class LightningDiT(nn.Module):
         return torch.einsum("nhwpqc->nchpwq", x).reshape(x.shape[0], c, h * p, h * p)
 
     def forward(self, x, t=None, y=None):
-        if x.is_cuda and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+        if x.is_cuda:
             from . import lightningdit_fast
             if lightningdit_fast.supported(self, x):
+                if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                    return lightningdit_fast.forward_train(self, x, t, y)        # autograd Functions over csrc/dit.hip
                 return lightningdit_fast.forward_inference(self, x, t, y)
         return self.forward_stock(x, t, y)
 

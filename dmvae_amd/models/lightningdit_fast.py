@@ -71,3 +71,28 @@ def forward_inference(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) 
     if model.learn_sigma:
         out, _ = out.chunk(2, dim=1)
     return out
+
+
+def forward_train(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """`forward` with gradients (the student's flow-matching turn, train_dmd.py:565-575) under the caller's autocast(bf16): embedders, adaLN Linears
+    and the output Linear through stock autograd (per-sample or single GEMMs), every block as one `functional.DitBlockFn`, the final norm as
+    `RmsnormModulateFn`.  Label dropout as in the module (`y_embedder(y, model.training)`)."""
+    from ..functional import DitBlockFn, RmsnormModulateFn
+    b, cin, hh, ww = x.shape
+    ps, c, heads = model.patch_size, model.hidden_size, model.num_heads
+    w = model.x_embedder.proj.weight
+    patches = x.view(b, cin, hh // ps, ps, ww // ps, ps).permute(0, 2, 4, 1, 3, 5).reshape(b, -1, cin * ps * ps)
+    h = (F.linear(patches, w.view(w.shape[0], -1), model.x_embedder.proj.bias).float() + model.pos_embed).contiguous()
+    cvec = model.t_embedder(t) + model.y_embedder(y, model.training)
+    rope = model.feat_rope
+    for blk in model.blocks:
+        mod = blk.adaLN_modulation(cvec)                                          # [B, 6C] bf16 under autocast, stock autograd
+        h = DitBlockFn.apply(h, mod, blk.norm1.weight, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.q_norm.weight, blk.attn.k_norm.weight,
+                             blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.mlp.w12.weight, blk.mlp.w12.bias, blk.mlp.w3.weight,
+                             blk.mlp.w3.bias, rope.freqs_cos, rope.freqs_sin, heads, blk.norm1.eps)
+    fl = model.final_layer
+    a = RmsnormModulateFn.apply(h, fl.norm_final.weight, fl.adaLN_modulation(cvec), 0, c, fl.norm_final.eps)
+    out = model.unpatchify(fl.linear(a))
+    if model.learn_sigma:
+        out, _ = out.chunk(2, dim=1)
+    return out

@@ -191,3 +191,45 @@ def test_qknorm_rope_bwd_kernel(heads, d):
     dqkv, dqw, dkw = ops.qknorm_rope_bwd(dq, dk, dv, qkv, qn.weight.detach().float(), kn.weight.detach().float(), rope.freqs_cos.float(), rope.freqs_sin.float(), heads)
     assert _rl2(dqkv, x.grad) < 4e-3                                             # bf16 result
     assert _rl2(dqw, qn.weight.grad) < 2e-3 and _rl2(dkw, kn.weight.grad) < 2e-3   # the forward's bf16-rounded normalised value enters the weight gradient
+
+
+@pytest.mark.parametrize("tag", ["dit_small_hd64", "dit_small_hd72"])
+def test_lightningdit_train_route_matches_stock_autocast(tag):
+    """forward with gradients on the HIP kernels (functional.DitBlockFn) vs the stock modules under autocast(bf16) on the same weights: output, input
+    gradient and every parameter gradient; and both as close to the reference's f32 gradients (fixture) as each other."""
+    import copy
+    g = load_golden(tag)
+    m = build(tag, g).to(DEV)
+    ref = copy.deepcopy(m)
+    x, t, y = g.t("x").to(DEV), g.t("t").to(DEV), torch.from_numpy(np.asarray(g["y"])).to(DEV)
+    dy = g.t("dy").to(DEV)
+    xa = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=BF):
+        out = m(xa, t, y)                                                        # grad enabled + trainable parameters: lightningdit_fast.forward_train
+    (out.float() * dy).sum().backward()
+    xb = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=BF):
+        outs = ref.forward_stock(xb, t, y)
+    (outs.float() * dy).sum().backward()
+    assert _rl2(out.float(), outs.float()) < 1e-2
+    assert _rl2(xa.grad, xb.grad) < 3e-2
+    pa, pb = dict(m.named_parameters()), dict(ref.named_parameters())
+    worst_hip = worst_stock = 0.0
+    for n_, p in pa.items():
+        if n_ == "pos_embed":
+            continue
+        assert p.grad is not None, n_
+        assert _rl2(p.grad, pb[n_].grad) < 4e-2, (n_, _rl2(p.grad, pb[n_].grad))
+        if "g." + n_ in g:
+            worst_hip = max(worst_hip, _rl2(p.grad.cpu(), g.t("g." + n_)))
+            worst_stock = max(worst_stock, _rl2(pb[n_].grad.cpu(), g.t("g." + n_)))
+    print(f"{tag}: worst rel-L2 of the captured parameter gradients to the f32 reference -- HIP {worst_hip:.2e}, stock autocast {worst_stock:.2e}")
+    assert worst_hip < 1.5 * worst_stock + 5e-3
+    assert _rl2(xa.grad.cpu(), g.t("dx")) < 1.5 * _rl2(xb.grad.cpu(), g.t("dx")) + 5e-3
+    # deterministic
+    m.zero_grad(set_to_none=True)
+    xc = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=BF):
+        out2 = m(xc, t, y)
+    (out2.float() * dy).sum().backward()
+    assert torch.equal(out, out2) and torch.equal(xa.grad, xc.grad)
