@@ -310,7 +310,7 @@ int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_o
   const int ups = d->upsample ? 1 : 0;
   const int wo = ups ? 2 * d->w : d->w;
   const long long M = (long long)d->n * d->h * d->w * (ups ? 4 : 1);
-  if (d->cin % 128 != 0 || d->cout % 128 != 0 || wo % 32 != 0 || M < 8192) return 0;
+  if (d->cin % 128 != 0 || d->cout % 128 != 0 || wo % 32 != 0 || M < 4096) return 0;
   if ((long long)M * d->cout * 2 >= (1ll << 31) || (long long)d->n * d->h * d->w * d->cin * 2 + (1ll << 22) >= (1ll << 31)) return 0;
   const int T = d->ks * d->ks;
   const int ngroups = T * (d->cin / 128);

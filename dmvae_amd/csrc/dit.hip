@@ -199,7 +199,7 @@ __global__ void swiglu_bwd_kernel(const bf16* __restrict__ dh, const bf16* __res
 // a = bf16( n * w * m + shift ),  n = x * rs,  m = bf16(1 + scale[b]):
 //   dx += rs * (g - n * mean(g * n)),  g = da * w * m;   dshift[b] = sum_n da;   dscale[b] = sum_n da * n * w;   dw = sum_rows da * m * n.
 // grid (BPS, B): the block's 4 waves walk the rows of sample b; part: [B][BPS][3][C] (dshift, dscale, dw contributions of the block)
-constexpr int RM_BPS = 8;
+constexpr int RM_BPS = 32;   // blocks per sample: 4 waves x 2 rows each at N = 256 tokens
 __global__ __launch_bounds__(256) void rmsnorm_modulate_bwd_kernel(const bf16* __restrict__ da, const float* __restrict__ x, const float* __restrict__ w,
                                                                    const bf16* __restrict__ mod, float* __restrict__ dx_io, float* __restrict__ part,
                                                                    int N, int C, int stride, int scale_off, float eps) {
@@ -272,23 +272,27 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_bwd_kernel(const bf16* _
   for (int i = threadIdx.x; i < 3 * C; i += 256)
     po[i] = (red[0 * 3 * C + i] + red[1 * 3 * C + i]) + (red[2 * 3 * C + i] + red[3 * 3 * C + i]);
 }
-// second stage: dmod[b][shift_off + c] = sum_blk part[b][blk][0][c] (skipped when shift_off < 0), dmod[b][scale_off + c] = ... [1] ...;
-// dw[c] (+)= sum_b sum_blk part[b][blk][2][c]
-__global__ void rmsnorm_modulate_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dmod, float* __restrict__ dw, int B, int bps, int C,
-                                                  int stride, int shift_off, int scale_off, int accumulate) {
+// second stage, grid (C/256, B): dmod[b][shift_off + c] = sum_blk part[b][blk][0][c] (skipped when shift_off < 0), dmod[b][scale_off + c] = ... [1] ...;
+// wpart[b][c] = sum_blk part[b][blk][2][c];  third stage: dw[c] (+)= sum_b wpart[b][c]
+__global__ void rmsnorm_modulate_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dmod, float* __restrict__ wpart, int bps, int C,
+                                                  int stride, int shift_off, int scale_off) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < bps; k++) {
+    const float* q = part + ((size_t)b * bps + k) * 3 * C;
+    s0 += q[c]; s1 += q[C + c]; s2 += q[2 * C + c];
+  }
+  if (shift_off >= 0) dmod[(size_t)b * stride + shift_off + c] = s0;
+  dmod[(size_t)b * stride + scale_off + c] = s1;
+  wpart[(size_t)b * C + c] = s2;
+}
+__global__ void rmsnorm_modulate_bwd_weight_kernel(const float* __restrict__ wpart, float* __restrict__ dw, int B, int C, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float wsum = 0.f;
-  for (int b = 0; b < B; b++) {
-    float s0 = 0.f, s1 = 0.f;
-    for (int k = 0; k < bps; k++) {
-      const float* q = part + ((size_t)b * bps + k) * 3 * C;
-      s0 += q[c]; s1 += q[C + c]; wsum += q[2 * C + c];
-    }
-    if (shift_off >= 0) dmod[(size_t)b * stride + shift_off + c] = s0;
-    dmod[(size_t)b * stride + scale_off + c] = s1;
-  }
-  if (dw) dw[c] = (accumulate ? dw[c] : 0.f) + wsum;
+  float a = 0.f;
+  for (int b = 0; b < B; b++) a += wpart[(size_t)b * C + c];
+  dw[c] = (accumulate ? dw[c] : 0.f) + a;
 }
 
 // Backward of qknorm_rope: dq', dk' [B*H][N][Dp] bf16 (w.r.t. the rotated, normalised q / k), dv [B*H][N][D] -> dqkv [B][N][3][H][D] bf16 and the
@@ -416,7 +420,7 @@ extern "C" int dmvae_gated_residual_f32(void* x, const void* y, const void* mod,
 
 // ---- backward entry points -----------------------------------------------------------------------------------------------------------
 extern "C" size_t dmvae_dit_bwd_workspace(int batch, int c) {
-  const size_t a = (size_t)batch * RM_BPS * 3 * (size_t)c * sizeof(float), b = (size_t)1024 * 2 * 128 * sizeof(float);
+  const size_t a = ((size_t)batch * RM_BPS * 3 + batch) * (size_t)c * sizeof(float), b = (size_t)1024 * 2 * 128 * sizeof(float);
   return a > b ? a : b;
 }
 
@@ -456,9 +460,14 @@ extern "C" int dmvae_rmsnorm_modulate_bwd(const void* da, const void* x, const v
   hipLaunchKernelGGL(rmsnorm_modulate_bwd_kernel, dim3(RM_BPS, batch), dim3(256), lds, stream, (const bf16*)da, (const float*)x, (const float*)w,
                      (const bf16*)mod, (float*)dx_io, (float*)workspace, seq, c, mod_stride, scale_off, eps);
   DMVAE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rmsnorm_modulate_bwd_final_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, (const float*)workspace, (float*)dmod, (float*)dw,
-                     batch, RM_BPS, c, mod_stride, shift_off, scale_off, accumulate);
+  float* wpart = (float*)workspace + (size_t)batch * RM_BPS * 3 * c;
+  hipLaunchKernelGGL(rmsnorm_modulate_bwd_final_kernel, dim3((c + 255) / 256, batch), dim3(256), 0, stream, (const float*)workspace, (float*)dmod, wpart,
+                     RM_BPS, c, mod_stride, shift_off, scale_off);
   DMVAE_CHECK_LAUNCH();
+  if (dw) {
+    hipLaunchKernelGGL(rmsnorm_modulate_bwd_weight_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, wpart, (float*)dw, batch, c, accumulate);
+    DMVAE_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -471,7 +480,7 @@ extern "C" int dmvae_qknorm_rope_bwd(const void* dq, const void* dk, const void*
   DMVAE_CHECK_ARG(head_dim % 2 == 0 && head_dim >= 2 && head_dim_padded >= head_dim && head_dim_padded <= 128,
                   "qknorm_rope_bwd: head dim must be even, padded head dim <= 128 (got %d, %d)", head_dim, head_dim_padded);
   const int tokens = batch * seq;
-  int nblk = (tokens + 3) / 4; if (nblk > 1024) nblk = 1024;
+  int nblk = (tokens + 3) / 4; if (nblk > 256) nblk = 256;   // one block per CU; the second stage sums nblk partials per weight serially
   DMVAE_CHECK_ARG(workspace_bytes >= (size_t)nblk * 2 * head_dim * sizeof(float), "qknorm_rope_bwd: workspace too small");
   hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (const bf16*)qkv,
                      (const float*)q_weight, (const float*)k_weight, (const float*)cos_table, (const float*)sin_table, (bf16*)dqkv, (float*)workspace,
