@@ -25,6 +25,12 @@ def bump_weight_epoch() -> None:
     _EPOCH[0] += 1
 
 
+def _epoch_of(w) -> int:
+    """Update counter of the flat buffer that owns `w` (optim.FlatParams tags its parameters), else the global one: an optimiser step on one
+    model must not invalidate the cached bf16 operands of another (the frozen DiT teacher next to the training student)."""
+    return getattr(w, "_dmvae_epoch", _EPOCH)[0]
+
+
 def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad: int = 0, frozen: bool = False,
            transposed: bool = False) -> torch.Tensor:
     """bf16 kernel operand of an f32 conv/linear weight, cached ON the parameter object until the weight changes
@@ -38,7 +44,7 @@ def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad
         except AttributeError:      # non-leaf views etc.: no caching
             pass
     key = (for_dgrad, rows_pad, cols_pad, transposed)
-    ver = (w.data_ptr(), w._version, -1 if frozen else _EPOCH[0])
+    ver = (w.data_ptr(), w._version, -1 if frozen else _epoch_of(w))
     hit = cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
@@ -422,7 +428,7 @@ class MLPFn(torch.autograd.Function):
 def _bf(w: torch.Tensor) -> torch.Tensor:
     """bf16 copy of an f32 Linear parameter -- what autocast(bf16) feeds the GEMM -- cached until the parameter changes."""
     cache = getattr(w, "_dmvae_bf16", None)
-    ver = (w.data_ptr(), w._version, _EPOCH[0])
+    ver = (w.data_ptr(), w._version, _epoch_of(w))
     if cache is not None and cache[0] == ver:
         return cache[1]
     v = w.detach().to(bf16)

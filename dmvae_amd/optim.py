@@ -31,23 +31,34 @@ class FlatParams:
             p.data = self.flat[off:off + p.numel()].view(p.shape)
             p.grad = self.grad[off:off + p.numel()].view(p.shape)
         self.ema = self.flat.clone() if with_ema else None
+        self.epoch = [0]                      # bumped whenever the flat buffer is updated through raw pointers (functional.packed / _bf caches)
+        for p in self.params:
+            p._dmvae_epoch = self.epoch
 
     def zero_grad(self):
         self.grad.zero_()
 
-    def enable_direct_grads(self) -> None:
+    def enable_direct_grads(self, only=None) -> None:
         """The HIP backward Functions (dmvae_amd.functional) then WRITE each parameter gradient straight into its slice of the
         flat buffer and hand that view to autograd, instead of returning a fresh tensor that AccumulateGrad adds into `.grad`
         (193 small add kernels + one memset per step for the tokenizer).  Requires every parameter to receive exactly one
         gradient per backward (true for the decoder / bottleneck); call `begin_step()` before each backward."""
+        ids = None if only is None else {id(p) for p in only}
         for p, off in zip(self.params, self.offsets):
-            p._dmvae_grad_view = self.grad[off:off + p.numel()].view(p.shape)
+            if ids is None or id(p) in ids:
+                p._dmvae_grad_view = self.grad[off:off + p.numel()].view(p.shape)
         self.direct = True
+        self.partial = ids is not None        # the other parameters keep accumulating into their (zeroed) flat views through autograd
 
     def begin_step(self) -> None:
         if getattr(self, "direct", False):
-            for p in self.params:
-                p.grad = None          # autograd adopts the returned flat-buffer view (no accumulation kernel)
+            if getattr(self, "partial", False):
+                self.grad.zero_()
+            for p, off in zip(self.params, self.offsets):
+                if hasattr(p, "_dmvae_grad_view"):
+                    p.grad = None      # autograd adopts the returned flat-buffer view (no accumulation kernel)
+                elif p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + off * 4:
+                    p.grad = self.grad[off:off + p.numel()].view(p.shape)
         else:
             self.zero_grad()
 
@@ -80,5 +91,5 @@ class FlatAdamWEMA:
         ops.grad_norm(self.fp.grad, self.max_norm, norm_out=self.norm)
         ops.adamw_ema_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.fp.ema, self.norm if self.max_norm > 0 else None,
                            lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, self.ema_decay)
-        Fn.bump_weight_epoch()      # weights changed through raw pointers: invalidate the packed bf16 operands
+        self.fp.epoch[0] += 1       # weights changed through raw pointers: the cached bf16 operands of THESE parameters are stale
         return self.norm            # device tensor; no host sync

@@ -229,9 +229,17 @@ class DMDTrainer:
         self.fp = FlatParams(params, with_ema=False)
         self.opt = FlatAdamWEMA(self.fp, lr=lr, weight_decay=wd, warmup_steps=warmup_steps, max_norm=max_norm)
         self.sync = dist.FlatGradSync(params, self.fp.grad, self.fp.offsets, bucket_bytes=bucket_bytes)
-        sp = [p for p in student.parameters()] if hasattr(student, "parameters") else []
-        self.sopt = torch.optim.AdamW(sp, lr=diff_lr, weight_decay=wd, betas=(0.9, 0.95), eps=1e-8) if sp else None
-        self.ssched = torch.optim.lr_scheduler.LambdaLR(self.sopt, lambda s: s / warmup_steps if s < warmup_steps else 1.0) if sp else None
+        # the student's AdamW (train_dmd.py:473, :565-575) on flat buffers like the VAE's: one norm pass + one fused update instead of torch's
+        # multi-pass foreach kernels over 675 M parameters; block parameters receive their gradients directly from functional.DitBlockFn
+        sp = [p for p in student.parameters() if p.requires_grad] if hasattr(student, "parameters") else []
+        self.sfp = self.sopt = None
+        if sp:
+            self.sfp = FlatParams(sp, with_ema=False)
+            direct = [p for n_, p in student.named_parameters() if p.requires_grad and n_.startswith("blocks.") and "adaLN_modulation" not in n_]
+            from .models.lightningdit import LightningDiT
+            if isinstance(student, LightningDiT) and direct:
+                self.sfp.enable_direct_grads(only=direct)
+            self.sopt = FlatAdamWEMA(self.sfp, lr=diff_lr, weight_decay=wd, warmup_steps=warmup_steps, max_norm=max_norm)
         self.log = torch.zeros(10, dtype=torch.float32, device=self.fp.flat.device)
         self.global_step = 0
 
@@ -302,8 +310,9 @@ class DMDTrainer:
         # student turn (every step): flow-matching loss on the current latents (transport.training_losses)
         sloss = None
         if self.sopt is not None:
-            for p in self.student.parameters():
+            for p in self.sfp.params:
                 p.requires_grad_(True)
+            self.sfp.begin_step()
             x1 = latents.detach()
             t, x0 = self._sample(x1)
             te = t.view(-1, *([1] * (x1.dim() - 1)))
@@ -313,16 +322,11 @@ class DMDTrainer:
                 sloss = ((out.float() - ut) ** 2).flatten(1).mean(1).mean()
             sloss.backward()
             if dist.initialized() and dist.get_world_size() > 1:
-                for p in self.student.parameters():
-                    if p.grad is not None:
-                        p.grad.div_(dist.get_world_size())
-                        dist.allreduce(p.grad)
-            snorm = torch.nn.utils.clip_grad_norm_(self.student.parameters(), self.max_norm)
-            self.sopt.step()
-            self.sopt.zero_grad(set_to_none=True)
-            self.ssched.step()
+                self.sfp.grad.div_(dist.get_world_size())
+                dist.allreduce(self.sfp.grad)
+            snorm = self.sopt.step()
             with torch.no_grad():
-                self.log[7], self.log[8] = sloss.detach(), snorm
+                self.log[7], self.log[8] = sloss.detach(), snorm[0]
         self.global_step += 1
         return (loss if vae_turn else sloss).detach()
 
