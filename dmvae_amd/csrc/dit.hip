@@ -53,48 +53,44 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(const float* __re
   }
 }
 
-// one wave per token (b, n); lane j < D/2 owns the feature pair (2j, 2j+1) of every head in turn
+// one wave per (token, head); lane j < D/2 owns the feature pair (2j, 2j+1)
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(const bf16* __restrict__ qkv, const float* __restrict__ qw, const float* __restrict__ kw,
                                                           const float* __restrict__ cosb, const float* __restrict__ sinb, bf16* __restrict__ qo,
                                                           bf16* __restrict__ ko, bf16* __restrict__ vo, int tokens, int N, int H, int D, int Dp,
                                                           float eps) {
-  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (tok >= tokens) return;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= tokens * H) return;
+  const int tok = row / H, h = row - tok * H;
   const int b = tok / N, n = tok - b * N;
   const bool live = 2 * lane < D, pad = 2 * lane >= D && 2 * lane < Dp;
-  float c0 = 0.f, s0 = 0.f, c1 = 0.f, s1 = 0.f, wq0 = 0.f, wq1 = 0.f, wk0 = 0.f, wk1 = 0.f;
+  const bf16* base = qkv + (size_t)tok * 3 * H * D;
+  float q0 = 0.f, q1 = 0.f, k0 = 0.f, k1 = 0.f, c0 = 0.f, s0 = 0.f, c1 = 0.f, s1 = 0.f, wq0 = 0.f, wq1 = 0.f, wk0 = 0.f, wk1 = 0.f;
+  bf16x2 vv = {(bf16)0.f, (bf16)0.f};
   if (live) {
+    const bf16x2 a = *reinterpret_cast<const bf16x2*>(base + (size_t)h * D + 2 * lane);
+    const bf16x2 c = *reinterpret_cast<const bf16x2*>(base + (size_t)(H + h) * D + 2 * lane);
+    vv = *reinterpret_cast<const bf16x2*>(base + (size_t)(2 * H + h) * D + 2 * lane);
+    q0 = (float)a[0]; q1 = (float)a[1]; k0 = (float)c[0]; k1 = (float)c[1];
     c0 = cosb[(size_t)n * D + 2 * lane]; c1 = cosb[(size_t)n * D + 2 * lane + 1];
     s0 = sinb[(size_t)n * D + 2 * lane]; s1 = sinb[(size_t)n * D + 2 * lane + 1];
     wq0 = qw[2 * lane]; wq1 = qw[2 * lane + 1]; wk0 = kw[2 * lane]; wk1 = kw[2 * lane + 1];
   }
-  const bf16* base = qkv + (size_t)tok * 3 * H * D;
-  for (int h = 0; h < H; h++) {
-    float q0 = 0.f, q1 = 0.f, k0 = 0.f, k1 = 0.f;
-    bf16x2 vv = {(bf16)0.f, (bf16)0.f};
-    if (live) {
-      const bf16x2 a = *reinterpret_cast<const bf16x2*>(base + (size_t)h * D + 2 * lane);
-      const bf16x2 c = *reinterpret_cast<const bf16x2*>(base + (size_t)(H + h) * D + 2 * lane);
-      vv = *reinterpret_cast<const bf16x2*>(base + (size_t)(2 * H + h) * D + 2 * lane);
-      q0 = (float)a[0]; q1 = (float)a[1]; k0 = (float)c[0]; k1 = (float)c[1];
-    }
-    const float rq = rsqrtf(wave_sum(q0 * q0 + q1 * q1) / (float)D + eps);
-    const float rk = rsqrtf(wave_sum(k0 * k0 + k1 * k1) / (float)D + eps);
-    // RMSNorm casts back to the input dtype (bf16) before the f32 weight multiplies (rms_norm.py:75-76)
-    const float nq0 = (float)(bf16)(q0 * rq) * wq0, nq1 = (float)(bf16)(q1 * rq) * wq1;
-    const float nk0 = (float)(bf16)(k0 * rk) * wk0, nk1 = (float)(bf16)(k1 * rk) * wk1;
-    const size_t o = ((size_t)(b * H + h) * N + n);
-    if (live) {
-      const bf16x2 qq = {(bf16)(nq0 * c0 - nq1 * s0), (bf16)(nq1 * c1 + nq0 * s1)};
-      const bf16x2 kk = {(bf16)(nk0 * c0 - nk1 * s0), (bf16)(nk1 * c1 + nk0 * s1)};
-      *reinterpret_cast<bf16x2*>(qo + o * Dp + 2 * lane) = qq;
-      *reinterpret_cast<bf16x2*>(ko + o * Dp + 2 * lane) = kk;
-      *reinterpret_cast<bf16x2*>(vo + o * D + 2 * lane) = vv;
-    } else if (pad) {
-      const bf16x2 z = {(bf16)0.f, (bf16)0.f};
-      *reinterpret_cast<bf16x2*>(qo + o * Dp + 2 * lane) = z;
-      *reinterpret_cast<bf16x2*>(ko + o * Dp + 2 * lane) = z;
-    }
+  const float rq = rsqrtf(wave_sum(q0 * q0 + q1 * q1) / (float)D + eps);
+  const float rk = rsqrtf(wave_sum(k0 * k0 + k1 * k1) / (float)D + eps);
+  // RMSNorm casts back to the input dtype (bf16) before the f32 weight multiplies (rms_norm.py:75-76)
+  const float nq0 = (float)(bf16)(q0 * rq) * wq0, nq1 = (float)(bf16)(q1 * rq) * wq1;
+  const float nk0 = (float)(bf16)(k0 * rk) * wk0, nk1 = (float)(bf16)(k1 * rk) * wk1;
+  const size_t o = ((size_t)(b * H + h) * N + n);
+  if (live) {
+    const bf16x2 qq = {(bf16)(nq0 * c0 - nq1 * s0), (bf16)(nq1 * c1 + nq0 * s1)};
+    const bf16x2 kk = {(bf16)(nk0 * c0 - nk1 * s0), (bf16)(nk1 * c1 + nk0 * s1)};
+    *reinterpret_cast<bf16x2*>(qo + o * Dp + 2 * lane) = qq;
+    *reinterpret_cast<bf16x2*>(ko + o * Dp + 2 * lane) = kk;
+    *reinterpret_cast<bf16x2*>(vo + o * D + 2 * lane) = vv;
+  } else if (pad) {
+    const bf16x2 z = {(bf16)0.f, (bf16)0.f};
+    *reinterpret_cast<bf16x2*>(qo + o * Dp + 2 * lane) = z;
+    *reinterpret_cast<bf16x2*>(ko + o * Dp + 2 * lane) = z;
   }
 }
 
@@ -307,7 +303,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16* __rest
   float gq0 = 0.f, gq1 = 0.f, gk0 = 0.f, gk1 = 0.f;     // weight-gradient accumulators of this lane's feature pair
   float wq0 = 0.f, wq1 = 0.f, wk0 = 0.f, wk1 = 0.f;
   if (live) { wq0 = qw[2 * lane]; wq1 = qw[2 * lane + 1]; wk0 = kw[2 * lane]; wk1 = kw[2 * lane + 1]; }
-  for (int tok = blockIdx.x * 4 + wave; tok < tokens; tok += gridDim.x * 4) {
+  for (int row = blockIdx.x * 4 + wave; row < tokens * H; row += gridDim.x * 4) {
+    const int tok = row / H, h = row - tok * H;
     const int b = tok / N, n = tok - b * N;
     float c0 = 0.f, s0 = 0.f, c1 = 0.f, s1 = 0.f;
     if (live) {
@@ -316,7 +313,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16* __rest
     }
     const bf16* base = qkv + (size_t)tok * 3 * H * D;
     bf16* dbase = dqkv + (size_t)tok * 3 * H * D;
-    for (int h = 0; h < H; h++) {
+    {
       const size_t o = ((size_t)(b * H + h) * N + n);
       float q0 = 0.f, q1 = 0.f, k0 = 0.f, k1 = 0.f, dq0 = 0.f, dq1 = 0.f, dk0 = 0.f, dk1 = 0.f;
       bf16x2 dvv = {(bf16)0.f, (bf16)0.f};
@@ -392,7 +389,7 @@ extern "C" int dmvae_qknorm_rope_bf16(const void* qkv, const void* q_weight, con
   DMVAE_CHECK_ARG(head_dim % 2 == 0 && head_dim >= 2 && head_dim_padded >= head_dim && head_dim_padded % 2 == 0 && head_dim_padded <= 128,
                   "qknorm_rope_bf16: head dim must be even, padded head dim <= 128 (got %d, %d)", head_dim, head_dim_padded);
   const int tokens = batch * seq;
-  hipLaunchKernelGGL(qknorm_rope_kernel, dim3((tokens + 3) / 4), dim3(256), 0, stream, (const bf16*)qkv, (const float*)q_weight, (const float*)k_weight,
+  hipLaunchKernelGGL(qknorm_rope_kernel, dim3((tokens * heads + 3) / 4), dim3(256), 0, stream, (const bf16*)qkv, (const float*)q_weight, (const float*)k_weight,
                      (const float*)cos_table, (const float*)sin_table, (bf16*)q_out, (bf16*)k_out, (bf16*)v_out, tokens, seq, heads, head_dim,
                      head_dim_padded, eps);
   DMVAE_CHECK_LAUNCH();
@@ -480,7 +477,7 @@ extern "C" int dmvae_qknorm_rope_bwd(const void* dq, const void* dk, const void*
   DMVAE_CHECK_ARG(head_dim % 2 == 0 && head_dim >= 2 && head_dim_padded >= head_dim && head_dim_padded <= 128,
                   "qknorm_rope_bwd: head dim must be even, padded head dim <= 128 (got %d, %d)", head_dim, head_dim_padded);
   const int tokens = batch * seq;
-  int nblk = (tokens + 3) / 4; if (nblk > 256) nblk = 256;   // one block per CU; the second stage sums nblk partials per weight serially
+  int nblk = (tokens * heads + 3) / 4; if (nblk > 512) nblk = 512;   // two blocks per CU; the second stage sums nblk partials per weight serially
   DMVAE_CHECK_ARG(workspace_bytes >= (size_t)nblk * 2 * head_dim * sizeof(float), "qknorm_rope_bwd: workspace too small");
   hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (const bf16*)qkv,
                      (const float*)q_weight, (const float*)k_weight, (const float*)cos_table, (const float*)sin_table, (bf16*)dqkv, (float*)workspace,
