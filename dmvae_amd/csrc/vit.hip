@@ -144,24 +144,41 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return *reinterpret_cast<unsigned*>(&t);
 }
 
-__global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int S, int H, float scale) {
+// DP: head dim as staged (64, or 96 = 72 zero-padded by the producer for LightningDiT-XL); D: real head dim (V / output width).
+// q / k / v: per-(batch, head) base = ptr + b * bs + h * hs (elements), token rows `rs` elements apart.
+struct AttnArgs {
+  const bf16 *q, *k, *v;
+  bf16* out;
+  long long q_bs, q_hs, k_bs, k_hs, v_bs, v_hs;
+  int q_rs, k_rs, v_rs;
+  int S, H, D;
+  float scale;
+};
+
+template <int DP>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 #if __HIP_DEVICE_COMPILE__
+  constexpr int KROW = DP == 64 ? 128 : 256;   // bytes per K row in LDS (8 or 16 chunks of 16 B, XOR-swizzled by key & 7)
+  constexpr int KSTEPS = DP / 16, DB = DP / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ks = smem;                       // [288][128 B]
-  char* vs = smem + ATT_KEYS * 128;      // [288][256 B] (channels 0..63 used)
+  char* ks = smem;                       // [288][KROW]
+  char* vs = smem + ATT_KEYS * KROW;     // [288][256 B] (channels 0..DP-1 used)
+  const int S = a.S, H = a.H;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const int C = H * ATT_D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bf16* base = qkv + (size_t)b * S * 3 * C + h * ATT_D;
-  // ---- stage K and V: 8 lanes x 16 B per key row -----------------------------------------------------------------------------------
-  for (int i = tid; i < ATT_KEYS * 8; i += 256) {
-    const int key = i >> 3, c = i & 7;
+  const bf16* qb_ = a.q + b * a.q_bs + h * a.q_hs;
+  const bf16* kb_ = a.k + b * a.k_bs + h * a.k_hs;
+  const bf16* vb_ = a.v + b * a.v_bs + h * a.v_hs;
+  const int vchunks = a.D / 8;           // V rows hold the real head dim
+  // ---- stage K and V: DP/8 lanes x 16 B per key row ------------------------------------------------------------------------------------
+  for (int i = tid; i < ATT_KEYS * (DP / 8); i += 256) {
+    const int key = i / (DP / 8), c = i - key * (DP / 8);
     uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
     if (key < S) {
-      kv = *reinterpret_cast<const uint4*>(base + ((size_t)key * 3 + 1) * C + c * 8);
-      vv = *reinterpret_cast<const uint4*>(base + ((size_t)key * 3 + 2) * C + c * 8);
+      kv = *reinterpret_cast<const uint4*>(kb_ + (size_t)key * a.k_rs + c * 8);
+      if (c < vchunks) vv = *reinterpret_cast<const uint4*>(vb_ + (size_t)key * a.v_rs + c * 8);
     }
-    *reinterpret_cast<uint4*>(ks + key * 128 + ((c ^ (key & 7)) << 4)) = kv;
+    *reinterpret_cast<uint4*>(ks + key * KROW + ((c ^ (key & 7)) << 4)) = kv;
     // V: channel chunk c (8 channels) -> 64-B segment c >> 2, swizzled by key & 3; 16-B slot c & 3 inside it
     *reinterpret_cast<uint4*>(vs + key * 256 + ((((c >> 2) ^ (key & 3))) << 6) + ((c & 3) << 4)) = vv;
   }
@@ -169,20 +186,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
   const int kg = lane >> 5, ql = lane & 31;
   // V transpose-read addressing (see conv_wgrad_pp.hip): lane supplies 4 channels of one key row
   const int g16 = (lane >> 4) & 1, rr = (lane & 15) >> 2, qq = lane & 3;
-  int voff[2];
+  int voff[DB];
 #pragma unroll
-  for (int db = 0; db < 2; db++) {
+  for (int db = 0; db < DB; db++) {
     const int ch = db * 32 + 16 * g16 + 4 * qq;
     voff[db] = (kg * 8 + rr) * 256 + ((((ch >> 5) ^ rr)) << 6) + (ch & 31) * 2;
   }
   for (int qb = wave; qb * 32 < S; qb += 4) {
     const int q = qb * 32 + ql;
     // Q fragments (B operand of the swapped product): 8 d's per lane per 16-step
-    bf16x8 qf[4];
+    bf16x8 qf[KSTEPS];
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
+    for (int kk = 0; kk < KSTEPS; kk++) {
       uint4 t = {0, 0, 0, 0};
-      if (q < S) t = *reinterpret_cast<const uint4*>(base + (size_t)q * 3 * C + kk * 16 + kg * 8);
+      if (q < S) t = *reinterpret_cast<const uint4*>(qb_ + (size_t)q * a.q_rs + kk * 16 + kg * 8);
       qf[kk] = *reinterpret_cast<bf16x8*>(&t);
     }
     // ---- S^T = K Q^T: acc[kb][r] = score(key = kb*32 + (r&3) + 8*(r>>2) + 4*kg, query q) ------------------------------------------
@@ -193,8 +210,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
       for (int r = 0; r < 16; r++) st[kb][r] = 0.f;
       const int key = kb * 32 + ql;
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + key * 128 + ((((kk * 2 + kg)) ^ (key & 7)) << 4));
+      for (int kk = 0; kk < KSTEPS; kk++) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + key * KROW + ((((kk * 2 + kg)) ^ (key & 7)) << 4));
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kb], 0, 0, 0);
       }
     }
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        const float v = key < S ? st[kb][r] * scale : -INFINITY;
+        const float v = key < S ? st[kb][r] * a.scale : -INFINITY;
         st[kb][r] = v;
         m = fmaxf(m, v);
       }
@@ -218,9 +235,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.f / sum;
     // ---- O = P V ---------------------------------------------------------------------------------------------------------------------
-    f32x16 o[2];
+    f32x16 o[DB];
 #pragma unroll
-    for (int db = 0; db < 2; db++)
+    for (int db = 0; db < DB; db++)
 #pragma unroll
       for (int r = 0; r < 16; r++) o[db][r] = 0.f;
 #pragma unroll
@@ -238,7 +255,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
         pa.u[0] = s0[0]; pa.u[1] = s1[0]; pa.u[2] = s0[1]; pa.u[3] = s1[1];
         const int ksn = kb * 2 + half;
 #pragma unroll
-        for (int db = 0; db < 2; db++) {
+        for (int db = 0; db < DB; db++) {
           union { bf16x8 v; s16x4 hlf[2]; } vf;
           vf.hlf[0] = tr_read_v(vs + ksn * 4096 + voff[db]);
           vf.hlf[1] = tr_read_v(vs + ksn * 4096 + voff[db] + 1024);
@@ -246,16 +263,31 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
         }
       }
     }
-    // ---- store: rows q = qb*32 + (r&3) + 8*(r>>2) + 4*kg, column d = db*32 + (lane & 31) -----------------------------------------------
+    // ---- store [B][S][H*D]: rows q = qb*32 + (r&3) + 8*(r>>2) + 4*kg, column d = db*32 + (lane & 31) ----------------------------------
+    const int C = H * a.D;
 #pragma unroll
-    for (int db = 0; db < 2; db++)
+    for (int db = 0; db < DB; db++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int qo = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        if (qo < S) out[((size_t)b * S + qo) * C + h * ATT_D + db * 32 + ql] = (bf16)o[db][r];
+        const int dcol = db * 32 + ql;
+        if (qo < S && dcol < a.D) a.out[((size_t)b * S + qo) * C + h * a.D + dcol] = (bf16)o[db][r];
       }
   }
 #endif
+}
+
+template <int DP>
+static int launch_attention(const AttnArgs& a, int batch, hipStream_t stream) {
+  constexpr int lds = ATT_KEYS * (DP == 64 ? 128 : 256) + ATT_KEYS * 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(attention_kernel<DP>, dim3(batch * a.H), dim3(256), lds, stream, a);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
 }
 
 }  // namespace dmvae_vit
@@ -265,13 +297,27 @@ extern "C" int dmvae_attention_qkv_bf16(const void* qkv, void* out, int batch, i
   using namespace dmvae_vit;
   DMVAE_CHECK_ARG(qkv && out && batch > 0 && heads > 0 && seq > 0, "attention_qkv_bf16: bad argument");
   DMVAE_CHECK_ARG(head_dim == ATT_D && seq <= ATT_KEYS, "attention_qkv_bf16: needs head_dim 64 and seq <= 288 (got %d, %d)", head_dim, seq);
-  constexpr int lds = ATT_KEYS * 128 + ATT_KEYS * 256;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(attention_kernel, dim3(batch * heads), dim3(256), lds, stream, (const bf16*)qkv, (bf16*)out, seq, heads, scale);
-  DMVAE_CHECK_LAUNCH();
-  return 0;
+  const long long C = (long long)heads * head_dim;
+  AttnArgs a;
+  a.q = (const bf16*)qkv; a.k = a.q + C; a.v = a.q + 2 * C; a.out = (bf16*)out;
+  a.q_bs = a.k_bs = a.v_bs = (long long)seq * 3 * C; a.q_hs = a.k_hs = a.v_hs = head_dim;
+  a.q_rs = a.k_rs = a.v_rs = (int)(3 * C);
+  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale;
+  return launch_attention<64>(a, batch, stream);
+}
+
+// Same kernel on head-major operands (q, k: [B*H][S][Dp], v: [B*H][S][D]; LightningDiT after QK-norm + RoPE, head dim 64 or 72 -> Dp 64 / 96).
+extern "C" int dmvae_attention_heads_bf16(const void* q, const void* k, const void* v, void* out, int batch, int seq, int heads, int head_dim,
+                                          int head_dim_padded, float scale, hipStream_t stream) {
+  using namespace dmvae_vit;
+  DMVAE_CHECK_ARG(q && k && v && out && batch > 0 && heads > 0 && seq > 0, "attention_heads_bf16: bad argument");
+  DMVAE_CHECK_ARG(seq <= ATT_KEYS && head_dim % 8 == 0 && head_dim <= head_dim_padded && (head_dim_padded == 64 || head_dim_padded == 96),
+                  "attention_heads_bf16: needs seq <= 288, head_dim %% 8 == 0, padded head dim 64 or 96 (got %d, %d, %d)", seq, head_dim, head_dim_padded);
+  AttnArgs a;
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out;
+  a.q_hs = a.k_hs = (long long)seq * head_dim_padded; a.q_bs = a.k_bs = a.q_hs * heads;
+  a.v_hs = (long long)seq * head_dim; a.v_bs = a.v_hs * heads;
+  a.q_rs = a.k_rs = head_dim_padded; a.v_rs = head_dim;
+  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale;
+  return head_dim_padded == 64 ? launch_attention<64>(a, batch, stream) : launch_attention<96>(a, batch, stream);
 }

@@ -2,9 +2,11 @@
 (the teacher's and the student's evaluations inside the DMD loss, train_dmd.py:211-217: four DiT-XL/1 forwards per VAE turn).
 
 Same arithmetic as `forward_stock` under autocast(bf16), with bf16 rounding at the sites where the reference's autocast graph rounds (see
-csrc/dit.hip); per block: 1 fused RMSNorm+modulate, qkv GEMM, 1 fused QK-norm+RoPE+head split, attention as batched QK^T GEMM / f32 softmax /
-PV GEMM (head dims 64 and 72 alike: the K step pads to 96), proj GEMM, 1 gated residual, RMSNorm+modulate, w12 GEMM, SwiGLU gate, w3 GEMM,
+csrc/dit.hip); per block: 1 fused RMSNorm+modulate, qkv GEMM, 1 fused QK-norm+RoPE+head split, attention in one fused kernel (csrc/vit.hip, head dims 64 and 72
+alike: the staged head dim pads to 96; composed batched QK^T GEMM / f32 softmax / PV GEMM beyond 288 tokens), proj GEMM, 1 gated residual, RMSNorm+modulate, w12 GEMM, SwiGLU gate, w3 GEMM,
 gated residual.  The tiny per-sample pieces (timestep / label embedding, adaLN Linear) stay stock PyTorch under autocast."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -32,11 +34,16 @@ def _bf(p):
     return cached(p)
 
 
+_FUSED_ATTN = os.environ.get("DMVAE_DIT_FUSED_ATTN", "1") != "0"
+
+
 def _attention(qkv, blk, rope, heads):
     b, n, c3 = qkv.shape
     c = c3 // 3
     d = c // heads
     q, k, v = ops.qknorm_rope(qkv, blk.attn.q_norm.weight, blk.attn.k_norm.weight, rope.freqs_cos, rope.freqs_sin, heads, blk.attn.q_norm.eps)
+    if _FUSED_ATTN and ops.attention_heads_supported(n, d):
+        return ops.attention_heads(q, k, v, b, d ** -0.5)
     p = ops.softmax_rows(ops.gemm_nt(q, k, out_f32=True), d ** -0.5)            # [B*H, N, N] bf16
     o = ops.gemm_nt(p, ops.transpose_last2(v))                                  # [B*H, N, D]
     return o.view(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, c)

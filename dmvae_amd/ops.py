@@ -434,6 +434,22 @@ def attention_qkv(qkv: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
     return out
 
 
+def attention_heads(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, scale: float) -> torch.Tensor:
+    """q, k [B*H, N, Dp], v [B*H, N, D] (bf16, as `qknorm_rope` returns them) -> softmax(scale q k^T) v as [B, N, H*D] bf16, one fused kernel."""
+    q = _req(q, bf16, "q"); k = _req(k, bf16, "k"); v = _req(v, bf16, "v")
+    bh, n, dp = q.shape
+    d = v.shape[-1]
+    heads = bh // batch
+    out = torch.empty(batch, n, heads * d, dtype=bf16, device=q.device)
+    check(_lib.lib().dmvae_attention_heads_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), batch, n, heads, d, dp, float(scale),
+                                                _stream()), "attention_heads_bf16")
+    return out
+
+
+def attention_heads_supported(n: int, d: int) -> bool:
+    return n <= 288 and d % 8 == 0 and (d + 31) // 32 * 32 in (64, 96)
+
+
 def scale_residual_(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor) -> torch.Tensor:
     """x (f32, in place) += gamma * y (bf16): LayerScale + residual add."""
     x = _req(x, f32, "x")

@@ -194,6 +194,12 @@ int dmvae_softmax_rows_bf16(const void* s, void* p, size_t rows, int cols, float
  * multi-head self-attention (timm Attention; dino_layers/attention.py:56-69) fused in one kernel.  head_dim 64, seq <= 288. */
 int dmvae_attention_qkv_bf16(const void* qkv, void* out, int batch, int seq, int heads, int head_dim, float scale,
                              dmvae_stream_t stream);
+/* The same fused kernel on head-major operands: q, k [batch*heads][seq][head_dim_padded] (channels >= head_dim zero), v
+ * [batch*heads][seq][head_dim] bf16 -- what dmvae_qknorm_rope_bf16 produces -> out [batch][seq][heads*head_dim].  LightningDiT's
+ * attention after QK-norm + RoPE (models/lightningdit.py:64-98, F.scaled_dot_product_attention); head_dim % 8 == 0, head_dim_padded 64 or 96,
+ * seq <= 288. */
+int dmvae_attention_heads_bf16(const void* q, const void* k, const void* v, void* out, int batch, int seq, int heads, int head_dim,
+                               int head_dim_padded, float scale, dmvae_stream_t stream);
 
 /* Backward side of the same encoder block, for the stages where the encoder trains (train_dmd.py:349,519).  Residual stream f32,
  * Linear operands / results bf16 (autocast).  workspace: dmvae_vit_bwd_workspace(c) bytes.

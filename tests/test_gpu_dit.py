@@ -73,6 +73,35 @@ def test_qknorm_rope_kernel(heads, d):
         assert float(q[..., d:].abs().max()) == 0.0 and float(k[..., d:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("b,heads,d,n", [(2, 16, 72, 256), (3, 2, 64, 64), (1, 4, 72, 288), (2, 3, 64, 37), (1, 2, 40, 96)])
+def test_fused_attention_heads_kernel(b, heads, d, n):
+    """dmvae_attention_heads_bf16 against softmax(scale q k^T) v in f64 on the same bf16 operands (P rounded to bf16 before the second product, as
+    the kernel and the autocast graph's flash kernel do), including ragged key counts and the zero-padded head dim."""
+    from dmvae_amd import ops
+    g = torch.Generator().manual_seed(b * 1000 + d + n)
+    dp = (d + 31) // 32 * 32
+    q = torch.zeros(b * heads, n, dp)
+    k = torch.zeros(b * heads, n, dp)
+    q[..., :d] = torch.randn(b * heads, n, d, generator=g)
+    k[..., :d] = torch.randn(b * heads, n, d, generator=g)
+    v = torch.randn(b * heads, n, d, generator=g)
+    q, k, v = q.to(DEV).to(BF), k.to(DEV).to(BF), v.to(DEV).to(BF)
+    assert ops.attention_heads_supported(n, d)
+    out = ops.attention_heads(q, k, v, b, d ** -0.5)
+    assert out.shape == (b, n, heads * d) and out.dtype == BF
+    p = torch.softmax(q.double() @ k.double().transpose(1, 2) * d ** -0.5, dim=-1)
+    ref = (p @ v.double()).view(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, heads * d)
+    assert _rl2(out, ref) < 6e-3
+    assert (out.double() - ref).abs().max() < 2 ** -6 * ref.abs().max() + 1e-3
+    assert torch.equal(out, ops.attention_heads(q, k, v, b, d ** -0.5))
+    if n % 32 or d % 8 or d < 64:
+        return
+    # and the composed route it replaces
+    pc = ops.softmax_rows(ops.gemm_nt(q, k, out_f32=True), d ** -0.5)
+    oc = ops.gemm_nt(pc, ops.transpose_last2(v)).view(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, heads * d)
+    assert _rl2(out, oc) < 6e-3
+
+
 @pytest.mark.parametrize("tag", ["dit_small_hd64", "dit_small_hd72"])
 def test_lightningdit_fast_forward_vs_fixture_oracle_and_stock(tag):
     g = load_golden(tag)
