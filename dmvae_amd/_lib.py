@@ -37,6 +37,8 @@ SIGNATURES = {
     "dmvae_maxpool2x2_relu_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dmvae_leaky_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
+    "dmvae_sde_euler_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t] + [c_float] * 6 + [c_void_p]),
+    "dmvae_image_to_u8": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
     "dmvae_diffaug_fwd": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "dmvae_diffaug_bwd": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "dmvae_im2col_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),

@@ -15,6 +15,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import functional as Fn
+from .. import ops
 
 
 @dataclass
@@ -203,6 +204,23 @@ class Decoder(nn.Module):
     def forward(self, z: Tensor, grad_ckpt=False) -> Tensor:
         """z: [B, 256, C] tokens (the reference hard-codes the 16x16 grid, :244-245) or NCHW [B, C, h, w].
         Returns the NCHW image; f32 (the reference returns bf16 under autocast and VAE.forward casts to float)."""
+        h = self._body_nhwc(z)
+        return Fn.NormConvOutFn.apply(h, self.norm_out.weight, self.norm_out.bias, self.conv_out.weight, self.conv_out.bias)
+
+    @torch.no_grad()
+    def forward_uint8(self, z: Tensor, round_bf16: bool = True) -> Tensor:
+        """Decode straight to the [B, H, W, 3] uint8 image sample_50k.py:149-151 builds (`clamp(127.5 * decode(z).float() + 128, 0, 255)`, channels
+        last, uint8): the output conv's f32 NHWC result goes through one conversion kernel instead of NHWC->NCHW f32, clamp, permute and a cast.
+        round_bf16: round the decoded value to bf16 first -- what `.float()` of the reference's autocast decoder output holds."""
+        h = self._body_nhwc(z)
+        cout = self.conv_out.weight.shape[0]
+        _, a = Fn._gn_swish(h, self.norm_out.weight, self.norm_out.bias)
+        cbp = torch.zeros(4, dtype=torch.float32, device=h.device)
+        cbp[:cout] = self.conv_out.bias
+        y4 = ops.conv2d_nhwc(a, Fn.packed(self.conv_out.weight, False, rows_pad=4), cbp, ks=3, out_f32=True)
+        return ops.image_to_u8(y4, cout, round_bf16)
+
+    def _body_nhwc(self, z: Tensor) -> Tensor:
         if z.ndim == 3:
             b, t, c = z.shape
             if t != 256:
@@ -223,7 +241,7 @@ class Decoder(nn.Module):
                 h = self.up[i_level].block[i_block].forward_nhwc(h)
             if i_level != 0:
                 h = self.up[i_level].upsample.forward_nhwc(h)
-        return Fn.NormConvOutFn.apply(h, self.norm_out.weight, self.norm_out.bias, self.conv_out.weight, self.conv_out.bias)
+        return h
 
     def post_init(self, z_channels):
         self.conv_in = nn.Sequential(

@@ -94,6 +94,11 @@ class VAE(nn.Module):
     def decode(self, latent_tokens):
         return self.decoder(latent_tokens)
 
+    @torch.inference_mode()
+    def decode_uint8(self, latent_tokens, round_bf16: bool = True):
+        """decode + the uint8 conversion of sample_50k.py:149-151 in one go -> [B, H, W, 3] uint8 on the device (not in the reference's API)."""
+        return self.decoder.forward_uint8(latent_tokens, round_bf16)
+
     def load_pretrained(self, state_dict_path, ema=False):
         if not os.path.exists(state_dict_path):
             print(f"[WARNING] VAE state_dict_path {state_dict_path} not found, skip loading")

@@ -603,6 +603,32 @@ def qknorm_rope_bwd(dq, dk, dv, qkv, qw, kw, cos, sin, heads: int, eps: float = 
     return dqkv, dqw, dkw
 
 
+# ---- downstream consumers (sampler state update, image -> uint8) ---------------------------------------
+def sde_euler_step(x: torch.Tensor, v: torch.Tensor, w: Optional[torch.Tensor], rar: float, var: float, diff: float, dt: float, sqrt_2diff: float,
+                   sqrt_dt: float, need_mean: bool = False):
+    """One Euler-Maruyama step (integrators.py:27-35 with transport.py:254-257 / path.py:74-89 folded in) -> (x_new, mean_x or None); w = None:
+    x_new = x + drift * dt (the sampler's last step).  x, w f32; v bf16 or f32; all the same shape."""
+    x = _req(x, f32, "x")
+    assert v.is_cuda and v.is_contiguous() and v.dtype in (bf16, f32) and v.shape == x.shape
+    if w is not None:
+        w = _req(w, f32, "w")
+        assert w.shape == x.shape
+    out = torch.empty_like(x)
+    mean = torch.empty_like(x) if need_mean else None
+    check(_lib.lib().dmvae_sde_euler_step(x.data_ptr(), v.data_ptr(), int(v.dtype == bf16), _ptr(w), out.data_ptr(), _ptr(mean), x.numel(), float(rar),
+                                          float(var), float(diff), float(dt), float(sqrt_2diff), float(sqrt_dt), _stream()), "sde_euler_step")
+    return out, mean
+
+
+def image_to_u8(y: torch.Tensor, channels: int, round_bf16: bool = False) -> torch.Tensor:
+    """y [N,H,W,Cs] f32 (NHWC, first `channels` used) -> [N,H,W,channels] uint8 = clamp(127.5 y + 128, 0, 255) truncated (sample_50k.py:151)."""
+    y = _req(y, f32, "y")
+    n, h, w_, cs = y.shape
+    out = torch.empty(n, h, w_, channels, dtype=torch.uint8, device=y.device)
+    check(_lib.lib().dmvae_image_to_u8(y.data_ptr(), out.data_ptr(), n * h * w_, int(channels), cs, int(round_bf16), _stream()), "image_to_u8")
+    return out
+
+
 # ---- losses ---------------------------------------------------------------------------------------
 def _loss_ws(device) -> torch.Tensor:
     return workspace(_lib.lib().dmvae_loss_workspace(), device, slot="loss")

@@ -206,8 +206,8 @@ class DMDTrainer:
     included, :519) trains on  rec_loss [+ adversarial term] + dmd_weight * DMD loss (:233-262, :204-230), then -- every step -- the student
     velocity model trains on the flow-matching loss of the current latents (transport.training_losses, transport.py:119-164).
 
-    `teacher` / `student` are callables `f(xt [B,C,h,w], t [B], labels [B]) -> velocity` (the reference's LightningDiT; SURVEY.md 8(f) rank 3 --
-    not rebuilt here, any nn.Module works).  The VAE side runs on the HIP kernels: trainable ViT encoder (functional.VitBlockFn), bottleneck,
+    `teacher` / `student` are callables `f(xt [B,C,h,w], t [B], labels [B]) -> velocity` (the reference's LightningDiT = models/lightningdit.py here;
+    any nn.Module works).  The VAE side runs on the HIP kernels: trainable ViT encoder (functional.VitBlockFn), bottleneck,
     decoder, LPIPS, `losses.dmd_loss` (csrc/losses.hip::dmd_*).  The student is updated with torch.optim.AdamW like the reference's
     optimizer_sit (:473).  The reference keeps no EMA in this stage."""
 
@@ -334,6 +334,74 @@ class DMDTrainer:
         v = self.log.tolist()
         return {"L1": v[0], "L2": v[1], "LPIPS": v[2], "rec_loss": v[3], "vae_norm": v[4], "dmd_loss": v[5], "dmd_gradient_norm": v[6],
                 "diffusion_loss": v[7], "sit_norm": v[8]}
+
+
+class DiffusionTrainer:
+    """Step of the downstream latent-diffusion trainer (train_diffusion.py:268-297): frozen `vae.encode` -> (tokens - latent_mean) * latent_scale ->
+    [B, C, h, w] -> `transport.training_losses` (flow matching, velocity target) on LightningDiT -> clip_grad_norm_(1.0) -> AdamW(lr, betas (0.9, 0.95),
+    weight_decay 0, constant lr; :204) -> EMA(0.9999; `update_ema`, :129-139).
+
+    Device work: the frozen ViT-L encoder and the bottleneck on the HIP path (models/vit_fast.py), LightningDiT forward + backward through
+    `functional.DitBlockFn` (models/lightningdit_fast.forward_train; the reference's `use_checkpoint` recomputation is a memory knob and not needed
+    at 288 GB), gradient norm + clip + AdamW + EMA as two passes over flat buffers (`optim.FlatAdamWEMA`), DP gradient all-reduce over the flat
+    gradient.  The EMA covers the trainable parameters; the reference also "updates" the fixed sin-cos `pos_embed` with itself (:137-139), which
+    only perturbs it by rounding."""
+
+    def __init__(self, model, vae: VAE, lr: float = 1e-4, latent_mean: float = 0.0, latent_scale: float = 1.0, max_norm: float = 1.0,
+                 ema_decay: float = 0.9999, path_type: str = "Linear", prediction: str = "velocity", loss_weight=None, train_eps=0.0, sample_eps=0.0,
+                 bucket_bytes: int = 64 << 20):
+        from .transport import create_transport
+        from .models.lightningdit import LightningDiT
+        self.model, self.vae = model, vae
+        self.latent_mean, self.latent_scale = latent_mean, latent_scale
+        self.transport = create_transport(path_type, prediction, loss_weight, train_eps, sample_eps)          # train_diffusion.py:190-196: no time shift
+        for p in vae.parameters():
+            p.requires_grad_(False)
+        vae.eval()
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.fp = FlatParams(params, with_ema=True)
+        direct = [p for n_, p in model.named_parameters() if p.requires_grad and n_.startswith("blocks.") and "adaLN_modulation" not in n_]
+        if isinstance(model, LightningDiT) and direct:
+            self.fp.enable_direct_grads(only=direct)
+        self.opt = FlatAdamWEMA(self.fp, lr=lr, betas=(0.9, 0.95), weight_decay=0.0, warmup_steps=0, max_norm=max_norm, ema_decay=ema_decay)
+        self.log = torch.zeros(2, dtype=torch.float32, device=self.fp.flat.device)
+        self.train_steps = 0
+
+    def latents(self, images: torch.Tensor) -> torch.Tensor:
+        """train_diffusion.py:276-287."""
+        from .sample import tokens_to_dit_input
+        with torch.no_grad():
+            tok = self.vae.encode(images)
+        return tokens_to_dit_input(tok.float(), self.latent_mean, self.latent_scale)
+
+    def step(self, images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        self.model.train()                                                  # label dropout for classifier-free guidance (:232)
+        self.fp.begin_step()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            x = self.latents(images)
+            _, terms = self.transport.training_losses(self.model, x, dict(y=labels))
+        loss = terms["loss"].mean().float()
+        loss.backward()
+        if dist.initialized() and dist.get_world_size() > 1:
+            self.fp.grad.div_(dist.get_world_size())
+            dist.allreduce(self.fp.grad)
+        norm = self.opt.step()
+        with torch.no_grad():
+            self.log[0], self.log[1] = loss.detach(), norm[0]
+        self.train_steps += 1
+        return loss.detach()
+
+    def ema_state_dict(self):
+        """The `ema` entry of the reference's checkpoint (:316-323): the model's state_dict with the trainable parameters replaced by their averages."""
+        sd = {k: v.clone() for k, v in self.model.state_dict().items()}
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        for p, e in zip(self.fp.params, self.fp.ema_state()):
+            sd[names[id(p)]] = e.clone()
+        return sd
+
+    def read_log(self) -> Dict[str, float]:
+        v = self.log.tolist()
+        return {"loss": v[0], "grad_norm": v[1]}
 
 
 def build_tokenizer_trainer(device="cuda", z_channels=32, model_size="large", seed=42, lpips_ckpt=None, **kw) -> TokenizerTrainer:

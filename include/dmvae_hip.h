@@ -300,6 +300,21 @@ int dmvae_adamw_ema_step(void* params, const void* grads, void* exp_avg, void* e
                          const void* norm_out3, size_t n, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int step, float ema_decay, dmvae_stream_t stream);
 
+/* ---- downstream consumers: SDE sampler state update and image -> uint8 (sample_50k.py:142-164) ---- */
+
+/* One Euler-Maruyama step of diffusion/transport/integrators.py:27-35 on the whole state with the drift of transport.py:254-257 and
+ * the velocity -> score conversion of path.py:74-89 folded in; every coefficient depends on t only (shared by the batch) and is
+ * passed as the f32 scalar the reference's graph holds:
+ *   score = (rar * v - x) / var;  drift = v + diff * score;  mean = x + drift * dt;  x' = mean + sqrt_2diff * (w * sqrt_dt)
+ * x, w, x_out, mean_out: [n] f32; v: [n] bf16 (v_is_bf16 != 0, the autocast model output) or f32.  w = NULL: x_out = mean (the
+ * "Mean" / "Euler" last step, transport.py:275-295, with dt = last_step_size).  x_out or mean_out may be NULL.  n % 4 == 0.
+ * Operation order and rounding are the reference's (no FMA contraction): bit-identical to the PyTorch-CPU f32 result for the same v. */
+int dmvae_sde_euler_step(const void* x, const void* v, int v_is_bf16, const void* w, void* x_out, void* mean_out, size_t n,
+                         float rar, float var, float diff, float dt, float sqrt_2diff, float sqrt_dt, dmvae_stream_t stream);
+/* out[npix][c] uint8 = (uint8) clamp(127.5 * y + 128, 0, 255) for y [npix][c_stride] f32 (NHWC decoder output, first c channels):
+ * sample_50k.py:151 without the NCHW round trip.  round_bf16 != 0 rounds y to bf16 first (an autocast decoder's `.float()`). */
+int dmvae_image_to_u8(const void* y, void* out, size_t npix, int c, int c_stride, int round_bf16, dmvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -620,3 +620,125 @@ def sshape_sample(n: int, seed: int = 42, thickness: float = 0.06, diffusion: fl
     pts += rng.normal(0.0, (diffusion * (0.4 + 0.6 * np.abs(t)))[:, None])
     pts[:, 1] *= -1
     return np.clip(pts, -1.0, 1.0)
+
+
+# --------------------------------------------------------------------------------------------
+# downstream consumers: SDE sampler (diffusion/transport/{integrators.py:8-77, transport.py:236-354, path.py:18-89}),
+# image -> uint8 and the work split of sample_50k.py:128-157, the diffusion trainer's latent handling (train_diffusion.py:276-290)
+# --------------------------------------------------------------------------------------------
+def icplan_score_coeffs(t: Tensor) -> Tuple[Tensor, Tensor]:
+    """(reverse_alpha_ratio, var) of ICPlan.get_score_from_velocity (path.py:82-88): alpha = t, d_alpha = 1, sigma = 1 - t, d_sigma = -1."""
+    sigma = 1 - t
+    rar = t / 1
+    return rar, sigma ** 2 - rar * -1 * sigma
+
+
+def icplan_diffusion(t: Tensor, form: str = "sigma", norm: float = 1.0) -> Tensor:
+    """ICPlan.compute_diffusion (path.py:42-72) for the tensor-valued forms."""
+    if form == "sigma":
+        return norm * (1 - t)
+    if form == "linear":
+        return norm * (1 - t)
+    if form == "SBDM":
+        sigma = 1 - t
+        return norm * ((1 / t) * (sigma ** 2) - sigma * -1)
+    if form == "decreasing":
+        return 0.25 * (norm * torch.cos(np.pi * t) + 1) ** 2
+    if form == "inccreasing-decreasing":
+        return norm * torch.sin(np.pi * t) ** 2
+    raise NotImplementedError(form)
+
+
+def sde_drift_from_velocity(v: Tensor, x: Tensor, t: Tensor, form: str = "sigma", norm: float = 1.0) -> Tensor:
+    """Sampler's sde_drift for a velocity model (transport.py:254-257): v + diffusion(t) * score(v, x, t)."""
+    te = expand_t(t, x)
+    rar, var = icplan_score_coeffs(te)
+    return v + icplan_diffusion(te, form, norm) * ((rar * v - x) / var)
+
+
+def sde_euler_step(x: Tensor, v: Tensor, w: Tensor, t: Tensor, dt: Tensor, form: str = "sigma", norm: float = 1.0) -> Tuple[Tensor, Tensor]:
+    """One Euler-Maruyama step (integrators.py:27-35) given the model output v: -> (x_new, mean_x)."""
+    te = expand_t(t, x)
+    mean = x + sde_drift_from_velocity(v, x, t, form, norm) * dt
+    return mean + torch.sqrt(2 * icplan_diffusion(te, form, norm)) * (w * torch.sqrt(dt)), mean
+
+
+def sde_interval(last_step: Optional[str], last_step_size: float, sample_eps: float = 0.0, form: str = "sigma") -> Tuple[float, float]:
+    """Transport.check_interval(sde=True, eval=True) for the Linear path with a velocity model (transport.py:75-102)."""
+    if last_step is None:
+        last_step_size = 0.0
+    t0 = sample_eps if form == "SBDM" else 0
+    t1 = 1 - sample_eps if last_step_size == 0 else 1 - last_step_size
+    return t0, t1
+
+
+def sde_sample(init: Tensor, model: Callable, *, num_steps: int = 250, method: str = "Euler", form: str = "sigma", norm: float = 1.0,
+               last_step: Optional[str] = "Mean", last_step_size: float = 0.04, sample_eps: float = 0.0) -> List[Tensor]:
+    """Sampler.sample_sde(...)(init, model) (transport.py:298-354 + integrators.py:62-77): `num_steps` states.  `model(x, t)` -> velocity.
+    Noise comes from the global CPU generator, one `torch.randn(x.size())` per step, like the reference."""
+    t0, t1 = sde_interval(last_step, last_step_size, sample_eps, form)
+    ts = torch.linspace(t0, t1, num_steps)
+    dt = ts[1] - ts[0]
+    drift = lambda x_, t_: sde_drift_from_velocity(model(x_, t_), x_, t_, form, norm)
+    x, xs = init, []
+    for ti in ts[:-1]:
+        w = torch.randn(x.size()).to(x)
+        t = torch.ones(x.size(0)).to(x) * ti
+        if method == "Euler":
+            x, _ = sde_euler_step(x, model(x, t), w, t, dt, form, norm)
+        elif method == "Heun":
+            xhat = x + torch.sqrt(2 * icplan_diffusion(expand_t(t, x), form, norm)) * (w * torch.sqrt(dt))
+            k1 = drift(xhat, t)
+            k2 = drift(xhat + dt * k1, t + dt)
+            x = xhat + 0.5 * dt * (k1 + k2)
+        else:
+            raise NotImplementedError(method)
+        xs.append(x)
+    t = torch.ones(init.size(0)) * t1
+    if last_step is None:
+        pass
+    elif last_step == "Mean":
+        x = x + drift(x, t) * last_step_size
+    elif last_step == "Euler":
+        x = x + model(x, t) * last_step_size
+    elif last_step == "Tweedie":
+        score = (icplan_score_coeffs(expand_t(t, x))[0] * model(x, t) - x) / icplan_score_coeffs(expand_t(t, x))[1]
+        x = x / t[0] + ((1 - t)[0] ** 2) / t[0] * score
+    else:
+        raise NotImplementedError(last_step)
+    xs.append(x)
+    return xs
+
+
+def image_to_uint8(img: Tensor) -> Tensor:
+    """sample_50k.py:151: NCHW float image in [-1, 1] -> [B, H, W, C] uint8 = trunc(clamp(127.5 x + 128, 0, 255))."""
+    return torch.clamp(127.5 * img + 128.0, 0, 255).permute(0, 2, 3, 1).to(torch.uint8)
+
+
+def sample50k_plan(num_fid_samples: int, num_classes: int, world_size: int, rank: int, n: int) -> Tuple[List[List[int]], List[List[int]]]:
+    """Work split of sample_50k.py:128-157: per iteration the class labels of this rank's batch and the file indices its images are saved under
+    (`f"{index:06d}.png"`; `total` is incremented BEFORE use, so indices start at n * world_size)."""
+    labels = list(range(num_classes)) * (num_fid_samples // num_classes)
+    per_rank = len(labels) // world_size
+    mine = labels[per_rank * rank: per_rank * (rank + 1)]
+    assert per_rank % n == 0
+    ys, idx, total = [], [], 0
+    for it in range(int(math.ceil(per_rank / n))):
+        total += n * world_size
+        ys.append(mine[it * n: (it + 1) * n])
+        idx.append([j * world_size + rank + total for j in range(n)])
+    return ys, idx
+
+
+def latents_to_dit_input(tokens: Tensor, latent_mean: float, latent_scale: float) -> Tensor:
+    """train_diffusion.py:279-287: [B, h*w, C] tokens -> (x - mean) * scale -> [B, C, h, w]."""
+    x = (tokens - latent_mean) * latent_scale
+    b, n, c = x.shape
+    h = int(n ** 0.5)
+    return x.reshape(b, h, h, c).permute(0, 3, 1, 2)
+
+
+def dit_output_to_latents(samples: Tensor, latent_mean: float, latent_scale: float) -> Tensor:
+    """sample_50k.py:143-148: [B, C, h, w] -> [B, h*w, C] tokens / scale + mean."""
+    b, c, h, w = samples.shape
+    return samples.permute(0, 2, 3, 1).reshape(b, h * w, c) / latent_scale + latent_mean

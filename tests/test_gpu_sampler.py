@@ -1,0 +1,204 @@
+"""Downstream consumers on the MI355X (-m gpu): the fused SDE state update and the uint8 conversion kernel (csrc/sampler.hip) bit-exact
+against the CPU oracle, the sampler on the HIP LightningDiT path against the trajectories captured from the reference, decode-to-uint8, the
+sample_50k loop and the diffusion trainer's step."""
+import copy
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import ref_cpu as R
+from test_oracle_sampler import CASES, DIT_KW, _kw, small_dit
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+@pytest.mark.parametrize("form,norm,tval", [("sigma", 1.0, 0.0), ("sigma", 1.0, 0.5139), ("linear", 0.7, 0.9599), ("decreasing", 1.0, 0.25),
+                                            ("inccreasing-decreasing", 1.3, 0.77), ("SBDM", 1.0, 0.3)])
+@pytest.mark.parametrize("vdtype", [torch.float32, BF])
+def test_sde_euler_step_kernel_bit_exact(form, norm, tval, vdtype):
+    """ops.sde_euler_step == the reference's f32 elementwise graph (oracle.sde_euler_step on the CPU) for the same model output, to the bit."""
+    from dmvae_amd import ops
+    from dmvae_amd.transport import ICPlan
+    g = torch.Generator().manual_seed(int(tval * 1e4) + len(form))
+    shape = (5, 8, 6, 6)
+    x, w = torch.randn(shape, generator=g) * 1.7, torch.randn(shape, generator=g)
+    v = (torch.randn(shape, generator=g) * 2).to(vdtype)
+    t = torch.tensor(tval, dtype=torch.float32)
+    dt = torch.linspace(0, 0.96, 250)[1] - torch.linspace(0, 0.96, 250)[0]
+    tv = torch.ones(shape[0]) * t
+    x_ref, mean_ref = R.sde_euler_step(x, v.float(), w, tv, dt, form, norm)
+    ps = ICPlan()
+    te = t.view(1, 1)
+    rar, var = ps._score_coeffs(te)
+    diff = ps.compute_diffusion(te, te.view(1), form=form, norm=norm)
+    out, mean = ops.sde_euler_step(x.to(DEV), v.to(DEV), w.to(DEV), float(rar), float(var), float(diff), float(dt), float(torch.sqrt(2 * diff)),
+                                   float(torch.sqrt(dt)), need_mean=True)
+    assert torch.equal(mean.cpu(), mean_ref) and torch.equal(out.cpu(), x_ref)
+    # last step ("Mean", transport.py:283-286): x + drift * last_step_size, no noise
+    last = ops.sde_euler_step(x.to(DEV), v.to(DEV), None, float(rar), float(var), float(diff), 0.04, 0.0, 0.0)[0]
+    assert torch.equal(last.cpu(), x + R.sde_drift_from_velocity(v.float(), x, tv, form, norm) * 0.04)
+
+
+def test_image_to_u8_kernel_bit_exact_vs_reference_fixture():
+    from dmvae_amd import ops
+    g = load_golden("image_u8")
+    s = g.t("s")                                                       # NCHW
+    y4 = torch.zeros(*s.permute(0, 2, 3, 1).shape[:3], 4)
+    y4[..., :3] = s.permute(0, 2, 3, 1)
+    y4[..., 3] = 1e9                                                   # the padding channel is never read
+    assert np.array_equal(ops.image_to_u8(y4.to(DEV), 3).cpu().numpy(), np.asarray(g["u8"]))
+    assert np.array_equal(ops.image_to_u8(y4.to(DEV), 3, round_bf16=True).cpu().numpy(), np.asarray(g["u8_bf16"]))
+    big = (torch.rand(3, 64, 64, 4, generator=torch.Generator().manual_seed(1)) * 3 - 1.5)
+    assert np.array_equal(ops.image_to_u8(big.to(DEV), 3).cpu().numpy(), R.image_to_uint8(big[..., :3].permute(0, 3, 1, 2)).numpy())
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_sampler_on_hip_dit_vs_reference_trajectory(tag):
+    """`transport.Sampler.sample_sde` with LightningDiT on the HIP kernels under autocast(bf16) -- the fused state update for Euler -- against the f32
+    trajectory captured from the reference (same noise stream): as close as the stock modules under autocast, and bit-identical to the same sampler
+    composed of tensor ops (the fused kernel changes no bit)."""
+    from dmvae_amd import transport as T
+    g = load_golden(tag)
+    kw = _kw(g)
+    m = small_dit(g["dit_seed"]).to(DEV)
+    z, y, ref = g.t("z").to(DEV), torch.from_numpy(np.asarray(g["y"])).to(DEV), g.t("xs")
+    sampler = T.Sampler(T.create_transport("Linear", "velocity", None, None, None, time_dist_shift=2.5))
+
+    def run(model_fn, fused=True):
+        fn = sampler.sample_sde(**kw)
+        T.FUSED_STATE_UPDATE = fused
+        try:
+            torch.manual_seed(int(g["seed"]))
+            with torch.no_grad(), torch.autocast("cuda", dtype=BF):
+                return torch.stack(fn(z, model_fn, y=y)).float().cpu()
+        finally:
+            T.FUSED_STATE_UPDATE = True
+
+    hip = run(m.forward)
+    stock = run(m.forward_stock)
+    e_hip, e_stock = rel_err(hip, ref), rel_err(stock, ref)
+    assert e_hip < max(2 * e_stock, 2e-2), (e_hip, e_stock)
+    assert rel_err(hip[-1], ref[-1]) < max(2 * rel_err(stock[-1], ref[-1]), 2e-2)
+    if kw["sampling_method"] == "Euler":
+        plain = run(m.forward, fused=False)
+        assert torch.equal(hip[:-1], plain[:-1])                       # every Euler-Maruyama state
+        if kw["last_step"] in ("Mean", None):
+            assert torch.equal(hip[-1], plain[-1])
+
+
+def test_decode_to_uint8_matches_decode_then_convert():
+    from dmvae_amd.models.vae import VAE
+    torch.manual_seed(3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=256, depth=1, num_heads=4)).to(DEV).eval()
+    tok = torch.randn(2, 256, 32, device=DEV) * 0.7
+    with torch.autocast("cuda", dtype=BF):
+        img = vae.decode(tok).float()
+        u8 = vae.decode_uint8(tok, round_bf16=False)
+        u8b = vae.decode_uint8(tok, round_bf16=True)
+    assert u8.shape == (2, 256, 256, 3) and u8.dtype == torch.uint8
+    assert torch.equal(u8.cpu(), R.image_to_uint8(img.cpu()))
+    assert torch.equal(u8b.cpu(), R.image_to_uint8(img.cpu().to(BF).float()))
+    assert 0 < u8.float().std() and u8.min() < 100 and u8.max() > 150     # not a degenerate image
+
+
+def test_sample_50k_loop_writes_the_reference_file_layout(tmp_path):
+    from PIL import Image
+    from dmvae_amd.models.lightningdit import LightningDiT
+    from dmvae_amd.models.vae import VAE
+    from dmvae_amd.sample import SamplePipeline, labels_and_indices
+    torch.manual_seed(4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=256, depth=1, num_heads=4)).to(DEV).eval()
+    dit = LightningDiT(input_size=16, patch_size=1, in_channels=32, hidden_size=128, depth=2, num_heads=2, num_classes=10).to(DEV).eval()
+    with torch.no_grad():
+        for blk in dit.blocks:
+            blk.adaLN_modulation[1].weight.normal_(0, 0.02)
+        dit.final_layer.linear.weight.normal_(0, 0.05)
+    pipe = SamplePipeline(dit, vae, num_sampling_steps=6, latent_mean=0.0685, latent_scale=0.1763, time_dist_shift=2.5)
+    for rank in (0, 1):
+        n = pipe.run(str(tmp_path), per_proc_batch_size=5, num_fid_samples=40, num_classes=10, rank=rank, world_size=2, max_iterations=2)
+        assert n == 10
+    names = sorted(os.listdir(tmp_path))
+    want = sorted(f"{i:06d}.png" for r in (0, 1) for row in labels_and_indices(40, 10, 2, r, 5)[1][:2] for i in row)
+    assert names == want and names[0] == "000010.png"
+    # one batch again with the same seeds: the PNG holds exactly the uint8 image of the pipeline
+    torch.manual_seed(9)
+    z = torch.randn(5, 32, 16, 16, device=DEV)
+    y = torch.tensor([0, 1, 2, 3, 4], device=DEV)
+    torch.manual_seed(10)
+    u8, tok = pipe.images_uint8(z, y)
+    torch.manual_seed(10)
+    u8b, _ = pipe.images_uint8(z, y)
+    assert torch.equal(u8, u8b) and tok.shape == (5, 256, 32) and torch.isfinite(tok).all()
+    p = tmp_path / "x.png"
+    Image.fromarray(u8[0].cpu().numpy()).save(p)
+    assert np.array_equal(np.asarray(Image.open(p)), u8[0].cpu().numpy())
+
+
+def test_diffusion_trainer_step_vs_stock_autocast_step():
+    """train_diffusion.py's step (frozen encode -> latents -> flow-matching loss -> clip -> AdamW -> EMA) on the HIP path against the same step written with
+    the stock modules, torch.optim.AdamW, clip_grad_norm_ and the reference's update_ema; same random draws."""
+    from dmvae_amd.models.lightningdit import LightningDiT
+    from dmvae_amd.models.vae import VAE
+    from dmvae_amd.train import DiffusionTrainer
+    torch.manual_seed(6)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=256, depth=1, num_heads=4)).to(DEV).eval()
+    dit = LightningDiT(input_size=16, patch_size=1, in_channels=32, hidden_size=128, depth=2, num_heads=2, num_classes=10).to(DEV)
+    with torch.no_grad():
+        for blk in dit.blocks:
+            blk.adaLN_modulation[1].weight.normal_(0, 0.02)
+        dit.final_layer.linear.weight.normal_(0, 0.05)
+    ref_m = copy.deepcopy(dit)
+    ema = copy.deepcopy(dit).eval().requires_grad_(False)
+    tr = DiffusionTrainer(dit, vae, lr=1e-3, latent_mean=0.05, latent_scale=0.8)
+    opt = torch.optim.AdamW([p for p in ref_m.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.95), weight_decay=0)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    images = torch.rand(4, 3, 256, 256, device=DEV, generator=g) * 2 - 1
+    labels = torch.tensor([3, 7, 1, 9], device=DEV)
+    x = tr.latents(images)
+    assert x.shape == (4, 32, 16, 16) and not x.requires_grad
+    for step in range(3):
+        p_before = tr.fp.flat.clone()
+        ema_before = tr.fp.ema.clone()
+        torch.manual_seed(100 + step)
+        loss = tr.step(images, labels)
+        # the stock step (train_diffusion.py:288-297)
+        ref_m.train()
+        torch.manual_seed(100 + step)
+        with torch.autocast("cuda", dtype=BF):
+            _, terms = tr.transport.training_losses(ref_m.forward_stock, x, dict(y=labels))
+        rloss = terms["loss"].mean().float()
+        opt.zero_grad()
+        rloss.backward()
+        rnorm = torch.nn.utils.clip_grad_norm_(ref_m.parameters(), 1.0)
+        opt.step()
+        with torch.no_grad():
+            for (n_, pe), (_, pm) in zip(ema.named_parameters(), ref_m.named_parameters()):
+                pe.mul_(0.9999).add_(pm.data, alpha=1 - 0.9999)
+        log = tr.read_log()
+        assert abs(log["loss"] - rloss.item()) < 2e-2 * abs(rloss.item()), (step, log, rloss.item())
+        assert abs(log["grad_norm"] - rnorm.item()) < 5e-2 * rnorm.item(), (step, log, rnorm.item())
+        # EMA recurrence of update_ema on the flat buffers
+        assert torch.allclose(tr.fp.ema, ema_before * 0.9999 + tr.fp.flat * (1 - 0.9999), rtol=1e-6, atol=1e-7)
+        d_hip = tr.fp.flat - p_before
+        assert d_hip.abs().max() <= 1e-3 * 1.0001                       # |AdamW update| <= lr at weight decay 0
+    # after three steps the two models moved the same way
+    names = {id(p): n for n, p in dit.named_parameters()}
+    ref_flat = torch.cat([dict(ref_m.named_parameters())[names[id(p)]].detach().flatten() for p in tr.fp.params])
+    init_flat = torch.cat([dict(ema.named_parameters())[names[id(p)]].detach().flatten() for p in tr.fp.params])       # ema ~ initial weights (decay 0.9999)
+    a, b = (tr.fp.flat - init_flat).double(), (ref_flat - init_flat).double()
+    cos = (a @ b / (a.norm() * b.norm())).item()
+    assert cos > 0.9, cos
+    sd = tr.ema_state_dict()
+    assert list(sd.keys()) == list(dit.state_dict().keys()) and torch.equal(sd["pos_embed"], dit.pos_embed)

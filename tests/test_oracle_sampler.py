@@ -1,0 +1,142 @@
+"""Downstream consumers on the CPU: the oracle's restatement of the reference's SDE sampler / interval table / uint8 conversion /
+work split, and the host mirror `dmvae_amd.transport` + `dmvae_amd.sample` (its generic tensor-op route; the fused kernel route is covered by
+tests/test_gpu_sampler.py), against the fixtures oracle/capture_golden_sampler.py captured from the reference's own `diffusion.transport` package."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import ref_cpu as R
+from oracle.detweights import det_fill_
+
+DIT_KW = dict(input_size=8, patch_size=1, in_channels=8, hidden_size=144, depth=2, num_heads=2, num_classes=10)
+CASES = ["sampler_euler_sigma_mean", "sampler_heun_linear_mean", "sampler_euler_decreasing_euler", "sampler_euler_incdec_tweedie", "sampler_euler_sigma_none"]
+
+
+def small_dit(seed):
+    from dmvae_amd.models.lightningdit import LightningDiT
+    m = LightningDiT(**DIT_KW).eval()
+    det_fill_(m, int(seed), skip=("pos_embed",))
+    return m
+
+
+def _kw(g):
+    ls = str(g["last_step"])
+    return dict(sampling_method=str(g["sampling_method"]), diffusion_form=str(g["diffusion_form"]), diffusion_norm=float(g["diffusion_norm"]),
+                last_step=None if ls == "None" else ls, last_step_size=float(g["last_step_size"]), num_steps=int(g["num_steps"]))
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_sde_sampler_oracle_and_host_mirror_vs_reference(tag):
+    from dmvae_amd.transport import Sampler, create_transport
+    g = load_golden(tag)
+    kw = _kw(g)
+    m = small_dit(g["dit_seed"])
+    z, y, ref = g.t("z"), torch.from_numpy(np.asarray(g["y"])), g.t("xs")
+    with torch.no_grad():
+        # oracle with the functional DiT restatement as the velocity model: f32 summation-order differences only, amplified over the steps
+        p = dict(m.state_dict())
+        torch.manual_seed(int(g["seed"]))
+        xs = R.sde_sample(z, lambda x, t: R.lightningdit_forward(x, t, y, p, DIT_KW["num_heads"], 1), num_steps=kw["num_steps"], method=kw["sampling_method"],
+                          form=kw["diffusion_form"], norm=kw["diffusion_norm"], last_step=kw["last_step"], last_step_size=kw["last_step_size"])
+        assert len(xs) == kw["num_steps"]
+        assert rel_err(torch.stack(xs), ref) < 2e-5
+        # oracle with the module mirror (same ops as the reference's module): the sampler arithmetic itself is reproduced to the last bit or two
+        torch.manual_seed(int(g["seed"]))
+        xs2 = R.sde_sample(z, lambda x, t: m.forward_stock(x, t, y), num_steps=kw["num_steps"], method=kw["sampling_method"], form=kw["diffusion_form"],
+                           norm=kw["diffusion_norm"], last_step=kw["last_step"], last_step_size=kw["last_step_size"])
+        assert (torch.stack(xs2) - ref).abs().max() <= 2e-6 * ref.abs().max()
+        # host mirror (generic route on CPU tensors), same names / arguments as the reference
+        fn = Sampler(create_transport("Linear", "velocity", None, None, None, time_dist_shift=2.5)).sample_sde(**kw)
+        torch.manual_seed(int(g["seed"]))
+        xs3 = fn(z, m.forward, y=y)
+        assert len(xs3) == kw["num_steps"]
+        assert (torch.stack(xs3) - ref).abs().max() <= 2e-6 * ref.abs().max()
+
+
+def test_sde_sampler_with_cfg_vs_reference():
+    from dmvae_amd.transport import Sampler, create_transport
+    g = load_golden("sampler_euler_cfg")
+    m = small_dit(g["dit_seed"])
+    z, y = g.t("z"), torch.from_numpy(np.asarray(g["y"]))
+    fn = Sampler(create_transport()).sample_sde(sampling_method="Euler", diffusion_form="sigma", last_step="Mean", last_step_size=0.04, num_steps=int(g["num_steps"]))
+    with torch.no_grad():
+        torch.manual_seed(int(g["seed"]))
+        xs = fn(z, m.forward_with_cfg, y=y, cfg_scale=float(g["cfg_scale"]), standard_cfg=True)
+    assert (torch.stack(xs) - g.t("xs")).abs().max() <= 2e-6 * g.t("xs").abs().max()
+
+
+def test_check_interval_table_and_training_losses_vs_reference():
+    from dmvae_amd.transport import ModelType, create_transport
+    g = load_golden("transport_train")
+    tr = create_transport("Linear", "velocity", None, None, None, time_dist_shift=float(g["time_dist_shift"]))
+    assert tr.model_type == ModelType.VELOCITY and tr.train_eps == 0 and tr.sample_eps == 0
+    for sbdm, sde, ev, rev, lss, t0, t1 in np.asarray(g["intervals"]):
+        got = tr.check_interval(tr.train_eps, tr.sample_eps, diffusion_form="SBDM" if sbdm else "sigma", sde=bool(sde), eval=bool(ev), reverse=bool(rev),
+                                last_step_size=float(lss))
+        assert got == (t0, t1), (sbdm, sde, ev, rev, lss)
+        if sde and ev and not rev:
+            assert R.sde_interval("Mean", float(lss), 0.0, "SBDM" if sbdm else "sigma") == (t0, t1)
+    m = small_dit(g["dit_seed"])
+    x1, y = g.t("x1"), torch.from_numpy(np.asarray(g["y"]))
+    with torch.no_grad():
+        torch.manual_seed(int(g["seed"]))
+        t, x0, _ = tr.sample(x1)
+        assert torch.equal(t, g.t("t")) and torch.equal(x0, g.t("x0"))            # same generator consumption: randn_like first, then rand
+        torch.manual_seed(int(g["seed"]))
+        t2, terms = tr.training_losses(m, x1, dict(y=y))
+    assert torch.equal(t2, g.t("t"))
+    assert rel_err(terms["pred"], g.t("pred")) < 2e-6 and rel_err(terms["loss"], g.t("loss")) < 2e-6
+    assert rel_err(R.transport_loss(g.t("pred"), t, x0, x1), g.t("loss")) < 1e-6
+    # other predictions / paths behave like the reference's factory
+    assert create_transport("Linear", "noise").train_eps == 1e-3
+    with pytest.raises(NotImplementedError):
+        create_transport("VP", "velocity")
+
+
+def test_image_uint8_and_latent_layout_vs_reference():
+    from dmvae_amd.sample import dit_output_to_tokens, tokens_to_dit_input
+    g = load_golden("image_u8")
+    s = g.t("s")
+    assert np.array_equal(R.image_to_uint8(s).numpy(), np.asarray(g["u8"]))
+    assert np.array_equal(R.image_to_uint8(s.to(torch.bfloat16).float()).numpy(), np.asarray(g["u8_bf16"]))
+    mean, scale = float(g["latent_mean"]), float(g["latent_scale"])
+    for f in (R.dit_output_to_latents, dit_output_to_tokens):
+        assert torch.equal(f(g.t("samples"), mean, scale), g.t("tokens"))
+    for f in (R.latents_to_dit_input, tokens_to_dit_input):
+        assert torch.equal(f(g.t("tokens"), mean, scale), g.t("back"))
+
+
+def test_sample50k_work_split_vs_reference():
+    from dmvae_amd.sample import labels_and_indices
+    g = load_golden("sample50k_plan")
+    for ws, n, nfid, ncls in ((8, 25, 50000, 1000), (2, 5, 40, 10)):
+        seen = set()
+        for rank in range(ws):
+            ys, idx = labels_and_indices(nfid, ncls, ws, rank, n)
+            assert (ys, idx) == R.sample50k_plan(nfid, ncls, ws, rank, n)
+            flat = [i for row in idx for i in row]
+            assert not seen & set(flat)                                      # ranks never write the same file
+            seen |= set(flat)
+            if rank in (0, ws - 1):
+                assert np.array_equal(np.array(ys), np.asarray(g[f"y_{ws}_{rank}"])) and np.array_equal(np.array(idx), np.asarray(g[f"i_{ws}_{rank}"]))
+        assert len(seen) == nfid and min(seen) == n * ws                     # the counter is advanced before its first use
+
+
+def test_fixed_grid_ode_orders():
+    """The fixed-grid ODE methods (unpinned: torchdiffeq is not in this image) on dx/dt = -x t-independent linear field: the error falls with the
+    method's order, and the time grid carries the reference's shift (integrators.py:97-98)."""
+    from dmvae_amd.transport import Sampler, create_transport
+    tr = create_transport(time_dist_shift=2.5)
+    x0 = torch.linspace(-1, 1, 16, dtype=torch.float64).view(2, 8)
+    errs = {}
+    for meth in ("euler", "midpoint", "heun3", "rk4"):
+        xs = Sampler(tr).sample_ode(sampling_method=meth, num_steps=21)(x0, lambda x, t: -x)
+        assert xs.shape == (21, 2, 8)
+        errs[meth] = (xs[-1] - x0 * np.exp(-1.0)).abs().max().item()
+    assert errs["euler"] > 10 * errs["midpoint"] > 10 * errs["heun3"] > errs["rk4"]
+    t = torch.linspace(0, 1, 21)
+    from dmvae_amd.transport import ode
+    assert torch.allclose(ode(None, t0=0, t1=1, sampler_type="euler", num_steps=21, atol=0, rtol=0, time_dist_shift=2.5).t, 1 - 2.5 * (1 - t) / (1 + 1.5 * (1 - t)))
+    with pytest.raises(NotImplementedError):
+        Sampler(tr).sample_ode(sampling_method="dopri5", num_steps=5)(x0, lambda x, t: -x)

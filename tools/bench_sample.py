@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""sample_50k.py's per-batch work at its defaults (per_proc_batch_size 25, SDE Euler, 250 steps, DiT-XL/1, ViT-L VAE decoder): images/s of
+noise -> latents -> decode -> uint8, HIP path (fused attention, fused state update, decode_uint8) vs the same loop on the stock modules with the state update
+composed of tensor ops and the reference's decode -> clamp -> permute -> uint8.  STEPS env shortens the trajectory for a quick look."""
+import os, sys, time, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dmvae_amd import transport as T
+from dmvae_amd.models.lightningdit import LightningDiT_models
+from dmvae_amd.models.vae import VAE
+from dmvae_amd.sample import SamplePipeline, dit_output_to_tokens
+N = int(os.environ.get("B", "25")); STEPS = int(os.environ.get("STEPS", "250"))
+torch.manual_seed(0)
+dit = LightningDiT_models["LightningDiT-XL/1"](input_size=16, in_channels=32, num_classes=1000).cuda().eval().requires_grad_(False)
+with torch.no_grad():
+    for blk in dit.blocks:
+        blk.adaLN_modulation[1].weight.normal_(0, 0.02)
+    dit.final_layer.linear.weight.normal_(0, 0.02)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    vae = VAE(z_channels=32, model_size="large").cuda().eval().requires_grad_(False)
+pipe = SamplePipeline(dit, vae, num_sampling_steps=STEPS, latent_mean=0.0685, latent_scale=0.1763, time_dist_shift=2.5)
+z = torch.randn(N, 32, 16, 16, device="cuda"); y = torch.randint(0, 1000, (N,), device="cuda")
+
+
+def hip():
+    return pipe.images_uint8(z, y)[0].cpu()
+
+
+def stock():
+    T.FUSED_STATE_UPDATE = False
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            s = pipe.sample_fn(z, dit.forward_stock, y=y)[-1]
+            img = vae.decode(dit_output_to_tokens(s.float(), 0.0685, 0.1763)).float()
+            return torch.clamp(127.5 * img + 128.0, 0, 255).permute(0, 2, 3, 1).to("cpu", dtype=torch.uint8)
+    finally:
+        T.FUSED_STATE_UPDATE = True
+
+
+for name, fn in (("hip", hip), ("stock DiT + tensor-op update", stock)):
+    fn() if STEPS <= 50 else None
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"{name}: {dt:.2f} s / batch of {N} ({STEPS} steps) = {N/dt:.2f} images/s, {dt/STEPS*1e3:.2f} ms / step; out {tuple(out.shape)} {out.dtype}", flush=True)
