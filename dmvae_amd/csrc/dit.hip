@@ -17,12 +17,15 @@ namespace dmvae_dit {
 constexpr int MAX_SWEEPS = 8;  // C <= 2048
 
 // one wave per row; mod: [B][stride] bf16 (the adaLN Linear's output), shift_off < 0: no shift
-__global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(const float* __restrict__ x, const float* __restrict__ w, const bf16* __restrict__ mod,
+// RES: first x[row] += bf16(gate[b] * r[row]) (the previous sub-layer's gated residual, written back), then the norm of the updated row.
+template <bool RES>
+__global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(float* __restrict__ x, const float* __restrict__ w, const bf16* __restrict__ mod,
                                                                bf16* __restrict__ y, int rows, int rows_per_sample, int C, int stride, int shift_off,
-                                                               int scale_off, float eps) {
+                                                               int scale_off, float eps, const bf16* __restrict__ r, const bf16* __restrict__ gmod,
+                                                               int gstride, int gate_off) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
-  const float* xr = x + (size_t)row * C;
+  float* xr = x + (size_t)row * C;
   f32x4 v[MAX_SWEEPS];
   float ss = 0.f;
 #pragma unroll
@@ -30,6 +33,13 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(const float* __re
     const int c = k * 256 + lane * 4;
     if (c < C) {
       v[k] = *reinterpret_cast<const f32x4*>(xr + c);
+      if constexpr (RES) {
+        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(r + (size_t)row * C + c);
+        const bf16x4 g = *reinterpret_cast<const bf16x4*>(gmod + (size_t)(row / rows_per_sample) * gstride + gate_off + c);
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[k][e] += (float)(bf16)((float)g[e] * (float)rv[e]);
+        *reinterpret_cast<f32x4*>(xr + c) = v[k];
+      }
       ss += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
     }
   }
@@ -375,8 +385,22 @@ extern "C" int dmvae_rmsnorm_modulate_bf16(const void* x, const void* w, const v
   DMVAE_CHECK_ARG(c % 4 == 0 && c >= 4 && c <= MAX_SWEEPS * 256, "rmsnorm_modulate_bf16: width must be a multiple of 4 up to 2048 (got %d)", c);
   DMVAE_CHECK_ARG(scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride,
                   "rmsnorm_modulate_bf16: modulation offsets must be multiples of 4 inside the row");
-  hipLaunchKernelGGL(rmsnorm_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y,
-                     rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps);
+  hipLaunchKernelGGL(rmsnorm_modulate_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
+                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_gated_residual_rmsnorm_modulate(void* x, const void* r, const void* gate_mod, int gate_stride, int gate_off, const void* w,
+                                                     const void* mod, void* y, int rows, int rows_per_sample, int c, int mod_stride, int shift_off,
+                                                     int scale_off, float eps, hipStream_t stream) {
+  DMVAE_CHECK_ARG(x && r && gate_mod && w && mod && y && rows > 0 && rows_per_sample > 0, "gated_residual_rmsnorm_modulate: bad argument");
+  DMVAE_CHECK_ARG(c % 4 == 0 && c >= 4 && c <= MAX_SWEEPS * 256, "gated_residual_rmsnorm_modulate: width must be a multiple of 4 up to 2048 (got %d)", c);
+  DMVAE_CHECK_ARG(scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride &&
+                      gate_off >= 0 && gate_off % 4 == 0 && gate_stride % 4 == 0 && gate_off + c <= gate_stride,
+                  "gated_residual_rmsnorm_modulate: modulation offsets must be multiples of 4 inside the row");
+  hipLaunchKernelGGL(rmsnorm_modulate_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
+                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }

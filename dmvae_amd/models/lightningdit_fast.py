@@ -2,7 +2,7 @@
 (the teacher's and the student's evaluations inside the DMD loss, train_dmd.py:211-217: four DiT-XL/1 forwards per VAE turn).
 
 Same arithmetic as `forward_stock` under autocast(bf16), with bf16 rounding at the sites where the reference's autocast graph rounds (see
-csrc/dit.hip); per block: 1 fused RMSNorm+modulate, qkv GEMM, 1 fused QK-norm+RoPE+head split, attention in one fused kernel (csrc/vit.hip, head dims 64 and 72
+csrc/dit.hip); per block: 1 fused (gated residual +) RMSNorm+modulate, qkv GEMM, 1 fused QK-norm+RoPE+head split, attention in one fused kernel (csrc/vit.hip, head dims 64 and 72
 alike: the staged head dim pads to 96; composed batched QK^T GEMM / f32 softmax / PV GEMM beyond 288 tokens), proj GEMM, 1 gated residual, RMSNorm+modulate, w12 GEMM, SwiGLU gate, w3 GEMM,
 gated residual.  The tiny per-sample pieces (timestep / label embedding, adaLN Linear) stay stock PyTorch under autocast."""
 import os
@@ -61,19 +61,31 @@ def forward_inference(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) 
     n = h.shape[1]
     cvec = model.t_embedder(t) + model.y_embedder(y, False)                     # stock modules under the caller's autocast: [B, C] f32
     sc = F.silu(cvec)
+    # Every gated residual is folded into the RMSNorm that follows it (one pass over the residual stream instead of two), so a block's MLP residual is applied
+    # by the NEXT block's norm1 -- or by the final layer's norm -- with that layer's modulation.
+    scb = sc.to(_BF)
+    fl = model.final_layer
+
+    def adaln(lin):
+        return F.linear(scb, _bf(lin.weight), _bf(lin.bias)).contiguous()       # [B, 6C]: shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp
+
+    pend = None                                                                   # (y, mod) of the previous block's MLP branch, not yet added to h
     for blk in model.blocks:
-        lin = blk.adaLN_modulation[1]
-        mod = F.linear(sc.to(_BF), _bf(lin.weight), _bf(lin.bias)).contiguous()  # [B, 6C]: shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp
-        a = ops.rmsnorm_modulate(h, blk.norm1.weight, mod, 0, c, blk.norm1.eps)
+        mod = adaln(blk.adaLN_modulation[1])
+        if pend is None:
+            a = ops.rmsnorm_modulate(h, blk.norm1.weight, mod, 0, c, blk.norm1.eps)
+        else:
+            a = ops.gated_residual_rmsnorm_modulate_(h, pend[0], pend[1], 5 * c, blk.norm1.weight, mod, 0, c, blk.norm1.eps)
         qkv = F.linear(a, _bf(blk.attn.qkv.weight), _bf(blk.attn.qkv.bias))
         o = F.linear(_attention(qkv, blk, model.feat_rope, heads), _bf(blk.attn.proj.weight), _bf(blk.attn.proj.bias))
-        ops.gated_residual_(h, o, mod, 2 * c)
-        a = ops.rmsnorm_modulate(h, blk.norm2.weight, mod, 3 * c, 4 * c, blk.norm2.eps)
+        a = ops.gated_residual_rmsnorm_modulate_(h, o, mod, 2 * c, blk.norm2.weight, mod, 3 * c, 4 * c, blk.norm2.eps)
         g = ops.swiglu(F.linear(a, _bf(blk.mlp.w12.weight), _bf(blk.mlp.w12.bias)))
-        ops.gated_residual_(h, F.linear(g, _bf(blk.mlp.w3.weight), _bf(blk.mlp.w3.bias)), mod, 5 * c)
-    fl = model.final_layer
-    mod = F.linear(sc.to(_BF), _bf(fl.adaLN_modulation[1].weight), _bf(fl.adaLN_modulation[1].bias)).contiguous()   # [B, 2C]: shift | scale
-    a = ops.rmsnorm_modulate(h, fl.norm_final.weight, mod, 0, c, fl.norm_final.eps)
+        pend = (F.linear(g, _bf(blk.mlp.w3.weight), _bf(blk.mlp.w3.bias)), mod)
+    mod = adaln(fl.adaLN_modulation[1])                                           # [B, 2C]: shift | scale
+    if pend is None:
+        a = ops.rmsnorm_modulate(h, fl.norm_final.weight, mod, 0, c, fl.norm_final.eps)
+    else:
+        a = ops.gated_residual_rmsnorm_modulate_(h, pend[0], pend[1], 5 * c, fl.norm_final.weight, mod, 0, c, fl.norm_final.eps)
     out = model.unpatchify(F.linear(a, _bf(fl.linear.weight), _bf(fl.linear.bias)))
     if model.learn_sigma:
         out, _ = out.chunk(2, dim=1)

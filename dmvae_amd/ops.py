@@ -520,6 +520,18 @@ def rmsnorm_modulate(x: torch.Tensor, w: torch.Tensor, mod: torch.Tensor, shift_
     return y
 
 
+def gated_residual_rmsnorm_modulate_(x: torch.Tensor, r: torch.Tensor, gate_mod: torch.Tensor, gate_off: int, w: torch.Tensor, mod: torch.Tensor,
+                                     shift_off: int, scale_off: int, eps: float = 1e-6) -> torch.Tensor:
+    """x [B,N,C] (f32, in place) += bf16(gate_mod[b, gate_off:gate_off+C] * r); returns rmsnorm_modulate(x, w, mod, shift_off, scale_off) -- one pass."""
+    x = _req(x, f32, "x"); r = _req(r, bf16, "r"); gate_mod = _req(gate_mod, bf16, "gate_mod"); mod = _req(mod, bf16, "mod")
+    b, n, c = x.shape
+    y = torch.empty(b, n, c, dtype=bf16, device=x.device)
+    check(_lib.lib().dmvae_gated_residual_rmsnorm_modulate(x.data_ptr(), r.data_ptr(), gate_mod.data_ptr(), gate_mod.shape[1], int(gate_off),
+                                                           _req(w, f32, "w").data_ptr(), mod.data_ptr(), y.data_ptr(), b * n, n, c, mod.shape[1],
+                                                           int(shift_off), int(scale_off), float(eps), _stream()), "gated_residual_rmsnorm_modulate")
+    return y
+
+
 def qknorm_rope(qkv: torch.Tensor, qw: torch.Tensor, kw: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, eps: float = 1e-6):
     """qkv [B,N,3*H*D] bf16 -> (q, k [B*H, N, Dp] with Dp = D rounded up to 32, v [B*H, N, D]): per-head RMSNorm * weight + 2-D RoPE on q and k."""
     qkv = _req(qkv, bf16, "qkv")

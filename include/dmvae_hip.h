@@ -222,9 +222,14 @@ int dmvae_gelu_bwd(const void* dy, const void* x, void* dx, size_t n, dmvae_stre
  * qknorm_rope: qkv [B][N][3][H][D] bf16 -> q, k: per-head RMSNorm (bf16 result) * weight, 2-D rotary embedding with the [N][D] cos / sin
  *   tables (pos_embed.py:96-135), bf16, head-major [B*H][N][Dp] zero-padded to Dp >= D; v copied head-major [B*H][N][D].  D even, Dp <= 128.
  * swiglu: out[rows][hidden] = bf16( bf16(silu(x1)) * x2 ), x12 = [x1 | x2] (swiglu_ffn.py:31-36).  hidden % 8 == 0.
- * gated_residual: x[rows][c] (f32) += bf16( gate[b] * y ).  c % 8 == 0. */
+ * gated_residual: x[rows][c] (f32) += bf16( gate[b] * y ).  c % 8 == 0.
+ * gated_residual_rmsnorm_modulate: the two back to back in one pass over the residual stream -- x += bf16(gate[b] * r) (gate from gate_mod, which may
+ *   be another adaLN output than `mod`: the next block's), x written back, then y = rmsnorm_modulate(x). */
 int dmvae_rmsnorm_modulate_bf16(const void* x, const void* w, const void* mod, void* y, int rows, int rows_per_sample, int c, int mod_stride,
                                 int shift_off, int scale_off, float eps, dmvae_stream_t stream);
+int dmvae_gated_residual_rmsnorm_modulate(void* x, const void* r, const void* gate_mod, int gate_stride, int gate_off, const void* w,
+                                          const void* mod, void* y, int rows, int rows_per_sample, int c, int mod_stride, int shift_off,
+                                          int scale_off, float eps, dmvae_stream_t stream);
 int dmvae_qknorm_rope_bf16(const void* qkv, const void* q_weight, const void* k_weight, const void* cos_table, const void* sin_table,
                            void* q_out, void* k_out, void* v_out, int batch, int seq, int heads, int head_dim, int head_dim_padded, float eps,
                            dmvae_stream_t stream);

@@ -48,6 +48,28 @@ def test_dit_elementwise_kernels(c, n):
     assert torch.equal(ops.swiglu(x12), want) or (ops.swiglu(x12).float() - want.float()).abs().max() <= 2 ** -7 * want.float().abs().max()
 
 
+@pytest.mark.parametrize("c,n", [(1152, 256), (144, 64), (2048, 32)])
+def test_gated_residual_rmsnorm_modulate_is_the_two_kernels_back_to_back(c, n):
+    from dmvae_amd import ops
+    g = torch.Generator().manual_seed(c + n)
+    b = 3
+    x = (torch.randn(b, n, c, generator=g) * 2).to(DEV)
+    r = torch.randn(b, n, c, generator=g).to(DEV).to(BF)
+    w = (1 + 0.3 * torch.randn(c, generator=g)).to(DEV)
+    gmod = (0.5 * torch.randn(b, 6 * c, generator=g)).to(DEV).to(BF)
+    mod = (0.5 * torch.randn(b, 6 * c, generator=g)).to(DEV).to(BF)
+    x1 = x.clone()
+    ops.gated_residual_(x1, r, gmod, 5 * c)
+    y1 = ops.rmsnorm_modulate(x1, w, mod, 3 * c, 4 * c)
+    x2 = x.clone()
+    y2 = ops.gated_residual_rmsnorm_modulate_(x2, r, gmod, 5 * c, w, mod, 3 * c, 4 * c)
+    assert torch.equal(x1, x2) and torch.equal(y1, y2)
+    y3 = ops.gated_residual_rmsnorm_modulate_(x.clone(), r, gmod, 2 * c, w, mod, -1, c)       # no shift
+    x4 = x.clone()
+    ops.gated_residual_(x4, r, gmod, 2 * c)
+    assert torch.equal(y3, ops.rmsnorm_modulate(x4, w, mod, -1, c))
+
+
 @pytest.mark.parametrize("heads,d", [(16, 72), (2, 64), (3, 32)])
 def test_qknorm_rope_kernel(heads, d):
     from dmvae_amd import ops

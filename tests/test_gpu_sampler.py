@@ -87,9 +87,12 @@ def test_sampler_on_hip_dit_vs_reference_trajectory(tag):
     assert rel_err(hip[-1], ref[-1]) < max(2 * rel_err(stock[-1], ref[-1]), 2e-2)
     if kw["sampling_method"] == "Euler":
         plain = run(m.forward, fused=False)
-        assert torch.equal(hip[:-1], plain[:-1])                       # every Euler-Maruyama state
-        if kw["last_step"] in ("Mean", None):
-            assert torch.equal(hip[-1], plain[-1])
+        if kw["diffusion_form"] in ("sigma", "linear"):
+            assert torch.equal(hip[:-1], plain[:-1])                   # every Euler-Maruyama state
+            if kw["last_step"] in ("Mean", None):
+                assert torch.equal(hip[-1], plain[-1])
+        else:       # cos / sin of the diffusion coefficient: evaluated on the host (= the CPU reference's libm) in the fused route, by the device's cosf / sinf in the composed one
+            assert rel_err(hip, plain) < 5e-3
 
 
 def test_decode_to_uint8_matches_decode_then_convert():
@@ -161,6 +164,7 @@ def test_diffusion_trainer_step_vs_stock_autocast_step():
         dit.final_layer.linear.weight.normal_(0, 0.05)
     ref_m = copy.deepcopy(dit)
     ema = copy.deepcopy(dit).eval().requires_grad_(False)
+    init = {n: p.detach().clone() for n, p in dit.named_parameters()}
     tr = DiffusionTrainer(dit, vae, lr=1e-3, latent_mean=0.05, latent_scale=0.8)
     opt = torch.optim.AdamW([p for p in ref_m.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.95), weight_decay=0)
     g = torch.Generator(device=DEV).manual_seed(0)
@@ -192,13 +196,17 @@ def test_diffusion_trainer_step_vs_stock_autocast_step():
         # EMA recurrence of update_ema on the flat buffers
         assert torch.allclose(tr.fp.ema, ema_before * 0.9999 + tr.fp.flat * (1 - 0.9999), rtol=1e-6, atol=1e-7)
         d_hip = tr.fp.flat - p_before
-        assert d_hip.abs().max() <= 1e-3 * 1.0001                       # |AdamW update| <= lr at weight decay 0
+        assert 0 < d_hip.abs().max() <= (1e-3 * 1.0001 if step == 0 else 1e-2)      # first AdamW update is lr * sign(g); no weight decay
     # after three steps the two models moved the same way
     names = {id(p): n for n, p in dit.named_parameters()}
     ref_flat = torch.cat([dict(ref_m.named_parameters())[names[id(p)]].detach().flatten() for p in tr.fp.params])
-    init_flat = torch.cat([dict(ema.named_parameters())[names[id(p)]].detach().flatten() for p in tr.fp.params])       # ema ~ initial weights (decay 0.9999)
-    a, b = (tr.fp.flat - init_flat).double(), (ref_flat - init_flat).double()
+    init_flat = torch.cat([init[names[id(p)]].flatten() for p in tr.fp.params])
+    hip_flat = torch.cat([p.detach().flatten() for p in tr.fp.params])
+    a, b = (hip_flat - init_flat).double(), (ref_flat - init_flat).double()
     cos = (a @ b / (a.norm() * b.norm())).item()
     assert cos > 0.9, cos
     sd = tr.ema_state_dict()
     assert list(sd.keys()) == list(dit.state_dict().keys()) and torch.equal(sd["pos_embed"], dit.pos_embed)
+    ema_ref = dict(ema.named_parameters())
+    k = "blocks.1.mlp.w12.weight"
+    assert (sd[k] - ema_ref[k]).abs().max() < 1e-2 * (ema_ref[k] - init[k]).abs().max() + 1e-7       # both averages sit 3e-4 of the way along ~the same path
