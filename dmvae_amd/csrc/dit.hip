@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(float* __restrict
                                                                bf16* __restrict__ y, int rows, int rows_per_sample, int C, int stride, int shift_off,
                                                                int scale_off, float eps, const bf16* __restrict__ r, const bf16* __restrict__ gmod,
                                                                int gstride, int gate_off) {
+#pragma clang fp contract(off)   // both instantiations evaluate the expressions exactly as written: fused and unfused routes agree to the bit
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   float* xr = x + (size_t)row * C;

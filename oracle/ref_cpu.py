@@ -24,6 +24,7 @@ Reference files followed (all under /root/reference):
   toy_example_2d/dmd.py:320-360, toy_example_2d/sshpae.py:29-71
   models/patchgan.py:99-151  utils/diffaug.py:43-114  train_tokenizer.py:190-227 (discriminator branch)
   diffusion/lightningdit/{lightningdit.py:27-421, rms_norm.py:34-76, swiglu_ffn.py:15-36, pos_embed.py:37-41,96-135}
+  diffusion/transport/{integrators.py:8-77, transport.py:75-102,236-354, path.py:42-89}  sample_50k.py:128-157  train_diffusion.py:276-290
 """
 from __future__ import annotations
 

@@ -149,7 +149,9 @@ def test_sample_50k_loop_writes_the_reference_file_layout(tmp_path):
 
 def test_diffusion_trainer_step_vs_stock_autocast_step():
     """train_diffusion.py's step (frozen encode -> latents -> flow-matching loss -> clip -> AdamW -> EMA) on the HIP path against the same step written with
-    the stock modules, torch.optim.AdamW, clip_grad_norm_ and the reference's update_ema; same random draws."""
+    the stock modules, torch.optim.AdamW, clip_grad_norm_ and the reference's update_ema; same random draws.  Forward / backward: loss and gradient norm
+    of the stock route at the same weights.  Optimiser tail: the stock optimiser fed the HIP path's gradients must land on the same weights (Adam's
+    g / sqrt(v) turns bf16 noise on near-zero gradients into full-size steps, so two independent bf16 runs cannot be compared weight by weight)."""
     from dmvae_amd.models.lightningdit import LightningDiT
     from dmvae_amd.models.vae import VAE
     from dmvae_amd.train import DiffusionTrainer
@@ -164,20 +166,18 @@ def test_diffusion_trainer_step_vs_stock_autocast_step():
         dit.final_layer.linear.weight.normal_(0, 0.05)
     ref_m = copy.deepcopy(dit)
     ema = copy.deepcopy(dit).eval().requires_grad_(False)
-    init = {n: p.detach().clone() for n, p in dit.named_parameters()}
     tr = DiffusionTrainer(dit, vae, lr=1e-3, latent_mean=0.05, latent_scale=0.8)
-    opt = torch.optim.AdamW([p for p in ref_m.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.95), weight_decay=0)
+    names = {id(p): n for n, p in dit.named_parameters()}
+    ref_p = dict(ref_m.named_parameters())
+    opt = torch.optim.AdamW([ref_p[names[id(p)]] for p in tr.fp.params], lr=1e-3, betas=(0.9, 0.95), weight_decay=0)
     g = torch.Generator(device=DEV).manual_seed(0)
     images = torch.rand(4, 3, 256, 256, device=DEV, generator=g) * 2 - 1
     labels = torch.tensor([3, 7, 1, 9], device=DEV)
     x = tr.latents(images)
     assert x.shape == (4, 32, 16, 16) and not x.requires_grad
     for step in range(3):
-        p_before = tr.fp.flat.clone()
         ema_before = tr.fp.ema.clone()
-        torch.manual_seed(100 + step)
-        loss = tr.step(images, labels)
-        # the stock step (train_diffusion.py:288-297)
+        # the stock forward / backward at the current weights (train_diffusion.py:288-293)
         ref_m.train()
         torch.manual_seed(100 + step)
         with torch.autocast("cuda", dtype=BF):
@@ -186,27 +186,25 @@ def test_diffusion_trainer_step_vs_stock_autocast_step():
         opt.zero_grad()
         rloss.backward()
         rnorm = torch.nn.utils.clip_grad_norm_(ref_m.parameters(), 1.0)
+        torch.manual_seed(100 + step)
+        loss = tr.step(images, labels)
+        log = tr.read_log()
+        assert abs(loss.item() - log["loss"]) < 1e-6
+        assert abs(log["loss"] - rloss.item()) < 2e-2 * abs(rloss.item()), (step, log, rloss.item())
+        assert abs(log["grad_norm"] - rnorm.item()) < 5e-2 * rnorm.item(), (step, log, rnorm.item())
+        # the stock tail (:294-297) on the HIP path's gradients
+        for p_, off in zip(tr.fp.params, tr.fp.offsets):
+            ref_p[names[id(p_)]].grad = tr.fp.grad[off:off + p_.numel()].view(p_.shape).clone()
+        torch.nn.utils.clip_grad_norm_([ref_p[names[id(p_)]] for p_ in tr.fp.params], 1.0)
         opt.step()
         with torch.no_grad():
             for (n_, pe), (_, pm) in zip(ema.named_parameters(), ref_m.named_parameters()):
                 pe.mul_(0.9999).add_(pm.data, alpha=1 - 0.9999)
-        log = tr.read_log()
-        assert abs(log["loss"] - rloss.item()) < 2e-2 * abs(rloss.item()), (step, log, rloss.item())
-        assert abs(log["grad_norm"] - rnorm.item()) < 5e-2 * rnorm.item(), (step, log, rnorm.item())
-        # EMA recurrence of update_ema on the flat buffers
-        assert torch.allclose(tr.fp.ema, ema_before * 0.9999 + tr.fp.flat * (1 - 0.9999), rtol=1e-6, atol=1e-7)
-        d_hip = tr.fp.flat - p_before
-        assert 0 < d_hip.abs().max() <= (1e-3 * 1.0001 if step == 0 else 1e-2)      # first AdamW update is lr * sign(g); no weight decay
-    # after three steps the two models moved the same way
-    names = {id(p): n for n, p in dit.named_parameters()}
-    ref_flat = torch.cat([dict(ref_m.named_parameters())[names[id(p)]].detach().flatten() for p in tr.fp.params])
-    init_flat = torch.cat([init[names[id(p)]].flatten() for p in tr.fp.params])
-    hip_flat = torch.cat([p.detach().flatten() for p in tr.fp.params])
-    a, b = (hip_flat - init_flat).double(), (ref_flat - init_flat).double()
-    cos = (a @ b / (a.norm() * b.norm())).item()
-    assert cos > 0.9, cos
+        for p_, e_ in zip(tr.fp.params, tr.fp.ema_state()):
+            n_ = names[id(p_)]
+            assert torch.allclose(p_.detach(), ref_p[n_].detach(), rtol=1e-5, atol=2e-6), (step, n_)
+            assert torch.allclose(e_, dict(ema.named_parameters())[n_], rtol=1e-5, atol=1e-6), (step, n_)
+        assert torch.allclose(tr.fp.ema, ema_before * 0.9999 + tr.fp.flat * (1 - 0.9999), rtol=1e-6, atol=1e-7)      # update_ema's recurrence
     sd = tr.ema_state_dict()
     assert list(sd.keys()) == list(dit.state_dict().keys()) and torch.equal(sd["pos_embed"], dit.pos_embed)
-    ema_ref = dict(ema.named_parameters())
-    k = "blocks.1.mlp.w12.weight"
-    assert (sd[k] - ema_ref[k]).abs().max() < 1e-2 * (ema_ref[k] - init[k]).abs().max() + 1e-7       # both averages sit 3e-4 of the way along ~the same path
+    assert not torch.equal(sd["blocks.1.mlp.w12.weight"], dit.state_dict()["blocks.1.mlp.w12.weight"])
