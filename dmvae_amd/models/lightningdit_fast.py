@@ -92,6 +92,41 @@ def forward_inference(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) 
     return out
 
 
+class GraphedInference:
+    """`forward_inference` of a FROZEN model captured once in a hipGraph and replayed: `f(x, t, y)` copies the arguments into the graph's static inputs,
+    replays ~330 kernel launches with one host call and returns the graph's static output buffer (overwritten by the next call -- consume it first).
+    For loops that call the same model hundreds of times at one shape (the sampler: 250 steps per batch, where launching the kernels one by one
+    leaves the GPU idle 10-15 % of the step).  Must be built and called under the autocast(bf16) context `forward_inference` needs.  The captured kernels
+    read the cached bf16 copies of the weights: rebuild after the weights change."""
+
+    def __init__(self, model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor, warmup: int = 2):
+        if not supported(model, x):
+            raise RuntimeError("GraphedInference needs the HIP inference route (CUDA tensors under torch.autocast('cuda', dtype=torch.bfloat16))")
+        self.model = model
+        self.x, self.t, self.y = x.detach().clone(), t.detach().clone(), y.detach().clone()
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():                      # warm-up off the capture: lazy kernel attributes, GEMM heuristics, weight caches
+            for _ in range(warmup):
+                forward_inference(model, self.x, self.t, self.y)
+        cur.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = forward_inference(model, self.x, self.t, self.y)
+
+    def matches(self, x, t, y) -> bool:
+        return x.shape == self.x.shape and x.dtype == self.x.dtype and t.shape == self.t.shape and y.shape == self.y.shape and x.device == self.x.device
+
+    def __call__(self, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        assert self.matches(x, t, y), "GraphedInference: shapes differ from the captured ones"
+        self.x.copy_(x)
+        self.t.copy_(t)
+        self.y.copy_(y)
+        self.graph.replay()
+        return self.out
+
+
 def forward_train(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """`forward` with gradients (the student's flow-matching turn, train_dmd.py:565-575) under the caller's autocast(bf16): embedders, adaLN Linears
     and the output Linear through stock autograd (per-sample or single GEMMs), every block as one `functional.DitBlockFn`, the final norm as

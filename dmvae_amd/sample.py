@@ -87,10 +87,11 @@ class SamplePipeline:
 
     def __init__(self, model, vae, *, mode="SDE", sampling_method="Euler", num_sampling_steps=250, diffusion_form="sigma", diffusion_norm=1.0,
                  last_step="Mean", last_step_size=0.04, atol=1e-6, rtol=1e-3, reverse=False, cfg_scale=1.0, latent_mean=0.0, latent_scale=1.0,
-                 path_type="Linear", prediction="velocity", loss_weight=None, train_eps=0.0, sample_eps=0.0, time_dist_shift=1.0):
+                 path_type="Linear", prediction="velocity", loss_weight=None, train_eps=0.0, sample_eps=0.0, time_dist_shift=1.0, use_graph=True):
         assert cfg_scale >= 1.0, "In almost all cases, cfg_scale be >= 1.0"
         self.model, self.vae = model, vae
         self.latent_mean, self.latent_scale, self.cfg_scale = latent_mean, latent_scale, cfg_scale
+        self.use_graph, self._graphed = use_graph, None      # the frozen DiT forward as one hipGraph replay per sampler step (models/lightningdit_fast.GraphedInference)
         transport = create_transport(path_type, prediction, loss_weight, train_eps, sample_eps, time_dist_shift=time_dist_shift)
         sampler = Sampler(transport)
         if mode == "ODE":
@@ -103,8 +104,18 @@ class SamplePipeline:
     def latents(self, z: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         """noise [n, C, h, w] + labels [n] -> latent tokens [n, h*w, C] (sample_50k.py:138-148), under autocast(bf16) like the script."""
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            samples = self.sample_fn(z, self.model.forward, y=y)[-1]          # the script never enables guidance (cfg_scale stays 1.0, :79)
+            samples = self.sample_fn(z, self._model_fn(z, y), y=y)[-1]        # the script never enables guidance (cfg_scale stays 1.0, :79)
         return dit_output_to_tokens(samples.float(), self.latent_mean, self.latent_scale)
+
+    def _model_fn(self, z, y):
+        """`model.forward`, or its hipGraph replay when the model takes the HIP inference route at this shape (called under autocast)."""
+        from .models import lightningdit_fast as fast
+        if not (self.use_graph and z.is_cuda and hasattr(self.model, "blocks") and fast.supported(self.model, z)):
+            return self.model.forward
+        t = torch.zeros(z.shape[0], device=z.device, dtype=z.dtype)
+        if self._graphed is None or not self._graphed.matches(z, t, y):
+            self._graphed = fast.GraphedInference(self.model, z, t, y)
+        return self._graphed
 
     @torch.no_grad()
     def images_uint8(self, z: torch.Tensor, y: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -95,6 +95,39 @@ def test_sampler_on_hip_dit_vs_reference_trajectory(tag):
             assert rel_err(hip, plain) < 5e-3
 
 
+def test_graphed_dit_forward_replays_bit_exactly():
+    """lightningdit_fast.GraphedInference (the frozen DiT forward captured in a hipGraph, one replay per sampler step) returns exactly what the kernel-by-kernel
+    forward returns, for new inputs each call; SamplePipeline produces the same latents with and without it."""
+    from dmvae_amd.models import lightningdit_fast as fast
+    from dmvae_amd.models.lightningdit import LightningDiT
+    from dmvae_amd.sample import SamplePipeline
+    torch.manual_seed(8)
+    dit = LightningDiT(input_size=16, patch_size=1, in_channels=32, hidden_size=144, depth=3, num_heads=2, num_classes=10).to(DEV).eval().requires_grad_(False)
+    with torch.no_grad():
+        for blk in dit.blocks:
+            blk.adaLN_modulation[1].weight.normal_(0, 0.02)
+        dit.final_layer.linear.weight.normal_(0, 0.05)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    mk = lambda: (torch.randn(5, 32, 16, 16, device=DEV, generator=g), torch.rand(5, device=DEV, generator=g), torch.randint(0, 11, (5,), device=DEV, generator=g))
+    with torch.no_grad(), torch.autocast("cuda", dtype=BF):
+        gi = fast.GraphedInference(dit, *mk())
+        for _ in range(3):
+            x, t, y = mk()
+            want = dit(x, t, y).clone()
+            got = gi(x, t, y)
+            assert torch.equal(got, want)
+        with pytest.raises(AssertionError):
+            gi(x[:2], t[:2], y[:2])
+    z, y = torch.randn(5, 32, 16, 16, device=DEV, generator=g), torch.tensor([0, 3, 5, 7, 9], device=DEV)
+    outs = []
+    for use_graph in (True, False):
+        pipe = SamplePipeline(dit, None, num_sampling_steps=7, latent_mean=0.0685, latent_scale=0.1763, use_graph=use_graph)
+        torch.manual_seed(77)
+        outs.append(pipe.latents(z, y))
+        assert (pipe._graphed is not None) == use_graph
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_decode_to_uint8_matches_decode_then_convert():
     from dmvae_amd.models.vae import VAE
     torch.manual_seed(3)
