@@ -76,6 +76,7 @@ SIGNATURES = {
     "dmvae_kl_mmd": (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "dmvae_grad_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_int, c_void_p]),
     "dmvae_adamw_ema_step": (c_int, [c_void_p] * 6 + [c_size_t] + [c_float] * 5 + [c_int, c_float, c_void_p]),
+    "dmvae_adamw_ema_step_shadow": (c_int, [c_void_p] * 7 + [c_size_t] + [c_float] * 5 + [c_int, c_float, c_void_p]),
     "dmvae_groupnorm_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dmvae_groupnorm_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dmvae_groupnorm_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

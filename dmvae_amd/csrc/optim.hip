@@ -41,7 +41,7 @@ __global__ void norm_final_kernel(const float* __restrict__ part, float* __restr
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, float* __restrict__ ema,
                                                         const float* __restrict__ clip, size_t n, float lr, float b1, float b2,
-                                                        float eps, float wd, float bc1, float bc2_sqrt, float decay) {
+                                                        float eps, float wd, float bc1, float bc2_sqrt, float decay, bf16* __restrict__ shadow) {
   const float coef = clip ? clip[1] : 1.f;
   const float step = lr / bc1;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, c
     pi -= step * mi / denom;
     p[i] = pi; m[i] = mi; v[i] = vi;
     if (ema) ema[i] = ema[i] * decay + pi * (1.f - decay);
+    if (shadow) shadow[i] = (bf16)pi;   // the bf16 copy autocast would make of the new weight (RNE), for the next forward's GEMM operands
   }
 }
 
@@ -71,9 +72,8 @@ extern "C" int dmvae_grad_norm(const void* grads, void* norm_out3, void* workspa
   return 0;
 }
 
-extern "C" int dmvae_adamw_ema_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, void* ema, const void* norm_out3,
-                                    size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                                    float ema_decay, hipStream_t stream) {
+static int adamw_launch(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, void* ema, void* shadow, const void* norm_out3, size_t n,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int step, float ema_decay, hipStream_t stream) {
   DMVAE_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, "adamw_ema_step: null pointer");
   DMVAE_CHECK_ARG(step >= 1, "adamw_ema_step: step counts from 1");
   if (n == 0) return 0;
@@ -81,7 +81,20 @@ extern "C" int dmvae_adamw_ema_step(void* params, const void* grads, void* exp_a
   const float bc2 = 1.f - powf(beta2, (float)step);
   size_t nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (float*)params, (const float*)grads, (float*)exp_avg,
-                     (float*)exp_avg_sq, (float*)ema, (const float*)norm_out3, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), ema_decay);
+                     (float*)exp_avg_sq, (float*)ema, (const float*)norm_out3, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), ema_decay,
+                     (bf16*)shadow);
   DMVAE_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int dmvae_adamw_ema_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, void* ema, const void* norm_out3,
+                                    size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                    float ema_decay, hipStream_t stream) {
+  return adamw_launch(params, grads, exp_avg, exp_avg_sq, ema, nullptr, norm_out3, n, lr, beta1, beta2, eps, weight_decay, step, ema_decay, stream);
+}
+
+extern "C" int dmvae_adamw_ema_step_shadow(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, void* ema, void* bf16_shadow,
+                                           const void* norm_out3, size_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                           int step, float ema_decay, hipStream_t stream) {
+  return adamw_launch(params, grads, exp_avg, exp_avg_sq, ema, bf16_shadow, norm_out3, n, lr, beta1, beta2, eps, weight_decay, step, ema_decay, stream);
 }

@@ -427,6 +427,17 @@ class MLPFn(torch.autograd.Function):
 # train_dmd.py:349,519) ------------------------------------------------------------------------------------------------------------
 def _bf(w: torch.Tensor) -> torch.Tensor:
     """bf16 copy of an f32 Linear parameter -- what autocast(bf16) feeds the GEMM -- cached until the parameter changes."""
+    sh = getattr(w, "_dmvae_shadow", None)
+    if sh is not None:                                   # optim.FlatParams.enable_bf16_shadow: kept current by the fused optimiser step
+        ver = (w.data_ptr(), w._version)
+        if w._dmvae_shadow_ver != ver:                   # changed by something else (load_state_dict, in-place op) or re-pointed: convert again
+            if w._dmvae_shadow_ver[0] != ver[0] or sh.shape != w.shape:      # the parameter no longer lives in the flat buffer
+                sh = None
+            else:
+                sh.copy_(w.detach())
+                w._dmvae_shadow_ver = ver
+        if sh is not None:
+            return sh
     cache = getattr(w, "_dmvae_bf16", None)
     ver = (w.data_ptr(), w._version, _epoch_of(w))
     if cache is not None and cache[0] == ver:

@@ -724,8 +724,15 @@ def grad_norm(flat_grads: torch.Tensor, max_norm: float, norm_out: Optional[torc
     return out
 
 
-def adamw_ema_step(p, g, m, v, ema, norm_out, lr, beta1, beta2, eps, wd, step, ema_decay):
+def adamw_ema_step(p, g, m, v, ema, norm_out, lr, beta1, beta2, eps, wd, step, ema_decay, shadow=None):
     for name, t in (("p", p), ("g", g), ("m", m), ("v", v)):
         _req(t, f32, name)
+    if shadow is not None:
+        _req(shadow, bf16, "shadow")
+        assert shadow.numel() == p.numel()
+        check(_lib.lib().dmvae_adamw_ema_step_shadow(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(ema), shadow.data_ptr(), _ptr(norm_out),
+                                                     p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step), float(ema_decay),
+                                                     _stream()), "adamw_ema_step_shadow")
+        return
     check(_lib.lib().dmvae_adamw_ema_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(ema), _ptr(norm_out), p.numel(), float(lr),
                                           float(beta1), float(beta2), float(eps), float(wd), int(step), float(ema_decay), _stream()), "adamw_ema_step")

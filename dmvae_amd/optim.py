@@ -38,6 +38,17 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
 
+    def enable_bf16_shadow(self) -> None:
+        """Keep a bf16 copy of the whole flat buffer that the fused optimiser step refreshes in the pass that writes the new weights
+        (`dmvae_adamw_ema_step_shadow`); `functional._bf` then hands GEMMs views of it instead of converting every Linear weight after every
+        step (the DMD stage: ~680 conversion launches per step over ViT-L + DiT-XL).  A parameter changed by anything else (load_state_dict,
+        an in-place torch op: `_version` moves) is re-converted on its next use."""
+        self.shadow = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat.device)
+        self.shadow.copy_(self.flat)
+        for p, off in zip(self.params, self.offsets):
+            p._dmvae_shadow = self.shadow[off:off + p.numel()].view(p.shape)
+            p._dmvae_shadow_ver = (p.data_ptr(), p._version)
+
     def enable_direct_grads(self, only=None) -> None:
         """The HIP backward Functions (dmvae_amd.functional) then WRITE each parameter gradient straight into its slice of the
         flat buffer and hand that view to autograd, instead of returning a fresh tensor that AccumulateGrad adds into `.grad`
@@ -90,6 +101,6 @@ class FlatAdamWEMA:
         self.t += 1
         ops.grad_norm(self.fp.grad, self.max_norm, norm_out=self.norm)
         ops.adamw_ema_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.fp.ema, self.norm if self.max_norm > 0 else None,
-                           lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, self.ema_decay)
+                           lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, self.ema_decay, shadow=getattr(self.fp, "shadow", None))
         self.fp.epoch[0] += 1       # weights changed through raw pointers: the cached bf16 operands of THESE parameters are stale
         return self.norm            # device tensor; no host sync

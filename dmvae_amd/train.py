@@ -227,6 +227,7 @@ class DMDTrainer:
         # gradients reach the embeddings through stock autograd and the blocks through the HIP Functions: both accumulate into the flat
         # buffer's views (no direct writes in this harness)
         self.fp = FlatParams(params, with_ema=False)
+        self.fp.enable_bf16_shadow()          # Linear weights of the trainable ViT / bottleneck: bf16 GEMM operands written by the optimiser step
         self.opt = FlatAdamWEMA(self.fp, lr=lr, weight_decay=wd, warmup_steps=warmup_steps, max_norm=max_norm)
         self.sync = dist.FlatGradSync(params, self.fp.grad, self.fp.offsets, bucket_bytes=bucket_bytes)
         # the student's AdamW (train_dmd.py:473, :565-575) on flat buffers like the VAE's: one norm pass + one fused update instead of torch's
@@ -235,6 +236,7 @@ class DMDTrainer:
         self.sfp = self.sopt = None
         if sp:
             self.sfp = FlatParams(sp, with_ema=False)
+            self.sfp.enable_bf16_shadow()
             direct = [p for n_, p in student.named_parameters() if p.requires_grad and n_.startswith("blocks.") and "adaLN_modulation" not in n_]
             from .models.lightningdit import LightningDiT
             if isinstance(student, LightningDiT) and direct:
@@ -360,6 +362,7 @@ class DiffusionTrainer:
         vae.eval()
         params = [p for p in model.parameters() if p.requires_grad]
         self.fp = FlatParams(params, with_ema=True)
+        self.fp.enable_bf16_shadow()
         direct = [p for n_, p in model.named_parameters() if p.requires_grad and n_.startswith("blocks.") and "adaLN_modulation" not in n_]
         if isinstance(model, LightningDiT) and direct:
             self.fp.enable_direct_grads(only=direct)

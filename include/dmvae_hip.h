@@ -304,6 +304,11 @@ int dmvae_grad_norm(const void* grads, void* norm_out3, void* workspace, size_t 
 int dmvae_adamw_ema_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, void* ema,
                          const void* norm_out3, size_t n, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int step, float ema_decay, dmvae_stream_t stream);
+/* Same step, also writing bf16_shadow[i] = bf16(params[i]) (round to nearest even): the copy torch.autocast(bfloat16) makes of every Linear weight
+ * on every forward (`weight.to(bfloat16)`), produced once per optimiser step in the pass that already holds the new value. */
+int dmvae_adamw_ema_step_shadow(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, void* ema, void* bf16_shadow,
+                                const void* norm_out3, size_t n, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, int step, float ema_decay, dmvae_stream_t stream);
 
 /* ---- downstream consumers: SDE sampler state update and image -> uint8 (sample_50k.py:142-164) ---- */
 

@@ -369,11 +369,18 @@ def test_adamw_ema_golden():
     sizes = [g["p0." + n].size for n in names]
     flat = torch.cat([g.t("p0." + n).flatten() for n in names]).to(DEV)
     ema, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+    flat0 = flat.clone()
     for it in range(6):
         gr = torch.cat([g.t(f"g{it}.{i}").flatten() for i in range(4)]).to(DEV)
         norm = ops.grad_norm(gr, 1.0)
         assert abs(norm[0].item() - float(g["norms"][it])) < 1e-5 * float(g["norms"][it])
         ops.adamw_ema_step(flat, gr, m, v, ema, norm, R.warmup_lr(it, 1e-4, int(g["warmup_steps"])), 0.9, 0.95, 1e-8, 0.005, it + 1, 0.9999)
+        # the shadow-writing variant: identical f32 state, plus bf16(new weight) -- autocast's per-forward `weight.to(bfloat16)` made once per step
+        if it == 0:
+            flat2, ema2, m2, v2, sh = flat0.clone(), flat0.clone(), torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros(flat.numel(), dtype=BF, device=DEV)
+        ops.adamw_ema_step(flat2, gr, m2, v2, ema2, norm, R.warmup_lr(it, 1e-4, int(g["warmup_steps"])), 0.9, 0.95, 1e-8, 0.005, it + 1, 0.9999, shadow=sh)
+        assert torch.equal(flat2, flat) and torch.equal(ema2, ema) and torch.equal(m2, m) and torch.equal(v2, v)
+        assert torch.equal(sh, flat.to(BF))
     off = 0
     for n, sz in zip(names, sizes):
         assert rel_err(flat[off:off + sz].cpu(), g.t("p6." + n).flatten()) < 1e-6

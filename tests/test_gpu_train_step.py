@@ -198,3 +198,11 @@ def test_dmd_stage_step_harness():
     assert enc_w.grad is not None and enc_w.grad.abs().max() > 0                       # the encoder trains in this stage
     tr2, snaps2 = run()
     assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(snaps, snaps2))
+    # the bf16 shadows the fused optimiser step maintains are what a fresh conversion would give, and functional._bf serves them
+    from dmvae_amd import functional as Fn
+    assert torch.equal(tr.fp.shadow, tr.fp.flat.to(torch.bfloat16))
+    w = tr.vae.encoder.model.blocks[0].attn.qkv.weight
+    assert Fn._bf(w).data_ptr() == w._dmvae_shadow.data_ptr() and torch.equal(Fn._bf(w), w.detach().to(torch.bfloat16))
+    with torch.no_grad():
+        w.mul_(1.5)                                      # changed behind the optimiser's back: converted again on next use
+    assert torch.equal(Fn._bf(w), w.detach().to(torch.bfloat16))
