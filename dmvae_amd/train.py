@@ -13,6 +13,7 @@ D(aug([images; recon])) plus the BCR consistency term, clip, AdamW (train_tokeni
 """
 from __future__ import annotations
 
+import os
 import warnings
 from typing import Dict, Optional
 
@@ -224,9 +225,16 @@ class DMDTrainer:
             p.requires_grad_(True)                                         # train_dmd.py:519
         params = backward_order_params_full(vae)
         assert sum(p.numel() for p in params) == sum(p.numel() for p in vae.parameters())
-        # gradients reach the embeddings through stock autograd and the blocks through the HIP Functions: both accumulate into the flat
-        # buffer's views (no direct writes in this harness)
+        # decoder, bottleneck and encoder-block gradients are written by the HIP Functions straight into the flat buffer (each of those parameters
+        # receives exactly one gradient per backward); the embeddings' gradients arrive through stock autograd and accumulate into their zeroed views
         self.fp = FlatParams(params, with_ema=False)
+        if os.environ.get("DMVAE_DMD_DIRECT_GRADS", "1") != "0":
+            from .models.vit_fast import hip_path_supported
+            vit = vae.encoder.model
+            pre = ("decoder.", "bottle_neck.")
+            if getattr(vit, "blocks", None) is not None and hasattr(vit, "pos_embed") and hip_path_supported(vit, vit.pos_embed.shape[1]):
+                pre += ("encoder.model.blocks.", "encoder.model.norm.")      # else the encoder runs on the stock modules and autograd owns its gradients
+            self.fp.enable_direct_grads(only=[p for n_, p in vae.named_parameters() if p.requires_grad and n_.startswith(pre)])
         self.fp.enable_bf16_shadow()          # Linear weights of the trainable ViT / bottleneck: bf16 GEMM operands written by the optimiser step
         self.opt = FlatAdamWEMA(self.fp, lr=lr, weight_decay=wd, warmup_steps=warmup_steps, max_norm=max_norm)
         self.sync = dist.FlatGradSync(params, self.fp.grad, self.fp.offsets, bucket_bytes=bucket_bytes)

@@ -1,6 +1,7 @@
 """Step-harness checks on the GPU: direct flat-buffer gradients == autograd-accumulated gradients (bit-exact), the step
 is deterministic, and the loss goes down."""
 import copy
+import os
 import warnings
 
 import pytest
@@ -198,6 +199,14 @@ def test_dmd_stage_step_harness():
     assert enc_w.grad is not None and enc_w.grad.abs().max() > 0                       # the encoder trains in this stage
     tr2, snaps2 = run()
     assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(snaps, snaps2))
+    # direct gradient writes (decoder, bottleneck, encoder blocks) change no bit against plain autograd accumulation into the zeroed flat buffer
+    os.environ["DMVAE_DMD_DIRECT_GRADS"] = "0"
+    try:
+        tr3, snaps3 = run()
+    finally:
+        del os.environ["DMVAE_DMD_DIRECT_GRADS"]
+    assert getattr(tr, "fp").direct and not getattr(tr3.fp, "direct", False)
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(snaps, snaps3))
     # the bf16 shadows the fused optimiser step maintains are what a fresh conversion would give, and functional._bf serves them
     from dmvae_amd import functional as Fn
     assert torch.equal(tr.fp.shadow, tr.fp.flat.to(torch.bfloat16))
