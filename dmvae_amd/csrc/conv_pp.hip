@@ -36,6 +36,7 @@ struct Args {
   void* y;            // [N, Ho, Wo, Cout] bf16 or f32
   int N, Hi, Wi, Cin, Ho, Wo, Cout;
   int ks, act, M, ctiles, total;  // total = pixel tiles x cout tiles
+  int so, pd, sd;                 // gather geometry (dmvae_conv_geometry): tap k of output o reads source (o * so - pd + k) / sd when that is an in-range integer
   int stagger;                    // start delay per group of CUs, units of 64 cycles (0 = off)
   unsigned long long* dbg;  // optional per-block s_memtime stamps (dmvae_debug_timing), null in production
 };
@@ -84,7 +85,12 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   // ---- descriptors ---------------------------------------------------------------------------------------------
   const unsigned wbytes = (unsigned)a.Cout * T * a.Cin * 2u;
   const unsigned xbytes = (unsigned)a.N * a.Hi * a.Wi * a.Cin * 2u;
-  const unsigned shift = (!UPS && a.ks == 3) ? (unsigned)(a.Wi + 1) * a.Cin * 2u : 0u;  // makes every tap offset >= 0
+  // Non-UPS gathers: a lane's base is its tap-0 source (by, bx) = (o * so - pd) for sd = 1, ceil((o - pd) / 2) for the zero-insertion gather
+  // (sd = 2: tap k then reads by + (k >> 1), and only when o - pd + k is even), which can sit up to SR rows / columns outside the image;
+  // the descriptor base is moved back by that much so that every lane offset and every wave-uniform tap offset is >= 0.
+  const int SR = (UPS || a.ks == 1) ? 0 : (a.sd == 2 ? 1 : a.pd);
+  const int sds = a.sd == 2 ? 1 : 0;
+  const unsigned shift = (!UPS && a.ks != 1) ? (unsigned)(SR * a.Wi + SR) * a.Cin * 2u : 0u;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, wbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB =
       __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.x) - shift), 0, xbytes + shift, 0x00020000);
@@ -126,12 +132,34 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       int n, r, y, x;
       divmod_small(m, hw, inv_hw, small_m, n, r);
       divmod_small(r, a.Wo, inv_wo, small_m, y, x);
-      if (a.ks == 3) {  // bit ky*3+kx set when the tap stays inside the image
-        const unsigned rm = (y > 0 ? 0x007u : 0u) | 0x038u | (y < a.Ho - 1 ? 0x1C0u : 0u);
-        const unsigned cm = (x > 0 ? 0x049u : 0u) | 0x092u | (x < a.Wo - 1 ? 0x124u : 0u);
-        mask = rm & cm;
-      } else {
+      int by = y, bx = x;
+      if (UPS) {
+        if (a.ks == 3) {  // bit ky*3+kx set when the tap stays inside the (upsampled) image
+          const unsigned rm = (y > 0 ? 0x007u : 0u) | 0x038u | (y < a.Ho - 1 ? 0x1C0u : 0u);
+          const unsigned cm = (x > 0 ? 0x049u : 0u) | 0x092u | (x < a.Wo - 1 ? 0x124u : 0u);
+          mask = rm & cm;
+        } else {
+          mask = 1;
+        }
+      } else if (a.ks == 1) {
         mask = 1;
+      } else {  // bit ky*ks+kx set when tap (ky, kx) reads a source pixel (inside the image, and on the grid for the zero-insertion gather)
+        const int y0 = y * a.so - a.pd, x0 = x * a.so - a.pd;
+        by = sds ? (y0 + 1) >> 1 : y0;
+        bx = sds ? (x0 + 1) >> 1 : x0;
+        unsigned rmk = 0, cmk = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (k < a.ks) {
+            const bool ry = sds ? (((y0 + k) & 1) == 0 && (unsigned)(by + (k >> 1)) < (unsigned)a.Hi) : (unsigned)(by + k) < (unsigned)a.Hi;
+            const bool rx = sds ? (((x0 + k) & 1) == 0 && (unsigned)(bx + (k >> 1)) < (unsigned)a.Wi) : (unsigned)(bx + k) < (unsigned)a.Wi;
+            rmk |= (unsigned)ry << k;
+            cmk |= (unsigned)rx << k;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (k < a.ks && ((rmk >> k) & 1u)) mask |= cmk << (k * a.ks);
       }
       if (UPS) {
 #pragma unroll
@@ -142,7 +170,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
         }
         if (a.ks != 3) ctrB[p] = rowo[UPS ? p : 0][1] + colo[UPS ? p : 0][1];
       } else {
-        ctrB[p] = (unsigned)((n * a.Hi + y) * a.Wi + x) * a.Cin * 2u + c * 16u;
+        ctrB[p] = (unsigned)((n * a.Hi + by + SR) * a.Wi + bx + SR) * a.Cin * 2u + c * 16u;
       }
     }
     maskB[p] = mask;
@@ -169,8 +197,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   f32x16 acc[BM][BP];
 
   auto new_tap = [&]() {
-    const int ky = a.ks == 3 ? it_tap / 3 : 1, kx = a.ks == 3 ? it_tap - (it_tap / 3) * 3 : 1;
-    soffB_tap = (!UPS && a.ks == 3) ? (unsigned)(ky * a.Wi + kx) * a.Cin * 2u : 0u;
+    const int ky = a.ks == 3 ? it_tap / 3 : (a.ks == 4 ? it_tap >> 2 : 1), kx = a.ks == 3 ? it_tap - (it_tap / 3) * 3 : (a.ks == 4 ? it_tap & 3 : 1);
+    soffB_tap = (!UPS && a.ks != 1) ? (unsigned)((ky >> sds) * a.Wi + (kx >> sds)) * a.Cin * 2u : 0u;
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
       unsigned v = ctrB[p];
@@ -418,14 +446,20 @@ int pick(const Args& a, hipStream_t st) {
 static unsigned long long* g_dbg = nullptr;
 extern "C" void dmvae_debug_timing(void* buf) { g_dbg = (unsigned long long*)buf; }  // diagnostics only (tools/probes/time_conv_pp.py)
 
+int dmvae_conv_geometry(const dmvae_conv_desc* d, int* ho, int* wo, int* so, int* pd, int* sd, int* fl);  // conv_fwd.hip
+
 int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void* residual, void* y, const dmvae_conv_desc* d,
                       hipStream_t stream) {
   using namespace dmvae_conv_pp;
   static const bool disabled = [] { const char* e = getenv("DMVAE_CONV_V1"); return e && atoi(e) != 0; }();
   if (disabled) return 1;
-  if (d->upsample == 2 || d->stride == 2 || d->ks == 4 || d->transposed) return 1;  // strided / zero-insertion / 4x4 gathers: the general kernel (conv_fwd.hip)
-  const int ups = d->upsample ? 1 : 0;
-  const long long M = (long long)d->n * d->h * d->w * (ups ? 4 : 1);
+  static const bool general = [] { const char* e = getenv("DMVAE_PP_GENERAL"); return e ? atoi(e) != 0 : true; }();  // 0: strided / zero-insertion / 4x4 gathers stay on conv_fwd.hip
+  int ho, wo, so, pd, sd, fl;
+  if (dmvae_conv_geometry(d, &ho, &wo, &so, &pd, &sd, &fl) != 0) return 1;
+  const bool plain = !(d->upsample == 2 || d->stride == 2 || d->ks == 4 || d->transposed);
+  if (!plain && !general) return 1;
+  const int ups = fl ? 1 : 0;      // nearest x2 folded into the gather: its own template variant
+  const long long M = (long long)d->n * ho * wo;
   const long long xbytes = (long long)d->n * d->h * d->w * d->cin * 2;
   const long long wbytes = (long long)d->cout * d->ks * d->ks * d->cin * 2;
   static const long long min_m = [] { const char* e = getenv("DMVAE_PP_MINM"); return e ? atoll(e) : 16384ll; }();
@@ -433,7 +467,7 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
   Args a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.res = (const bf16*)residual; a.y = y;
   a.N = d->n; a.Hi = d->h; a.Wi = d->w; a.Cin = d->cin; a.Cout = d->cout;
-  a.Ho = ups ? 2 * d->h : d->h; a.Wo = ups ? 2 * d->w : d->w;
+  a.Ho = ho; a.Wo = wo; a.so = so; a.pd = pd; a.sd = sd;
   a.ks = d->ks; a.act = d->act; a.M = (int)M; a.ctiles = 0; a.dbg = g_dbg;
   { static const int stag = [] { const char* e = getenv("DMVAE_PP_STAGGER"); return e ? atoi(e) : 0; }(); a.stagger = stag; }
   const bool f32 = d->out_f32 != 0;

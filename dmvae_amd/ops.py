@@ -113,9 +113,10 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
         e1.record()
         # which kernel dmvae_conv2d_nhwc_fwd dispatched to (csrc/conv_pp.hip::dmvae_conv_pp_try), so that the bench's per-kernel
         # average can be checked against rocprofv3's per-kernel-name average
-        if cin % 32 == 0 and cout >= 64 and cout % 8 == 0 and n * ho * wo >= 16384 and int(upsample) < 2 and stride != 2 and ks != 4 and not transposed:
-            label = "conv_pp_kernel<%s, %s, %s, %s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", "true" if upsample else "false",
-                                                         "true" if out_f32 else "false", "false" if upsample else _PP_KORDER)
+        if cin % 32 == 0 and cout >= 64 and cout % 8 == 0 and n * ho * wo >= 16384:
+            ups1 = int(upsample) == 1                  # nearest x2 folded into the gather: its own template variant
+            label = "conv_pp_kernel<%s, %s, %s, %s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", "true" if ups1 else "false",
+                                                         "true" if out_f32 else "false", "false" if ups1 else _PP_KORDER)
         else:
             label = "conv_fwd_kernel"
         timing.append((label, e0, e1, 2.0 * n * ho * wo * cout * cin * ks * ks))

@@ -61,7 +61,8 @@ def test_conv_fwd(case, act):
     assert torch.equal(y16, y32.to(BF))        # bf16 store == RNE of the f32 result, bit-exact
 
 
-S2_CASES = [(2, 6, 6, 32, 32), (1, 20, 28, 96, 72), (3, 16, 16, 64, 128), (1, 64, 64, 128, 128), (1, 2, 2, 32, 8)]  # N, H, W, Cin, Cout
+S2_CASES = [(2, 6, 6, 32, 32), (1, 20, 28, 96, 72), (3, 16, 16, 64, 128), (1, 64, 64, 128, 128), (1, 2, 2, 32, 8),
+            (4, 128, 128, 64, 128), (2, 192, 100, 96, 64)]  # N, H, W, Cin, Cout; the last two are large enough for the ping-pong kernel (>= 16384 output pixels)
 
 
 @pytest.mark.parametrize("case", S2_CASES)
@@ -97,7 +98,7 @@ def test_conv_stride2_fwd_dgrad_wgrad(case):
 
 
 K4_CASES = [(2, 8, 8, 32, 64, 2), (1, 9, 11, 32, 32, 1), (3, 16, 16, 64, 128, 2), (1, 7, 10, 96, 8, 1), (2, 64, 64, 64, 128, 2), (2, 33, 32, 256, 512, 1),
-            (1, 12, 10, 32, 4, 1)]  # N, H, W, Cin, Cout, stride
+            (1, 12, 10, 32, 4, 1), (4, 130, 128, 64, 128, 2), (2, 96, 97, 64, 192, 1), (5, 66, 64, 32, 64, 1)]  # N, H, W, Cin, Cout, stride; the last three reach the ping-pong kernel
 
 
 @pytest.mark.parametrize("case", K4_CASES)
