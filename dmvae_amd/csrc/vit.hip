@@ -153,9 +153,41 @@ struct AttnArgs {
   int q_rs, k_rs, v_rs;
   int S, H, D;
   float scale;
+  // NR variant: per-head RMSNorm (bf16 result) * weight and the 2-D rotary embedding are applied to q and k on their way in
+  const float *qw, *kw, *cosb, *sinb;   // [D], [D], [S][D], [S][D]
+  float eps;
 };
 
-template <int DP>
+// RMSNorm + RoPE of 8 consecutive channels d0..d0+7 of token `tok` (csrc/dit.hip::qknorm_rope_kernel's arithmetic: the normalised value is rounded to
+// bf16 before the f32 weight multiplies; pairs (2i, 2i+1) rotate with their own table entries)
+__device__ __forceinline__ uint4 norm_rope8(const uint4 raw, float r, const float* __restrict__ w, const float* __restrict__ cosb,
+                                            const float* __restrict__ sinb, int tok, int D, int d0) {
+  const bf16x8 x = *reinterpret_cast<const bf16x8*>(&raw);
+  const float4 w0 = *reinterpret_cast<const float4*>(w + d0), w1 = *reinterpret_cast<const float4*>(w + d0 + 4);
+  const float4 c0 = *reinterpret_cast<const float4*>(cosb + (size_t)tok * D + d0), c1 = *reinterpret_cast<const float4*>(cosb + (size_t)tok * D + d0 + 4);
+  const float4 s0 = *reinterpret_cast<const float4*>(sinb + (size_t)tok * D + d0), s1 = *reinterpret_cast<const float4*>(sinb + (size_t)tok * D + d0 + 4);
+  const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+  const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  float n[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) n[e] = (float)(bf16)((float)x[e] * r) * wv[e];
+  uint4 o;
+  o.x = pack_bf16(n[0] * cv[0] - n[1] * sv[0], n[1] * cv[1] + n[0] * sv[1]);
+  o.y = pack_bf16(n[2] * cv[2] - n[3] * sv[2], n[3] * cv[3] + n[2] * sv[3]);
+  o.z = pack_bf16(n[4] * cv[4] - n[5] * sv[4], n[5] * cv[5] + n[4] * sv[5]);
+  o.w = pack_bf16(n[6] * cv[6] - n[7] * sv[6], n[7] * cv[7] + n[6] * sv[7]);
+  return o;
+}
+__device__ __forceinline__ float sumsq8(const uint4 raw) {
+  const bf16x8 x = *reinterpret_cast<const bf16x8*>(&raw);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; e++) s += (float)x[e] * (float)x[e];
+  return s;
+}
+
+template <int DP, bool NR>
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int KROW = DP == 64 ? 128 : 256;   // bytes per K row in LDS (8 or 16 chunks of 16 B, XOR-swizzled by key & 7)
@@ -171,6 +203,25 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   const bf16* vb_ = a.v + b * a.v_bs + h * a.v_hs;
   const int vchunks = a.D / 8;           // V rows hold the real head dim
   // ---- stage K and V: DP/8 lanes x 16 B per key row ------------------------------------------------------------------------------------
+  if constexpr (NR) {  // 16 lanes per key row (the first DP/8 carry data) so that the row's sum of squares is a 16-lane butterfly
+    const int c = tid & 15;
+    for (int key = tid >> 4; key < ATT_KEYS; key += 16) {
+      uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+      const bool live = key < S && c < vchunks;
+      if (live) {
+        kv = *reinterpret_cast<const uint4*>(kb_ + (size_t)key * a.k_rs + c * 8);
+        vv = *reinterpret_cast<const uint4*>(vb_ + (size_t)key * a.v_rs + c * 8);
+      }
+      float ss = sumsq8(kv);
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
+      if (live) kv = norm_rope8(kv, rsqrtf(ss / (float)a.D + a.eps), a.kw, a.cosb, a.sinb, key, a.D, c * 8);
+      if (c < DP / 8) {
+        *reinterpret_cast<uint4*>(ks + key * KROW + ((c ^ (key & 7)) << 4)) = kv;
+        *reinterpret_cast<uint4*>(vs + key * 256 + ((((c >> 2) ^ (key & 3))) << 6) + ((c & 3) << 4)) = vv;
+      }
+    }
+  } else
   for (int i = tid; i < ATT_KEYS * (DP / 8); i += 256) {
     const int key = i / (DP / 8), c = i - key * (DP / 8);
     uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
@@ -199,8 +250,21 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; kk++) {
       uint4 t = {0, 0, 0, 0};
-      if (q < S) t = *reinterpret_cast<const uint4*>(qb_ + (size_t)q * a.q_rs + kk * 16 + kg * 8);
+      if (q < S && (!NR || kk * 16 + kg * 8 < a.D)) t = *reinterpret_cast<const uint4*>(qb_ + (size_t)q * a.q_rs + kk * 16 + kg * 8);
       qf[kk] = *reinterpret_cast<bf16x8*>(&t);
+    }
+    if constexpr (NR) {  // this lane and lane ^ 32 hold the two halves of query q's row
+      float ss = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; kk++) ss += sumsq8(*reinterpret_cast<const uint4*>(&qf[kk]));
+      ss += __shfl_xor(ss, 32, 64);
+      const float rq = rsqrtf(ss / (float)a.D + a.eps);
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; kk++)
+        if (q < S && kk * 16 + kg * 8 < a.D) {
+          const uint4 o = norm_rope8(*reinterpret_cast<const uint4*>(&qf[kk]), rq, a.qw, a.cosb, a.sinb, q, a.D, kk * 16 + kg * 8);
+          qf[kk] = *reinterpret_cast<const bf16x8*>(&o);
+        }
     }
     // ---- S^T = K Q^T: acc[kb][r] = score(key = kb*32 + (r&3) + 8*(r>>2) + 4*kg, query q) ------------------------------------------
     f32x16 st[ATT_KB];
@@ -277,15 +341,15 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 #endif
 }
 
-template <int DP>
+template <int DP, bool NR = false>
 static int launch_attention(const AttnArgs& a, int batch, hipStream_t stream) {
   constexpr int lds = ATT_KEYS * (DP == 64 ? 128 : 256) + ATT_KEYS * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DP, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(attention_kernel<DP>, dim3(batch * a.H), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((attention_kernel<DP, NR>), dim3(batch * a.H), dim3(256), lds, stream, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -298,7 +362,7 @@ extern "C" int dmvae_attention_qkv_bf16(const void* qkv, void* out, int batch, i
   DMVAE_CHECK_ARG(qkv && out && batch > 0 && heads > 0 && seq > 0, "attention_qkv_bf16: bad argument");
   DMVAE_CHECK_ARG(head_dim == ATT_D && seq <= ATT_KEYS, "attention_qkv_bf16: needs head_dim 64 and seq <= 288 (got %d, %d)", head_dim, seq);
   const long long C = (long long)heads * head_dim;
-  AttnArgs a;
+  AttnArgs a = {};
   a.q = (const bf16*)qkv; a.k = a.q + C; a.v = a.q + 2 * C; a.out = (bf16*)out;
   a.q_bs = a.k_bs = a.v_bs = (long long)seq * 3 * C; a.q_hs = a.k_hs = a.v_hs = head_dim;
   a.q_rs = a.k_rs = a.v_rs = (int)(3 * C);
@@ -313,11 +377,29 @@ extern "C" int dmvae_attention_heads_bf16(const void* q, const void* k, const vo
   DMVAE_CHECK_ARG(q && k && v && out && batch > 0 && heads > 0 && seq > 0, "attention_heads_bf16: bad argument");
   DMVAE_CHECK_ARG(seq <= ATT_KEYS && head_dim % 8 == 0 && head_dim <= head_dim_padded && (head_dim_padded == 64 || head_dim_padded == 96),
                   "attention_heads_bf16: needs seq <= 288, head_dim %% 8 == 0, padded head dim 64 or 96 (got %d, %d, %d)", seq, head_dim, head_dim_padded);
-  AttnArgs a;
+  AttnArgs a = {};
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out;
   a.q_hs = a.k_hs = (long long)seq * head_dim_padded; a.q_bs = a.k_bs = a.q_hs * heads;
   a.v_hs = (long long)seq * head_dim; a.v_bs = a.v_hs * heads;
   a.q_rs = a.k_rs = head_dim_padded; a.v_rs = head_dim;
   a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale;
   return head_dim_padded == 64 ? launch_attention<64>(a, batch, stream) : launch_attention<96>(a, batch, stream);
+}
+
+// LightningDiT's attention straight from the qkv Linear's output [B][N][3][H][D]: QK RMSNorm + weight, 2-D RoPE (what dmvae_qknorm_rope_bf16 does) applied
+// while K is staged / Q fragments are loaded, then the same fused softmax(q k^T) v -- no head-major q / k / v round trip through HBM.
+extern "C" int dmvae_attention_qknorm_rope_bf16(const void* qkv, const void* q_weight, const void* k_weight, const void* cos_table, const void* sin_table,
+                                                void* out, int batch, int seq, int heads, int head_dim, float eps, float scale, hipStream_t stream) {
+  using namespace dmvae_vit;
+  DMVAE_CHECK_ARG(qkv && q_weight && k_weight && cos_table && sin_table && out && batch > 0 && heads > 0 && seq > 0, "attention_qknorm_rope_bf16: bad argument");
+  DMVAE_CHECK_ARG(seq <= ATT_KEYS && head_dim % 8 == 0 && head_dim >= 8 && head_dim <= 96,
+                  "attention_qknorm_rope_bf16: needs seq <= 288 and head_dim a multiple of 8 up to 96 (got %d, %d)", seq, head_dim);
+  const long long C = (long long)heads * head_dim;
+  AttnArgs a = {};
+  a.q = (const bf16*)qkv; a.k = a.q + C; a.v = a.q + 2 * C; a.out = (bf16*)out;
+  a.q_bs = a.k_bs = a.v_bs = (long long)seq * 3 * C; a.q_hs = a.k_hs = a.v_hs = head_dim;
+  a.q_rs = a.k_rs = a.v_rs = (int)(3 * C);
+  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale;
+  a.qw = (const float*)q_weight; a.kw = (const float*)k_weight; a.cosb = (const float*)cos_table; a.sinb = (const float*)sin_table; a.eps = eps;
+  return head_dim <= 64 ? launch_attention<64, true>(a, batch, stream) : launch_attention<96, true>(a, batch, stream);
 }

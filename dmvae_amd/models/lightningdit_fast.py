@@ -35,12 +35,15 @@ def _bf(p):
 
 
 _FUSED_ATTN = os.environ.get("DMVAE_DIT_FUSED_ATTN", "1") != "0"
+_FUSED_QKNORM = os.environ.get("DMVAE_DIT_FUSED_QKNORM", "1") != "0"      # QK-norm + RoPE inside the attention kernel
 
 
 def _attention(qkv, blk, rope, heads):
     b, n, c3 = qkv.shape
     c = c3 // 3
     d = c // heads
+    if _FUSED_ATTN and _FUSED_QKNORM and ops.attention_heads_supported(n, d):
+        return ops.attention_qknorm_rope(qkv, blk.attn.q_norm.weight, blk.attn.k_norm.weight, rope.freqs_cos, rope.freqs_sin, heads, blk.attn.q_norm.eps, d ** -0.5)
     q, k, v = ops.qknorm_rope(qkv, blk.attn.q_norm.weight, blk.attn.k_norm.weight, rope.freqs_cos, rope.freqs_sin, heads, blk.attn.q_norm.eps)
     if _FUSED_ATTN and ops.attention_heads_supported(n, d):
         return ops.attention_heads(q, k, v, b, d ** -0.5)

@@ -447,6 +447,19 @@ def attention_heads(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: in
     return out
 
 
+def attention_qknorm_rope(qkv: torch.Tensor, qw: torch.Tensor, kw: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, eps: float,
+                          scale: float) -> torch.Tensor:
+    """qkv [B,N,3*H*D] bf16 -> softmax(scale rope(norm(q)) rope(norm(k))^T) v as [B,N,H*D] bf16: `qknorm_rope` + `attention_heads` in one kernel."""
+    qkv = _req(qkv, bf16, "qkv")
+    b, n, c3 = qkv.shape
+    c = c3 // 3
+    out = torch.empty(b, n, c, dtype=bf16, device=qkv.device)
+    check(_lib.lib().dmvae_attention_qknorm_rope_bf16(qkv.data_ptr(), _req(qw, f32, "qw").data_ptr(), _req(kw, f32, "kw").data_ptr(),
+                                                      _req(cos, f32, "cos").data_ptr(), _req(sin, f32, "sin").data_ptr(), out.data_ptr(), b, n, heads,
+                                                      c // heads, float(eps), float(scale), _stream()), "attention_qknorm_rope_bf16")
+    return out
+
+
 def attention_heads_supported(n: int, d: int) -> bool:
     return n <= 288 and d % 8 == 0 and (d + 31) // 32 * 32 in (64, 96)
 

@@ -200,6 +200,11 @@ int dmvae_attention_qkv_bf16(const void* qkv, void* out, int batch, int seq, int
  * seq <= 288. */
 int dmvae_attention_heads_bf16(const void* q, const void* k, const void* v, void* out, int batch, int seq, int heads, int head_dim,
                                int head_dim_padded, float scale, dmvae_stream_t stream);
+/* The whole attention of a LightningDiT block from the qkv Linear's output [batch][seq][3][heads][head_dim] bf16: per-head RMSNorm (bf16 result) * weight
+ * and the 2-D rotary embedding (the arithmetic of dmvae_qknorm_rope_bf16; cos / sin tables [seq][head_dim] f32) are applied to q and k as they enter the
+ * fused kernel -> out [batch][seq][heads*head_dim].  lightningdit.py:66-88 in one launch, no head-major q / k / v in HBM.  head_dim % 8 == 0, <= 96; seq <= 288. */
+int dmvae_attention_qknorm_rope_bf16(const void* qkv, const void* q_weight, const void* k_weight, const void* cos_table, const void* sin_table,
+                                     void* out, int batch, int seq, int heads, int head_dim, float eps, float scale, dmvae_stream_t stream);
 
 /* Backward side of the same encoder block, for the stages where the encoder trains (train_dmd.py:349,519).  Residual stream f32,
  * Linear operands / results bf16 (autocast).  workspace: dmvae_vit_bwd_workspace(c) bytes.

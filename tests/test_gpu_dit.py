@@ -124,6 +124,26 @@ def test_fused_attention_heads_kernel(b, heads, d, n):
     assert _rl2(out, oc) < 6e-3
 
 
+@pytest.mark.parametrize("b,heads,d,n", [(2, 16, 72, 256), (3, 2, 64, 64), (1, 4, 72, 288), (2, 3, 64, 37), (1, 2, 40, 96)])
+def test_attention_with_qknorm_rope_inside_equals_the_two_kernels(b, heads, d, n):
+    """dmvae_attention_qknorm_rope_bf16 == dmvae_qknorm_rope_bf16 followed by dmvae_attention_heads_bf16 (same arithmetic; only the order of the
+    f32 additions in the row's sum of squares differs)."""
+    from dmvae_amd import ops
+    g = torch.Generator().manual_seed(b * 100 + d + n)
+    qkv = (torch.randn(b, n, 3 * heads * d, generator=g) * 1.5).to(DEV).to(BF)
+    qw = (1 + 0.3 * torch.randn(d, generator=g)).to(DEV)
+    kw = (1 + 0.3 * torch.randn(d, generator=g)).to(DEV)
+    ang = torch.rand(n, d, generator=g) * 6.28
+    cos, sin = ang.cos().to(DEV), ang.sin().to(DEV)
+    q, k, v = ops.qknorm_rope(qkv, qw, kw, cos, sin, heads, 1e-6)
+    want = ops.attention_heads(q, k, v, b, d ** -0.5)
+    got = ops.attention_qknorm_rope(qkv, qw, kw, cos, sin, heads, 1e-6, d ** -0.5)
+    assert got.shape == want.shape == (b, n, heads * d)
+    assert _rl2(got, want) < 2e-3
+    assert (got.float() - want.float()).abs().max() <= 2 ** -6 * want.float().abs().max() + 1e-3
+    assert torch.equal(got, ops.attention_qknorm_rope(qkv, qw, kw, cos, sin, heads, 1e-6, d ** -0.5))
+
+
 @pytest.mark.parametrize("tag", ["dit_small_hd64", "dit_small_hd72"])
 def test_lightningdit_fast_forward_vs_fixture_oracle_and_stock(tag):
     g = load_golden(tag)
