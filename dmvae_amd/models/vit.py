@@ -95,10 +95,17 @@ class DinoV2ViT(nn.Module):
                 nn.init.zeros_(m.bias)
 
     def forward_features(self, x):
-        if x.is_cuda and torch.is_grad_enabled() and self.pos_embed.requires_grad:
-            from .vit_fast import hip_path_supported, trainable_forward_features
+        if x.is_cuda:
+            from .vit_fast import frozen_forward_features, hip_path_supported, trainable_forward_features
             if hip_path_supported(self, self.pos_embed.shape[1]):
-                return trainable_forward_features(self, x)        # trainable encoder on the HIP kernels (csrc/vit.hip, vit_bwd.hip)
+                if torch.is_grad_enabled() and self.pos_embed.requires_grad:
+                    return trainable_forward_features(self, x)    # trainable encoder on the HIP kernels (csrc/vit.hip, vit_bwd.hip)
+                needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+                if not needs_grad and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+                    # frozen / no-grad use under autocast(bf16) -- `vae.encode`, `vae(x, freeze_encoder=True)`: the fused inference route on cached
+                    # bf16 weights.  Tokens come back in bf16 (the stock modules' final LayerNorm returns f32 under autocast; the bottleneck's
+                    # Linear casts to bf16 either way).
+                    return frozen_forward_features(self, x.float())
         return self.forward_features_stock(x)
 
     def forward_features_stock(self, x):

@@ -19,12 +19,23 @@ def patch_embed_gemm(vit, x: torch.Tensor) -> torch.Tensor:
     p = w.shape[-1]
     assert hh % p == 0 and ww % p == 0, "image size must be a multiple of the patch size"
     patches = x.view(b_, c, hh // p, p, ww // p, p).permute(0, 2, 4, 1, 3, 5).reshape(b_, (hh // p) * (ww // p), c * p * p)
+    if not torch.is_grad_enabled():          # frozen use: the cached bf16 copies (functional._bf), not a conversion per call
+        return F.linear(patches.to(torch.bfloat16), _w(w).view(w.shape[0], -1), _w(vit.patch_embed.proj.bias))
     return F.linear(patches.to(torch.bfloat16), w.view(w.shape[0], -1).to(torch.bfloat16), vit.patch_embed.proj.bias.to(torch.bfloat16))
+
+
+def _w(p: torch.Tensor) -> torch.Tensor:
+    """A Linear operand in bf16: the parameter itself when the module is a bf16 shadow (train.frozen_bf16_shadow), else its cached bf16 copy."""
+    if p.dtype == torch.bfloat16:
+        return p
+    from ..functional import _bf
+    return _bf(p)
 
 
 @torch.no_grad()
 def frozen_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
-    """vit: a DinoV2ViT whose Linear / Conv2d weights are bf16 (train.frozen_bf16_shadow); x: [B,3,H,W] f32, already normalised.
+    """vit: a DinoV2ViT -- either a bf16 shadow (train.frozen_bf16_shadow: Linear / Conv2d weights already bf16) or the f32 module itself, whose
+    Linear weights are then served as cached bf16 copies (`functional._bf`, refreshed when a parameter changes); x: [B,3,H,W] f32, already normalised.
     Returns the final-norm tokens [B, 1+N, C] in bf16 (what the bottleneck MLP consumes)."""
     bf = torch.bfloat16
     t = patch_embed_gemm(vit, x).float()
@@ -35,18 +46,18 @@ def frozen_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
         hn = ops.layernorm_bf16(t, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
         nh = blk.attn.num_heads
         hd = c // nh
-        qkv = F.linear(hn, blk.attn.qkv.weight, blk.attn.qkv.bias)              # [b, s, 3*c] = [b, s, 3, heads, hd]
+        qkv = F.linear(hn, _w(blk.attn.qkv.weight), _w(blk.attn.qkv.bias))              # [b, s, 3*c] = [b, s, 3, heads, hd]
         if hd == 64 and s <= 288:
             o = ops.attention_qkv(qkv, nh, hd ** -0.5)                             # fused: nothing of size s x s reaches HBM
         else:
             qkv = qkv.reshape(b, s, 3, nh, hd).permute(2, 0, 3, 1, 4)
             att = ops.softmax_rows_bf16(qkv[0] @ qkv[1].transpose(-2, -1), hd ** -0.5)   # scale, f32 softmax and the casts in one pass
             o = (att @ qkv[2]).transpose(1, 2).reshape(b, s, c)
-        o = F.linear(o, blk.attn.proj.weight, blk.attn.proj.bias)
+        o = F.linear(o, _w(blk.attn.proj.weight), _w(blk.attn.proj.bias))
         ops.scale_residual_(t, o.contiguous(), blk.ls1.gamma)
         hn = ops.layernorm_bf16(t, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-        h = F.gelu(F.linear(hn, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
-        o = F.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+        h = F.gelu(F.linear(hn, _w(blk.mlp.fc1.weight), _w(blk.mlp.fc1.bias)))
+        o = F.linear(h, _w(blk.mlp.fc2.weight), _w(blk.mlp.fc2.bias))
         ops.scale_residual_(t, o, blk.ls2.gamma)
     return ops.layernorm_bf16(t, vit.norm.weight, vit.norm.bias, vit.norm.eps)
 

@@ -82,9 +82,22 @@ def test_frozen_vit_fast_path_matches_stock_module():
             blk.ls1.gamma.fill_(0.5); blk.ls2.gamma.fill_(0.5)
     img = torch.randn(3, 3, 64, 64, generator=g).cuda()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-        want = vit.forward_features(img).float()
+        want = vit.forward_features_stock(img).float()
     got = frozen_forward_features(frozen_bf16_shadow(vit), img).float()
     assert ((got - want).norm() / want.norm()).item() < 2e-2
+    # the module itself takes the same route when nothing needs a gradient under autocast(bf16) -- `vae.encode`, `vae(x, freeze_encoder=True)` -- on cached bf16
+    # copies of its f32 weights: identical to the shadow-module route, and refreshed when a weight changes
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        via_module = vit.forward_features(img)
+    assert via_module.dtype == torch.bfloat16 and torch.equal(via_module.float(), got)
+    with torch.no_grad():
+        vit.blocks[1].mlp.fc2.weight.mul_(1.25)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        again = vit.forward_features(img)
+        want2 = vit.forward_features_stock(img).float()
+    assert not torch.equal(again, via_module) and ((again.float() - want2).norm() / want2.norm()).item() < 2e-2
+    with torch.no_grad():
+        assert vit.forward_features(img).dtype == torch.float32          # no autocast: the stock f32 modules
 
 
 @pytest.mark.parametrize("shape", [(2, 257, 16), (3, 65, 4), (1, 288, 2), (2, 17, 3)])
