@@ -10,6 +10,7 @@
 //
 // All HBM-bound single passes with 8- or 16-byte accesses.  GEMMs go through the library, attention through the batched GEMM + softmax kernels.
 #include "common.h"
+#include <type_traits>
 #include "dmvae_hip.h"
 
 namespace dmvae_dit {
@@ -207,14 +208,16 @@ __global__ void swiglu_bwd_kernel(const bf16* __restrict__ dh, const bf16* __res
 //   dx += rs * (g - n * mean(g * n)),  g = da * w * m;   dshift[b] = sum_n da;   dscale[b] = sum_n da * n * w;   dw = sum_rows da * m * n.
 // grid (BPS, B): the block's 4 waves walk the rows of sample b; part: [B][BPS][3][C] (dshift, dscale, dw contributions of the block)
 constexpr int RM_BPS = 32;   // blocks per sample: 4 waves x 2 rows each at N = 256 tokens
+// SW = ceil(C / 256) sweeps per row: seven f32x4 arrays of that length live in registers (224 VGPRs at the 2048-channel maximum, 140 at 1152)
+template <int SW>
 __global__ __launch_bounds__(256) void rmsnorm_modulate_bwd_kernel(const bf16* __restrict__ da, const float* __restrict__ x, const float* __restrict__ w,
                                                                    const bf16* __restrict__ mod, float* __restrict__ dx_io, float* __restrict__ part,
                                                                    int N, int C, int stride, int scale_off, float eps) {
   extern __shared__ float red[];  // [4 waves][3][C]
   const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  f32x4 gw[MAX_SWEEPS], gm[MAX_SWEEPS], a0[MAX_SWEEPS], a1[MAX_SWEEPS], a2[MAX_SWEEPS];
+  f32x4 gw[SW], gm[SW], a0[SW], a1[SW], a2[SW];
 #pragma unroll
-  for (int k = 0; k < MAX_SWEEPS; k++) {
+  for (int k = 0; k < SW; k++) {
     const int c = k * 256 + lane * 4;
     a0[k] = f32x4{0, 0, 0, 0}; a1[k] = f32x4{0, 0, 0, 0}; a2[k] = f32x4{0, 0, 0, 0};
     if (c < C) {
@@ -226,10 +229,10 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_bwd_kernel(const bf16* _
   }
   for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
     const size_t row = (size_t)b * N + n;
-    f32x4 v[MAX_SWEEPS], g[MAX_SWEEPS];
+    f32x4 v[SW], g[SW];
     float ss = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAX_SWEEPS; k++) {
+    for (int k = 0; k < SW; k++) {
       const int c = k * 256 + lane * 4;
       if (c < C) {
         v[k] = *reinterpret_cast<const f32x4*>(x + row * C + c);
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_bwd_kernel(const bf16* _
     const float rs = rsqrtf(wave_sum(ss) / (float)C + eps);
     float s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAX_SWEEPS; k++) {
+    for (int k = 0; k < SW; k++) {
       const int c = k * 256 + lane * 4;
       if (c < C) {
         const bf16x4 d = *reinterpret_cast<const bf16x4*>(da + row * C + c);
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_bwd_kernel(const bf16* _
     }
     const float m2 = wave_sum(s2) / (float)C;
 #pragma unroll
-    for (int k = 0; k < MAX_SWEEPS; k++) {
+    for (int k = 0; k < SW; k++) {
       const int c = k * 256 + lane * 4;
       if (c < C) {
         f32x4 o = *reinterpret_cast<const f32x4*>(dx_io + row * C + c);
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_bwd_kernel(const bf16* _
     }
   }
 #pragma unroll
-  for (int k = 0; k < MAX_SWEEPS; k++) {
+  for (int k = 0; k < SW; k++) {
     const int c = k * 256 + lane * 4;
     if (c < C) {
       *reinterpret_cast<f32x4*>(&red[(wave * 3 + 0) * C + c]) = a0[k];
@@ -362,14 +365,24 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16* __rest
     part[((size_t)blockIdx.x * 2 + which) * D + d] = (red[0][slot][ln] + red[1][slot][ln]) + (red[2][slot][ln] + red[3][slot][ln]);
   }
 }
-__global__ void colsum2_kernel(const float* __restrict__ part, float* __restrict__ o0, float* __restrict__ o1, int nblk, int D, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * D) return;
-  const int which = i / D, d = i - which * D;
+// part[nblk][2][D] -> o0[d], o1[d]: 16 columns per block, 16 row groups per column (fixed assignment and a fixed-order LDS combine: deterministic)
+__global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ part, float* __restrict__ o0, float* __restrict__ o1, int nblk, int D, int accumulate) {
+  __shared__ float red[16][17];
+  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + col;
   float a = 0.f;
-  for (int b = 0; b < nblk; b++) a += part[((size_t)b * 2 + which) * D + d];
-  float* o = which ? o1 : o0;
-  o[d] = (accumulate ? o[d] : 0.f) + a;
+  if (i < 2 * D)
+    for (int b = grp; b < nblk; b += 16) a += part[(size_t)b * 2 * D + i];
+  red[grp][col] = a;
+  __syncthreads();
+  if (threadIdx.x < 16 && i < 2 * D) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; g++) t += red[g][col];
+    const int which = i / D, d = i - which * D;
+    float* o = which ? o1 : o0;
+    o[d] = (accumulate ? o[d] : 0.f) + t;
+  }
 }
 
 static inline int grid_for(size_t n, int block = 256, int cap = 4096) {
@@ -442,7 +455,7 @@ extern "C" int dmvae_gated_residual_f32(void* x, const void* y, const void* mod,
 
 // ---- backward entry points -----------------------------------------------------------------------------------------------------------
 extern "C" size_t dmvae_dit_bwd_workspace(int batch, int c) {
-  const size_t a = ((size_t)batch * RM_BPS * 3 + batch) * (size_t)c * sizeof(float), b = (size_t)1024 * 2 * 128 * sizeof(float);
+  const size_t a = ((size_t)batch * RM_BPS * 3 + batch) * (size_t)c * sizeof(float), b = (size_t)2048 * 2 * 128 * sizeof(float);
   return a > b ? a : b;
 }
 
@@ -474,17 +487,33 @@ extern "C" int dmvae_rmsnorm_modulate_bwd(const void* da, const void* x, const v
                   "rmsnorm_modulate_bwd: modulation offsets must be multiples of 4 inside the row");
   DMVAE_CHECK_ARG(workspace_bytes >= dmvae_dit_bwd_workspace(batch, c), "rmsnorm_modulate_bwd: workspace too small");
   const size_t lds = (size_t)4 * 3 * c * sizeof(float);
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_modulate_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_lds = lds;
+  // blocks per sample: enough blocks to fill the chip (~1024), few enough that the per-block partial sums (3 * c floats through LDS and the workspace) stay small
+  // next to the rows a block walks -- 32 at batch 16 (2 rows per wave at 256 tokens), 16 at batch 64
+  int bps = 1024 / batch;
+  bps = bps > RM_BPS ? RM_BPS : (bps < 4 ? 4 : bps);
+  auto go = [&](auto sw) {
+    constexpr int SW = decltype(sw)::value;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_modulate_bwd_kernel<SW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_lds = lds;
+    }
+    hipLaunchKernelGGL(rmsnorm_modulate_bwd_kernel<SW>, dim3(bps, batch), dim3(256), lds, stream, (const bf16*)da, (const float*)x, (const float*)w,
+                       (const bf16*)mod, (float*)dx_io, (float*)workspace, seq, c, mod_stride, scale_off, eps);
+  };
+  switch ((c + 255) / 256) {
+    case 1: go(std::integral_constant<int, 1>{}); break;
+    case 2: go(std::integral_constant<int, 2>{}); break;
+    case 3: go(std::integral_constant<int, 3>{}); break;
+    case 4: go(std::integral_constant<int, 4>{}); break;
+    case 5: go(std::integral_constant<int, 5>{}); break;
+    case 6: go(std::integral_constant<int, 6>{}); break;
+    default: go(std::integral_constant<int, 8>{}); break;
   }
-  hipLaunchKernelGGL(rmsnorm_modulate_bwd_kernel, dim3(RM_BPS, batch), dim3(256), lds, stream, (const bf16*)da, (const float*)x, (const float*)w,
-                     (const bf16*)mod, (float*)dx_io, (float*)workspace, seq, c, mod_stride, scale_off, eps);
   DMVAE_CHECK_LAUNCH();
   float* wpart = (float*)workspace + (size_t)batch * RM_BPS * 3 * c;
   hipLaunchKernelGGL(rmsnorm_modulate_bwd_final_kernel, dim3((c + 255) / 256, batch), dim3(256), 0, stream, (const float*)workspace, (float*)dmod, wpart,
-                     RM_BPS, c, mod_stride, shift_off, scale_off);
+                     bps, c, mod_stride, shift_off, scale_off);
   DMVAE_CHECK_LAUNCH();
   if (dw) {
     hipLaunchKernelGGL(rmsnorm_modulate_bwd_weight_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, wpart, (float*)dw, batch, c, accumulate);
@@ -502,13 +531,13 @@ extern "C" int dmvae_qknorm_rope_bwd(const void* dq, const void* dk, const void*
   DMVAE_CHECK_ARG(head_dim % 2 == 0 && head_dim >= 2 && head_dim_padded >= head_dim && head_dim_padded <= 128,
                   "qknorm_rope_bwd: head dim must be even, padded head dim <= 128 (got %d, %d)", head_dim, head_dim_padded);
   const int tokens = batch * seq;
-  int nblk = (tokens * heads + 3) / 4; if (nblk > 512) nblk = 512;   // two blocks per CU; the second stage sums nblk partials per weight serially
+  int nblk = (tokens * heads + 3) / 4; if (nblk > 2048) nblk = 2048;   // eight blocks per CU: the rows are short (4-B lanes, four wave reductions each) and latency-bound
   DMVAE_CHECK_ARG(workspace_bytes >= (size_t)nblk * 2 * head_dim * sizeof(float), "qknorm_rope_bwd: workspace too small");
   hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (const bf16*)qkv,
                      (const float*)q_weight, (const float*)k_weight, (const float*)cos_table, (const float*)sin_table, (bf16*)dqkv, (float*)workspace,
                      tokens, seq, heads, head_dim, head_dim_padded, eps);
   DMVAE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum2_kernel, dim3((2 * head_dim + 255) / 256), dim3(256), 0, stream, (const float*)workspace, (float*)dq_weight, (float*)dk_weight,
+  hipLaunchKernelGGL(colsum2_kernel, dim3((2 * head_dim + 15) / 16), dim3(256), 0, stream, (const float*)workspace, (float*)dq_weight, (float*)dk_weight,
                      nblk, head_dim, accumulate);
   DMVAE_CHECK_LAUNCH();
   return 0;
