@@ -60,6 +60,7 @@ SIGNATURES = {
     "dmvae_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dmvae_rmsnorm_modulate_bf16": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float, c_void_p]),
     "dmvae_gated_residual_rmsnorm_modulate": (c_int, [c_void_p] * 3 + [c_int] * 2 + [c_void_p] * 3 + [c_int] * 6 + [c_float, c_void_p]),
+    "dmvae_gated_residual_out": (c_int, [c_void_p] * 4 + [c_int] * 2 + [c_void_p] * 3 + [c_int] * 6 + [c_float, c_void_p]),
     "dmvae_qknorm_rope_bf16": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),
     "dmvae_swiglu_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "dmvae_dit_bwd_workspace": (c_size_t, [c_int, c_int]),

@@ -20,14 +20,14 @@ constexpr int MAX_SWEEPS = 8;  // C <= 2048
 // one wave per row; mod: [B][stride] bf16 (the adaLN Linear's output), shift_off < 0: no shift
 // RES: first x[row] += bf16(gate[b] * r[row]) (the previous sub-layer's gated residual, written back), then the norm of the updated row.
 template <bool RES>
-__global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(float* __restrict__ x, const float* __restrict__ w, const bf16* __restrict__ mod,
+__global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(const float* x, const float* __restrict__ w, const bf16* __restrict__ mod,
                                                                bf16* __restrict__ y, int rows, int rows_per_sample, int C, int stride, int shift_off,
                                                                int scale_off, float eps, const bf16* __restrict__ r, const bf16* __restrict__ gmod,
-                                                               int gstride, int gate_off) {
+                                                               int gstride, int gate_off, float* xo) {   // RES: updated rows go to xo (== x: in place); y == null: no norm
 #pragma clang fp contract(off)   // both instantiations evaluate the expressions exactly as written: fused and unfused routes agree to the bit
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
-  float* xr = x + (size_t)row * C;
+  const float* xr = x + (size_t)row * C;
   f32x4 v[MAX_SWEEPS];
   float ss = 0.f;
 #pragma unroll
@@ -40,11 +40,12 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(float* __restrict
         const bf16x4 g = *reinterpret_cast<const bf16x4*>(gmod + (size_t)(row / rows_per_sample) * gstride + gate_off + c);
 #pragma unroll
         for (int e = 0; e < 4; e++) v[k][e] += (float)(bf16)((float)g[e] * (float)rv[e]);
-        *reinterpret_cast<f32x4*>(xr + c) = v[k];
+        *reinterpret_cast<f32x4*>(xo + (size_t)row * C + c) = v[k];
       }
       ss += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
     }
   }
+  if (RES && !y) return;                       // gated residual only (wave-uniform)
   const float rs = rsqrtf(wave_sum(ss) / (float)C + eps);
   const bf16* mrow = mod + (size_t)(row / rows_per_sample) * stride;
   bf16* yr = y + (size_t)row * C;
@@ -400,7 +401,7 @@ extern "C" int dmvae_rmsnorm_modulate_bf16(const void* x, const void* w, const v
   DMVAE_CHECK_ARG(scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride,
                   "rmsnorm_modulate_bf16: modulation offsets must be multiples of 4 inside the row");
   hipLaunchKernelGGL(rmsnorm_modulate_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
-                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0);
+                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -413,8 +414,24 @@ extern "C" int dmvae_gated_residual_rmsnorm_modulate(void* x, const void* r, con
   DMVAE_CHECK_ARG(scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride &&
                       gate_off >= 0 && gate_off % 4 == 0 && gate_stride % 4 == 0 && gate_off + c <= gate_stride,
                   "gated_residual_rmsnorm_modulate: modulation offsets must be multiples of 4 inside the row");
-  hipLaunchKernelGGL(rmsnorm_modulate_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
-                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off);
+  hipLaunchKernelGGL(rmsnorm_modulate_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
+                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+// Out-of-place form for the training route, where the residual stream before the update is kept for the backward pass: x_out = x_in + bf16(gate * r), and,
+// when y is given, y = rmsnorm_modulate(x_out) in the same pass (w, mod, offsets then required).  Saves the clone the in-place kernels need there.
+extern "C" int dmvae_gated_residual_out(const void* x_in, void* x_out, const void* r, const void* gate_mod, int gate_stride, int gate_off, const void* w,
+                                        const void* mod, void* y, int rows, int rows_per_sample, int c, int mod_stride, int shift_off, int scale_off,
+                                        float eps, hipStream_t stream) {
+  DMVAE_CHECK_ARG(x_in && x_out && r && gate_mod && rows > 0 && rows_per_sample > 0 && (!y || (w && mod)), "gated_residual_out: bad argument");
+  DMVAE_CHECK_ARG(c % 4 == 0 && c >= 4 && c <= MAX_SWEEPS * 256, "gated_residual_out: width must be a multiple of 4 up to 2048 (got %d)", c);
+  DMVAE_CHECK_ARG(gate_off >= 0 && gate_off % 4 == 0 && gate_stride % 4 == 0 && gate_off + c <= gate_stride &&
+                      (!y || (scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride)),
+                  "gated_residual_out: modulation offsets must be multiples of 4 inside the row");
+  hipLaunchKernelGGL(rmsnorm_modulate_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
+                     rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -578,12 +578,11 @@ class DitBlockFn(torch.autograd.Function):
         p = ops.softmax_rows(ops.gemm_nt(q, k, out_f32=True), d ** -0.5)
         o = ops.gemm_nt(p, ops.transpose_last2(v)).view(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, c)
         o2 = F.linear(o, _bf(pw), _bf(pb))
-        h_mid = ops.gated_residual_(h.clone(), o2, mod, 2 * c)
-        a2 = ops.rmsnorm_modulate(h_mid, n2w, mod, 3 * c, 4 * c, eps)
+        h_mid, a2 = ops.gated_residual_out(h, o2, mod, 2 * c, n2w, mod, 3 * c, 4 * c, eps)       # h itself is saved for the backward pass
         x12 = F.linear(a2, _bf(w12w), _bf(w12b))
         g = ops.swiglu(x12)
         o3 = F.linear(g, _bf(w3w), _bf(w3b))
-        h_out = ops.gated_residual_(h_mid.clone(), o3, mod, 5 * c)
+        h_out, _ = ops.gated_residual_out(h_mid, o3, mod, 5 * c)
         ctx.save_for_backward(h, mod, a1, qkv, q, k, v, p, o, o2, h_mid, a2, x12, g, o3, n1w, qkvw, qnw, knw, pw, n2w, w12w, w3w, cos, sin)
         ctx.others = (qkvb, pb, w12b, w3b, heads, eps)
         return h_out

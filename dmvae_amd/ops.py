@@ -546,6 +546,23 @@ def gated_residual_rmsnorm_modulate_(x: torch.Tensor, r: torch.Tensor, gate_mod:
     return y
 
 
+def gated_residual_out(x: torch.Tensor, r: torch.Tensor, gate_mod: torch.Tensor, gate_off: int, w: Optional[torch.Tensor] = None,
+                       mod: Optional[torch.Tensor] = None, shift_off: int = -1, scale_off: int = 0, eps: float = 1e-6):
+    """-> (x_new = x + bf16(gate * r) as a NEW tensor, rmsnorm_modulate(x_new, w, mod, ...) or None when w is None): the out-of-place form of
+    `gated_residual_` / `gated_residual_rmsnorm_modulate_` for the training route (x is kept for the backward pass)."""
+    x = _req(x, f32, "x"); r = _req(r, bf16, "r"); gate_mod = _req(gate_mod, bf16, "gate_mod")
+    b, n, c = x.shape
+    xo = torch.empty_like(x)
+    y = None
+    if w is not None:
+        mod = _req(mod, bf16, "mod")
+        y = torch.empty(b, n, c, dtype=bf16, device=x.device)
+    check(_lib.lib().dmvae_gated_residual_out(x.data_ptr(), xo.data_ptr(), r.data_ptr(), gate_mod.data_ptr(), gate_mod.shape[1], int(gate_off),
+                                              _ptr(_req(w, f32, "w") if w is not None else None), _ptr(mod), _ptr(y), b * n, n, c,
+                                              mod.shape[1] if mod is not None else 0, int(shift_off), int(scale_off), float(eps), _stream()), "gated_residual_out")
+    return xo, y
+
+
 def qknorm_rope(qkv: torch.Tensor, qw: torch.Tensor, kw: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, eps: float = 1e-6):
     """qkv [B,N,3*H*D] bf16 -> (q, k [B*H, N, Dp] with Dp = D rounded up to 32, v [B*H, N, D]): per-head RMSNorm * weight + 2-D RoPE on q and k."""
     qkv = _req(qkv, bf16, "qkv")

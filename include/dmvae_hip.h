@@ -235,6 +235,11 @@ int dmvae_rmsnorm_modulate_bf16(const void* x, const void* w, const void* mod, v
 int dmvae_gated_residual_rmsnorm_modulate(void* x, const void* r, const void* gate_mod, int gate_stride, int gate_off, const void* w,
                                           const void* mod, void* y, int rows, int rows_per_sample, int c, int mod_stride, int shift_off,
                                           int scale_off, float eps, dmvae_stream_t stream);
+/* Out-of-place form (the training route keeps the residual stream before the update for its backward): x_out = x_in + bf16(gate[b] * r); y != NULL: also
+ * y = rmsnorm_modulate(x_out) in the same pass (w, mod and the offsets are then required), y == NULL: the residual update alone. */
+int dmvae_gated_residual_out(const void* x_in, void* x_out, const void* r, const void* gate_mod, int gate_stride, int gate_off, const void* w,
+                             const void* mod, void* y, int rows, int rows_per_sample, int c, int mod_stride, int shift_off, int scale_off,
+                             float eps, dmvae_stream_t stream);
 int dmvae_qknorm_rope_bf16(const void* qkv, const void* q_weight, const void* k_weight, const void* cos_table, const void* sin_table,
                            void* q_out, void* k_out, void* v_out, int batch, int seq, int heads, int head_dim, int head_dim_padded, float eps,
                            dmvae_stream_t stream);

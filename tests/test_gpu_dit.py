@@ -64,6 +64,11 @@ def test_gated_residual_rmsnorm_modulate_is_the_two_kernels_back_to_back(c, n):
     x2 = x.clone()
     y2 = ops.gated_residual_rmsnorm_modulate_(x2, r, gmod, 5 * c, w, mod, 3 * c, 4 * c)
     assert torch.equal(x1, x2) and torch.equal(y1, y2)
+    xin = x.clone()
+    x5, y5 = ops.gated_residual_out(xin, r, gmod, 5 * c, w, mod, 3 * c, 4 * c)                 # out of place: the input survives
+    assert torch.equal(xin, x) and torch.equal(x5, x1) and torch.equal(y5, y1)
+    x6, none = ops.gated_residual_out(xin, r, gmod, 5 * c)
+    assert none is None and torch.equal(x6, x1)
     y3 = ops.gated_residual_rmsnorm_modulate_(x.clone(), r, gmod, 2 * c, w, mod, -1, c)       # no shift
     x4 = x.clone()
     ops.gated_residual_(x4, r, gmod, 2 * c)
