@@ -214,7 +214,7 @@ template <int SW>
 __global__ __launch_bounds__(256) void rmsnorm_modulate_bwd_kernel(const bf16* __restrict__ da, const float* __restrict__ x, const float* __restrict__ w,
                                                                    const bf16* __restrict__ mod, float* __restrict__ dx_io, float* __restrict__ part,
                                                                    int N, int C, int stride, int scale_off, float eps) {
-  extern __shared__ float red[];  // [4 waves][3][C]
+  extern __shared__ float red[];  // [2 wave pairs][3][C]
   const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   f32x4 gw[SW], gm[SW], a0[SW], a1[SW], a2[SW];
 #pragma unroll
@@ -269,19 +269,31 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_bwd_kernel(const bf16* _
       }
     }
   }
+  // waves 0/1 and 2/3 combine in registers-through-LDS pairs in a fixed order: one [2][3][C] buffer (27 KB at C = 1152) instead of [4][3][C], so that
+  // LDS no longer caps the kernel at two blocks per CU
 #pragma unroll
   for (int k = 0; k < SW; k++) {
     const int c = k * 256 + lane * 4;
-    if (c < C) {
-      *reinterpret_cast<f32x4*>(&red[(wave * 3 + 0) * C + c]) = a0[k];
-      *reinterpret_cast<f32x4*>(&red[(wave * 3 + 1) * C + c]) = a1[k];
-      *reinterpret_cast<f32x4*>(&red[(wave * 3 + 2) * C + c]) = a2[k];
+    if (c < C && (wave & 1)) {
+      *reinterpret_cast<f32x4*>(&red[((wave >> 1) * 3 + 0) * C + c]) = a0[k];
+      *reinterpret_cast<f32x4*>(&red[((wave >> 1) * 3 + 1) * C + c]) = a1[k];
+      *reinterpret_cast<f32x4*>(&red[((wave >> 1) * 3 + 2) * C + c]) = a2[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SW; k++) {
+    const int c = k * 256 + lane * 4;
+    if (c < C && !(wave & 1)) {
+      f32x4* p0 = reinterpret_cast<f32x4*>(&red[((wave >> 1) * 3 + 0) * C + c]);
+      f32x4* p1 = reinterpret_cast<f32x4*>(&red[((wave >> 1) * 3 + 1) * C + c]);
+      f32x4* p2 = reinterpret_cast<f32x4*>(&red[((wave >> 1) * 3 + 2) * C + c]);
+      *p0 = a0[k] + *p0; *p1 = a1[k] + *p1; *p2 = a2[k] + *p2;
     }
   }
   __syncthreads();
   float* po = part + ((size_t)b * gridDim.x + blockIdx.x) * 3 * C;
-  for (int i = threadIdx.x; i < 3 * C; i += 256)
-    po[i] = (red[0 * 3 * C + i] + red[1 * 3 * C + i]) + (red[2 * 3 * C + i] + red[3 * 3 * C + i]);
+  for (int i = threadIdx.x; i < 3 * C; i += 256) po[i] = red[i] + red[3 * C + i];
 }
 // second stage, grid (C/256, B): dmod[b][shift_off + c] = sum_blk part[b][blk][0][c] (skipped when shift_off < 0), dmod[b][scale_off + c] = ... [1] ...;
 // wpart[b][c] = sum_blk part[b][blk][2][c];  third stage: dw[c] (+)= sum_b wpart[b][c]
@@ -503,7 +515,7 @@ extern "C" int dmvae_rmsnorm_modulate_bwd(const void* da, const void* x, const v
   DMVAE_CHECK_ARG(scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride,
                   "rmsnorm_modulate_bwd: modulation offsets must be multiples of 4 inside the row");
   DMVAE_CHECK_ARG(workspace_bytes >= dmvae_dit_bwd_workspace(batch, c), "rmsnorm_modulate_bwd: workspace too small");
-  const size_t lds = (size_t)4 * 3 * c * sizeof(float);
+  const size_t lds = (size_t)2 * 3 * c * sizeof(float);
   // blocks per sample: enough blocks to fill the chip (~1024), few enough that the per-block partial sums (3 * c floats through LDS and the workspace) stay small
   // next to the rows a block walks -- 32 at batch 16 (2 rows per wave at 256 tokens), 16 at batch 64
   int bps = 1024 / batch;
