@@ -63,7 +63,9 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool OUT_F32, bool KO>
+// GEN: the general gather geometry (4x4 taps, output stride 2, zero-insertion sources) -- a separate instantiation, because its per-tile setup and per-K-tile
+// tap arithmetic cost the plain 3x3 / 1x1 kernel 13-19 % when compiled into it (measured in the step: 337 -> 382 us per launch).
+template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool OUT_F32, bool KO, bool GEN = false>
 __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__  // the host pass only needs the launch stub (hipcc drops the stub when it cannot digest the gfx950 body)
   constexpr int BM = TM / WM / 32, BP = TP / WP / 32;  // 32x32 accumulator blocks per wave
@@ -88,9 +90,10 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   // Non-UPS gathers: a lane's base is its tap-0 source (by, bx) = (o * so - pd) for sd = 1, ceil((o - pd) / 2) for the zero-insertion gather
   // (sd = 2: tap k then reads by + (k >> 1), and only when o - pd + k is even), which can sit up to SR rows / columns outside the image;
   // the descriptor base is moved back by that much so that every lane offset and every wave-uniform tap offset is >= 0.
-  const int SR = (UPS || a.ks == 1) ? 0 : (a.sd == 2 ? 1 : a.pd);
-  const int sds = a.sd == 2 ? 1 : 0;
-  const unsigned shift = (!UPS && a.ks != 1) ? (unsigned)(SR * a.Wi + SR) * a.Cin * 2u : 0u;
+  const int SR = GEN ? ((UPS || a.ks == 1) ? 0 : (a.sd == 2 ? 1 : a.pd)) : 1;
+  const int sds = GEN && a.sd == 2 ? 1 : 0;
+  const unsigned shift = GEN ? ((!UPS && a.ks != 1) ? (unsigned)(SR * a.Wi + SR) * a.Cin * 2u : 0u)
+                             : ((!UPS && a.ks == 3) ? (unsigned)(a.Wi + 1) * a.Cin * 2u : 0u);  // makes every tap offset >= 0
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, wbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB =
       __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.x) - shift), 0, xbytes + shift, 0x00020000);
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       divmod_small(m, hw, inv_hw, small_m, n, r);
       divmod_small(r, a.Wo, inv_wo, small_m, y, x);
       int by = y, bx = x;
-      if (UPS) {
+      if (UPS || !GEN) {
         if (a.ks == 3) {  // bit ky*3+kx set when the tap stays inside the (upsampled) image
           const unsigned rm = (y > 0 ? 0x007u : 0u) | 0x038u | (y < a.Ho - 1 ? 0x1C0u : 0u);
           const unsigned cm = (x > 0 ? 0x049u : 0u) | 0x092u | (x < a.Wo - 1 ? 0x124u : 0u);
@@ -170,7 +173,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
         }
         if (a.ks != 3) ctrB[p] = rowo[UPS ? p : 0][1] + colo[UPS ? p : 0][1];
       } else {
-        ctrB[p] = (unsigned)((n * a.Hi + by + SR) * a.Wi + bx + SR) * a.Cin * 2u + c * 16u;
+        if constexpr (GEN) ctrB[p] = (unsigned)((n * a.Hi + by + SR) * a.Wi + bx + SR) * a.Cin * 2u + c * 16u;
+        else ctrB[p] = (unsigned)((n * a.Hi + y) * a.Wi + x) * a.Cin * 2u + c * 16u;
       }
     }
     maskB[p] = mask;
@@ -197,8 +201,14 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   f32x16 acc[BM][BP];
 
   auto new_tap = [&]() {
-    const int ky = a.ks == 3 ? it_tap / 3 : (a.ks == 4 ? it_tap >> 2 : 1), kx = a.ks == 3 ? it_tap - (it_tap / 3) * 3 : (a.ks == 4 ? it_tap & 3 : 1);
-    soffB_tap = (!UPS && a.ks != 1) ? (unsigned)((ky >> sds) * a.Wi + (kx >> sds)) * a.Cin * 2u : 0u;
+    int ky, kx;
+    if constexpr (GEN) {
+      ky = a.ks == 3 ? it_tap / 3 : (a.ks == 4 ? it_tap >> 2 : 1); kx = a.ks == 3 ? it_tap - (it_tap / 3) * 3 : (a.ks == 4 ? it_tap & 3 : 1);
+      soffB_tap = (!UPS && a.ks != 1) ? (unsigned)((ky >> sds) * a.Wi + (kx >> sds)) * a.Cin * 2u : 0u;
+    } else {
+      ky = a.ks == 3 ? it_tap / 3 : 1; kx = a.ks == 3 ? it_tap - (it_tap / 3) * 3 : 1;
+      soffB_tap = (!UPS && a.ks == 3) ? (unsigned)(ky * a.Wi + kx) * a.Cin * 2u : 0u;
+    }
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
       unsigned v = ctrB[p];
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #endif
 }
 
-template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32, bool KO>
+template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32, bool KO, bool GEN = false>
 int launch(Args a, hipStream_t st) {
   a.ctiles = (a.Cout + TM - 1) / TM;
   a.total = ((a.M + TP - 1) / TP) * a.ctiles;
@@ -414,11 +424,11 @@ int launch(Args a, hipStream_t st) {
   constexpr int lds = ring > epi ? ring : epi;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO>), dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN>), dim3(grid), dim3(512), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -429,8 +439,14 @@ int launch(Args a, hipStream_t st) {
 // FETCH_SIZE per launch 9.0x vs 2.2x the compulsory bytes at 512->512 @128^2 (profiles/r1_conv_hbm_traffic.txt).  The folded-upsample
 // variant keeps the taps outer (its per-tap source selection is too costly to redo every K tile).
 template <bool UPS, bool F32>
-int pick(const Args& a, hipStream_t st) {
+int pick(const Args& a, hipStream_t st, bool gen) {
   static const bool ko = [] { const char* e = getenv("DMVAE_PP_KORDER"); return e ? atoi(e) != 0 : true; }();
+  if constexpr (!UPS) {
+    if (gen) {  // strided / 4x4 / zero-insertion gathers: chunk-outer K order only
+      if (a.Cout <= 128) return launch<128, 512, 2, 4, 4, false, F32, true, true>(a, st);
+      return launch<256, 256, 2, 4, 4, false, F32, true, true>(a, st);
+    }
+  }
   if constexpr (UPS) {
     if (a.Cout <= 128) return launch<128, 512, 2, 4, 4, UPS, F32, false>(a, st);
     return launch<256, 256, 2, 4, 4, UPS, F32, false>(a, st);
@@ -471,6 +487,6 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
   a.ks = d->ks; a.act = d->act; a.M = (int)M; a.ctiles = 0; a.dbg = g_dbg;
   { static const int stag = [] { const char* e = getenv("DMVAE_PP_STAGGER"); return e ? atoi(e) : 0; }(); a.stagger = stag; }
   const bool f32 = d->out_f32 != 0;
-  if (ups) return f32 ? pick<true, true>(a, stream) : pick<true, false>(a, stream);
-  return f32 ? pick<false, true>(a, stream) : pick<false, false>(a, stream);
+  if (ups) return f32 ? pick<true, true>(a, stream, false) : pick<true, false>(a, stream, false);
+  return f32 ? pick<false, true>(a, stream, !plain) : pick<false, false>(a, stream, !plain);
 }
