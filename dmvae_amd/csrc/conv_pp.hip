@@ -58,9 +58,14 @@ __device__ __forceinline__ void divmod_small(int m, int d, float inv_d, bool sma
   }
 }
 
+// s_waitcnt vmcnt(N) through the builtin, not inline asm: the compiler's own wait-count pass then SEES the wait.  With the asm form it kept a VMEM event from
+// before the K loop pending on a fragment register for ever (the loop's own LDS-DMA instructions make its count imprecise) and put an s_waitcnt vmcnt(0) in
+// front of the second ds_read of every K tile.  Removing that drain changed nothing measurable (342 vs 340 us per launch in the step): by then the pieces
+// of the next tiles have landed anyway -- the loop is not waiting on the DMA queue.
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_s_waitcnt((N & 15) | 0x0F70 | ((N >> 4) << 14));   // gfx9 encoding: vmcnt[3:0] | expcnt 7 | lgkmcnt 15 | vmcnt[5:4] << 14
+  asm volatile("" ::: "memory");
 }
 
 // GEN: the general gather geometry (4x4 taps, output stride 2, zero-insertion sources) -- a separate instantiation, because its per-tile setup and per-K-tile

@@ -39,7 +39,9 @@ constexpr unsigned SENT = 0x80000000u;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  // the builtin, not inline asm, so that the compiler's wait-count pass sees it (see conv_pp.hip: otherwise it drains the queue with vmcnt(0) every K tile)
+  __builtin_amdgcn_s_waitcnt((N & 15) | 0x0F70 | ((N >> 4) << 14));
+  asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ s16x4 tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
