@@ -10,6 +10,7 @@
 //
 // All HBM-bound single passes with 8- or 16-byte accesses.  GEMMs go through the library, attention through the batched GEMM + softmax kernels.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 #include "dmvae_hip.h"
 
@@ -208,6 +209,7 @@ __global__ void swiglu_bwd_kernel(const bf16* __restrict__ dh, const bf16* __res
 // a = bf16( n * w * m + shift ),  n = x * rs,  m = bf16(1 + scale[b]):
 //   dx += rs * (g - n * mean(g * n)),  g = da * w * m;   dshift[b] = sum_n da;   dscale[b] = sum_n da * n * w;   dw = sum_rows da * m * n.
 // grid (BPS, B): the block's 4 waves walk the rows of sample b; part: [B][BPS][3][C] (dshift, dscale, dw contributions of the block)
+constexpr int RM_MAX_SEQ = 4096;   // row statistics of the two-kernel RMSNorm backward live in the workspace up to this many tokens per sample
 constexpr int RM_BPS = 32;   // blocks per sample: 4 waves x 2 rows each at N = 256 tokens
 // SW = ceil(C / 256) sweeps per row: seven f32x4 arrays of that length live in registers (224 VGPRs at the 2048-channel maximum, 140 at 1152)
 template <int SW>
@@ -297,6 +299,66 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_bwd_kernel(const bf16* _
 }
 // second stage, grid (C/256, B): dmod[b][shift_off + c] = sum_blk part[b][blk][0][c] (skipped when shift_off < 0), dmod[b][scale_off + c] = ... [1] ...;
 // wpart[b][c] = sum_blk part[b][blk][2][c];  third stage: dw[c] (+)= sum_b wpart[b][c]
+// Two-kernel form of the same backward (used when the row statistics fit the workspace): (A) one wave per row -> rstd and m2 = mean_c(g * xhat),
+// g = da * w * bf16(1 + scale); (B) one thread per 4 columns walking the block's rows with fully coalesced row accesses, 12 accumulators per thread and no
+// cross-lane work -- the single-pass kernel above keeps 7 x SW f32x4 arrays per lane and two dependent wave reductions per row, and is latency-bound.
+__global__ __launch_bounds__(256) void rmsnorm_rowstat_kernel(const bf16* __restrict__ da, const float* __restrict__ x, const float* __restrict__ w,
+                                                              const bf16* __restrict__ mod, float2* __restrict__ rowstat, int rows, int N, int C, int stride,
+                                                              int scale_off, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const bf16* mrow = mod + (size_t)(row / N) * stride + scale_off;
+  float ss = 0.f, s2 = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)row * C + c);
+    const bf16x4 d = *reinterpret_cast<const bf16x4*>(da + (size_t)row * C + c);
+    const f32x4 gw = *reinterpret_cast<const f32x4*>(w + c);
+    const bf16x4 sc = *reinterpret_cast<const bf16x4*>(mrow + c);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      ss += v[e] * v[e];
+      s2 += (float)d[e] * gw[e] * (float)(bf16)(1.f + (float)sc[e]) * v[e];
+    }
+  }
+  const float rs = rsqrtf(wave_sum(ss) / (float)C + eps);
+  const float m2 = wave_sum(s2) * rs / (float)C;
+  if (lane == 0) rowstat[row] = make_float2(rs, m2);
+}
+
+__global__ __launch_bounds__(512) void rmsnorm_modulate_bwd_apply_kernel(const bf16* __restrict__ da, const float* __restrict__ x, const float* __restrict__ w,
+                                                                         const bf16* __restrict__ mod, const float2* __restrict__ rowstat,
+                                                                         float* __restrict__ dx_io, float* __restrict__ part, int N, int C, int stride,
+                                                                         int scale_off) {
+  const int b = blockIdx.y, c = threadIdx.x * 4;
+  if (c >= C) return;
+  const f32x4 gw = *reinterpret_cast<const f32x4*>(w + c);
+  const bf16x4 sc = *reinterpret_cast<const bf16x4*>(mod + (size_t)b * stride + scale_off + c);
+  f32x4 gm, a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+#pragma unroll
+  for (int e = 0; e < 4; e++) gm[e] = (float)(bf16)(1.f + (float)sc[e]);
+  const int rpb = (N + gridDim.x - 1) / gridDim.x;
+  const int n1 = min(N, (int)(blockIdx.x + 1) * rpb);
+  for (int n = blockIdx.x * rpb; n < n1; n++) {
+    const size_t row = (size_t)b * N + n;
+    const float2 st = rowstat[row];
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * C + c);
+    const bf16x4 d = *reinterpret_cast<const bf16x4*>(da + row * C + c);
+    f32x4 o = *reinterpret_cast<const f32x4*>(dx_io + row * C + c);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float nh = v[e] * st.x, dv = (float)d[e];
+      const float g = dv * gw[e] * gm[e];
+      o[e] += st.x * (g - nh * st.y);
+      a0[e] += dv; a1[e] += dv * nh * gw[e]; a2[e] += dv * gm[e] * nh;
+    }
+    *reinterpret_cast<f32x4*>(dx_io + row * C + c) = o;
+  }
+  float* po = part + ((size_t)b * gridDim.x + blockIdx.x) * 3 * C;
+  *reinterpret_cast<f32x4*>(po + c) = a0;
+  *reinterpret_cast<f32x4*>(po + C + c) = a1;
+  *reinterpret_cast<f32x4*>(po + 2 * C + c) = a2;
+}
+
 __global__ void rmsnorm_modulate_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dmod, float* __restrict__ wpart, int bps, int C,
                                                   int stride, int shift_off, int scale_off) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
@@ -484,7 +546,8 @@ extern "C" int dmvae_gated_residual_f32(void* x, const void* y, const void* mod,
 
 // ---- backward entry points -----------------------------------------------------------------------------------------------------------
 extern "C" size_t dmvae_dit_bwd_workspace(int batch, int c) {
-  const size_t a = ((size_t)batch * RM_BPS * 3 + batch) * (size_t)c * sizeof(float), b = (size_t)2048 * 2 * 128 * sizeof(float);
+  const size_t a = ((size_t)batch * RM_BPS * 3 + batch) * (size_t)c * sizeof(float) + (size_t)batch * RM_MAX_SEQ * sizeof(float2),
+               b = (size_t)2048 * 2 * 128 * sizeof(float);
   return a > b ? a : b;
 }
 
@@ -520,6 +583,18 @@ extern "C" int dmvae_rmsnorm_modulate_bwd(const void* da, const void* x, const v
   // next to the rows a block walks -- 32 at batch 16 (2 rows per wave at 256 tokens), 16 at batch 64
   int bps = 1024 / batch;
   bps = bps > RM_BPS ? RM_BPS : (bps < 4 ? 4 : bps);
+  static const bool split_ok = [] { const char* e = getenv("DMVAE_RMS_BWD_SPLIT"); return e ? atoi(e) != 0 : true; }();
+  if (split_ok && seq <= RM_MAX_SEQ) {
+    float2* rowstat = reinterpret_cast<float2*>((float*)workspace + ((size_t)batch * RM_BPS * 3 + batch) * (size_t)c);
+    const int rows = batch * seq;
+    hipLaunchKernelGGL(rmsnorm_rowstat_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)da, (const float*)x, (const float*)w, (const bf16*)mod,
+                       rowstat, rows, seq, c, mod_stride, scale_off, eps);
+    DMVAE_CHECK_LAUNCH();
+    const int bt = ((c / 4) + 63) / 64 * 64;
+    hipLaunchKernelGGL(rmsnorm_modulate_bwd_apply_kernel, dim3(bps, batch), dim3(bt), 0, stream, (const bf16*)da, (const float*)x, (const float*)w,
+                       (const bf16*)mod, rowstat, (float*)dx_io, (float*)workspace, seq, c, mod_stride, scale_off);
+    DMVAE_CHECK_LAUNCH();
+  } else {
   auto go = [&](auto sw) {
     constexpr int SW = decltype(sw)::value;
     static size_t attr_lds = 0;
@@ -540,6 +615,7 @@ extern "C" int dmvae_rmsnorm_modulate_bwd(const void* da, const void* x, const v
     default: go(std::integral_constant<int, 8>{}); break;
   }
   DMVAE_CHECK_LAUNCH();
+  }
   float* wpart = (float*)workspace + (size_t)batch * RM_BPS * 3 * c;
   hipLaunchKernelGGL(rmsnorm_modulate_bwd_final_kernel, dim3((c + 255) / 256, batch), dim3(256), 0, stream, (const float*)workspace, (float*)dmod, wpart,
                      bps, c, mod_stride, shift_off, scale_off);
