@@ -40,3 +40,37 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned flat, unsigned total) {
   const unsigned start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   return start + (flat >> 3);
 }
+
+__device__ __forceinline__ unsigned dmvae_pack_bf16x2(float a, float b) {
+  bf16x2 t = {(bf16)a, (bf16)b};
+  return *reinterpret_cast<unsigned*>(&t);
+}
+// RMSNorm + RoPE of 8 consecutive channels d0..d0+7 of token `tok` (csrc/dit.hip::qknorm_rope_kernel's arithmetic: the normalised value is rounded to
+// bf16 before the f32 weight multiplies; pairs (2i, 2i+1) rotate with their own table entries)
+__device__ __forceinline__ uint4 dmvae_norm_rope8(const uint4 raw, float r, const float* __restrict__ w, const float* __restrict__ cosb,
+                                            const float* __restrict__ sinb, int tok, int D, int d0) {
+  const bf16x8 x = *reinterpret_cast<const bf16x8*>(&raw);
+  const float4 w0 = *reinterpret_cast<const float4*>(w + d0), w1 = *reinterpret_cast<const float4*>(w + d0 + 4);
+  const float4 c0 = *reinterpret_cast<const float4*>(cosb + (size_t)tok * D + d0), c1 = *reinterpret_cast<const float4*>(cosb + (size_t)tok * D + d0 + 4);
+  const float4 s0 = *reinterpret_cast<const float4*>(sinb + (size_t)tok * D + d0), s1 = *reinterpret_cast<const float4*>(sinb + (size_t)tok * D + d0 + 4);
+  const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+  const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  float n[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) n[e] = (float)(bf16)((float)x[e] * r) * wv[e];
+  uint4 o;
+  o.x = dmvae_pack_bf16x2(n[0] * cv[0] - n[1] * sv[0], n[1] * cv[1] + n[0] * sv[1]);
+  o.y = dmvae_pack_bf16x2(n[2] * cv[2] - n[3] * sv[2], n[3] * cv[3] + n[2] * sv[3]);
+  o.z = dmvae_pack_bf16x2(n[4] * cv[4] - n[5] * sv[4], n[5] * cv[5] + n[4] * sv[5]);
+  o.w = dmvae_pack_bf16x2(n[6] * cv[6] - n[7] * sv[6], n[7] * cv[7] + n[6] * sv[7]);
+  return o;
+}
+__device__ __forceinline__ float dmvae_sumsq8(const uint4 raw) {
+  const bf16x8 x = *reinterpret_cast<const bf16x8*>(&raw);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; e++) s += (float)x[e] * (float)x[e];
+  return s;
+}
+

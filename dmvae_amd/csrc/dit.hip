@@ -510,6 +510,42 @@ extern "C" int dmvae_gated_residual_out(const void* x_in, void* x_out, const voi
   return 0;
 }
 
+namespace dmvae_dit {
+// 16 lanes per (token, head) row, 8 channels (16 B) per lane: the same arithmetic as qknorm_rope_kernel with a quarter of the memory instructions
+// (head dims that are multiples of 8: 64 -> 8 live lanes of 16, 72 -> 9).
+__global__ __launch_bounds__(256) void qknorm_rope16_kernel(const bf16* __restrict__ qkv, const float* __restrict__ qw, const float* __restrict__ kw,
+                                                            const float* __restrict__ cosb, const float* __restrict__ sinb, bf16* __restrict__ qo,
+                                                            bf16* __restrict__ ko, bf16* __restrict__ vo, int tokens, int N, int H, int D, int Dp,
+                                                            float eps) {
+  const int sub = threadIdx.x & 15;
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool inr = row < tokens * H;
+  const int tok = inr ? row / H : 0, h = inr ? row - tok * H : 0;
+  const int b = tok / N, n = tok - b * N;
+  const int d0 = sub * 8;
+  const bool live = inr && d0 < D;
+  uint4 q = {0, 0, 0, 0}, k = {0, 0, 0, 0}, v = {0, 0, 0, 0};
+  if (live) {
+    const bf16* base = qkv + (size_t)tok * 3 * H * D + d0;
+    q = *reinterpret_cast<const uint4*>(base + (size_t)h * D);
+    k = *reinterpret_cast<const uint4*>(base + (size_t)(H + h) * D);
+    v = *reinterpret_cast<const uint4*>(base + (size_t)(2 * H + h) * D);
+  }
+  float sq = dmvae_sumsq8(q), sk = dmvae_sumsq8(k);
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) { sq += __shfl_xor(sq, o, 64); sk += __shfl_xor(sk, o, 64); }
+  if (!inr || d0 >= Dp) return;
+  const size_t o = ((size_t)(b * H + h) * N + n);
+  if (live) {
+    q = dmvae_norm_rope8(q, rsqrtf(sq / (float)D + eps), qw, cosb, sinb, n, D, d0);
+    k = dmvae_norm_rope8(k, rsqrtf(sk / (float)D + eps), kw, cosb, sinb, n, D, d0);
+    *reinterpret_cast<uint4*>(vo + o * D + d0) = v;
+  }
+  *reinterpret_cast<uint4*>(qo + o * Dp + d0) = q;      // zeros in the padding chunks
+  *reinterpret_cast<uint4*>(ko + o * Dp + d0) = k;
+}
+}  // namespace dmvae_dit
+
 extern "C" int dmvae_qknorm_rope_bf16(const void* qkv, const void* q_weight, const void* k_weight, const void* cos_table, const void* sin_table,
                                       void* q_out, void* k_out, void* v_out, int batch, int seq, int heads, int head_dim, int head_dim_padded,
                                       float eps, hipStream_t stream) {
@@ -518,6 +554,13 @@ extern "C" int dmvae_qknorm_rope_bf16(const void* qkv, const void* q_weight, con
   DMVAE_CHECK_ARG(head_dim % 2 == 0 && head_dim >= 2 && head_dim_padded >= head_dim && head_dim_padded % 2 == 0 && head_dim_padded <= 128,
                   "qknorm_rope_bf16: head dim must be even, padded head dim <= 128 (got %d, %d)", head_dim, head_dim_padded);
   const int tokens = batch * seq;
+  if (head_dim % 8 == 0 && head_dim_padded % 8 == 0) {
+    hipLaunchKernelGGL(qknorm_rope16_kernel, dim3((tokens * heads + 15) / 16), dim3(256), 0, stream, (const bf16*)qkv, (const float*)q_weight,
+                       (const float*)k_weight, (const float*)cos_table, (const float*)sin_table, (bf16*)q_out, (bf16*)k_out, (bf16*)v_out, tokens, seq, heads,
+                       head_dim, head_dim_padded, eps);
+    DMVAE_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(qknorm_rope_kernel, dim3((tokens * heads + 3) / 4), dim3(256), 0, stream, (const bf16*)qkv, (const float*)q_weight, (const float*)k_weight,
                      (const float*)cos_table, (const float*)sin_table, (bf16*)q_out, (bf16*)k_out, (bf16*)v_out, tokens, seq, heads, head_dim,
                      head_dim_padded, eps);
@@ -627,6 +670,90 @@ extern "C" int dmvae_rmsnorm_modulate_bwd(const void* da, const void* x, const v
   return 0;
 }
 
+namespace dmvae_dit {
+// Backward with the same 16-lanes-per-row mapping (head dim % 8 == 0): per lane 8 channels of q and k, the two per-row reductions as 16-lane butterflies,
+// weight-gradient accumulators per lane over the rows it walks, combined over the block's 16 row groups in a fixed order.
+__global__ __launch_bounds__(256) void qknorm_rope16_bwd_kernel(const bf16* __restrict__ dq, const bf16* __restrict__ dk, const bf16* __restrict__ dv,
+                                                                const bf16* __restrict__ qkv, const float* __restrict__ qw, const float* __restrict__ kw,
+                                                                const float* __restrict__ cosb, const float* __restrict__ sinb, bf16* __restrict__ dqkv,
+                                                                float* __restrict__ part, int tokens, int N, int H, int D, int Dp, float eps) {
+  __shared__ float red[16][16][17];
+  const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int d0 = sub * 8;
+  const bool lane_live = d0 < D;
+  float wq[8], wk[8], gq[8], gk[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { wq[e] = lane_live ? qw[d0 + e] : 0.f; wk[e] = lane_live ? kw[d0 + e] : 0.f; gq[e] = 0.f; gk[e] = 0.f; }
+  const int rows = tokens * H;
+  for (int row0 = blockIdx.x * 16; row0 < rows; row0 += gridDim.x * 16) {
+    const int row = row0 + grp;
+    const bool live = lane_live && row < rows;
+    const int tok = row < rows ? row / H : 0, h = row < rows ? row - tok * H : 0;
+    const int b = tok / N, n = tok - b * N;
+    const size_t o = ((size_t)(b * H + h) * N + n);
+    float q[8], k[8], eq[8], ek[8], nq[8], nk[8];
+    uint4 dvv = {0, 0, 0, 0};
+    float sq = 0.f, sk = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { q[e] = 0.f; k[e] = 0.f; eq[e] = 0.f; ek[e] = 0.f; }
+    if (live) {
+      const bf16* base = qkv + (size_t)tok * 3 * H * D + d0;
+      const uint4 qa = *reinterpret_cast<const uint4*>(base + (size_t)h * D), ka = *reinterpret_cast<const uint4*>(base + (size_t)(H + h) * D);
+      const uint4 ga = *reinterpret_cast<const uint4*>(dq + o * Dp + d0), gc = *reinterpret_cast<const uint4*>(dk + o * Dp + d0);
+      dvv = *reinterpret_cast<const uint4*>(dv + o * D + d0);
+      const bf16x8 qb = *reinterpret_cast<const bf16x8*>(&qa), kb = *reinterpret_cast<const bf16x8*>(&ka);
+      const bf16x8 gqb = *reinterpret_cast<const bf16x8*>(&ga), gkb = *reinterpret_cast<const bf16x8*>(&gc);
+      const float4 c0 = *reinterpret_cast<const float4*>(cosb + (size_t)n * D + d0), c1 = *reinterpret_cast<const float4*>(cosb + (size_t)n * D + d0 + 4);
+      const float4 s0 = *reinterpret_cast<const float4*>(sinb + (size_t)n * D + d0), s1 = *reinterpret_cast<const float4*>(sinb + (size_t)n * D + d0 + 4);
+      const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {  // transpose of the pair rotation: out0 = a0*c0 - a1*s0, out1 = a1*c1 + a0*s1
+        q[e] = (float)qb[e]; q[e + 1] = (float)qb[e + 1]; k[e] = (float)kb[e]; k[e + 1] = (float)kb[e + 1];
+        eq[e] = (float)gqb[e] * cv[e] + (float)gqb[e + 1] * sv[e + 1]; eq[e + 1] = (float)gqb[e + 1] * cv[e + 1] - (float)gqb[e] * sv[e];
+        ek[e] = (float)gkb[e] * cv[e] + (float)gkb[e + 1] * sv[e + 1]; ek[e + 1] = (float)gkb[e + 1] * cv[e + 1] - (float)gkb[e] * sv[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) { sq += q[e] * q[e]; sk += k[e] * k[e]; }
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) { sq += __shfl_xor(sq, m, 64); sk += __shfl_xor(sk, m, 64); }
+    const float rq = rsqrtf(sq / (float)D + eps), rk = rsqrtf(sk / (float)D + eps);
+    float mq = 0.f, mk = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      nq[e] = q[e] * rq; nk[e] = k[e] * rk;
+      gq[e] += eq[e] * (float)(bf16)nq[e]; gk[e] += ek[e] * (float)(bf16)nk[e];       // d(weight): the weight multiplies the bf16-rounded normalised value
+      eq[e] *= wq[e]; ek[e] *= wk[e];                                                 // d(normalised)
+      mq += eq[e] * nq[e]; mk += ek[e] * nk[e];
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) { mq += __shfl_xor(mq, m, 64); mk += __shfl_xor(mk, m, 64); }
+    mq /= (float)D; mk /= (float)D;
+    if (live) {
+      uint4 oq, ok;
+      oq.x = dmvae_pack_bf16x2(rq * (eq[0] - nq[0] * mq), rq * (eq[1] - nq[1] * mq)); oq.y = dmvae_pack_bf16x2(rq * (eq[2] - nq[2] * mq), rq * (eq[3] - nq[3] * mq));
+      oq.z = dmvae_pack_bf16x2(rq * (eq[4] - nq[4] * mq), rq * (eq[5] - nq[5] * mq)); oq.w = dmvae_pack_bf16x2(rq * (eq[6] - nq[6] * mq), rq * (eq[7] - nq[7] * mq));
+      ok.x = dmvae_pack_bf16x2(rk * (ek[0] - nk[0] * mk), rk * (ek[1] - nk[1] * mk)); ok.y = dmvae_pack_bf16x2(rk * (ek[2] - nk[2] * mk), rk * (ek[3] - nk[3] * mk));
+      ok.z = dmvae_pack_bf16x2(rk * (ek[4] - nk[4] * mk), rk * (ek[5] - nk[5] * mk)); ok.w = dmvae_pack_bf16x2(rk * (ek[6] - nk[6] * mk), rk * (ek[7] - nk[7] * mk));
+      bf16* dbase = dqkv + (size_t)tok * 3 * H * D + d0;
+      *reinterpret_cast<uint4*>(dbase + (size_t)h * D) = oq;
+      *reinterpret_cast<uint4*>(dbase + (size_t)(H + h) * D) = ok;
+      *reinterpret_cast<uint4*>(dbase + (size_t)(2 * H + h) * D) = dvv;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) { red[grp][sub][e] = gq[e]; red[grp][sub][8 + e] = gk[e]; }
+  __syncthreads();
+  if (threadIdx.x < 2 * D) {            // part[blk][0][d] = dq_weight partial, part[blk][1][d] = dk_weight partial
+    const int which = threadIdx.x / D, d = threadIdx.x - which * D;
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; g++) t += red[g][d >> 3][which * 8 + (d & 7)];
+    part[((size_t)blockIdx.x * 2 + which) * D + d] = t;
+  }
+}
+}  // namespace dmvae_dit
+
 extern "C" int dmvae_qknorm_rope_bwd(const void* dq, const void* dk, const void* dv, const void* qkv, const void* q_weight, const void* k_weight,
                                      const void* cos_table, const void* sin_table, void* dqkv, void* dq_weight, void* dk_weight, void* workspace,
                                      size_t workspace_bytes, int batch, int seq, int heads, int head_dim, int head_dim_padded, float eps, int accumulate,
@@ -638,6 +765,12 @@ extern "C" int dmvae_qknorm_rope_bwd(const void* dq, const void* dk, const void*
   const int tokens = batch * seq;
   int nblk = (tokens * heads + 3) / 4; if (nblk > 2048) nblk = 2048;   // eight blocks per CU: the rows are short (4-B lanes, four wave reductions each) and latency-bound
   DMVAE_CHECK_ARG(workspace_bytes >= (size_t)nblk * 2 * head_dim * sizeof(float), "qknorm_rope_bwd: workspace too small");
+  if (head_dim % 8 == 0 && head_dim_padded % 8 == 0 && 2 * head_dim <= 256) {
+    nblk = (tokens * heads + 15) / 16; if (nblk > 2048) nblk = 2048;
+    hipLaunchKernelGGL(qknorm_rope16_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (const bf16*)qkv,
+                       (const float*)q_weight, (const float*)k_weight, (const float*)cos_table, (const float*)sin_table, (bf16*)dqkv, (float*)workspace,
+                       tokens, seq, heads, head_dim, head_dim_padded, eps);
+  } else
   hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (const bf16*)qkv,
                      (const float*)q_weight, (const float*)k_weight, (const float*)cos_table, (const float*)sin_table, (bf16*)dqkv, (float*)workspace,
                      tokens, seq, heads, head_dim, head_dim_padded, eps);

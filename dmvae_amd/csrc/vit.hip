@@ -158,35 +158,6 @@ struct AttnArgs {
   float eps;
 };
 
-// RMSNorm + RoPE of 8 consecutive channels d0..d0+7 of token `tok` (csrc/dit.hip::qknorm_rope_kernel's arithmetic: the normalised value is rounded to
-// bf16 before the f32 weight multiplies; pairs (2i, 2i+1) rotate with their own table entries)
-__device__ __forceinline__ uint4 norm_rope8(const uint4 raw, float r, const float* __restrict__ w, const float* __restrict__ cosb,
-                                            const float* __restrict__ sinb, int tok, int D, int d0) {
-  const bf16x8 x = *reinterpret_cast<const bf16x8*>(&raw);
-  const float4 w0 = *reinterpret_cast<const float4*>(w + d0), w1 = *reinterpret_cast<const float4*>(w + d0 + 4);
-  const float4 c0 = *reinterpret_cast<const float4*>(cosb + (size_t)tok * D + d0), c1 = *reinterpret_cast<const float4*>(cosb + (size_t)tok * D + d0 + 4);
-  const float4 s0 = *reinterpret_cast<const float4*>(sinb + (size_t)tok * D + d0), s1 = *reinterpret_cast<const float4*>(sinb + (size_t)tok * D + d0 + 4);
-  const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-  const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-  const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-  float n[8];
-#pragma unroll
-  for (int e = 0; e < 8; e++) n[e] = (float)(bf16)((float)x[e] * r) * wv[e];
-  uint4 o;
-  o.x = pack_bf16(n[0] * cv[0] - n[1] * sv[0], n[1] * cv[1] + n[0] * sv[1]);
-  o.y = pack_bf16(n[2] * cv[2] - n[3] * sv[2], n[3] * cv[3] + n[2] * sv[3]);
-  o.z = pack_bf16(n[4] * cv[4] - n[5] * sv[4], n[5] * cv[5] + n[4] * sv[5]);
-  o.w = pack_bf16(n[6] * cv[6] - n[7] * sv[6], n[7] * cv[7] + n[6] * sv[7]);
-  return o;
-}
-__device__ __forceinline__ float sumsq8(const uint4 raw) {
-  const bf16x8 x = *reinterpret_cast<const bf16x8*>(&raw);
-  float s = 0.f;
-#pragma unroll
-  for (int e = 0; e < 8; e++) s += (float)x[e] * (float)x[e];
-  return s;
-}
-
 template <int DP, bool NR>
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 #if __HIP_DEVICE_COMPILE__
@@ -212,10 +183,10 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         kv = *reinterpret_cast<const uint4*>(kb_ + (size_t)key * a.k_rs + c * 8);
         vv = *reinterpret_cast<const uint4*>(vb_ + (size_t)key * a.v_rs + c * 8);
       }
-      float ss = sumsq8(kv);
+      float ss = dmvae_sumsq8(kv);
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
-      if (live) kv = norm_rope8(kv, rsqrtf(ss / (float)a.D + a.eps), a.kw, a.cosb, a.sinb, key, a.D, c * 8);
+      if (live) kv = dmvae_norm_rope8(kv, rsqrtf(ss / (float)a.D + a.eps), a.kw, a.cosb, a.sinb, key, a.D, c * 8);
       if (c < DP / 8) {
         *reinterpret_cast<uint4*>(ks + key * KROW + ((c ^ (key & 7)) << 4)) = kv;
         *reinterpret_cast<uint4*>(vs + key * 256 + ((((c >> 2) ^ (key & 3))) << 6) + ((c & 3) << 4)) = vv;
@@ -256,13 +227,13 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     if constexpr (NR) {  // this lane and lane ^ 32 hold the two halves of query q's row
       float ss = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < KSTEPS; kk++) ss += sumsq8(*reinterpret_cast<const uint4*>(&qf[kk]));
+      for (int kk = 0; kk < KSTEPS; kk++) ss += dmvae_sumsq8(*reinterpret_cast<const uint4*>(&qf[kk]));
       ss += __shfl_xor(ss, 32, 64);
       const float rq = rsqrtf(ss / (float)a.D + a.eps);
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; kk++)
         if (q < S && kk * 16 + kg * 8 < a.D) {
-          const uint4 o = norm_rope8(*reinterpret_cast<const uint4*>(&qf[kk]), rq, a.qw, a.cosb, a.sinb, q, a.D, kk * 16 + kg * 8);
+          const uint4 o = dmvae_norm_rope8(*reinterpret_cast<const uint4*>(&qf[kk]), rq, a.qw, a.cosb, a.sinb, q, a.D, kk * 16 + kg * 8);
           qf[kk] = *reinterpret_cast<const bf16x8*>(&o);
         }
     }
