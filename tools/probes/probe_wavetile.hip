@@ -95,6 +95,82 @@ __global__ __launch_bounds__(512) void kern_a(const bf16* wsrc, const bf16* xsrc
   out[(size_t)blockIdx.x * 512 + tid] = s;
 }
 
+// ---------------------------------------------------------------- C: A's schedule with 64-channel K tiles ------------------------------------
+// 8 waves, two per SIMD alternating LOAD / COMPUTE, but a K tile is 64 channels (128-B LDS rows): 32 MFMAs per COMPUTE interval, half the barriers and half
+// the per-tile issue overhead per MFMA; two 64-KiB slots (prefetch distance one tile).
+__global__ __launch_bounds__(512) void kern_c(const bf16* wsrc, const bf16* xsrc, float* out, int reps) {
+  constexpr int TM = 256, TP = 256, WP = 4, BM = 4, BP = 2;
+  constexpr int TILE_A = TM * 128, SLOT = (TM + TP) * 128, NPA = 4, NPB = 4, NP = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2;
+  const int wm = wave / WP, wp = wave % WP;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, 0, 256u * KROW * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + (size_t)blockIdx.x * 256 * KROW), 0, 256u * KROW * 2u, 0x00020000);
+  unsigned voffA[NPA], voffB[NPB];
+  for (int p = 0; p < NPA; p++) { const int row = (wave * NPA + p) * 8 + (lane >> 3); voffA[p] = (unsigned)row * KROW * 2u + (((lane & 7) ^ swz128(row)) << 4); }
+  for (int p = 0; p < NPB; p++) { const int row = (wave * NPB + p) * 8 + (lane >> 3); voffB[p] = (unsigned)row * KROW * 2u + (((lane & 7) ^ swz128(row)) << 4); }
+  const int kg = lane >> 5;
+  int arow[BM], brow[BP];
+  for (int i = 0; i < BM; i++) arow[i] = wm * 128 + i * 32 + (lane & 31);
+  for (int j = 0; j < BP; j++) brow[j] = wp * 64 + j * 32 + (lane & 31);
+  const int nK = KROW / 64;
+  int it = 0;
+  auto issue = [&](int slot) {
+    const unsigned so = (unsigned)(it % nK) * 128u;
+#pragma unroll
+    for (int p = 0; p < NPA; p++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + slot + (wave * NPA + p) * 1024), 16, voffA[p], so, 0, 0);
+#pragma unroll
+    for (int p = 0; p < NPB; p++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + TILE_A + (wave * NPB + p) * 1024), 16, voffB[p], so, 0, 0);
+    it++;
+  };
+  f32x16 acc[BM][BP];
+  for (int i = 0; i < BM; i++) for (int j = 0; j < BP; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  issue(0);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  bf16x8 af[4][BM], bfr[4][BP];
+  int slot_rd = 0;
+  const int total = reps * nK;
+#pragma unroll 1
+  for (int t = 0; t < total; t++) {
+    const char* sb = smem + slot_rd;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+#pragma unroll
+      for (int j = 0; j < BP; j++) bfr[kk][j] = *reinterpret_cast<const bf16x8*>(sb + TILE_A + brow[j] * 128 + ((((kk << 1) | kg) ^ swz128(brow[j])) << 4));
+#pragma unroll
+      for (int i = 0; i < BM; i++) af[kk][i] = *reinterpret_cast<const bf16x8*>(sb + arow[i] * 128 + ((((kk << 1) | kg) ^ swz128(arow[i])) << 4));
+    }
+    // the other slot was last read two intervals ago by this group and one interval ago by the partner group, whose reads completed before the barrier
+    // that ended its LOAD interval
+    issue(slot_rd ^ SLOT);
+    slot_rd ^= SLOT;
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+      for (int i = 0; i < BM; i++)
+#pragma unroll
+        for (int j = 0; j < BP; j++) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[kk][i]), "v"(bfr[kk][j]));
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  wait_vmcnt<0>();
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  float s_ = 0.f;
+  for (int i = 0; i < BM; i++) for (int j = 0; j < BP; j++) for (int r = 0; r < 16; r++) s_ += acc[i][j][r];
+  out[(size_t)blockIdx.x * 512 + tid] = s_;
+}
+
 // ---------------------------------------------------------------- B: 4 waves, 128x128 per wave ------------------------------------------
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void kern_b(const bf16* wsrc, const bf16* xsrc, float* out, int reps) {
   constexpr int TM = 256, TP = 256, BM = 4, BP = 4, NBUF = 2;
@@ -182,17 +258,18 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(w, h.data(), nw * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(x, h.data(), nx * 2, hipMemcpyHostToDevice));
   CK(hipFuncSetAttribute((const void*)kern_a, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 64));
   CK(hipFuncSetAttribute((const void*)kern_b, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+  CK(hipFuncSetAttribute((const void*)kern_c, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double flop = (double)blocks * reps * 256.0 * 256.0 * KROW * 2.0;
   for (int round = 0; round < 3; round++) {
-    for (int v = 0; v < 2; v++) {
+    for (int v = 0; v < 3; v++) {
       const int n = 20;
-      for (int k = 0; k < 3; k++) { if (v == 0) hipLaunchKernelGGL(kern_a, dim3(blocks), dim3(512), 4 * 512 * 64, 0, w, x, out, reps); else hipLaunchKernelGGL(kern_b, dim3(blocks), dim3(256), 2 * 512 * 128, 0, w, x, out, reps); }
+      for (int k = 0; k < 3; k++) { if (v == 0) hipLaunchKernelGGL(kern_a, dim3(blocks), dim3(512), 4 * 512 * 64, 0, w, x, out, reps); else if (v == 1) hipLaunchKernelGGL(kern_b, dim3(blocks), dim3(256), 2 * 512 * 128, 0, w, x, out, reps); else hipLaunchKernelGGL(kern_c, dim3(blocks), dim3(512), 2 * 512 * 128, 0, w, x, out, reps); }
       CK(hipEventRecord(e0));
-      for (int k = 0; k < n; k++) { if (v == 0) hipLaunchKernelGGL(kern_a, dim3(blocks), dim3(512), 4 * 512 * 64, 0, w, x, out, reps); else hipLaunchKernelGGL(kern_b, dim3(blocks), dim3(256), 2 * 512 * 128, 0, w, x, out, reps); }
+      for (int k = 0; k < n; k++) { if (v == 0) hipLaunchKernelGGL(kern_a, dim3(blocks), dim3(512), 4 * 512 * 64, 0, w, x, out, reps); else if (v == 1) hipLaunchKernelGGL(kern_b, dim3(blocks), dim3(256), 2 * 512 * 128, 0, w, x, out, reps); else hipLaunchKernelGGL(kern_c, dim3(blocks), dim3(512), 2 * 512 * 128, 0, w, x, out, reps); }
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      printf("%s %s: %.1f us / launch, %.1f TFLOP/s\n", v == 0 ? "A 8 waves 128x64 pingpong K32" : "B 4 waves 128x128 regpipe K64", zeros ? "zeros" : "random", ms / n * 1e3, flop / (ms / n * 1e-3) / 1e12);
+      printf("%s %s: %.1f us / launch, %.1f TFLOP/s\n", v == 0 ? "A 8 waves 128x64 pingpong K32" : (v == 1 ? "B 4 waves 128x128 regpipe K64" : "C 8 waves 128x64 pingpong K64"), zeros ? "zeros" : "random", ms / n * 1e3, flop / (ms / n * 1e-3) / 1e12);
     }
   }
   CK(hipGetLastError());
