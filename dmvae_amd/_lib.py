@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdmvae_hip.so")
+LIB_PATH = os.environ.get("DMVAE_LIB") or os.path.join(_HERE, "libdmvae_hip.so")      # DMVAE_LIB: another build of the same ABI (kernel A/B runs on one box)
 
 
 class ConvDesc(Structure):

@@ -12,6 +12,7 @@
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 constexpr unsigned SENT = 0x80000000u;
@@ -82,6 +83,84 @@ __global__ __launch_bounds__(512) void kern_a(const bf16* wsrc, const bf16* xsrc
       for (int i = 0; i < BM; i++)
 #pragma unroll
         for (int j = 0; j < BP; j++) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[kk][i]), "v"(bfr[kk][j]));
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  wait_vmcnt<0>();
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  float s = 0.f;
+  for (int i = 0; i < BM; i++) for (int j = 0; j < BP; j++) for (int r = 0; r < 16; r++) s += acc[i][j][r];
+  out[(size_t)blockIdx.x * 512 + tid] = s;
+}
+
+// ---------------------------------------------------------------- D: A with 16x16x32 MFMAs (power comparison only: operand mapping not meaningful) ----
+__global__ __launch_bounds__(512) void kern_d(const bf16* wsrc, const bf16* xsrc, float* out, int reps) {
+  constexpr int TM = 256, TP = 256, WP = 4, BM = 4, BP = 2, NBUF = 4, PF = 3;
+  constexpr int TILE_A = TM * 64, SLOT = (TM + TP) * 64, NPA = 2, NPB = 2, NP = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2;
+  const int wm = wave / WP, wp = wave % WP;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, 0, 256u * KROW * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + (size_t)blockIdx.x * 256 * KROW), 0, 256u * KROW * 2u, 0x00020000);
+  unsigned voffA[NPA], voffB[NPB];
+  for (int p = 0; p < NPA; p++) { const int row = (wave * NPA + p) * 16 + (lane >> 2); voffA[p] = (unsigned)row * KROW * 2u + (((lane & 3) ^ swz64(row)) << 4); }
+  for (int p = 0; p < NPB; p++) { const int row = (wave * NPB + p) * 16 + (lane >> 2); voffB[p] = (unsigned)row * KROW * 2u + (((lane & 3) ^ swz64(row)) << 4); }
+  const int kg = lane >> 5;
+  int aoff[2][BM], boff[2][BP];
+  for (int i = 0; i < BM; i++) { const int row = wm * 128 + i * 32 + (lane & 31); aoff[0][i] = row * 64 + ((kg ^ swz64(row)) << 4); aoff[1][i] = aoff[0][i] ^ 32; }
+  for (int j = 0; j < BP; j++) { const int row = wp * 64 + j * 32 + (lane & 31); boff[0][j] = TILE_A + row * 64 + ((kg ^ swz64(row)) << 4); boff[1][j] = boff[0][j] ^ 32; }
+  const int nK = KROW / 32;
+  int it = 0;
+  auto issue = [&](int slot) {
+    const unsigned so = (unsigned)(it % nK) * 64u;
+#pragma unroll
+    for (int p = 0; p < NPA; p++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + slot + (wave * NPA + p) * 1024), 16, voffA[p], so, 0, 0);
+#pragma unroll
+    for (int p = 0; p < NPB; p++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + TILE_A + (wave * NPB + p) * 1024), 16, voffB[p], so, 0, 0);
+    it++;
+  };
+  f32x16 acc[BM][BP];
+  for (int i = 0; i < BM; i++) for (int j = 0; j < BP; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int u = 0; u < PF; u++) issue(u * SLOT);
+  wait_vmcnt<(PF - 1) * NP>();
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  bf16x8 af[2][BM], bfr[2][BP];
+  int slot_rd = 0, slot_wr = PF * SLOT;
+  const int total = reps * nK;
+#pragma unroll 1
+  for (int t = 0; t < total; t++) {
+    const char* sb = smem + slot_rd;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+#pragma unroll
+      for (int j = 0; j < BP; j++) bfr[kk][j] = *reinterpret_cast<const bf16x8*>(sb + boff[kk][j]);
+#pragma unroll
+      for (int i = 0; i < BM; i++) af[kk][i] = *reinterpret_cast<const bf16x8*>(sb + aoff[kk][i]);
+    }
+    issue(slot_wr);
+    slot_rd = slot_rd + SLOT == NBUF * SLOT ? 0 : slot_rd + SLOT;
+    slot_wr = slot_wr + SLOT == NBUF * SLOT ? 0 : slot_wr + SLOT;
+    wait_vmcnt<(PF - 1) * NP>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+      for (int i = 0; i < BM; i++)
+#pragma unroll
+        for (int j = 0; j < BP; j++) {   // the same flops per K tile as two 32x32x16 per block pair, issued as four 16x16x32 on 4-register accumulators
+          f32x4* sub = reinterpret_cast<f32x4*>(&acc[i][j]);
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(sub[kk * 2 + 0]) : "v"(af[kk][i]), "v"(bfr[kk][j]));
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(sub[kk * 2 + 1]) : "v"(af[kk ^ 1][i]), "v"(bfr[kk][j]));
+        }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -258,18 +337,19 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(w, h.data(), nw * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(x, h.data(), nx * 2, hipMemcpyHostToDevice));
   CK(hipFuncSetAttribute((const void*)kern_a, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 64));
   CK(hipFuncSetAttribute((const void*)kern_b, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+  CK(hipFuncSetAttribute((const void*)kern_d, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 64));
   CK(hipFuncSetAttribute((const void*)kern_c, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double flop = (double)blocks * reps * 256.0 * 256.0 * KROW * 2.0;
   for (int round = 0; round < 3; round++) {
-    for (int v = 0; v < 3; v++) {
+    for (int v = 0; v < 4; v++) {
       const int n = 20;
-      for (int k = 0; k < 3; k++) { if (v == 0) hipLaunchKernelGGL(kern_a, dim3(blocks), dim3(512), 4 * 512 * 64, 0, w, x, out, reps); else if (v == 1) hipLaunchKernelGGL(kern_b, dim3(blocks), dim3(256), 2 * 512 * 128, 0, w, x, out, reps); else hipLaunchKernelGGL(kern_c, dim3(blocks), dim3(512), 2 * 512 * 128, 0, w, x, out, reps); }
+      for (int k = 0; k < 3; k++) { if (v == 0) hipLaunchKernelGGL(kern_a, dim3(blocks), dim3(512), 4 * 512 * 64, 0, w, x, out, reps); else if (v == 1) hipLaunchKernelGGL(kern_b, dim3(blocks), dim3(256), 2 * 512 * 128, 0, w, x, out, reps); else if (v == 2) hipLaunchKernelGGL(kern_c, dim3(blocks), dim3(512), 2 * 512 * 128, 0, w, x, out, reps); else hipLaunchKernelGGL(kern_d, dim3(blocks), dim3(512), 4 * 512 * 64, 0, w, x, out, reps); }
       CK(hipEventRecord(e0));
-      for (int k = 0; k < n; k++) { if (v == 0) hipLaunchKernelGGL(kern_a, dim3(blocks), dim3(512), 4 * 512 * 64, 0, w, x, out, reps); else if (v == 1) hipLaunchKernelGGL(kern_b, dim3(blocks), dim3(256), 2 * 512 * 128, 0, w, x, out, reps); else hipLaunchKernelGGL(kern_c, dim3(blocks), dim3(512), 2 * 512 * 128, 0, w, x, out, reps); }
+      for (int k = 0; k < n; k++) { if (v == 0) hipLaunchKernelGGL(kern_a, dim3(blocks), dim3(512), 4 * 512 * 64, 0, w, x, out, reps); else if (v == 1) hipLaunchKernelGGL(kern_b, dim3(blocks), dim3(256), 2 * 512 * 128, 0, w, x, out, reps); else if (v == 2) hipLaunchKernelGGL(kern_c, dim3(blocks), dim3(512), 2 * 512 * 128, 0, w, x, out, reps); else hipLaunchKernelGGL(kern_d, dim3(blocks), dim3(512), 4 * 512 * 64, 0, w, x, out, reps); }
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      printf("%s %s: %.1f us / launch, %.1f TFLOP/s\n", v == 0 ? "A 8 waves 128x64 pingpong K32" : (v == 1 ? "B 4 waves 128x128 regpipe K64" : "C 8 waves 128x64 pingpong K64"), zeros ? "zeros" : "random", ms / n * 1e3, flop / (ms / n * 1e-3) / 1e12);
+      printf("%s %s: %.1f us / launch, %.1f TFLOP/s\n", v == 0 ? "A 8 waves 128x64 pingpong K32" : (v == 1 ? "B 4 waves 128x128 regpipe K64" : (v == 2 ? "C 8 waves 128x64 pingpong K64" : "D = A with 16x16x32 MFMAs")), zeros ? "zeros" : "random", ms / n * 1e3, flop / (ms / n * 1e-3) / 1e12);
     }
   }
   CK(hipGetLastError());
