@@ -568,6 +568,38 @@ def ema_update(ema: Tensor, p: Tensor, decay: float = 0.9999) -> Tensor:
     return ema * decay + p * (1 - decay)
 
 
+def tokenizer_train_steps(images: Tensor, p: P, lpips_p: P, trainable: Sequence[str], steps: int, base_lr: float = 1e-4,
+                          warmup_steps: int = 1000, num_heads: int = 16, max_norm: float = 1.0, ema_decay: float = 0.9999, q: Q = None,
+                          on_grads: Optional[Callable[[int, Dict[str, Tensor]], None]] = None):
+    """The loop body of train_tokenizer.py:403-437 with the discriminator branch off, `steps` times on the same batch:
+    VAE.forward (frozen encoder, :411) -> forward_generator (:412) -> backward (:414) -> clip_grad_norm_ over every parameter that
+    received a gradient (:415) -> AdamW(betas (0.9, 0.95), eps 1e-8, wd 0.005; :382) at LambdaLR's rate for this step (:385-392) ->
+    update_ema (:437; the frozen encoder's EMA copy equals the encoder and is not tracked here).
+    p is updated functionally; returns (per-step logs, parameters, EMA of the trainable parameters).  Pinned by tests/golden/step_small.npz."""
+    p = dict(p)
+    m = {k: torch.zeros_like(p[k]) for k in trainable}
+    v = {k: torch.zeros_like(p[k]) for k in trainable}
+    ema = {k: p[k].detach().clone() for k in trainable}
+    logs = []
+    for step in range(steps):
+        leaves = {k: p[k].detach().clone().requires_grad_(True) for k in trainable}
+        pp = {**{k: t.detach() for k, t in p.items()}, **leaves}
+        with torch.no_grad():
+            tok = dino_encoder_forward(images, pp, num_heads=num_heads, q=q)
+        rec = decoder_forward(mlp_forward(tok, pp, q=q), pp, pre="decoder.", q=q).float()
+        loss, log = forward_generator(images, rec, lpips_p, q=q)
+        grads = dict(zip(trainable, torch.autograd.grad(loss, [leaves[k] for k in trainable])))
+        if on_grads is not None:
+            on_grads(step, grads)
+        total, clipped = clip_grad_norm([grads[k] for k in trainable], max_norm)
+        lr = warmup_lr(step, base_lr, warmup_steps)
+        for k, g in zip(trainable, clipped):
+            p[k], m[k], v[k] = adamw_step(p[k].detach(), g, m[k], v[k], step + 1, lr)
+            ema[k] = ema_update(ema[k], p[k], ema_decay)
+        logs.append({**{kk: float(vv.detach()) for kk, vv in log.items()}, "vae_norm": float(total), "lr": lr})
+    return logs, p, ema
+
+
 def warmup_lr(step: int, base_lr: float, warmup_steps: int = 1000) -> float:
     """LambdaLR of train_tokenizer.py:385-392, lr_lambda(step) = step / warmup if step < warmup else 1: the learning rate in force
     for optimiser step number `step` (0-based) -- the very first step runs at lr 0."""

@@ -228,3 +228,40 @@ def test_dmd_stage_step_harness():
     with torch.no_grad():
         w.mul_(1.5)                                      # changed behind the optimiser's back: converted again on next use
     assert torch.equal(Fn._bf(w), w.detach().to(torch.bfloat16))
+
+
+def test_step_small_vs_reference_capture():
+    """G12: four steps of TokenizerTrainer on the HIP path against four steps of the REFERENCE's own modules and optimiser
+    (tests/golden/step_small.npz, captured by oracle/capture_golden_step.py in fp32 on the CPU; tests/test_oracle_step.py holds the oracle to the
+    same fixture at f32 tolerances).  Same name-seeded weights, same two images, same lr schedule.  The HIP path computes in bf16 where the
+    reference's CUDA autocast would, the capture is fp32, so the bars are the bf16 floor of a 60-layer forward + backward: losses 2 %, gradient
+    norm 5 %; the optimiser tail is then checked through what it did to the weights -- per-tensor sum|update| (lr x Adam direction + decay) for
+    all 140 trainable tensors, and the direction of the complete update of eight small tensors."""
+    from conftest import load_golden
+    from test_oracle_golden import lpips_params
+    from test_oracle_step import check_step_small, step_small_inputs
+    from dmvae_amd.train import TokenizerTrainer
+    from dmvae_amd.utils.lpips import LPIPS
+    g = load_golden("step_small")
+    p, vae, names, images = step_small_inputs(g)
+    vae.load_state_dict(p, strict=True)
+    vae = vae.cuda()
+    lp = LPIPS().eval().requires_grad_(False)
+    missing = lp.load_state_dict(lpips_params(g, "lp."), strict=False)
+    assert not missing.unexpected_keys and all("scaling_layer" in k for k in missing.missing_keys), missing
+    tr = TokenizerTrainer(vae, lp.cuda(), lr=float(g["base_lr"]), warmup_steps=int(g["warmup_steps"]))
+    p0 = {k: p[k].clone() for k in names}
+    x = images.cuda()
+    steps = len(g["lr"])
+    logs = []
+    for s in range(steps):
+        lr = tr.opt.current_lr()
+        tr.step(x)
+        logs.append({**tr.read_log(), "lr": lr})
+    assert logs[0]["rec_loss"] == logs[1]["rec_loss"]            # the first optimiser step runs at lr 0
+    assert logs[3]["rec_loss"] < logs[2]["rec_loss"] < logs[1]["rec_loss"]
+    by_id = {id(q): n for n, q in vae.named_parameters()}
+    p1 = {k: q.detach().cpu() for k, q in vae.named_parameters() if k in p0}
+    ema = {by_id[id(q)]: e.detach().cpu() for q, e in zip(tr.fp.params, tr.fp.ema_state())}
+    assert sorted(ema) == sorted(names)
+    check_step_small(g, logs, p0, p1, ema, names, steps - 1, tol_loss=2e-2, tol_norm=5e-2, tol_abs_delta=5e-2, tol_signed=0.25, min_cos=0.9, tol_ema=0.5)

@@ -122,7 +122,7 @@ def test_mlp():
         assert rel_err(v, g.t("g." + k[len("bottle_neck."):])) < TOL
 
 
-def vae_tiny_params():
+def vae_tiny_params(seed=33):
     """Parameters of the tiny-ViT VAE fixture, regenerated from the capture's names (reference adapter inserts 'vit.')."""
     from dmvae_amd.models.vae import VAE
     import warnings
@@ -134,7 +134,7 @@ def vae_tiny_params():
     for k, v in vae.state_dict().items():
         if k in params:
             ref_name = k.replace("encoder.model.", "encoder.model.vit.", 1) if k.startswith("encoder.model.") else k
-            p[k] = det_tensor(ref_name, v.shape, 33)
+            p[k] = det_tensor(ref_name, v.shape, seed)
         else:
             p[k] = v.clone()
     return p, vae
@@ -169,8 +169,8 @@ def test_vae_large_key_manifest():
         assert str(tuple(v.shape)) == ref_shapes[k], k
 
 
-def lpips_params(g):
-    p = dict(g.sub("p."))
+def lpips_params(g, prefix="p."):
+    p = dict(g.sub(prefix))
     chans = [3] + [c for c in R.VGG_CFG if c != "M"]
     idx, ci, bounds = 0, 0, (4, 9, 16, 23, 30)
     for v in R.VGG_CFG:
