@@ -43,6 +43,10 @@ __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((N & 15) | 0x0F70 | ((N >> 4) << 14));
   asm volatile("" ::: "memory");
 }
+// Wave-uniform values that come out of an integer division sit in VGPRs (the division runs on the VALU); everything derived from them then
+// stays there and every LDS-DMA issue whose soffset depends on them becomes a readfirstlane waterfall loop -- four per K tile, plus a
+// compiler-inserted vmcnt(0) at the loop head because its wait-count model cannot count loads inside those loops.  Pin them to SGPRs.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ s16x4 tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
@@ -67,12 +71,13 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   const int wm = wave / WN, wn = wave % WN;
   const int T = a.ks * a.ks;
 
-  const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned wid = (unsigned)uni((int)xcd_remap(blockIdx.x, gridDim.x));
   const int tiles = a.mtiles * a.ntiles;
-  const int split = (int)(wid / tiles);
-  const int tile = (int)(wid % tiles);
-  const int co0 = (tile / a.ntiles) * TM;
-  const int g0 = (tile % a.ntiles) * GB;  // first column group of this block
+  const int split = uni((int)(wid / tiles));
+  const int tile = uni((int)(wid - (unsigned)split * tiles));
+  const int mt = uni(tile / a.ntiles);
+  const int co0 = mt * TM;
+  const int g0 = (tile - mt * a.ntiles) * GB;  // first column group of this block
   const int k0 = split * a.kchunk;
   const int k1 = min(k0 + a.kchunk, a.M);
   const int nK = (k1 - k0) >> 5;
@@ -107,9 +112,9 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     const int sub = pb >> 3, row = (pb & 7) * 4 + (lane >> 4);
     const int clog = ((((cphys >> 2) ^ (row & 3)) << 2) | (cphys & 3)) * 8;
     const int g = g0 + sub;
-    const int tap = g / a.gpt, ci = (g - tap * a.gpt) * 128 + clog;
+    const int tap = uni(g / a.gpt), ci = (g - tap * a.gpt) * 128 + clog;
     const bool ok = g < a.ngroups;
-    kyB[p] = a.ks == 3 ? tap / 3 : 1;
+    kyB[p] = a.ks == 3 ? uni(tap / 3) : 1;
     kxB[p] = a.ks == 3 ? tap - (tap / 3) * 3 : 1;
     tapoB[p] = (!a.ups && a.ks == 3) ? (unsigned)(kyB[p] * a.Wi + kxB[p]) * a.Cin * 2u : 0u;
     rowB[p] = row;
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   // index equals the cout block.  The ntiles blocks that share a (split, cout tile) take the K tiles round-robin, so every
   // block does 1/ntiles of it (one block doing all of it would set the critical path of a single-round launch) -- instead of
   // a second 2 B/elem pass over dy.
-  const int my_nt = tile % a.ntiles;
+  const int my_nt = tile - mt * a.ntiles;
   const bool do_bias = a.bslab != nullptr && wn < BM;
   int bias_cnt = my_nt;
   f32x16 accb;
@@ -163,9 +168,9 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   int px0, py, pn;
   {
     const int hw = a.Ho * a.Wo;
-    pn = k0 / hw;
+    pn = uni(k0 / hw);
     const int r = k0 - pn * hw;
-    py = r / a.Wo;
+    py = uni(r / a.Wo);
     px0 = r - py * a.Wo;
   }
   auto issue = [&](int slot) {
