@@ -233,8 +233,14 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   auto issue = [&](int slot) {
     const bool live = it < nK;
     if (live && (KO || it_ch == 0)) new_tap();
-    const unsigned soA = (unsigned)(it_tap * a.Cin + it_ch * 32) * 2u;
-    const unsigned soB = soffB_tap + (unsigned)it_ch * 64u;
+    unsigned soA = (unsigned)(it_tap * a.Cin + it_ch * 32) * 2u;
+    unsigned soB = soffB_tap + (unsigned)it_ch * 64u;
+    // GEN: the tap offset and the chunk counter end up in VGPRs (phis of VALU-computed values) and every piece issue became a readfirstlane
+    // waterfall loop; pin the two wave-uniform offsets to SGPRs (the plain instantiation's code is unchanged)
+    if constexpr (GEN) {
+      soA = (unsigned)__builtin_amdgcn_readfirstlane((int)soA);
+      soB = (unsigned)__builtin_amdgcn_readfirstlane((int)soB);
+    }
 #pragma unroll
     for (int p = 0; p < NPA; p++)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + slot + (wave * NPA + p) * 1024), 16, live ? voffA[p] : SENT, soA, 0, 0);

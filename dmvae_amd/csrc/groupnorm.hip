@@ -24,6 +24,13 @@ __device__ __forceinline__ void load8(const bf16* p, float (&v)[8]) {
 #pragma unroll
   for (int e = 0; e < 8; e++) v[e] = (float)t[e];
 }
+// Raw 16-B load / later conversion, so that a loop can put the loads of TWO pixel rows in flight before it touches either: with one row per
+// iteration and 5 (backward) to 8 waves per SIMD a CU holds 20-40 KB of reads in flight against the ~64 KB that 8 TB/s x ~2 us of latency asks of it.
+__device__ __forceinline__ bf16x8 ldraw(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void cvt8(const bf16x8& t, float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; e++) v[e] = (float)t[e];
+}
 __device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
   bf16x8 t;
 #pragma unroll
@@ -66,12 +73,19 @@ __global__ __launch_bounds__(256) void stats_partial_kernel(const bf16* __restri
   for (int e = 0; e < 8; e++) { s[e] = 0.f; ss[e] = 0.f; }
   if (active) {
     const bf16* base = x + (size_t)n * g.HW * g.C + lane_c * 8;
-    for (int p = p0 + prow; p < p1; p += g.rows) {
+    auto acc = [&](const bf16x8& r) {
       float v[8];
-      load8(base + (size_t)p * g.C, v);
+      cvt8(r, v);
 #pragma unroll
       for (int e = 0; e < 8; e++) { s[e] += v[e]; ss[e] += v[e] * v[e]; }
+    };
+    int p = p0 + prow;
+    for (; p + 3 * g.rows < p1; p += 4 * g.rows) {       // four rows in flight; accumulated in the same order as one at a time
+      const bf16x8 r0 = ldraw(base + (size_t)p * g.C), r1 = ldraw(base + (size_t)(p + g.rows) * g.C);
+      const bf16x8 r2 = ldraw(base + (size_t)(p + 2 * g.rows) * g.C), r3 = ldraw(base + (size_t)(p + 3 * g.rows) * g.C);
+      acc(r0); acc(r1); acc(r2); acc(r3);
     }
+    for (; p < p1; p += g.rows) acc(ldraw(base + (size_t)p * g.C));
   }
   block_reduce_store(s, ss, part, g, lane_c, prow, active);
 }
@@ -118,16 +132,22 @@ __global__ __launch_bounds__(256) void apply_kernel(const bf16* __restrict__ x, 
     sh[e] = beta[c] - st[0] * sc[e];
   }
   const size_t base = (size_t)n * g.HW * g.C + lane_c * 8;
-  for (int p = p0 + prow; p < p1; p += g.rows) {
+  auto row = [&](const bf16x8& r, int p) {
     float v[8];
-    load8(x + base + (size_t)p * g.C, v);
+    cvt8(r, v);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const float t = v[e] * sc[e] + sh[e];
       v[e] = ACT == 1 ? t * sigmoidf_(t) : (ACT == 2 ? (t > 0.f ? t : 0.2f * t) : t);
     }
     store8(y + base + (size_t)p * g.C, v);
+  };
+  int p = p0 + prow;
+  for (; p + g.rows < p1; p += 2 * g.rows) {
+    const bf16x8 r0 = ldraw(x + base + (size_t)p * g.C), r1 = ldraw(x + base + (size_t)(p + g.rows) * g.C);
+    row(r0, p); row(r1, p + g.rows);
   }
+  if (p < p1) row(ldraw(x + base + (size_t)p * g.C), p);
 }
 
 template <int ACT>
@@ -151,10 +171,10 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const bf16* __restrict
       mu[e] = st[0]; rs[e] = st[1]; ga[e] = gamma[c]; be[e] = beta[c];
     }
     const size_t base = (size_t)n * g.HW * g.C + lane_c * 8;
-    for (int p = p0 + prow; p < p1; p += g.rows) {
+    auto row = [&](const bf16x8& rx, const bf16x8& rd) {
       float v[8], d[8];
-      load8(x + base + (size_t)p * g.C, v);
-      load8(da + base + (size_t)p * g.C, d);
+      cvt8(rx, v);
+      cvt8(rd, d);
 #pragma unroll
       for (int e = 0; e < 8; e++) {
         const float xh = (v[e] - mu[e]) * rs[e];
@@ -168,7 +188,14 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const bf16* __restrict
         }
         A[e] += dy; B[e] += dy * xh;
       }
+    };
+    int p = p0 + prow;
+    for (; p + g.rows < p1; p += 2 * g.rows) {          // two rows in flight; accumulated in the same order as one at a time
+      const size_t o0 = base + (size_t)p * g.C, o1 = base + (size_t)(p + g.rows) * g.C;
+      const bf16x8 x0 = ldraw(x + o0), d0 = ldraw(da + o0), x1 = ldraw(x + o1), d1 = ldraw(da + o1);
+      row(x0, d0); row(x1, d1);
     }
+    if (p < p1) row(ldraw(x + base + (size_t)p * g.C), ldraw(da + base + (size_t)p * g.C));
   }
   block_reduce_store(A, B, part, g, lane_c, prow, active);
 }
@@ -227,11 +254,11 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const bf16* __restrict__
     s1[e] = S[gi] * inv_m; s2[e] = S[gi + 1] * inv_m;
   }
   const size_t base = (size_t)n * g.HW * g.C + lane_c * 8;
-  for (int p = p0 + prow; p < p1; p += g.rows) {
+  auto row = [&](const bf16x8& rx, const bf16x8& rd, const bf16x8& ro, int p) {
     float v[8], d[8], o[8];
-    load8(x + base + (size_t)p * g.C, v);
-    load8(da + base + (size_t)p * g.C, d);
-    if (dres) load8(dres + base + (size_t)p * g.C, o);
+    cvt8(rx, v);
+    cvt8(rd, d);
+    if (dres) cvt8(ro, o);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const float xh = (v[e] - mu[e]) * rs[e];
@@ -247,6 +274,19 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const bf16* __restrict__
       o[e] = dres ? o[e] + r : r;
     }
     store8(dx + base + (size_t)p * g.C, o);
+  };
+  int p = p0 + prow;
+  for (; p + g.rows < p1; p += 2 * g.rows) {
+    const size_t o0 = base + (size_t)p * g.C, o1 = base + (size_t)(p + g.rows) * g.C;
+    const bf16x8 x0 = ldraw(x + o0), d0 = ldraw(da + o0), x1 = ldraw(x + o1), d1 = ldraw(da + o1);
+    bf16x8 q0 = x0, q1 = x1;
+    if (dres) { q0 = ldraw(dres + o0); q1 = ldraw(dres + o1); }
+    row(x0, d0, q0, p); row(x1, d1, q1, p + g.rows);
+  }
+  if (p < p1) {
+    const size_t o0 = base + (size_t)p * g.C;
+    const bf16x8 x0 = ldraw(x + o0), d0 = ldraw(da + o0);
+    row(x0, d0, dres ? ldraw(dres + o0) : x0, p);
   }
 }
 
