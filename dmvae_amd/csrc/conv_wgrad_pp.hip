@@ -7,9 +7,12 @@
 //
 // GEMM view: M = cout, N = (tap, cin) flattened in column groups of 128 channels, K = pixels.  Both operands are
 // channel-contiguous while the reduction runs over pixels, so LDS holds [32 pixels][128 channels] sub-tiles exactly as
-// DMA'd and the MFMA fragments come from the gfx950 transpose read ds_read_b64_tr_b16 (64-B segment XOR swizzle keyed
-// on pixel & 3, applied on the DMA source address and on the read -- same image as conv_wgrad.hip, hardware-checked by
-// tools/probes/probe_tr16.hip).
+// DMA'd and the MFMA fragments come from the gfx950 transpose read ds_read_b64_tr_b16 (hardware-checked by
+// tools/probes/probe_tr16.hip).  The MFMA is v_mfma_f32_16x16x32_bf16 (one instruction = 16 x 16 outputs over the whole 32-pixel K tile;
+// same flops for ~5 % less power than 32x32x16 in the power-limited regime, see conv_pp.hip): lane group G = lane >> 4 supplies pixels
+// 8 G .. 8 G + 7, so the two groups a transpose read serves per LDS pass ({0,1} or {2,3}) touch pixel rows {0-3, 8-11} (+4, +16) of the same
+// 16-channel block.  The LDS image is therefore XOR-swizzled in 32-B slots keyed on ((pixel & 3) << 1) | ((pixel >> 3) & 1) -- eight
+// distinct slots for those eight rows, 256 B per pass -- applied on the DMA source address and on the read.
 //
 // Structure = conv_pp.hip: 8 waves, each 128x64 (or 64x96) of the 256x256 (or 128x384) output tile, a 4-deep LDS ring
 // filled by LDS-DMA through buffer descriptors three K tiles ahead (counted vmcnt), the two waves of a SIMD alternating
@@ -56,7 +59,7 @@ template <int GA, int GB, int WM, int WN>
 __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int TM = GA * 128, TN = GB * 128;
-  constexpr int BM = TM / WM / 32, BN = TN / WN / 32;
+  constexpr int BM = TM / WM / 16, BN = TN / WN / 16;  // 16 x 16 output blocks per wave
   constexpr int SUB = 32 * 256;  // bytes of one [32 px][128 ch] sub-tile
   constexpr int SLOT = (GA + GB) * SUB;
   constexpr int NBUF = 4, PF = 3;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   for (int p = 0; p < NPA; p++) {
     const int pb = wave * NPA + p;
     const int sub = pb >> 3, row = (pb & 7) * 4 + (lane >> 4);
-    const int clog = ((((cphys >> 2) ^ (row & 3)) << 2) | (cphys & 3)) * 8;
+    const int clog = ((((cphys >> 1) ^ (((row & 3) << 1) | ((row >> 3) & 1))) << 1) | (cphys & 1)) * 8;
     const int co = co0 + sub * 128 + clog;
     voffA[p] = co < a.Cout ? (unsigned)(row * a.Cout + co) * 2u : SENT;
   }
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   for (int p = 0; p < NPB; p++) {
     const int pb = wave * NPB + p;
     const int sub = pb >> 3, row = (pb & 7) * 4 + (lane >> 4);
-    const int clog = ((((cphys >> 2) ^ (row & 3)) << 2) | (cphys & 3)) * 8;
+    const int clog = ((((cphys >> 1) ^ (((row & 3) << 1) | ((row >> 3) & 1))) << 1) | (cphys & 1)) * 8;
     const int g = g0 + sub;
     const int tap = uni(g / a.gpt), ci = (g - tap * a.gpt) * 128 + clog;
     const bool ok = g < a.ngroups;
@@ -124,20 +127,21 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     voffBR[p] = (ok && row != 31) ? v : SENT;
   }
 
-  // ---- fragment read addresses (bytes inside a slot): one per 32-row block, (kk, h) are immediates --------------------------
-  const int g16 = (lane >> 4) & 1, kq = lane >> 5, rr = (lane & 15) >> 2, qq = lane & 3;
+  // ---- fragment read addresses (bytes inside a slot): one per 16-channel block; the second half (+4 pixel rows) is an immediate ------------
+  const int G = lane >> 4, rr = (lane & 15) >> 2, qq = lane & 3;
+  const int fkey = (rr << 1) | (G & 1);  // swizzle key of pixel rows 8 G + rr and 8 G + rr + 4
   int aoff[BM], boff[BN];
 #pragma unroll
   for (int i = 0; i < BM; i++) {
-    const int ch = wm * (TM / WM) + i * 32 + 16 * g16 + 4 * qq;  // channel inside the TM-wide operand
+    const int ch = wm * (TM / WM) + i * 16 + 4 * qq;  // channel inside the TM-wide operand
     const int sub = ch >> 7, c = ch & 127;
-    aoff[i] = sub * SUB + (kq * 8 + rr) * 256 + ((((c >> 5) ^ rr)) << 6) + (c & 31) * 2;
+    aoff[i] = sub * SUB + (G * 8 + rr) * 256 + ((((c >> 4) & 7) ^ fkey) << 5) + (c & 15) * 2;
   }
 #pragma unroll
   for (int j = 0; j < BN; j++) {
-    const int ch = wn * (TN / WN) + j * 32 + 16 * g16 + 4 * qq;
+    const int ch = wn * (TN / WN) + j * 16 + 4 * qq;
     const int sub = ch >> 7, c = ch & 127;
-    boff[j] = GA * SUB + sub * SUB + (kq * 8 + rr) * 256 + ((((c >> 5) ^ rr)) << 6) + (c & 31) * 2;
+    boff[j] = GA * SUB + sub * SUB + (G * 8 + rr) * 256 + ((((c >> 4) & 7) ^ fkey) << 5) + (c & 15) * 2;
   }
 
   // Bias gradient (column sums of dy) rides along on the matrix pipe: dy fragment x all-ones fragment, in the wave whose N
@@ -145,22 +149,24 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   // block does 1/ntiles of it (one block doing all of it would set the critical path of a single-round launch) -- instead of
   // a second 2 B/elem pass over dy.
   const int my_nt = tile - mt * a.ntiles;
-  const bool do_bias = a.bslab != nullptr && wn < BM;
+  const bool do_bias = a.bslab != nullptr && 2 * wn < BM;  // wave (wm, wn) sums cout blocks 2 wn and 2 wn + 1 of its row
   int bias_cnt = my_nt;
-  f32x16 accb;
+  f32x4 accb[2];
 #pragma unroll
-  for (int r = 0; r < 16; r++) accb[r] = 0.f;
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) accb[h][r] = 0.f;
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; e++) ones[e] = (bf16)1.0f;
 
-  f32x16 acc[BM][BN];
+  f32x4 acc[BM][BN];  // acc[i][j][r]: cout block i, row 4 * (lane >> 4) + r; column block j, column lane & 15
 #pragma unroll
   for (int i = 0; i < BM; i++)
 #pragma unroll
     for (int j = 0; j < BN; j++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 4; r++) acc[i][j][r] = 0.f;
 
   // ---- DMA issue state: tile `it` starts at pixel pt = (n, y, x0), all wave-uniform -----------------------------------------
   int it = 0;
@@ -214,23 +220,20 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   if (grp == 1) __builtin_amdgcn_s_barrier();
 
   union Frag { bf16x8 v; s16x4 h[2]; };
-  Frag af[2][BM], bfr[2][BN];
+  Frag af[BM], bfr[BN];
   int slot_rd = 0, slot_wr = PF * SLOT;
 #pragma unroll 1
   for (int t = 0; t < nK; t++) {
     const char* sb = smem + slot_rd;
 #pragma unroll
-    for (int kk = 0; kk < 2; kk++) {
+    for (int j = 0; j < BN; j++) {
+      bfr[j].h[0] = tr_read(sb + boff[j]);
+      bfr[j].h[1] = tr_read(sb + boff[j] + 1024);
+    }
 #pragma unroll
-      for (int j = 0; j < BN; j++) {
-        bfr[kk][j].h[0] = tr_read(sb + boff[j] + kk * 4096);
-        bfr[kk][j].h[1] = tr_read(sb + boff[j] + kk * 4096 + 1024);
-      }
-#pragma unroll
-      for (int i = 0; i < BM; i++) {
-        af[kk][i].h[0] = tr_read(sb + aoff[i] + kk * 4096);
-        af[kk][i].h[1] = tr_read(sb + aoff[i] + kk * 4096 + 1024);
-      }
+    for (int i = 0; i < BM; i++) {
+      af[i].h[0] = tr_read(sb + aoff[i]);
+      af[i].h[1] = tr_read(sb + aoff[i] + 1024);
     }
     issue(slot_wr);
     slot_rd = slot_rd + SLOT == NBUF * SLOT ? 0 : slot_rd + SLOT;
@@ -242,22 +245,18 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int kk = 0; kk < 2; kk++)
+    for (int i = 0; i < BM; i++)
 #pragma unroll
-      for (int i = 0; i < BM; i++)
-#pragma unroll
-        for (int j = 0; j < BN; j++)
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[kk][i].v), "v"(bfr[kk][j].v));
+      for (int j = 0; j < BN; j++)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[i].v), "v"(bfr[j].v));
     const bool bias_now = do_bias && bias_cnt == 0;
     bias_cnt = bias_cnt == 0 ? a.ntiles - 1 : bias_cnt - 1;
     if (bias_now) {
 #pragma unroll
-      for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-        for (int i = 0; i < BM; i++)
-          if (i == wn)  // accumulator pinned to VGPRs ("+v"): the 128 AGPRs of the main accumulators are left exactly as they are
-            // s_nop: the compiler rematerialises `ones` with v_mov right before the statement and pads nothing for inline asm
-            asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accb) : "v"(af[kk][i].v), "v"(ones));
+      for (int i = 0; i < BM; i++)
+        if ((i >> 1) == wn)  // accumulator pinned to VGPRs ("+v"): the AGPRs of the main accumulators are left exactly as they are
+          // s_nop: the compiler rematerialises `ones` with v_mov right before the statement and pads nothing for inline asm
+          asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accb[i & 1]) : "v"(af[i].v), "v"(ones));
     }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -268,26 +267,28 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   wait_vmcnt<0>();
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
-  if (do_bias && (lane & 31) == 0) {  // every column of accb holds the same sums: column 0 lives in lanes 0 and 32
+  if (do_bias && (lane & 15) == 0) {  // every column of accb holds the same sums: column 0 lives in lanes 0, 16, 32, 48
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int co = co0 + wm * (TM / WM) + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
-      if (co < a.Cout) a.bslab[((size_t)split * a.ntiles + my_nt) * a.Cout + co] = accb[r];
-    }
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int co = co0 + wm * (TM / WM) + (2 * wn + h) * 16 + 4 * G + r;
+        if (co < a.Cout) a.bslab[((size_t)split * a.ntiles + my_nt) * a.Cout + co] = accb[h][r];
+      }
   }
-  // ---- slab store: lane owns column (l & 31) of each N block, 16 couts per accumulator ------------------------------------------
+  // ---- slab store: lane owns column (l & 15) of each N block, 4 couts per accumulator ---------------------------------------------
   float* slab = a.slab + (size_t)split * a.Cout * T * a.Cin;
 #pragma unroll
   for (int j = 0; j < BN; j++) {
-    const int nn = wn * (TN / WN) + j * 32 + (lane & 31);  // column inside the block's TN
+    const int nn = wn * (TN / WN) + j * 16 + (lane & 15);  // column inside the block's TN
     const int g = g0 + (nn >> 7);
     if (g >= a.ngroups) continue;
     const int tap = g / a.gpt, ci = (g - tap * a.gpt) * 128 + (nn & 127);
 #pragma unroll
     for (int i = 0; i < BM; i++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int co = co0 + wm * (TM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+      for (int r = 0; r < 4; r++) {
+        const int co = co0 + wm * (TM / WM) + i * 16 + 4 * G + r;
         if (co < a.Cout) slab[((size_t)co * T + tap) * a.Cin + ci] = acc[i][j][r];
       }
   }
