@@ -182,10 +182,27 @@ __global__ void tn_reduce_kernel(const float* __restrict__ slab, OutT* __restric
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int splits, int Cout, int T,
-                                    int Cin, int accumulate) {
+// Blocks [0, rb) reduce the weight slabs; blocks [rb, gridDim.x), present when the ping-pong kernel left per-split column sums of dy behind the
+// slabs, do colsum_final_kernel's work (same summation order, bit-identical) -- one launch instead of two per weight gradient.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int splits, int Cout, int T,
+                                                           int Cin, int accumulate, int rb, const float* __restrict__ bpart,
+                                                           float* __restrict__ dbias, int nparts) {
+  if ((int)blockIdx.x >= rb) {
+    __shared__ float sh[4][64];
+    const int c = ((int)blockIdx.x - rb) * 64 + (threadIdx.x & 63), kl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < Cout)
+      for (int k = kl; k < nparts; k += 4) s += bpart[(size_t)k * Cout + c];
+    sh[kl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (kl == 0 && c < Cout) {
+      const float t = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+      dbias[c] = accumulate ? dbias[c] + t : t;
+    }
+    return;
+  }
   const size_t total = (size_t)Cout * T * Cin;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)rb * blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < splits; k++) s += slab[(size_t)k * total + i];
     const int ci = i % Cin;
@@ -317,13 +334,11 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
   }
   const size_t total = (size_t)w.Cout * T * w.Cin;
   int rb = (int)((total + 255) / 256); if (rb > 2048) rb = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, w.slab, (float*)dw, splits, w.Cout, T, w.Cin, accumulate);
+  const int nb = bias_fused ? (w.Cout + 63) / 64 : 0;  // the ping-pong kernel left per-split column sums of dy behind the weight slabs
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb + nb), dim3(256), 0, stream, w.slab, (float*)dw, splits, w.Cout, T, w.Cin, accumulate, rb,
+                     w.slab + (size_t)splits * total, (float*)dbias, splits * pp_ntiles);
   DMVAE_CHECK_LAUNCH();
-  if (bias_fused) {  // the ping-pong kernel left per-split column sums of dy behind the weight slabs
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((w.Cout + 63) / 64), dim3(256), 0, stream, w.slab + (size_t)splits * total, (float*)dbias,
-                       splits * pp_ntiles, w.Cout, accumulate);
-    DMVAE_CHECK_LAUNCH();
-  } else if (dbias) {
+  if (!bias_fused && dbias) {
     float* part = w.slab + (size_t)splits * total;
     int tp = 1, tps = 0;
     while (tp < 64 && tp * 8 < w.Cout) { tp <<= 1; tps++; }
