@@ -37,8 +37,8 @@ def init_distributed_mode(backend: Optional[str] = None, timeout_minutes: int = 
     use_gpu = torch.cuda.is_available()
     if use_gpu:
         torch.cuda.set_device(_local_rank % torch.cuda.device_count())
-    if backend is None:
-        backend = "nccl" if use_gpu else "gloo"
+    if backend is None:       # DMVAE_DIST_BACKEND=gloo: diagnostics (several ranks sharing one GPU, which RCCL refuses)
+        backend = os.environ.get("DMVAE_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
     if not tdist.is_initialized():
         kw = {}
         if use_gpu and backend == "nccl":
