@@ -16,6 +16,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # this pool's host driver only supports dmabuf IPC; RCCL needs it for N > 1 (already exported on the GPU boxes)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
