@@ -106,6 +106,8 @@ class FlatGradSync:
         self._pending = [b[2] for b in self.buckets]
         self._works = []
         self._handles = []
+        self.hook_launches = 0      # buckets whose all-reduce was started from a gradient hook, i.e. DURING backward, in the last step
+        self._in_wait = False
         if self.enabled:
             for i, p in enumerate(params):
                 self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -119,6 +121,8 @@ class FlatGradSync:
         return hook
 
     def _launch(self, b):
+        if not self._in_wait:
+            self.hook_launches += 1
         s, e, _ = self.buckets[b]
         sl = self.flat_grad[s:e]
         sl.div_(self.world)
@@ -128,13 +132,16 @@ class FlatGradSync:
         """Block the current stream until every bucket's all-reduce has completed; re-arm for the next backward."""
         if not self.enabled:
             return
+        self._in_wait = True
         for b, left in enumerate(self._pending):      # parameters that received no gradient this step
             if left > 0:
                 self._launch(b)
+        self._in_wait = False
         for w in self._works:
             w.wait()
         self._works.clear()
         self._pending = [b[2] for b in self.buckets]
+        self.last_hook_launches, self.hook_launches = self.hook_launches, 0
 
     def remove(self):
         for h in self._handles:

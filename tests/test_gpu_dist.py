@@ -54,6 +54,9 @@ def _worker(rank, world, port, q):
         assert not torch.equal(both[0], both[1])           # the ranks really saw different images
         ref = both[0] / world + both[1] / world
         err = ((tr.fp.grad - ref).abs().max() / ref.abs().max()).item()
+        # every bucket was started from a gradient hook, i.e. while backward was still running (the direct flat-buffer gradient writes still go through
+        # AccumulateGrad, so the post-accumulate hooks fire); nothing was left for wait() to launch
+        assert tr.sync.last_hook_launches == len(tr.sync.buckets), (tr.sync.last_hook_launches, len(tr.sync.buckets))
         for _ in range(3):                                  # lr warm-up: the weights move from the second step on
             tr.step(x)
         flats = [torch.empty_like(tr.fp.flat) for _ in range(world)]
