@@ -39,6 +39,26 @@ def _gn(c):
     return nn.GroupNorm(num_groups=32, num_channels=c, eps=1e-6, affine=True)
 
 
+def _mid_stage(c: int) -> nn.Module:
+    """ResnetBlock -> AttnBlock -> ResnetBlock at constant width (registered as block_1 / attn_1 / block_2, the checkpoint's names)."""
+    stage = nn.Module()
+    stage.block_1 = ResnetBlock(c, c)
+    stage.attn_1 = AttnBlock(c)
+    stage.block_2 = ResnetBlock(c, c)
+    return stage
+
+
+def _level(c_in: int, c_out: int, n_blocks: int, resample=None, resample_name: str = "") -> nn.Module:
+    """One resolution level: `n_blocks` ResnetBlocks (the first one changes the width), an `attn` list the reference registers but never fills, and
+    optionally the level's resampling module, registered last under `resample_name`."""
+    lvl = nn.Module()
+    lvl.block = nn.ModuleList(ResnetBlock(c_in if i == 0 else c_out, c_out) for i in range(n_blocks))
+    lvl.attn = nn.ModuleList()
+    if resample is not None:
+        setattr(lvl, resample_name, resample(c_out))
+    return lvl
+
+
 class _NCHWAdapter(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         return Fn.to_nchw(self.forward_nhwc(Fn.to_nhwc_bf16(x)), x.dtype if x.dtype != torch.float64 else torch.float32)
@@ -112,38 +132,17 @@ class _Conv3x3(nn.Conv2d):
 class Encoder(nn.Module):
     def __init__(self, resolution: int, in_channels: int, ch: int, ch_mult: list, num_res_blocks: int, z_channels: int):
         super().__init__()
-        self.ch = ch
-        self.num_resolutions = len(ch_mult)
-        self.num_res_blocks = num_res_blocks
-        self.resolution = resolution
-        self.in_channels = in_channels
-        self.conv_in = _Conv3x3(in_channels, self.ch, kernel_size=3, stride=1, padding=1)
-        curr_res = resolution
-        in_ch_mult = (1,) + tuple(ch_mult)
-        self.in_ch_mult = in_ch_mult
-        self.down = nn.ModuleList()
-        block_in = self.ch
-        for i_level in range(self.num_resolutions):
-            block = nn.ModuleList()
-            attn = nn.ModuleList()
-            block_in = ch * in_ch_mult[i_level]
-            block_out = ch * ch_mult[i_level]
-            for _ in range(self.num_res_blocks):
-                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out))
-                block_in = block_out
-            down = nn.Module()
-            down.block = block
-            down.attn = attn
-            if i_level != self.num_resolutions - 1:
-                down.downsample = Downsample(block_in)
-                curr_res = curr_res // 2
-            self.down.append(down)
-        self.mid = nn.Module()
-        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in)
-        self.mid.attn_1 = AttnBlock(block_in)
-        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in)
-        self.norm_out = _gn(block_in)
-        self.conv_out = _Conv3x3(block_in, z_channels * 2, kernel_size=3, stride=1, padding=1)
+        self.ch, self.resolution, self.in_channels = ch, resolution, in_channels
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        self.in_ch_mult = (1,) + tuple(ch_mult)
+        widths = [ch * m for m in self.in_ch_mult]          # widths[i] -> widths[i + 1] across level i
+        last = self.num_resolutions - 1
+        self.conv_in = _Conv3x3(in_channels, ch, kernel_size=3, stride=1, padding=1)
+        self.down = nn.ModuleList(
+            _level(widths[i], widths[i + 1], num_res_blocks, Downsample if i != last else None, "downsample") for i in range(self.num_resolutions))
+        self.mid = _mid_stage(widths[-1])
+        self.norm_out = _gn(widths[-1])
+        self.conv_out = _Conv3x3(widths[-1], 2 * z_channels, kernel_size=3, stride=1, padding=1)
 
     def forward(self, x: Tensor) -> Tensor:
         """Reference :160-181 (downsampling stack -> mid -> norm_out/swish/conv_out), NCHW in, NCHW [B, 2*z, H/2^(L-1), W/2^(L-1)] out."""
@@ -168,38 +167,21 @@ class Encoder(nn.Module):
 class Decoder(nn.Module):
     def __init__(self, ch: int, out_ch: int, ch_mult: list, num_res_blocks: int, in_channels: int, resolution: int, z_channels: int):
         super().__init__()
-        self.ch = ch
-        self.num_resolutions = len(ch_mult)
-        self.num_res_blocks = num_res_blocks
-        self.resolution = resolution
-        self.in_channels = in_channels
-        self.ffactor = 2 ** (self.num_resolutions - 1)
-        block_in = ch * ch_mult[self.num_resolutions - 1]
-        self.block_in = block_in
-        curr_res = resolution // 2 ** (self.num_resolutions - 1)
-        self.z_shape = (1, z_channels, curr_res, curr_res)
-        self.conv_in = _Conv3x3(z_channels, block_in, kernel_size=3, stride=1, padding=1)
-        self.mid = nn.Module()
-        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in)
-        self.mid.attn_1 = AttnBlock(block_in)
-        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in)
-        self.up = nn.ModuleList()
-        for i_level in reversed(range(self.num_resolutions)):
-            block = nn.ModuleList()
-            attn = nn.ModuleList()
-            block_out = ch * ch_mult[i_level]
-            for _ in range(self.num_res_blocks + 1):
-                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out))
-                block_in = block_out
-            up = nn.Module()
-            up.block = block
-            up.attn = attn
-            if i_level != 0:
-                up.upsample = Upsample(block_in)
-                curr_res = curr_res * 2
-            self.up.insert(0, up)
-        self.norm_out = _gn(block_in)
-        self.conv_out = nn.Conv2d(block_in, out_ch, kernel_size=3, stride=1, padding=1)
+        self.ch, self.resolution, self.in_channels = ch, resolution, in_channels
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        top = self.num_resolutions - 1
+        self.ffactor = 1 << top
+        widths = [ch * m for m in ch_mult]                  # level i runs at widths[i]; it is entered from level i + 1 (the top level from `block_in`)
+        self.block_in = widths[top]
+        low_res = resolution // self.ffactor
+        self.z_shape = (1, z_channels, low_res, low_res)
+        self.conv_in = _Conv3x3(z_channels, self.block_in, kernel_size=3, stride=1, padding=1)
+        self.mid = _mid_stage(self.block_in)
+        # `up[i]` is level i of the checkpoint (the reference builds top-down and inserts at the front; the registration order is the same)
+        self.up = nn.ModuleList(
+            _level(widths[min(i + 1, top)], widths[i], num_res_blocks + 1, Upsample if i != 0 else None, "upsample") for i in range(self.num_resolutions))
+        self.norm_out = _gn(widths[0])
+        self.conv_out = nn.Conv2d(widths[0], out_ch, kernel_size=3, stride=1, padding=1)
 
     def forward(self, z: Tensor, grad_ckpt=False) -> Tensor:
         """z: [B, 256, C] tokens (the reference hard-codes the 16x16 grid, :244-245) or NCHW [B, C, h, w].
