@@ -18,7 +18,7 @@ import torch
 import torch.distributed as tdist
 
 __all__ = ["init_distributed_mode", "initialized", "get_rank", "get_world_size", "get_local_rank", "barrier", "allreduce",
-           "is_master", "FlatGradSync"]
+           "is_master", "FlatGradSync", "broadcast_tensors", "broadcast_module_state", "require_initialized"]
 
 _initialized = False
 _rank, _world, _local_rank = 0, 1, 0
@@ -78,6 +78,76 @@ def allreduce(t: torch.Tensor, async_op: bool = False, op=None):
     return None
 
 
+def require_initialized(what: str) -> None:
+    """A launcher exported WORLD_SIZE > 1 but `init_distributed_mode()` has not run: anything that latches "is this job distributed?" at
+    construction time (FlatGradSync, the trainers' initial broadcast) would silently train every rank on its own gradients.  Fail loudly."""
+    if not _initialized and int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ:
+        raise RuntimeError(f"{what}: WORLD_SIZE={os.environ['WORLD_SIZE']} but dmvae_amd.dist.init_distributed_mode() has not been called; "
+                           "call it before building models / trainers (gradients would not be synchronised)")
+
+
+def broadcast_tensors(tensors: Sequence[torch.Tensor], src: int = 0, chunk_bytes: int = 256 << 20) -> int:
+    """Rank `src`'s values of `tensors` -> every rank, in place.  Small tensors are coalesced per dtype into staging buffers of at most
+    `chunk_bytes` (one collective per ~256 MB instead of one per tensor: xGMI links are per-message bound); a tensor that is already large and
+    contiguous is broadcast as it is.  Returns the number of collectives issued (0 when the job is not distributed)."""
+    if not _initialized or _world <= 1:
+        return 0
+    calls = 0
+    by_dtype = {}
+    for t in tensors:
+        if t.numel() == 0:
+            continue
+        if t.is_contiguous() and t.numel() * t.element_size() >= chunk_bytes // 4:
+            tdist.broadcast(t, src=src)
+            calls += 1
+        else:
+            by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, device), group in by_dtype.items():
+        i = 0
+        while i < len(group):
+            j, n = i, 0
+            while j < len(group) and (j == i or (n + group[j].numel()) * group[j].element_size() <= chunk_bytes):
+                n += group[j].numel()
+                j += 1
+            stage = torch.empty(n, dtype=dtype, device=device)
+            o = 0
+            for t in group[i:j]:
+                stage[o:o + t.numel()].copy_(t.detach().reshape(-1))
+                o += t.numel()
+            tdist.broadcast(stage, src=src)
+            calls += 1
+            o = 0
+            with torch.no_grad():
+                for t in group[i:j]:
+                    t.copy_(stage[o:o + t.numel()].view(t.shape))
+                    o += t.numel()
+            i = j
+    return calls
+
+
+def broadcast_module_state(*modules, extra: Sequence[torch.Tensor] = (), src: int = 0) -> int:
+    """What DistributedDataParallel's constructor does for the reference (train_tokenizer.py:302,319; train_dmd.py:348,355: `_sync_module_states`
+    over every parameter AND buffer of the wrapped module, trainable or not): after it every rank holds rank 0's weights, BatchNorm running
+    statistics included, whatever each rank's RNG produced at construction.  `extra`: optimiser / EMA state kept outside the modules.
+    Tensors that alias each other (parameters re-homed as views of a flat buffer) are sent once."""
+    seen, todo = set(), []
+    for t in extra:
+        if t is not None and t.data_ptr() not in seen:
+            seen.add(t.data_ptr())
+            todo.append(t)
+    covered = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in todo]
+    for m in modules:
+        if m is None:
+            continue
+        for t in list(m.parameters()) + list(m.buffers()):
+            a = t.data_ptr()
+            if a in seen or any(lo <= a < hi for lo, hi in covered):
+                continue
+            seen.add(a)
+            todo.append(t.data if isinstance(t, torch.nn.Parameter) else t)
+    return broadcast_tensors(todo, src=src)
+
+
 class FlatGradSync:
     """Bucketed asynchronous gradient averaging over a flat gradient buffer.
 
@@ -90,6 +160,7 @@ class FlatGradSync:
 
     def __init__(self, params: Sequence[torch.nn.Parameter], flat_grad: torch.Tensor, offsets: Sequence[int],
                  bucket_bytes: int = 64 << 20):
+        require_initialized("FlatGradSync")
         self.flat_grad = flat_grad
         self.world = get_world_size()
         self.enabled = initialized() and (self.world > 1 or os.environ.get("DMVAE_FORCE_DIST", "0") != "0")

@@ -73,6 +73,17 @@ class FlatParams:
         else:
             self.zero_grad()
 
+    def after_external_update(self, reset_ema: bool = False) -> None:
+        """The flat buffer was written by something other than the fused optimiser step (initial broadcast from rank 0, checkpoint load):
+        invalidate the cached bf16 / packed operands of these parameters, refresh the bf16 shadow, optionally restart the EMA from the weights."""
+        self.epoch[0] += 1
+        if getattr(self, "shadow", None) is not None:
+            self.shadow.copy_(self.flat)
+            for p in self.params:
+                p._dmvae_shadow_ver = (p.data_ptr(), p._version)
+        if reset_ema and self.ema is not None:
+            self.ema.copy_(self.flat)
+
     def ema_state(self):
         """name-less list of EMA tensors aligned with self.params (views)."""
         return [self.ema[off:off + p.numel()].view(p.shape) for p, off in zip(self.params, self.offsets)]

@@ -77,6 +77,9 @@ class TokenizerTrainer:
             self.dopt = FlatAdamWEMA(self.dfp, lr=disc_lr, weight_decay=disc_wd, max_norm=max_norm,
                                      warmup_steps=warmup_steps if disc_warmup_steps is None else disc_warmup_steps)
             self.dlog = torch.zeros(8, dtype=torch.float32, device=self.dfp.flat.device)
+            # discriminator gradients (train_tokenizer.py:319: its own DDP wrapper): bucketed asynchronous all-reduce from the gradient hooks like the
+            # VAE's; FlatParams holds them in forward order, backward completes them last-to-first, so the buckets fill back to front
+            self.dsync = dist.FlatGradSync(self.dfp.params, self.dfp.grad, self.dfp.offsets, bucket_bytes=min(bucket_bytes, 4 << 20))
         self.w = dict(l1=l1, l2=l2, lpips=lpips_w, kl=kl_w, mmd=mmd_w)
         vae.encoder.eval()
         for p in vae.encoder.parameters():                 # train_tokenizer.py:295-297
@@ -90,7 +93,22 @@ class TokenizerTrainer:
         self.sync = dist.FlatGradSync(params, self.fp.grad, self.fp.offsets, bucket_bytes=bucket_bytes)
         self.log = torch.zeros(8, dtype=torch.float32, device=self.fp.flat.device)
         self.global_step = 0
+        self.sync_initial_state()
         self.refresh_frozen_shadows()
+
+    def sync_initial_state(self) -> int:
+        """DistributedDataParallel's constructor-time broadcast (train_tokenizer.py:302,319): every rank starts from rank 0's parameters and buffers
+        (frozen encoder, LPIPS, BatchNorm running statistics included) and from rank 0's EMA / optimiser state, whatever seed each rank built its
+        modules with.  No-op on a single rank.  Returns the number of collectives."""
+        extra = [self.fp.flat, self.fp.ema, self.opt.exp_avg, self.opt.exp_avg_sq]
+        if self.disc is not None:
+            extra += [self.dfp.flat, self.dopt.exp_avg, self.dopt.exp_avg_sq]
+        n = dist.broadcast_module_state(self.vae, self.lpips, self.disc, extra=extra)
+        if n:
+            self.fp.after_external_update()
+            if self.disc is not None:
+                self.dfp.after_external_update()
+        return n
 
     def refresh_frozen_shadows(self) -> None:
         """(Re)build the bf16 shadows of the frozen encoder and LPIPS trunk; call after loading new weights into them."""
@@ -154,9 +172,7 @@ class TokenizerTrainer:
         self.dfp.begin_step()
         d_total, log = losses.discriminator_loss(images, recon, self.disc, self.daug, self.bcr_strong_aug, self.bcr_weight)
         d_total.backward()
-        if dist.initialized() and dist.get_world_size() > 1:
-            self.dfp.grad.div_(dist.get_world_size())
-            dist.allreduce(self.dfp.grad)
+        self.dsync.wait()
         dnorm = self.dopt.step()
         with torch.no_grad():
             self.dlog[0], self.dlog[1], self.dlog[2], self.dlog[3] = log["d_loss"], log["bcr_loss"], log["acc_real"], log["acc_fake"]
@@ -250,8 +266,24 @@ class DMDTrainer:
             if isinstance(student, LightningDiT) and direct:
                 self.sfp.enable_direct_grads(only=direct)
             self.sopt = FlatAdamWEMA(self.sfp, lr=diff_lr, weight_decay=wd, warmup_steps=warmup_steps, max_norm=max_norm)
+            # train_dmd.py:355: the student's DDP wrapper -- 2.7 GB of gradients, bucketed and overlapped with its backward
+            self.ssync = dist.FlatGradSync(self.sfp.params, self.sfp.grad, self.sfp.offsets, bucket_bytes=bucket_bytes)
         self.log = torch.zeros(10, dtype=torch.float32, device=self.fp.flat.device)
         self.global_step = 0
+        self.sync_initial_state()
+
+    def sync_initial_state(self) -> int:
+        """DDP's constructor-time broadcast for vae_ddp / sit_ddp (train_dmd.py:348,355) plus the frozen teacher and LPIPS."""
+        extra = [self.fp.flat, self.opt.exp_avg, self.opt.exp_avg_sq]
+        if self.sfp is not None:
+            extra += [self.sfp.flat, self.sopt.exp_avg, self.sopt.exp_avg_sq]
+        mods = [m for m in (self.vae, self.lpips, self.teacher, self.student) if isinstance(m, torch.nn.Module)]
+        n = dist.broadcast_module_state(*mods, extra=extra)
+        if n:
+            self.fp.after_external_update()
+            if self.sfp is not None:
+                self.sfp.after_external_update()
+        return n
 
     def _sample(self, x1: torch.Tensor):
         """Transport.sample (transport.py:105-116): x0 on the device generator, t on the CPU generator, optional time shift."""
@@ -331,9 +363,7 @@ class DMDTrainer:
                 out = self.student(xt, t, labels)
                 sloss = ((out.float() - ut) ** 2).flatten(1).mean(1).mean()
             sloss.backward()
-            if dist.initialized() and dist.get_world_size() > 1:
-                self.sfp.grad.div_(dist.get_world_size())
-                dist.allreduce(self.sfp.grad)
+            self.ssync.wait()
             snorm = self.sopt.step()
             with torch.no_grad():
                 self.log[7], self.log[8] = sloss.detach(), snorm[0]
@@ -375,8 +405,11 @@ class DiffusionTrainer:
         if isinstance(model, LightningDiT) and direct:
             self.fp.enable_direct_grads(only=direct)
         self.opt = FlatAdamWEMA(self.fp, lr=lr, betas=(0.9, 0.95), weight_decay=0.0, warmup_steps=0, max_norm=max_norm, ema_decay=ema_decay)
+        self.sync = dist.FlatGradSync(self.fp.params, self.fp.grad, self.fp.offsets, bucket_bytes=bucket_bytes)      # train_diffusion.py:215 (DDP)
         self.log = torch.zeros(2, dtype=torch.float32, device=self.fp.flat.device)
         self.train_steps = 0
+        if dist.broadcast_module_state(self.model, self.vae, extra=[self.fp.flat, self.fp.ema, self.opt.exp_avg, self.opt.exp_avg_sq]):
+            self.fp.after_external_update()
 
     def latents(self, images: torch.Tensor) -> torch.Tensor:
         """train_diffusion.py:276-287."""
@@ -393,9 +426,7 @@ class DiffusionTrainer:
             _, terms = self.transport.training_losses(self.model, x, dict(y=labels))
         loss = terms["loss"].mean().float()
         loss.backward()
-        if dist.initialized() and dist.get_world_size() > 1:
-            self.fp.grad.div_(dist.get_world_size())
-            dist.allreduce(self.fp.grad)
+        self.sync.wait()
         norm = self.opt.step()
         with torch.no_grad():
             self.log[0], self.log[1] = loss.detach(), norm[0]

@@ -67,6 +67,7 @@ def make_disc(seed):
 def main():
     cg.install_stubs()
     torch.set_grad_enabled(True)
+    torch.manual_seed(4321)          # DiffAug draws from the GLOBAL generator (utils/diffaug.py:74-113): seed it so the capture is reproducible
     g = torch.Generator().manual_seed(4321)
 
     # ---- PatchGAN: eval-mode logits, then one training forward + backward ---------------------------------------------------

@@ -105,3 +105,76 @@ def test_sync_batchnorm_statistics_two_ranks_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _bcast_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from dmvae_amd import dist
+    from dmvae_amd.optim import FlatParams
+    # built BEFORE init_distributed_mode(): must refuse instead of silently training unsynchronised
+    torch.manual_seed(1000 + rank)                       # every rank builds DIFFERENT weights
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.BatchNorm1d(32), torch.nn.Linear(32, 4))
+    frozen = torch.nn.Linear(5, 5).requires_grad_(False)
+    net[1].running_mean.add_(rank + 1.0)
+    refused = False
+    try:
+        fp0 = FlatParams(list(net.parameters()), with_ema=True)
+        dist.FlatGradSync(fp0.params, fp0.grad, fp0.offsets)
+    except RuntimeError as e:
+        refused = "init_distributed_mode" in str(e)
+    dist.init_distributed_mode(backend="gloo")
+    fp = FlatParams(list(net.parameters()), with_ema=True)
+    extra_state = torch.full((7,), float(rank + 3))
+    n = dist.broadcast_module_state(net, frozen, extra=[fp.flat, fp.ema, extra_state])
+    fp.after_external_update()
+    # after the broadcast every rank holds rank 0's values: gather and compare bit for bit
+    mine = torch.cat([fp.flat, fp.ema, extra_state, net[1].running_mean, net[1].running_var, frozen.weight.reshape(-1), frozen.bias,
+                      torch.cat([p.detach().reshape(-1) for p in net.parameters()])])
+    both = [torch.empty_like(mine) for _ in range(world)]
+    torch.distributed.all_gather(both, mine)
+    same = all(torch.equal(both[0], b) for b in both)
+    torch.manual_seed(1000)                              # rank 0's construction
+    ref = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.BatchNorm1d(32), torch.nn.Linear(32, 4))
+    is_rank0 = all(torch.equal(a.detach(), b.detach()) for a, b in zip(net.parameters(), ref.parameters())) and \
+        torch.equal(net[1].running_mean, torch.ones(32)) and torch.equal(extra_state, torch.full((7,), 3.0))
+    # parameters are still views of the flat buffer (the broadcast wrote through them, it did not re-home them)
+    views = all(p.data_ptr() == fp.flat.data_ptr() + 4 * off for p, off in zip(fp.params, fp.offsets))
+    dist.barrier()
+    q.put((rank, refused and same and is_rank0 and views and n >= 1))
+    torch.distributed.destroy_process_group()
+
+
+def test_initial_state_broadcast_and_refusal_two_ranks_gloo():
+    """DDP's constructor-time broadcast (reference train_tokenizer.py:302,319): ranks that built their modules from different seeds hold rank 0's
+    parameters, buffers, EMA and extra optimiser state afterwards; FlatGradSync built under WORLD_SIZE > 1 before init_distributed_mode() raises."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_asked():
+    """`python bench.py --gpus 2` started plainly must launch its own ranks or fail loudly -- never print an n_gpus: 1 line (round-1 verdict).  This
+    container has no GPU, so it has to refuse; on a 1-GPU box the same holds (tests/test_gpu_dist.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this node really has two GPUs")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2" in r.stderr and "GPU(s)" in r.stderr
+    assert '"n_gpus"' not in r.stdout
+    # a launcher whose WORLD_SIZE disagrees with --gpus is refused too
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env2,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout) and '"n_gpus"' not in r.stdout

@@ -22,10 +22,10 @@ def _free_port():
     return port
 
 
-def _trainer(bucket_bytes):
+def _trainer(bucket_bytes, seed=5):
     from dmvae_amd.models.vae import VAE
     from dmvae_amd.train import TokenizerTrainer
-    torch.manual_seed(5)
+    torch.manual_seed(seed)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=64, depth=1, num_heads=2)).cuda()
@@ -39,9 +39,16 @@ def _worker(rank, world, port, q):
         from dmvae_amd import dist
         dist.init_distributed_mode(backend="gloo")
         assert dist.initialized() and dist.get_world_size() == world and torch.cuda.current_device() == 0
-        tr = _trainer(bucket_bytes=32 << 20)               # 200 MB of gradients: 7 buckets
+        # each rank builds its model from a DIFFERENT seed: the constructor-time broadcast (DDP's, train_tokenizer.py:302) must leave rank 0's
+        # weights, EMA and frozen-encoder parameters everywhere
+        tr = _trainer(bucket_bytes=32 << 20, seed=5 + 17 * rank)               # 200 MB of gradients: 7 buckets
         assert tr.sync.enabled and len(tr.sync.buckets) >= 4
-        local = _trainer(bucket_bytes=32 << 20)            # same weights, gradient sync switched off: this rank's own gradient
+        start = torch.cat([tr.fp.flat, tr.fp.ema, torch.cat([p.detach().reshape(-1) for p in tr.vae.encoder.parameters()])])
+        starts = [torch.empty_like(start) for _ in range(world)]
+        tdist.all_gather(starts, start)
+        assert torch.equal(starts[0], starts[1]), "initial broadcast did not equalise the ranks"
+        del start, starts
+        local = _trainer(bucket_bytes=32 << 20, seed=99 + rank)            # same weights after ITS broadcast; gradient sync switched off below: this rank's own gradient
         local.sync.remove()
         local.sync.enabled = False
         assert torch.equal(tr.fp.flat, local.fp.flat)
@@ -84,4 +91,79 @@ def test_tokenizer_trainer_two_ranks_share_one_gpu():
     for rank, err, same, tb in res:
         assert tb == "", tb
         assert err < 1e-6, (rank, err)      # (g0 / 2 + g1 / 2) in f32 on both sides
+        assert same, rank
+
+
+def test_bench_gpus_2_refused_or_run_on_this_box():
+    """`python bench.py --gpus 2` started plainly: on a 1-GPU box it must exit non-zero with a clear message (never an `n_gpus: 1` line); on a
+    node with >= 2 devices it launches two RCCL ranks itself and rank 0 prints `n_gpus: 2`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        out = json.loads(line)
+        assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and "world=2" in r.stderr
+    else:
+        assert r.returncode != 0
+        assert "--gpus 2" in r.stderr and "only 1 GPU" in r.stderr
+        assert '"n_gpus"' not in r.stdout
+
+
+def _rccl_worker(rank, world, port, q):
+    try:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as tdist
+        from dmvae_amd import dist
+        dist.init_distributed_mode()                       # backend "nccl" = RCCL, one device per rank
+        assert tdist.get_backend() == "nccl" and torch.cuda.current_device() == rank
+        tr = _trainer(bucket_bytes=32 << 20, seed=5 + 17 * rank)
+        local = _trainer(bucket_bytes=32 << 20, seed=99 + rank)
+        local.sync.remove()
+        local.sync.enabled = False
+        assert torch.equal(tr.fp.flat, local.fp.flat)
+        x = torch.rand(2, 3, 256, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(100 + rank)) * 2 - 1
+        tr.step(x)
+        local.step(x)
+        mine = local.fp.grad.clone()
+        both = [torch.empty_like(mine) for _ in range(world)]
+        tdist.all_gather(both, mine)
+        ref = both[0] / world + both[1] / world
+        err = ((tr.fp.grad - ref).abs().max() / ref.abs().max()).item()
+        hooks_ok = tr.sync.last_hook_launches == len(tr.sync.buckets)
+        for _ in range(3):
+            tr.step(x)
+        flats = [torch.empty_like(tr.fp.flat) for _ in range(world)]
+        tdist.all_gather(flats, tr.fp.flat)
+        same = torch.equal(flats[0], flats[1]) and hooks_ok
+        dist.barrier()
+        q.put((rank, err, same, ""))
+        tdist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, float("inf"), False, traceback.format_exc()[-1500:]))
+        raise e
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X on one node (RCCL over xGMI)")
+def test_tokenizer_trainer_two_gpus_rccl():
+    """The same step on TWO devices over RCCL: bucketed asynchronous all-reduce from the gradient hooks, ranks bit-identical afterwards."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    for rank, err, same, tb in res:
+        assert tb == "", tb
+        assert err < 1e-6, (rank, err)
         assert same, rank
