@@ -48,7 +48,7 @@ def _worker(rank, world, port, q):
         tdist.all_gather(starts, start)
         assert torch.equal(starts[0], starts[1]), "initial broadcast did not equalise the ranks"
         del start, starts
-        local = _trainer(bucket_bytes=32 << 20, seed=99 + rank)            # same weights after ITS broadcast; gradient sync switched off below: this rank's own gradient
+        local = _trainer(bucket_bytes=32 << 20, seed=5)            # rank 0 builds the same model again, the others receive it; gradient sync switched off below: this rank's own gradient
         local.sync.remove()
         local.sync.enabled = False
         assert torch.equal(tr.fp.flat, local.fp.flat)
@@ -124,7 +124,7 @@ def _rccl_worker(rank, world, port, q):
         dist.init_distributed_mode()                       # backend "nccl" = RCCL, one device per rank
         assert tdist.get_backend() == "nccl" and torch.cuda.current_device() == rank
         tr = _trainer(bucket_bytes=32 << 20, seed=5 + 17 * rank)
-        local = _trainer(bucket_bytes=32 << 20, seed=99 + rank)
+        local = _trainer(bucket_bytes=32 << 20, seed=5)
         local.sync.remove()
         local.sync.enabled = False
         assert torch.equal(tr.fp.flat, local.fp.flat)
