@@ -86,6 +86,19 @@ SIGNATURES = {
     "dmvae_groupnorm_bwd_reduce": (c_int, [c_void_p] * 9 + [c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_groupnorm_bwd_apply": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dmvae_conv2d_nhwc_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(ConvDesc), c_int, c_void_p]),
+    # fp32 parity mode (csrc/parity.hip)
+    "dmvae_split3_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_size_t, c_size_t, c_size_t, c_size_t, c_int, c_void_p]),
+    "dmvae_groupnorm_stats_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "dmvae_groupnorm_apply_f32": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "dmvae_groupnorm_f32_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "dmvae_groupnorm_bwd_f32": (c_int, [c_void_p] * 10 + [c_size_t] + [c_int] * 6 + [c_float, c_void_p]),
+    "dmvae_eltwise_f32": (c_int, [c_int] + [c_void_p] * 4 + [c_size_t, c_int, c_int, c_float, c_void_p]),
+    "dmvae_softmax_rows_fwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "dmvae_softmax_rows_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "dmvae_pool2x2_f32": (c_int, [c_int] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "dmvae_nchw_f32_to_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dmvae_lpips_diff_f32": (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "dmvae_layernorm_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p]),
 }
 
 _lib = None

@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from . import ops
+from . import ops, parity
 from .ops import bf16, f32
 
 _EPOCH = [0]   # bumped by optimisers that update weights through raw pointers
@@ -43,7 +43,7 @@ def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad
             w._dmvae_packed = cache
         except AttributeError:      # non-leaf views etc.: no caching
             pass
-    key = (for_dgrad, rows_pad, cols_pad, transposed)
+    key = (for_dgrad, rows_pad, cols_pad, transposed, parity.on())
     ver = (w.data_ptr(), w._version, -1 if frozen else _epoch_of(w))
     hit = cache.get(key)
     if hit is not None and hit[0] == ver:
@@ -373,7 +373,7 @@ class NormConvOutFn(torch.autograd.Function):
         cout = cw.shape[0]
         dyf = _c(dy.float())
         dyp = ops.nchw_to_nhwc_bf16(dyf, c_pad=32)                 # the input-gradient conv's reduction dimension: 32-channel K steps
-        if cout <= 8 and a.numel() // a.shape[-1] >= 16384 and os.environ.get("DMVAE_CONVOUT_IM2COL", "1") != "0":
+        if cout <= 8 and a.numel() // a.shape[-1] >= 16384 and os.environ.get("DMVAE_CONVOUT_IM2COL", "1") != "0" and not parity.on():
             # With 3 output channels a 128-row weight-gradient tile is 98 % padding (1.4 ms at B = 32).  Instead: im2col of the GRADIENT
             # (8 padded channels x 9 taps = 72 columns, col[q][t*8+co] = dy[q + off(t)][co]) and ONE 1x1 weight-gradient GEMM against `a`:
             #   G[(t, co)][ci] = sum_q dy[q + off(t)][co] * a[q][ci]  =  dW[co][ci][8 - t]   (the tap seen from the other side),
@@ -401,9 +401,9 @@ class MLPFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w0, b0, w2, b2):
-        h = ops.gemm_nt(x, packed(w0).view(w0.shape[0], w0.shape[1]), b0)
+        h = ops.gemm_nt(x, packed(w0).view(w0.shape[0], -1), b0)          # [out, in] (parity mode: [out, 6*in], the split weight-side parts)
         a = ops.silu(h)
-        y = ops.gemm_nt(a, packed(w2).view(w2.shape[0], w2.shape[1]), b2)
+        y = ops.gemm_nt(a, packed(w2).view(w2.shape[0], -1), b2)
         ctx.save_for_backward(x, h, a, w0, w2)
         ctx.bias_params = (b0, b2)
         return y
@@ -416,10 +416,10 @@ class MLPFn(torch.autograd.Function):
         b0, b2 = ctx.bias_params
         v4 = lambda t: None if t is None else t.view(t.shape[0], t.shape[1], 1, 1)
         dw2, db2 = ops.conv2d_nhwc_wgrad(dy.view(1, 1, m, -1), a.view(1, 1, m, -1), 1, dw_out=v4(_dst(w2)), db_out=_dst(b2))
-        da = ops.gemm_nt(dy, packed(w2, True).view(w2.shape[1], w2.shape[0]))
+        da = ops.gemm_nt(dy, packed(w2, True).view(w2.shape[1], -1))
         dh = ops.silu_bwd(h, da)
         dw0, db0 = ops.conv2d_nhwc_wgrad(dh.view(1, 1, m, -1), x.view(1, 1, m, -1), 1, dw_out=v4(_dst(w0)), db_out=_dst(b0))
-        dx = ops.gemm_nt(dh, packed(w0, True).view(w0.shape[1], w0.shape[0])) if ctx.needs_input_grad[0] else None
+        dx = ops.gemm_nt(dh, packed(w0, True).view(w0.shape[1], -1)) if ctx.needs_input_grad[0] else None
         return dx, dw0.view(w0.shape), db0, dw2.view(w2.shape), db2
 
 
@@ -640,8 +640,8 @@ class RmsnormModulateFn(torch.autograd.Function):
 
 
 def to_nhwc_bf16(x: torch.Tensor) -> torch.Tensor:
-    """NCHW (any float dtype) -> NHWC bf16 contiguous, differentiable (boundary plumbing)."""
-    return x.permute(0, 2, 3, 1).contiguous().to(bf16)
+    """NCHW (any float dtype) -> NHWC bf16 (f32 in parity mode) contiguous, differentiable (boundary plumbing)."""
+    return x.permute(0, 2, 3, 1).contiguous().to(parity.act_dtype())
 
 
 def to_nchw(x: torch.Tensor, dtype=None) -> torch.Tensor:

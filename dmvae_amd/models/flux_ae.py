@@ -207,7 +207,7 @@ class Decoder(nn.Module):
             b, t, c = z.shape
             if t != 256:
                 raise ValueError("Decoder expects 256 tokens (16x16) like the reference (flux_ae.py:245)")
-            h = z.reshape(b, 16, 16, c).to(torch.bfloat16).contiguous()      # tokens are already channels-last
+            h = z.reshape(b, 16, 16, c).to(Fn.parity.act_dtype()).contiguous()      # tokens are already channels-last (bf16; f32 in the parity mode)
         else:
             h = Fn.to_nhwc_bf16(z)
         if isinstance(self.conv_in, nn.Sequential):

@@ -85,7 +85,7 @@ class MLP(nn.Module):
     def forward(self, x):
         fc1, fc2 = self.mlp[0], self.mlp[2]
         lead = x.shape[:-1]
-        rows = x.reshape(-1, x.shape[-1]).to(torch.bfloat16).contiguous()
+        rows = x.reshape(-1, x.shape[-1]).to(Fn.parity.act_dtype()).contiguous()
         return Fn.MLPFn.apply(rows, fc1.weight, fc1.bias, fc2.weight, fc2.bias).reshape(*lead, -1)
 
     def get_last_layer(self):

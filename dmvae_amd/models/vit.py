@@ -97,6 +97,13 @@ class DinoV2ViT(nn.Module):
     def forward_features(self, x):
         if x.is_cuda:
             from .vit_fast import frozen_forward_features, hip_path_supported, trainable_forward_features
+            from .. import parity
+            if parity.on():
+                # fp32 parity mode: f32 activations, every contraction on the MFMA kernels over exactly-split operands (any width); forward only
+                if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+                    raise NotImplementedError("DMVAE_PARITY=1 covers the frozen encoder (train_tokenizer.py:295-297); run the ViT under no_grad / freeze_encoder")
+                from .vit_fast import parity_forward_features
+                return parity_forward_features(self, x)
             if hip_path_supported(self, self.pos_embed.shape[1]):
                 if torch.is_grad_enabled() and self.pos_embed.requires_grad:
                     return trainable_forward_features(self, x)    # trainable encoder on the HIP kernels (csrc/vit.hip, vit_bwd.hip)

@@ -83,3 +83,53 @@ def trainable_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
                              blk.ls1.gamma, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight,
                              blk.mlp.fc2.bias, blk.ls2.gamma, blk.attn.num_heads, blk.norm1.eps)
     return LayerNormBf16Fn.apply(t, vit.norm.weight, vit.norm.bias, vit.norm.eps)
+
+
+@torch.no_grad()
+def parity_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
+    """The frozen encoder in the fp32 parity mode (dmvae_amd/parity.py): f32 residual stream and f32 activations throughout, every Linear (patch
+    embedding included) and both attention contractions on the MFMA GEMM kernel over exactly-split bf16 operands, LayerNorm / GELU / LayerScale /
+    softmax on the f32 kernels of csrc/parity.hip.  Any width / head count (the reduced ViT stand-ins of the golden fixtures included): the
+    production route's shape limits come from its fused kernels, which this mode does not use.  Same block algebra as
+    `vit.DinoV2ViT.forward_features_stock` (reference: models/dinov2.py + dino_layers, reached through models/vae.py:47-53)."""
+    from .. import parity
+    from ..functional import packed
+
+    def linear(a2, lin):                       # [rows, in] f32 -> [rows, out] f32
+        w = lin.weight
+        return ops.gemm_nt(a2, packed(w, frozen=not w.requires_grad).view(w.shape[0], -1), lin.bias.detach().float())
+
+    w = vit.patch_embed.proj.weight
+    b_, c_in, hh, ww = x.shape
+    p = w.shape[-1]
+    patches = x.float().view(b_, c_in, hh // p, p, ww // p, p).permute(0, 2, 4, 1, 3, 5).reshape(b_ * (hh // p) * (ww // p), c_in * p * p).contiguous()
+    kpad = (-patches.shape[1]) % 16                      # the split operand's reduction length 6*K must be a multiple of 32
+    wp = w.detach().float().reshape(w.shape[0], -1)
+    if kpad:
+        patches = torch.nn.functional.pad(patches, (0, kpad))
+        wp = torch.nn.functional.pad(wp, (0, kpad))
+    t = ops.gemm_nt(patches, parity.pack_conv_weight(wp.contiguous()).view(w.shape[0], -1), vit.patch_embed.proj.bias.detach().float())
+    t = t.view(b_, -1, w.shape[0])
+    t = (torch.cat([vit.cls_token.expand(b_, -1, -1).float(), t], dim=1) + vit.pos_embed.float()).contiguous()
+    b, s, c = t.shape
+    sp = (s + 15) // 16 * 16                             # keys padded (and masked) so that the P.V reduction length 6*sp is a multiple of 32
+    for blk in vit.blocks:
+        nh = blk.attn.num_heads
+        hd = c // nh
+        hn = parity.layernorm(t, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+        qkv = linear(hn.view(b * s, c), blk.attn.qkv).view(b, s, 3, nh, hd)
+        buf = torch.zeros(3, b * nh, sp, hd, dtype=torch.float32, device=t.device)
+        buf[:, :, :s] = qkv.permute(2, 0, 3, 1, 4).reshape(3, b * nh, s, hd)
+        sc = ops.gemm_nt(buf[0], buf[1], out_f32=True)                              # [b*nh, sp, sp]
+        if sp != s:
+            sc[:, :, s:] = float("-inf")
+        pr = ops.softmax_rows(sc, hd ** -0.5)
+        o = ops.gemm_nt(pr, ops.transpose_last2(buf[2]), out_f32=True)[:, :s]        # [b*nh, s, hd]
+        o = o.reshape(b, nh, s, hd).permute(0, 2, 1, 3).reshape(b * s, c).contiguous()
+        o = linear(o, blk.attn.proj).view(b, s, c)
+        t = parity.eltwise(6, t, o, g=blk.ls1.gamma.detach().float(), out=t)
+        hn = parity.layernorm(t, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        h = parity.eltwise(4, linear(hn.view(b * s, c), blk.mlp.fc1))
+        o = linear(h, blk.mlp.fc2).view(b, s, c)
+        t = parity.eltwise(6, t, o, g=blk.ls2.gamma.detach().float(), out=t)
+    return parity.layernorm(t, vit.norm.weight, vit.norm.bias, vit.norm.eps)

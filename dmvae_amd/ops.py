@@ -2,7 +2,9 @@
 
 Every function takes CUDA(HIP) tensors, validates dtype/contiguity, launches on the current stream
 and returns freshly allocated outputs.  No function here has a CPU path: CPU tensors raise.
-Activations are NHWC bf16 ``[N, H, W, C]``.
+Activations are NHWC bf16 ``[N, H, W, C]`` -- or, in the fp32 parity mode (dmvae_amd/parity.py, DMVAE_PARITY=1), NHWC f32: every wrapper
+below that sees f32 activations while the mode is on routes the contraction through the SAME kernels on exactly-split bf16 operands and the
+elementwise work through the f32 kernels of csrc/parity.hip.
 """
 from __future__ import annotations
 
@@ -12,7 +14,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import _lib
+from . import _lib, parity
 from ._lib import ConvDesc, check
 
 bf16 = torch.bfloat16
@@ -59,7 +61,9 @@ def workspace(nbytes: int, device, slot: str = "main") -> torch.Tensor:
 
 # ---- conv / GEMM ------------------------------------------------------------------------------
 def pack_conv_weight(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad: int = 0) -> torch.Tensor:
-    """f32 [cout, cin, ks, ks] (or [out, in] for Linear) -> bf16 [rows, ks*ks, cols] kernel operand."""
+    """f32 [cout, cin, ks, ks] (or [out, in] for Linear) -> bf16 [rows, ks*ks, cols] kernel operand (parity mode: [rows, ks*ks, 6*cols])."""
+    if parity.on():
+        return parity.pack_conv_weight(w, for_dgrad, rows_pad, cols_pad)
     w = _req(w, f32, "weight")
     if w.dim() == 2:
         cout, cin, ks = w.shape[0], w.shape[1], 1
@@ -89,6 +93,11 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
     upsample: False/0 none, True/1 nearest x2 folded into the gather, 2 zero-insertion x2 (dgrad of the stride-2 3x3 conv);
     stride 2 with ks 3: the Downsample conv (input padded bottom/right by one, flux_ae.py:85-95); ks 4 (stride 1 | 2, padding 1): the
     PatchGAN convs (patchgan.py:125-147); transposed: the input gradient of the ks-4 conv with that stride (w_packed packed for_dgrad)."""
+    if x.dtype == f32 and parity.on():
+        # f32 activations: the same kernel over the six exact bf16 partial products laid out along the channel (reduction) axis; bias in the
+        # kernel's f32 epilogue, residual / activation afterwards in f32
+        y = conv2d_nhwc(parity.split_channels(x, parity.A_SIDE), w_packed, bias, None, ks, upsample, ACT_NONE, True, stride, transposed)
+        return parity.epilogue(y, residual, act)
     x = _req(x, bf16, "x")
     w_packed = _req(w_packed, bf16, "w_packed")
     n, h, w_, cin = x.shape
@@ -129,6 +138,16 @@ def conv2d_nhwc_wgrad(dy: torch.Tensor, a: torch.Tensor, ks: int, upsample: bool
                       dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None,
                       accumulate: bool = False, stride: int = 1) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """dW [Cout,Cin,ks,ks] f32 and db [Cout] f32 from dy [N,Ho,Wo,Cout] and the conv input a [N,H,W,Cin] (bf16)."""
+    if dy.dtype == f32 and parity.on():
+        # the reduction runs over images x pixels: the six partial products become six times the images
+        dw, _ = conv2d_nhwc_wgrad(parity.split_batch(dy, parity.A_SIDE), parity.split_batch(a, parity.W_SIDE), ks, upsample, False, dw_out, None,
+                                  accumulate, stride)
+        db = None
+        if need_bias:
+            db = parity.colsum(dy.reshape(-1, dy.shape[-1]))
+            if db_out is not None:
+                db = db_out.add_(db) if accumulate else db_out.copy_(db)
+        return dw, db
     dy = _req(dy, bf16, "dy")
     a = _req(a, bf16, "a")
     n, h, w_, cin = a.shape
@@ -147,6 +166,9 @@ def conv2d_nhwc_wgrad(dy: torch.Tensor, a: torch.Tensor, ks: int, upsample: bool
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
             act: int = ACT_NONE, out_f32: bool = False) -> torch.Tensor:
     """C[..., m, n] = act(A[..., m, k] @ B[..., n, k]^T + bias + residual).  A/B bf16; a 2-D operand is shared by the batch."""
+    if a.dtype == f32 and parity.on():
+        bs = b if b.dtype == bf16 else parity.split_channels(b, parity.W_SIDE)          # bf16: a weight operand packed in parity mode (already split)
+        return parity.epilogue(gemm_nt(parity.split_channels(a, parity.A_SIDE), bs, bias, None, ACT_NONE, True), residual, act)
     a = _req(a, bf16, "A")
     b = _req(b, bf16, "B")
     batch = a.shape[0] if a.dim() == 3 else (b.shape[0] if b.dim() == 3 else 1)
@@ -165,6 +187,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, out_f32: bool = False) -> torch.Tensor:
     """C[b] = alpha * A[b]^T @ B[b] with A [batch, K, M], B [batch, K, N] bf16 (reduction over the slow dim)."""
+    if a.dtype == f32 and parity.on():
+        return gemm_tn(parity.split_rows(a, parity.A_SIDE), parity.split_rows(b, parity.W_SIDE), alpha, True)
     a = _req(a, bf16, "A")
     b = _req(b, bf16, "B")
     assert a.dim() == 3 and b.dim() == 3 and a.shape[:2] == b.shape[:2]
@@ -180,6 +204,8 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, out_f32: bool 
 
 
 def softmax_rows(s: torch.Tensor, scale: float) -> torch.Tensor:
+    if parity.on():
+        return parity.softmax_rows(s, scale)
     s = _req(s, f32, "S")
     p = torch.empty(s.shape, dtype=bf16, device=s.device)
     check(_lib.lib().dmvae_softmax_rows_fwd(s.data_ptr(), p.data_ptr(), s.numel() // s.shape[-1], s.shape[-1], float(scale), _stream()), "softmax_rows_fwd")
@@ -187,6 +213,8 @@ def softmax_rows(s: torch.Tensor, scale: float) -> torch.Tensor:
 
 
 def softmax_rows_bwd(dp: torch.Tensor, p: torch.Tensor, scale: float) -> torch.Tensor:
+    if p.dtype == f32 and parity.on():
+        return parity.softmax_rows_bwd(dp, p, scale)
     dp = _req(dp, f32, "dP")
     p = _req(p, bf16, "P")
     ds = torch.empty_like(p)
@@ -196,6 +224,8 @@ def softmax_rows_bwd(dp: torch.Tensor, p: torch.Tensor, scale: float) -> torch.T
 
 
 def transpose_last2(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == f32 and parity.on():
+        return parity.transpose_last2(x)
     x = _req(x, bf16, "x")
     assert x.dim() == 3
     out = torch.empty(x.shape[0], x.shape[2], x.shape[1], dtype=bf16, device=x.device)
@@ -205,6 +235,8 @@ def transpose_last2(x: torch.Tensor) -> torch.Tensor:
 
 # ---- GroupNorm ----------------------------------------------------------------------------------
 def groupnorm_stats(x: torch.Tensor, groups: int = 32, eps: float = 1e-6) -> torch.Tensor:
+    if x.dtype == f32 and parity.on():
+        return parity.groupnorm_stats(x, groups, eps)
     x = _req(x, bf16, "x")
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)
@@ -219,6 +251,8 @@ def groupnorm_stats(x: torch.Tensor, groups: int = 32, eps: float = 1e-6) -> tor
 
 
 def groupnorm_apply(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, swish: bool, groups: int = 32) -> torch.Tensor:
+    if x.dtype == f32 and parity.on():
+        return parity.groupnorm_apply(x, stats, gamma, beta, int(swish), groups)
     x = _req(x, bf16, "x")
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)
@@ -231,6 +265,8 @@ def groupnorm_apply(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, b
 def groupnorm_bwd(da: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, swish: bool,
                   dres: Optional[torch.Tensor] = None, groups: int = 32, need_param_grads: bool = True,
                   dg_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None):
+    if x.dtype == f32 and parity.on():
+        return parity.groupnorm_bwd(da, x, stats, gamma, beta, int(swish), dres, groups, need_param_grads, dg_out, db_out)
     da = _req(da, bf16, "da")
     x = _req(x, bf16, "x")
     n, c = x.shape[0], x.shape[-1]
@@ -331,6 +367,8 @@ def diffaug_bwd(dy: torch.Tensor, rand01: torch.Tensor, flags: int = 7, cutout: 
 
 
 def leaky_relu_bwd(dy: torch.Tensor, y: torch.Tensor, slope: float = 0.2) -> torch.Tensor:
+    if dy.dtype == f32 and parity.on():
+        return parity.eltwise(3, dy, y, param=slope)
     dy = _req(dy, bf16, "dy")
     y = _req(y, bf16, "y")
     dx = torch.empty_like(dy)
@@ -340,6 +378,8 @@ def leaky_relu_bwd(dy: torch.Tensor, y: torch.Tensor, slope: float = 0.2) -> tor
 
 
 def sumpool2x2(dy: torch.Tensor) -> torch.Tensor:
+    if dy.dtype == f32 and parity.on():
+        return parity.pool2x2(0, dy)
     dy = _req(dy, bf16, "dy")
     n, h2, w2, c = dy.shape
     dx = torch.empty(n, h2 // 2, w2 // 2, c, dtype=bf16, device=dy.device)
@@ -348,6 +388,8 @@ def sumpool2x2(dy: torch.Tensor) -> torch.Tensor:
 
 
 def maxpool2x2(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == f32 and parity.on():
+        return parity.pool2x2(1, x)
     x = _req(x, bf16, "x")
     n, h2, w2, c = x.shape
     y = torch.empty(n, h2 // 2, w2 // 2, c, dtype=bf16, device=x.device)
@@ -357,6 +399,8 @@ def maxpool2x2(x: torch.Tensor) -> torch.Tensor:
 
 def maxpool2x2_relu_bwd(dpool: Optional[torch.Tensor], x: torch.Tensor, extra: Optional[torch.Tensor]) -> torch.Tensor:
     """dx = x > 0 ? route(dpool to the first maximum of each 2x2 window of x) + extra : 0."""
+    if x.dtype == f32 and parity.on():
+        return parity.pool2x2(2, dpool, x, extra)
     x = _req(x, bf16, "x")
     n, h2, w2, c = x.shape
     for name, t in (("dpool", dpool), ("extra", extra)):
@@ -369,6 +413,8 @@ def maxpool2x2_relu_bwd(dpool: Optional[torch.Tensor], x: torch.Tensor, extra: O
 
 
 def relu_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    if dy.dtype == f32 and parity.on():
+        return parity.eltwise(3, dy, y, param=0.0)
     dy = _req(dy, bf16, "dy")
     y = _req(y, bf16, "y")
     dx = torch.empty_like(dy)
@@ -377,6 +423,9 @@ def relu_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
 
 
 def nchw_to_nhwc_bf16(x: torch.Tensor, c_pad: int = 0) -> torch.Tensor:
+    """NCHW f32 image -> NHWC activation (bf16; f32 in parity mode), channels zero-padded to c_pad."""
+    if parity.on():
+        return parity.nchw_to_nhwc(x, c_pad)
     x = _req(x, f32, "x")
     n, c, h, w = x.shape
     c_pad = max(c_pad, c)
@@ -394,6 +443,8 @@ def nhwc_to_nchw_f32(x: torch.Tensor, c: int) -> torch.Tensor:
 
 
 def silu(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == f32 and parity.on():
+        return parity.eltwise(1, x)
     x = _req(x, bf16, "x")
     y = torch.empty_like(x)
     check(_lib.lib().dmvae_silu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "silu_fwd")
@@ -401,6 +452,8 @@ def silu(x: torch.Tensor) -> torch.Tensor:
 
 
 def silu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    if x.dtype == f32 and parity.on():
+        return parity.eltwise(2, x, dy)
     x = _req(x, bf16, "x")
     dy = _req(dy, bf16, "dy")
     dx = torch.empty_like(x)
@@ -694,6 +747,8 @@ def l1_mse(recon: torch.Tensor, images: torch.Tensor, w1: float = 1.0, w2: float
 
 def lpips_diff(f0: torch.Tensor, f1: torch.Tensor, lin_w: torch.Tensor, out: torch.Tensor, gscale: float, need_grad: bool, accumulate: bool):
     """One LPIPS level on NHWC bf16 features; accumulates the level value into out[0]; returns d/d f1 (bf16) or None."""
+    if f0.dtype == f32 and parity.on():
+        return parity.lpips_diff(f0, f1, _req(lin_w, f32, "lin_w"), out, gscale, need_grad, accumulate)
     f0 = _req(f0, bf16, "f0")
     f1 = _req(f1, bf16, "f1")
     n, c = f0.shape[0], f0.shape[-1]

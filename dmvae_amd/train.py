@@ -19,7 +19,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import dist, losses
+from . import dist, losses, parity
 from .models.vae import VAE
 from .optim import FlatAdamWEMA, FlatParams
 from .utils.lpips import LPIPS
@@ -112,13 +112,15 @@ class TokenizerTrainer:
 
     def refresh_frozen_shadows(self) -> None:
         """(Re)build the bf16 shadows of the frozen encoder and LPIPS trunk; call after loading new weights into them."""
-        self._enc = frozen_bf16_shadow(self.vae.encoder)
+        self._enc = self.vae.encoder if parity.on() else frozen_bf16_shadow(self.vae.encoder)      # parity mode: the f32 weights themselves
         self._lpips = self.lpips          # LPIPS runs on the HIP conv kernels with cached bf16 operands: no shadow needed
 
     def _encode(self, images: torch.Tensor) -> torch.Tensor:
         """Frozen encoder forward (DINOEncoder.forward, models/vae.py:52-53) on the bf16 shadow; widths the HIP LayerNorm covers
         take the fused elementwise path, anything else the stock module."""
         enc = self._enc
+        if parity.on():
+            return enc(images)                # DinoV2ViT.forward_features -> vit_fast.parity_forward_features (f32, split-operand GEMMs)
         if enc.model.embed_dim % 256 == 0 and enc.model.embed_dim <= 1536:
             from .models.vit_fast import frozen_forward_features
             return frozen_forward_features(enc.model, enc.scale(enc.de_scale(images)))[:, enc.model.num_prefix_tokens:]
@@ -127,7 +129,7 @@ class TokenizerTrainer:
     def step(self, images: torch.Tensor) -> torch.Tensor:
         vae, w = self.vae, self.w
         self.fp.begin_step()
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not parity.on()):      # the reference's autocast (train_tokenizer.py:410); off in the fp32 parity mode
             with torch.no_grad():
                 tokens = self._encode(images)
             latent = vae.bottle_neck(tokens)

@@ -335,6 +335,46 @@ int dmvae_sde_euler_step(const void* x, const void* v, int v_is_bf16, const void
  * sample_50k.py:151 without the NCHW round trip.  round_bf16 != 0 rounds y to bf16 first (an autocast decoder's `.float()`). */
 int dmvae_image_to_u8(const void* y, void* out, size_t npix, int c, int c_stride, int round_bf16, dmvae_stream_t stream);
 
+/* ---- fp32 parity mode (DMVAE_PARITY=1; csrc/parity.hip) ---------------------------------------------------------------------------
+ * north_star: "match the reference PyTorch-CPU path within 1e-4 relative fp32".  In this mode activations are f32 NHWC and every
+ * contraction still runs on the bf16 MFMA kernels above: dmvae_split3_bf16 splits an f32 operand EXACTLY into hi + mid + lo bf16 terms and
+ * lays the six partial products of order <= 2 along the reduction dimension, so one launch of dmvae_conv2d_nhwc_fwd / _wgrad /
+ * dmvae_gemm_nt_batched / dmvae_gemm_tn_batched with a 6x longer reduction accumulates x*w to ~2^-24 in its f32 accumulator.  The other
+ * entry points are the f32-in / f32-out forms of the HBM-bound kernels (f64 statistics), replacing the same reference sites as their bf16
+ * counterparts (models/flux_ae.py:21-107,239-269; models/vae.py:56-65; utils/lpips.py:86-162). */
+
+/* x [rows][cols] f32 -> bf16 parts; part q of element (r, c) is written to
+ *   out[(r / rows_per_batch) * batch_stride + q * part_stride + (r % rows_per_batch) * row_stride + c],  q = 0..5
+ * pattern 0 (activation side): [hi, mid, lo, hi, mid, hi];  pattern 1 (weight side): [hi, hi, hi, mid, mid, lo]. */
+int dmvae_split3_bf16(const void* x, void* out, size_t rows, int cols, size_t rows_per_batch, size_t batch_stride, size_t part_stride,
+                      size_t row_stride, int pattern, dmvae_stream_t stream);
+/* GroupNorm on f32 NHWC (statistics accumulated in f64); act as dmvae_groupnorm_apply.  nn.GroupNorm at flux_ae.py:28,62,64,236. */
+int dmvae_groupnorm_stats_f32(const void* x, void* stats, int n, int hw, int c, int groups, float eps, dmvae_stream_t stream);
+int dmvae_groupnorm_apply_f32(const void* x, const void* stats, const void* gamma, const void* beta, void* y, int n, int hw, int c,
+                              int groups, int act, dmvae_stream_t stream);
+size_t dmvae_groupnorm_f32_workspace(int n, int c, int groups);
+/* dx = GroupNorm backward of da (+ dres), dgamma / dbeta (NULL to skip); inv_count <= 0 selects 1 / (hw * c / groups). */
+int dmvae_groupnorm_bwd_f32(const void* da, const void* x, const void* dres, const void* stats, const void* gamma, const void* beta, void* dx,
+                            void* dgamma, void* dbeta, void* workspace, size_t workspace_bytes, int n, int hw, int c, int groups, int act,
+                            int accumulate, float inv_count, dmvae_stream_t stream);
+/* Elementwise f32 family.  op 0: out = act(a + b) (b may be NULL; act 0 none, 1 SiLU, 2 ReLU, 4 LeakyReLU(param), 3: out = b > 0 ? a : 0);
+ * 1: SiLU(a); 2: b * SiLU'(a); 3: a * (b > 0 ? 1 : param) (ReLU / LeakyReLU backward from the saved output b); 4: GELU(a) (erf form);
+ * 5: b * GELU'(a); 6: a + b * g[i % cols] (LayerScale + residual); 7: a * param. */
+int dmvae_eltwise_f32(int op, const void* a, const void* b, const void* g, void* out, size_t n, int cols, int act, float param,
+                      dmvae_stream_t stream);
+/* Row softmax with f32 probabilities (flux_ae.py:47) and its backward dS = scale * P .* (dP - sum(dP .* P)). */
+int dmvae_softmax_rows_fwd_f32(const void* s, void* p, int rows, int cols, float scale, dmvae_stream_t stream);
+int dmvae_softmax_rows_bwd_f32(const void* dp, const void* p, void* ds, int rows, int cols, float scale, dmvae_stream_t stream);
+/* 2x2 pools on f32 NHWC; n, h, w = POOLED size.  op 0: sum (backward of nearest x2, flux_ae.py:104); 1: max (lpips.py VGG trunk);
+ * 2: out [n,2h,2w,c] = ReLU-masked max-pool backward of a (may be NULL) at the argmax of x's window, plus extra (may be NULL). */
+int dmvae_pool2x2_f32(int op, const void* a, const void* x, const void* extra, void* out, int n, int h, int w, int c, dmvae_stream_t stream);
+int dmvae_nchw_f32_to_nhwc_f32(const void* src, void* dst, int n, int c, int hw, int c_pad, dmvae_stream_t stream);
+/* dmvae_lpips_diff on f32 features; workspace >= 2048 * 8 bytes. */
+int dmvae_lpips_diff_f32(const void* f0, const void* f1, const void* lin_w, void* df1, void* out, void* workspace, size_t workspace_bytes, int n,
+                         int hw, int c, float gscale, int accumulate, dmvae_stream_t stream);
+/* LayerNorm over the last dimension, f32 in / f32 out (timm ViT block reached through models/vae.py:47-53). */
+int dmvae_layernorm_f32(const void* x, const void* gamma, const void* beta, void* y, int rows, int cols, float eps, dmvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
