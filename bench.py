@@ -267,8 +267,13 @@ def main():
         a = per.setdefault(label, [0.0, 0.0, 0])
         a[0] += e0.elapsed_time(e1); a[1] += fl; a[2] += 1
     k_ms, k_flop, k_n = per.get(DOMINANT, [0.0, 0.0, 0])
-    all_ms = sum(a[0] for a in per.values())
-    all_flop = sum(a[1] for a in per.values())
+    conv = {k: v for k, v in per.items() if not k.startswith("wgrad")}
+    all_ms = sum(a[0] for a in conv.values())
+    all_flop = sum(a[1] for a in conv.values())
+    n_conv = sum(a[2] for a in conv.values())
+    wg_ms, wg_flop, wg_n = per.get("wgrad_pp", [0.0, 0.0, 0])
+    wgs_ms, wgs_flop, wgs_n = per.get("wgrad_small", [0.0, 0.0, 0])
+    wg_ach = wg_flop / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
     achieved = k_flop / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure is the one collected over
     # this same command by tools/pmc_step_traffic.sh (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied)
@@ -300,8 +305,15 @@ def main():
                      "traffic_source": traffic_src,
                      "launches": k_n, "avg_launch_us": round(k_ms * 1e3 / max(1, k_n), 2),
                      "share_of_step": round(k_ms / (dt * 1e3), 3),
-                     "all_conv_fwd_dgrad_launches": {"launches": len(timing), "achieved_TFLOPs": round(all_flop / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,
+                     "all_conv_fwd_dgrad_launches": {"launches": n_conv, "achieved_TFLOPs": round(all_flop / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,
                                                      "share_of_step": round(all_ms / (dt * 1e3), 3)}},
+        # the second MFMA-bound family: conv weight gradients (csrc/conv_wgrad_pp.hip: split-K over pixels, transpose reads, + slab reduce and
+        # the bias gradient), timed per call like the forward / input-gradient launches
+        "roofline_wgrad": {"bound": "mfma", "kernel": "dmvae_wgrad_pp::wgrad_pp_kernel + wgrad_reduce_kernel (conv / Linear weight + bias gradient, whole call)",
+                           "achieved": round(wg_ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(wg_ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                           "traffic": None, "launches": wg_n, "avg_launch_us": round(wg_ms * 1e3 / max(1, wg_n), 2),
+                           "share_of_step": round(wg_ms / (dt * 1e3), 3),
+                           "small_shape_calls": {"launches": wgs_n, "share_of_step": round(wgs_ms / (dt * 1e3), 3)}},
     }
     if world == 1:
         out["kl_mmd"] = kl_mmd_roofline(dev)

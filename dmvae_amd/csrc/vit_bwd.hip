@@ -205,7 +205,7 @@ extern "C" int dmvae_layernorm_bwd_f32(const void* dy, const void* x, const void
 extern "C" int dmvae_layerscale_bwd(const void* dt, const void* y, const void* gamma, void* dy, void* dgamma, void* workspace,
                                     size_t workspace_bytes, int rows, int c, int accumulate, hipStream_t stream) {
   DMVAE_CHECK_ARG(dt && y && gamma && dy && dgamma && workspace && rows > 0, "layerscale_bwd: bad argument");
-  DMVAE_CHECK_ARG(c % 8 == 0 && c >= 8 && c <= 2048 && 256 % (c / 8) == 0, "layerscale_bwd: width must be 8 * a divisor of 256 (got %d)", c);
+  DMVAE_CHECK_ARG(c % 8 == 0 && c >= 8 && c <= 2048, "layerscale_bwd: width must be a multiple of 8 up to 2048 (got %d)", c);   // c / 8 lanes per row, 256 / (c / 8) rows per block (ViT-B: 96 lanes, 2 rows, 64 idle threads)
   DMVAE_CHECK_ARG(workspace_bytes >= dmvae_vit_bwd_workspace(c), "layerscale_bwd: workspace too small");
   const int rpb = 256 / (c / 8);
   int nblk = (rows + rpb * 8 - 1) / (rpb * 8); if (nblk > LN_MAX_BLOCKS) nblk = LN_MAX_BLOCKS; if (nblk < 1) nblk = 1;

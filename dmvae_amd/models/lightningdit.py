@@ -289,6 +289,12 @@ class LightningDiT(nn.Module):
                 if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                     return lightningdit_fast.forward_train(self, x, t, y)        # autograd Functions over csrc/dit.hip
                 return lightningdit_fast.forward_inference(self, x, t, y)
+            why = ("call outside autocast(bfloat16) or a configuration the DiT kernels do not cover (RoPE + RMSNorm + SwiGLU blocks, width <= 2048, "
+                   "even head dim <= 128, tokens a multiple of 32)")
+        else:
+            why = "CPU tensor"
+        from .._stock import require_opt_in
+        require_opt_in("LightningDiT.forward", why)
         return self.forward_stock(x, t, y)
 
     def forward_stock(self, x, t=None, y=None):

@@ -113,6 +113,15 @@ class DinoV2ViT(nn.Module):
                     # bf16 weights.  Tokens come back in bf16 (the stock modules' final LayerNorm returns f32 under autocast; the bottleneck's
                     # Linear casts to bf16 either way).
                     return frozen_forward_features(self, x.float())
+                why = "frozen / no-grad use outside autocast(bfloat16) (the HIP route implements the reference's autocast arithmetic; f32: DMVAE_PARITY=1)"
+            else:
+                nh = self.blocks[0].attn.num_heads
+                why = (f"width {self.embed_dim} with {nh} heads at {self.pos_embed.shape[1]} tokens is outside the encoder kernels' range "
+                       "(width 256/512/768/1024/1280/1536, head dim 64, <= 288 tokens)")
+        else:
+            why = "CPU tensor"
+        from .._stock import require_opt_in
+        require_opt_in("DinoV2ViT.forward_features", why)
         return self.forward_features_stock(x)
 
     def forward_features_stock(self, x):

@@ -63,11 +63,11 @@ def frozen_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
 
 
 def hip_path_supported(vit, seq_len: int) -> bool:
-    """Shapes the encoder kernels cover: width a multiple of 256 up to 1536 with 8 * (a divisor of 256) channels (LayerNorm / LayerScale
-    kernels), head dim 64, at most 288 tokens (fused attention)."""
+    """Shapes the encoder kernels cover: width 256 / 512 / 768 / 1024 / 1280 / 1536 (LayerNorm kernels; ViT-B = 768 and ViT-L = 1024 are the
+    reference's two sizes, models/vae.py:41-48), head dim 64, at most 288 tokens (fused attention)."""
     c = vit.embed_dim
     nh = vit.blocks[0].attn.num_heads
-    return c % 256 == 0 and c <= 1536 and 256 % (c // 8) == 0 and c // nh == 64 and seq_len <= 288
+    return c in (256, 512, 768, 1024, 1280, 1536) and c // nh == 64 and seq_len <= 288
 
 
 def trainable_forward_features(vit, x: torch.Tensor) -> torch.Tensor:

@@ -158,8 +158,20 @@ def conv2d_nhwc_wgrad(dy: torch.Tensor, a: torch.Tensor, ks: int, upsample: bool
     ws = workspace(wsb, a.device)
     dw = dw_out if dw_out is not None else torch.empty(cout, cin, ks, ks, dtype=f32, device=a.device)
     db = (db_out if db_out is not None else torch.empty(cout, dtype=f32, device=a.device)) if need_bias else None
+    timing = KERNEL_TIMING
+    if timing is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(L.dmvae_conv2d_nhwc_wgrad(dy.data_ptr(), a.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel(), ctypes.byref(d),
                                     int(accumulate), _stream()), "conv2d_nhwc_wgrad")
+    if timing is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        # the whole weight-gradient call: split-K main kernel + fixed-order slab reduce (+ fused bias gradient); csrc/conv_wgrad_pp.hip takes
+        # stride-1 3x3 / 1x1 shapes whose rows are multiples of 32 pixels with >= 4096 reduction rows, csrc/conv_wgrad.hip the rest
+        ho, wo = dy.shape[1], dy.shape[2]
+        big = stride == 1 and ks in (1, 3) and wo % 32 == 0 and cin % 128 == 0 and cout % 128 == 0 and n * ho * wo >= 4096
+        timing.append(("wgrad_pp" if big else "wgrad_small", e0, e1, 2.0 * n * ho * wo * cout * cin * ks * ks))
     return dw, db
 
 

@@ -121,10 +121,10 @@ class TokenizerTrainer:
         enc = self._enc
         if parity.on():
             return enc(images)                # DinoV2ViT.forward_features -> vit_fast.parity_forward_features (f32, split-operand GEMMs)
-        if enc.model.embed_dim % 256 == 0 and enc.model.embed_dim <= 1536:
-            from .models.vit_fast import frozen_forward_features
+        from .models.vit_fast import frozen_forward_features, hip_path_supported
+        if hip_path_supported(enc.model, enc.model.pos_embed.shape[1]):
             return frozen_forward_features(enc.model, enc.scale(enc.de_scale(images)))[:, enc.model.num_prefix_tokens:]
-        return enc(images)
+        return enc(images)                    # raises unless DMVAE_ALLOW_STOCK=1 (dmvae_amd/_stock.py): no silent ATen route
 
     def step(self, images: torch.Tensor) -> torch.Tensor:
         vae, w = self.vae, self.w

@@ -26,7 +26,10 @@ def main():
     g = torch.Generator().manual_seed(777)
     for tag, kw, seed in (("dit_small_hd64", dict(input_size=8, patch_size=1, in_channels=8, hidden_size=128, depth=2, num_heads=2, num_classes=10), 71),
                           ("dit_small_hd72", dict(input_size=8, patch_size=1, in_channels=8, hidden_size=144, depth=2, num_heads=2, num_classes=10), 72),
-                          ("dit_small_p2", dict(input_size=8, patch_size=2, in_channels=4, hidden_size=128, depth=1, num_heads=2, num_classes=10), 73)):
+                          ("dit_small_p2", dict(input_size=8, patch_size=2, in_channels=4, hidden_size=128, depth=1, num_heads=2, num_classes=10), 73),
+                          # head dim 64 again, at a width whose SwiGLU inner size int(2/3 * 4 * 192) = 512 is a multiple of 8: hidden 128 gives 341, which
+                          # the HIP DiT kernels (16-byte rows) do not take, so `dit_small_hd64` can only pin the CPU oracle / stock module
+                          ("dit_small_hd64w", dict(input_size=8, patch_size=1, in_channels=8, hidden_size=192, depth=2, num_heads=3, num_classes=10), 74)):
         m = LightningDiT(**kw).eval()
         fixed = {k: v.clone() for k, v in m.state_dict().items() if k == "pos_embed" or k.startswith("feat_rope")}
         det_fill_(m, seed, skip=("pos_embed",))

@@ -24,6 +24,18 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture
+def allow_stock(monkeypatch):
+    """Opt in to the stock-PyTorch routes of the ViT / LightningDiT mirrors (dmvae_amd/_stock.py) for a test whose SUBJECT is host logic around the
+    model on the CPU (sampler / transport mirrors, state_dict layout) or a reduced reference fixture whose width the HIP kernels do not cover.
+    Without it an implicit fallback raises."""
+    import warnings
+    monkeypatch.setenv("DMVAE_ALLOW_STOCK", "1")
+    with warnings.catch_warnings():
+        warnings.filterwarnings("ignore", message=".*STOCK PyTorch modules.*")
+        yield
+
+
 class Golden(dict):
     def t(self, k, dtype=torch.float32):
         return torch.from_numpy(np.asarray(self[k])).to(dtype)

@@ -28,7 +28,7 @@ def _trainer(bucket_bytes, seed=5):
     torch.manual_seed(seed)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=64, depth=1, num_heads=2)).cuda()
+        vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=256, depth=1, num_heads=4)).cuda()
     return TokenizerTrainer(vae, None, warmup_steps=2, bucket_bytes=bucket_bytes)
 
 

@@ -196,7 +196,9 @@ def test_decoder_full_b1_tokens():
     assert abs(y.double().abs().sum().item() - g["y_sum"][1]) < 2e-2 * g["y_sum"][1]
 
 
-def test_vae_forward_tiny_and_api():
+def test_vae_forward_tiny_and_api(allow_stock):
+    # allow_stock: the capture's reduced ViT (width 64, 4 heads) is outside the bf16 encoder kernels' range; the fp32 parity mode runs this fixture with
+    # the encoder on the MFMA GEMM route (tests/test_gpu_parity_fp32.py) and tests/test_gpu_vit_pin.py pins the bf16 encoder routes to the reference
     from test_oracle_golden import vae_tiny_params
     g = load_golden("vae_forward_tiny")
     p, vae = vae_tiny_params()

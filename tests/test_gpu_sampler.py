@@ -154,7 +154,7 @@ def test_sample_50k_loop_writes_the_reference_file_layout(tmp_path):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=256, depth=1, num_heads=4)).to(DEV).eval()
-    dit = LightningDiT(input_size=16, patch_size=1, in_channels=32, hidden_size=128, depth=2, num_heads=2, num_classes=10).to(DEV).eval()
+    dit = LightningDiT(input_size=16, patch_size=1, in_channels=32, hidden_size=192, depth=2, num_heads=3, num_classes=10).to(DEV).eval()
     with torch.no_grad():
         for blk in dit.blocks:
             blk.adaLN_modulation[1].weight.normal_(0, 0.02)
@@ -192,7 +192,7 @@ def test_diffusion_trainer_step_vs_stock_autocast_step():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=256, depth=1, num_heads=4)).to(DEV).eval()
-    dit = LightningDiT(input_size=16, patch_size=1, in_channels=32, hidden_size=128, depth=2, num_heads=2, num_classes=10).to(DEV)
+    dit = LightningDiT(input_size=16, patch_size=1, in_channels=32, hidden_size=192, depth=2, num_heads=3, num_classes=10).to(DEV)
     with torch.no_grad():
         for blk in dit.blocks:
             blk.adaLN_modulation[1].weight.normal_(0, 0.02)

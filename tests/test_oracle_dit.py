@@ -9,9 +9,14 @@ from conftest import load_golden, rel_err
 from oracle import ref_cpu as R
 from oracle.detweights import det_fill_
 
+# CPU tests of the host mirrors (parameter layout, transport / sampler logic): the model's stock-PyTorch route is what they run on, explicitly
+pytestmark = pytest.mark.usefixtures("allow_stock")
+
 CFGS = {"dit_small_hd64": dict(input_size=8, patch_size=1, in_channels=8, hidden_size=128, depth=2, num_heads=2, num_classes=10),
         "dit_small_hd72": dict(input_size=8, patch_size=1, in_channels=8, hidden_size=144, depth=2, num_heads=2, num_classes=10),
-        "dit_small_p2": dict(input_size=8, patch_size=2, in_channels=4, hidden_size=128, depth=1, num_heads=2, num_classes=10)}
+        "dit_small_p2": dict(input_size=8, patch_size=2, in_channels=4, hidden_size=128, depth=1, num_heads=2, num_classes=10),
+        # head dim 64 at a width whose SwiGLU inner size (512) the HIP kernels take; hidden 128 gives 341 (CPU oracle / stock module only)
+        "dit_small_hd64w": dict(input_size=8, patch_size=1, in_channels=8, hidden_size=192, depth=2, num_heads=3, num_classes=10)}
 
 
 def build(tag, g):

@@ -9,6 +9,9 @@ from conftest import load_golden, rel_err
 from oracle import ref_cpu as R
 from oracle.detweights import det_fill_
 
+# CPU tests of the host mirrors (parameter layout, transport / sampler logic): the model's stock-PyTorch route is what they run on, explicitly
+pytestmark = pytest.mark.usefixtures("allow_stock")
+
 DIT_KW = dict(input_size=8, patch_size=1, in_channels=8, hidden_size=144, depth=2, num_heads=2, num_classes=10)
 CASES = ["sampler_euler_sigma_mean", "sampler_heun_linear_mean", "sampler_euler_decreasing_euler", "sampler_euler_incdec_tweedie", "sampler_euler_sigma_none"]
 
