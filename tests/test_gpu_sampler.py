@@ -206,7 +206,8 @@ def test_diffusion_trainer_step_vs_stock_autocast_step():
     g = torch.Generator(device=DEV).manual_seed(0)
     images = torch.rand(4, 3, 256, 256, device=DEV, generator=g) * 2 - 1
     labels = torch.tensor([3, 7, 1, 9], device=DEV)
-    x = tr.latents(images)
+    with torch.autocast("cuda", dtype=BF):              # train_diffusion.py:276-287 runs the frozen encode under autocast: the HIP encoder route
+        x = tr.latents(images)
     assert x.shape == (4, 32, 16, 16) and not x.requires_grad
     for step in range(3):
         ema_before = tr.fp.ema.clone()

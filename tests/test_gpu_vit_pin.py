@@ -80,9 +80,11 @@ def test_parity_mode_vs_reference_capture(name):
 
 def test_uncovered_width_raises_instead_of_running_stock(monkeypatch):
     import warnings
+    from dmvae_amd import _stock
     from dmvae_amd._lib import DmvaeHipError
     from dmvae_amd.models.vit import DinoV2ViT
     monkeypatch.delenv("DMVAE_ALLOW_STOCK", raising=False)
+    monkeypatch.setattr(_stock, "_warned", set())          # the warning is issued once per call site per process
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         vit = DinoV2ViT(embed_dim=64, depth=1, num_heads=2, patch_size=16, img_size=64).to(DEV).eval().requires_grad_(False)
