@@ -115,3 +115,47 @@ class FlatAdamWEMA:
                            lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, self.ema_decay, shadow=getattr(self.fp, "shadow", None))
         self.fp.epoch[0] += 1       # weights changed through raw pointers: the cached bf16 operands of THESE parameters are stale
         return self.norm            # device tensor; no host sync
+
+    # ---- checkpoint / resume (train_tokenizer.py:440-450 saves opt_vae / opt_disc / scheduler_*; train_dmd.py:577-590; train_diffusion.py:318-325) ----
+    def state_dict(self, param_order=None) -> dict:
+        """torch.optim.AdamW's layout, so that the entry is interchangeable with the reference's `opt_*` checkpoint entries:
+        {"state": {index: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [{..., "params": [indices]}]} with index = position of the parameter in
+        `param_order` (the reference builds its optimisers over `module.parameters()`, frozen ones included: they have no state) -- default: this
+        buffer's own order.  The LambdaLR position is the step counter (`scheduler_state_dict`)."""
+        order = list(param_order) if param_order is not None else self.fp.params
+        index = {id(p): i for i, p in enumerate(order)}
+        state = {}
+        for p, off in zip(self.fp.params, self.fp.offsets):
+            if self.t > 0:
+                n = p.numel()
+                state[index[id(p)]] = {"step": torch.tensor(float(self.t)), "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                                       "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        group = {"lr": self.current_lr(), "initial_lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(order)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: dict, param_order=None) -> None:
+        """Inverse of `state_dict` (also accepts a reference `torch.optim.AdamW.state_dict()` taken over `param_order`)."""
+        order = list(param_order) if param_order is not None else self.fp.params
+        index = {id(p): i for i, p in enumerate(order)}
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for p, off in zip(self.fp.params, self.fp.offsets):
+            st = sd["state"].get(index[id(p)])
+            if st is None:
+                continue
+            n = p.numel()
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"FlatAdamWEMA.load_state_dict: parameters carry different step counts {sorted(steps)}; one fused update has one counter")
+        self.t = steps.pop() if steps else 0
+        g = sd["param_groups"][0]
+        self.lr = g.get("initial_lr", self.lr)
+        self.betas, self.eps, self.wd = tuple(g.get("betas", self.betas)), g.get("eps", self.eps), g.get("weight_decay", self.wd)
+
+    def scheduler_state_dict(self) -> dict:
+        """What torch's LambdaLR.state_dict() carries that matters on resume: the number of completed scheduler steps."""
+        return {"last_epoch": self.t, "base_lrs": [self.lr], "_last_lr": [self.current_lr()]}

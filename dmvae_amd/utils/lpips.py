@@ -8,6 +8,8 @@ argument's features in one pass over NHWC bf16 features).  The VGG16 trunk (SURV
 implicit-GEMM conv kernel as the decoder (ReLU epilogue, NHWC bf16, both LPIPS branches batched as one pass), with HIP
 2x2 max pools; its backward is hand-scheduled (`_VggLpips`).  torchvision is not installed here, so the 'D' layer list is built
 locally; pretrained trunk weights must be loaded from a checkpoint -- they are not downloadable offline."""
+import warnings
+
 import torch
 import torch.nn as nn
 
@@ -56,9 +58,48 @@ class vgg16(nn.Module):
                 c = v
                 idx += 2
         self.slice1, self.slice2, self.slice3, self.slice4, self.slice5 = slices
+        # The reference takes the trunk from torchvision's `vgg16(pretrained=True)` (utils/lpips.py:119) -- its ckpt_vae/vgg.pth holds only the five
+        # lin*.model.1.weight tensors.  torchvision is not installed in this image and there is no network: `trunk_loaded` stays False until
+        # `load_trunk()` (or a state_dict that carries net.slice*) supplies the weights, and LPIPS warns / raises on use accordingly.
+        self.trunk_loaded = False
+        if pretrained:
+            try:
+                import torchvision                                                            # noqa: F401
+                tv = torchvision.models.vgg16(weights=torchvision.models.VGG16_Weights.IMAGENET1K_V1)
+                self.load_torchvision_features(tv.features.state_dict())
+            except Exception as e:                                                            # ImportError offline, URLError without network, ...
+                import os
+                if os.environ.get("DMVAE_LPIPS_RANDOM_TRUNK", "0") in ("", "0"):
+                  warnings.warn("LPIPS: torchvision's pretrained VGG16 trunk is not available here (%s: %s); the trunk is RANDOMLY initialised until "
+                              "LPIPS.load_trunk(path) loads torchvision-layout (`features.N.weight/bias`) or net.slice* weights"
+                              % (type(e).__name__, str(e)[:80]), stacklevel=3)
         if not requires_grad:
             for p in self.parameters():
                 p.requires_grad = False
+
+    def load_torchvision_features(self, sd: dict) -> None:
+        """torchvision VGG16 `features` state_dict ({"N.weight", "N.bias"} or {"features.N.weight", ...}, N = the layer index 0..28 the reference's
+        slices also use, utils/lpips.py:126-135) -> net.slice{k}.{N}.*; every one of the 13 convolutions must be present."""
+        own = {}
+        for k in range(1, 6):
+            for idx, m in getattr(self, f"slice{k}").named_children():
+                if isinstance(m, nn.Conv2d):
+                    own[int(idx)] = m
+        got = {}
+        for name, t in sd.items():
+            parts = name.split(".")
+            if parts[0] == "features":
+                parts = parts[1:]
+            if len(parts) == 2 and parts[0].isdigit() and parts[1] in ("weight", "bias"):
+                got[(int(parts[0]), parts[1])] = t
+        missing = [f"features.{i}.{w}" for i in sorted(own) for w in ("weight", "bias") if (i, w) not in got]
+        if missing:
+            raise KeyError(f"VGG16 trunk weights incomplete: missing {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        with torch.no_grad():
+            for i, m in own.items():
+                m.weight.copy_(got[(i, "weight")])
+                m.bias.copy_(got[(i, "bias")])
+        self.trunk_loaded = True
 
     def forward(self, x):
         outs = []
@@ -144,25 +185,66 @@ class _VggLpips(torch.autograd.Function):
 
 
 class LPIPS(nn.Module):
-    def __init__(self, ckpt_path=None, use_dropout=True):
+    def __init__(self, ckpt_path=None, use_dropout=True, trunk_path=None):
+        """ckpt_path: the reference's vgg.pth (lin layers; may also carry net.slice*).  trunk_path (not in the reference's signature, optional): a
+        torchvision VGG16 checkpoint / `features` state_dict for offline use, see `load_trunk`."""
         super().__init__()
         self.scaling_layer = ScalingLayer()
         self.chns = [64, 128, 256, 512, 512]
-        self.net = vgg16(pretrained=True, requires_grad=False)
+        with warnings.catch_warnings():
+            if trunk_path is not None:
+                warnings.simplefilter("ignore")                  # the trunk is about to be loaded explicitly
+            self.net = vgg16(pretrained=True, requires_grad=False)
         self.lin0 = NetLinLayer(self.chns[0], use_dropout=use_dropout)
         self.lin1 = NetLinLayer(self.chns[1], use_dropout=use_dropout)
         self.lin2 = NetLinLayer(self.chns[2], use_dropout=use_dropout)
         self.lin3 = NetLinLayer(self.chns[3], use_dropout=use_dropout)
         self.lin4 = NetLinLayer(self.chns[4], use_dropout=use_dropout)
+        if trunk_path is not None:
+            self.load_trunk(trunk_path)
         if ckpt_path is not None:
             self.load_from_pretrained(ckpt_path)
         for param in self.parameters():
             param.requires_grad = False
 
+    def load_trunk(self, path_or_state_dict) -> None:
+        """VGG16 trunk weights from a torchvision checkpoint (`vgg16-*.pth`: keys features.N.*, classifier.* ignored), a bare `features` state_dict, or
+        a dict in this module's own layout (net.slice{k}.{N}.* / slice{k}.{N}.*)."""
+        sd = path_or_state_dict
+        if not isinstance(sd, dict):
+            sd = torch.load(sd, map_location="cpu", weights_only=True)
+        own_layout = {k.split("net.", 1)[-1]: v for k, v in sd.items() if "slice" in k}
+        if own_layout:
+            res = self.net.load_state_dict(own_layout, strict=False)
+            if res.missing_keys:
+                raise KeyError(f"VGG16 trunk weights incomplete: missing {res.missing_keys[:4]}")
+            self.net.trunk_loaded = True
+        else:
+            self.net.load_torchvision_features(sd)
+
     def load_from_pretrained(self, ckpt_path=None, name="vgg_lpips"):
-        self.load_state_dict(torch.load(ckpt_path, map_location=torch.device("cpu"), weights_only=True), strict=False)
+        """utils/lpips.py:75-78 (`strict=False`).  The reference's file carries the lin layers only; what `strict=False` skipped is inspected instead of
+        ignored: missing lin weights are an error, a missing trunk is reported once (it must come from torchvision / `load_trunk`)."""
+        sd = torch.load(ckpt_path, map_location=torch.device("cpu"), weights_only=True)
+        res = self.load_state_dict(sd, strict=False)
+        lin_missing = [k for k in res.missing_keys if k.startswith("lin")]
+        if lin_missing:
+            raise KeyError(f"LPIPS checkpoint {ckpt_path} lacks the linear layers {lin_missing}")
+        if not any(k.startswith("net.slice") for k in res.missing_keys):
+            self.net.trunk_loaded = True
+        elif not self.net.trunk_loaded:
+            import os
+            if os.environ.get("DMVAE_LPIPS_RANDOM_TRUNK", "0") in ("", "0"):
+              warnings.warn(f"LPIPS: {ckpt_path} holds no VGG16 trunk ({sum(k.startswith('net.slice') for k in res.missing_keys)} net.slice* tensors missing) and no "
+                          "pretrained trunk was loaded: the perceptual loss would run on RANDOM features. Call LPIPS.load_trunk(<torchvision vgg16 .pth>) "
+                          "or pass trunk_path=...; set DMVAE_LPIPS_RANDOM_TRUNK=1 to accept a random trunk (benchmarks, synthetic tests)", stacklevel=2)
 
     def forward(self, input, target):
         if not (input.is_cuda and target.is_cuda):
             raise ops._lib.DmvaeHipError("LPIPS: expected GPU tensors; dmvae_amd has no CPU path")
         return _VggLpips.apply(input, target, self)
+
+    @property
+    def trunk_loaded(self) -> bool:
+        """True once the VGG16 trunk holds loaded (not randomly initialised) weights."""
+        return bool(self.net.trunk_loaded)

@@ -269,3 +269,81 @@ def test_step_small_vs_reference_capture(allow_stock):
     ema = {by_id[id(q)]: e.detach().cpu() for q, e in zip(tr.fp.params, tr.fp.ema_state())}
     assert sorted(ema) == sorted(names)
     check_step_small(g, logs, p0, p1, ema, names, steps - 1, tol_loss=2e-2, tol_norm=5e-2, tol_abs_delta=5e-2, tol_signed=0.25, min_cos=0.9, tol_ema=0.5)
+
+
+class _ModeRecordingVelocity(_TinyVelocity):
+    """_TinyVelocity that records (module.training, torch.is_grad_enabled()) at every call."""
+
+    def __init__(self):
+        super().__init__()
+        self.calls = []
+
+    def forward(self, xt, t, y):
+        self.calls.append((self.training, torch.is_grad_enabled()))
+        return super().forward(xt, t, y)
+
+
+def test_dmd_trainer_student_modes_and_adversarial_branch():
+    """train_dmd.py:534 / :561-562: the student is in EVAL mode (no label dropout) for the no-grad velocity evaluations of the DMD loss and in TRAIN mode
+    for its own flow-matching turn, whatever mode the caller left it in; :244-256 / :546-556: with a discriminator attached the VAE turn carries the
+    adaptive-weight adversarial term and the discriminator takes its own step, from `disc_start_step` on."""
+    from dmvae_amd.models.init_param import init_weights
+    from dmvae_amd.models.patchgan import NLayerDiscriminator
+    from dmvae_amd.models.vae import VAE
+    from dmvae_amd.train import DMDTrainer
+    torch.manual_seed(31)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=256, depth=1, num_heads=4)).cuda()
+    teacher, student = _TinyVelocity().cuda().requires_grad_(False), _ModeRecordingVelocity().cuda()
+    disc = NLayerDiscriminator()
+    init_weights(disc, 0.02)
+    disc = disc.cuda()
+    d0 = torch.cat([p.detach().flatten() for p in disc.parameters()]).clone()
+    tr = DMDTrainer(vae, None, teacher, student, dmd_weight=5.0, dmd_cfg_scale=2.0, num_classes=10, vae_train_every=2, warmup_steps=1, disc=disc,
+                    disc_weight=0.5, disc_start_step=2)
+    images = torch.rand(2, 3, 256, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0)) * 2 - 1
+    labels = torch.tensor([3, 7], device="cuda")
+    student.eval()                                     # the reference's pre-loop state (train_dmd.py:501)
+    tr.step(images, labels)                            # step 0: VAE turn (DMD: two student evaluations with CFG), then the student's turn
+    assert student.calls == [(False, False), (False, False), (True, True)], student.calls
+    assert tr.read_log()["d_weight"] == 0.0 and torch.equal(torch.cat([p.detach().flatten() for p in disc.parameters()]), d0)    # before disc_start_step
+    student.calls.clear()
+    tr.step(images, labels)                            # step 1: student only
+    assert student.calls == [(True, True)]
+    student.calls.clear()
+    tr.step(images, labels)                            # step 2: VAE turn again, adversarial branch active now
+    assert student.calls == [(False, False), (False, False), (True, True)], student.calls
+    log, dlog = tr.read_log(), tr.read_disc_log()
+    assert log["d_weight"] > 0 and dlog["d_loss"] > 0 and dlog["disc_norm"] > 0
+    assert all(v == v and abs(v) < 1e6 for v in log.values())
+    tr.step(images, labels)
+    tr.step(images, labels)                            # step 4: second discriminator step (the first ran at warm-up lr 0)
+    assert not torch.equal(torch.cat([p.detach().flatten() for p in disc.parameters()]), d0)
+    ck = tr.checkpoint()
+    assert set(ck) >= {"model", "vae_wo_ddp", "disc_wo_ddp", "opt_sit", "opt_vae", "opt_disc", "steps"} and ck["steps"] == 5
+
+
+def test_tokenizer_trainer_checkpoint_resume_is_bit_exact():
+    """checkpoint() -> load() into a trainer built from OTHER weights: the continued run equals the uninterrupted one bit for bit (weights, EMA, both
+    Adam moments, warm-up position), and the optimiser entry loads into torch.optim.AdamW over vae.parameters() like the reference's opt_vae."""
+    images = torch.rand(2, 3, 256, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0)) * 2 - 1
+    a = _trainer(True, seed=3, with_lpips=False)
+    for _ in range(3):
+        a.step(images)
+    ck = a.checkpoint()
+    assert set(ck) >= {"vae_wo_ddp", "vae_ema", "opt_vae", "scheduler_vae", "steps"} and ck["steps"] == 3 and ck["scheduler_vae"]["last_epoch"] == 3
+    for _ in range(2):
+        a.step(images)
+    b = _trainer(True, seed=11, with_lpips=False)
+    assert not torch.equal(a.fp.flat, b.fp.flat)
+    b.load(ck)
+    assert b.global_step == 3 and b.opt.t == 3
+    for _ in range(2):
+        b.step(images)
+    assert torch.equal(a.fp.flat, b.fp.flat) and torch.equal(a.fp.ema, b.fp.ema)
+    assert torch.equal(a.opt.exp_avg, b.opt.exp_avg) and torch.equal(a.opt.exp_avg_sq, b.opt.exp_avg_sq)
+    ref_opt = torch.optim.AdamW(list(a.vae.parameters()), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.005)
+    ref_opt.load_state_dict(ck["opt_vae"])                       # the reference's resume path accepts the entry
+    p_last = list(a.vae.parameters())[-1]
+    assert float(ref_opt.state[p_last]["step"]) == 3.0

@@ -115,3 +115,76 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_flat_adamw_state_dict_is_torch_adamw_layout():
+    """FlatAdamWEMA.state_dict(param_order) is what torch.optim.AdamW.state_dict() holds for the same parameters (the reference's opt_vae / opt_disc /
+    opt_sit / opt checkpoint entries): indices follow `module.parameters()`, frozen parameters carry no state, and it round-trips."""
+    import torch
+    from dmvae_amd.optim import FlatAdamWEMA, FlatParams
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.Linear(8, 8), torch.nn.Linear(8, 2))
+    for p in net[1].parameters():
+        p.requires_grad_(False)                                  # frozen block in the middle
+    trainable = [p for p in net.parameters() if p.requires_grad]
+    fp = FlatParams(list(reversed(trainable)), with_ema=False)   # the flat buffer's order differs from the module's
+    opt = FlatAdamWEMA(fp, lr=3e-4, weight_decay=0.01, warmup_steps=10)
+    opt.exp_avg.normal_(); opt.exp_avg_sq.uniform_(0.1, 1.0); opt.t = 4
+    sd = opt.state_dict(list(net.parameters()))
+    assert sorted(sd["state"]) == [0, 1, 4, 5] and sd["param_groups"][0]["params"] == list(range(6))
+    ref = torch.optim.AdamW(list(net.parameters()), lr=3e-4, betas=(0.9, 0.95), weight_decay=0.01)
+    ref.load_state_dict(sd)
+    w0 = list(net.parameters())[0]
+    assert float(ref.state[w0]["step"]) == 4.0 and ref.state[w0]["exp_avg"].shape == w0.shape
+    off = fp.offsets[[id(q) for q in fp.params].index(id(w0))]
+    assert torch.equal(ref.state[w0]["exp_avg"].reshape(-1), opt.exp_avg[off:off + w0.numel()])
+    # round trip through the reference optimiser's own state_dict
+    opt2 = FlatAdamWEMA(FlatParams(list(reversed(trainable)), with_ema=False), lr=1.0, warmup_steps=10)
+    opt2.load_state_dict(ref.state_dict(), list(net.parameters()))
+    assert opt2.t == 4
+    for q, o in zip(fp.params, fp.offsets):               # (the 16-byte alignment padding between tensors is not state)
+        assert torch.equal(opt2.exp_avg[o:o + q.numel()], opt.exp_avg[o:o + q.numel()]) and torch.equal(opt2.exp_avg_sq[o:o + q.numel()], opt.exp_avg_sq[o:o + q.numel()])
+    assert opt.scheduler_state_dict()["last_epoch"] == 4 and abs(opt.current_lr() - 3e-4 * 0.4) < 1e-12
+
+
+def test_lpips_reports_a_missing_trunk_and_loads_torchvision_layout(tmp_path, monkeypatch):
+    """The reference's vgg.pth holds only the five lin layers; its trunk comes from torchvision's pretrained VGG16 (utils/lpips.py:119), which is not
+    available offline.  `strict=False` must not hide that: a warning names the missing trunk, `trunk_loaded` says so, `load_trunk` maps
+    torchvision's features.N.* keys onto net.slice{k}.{N}.*, and a checkpoint without the lin layers is an error."""
+    import warnings
+    import pytest
+    import torch
+    from dmvae_amd.utils.lpips import LPIPS
+    monkeypatch.delenv("DMVAE_LPIPS_RANDOM_TRUNK", raising=False)
+    lin_only = {f"lin{i}.model.1.weight": torch.rand(1, c, 1, 1) for i, c in enumerate((64, 128, 256, 512, 512))}
+    ck = tmp_path / "vgg.pth"
+    torch.save(lin_only, ck)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        lp = LPIPS(ckpt_path=str(ck))
+    msgs = " | ".join(str(w.message) for w in rec)
+    assert "RANDOM" in msgs and "net.slice" in msgs and not lp.trunk_loaded
+    assert torch.equal(lp.lin2.model[1].weight, lin_only["lin2.model.1.weight"])
+    tv = {}
+    for k in range(1, 6):
+        for idx, m in getattr(lp.net, f"slice{k}").named_children():
+            if isinstance(m, torch.nn.Conv2d):
+                tv[f"features.{idx}.weight"], tv[f"features.{idx}.bias"] = torch.randn_like(m.weight), torch.randn_like(m.bias)
+    tv["classifier.0.weight"] = torch.zeros(2, 2)
+    assert len(tv) == 27
+    tvp = tmp_path / "vgg16-397923af.pth"
+    torch.save(tv, tvp)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        lp2 = LPIPS(ckpt_path=str(ck), trunk_path=str(tvp))
+    assert lp2.trunk_loaded and not rec
+    assert torch.equal(dict(lp2.net.slice3.named_children())["14"].weight, tv["features.14.weight"])
+    assert torch.equal(lp2.net.slice1[0].bias, tv["features.0.bias"])
+    del tv["features.28.bias"]
+    with pytest.raises(KeyError, match="features.28.bias"):
+        lp.load_trunk(tv)
+    torch.save({k: v for k, v in lin_only.items() if not k.startswith("lin4")}, ck)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(KeyError, match="lin4"):
+            LPIPS(ckpt_path=str(ck))
