@@ -155,9 +155,14 @@ def kl_mmd_roofline(dev):
     us = timed(lambda: ops.kl_mmd(z, y, need_grad=True), 50)
     byt = 3 * z.numel() * 4
     pairs = 32 * 3 * 256 * 256
-    out["fused_B32"] = {"shape": "G=32 n=m=256 d=32, value+grad", "us_per_call": round(us, 1), "algorithmic_MB": round(byt / 1e6, 2),
+    # VALU work per kernel evaluation with gradient: 32 FMA (a.b) + 32 FMA (sum w b) + ~14 (norm combine, five bandwidths by repeated squaring, weights)
+    # + one v_exp_f32 (quarter rate: 4 issue slots) = ~82 f32 lane-operations; peak = 157.3 TFLOP/s / 2 = 78.6 T lane-FMA/s (MI355X_MICROARCH.md)
+    LANE_OPS_PER_PAIR, VALU_PEAK_TOPS = 82.0, 78.65
+    out["fused_B32"] = {"shape": "G=32 n=m=256 d=32, value+grad", "us_per_call": round(us, 1), "launches": 2, "algorithmic_MB": round(byt / 1e6, 2),
                         "achieved_GBps": round(byt / us / 1e3, 1), "hbm_frac": round(byt / us / 1e3 / HBM_PEAK, 4),
-                        "Gpair_per_s": round(pairs / us / 1e3, 1), "bound": "valu/exp + launch (5 launches), not HBM: see DESIGN.md 3.4"}
+                        "Gpair_per_s": round(pairs / us / 1e3, 1), "valu_Tlaneops_per_s": round(pairs * LANE_OPS_PER_PAIR / us / 1e6, 2),
+                        "valu_frac": round(pairs * LANE_OPS_PER_PAIR / us / 1e6 / VALU_PEAK_TOPS, 4),
+                        "bound": "valu/exp (3 MB of traffic against 6.3 M kernel evaluations), not HBM: see DESIGN.md 3.4"}
     zl = torch.randn(8192, 256, 32, device=dev)       # 268 MB
     us = timed(lambda: ops.kl_mmd(zl, None, need_grad=True), 10)
     byt = 3 * zl.numel() * 4
@@ -172,7 +177,8 @@ def kl_mmd_roofline(dev):
     pairs = 1024 * 3 * 256 * 256
     out["fused_B1024"] = {"shape": "G=1024 n=m=256 d=32, value+grad", "us_per_call": round(us, 1), "algorithmic_MB": round(byt / 1e6, 1),
                           "achieved_GBps": round(byt / us / 1e3, 1), "hbm_frac": round(byt / us / 1e3 / HBM_PEAK, 4),
-                          "Gpair_per_s": round(pairs / us / 1e3, 1), "bound": "valu/exp"}
+                          "Gpair_per_s": round(pairs / us / 1e3, 1), "valu_Tlaneops_per_s": round(pairs * LANE_OPS_PER_PAIR / us / 1e6, 2),
+                          "valu_frac": round(pairs * LANE_OPS_PER_PAIR / us / 1e6 / VALU_PEAK_TOPS, 4), "bound": "valu/exp"}
     return out
 
 

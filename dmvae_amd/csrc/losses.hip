@@ -8,6 +8,7 @@
 #include "common.h"
 #include "dmvae_hip.h"
 #include <float.h>
+#include <cstdlib>
 
 namespace dmvae_loss {
 
@@ -288,19 +289,24 @@ __global__ __launch_bounds__(1024) void kl_final_kernel(const float* __restrict_
 // Outputs: ksum[g][tile] = sum of k over the tile (fixed order), gpart[type][g][row][:] = a*SW - SB = sum_j w (a - b_j).
 template <bool GRAD>
 __global__ __launch_bounds__(256, 2) void mmd_pair_kernel(const float* __restrict__ z, const float* __restrict__ y, float* __restrict__ ksum,
-                                                       float* __restrict__ gpart, int n, int m, int tiles_x, int tiles_y) {
+                                                       float* __restrict__ gpart, float* __restrict__ klpart, int n, int m, int tiles_x, int tiles_y,
+                                                       int csplit) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* cols = sm;                          // [MMD_CCH][32]
   float* cnorm = sm + MMD_CCH * MMD_D;       // [MMD_CCH]
   constexpr int SCR = 2 * MMD_ROWS * 34 > MMD_CCH * MMD_D + MMD_CCH ? 2 * MMD_ROWS * 34 : MMD_CCH * MMD_D + MMD_CCH;
   float* sc = sm + SCR;                      // [MMD_NQ] tile-sum scalars, above both uses of the region below
   float* red = sm;                           // [2][MMD_ROWS][34] gradient scratch, aliases cols/cnorm once the sweep is over
-  const int g = blockIdx.y, tile = blockIdx.x;
+  // csplit > 1 (small problems only): the columns of a (group, type, row tile) are shared out over `csplit` workgroups so that a 32-image batch still
+  // puts two waves on every SIMD; each writes its own partial sums, combined in fixed order by kl_mmd_finish_kernel
+  const int g = blockIdx.y, tile = blockIdx.x / csplit, cs = blockIdx.x - tile * csplit;
   const int type = tile < tiles_x ? 0 : (tile < 2 * tiles_x ? 1 : 2);
   const int rt = type == 0 ? tile : (type == 1 ? tile - tiles_x : tile - 2 * tiles_x);
   const float* rsrc = type == 2 ? y + (size_t)g * m * MMD_D : z + (size_t)g * n * MMD_D;
   const float* csrc = type == 0 ? z + (size_t)g * n * MMD_D : y + (size_t)g * m * MMD_D;
-  const int nrows = type == 2 ? m : n, ncols = type == 0 ? n : m;
+  const int nrows = type == 2 ? m : n, ncols_all = type == 0 ? n : m;
+  const int cper = csplit > 1 ? ((ncols_all + csplit - 1) / csplit + 3) & ~3 : ncols_all;      // columns of this workgroup: [cbeg, cend)
+  const int cbeg = min(cs * cper, ncols_all), ncols = min(cbeg + cper, ncols_all);
   const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r0 = rt * MMD_ROWS + lane, r1 = r0 + 64;
 
@@ -315,6 +321,25 @@ __global__ __launch_bounds__(256, 2) void mmd_pair_kernel(const float* __restric
       na0 += v0[e] * v0[e]; na1 += v1[e] * v1[e];
     }
   }
+  // Fused path (klpart != null): the x-x blocks already hold their 128 rows of z in registers, in every wave -- wave q reduces channels 8q .. 8q+7
+  // of this tile to (sum, sum of squares) for the KL moments, so that no separate pass over z is launched (rows past the end were loaded as 0).
+  if (klpart && type == 0 && cs == 0) {
+    float ms = 0.f, mss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int c = q * 8 + e;
+      float su = 0.f, sq = 0.f;
+#pragma unroll
+      for (int k = 0; k < MMD_D; k++)      // compile-time register index: select channel c = 8q + e without dynamic indexing
+        if (k == c) { su = a0[k] + a1[k]; sq = a0[k] * a0[k] + a1[k] * a1[k]; }
+      su = wave_sum(su); sq = wave_sum(sq);
+      if (lane == e) { ms = su; mss = sq; }
+    }
+    if (lane < 8) {
+      float* o = klpart + ((size_t)(g * tiles_x + rt) * MMD_D + q * 8 + lane) * 2;
+      o[0] = ms; o[1] = mss;
+    }
+  }
   float s0 = 0.f, s1 = 0.f, sw0 = 0.f, sw1 = 0.f;
   float sb0[GRAD ? MMD_D : 1], sb1[GRAD ? MMD_D : 1];
   if (GRAD) {
@@ -323,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void mmd_pair_kernel(const float* __restric
   }
   const float inv16d = 1.f / (16.f * MMD_D), invd = 1.f / (float)MMD_D;
 
-  for (int c0 = 0; c0 < ncols; c0 += MMD_CCH) {
+  for (int c0 = cbeg; c0 < ncols; c0 += MMD_CCH) {
     const int cc = min(MMD_CCH, ncols - c0);
     // stage the column chunk: 8 lanes x float4 per column row, squared norms by an 8-lane shuffle
     for (int i = threadIdx.x; i < MMD_CCH * 8; i += 256) {
@@ -336,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void mmd_pair_kernel(const float* __restric
       if (e4 == 0) cnorm[j] = p;
     }
     __syncthreads();
-    const int cpw = MMD_CCH / MMD_NQ;
+    const int cpw = (cc + MMD_NQ - 1) / MMD_NQ;      // a full chunk: 64 columns per wave
     const int j1 = min(cc, (q + 1) * cpw);
     // software-pipelined column fetch: column j+1 is in flight (LDS broadcast reads) while column j is evaluated
     f32x4 bq[MMD_D / 4];
@@ -409,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void mmd_pair_kernel(const float* __restric
       const float* s1p = red + (size_t)MMD_ROWS * 34 + r * 34;
       const float SW = s0p[32] + s1p[32];
       const float* ar = rsrc + (size_t)rg * MMD_D + ch * 16;
-      float* o = gpart + (((size_t)type * gridDim.y + g) * n + rg) * MMD_D + ch * 16;
+      float* o = gpart + ((((size_t)cs * 2 + type) * gridDim.y + g) * n + rg) * MMD_D + ch * 16;
 #pragma unroll
       for (int e = 0; e < 16; e++) o[e] = ar[e] * SW - (s0p[ch * 16 + e] + s1p[ch * 16 + e]);
     }
@@ -418,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void mmd_pair_kernel(const float* __restric
   if (threadIdx.x == 0) {
     float t = 0.f;
     for (int k = 0; k < MMD_NQ; k++) t += sc[k];
-    ksum[(size_t)g * gridDim.x + tile] = t;
+    ksum[(size_t)g * gridDim.x + blockIdx.x] = t;      // [g][tile][cs]
   }
 }
 
@@ -460,6 +485,75 @@ __global__ __launch_bounds__(256) void kl_mmd_grad_kernel(const float* __restric
 #pragma unroll
     for (int e = 0; e < 4; e++) o[e] = kscale * (mu[e] + slope[e] * (x[e] - mu[e])) + cxx * a[e] + cxy * b[e];
     __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dz) + i);
+  }
+}
+
+// Second (and last) launch of the fused path: every block reduces the per-tile moment partials to the 32 channel statistics itself (nparts <= 1024
+// rows of 64 floats, L2-resident, fixed order: every block arrives at bit-identical statistics), block 0 also writes kl[33], the statistics and
+// mmd[g]; then the gradient pass of kl_mmd_grad_kernel.
+__global__ __launch_bounds__(256) void kl_mmd_finish_kernel(const float* __restrict__ z, const float* __restrict__ gpart, const float* __restrict__ klpart,
+                                                            int nparts, const float* __restrict__ ksum, float* __restrict__ kl, float* __restrict__ stats_out,
+                                                            float* __restrict__ mmd, float* __restrict__ dz, int G, int n, int m, int tiles_x, int tiles_y,
+                                                            int csplit, float w_kl, float w_mmd) {
+  __shared__ double sh[4][64];
+  __shared__ float st[64];
+  const int cm = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  double a0 = 0.0, a1 = 0.0;
+  int p = pl;
+  for (; p + 4 < nparts; p += 8) { a0 += klpart[(size_t)p * 64 + cm]; a1 += klpart[(size_t)(p + 4) * 64 + cm]; }
+  for (; p < nparts; p += 4) a0 += klpart[(size_t)p * 64 + cm];
+  sh[pl][cm] = a0 + a1;
+  __syncthreads();
+  const double rows = (double)G * n;
+  double v = 0.0;
+  if (threadIdx.x < MMD_D) {
+    const int c = threadIdx.x;
+    const double s = (sh[0][2 * c] + sh[1][2 * c]) + (sh[2][2 * c] + sh[3][2 * c]);
+    const double ss = (sh[0][2 * c + 1] + sh[1][2 * c + 1]) + (sh[2][2 * c + 1] + sh[3][2 * c + 1]);
+    const double mu = s / rows;
+    double var = ss / rows - mu * mu;
+    if (var < 1e-30) var = 1e-30;
+    st[2 * c] = (float)mu; st[2 * c + 1] = (float)var;
+    v = 0.5 * (mu * mu + var - 1.0 - log(var));
+    if (blockIdx.x == 0) { kl[c] = (float)v; stats_out[2 * c] = (float)mu; stats_out[2 * c + 1] = (float)var; }
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 64) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (threadIdx.x == 0) kl[MMD_D] = (float)(v / MMD_D);
+    }
+    const int nt = (2 * tiles_x + tiles_y) * csplit;
+    for (int g = threadIdx.x; g < G; g += 256) {
+      double kxx = 0, kxy = 0, kyy = 0;
+      for (int t = 0; t < tiles_x * csplit; t++) { kxx += ksum[(size_t)g * nt + t]; kxy += ksum[(size_t)g * nt + tiles_x * csplit + t]; }
+      for (int t = 0; t < tiles_y * csplit; t++) kyy += ksum[(size_t)g * nt + 2 * tiles_x * csplit + t];
+      mmd[g] = (float)(kxx / ((double)n * n) + kyy / ((double)m * m) - 2.0 * kxy / ((double)n * m));
+    }
+  }
+  if (!dz) return;
+  __syncthreads();
+  const size_t total4 = (size_t)G * n * (MMD_D / 4);
+  const float cxx = -2.f / ((float)n * (float)n) * w_mmd / (float)G, cxy = 2.f / ((float)n * (float)m) * w_mmd / (float)G;
+  const float* gxx = gpart;
+  const float* gxy = gpart + (size_t)G * n * MMD_D;
+  const int c4 = (int)(threadIdx.x & 7) * 4;      // blockDim * gridDim is a multiple of 8: a thread keeps its channel quad
+  float mu[4], slope[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) { mu[e] = st[(c4 + e) * 2]; slope[e] = 1.f - 1.f / st[(c4 + e) * 2 + 1]; }
+  const float kscale = w_kl / ((float)G * (float)n) / (float)MMD_D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 x = reinterpret_cast<const f32x4*>(z)[i];
+    f32x4 a = reinterpret_cast<const f32x4*>(gxx)[i], b = reinterpret_cast<const f32x4*>(gxy)[i];
+    for (int k = 1; k < csplit; k++) {       // the column splits' partial gradients, fixed order
+      const f32x4 ak = reinterpret_cast<const f32x4*>(gxx + (size_t)k * 2 * G * n * MMD_D)[i], bk = reinterpret_cast<const f32x4*>(gxy + (size_t)k * 2 * G * n * MMD_D)[i];
+#pragma unroll
+      for (int e = 0; e < 4; e++) { a[e] += ak[e]; b[e] += bk[e]; }
+    }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e] = kscale * (mu[e] + slope[e] * (x[e] - mu[e])) + cxx * a[e] + cxy * b[e];
+    reinterpret_cast<f32x4*>(dz)[i] = o;
   }
 }
 
@@ -540,12 +634,23 @@ static inline void kl_mmd_plan(int groups, int n, int m, int* tx, int* ty, int* 
   size_t nb = (R + 255) / 256;  // >= 8 row sweeps per block
   *nmom = (int)(nb > 2048 ? 2048 : (nb < 1 ? 1 : nb));
 }
-// layout (floats): mom[nmom][32][2] | stats[64] | ksum[G][2tx+ty] | gpart[2][G][n][32]
+// Column split of the two-launch path: enough workgroups for two per CU (two waves per SIMD) on a 256-CU part, at most 4 splits; 1 otherwise.
+static inline int kl_mmd_csplit(int groups, int tx, int ty) {
+  const char* e = getenv("DMVAE_KLMMD_CSPLIT");
+  if (e && atoi(e) > 0) return atoi(e) > 4 ? 4 : atoi(e);
+  const long long blocks = (long long)groups * (2 * tx + ty);
+  if ((size_t)groups * tx > 1024 || blocks >= 512) return 1;
+  int cs = (int)((512 + blocks - 1) / blocks);
+  return cs > 4 ? 4 : cs;
+}
+// layout (floats): mom[nmom][32][2] | stats[64] | ksum[G][2tx+ty][cs] | gpart[cs][2][G][n][32]
 extern "C" size_t dmvae_kl_mmd_workspace(int groups, int n, int m) {
   if (groups <= 0 || n <= 0 || m < 0) return 0;
   int tx, ty, nmom;
   kl_mmd_plan(groups, n, m, &tx, &ty, &nmom);
-  return ((size_t)nmom * MMD_D * 2 + 64 + (size_t)groups * (2 * tx + ty) + (size_t)2 * groups * n * MMD_D) * sizeof(float);
+  const size_t nmom_ws = (size_t)nmom > (size_t)groups * tx ? (size_t)nmom : (size_t)groups * tx;     // the fused path keeps one partial row per x tile
+  const size_t cs = kl_mmd_csplit(groups, tx, ty);
+  return (nmom_ws * MMD_D * 2 + 64 + cs * groups * (2 * tx + ty) + cs * 2 * groups * n * MMD_D) * sizeof(float);
 }
 
 extern "C" int dmvae_kl_mmd(const void* z, const void* y, void* kl, void* mmd, void* dz, void* workspace, size_t workspace_bytes,
@@ -558,14 +663,24 @@ extern "C" int dmvae_kl_mmd(const void* z, const void* y, void* kl, void* mmd, v
   DMVAE_CHECK_ARG(workspace_bytes >= need, "kl_mmd: workspace too small (need %zu bytes, see dmvae_kl_mmd_workspace)", need);
   int tx, ty, nmom;
   kl_mmd_plan(groups, n, m, &tx, &ty, &nmom);
+  const size_t nmom_ws = (size_t)nmom > (size_t)groups * tx ? (size_t)nmom : (size_t)groups * tx;
   float* mom = (float*)workspace;
-  float* stats = mom + (size_t)nmom * MMD_D * 2;
+  float* stats = mom + nmom_ws * MMD_D * 2;
   float* ksum = stats + 64;
-  float* gpart = ksum + (size_t)groups * (2 * tx + ty);
-  hipLaunchKernelGGL(kl_moments_kernel, dim3(nmom), dim3(256), 0, stream, (const float*)z, mom, (size_t)groups * n);
-  DMVAE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(1024), 0, stream, mom, (float*)kl, stats, nmom, (double)groups * n);
-  DMVAE_CHECK_LAUNCH();
+  const int csplit_ws = kl_mmd_csplit(groups, tx, ty);
+  float* gpart = ksum + (size_t)csplit_ws * groups * (2 * tx + ty);
+  // Small problems (the training step's own shape: 32 images x 256 tokens) are launch-bound: two launches -- pair kernel with the KL moment partials
+  // folded in, then one finishing kernel -- instead of five.  Large ones keep the streaming moment pass (HBM-bound, its own roofline) and the
+  // single-block final reduce.  DMVAE_KLMMD_FUSED=0 forces the five-launch path (A/B, tests).
+  const char* fenv = getenv("DMVAE_KLMMD_FUSED");          // read per call (two getenv-free paths would need a second entry point; this one is not on the measured step)
+  const bool fused_ok = !(fenv && atoi(fenv) == 0);
+  const bool fused = fused_ok && !kl_only && (size_t)groups * tx <= 1024;
+  if (!fused) {
+    hipLaunchKernelGGL(kl_moments_kernel, dim3(nmom), dim3(256), 0, stream, (const float*)z, mom, (size_t)groups * n);
+    DMVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(1024), 0, stream, mom, (float*)kl, stats, nmom, (double)groups * n);
+    DMVAE_CHECK_LAUNCH();
+  }
   // cols + norms + tile scalars; the gradient scratch (2 x 128 x 34 floats = 34.8 KB) aliases cols + norms, the scalars sit above both
   if (kl_only) {
     if (dz) {
@@ -584,12 +699,23 @@ extern "C" int dmvae_kl_mmd(const void* z, const void* y, void* kl, void* mmd, v
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mmd_pair_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v);
     attr_done = true;
   }
-  const dim3 grid(2 * tx + ty, groups);
+  const int csplit = fused ? csplit_ws : 1;
+  const dim3 grid((2 * tx + ty) * csplit, groups);
+  float* klpart = fused ? mom : nullptr;
   if (dz)
-    hipLaunchKernelGGL(mmd_pair_kernel<true>, grid, dim3(256), lds_g, stream, (const float*)z, (const float*)y, ksum, gpart, n, m, tx, ty);
+    hipLaunchKernelGGL(mmd_pair_kernel<true>, grid, dim3(256), lds_g, stream, (const float*)z, (const float*)y, ksum, gpart, klpart, n, m, tx, ty, csplit);
   else
-    hipLaunchKernelGGL(mmd_pair_kernel<false>, grid, dim3(256), lds_v, stream, (const float*)z, (const float*)y, ksum, gpart, n, m, tx, ty);
+    hipLaunchKernelGGL(mmd_pair_kernel<false>, grid, dim3(256), lds_v, stream, (const float*)z, (const float*)y, ksum, gpart, klpart, n, m, tx, ty, csplit);
   DMVAE_CHECK_LAUNCH();
+  if (fused) {
+    size_t nb = dz ? ((size_t)groups * n * 8 + 1023) / 1024 : 1;      // four float4 per thread
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(kl_mmd_finish_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)z, gpart, klpart, groups * tx, ksum, (float*)kl, stats,
+                       (float*)mmd, (float*)dz, groups, n, m, tx, ty, csplit, w_kl, w_mmd);
+    DMVAE_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(mmd_final_kernel, dim3(groups), dim3(64), 0, stream, ksum, (float*)mmd, n, m, tx, ty);
   DMVAE_CHECK_LAUNCH();
   if (dz) {

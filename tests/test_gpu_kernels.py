@@ -358,9 +358,39 @@ def test_kl_mmd_ragged_tiles_and_chunks(shape):
     kl2, none, dz2 = ops.kl_mmd(z.to(DEV), None, w_kl=1.0)
     zr2 = z.double().requires_grad_(True)
     R.kl_moment(zr2)[1].backward()
-    assert none is None and torch.equal(kl2, kl) and rel_err(dz2.cpu(), zr2.grad) < 1e-5
+    assert none is None and rel_err(kl2, kl) < 1e-6 and rel_err(dz2.cpu(), zr2.grad) < 1e-5      # (KL-only: streaming moment pass; with y: moments folded into the pair kernel)
     kl3, mmd3, dz3 = ops.kl_mmd(z.to(DEV), y.to(DEV), w_kl=1.0, w_mmd=0.5)
     assert torch.equal(dz3, dz) and torch.equal(mmd3, mmd)          # deterministic
+
+
+def test_kl_mmd_two_launch_path_matches_five_launch_path(monkeypatch):
+    """At the training step's own shape (32 images x 256 tokens vs 256 prior samples) the op runs as TWO launches (pair kernel with the KL moment partials
+    folded in + one finishing kernel); DMVAE_KLMMD_FUSED=0 selects the five-launch path (streaming moment pass, single-block final, pair kernel, MMD
+    final, gradient pass).  Same results to f32 summation order (the two-launch path shares the columns of a row tile out over up to four workgroups at this size, so its
+    fixed summation order is a different one), both deterministic, both vs the f64 spec; with DMVAE_KLMMD_CSPLIT=1 the MMD part agrees bit for bit."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(3)
+    z = (torch.randn(32, 256, 32, generator=gen) * 0.8 + 0.1).to(DEV)
+    y = torch.randn(32, 256, 32, generator=gen).to(DEV)
+    monkeypatch.setenv("DMVAE_KLMMD_FUSED", "1")
+    kl_a, mmd_a, dz_a = ops.kl_mmd(z, y, w_kl=0.7, w_mmd=1.5)
+    kl_a2, mmd_a2, dz_a2 = ops.kl_mmd(z, y, w_kl=0.7, w_mmd=1.5)
+    assert torch.equal(kl_a, kl_a2) and torch.equal(mmd_a, mmd_a2) and torch.equal(dz_a, dz_a2)
+    monkeypatch.setenv("DMVAE_KLMMD_FUSED", "0")
+    kl_b, mmd_b, dz_b = ops.kl_mmd(z, y, w_kl=0.7, w_mmd=1.5)
+    assert rel_err(mmd_a, mmd_b) < 1e-6 and rel_err(kl_a, kl_b) < 1e-6 and rel_err(dz_a, dz_b) < 1e-6
+    zr = z.cpu().double().requires_grad_(True)
+    klr, klm = R.kl_moment(zr)
+    mr = R.mmd_rbf(zr, y.cpu().double())
+    (0.7 * klm + 1.5 * mr.mean()).backward()
+    assert rel_err(kl_a[:32].cpu(), klr) < 1e-4 and rel_err(mmd_a.cpu(), mr) < 1e-4 and rel_err(dz_a.cpu(), zr.grad) < 1e-4
+    _, mmd_v, none = ops.kl_mmd(z, y, need_grad=False)                     # value-only call on the two-launch path
+    monkeypatch.setenv("DMVAE_KLMMD_FUSED", "1")
+    kl_v, mmd_v2, none2 = ops.kl_mmd(z, y, need_grad=False)
+    assert none is None and none2 is None and rel_err(mmd_v, mmd_v2) < 1e-6 and rel_err(kl_v, kl_a) < 1e-6
+    monkeypatch.setenv("DMVAE_KLMMD_CSPLIT", "1")                         # no column split: same per-tile order as the five-launch path
+    _, mmd_c, dz_c = ops.kl_mmd(z, y, w_kl=0.7, w_mmd=1.5)
+    assert torch.equal(mmd_c, mmd_b) and rel_err(dz_c, dz_b) < 1e-6
 
 
 def test_adamw_ema_golden():
