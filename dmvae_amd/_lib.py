@@ -32,6 +32,9 @@ SIGNATURES = {
     "dmvae_softmax_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dmvae_transpose_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dmvae_pack_conv_weight": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "dmvae_subpixel_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dmvae_subpixel_weight_fold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dmvae_colsum_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_int, c_void_p]),
     "dmvae_sumpool2x2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_maxpool2x2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_maxpool2x2_relu_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

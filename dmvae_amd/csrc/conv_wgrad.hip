@@ -256,6 +256,22 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   }
 }
 
+static int colsum_launch(const bf16* dy, float* dbias, float* part, int M, int C, int accumulate, hipStream_t stream) {
+  int tp = 1, tps = 0;
+  while (tp < 64 && tp * 8 < C) { tp <<= 1; tps++; }
+  const int rows = 256 / tp;
+  int nparts = (M + rows * 8 - 1) / (rows * 8);   // >= 8 row iterations per block
+  if (nparts > 512) nparts = 512;
+  if (nparts < 1) nparts = 1;
+  const int rpb = (M + nparts - 1) / nparts;
+  nparts = (M + rpb - 1) / rpb;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nparts, (C + tp * 8 - 1) / (tp * 8)), dim3(256), 0, stream, dy, part, M, C, tps, rpb);
+  DMVAE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, part, dbias, nparts, C, accumulate);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
 static int pick_splits(int M, int tiles) {
   // aim for ~1024 workgroups, at least 8 K steps each
   int want = (1024 + tiles - 1) / tiles;
@@ -338,23 +354,17 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb + nb), dim3(256), 0, stream, w.slab, (float*)dw, splits, w.Cout, T, w.Cin, accumulate, rb,
                      w.slab + (size_t)splits * total, (float*)dbias, splits * pp_ntiles);
   DMVAE_CHECK_LAUNCH();
-  if (!bias_fused && dbias) {
-    float* part = w.slab + (size_t)splits * total;
-    int tp = 1, tps = 0;
-    while (tp < 64 && tp * 8 < w.Cout) { tp <<= 1; tps++; }
-    const int rows = 256 / tp;
-    int nparts = (w.M + rows * 8 - 1) / (rows * 8);   // >= 8 row iterations per block
-    if (nparts > 512) nparts = 512;
-    if (nparts < 1) nparts = 1;
-    const int rpb = (w.M + nparts - 1) / nparts;
-    nparts = (w.M + rpb - 1) / rpb;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nparts, (w.Cout + tp * 8 - 1) / (tp * 8)), dim3(256), 0, stream, w.dy, part, w.M,
-                       w.Cout, tps, rpb);
-    DMVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((w.Cout + 63) / 64), dim3(256), 0, stream, part, (float*)dbias, nparts, w.Cout, accumulate);
-    DMVAE_CHECK_LAUNCH();
-  }
+  if (!bias_fused && dbias) return colsum_launch(w.dy, (float*)dbias, w.slab + (size_t)splits * total, w.M, w.Cout, accumulate, stream);
   return 0;
+}
+
+// out[c] (+)= sum_r x[r][c] over a row-major bf16 matrix: the bias gradient on its own (callers that obtain the weight gradient with the operands'
+// roles exchanged -- the sub-pixel form of Upsample's conv -- cannot take it from dmvae_conv2d_nhwc_wgrad).  workspace >= 512 * cols * 4 bytes.
+extern "C" int dmvae_colsum_bf16(const void* x, void* out, void* workspace, size_t workspace_bytes, size_t rows, int cols, int accumulate,
+                                 hipStream_t stream) {
+  DMVAE_CHECK_ARG(x && out && workspace && rows > 0 && rows < (1ull << 31) && cols > 0 && cols % 8 == 0, "colsum_bf16: bad argument (cols must be a multiple of 8)");
+  DMVAE_CHECK_ARG(workspace_bytes >= (size_t)512 * cols * sizeof(float), "colsum_bf16: workspace too small (need 512 * cols * 4 bytes)");
+  return colsum_launch((const bf16*)x, (float*)out, (float*)workspace, (int)rows, cols, accumulate, stream);
 }
 
 // C[b][m][n] = alpha * sum_k A[b][k][m] * B[b][k][n]   (A: [K][M], B: [K][N] row-major bf16; C bf16 or f32)

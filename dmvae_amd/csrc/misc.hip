@@ -25,6 +25,42 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, bf16* __restri
   }
 }
 
+// ---- sub-pixel form of Upsample's conv (flux_ae.py:103-107: conv3x3(nearest-x2(x))) -----------------------------------
+// Output pixel (2y + py, 2x + px) of the 3x3 conv over the nearest-x2 image only ever sees the 2x2 source pixels
+// (y - 1 + py + a, x - 1 + px + b): taps that land on the same source pixel can be added up front.  In PyTorch terms
+//   conv2d(interpolate(x, 2, 'nearest'), W, padding=1)  ==  conv_transpose2d(x, WD, stride=2, padding=1)
+//   WD[ci][co][r][s] = sum_{ky in K(r)} sum_{kx in K(s)} W[co][ci][ky][kx],   K(r) = {k : 2 <= r + k <= 3}  (K(0)={2}, K(1)={1,2}, K(2)={0,1}, K(3)={0})
+// -- 16 taps per SOURCE pixel instead of 9 per OUTPUT pixel: 4/9 of the multiply-adds, forward, input gradient (a 4x4 stride-2 conv over dy
+// with WD) and weight gradient (that conv's weight gradient, folded back by the transpose of the map above) alike.
+__global__ void subpixel_weight_kernel(const float* __restrict__ w, float* __restrict__ wd, int cout, int cin) {
+  const size_t total = (size_t)cin * cout * 16;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int s = i & 3, r = (i >> 2) & 3;
+    const size_t q = i >> 4;
+    const int co = q % cout, ci = q / cout;
+    const float* src = w + ((size_t)co * cin + ci) * 9;
+    float v = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++)
+        if (r + ky >= 2 && r + ky <= 3 && s + kx >= 2 && s + kx <= 3) v += src[ky * 3 + kx];
+    wd[i] = v;
+  }
+}
+// dW[co][ci][ky][kx] (+)= sum_{r in {2-ky, 3-ky}} sum_{s in {2-kx, 3-kx}} dWD[ci][co][r][s]   (fixed order)
+__global__ void subpixel_fold_kernel(const float* __restrict__ dwd, float* __restrict__ dw, int cout, int cin, int accumulate) {
+  const size_t total = (size_t)cout * cin * 9;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int t = i % 9, ky = t / 3, kx = t - ky * 3;
+    const size_t q = i / 9;
+    const int ci = q % cin, co = q / cin;
+    const float* src = dwd + ((size_t)ci * cout + co) * 16;
+    const float v = (src[(2 - ky) * 4 + 2 - kx] + src[(2 - ky) * 4 + 3 - kx]) + (src[(3 - ky) * 4 + 2 - kx] + src[(3 - ky) * 4 + 3 - kx]);
+    dw[i] = accumulate ? dw[i] + v : v;
+  }
+}
+
 // ---- 2x2 sum pool (backward of nearest x2 upsample, flux_ae.py:104) ---------------------------
 __global__ void sumpool2x2_kernel(const bf16* __restrict__ dy, bf16* __restrict__ dx, int N, int H, int W, int C) {
   const int c8 = C / 8;
@@ -311,6 +347,19 @@ extern "C" int dmvae_pack_conv_weight(const void* w, void* out, int cout, int ci
   const size_t total = (size_t)rows_pad * T * cols_pad;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)w, (bf16*)out, cout, cin, T, rows_pad,
                      cols_pad, for_dgrad ? 1 : 0);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_subpixel_weight(const void* w, void* wd, int cout, int cin, hipStream_t stream) {
+  DMVAE_CHECK_ARG(w && wd && cout > 0 && cin > 0, "subpixel_weight: bad argument");
+  hipLaunchKernelGGL(subpixel_weight_kernel, dim3(grid_for((size_t)cin * cout * 16)), dim3(256), 0, stream, (const float*)w, (float*)wd, cout, cin);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int dmvae_subpixel_weight_fold(const void* dwd, void* dw, int cout, int cin, int accumulate, hipStream_t stream) {
+  DMVAE_CHECK_ARG(dwd && dw && cout > 0 && cin > 0, "subpixel_weight_fold: bad argument");
+  hipLaunchKernelGGL(subpixel_fold_kernel, dim3(grid_for((size_t)cin * cout * 9)), dim3(256), 0, stream, (const float*)dwd, (float*)dw, cout, cin, accumulate);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -32,10 +32,11 @@ def _epoch_of(w) -> int:
 
 
 def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad: int = 0, frozen: bool = False,
-           transposed: bool = False) -> torch.Tensor:
+           transposed: bool = False, subpixel: bool = False) -> torch.Tensor:
     """bf16 kernel operand of an f32 conv/linear weight, cached ON the parameter object until the weight changes
     (in-place updates bump ``_version``; raw-pointer optimisers call bump_weight_epoch, which `frozen` weights -- not owned
-    by any optimiser, e.g. the LPIPS trunk -- ignore)."""
+    by any optimiser, e.g. the LPIPS trunk -- ignore).  subpixel: the operand of the 4x4 stride-2 conv D that Upsample's
+    3x3 conv turns into (ops.subpixel_weight; for_dgrad=True then packs D's transpose, i.e. the FORWARD operand of the upsample conv)."""
     cache = getattr(w, "_dmvae_packed", None)
     if cache is None:
         cache = {}
@@ -43,12 +44,15 @@ def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad
             w._dmvae_packed = cache
         except AttributeError:      # non-leaf views etc.: no caching
             pass
-    key = (for_dgrad, rows_pad, cols_pad, transposed, parity.on())
+    key = (for_dgrad, rows_pad, cols_pad, transposed, parity.on(), subpixel)
     ver = (w.data_ptr(), w._version, -1 if frozen else _epoch_of(w))
     hit = cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
-    p = ops.pack_conv_weight(w.detach().contiguous(), for_dgrad, rows_pad, cols_pad)
+    src = w.detach().contiguous()
+    if subpixel:
+        src = ops.subpixel_weight(src)
+    p = ops.pack_conv_weight(src, for_dgrad, rows_pad, cols_pad)
     if transposed:       # [rows][taps*cols] -> [taps*cols][rows]: the B operand of the im2col convs' input-gradient GEMM
         p = p.view(p.shape[0], -1).t().contiguous()
     cache[key] = (ver, p)
@@ -151,20 +155,43 @@ class AttnBlockFn(torch.autograd.Function):
         return dx, dnw, dnb, dqw, dqb, dkw, dkb, dvw, dvb, dpw, dpb
 
 
+def _subpixel_upsample() -> bool:
+    """DMVAE_UPS_SUBPIXEL=0: Upsample's conv as nine taps per output pixel gathered from the half-resolution image (the first implementation; A/B runs).
+    Unset: on, except in the fp32 parity mode, which keeps the reference's own evaluation order (the layer agrees to 1e-4 either way --
+    tests/test_gpu_parity_fp32.py -- but the four-step Adam trajectory test amplifies any reordering of f32 sums past that bar); =1 forces it on there too."""
+    v = os.environ.get("DMVAE_UPS_SUBPIXEL", "")
+    return (not parity.on()) if v == "" else v != "0"
+
+
 class ConvFn(torch.autograd.Function):
-    """Plain conv (3x3 pad 1 or 1x1), optionally on the nearest-x2 upsampled input (flux_ae.py:103-107)."""
+    """Plain conv (3x3 pad 1 or 1x1), optionally on the nearest-x2 upsampled input (flux_ae.py:103-107).
+
+    The upsampled case runs in its sub-pixel form (include/dmvae_hip.h, dmvae_subpixel_weight): with WD the 4x4 weight obtained by adding the taps of W
+    that read the same source pixel, forward = the transposed 4x4 stride-2 conv of x with WD, input gradient = the 4x4 stride-2 conv of dy with WD,
+    weight gradient = that conv's weight gradient (operands' roles exchanged) folded back to 3x3 -- 16 taps per source pixel instead of 9 per output
+    pixel, 4/9 of the multiply-adds in all three; no upsampled tensor, no full-resolution input gradient to pool."""
 
     @staticmethod
     def forward(ctx, x, w, b, ks, upsample):
-        y = ops.conv2d_nhwc(x, packed(w), b, ks=ks, upsample=upsample)
+        sub = bool(upsample) and ks == 3 and _subpixel_upsample()
+        if sub:
+            y = ops.conv2d_nhwc(x, packed(w, True, subpixel=True), b, ks=4, stride=2, transposed=True)
+        else:
+            y = ops.conv2d_nhwc(x, packed(w), b, ks=ks, upsample=upsample)
         ctx.save_for_backward(x, w)
-        ctx.ks, ctx.upsample, ctx.bias_param = ks, upsample, b
+        ctx.ks, ctx.upsample, ctx.bias_param, ctx.sub = ks, upsample, b, sub
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = _c(dy)
+        if ctx.sub:
+            dwd, _ = ops.conv2d_nhwc_wgrad(x, dy, 4, need_bias=False, stride=2)          # D's weight gradient: D maps dy [N,2H,2W,Cout] to [N,H,W,Cin]
+            dw = ops.subpixel_weight_fold(dwd, dw_out=_dst(w))
+            db = ops.colsum(dy, out=_dst(ctx.bias_param)) if ctx.bias_param is not None else None
+            dx = ops.conv2d_nhwc(dy, packed(w, False, subpixel=True), ks=4, stride=2) if ctx.needs_input_grad[0] else None
+            return dx, dw, db, None, None
         dw, db = ops.conv2d_nhwc_wgrad(dy, x, ctx.ks, upsample=ctx.upsample, dw_out=_dst(w), db_out=_dst(ctx.bias_param))
         dx = None
         if ctx.needs_input_grad[0]:

@@ -77,6 +77,42 @@ def pack_conv_weight(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0
     return out
 
 
+def subpixel_weight(w: torch.Tensor) -> torch.Tensor:
+    """nn.Conv2d weight f32 [cout, cin, 3, 3] of Upsample's conv (flux_ae.py:101-107) -> WD f32 [cin, cout, 4, 4], the weight of the 4x4 stride-2
+    conv D (cout -> cin) with conv3x3(nearest-x2(x), W) == conv_transpose2d(x, WD, stride 2, padding 1)  (include/dmvae_hip.h: dmvae_subpixel_weight)."""
+    w = _req(w, f32, "weight")
+    cout, cin = w.shape[0], w.shape[1]
+    assert tuple(w.shape[2:]) == (3, 3), w.shape
+    wd = torch.empty(cin, cout, 4, 4, dtype=f32, device=w.device)
+    check(_lib.lib().dmvae_subpixel_weight(w.data_ptr(), wd.data_ptr(), cout, cin, _stream()), "subpixel_weight")
+    return wd
+
+
+def subpixel_weight_fold(dwd: torch.Tensor, dw_out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """dL/dWD f32 [cin, cout, 4, 4] -> dL/dW f32 [cout, cin, 3, 3] (the transpose of subpixel_weight's linear map)."""
+    dwd = _req(dwd, f32, "dwd")
+    cin, cout = dwd.shape[0], dwd.shape[1]
+    dw = dw_out if dw_out is not None else torch.empty(cout, cin, 3, 3, dtype=f32, device=dwd.device)
+    assert dw.is_contiguous() and dw.numel() == cout * cin * 9
+    check(_lib.lib().dmvae_subpixel_weight_fold(dwd.data_ptr(), dw.data_ptr(), cout, cin, int(accumulate), _stream()), "subpixel_weight_fold")
+    return dw
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """sum over all leading dimensions of x [..., C] -> f32 [C]: a conv's bias gradient on its own."""
+    c = x.shape[-1]
+    if x.dtype == f32 and parity.on():
+        s = parity.colsum(x.reshape(-1, c))
+        if out is None:
+            return s
+        return out.add_(s) if accumulate else out.copy_(s)
+    x = _req(x, bf16, "x")
+    out = out if out is not None else torch.empty(c, dtype=f32, device=x.device)
+    ws = workspace(512 * c * 4, x.device, slot="colsum")
+    check(_lib.lib().dmvae_colsum_bf16(x.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), x.numel() // c, c, int(accumulate), _stream()), "colsum_bf16")
+    return out
+
+
 def conv_out_size(h: int, w: int, ks: int, upsample: int = 0, stride: int = 1, transposed: bool = False):
     """Output height / width of dmvae_conv2d_nhwc_fwd for a descriptor (csrc/conv_fwd.hip::dmvae_conv_geometry)."""
     if ks == 4:

@@ -142,6 +142,23 @@ int dmvae_transpose_bf16(const void* src, void* dst, int batch, int rows, int co
  * Padding rows/cols are zero-filled. */
 int dmvae_pack_conv_weight(const void* w, void* out, int cout, int cin, int ks, int rows_pad, int cols_pad,
                            int for_dgrad, dmvae_stream_t stream);
+/* Sub-pixel form of Upsample's conv (models/flux_ae.py:103-107: conv3x3(F.interpolate(x, 2, 'nearest'))): output pixel (2y+py, 2x+px) only sees the 2x2
+ * source pixels around (y, x), so taps that land on one source pixel are added up front --
+ *   conv2d(interpolate(x,2), W, padding=1) == conv_transpose2d(x, WD, stride=2, padding=1),
+ *   WD[ci][co][r][s] = sum_{ky in K(r), kx in K(s)} W[co][ci][ky][kx],  K(r) = {k : 2 <= r+k <= 3}
+ * i.e. 16 taps per source pixel instead of 9 per output pixel (4/9 of the multiply-adds).  With D = the 4x4 stride-2 padding-1 conv whose weight is WD
+ * (Cout -> Cin):  forward  = conv2d_nhwc_fwd(x, pack(WD, for_dgrad=1), desc{ks 4, stride 2, transposed 1});
+ *                 dL/dx    = conv2d_nhwc_fwd(dy, pack(WD), desc{ks 4, stride 2});
+ *                 dL/dWD   = conv2d_nhwc_wgrad(dy := x, a := dy, desc{ks 4, stride 2}), dL/dW = subpixel_weight_fold(dL/dWD);
+ *                 dL/dbias = colsum_bf16(dy).
+ * w: f32 [cout][cin][3][3]; wd: f32 [cin][cout][4][4]. */
+int dmvae_subpixel_weight(const void* w, void* wd, int cout, int cin, dmvae_stream_t stream);
+/* dw[co][ci][ky][kx] (+)= sum_{r in {2-ky,3-ky}, s in {2-kx,3-kx}} dwd[ci][co][r][s] -- the transpose of the map above (f32, fixed order). */
+int dmvae_subpixel_weight_fold(const void* dwd, void* dw, int cout, int cin, int accumulate, dmvae_stream_t stream);
+/* out[c] (+)= sum_r x[r][c], x row-major bf16 [rows][cols], out f32 [cols]; two-stage, fixed order.  workspace >= 512*cols*4 bytes.
+ * The bias gradient of nn.Conv2d on its own (autograd's sum over N,H,W of the output gradient). */
+int dmvae_colsum_bf16(const void* x, void* out, void* workspace, size_t workspace_bytes, size_t rows, int cols, int accumulate,
+                      dmvae_stream_t stream);
 /* dx[n,h,w,c] = sum of the 2x2 block of dy[n,2h,2w,c]: backward of F.interpolate(scale=2,'nearest')
  * (flux_ae.py:104).  bf16, c%8==0. */
 int dmvae_sumpool2x2_nhwc(const void* dy, void* dx, int n, int h, int w, int c, dmvae_stream_t stream);

@@ -139,8 +139,24 @@ def attn_block(x: Tensor, p: P, pre: str, q: Q = None) -> Tensor:
     return _q(q, x + o)
 
 
+_SUBPIX = torch.tensor([[0., 0., 1.], [0., 1., 1.], [1., 1., 0.], [1., 0., 0.]])      # [r][k] = 1 when 2 <= r + k <= 3
+
+
+def subpixel_weight(w: Tensor) -> Tensor:
+    """W [cout, cin, 3, 3] -> WD [cin, cout, 4, 4] with conv2d(nearest_x2(x), W, padding=1) == conv_transpose2d(x, WD, stride=2, padding=1):
+    output pixel (2y+py, 2x+px) of flux_ae.py:103-107 only sees the 2x2 source pixels around (y, x), so the taps of W that read the same source
+    pixel are added up front (WD[ci][co][r][s] = sum over ky, kx with 2 <= r+ky <= 3, 2 <= s+kx <= 3).  This is how the HIP path evaluates the
+    layer (include/dmvae_hip.h: dmvae_subpixel_weight); the plain-f32 oracle below stays the reference's own two-step form."""
+    e = _SUBPIX.to(w.dtype)
+    return torch.einsum("rk,sl,oikl->iors", e, e, w)
+
+
 def upsample(x: Tensor, p: P, pre: str, q: Q = None) -> Tensor:
-    """flux_ae.py:103-107: nearest x2 then conv3x3."""
+    """flux_ae.py:103-107: nearest x2 then conv3x3.  With q (bf16 rounding at the HIP path's storage sites) the layer is evaluated the way the HIP path
+    evaluates it -- sub-pixel form, the bf16 rounding on the pre-added 4x4 weights -- which is the same function of (x, W) up to that rounding."""
+    if q is not None:
+        wd = _qw(q, subpixel_weight(p[pre + "conv.weight"]))
+        return _q(q, F.conv_transpose2d(_q(q, x), wd, p[pre + "conv.bias"], stride=2, padding=1))
     x = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
     return conv2d(x, p, pre + "conv", q)
 

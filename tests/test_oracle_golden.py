@@ -288,3 +288,25 @@ def test_kl_mmd_closed_forms():
     assert torch.allclose(R.mmd_rbf(x, y), R.mmd_rbf(y, x), atol=1e-6)
     a, b = R.mmd_rbf(x, y + 0.5), R.mmd_rbf(x, y + 1.5)
     assert (b > a).all() and (a > 0).all()
+
+
+def test_subpixel_identity():
+    """conv3x3(nearest_x2(x), W) == conv_transpose2d(x, WD, stride 2, padding 1) with WD = R.subpixel_weight(W) (the form the HIP path evaluates, flux_ae.py:103-107):
+    output, input gradient (= the 4x4 stride-2 conv of dy with WD) and weight gradient (through the linear map W -> WD) in fp64, and the golden of the layer."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 5, 6, 7, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(4, 5, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(4, generator=g, dtype=torch.float64)
+    dy = torch.randn(2, 4, 12, 14, generator=g, dtype=torch.float64)
+    y0 = F.conv2d(x.repeat_interleave(2, 2).repeat_interleave(2, 3), w, b, padding=1)
+    gx0, gw0 = torch.autograd.grad(y0, (x, w), dy)
+    wd = R.subpixel_weight(w)
+    y1 = F.conv_transpose2d(x, wd, b, stride=2, padding=1)
+    gx1, gw1 = torch.autograd.grad(y1, (x, w), dy)
+    assert rel_err(y1, y0) < 1e-13 and rel_err(gx1, gx0) < 1e-13 and rel_err(gw1, gw0) < 1e-13
+    assert rel_err(F.conv2d(dy, wd.detach(), stride=2, padding=1), gx0) < 1e-13
+    gold = load_golden("upsample")
+    p = gold.sub("p.")
+    yq = R.upsample(gold.t("x"), p, "", q=R.bf16_round)                    # sub-pixel form with bf16 rounding sites
+    assert rel_err(R.upsample(gold.t("x"), p, ""), gold.t("y")) < 1e-5 and rel_err(yq, gold.t("y")) < 2e-2
