@@ -37,6 +37,7 @@ struct Args {
   int N, Hi, Wi, Cin, Ho, Wo, Cout;
   int ks, act, M, ctiles, total;  // total = pixel tiles x cout tiles
   int so, pd, sd;                 // gather geometry (dmvae_conv_geometry): tap k of output o reads source (o * so - pd + k) / sd when that is an in-range integer
+  int Ml;                         // SUB: source pixels N * Hi * Wi (= output pixels of one parity class); M is set to the same value
   int stagger;                    // start delay per group of CUs, units of 64 cycles (0 = off)
   unsigned long long* dbg;  // optional per-block s_memtime stamps (dmvae_debug_timing), null in production
 };
@@ -73,7 +74,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // GEN: the general gather geometry (4x4 taps, output stride 2, zero-insertion sources) -- a separate instantiation, because its per-tile setup and per-K-tile
 // tap arithmetic cost the plain 3x3 / 1x1 kernel 13-19 % when compiled into it (measured in the step: 337 -> 382 us per launch).
-template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool OUT_F32, bool KO, bool GEN = false>
+// SUB: the transposed 4x4 stride-2 padding-1 conv (input gradient of the PatchGAN stride-2 convs, models/patchgan.py:125-133; and the FORWARD of Upsample's
+// conv in its sub-pixel form, flux_ae.py:103-107 / dmvae_subpixel_weight) decomposed by output parity: output pixel (2y + py, 2x + px) reads exactly the 2x2
+// source pixels (y - 1 + py + a, x - 1 + px + b) through taps (py + 2a, px + 2b) of the packed 16-tap operand -- four dense 2x2 convolutions writing
+// interleaved pixels.  As a zero-insertion gather (GEN, sd = 2) twelve of the sixteen taps of every output pixel are masked: 4x the MFMA work.  A pixel
+// tile holds output pixels of ONE parity class (wave-uniform tap set); the four classes of a source region are adjacent in the block order so that the
+// region is fetched into the XCD's L2 once.
+template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool OUT_F32, bool KO, bool GEN = false, bool SUB = false>
 __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__  // the host pass only needs the launch stub (hipcc drops the stub when it cannot digest the gfx950 body)
   constexpr int BM = TM / WM / 32, BP = TP / WP / 32;  // 32x32 accumulator blocks per wave
@@ -90,12 +97,14 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;
   const int wm = wave / WP, wp = wave % WP;
-  const int T = a.ks * a.ks;
+  static_assert(!SUB || (!UPS && !GEN && KO), "SUB: its own instantiation, chunk-outer K order");
+  const int T = SUB ? 4 : a.ks * a.ks;    // taps walked per output pixel
+  const int TW = SUB ? 16 : T;            // taps per cout row of the packed weights
   const int nchunk = a.Cin >> 5;
   const int nK = T * nchunk;
 
   // ---- descriptors ---------------------------------------------------------------------------------------------
-  const unsigned wbytes = (unsigned)a.Cout * T * a.Cin * 2u;
+  const unsigned wbytes = (unsigned)a.Cout * TW * a.Cin * 2u;
   const unsigned xbytes = (unsigned)a.N * a.Hi * a.Wi * a.Cin * 2u;
   // Non-UPS gathers: a lane's base is its tap-0 source (by, bx) = (o * so - pd) for sd = 1, ceil((o - pd) / 2) for the zero-insertion gather
   // (sd = 2: tap k then reads by + (k >> 1), and only when o - pd + k is even), which can sit up to SR rows / columns outside the image;
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   const int SR = GEN ? ((UPS || a.ks == 1) ? 0 : (a.sd == 2 ? 1 : a.pd)) : 1;
   const int sds = GEN && a.sd == 2 ? 1 : 0;
   const unsigned shift = GEN ? ((!UPS && a.ks != 1) ? (unsigned)(SR * a.Wi + SR) * a.Cin * 2u : 0u)
-                             : ((!UPS && a.ks == 3) ? (unsigned)(a.Wi + 1) * a.Cin * 2u : 0u);  // makes every tap offset >= 0
+                             : ((!UPS && (SUB || a.ks == 3)) ? (unsigned)(a.Wi + 1) * a.Cin * 2u : 0u);  // makes every tap offset >= 0
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, wbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB =
       __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.x) - shift), 0, xbytes + shift, 0x00020000);
@@ -113,10 +122,12 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   // block's tiles stay on one XCD's contiguous range of the XCD-aware order.  The per-tile address setup and the DMA of the
   // NEXT tile's first two K tiles are issued before the epilogue of the current tile, so the first-tile latency (3-8 k
   // cycles) hides under the store-bound epilogue (11-13 k cycles); the epilogue stages through ring slots 2.. for that.
-  const int hw = a.Ho * a.Wo;
-  const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)a.Wo;
+  const int dvw = SUB ? a.Wi : a.Wo;   // pixel index -> (image, row, column) of the OUTPUT grid; SUB: of the source grid (one parity class of the output)
+  const int hw = SUB ? a.Hi * a.Wi : a.Ho * a.Wo;
+  const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)dvw;
   const bool small_m = a.M < (1 << 24);
   int m0 = 0, n0 = 0;  // tile whose DMA sources are currently set up
+  int par = 0;         // SUB: output parity class (py << 1 | px) of that tile, wave-uniform
   unsigned voffA[NPA];
   unsigned ctrB[NPB], maskB[NPB], selB[NPB];
   unsigned rowo[UPS ? NPB : 1][3], colo[UPS ? NPB : 1][3];
@@ -124,15 +135,22 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   unsigned soffB_tap = 0;
   auto setup = [&](unsigned work) {
     const unsigned wid = xcd_remap(work, a.total);
-    m0 = (int)(wid / a.ctiles) * TP;  // first pixel
-    n0 = (int)(wid % a.ctiles) * TM;  // first cout
+    if constexpr (SUB) {  // order: source region, parity class, cout tile
+      const unsigned q = wid / a.ctiles;
+      n0 = (int)(wid - q * a.ctiles) * TM;
+      par = __builtin_amdgcn_readfirstlane((int)(q & 3u));  // feeds the weight soffset: keep it on the scalar unit
+      m0 = (int)(q >> 2) * TP;
+    } else {
+      m0 = (int)(wid / a.ctiles) * TP;  // first pixel
+      n0 = (int)(wid % a.ctiles) * TM;  // first cout
+    }
     it = it_tap = it_ch = 0;
 #pragma unroll
     for (int p = 0; p < NPA; p++) {
       const int row = (wave * NPA + p) * 16 + (lane >> 2);
       const int co = n0 + row;
       const int c = (lane & 3) ^ swz64(row);  // logical 16-B chunk this lane fetches (LDS image stays lane-linear)
-      voffA[p] = co < a.Cout ? (unsigned)co * T * a.Cin * 2u + c * 16u : SENT;
+      voffA[p] = co < a.Cout ? (unsigned)co * TW * a.Cin * 2u + c * 16u : SENT;
     }
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
@@ -144,9 +162,14 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     if (m < a.M) {
       int n, r, y, x;
       divmod_small(m, hw, inv_hw, small_m, n, r);
-      divmod_small(r, a.Wo, inv_wo, small_m, y, x);
+      divmod_small(r, dvw, inv_wo, small_m, y, x);
       int by = y, bx = x;
-      if (UPS || !GEN) {
+      if constexpr (SUB) {  // bit a*2+b set when source pixel (by + a, bx + b) is inside the image
+        by = y - 1 + (par >> 1); bx = x - 1 + (par & 1);
+        const unsigned rm = (by >= 0 ? 0x3u : 0u) | (by + 1 < a.Hi ? 0xCu : 0u);
+        const unsigned cm = (bx >= 0 ? 0x5u : 0u) | (bx + 1 < a.Wi ? 0xAu : 0u);
+        mask = rm & cm;
+      } else if (UPS || !GEN) {
         if (a.ks == 3) {  // bit ky*3+kx set when the tap stays inside the (upsampled) image
           const unsigned rm = (y > 0 ? 0x007u : 0u) | 0x038u | (y < a.Ho - 1 ? 0x1C0u : 0u);
           const unsigned cm = (x > 0 ? 0x049u : 0u) | 0x092u | (x < a.Wo - 1 ? 0x124u : 0u);
@@ -184,6 +207,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
         if (a.ks != 3) ctrB[p] = rowo[UPS ? p : 0][1] + colo[UPS ? p : 0][1];
       } else {
         if constexpr (GEN) ctrB[p] = (unsigned)((n * a.Hi + by + SR) * a.Wi + bx + SR) * a.Cin * 2u + c * 16u;
+        else if constexpr (SUB) ctrB[p] = (unsigned)((n * a.Hi + by + 1) * a.Wi + bx + 1) * a.Cin * 2u + c * 16u;
         else ctrB[p] = (unsigned)((n * a.Hi + y) * a.Wi + x) * a.Cin * 2u + c * 16u;
       }
     }
@@ -213,6 +237,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     if constexpr (GEN) {
       ky = a.ks == 3 ? it_tap / 3 : (a.ks == 4 ? it_tap >> 2 : 1); kx = a.ks == 3 ? it_tap - (it_tap / 3) * 3 : (a.ks == 4 ? it_tap & 3 : 1);
       soffB_tap = (!UPS && a.ks != 1) ? (unsigned)((ky >> sds) * a.Wi + (kx >> sds)) * a.Cin * 2u : 0u;
+    } else if constexpr (SUB) {
+      ky = it_tap >> 1; kx = it_tap & 1;
+      soffB_tap = (unsigned)(ky * a.Wi + kx) * a.Cin * 2u;
     } else {
       ky = a.ks == 3 ? it_tap / 3 : 1; kx = a.ks == 3 ? it_tap - (it_tap / 3) * 3 : 1;
       soffB_tap = (!UPS && a.ks == 3) ? (unsigned)(ky * a.Wi + kx) * a.Cin * 2u : 0u;
@@ -234,6 +261,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     const bool live = it < nK;
     if (live && (KO || it_ch == 0)) new_tap();
     unsigned soA = (unsigned)(it_tap * a.Cin + it_ch * 32) * 2u;
+    if constexpr (SUB)  // tap (py + 2a, px + 2b) of the 4x4 operand
+      soA = (unsigned)(((((par >> 1) + (it_tap & 2)) << 2) + (par & 1) + ((it_tap & 1) << 1)) * a.Cin + it_ch * 32) * 2u;
     unsigned soB = soffB_tap + (unsigned)it_ch * 64u;
     // GEN: the tap offset and the chunk counter end up in VGPRs (phis of VALU-computed values) and every piece issue became a readfirstlane
     // waterfall loop; pin the two wave-uniform offsets to SGPRs (the plain instantiation's code is unchanged)
@@ -266,6 +295,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   for (int u = 0; u < PF; u++) issue(u * SLOT);
   for (unsigned work = blockIdx.x; work < (unsigned)a.total;) {
   const int m0c = m0, n0c = n0;  // the tile being computed (setup() moves m0 / n0 on to the next one before the epilogue)
+  const int parc = par;
 #pragma unroll
   for (int i = 0; i < BM16; i++)
 #pragma unroll
@@ -349,11 +379,23 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       for (int j = 0; j < BP; j++) {
         // residual / gate operand of this pass: issued up front so the loads fly under the LDS transpose below
         bf16x8 r8s[32 / RPI];
+        unsigned opx[SUB ? 32 / RPI : 1];  // SUB: output pixel index of the lane's rows (parity-interleaved), else the row index itself
+        if constexpr (SUB) {
+#pragma unroll
+          for (int it2 = 0; it2 < 32 / RPI; it2++) {
+            const int m = m0c + wp * (TP / WP) + j * 32 + it2 * RPI + rg;
+            int n, r, y, x;
+            divmod_small(m, hw, inv_hw, small_m, n, r);
+            divmod_small(r, dvw, inv_wo, small_m, y, x);
+            opx[it2] = (unsigned)((n * a.Ho + 2 * y + (parc >> 1)) * a.Wo + 2 * x + (parc & 1));
+          }
+        }
         if (a.res) {
 #pragma unroll
           for (int it2 = 0; it2 < 32 / RPI; it2++) {
             const int m = m0c + wp * (TP / WP) + j * 32 + it2 * RPI + rg;
-            if (m < a.M && c_ok) r8s[it2] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(a.res + (size_t)m * a.Cout + cb));
+            const size_t mo = SUB ? (size_t)opx[SUB ? it2 : 0] : (size_t)m;
+            if (m < a.M && c_ok) r8s[it2] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(a.res + mo * a.Cout + cb));
           }
         }
 #pragma unroll
@@ -372,7 +414,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] += bias8[e];
-            const size_t off = (size_t)m * a.Cout + cb;
+            const size_t off = (SUB ? (size_t)opx[SUB ? it2 : 0] : (size_t)m) * a.Cout + cb;
             if (a.res) {
               const bf16x8 r8 = r8s[it2];
               if (a.act == 3) {  // ReLU-backward gate: `res` is the saved activation, not an addend
@@ -420,21 +462,21 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #endif
 }
 
-template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32, bool KO, bool GEN = false>
+template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32, bool KO, bool GEN = false, bool SUB = false>
 int launch(Args a, hipStream_t st) {
   a.ctiles = (a.Cout + TM - 1) / TM;
-  a.total = ((a.M + TP - 1) / TP) * a.ctiles;
+  a.total = ((a.M + TP - 1) / TP) * a.ctiles * (SUB ? 4 : 1);
   static const int persist = [] { const char* e = getenv("DMVAE_PP_GRID"); return e ? atoi(e) : 256; }();  // 0: one block per tile
   const unsigned grid = (persist > 0 && a.total > persist) ? (unsigned)persist : (unsigned)a.total;
   constexpr int ring = NBUF * (TM + TP) * 64, epi = 2 * (TM + TP) * 64 + 8 * 32 * ((TM / WM / 2) * 4 + 16);
   constexpr int lds = ring > epi ? ring : epi;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN>), dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB>), dim3(grid), dim3(512), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -480,6 +522,8 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
   if (dmvae_conv_geometry(d, &ho, &wo, &so, &pd, &sd, &fl) != 0) return 1;
   const bool plain = !(d->upsample == 2 || d->stride == 2 || d->ks == 4 || d->transposed);
   if (!plain && !general) return 1;
+  static const bool subpix = [] { const char* e = getenv("DMVAE_PP_SUBPIXEL"); return e ? atoi(e) != 0 : true; }();  // 0: the zero-insertion gather (GEN)
+  const bool sub = subpix && d->transposed && d->ks == 4 && d->stride == 2;
   const int ups = fl ? 1 : 0;      // nearest x2 folded into the gather: its own template variant
   const long long M = (long long)d->n * ho * wo;
   const long long xbytes = (long long)d->n * d->h * d->w * d->cin * 2;
@@ -491,8 +535,14 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
   a.N = d->n; a.Hi = d->h; a.Wi = d->w; a.Cin = d->cin; a.Cout = d->cout;
   a.Ho = ho; a.Wo = wo; a.so = so; a.pd = pd; a.sd = sd;
   a.ks = d->ks; a.act = d->act; a.M = (int)M; a.ctiles = 0; a.dbg = g_dbg;
+  a.Ml = d->n * d->h * d->w;
   { static const int stag = [] { const char* e = getenv("DMVAE_PP_STAGGER"); return e ? atoi(e) : 0; }(); a.stagger = stag; }
   const bool f32 = d->out_f32 != 0;
+  if (sub) {  // per-parity 2x2 decomposition: pixel tiles run over the source grid, once per parity class
+    a.M = a.Ml;
+    if (a.Cout <= 128) return f32 ? launch<128, 512, 2, 4, 4, false, true, true, false, true>(a, stream) : launch<128, 512, 2, 4, 4, false, false, true, false, true>(a, stream);
+    return f32 ? launch<256, 256, 2, 4, 4, false, true, true, false, true>(a, stream) : launch<256, 256, 2, 4, 4, false, false, true, false, true>(a, stream);
+  }
   if (ups) return f32 ? pick<true, true>(a, stream, false) : pick<true, false>(a, stream, false);
   return f32 ? pick<false, true>(a, stream, !plain) : pick<false, false>(a, stream, !plain);
 }

@@ -47,6 +47,7 @@ _WS = {}
 # entries are (name, start_event, end_event, algorithmic_flops)
 KERNEL_TIMING = None
 _PP_KORDER = "false" if os.environ.get("DMVAE_PP_KORDER", "1") == "0" else "true"   # csrc/conv_pp.hip::pick
+_PP_SUBPIXEL = os.environ.get("DMVAE_PP_SUBPIXEL", "1") != "0"                        # csrc/conv_pp.hip::dmvae_conv_pp_try
 
 
 def workspace(nbytes: int, device, slot: str = "main") -> torch.Tensor:
@@ -158,15 +159,16 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
         e1.record()
         # which kernel dmvae_conv2d_nhwc_fwd dispatched to (csrc/conv_pp.hip::dmvae_conv_pp_try), so that the bench's per-kernel
         # average can be checked against rocprofv3's per-kernel-name average
+        sub = bool(transposed) and ks == 4 and stride == 2    # per-parity 2x2 decomposition: 4 of the 16 taps per output pixel are multiply-adds
         if cin % 32 == 0 and cout >= 64 and cout % 8 == 0 and n * ho * wo >= 16384:
             ups1 = int(upsample) == 1                  # nearest x2 folded into the gather: its own template variant
-            gen = int(upsample) == 2 or stride == 2 or ks == 4 or bool(transposed)       # the general-gather instantiation (chunk-outer K order only)
-            label = "conv_pp_kernel<%s, %s, %s, %s, %s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", "true" if ups1 else "false",
-                                                             "true" if out_f32 else "false", "false" if ups1 else ("true" if gen else _PP_KORDER),
-                                                             "true" if gen else "false")
+            gen = (int(upsample) == 2 or stride == 2 or ks == 4 or bool(transposed)) and not (sub and _PP_SUBPIXEL)   # the general-gather instantiation
+            label = "conv_pp_kernel<%s, %s, %s, %s, %s%s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", "true" if ups1 else "false",
+                                                               "true" if out_f32 else "false", "false" if ups1 else ("true" if gen else _PP_KORDER),
+                                                               "true" if gen else "false", ", true" if (sub and _PP_SUBPIXEL) else "")
         else:
             label = "conv_fwd_kernel"
-        timing.append((label, e0, e1, 2.0 * n * ho * wo * cout * cin * ks * ks))
+        timing.append((label, e0, e1, 2.0 * n * ho * wo * cout * cin * (4 if sub else ks * ks)))
     return y
 
 

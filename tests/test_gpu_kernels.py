@@ -378,7 +378,8 @@ def test_kl_mmd_two_launch_path_matches_five_launch_path(monkeypatch):
     assert torch.equal(kl_a, kl_a2) and torch.equal(mmd_a, mmd_a2) and torch.equal(dz_a, dz_a2)
     monkeypatch.setenv("DMVAE_KLMMD_FUSED", "0")
     kl_b, mmd_b, dz_b = ops.kl_mmd(z, y, w_kl=0.7, w_mmd=1.5)
-    assert rel_err(mmd_a, mmd_b) < 1e-6 and rel_err(kl_a, kl_b) < 1e-6 and rel_err(dz_a, dz_b) < 1e-6
+    # MMD^2 = kxx/n^2 + kyy/m^2 - 2 kxy/(n m) cancels ~two digits: 1e-7 on the three f32 sums shows as ~1e-5 on the difference
+    assert rel_err(mmd_a, mmd_b) < 5e-5 and rel_err(kl_a, kl_b) < 1e-6 and rel_err(dz_a, dz_b) < 1e-6
     zr = z.cpu().double().requires_grad_(True)
     klr, klm = R.kl_moment(zr)
     mr = R.mmd_rbf(zr, y.cpu().double())
@@ -387,7 +388,7 @@ def test_kl_mmd_two_launch_path_matches_five_launch_path(monkeypatch):
     _, mmd_v, none = ops.kl_mmd(z, y, need_grad=False)                     # value-only call on the two-launch path
     monkeypatch.setenv("DMVAE_KLMMD_FUSED", "1")
     kl_v, mmd_v2, none2 = ops.kl_mmd(z, y, need_grad=False)
-    assert none is None and none2 is None and rel_err(mmd_v, mmd_v2) < 1e-6 and rel_err(kl_v, kl_a) < 1e-6
+    assert none is None and none2 is None and rel_err(mmd_v, mmd_v2) < 5e-5 and rel_err(kl_v, kl_a) < 1e-6
     monkeypatch.setenv("DMVAE_KLMMD_CSPLIT", "1")                         # no column split: same per-tile order as the five-launch path
     _, mmd_c, dz_c = ops.kl_mmd(z, y, w_kl=0.7, w_mmd=1.5)
     assert torch.equal(mmd_c, mmd_b) and rel_err(dz_c, dz_b) < 1e-6
