@@ -294,7 +294,7 @@ extern "C" size_t dmvae_conv2d_nhwc_wgrad_workspace(const dmvae_conv_desc* d) {
   const int T = d->ks * d->ks;
   {
     int sp, kc, cfg;
-    if ((d->ks == 1 || d->ks == 3) && dmvae_wgrad_pp_plan(d, &sp, &kc, &cfg))
+    if (dmvae_wgrad_pp_plan(d, &sp, &kc, &cfg))
       return (size_t)sp * d->cout * T * d->cin * sizeof(float) + (size_t)4096 * d->cout * sizeof(float);  // + [splits*ntiles <= 4096][cout] bias partials
   }
   int ho = 0, wo = 0, g0, g1, g2, g3;

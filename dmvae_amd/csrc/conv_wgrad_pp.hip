@@ -22,6 +22,10 @@
 // A K tile is 32 consecutive pixels of one image row (the host only selects this kernel when W % 32 == 0), so the
 // zero-padding test is wave-uniform except for the first / last pixel of a row: per-lane sources are fixed for the
 // whole kernel and only the wave-uniform soffset advances.
+//
+// S2 instantiation: the 4x4 stride-2 padding-1 conv (models/patchgan.py:125-133; and, with the operands' roles exchanged, the weight gradient of Upsample's
+// conv in its sub-pixel form -- include/dmvae_hip.h, dmvae_subpixel_weight): tap (ky, kx) of output pixel (y, x) reads source (2y - 1 + ky, 2x - 1 + kx), so
+// a K tile's 32 pixels sit two source pixels apart (per-lane offsets doubled) and the row test reads 2y - 1 + ky; sixteen taps instead of nine.
 #include "common.h"
 #include "dmvae_hip.h"
 #include <cstdlib>
@@ -55,7 +59,7 @@ __device__ __forceinline__ s16x4 tr_read(const char* p) {
 }
 
 // GA / GB: 128-channel sub-tiles of the dy / activation operand per block; waves WM x WN.
-template <int GA, int GB, int WM, int WN>
+template <int GA, int GB, int WM, int WN, bool S2 = false>
 __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int TM = GA * 128, TN = GB * 128;
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   // ---- descriptors: dy is linear in the pixel index; the activation base is shifted so every tap offset is >= 0 -------
   const unsigned dybytes = (unsigned)a.M * a.Cout * 2u;
   const unsigned abytes = (unsigned)a.N * a.Hi * a.Wi * a.Cin * 2u;
-  const unsigned shift = (!a.ups && a.ks == 3) ? (unsigned)(a.Wi + 1) * a.Cin * 2u : 0u;
+  const unsigned shift = (S2 || (!a.ups && a.ks == 3)) ? (unsigned)(a.Wi + 1) * a.Cin * 2u : 0u;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, dybytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB =
       __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.a) - shift), 0, abytes + shift, 0x00020000);
@@ -117,11 +121,11 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     const int g = g0 + sub;
     const int tap = uni(g / a.gpt), ci = (g - tap * a.gpt) * 128 + clog;
     const bool ok = g < a.ngroups;
-    kyB[p] = a.ks == 3 ? uni(tap / 3) : 1;
-    kxB[p] = a.ks == 3 ? tap - (tap / 3) * 3 : 1;
-    tapoB[p] = (!a.ups && a.ks == 3) ? (unsigned)(kyB[p] * a.Wi + kxB[p]) * a.Cin * 2u : 0u;
+    kyB[p] = S2 ? tap >> 2 : (a.ks == 3 ? uni(tap / 3) : 1);
+    kxB[p] = S2 ? tap & 3 : (a.ks == 3 ? tap - (tap / 3) * 3 : 1);
+    tapoB[p] = (S2 || (!a.ups && a.ks == 3)) ? (unsigned)(kyB[p] * a.Wi + kxB[p]) * a.Cin * 2u : 0u;
     rowB[p] = row;
-    const unsigned v = a.ups ? (unsigned)ci * 2u : (unsigned)(row * a.Cin + ci) * 2u;
+    const unsigned v = S2 ? (unsigned)(2 * row * a.Cin + ci) * 2u : (a.ups ? (unsigned)ci * 2u : (unsigned)(row * a.Cin + ci) * 2u);
     voffB[p] = ok ? v : SENT;
     voffBL[p] = (ok && row != 0) ? v : SENT;
     voffBR[p] = (ok && row != 31) ? v : SENT;
@@ -190,12 +194,14 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
       const int pb = wave * NPB + p;
-      const int yy = py + kyB[p] - 1;
-      const bool yok = (unsigned)yy < (unsigned)a.Ho;
-      const bool edgeL = kxB[p] == 0 && px0 == 0, edgeR = kxB[p] == 2 && px0 + 32 == a.Wo;
+      const int yy = S2 ? 2 * py + kyB[p] - 1 : py + kyB[p] - 1;
+      const bool yok = (unsigned)yy < (unsigned)(S2 ? a.Hi : a.Ho);
+      const bool edgeL = kxB[p] == 0 && px0 == 0, edgeR = kxB[p] == (S2 ? 3 : 2) && px0 + 32 == a.Wo;
       unsigned v = edgeL ? voffBL[p] : (edgeR ? voffBR[p] : voffB[p]);
       unsigned so;
-      if (a.ups) {
+      if constexpr (S2) {
+        so = (unsigned)((pn * a.Hi + 2 * py) * a.Wi + 2 * px0) * a.Cin * 2u + tapoB[p];
+      } else if (a.ups) {
         const int xx = px0 + rowB[p] + kxB[p] - 1;  // masked lanes never use it
         v = v == SENT ? SENT : v + (unsigned)(xx >> 1) * a.Cin * 2u;
         so = (unsigned)((pn * a.Hi + (yy >> 1)) * a.Wi) * a.Cin * 2u;
@@ -295,15 +301,15 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #endif
 }
 
-template <int GA, int GB, int WM, int WN>
+template <int GA, int GB, int WM, int WN, bool S2 = false>
 int launch(const Args& a, int splits, hipStream_t st) {
   constexpr int lds = 4 * (GA + GB) * 32 * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_kernel<GA, GB, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_kernel<GA, GB, WM, WN, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_pp_kernel<GA, GB, WM, WN>), dim3((unsigned)(splits * a.mtiles * a.ntiles)), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((wgrad_pp_kernel<GA, GB, WM, WN, S2>), dim3((unsigned)(splits * a.mtiles * a.ntiles)), dim3(512), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -314,10 +320,12 @@ int launch(const Args& a, int splits, hipStream_t st) {
 int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_out, int* cfg_out) {
   static const bool disabled = [] { const char* e = getenv("DMVAE_WGRAD_V1"); return e && atoi(e) != 0; }();
   if (disabled) return 0;
-  if (d->stride == 2 || d->upsample == 2 || d->ks == 4 || d->transposed) return 0;  // strided / 4x4 gathers: the general kernel (conv_wgrad.hip)
+  static const bool s2_ok = [] { const char* e = getenv("DMVAE_WGRAD_PP_S2"); return e ? atoi(e) != 0 : true; }();
+  const bool s2 = s2_ok && d->ks == 4 && d->stride == 2 && !d->upsample && !d->transposed && d->h % 2 == 0 && d->w % 2 == 0;  // 4x4 stride 2: its own instantiation
+  if (!s2 && (d->stride == 2 || d->upsample == 2 || d->ks == 4 || d->transposed)) return 0;  // other strided / 4x4 gathers: the general kernel (conv_wgrad.hip)
   const int ups = d->upsample ? 1 : 0;
-  const int wo = ups ? 2 * d->w : d->w;
-  const long long M = (long long)d->n * d->h * d->w * (ups ? 4 : 1);
+  const int wo = s2 ? d->w / 2 : (ups ? 2 * d->w : d->w);
+  const long long M = s2 ? (long long)d->n * (d->h / 2) * (d->w / 2) : (long long)d->n * d->h * d->w * (ups ? 4 : 1);
   if (d->cin % 128 != 0 || d->cout % 128 != 0 || wo % 32 != 0 || M < 4096) return 0;
   if ((long long)M * d->cout * 2 >= (1ll << 31) || (long long)d->n * d->h * d->w * d->cin * 2 + (1ll << 22) >= (1ll << 31)) return 0;
   const int T = d->ks * d->ks;
@@ -351,15 +359,16 @@ int dmvae_wgrad_pp_launch(const void* dy, const void* act, float* slab, float* b
   a.dy = (const bf16*)dy; a.a = (const bf16*)act; a.slab = slab; a.bslab = bslab;
   a.N = d->n; a.Hi = d->h; a.Wi = d->w; a.Cin = d->cin; a.Cout = d->cout; a.ks = d->ks;
   a.ups = d->upsample ? 1 : 0;
-  a.Ho = a.ups ? 2 * d->h : d->h; a.Wo = a.ups ? 2 * d->w : d->w;
+  const bool s2 = d->ks == 4 && d->stride == 2;
+  a.Ho = s2 ? d->h / 2 : (a.ups ? 2 * d->h : d->h); a.Wo = s2 ? d->w / 2 : (a.ups ? 2 * d->w : d->w);
   a.M = a.N * a.Ho * a.Wo;
   a.kchunk = kchunk;
   a.gpt = d->cin / 128;
   a.ngroups = d->ks * d->ks * a.gpt;
   if (cfg == 0) {
     a.mtiles = d->cout / 256; a.ntiles = a.ngroups / 2;
-    return launch<2, 2, 2, 4>(a, splits, stream);
+    return s2 ? launch<2, 2, 2, 4, true>(a, splits, stream) : launch<2, 2, 2, 4>(a, splits, stream);
   }
   a.mtiles = d->cout / 128; a.ntiles = (a.ngroups + 2) / 3;
-  return launch<1, 3, 2, 4>(a, splits, stream);
+  return s2 ? launch<1, 3, 2, 4, true>(a, splits, stream) : launch<1, 3, 2, 4>(a, splits, stream);
 }

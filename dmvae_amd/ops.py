@@ -206,9 +206,10 @@ def conv2d_nhwc_wgrad(dy: torch.Tensor, a: torch.Tensor, ks: int, upsample: bool
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         # the whole weight-gradient call: split-K main kernel + fixed-order slab reduce (+ fused bias gradient); csrc/conv_wgrad_pp.hip takes
-        # stride-1 3x3 / 1x1 shapes whose rows are multiples of 32 pixels with >= 4096 reduction rows, csrc/conv_wgrad.hip the rest
+        # stride-1 3x3 / 1x1 and stride-2 4x4 shapes whose rows are multiples of 32 pixels with >= 4096 reduction rows, csrc/conv_wgrad.hip the rest
         ho, wo = dy.shape[1], dy.shape[2]
-        big = stride == 1 and ks in (1, 3) and wo % 32 == 0 and cin % 128 == 0 and cout % 128 == 0 and n * ho * wo >= 4096
+        big = ((stride == 1 and ks in (1, 3)) or (stride == 2 and ks == 4 and h % 2 == 0 and w_ % 2 == 0)) and wo % 32 == 0 and cin % 128 == 0 \
+            and cout % 128 == 0 and n * ho * wo >= 4096
         timing.append(("wgrad_pp" if big else "wgrad_small", e0, e1, 2.0 * n * ho * wo * cout * cin * ks * ks))
     return dw, db
 

@@ -98,7 +98,8 @@ def test_conv_stride2_fwd_dgrad_wgrad(case):
 
 
 K4_CASES = [(2, 8, 8, 32, 64, 2), (1, 9, 11, 32, 32, 1), (3, 16, 16, 64, 128, 2), (1, 7, 10, 96, 8, 1), (2, 64, 64, 64, 128, 2), (2, 33, 32, 256, 512, 1),
-            (1, 12, 10, 32, 4, 1), (4, 130, 128, 64, 128, 2), (2, 96, 97, 64, 192, 1), (5, 66, 64, 32, 64, 1)]  # N, H, W, Cin, Cout, stride; the last three reach the ping-pong kernel
+            (1, 12, 10, 32, 4, 1), (4, 130, 128, 64, 128, 2), (2, 96, 97, 64, 192, 1), (5, 66, 64, 32, 64, 1),   # N, H, W, Cin, Cout, stride; these three reach the ping-pong kernel
+            (2, 128, 128, 128, 256, 2), (1, 66, 128, 256, 128, 2), (3, 64, 64, 128, 128, 2)]  # stride 2 with 128-multiples and 32-pixel output rows: wgrad_pp's S2 instantiation (both tile configurations)
 
 
 @pytest.mark.parametrize("case", K4_CASES)
