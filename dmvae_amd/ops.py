@@ -163,9 +163,9 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
         if cin % 32 == 0 and cout >= 64 and cout % 8 == 0 and n * ho * wo >= 16384:
             ups1 = int(upsample) == 1                  # nearest x2 folded into the gather: its own template variant
             gen = (int(upsample) == 2 or stride == 2 or ks == 4 or bool(transposed)) and not (sub and _PP_SUBPIXEL)   # the general-gather instantiation
-            label = "conv_pp_kernel<%s, %s, %s, %s, %s%s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", "true" if ups1 else "false",
-                                                               "true" if out_f32 else "false", "false" if ups1 else ("true" if gen else _PP_KORDER),
-                                                               "true" if gen else "false", ", true" if (sub and _PP_SUBPIXEL) else "")
+            label = "conv_pp_kernel<%s, %s, %s, %s, %s, %s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", "true" if ups1 else "false",
+                                                                 "true" if out_f32 else "false", "false" if ups1 else ("true" if gen else _PP_KORDER),
+                                                                 "true" if gen else "false", "true" if (sub and _PP_SUBPIXEL) else "false")
         else:
             label = "conv_fwd_kernel"
         timing.append((label, e0, e1, 2.0 * n * ho * wo * cout * cin * (4 if sub else ks * ks)))

@@ -1,0 +1,87 @@
+"""Config C1 (toy_example_2d/dmd.py) on the HIP path: dmvae_amd.toy.ToyDMDTrainer.
+
+The points turn is held to the reference's own compute_distribution_matching_loss ("dmd" branch, golden dmd_loss_toy: injected t, x0 and velocities)
+-- loss and gradient at 1e-4 -- and to torch.optim.AdamW for the update; the loop's turn-taking (vae_train_every / fake_warmup_steps), the student's
+flow-matching turn and the qualitative behaviour (points move towards the teacher's distribution) are checked on an analytic velocity field."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+class _Inject(torch.nn.Module):
+    def __init__(self, v):
+        super().__init__()
+        self.v = v
+
+    def forward(self, xt, t, y):
+        return self.v
+
+
+def test_points_turn_vs_reference_fixture_and_adamw():
+    from dmvae_amd.toy import ToyDMDTrainer
+    g = load_golden("dmd_loss_toy")
+    pts0 = g.t("points")
+    tr = ToyDMDTrainer(_Inject(g.t("v_teacher").to(DEV)), _Inject(g.t("v_student").to(DEV)), points=pts0.to(DEV), lr=1e-2)
+    labels = torch.zeros(64, dtype=torch.long, device=DEV)
+    loss, log = tr.dmd_loss(labels, t=g.t("t_raw").to(DEV), x0=g.t("x0").to(DEV))
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert rel_err(tr.points.grad.cpu(), g.t("dpoints")) < 1e-4
+    # the update: clip at 1e5 (inactive) + AdamW(lr, wd 0, betas (0.9, 0.95), eps 1e-8), first step (toy_example_2d/dmd.py:628, :677-679)
+    ref = torch.nn.Parameter(pts0.clone())
+    ref.grad = g.t("dpoints").clone()
+    opt = torch.optim.AdamW([ref], lr=1e-2, weight_decay=0, betas=(0.9, 0.95), eps=1e-8)
+    torch.nn.utils.clip_grad_norm_(ref, max_norm=100000.0)
+    opt.step()
+    norm = tr.popt.step()
+    assert rel_err(tr.points.detach().cpu(), ref.detach()) < 1e-5
+    assert abs(norm[0].item() - g.t("dpoints").norm().item()) < 1e-4 * g.t("dpoints").norm().item()
+
+
+class _Field(torch.nn.Module):
+    """Velocity of the linear path towards a point mass at `target`: v(xt, t) = (target - xt) / (1 - t) (clamped), i.e. pred_x1 = xt + (1-t) v = target."""
+    def __init__(self, target, trainable=False):
+        super().__init__()
+        self.target = torch.nn.Parameter(torch.tensor(target, dtype=torch.float32).view(1, 2, 1, 1), requires_grad=trainable)
+
+    def forward(self, xt, t, y):
+        return (self.target - xt.float()) / (1 - t.float()).clamp_min(1e-3).view(-1, 1, 1, 1)
+
+
+def test_toy_loop_turns_and_convergence():
+    from dmvae_amd.toy import ToyDMDTrainer
+    teacher = _Field([0.5, -0.25]).to(DEV)
+    student = _Field([-1.0, 1.0], trainable=True).to(DEV)
+    tr = ToyDMDTrainer(teacher, student, num_points=256, lr=5e-2, diff_lr=5e-2, vae_train_every=2, fake_warmup_steps=4, t0=0.02, t1=0.98, seed=3)
+    p0 = tr.points.detach().clone()
+    assert p0.shape == (256, 2) and p0.abs().max() <= 1.5
+    turns = []
+    for _ in range(10):
+        out = tr.step()
+        turns.append(out["dmd_loss"] is not None)
+        assert out["sit_loss"] is not None                    # the student trains every step (:690-709)
+    # steps 0..3: every = fake_warmup_steps = 4 -> only step 0; from step 4 on every 2nd step (:650-655)
+    assert turns == [True, False, False, False, True, False, True, False, True, False]
+    assert tr.global_step == 10 and student.training             # left in train mode by its own turn (:688)
+    log = tr.read_log()
+    assert all(v == v for v in log.values()) and log["points_grad_norm"] > 0
+    # DMD gradient = pred_student - pred_teacher: with the student's point mass tracking the points' mean (flow matching on the points) and the teacher's
+    # at `target`, the points drift towards the teacher's target
+    for _ in range(300):
+        tr.step()
+    d0 = (p0.mean(0).cpu() - torch.tensor([0.5, -0.25])).norm().item()
+    d1 = (tr.points.detach().mean(0).cpu() - torch.tensor([0.5, -0.25])).norm().item()
+    assert d1 < 0.5 * d0, (d0, d1)
+    ck = tr.checkpoint()
+    assert set(ck) == {"model", "points", "opt_sit", "steps"} and ck["steps"] == 310 and ck["points"].shape == (256, 2)
+
+
+def test_toy_rejects_cpu_points():
+    from dmvae_amd._lib import DmvaeHipError
+    from dmvae_amd.toy import ToyDMDTrainer
+    with pytest.raises(DmvaeHipError):
+        ToyDMDTrainer(lambda *a: None, lambda *a: None, num_points=8, device="cpu")

@@ -1,5 +1,6 @@
 """CPU: host-side mirror of the reference interface -- constructor/RNG parity, state_dict layout, checkpoint layout,
 flat-buffer optimiser plumbing, loud failure without a GPU."""
+import os
 import warnings
 
 import numpy as np
@@ -188,3 +189,58 @@ def test_lpips_reports_a_missing_trunk_and_loads_torchvision_layout(tmp_path, mo
         warnings.simplefilter("ignore")
         with pytest.raises(KeyError, match="lin4"):
             LPIPS(ckpt_path=str(ck))
+
+
+def test_toy_sshape_sampler_and_points_match_the_reference():
+    """dmvae_amd.toy's host-side pieces of config C1: SShapeDistribution2D reproduces the reference's samples bit for bit (golden G13, captured from
+    toy_example_2d/sshpae.py with random_state=42) and create_learnable_points its initialiser (toy_example_2d/dmd.py:139-145: global seed, U[-1.5, 1.5])."""
+    from dmvae_amd.toy import SShapeDistribution2D, create_learnable_points
+    g = load_golden("sshape")
+    pts, comp = SShapeDistribution2D(random_state=42).sample(1536)
+    assert np.array_equal(pts, g["samples"]) and comp.shape == (1536,) and not comp.any()
+    assert np.abs(pts).max() <= 1.0
+    unflipped, _ = SShapeDistribution2D(random_state=42, flip_y=False).sample(1536)
+    assert np.array_equal(unflipped[:, 0], g["samples"][:, 0]) and np.array_equal(unflipped[:, 1], -g["samples"][:, 1])     # flip_y mirrors the ordinate only
+    p = create_learnable_points(1536, 2, "cpu", seed=42)
+    torch.manual_seed(42)
+    assert torch.equal(p.data, torch.rand(1536, 2) * 3.0 - 1.5) and isinstance(p, torch.nn.Parameter)
+    assert p.min() >= -1.5 and p.max() <= 1.5
+
+
+def test_run_on_mi355x_launcher_shadows_the_reference_import_paths():
+    """run_on_mi355x.py: in a fresh interpreter, after install_shadow() every module path the reference's drivers import their model
+    code from (train_tokenizer.py:10-17, train_dmd.py:10-17, train_diffusion.py:15-17, sample_50k.py:6-14) resolves to this build's mirror, the names they
+    import exist, and a module this build does not shadow still resolves below the reference's directory when one is given."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, os, tempfile
+sys.path.insert(0, %r)
+import run_on_mi355x as L
+ref = tempfile.mkdtemp()
+os.makedirs(os.path.join(ref, "models")); os.makedirs(os.path.join(ref, "utils"))
+open(os.path.join(ref, "models", "dinodisc.py"), "w").write("class DinoDisc: marker = 'reference file'\n")
+open(os.path.join(ref, "utils", "dist.py"), "w").write("WHO = 'reference utils.dist'\n")
+L.install_shadow(ref)
+from models.vae import VAE
+from models import VAE as V2, NLayerDiscriminator, DinoDisc
+from models.flux_ae import Decoder, Encoder
+from models.init_param import init_weights
+from models.patchgan import NLayerDiscriminator as N2
+from utils.lpips import LPIPS
+from utils.diffaug import DiffAug
+import utils.dist as dist
+from diffusion.lightningdit.lightningdit import LightningDiT_models, LightningDiT
+from diffusion.transport import create_transport, Transport, Sampler
+import dmvae_amd.models.vae, dmvae_amd.models.flux_ae, dmvae_amd.utils.lpips, dmvae_amd.transport, dmvae_amd.models.lightningdit
+assert VAE is dmvae_amd.models.vae.VAE is V2 and Decoder is dmvae_amd.models.flux_ae.Decoder and LPIPS is dmvae_amd.utils.lpips.LPIPS
+assert NLayerDiscriminator is N2 and create_transport is dmvae_amd.transport.create_transport
+assert LightningDiT is dmvae_amd.models.lightningdit.LightningDiT and "LightningDiT-XL/1" in LightningDiT_models
+assert DinoDisc.marker == 'reference file' and dist.WHO == 'reference utils.dist'
+print("shadow ok")
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "shadow ok" in r.stdout, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "run_on_mi355x.py"), "--check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "models.vae" in r.stdout and "dmvae_amd.transport" in r.stdout, r.stderr[-2000:]
