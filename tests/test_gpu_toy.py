@@ -69,13 +69,25 @@ def test_toy_loop_turns_and_convergence():
     assert tr.global_step == 10 and student.training             # left in train mode by its own turn (:688)
     log = tr.read_log()
     assert all(v == v for v in log.values()) and log["points_grad_norm"] > 0
-    # DMD gradient = pred_student - pred_teacher: with the student's point mass tracking the points' mean (flow matching on the points) and the teacher's
-    # at `target`, the points drift towards the teacher's target
+    # the student's turn is flow matching on the current points: with this field its loss is |target_s - x1|^2 / (1 - t)^2, minimised by the points' mean
+    s0 = torch.tensor([-1.0, 1.0])
     for _ in range(300):
         tr.step()
-    d0 = (p0.mean(0).cpu() - torch.tensor([0.5, -0.25])).norm().item()
-    d1 = (tr.points.detach().mean(0).cpu() - torch.tensor([0.5, -0.25])).norm().item()
-    assert d1 < 0.5 * d0, (d0, d1)
+    mean_now = tr.points.detach().mean(0).cpu()
+    s_now = student.target.detach().view(2).cpu()
+    assert (s_now - mean_now).norm() < 0.5 * (s0 - p0.mean(0).cpu()).norm(), (s_now, mean_now)
+    # the points' turn with a FROZEN student: DMD gradient = pred_student - pred_teacher = target_s - target_t for every point, so AdamW moves all
+    # points along target_t - target_s (:349-360: grad = p_real - p_student; the surrogate loss's gradient is grad / numel)
+    frozen = _Field([-1.0, 1.0]).to(DEV)
+    tr2 = ToyDMDTrainer(teacher, frozen, num_points=128, lr=1e-2, vae_train_every=1, seed=5)
+    q0 = tr2.points.detach().clone()
+    for _ in range(20):
+        out = tr2.step()
+        assert out["dmd_loss"] is not None and out["sit_loss"] is None          # nothing to train in the student
+    disp = (tr2.points.detach() - q0).cpu()
+    want = torch.tensor([0.5, -0.25]) - torch.tensor([-1.0, 1.0])
+    cos = torch.nn.functional.cosine_similarity(disp, want.expand_as(disp), dim=1)
+    assert cos.min() > 0.9 and disp.norm(dim=1).min() > 0.1, (cos.min(), disp.norm(dim=1).min())       # ~20 Adam steps of 1e-2 per coordinate
     ck = tr.checkpoint()
     assert set(ck) == {"model", "points", "opt_sit", "steps"} and ck["steps"] == 310 and ck["points"].shape == (256, 2)
 
