@@ -1,0 +1,344 @@
+// Backward of the fused multi-head self-attention of vit.hip (timm Attention / dino_layers/attention.py:56-69 for the trainable ViT encoder of
+// train_dmd.py:349,519; LightningDiT's Attention, diffusion/lightningdit/lightningdit.py:76-88, for the student's training turn) -- S <= 288 tokens,
+// head dim 64 (ViT) or 72 zero-padded to 96 (LightningDiT-XL).  Replaces autograd's SDPA backward; the GEMM-composed version this build used before
+// moved the S x S scores / probabilities through HBM four times per block.
+//
+//   P = softmax(scale Q K^T)        dV = P^T dO        dP = dO V^T        dS = P o (dP - delta),  delta_q = dO_q . O_q        dQ = scale dS K        dK = scale dS^T Q
+//
+// One workgroup (4 waves) per (batch, head), two phases, nothing of size S x S leaves the registers:
+//   A  K and V resident in LDS; a wave owns 32 queries at a time (as the forward kernel): S^T = K Q^T and dP^T = V dO^T on the matrix cores with the
+//      queries along the lanes (row statistics need one swap with lane ^ 32), dS^T -> bf16 A-fragments by v_permlane32_swap, dQ = dS K through the LDS
+//      transpose read of K.  Leaves L_q = max + log(sum) and delta_q in LDS.
+//   B  Q and dO resident in LDS (restaged over K / V); a wave owns 32 keys: S = Q K^T and dP = dO V^T with the KEYS along the lanes, P = exp(scale S - L),
+//      P^T / dS^T as A-fragments by the same swap, dV += P^T dO and dK += dS^T Q through transpose reads of dO / Q.
+// Seven S x S x d contractions instead of the minimal five (S and dP are formed in both orientations): the alternative is an LDS transpose of P and dS
+// per 32 x 32 block or float atomics on dQ; at S <= 288 the extra matrix work is the cheaper price and every sum keeps a fixed order.
+//
+// LDS image of a [token][d] operand (one copy serves both access kinds): 192-B rows, 16-B chunks XOR-ed inside their 64-B segment by (row >> 2) & 3.
+//   row reads (A / B fragments of the "NT" products: lane -> row l & 31, chunk 2 kk + (l >> 5)): 16 consecutive rows land in 16 distinct 16-B slots mod 256 B
+//     (row * 12 mod 16 cycles through {0, 12, 8, 4}, the XOR through the other two bits);
+//   transpose reads (ds_read_b64_tr_b16, B fragments with the reduction along tokens): the four rows of a pass start 48 banks apart, i.e. in four
+//     different 16-bank quarters, and a pass reads one whole 64-B segment of each -- the XOR only permutes inside it.
+#include "common.h"
+#include "dmvae_hip.h"
+
+namespace dmvae_attn_bwd {
+
+constexpr int KEYS = 288, NB = KEYS / 32, PITCH = 192;
+constexpr int BUF = KEYS * PITCH;
+
+struct Args {
+  const bf16 *q, *k, *v;         // per (batch, head): base + b * bs + h * hs, token rows rs elements apart; q / k rows hold DP (padded) channels
+  const bf16 *o, *dout;          // [B][S][H * D]
+  bf16 *dq, *dk, *dv;            // same geometry as q / k / v
+  long long q_bs, q_hs, k_bs, k_hs, v_bs, v_hs;
+  int q_rs, k_rs, v_rs;
+  int S, H, D;
+  float scale;
+};
+
+__device__ __forceinline__ s16x4 tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  bf16x2 t = {(bf16)a, (bf16)b};
+  return *reinterpret_cast<unsigned*>(&t);
+}
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * PITCH + (((chunk & ~3) | ((chunk & 3) ^ ((row >> 2) & 3))) << 4); }
+__device__ __forceinline__ float dot8(const uint4& a, const uint4& b) {
+  const bf16x8 x = *reinterpret_cast<const bf16x8*>(&a), y = *reinterpret_cast<const bf16x8*>(&b);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; e++) s += (float)x[e] * (float)y[e];
+  return s;
+}
+// C-layout registers of a 32 x 32 block (row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31), 16 of them scaled to bf16 -> the two A fragments
+// (reduction index = the block's ROW, 8 consecutive per lane) of its two 16-row halves
+__device__ __forceinline__ void to_afrag(const f32x16& c, bf16x8 out[2]) {
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    const unsigned p0 = pack2(c[half * 8 + 0], c[half * 8 + 1]), p1 = pack2(c[half * 8 + 2], c[half * 8 + 3]);
+    const unsigned p2 = pack2(c[half * 8 + 4], c[half * 8 + 5]), p3 = pack2(c[half * 8 + 6], c[half * 8 + 7]);
+    // lanes < 32 hold rows {0-3, 8-11} of the half, lanes >= 32 rows {4-7, 12-15}: the fragment wants {0-7} / {8-15}
+    const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p2, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(p1, p3, false, false);
+    union { unsigned u[4]; bf16x8 v; } pa;
+    pa.u[0] = s0[0]; pa.u[1] = s1[0]; pa.u[2] = s0[1]; pa.u[3] = s1[1];
+    out[half] = pa.v;
+  }
+}
+
+template <int DP>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(Args a) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int KSTEPS = DP / 16, DB = DP / 32, CH = DP / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* buf0 = smem;                    // phase A: K, phase B: Q
+  char* buf1 = smem + BUF;              // phase A: V, phase B: dO
+  float* Ls = reinterpret_cast<float*>(smem + 2 * BUF);  // [288] max + log(sum) of the scaled scores; +inf for padded queries
+  float* Ds = Ls + KEYS;                                  // [288] delta
+  const int S = a.S, H = a.H, D = a.D, C = H * D;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16* qg = a.q + b * a.q_bs + h * a.q_hs;
+  const bf16* kg_ = a.k + b * a.k_bs + h * a.k_hs;
+  const bf16* vg = a.v + b * a.v_bs + h * a.v_hs;
+  const bf16* og = a.o + (size_t)b * S * C + h * D;
+  const bf16* dog = a.dout + (size_t)b * S * C + h * D;
+  const int dchunks = D / 8;            // real channels of v / o / dout; q and k rows carry DP (the producer zero-pads)
+  const int nblk = (S + 31) >> 5;
+
+  // stage two [token][*] operands: CH lanes x 16 B per row
+  auto stage = [&](const bf16* s0, int rs0, int ch0, const bf16* s1, int rs1, int ch1) {
+    for (int i = tid; i < KEYS * CH; i += 256) {
+      const int row = i / CH, c = i - row * CH;
+      uint4 x = {0, 0, 0, 0}, y = {0, 0, 0, 0};
+      if (row < S) {
+        if (c < ch0) x = *reinterpret_cast<const uint4*>(s0 + (size_t)row * rs0 + c * 8);
+        if (c < ch1) y = *reinterpret_cast<const uint4*>(s1 + (size_t)row * rs1 + c * 8);
+      }
+      const int off = lds_off(row, c);
+      *reinterpret_cast<uint4*>(buf0 + off) = x;
+      *reinterpret_cast<uint4*>(buf1 + off) = y;
+    }
+  };
+  stage(kg_, a.k_rs, CH, vg, a.v_rs, dchunks);
+  __syncthreads();
+
+  const int kg = lane >> 5, ql = lane & 31;
+  // transpose-read addressing: lane supplies 4 channels (8 B) of token row 8 kg + rr (and + 4) of a 16-token step, channel block db
+  const int g16 = (lane >> 4) & 1, rr = (lane & 15) >> 2, qq = lane & 3;
+  int toff0[DB], toff1[DB];
+#pragma unroll
+  for (int db = 0; db < DB; db++) {
+    const int chunk = db * 4 + g16 * 2 + (qq >> 1);
+    toff0[db] = lds_off(kg * 8 + rr, chunk) + (qq & 1) * 8;
+    toff1[db] = lds_off(kg * 8 + rr + 4, chunk) + (qq & 1) * 8;
+  }
+  const float scale = a.scale;
+
+  // ================= phase A: per 32-query block -- statistics, dQ ==================================================================================
+  for (int qb = wave; qb < nblk; qb += 4) {
+    const int q = qb * 32 + ql;
+    bf16x8 qf[KSTEPS], dof[KSTEPS];
+    float delta = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++) {
+      uint4 tq = {0, 0, 0, 0}, td = {0, 0, 0, 0}, to = {0, 0, 0, 0};
+      const int d0 = kk * 16 + kg * 8;
+      if (q < S) {
+        tq = *reinterpret_cast<const uint4*>(qg + (size_t)q * a.q_rs + d0);
+        if (d0 < D) {
+          td = *reinterpret_cast<const uint4*>(dog + (size_t)q * C + d0);
+          to = *reinterpret_cast<const uint4*>(og + (size_t)q * C + d0);
+        }
+      }
+      qf[kk] = *reinterpret_cast<bf16x8*>(&tq);
+      dof[kk] = *reinterpret_cast<bf16x8*>(&td);
+      delta += dot8(td, to);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    // S^T = K Q^T: st[kb][r] = score(key kb*32 + (r&3) + 8 (r>>2) + 4 kg, query q)
+    f32x16 st[NB];
+#pragma unroll
+    for (int kb = 0; kb < NB; kb++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) st[kb][r] = 0.f;
+      const int key = kb * 32 + ql;
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; kk++) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(buf0 + lds_off(key, kk * 2 + kg));
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kb], 0, 0, 0);
+      }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NB; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        const float v = key < S ? st[kb][r] * scale : -INFINITY;
+        st[kb][r] = v;
+        m = fmaxf(m, v);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NB; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { const float e = __expf(st[kb][r] - m); st[kb][r] = e; sum += e; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    if (kg == 0) { Ls[q] = q < S ? m + __logf(sum) : INFINITY; Ds[q] = delta; }
+    // dP^T = V dO^T per key block, dS^T = P o (dP^T - delta) * scale, dQ += dS K
+    f32x16 dq[DB];
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) dq[db][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NB; kb++) {
+      f32x16 dpt;
+#pragma unroll
+      for (int r = 0; r < 16; r++) dpt[r] = 0.f;
+      const int key = kb * 32 + ql;
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; kk++) {
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(buf1 + lds_off(key, kk * 2 + kg));
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], dpt, 0, 0, 0);
+      }
+      const float ps = inv * scale;
+#pragma unroll
+      for (int r = 0; r < 16; r++) dpt[r] = st[kb][r] * ps * (dpt[r] - delta);
+      bf16x8 af[2];
+      to_afrag(dpt, af);
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const char* base = buf0 + (kb * 2 + half) * 16 * PITCH;
+#pragma unroll
+        for (int db = 0; db < DB; db++) {
+          union { bf16x8 v; s16x4 hlf[2]; } kf;
+          kf.hlf[0] = tr_read(base + toff0[db]);
+          kf.hlf[1] = tr_read(base + toff1[db]);
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[half], kf.v, dq[db], 0, 0, 0);
+        }
+      }
+    }
+    bf16* dqg = a.dq + b * a.q_bs + h * a.q_hs;
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int qo = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (qo < S) dqg[(size_t)qo * a.q_rs + db * 32 + ql] = (bf16)dq[db][r];
+      }
+  }
+  __syncthreads();
+  // ================= phase B: Q and dO resident; per 32-key block -- dK, dV ===========================================================================
+  stage(qg, a.q_rs, CH, dog, C, dchunks);
+  __syncthreads();
+  for (int kb = wave; kb < nblk; kb += 4) {
+    const int key = kb * 32 + ql;
+    bf16x8 kfb[KSTEPS], vfb[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++) {
+      uint4 tk = {0, 0, 0, 0}, tv = {0, 0, 0, 0};
+      const int d0 = kk * 16 + kg * 8;
+      if (key < S) {
+        tk = *reinterpret_cast<const uint4*>(kg_ + (size_t)key * a.k_rs + d0);
+        if (d0 < D) tv = *reinterpret_cast<const uint4*>(vg + (size_t)key * a.v_rs + d0);
+      }
+      kfb[kk] = *reinterpret_cast<bf16x8*>(&tk);
+      vfb[kk] = *reinterpret_cast<bf16x8*>(&tv);
+    }
+    f32x16 dk[DB], dv[DB];
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    for (int qb = 0; qb < nblk; qb++) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+      const int qrow = qb * 32 + ql;
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; kk++) {
+        const int off = lds_off(qrow, kk * 2 + kg);
+        const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(buf0 + off);
+        const bf16x8 dor = *reinterpret_cast<const bf16x8*>(buf1 + off);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kfb[kk], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dor, vfb[kk], dp, 0, 0, 0);
+      }
+      // rows: queries qb*32 + (r&3) + 8 (r>>2) + 4 kg; column: this lane's key
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++) {
+        const f32x4 Lv = *reinterpret_cast<const f32x4*>(Ls + qb * 32 + 8 * r4 + 4 * kg);
+        const f32x4 Dv = *reinterpret_cast<const f32x4*>(Ds + qb * 32 + 8 * r4 + 4 * kg);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float p = key < S ? __expf(s[r4 * 4 + r] * scale - Lv[r]) : 0.f;
+          s[r4 * 4 + r] = p;
+          dp[r4 * 4 + r] = p * (dp[r4 * 4 + r] - Dv[r]) * scale;
+        }
+      }
+      bf16x8 pf[2], dsf[2];
+      to_afrag(s, pf);
+      to_afrag(dp, dsf);
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const int rbase = (qb * 2 + half) * 16 * PITCH;
+#pragma unroll
+        for (int db = 0; db < DB; db++) {
+          union { bf16x8 v; s16x4 hlf[2]; } df, qf2;
+          df.hlf[0] = tr_read(buf1 + rbase + toff0[db]);
+          df.hlf[1] = tr_read(buf1 + rbase + toff1[db]);
+          qf2.hlf[0] = tr_read(buf0 + rbase + toff0[db]);
+          qf2.hlf[1] = tr_read(buf0 + rbase + toff1[db]);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[half], df.v, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf[half], qf2.v, dk[db], 0, 0, 0);
+        }
+      }
+    }
+    bf16* dkg = a.dk + b * a.k_bs + h * a.k_hs;
+    bf16* dvg = a.dv + b * a.v_bs + h * a.v_hs;
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        const int dcol = db * 32 + ql;
+        if (ko < S) {
+          dkg[(size_t)ko * a.k_rs + dcol] = (bf16)dk[db][r];
+          if (dcol < D) dvg[(size_t)ko * a.v_rs + dcol] = (bf16)dv[db][r];
+        }
+      }
+  }
+#endif
+}
+
+template <int DP>
+static int launch(const Args& a, int batch, hipStream_t stream) {
+  constexpr int lds = 2 * BUF + 2 * KEYS * (int)sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel<DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((attention_bwd_kernel<DP>), dim3(batch * a.H), dim3(256), lds, stream, a);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace dmvae_attn_bwd
+
+extern "C" int dmvae_attention_bwd_qkv_bf16(const void* qkv, const void* out, const void* dout, void* dqkv, int batch, int seq, int heads, int head_dim,
+                                            float scale, hipStream_t stream) {
+  using namespace dmvae_attn_bwd;
+  DMVAE_CHECK_ARG(qkv && out && dout && dqkv && batch > 0 && heads > 0 && seq > 0, "attention_bwd_qkv_bf16: bad argument");
+  DMVAE_CHECK_ARG(head_dim == 64 && seq <= KEYS, "attention_bwd_qkv_bf16: needs head_dim 64 and seq <= 288 (got %d, %d)", head_dim, seq);
+  const long long C = (long long)heads * head_dim;
+  Args a = {};
+  a.q = (const bf16*)qkv; a.k = a.q + C; a.v = a.q + 2 * C;
+  a.dq = (bf16*)dqkv; a.dk = a.dq + C; a.dv = a.dq + 2 * C;
+  a.o = (const bf16*)out; a.dout = (const bf16*)dout;
+  a.q_bs = a.k_bs = a.v_bs = (long long)seq * 3 * C; a.q_hs = a.k_hs = a.v_hs = head_dim;
+  a.q_rs = a.k_rs = a.v_rs = (int)(3 * C);
+  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale;
+  return launch<64>(a, batch, stream);
+}
+
+extern "C" int dmvae_attention_bwd_heads_bf16(const void* q, const void* k, const void* v, const void* out, const void* dout, void* dq, void* dk, void* dv,
+                                              int batch, int seq, int heads, int head_dim, int head_dim_padded, float scale, hipStream_t stream) {
+  using namespace dmvae_attn_bwd;
+  DMVAE_CHECK_ARG(q && k && v && out && dout && dq && dk && dv && batch > 0 && heads > 0 && seq > 0, "attention_bwd_heads_bf16: bad argument");
+  DMVAE_CHECK_ARG(seq <= KEYS && head_dim % 8 == 0 && head_dim <= head_dim_padded && (head_dim_padded == 64 || head_dim_padded == 96),
+                  "attention_bwd_heads_bf16: needs seq <= 288, head_dim %% 8 == 0, padded head dim 64 or 96 (got %d, %d, %d)", seq, head_dim, head_dim_padded);
+  Args a = {};
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (const bf16*)out; a.dout = (const bf16*)dout;
+  a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv;
+  a.q_hs = a.k_hs = (long long)seq * head_dim_padded; a.q_bs = a.k_bs = a.q_hs * heads;
+  a.v_hs = (long long)seq * head_dim; a.v_bs = a.v_hs * heads;
+  a.q_rs = a.k_rs = head_dim_padded; a.v_rs = head_dim;
+  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale;
+  return head_dim_padded == 64 ? launch<64>(a, batch, stream) : launch<96>(a, batch, stream);
+}

@@ -493,6 +493,11 @@ def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Te
     return (dy2 @ _bf(w)) if need_dx else None, dw, db
 
 
+def _fused_attn_bwd() -> bool:
+    """DMVAE_ATTN_BWD_FUSED=0: the GEMM-composed attention backward (probabilities through HBM; the first implementation, kept for A/B runs and tests)."""
+    return os.environ.get("DMVAE_ATTN_BWD_FUSED", "1") != "0"
+
+
 def _attention_bwd(qkv: torch.Tensor, do: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
     """d(qkv) of multi-head self-attention from the qkv Linear's output [B,S,3*C] and d(out) [B,S,C] (bf16): the probabilities are
     recomputed (QK^T GEMM + f32 softmax, keys padded to a multiple of 32 and masked), then the four GEMMs of the decoder AttnBlock's
@@ -562,7 +567,10 @@ class VitBlockFn(torch.autograd.Function):
         # attention branch
         do2, dls1 = ops.layerscale_bwd(dt, o2, ls1, dg_out=_dst(ls1))
         do, dpw, dpb = _lin_grads(do2.view(rows, c), o.view(rows, c), pw, pb)
-        dqkv = _attention_bwd(qkv, do.view(b, s, c), heads, (c // heads) ** -0.5)
+        if c // heads == 64 and s <= 288 and _fused_attn_bwd():
+            dqkv = ops.attention_bwd_qkv(qkv, o, do.view(b, s, c), heads, (c // heads) ** -0.5)      # one kernel, nothing S x S in HBM
+        else:
+            dqkv = _attention_bwd(qkv, do.view(b, s, c), heads, (c // heads) ** -0.5)
         dhn1, dqkvw, dqkvb = _lin_grads(dqkv.view(rows, 3 * c), hn1.view(rows, c), qkvw, qkvb)
         dn1w, dn1b = ops.layernorm_bwd_(dt, dhn1.view(b, s, c), t, n1w, eps, dg_out=_dst(n1w), db_out=_dst(n1b))
         return dt, dn1w, dn1b, dqkvw, dqkvb, dpw, dpb, dls1, dn2w, dn2b, df1w, df1b, df2w, df2b, dls2, None, None
@@ -602,8 +610,13 @@ class DitBlockFn(torch.autograd.Function):
         a1 = ops.rmsnorm_modulate(h, n1w, mod, 0, c, eps)
         qkv = F.linear(a1, _bf(qkvw), _bf(qkvb))
         q, k, v = ops.qknorm_rope(qkv, qnw, knw, cos, sin, heads, eps)
-        p = ops.softmax_rows(ops.gemm_nt(q, k, out_f32=True), d ** -0.5)
-        o = ops.gemm_nt(p, ops.transpose_last2(v)).view(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, c)
+        fused = ops.attention_heads_supported(n, d) and _fused_attn_bwd()
+        if fused:       # the inference kernel; its backward recomputes the probabilities in registers (csrc/attention_bwd.hip)
+            p = None
+            o = ops.attention_heads(q, k, v, b, d ** -0.5)
+        else:
+            p = ops.softmax_rows(ops.gemm_nt(q, k, out_f32=True), d ** -0.5)
+            o = ops.gemm_nt(p, ops.transpose_last2(v)).view(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, c)
         o2 = F.linear(o, _bf(pw), _bf(pb))
         h_mid, a2 = ops.gated_residual_out(h, o2, mod, 2 * c, n2w, mod, 3 * c, 4 * c, eps)       # h itself is saved for the backward pass
         x12 = F.linear(a2, _bf(w12w), _bf(w12b))
@@ -612,6 +625,7 @@ class DitBlockFn(torch.autograd.Function):
         h_out, _ = ops.gated_residual_out(h_mid, o3, mod, 5 * c)
         ctx.save_for_backward(h, mod, a1, qkv, q, k, v, p, o, o2, h_mid, a2, x12, g, o3, n1w, qkvw, qnw, knw, pw, n2w, w12w, w3w, cos, sin)
         ctx.others = (qkvb, pb, w12b, w3b, heads, eps)
+        ctx.fused_attn = fused
         return h_out
 
     @staticmethod
@@ -633,13 +647,16 @@ class DitBlockFn(torch.autograd.Function):
         # attention branch
         do2 = ops.gated_residual_bwd(dt, o2, mod, dmod, 2 * c)
         do, dpw, dpb = _lin_grads(do2.view(rows, c), o.view(rows, c), pw, pb)
-        do_h = do.view(b, n, heads, d).permute(0, 2, 1, 3).reshape(b * heads, n, d)
-        pad = dp_ - d                                                   # head dim padded to the GEMM kernel's 32-wide K step (72 -> 96)
-        do_p, v_p = (F.pad(do_h, (0, pad)), F.pad(v, (0, pad))) if pad else (do_h.contiguous(), v)
-        ds = ops.softmax_rows_bwd(ops.gemm_nt(do_p, v_p, out_f32=True), p, d ** -0.5)
-        dv = ops.gemm_tn(p, do_h.contiguous())                          # [B*H, key, D]
-        dq = ops.gemm_nt(ds, ops.transpose_last2(k))                    # [B*H, N, Dp]
-        dk = ops.gemm_tn(ds, q)
+        if ctx.fused_attn:
+            dq, dk, dv = ops.attention_bwd_heads(q, k, v, o, do.view(b, n, c), b, d ** -0.5)
+        else:
+            do_h = do.view(b, n, heads, d).permute(0, 2, 1, 3).reshape(b * heads, n, d)
+            pad = dp_ - d                                                   # head dim padded to the GEMM kernel's 32-wide K step (72 -> 96)
+            do_p, v_p = (F.pad(do_h, (0, pad)), F.pad(v, (0, pad))) if pad else (do_h.contiguous(), v)
+            ds = ops.softmax_rows_bwd(ops.gemm_nt(do_p, v_p, out_f32=True), p, d ** -0.5)
+            dv = ops.gemm_tn(p, do_h.contiguous())                          # [B*H, key, D]
+            dq = ops.gemm_nt(ds, ops.transpose_last2(k))                    # [B*H, N, Dp]
+            dk = ops.gemm_tn(ds, q)
         dqkv, dqnw, dknw = ops.qknorm_rope_bwd(dq, dk, dv, qkv, qnw, knw, cos, sin, heads, eps, dqw_out=_dst(qnw), dkw_out=_dst(knw))
         da1, dqkvw, dqkvb = _lin_grads(dqkv.view(rows, 3 * c), a1.view(rows, c), qkvw, qkvb)
         dn1w = ops.rmsnorm_modulate_bwd_(dt, da1.view(b, n, c), h, n1w, mod, dmod, 0, c, eps, dw_out=_dst(n1w))

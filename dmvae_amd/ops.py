@@ -566,6 +566,31 @@ def attention_qknorm_rope(qkv: torch.Tensor, qw: torch.Tensor, kw: torch.Tensor,
     return out
 
 
+def attention_bwd_qkv(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """d(qkv) [B,S,3*C] of `attention_qkv` from its input, its result `out` [B,S,C] and d(out) (bf16): one fused kernel (csrc/attention_bwd.hip)."""
+    qkv = _req(qkv, bf16, "qkv"); out = _req(out, bf16, "out"); dout = _req(dout, bf16, "dout")
+    b, s, c3 = qkv.shape
+    c = c3 // 3
+    assert out.shape == (b, s, c) and dout.shape == (b, s, c)
+    dqkv = torch.empty_like(qkv)
+    check(_lib.lib().dmvae_attention_bwd_qkv_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), b, s, heads, c // heads, float(scale),
+                                                  _stream()), "attention_bwd_qkv_bf16")
+    return dqkv
+
+
+def attention_bwd_heads(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, batch: int, scale: float):
+    """(dq, dk [B*H,N,Dp], dv [B*H,N,D]) of `attention_heads` from its operands, its result `out` [B,N,H*D] and d(out)."""
+    q = _req(q, bf16, "q"); k = _req(k, bf16, "k"); v = _req(v, bf16, "v"); out = _req(out, bf16, "out"); dout = _req(dout, bf16, "dout")
+    bh, n, dp = q.shape
+    d = v.shape[-1]
+    heads = bh // batch
+    assert out.shape == (batch, n, heads * d) and dout.shape == out.shape
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    check(_lib.lib().dmvae_attention_bwd_heads_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                                    dv.data_ptr(), batch, n, heads, d, dp, float(scale), _stream()), "attention_bwd_heads_bf16")
+    return dq, dk, dv
+
+
 def attention_heads_supported(n: int, d: int) -> bool:
     return n <= 288 and d % 8 == 0 and (d + 31) // 32 * 32 in (64, 96)
 

@@ -223,6 +223,17 @@ int dmvae_attention_heads_bf16(const void* q, const void* k, const void* v, void
 int dmvae_attention_qknorm_rope_bf16(const void* qkv, const void* q_weight, const void* k_weight, const void* cos_table, const void* sin_table,
                                      void* out, int batch, int seq, int heads, int head_dim, float eps, float scale, dmvae_stream_t stream);
 
+/* Backward of the fused attention above (autograd's SDPA backward for timm Attention, dino_layers/attention.py:56-69, in the stages where the encoder
+ * trains -- train_dmd.py:349,519 -- and for LightningDiT's Attention, lightningdit.py:76-88, in the student's training turn): one kernel per call, the
+ * S x S probabilities are recomputed in registers and never reach HBM.  out = the forward result [batch][seq][heads*head_dim], dout = its gradient (bf16).
+ * _qkv: qkv [batch][seq][3][heads][64] -> dqkv in the same layout (every element of rows < seq written).  head_dim 64, seq <= 288.
+ * _heads: q, k [batch*heads][seq][head_dim_padded], v [batch*heads][seq][head_dim] -> dq, dk, dv in the same layouts (padded channels of dq / dk
+ *         come out as the zeros the padded operands imply).  head_dim % 8 == 0, head_dim_padded 64 or 96, seq <= 288. */
+int dmvae_attention_bwd_qkv_bf16(const void* qkv, const void* out, const void* dout, void* dqkv, int batch, int seq, int heads, int head_dim,
+                                 float scale, dmvae_stream_t stream);
+int dmvae_attention_bwd_heads_bf16(const void* q, const void* k, const void* v, const void* out, const void* dout, void* dq, void* dk, void* dv,
+                                   int batch, int seq, int heads, int head_dim, int head_dim_padded, float scale, dmvae_stream_t stream);
+
 /* Backward side of the same encoder block, for the stages where the encoder trains (train_dmd.py:349,519).  Residual stream f32,
  * Linear operands / results bf16 (autocast).  workspace: dmvae_vit_bwd_workspace(c) bytes.
  * layernorm_bwd: dx_io[rows][c] (f32, the residual-stream gradient) += LayerNorm backward of dy (bf16) at input x (f32);

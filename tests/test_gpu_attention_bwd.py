@@ -1,0 +1,81 @@
+"""csrc/attention_bwd.hip: backward of the fused multi-head self-attention (timm Attention, dino_layers/attention.py:56-69; LightningDiT Attention,
+lightningdit.py:76-88) against fp64 autograd on the same bf16 operands -- both layouts (qkv-interleaved head dim 64; head-major with head dim 64 and
+72 padded to 96), ragged token counts around the 32-token blocks, the 257 / 256 tokens of the two models.  The kernel rounds P and dS to bf16 where they
+enter the matrix cores (as the GEMM-composed backward it replaces did, and as autocast SDPA does), so the bar is the bf16 operand floor; the composed
+route is held to the same reference next to it."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _ref(q, k, v, do, scale):
+    """q, k, v, do: [B, H, S, D] fp64 -> o, dq, dk, dv"""
+    q, k, v = (t.clone().requires_grad_(True) for t in (q, k, v))
+    p = torch.softmax(scale * q @ k.transpose(-1, -2), dim=-1)
+    o = p @ v
+    o.backward(do)
+    return o.detach(), q.grad, k.grad, v.grad
+
+
+def _rl2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("b,s,h", [(2, 257, 4), (1, 288, 2), (3, 64, 2), (2, 33, 1), (1, 1, 2), (1, 200, 16)])
+def test_attention_bwd_qkv_layout(b, s, h, monkeypatch):
+    from dmvae_amd import ops, functional as Fn
+    d, c = 64, h * 64
+    g = torch.Generator().manual_seed(s + h)
+    qkv = (torch.randn(b, s, 3, h, d, generator=g) * 1.5).to(BF)
+    do = torch.randn(b, s, c, generator=g).to(BF)
+    scale = d ** -0.5
+    q, k, v = (qkv[:, :, i].double().permute(0, 2, 1, 3) for i in range(3))
+    o_r, dq_r, dk_r, dv_r = _ref(q, k, v, do.double().view(b, s, h, d).permute(0, 2, 1, 3), scale)
+    want = torch.stack([dq_r, dk_r, dv_r], 0).permute(1, 3, 0, 2, 4).reshape(b, s, 3 * c)      # [3,B,H,S,D] -> [B,S,3,H,D]
+    qkv_g, do_g = qkv.view(b, s, 3 * c).to(DEV), do.to(DEV)
+    o = ops.attention_qkv(qkv_g, h, scale)
+    assert _rl2(o.cpu(), o_r.permute(0, 2, 1, 3).reshape(b, s, c)) < 6e-3
+    dqkv = ops.attention_bwd_qkv(qkv_g, o, do_g, h, scale)
+    assert dqkv.shape == (b, s, 3 * c) and torch.isfinite(dqkv.float()).all()
+    for i, name in enumerate("qkv"):
+        got = dqkv.view(b, s, 3, c)[:, :, i].float().cpu()
+        ref = want.view(b, s, 3, c)[:, :, i]
+        if s == 1 and name != "v":         # a single key: the softmax is constant, dq = dk = 0 exactly; the kernel leaves rounding noise of P - 1
+            assert got.abs().max() < 1e-5
+            continue
+        assert _rl2(got, ref) < 1.2e-2, (name, _rl2(got, ref))
+        assert rel_err(got, ref) < 3e-2, name
+    assert torch.equal(dqkv, ops.attention_bwd_qkv(qkv_g, o, do_g, h, scale))                    # fixed summation order
+    comp = Fn._attention_bwd(qkv_g, do_g, h, scale)                                               # the GEMM-composed route: same bar, and close to the fused one
+    if s > 1:
+        assert _rl2(comp.float().cpu(), want) < 1.2e-2 and _rl2(dqkv.float(), comp.float()) < 1.2e-2
+
+
+@pytest.mark.parametrize("b,n,h,d", [(2, 256, 4, 72), (2, 256, 3, 64), (1, 100, 2, 72), (1, 288, 1, 40)])
+def test_attention_bwd_heads_layout(b, n, h, d):
+    from dmvae_amd import ops
+    dp = (d + 31) // 32 * 32
+    g = torch.Generator().manual_seed(n + d)
+    q = torch.zeros(b * h, n, dp, dtype=BF); k = torch.zeros(b * h, n, dp, dtype=BF)
+    q[..., :d] = (torch.randn(b * h, n, d, generator=g)).to(BF)
+    k[..., :d] = (torch.randn(b * h, n, d, generator=g)).to(BF)
+    v = torch.randn(b * h, n, d, generator=g).to(BF)
+    do = torch.randn(b, n, h * d, generator=g).to(BF)
+    scale = d ** -0.5
+    f = lambda t: t[..., :d].double().view(b, h, n, d)
+    o_r, dq_r, dk_r, dv_r = _ref(f(q), f(k), f(v), do.double().view(b, n, h, d).permute(0, 2, 1, 3), scale)
+    qg, kg, vg, dog = q.to(DEV), k.to(DEV), v.to(DEV), do.to(DEV)
+    o = ops.attention_heads(qg, kg, vg, b, scale)
+    assert _rl2(o.cpu(), o_r.permute(0, 2, 1, 3).reshape(b, n, h * d)) < 6e-3
+    dq, dk, dv = ops.attention_bwd_heads(qg, kg, vg, o, dog, b, scale)
+    assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
+    for got, ref, name in ((dq, dq_r, "dq"), (dk, dk_r, "dk"), (dv, dv_r, "dv")):
+        gf = got.float().cpu()
+        assert _rl2(gf[..., :d], ref.reshape(b * h, n, d)) < 1.2e-2, name
+        if gf.shape[-1] > d:
+            assert gf[..., d:].abs().max() == 0, name + ": padded channels"
