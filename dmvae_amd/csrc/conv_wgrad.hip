@@ -335,7 +335,7 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
     const int rc = dmvae_wgrad_pp_launch(dy, a, w.slab, dbias ? w.slab + (size_t)splits * tot : nullptr, d, splits, pp_kchunk, pp_cfg, stream);
     if (rc) return rc;
     bias_fused = dbias != nullptr;
-    { const int ng = T * (d->cin / 128); pp_ntiles = pp_cfg == 0 ? ng / 2 : (ng + 2) / 3; }
+    { const int ng = T * (d->cin / 128); pp_ntiles = pp_cfg == 0 ? (ng + 1) / 2 : (ng + 2) / 3; }
   } else {
     w.kchunk = (((w.M + splits - 1) / splits) + BKP - 1) / BKP * BKP;
     splits = (w.M + w.kchunk - 1) / w.kchunk;

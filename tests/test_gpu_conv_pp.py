@@ -89,6 +89,10 @@ WGRAD_CASES = [  # N, H, W, Cin, Cout, ks, ups  -- shapes the ping-pong wgrad ke
     (1, 128, 128, 256, 128, 1, 0),   # 1x1 with a partially filled column-group triple
     (1, 128, 64, 512, 256, 1, 0),    # 1x1, 256x256 tiles, W = 64
     (1, 1, 8192, 1024, 256, 1, 0),   # Linear layer as a 1x1 conv over tokens (MLP wgrad)
+    (1, 1, 4096, 1152, 1152, 1, 0),  # LightningDiT-XL width: 4.5 cout tiles x 4.5 column-group pairs on the 256x256 tile (ragged rows and an odd group count, masked)
+    (1, 1, 4096, 1152, 3456, 1, 0),  # its qkv Linear: 13.5 cout tiles
+    (1, 1, 2048, 3072, 1152, 1, 0),  # its w3 Linear
+    (1, 32, 64, 384, 640, 3, 0),     # 3x3 with 2.5 cout tiles / 27 column groups
 ]
 
 
