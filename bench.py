@@ -286,11 +286,11 @@ def main():
     # and committed under profiles/; null when the committed profile is for a different kernel
     traffic, traffic_src = None, None
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_conv_pp_traffic.json")) as f:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_conv_pp_traffic.json")) as f:
             tp = json.load(f)
         if tp.get("kernel") == DOMINANT and args.batch == LOCAL_BATCH:
             traffic = int(tp["hbm_MB_per_launch"] * 1e6)
-            traffic_src = "profiles/r1_conv_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, %d launches; FETCH_SIZE x2 per MI355X_MICROARCH.md)" % tp["launches_profiled"]
+            traffic_src = "profiles/r2_conv_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, %d launches; FETCH_SIZE x2 per MI355X_MICROARCH.md)" % tp["launches_profiled"]
     except (OSError, ValueError, KeyError):
         pass
     out = {

@@ -24,7 +24,9 @@
 #include "common.h"
 #include "dmvae_hip.h"
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 namespace dmvae_conv_pp {
 
@@ -38,7 +40,8 @@ struct Args {
   int ks, act, M, ctiles, total;  // total = pixel tiles x cout tiles
   int so, pd, sd;                 // gather geometry (dmvae_conv_geometry): tap k of output o reads source (o * so - pd + k) / sd when that is an in-range integer
   int Ml;                         // SUB: source pixels N * Hi * Wi (= output pixels of one parity class); M is set to the same value
-  int stagger;                    // start delay per group of CUs, units of 64 cycles (0 = off)
+  unsigned* sched;                // DYN: this stream's scheduling words -- [0..7] tiles claimed past the static first round, per XCD range; [8] blocks finished;
+                                  // [16 + b] the tile block b runs next.  All zero between launches (the last block to finish resets them).
   unsigned long long* dbg;  // optional per-block s_memtime stamps (dmvae_debug_timing), null in production
 };
 
@@ -80,7 +83,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // interleaved pixels.  As a zero-insertion gather (GEN, sd = 2) twelve of the sixteen taps of every output pixel are masked: 4x the MFMA work.  A pixel
 // tile holds output pixels of ONE parity class (wave-uniform tap set); the four classes of a source region are adjacent in the block order so that the
 // region is fetched into the XCD's L2 once.
-template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool OUT_F32, bool KO, bool GEN = false, bool SUB = false>
+// DYN: tiles after a block's first are claimed from per-XCD counters instead of a static stride.  With the static stride a persistent block that starts
+// late -- its CU held by another stream's kernel, e.g. an RCCL all-reduce overlapping backward: a block needs 128-160 KB of LDS, so it cannot share a CU
+// with anything -- still owes all of its tiles and the launch ends a whole block-time late; with the counters the blocks that run take the tiles and the
+// launch degrades by the fraction of CUs taken.  A block claims from its own XCD's contiguous range first (the L2 locality of the static order) and from
+// the others' once that is exhausted.  Results do not depend on who computes which tile.
+template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool OUT_F32, bool KO, bool GEN = false, bool SUB = false, bool DYN = false>
 __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__  // the host pass only needs the launch stub (hipcc drops the stub when it cannot digest the gfx950 body)
   constexpr int BM = TM / WM / 32, BP = TP / WP / 32;  // 32x32 accumulator blocks per wave
@@ -288,6 +296,20 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   auto stamp = [&](unsigned work, int k) {
     if (a.dbg && tid == 0) a.dbg[(size_t)work * 8 + k] = __builtin_amdgcn_s_memtime();
   };
+  // DYN: thread 0 claims the tile AFTER the one being started and publishes it; every wave picks it up with the trailing DMA wait of the main loop
+  auto claim = [&]() {
+    if (tid == 0) {
+      const unsigned x = blockIdx.x & 7u, first = gridDim.x >> 3;  // gridDim.x is a multiple of 8: `first` tiles per XCD range are the static first round
+      unsigned flat = 0xFFFFFFFFu;
+      for (unsigned k = 0; k < 8u; k++) {
+        const unsigned xx = (x + k) & 7u;
+        const unsigned cnt = ((unsigned)a.total >> 3) + (xx < ((unsigned)a.total & 7u) ? 1u : 0u);
+        const unsigned j = first + atomicAdd(a.sched + xx, 1u);
+        if (j < cnt) { flat = j * 8u + xx; break; }
+      }
+      __hip_atomic_store(a.sched + 16 + blockIdx.x, flat, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // read back by this block's own waves only
+    }
+  };
   stamp(blockIdx.x, 0);
   setup(blockIdx.x);
   stamp(blockIdx.x, 1);
@@ -296,6 +318,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   for (unsigned work = blockIdx.x; work < (unsigned)a.total;) {
   const int m0c = m0, n0c = n0;  // the tile being computed (setup() moves m0 / n0 on to the next one before the epilogue)
   const int parc = par;
+  if constexpr (DYN) claim();
 #pragma unroll
   for (int i = 0; i < BM16; i++)
 #pragma unroll
@@ -340,6 +363,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   }
   stamp(work, 3);
   if (grp == 0) __builtin_amdgcn_s_barrier();  // matches group 1's extra barrier
+  unsigned next_dyn = 0;
+  if constexpr (DYN) next_dyn = __hip_atomic_load(a.sched + 16 + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);  // published >= one barrier ago
   wait_vmcnt<0>();                             // the trailing all-zero pieces
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA (inline asm, invisible to the hazard recognizer) -> accumulator reads
 
@@ -350,7 +375,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   // global_store_dwordx4 wave-instruction), independent of what other CUs do -- so the next tile's setup and first DMA are
   // started first and fly underneath it (staging uses ring slots 2.. in half-cout passes to leave slots 0-1 to that DMA).
   __builtin_amdgcn_s_barrier();  // every wave's trailing DMA has landed and all fragment reads are done: the ring is free
-  const unsigned next = work + gridDim.x;
+  const unsigned next = DYN ? (unsigned)__builtin_amdgcn_readfirstlane((int)next_dyn) : work + gridDim.x;
   const bool has_next = next < (unsigned)a.total;
   if (has_next) {
     stamp(next, 0);
@@ -459,24 +484,56 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   if (has_next) issue(2 * SLOT);
   work = next;
   }  // persistent tile loop
+  if constexpr (DYN) {
+    if (tid == 0 && atomicAdd(a.sched + 8, 1u) == gridDim.x - 1) {  // last block out: nobody claims any more -- leave the words zero for the next launch
+#pragma unroll
+      for (int k = 0; k < 9; k++) __hip_atomic_store(a.sched + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 #endif
 }
 
-template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32, bool KO, bool GEN = false, bool SUB = false>
+// Scheduling words of the DYN instantiation: one set per stream (launches on one stream never overlap; sets are self-cleaning, so a captured graph replays
+// correctly).  Static device memory of the code object, zero at load: the library allocates nothing.
+constexpr int SCHED_WORDS = 16 + 512, SCHED_SLOTS = 32;
+__device__ unsigned g_sched[SCHED_SLOTS * SCHED_WORDS];
+
+static unsigned* sched_for(hipStream_t st) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, int> slot;
+  static unsigned* base = nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!base && hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_sched)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  auto it = slot.find(st);
+  if (it == slot.end()) {
+    if ((int)slot.size() >= SCHED_SLOTS) return nullptr;  // more streams than sets: those launches keep the static stride
+    it = slot.emplace(st, (int)slot.size()).first;
+  }
+  return base + (size_t)it->second * SCHED_WORDS;
+}
+
+template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32, bool KO, bool GEN = false, bool SUB = false, bool DYN = false>
 int launch(Args a, hipStream_t st) {
   a.ctiles = (a.Cout + TM - 1) / TM;
   a.total = ((a.M + TP - 1) / TP) * a.ctiles * (SUB ? 4 : 1);
   static const int persist = [] { const char* e = getenv("DMVAE_PP_GRID"); return e ? atoi(e) : 256; }();  // 0: one block per tile
   const unsigned grid = (persist > 0 && a.total > persist) ? (unsigned)persist : (unsigned)a.total;
+  if constexpr (!DYN && !UPS && KO && !F32) {  // the bf16-output, chunk-outer instantiations (every large launch of the training step) have a DYN twin
+    static const bool dyn = [] { const char* e = getenv("DMVAE_PP_DYNAMIC"); return e ? atoi(e) != 0 : false; }();
+    if (dyn && grid == 256u && (unsigned)a.total > grid) {
+      a.sched = sched_for(st);
+      if (a.sched) return launch<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, true>(a, st);
+    }
+  }
   constexpr int ring = NBUF * (TM + TP) * 64, epi = 2 * (TM + TP) * 64 + 8 * 32 * ((TM / WM / 2) * 4 + 16);
   constexpr int lds = ring > epi ? ring : epi;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, DYN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB>), dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, DYN>), dim3(grid), dim3(512), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -510,6 +567,22 @@ int pick(const Args& a, hipStream_t st, bool gen) {
 static unsigned long long* g_dbg = nullptr;
 extern "C" void dmvae_debug_timing(void* buf) { g_dbg = (unsigned long long*)buf; }  // diagnostics only (tools/probes/time_conv_pp.py)
 
+// Diagnostics only (tools/probes/contention.py): `blocks` workgroups that each hold `lds_bytes` of LDS and spin for `microseconds` -- a stand-in for another
+// stream's resident kernel (an RCCL collective) taking CUs away from the persistent conv blocks.
+__global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks) {
+  extern __shared__ char occ[];
+  occ[threadIdx.x] = 0;
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int dmvae_debug_occupy(int blocks, int lds_bytes, int microseconds, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(64), lds_bytes, stream, (unsigned long long)microseconds * 100ull);  // wall_clock64: 100 MHz
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
 int dmvae_conv_geometry(const dmvae_conv_desc* d, int* ho, int* wo, int* so, int* pd, int* sd, int* fl);  // conv_fwd.hip
 
 int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void* residual, void* y, const dmvae_conv_desc* d,
@@ -536,7 +609,7 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
   a.Ho = ho; a.Wo = wo; a.so = so; a.pd = pd; a.sd = sd;
   a.ks = d->ks; a.act = d->act; a.M = (int)M; a.ctiles = 0; a.dbg = g_dbg;
   a.Ml = d->n * d->h * d->w;
-  { static const int stag = [] { const char* e = getenv("DMVAE_PP_STAGGER"); return e ? atoi(e) : 0; }(); a.stagger = stag; }
+  a.sched = nullptr;
   const bool f32 = d->out_f32 != 0;
   if (sub) {  // per-parity 2x2 decomposition: pixel tiles run over the source grid, once per parity class
     a.M = a.Ml;

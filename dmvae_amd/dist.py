@@ -34,6 +34,12 @@ def init_distributed_mode(backend: Optional[str] = None, timeout_minutes: int = 
         return
     _rank, _world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     _local_rank = int(os.environ.get("LOCAL_RANK", _rank))
+    if _world > 1:
+        # From here on the collectives' kernels share the GPU with the persistent conv blocks, which need a whole CU each (128-160 KB of LDS): claim tiles
+        # dynamically so that a launch slows down by the fraction of CUs taken instead of a whole block-time (csrc/conv_pp.hip, DYN; measured with a resident
+        # side-stream kernel on one GPU, tools/probes/contention.py: 16 CUs taken cost +6..+38 % instead of +48..+75 %; 0.3-1.4 % slower with no contention, which
+        # is why a single rank keeps the static stride).  The library reads the flag at its first conv launch: it has to be in the C environment before that.
+        os.environ.setdefault("DMVAE_PP_DYNAMIC", "1")
     use_gpu = torch.cuda.is_available()
     if use_gpu:
         torch.cuda.set_device(_local_rank % torch.cuda.device_count())
