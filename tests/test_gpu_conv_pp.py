@@ -115,3 +115,48 @@ def test_conv_pp_wgrad(case):
     assert rel_err(dw, wr.grad) < 1e-5 and rel_err(db, br.grad) < 1e-5
     dw2, _ = ops.conv2d_nhwc_wgrad(dy, a, ks, upsample=bool(ups))
     assert torch.equal(dw, dw2)                       # deterministic split-K (fixed-order slab reduction)
+
+
+def test_dynamic_tile_claiming_is_bit_identical(tmp_path):
+    """DMVAE_PP_DYNAMIC=1 (what dmvae_amd.dist sets when more than one rank runs): persistent blocks claim their tiles from per-XCD counters instead of a
+    static stride.  Which block computes a tile must not matter: the outputs of a fresh process with the flag on -- including launches that run while a
+    side-stream kernel holds 48 CUs, and back-to-back launches that reuse the self-cleaning counters -- equal this process's static-stride outputs bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from dmvae_amd import ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import ctypes, sys, time, torch
+sys.path.insert(0, %r)
+from dmvae_amd import ops, _lib
+L = _lib.lib(); L.dmvae_debug_occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+out = {}
+side = torch.cuda.Stream()
+for tag, (n, h, w, cin, cout, ks, kw) in {"a": (8, 128, 128, 128, 256, 3, {}), "b": (16, 64, 64, 64, 128, 3, {}), "c": (4, 96, 96, 64, 256, 4, {"stride": 2, "transposed": True})}.items():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16).cuda()
+    wt = (torch.randn(cout, ks * ks, cin, generator=g) * 0.03).to(torch.bfloat16).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    y0 = ops.conv2d_nhwc(x, wt, b, ks=ks, **kw)
+    y1 = ops.conv2d_nhwc(x, wt, b, ks=ks, **kw)
+    L.dmvae_debug_occupy(48, 64 * 1024, 20000, side.cuda_stream); time.sleep(0.003)
+    y2 = ops.conv2d_nhwc(x, wt, b, ks=ks, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(y0, y2), tag
+    out[tag] = y0.cpu()
+torch.save(out, %r)
+print("dyn ok")
+"""
+    path = str(tmp_path / "dyn.pt")
+    env = dict(os.environ, DMVAE_PP_DYNAMIC="1")
+    r = subprocess.run([sys.executable, "-c", script % (root, path)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "dyn ok" in r.stdout, r.stderr[-3000:]
+    got = torch.load(path)
+    for tag, (n, h, w, cin, cout, ks, kw) in {"a": (8, 128, 128, 128, 256, 3, {}), "b": (16, 64, 64, 64, 128, 3, {}),
+                                               "c": (4, 96, 96, 64, 256, 4, {"stride": 2, "transposed": True})}.items():
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(n, h, w, cin, generator=g).to(BF).to(DEV)
+        wt = (torch.randn(cout, ks * ks, cin, generator=g) * 0.03).to(BF).to(DEV)
+        b = torch.randn(cout, generator=g).to(DEV)
+        assert torch.equal(ops.conv2d_nhwc(x, wt, b, ks=ks, **kw).cpu(), got[tag]), tag
