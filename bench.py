@@ -267,7 +267,7 @@ def main():
     log = tr.read_log()
     if rank != 0:
         return
-    DOMINANT = "conv_pp_kernel<256, 256, 2, 4, 4, false, false, true, false, false>"
+    DOMINANT = "conv_pp_kernel<256, 256, 2, 4, 4, false, false, true, false, false, false, false>"
     per = {}
     for label, e0, e1, fl in timing:
         a = per.setdefault(label, [0.0, 0.0, 0])

@@ -24,6 +24,8 @@ SIGNATURES = {
     "dmvae_last_error": (c_char_p, []),
     "dmvae_abi_version": (c_int, []),
     "dmvae_conv2d_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvDesc), c_void_p]),
+    "dmvae_conv2d_nhwc_fwd_gnstats_workspace": (c_size_t, [POINTER(ConvDesc), c_int]),
+    "dmvae_conv2d_nhwc_fwd_gnstats": (c_int, [c_void_p] * 7 + [c_size_t, c_int, c_float, POINTER(ConvDesc), c_void_p]),
     "dmvae_conv2d_nhwc_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "dmvae_gemm_nt_batched": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_longlong] * 3 + [c_int, c_int, c_void_p]),
     "dmvae_gemm_tn_batched_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),

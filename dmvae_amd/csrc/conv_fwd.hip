@@ -248,7 +248,8 @@ int launch(const ConvArgs& a_in, hipStream_t st, int batch = 1) {
 using namespace dmvae_conv_fwd;
 
 int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void* residual, void* y, const dmvae_conv_desc* d,
-                      hipStream_t stream);  // conv_pp.hip; returns 1 when it declines the shape
+                      hipStream_t stream, float* gnpart, int gn_groups, int* gn_tp);  // conv_pp.hip; returns 1 when it declines the shape
+int dmvae_gn_stats_from_quads(const float* part, float* stats, int n, int hw, int c, int groups, int tp, float eps, hipStream_t stream);  // groupnorm.hip
 
 // Output size and gather parameters (see ConvArgs) of a conv descriptor; shared with conv_wgrad.hip.  Returns non-zero for combinations
 // that are not built.
@@ -299,7 +300,7 @@ extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* b
   DMVAE_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0, "conv2d_nhwc_fwd: empty shape");
   DMVAE_CHECK_ARG(d->act >= 0 && d->act <= 4 && (d->act != 3 || residual), "conv2d_nhwc_fwd: bad activation code %d", d->act);
   {
-    const int r = dmvae_conv_pp_try(x, w, bias, residual, y, d, stream);  // large shapes: the ping-pong kernel
+    const int r = dmvae_conv_pp_try(x, w, bias, residual, y, d, stream, nullptr, 0, nullptr);  // large shapes: the ping-pong kernel
     if (r <= 0) return r;
   }
   ConvArgs a;
@@ -323,6 +324,39 @@ extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* b
     return f32 ? launch<64, true, 32, 256>(a, stream) : launch<64, false, 32, 256>(a, stream);
   if (a.Cin % 64 == 0) return f32 ? launch<64, true>(a, stream) : launch<64, false>(a, stream);
   return f32 ? launch<32, true>(a, stream) : launch<32, false>(a, stream);
+}
+
+// conv2d_nhwc_fwd + the GroupNorm statistics of its bf16 result.  Large shapes: the ping-pong kernel's STATS instantiation sums the rounded results in its
+// epilogue and a finishing kernel combines the per-tile partials; everything else: the conv, then the two-kernel statistics pass over the result.
+extern "C" size_t dmvae_conv2d_nhwc_fwd_gnstats_workspace(const dmvae_conv_desc* d, int groups) {
+  if (!d || groups <= 0) return 0;
+  int ho, wo, g0, g1, g2, g3;
+  if (dmvae_conv_geometry(d, &ho, &wo, &g0, &g1, &g2, &g3)) return 0;
+  const size_t M = (size_t)d->n * ho * wo;
+  const size_t quads = ((M + 255) / 256 + 8) * (size_t)d->cout * 2 * sizeof(float);   // [pixel tiles of >= 256][4][Cout / 4][2]
+  const size_t two_pass = dmvae_groupnorm_workspace(d->n, ho * wo, d->cout, groups);
+  return quads > two_pass ? quads : two_pass;
+}
+
+extern "C" int dmvae_conv2d_nhwc_fwd_gnstats(const void* x, const void* w, const void* bias, const void* residual, void* y, void* stats, void* workspace,
+                                             size_t workspace_bytes, int groups, float eps, const dmvae_conv_desc* d, hipStream_t stream) {
+  DMVAE_CHECK_ARG(x && w && y && stats && workspace && d, "conv2d_nhwc_fwd_gnstats: null pointer");
+  DMVAE_CHECK_ARG(!d->out_f32, "conv2d_nhwc_fwd_gnstats: the statistics are those of the bf16 result (out_f32 must be 0)");
+  int ho, wo, g0, g1, g2, g3;
+  DMVAE_CHECK_ARG(dmvae_conv_geometry(d, &ho, &wo, &g0, &g1, &g2, &g3) == 0, "conv2d_nhwc_fwd_gnstats: unsupported conv descriptor");
+  DMVAE_CHECK_ARG(workspace_bytes >= dmvae_conv2d_nhwc_fwd_gnstats_workspace(d, groups) && dmvae_groupnorm_workspace(d->n, ho * wo, d->cout, groups) > 0,
+                  "conv2d_nhwc_fwd_gnstats: workspace too small or unsupported GroupNorm shape (n=%d hw=%d c=%d groups=%d)", d->n, ho * wo, d->cout, groups);
+  static const bool fuse = [] { const char* e = getenv("DMVAE_GN_STATS_FUSED"); return e ? atoi(e) != 0 : true; }();
+  if (fuse && d->ks != 0 && d->cin % 32 == 0 && d->cout % 4 == 0 && d->act >= 0 && d->act <= 4 && (d->act != 3 || residual)) {
+    int tp = 0;
+    const int r = dmvae_conv_pp_try(x, w, bias, residual, y, d, stream, (float*)workspace, groups, &tp);
+    if (r < 0) return r;
+    if (r == 0 && tp > 0) return dmvae_gn_stats_from_quads((const float*)workspace, (float*)stats, d->n, ho * wo, d->cout, groups, tp, eps, stream);
+    if (r == 0) return dmvae_groupnorm_stats(y, stats, workspace, workspace_bytes, d->n, ho * wo, d->cout, groups, eps, stream);
+  }
+  const int r = dmvae_conv2d_nhwc_fwd(x, w, bias, residual, y, d, stream);
+  if (r) return r;
+  return dmvae_groupnorm_stats(y, stats, workspace, workspace_bytes, d->n, ho * wo, d->cout, groups, eps, stream);
 }
 
 // C[b][m][n] = act( sum_k A[b][m][k] * B[b][n][k] + bias[n] + R[b][m][n] ), all row-major bf16 (C bf16 or f32).

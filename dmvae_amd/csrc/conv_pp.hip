@@ -40,6 +40,7 @@ struct Args {
   int ks, act, M, ctiles, total;  // total = pixel tiles x cout tiles
   int so, pd, sd;                 // gather geometry (dmvae_conv_geometry): tap k of output o reads source (o * so - pd + k) / sd when that is an in-range integer
   int Ml;                         // SUB: source pixels N * Hi * Wi (= output pixels of one parity class); M is set to the same value
+  float* gnpart;                  // STATS: [pixel tile][wave column 0..3][Cout / 4][2] per-tile (sum, sum of squares) of the bf16 results, 4 channels each
   unsigned* sched;                // DYN: this stream's scheduling words -- [0..7] tiles claimed past the static first round, per XCD range; [8] blocks finished;
                                   // [16 + b] the tile block b runs next.  All zero between launches (the last block to finish resets them).
   unsigned long long* dbg;  // optional per-block s_memtime stamps (dmvae_debug_timing), null in production
@@ -88,7 +89,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // with anything -- still owes all of its tiles and the launch ends a whole block-time late; with the counters the blocks that run take the tiles and the
 // launch degrades by the fraction of CUs taken.  A block claims from its own XCD's contiguous range first (the L2 locality of the static order) and from
 // the others' once that is exhausted.  Results do not depend on who computes which tile.
-template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool OUT_F32, bool KO, bool GEN = false, bool SUB = false, bool DYN = false>
+// STATS: the epilogue also sums the (bf16-rounded) results and their squares per 4 output channels and pixel tile -- the statistics pass of the GroupNorm
+// that follows most decoder convs (flux_ae.py:62,64,71-76) then has nothing left to read: a finishing kernel combines the partials per (image, group) in
+// f64 (groupnorm.hip::stats_from_quads_kernel).  Its own instantiation: the plain kernel's code is unchanged.
+template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool OUT_F32, bool KO, bool GEN = false, bool SUB = false, bool DYN = false, bool STATS = false>
 __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__  // the host pass only needs the launch stub (hipcc drops the stub when it cannot digest the gfx950 body)
   constexpr int BM = TM / WM / 32, BP = TP / WP / 32;  // 32x32 accumulator blocks per wave
@@ -392,6 +396,12 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     char* reg = smem + 2 * SLOT + wave * (32 * ROWB);
     const int px_w = lane & 31;
     const int cl = lane % LPR, rg = lane / LPR;
+    static_assert(!STATS || !OUT_F32, "STATS: statistics of the bf16 result");
+    float sacc[STATS ? 2 : 1][2][2];  // [pass][4-channel half of the lane's 8 couts][sum, sum of squares]
+    if constexpr (STATS) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) (&sacc[0][0][0])[i] = 0.f;
+    }
 #pragma unroll
     for (int hh = 0; hh < 2; hh++) {
       if (n0c + wm * (TM / WM) + hh * CWH >= a.Cout) continue;  // this wave's couts of the pass are all padding (wave-uniform; e.g. Cout = 64 on the 128-row tile)
@@ -468,6 +478,17 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
               bf16x8 o;
 #pragma unroll
               for (int e = 0; e < 8; e++) o[e] = (bf16)v[e];
+              if constexpr (STATS) {  // v_dot2c_f32_bf16 on the packed result: two channels per instruction, 8 instructions per store instead of 24
+                const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+                for (int pr = 0; pr < 4; pr++) {
+                  const bf16x2 p2 = {o[2 * pr], o[2 * pr + 1]};
+                  float& s1 = sacc[STATS ? hh : 0][pr >> 1][0];
+                  float& s2 = sacc[STATS ? hh : 0][pr >> 1][1];
+                  s1 = __builtin_amdgcn_fdot2_f32_bf16(p2, one2, s1, false);
+                  s2 = __builtin_amdgcn_fdot2_f32_bf16(p2, p2, s2, false);
+                }
+              }
               // non-temporal: the tile is next read by a later kernel, after far more than an L2 of other traffic
               __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.y) + off));
             }
@@ -475,6 +496,19 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads retired before the next block overwrites the region
       }
+    }
+    if constexpr (STATS) {  // lanes that share `cl` hold different pixel rows of the same 8 couts: fold them, then one partial per (tile, wave column, quad)
+      const size_t trow = (size_t)(SUB ? (m0c / TP) * 4 + parc : m0c / TP) * WP + wp;
+#pragma unroll
+      for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+        for (int qd = 0; qd < 2; qd++) {
+          float s1 = sacc[STATS ? hh : 0][qd][0], s2 = sacc[STATS ? hh : 0][qd][1];
+#pragma unroll
+          for (int off = LPR; off < 64; off <<= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+          const int cq = n0c + wm * (TM / WM) + hh * CWH + lane * 8 + qd * 4;
+          if (lane < LPR && cq < a.Cout) *reinterpret_cast<f32x2*>(a.gnpart + (trow * (a.Cout >> 2) + (cq >> 2)) * 2) = f32x2{s1, s2};
+        }
     }
   }
   stamp(work, 4);
@@ -512,7 +546,7 @@ static unsigned* sched_for(hipStream_t st) {
   return base + (size_t)it->second * SCHED_WORDS;
 }
 
-template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32, bool KO, bool GEN = false, bool SUB = false, bool DYN = false>
+template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32, bool KO, bool GEN = false, bool SUB = false, bool DYN = false, bool STATS = false>
 int launch(Args a, hipStream_t st) {
   a.ctiles = (a.Cout + TM - 1) / TM;
   a.total = ((a.M + TP - 1) / TP) * a.ctiles * (SUB ? 4 : 1);
@@ -522,18 +556,18 @@ int launch(Args a, hipStream_t st) {
     static const bool dyn = [] { const char* e = getenv("DMVAE_PP_DYNAMIC"); return e ? atoi(e) != 0 : false; }();
     if (dyn && grid == 256u && (unsigned)a.total > grid) {
       a.sched = sched_for(st);
-      if (a.sched) return launch<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, true>(a, st);
+      if (a.sched) return launch<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, true, STATS>(a, st);
     }
   }
   constexpr int ring = NBUF * (TM + TP) * 64, epi = 2 * (TM + TP) * 64 + 8 * 32 * ((TM / WM / 2) * 4 + 16);
   constexpr int lds = ring > epi ? ring : epi;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, DYN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, DYN, STATS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, DYN>), dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, DYN, STATS>), dim3(grid), dim3(512), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -556,6 +590,12 @@ int pick(const Args& a, hipStream_t st, bool gen) {
     if (a.Cout <= 128) return launch<128, 512, 2, 4, 4, UPS, F32, false>(a, st);
     return launch<256, 256, 2, 4, 4, UPS, F32, false>(a, st);
   } else {
+    if constexpr (!F32) {
+      if (a.gnpart) {  // GroupNorm statistics of the result in the epilogue (chunk-outer K order only)
+        if (a.Cout <= 128) return launch<128, 512, 2, 4, 4, false, false, true, false, false, false, true>(a, st);
+        return launch<256, 256, 2, 4, 4, false, false, true, false, false, false, true>(a, st);
+      }
+    }
     if (a.Cout <= 128) return ko ? launch<128, 512, 2, 4, 4, UPS, F32, true>(a, st) : launch<128, 512, 2, 4, 4, UPS, F32, false>(a, st);  // 160 KiB of LDS: the whole CU
     return ko ? launch<256, 256, 2, 4, 4, UPS, F32, true>(a, st) : launch<256, 256, 2, 4, 4, UPS, F32, false>(a, st);
   }
@@ -585,8 +625,11 @@ extern "C" int dmvae_debug_occupy(int blocks, int lds_bytes, int microseconds, h
 
 int dmvae_conv_geometry(const dmvae_conv_desc* d, int* ho, int* wo, int* so, int* pd, int* sd, int* fl);  // conv_fwd.hip
 
+// gnpart / gn_groups: when non-null and the shape allows (bf16 result, plain or per-parity route, whole pixel tiles per image, groups of a multiple of 4
+// channels) the launch also leaves per-tile GroupNorm partials there and *gn_tp is set to the pixel-tile size (else 0: the caller computes the statistics itself).
 int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void* residual, void* y, const dmvae_conv_desc* d,
-                      hipStream_t stream) {
+                      hipStream_t stream, float* gnpart, int gn_groups, int* gn_tp) {
+  if (gn_tp) *gn_tp = 0;
   using namespace dmvae_conv_pp;
   static const bool disabled = [] { const char* e = getenv("DMVAE_CONV_V1"); return e && atoi(e) != 0; }();
   if (disabled) return 1;
@@ -609,10 +652,21 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
   a.Ho = ho; a.Wo = wo; a.so = so; a.pd = pd; a.sd = sd;
   a.ks = d->ks; a.act = d->act; a.M = (int)M; a.ctiles = 0; a.dbg = g_dbg;
   a.Ml = d->n * d->h * d->w;
+  a.gnpart = nullptr;
+  if (gnpart && gn_tp && !d->out_f32 && (plain || sub) && !ups && gn_groups > 0 && d->cout % gn_groups == 0 && (d->cout / gn_groups) % 4 == 0) {
+    static const bool ko1 = [] { const char* e = getenv("DMVAE_PP_KORDER"); return e ? atoi(e) != 0 : true; }();
+    const int tp = d->cout <= 128 ? 512 : 256;
+    const long long per_image = sub ? (long long)d->h * d->w : (long long)ho * wo;   // pixels of one image per pixel-tile sequence (per parity class for SUB)
+    if (ko1 && per_image % tp == 0) { a.gnpart = gnpart; *gn_tp = tp; }
+  }
   a.sched = nullptr;
   const bool f32 = d->out_f32 != 0;
   if (sub) {  // per-parity 2x2 decomposition: pixel tiles run over the source grid, once per parity class
     a.M = a.Ml;
+    if (a.gnpart) {
+      if (a.Cout <= 128) return launch<128, 512, 2, 4, 4, false, false, true, false, true, false, true>(a, stream);
+      return launch<256, 256, 2, 4, 4, false, false, true, false, true, false, true>(a, stream);
+    }
     if (a.Cout <= 128) return f32 ? launch<128, 512, 2, 4, 4, false, true, true, false, true>(a, stream) : launch<128, 512, 2, 4, 4, false, false, true, false, true>(a, stream);
     return f32 ? launch<256, 256, 2, 4, 4, false, true, true, false, true>(a, stream) : launch<256, 256, 2, 4, 4, false, false, true, false, true>(a, stream);
   }

@@ -114,6 +114,32 @@ __global__ void stats_final_kernel(const float* __restrict__ part, float* __rest
   }
 }
 
+// one wave per (n, group): combine the per-tile, per-4-channel partials a conv epilogue left behind (conv_pp.hip, STATS) in f64
+//   part[pixel tile][wave column 0..3][C / 4][2], tiles of `tp` pixels, whole tiles per image
+__global__ void stats_from_quads_kernel(const float* __restrict__ part, float* __restrict__ stats, int N, int HW, int C, int G, int tp, float eps) {
+  const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wid >= N * G) return;
+  const int n = wid / G, grp = wid % G;
+  const int qpg = C / G / 4, tpi = HW / tp, cq = C >> 2;   // quads per group, tiles per image
+  double s = 0.0, ss = 0.0;
+  const int items = tpi * 4 * qpg;
+  for (int i = lane; i < items; i += 64) {
+    const int q = i % qpg, r = i / qpg;                    // r = tile-in-image * 4 + wave column
+    const float* p = part + ((size_t)(n * tpi * 4 + r) * cq + grp * qpg + q) * 2;
+    s += p[0]; ss += p[1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+  if (lane == 0) {
+    const double cnt = (double)(C / G) * HW;
+    const double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    if (var < 0) var = 0;
+    stats[wid * 2] = (float)mean;
+    stats[wid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 template <int ACT>
 __global__ __launch_bounds__(256) void apply_kernel(const bf16* __restrict__ x, const float* __restrict__ stats,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -327,6 +353,14 @@ extern "C" int dmvae_groupnorm_stats(const void* x, void* stats, void* workspace
   DMVAE_CHECK_LAUNCH();
   const int waves = n * groups;
   hipLaunchKernelGGL(stats_final_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, (const float*)workspace, (float*)stats, g, n, eps);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int dmvae_gn_stats_from_quads(const float* part, float* stats, int n, int hw, int c, int groups, int tp, float eps, hipStream_t stream) {
+  DMVAE_CHECK_ARG(part && stats && groups > 0 && c % groups == 0 && (c / groups) % 4 == 0 && tp > 0 && hw % tp == 0, "gn_stats_from_quads: bad shape");
+  const int waves = n * groups;
+  hipLaunchKernelGGL(stats_from_quads_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, part, stats, n, hw, c, groups, tp, eps);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }

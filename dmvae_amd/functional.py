@@ -68,8 +68,30 @@ def _dst(param):
     return None if v is None else v.view(v.shape)
 
 
+def _tag_stats(y: torch.Tensor, st: torch.Tensor) -> torch.Tensor:
+    """Leave the GroupNorm(32, eps 1e-6) statistics a conv epilogue computed on its result tensor, for the norm that consumes it next (the modules of
+    flux_ae.Decoder hand their outputs straight to each other).  Keyed on the tensor's version and storage: a changed or re-created tensor falls back to the
+    statistics pass."""
+    try:
+        y._dmvae_gn = (st, _ver(y), y.data_ptr())
+    except AttributeError:
+        pass
+    return y
+
+
+def _ver(t: torch.Tensor) -> int:
+    return -1 if t.is_inference() else t._version        # inference tensors keep no version counter
+
+
+def _stats_of(x: torch.Tensor) -> torch.Tensor:
+    tag = getattr(x, "_dmvae_gn", None)
+    if tag is not None and tag[1] == _ver(x) and tag[2] == x.data_ptr() and tag[0].shape[0] == x.shape[0]:
+        return tag[0]
+    return ops.groupnorm_stats(x)
+
+
 def _gn_swish(x, gw, gb, swish=True):
-    st = ops.groupnorm_stats(x)
+    st = _stats_of(x)
     return st, ops.groupnorm_apply(x, st, gw, gb, swish)
 
 
@@ -83,13 +105,13 @@ class ResnetBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, sw, sb):
         st1, a1 = _gn_swish(x, n1w, n1b)
-        h1 = ops.conv2d_nhwc(a1, packed(c1w), c1b, ks=3)
-        st2, a2 = _gn_swish(h1, n2w, n2b)
+        h1, st2 = ops.conv2d_nhwc_gnstats(a1, packed(c1w), c1b, ks=3)             # norm2's statistics from conv1's epilogue
+        a2 = ops.groupnorm_apply(h1, st2, n2w, n2b, True)
         xs = x if sw is None else ops.conv2d_nhwc(x, packed(sw), sb, ks=1)
-        y = ops.conv2d_nhwc(a2, packed(c2w), c2b, residual=xs, ks=3)
+        y, sty = ops.conv2d_nhwc_gnstats(a2, packed(c2w), c2b, residual=xs, ks=3)   # ... and the next module's norm from conv2's
         ctx.save_for_backward(x, st1, a1, h1, st2, a2, n1w, n1b, c1w, n2w, n2b, c2w, sw)
         ctx.bias_params = (c1b, c2b, sb)     # only for their gradient destinations
-        return y
+        return _tag_stats(y, sty)
 
     @staticmethod
     def backward(ctx, dy):
@@ -124,11 +146,11 @@ class AttnBlockFn(torch.autograd.Function):
         scale = float(c) ** -0.5
         p = ops.softmax_rows(ops.gemm_nt(q, k, out_f32=True), scale)          # [n, s, s] bf16
         o = ops.gemm_nt(p, ops.transpose_last2(v))                            # [n, s, c]
-        y = ops.conv2d_nhwc(o.view(n, h, w, c), packed(pw), pb, residual=x, ks=1)
+        y, sty = ops.conv2d_nhwc_gnstats(o.view(n, h, w, c), packed(pw), pb, residual=x, ks=1)
         ctx.save_for_backward(x, st, hn, q, k, v, p, o, nw, nb, qw, kw, vw, pw)
         ctx.bias_params = (qb, kb, vb, pb)
         ctx.scale = scale
-        return y
+        return _tag_stats(y, sty)
 
     @staticmethod
     def backward(ctx, dy):
@@ -174,13 +196,18 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, ks, upsample):
         sub = bool(upsample) and ks == 3 and _subpixel_upsample()
-        if sub:
+        sty = None
+        if sub and w.shape[0] % 128 == 0:                                   # Upsample inside the decoder: a ResnetBlock's norm1 reads the result next
+            y, sty = ops.conv2d_nhwc_gnstats(x, packed(w, True, subpixel=True), b, ks=4, stride=2, transposed=True)
+        elif sub:                                                           # conv_in.0 (z_channels wide): feeds a conv, no statistics wanted
             y = ops.conv2d_nhwc(x, packed(w, True, subpixel=True), b, ks=4, stride=2, transposed=True)
+        elif not upsample and w.shape[0] % 128 == 0:
+            y, sty = ops.conv2d_nhwc_gnstats(x, packed(w), b, ks=ks)        # conv_in.1: a ResnetBlock's norm1 reads the result next
         else:
             y = ops.conv2d_nhwc(x, packed(w), b, ks=ks, upsample=upsample)
         ctx.save_for_backward(x, w)
         ctx.ks, ctx.upsample, ctx.bias_param, ctx.sub = ks, upsample, b, sub
-        return y
+        return y if sty is None else _tag_stats(y, sty)
 
     @staticmethod
     def backward(ctx, dy):

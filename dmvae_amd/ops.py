@@ -123,6 +123,22 @@ def conv_out_size(h: int, w: int, ks: int, upsample: int = 0, stride: int = 1, t
     return (h // 2, w // 2) if stride == 2 else (h, w)
 
 
+def _conv_label(n, ho, wo, cin, cout, ks, upsample, out_f32, stride, transposed, stats):
+    """(kernel the call dispatches to -- csrc/conv_pp.hip::dmvae_conv_pp_try -- as rocprofv3 prints it, multiply-add FLOPs of the call), so that bench.py's
+    per-kernel average can be checked against rocprofv3's per-kernel-name average."""
+    sub = bool(transposed) and ks == 4 and stride == 2    # per-parity 2x2 decomposition: 4 of the 16 taps per output pixel are multiply-adds
+    if cin % 32 == 0 and cout >= 64 and cout % 8 == 0 and n * ho * wo >= 16384:
+        ups1 = int(upsample) == 1                  # nearest x2 folded into the gather: its own template variant
+        gen = (int(upsample) == 2 or stride == 2 or ks == 4 or bool(transposed)) and not (sub and _PP_SUBPIXEL)   # the general-gather instantiation
+        t = lambda f: "true" if f else "false"
+        dyn = os.environ.get("DMVAE_PP_DYNAMIC", "0") not in ("", "0") and not ups1 and not out_f32 and (n * ho * wo // (512 if cout <= 128 else 256)) * ((cout + 255) // 256 if cout > 128 else 1) > 256
+        label = "conv_pp_kernel<%s, %s, %s, %s, %s, %s, %s, %s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", t(ups1), t(out_f32),
+                                                                   "false" if ups1 else ("true" if gen else _PP_KORDER), t(gen), t(sub and _PP_SUBPIXEL), t(dyn), t(stats))
+    else:
+        label = "conv_fwd_kernel"
+    return label, 2.0 * n * ho * wo * cout * cin * (4 if sub else ks * ks)
+
+
 def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None, ks: int = 3, upsample=False, act: int = ACT_NONE,
                 out_f32: bool = False, stride: int = 1, transposed: bool = False) -> torch.Tensor:
@@ -159,17 +175,56 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
         e1.record()
         # which kernel dmvae_conv2d_nhwc_fwd dispatched to (csrc/conv_pp.hip::dmvae_conv_pp_try), so that the bench's per-kernel
         # average can be checked against rocprofv3's per-kernel-name average
-        sub = bool(transposed) and ks == 4 and stride == 2    # per-parity 2x2 decomposition: 4 of the 16 taps per output pixel are multiply-adds
-        if cin % 32 == 0 and cout >= 64 and cout % 8 == 0 and n * ho * wo >= 16384:
-            ups1 = int(upsample) == 1                  # nearest x2 folded into the gather: its own template variant
-            gen = (int(upsample) == 2 or stride == 2 or ks == 4 or bool(transposed)) and not (sub and _PP_SUBPIXEL)   # the general-gather instantiation
-            label = "conv_pp_kernel<%s, %s, %s, %s, %s, %s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", "true" if ups1 else "false",
-                                                                 "true" if out_f32 else "false", "false" if ups1 else ("true" if gen else _PP_KORDER),
-                                                                 "true" if gen else "false", "true" if (sub and _PP_SUBPIXEL) else "false")
-        else:
-            label = "conv_fwd_kernel"
-        timing.append((label, e0, e1, 2.0 * n * ho * wo * cout * cin * (4 if sub else ks * ks)))
+        label, fl = _conv_label(n, ho, wo, cin, cout, ks, upsample, out_f32, stride, transposed, False)
+        timing.append((label, e0, e1, fl))
     return y
+
+
+_GN_FUSED = os.environ.get("DMVAE_GN_STATS_FUSED", "1") != "0"      # csrc/conv_fwd.hip::dmvae_conv2d_nhwc_fwd_gnstats
+
+
+def conv2d_nhwc_gnstats(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, ks: int = 3,
+                        act: int = ACT_NONE, stride: int = 1, transposed: bool = False, groups: int = 32, eps: float = 1e-6):
+    """(y, stats): conv2d_nhwc plus the GroupNorm statistics [N, groups, 2] = (mean, rstd) of its bf16 result, which the large-shape conv kernel sums in its
+    epilogue (no separate pass over y); other shapes / the f32 parity mode: the conv followed by groupnorm_stats."""
+    if (x.dtype == f32 and parity.on()) or not _GN_FUSED:
+        y = conv2d_nhwc(x, w_packed, bias, residual, ks=ks, act=act, stride=stride, transposed=transposed)
+        return y, groupnorm_stats(y, groups, eps)
+    x = _req(x, bf16, "x")
+    w_packed = _req(w_packed, bf16, "w_packed")
+    n, h, w_, cin = x.shape
+    cout = w_packed.shape[0]
+    assert w_packed.shape[1] == ks * ks and w_packed.shape[2] == cin, (w_packed.shape, ks, cin)
+    ho, wo = conv_out_size(h, w_, ks, 0, stride, transposed)
+    y = torch.empty(n, ho, wo, cout, dtype=bf16, device=x.device)
+    if bias is not None:
+        _req(bias, f32, "bias")
+    if residual is not None:
+        _req(residual, bf16, "residual")
+        assert residual.shape == y.shape
+    d = ConvDesc(n, h, w_, cin, cout, ks, 0, act, 0, stride, int(transposed))
+    L = _lib.lib()
+    wsb = L.dmvae_conv2d_nhwc_fwd_gnstats_workspace(ctypes.byref(d), groups)
+    if wsb == 0:
+        raise ValueError(f"conv2d_nhwc_gnstats: unsupported shape {tuple(y.shape)} with {groups} groups")
+    ws = workspace(wsb, x.device, slot="gnstats")
+    stats = torch.empty(n, groups, 2, dtype=f32, device=x.device)
+    timing = KERNEL_TIMING
+    if timing is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(L.dmvae_conv2d_nhwc_fwd_gnstats(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(), stats.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), groups, float(eps), ctypes.byref(d), _stream()), "conv2d_nhwc_fwd_gnstats")
+    if timing is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        sub = bool(transposed) and ks == 4 and stride == 2
+        plain = ks in (1, 3) and stride == 1 and not transposed
+        tp = 512 if cout <= 128 else 256
+        fused = (plain or (sub and _PP_SUBPIXEL)) and cout % groups == 0 and (cout // groups) % 4 == 0 and ((h * w_) if sub else (ho * wo)) % tp == 0 and _PP_KORDER == "true"
+        label, fl = _conv_label(n, ho, wo, cin, cout, ks, 0, False, stride, transposed, fused)
+        timing.append((label + (" + gn stats" if label == "conv_fwd_kernel" or not fused else ""), e0, e1, fl))
+    return y, stats
 
 
 def conv2d_nhwc_wgrad(dy: torch.Tensor, a: torch.Tensor, ks: int, upsample: bool = False, need_bias: bool = True,

@@ -61,6 +61,15 @@ typedef struct dmvae_conv_desc {
 int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* bias, const void* residual, void* y,
                           const dmvae_conv_desc* d, dmvae_stream_t stream);
 
+/* The conv above with the GroupNorm statistics of its (bf16) result as a by-product: stats[n][groups][2] = (mean, rstd) over (ho*wo, cout/groups) of y,
+ * exactly what dmvae_groupnorm_stats(y) returns up to f32 summation order.  Most convs of flux_ae.Decoder feed a GroupNorm (models/flux_ae.py:62,64,71-76,
+ * 236,266): for the large shapes the conv kernel sums its rounded results per tile in the epilogue and a finishing kernel combines them, so the
+ * statistics pass -- a full read of y -- disappears; other shapes run the conv, then the statistics pass.  out_f32 must be 0.
+ * workspace >= dmvae_conv2d_nhwc_fwd_gnstats_workspace(d, groups) bytes. */
+size_t dmvae_conv2d_nhwc_fwd_gnstats_workspace(const dmvae_conv_desc* d, int groups);
+int dmvae_conv2d_nhwc_fwd_gnstats(const void* x, const void* w, const void* bias, const void* residual, void* y, void* stats, void* workspace,
+                                  size_t workspace_bytes, int groups, float eps, const dmvae_conv_desc* d, dmvae_stream_t stream);
+
 /* Weight/bias gradient of the conv above (reduction over pixels, split-K, deterministic).
  * dy: [n,ho,wo,cout] bf16; a: the conv's bf16 input [n,h,w,cin] (pre-upsample when d->upsample);
  * dw: [cout][cin][ks][ks] f32 (PyTorch nn.Conv2d.weight layout); dbias: [cout] f32 or NULL.

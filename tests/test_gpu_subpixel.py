@@ -128,3 +128,37 @@ def test_subpixel_route_vs_gather_route(case, monkeypatch):
     rl2 = lambda a, r: ((a.double() - r.double()).norm() / r.double().norm()).item()
     assert rl2(res[0][0], res[1][0]) < 6e-3 and rl2(res[0][1], res[1][1]) < 8e-3          # bf16 outputs, weights rounded at different sites
     assert rl2(res[0][2], res[1][2]) < 1e-5 and rel_err(res[0][3], res[1][3]) < 1e-5       # weight / bias gradients: no weight rounding involved
+
+
+@pytest.mark.parametrize("case", [  # N, H, W, Cin, Cout, ks, kind (0 plain, 1 per-parity transposed 4x4 stride 2), residual
+    (2, 64, 64, 128, 256, 3, 0, True),      # 256-row tile
+    (2, 64, 64, 64, 128, 3, 0, False),      # 128-row tile: 4 channels per group
+    (1, 128, 128, 256, 512, 1, 0, True),    # 1x1 + residual (AttnBlock.proj_out), two cout tiles
+    (3, 32, 32, 256, 256, 3, 1, False),     # Upsample's sub-pixel forward: parity-interleaved tiles
+    (2, 48, 40, 128, 256, 3, 0, False),     # H*W not a multiple of the pixel tile: the two-pass route behind the same entry point
+    (2, 16, 16, 32, 64, 3, 0, False),       # small shape (general conv kernel) + two-pass statistics
+])
+def test_conv_gnstats_matches_separate_statistics_pass(case):
+    """dmvae_conv2d_nhwc_fwd_gnstats: same y as dmvae_conv2d_nhwc_fwd bit for bit, and the (mean, rstd) its epilogue partials give equal those of the
+    statistics pass over y (and the f64 statistics of y) to f32 summation order."""
+    from dmvae_amd import ops
+    n, h, w_, cin, cout, ks, kind, res = case
+    g = torch.Generator().manual_seed(31 + cin + cout)
+    x = torch.randn(n, h, w_, cin, generator=g).to(BF).to(DEV)
+    kw = dict(ks=4, stride=2, transposed=True) if kind else dict(ks=ks)
+    taps = 16 if kind else ks * ks
+    wt = (torch.randn(cout, taps, cin, generator=g) * 0.05).to(BF).to(DEV)
+    b = (torch.randn(cout, generator=g) * 2).to(DEV)
+    ho, wo = (2 * h, 2 * w_) if kind else (h, w_)
+    r = torch.randn(n, ho, wo, cout, generator=g).to(BF).to(DEV) if res else None
+    y0 = ops.conv2d_nhwc(x, wt, b, r, **kw)
+    y, st = ops.conv2d_nhwc_gnstats(x, wt, b, r, **kw)
+    assert torch.equal(y, y0) and st.shape == (n, 32, 2)
+    st0 = ops.groupnorm_stats(y0)
+    yd = y0.double().view(n, ho * wo, 32, cout // 32)
+    mean = yd.mean(dim=(1, 3))
+    rstd = 1.0 / torch.sqrt(yd.var(dim=(1, 3), unbiased=False) + 1e-6)
+    assert rel_err(st[..., 0], mean) < 1e-5 and rel_err(st[..., 1], rstd) < 1e-5
+    assert rel_err(st, st0) < 1e-5
+    y2, st2 = ops.conv2d_nhwc_gnstats(x, wt, b, r, **kw)
+    assert torch.equal(st, st2)                                          # fixed summation order
