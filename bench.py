@@ -149,20 +149,45 @@ def kl_mmd_roofline(dev):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps * 1e3     # us
 
+    def timed_graph(fn, reps):
+        """The same `reps` calls recorded once into a HIP graph and replayed: what the op costs on its stream when the host is not the limit (issuing the
+        two launches from Python takes longer than they run; inside the training step the host runs ahead of the stream anyway)."""
+        try:
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(reps):
+                    fn()
+            g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e3
+        except Exception:      # capture unsupported: report the eager figure only
+            return None
+
     out = {}
     z = torch.randn(32, 256, 32, device=dev) * 0.7 + 0.2
     y = torch.randn(32, 256, 32, device=dev)
-    us = timed(lambda: ops.kl_mmd(z, y, need_grad=True), 50)
+    us_eager = timed(lambda: ops.kl_mmd(z, y, need_grad=True), 50)
+    us_graph = timed_graph(lambda: ops.kl_mmd(z, y, need_grad=True), 20)
+    us = us_graph if us_graph is not None else us_eager
     byt = 3 * z.numel() * 4
     pairs = 32 * 3 * 256 * 256
     # VALU work per kernel evaluation with gradient: 32 FMA (a.b) + 32 FMA (sum w b) + ~14 (norm combine, five bandwidths by repeated squaring, weights)
     # + one v_exp_f32 (quarter rate: 4 issue slots) = ~82 f32 lane-operations; peak = 157.3 TFLOP/s / 2 = 78.6 T lane-FMA/s (MI355X_MICROARCH.md)
     LANE_OPS_PER_PAIR, VALU_PEAK_TOPS = 82.0, 78.65
-    out["fused_B32"] = {"shape": "G=32 n=m=256 d=32, value+grad", "us_per_call": round(us, 1), "launches": 2, "algorithmic_MB": round(byt / 1e6, 2),
+    out["fused_B32"] = {"shape": "G=32 n=m=256 d=32, value+grad", "us_per_call": round(us, 1), "timing": "20 calls replayed from one HIP graph" if us_graph is not None else "eager",
+                        "us_per_call_issued_from_python": round(us_eager, 1), "launches": 2, "algorithmic_MB": round(byt / 1e6, 2),
                         "achieved_GBps": round(byt / us / 1e3, 1), "hbm_frac": round(byt / us / 1e3 / HBM_PEAK, 4),
                         "Gpair_per_s": round(pairs / us / 1e3, 1), "valu_Tlaneops_per_s": round(pairs * LANE_OPS_PER_PAIR / us / 1e6, 2),
                         "valu_frac": round(pairs * LANE_OPS_PER_PAIR / us / 1e6 / VALU_PEAK_TOPS, 4),
-                        "bound": "valu/exp (3 MB of traffic against 6.3 M kernel evaluations), not HBM: see DESIGN.md 3.4"}
+                        "bound": "latency (two launches of ~5 us floor each) + f32 matrix cores / exp, not HBM (3 MB of traffic against 6.3 M kernel evaluations): see DESIGN.md 3.4"}
     zl = torch.randn(8192, 256, 32, device=dev)       # 268 MB
     us = timed(lambda: ops.kl_mmd(zl, None, need_grad=True), 10)
     byt = 3 * zl.numel() * 4

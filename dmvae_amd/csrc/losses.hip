@@ -488,6 +488,187 @@ __global__ __launch_bounds__(256) void kl_mmd_grad_kernel(const float* __restric
   }
 }
 
+// Matrix-core version of mmd_pair_kernel for the launch-bound training shapes (the two-launch path): same work split (one workgroup per group, pair type,
+// 128-row tile and column share; wave q owns rows 32 q .. 32 q + 31), same outputs, but the two contractions over the 32 latent channels run on
+// v_mfma_f32_32x32x2_f32 (true f32: the kernel values feed a difference of sums that cancels two digits) instead of 64 scalar FMAs per pair:
+//   G^T[j][i] = b_j . a_i     A operand = columns from LDS (lane -> column j = l & 31, channel parity l >> 5), B operand = the wave's rows, in registers;
+//                             result layout: lane <-> row i, registers <-> 16 of the block's 32 columns (j = 8 (r >> 2) + (r & 3) + 4 (l >> 5))
+//   SB^T[c][i] += sum_j b_j[c] w_ij   the weights w are born in exactly the B-operand layout of this product (lane <-> i, one register <-> the two columns
+//                             a K = 2 step consumes), so they go from the VALU straight back into the matrix pipe; A operand = b_j[c] from LDS.
+// Per 32 x 32 pair block: 16 + 16 MFMAs and ~22 VALU operations per pair (norm combine, one exp, four squarings, the two bandwidth sums) that overlap them.
+// Rows / columns past the end carry an infinite squared norm: every exp() is 0 there and no mask is needed.
+// LDS columns: [j][parity][16] floats, 16-B slots XOR-ed by (j >> 1) & 7 (conflict-free 16-B operand reads across 16 consecutive columns).
+// Extra workgroups past the pair blocks (fused KL): one per (group, x tile) sums the tile's rows and squares per channel (klpart).
+__device__ __forceinline__ int mmd_slot(int j, int slot) { return j * 32 + ((slot ^ ((j >> 1) & 7)) << 2); }  // float index of a 16-B slot of column j
+
+template <bool GRAD>
+__global__ __launch_bounds__(256) void mmd_pair_mfma_kernel(const float* __restrict__ z, const float* __restrict__ y, float* __restrict__ ksum,
+                                                            float* __restrict__ gpart, float* __restrict__ klpart, int n, int m, int tiles_x, int tiles_y,
+                                                            int csplit, int npair) {
+#if __HIP_DEVICE_COMPILE__
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int g = blockIdx.y, lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if ((int)blockIdx.x >= npair) {  // ---- KL moment partials of one 128-row x tile (fixed order) ----
+    const int rt = blockIdx.x - npair;
+    if (!klpart || rt >= tiles_x) return;
+    float (*red)[8][8] = reinterpret_cast<float (*)[8][8]>(sm);  // [32 row lanes][8 channel quads][4 sums + 4 sums of squares]
+    const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    float s4[4] = {0, 0, 0, 0}, ss4[4] = {0, 0, 0, 0};
+    for (int r = rt * MMD_ROWS + rl; r < min(n, (rt + 1) * MMD_ROWS); r += 32) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(z + ((size_t)g * n + r) * MMD_D + cq * 4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) { s4[e] += v[e]; ss4[e] = fmaf(v[e], v[e], ss4[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) { red[rl][cq][e] = s4[e]; red[rl][cq][4 + e] = ss4[e]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int c = threadIdx.x & 31, w = threadIdx.x >> 5;
+      float a = 0.f;
+      for (int r = 0; r < 32; r++) a += red[r][c >> 2][w * 4 + (c & 3)];
+      klpart[((size_t)(g * tiles_x + rt) * MMD_D + c) * 2 + w] = a;
+    }
+    return;
+  }
+  const int tile = blockIdx.x / csplit, cs = blockIdx.x - tile * csplit;
+  const int type = tile < tiles_x ? 0 : (tile < 2 * tiles_x ? 1 : 2);
+  const int rt = type == 0 ? tile : (type == 1 ? tile - tiles_x : tile - 2 * tiles_x);
+  const float* rsrc = type == 2 ? y + (size_t)g * m * MMD_D : z + (size_t)g * n * MMD_D;
+  const float* csrc = type == 0 ? z + (size_t)g * n * MMD_D : y + (size_t)g * m * MMD_D;
+  const int nrows = type == 2 ? m : n, ncols_all = type == 0 ? n : m;
+  const int cper = csplit > 1 ? ((ncols_all + csplit - 1) / csplit + 31) & ~31 : (ncols_all + 31) & ~31;  // whole 32-column blocks per share
+  const int cbeg = min(cs * cper, ncols_all), cend = min(cbeg + cper, ncols_all);
+  const int nblk = (cend - cbeg + 31) >> 5;
+  float* cols = sm;                         // [nblk * 32][32] in the parity-split, slot-swizzled layout
+  float* cnorm = sm + (size_t)nblk * 32 * MMD_D;   // [nblk * 32], +inf past the end
+  float* sc = cnorm + nblk * 32;            // [4] per-wave sums of k
+  // ---- operands in: every global load of the block is issued before the first one is consumed (one memory round trip, not one per staging sweep: at
+  // these sizes the kernel's duration is its latency chain) -----------------------------------------------------------------------------------------
+  const int total = nblk * 32 * 8;          // 8 lanes x 16 B per column
+  constexpr int SWEEPS = 8;                 // sweeps of 256 threads held in registers: shares of up to 256 columns
+  f32x4 vst[SWEEPS];
+#pragma unroll
+  for (int it = 0; it < SWEEPS; it++) {
+    const int i = threadIdx.x + it * 256, j = i >> 3, e4 = i & 7;
+    vst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < total && cbeg + j < cend) vst[it] = *reinterpret_cast<const f32x4*>(csrc + (size_t)(cbeg + j) * MMD_D + e4 * 4);
+  }
+  // this wave's 32 rows as the B operand: lane (i = l & 31, h = l >> 5) holds a_i[2 kk + h]
+  const int il = lane & 31, h = lane >> 5;
+  const int rg = rt * MMD_ROWS + q * 32 + il;
+  f32x4 vrow[8];
+#pragma unroll
+  for (int k4 = 0; k4 < 8; k4++) {
+    vrow[k4] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (rg < nrows) vrow[k4] = *reinterpret_cast<const f32x4*>(rsrc + (size_t)rg * MMD_D + k4 * 4);
+  }
+  // columns -> LDS: squared norms by an 8-lane butterfly; channels 4 e4 .. 4 e4 + 3 go to the parity halves (even ones to index 2 e4, 2 e4 + 1 of half 0)
+  auto put = [&](int i, const f32x4& v) {
+    const int j = i >> 3, e4 = i & 7;
+    float p = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    p += __shfl_xor(p, 1, 64); p += __shfl_xor(p, 2, 64); p += __shfl_xor(p, 4, 64);
+    const int lo = mmd_slot(j, (2 * e4) >> 2) + ((2 * e4) & 3), hi = mmd_slot(j, 4 + ((2 * e4) >> 2)) + ((2 * e4) & 3);
+    *reinterpret_cast<f32x2*>(cols + lo) = f32x2{v[0], v[2]};
+    *reinterpret_cast<f32x2*>(cols + hi) = f32x2{v[1], v[3]};
+    if (e4 == 0) cnorm[j] = cbeg + j < cend ? p : INFINITY;
+  };
+#pragma unroll
+  for (int it = 0; it < SWEEPS; it++)
+    if (threadIdx.x + it * 256 < total) put(threadIdx.x + it * 256, vst[it]);
+  for (int i = threadIdx.x + SWEEPS * 256; i < total; i += 256) {  // larger shares: the remaining sweeps one by one
+    const int j = i >> 3, e4 = i & 7;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (cbeg + j < cend) v = *reinterpret_cast<const f32x4*>(csrc + (size_t)(cbeg + j) * MMD_D + e4 * 4);
+    put(i, v);
+  }
+  float areg[16];
+  float na = 0.f;
+#pragma unroll
+  for (int k4 = 0; k4 < 8; k4++) {
+    const f32x4 v = vrow[k4];
+    areg[2 * k4] = h ? v[1] : v[0];
+    areg[2 * k4 + 1] = h ? v[3] : v[2];
+    na += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (rg >= nrows) na = INFINITY;
+  __syncthreads();
+  float s = 0.f, sw = 0.f;
+  f32x16 sbt;
+#pragma unroll
+  for (int r = 0; r < 16; r++) sbt[r] = 0.f;
+  const float inv16d = 1.f / (16.f * MMD_D), invd = 1.f / (float)MMD_D;
+  // G^T of the next column block is issued before this block's VALU work (the matrix pipe runs it underneath).  An explicitly interleaved version (gradient
+  // product of block jb - 1 and G^T of block jb + 1 alternating with the VALU work of block jb via sched_group_barrier) measured no faster: at the
+  // training shape the launch is latency-, not issue-bound.
+  auto gram = [&](int jb) {
+    const int j = jb * 32 + il;
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; r++) c[r] = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {  // four 16-B operand reads cover this lane's 16 channels of column j
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(cols + mmd_slot(j, h * 4 + s4));
+#pragma unroll
+      for (int e = 0; e < 4; e++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[e], areg[s4 * 4 + e], c, 0, 0, 0);
+    }
+    return c;
+  };
+  f32x16 acc_next;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc_next[r] = 0.f;
+  if (nblk > 0) acc_next = gram(0);
+  for (int jb = 0; jb < nblk; jb++) {
+    const f32x16 acc = acc_next;
+    if (jb + 1 < nblk) acc_next = gram(jb + 1);
+    f32x16 wv;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++) {
+      const f32x4 nb = *reinterpret_cast<const f32x4*>(cnorm + jb * 32 + 8 * r4 + 4 * h);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float d2 = fmaxf(na + nb[r] - 2.f * acc[r4 * 4 + r], 0.f);
+        const float e8 = __expf(-d2 * inv16d);
+        const float e4 = e8 * e8, e2 = e4 * e4, e1 = e2 * e2, eh = e1 * e1;
+        s += 0.2f * (e8 + e4 + e2 + e1 + eh);
+        if (GRAD) {
+          const float w = 0.2f * invd * (0.125f * e8 + 0.25f * e4 + 0.5f * e2 + e1 + 2.f * eh);
+          wv[r4 * 4 + r] = w;
+          sw += w;
+        }
+      }
+    }
+    if (GRAD && type != 2) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {  // K step r: columns j_r(0) (lanes < 32) and j_r(0) + 4 (lanes >= 32); A operand = b_j[c], c = l & 31
+        const int jr = jb * 32 + 8 * (r >> 2) + (r & 3) + 4 * h;
+        const float bc = cols[mmd_slot(jr, (il & 1) * 4 + (il >> 3)) + ((il >> 1) & 3)];
+        sbt = __builtin_amdgcn_mfma_f32_32x32x2f32(bc, wv[r], sbt, 0, 0, 0);
+      }
+    }
+  }
+  // ---- tile sum of k: wave sum, then the four waves in fixed order ---------------------------------------------------------------------------------
+  const float st = wave_sum(s);
+  if (lane == 0) sc[q] = st;
+  if (GRAD && type != 2) {  // gpart[row][c] = a_i[c] * SW - SB[c]; lane (i, h) holds channels 8 r4 + 4 h + 0..3
+    const float SW = sw + __shfl_xor(sw, 32, 64);
+    if (rg < nrows) {
+      const float* ar = rsrc + (size_t)rg * MMD_D;
+      float* o = gpart + ((((size_t)cs * 2 + type) * gridDim.y + g) * n + rg) * MMD_D;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ar + 8 * r4 + 4 * h);
+        f32x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; r++) ov[r] = av[r] * SW - sbt[r4 * 4 + r];
+        *reinterpret_cast<f32x4*>(o + 8 * r4 + 4 * h) = ov;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) ksum[(size_t)g * npair + blockIdx.x] = (sc[0] + sc[1]) + (sc[2] + sc[3]);
+#endif
+}
+
 // Second (and last) launch of the fused path: every block reduces the per-tile moment partials to the 32 channel statistics itself (nparts <= 1024
 // rows of 64 floats, L2-resident, fixed order: every block arrives at bit-identical statistics), block 0 also writes kl[33], the statistics and
 // mmd[g]; then the gradient pass of kl_mmd_grad_kernel.
@@ -702,13 +883,32 @@ extern "C" int dmvae_kl_mmd(const void* z, const void* y, void* kl, void* mmd, v
   const int csplit = fused ? csplit_ws : 1;
   const dim3 grid((2 * tx + ty) * csplit, groups);
   float* klpart = fused ? mom : nullptr;
-  if (dz)
+  static const bool mfma_ok = [] { const char* e = getenv("DMVAE_KLMMD_MFMA"); return e ? atoi(e) != 0 : true; }();   // 0: the scalar-FMA pair kernel (A/B, tests)
+  if (fused && mfma_ok && n <= 1024 && m <= 1024) {  // launch-bound shapes: the two contractions of every pair on the matrix cores
+    const int nmax = n > m ? n : m;
+    const int cper = csplit > 1 ? ((nmax + csplit - 1) / csplit + 31) & ~31 : (nmax + 31) & ~31;
+    const size_t lds = ((size_t)cper * (MMD_D + 1) + 8) * sizeof(float);
+    const size_t lds_eff = lds < 8192 ? 8192 : lds;     // the moment blocks' reduction scratch
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mmd_pair_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mmd_pair_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+      attr2 = true;
+    }
+    const int npair = (2 * tx + ty) * csplit;
+    const dim3 grid2(npair + tx, groups);           // + one moment block per x tile
+    if (dz)
+      hipLaunchKernelGGL(mmd_pair_mfma_kernel<true>, grid2, dim3(256), lds_eff, stream, (const float*)z, (const float*)y, ksum, gpart, klpart, n, m, tx, ty, csplit, npair);
+    else
+      hipLaunchKernelGGL(mmd_pair_mfma_kernel<false>, grid2, dim3(256), lds_eff, stream, (const float*)z, (const float*)y, ksum, gpart, klpart, n, m, tx, ty, csplit, npair);
+    DMVAE_CHECK_LAUNCH();
+  } else if (dz)
     hipLaunchKernelGGL(mmd_pair_kernel<true>, grid, dim3(256), lds_g, stream, (const float*)z, (const float*)y, ksum, gpart, klpart, n, m, tx, ty, csplit);
   else
     hipLaunchKernelGGL(mmd_pair_kernel<false>, grid, dim3(256), lds_v, stream, (const float*)z, (const float*)y, ksum, gpart, klpart, n, m, tx, ty, csplit);
   DMVAE_CHECK_LAUNCH();
   if (fused) {
-    size_t nb = dz ? ((size_t)groups * n * 8 + 1023) / 1024 : 1;      // four float4 per thread
+    size_t nb = dz ? ((size_t)groups * n * 8 + 255) / 256 : 1;        // one float4 per thread: at 32 x 256 rows that is 256 workgroups, one per CU
     if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(kl_mmd_finish_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)z, gpart, klpart, groups * tx, ksum, (float*)kl, stats,

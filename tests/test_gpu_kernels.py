@@ -391,8 +391,9 @@ def test_kl_mmd_two_launch_path_matches_five_launch_path(monkeypatch):
     kl_v, mmd_v2, none2 = ops.kl_mmd(z, y, need_grad=False)
     assert none is None and none2 is None and rel_err(mmd_v, mmd_v2) < 5e-5 and rel_err(kl_v, kl_a) < 1e-6
     monkeypatch.setenv("DMVAE_KLMMD_CSPLIT", "1")                         # no column split: same per-tile order as the five-launch path
-    _, mmd_c, dz_c = ops.kl_mmd(z, y, w_kl=0.7, w_mmd=1.5)
-    assert torch.equal(mmd_c, mmd_b) and rel_err(dz_c, dz_b) < 1e-6
+    _, mmd_c, dz_c = ops.kl_mmd(z, y, w_kl=0.7, w_mmd=1.5)                # (pair sums on the matrix cores: another fixed order, same bar as above)
+    assert rel_err(mmd_c, mmd_b) < 5e-5 and rel_err(dz_c, dz_b) < 1e-6
+    assert rel_err(mmd_c.cpu(), mr) < 1e-4 and rel_err(dz_c.cpu(), zr.grad) < 1e-4
 
 
 def test_adamw_ema_golden():
