@@ -179,14 +179,15 @@ def kl_mmd_roofline(dev):
     us = us_graph if us_graph is not None else us_eager
     byt = 3 * z.numel() * 4
     pairs = 32 * 3 * 256 * 256
-    # VALU work per kernel evaluation with gradient: 32 FMA (a.b) + 32 FMA (sum w b) + ~14 (norm combine, five bandwidths by repeated squaring, weights)
-    # + one v_exp_f32 (quarter rate: 4 issue slots) = ~82 f32 lane-operations; peak = 157.3 TFLOP/s / 2 = 78.6 T lane-FMA/s (MI355X_MICROARCH.md)
+    # scalar pair kernel (large batches): per kernel evaluation with gradient 32 FMA (a.b) + 32 FMA (sum w b) + ~14 (norm combine, five bandwidths by repeated
+    # squaring, weights) + one v_exp_f32 (quarter rate: 4 issue slots) = ~82 f32 lane-operations; peak = 157.3 TFLOP/s / 2 = 78.6 T lane-FMA/s (MI355X_MICROARCH.md)
     LANE_OPS_PER_PAIR, VALU_PEAK_TOPS = 82.0, 78.65
     out["fused_B32"] = {"shape": "G=32 n=m=256 d=32, value+grad", "us_per_call": round(us, 1), "timing": "20 calls replayed from one HIP graph" if us_graph is not None else "eager",
                         "us_per_call_issued_from_python": round(us_eager, 1), "launches": 2, "algorithmic_MB": round(byt / 1e6, 2),
                         "achieved_GBps": round(byt / us / 1e3, 1), "hbm_frac": round(byt / us / 1e3 / HBM_PEAK, 4),
-                        "Gpair_per_s": round(pairs / us / 1e3, 1), "valu_Tlaneops_per_s": round(pairs * LANE_OPS_PER_PAIR / us / 1e6, 2),
-                        "valu_frac": round(pairs * LANE_OPS_PER_PAIR / us / 1e6 / VALU_PEAK_TOPS, 4),
+                        "Gpair_per_s": round(pairs / us / 1e3, 1),
+                        # this shape runs the matrix-core pair kernel: 64 FLOP (a.b) per pair + 64 FLOP (sum w b) for the two thirds of the pairs that carry a gradient
+                        "mfma_f32_TFLOPs": round(pairs * (64.0 + 64.0 * 2 / 3) / us / 1e6, 2), "mfma_f32_frac": round(pairs * (64.0 + 64.0 * 2 / 3) / us / 1e6 / 157.3, 4),
                         "bound": "latency (two launches of ~5 us floor each) + f32 matrix cores / exp, not HBM (3 MB of traffic against 6.3 M kernel evaluations): see DESIGN.md 3.4"}
     zl = torch.randn(8192, 256, 32, device=dev)       # 268 MB
     us = timed(lambda: ops.kl_mmd(zl, None, need_grad=True), 10)
