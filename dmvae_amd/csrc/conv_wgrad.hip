@@ -358,6 +358,39 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
   return 0;
 }
 
+// the same reduction for thousands of partial rows (one per GroupNorm chunk): 16 channels per block, 64 strided partial-lanes per channel with four loads in
+// flight each, fixed-order LDS tree -- colsum_final_kernel's 4 lanes per channel walk 2048 rows in 512 dependent steps (83 us)
+__global__ __launch_bounds__(1024) void colsum_final_wide_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int C, int accumulate) {
+  __shared__ float sh[64][17];
+  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < C) {
+    int k = kl;
+    for (; k + 192 < nparts; k += 256) {
+      a0 += part[(size_t)k * C + c]; a1 += part[(size_t)(k + 64) * C + c]; a2 += part[(size_t)(k + 128) * C + c]; a3 += part[(size_t)(k + 192) * C + c];
+    }
+    for (; k < nparts; k += 64) a0 += part[(size_t)k * C + c];
+  }
+  sh[kl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (threadIdx.x < 16 && c < C) {
+    float t = 0.f;
+    for (int r = 0; r < 64; r++) t += sh[r][threadIdx.x];
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+
+int dmvae_colsum_final(const float* part, float* out, int nparts, int C, int accumulate, hipStream_t stream) {  // used by groupnorm.hip
+  if (nparts > 256) {
+    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((C + 15) / 16), dim3(1024), 0, stream, part, out, nparts, C, accumulate);
+    DMVAE_CHECK_LAUNCH();
+    return 0;
+  }
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, part, out, nparts, C, accumulate);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
 // out[c] (+)= sum_r x[r][c] over a row-major bf16 matrix: the bias gradient on its own (callers that obtain the weight gradient with the operands'
 // roles exchanged -- the sub-pixel form of Upsample's conv -- cannot take it from dmvae_conv2d_nhwc_wgrad).  workspace >= 512 * cols * 4 bytes.
 extern "C" int dmvae_colsum_bf16(const void* x, void* out, void* workspace, size_t workspace_bytes, size_t rows, int cols, int accumulate,

@@ -260,21 +260,31 @@ __global__ void bwd_param_kernel(const float* __restrict__ AB, float* __restrict
   dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)b;
 }
 
-template <int ACT>
+// COLS: the block also sums the (bf16-rounded) dx it stores per channel -> colpart[n * nchunk + chunk][C].  dx of a ResnetBlock's norm1 is the output gradient
+// of the conv before it; when that conv is Upsample's in its sub-pixel form, its bias gradient (the column sums of dx) cannot come out of the weight-gradient
+// kernel (operands' roles exchanged), and a separate pass over the full-resolution gradient costs 0.1-0.25 ms per layer.
+template <int ACT, bool COLS = false>
 __global__ __launch_bounds__(256) void bwd_apply_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x,
                                                         const bf16* __restrict__ dres, const float* __restrict__ stats,
                                                         const float* __restrict__ S, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, bf16* __restrict__ dx, Geom g, float inv_count) {
+                                                        const float* __restrict__ beta, bf16* __restrict__ dx, Geom g, float inv_count,
+                                                        float* __restrict__ colpart = nullptr) {
   const int tp = 1 << g.tp_shift;
   const int lane_c = threadIdx.x & (tp - 1), prow = threadIdx.x >> g.tp_shift;
-  if (lane_c * 8 >= g.C) return;
+  if (!COLS && lane_c * 8 >= g.C) return;
+  const bool live = lane_c * 8 < g.C;     // COLS: idle channel lanes stay for the block reduction
   const int n = blockIdx.y;
-  const int p0 = blockIdx.x * g.ppc, p1 = min(p0 + g.ppc, g.HW);
+  const int p0 = blockIdx.x * g.ppc, p1 = live ? min(p0 + g.ppc, g.HW) : p0;
   const float inv_m = inv_count > 0.f ? inv_count : 1.0f / ((float)g.cpg * (float)g.HW);
   float mu[8], rs[8], ga[8], be[8], s1[8], s2[8];
+  float cs[COLS ? 8 : 1];
+  if constexpr (COLS) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) cs[e] = 0.f;
+  }
 #pragma unroll
   for (int e = 0; e < 8; e++) {
-    const int c = lane_c * 8 + e;
+    const int c = live ? lane_c * 8 + e : 0;
     const size_t gi = ((size_t)n * g.G + c / g.cpg) * 2;
     mu[e] = stats[gi]; rs[e] = stats[gi + 1]; ga[e] = gamma[c]; be[e] = beta[c];
     s1[e] = S[gi] * inv_m; s2[e] = S[gi + 1] * inv_m;
@@ -298,6 +308,7 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const bf16* __restrict__
       }
       const float r = rs[e] * (dy * ga[e] - s1[e] - xh * s2[e]);
       o[e] = dres ? o[e] + r : r;
+      if constexpr (COLS) cs[e] += (float)(bf16)o[e];      // what is stored, as a later pass over dx would read it
     }
     store8(dx + base + (size_t)p * g.C, o);
   };
@@ -313,6 +324,17 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const bf16* __restrict__
     const size_t o0 = base + (size_t)p * g.C;
     const bf16x8 x0 = ldraw(x + o0), d0 = ldraw(da + o0);
     row(x0, d0, dres ? ldraw(dres + o0) : x0, p);
+  }
+  if constexpr (COLS) {  // fold the block's pixel rows in fixed order: [rows][tp * 8] through LDS
+    __shared__ float red[256 * 8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) red[(prow * tp + lane_c) * 8 + e] = cs[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < tp * 8; c += 256) {
+      float a = 0.f;
+      for (int r = 0; r < g.rows; r++) a += red[(r * tp + (c >> 3)) * 8 + (c & 7)];
+      if (c < g.C) colpart[((size_t)n * g.nchunk + blockIdx.x) * g.C + c] = a;
+    }
   }
 }
 
@@ -435,4 +457,28 @@ extern "C" int dmvae_groupnorm_bwd(const void* da, const void* x, const void* dr
   int rc = dmvae_groupnorm_bwd_reduce(da, x, stats, gamma, beta, S, dgamma, dbeta, workspace, workspace_bytes, n, hw, c, groups, act, accumulate, stream);
   if (rc) return rc;
   return dmvae_groupnorm_bwd_apply(da, x, dres, stats, S, gamma, beta, dx, n, hw, c, groups, act, 0.f, stream);
+}
+
+int dmvae_colsum_final(const float* part, float* out, int nparts, int C, int accumulate, hipStream_t stream);  // conv_wgrad.hip
+
+// dmvae_groupnorm_bwd that also returns colsum[c] = sum over (n, hw) of the dx it stores: the bias gradient of the conv whose output gradient dx is.
+extern "C" int dmvae_groupnorm_bwd_colsum(const void* da, const void* x, const void* dres, const void* stats, const void* gamma, const void* beta, void* dx,
+                                          void* dgamma, void* dbeta, void* colsum, void* workspace, size_t workspace_bytes, int n, int hw, int c, int groups,
+                                          int act, int accumulate, int colsum_accumulate, hipStream_t stream) {
+  Geom g;
+  DMVAE_CHECK_ARG(da && x && stats && gamma && beta && dx && colsum && workspace, "groupnorm_bwd_colsum: null pointer");
+  DMVAE_CHECK_ARG(act >= 0 && act <= 2, "groupnorm_bwd_colsum: act must be 0, 1 or 2");
+  DMVAE_CHECK_ARG(make_geom(g, n, hw, c, groups) == 0, "groupnorm_bwd_colsum: unsupported shape n=%d hw=%d c=%d groups=%d", n, hw, c, groups);
+  DMVAE_CHECK_ARG(workspace_bytes >= dmvae_groupnorm_workspace(n, hw, c, groups), "groupnorm_bwd_colsum: workspace too small");
+  float* S = (float*)workspace + (size_t)n * g.nchunk * c * 2 + (size_t)n * c * 2;
+  int rc = dmvae_groupnorm_bwd_reduce(da, x, stats, gamma, beta, S, dgamma, dbeta, workspace, workspace_bytes, n, hw, c, groups, act, accumulate, stream);
+  if (rc) return rc;
+  float* colpart = (float*)workspace;   // the reduce half's partials are consumed by now (stream order): their space takes the column partials
+  const dim3 grid(g.nchunk, n);
+#define DMVAE_GN_BAPPLYC(A) hipLaunchKernelGGL((bwd_apply_kernel<A, true>), grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)x, (const bf16*)dres, \
+                                               (const float*)stats, (const float*)S, (const float*)gamma, (const float*)beta, (bf16*)dx, g, 0.f, colpart)
+  if (act == 1) DMVAE_GN_BAPPLYC(1); else if (act == 2) DMVAE_GN_BAPPLYC(2); else DMVAE_GN_BAPPLYC(0);
+#undef DMVAE_GN_BAPPLYC
+  DMVAE_CHECK_LAUNCH();
+  return dmvae_colsum_final(colpart, (float*)colsum, n * g.nchunk, c, colsum_accumulate, stream);
 }

@@ -111,6 +111,7 @@ class ResnetBlockFn(torch.autograd.Function):
         y, sty = ops.conv2d_nhwc_gnstats(a2, packed(c2w), c2b, residual=xs, ks=3)   # ... and the next module's norm from conv2's
         ctx.save_for_backward(x, st1, a1, h1, st2, a2, n1w, n1b, c1w, n2w, n2b, c2w, sw)
         ctx.bias_params = (c1b, c2b, sb)     # only for their gradient destinations
+        ctx.want_colsum = bool(getattr(x, "_dmvae_want_colsum", False)) and not parity.on()
         return _tag_stats(y, sty)
 
     @staticmethod
@@ -128,7 +129,7 @@ class ResnetBlockFn(torch.autograd.Function):
         else:
             dsw, dsb = ops.conv2d_nhwc_wgrad(dy, x, 1, dw_out=_dst(sw), db_out=_dst(sb))
             dxs = ops.conv2d_nhwc(dy, packed(sw, True), ks=1)
-        dx, dn1w, dn1b = ops.groupnorm_bwd(da1, x, st1, n1w, n1b, True, dres=dxs, dg_out=_dst(n1w), db_out=_dst(n1b))
+        dx, dn1w, dn1b = ops.groupnorm_bwd(da1, x, st1, n1w, n1b, True, dres=dxs, dg_out=_dst(n1w), db_out=_dst(n1b), want_colsum=ctx.want_colsum)
         return dx, dn1w, dn1b, dc1w, dc1b, dn2w, dn2b, dc2w, dc2b, dsw, dsb
 
 
@@ -207,6 +208,11 @@ class ConvFn(torch.autograd.Function):
             y = ops.conv2d_nhwc(x, packed(w), b, ks=ks, upsample=upsample)
         ctx.save_for_backward(x, w)
         ctx.ks, ctx.upsample, ctx.bias_param, ctx.sub = ks, upsample, b, sub
+        if sub and b is not None:
+            try:
+                y._dmvae_want_colsum = True      # the module that consumes y can hand back the column sums of dL/dy (this layer's bias gradient) for free
+            except AttributeError:
+                pass
         return y if sty is None else _tag_stats(y, sty)
 
     @staticmethod
@@ -216,7 +222,13 @@ class ConvFn(torch.autograd.Function):
         if ctx.sub:
             dwd, _ = ops.conv2d_nhwc_wgrad(x, dy, 4, need_bias=False, stride=2)          # D's weight gradient: D maps dy [N,2H,2W,Cout] to [N,H,W,Cin]
             dw = ops.subpixel_weight_fold(dwd, dw_out=_dst(w))
-            db = ops.colsum(dy, out=_dst(ctx.bias_param)) if ctx.bias_param is not None else None
+            db = None
+            if ctx.bias_param is not None:
+                tag, dst = getattr(dy, "_dmvae_colsum", None), _dst(ctx.bias_param)
+                if tag is not None and tag[1] == dy._version and tag[2] == dy.data_ptr():
+                    db = tag[0] if dst is None else dst.copy_(tag[0])       # summed by the GroupNorm backward that wrote dy (ResnetBlockFn.backward)
+                else:
+                    db = ops.colsum(dy, out=dst)
             dx = ops.conv2d_nhwc(dy, packed(w, False, subpixel=True), ks=4, stride=2) if ctx.needs_input_grad[0] else None
             return dx, dw, db, None, None
         dw, db = ops.conv2d_nhwc_wgrad(dy, x, ctx.ks, upsample=ctx.upsample, dw_out=_dst(w), db_out=_dst(ctx.bias_param))

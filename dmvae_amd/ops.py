@@ -370,7 +370,9 @@ def groupnorm_apply(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, b
 
 def groupnorm_bwd(da: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, swish: bool,
                   dres: Optional[torch.Tensor] = None, groups: int = 32, need_param_grads: bool = True,
-                  dg_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None):
+                  dg_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None, want_colsum: bool = False):
+    """-> (dx, dgamma, dbeta).  want_colsum: dx additionally carries `_dmvae_colsum` = (sum of dx over (n, hw) per channel [C] f32, version, data_ptr) -- the
+    bias gradient of the conv that produced x, a by-product of the pass that writes dx (dmvae_groupnorm_bwd_colsum)."""
     if x.dtype == f32 and parity.on():
         return parity.groupnorm_bwd(da, x, stats, gamma, beta, int(swish), dres, groups, need_param_grads, dg_out, db_out)
     da = _req(da, bf16, "da")
@@ -385,6 +387,13 @@ def groupnorm_bwd(da: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma:
     db = (db_out if db_out is not None else torch.empty(c, dtype=f32, device=x.device)) if need_param_grads else None
     if dres is not None:
         _req(dres, bf16, "dres")
+    if want_colsum:
+        cs = torch.empty(c, dtype=f32, device=x.device)
+        check(L.dmvae_groupnorm_bwd_colsum(da.data_ptr(), x.data_ptr(), _ptr(dres), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dx.data_ptr(),
+                                           _ptr(dg), _ptr(db), cs.data_ptr(), ws.data_ptr(), ws.numel(), n, hw, c, groups, int(swish), 0, 0, _stream()),
+              "groupnorm_bwd_colsum")
+        dx._dmvae_colsum = (cs, dx._version, dx.data_ptr())
+        return dx, dg, db
     check(L.dmvae_groupnorm_bwd(da.data_ptr(), x.data_ptr(), _ptr(dres), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dx.data_ptr(),
                                 _ptr(dg), _ptr(db), ws.data_ptr(), ws.numel(), n, hw, c, groups, int(swish), 0, _stream()), "groupnorm_bwd")
     return dx, dg, db

@@ -107,6 +107,11 @@ int dmvae_groupnorm_bwd(const void* da, const void* x, const void* dres, const v
                         const void* beta, void* dx, void* dgamma, void* dbeta, void* workspace,
                         size_t workspace_bytes, int n, int hw, int c, int groups, int act, int accumulate,
                         dmvae_stream_t stream);
+/* dmvae_groupnorm_bwd with one more by-product: colsum[c] (+)= sum over (n, hw) of the dx it stores (bf16-rounded, f32 sum, fixed order) -- when dx is the
+ * output gradient of a conv (a ResnetBlock's norm1 behind Upsample's conv, flux_ae.py:71,103-107), that is the conv's bias gradient, for free. */
+int dmvae_groupnorm_bwd_colsum(const void* da, const void* x, const void* dres, const void* stats, const void* gamma, const void* beta, void* dx,
+                               void* dgamma, void* dbeta, void* colsum, void* workspace, size_t workspace_bytes, int n, int hw, int c, int groups, int act,
+                               int accumulate, int colsum_accumulate, dmvae_stream_t stream);
 /* The two halves, for callers that own the statistics (SyncBatchNorm: all-reduce `sums` over ranks in between and pass
  * inv_count = 1 / global element count; eval-mode BatchNorm: skip the reduce and pass zero sums).
  * sums: [n][groups][2] f32 = (sum g, sum g*x_hat), g = da*act'(.)*gamma.  inv_count <= 0 selects 1/(hw*c/groups). */

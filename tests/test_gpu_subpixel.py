@@ -162,3 +162,45 @@ def test_conv_gnstats_matches_separate_statistics_pass(case):
     assert rel_err(st, st0) < 1e-5
     y2, st2 = ops.conv2d_nhwc_gnstats(x, wt, b, r, **kw)
     assert torch.equal(st, st2)                                          # fixed summation order
+
+
+def test_bias_gradient_rides_on_the_groupnorm_backward():
+    """Upsample -> ResnetBlock (flux_ae.py:257-262): the ResnetBlock's norm1 backward writes the Upsample conv's output gradient and sums it per channel on the
+    way (dmvae_groupnorm_bwd_colsum); ConvFn.backward takes that as the bias gradient instead of a separate pass.  Same bias gradient as the separate pass
+    (DMVAE_* off is not needed: the fallback is exercised by calling the layer alone), and the kernel pair agrees with the plain backward bit for bit on dx."""
+    from dmvae_amd import ops
+    from dmvae_amd.models.flux_ae import ResnetBlock, Upsample
+    g = torch.Generator().manual_seed(17)
+    up, blk = Upsample(128).to(DEV), ResnetBlock(128, 128).to(DEV)
+    with torch.no_grad():
+        for p in list(up.parameters()) + list(blk.parameters()):
+            p.copy_(torch.randn(p.shape, generator=g) * (0.05 if p.dim() > 1 else 0.3))
+    x = torch.randn(2, 32, 32, 128, generator=g).to(BF).to(DEV)
+    dy = torch.randn(2, 64, 64, 128, generator=g).to(BF).to(DEV)
+
+    def run(chain):
+        for p in list(up.parameters()) + list(blk.parameters()):
+            p.grad = None
+        h = up.forward_nhwc(x)
+        (blk.forward_nhwc(h) if chain else h).backward(dy)
+        return up.conv.bias.grad.clone(), up.conv.weight.grad.clone()
+    h = up.forward_nhwc(x)
+    assert getattr(h, "_dmvae_want_colsum", False)
+    db_chain, dw_chain = run(True)
+    # reference for the chained case: the block's input gradient summed over pixels, from a second backward through the block alone
+    hh = up.forward_nhwc(x).detach().requires_grad_(True)
+    blk.forward_nhwc(hh).backward(dy)
+    assert getattr(hh.grad, "_dmvae_colsum", None) is None                         # not requested: hh does not come from the sub-pixel conv
+    want = hh.grad.float().sum(dim=(0, 1, 2))
+    assert rel_err(db_chain, want) < 1e-5
+    db_alone, _ = run(False)                                                       # the layer alone: the separate column-sum pass over dy
+    assert rel_err(db_alone, dy.float().sum(dim=(0, 1, 2))) < 1e-5
+    # kernel level: dx identical with and without the by-product; column sums = sums of the stored dx
+    xs = torch.randn(2, 64 * 64, 128, generator=g).to(BF).to(DEV)
+    da = torch.randn(2, 64 * 64, 128, generator=g).to(BF).to(DEV)
+    st = ops.groupnorm_stats(xs)
+    gw, gb = torch.rand(128, generator=g).to(DEV) + 0.5, torch.randn(128, generator=g).to(DEV)
+    dx0, dg0, db0 = ops.groupnorm_bwd(da, xs, st, gw, gb, True, dres=da)
+    dx1, dg1, db1 = ops.groupnorm_bwd(da, xs, st, gw, gb, True, dres=da, want_colsum=True)
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert rel_err(dx1._dmvae_colsum[0], dx1.float().sum(dim=(0, 1))) < 1e-5
