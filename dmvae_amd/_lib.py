@@ -53,6 +53,7 @@ SIGNATURES = {
     "dmvae_silu_fwd": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "dmvae_silu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dmvae_layernorm_f32_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "dmvae_scale_residual_layernorm": (c_int, [c_void_p] * 6 + [c_int, c_int, c_float, c_void_p]),
     "dmvae_scale_residual_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "dmvae_softmax_rows_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_float, c_void_p]),
     "dmvae_attention_qkv_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),

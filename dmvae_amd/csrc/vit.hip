@@ -9,19 +9,29 @@
 
 namespace dmvae_vit {
 
-// one wave per row; C % 256 == 0 (4 floats per lane per sweep), C <= 4096
-template <int SWEEPS>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, bf16* __restrict__ y, int rows, float eps) {
+// one wave per row; C % 256 == 0 (4 floats per lane per sweep), C <= 4096.
+// RES: the LayerScale + residual add that precedes every LayerNorm but the first (x += ls * r, the previous branch's output r in bf16) in the same pass --
+// the f32 residual stream is read and written once instead of read-written by one kernel and read again by the next (bit-identical to the two kernels).
+template <int SWEEPS, bool RES = false>
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16* __restrict__ y, int rows, float eps,
+                                                        const bf16* __restrict__ r = nullptr, const float* __restrict__ ls = nullptr) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   constexpr int C = SWEEPS * 256;
-  const float* xr = x + (size_t)row * C;
+  float* xr = x + (size_t)row * C;
   f32x4 v[SWEEPS];
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < SWEEPS; k++) {
     v[k] = *reinterpret_cast<const f32x4*>(xr + k * 256 + lane * 4);
+    if constexpr (RES) {
+      const bf16x4 rv = *reinterpret_cast<const bf16x4*>(r + (size_t)row * C + k * 256 + lane * 4);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(ls + k * 256 + lane * 4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[k][e] = fmaf(g[e], (float)rv[e], v[k][e]);
+      *reinterpret_cast<f32x4*>(xr + k * 256 + lane * 4) = v[k];
+    }
     s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
   }
   const float mean = wave_sum(s) * (1.f / C);
@@ -96,13 +106,34 @@ extern "C" int dmvae_layernorm_f32_bf16(const void* x, const void* gamma, const 
                   "layernorm_f32_bf16: width must be a multiple of 256 up to 1536 (got %d)", c);
   const dim3 grid((rows + 3) / 4), block(256);
   switch (c / 256) {
-    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, (const float*)x, (const float*)gamma, (const float*)beta, (bf16*)y, rows, eps); break;
-    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, (const float*)x, (const float*)gamma, (const float*)beta, (bf16*)y, rows, eps); break;
-    case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, stream, (const float*)x, (const float*)gamma, (const float*)beta, (bf16*)y, rows, eps); break;
-    case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, (const float*)x, (const float*)gamma, (const float*)beta, (bf16*)y, rows, eps); break;
-    case 5: hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, stream, (const float*)x, (const float*)gamma, (const float*)beta, (bf16*)y, rows, eps); break;
-    default: hipLaunchKernelGGL(layernorm_kernel<6>, grid, block, 0, stream, (const float*)x, (const float*)gamma, (const float*)beta, (bf16*)y, rows, eps); break;
+    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, (float*)x, (const float*)gamma, (const float*)beta, (bf16*)y, rows, eps, nullptr, nullptr); break;
+    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, (float*)x, (const float*)gamma, (const float*)beta, (bf16*)y, rows, eps, nullptr, nullptr); break;
+    case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, stream, (float*)x, (const float*)gamma, (const float*)beta, (bf16*)y, rows, eps, nullptr, nullptr); break;
+    case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, (float*)x, (const float*)gamma, (const float*)beta, (bf16*)y, rows, eps, nullptr, nullptr); break;
+    case 5: hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, stream, (float*)x, (const float*)gamma, (const float*)beta, (bf16*)y, rows, eps, nullptr, nullptr); break;
+    default: hipLaunchKernelGGL(layernorm_kernel<6>, grid, block, 0, stream, (float*)x, (const float*)gamma, (const float*)beta, (bf16*)y, rows, eps, nullptr, nullptr); break;
   }
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_scale_residual_layernorm(void* x, const void* r, const void* ls_gamma, const void* gamma, const void* beta, void* y, int rows, int c,
+                                              float eps, hipStream_t stream) {
+  DMVAE_CHECK_ARG(x && r && ls_gamma && gamma && beta && y && rows > 0, "scale_residual_layernorm: bad argument");
+  DMVAE_CHECK_ARG(c == 256 || c == 512 || c == 768 || c == 1024 || c == 1280 || c == 1536,
+                  "scale_residual_layernorm: width must be a multiple of 256 up to 1536 (got %d)", c);
+  const dim3 grid((rows + 3) / 4), block(256);
+#define DMVAE_SRLN(S) hipLaunchKernelGGL((layernorm_kernel<S, true>), grid, block, 0, stream, (float*)x, (const float*)gamma, (const float*)beta, (bf16*)y, rows, eps, \
+                                         (const bf16*)r, (const float*)ls_gamma)
+  switch (c / 256) {
+    case 1: DMVAE_SRLN(1); break;
+    case 2: DMVAE_SRLN(2); break;
+    case 3: DMVAE_SRLN(3); break;
+    case 4: DMVAE_SRLN(4); break;
+    case 5: DMVAE_SRLN(5); break;
+    default: DMVAE_SRLN(6); break;
+  }
+#undef DMVAE_SRLN
   DMVAE_CHECK_LAUNCH();
   return 0;
 }

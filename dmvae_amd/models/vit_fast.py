@@ -42,8 +42,9 @@ def frozen_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
     t = torch.cat([vit.cls_token.expand(t.shape[0], -1, -1).float(), t], dim=1) + vit.pos_embed.float()
     t = t.contiguous()                                   # f32 residual stream [B, S, C]
     b, s, c = t.shape
-    for blk in vit.blocks:
-        hn = ops.layernorm_bf16(t, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+    hn = ops.layernorm_bf16(t, vit.blocks[0].norm1.weight, vit.blocks[0].norm1.bias, vit.blocks[0].norm1.eps)
+    nblk = len(vit.blocks)
+    for i, blk in enumerate(vit.blocks):
         nh = blk.attn.num_heads
         hd = c // nh
         qkv = F.linear(hn, _w(blk.attn.qkv.weight), _w(blk.attn.qkv.bias))              # [b, s, 3*c] = [b, s, 3, heads, hd]
@@ -54,12 +55,13 @@ def frozen_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
             att = ops.softmax_rows_bf16(qkv[0] @ qkv[1].transpose(-2, -1), hd ** -0.5)   # scale, f32 softmax and the casts in one pass
             o = (att @ qkv[2]).transpose(1, 2).reshape(b, s, c)
         o = F.linear(o, _w(blk.attn.proj.weight), _w(blk.attn.proj.bias))
-        ops.scale_residual_(t, o.contiguous(), blk.ls1.gamma)
-        hn = ops.layernorm_bf16(t, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-        h = F.gelu(F.linear(hn, _w(blk.mlp.fc1.weight), _w(blk.mlp.fc1.bias)))
+        # every LayerScale + residual add is followed by a LayerNorm (this block's norm2, the next block's norm1, the final norm): one pass over the stream
+        hn = ops.scale_residual_layernorm_(t, o.contiguous(), blk.ls1.gamma, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        h = ops.gelu(F.linear(hn, _w(blk.mlp.fc1.weight), _w(blk.mlp.fc1.bias)))
         o = F.linear(h, _w(blk.mlp.fc2.weight), _w(blk.mlp.fc2.bias))
-        ops.scale_residual_(t, o, blk.ls2.gamma)
-    return ops.layernorm_bf16(t, vit.norm.weight, vit.norm.bias, vit.norm.eps)
+        nxt = vit.blocks[i + 1].norm1 if i + 1 < nblk else vit.norm
+        hn = ops.scale_residual_layernorm_(t, o, blk.ls2.gamma, nxt.weight, nxt.bias, nxt.eps)
+    return hn
 
 
 def hip_path_supported(vit, seq_len: int) -> bool:

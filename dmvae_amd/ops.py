@@ -659,6 +659,19 @@ def attention_heads_supported(n: int, d: int) -> bool:
     return n <= 288 and d % 8 == 0 and (d + 31) // 32 * 32 in (64, 96)
 
 
+def scale_residual_layernorm_(x: torch.Tensor, r: torch.Tensor, ls_gamma: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """x (f32, in place) += ls_gamma * r (bf16), then LayerNorm(x) -> bf16: `scale_residual_` + `layernorm_bf16` in one pass over the residual stream."""
+    x = _req(x, f32, "x")
+    r = _req(r, bf16, "r")
+    assert x.shape == r.shape
+    c = x.shape[-1]
+    y = torch.empty(x.shape, dtype=bf16, device=x.device)
+    check(_lib.lib().dmvae_scale_residual_layernorm(x.data_ptr(), r.data_ptr(), _req(ls_gamma, f32, "ls_gamma").data_ptr(), _req(gamma, f32, "gamma").data_ptr(),
+                                                    _req(beta, f32, "beta").data_ptr(), y.data_ptr(), x.numel() // c, c, float(eps), _stream()),
+          "scale_residual_layernorm")
+    return y
+
+
 def scale_residual_(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor) -> torch.Tensor:
     """x (f32, in place) += gamma * y (bf16): LayerScale + residual add."""
     x = _req(x, f32, "x")

@@ -217,6 +217,10 @@ int dmvae_silu_bwd(const void* x, const void* dy, void* dx, size_t n, dmvae_stre
  * of the following Linear.  c in {256, 512, ..., 1536}. */
 int dmvae_layernorm_f32_bf16(const void* x, const void* gamma, const void* beta, void* y, int rows, int c, float eps,
                              dmvae_stream_t stream);
+/* The two calls below fused, for every LayerNorm that follows a LayerScale + residual add (all but a block's first): x += ls_gamma * r (in place, f32), then
+ * y = bf16(LayerNorm(x)); one pass over the residual stream, bit-identical to scale_residual_f32 followed by layernorm_f32_bf16. */
+int dmvae_scale_residual_layernorm(void* x, const void* r, const void* ls_gamma, const void* gamma, const void* beta, void* y, int rows, int c, float eps,
+                                   dmvae_stream_t stream);
 /* x[rows][c] (f32, in place) += gamma[c] * y[rows][c] (bf16): LayerScale (dino_layers/layer_scale.py:15-26) + residual add. c%8==0. */
 int dmvae_scale_residual_f32(void* x, const void* y, const void* gamma, size_t rows, int c, dmvae_stream_t stream);
 /* p[rows][cols] (bf16) = softmax(scale * s[rows][cols]) with bf16 scores, f32 inside; cols <= 512 (encoder attention, S = 257). */
