@@ -23,6 +23,9 @@
 //        retired by lgkmcnt(0) before B_{2t}.
 #include "common.h"
 #include "dmvae_hip.h"
+#ifndef DMVAE_PP_PRIO_MODE
+#define DMVAE_PP_PRIO_MODE 1   // 0: s_setprio 1 / 0 around every COMPUTE interval (round 1); 1: static priority 1 for the second-dispatched wave group; 2: none
+#endif
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -332,6 +335,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   wait_vmcnt<(PF - 1) * NP>();
   __builtin_amdgcn_s_barrier();                // B_0: everybody's pieces of tile 0 have landed
   stamp(work, 2);
+#if DMVAE_PP_PRIO_MODE == 1
+  if (grp == 1) __builtin_amdgcn_s_setprio(1);  // static priority for the second-dispatched half, no per-interval flips (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#endif
   if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger group 1 by one interval
 
   // ---- main loop ------------------------------------------------------------------------------------------------------
@@ -354,13 +360,17 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // COMPUTE interval (issuing the DMA from here, in the MFMA shadow, measured 5-8 % slower than from the LOAD interval)
+#if DMVAE_PP_PRIO_MODE == 0
     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int i = 0; i < BM16; i++)
 #pragma unroll
       for (int j = 0; j < BP16; j++)  // in-place accumulate in the AGPR half of the register file
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[i]), "v"(bfr[j]));
+#if DMVAE_PP_PRIO_MODE == 0
     __builtin_amdgcn_s_setprio(0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);

@@ -28,6 +28,9 @@
 // a K tile's 32 pixels sit two source pixels apart (per-lane offsets doubled) and the row test reads 2y - 1 + ky; sixteen taps instead of nine.
 #include "common.h"
 #include "dmvae_hip.h"
+#ifndef DMVAE_PP_PRIO_MODE
+#define DMVAE_PP_PRIO_MODE 1   // 0: s_setprio 1 / 0 around every COMPUTE interval (round 1); 1: static priority 1 for the second-dispatched wave group; 2: none
+#endif
 #include <cstdlib>
 
 namespace dmvae_wgrad_pp {
@@ -223,6 +226,9 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   for (int u = 0; u < PF; u++) issue(u * SLOT);
   wait_vmcnt<(PF - 1) * NP>();
   __builtin_amdgcn_s_barrier();
+#if DMVAE_PP_PRIO_MODE == 1
+  if (grp == 1) __builtin_amdgcn_s_setprio(1);
+#endif
   if (grp == 1) __builtin_amdgcn_s_barrier();
 
   union Frag { bf16x8 v; s16x4 h[2]; };
@@ -249,7 +255,9 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+#if DMVAE_PP_PRIO_MODE == 0
     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int i = 0; i < BM; i++)
 #pragma unroll
@@ -264,7 +272,9 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
           // s_nop: the compiler rematerialises `ones` with v_mov right before the statement and pads nothing for inline asm
           asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accb[i & 1]) : "v"(af[i].v), "v"(ones));
     }
+#if DMVAE_PP_PRIO_MODE == 0
     __builtin_amdgcn_s_setprio(0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
