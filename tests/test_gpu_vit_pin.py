@@ -95,3 +95,23 @@ def test_uncovered_width_raises_instead_of_running_stock(monkeypatch):
         monkeypatch.setenv("DMVAE_ALLOW_STOCK", "1")
         with pytest.warns(UserWarning, match="STOCK"):
             vit.forward_features(x)
+
+
+@pytest.mark.parametrize("c", [256, 768, 1024])
+def test_scale_residual_layernorm_is_the_two_kernels_in_one_pass(c):
+    """dmvae_scale_residual_layernorm (LayerScale + residual add fused into the LayerNorm that follows it; dino_layers/block.py:89-115) against
+    scale_residual_ followed by layernorm_bf16: the updated residual stream and the normalised tokens bit for bit, and against f64."""
+    from dmvae_amd import ops
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(3, 257, c, generator=g).to(DEV)
+    r = torch.randn(3, 257, c, generator=g).to(torch.bfloat16).to(DEV)
+    ls = (torch.randn(c, generator=g) * 0.1).to(DEV)
+    w, b = (torch.rand(c, generator=g) + 0.5).to(DEV), torch.randn(c, generator=g).to(DEV)
+    x1 = x.clone()
+    y1 = ops.scale_residual_layernorm_(x1, r, ls, w, b, 1e-6)
+    x2 = ops.scale_residual_(x.clone(), r, ls)
+    y2 = ops.layernorm_bf16(x2, w, b, 1e-6)
+    assert torch.equal(x1, x2) and torch.equal(y1, y2)
+    xr = x.double() + ls.double() * r.double()
+    yr = torch.nn.functional.layer_norm(xr, (c,), w.double(), b.double(), 1e-6)
+    assert ((y1.double() - yr).abs().max() / yr.abs().max()).item() < 2.0 ** -8
