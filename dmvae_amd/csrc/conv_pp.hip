@@ -399,7 +399,15 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     issue(SLOT);
   }
   {
-    constexpr int EH = BM / 2;               // cout blocks per staging pass
+    // 64 couts (two 32-cout blocks) per staging pass: a store instruction then writes 8 pixel rows x 128 contiguous bytes.  The 128-row tile (one wave =
+    // 64 couts) used to take them in two passes of 32 -- 16 rows x 64 B per store instruction, i.e. twice the cache lines per instruction, which is what the
+    // epilogue's time tracks -- and now takes them in one (DMVAE_PP_EPI_HALF restores the two passes for A/B builds).
+#ifdef DMVAE_PP_EPI_HALF
+    constexpr int EH = BM / 2;
+#else
+    constexpr int EH = BM >= 4 ? BM / 2 : BM;   // cout blocks per staging pass
+#endif
+    constexpr int NH = BM / EH;              // staging passes over the wave's couts
     constexpr int CWH = EH * 32;             // couts per wave per pass
     constexpr int ROWB = CWH * 4 + 16;       // padded f32 row (bank-conflict-free ds_write_b128)
     constexpr int LPR = CWH / 8, RPI = 64 / LPR;
@@ -413,7 +421,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       for (int i = 0; i < 8; i++) (&sacc[0][0][0])[i] = 0.f;
     }
 #pragma unroll
-    for (int hh = 0; hh < 2; hh++) {
+    for (int hh = 0; hh < NH; hh++) {
       if (n0c + wm * (TM / WM) + hh * CWH >= a.Cout) continue;  // this wave's couts of the pass are all padding (wave-uniform; e.g. Cout = 64 on the 128-row tile)
       const int cb = n0c + wm * (TM / WM) + hh * CWH + cl * 8;  // this lane's 8 couts in the read phase
       const bool c_ok = cb < a.Cout;
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     if constexpr (STATS) {  // lanes that share `cl` hold different pixel rows of the same 8 couts: fold them, then one partial per (tile, wave column, quad)
       const size_t trow = (size_t)(SUB ? (m0c / TP) * 4 + parc : m0c / TP) * WP + wp;
 #pragma unroll
-      for (int hh = 0; hh < 2; hh++)
+      for (int hh = 0; hh < NH; hh++)
 #pragma unroll
         for (int qd = 0; qd < 2; qd++) {
           float s1 = sacc[STATS ? hh : 0][qd][0], s2 = sacc[STATS ? hh : 0][qd][1];
@@ -569,7 +577,8 @@ int launch(Args a, hipStream_t st) {
       if (a.sched) return launch<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, true, STATS>(a, st);
     }
   }
-  constexpr int ring = NBUF * (TM + TP) * 64, epi = 2 * (TM + TP) * 64 + 8 * 32 * ((TM / WM / 2) * 4 + 16);
+  constexpr int cwh = (TM / WM / 32 >= 4) ? TM / WM / 2 : TM / WM;    // couts per staging pass (the kernel's CWH)
+  constexpr int ring = NBUF * (TM + TP) * 64, epi = 2 * (TM + TP) * 64 + 8 * 32 * (cwh * 4 + 16);
   constexpr int lds = ring > epi ? ring : epi;
   static bool attr_done = false;
   if (!attr_done) {
