@@ -223,17 +223,29 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         *reinterpret_cast<uint4*>(vs + key * 256 + ((((c >> 2) ^ (key & 3))) << 6) + ((c & 3) << 4)) = vv;
       }
     }
-  } else
-  for (int i = tid; i < ATT_KEYS * (DP / 8); i += 256) {
-    const int key = i / (DP / 8), c = i - key * (DP / 8);
-    uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-    if (key < S) {
-      kv = *reinterpret_cast<const uint4*>(kb_ + (size_t)key * a.k_rs + c * 8);
-      if (c < vchunks) vv = *reinterpret_cast<const uint4*>(vb_ + (size_t)key * a.v_rs + c * 8);
+  } else {
+    // every global load of the staging is issued before the first LDS store (the loop form waited for each sweep's loads before issuing the next sweep's:
+    // nine to fourteen serial memory round trips, a third of the kernel's time at these sizes)
+    constexpr int SWEEPS = (ATT_KEYS * (DP / 8) + 255) / 256;
+    uint4 kv[SWEEPS], vv[SWEEPS];
+#pragma unroll
+    for (int it = 0; it < SWEEPS; it++) {
+      const int i = tid + it * 256, key = i / (DP / 8), c = i - key * (DP / 8);
+      kv[it] = uint4{0, 0, 0, 0}; vv[it] = uint4{0, 0, 0, 0};
+      if (i < ATT_KEYS * (DP / 8) && key < S) {
+        kv[it] = *reinterpret_cast<const uint4*>(kb_ + (size_t)key * a.k_rs + c * 8);
+        if (c < vchunks) vv[it] = *reinterpret_cast<const uint4*>(vb_ + (size_t)key * a.v_rs + c * 8);
+      }
     }
-    *reinterpret_cast<uint4*>(ks + key * KROW + ((c ^ (key & 7)) << 4)) = kv;
-    // V: channel chunk c (8 channels) -> 64-B segment c >> 2, swizzled by key & 3; 16-B slot c & 3 inside it
-    *reinterpret_cast<uint4*>(vs + key * 256 + ((((c >> 2) ^ (key & 3))) << 6) + ((c & 3) << 4)) = vv;
+#pragma unroll
+    for (int it = 0; it < SWEEPS; it++) {
+      const int i = tid + it * 256, key = i / (DP / 8), c = i - key * (DP / 8);
+      if (i < ATT_KEYS * (DP / 8)) {
+        *reinterpret_cast<uint4*>(ks + key * KROW + ((c ^ (key & 7)) << 4)) = kv[it];
+        // V: channel chunk c (8 channels) -> 64-B segment c >> 2, swizzled by key & 3; 16-B slot c & 3 inside it
+        *reinterpret_cast<uint4*>(vs + key * 256 + ((((c >> 2) ^ (key & 3))) << 6) + ((c & 3) << 4)) = vv[it];
+      }
+    }
   }
   __syncthreads();
   const int kg = lane >> 5, ql = lane & 31;
