@@ -189,8 +189,15 @@ struct AttnArgs {
   float eps;
 };
 
+// NT threads: 512 = two waves per SIMD.  One wave's softmax (the kernel's VALU-bound part: 144 exponentials and their bookkeeping per lane and query block)
+// then runs under the other's matrix work and memory latency; with 256 threads the query blocks of a head were three serial rounds of load -> MFMA ->
+// softmax -> MFMA -> store per wave.  (DMVAE_ATTN_THREADS=256 at build time restores the one-wave-per-SIMD form.)
+#ifndef DMVAE_ATTN_THREADS
+#define DMVAE_ATTN_THREADS 512
+#endif
 template <int DP, bool NR>
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+__global__ __launch_bounds__(DMVAE_ATTN_THREADS) void attention_kernel(AttnArgs a) {
+  constexpr int NT = DMVAE_ATTN_THREADS;
 #if __HIP_DEVICE_COMPILE__
   constexpr int KROW = DP == 64 ? 128 : 256;   // bytes per K row in LDS (8 or 16 chunks of 16 B, XOR-swizzled by key & 7)
   constexpr int KSTEPS = DP / 16, DB = DP / 32;
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   // ---- stage K and V: DP/8 lanes x 16 B per key row ------------------------------------------------------------------------------------
   if constexpr (NR) {  // 16 lanes per key row (the first DP/8 carry data) so that the row's sum of squares is a 16-lane butterfly
     const int c = tid & 15;
-    for (int key = tid >> 4; key < ATT_KEYS; key += 16) {
+    for (int key = tid >> 4; key < ATT_KEYS; key += NT / 16) {
       uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
       const bool live = key < S && c < vchunks;
       if (live) {
@@ -226,11 +233,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   } else {
     // every global load of the staging is issued before the first LDS store (the loop form waited for each sweep's loads before issuing the next sweep's:
     // nine to fourteen serial memory round trips, a third of the kernel's time at these sizes)
-    constexpr int SWEEPS = (ATT_KEYS * (DP / 8) + 255) / 256;
+    constexpr int SWEEPS = (ATT_KEYS * (DP / 8) + NT - 1) / NT;
     uint4 kv[SWEEPS], vv[SWEEPS];
 #pragma unroll
     for (int it = 0; it < SWEEPS; it++) {
-      const int i = tid + it * 256, key = i / (DP / 8), c = i - key * (DP / 8);
+      const int i = tid + it * NT, key = i / (DP / 8), c = i - key * (DP / 8);
       kv[it] = uint4{0, 0, 0, 0}; vv[it] = uint4{0, 0, 0, 0};
       if (i < ATT_KEYS * (DP / 8) && key < S) {
         kv[it] = *reinterpret_cast<const uint4*>(kb_ + (size_t)key * a.k_rs + c * 8);
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     }
 #pragma unroll
     for (int it = 0; it < SWEEPS; it++) {
-      const int i = tid + it * 256, key = i / (DP / 8), c = i - key * (DP / 8);
+      const int i = tid + it * NT, key = i / (DP / 8), c = i - key * (DP / 8);
       if (i < ATT_KEYS * (DP / 8)) {
         *reinterpret_cast<uint4*>(ks + key * KROW + ((c ^ (key & 7)) << 4)) = kv[it];
         // V: channel chunk c (8 channels) -> 64-B segment c >> 2, swizzled by key & 3; 16-B slot c & 3 inside it
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const int ch = db * 32 + 16 * g16 + 4 * qq;
     voff[db] = (kg * 8 + rr) * 256 + ((((ch >> 5) ^ rr)) << 6) + (ch & 31) * 2;
   }
-  for (int qb = wave; qb * 32 < S; qb += 4) {
+  for (int qb = wave; qb * 32 < S; qb += NT / 64) {
     const int q = qb * 32 + ql;
     // Q fragments (B operand of the swapped product): 8 d's per lane per 16-step
     bf16x8 qf[KSTEPS];
@@ -280,52 +287,51 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
           qf[kk] = *reinterpret_cast<const bf16x8*>(&o);
         }
     }
-    // ---- S^T = K Q^T: acc[kb][r] = score(key = kb*32 + (r&3) + 8*(r>>2) + 4*kg, query q) ------------------------------------------
-    f32x16 st[ATT_KB];
+    // ---- two sweeps over the key blocks, 16 score registers live instead of 144 (two waves per SIMD fit) ---------------------------------------------
+    // sweep 1: S^T = K Q^T block by block for the row maximum only; sweep 2: the same product again, e = exp(s - max) straight into bf16 A fragments
+    // (v_permlane32_swap), O += e V, and the row sum; O is normalised at the end.  The second QK^T costs 4-6 MFMAs per block -- the kernel is bound by the
+    // exponentials, which are computed once either way.  st[r] = score(key = kb*32 + (r&3) + 8*(r>>2) + 4*kg, query q).
+    auto scores = [&](int kb) {
+      f32x16 st;
 #pragma unroll
-    for (int kb = 0; kb < ATT_KB; kb++) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) st[kb][r] = 0.f;
+      for (int r = 0; r < 16; r++) st[r] = 0.f;
       const int key = kb * 32 + ql;
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; kk++) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + key * KROW + ((((kk * 2 + kg)) ^ (key & 7)) << 4));
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kb], 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st, 0, 0, 0);
       }
-    }
-    // ---- softmax over keys (this lane + lane^32 own the column) ------------------------------------------------------------------
-    float m = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < ATT_KB; kb++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        const float v = key < S ? st[kb][r] * a.scale : -INFINITY;
-        st[kb][r] = v;
-        m = fmaxf(m, v);
+        const int key_r = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        st[r] = key_r < S ? st[r] * a.scale : -INFINITY;
       }
+      return st;
+    };
+    const int nkb = (S + 31) >> 5;
+    float m = -INFINITY;
+    for (int kb = 0; kb < nkb; kb++) {
+      const f32x16 st = scores(kb);
+#pragma unroll
+      for (int r = 0; r < 16; r++) m = fmaxf(m, st[r]);
+    }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float sum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < ATT_KB; kb++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) { const float e = __expf(st[kb][r] - m); st[kb][r] = e; sum += e; }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.f / sum;
-    // ---- O = P V ---------------------------------------------------------------------------------------------------------------------
     f32x16 o[DB];
 #pragma unroll
     for (int db = 0; db < DB; db++)
 #pragma unroll
       for (int r = 0; r < 16; r++) o[db][r] = 0.f;
+    for (int kb = 0; kb < nkb; kb++) {
+      f32x16 st = scores(kb);
 #pragma unroll
-    for (int kb = 0; kb < ATT_KB; kb++) {
+      for (int r = 0; r < 16; r++) { st[r] = __expf(st[r] - m); sum += st[r]; }
 #pragma unroll
       for (int half = 0; half < 2; half++) {  // 16-key step: registers r = half*8 .. half*8+7 of this block
-        unsigned p0 = pack_bf16(st[kb][half * 8 + 0] * inv, st[kb][half * 8 + 1] * inv);
-        unsigned p1 = pack_bf16(st[kb][half * 8 + 2] * inv, st[kb][half * 8 + 3] * inv);
-        unsigned p2 = pack_bf16(st[kb][half * 8 + 4] * inv, st[kb][half * 8 + 5] * inv);
-        unsigned p3 = pack_bf16(st[kb][half * 8 + 6] * inv, st[kb][half * 8 + 7] * inv);
+        unsigned p0 = pack_bf16(st[half * 8 + 0], st[half * 8 + 1]);
+        unsigned p1 = pack_bf16(st[half * 8 + 2], st[half * 8 + 3]);
+        unsigned p2 = pack_bf16(st[half * 8 + 4], st[half * 8 + 5]);
+        unsigned p3 = pack_bf16(st[half * 8 + 6], st[half * 8 + 7]);
         // lanes < 32 hold keys {0-3, 8-11} of the step, lanes >= 32 {4-7, 12-15}: the A fragment wants {0-7} / {8-15}
         auto s0 = __builtin_amdgcn_permlane32_swap(p0, p2, false, false);
         auto s1 = __builtin_amdgcn_permlane32_swap(p1, p3, false, false);
@@ -341,6 +347,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         }
       }
     }
+    sum += __shfl_xor(sum, 32, 64);
+    // the output's rows are queries along the REGISTERS (C layout), the sums live per query along the LANES: fetch each row's 1 / sum from the lane that owns it
+    const float inv = 1.f / sum;
     // ---- store [B][S][H*D]: rows q = qb*32 + (r&3) + 8*(r>>2) + 4*kg, column d = db*32 + (lane & 31) ----------------------------------
     const int C = H * a.D;
 #pragma unroll
@@ -349,7 +358,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
       for (int r = 0; r < 16; r++) {
         const int qo = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
         const int dcol = db * 32 + ql;
-        if (qo < S && dcol < a.D) a.out[((size_t)b * S + qo) * C + h * a.D + dcol] = (bf16)o[db][r];
+        const float invr = __shfl(inv, (r & 3) + 8 * (r >> 2) + 4 * kg, 64);      // lane l < 32 holds the sum of query qb*32 + l
+        if (qo < S && dcol < a.D) a.out[((size_t)b * S + qo) * C + h * a.D + dcol] = (bf16)(o[db][r] * invr);
       }
   }
 #endif
@@ -363,7 +373,7 @@ static int launch_attention(const AttnArgs& a, int batch, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DP, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((attention_kernel<DP, NR>), dim3(batch * a.H), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((attention_kernel<DP, NR>), dim3(batch * a.H), dim3(DMVAE_ATTN_THREADS), lds, stream, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
