@@ -383,25 +383,28 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA (inline asm, invisible to the hazard recognizer) -> accumulator reads
 
   // ---- epilogue: accumulators -> LDS (f32, per-wave region) -> whole pixel rows, 16-B coalesced stores --------------------------
-  // The MFMA layout gives a lane 4 couts of one pixel: storing that directly touches 32 cache lines per instruction.  Staged
-  // through LDS each store instruction writes RPI rows of CWH contiguous couts instead.  Measured (s_memtime stamps,
-  // tools/probes/time_conv_pp.py): 11-13 k cycles per 128 KB tile = the CU's store-issue rate (~75 cycles per
-  // global_store_dwordx4 wave-instruction), independent of what other CUs do -- so the next tile's setup and first DMA are
-  // started first and fly underneath it (staging uses ring slots 2.. in half-cout passes to leave slots 0-1 to that DMA).
+  // The MFMA layout gives a lane 4 couts of one pixel: stored directly, a wave-instruction scatters its lanes over 16 rows and the address path takes ~67
+  // cycles for it whatever else the chip does (tools/probes/probe_store_bw.hip: 8.6 k cycles per 128 KB tile); 8 rows x 128 contiguous bytes with
+  // consecutive lanes on consecutive bytes take 24 (3.0 k per tile from one CU, 4.8 k with all 256 CUs bursting).  So the tile is staged through LDS
+  // and each store instruction writes RPI rows of CWH contiguous couts.  Phases per tile at 256->256 @128^2 (s_memtime stamps, tools/probes/time_conv_pp.py;
+  // main loop 97.6 k cycles): ring free 0.7 k, bias + next tile's setup 2.2 k, its first two K tiles' DMA 2.0 k (queue time of the 64 KB), staging +
+  // stores 6.4 k, drain 0.4 k; the staging uses ring slots 2.. in half-cout passes and leaves slots 0-1 to that DMA.
   __builtin_amdgcn_s_barrier();  // every wave's trailing DMA has landed and all fragment reads are done: the ring is free
+  stamp(work, 6);
   const unsigned next = DYN ? (unsigned)__builtin_amdgcn_readfirstlane((int)next_dyn) : work + gridDim.x;
   const bool has_next = next < (unsigned)a.total;
-  if (has_next) {
-    stamp(next, 0);
-    setup(next);
-    stamp(next, 1);
-    issue(0);
-    issue(SLOT);
-  }
   {
     // 64 couts (two 32-cout blocks) per staging pass: a store instruction then writes 8 pixel rows x 128 contiguous bytes.  The 128-row tile (one wave =
-    // 64 couts) used to take them in two passes of 32 -- 16 rows x 64 B per store instruction, i.e. twice the cache lines per instruction, which is what the
-    // epilogue's time tracks -- and now takes them in one (DMVAE_PP_EPI_HALF restores the two passes for A/B builds).
+    // 64 couts) used to take them in two passes of 32 -- 16 rows x 64 B per store instruction, i.e. twice the cache lines per instruction -- and now takes
+    // them in one (DMVAE_PP_EPI_HALF restores the two passes for A/B builds).
+    //
+    // Straight-line code, no exec-masked branches: rows past M / couts past Cout are out-of-range offsets of buffer descriptors (stores dropped, loads
+    // return 0), the residual operand and the activation are compile-time cases.  The first form of this epilogue tested `m < M && c_ok` around each
+    // store and loaded the residual under `if (a.res)`; with VMEM operations inside conditional blocks the compiler's wait-count pass could not count
+    // them and put `s_waitcnt vmcnt(0)` behind every pair of staging reads -- every one of the 16 stores of a wave waited for the previous store's
+    // acknowledgement from memory (17-19 k cycles per 128 KB tile, 12-24 % of the kernel; the stores themselves need ~3 k at the rate
+    // tools/probes/probe_store_bw.hip measures with every CU bursting).  A wave's LDS operations execute in order, so the staging region needs no
+    // waits of its own either: the next round's accumulators are written right behind this round's reads.
 #ifdef DMVAE_PP_EPI_HALF
     constexpr int EH = BM / 2;
 #else
@@ -411,66 +414,101 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     constexpr int CWH = EH * 32;             // couts per wave per pass
     constexpr int ROWB = CWH * 4 + 16;       // padded f32 row (bank-conflict-free ds_write_b128)
     constexpr int LPR = CWH / 8, RPI = 64 / LPR;
-    char* reg = smem + 2 * SLOT + wave * (32 * ROWB);
-    const int px_w = lane & 31;
-    const int cl = lane % LPR, rg = lane / LPR;
+    constexpr int NI = 32 / RPI;             // store instructions per round (32 pixel rows)
+    constexpr unsigned ES = OUT_F32 ? 4u : 2u;
     static_assert(!STATS || !OUT_F32, "STATS: statistics of the bf16 result");
-    float sacc[STATS ? 2 : 1][2][2];  // [pass][4-channel half of the lane's 8 couts][sum, sum of squares]
-    if constexpr (STATS) {
-#pragma unroll
-      for (int i = 0; i < 8; i++) (&sacc[0][0][0])[i] = 0.f;
-    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    char* reg = smem + 2 * SLOT + wave * (32 * ROWB);
+    const int cl = lane % LPR, rg = lane / LPR;
+    const unsigned mout = SUB ? 4u * (unsigned)a.M : (unsigned)a.M;   // output pixels (the host keeps mout * Cout * ES below 2^31: SENT stays out of range)
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, mout * (unsigned)a.Cout * ES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)a.Cout * 4u : 0u, 0x00020000);
+    // bias of every pass, loaded while the memory queue is empty: behind the next tile's prefetch (vmcnt counts in order) the first use below would wait
+    // for those LDS-DMA pieces to land -- 2-3 k cycles per tile
+    f32x4 bias_lo[NH], bias_hi[NH];
 #pragma unroll
     for (int hh = 0; hh < NH; hh++) {
-      if (n0c + wm * (TM / WM) + hh * CWH >= a.Cout) continue;  // this wave's couts of the pass are all padding (wave-uniform; e.g. Cout = 64 on the 128-row tile)
-      const int cb = n0c + wm * (TM / WM) + hh * CWH + cl * 8;  // this lane's 8 couts in the read phase
-      const bool c_ok = cb < a.Cout;
-      float bias8[8];
+      const int cb = n0c + wm * (TM / WM) + hh * CWH + cl * 8;
+      const unsigned vo = cb < a.Cout ? (unsigned)cb * 4u : SENT;
+      const u32x4 b0 = __builtin_amdgcn_raw_buffer_load_b128(rBias, vo, 0, 0), b1 = __builtin_amdgcn_raw_buffer_load_b128(rBias, vo + 16u, 0, 0);
+      bias_lo[hh] = *reinterpret_cast<const f32x4*>(&b0);
+      bias_hi[hh] = *reinterpret_cast<const f32x4*>(&b1);
+    }
+    // The next tile's setup and its first two K tiles go out before the stores.  The DMA issue is unconditional (past the last tile: all-zero pieces), so
+    // that the compiler can count the operations between the bias loads and their first use instead of draining the queue at a control-flow join.
+    if (has_next) {
+      stamp(next, 0);
+      setup(next);
+      stamp(next, 1);
+    } else {
+      it = nK;
+    }
+    issue(0);
+    issue(SLOT);
+    stamp(work, 7);
+    float sacc[STATS ? NH : 1][2][2];  // [pass][4-channel half of the lane's 8 couts][sum, sum of squares]
+    if constexpr (STATS) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) bias8[e] = (a.bias && c_ok) ? a.bias[cb + e] : 0.f;
+      for (int i = 0; i < NH * 4; i++) (&sacc[0][0][0])[i] = 0.f;
+    }
+    auto body = [&](auto RESc, auto ACTc) __attribute__((always_inline)) {
+      constexpr bool RES = decltype(RESc)::value;
+      constexpr int ACTC = decltype(ACTc)::value;   // < 0: a.act is read at run time (the activations that are not hot)
+      const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, RES ? mout * (unsigned)a.Cout * 2u : 0u, 0x00020000);
 #pragma unroll
-      for (int j = 0; j < BP; j++) {
-        // residual / gate operand of this pass: issued up front so the loads fly under the LDS transpose below
-        bf16x8 r8s[32 / RPI];
-        unsigned opx[SUB ? 32 / RPI : 1];  // SUB: output pixel index of the lane's rows (parity-interleaved), else the row index itself
-        if constexpr (SUB) {
-#pragma unroll
-          for (int it2 = 0; it2 < 32 / RPI; it2++) {
-            const int m = m0c + wp * (TP / WP) + j * 32 + it2 * RPI + rg;
+      for (int hh = 0; hh < NH; hh++) {
+        if (n0c + wm * (TM / WM) + hh * CWH >= a.Cout) continue;  // this wave's couts of the pass are all padding (wave-uniform; e.g. Cout = 64 on the 128-row tile)
+        const int cb = n0c + wm * (TM / WM) + hh * CWH + cl * 8;  // this lane's 8 couts in the read phase
+        const bool c_ok = cb < a.Cout;
+        // byte offset of (pixel row it2 of round j, couts cb..cb+7) in y / res, or SENT
+        auto row_off = [&](int j, int it2) -> unsigned {
+          const int m = m0c + wp * (TP / WP) + j * 32 + it2 * RPI + rg;
+          unsigned mo = (unsigned)m;
+          if constexpr (SUB) {  // output pixel of the lane's row (parity-interleaved)
             int n, r, y, x;
             divmod_small(m, hw, inv_hw, small_m, n, r);
             divmod_small(r, dvw, inv_wo, small_m, y, x);
-            opx[it2] = (unsigned)((n * a.Ho + 2 * y + (parc >> 1)) * a.Wo + 2 * x + (parc & 1));
+            mo = (unsigned)((n * a.Ho + 2 * y + (parc >> 1)) * a.Wo + 2 * x + (parc & 1));
           }
-        }
-        if (a.res) {
+          return (m < a.M && c_ok) ? mo * (unsigned)a.Cout + (unsigned)cb : SENT;   // in elements
+        };
+        auto stage = [&](int j) {   // accumulators of pixel block j -> the wave's staging region
 #pragma unroll
-          for (int it2 = 0; it2 < 32 / RPI; it2++) {
-            const int m = m0c + wp * (TP / WP) + j * 32 + it2 * RPI + rg;
-            const size_t mo = SUB ? (size_t)opx[SUB ? it2 : 0] : (size_t)m;
-            if (m < a.M && c_ok) r8s[it2] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(a.res + mo * a.Cout + cb));
+          for (int i = 0; i < EH * 2; i++)       // 16-cout blocks of this pass
+#pragma unroll
+            for (int jb = 0; jb < 2; jb++)       // the two 16-pixel blocks of pixel block j
+              *reinterpret_cast<f32x4*>(reg + (jb * 16 + (lane & 15)) * ROWB + (i * 16 + 4 * (lane >> 4)) * 4) = acc[hh * EH * 2 + i][j * 2 + jb];
+        };
+        unsigned eo[2][NI];     // element offsets of the round's rows
+        u32x4 r8s[2][NI];       // residual / gate operand, one round ahead: its loads are issued before the previous round's stores
+        auto fetch = [&](int j) {
+#pragma unroll
+          for (int it2 = 0; it2 < NI; it2++) {
+            eo[j & 1][it2] = row_off(j, it2);
+            if constexpr (RES) r8s[j & 1][it2] = __builtin_amdgcn_raw_buffer_load_b128(rR, eo[j & 1][it2] == SENT ? SENT : eo[j & 1][it2] * 2u, 0, 2);
           }
-        }
+        };
+        fetch(0);
+        stage(0);
 #pragma unroll
-        for (int i = 0; i < EH * 2; i++)       // 16-cout blocks of this pass
+        for (int j = 0; j < BP; j++) {
+          f32x4 lo[NI], hi[NI];
 #pragma unroll
-          for (int jb = 0; jb < 2; jb++)       // the two 16-pixel blocks of pixel block j
-            *reinterpret_cast<f32x4*>(reg + (jb * 16 + (lane & 15)) * ROWB + (i * 16 + 4 * (lane >> 4)) * 4) = acc[hh * EH * 2 + i][j * 2 + jb];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS ops are ordered; the region is private to the wave
+          for (int it2 = 0; it2 < NI; it2++) {
+            const int px = it2 * RPI + rg;
+            lo[it2] = *reinterpret_cast<const f32x4*>(reg + px * ROWB + cl * 32);
+            hi[it2] = *reinterpret_cast<const f32x4*>(reg + px * ROWB + cl * 32 + 16);
+          }
+          if (j + 1 < BP) { fetch(j + 1); stage(j + 1); }   // in-order LDS: these writes land behind the reads above
 #pragma unroll
-        for (int it2 = 0; it2 < 32 / RPI; it2++) {
-          const int px = it2 * RPI + rg;
-          const int m = m0c + wp * (TP / WP) + j * 32 + px;
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + px * ROWB + cl * 32);
-          const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + px * ROWB + cl * 32 + 16);
-          if (m < a.M && c_ok) {
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          for (int it2 = 0; it2 < NI; it2++) {
+            float v[8] = {lo[it2][0], lo[it2][1], lo[it2][2], lo[it2][3], hi[it2][0], hi[it2][1], hi[it2][2], hi[it2][3]};
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] += bias8[e];
-            const size_t off = (SUB ? (size_t)opx[SUB ? it2 : 0] : (size_t)m) * a.Cout + cb;
-            if (a.res) {
-              const bf16x8 r8 = r8s[it2];
-              if (a.act == 3) {  // ReLU-backward gate: `res` is the saved activation, not an addend
+            for (int e = 0; e < 4; e++) { v[e] += bias_lo[hh][e]; v[e + 4] += bias_hi[hh][e]; }
+            const int act = ACTC >= 0 ? ACTC : a.act;
+            if constexpr (RES) {
+              const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(&r8s[j & 1][it2]);
+              if (act == 3) {  // ReLU-backward gate: `res` is the saved activation, not an addend
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = (float)r8[e] > 0.f ? v[e] : 0.f;
               } else {
@@ -478,25 +516,28 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
                 for (int e = 0; e < 8; e++) v[e] += (float)r8[e];
               }
             }
-            if (a.act == 1) {
+            if (act == 1) {
 #pragma unroll
               for (int e = 0; e < 8; e++) v[e] = v[e] * sigmoidf_(v[e]);
-            } else if (a.act == 2) {
+            } else if (act == 2) {
 #pragma unroll
               for (int e = 0; e < 8; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
-            } else if (a.act == 4) {
+            } else if (act == 4) {
 #pragma unroll
               for (int e = 0; e < 8; e++) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
             }
-            if (OUT_F32) {
-              float* yo = reinterpret_cast<float*>(a.y) + off;
-              *reinterpret_cast<f32x4*>(yo) = f32x4{v[0], v[1], v[2], v[3]};
-              *reinterpret_cast<f32x4*>(yo + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            const unsigned off = eo[j & 1][it2];
+            if constexpr (OUT_F32) {
+              const unsigned vo = off == SENT ? SENT : off * 4u;
+              const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+              __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o0), rY, vo, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o1), rY, vo + 16u, 0, 0);
             } else {
               bf16x8 o;
 #pragma unroll
               for (int e = 0; e < 8; e++) o[e] = (bf16)v[e];
               if constexpr (STATS) {  // v_dot2c_f32_bf16 on the packed result: two channels per instruction, 8 instructions per store instead of 24
+                // rows past M do not occur (whole pixel tiles per image), couts past Cout carry exact zeros (zero weights, zero bias, zero residual)
                 const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
 #pragma unroll
                 for (int pr = 0; pr < 4; pr++) {
@@ -508,12 +549,21 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
                 }
               }
               // non-temporal: the tile is next read by a later kernel, after far more than an L2 of other traffic
-              __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.y) + off));
+              __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), rY, off == SENT ? SENT : off * 2u, 0, 2);
             }
           }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads retired before the next block overwrites the region
       }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    if (a.res) {
+      if (a.act == 0) body(T_{}, std::integral_constant<int, 0>{});
+      else if (a.act == 3) body(T_{}, std::integral_constant<int, 3>{});
+      else body(T_{}, std::integral_constant<int, -1>{});
+    } else {
+      if (a.act == 0) body(F_{}, std::integral_constant<int, 0>{});
+      else if (a.act == 2) body(F_{}, std::integral_constant<int, 2>{});
+      else body(F_{}, std::integral_constant<int, -1>{});
     }
     if constexpr (STATS) {  // lanes that share `cl` hold different pixel rows of the same 8 couts: fold them, then one partial per (tile, wave column, quad)
       const size_t trow = (size_t)(SUB ? (m0c / TP) * 4 + parc : m0c / TP) * WP + wp;
@@ -665,6 +715,7 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
   const long long wbytes = (long long)d->cout * d->ks * d->ks * d->cin * 2;
   static const long long min_m = [] { const char* e = getenv("DMVAE_PP_MINM"); return e ? atoll(e) : 16384ll; }();
   if (d->cin % 32 != 0 || d->cout < 64 || d->cout % 8 != 0 || M < min_m || xbytes + (1ll << 22) >= (1ll << 31) || wbytes >= (1ll << 31)) return 1;
+  if (M * d->cout * (d->out_f32 ? 4 : 2) >= (1ll << 31)) return 1;   // the epilogue addresses y (and the residual) through 32-bit buffer offsets; SENT must stay out of range
   Args a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.res = (const bf16*)residual; a.y = y;
   a.N = d->n; a.Hi = d->h; a.Wi = d->w; a.Cin = d->cin; a.Cout = d->cout;

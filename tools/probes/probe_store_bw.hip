@@ -7,7 +7,7 @@
 #include <cstdlib>
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-struct A { char* out; int reps, nt, stride, xcd_only, gap; unsigned long long* st; };
+struct A { char* out; int reps, nt, stride, xcd_only, gap, seg64; unsigned long long* st; };
 __global__ __launch_bounds__(512) void k(A a) {
   extern __shared__ char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -22,6 +22,25 @@ __global__ __launch_bounds__(512) void k(A a) {
   for (int r = 0; r < a.reps; r++) {
     const unsigned long long b0 = __builtin_amdgcn_s_memtime(), r0 = wall_clock64();
     char* tile = a.out + ((size_t)active_idx * a.reps + r) * (size_t)(256 * a.stride);
+    if (a.seg64) {  // the MFMA result layout with permuted weight rows: 16 pixel rows x 64 contiguous bytes per instruction, 16 instructions per wave
+#pragma unroll
+      for (int ip = 0; ip < 4; ip++)
+#pragma unroll
+        for (int jb = 0; jb < 4; jb++) {
+          const int row = (wave & 3) * 64 + jb * 16 + (lane & 15);
+          char* p = tile + (size_t)row * a.stride + (wave >> 2) * 256 + ip * 64 + (lane >> 4) * 16;
+          if (a.nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+          else *reinterpret_cast<f32x4*>(p) = v;
+        }
+    } else if (a.seg64 == 2) {  // 4 pixel rows x 256 contiguous bytes per instruction (all 128 couts of the wave per row)
+#pragma unroll
+      for (int it = 0; it < 16; it++) {
+        const int row = (wave & 3) * 64 + it * 4 + (lane >> 4);
+        char* p = tile + (size_t)row * a.stride + (wave >> 2) * 256 + (lane & 15) * 16;
+        if (a.nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+        else *reinterpret_cast<f32x4*>(p) = v;
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -32,6 +51,7 @@ __global__ __launch_bounds__(512) void k(A a) {
         if (a.nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
         else *reinterpret_cast<f32x4*>(p) = v;
       }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     burst += __builtin_amdgcn_s_memtime() - b0;
@@ -49,13 +69,14 @@ int main(int argc, char** argv) {
   hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   printf("tile = 128 KB (256 rows x 512 B of a row); %d tiles per block; cycles = s_memtime per tile, mean over active blocks\n", reps);
-  for (int stride : {512, 1024})
-    for (int nt : {1, 0})
-      for (int gap : {0, 40}) {
+  for (int stride : {512})
+    for (int nt : {1})
+      for (int gap : {0, 40})
+      for (int seg64 : {0, 2}) {
         struct Cfg { int grid, xcd; const char* name; };
         const Cfg cfgs[] = {{8, -1, "1 CU per XCD (8)"}, {256, 0, "32 CUs, XCD 0 only"}, {64, -1, "8 CUs per XCD (64)"}, {128, -1, "16 per XCD (128)"}, {256, -1, "all 256 CUs"}};
         for (const Cfg& c : cfgs) {
-          A a{d, reps, nt, stride, c.xcd, gap, st};
+          A a{d, reps, nt, stride, c.xcd, gap, seg64, st};
           for (int w = 0; w < 2; w++) {
             hipMemset(st, 0, 256 * 16);
             hipEventRecord(e0);
@@ -69,7 +90,7 @@ int main(int argc, char** argv) {
           double sum = 0, rsum = 0; int n = 0;
           for (int b = 0; b < c.grid; b++) if (h[2 * b + 1]) { sum += (double)h[2 * b + 1]; rsum += (double)h[2 * b]; n++; }
           const double cyc = sum / n / reps, ns = rsum / n / reps * 10.0;  // wall_clock64: 100 MHz
-          printf("stride %4d %s gap %2d | %-22s: active %3d, %8.0f cycles per 128-KB burst, %6.1f B/clk/CU, %6.0f ns = %5.1f GB/s per CU, %6.2f TB/s over the active CUs, launch %7.1f us\n", stride, nt ? "nt   " : "plain", gap,
+          printf("stride %4d %s gap %2d %s | %-22s: active %3d, %8.0f cycles per 128-KB burst, %6.1f B/clk/CU, %6.0f ns = %5.1f GB/s per CU, %6.2f TB/s over the active CUs, launch %7.1f us\n", stride, nt ? "nt   " : "plain", gap, seg64 == 2 ? "4x256B" : (seg64 ? "16x64B " : "8x128B"),
                  c.name, n, cyc, 131072.0 / cyc, ns, 131072.0 / ns, 131072.0 / ns * n / 1e3, ms * 1e3);
         }
       }

@@ -27,6 +27,7 @@ for name, n, h, w, cin, cout, ks in SHAPES:
     d = t[:, 1:6] - t[:, 0:5]
     print(f"{name}: blocks {nb}; mean cycles: setup {d[:,0].mean():.0f} first-tile {d[:,1].mean():.0f} loop {d[:,2].mean():.0f} "
           f"epilogue {d[:,3].mean():.0f} (min {d[:,3].min():.0f} max {d[:,3].max():.0f}) drain {d[:,4].mean():.0f} | block {(t[:,5]-t[:,0]).mean():.0f}")
+    print(f"   epilogue split: loop end -> ring free {(t[:,6]-t[:,3]).mean():.0f}, bias + next setup + 2 DMA issues {(t[:,7]-t[:,6]).mean():.0f}, staging + stores {(t[:,4]-t[:,7]).mean():.0f}")
     xcd = 0
     tx = t[xcd::8]
     t0 = tx[:, 0].min()
