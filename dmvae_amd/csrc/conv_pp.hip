@@ -56,17 +56,13 @@ constexpr unsigned SENT = 0x80000000u;  // voffset beyond any descriptor's num_r
 // a group that share row % 4 land in four different 16-B slots of the bank row (derivation in DESIGN.md 3.1).
 __device__ __forceinline__ int swz64(int row) { return (0 - (row >> 2)) & 3; }
 
-// q = m / d, r = m % d for 0 <= m < 2^24 (exact in f32) via one reciprocal and a +-1 fix-up; plain division otherwise
-__device__ __forceinline__ void divmod_small(int m, int d, float inv_d, bool small, int& q, int& r) {
-  if (small) {
-    q = (int)((float)m * inv_d);
-    r = m - q * d;
-    if (r < 0) { q--; r += d; }
-    if (r >= d) { q++; r -= d; }
-  } else {
-    q = m / d;
-    r = m - q * d;
-  }
+// q = m / d, r = m % d for 0 <= m < 2^24 (exact in f32) via one reciprocal and a +-1 fix-up.  The host declines shapes with 2^24 pixels or more: a plain
+// integer division as the other arm kept its reciprocal sequences alive (and spilled) across the whole kernel.
+__device__ __forceinline__ void divmod_small(int m, int d, float inv_d, bool, int& q, int& r) {
+  q = (int)((float)m * inv_d);
+  r = m - q * d;
+  if (r < 0) { q--; r += d; }
+  if (r >= d) { q++; r -= d; }
 }
 
 // s_waitcnt vmcnt(N) through the builtin, not inline asm: the compiler's own wait-count pass then SEES the wait.  With the asm form it kept a VMEM event from
@@ -419,7 +415,11 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     static_assert(!STATS || !OUT_F32, "STATS: statistics of the bf16 result");
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     char* reg = smem + 2 * SLOT + wave * (32 * ROWB);
-    const int cl = lane % LPR, rg = lane / LPR;
+    // an opaque copy of the lane index: everything the epilogue derives from it is recomputed per tile instead of being hoisted out of the tile loop and
+    // carried (spilled) across the main loop
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int cl = lane_o % LPR, rg = lane_o / LPR;
     const unsigned mout = SUB ? 4u * (unsigned)a.M : (unsigned)a.M;   // output pixels (the host keeps mout * Cout * ES below 2^31: SENT stays out of range)
     const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, mout * (unsigned)a.Cout * ES, 0x00020000);
     const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)a.Cout * 4u : 0u, 0x00020000);
@@ -460,51 +460,69 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
         if (n0c + wm * (TM / WM) + hh * CWH >= a.Cout) continue;  // this wave's couts of the pass are all padding (wave-uniform; e.g. Cout = 64 on the 128-row tile)
         const int cb = n0c + wm * (TM / WM) + hh * CWH + cl * 8;  // this lane's 8 couts in the read phase
         const bool c_ok = cb < a.Cout;
-        // byte offset of (pixel row it2 of round j, couts cb..cb+7) in y / res, or SENT
-        auto row_off = [&](int j, int it2) -> unsigned {
+        // Addresses.  Plain tiles: the lane's row (rg, couts cb..) has ONE byte offset per pass -- SENT when its couts are past Cout -- and every later row of
+        // the tile is a wave-uniform multiple of the row stride further (the instruction's scalar offset; rows past M fall off the descriptor's end).
+        // SUB: output pixels are parity-interleaved, so each row's offset is computed (two divmods).
+        const unsigned row_e = (unsigned)(m0c + wp * (TP / WP) + rg) * (unsigned)a.Cout + (unsigned)cb;
+        const unsigned ybase = c_ok ? row_e * ES : SENT, rbase = c_ok ? row_e * 2u : SENT;
+        const unsigned ystep = (unsigned)(RPI * a.Cout) * ES, rstep = (unsigned)(RPI * a.Cout) * 2u;   // wave-uniform
+        auto sub_off = [&](int j, int it2) -> unsigned {   // element offset of the lane's row for the per-parity kernel, or SENT
           const int m = m0c + wp * (TP / WP) + j * 32 + it2 * RPI + rg;
-          unsigned mo = (unsigned)m;
-          if constexpr (SUB) {  // output pixel of the lane's row (parity-interleaved)
-            int n, r, y, x;
-            divmod_small(m, hw, inv_hw, small_m, n, r);
-            divmod_small(r, dvw, inv_wo, small_m, y, x);
-            mo = (unsigned)((n * a.Ho + 2 * y + (parc >> 1)) * a.Wo + 2 * x + (parc & 1));
-          }
-          return (m < a.M && c_ok) ? mo * (unsigned)a.Cout + (unsigned)cb : SENT;   // in elements
+          int n, r, y, x;
+          divmod_small(m, hw, inv_hw, small_m, n, r);
+          divmod_small(r, dvw, inv_wo, small_m, y, x);
+          const unsigned mo = (unsigned)((n * a.Ho + 2 * y + (parc >> 1)) * a.Wo + 2 * x + (parc & 1));
+          return (m < a.M && c_ok) ? mo * (unsigned)a.Cout + (unsigned)cb : SENT;
         };
         auto stage = [&](int j) {   // accumulators of pixel block j -> the wave's staging region
 #pragma unroll
           for (int i = 0; i < EH * 2; i++)       // 16-cout blocks of this pass
 #pragma unroll
             for (int jb = 0; jb < 2; jb++)       // the two 16-pixel blocks of pixel block j
-              *reinterpret_cast<f32x4*>(reg + (jb * 16 + (lane & 15)) * ROWB + (i * 16 + 4 * (lane >> 4)) * 4) = acc[hh * EH * 2 + i][j * 2 + jb];
+              *reinterpret_cast<f32x4*>(reg + (jb * 16 + (lane_o & 15)) * ROWB + (i * 16 + 4 * (lane_o >> 4)) * 4) = acc[hh * EH * 2 + i][j * 2 + jb];
         };
-        unsigned eo[2][NI];     // element offsets of the round's rows
-        u32x4 r8s[2][NI];       // residual / gate operand, one round ahead: its loads are issued before the previous round's stores
-        auto fetch = [&](int j) {
+        // Register budget (128 VGPRs beside the 128 accumulators, two waves per SIMD): with a residual operand the staging reads are taken in two halves
+        // of NI / 2 rows and the operand is held one round ahead (its loads go out before the previous round's stores: vmcnt counts in order, a load queued
+        // behind a store waits for that store's acknowledgement).  Holding whole rounds of reads, offsets and residuals spilled 3-58 VGPRs to scratch.
+        constexpr int NPART = RES ? 2 : 1, NQ = NI / NPART;
+        u32x4 r8s[RES ? 2 : 1][RES ? NI : 1];
+        auto fetch = [&](int j, int h2) {   // residual / gate operand of rows h2 * NQ .. of round j
+          if constexpr (RES) {
 #pragma unroll
-          for (int it2 = 0; it2 < NI; it2++) {
-            eo[j & 1][it2] = row_off(j, it2);
-            if constexpr (RES) r8s[j & 1][it2] = __builtin_amdgcn_raw_buffer_load_b128(rR, eo[j & 1][it2] == SENT ? SENT : eo[j & 1][it2] * 2u, 0, 2);
+            for (int it2 = h2 * NQ; it2 < (h2 + 1) * NQ; it2++) {
+              if constexpr (SUB) {
+                const unsigned eo = sub_off(j, it2);
+                r8s[j & 1][it2] = __builtin_amdgcn_raw_buffer_load_b128(rR, eo == SENT ? SENT : eo * 2u, 0, 2);
+              } else {
+                r8s[j & 1][it2] = __builtin_amdgcn_raw_buffer_load_b128(rR, rbase, (unsigned)(j * NI + it2) * rstep, 2);
+              }
+            }
           }
         };
-        fetch(0);
+#pragma unroll
+        for (int h2 = 0; h2 < NPART; h2++) fetch(0, h2);
         stage(0);
 #pragma unroll
         for (int j = 0; j < BP; j++) {
-          f32x4 lo[NI], hi[NI];
 #pragma unroll
-          for (int it2 = 0; it2 < NI; it2++) {
-            const int px = it2 * RPI + rg;
-            lo[it2] = *reinterpret_cast<const f32x4*>(reg + px * ROWB + cl * 32);
-            hi[it2] = *reinterpret_cast<const f32x4*>(reg + px * ROWB + cl * 32 + 16);
+          for (int h2 = 0; h2 < NPART; h2++) {
+          f32x4 lo[NQ], hi[NQ];
+#pragma unroll
+          for (int q = 0; q < NQ; q++) {
+            const int px = (h2 * NQ + q) * RPI + rg;
+            lo[q] = *reinterpret_cast<const f32x4*>(reg + px * ROWB + cl * 32);
+            hi[q] = *reinterpret_cast<const f32x4*>(reg + px * ROWB + cl * 32 + 16);
           }
-          if (j + 1 < BP) { fetch(j + 1); stage(j + 1); }   // in-order LDS: these writes land behind the reads above
+          if (j + 1 < BP) {
+            if (h2 == NPART - 1) stage(j + 1);   // in-order LDS: these writes land behind the reads above (all of round j's reads have been issued)
+            fetch(j + 1, h2);
+          }
+          u32x4 keep[OUT_F32 ? 2 * NQ : NQ];
 #pragma unroll
-          for (int it2 = 0; it2 < NI; it2++) {
-            float v[8] = {lo[it2][0], lo[it2][1], lo[it2][2], lo[it2][3], hi[it2][0], hi[it2][1], hi[it2][2], hi[it2][3]};
-#pragma unroll
-            for (int e = 0; e < 4; e++) { v[e] += bias_lo[hh][e]; v[e + 4] += bias_hi[hh][e]; }
+          for (int q = 0; q < NQ; q++) {
+            const int it2 = h2 * NQ + q;
+            f32x4 v0 = lo[q] + bias_lo[hh], v1 = hi[q] + bias_hi[hh];
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             const int act = ACTC >= 0 ? ACTC : a.act;
             if constexpr (RES) {
               const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(&r8s[j & 1][it2]);
@@ -526,22 +544,27 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #pragma unroll
               for (int e = 0; e < 8; e++) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
             }
-            const unsigned off = eo[j & 1][it2];
+            unsigned voff = ybase, soff = (unsigned)(j * NI + it2) * ystep;
+            if constexpr (SUB) {
+              const unsigned eo = sub_off(j, it2);
+              voff = eo == SENT ? SENT : eo * ES;
+              soff = 0u;
+            }
             if constexpr (OUT_F32) {
-              const unsigned vo = off == SENT ? SENT : off * 4u;
               const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-              __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o0), rY, vo, 0, 0);
-              __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o1), rY, vo + 16u, 0, 0);
+              keep[2 * q] = *reinterpret_cast<const u32x4*>(&o0);
+              keep[2 * q + 1] = *reinterpret_cast<const u32x4*>(&o1);
+              __builtin_amdgcn_raw_buffer_store_b128(keep[2 * q], rY, voff, soff, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(keep[2 * q + 1], rY, voff + 16u, soff, 0);
             } else {
-              bf16x8 o;
-#pragma unroll
-              for (int e = 0; e < 8; e++) o[e] = (bf16)v[e];
+              const u32x4 o = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3]), dmvae_pack_bf16x2(v[4], v[5]), dmvae_pack_bf16x2(v[6], v[7])};
               if constexpr (STATS) {  // v_dot2c_f32_bf16 on the packed result: two channels per instruction, 8 instructions per store instead of 24
                 // rows past M do not occur (whole pixel tiles per image), couts past Cout carry exact zeros (zero weights, zero bias, zero residual)
                 const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
 #pragma unroll
                 for (int pr = 0; pr < 4; pr++) {
-                  const bf16x2 p2 = {o[2 * pr], o[2 * pr + 1]};
+                  const unsigned pw = o[pr];
+                  const bf16x2 p2 = *reinterpret_cast<const bf16x2*>(&pw);
                   float& s1 = sacc[STATS ? hh : 0][pr >> 1][0];
                   float& s2 = sacc[STATS ? hh : 0][pr >> 1][1];
                   s1 = __builtin_amdgcn_fdot2_f32_bf16(p2, one2, s1, false);
@@ -549,8 +572,17 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
                 }
               }
               // non-temporal: the tile is next read by a later kernel, after far more than an L2 of other traffic
-              __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), rY, off == SENT ? SENT : off * 2u, 0, 2);
+              keep[q] = o;
+              __builtin_amdgcn_raw_buffer_store_b128(o, rY, voff, soff, 2);
             }
+          }
+          // gfx950 hazard that hipcc (ROCm 7.2) does not pad: a VALU instruction that directly follows a buffer_store_dwordx4 and writes one of its data
+          // VGPRs is seen by the store in lanes 12-15 of every 16 -- also when the scalar offset is an SGPR, the case LLVM's hazard recogniser exempts
+          // (tools/probes/probe_store_war.hip: 0.2-5 % of the dwords clobbered at distance 0, none with one wait state).  With 8 VALU instructions per
+          // row the next row's v_pk_add_f32 landed right behind the store and its sums in the previous row's output (deterministic per build, found by
+          // tools/probes/dbg_epi2.py).  Every row's packed result of the part stays live up to the s_nop below, so no store's data can be written before it.
+#pragma unroll
+          for (int q = 0; q < (OUT_F32 ? 2 * NQ : NQ); q++) asm volatile("s_nop 0" :: "v"(keep[q]));
           }
         }
       }
@@ -574,8 +606,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
           float s1 = sacc[STATS ? hh : 0][qd][0], s2 = sacc[STATS ? hh : 0][qd][1];
 #pragma unroll
           for (int off = LPR; off < 64; off <<= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
-          const int cq = n0c + wm * (TM / WM) + hh * CWH + lane * 8 + qd * 4;
-          if (lane < LPR && cq < a.Cout) *reinterpret_cast<f32x2*>(a.gnpart + (trow * (a.Cout >> 2) + (cq >> 2)) * 2) = f32x2{s1, s2};
+          const int cq = n0c + wm * (TM / WM) + hh * CWH + lane_o * 8 + qd * 4;
+          if (lane_o < LPR && cq < a.Cout) *reinterpret_cast<f32x2*>(a.gnpart + (trow * (a.Cout >> 2) + (cq >> 2)) * 2) = f32x2{s1, s2};
         }
     }
   }
@@ -715,6 +747,7 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
   const long long wbytes = (long long)d->cout * d->ks * d->ks * d->cin * 2;
   static const long long min_m = [] { const char* e = getenv("DMVAE_PP_MINM"); return e ? atoll(e) : 16384ll; }();
   if (d->cin % 32 != 0 || d->cout < 64 || d->cout % 8 != 0 || M < min_m || xbytes + (1ll << 22) >= (1ll << 31) || wbytes >= (1ll << 31)) return 1;
+  if (M >= (1ll << 24)) return 1;   // divmod_small
   if (M * d->cout * (d->out_f32 ? 4 : 2) >= (1ll << 31)) return 1;   // the epilogue addresses y (and the residual) through 32-bit buffer offsets; SENT must stay out of range
   Args a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.res = (const bf16*)residual; a.y = y;
