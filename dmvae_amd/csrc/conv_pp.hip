@@ -434,8 +434,10 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       bias_lo[hh] = *reinterpret_cast<const f32x4*>(&b0);
       bias_hi[hh] = *reinterpret_cast<const f32x4*>(&b1);
     }
-    // The next tile's setup and its first two K tiles go out before the stores.  The DMA issue is unconditional (past the last tile: all-zero pieces), so
-    // that the compiler can count the operations between the bias loads and their first use instead of draining the queue at a control-flow join.
+    // The next tile's setup and its first K tile go out before the stores, its second K tile behind them (all eight waves' pieces of two K tiles in front of
+    // the stores held every wave at the issue for 2-3 k cycles; the second tile is not read before the main loop's second iteration).  The first issue is
+    // unconditional (past the last tile: all-zero pieces), so that the compiler can count the operations between the bias loads and their first use
+    // instead of draining the queue at a control-flow join.
     if (has_next) {
       stamp(next, 0);
       setup(next);
@@ -444,7 +446,6 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       it = nK;
     }
     issue(0);
-    issue(SLOT);
     stamp(work, 7);
     float sacc[STATS ? NH : 1][2][2];  // [pass][4-channel half of the lane's 8 couts][sum, sum of squares]
     if constexpr (STATS) {
@@ -611,8 +612,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
         }
     }
   }
+  if (has_next) issue(SLOT);
   stamp(work, 4);
-  wait_vmcnt<0>();               // the epilogue's stores share vmcnt with the two prefetched K tiles: drain both
+  wait_vmcnt<NP>();              // the epilogue's stores share vmcnt with the prefetched K tiles: everything but the second tile's pieces (the newest) has landed
   stamp(work, 5);
   __builtin_amdgcn_s_barrier();  // staging reads done before ring slots 2.. are refilled
   if (has_next) issue(2 * SLOT);
