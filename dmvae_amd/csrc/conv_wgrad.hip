@@ -201,16 +201,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     return;
   }
+  // Slab block = (cout, 64 input channels): [T][64] of every slab is read as 16-B pieces (a 16-lane group per tap row), summed over the splits in order,
+  // turned through LDS and written as the contiguous [64][T] run of PyTorch's [cout][cin][kh][kw] layout.  The first form walked the flat index with 64-bit
+  // divisions per element and stored 4-B words T * 4 bytes apart (32 us per call on average, 1.35 ms per step).
+  __shared__ float tile[16][68];
+  const int cchunks = (Cin + 63) >> 6;
+  const int co = (int)blockIdx.x / cchunks, ci0 = ((int)blockIdx.x - co * cchunks) * 64;
   const size_t total = (size_t)Cout * T * Cin;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)rb * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < splits; k++) s += slab[(size_t)k * total + i];
-    const int ci = i % Cin;
-    const size_t r = i / Cin;
-    const int tap = r % T;
-    const size_t co = r / T;
-    const size_t o = (co * Cin + ci) * T + tap;
-    out[o] = accumulate ? out[o] + s : s;
+  {
+    const int tap = threadIdx.x >> 4, c = (threadIdx.x & 15) * 4;
+    if (tap < T && ci0 + c < Cin) {   // Cin % 4 == 0 (host)
+      const float* src = slab + ((size_t)co * T + tap) * Cin + ci0 + c;
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int k = 0; k < splits; k++) sum += *reinterpret_cast<const f32x4*>(src + (size_t)k * total);
+      *reinterpret_cast<f32x4*>(&tile[tap][c]) = sum;
+    }
+  }
+  __syncthreads();
+  const int ncol = min(64, Cin - ci0), nout = ncol * T;
+  const unsigned rcp = (65536u + (unsigned)T - 1u) / (unsigned)T;   // e / T for e < 1024, T <= 16
+  float* dst = out + ((size_t)co * Cin + ci0) * T;
+  for (int e = threadIdx.x; e < nout; e += 256) {
+    const int c = (int)(((unsigned)e * rcp) >> 16), tap = e - c * T;
+    const float v = tile[tap][c];
+    dst[e] = accumulate ? dst[e] + v : v;
   }
 }
 
@@ -349,7 +364,7 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
     DMVAE_CHECK_LAUNCH();
   }
   const size_t total = (size_t)w.Cout * T * w.Cin;
-  int rb = (int)((total + 255) / 256); if (rb > 2048) rb = 2048;
+  const int rb = w.Cout * ((w.Cin + 63) / 64);   // one block per (cout, 64 input channels)
   const int nb = bias_fused ? (w.Cout + 63) / 64 : 0;  // the ping-pong kernel left per-split column sums of dy behind the weight slabs
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb + nb), dim3(256), 0, stream, w.slab, (float*)dw, splits, w.Cout, T, w.Cin, accumulate, rb,
                      w.slab + (size_t)splits * total, (float*)dbias, splits * pp_ntiles);
