@@ -297,7 +297,11 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 
   // ---- persistent tile loop ---------------------------------------------------------------------------------------------
   auto stamp = [&](unsigned work, int k) {
+    #ifdef DMVAE_PP_TRACE
+    if (a.dbg && tid == 0) a.dbg[(size_t)work * 16 + k] = __builtin_amdgcn_s_memtime();
+#else
     if (a.dbg && tid == 0) a.dbg[(size_t)work * 8 + k] = __builtin_amdgcn_s_memtime();
+#endif
   };
   // DYN: thread 0 claims the tile AFTER the one being started and publishes it; every wave picks it up with the trailing DMA wait of the main loop
   auto claim = [&]() {
@@ -339,6 +343,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   // ---- main loop ------------------------------------------------------------------------------------------------------
   bf16x8 af[BM16], bfr[BP16];
   int slot_rd = 0, slot_wr = PF * SLOT;
+#ifdef DMVAE_PP_TRACE
+  unsigned long long trace_w1 = 0, trace_w2 = 0, trace_load = 0, trace_comp = 0, trace_last = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll 1
   for (int t = 0; t < nK; t++) {
     // LOAD interval
@@ -353,7 +360,14 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     wait_vmcnt<(PF - 1) * NP>();  // own pieces of the NEXT tile have landed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+#ifdef DMVAE_PP_TRACE
+    const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+#endif
     __builtin_amdgcn_s_barrier();
+#ifdef DMVAE_PP_TRACE
+    const unsigned long long tb1 = __builtin_amdgcn_s_memtime();
+    trace_w1 += tb1 - tb0; trace_load += tb0 - trace_last; trace_last = tb1;
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // COMPUTE interval (issuing the DMA from here, in the MFMA shadow, measured 5-8 % slower than from the LOAD interval)
 #if DMVAE_PP_PRIO_MODE == 0
@@ -368,9 +382,22 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     __builtin_amdgcn_s_setprio(0);
 #endif
     __builtin_amdgcn_sched_barrier(0);
+#ifdef DMVAE_PP_TRACE
+    const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+#endif
     __builtin_amdgcn_s_barrier();
+#ifdef DMVAE_PP_TRACE
+    const unsigned long long tc1 = __builtin_amdgcn_s_memtime();
+    trace_w2 += tc1 - tc0; trace_comp += tc0 - trace_last; trace_last = tc1;
+#endif
     __builtin_amdgcn_sched_barrier(0);
   }
+#ifdef DMVAE_PP_TRACE
+  if (a.dbg && (tid == 0 || tid == 256)) {   // per tile: [load, wait after load, compute issue, wait after compute] for wave 0 (slots 8..11) and wave 4 (12..15)
+    unsigned long long* q = a.dbg + (size_t)work * 16 + 8 + (tid >> 8) * 4;
+    q[0] = trace_load; q[1] = trace_w1; q[2] = trace_comp; q[3] = trace_w2;
+  }
+#endif
   stamp(work, 3);
   if (grp == 0) __builtin_amdgcn_s_barrier();  // matches group 1's extra barrier
   unsigned next_dyn = 0;
