@@ -32,6 +32,12 @@
 #define DMVAE_PP_PRIO_MODE 1   // 0: s_setprio 1 / 0 around every COMPUTE interval (round 1); 1: static priority 1 for the second-dispatched wave group; 2: none
 #endif
 #include <cstdlib>
+#ifndef DMVAE_WG_EXP
+#define DMVAE_WG_EXP 0
+#endif
+#ifndef DMVAE_WG_HALO_NBUF
+#define DMVAE_WG_HALO_NBUF 4
+#endif
 
 namespace dmvae_wgrad_pp {
 
@@ -57,22 +63,35 @@ __device__ __forceinline__ void wait_vmcnt() {
 // stays there and every LDS-DMA issue whose soffset depends on them becomes a readfirstlane waterfall loop -- four per K tile, plus a
 // compiler-inserted vmcnt(0) at the loop head because its wait-count model cannot count loads inside those loops.  Pin them to SGPRs.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ s16x4 tr_read(const char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+// Transpose read as inline asm, not __builtin_amdgcn_ds_read_tr16_b64: the compiler's wait-count pass orders every LDS read it can see behind every earlier LDS-DMA
+// (it cannot prove the ring slots disjoint) and put an s_waitcnt vmcnt(0) at the head of the K loop -- the three-tile prefetch queue was drained once per K tile and
+// the loop ran at the latency of the newest piece (tools/loop_waits.py shows the skeleton; 128->128 @256^2: 815 -> see DESIGN.md 8.12).  The asm form carries no memory
+// operand; the loop's own counted vmcnt + barrier protocol is what orders the reads behind the pieces they need, and lgkmcnt(0) ahead of the barrier covers the results.
+template <int OFF>
+__device__ __forceinline__ s16x4 tr_read(unsigned lds_addr) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
+  return r;
 }
 
 // GA / GB: 128-channel sub-tiles of the dy / activation operand per block; waves WM x WN.
-template <int GA, int GB, int WM, int WN, bool S2 = false>
+// HALO (3x3 stride 1, GB = 3): the block's three column groups are the taps kx = 0, 1, 2 of ONE (ky, 128-channel slice), and the activation operand of a K tile is
+// staged once as the 34 pixels x0 - 1 .. x0 + 32 of source row y + ky - 1 (36 LDS rows, 9 pieces) instead of three shifted copies of 32 (24 pieces): a tap's
+// fragment is the same transpose read one pixel row further on.  Per K tile the block then stages 17 KiB instead of 32 -- the 128 x 384 tile runs 24 MFMAs per
+// wave between barriers against the 256 x 256 tile's 32 with the same four DMA issues per wave, and its LOAD interval, not its COMPUTE interval, set the pace.
+template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false>
 __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int TM = GA * 128, TN = GB * 128;
   constexpr int BM = TM / WM / 16, BN = TN / WN / 16;  // 16 x 16 output blocks per wave
   constexpr int SUB = 32 * 256;  // bytes of one [32 px][128 ch] sub-tile
-  constexpr int SLOT = (GA + GB) * SUB;
-  constexpr int NBUF = 4, PF = 3;
-  constexpr int NPA = GA, NPB = GB;  // 1-KiB pieces per wave per K tile (8 pieces per sub-tile, 8 waves)
+  constexpr int BSZ = HALO ? 36 * 256 : GB * SUB;
+  constexpr int SLOT = GA * SUB + BSZ;
+  constexpr int NBUF = HALO ? DMVAE_WG_HALO_NBUF : 4, PF = NBUF - 1;
+  constexpr int NPA = GA, NPB = HALO ? 2 : GB;  // 1-KiB pieces per wave per K tile (8 pieces per sub-tile, 8 waves); HALO: 9 pieces, the ninth is wave 7's second
   constexpr int NP = NPA + NPB;
   static_assert(WM * WN == 8, "8 waves");
+  static_assert(!HALO || (GB == 3 && !S2), "HALO: three taps of one kernel row");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -116,8 +135,23 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   int kyB[NPB], kxB[NPB];                           // tap of the piece's column group (wave-uniform)
   unsigned tapoB[NPB];                              // wave-uniform byte offset of the tap (+ shift), non-upsampled case
   int rowB[NPB];
+  const int my_nt0 = tile - mt * a.ntiles;
+  const int hky = uni(my_nt0 / a.gpt), hhalf = my_nt0 - hky * a.gpt;  // HALO: kernel row and 128-channel slice of this block
 #pragma unroll
   for (int p = 0; p < NPB; p++) {
+    if constexpr (HALO) {
+      const int q = p == 0 ? wave : 8;                 // piece: LDS rows 4 q .. 4 q + 3 <-> source pixels x0 - 1 + row
+      const int row = q * 4 + (lane >> 4);
+      const int clog = ((((cphys >> 1) ^ (((row & 3) << 1) | ((row >> 3) & 1))) << 1) | (cphys & 1)) * 8;
+      const bool ok = row < 34 && (p == 0 || wave == 7);
+      const unsigned v = (unsigned)(row * a.Cin + hhalf * 128 + clog) * 2u;
+      kyB[p] = hky; kxB[p] = 0; rowB[p] = row;
+      tapoB[p] = (unsigned)(hky * a.Wi) * a.Cin * 2u;
+      voffB[p] = ok ? v : SENT;
+      voffBL[p] = (ok && row != 0) ? v : SENT;
+      voffBR[p] = (ok && row != 33) ? v : SENT;
+      continue;
+    }
     const int pb = wave * NPB + p;
     const int sub = pb >> 3, row = (pb & 7) * 4 + (lane >> 4);
     const int clog = ((((cphys >> 1) ^ (((row & 3) << 1) | ((row >> 3) & 1))) << 1) | (cphys & 1)) * 8;
@@ -137,7 +171,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   // ---- fragment read addresses (bytes inside a slot): one per 16-channel block; the second half (+4 pixel rows) is an immediate ------------
   const int G = lane >> 4, rr = (lane & 15) >> 2, qq = lane & 3;
   const int fkey = (rr << 1) | (G & 1);  // swizzle key of pixel rows 8 G + rr and 8 G + rr + 4
-  int aoff[BM], boff[BN];
+  int aoff[BM], boff[BN], boff1[HALO ? BN : 1];
 #pragma unroll
   for (int i = 0; i < BM; i++) {
     const int ch = wm * (TM / WM) + i * 16 + 4 * qq;  // channel inside the TM-wide operand
@@ -148,7 +182,13 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   for (int j = 0; j < BN; j++) {
     const int ch = wn * (TN / WN) + j * 16 + 4 * qq;
     const int sub = ch >> 7, c = ch & 127;
-    boff[j] = GA * SUB + sub * SUB + (G * 8 + rr) * 256 + ((((c >> 4) & 7) ^ fkey) << 5) + (c & 15) * 2;
+    if constexpr (HALO) {  // tap kx = sub: pixel rows 8 G + rr + kx and + 4 of the halo tile (the + 4 may cross an 8-row boundary: its own swizzle key)
+      const int r0 = G * 8 + rr + sub, r1 = r0 + 4;
+      boff[j] = GA * SUB + r0 * 256 + ((((c >> 4) & 7) ^ (((r0 & 3) << 1) | ((r0 >> 3) & 1))) << 5) + (c & 15) * 2;
+      boff1[j] = GA * SUB + r1 * 256 + ((((c >> 4) & 7) ^ (((r1 & 3) << 1) | ((r1 >> 3) & 1))) << 5) + (c & 15) * 2;
+    } else {
+      boff[j] = GA * SUB + sub * SUB + (G * 8 + rr) * 256 + ((((c >> 4) & 7) ^ fkey) << 5) + (c & 15) * 2;
+    }
   }
 
   // Bias gradient (column sums of dy) rides along on the matrix pipe: dy fragment x all-ones fragment, in the wave whose N
@@ -196,6 +236,15 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     }
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
+      if constexpr (HALO) {
+        if (p == 1 && wave != 7) continue;  // wave-uniform: the ninth piece (halo rows 32 .. 35) is wave 7's
+        const int yy = py + kyB[p] - 1;
+        const bool yok = (unsigned)yy < (unsigned)a.Ho;
+        const unsigned v = p == 0 ? (px0 == 0 ? voffBL[p] : voffB[p]) : (px0 + 32 == a.Wo ? voffBR[p] : voffB[p]);
+        const unsigned so = (unsigned)pt * a.Cin * 2u + tapoB[p];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + GA * SUB + (p == 0 ? wave : 8) * 1024), 16, (live && yok) ? v : SENT, yok ? so : 0u, 0, 0);
+        continue;
+      }
       const int pb = wave * NPB + p;
       const int yy = S2 ? 2 * py + kyB[p] - 1 : py + kyB[p] - 1;
       const bool yok = (unsigned)yy < (unsigned)(S2 ? a.Hi : a.Ho);
@@ -222,9 +271,17 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     }
   };
 
+  auto wait_ring = [&]() {  // all but the newest PF - 1 tiles' pieces of this wave have landed
+    constexpr int AH = (DMVAE_WG_EXP & 16) ? PF - 2 : PF - 1;
+    if constexpr (HALO) {
+      if (wave == 7) wait_vmcnt<AH * NP>(); else wait_vmcnt<AH * (NP - 1)>();
+    } else {
+      wait_vmcnt<AH * NP>();
+    }
+  };
 #pragma unroll
   for (int u = 0; u < PF; u++) issue(u * SLOT);
-  wait_vmcnt<(PF - 1) * NP>();
+  wait_ring();
   __builtin_amdgcn_s_barrier();
 #if DMVAE_PP_PRIO_MODE == 1
   if (grp == 1) __builtin_amdgcn_s_setprio(1);
@@ -233,27 +290,40 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 
   union Frag { bf16x8 v; s16x4 h[2]; };
   Frag af[BM], bfr[BN];
+#if DMVAE_WG_EXP & 2
+  for (int i = 0; i < BM; i++) af[i].v = ones;
+  for (int j = 0; j < BN; j++) bfr[j].v = ones;
+#endif
   int slot_rd = 0, slot_wr = PF * SLOT;
 #pragma unroll 1
   for (int t = 0; t < nK; t++) {
-    const char* sb = smem + slot_rd;
+    const unsigned sb = (unsigned)(size_t)LPTR(smem) + (unsigned)slot_rd;
+#if DMVAE_WG_EXP & 8
+    issue(slot_wr);
+#endif
+#if !(DMVAE_WG_EXP & 2)   // timing experiments (tools/probes/build_variant.sh): 1 = no DMA issue in the loop, 2 = no fragment reads, 4 = no barriers
 #pragma unroll
     for (int j = 0; j < BN; j++) {
-      bfr[j].h[0] = tr_read(sb + boff[j]);
-      bfr[j].h[1] = tr_read(sb + boff[j] + 1024);
+      bfr[j].h[0] = tr_read<0>(sb + boff[j]);
+      bfr[j].h[1] = HALO ? tr_read<0>(sb + boff1[HALO ? j : 0]) : tr_read<1024>(sb + boff[j]);
     }
 #pragma unroll
     for (int i = 0; i < BM; i++) {
-      af[i].h[0] = tr_read(sb + aoff[i]);
-      af[i].h[1] = tr_read(sb + aoff[i] + 1024);
+      af[i].h[0] = tr_read<0>(sb + aoff[i]);
+      af[i].h[1] = tr_read<1024>(sb + aoff[i]);
     }
+#endif
+#if !(DMVAE_WG_EXP & (1 | 8 | 16))
     issue(slot_wr);
+#endif
     slot_rd = slot_rd + SLOT == NBUF * SLOT ? 0 : slot_rd + SLOT;
     slot_wr = slot_wr + SLOT == NBUF * SLOT ? 0 : slot_wr + SLOT;
-    wait_vmcnt<(PF - 1) * NP>();
+    wait_ring();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+#if !(DMVAE_WG_EXP & 4)
     __builtin_amdgcn_s_barrier();
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #if DMVAE_PP_PRIO_MODE == 0
     __builtin_amdgcn_s_setprio(1);
@@ -261,8 +331,12 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #pragma unroll
     for (int i = 0; i < BM; i++)
 #pragma unroll
-      for (int j = 0; j < BN; j++)
+      for (int j = 0; j < BN; j++) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[i].v), "v"(bfr[j].v));
+#if DMVAE_WG_EXP & 16
+        if (i == 0 && j == 3) issue((slot_wr == 0 ? NBUF * SLOT : slot_wr) - SLOT);
+#endif
+      }
     const bool bias_now = do_bias && bias_cnt == 0;
     bias_cnt = bias_cnt == 0 ? a.ntiles - 1 : bias_cnt - 1;
     if (bias_now) {
@@ -276,7 +350,9 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     __builtin_amdgcn_s_setprio(0);
 #endif
     __builtin_amdgcn_sched_barrier(0);
+#if !(DMVAE_WG_EXP & 4)
     __builtin_amdgcn_s_barrier();
+#endif
     __builtin_amdgcn_sched_barrier(0);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
@@ -298,8 +374,8 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   for (int j = 0; j < BN; j++) {
     const int nn = wn * (TN / WN) + j * 16 + (lane & 15);  // column inside the block's TN
     const int g = g0 + (nn >> 7);
-    if (g >= a.ngroups) continue;
-    const int tap = g / a.gpt, ci = (g - tap * a.gpt) * 128 + (nn & 127);
+    if (!HALO && g >= a.ngroups) continue;
+    const int tap = HALO ? hky * 3 + (nn >> 7) : g / a.gpt, ci = HALO ? hhalf * 128 + (nn & 127) : (g - tap * a.gpt) * 128 + (nn & 127);
 #pragma unroll
     for (int i = 0; i < BM; i++)
 #pragma unroll
@@ -311,15 +387,15 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #endif
 }
 
-template <int GA, int GB, int WM, int WN, bool S2 = false>
+template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false>
 int launch(const Args& a, int splits, hipStream_t st) {
-  constexpr int lds = 4 * (GA + GB) * 32 * 256;
+  constexpr int lds = (HALO ? DMVAE_WG_HALO_NBUF : 4) * (GA * 32 + (HALO ? 36 : GB * 32)) * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_kernel<GA, GB, WM, WN, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_kernel<GA, GB, WM, WN, S2, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_pp_kernel<GA, GB, WM, WN, S2>), dim3((unsigned)(splits * a.mtiles * a.ntiles)), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((wgrad_pp_kernel<GA, GB, WM, WN, S2, HALO>), dim3((unsigned)(splits * a.mtiles * a.ntiles)), dim3(512), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -395,5 +471,8 @@ int dmvae_wgrad_pp_launch(const void* dy, const void* act, float* slab, float* b
     return s2 ? launch<2, 2, 2, 4, true>(a, splits, stream) : launch<2, 2, 2, 4>(a, splits, stream);
   }
   a.mtiles = d->cout / 128; a.ntiles = (a.ngroups + 2) / 3;
+  // 3x3 stride 1: the halo form (three taps of one kernel row per block; ntiles = 3 * gpt either way)
+  static const bool halo = [] { const char* e = getenv("DMVAE_WGRAD_PP_HALO"); return e ? atoi(e) != 0 : true; }();
+  if (halo && !s2 && d->ks == 3 && !a.ups) return launch<1, 3, 2, 4, false, true>(a, splits, stream);
   return s2 ? launch<1, 3, 2, 4, true>(a, splits, stream) : launch<1, 3, 2, 4>(a, splits, stream);
 }
