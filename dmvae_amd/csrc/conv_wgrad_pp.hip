@@ -38,6 +38,9 @@
 #ifndef DMVAE_WG_HALO_NBUF
 #define DMVAE_WG_HALO_NBUF 4
 #endif
+#ifndef DMVAE_WG_NBUF
+#define DMVAE_WG_NBUF 4
+#endif
 
 namespace dmvae_wgrad_pp {
 
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   constexpr int SUB = 32 * 256;  // bytes of one [32 px][128 ch] sub-tile
   constexpr int BSZ = HALO ? 36 * 256 : GB * SUB;
   constexpr int SLOT = GA * SUB + BSZ;
-  constexpr int NBUF = HALO ? DMVAE_WG_HALO_NBUF : 4, PF = NBUF - 1;
+  constexpr int NBUF = HALO ? DMVAE_WG_HALO_NBUF : DMVAE_WG_NBUF, PF = NBUF - 1;
   constexpr int NPA = GA, NPB = HALO ? 2 : GB;  // 1-KiB pieces per wave per K tile (8 pieces per sub-tile, 8 waves); HALO: 9 pieces, the ninth is wave 7's second
   constexpr int NP = NPA + NPB;
   static_assert(WM * WN == 8, "8 waves");
@@ -227,7 +230,11 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     px0 = r - py * a.Wo;
   }
   auto issue = [&](int slot) {
+#if DMVAE_WG_EXP & 32
+    const bool live = it < 0;     // timing experiment: every piece fully masked (issue + LDS write, no L2 / HBM traffic)
+#else
     const bool live = it < nK;
+#endif
     const unsigned soA = (unsigned)pt * a.Cout * 2u;
 #pragma unroll
     for (int p = 0; p < NPA; p++) {
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 
 template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false>
 int launch(const Args& a, int splits, hipStream_t st) {
-  constexpr int lds = (HALO ? DMVAE_WG_HALO_NBUF : 4) * (GA * 32 + (HALO ? 36 : GB * 32)) * 256;
+  constexpr int lds = (HALO ? DMVAE_WG_HALO_NBUF : DMVAE_WG_NBUF) * (GA * 32 + (HALO ? 36 : GB * 32)) * 256;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_kernel<GA, GB, WM, WN, S2, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -37,7 +37,8 @@ def frozen_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
     """vit: a DinoV2ViT -- either a bf16 shadow (train.frozen_bf16_shadow: Linear / Conv2d weights already bf16) or the f32 module itself, whose
     Linear weights are then served as cached bf16 copies (`functional._bf`, refreshed when a parameter changes); x: [B,3,H,W] f32, already normalised.
     Returns the final-norm tokens [B, 1+N, C] in bf16 (what the bottleneck MLP consumes)."""
-    bf = torch.bfloat16
+    from .. import gemm_select
+    gemm_select.enable()                                 # fixed hipBLASLt solution table for the four Linear GEMMs (dmvae_amd/tuned/)
     t = patch_embed_gemm(vit, x).float()
     t = torch.cat([vit.cls_token.expand(t.shape[0], -1, -1).float(), t], dim=1) + vit.pos_embed.float()
     t = t.contiguous()                                   # f32 residual stream [B, S, C]
