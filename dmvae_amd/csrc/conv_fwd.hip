@@ -247,6 +247,7 @@ int launch(const ConvArgs& a_in, hipStream_t st, int batch = 1) {
 }  // namespace dmvae_conv_fwd
 using namespace dmvae_conv_fwd;
 
+int dmvae_conv_thin_try(const void* x, const void* w, const void* bias, const void* residual, void* y, const dmvae_conv_desc* d, hipStream_t stream);  // conv_thin.hip
 int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void* residual, void* y, const dmvae_conv_desc* d,
                       hipStream_t stream, float* gnpart, int gn_groups, int* gn_tp);  // conv_pp.hip; returns 1 when it declines the shape
 int dmvae_gn_stats_from_quads(const float* part, float* stats, int n, int hw, int c, int groups, int tp, float eps, hipStream_t stream);  // groupnorm.hip
@@ -301,6 +302,10 @@ extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* b
   DMVAE_CHECK_ARG(d->act >= 0 && d->act <= 4 && (d->act != 3 || residual), "conv2d_nhwc_fwd: bad activation code %d", d->act);
   {
     const int r = dmvae_conv_pp_try(x, w, bias, residual, y, d, stream, nullptr, 0, nullptr);  // large shapes: the ping-pong kernel
+    if (r <= 0) return r;
+  }
+  {
+    const int r = dmvae_conv_thin_try(x, w, bias, residual, y, d, stream);  // 3x3 to four f32 output channels: the halo-tile kernel
     if (r <= 0) return r;
   }
   ConvArgs a;

@@ -55,6 +55,8 @@ def _attention(qkv, blk, rope, heads):
 @torch.no_grad()
 def forward_inference(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """x [B,C,H,W], t [B], y [B] -> velocity [B,C_out,H,W] in bf16 (what the stock modules return under autocast)."""
+    from .. import gemm_select
+    gemm_select.enable()             # fixed hipBLASLt solution table for the Linear GEMMs (dmvae_amd/tuned/)
     b, cin, hh, ww = x.shape
     ps, c, heads = model.patch_size, model.hidden_size, model.num_heads
     w = model.x_embedder.proj.weight
@@ -134,6 +136,8 @@ def forward_train(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> t
     """`forward` with gradients (the student's flow-matching turn, train_dmd.py:565-575) under the caller's autocast(bf16): embedders, adaLN Linears
     and the output Linear through stock autograd (per-sample or single GEMMs), every block as one `functional.DitBlockFn`, the final norm as
     `RmsnormModulateFn`.  Label dropout as in the module (`y_embedder(y, model.training)`)."""
+    from .. import gemm_select
+    gemm_select.enable()             # fixed hipBLASLt solution table for the Linear GEMMs (dmvae_amd/tuned/)
     from ..functional import DitBlockFn, RmsnormModulateFn
     b, cin, hh, ww = x.shape
     ps, c, heads = model.patch_size, model.hidden_size, model.num_heads

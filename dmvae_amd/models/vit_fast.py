@@ -78,6 +78,8 @@ def trainable_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
     (one GEMM over patches), class token and position embedding through stock autograd, every transformer block as one `VitBlockFn` on the f32
     residual stream, the final LayerNorm as `LayerNormBf16Fn`.  Same arithmetic as the module under autocast(bf16)."""
     from ..functional import LayerNormBf16Fn, VitBlockFn
+    from .. import gemm_select
+    gemm_select.enable()
     t = patch_embed_gemm(vit, x)
     t = torch.cat([vit.cls_token.expand(t.shape[0], -1, -1).float(), t.float()], dim=1) + vit.pos_embed.float()
     t = t.contiguous()
