@@ -201,9 +201,15 @@ __global__ __launch_bounds__(DMVAE_ATTN_THREADS) void attention_kernel(AttnArgs 
 #if __HIP_DEVICE_COMPILE__
   constexpr int KROW = DP == 64 ? 128 : 256;   // bytes per K row in LDS (8 or 16 chunks of 16 B, XOR-swizzled by key & 7)
   constexpr int KSTEPS = DP / 16, DB = DP / 32;
+  // V rows: DP = 64 -> 128 B (two 64-B segments, swizzled by (key >> 1) & 1: the four key rows a transpose-read pass touches then sit in four distinct 64-B bank
+  // slots of the 256-B LDS row); wider heads -> 256 B (four segments, swizzled by key & 3).  72 KiB per workgroup at DP = 64: TWO workgroups per CU -- with
+  // S = 257 a head has nine 32-query blocks for eight waves, so one wave works a second round while seven idle, and a second resident head fills those slots.
+  constexpr int VROW = DP == 64 ? 128 : 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ks = smem;                       // [288][KROW]
-  char* vs = smem + ATT_KEYS * KROW;     // [288][256 B] (channels 0..DP-1 used)
+  char* vs = smem + ATT_KEYS * KROW;     // [288][VROW]
+  auto vslot = [](int key, int c) { return VROW == 128 ? key * 128 + ((((c >> 2) ^ ((key >> 1) & 1))) << 6) + ((c & 3) << 4)
+                                                        : key * 256 + ((((c >> 2) ^ (key & 3))) << 6) + ((c & 3) << 4); };
   const int S = a.S, H = a.H;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(DMVAE_ATTN_THREADS) void attention_kernel(AttnArgs 
       if (live) kv = dmvae_norm_rope8(kv, rsqrtf(ss / (float)a.D + a.eps), a.kw, a.cosb, a.sinb, key, a.D, c * 8);
       if (c < DP / 8) {
         *reinterpret_cast<uint4*>(ks + key * KROW + ((c ^ (key & 7)) << 4)) = kv;
-        *reinterpret_cast<uint4*>(vs + key * 256 + ((((c >> 2) ^ (key & 3))) << 6) + ((c & 3) << 4)) = vv;
+        *reinterpret_cast<uint4*>(vs + vslot(key, c)) = vv;
       }
     }
   } else {
@@ -249,8 +255,8 @@ __global__ __launch_bounds__(DMVAE_ATTN_THREADS) void attention_kernel(AttnArgs 
       const int i = tid + it * NT, key = i / (DP / 8), c = i - key * (DP / 8);
       if (i < ATT_KEYS * (DP / 8)) {
         *reinterpret_cast<uint4*>(ks + key * KROW + ((c ^ (key & 7)) << 4)) = kv[it];
-        // V: channel chunk c (8 channels) -> 64-B segment c >> 2, swizzled by key & 3; 16-B slot c & 3 inside it
-        *reinterpret_cast<uint4*>(vs + key * 256 + ((((c >> 2) ^ (key & 3))) << 6) + ((c & 3) << 4)) = vv[it];
+        // V: channel chunk c (8 channels) -> 64-B segment c >> 2, swizzled per key (vslot); 16-B slot c & 3 inside it
+        *reinterpret_cast<uint4*>(vs + vslot(key, c)) = vv[it];
       }
     }
   }
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(DMVAE_ATTN_THREADS) void attention_kernel(AttnArgs 
 #pragma unroll
   for (int db = 0; db < DB; db++) {
     const int ch = db * 32 + 16 * g16 + 4 * qq;
-    voff[db] = (kg * 8 + rr) * 256 + ((((ch >> 5) ^ rr)) << 6) + (ch & 31) * 2;
+    voff[db] = (kg * 8 + rr) * VROW + ((((ch >> 5) ^ (VROW == 128 ? (rr >> 1) & 1 : rr))) << 6) + (ch & 31) * 2;
   }
   for (int qb = wave; qb * 32 < S; qb += NT / 64) {
     const int q = qb * 32 + ql;
@@ -341,8 +347,8 @@ __global__ __launch_bounds__(DMVAE_ATTN_THREADS) void attention_kernel(AttnArgs 
 #pragma unroll
         for (int db = 0; db < DB; db++) {
           union { bf16x8 v; s16x4 hlf[2]; } vf;
-          vf.hlf[0] = tr_read_v(vs + ksn * 4096 + voff[db]);
-          vf.hlf[1] = tr_read_v(vs + ksn * 4096 + voff[db] + 1024);
+          vf.hlf[0] = tr_read_v(vs + ksn * (16 * VROW) + voff[db]);
+          vf.hlf[1] = tr_read_v(vs + ksn * (16 * VROW) + voff[db] + 4 * VROW);
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.v, vf.v, o[db], 0, 0, 0);
         }
       }
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(DMVAE_ATTN_THREADS) void attention_kernel(AttnArgs 
 
 template <int DP, bool NR = false>
 static int launch_attention(const AttnArgs& a, int batch, hipStream_t stream) {
-  constexpr int lds = ATT_KEYS * (DP == 64 ? 128 : 256) + ATT_KEYS * 256;
+  constexpr int lds = ATT_KEYS * (DP == 64 ? 128 : 256) + ATT_KEYS * (DP == 64 ? 128 : 256);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DP, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
