@@ -28,7 +28,7 @@ def enable() -> bool:
             tun.write_file_on_exit(False)
         else:                                  # this PyTorch writes its table at exit unconditionally: point it away from the working directory
             import tempfile
-            tun.set_filename(os.path.join(tempfile.gettempdir(), "dmvae_tunableop_unused.csv"))
+            tun.set_filename(os.path.join(tempfile.gettempdir(), "dmvae_tunableop_unused_%d.csv" % os.getpid()))     # one per process (rank)
         ok = False
         for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "*.csv"))):
             ok = bool(tun.read_file(f)) or ok
