@@ -37,6 +37,8 @@ SIGNATURES = {
     "dmvae_subpixel_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dmvae_subpixel_weight_fold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dmvae_colsum_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_int, c_void_p]),
+    "dmvae_conv_out_wgrad_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "dmvae_conv_out_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_sumpool2x2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_maxpool2x2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_maxpool2x2_relu_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

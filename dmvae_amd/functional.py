@@ -439,7 +439,12 @@ class NormConvOutFn(torch.autograd.Function):
         cout = cw.shape[0]
         dyf = _c(dy.float())
         dyp = ops.nchw_to_nhwc_bf16(dyf, c_pad=32)                 # the input-gradient conv's reduction dimension: 32-channel K steps
-        if cout <= 8 and a.numel() // a.shape[-1] >= 16384 and os.environ.get("DMVAE_CONVOUT_IM2COL", "1") != "0" and not parity.on():
+        if os.environ.get("DMVAE_CONVOUT_THIN", "1") != "0" and not parity.on() and ops.conv_out_wgrad_supported(a.shape[0], a.shape[1], a.shape[2], a.shape[3], cout):
+            # three output channels: `a` is read once against three x-shifted planar copies of the gradient (csrc/wgrad_thin.hip: 570 -> ~150 us at B = 32);
+            # the bias gradient is the plain sum of the gradient
+            dwp = ops.conv_out_wgrad(dyf, a)
+            dbp = dyf.sum(dim=(0, 2, 3))
+        elif cout <= 8 and a.numel() // a.shape[-1] >= 16384 and os.environ.get("DMVAE_CONVOUT_IM2COL", "1") != "0" and not parity.on():
             # With 3 output channels a 128-row weight-gradient tile is 98 % padding (1.4 ms at B = 32).  Instead: im2col of the GRADIENT
             # (8 padded channels x 9 taps = 72 columns, col[q][t*8+co] = dy[q + off(t)][co]) and ONE 1x1 weight-gradient GEMM against `a`:
             #   G[(t, co)][ci] = sum_q dy[q + off(t)][co] * a[q][ci]  =  dW[co][ci][8 - t]   (the tap seen from the other side),

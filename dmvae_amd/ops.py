@@ -269,6 +269,29 @@ def conv2d_nhwc_wgrad(dy: torch.Tensor, a: torch.Tensor, ks: int, upsample: bool
     return dw, db
 
 
+def conv_out_wgrad_supported(n: int, h: int, w: int, cin: int, cout: int) -> bool:
+    return _lib.lib().dmvae_conv_out_wgrad_workspace(n, h, w, cin, cout) > 0
+
+
+def conv_out_wgrad(dy_nchw: torch.Tensor, a: torch.Tensor, dw_out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """dW [cout,128,3,3] f32 of a 3x3 stride-1 conv with <= 4 output channels from its NCHW f32 output gradient [N,cout,H,W] and its NHWC bf16 input
+    a [N,H,W,128] (the decoder's conv_out, flux_ae.py:237,274; csrc/wgrad_thin.hip: `a` is read once)."""
+    dy_nchw = _req(dy_nchw, f32, "dy")
+    a = _req(a, bf16, "a")
+    n, h, w_, cin = a.shape
+    cout = dy_nchw.shape[1]
+    assert dy_nchw.shape == (n, cout, h, w_), (dy_nchw.shape, a.shape)
+    L = _lib.lib()
+    wsb = L.dmvae_conv_out_wgrad_workspace(n, h, w_, cin, cout)
+    if wsb == 0:
+        raise ValueError(f"conv_out_wgrad: unsupported shape a={tuple(a.shape)} cout={cout}")
+    ws = workspace(wsb, a.device)
+    dw = dw_out if dw_out is not None else torch.empty(cout, cin, 3, 3, dtype=f32, device=a.device)
+    check(L.dmvae_conv_out_wgrad(dy_nchw.data_ptr(), a.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w_, cin, cout, int(accumulate), _stream()),
+          "conv_out_wgrad")
+    return dw
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
             act: int = ACT_NONE, out_f32: bool = False) -> torch.Tensor:
     """C[..., m, n] = act(A[..., m, k] @ B[..., n, k]^T + bias + residual).  A/B bf16; a 2-D operand is shared by the batch."""

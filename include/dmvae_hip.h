@@ -81,6 +81,14 @@ int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, void* dbias
                             size_t workspace_bytes, const dmvae_conv_desc* d, int accumulate,
                             dmvae_stream_t stream);
 
+/* Weight gradient of a 3x3 stride-1 conv with <= 4 output channels and Cin = 128 (the decoder's conv_out, models/flux_ae.py:237,274) straight from the
+ * image gradient as autograd hands it over: dy [n][cout][h][w] f32 (NCHW), a [n][h][w][128] bf16 (the conv's input), dw [cout][128][3][3] f32
+ * ((+)= with accumulate).  `a` is read once (csrc/wgrad_thin.hip); w % 32 == 0.  workspace >= dmvae_conv_out_wgrad_workspace(...) bytes (0: unsupported shape).
+ * Replaces autograd's conv weight gradient at that site (the bias gradient is the plain sum of dy over n, h, w). */
+size_t dmvae_conv_out_wgrad_workspace(int n, int h, int w, int cin, int cout);
+int dmvae_conv_out_wgrad(const void* dy, const void* a, void* dw, void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout,
+                         int accumulate, dmvae_stream_t stream);
+
 /* ---- GroupNorm(+swish) on NHWC bf16 (HBM-bound) --------------------------------------------- */
 
 /* Workspace bytes needed by groupnorm_stats / groupnorm_bwd for x: [n, hw, c]; 0 if unsupported

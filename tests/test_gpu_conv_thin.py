@@ -40,3 +40,27 @@ def test_conv_thin_matches_fp64(case):
     _check(y[..., :3], ref, "conv_thin")
     assert torch.count_nonzero(y[..., 3]) == 0                     # the padding row: zero weights, zero bias
     assert torch.equal(y, ops.conv2d_nhwc(x, wp, bp, None, ks=3, act=0, out_f32=True))
+
+
+#          N, H,  W,  cout
+WCASES = [(2, 4, 32, 3), (1, 9, 64, 3), (3, 16, 96, 4), (2, 256, 256, 3), (1, 5, 32, 1)]
+
+
+@pytest.mark.parametrize("case", WCASES, ids=["%dx%dx%d_co%d" % c for c in WCASES])
+def test_conv_out_wgrad_matches_fp64(case):
+    """csrc/wgrad_thin.hip: dW of the decoder's conv_out from the NCHW f32 image gradient and the NHWC bf16 conv input (flux_ae.py:237,274)."""
+    from dmvae_amd import ops
+    from test_gpu_conv_c2_shapes import wgrad3x3_ref64
+    n, h, w_, cout = case
+    g = torch.Generator().manual_seed(11 + h + w_)
+    a = torch.randn(n, h, w_, 128, generator=g).to(DEV).to(BF)
+    dy = torch.randn(n, cout, h, w_, generator=g).to(DEV)
+    assert ops.conv_out_wgrad_supported(n, h, w_, 128, cout)
+    dw = ops.conv_out_wgrad(dy, a)
+    ref, _ = wgrad3x3_ref64(dy.to(BF).permute(0, 2, 3, 1).contiguous(), a)          # the kernel rounds the gradient to bf16, like the conv path it replaces
+    _check(dw, ref, "conv_out_wgrad")
+    assert torch.equal(dw, ops.conv_out_wgrad(dy, a))                               # fixed-order reduction
+    acc = torch.full_like(dw, 0.5)
+    ops.conv_out_wgrad(dy, a, dw_out=acc, accumulate=True)
+    assert torch.allclose(acc, dw + 0.5, rtol=0, atol=1e-6 * dw.abs().max().item() + 1e-7)
+    assert not ops.conv_out_wgrad_supported(n, h, w_ + 1, 128, cout) and not ops.conv_out_wgrad_supported(n, h, w_, 64, cout)

@@ -29,7 +29,7 @@ for m in re.finditer(r'^(_Z\S+):.*\n', txt, re.M):
         key = 'Header=' + hd.lstrip('.L')
         loop = [b for b in blocks if b[0] == hd or key in b[1]]
         nm = sum('v_mfma' in x for b in loop for x in b[2])
-        if nm < 8: continue
+        if nm < 4: continue
         print(name[:110], f'loop {hd}: {nm} mfma, {sum(len(b[2]) for b in loop)} lines in {len(loop)} blocks')
         for b in loop:
             seq = []
