@@ -82,7 +82,7 @@ __device__ __forceinline__ s16x4 tr_read(unsigned lds_addr) {
 // staged once as the 34 pixels x0 - 1 .. x0 + 32 of source row y + ky - 1 (36 LDS rows, 9 pieces) instead of three shifted copies of 32 (24 pieces): a tap's
 // fragment is the same transpose read one pixel row further on.  Per K tile the block then stages 17 KiB instead of 32 -- the 128 x 384 tile runs 24 MFMAs per
 // wave between barriers against the 256 x 256 tile's 32 with the same four DMA issues per wave, and its LOAD interval, not its COMPUTE interval, set the pace.
-template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false>
+template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false, bool UPS = false>
 __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int TM = GA * 128, TN = GB * 128;
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   constexpr int NP = NPA + NPB;
   static_assert(WM * WN == 8, "8 waves");
   static_assert(!HALO || (GB == 3 && !S2), "HALO: three taps of one kernel row");
+  static_assert(!UPS || (!S2 && !HALO), "UPS: nearest-x2 source walk of the plain 3x3 form");   // compile-time: the run-time test put two exec-masked blocks into every K tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   // ---- descriptors: dy is linear in the pixel index; the activation base is shifted so every tap offset is >= 0 -------
   const unsigned dybytes = (unsigned)a.M * a.Cout * 2u;
   const unsigned abytes = (unsigned)a.N * a.Hi * a.Wi * a.Cin * 2u;
-  const unsigned shift = (S2 || (!a.ups && a.ks == 3)) ? (unsigned)(a.Wi + 1) * a.Cin * 2u : 0u;
+  const unsigned shift = (S2 || (!UPS && a.ks == 3)) ? (unsigned)(a.Wi + 1) * a.Cin * 2u : 0u;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, dybytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB =
       __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.a) - shift), 0, abytes + shift, 0x00020000);
@@ -163,9 +164,9 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     const bool ok = g < a.ngroups;
     kyB[p] = S2 ? tap >> 2 : (a.ks == 3 ? uni(tap / 3) : 1);
     kxB[p] = S2 ? tap & 3 : (a.ks == 3 ? tap - (tap / 3) * 3 : 1);
-    tapoB[p] = (S2 || (!a.ups && a.ks == 3)) ? (unsigned)(kyB[p] * a.Wi + kxB[p]) * a.Cin * 2u : 0u;
+    tapoB[p] = (S2 || (!UPS && a.ks == 3)) ? (unsigned)(kyB[p] * a.Wi + kxB[p]) * a.Cin * 2u : 0u;
     rowB[p] = row;
-    const unsigned v = S2 ? (unsigned)(2 * row * a.Cin + ci) * 2u : (a.ups ? (unsigned)ci * 2u : (unsigned)(row * a.Cin + ci) * 2u);
+    const unsigned v = S2 ? (unsigned)(2 * row * a.Cin + ci) * 2u : (UPS ? (unsigned)ci * 2u : (unsigned)(row * a.Cin + ci) * 2u);
     voffB[p] = ok ? v : SENT;
     voffBL[p] = (ok && row != 0) ? v : SENT;
     voffBR[p] = (ok && row != 31) ? v : SENT;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
       unsigned so;
       if constexpr (S2) {
         so = (unsigned)((pn * a.Hi + 2 * py) * a.Wi + 2 * px0) * a.Cin * 2u + tapoB[p];
-      } else if (a.ups) {
+      } else if constexpr (UPS) {
         const int xx = px0 + rowB[p] + kxB[p] - 1;  // masked lanes never use it
         v = v == SENT ? SENT : v + (unsigned)(xx >> 1) * a.Cin * 2u;
         so = (unsigned)((pn * a.Hi + (yy >> 1)) * a.Wi) * a.Cin * 2u;
@@ -394,15 +395,15 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #endif
 }
 
-template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false>
+template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false, bool UPS = false>
 int launch(const Args& a, int splits, hipStream_t st) {
   constexpr int lds = (HALO ? DMVAE_WG_HALO_NBUF : DMVAE_WG_NBUF) * (GA * 32 + (HALO ? 36 : GB * 32)) * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_kernel<GA, GB, WM, WN, S2, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_kernel<GA, GB, WM, WN, S2, HALO, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_pp_kernel<GA, GB, WM, WN, S2, HALO>), dim3((unsigned)(splits * a.mtiles * a.ntiles)), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((wgrad_pp_kernel<GA, GB, WM, WN, S2, HALO, UPS>), dim3((unsigned)(splits * a.mtiles * a.ntiles)), dim3(512), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -475,11 +476,13 @@ int dmvae_wgrad_pp_launch(const void* dy, const void* act, float* slab, float* b
   a.ngroups = d->ks * d->ks * a.gpt;
   if (cfg == 0) {
     a.mtiles = (d->cout + 255) / 256; a.ntiles = (a.ngroups + 1) / 2;
+    if (a.ups) return launch<2, 2, 2, 4, false, false, true>(a, splits, stream);
     return s2 ? launch<2, 2, 2, 4, true>(a, splits, stream) : launch<2, 2, 2, 4>(a, splits, stream);
   }
   a.mtiles = d->cout / 128; a.ntiles = (a.ngroups + 2) / 3;
   // 3x3 stride 1: the halo form (three taps of one kernel row per block; ntiles = 3 * gpt either way)
   static const bool halo = [] { const char* e = getenv("DMVAE_WGRAD_PP_HALO"); return e ? atoi(e) != 0 : true; }();
   if (halo && !s2 && d->ks == 3 && !a.ups) return launch<1, 3, 2, 4, false, true>(a, splits, stream);
+  if (a.ups) return launch<1, 3, 2, 4, false, false, true>(a, splits, stream);
   return s2 ? launch<1, 3, 2, 4, true>(a, splits, stream) : launch<1, 3, 2, 4>(a, splits, stream);
 }
