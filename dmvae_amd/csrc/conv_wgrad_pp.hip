@@ -82,19 +82,26 @@ __device__ __forceinline__ s16x4 tr_read(unsigned lds_addr) {
 // staged once as the 34 pixels x0 - 1 .. x0 + 32 of source row y + ky - 1 (36 LDS rows, 9 pieces) instead of three shifted copies of 32 (24 pieces): a tap's
 // fragment is the same transpose read one pixel row further on.  Per K tile the block then stages 17 KiB instead of 32 -- the 128 x 384 tile runs 24 MFMAs per
 // wave between barriers against the 256 x 256 tile's 32 with the same four DMA issues per wave, and its LOAD interval, not its COMPUTE interval, set the pace.
-template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false, bool UPS = false>
+// KP = 64 (HALO only): a K tile is 64 pixels -- two 32-pixel halves of the dy operand and one 66-pixel halo tile (68 LDS rows, 17 pieces); 48 MFMAs per wave between
+// barriers instead of 24 against 40 fragment reads and 4-5 DMA issues: the 24-MFMA COMPUTE interval (384 cycles) sat under a ~600-cycle LOAD interval.
+template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false, bool UPS = false, int KP = 32>
 __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int TM = GA * 128, TN = GB * 128;
   constexpr int BM = TM / WM / 16, BN = TN / WN / 16;  // 16 x 16 output blocks per wave
   constexpr int SUB = 32 * 256;  // bytes of one [32 px][128 ch] sub-tile
-  constexpr int BSZ = HALO ? 36 * 256 : GB * SUB;
-  constexpr int SLOT = GA * SUB + BSZ;
-  constexpr int NBUF = HALO ? DMVAE_WG_HALO_NBUF : DMVAE_WG_NBUF, PF = NBUF - 1;
-  constexpr int NPA = GA, NPB = HALO ? 2 : GB;  // 1-KiB pieces per wave per K tile (8 pieces per sub-tile, 8 waves); HALO: 9 pieces, the ninth is wave 7's second
+  constexpr int KH = KP / 32;    // 32-pixel halves per K tile
+  constexpr int HROWS = KP + 4;  // HALO: LDS rows of the halo tile (KP + 2 pixels, padded to whole 4-row pieces)
+  constexpr int BSZ = HALO ? HROWS * 256 : GB * SUB;
+  constexpr int ASZ = GA * KH * SUB;
+  constexpr int SLOT = ASZ + BSZ;
+  constexpr int NBUF = HALO ? (KH == 2 ? 4 : DMVAE_WG_HALO_NBUF) : DMVAE_WG_NBUF, PF = NBUF - 1;
+  constexpr int NQ = HROWS / 4, FP = (NQ - 1) / 8;   // HALO: pieces of the halo tile; FP per wave + the last one, which is wave 7's
+  constexpr int NPA = GA * KH, NPB = HALO ? FP + 1 : GB;  // 1-KiB pieces per wave per K tile (8 pieces per sub-tile, 8 waves)
   constexpr int NP = NPA + NPB;
   static_assert(WM * WN == 8, "8 waves");
   static_assert(!HALO || (GB == 3 && !S2), "HALO: three taps of one kernel row");
+  static_assert(KP == 32 || (KP == 64 && HALO && GA == 1), "64-pixel K tiles: the halo form only");
   static_assert(!UPS || (!S2 && !HALO), "UPS: nearest-x2 source walk of the plain 3x3 form");   // compile-time: the run-time test put two exec-masked blocks into every K tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   const int g0 = (tile - mt * a.ntiles) * GB;  // first column group of this block
   const int k0 = split * a.kchunk;
   const int k1 = min(k0 + a.kchunk, a.M);
-  const int nK = (k1 - k0) >> 5;
+  const int nK = (k1 - k0) / KP;
 
   // ---- descriptors: dy is linear in the pixel index; the activation base is shifted so every tap offset is >= 0 -------
   const unsigned dybytes = (unsigned)a.M * a.Cout * 2u;
@@ -132,8 +139,9 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     const int pb = wave * NPA + p;
     const int sub = pb >> 3, row = (pb & 7) * 4 + (lane >> 4);
     const int clog = ((((cphys >> 1) ^ (((row & 3) << 1) | ((row >> 3) & 1))) << 1) | (cphys & 1)) * 8;
-    const int co = co0 + sub * 128 + clog;
-    voffA[p] = co < a.Cout ? (unsigned)(row * a.Cout + co) * 2u : SENT;
+    // KH == 1: sub-tile = 128-channel group of the block's couts; KH == 2 (GA == 1): sub-tile = 32-pixel half of the K tile
+    const int co = co0 + (KH == 2 ? 0 : sub * 128) + clog;
+    voffA[p] = co < a.Cout ? (unsigned)(((KH == 2 ? sub * 32 : 0) + row) * a.Cout + co) * 2u : SENT;
   }
   unsigned voffB[NPB], voffBL[NPB], voffBR[NPB];  // plain / first pixel of a row masked / last pixel masked
   int kyB[NPB], kxB[NPB];                           // tap of the piece's column group (wave-uniform)
@@ -144,16 +152,16 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #pragma unroll
   for (int p = 0; p < NPB; p++) {
     if constexpr (HALO) {
-      const int q = p == 0 ? wave : 8;                 // piece: LDS rows 4 q .. 4 q + 3 <-> source pixels x0 - 1 + row
+      const int q = p < FP ? wave + 8 * p : NQ - 1;     // piece: LDS rows 4 q .. 4 q + 3 <-> source pixels x0 - 1 + row
       const int row = q * 4 + (lane >> 4);
       const int clog = ((((cphys >> 1) ^ (((row & 3) << 1) | ((row >> 3) & 1))) << 1) | (cphys & 1)) * 8;
-      const bool ok = row < 34 && (p == 0 || wave == 7);
+      const bool ok = row < KP + 2 && (p < FP || wave == 7);
       const unsigned v = (unsigned)(row * a.Cin + hhalf * 128 + clog) * 2u;
       kyB[p] = hky; kxB[p] = 0; rowB[p] = row;
       tapoB[p] = (unsigned)(hky * a.Wi) * a.Cin * 2u;
       voffB[p] = ok ? v : SENT;
       voffBL[p] = (ok && row != 0) ? v : SENT;
-      voffBR[p] = (ok && row != 33) ? v : SENT;
+      voffBR[p] = (ok && row != KP + 1) ? v : SENT;
       continue;
     }
     const int pb = wave * NPB + p;
@@ -188,8 +196,8 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     const int sub = ch >> 7, c = ch & 127;
     if constexpr (HALO) {  // tap kx = sub: pixel rows 8 G + rr + kx and + 4 of the halo tile (the + 4 may cross an 8-row boundary: its own swizzle key)
       const int r0 = G * 8 + rr + sub, r1 = r0 + 4;
-      boff[j] = GA * SUB + r0 * 256 + ((((c >> 4) & 7) ^ (((r0 & 3) << 1) | ((r0 >> 3) & 1))) << 5) + (c & 15) * 2;
-      boff1[j] = GA * SUB + r1 * 256 + ((((c >> 4) & 7) ^ (((r1 & 3) << 1) | ((r1 >> 3) & 1))) << 5) + (c & 15) * 2;
+      boff[j] = ASZ + r0 * 256 + ((((c >> 4) & 7) ^ (((r0 & 3) << 1) | ((r0 >> 3) & 1))) << 5) + (c & 15) * 2;
+      boff1[j] = ASZ + r1 * 256 + ((((c >> 4) & 7) ^ (((r1 & 3) << 1) | ((r1 >> 3) & 1))) << 5) + (c & 15) * 2;
     } else {
       boff[j] = GA * SUB + sub * SUB + (G * 8 + rr) * 256 + ((((c >> 4) & 7) ^ fkey) << 5) + (c & 15) * 2;
     }
@@ -245,12 +253,12 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
       if constexpr (HALO) {
-        if (p == 1 && wave != 7) continue;  // wave-uniform: the ninth piece (halo rows 32 .. 35) is wave 7's
+        if (p == FP && wave != 7) continue;  // wave-uniform: the last piece (halo rows KP .. KP + 3) is wave 7's
         const int yy = py + kyB[p] - 1;
         const bool yok = (unsigned)yy < (unsigned)a.Ho;
-        const unsigned v = p == 0 ? (px0 == 0 ? voffBL[p] : voffB[p]) : (px0 + 32 == a.Wo ? voffBR[p] : voffB[p]);
+        const unsigned v = p < FP ? (px0 == 0 ? voffBL[p] : voffB[p]) : (px0 + KP == a.Wo ? voffBR[p] : voffB[p]);
         const unsigned so = (unsigned)pt * a.Cin * 2u + tapoB[p];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + GA * SUB + (p == 0 ? wave : 8) * 1024), 16, (live && yok) ? v : SENT, yok ? so : 0u, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + ASZ + (p < FP ? wave + 8 * p : NQ - 1) * 1024), 16, (live && yok) ? v : SENT, yok ? so : 0u, 0, 0);
         continue;
       }
       const int pb = wave * NPB + p;
@@ -268,11 +276,11 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
       } else {
         so = (unsigned)pt * a.Cin * 2u + tapoB[p];
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + GA * SUB + pb * 1024), 16, (live && yok) ? v : SENT, yok ? so : 0u, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + ASZ + pb * 1024), 16, (live && yok) ? v : SENT, yok ? so : 0u, 0, 0);
     }
     it++;
-    pt += 32;
-    px0 += 32;
+    pt += KP;
+    px0 += KP;
     if (px0 == a.Wo) {
       px0 = 0;
       if (++py == a.Ho) { py = 0; pn++; }
@@ -297,10 +305,12 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   if (grp == 1) __builtin_amdgcn_s_barrier();
 
   union Frag { bf16x8 v; s16x4 h[2]; };
-  Frag af[BM], bfr[BN];
+  Frag af[KH][BM], bfr[KH][BN];
 #if DMVAE_WG_EXP & 2
-  for (int i = 0; i < BM; i++) af[i].v = ones;
-  for (int j = 0; j < BN; j++) bfr[j].v = ones;
+  for (int h = 0; h < KH; h++) {
+    for (int i = 0; i < BM; i++) af[h][i].v = ones;
+    for (int j = 0; j < BN; j++) bfr[h][j].v = ones;
+  }
 #endif
   int slot_rd = 0, slot_wr = PF * SLOT;
 #pragma unroll 1
@@ -312,13 +322,25 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #if !(DMVAE_WG_EXP & 2)   // timing experiments (tools/probes/build_variant.sh): 1 = no DMA issue in the loop, 2 = no fragment reads, 4 = no barriers
 #pragma unroll
     for (int j = 0; j < BN; j++) {
-      bfr[j].h[0] = tr_read<0>(sb + boff[j]);
-      bfr[j].h[1] = HALO ? tr_read<0>(sb + boff1[HALO ? j : 0]) : tr_read<1024>(sb + boff[j]);
+      bfr[0][j].h[0] = tr_read<0>(sb + boff[j]);
+      bfr[0][j].h[1] = HALO ? tr_read<0>(sb + boff1[HALO ? j : 0]) : tr_read<1024>(sb + boff[j]);
     }
 #pragma unroll
     for (int i = 0; i < BM; i++) {
-      af[i].h[0] = tr_read<0>(sb + aoff[i]);
-      af[i].h[1] = tr_read<1024>(sb + aoff[i]);
+      af[0][i].h[0] = tr_read<0>(sb + aoff[i]);
+      af[0][i].h[1] = tr_read<1024>(sb + aoff[i]);
+    }
+    if constexpr (KH == 2) {  // second 32-pixel half: 32 halo rows / one dy sub-tile further on (the swizzle key repeats every 16 rows)
+#pragma unroll
+      for (int j = 0; j < BN; j++) {
+        bfr[KH - 1][j].h[0] = tr_read<8192>(sb + boff[j]);
+        bfr[KH - 1][j].h[1] = tr_read<8192>(sb + boff1[HALO ? j : 0]);
+      }
+#pragma unroll
+      for (int i = 0; i < BM; i++) {
+        af[KH - 1][i].h[0] = tr_read<SUB>(sb + aoff[i]);
+        af[KH - 1][i].h[1] = tr_read<SUB + 1024>(sb + aoff[i]);
+      }
     }
 #endif
 #if !(DMVAE_WG_EXP & (1 | 8 | 16))
@@ -337,22 +359,26 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
+    for (int h = 0; h < KH; h++)
+#pragma unroll
     for (int i = 0; i < BM; i++)
 #pragma unroll
       for (int j = 0; j < BN; j++) {
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[i].v), "v"(bfr[j].v));
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[h][i].v), "v"(bfr[h][j].v));
 #if DMVAE_WG_EXP & 16
-        if (i == 0 && j == 3) issue((slot_wr == 0 ? NBUF * SLOT : slot_wr) - SLOT);
+        if (h == 0 && i == 0 && j == 3) issue((slot_wr == 0 ? NBUF * SLOT : slot_wr) - SLOT);
 #endif
       }
     const bool bias_now = do_bias && bias_cnt == 0;
     bias_cnt = bias_cnt == 0 ? a.ntiles - 1 : bias_cnt - 1;
     if (bias_now) {
 #pragma unroll
+      for (int h = 0; h < KH; h++)
+#pragma unroll
       for (int i = 0; i < BM; i++)
         if ((i >> 1) == wn)  // accumulator pinned to VGPRs ("+v"): the AGPRs of the main accumulators are left exactly as they are
           // s_nop: the compiler rematerialises `ones` with v_mov right before the statement and pads nothing for inline asm
-          asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accb[i & 1]) : "v"(af[i].v), "v"(ones));
+          asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accb[i & 1]) : "v"(af[h][i].v), "v"(ones));
     }
 #if DMVAE_PP_PRIO_MODE == 0
     __builtin_amdgcn_s_setprio(0);
@@ -395,20 +421,27 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #endif
 }
 
-template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false, bool UPS = false>
+template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false, bool UPS = false, int KP = 32>
 int launch(const Args& a, int splits, hipStream_t st) {
-  constexpr int lds = (HALO ? DMVAE_WG_HALO_NBUF : DMVAE_WG_NBUF) * (GA * 32 + (HALO ? 36 : GB * 32)) * 256;
+  constexpr int lds = (HALO ? (KP == 64 ? 4 : DMVAE_WG_HALO_NBUF) : DMVAE_WG_NBUF) * (GA * KP + (HALO ? KP + 4 : GB * 32)) * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_kernel<GA, GB, WM, WN, S2, HALO, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_kernel<GA, GB, WM, WN, S2, HALO, UPS, KP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_pp_kernel<GA, GB, WM, WN, S2, HALO, UPS>), dim3((unsigned)(splits * a.mtiles * a.ntiles)), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((wgrad_pp_kernel<GA, GB, WM, WN, S2, HALO, UPS, KP>), dim3((unsigned)(splits * a.mtiles * a.ntiles)), dim3(512), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
 
 }  // namespace dmvae_wgrad_pp
+
+// The 128 x 384 tile's halo form with 64-pixel K tiles: 3x3 stride 1, output rows of a multiple of 64 pixels (a K tile never straddles a row).
+static bool wgrad_pp_halo_on() { static const bool v = [] { const char* e = getenv("DMVAE_WGRAD_PP_HALO"); return e ? atoi(e) != 0 : true; }(); return v; }
+static bool wgrad_pp_k64(const dmvae_conv_desc* d, int cfg) {
+  static const bool on = [] { const char* e = getenv("DMVAE_WGRAD_PP_K64"); return e ? atoi(e) != 0 : true; }();
+  return on && wgrad_pp_halo_on() && cfg == 1 && d->ks == 3 && d->stride <= 1 && !d->upsample && !d->transposed && d->w % 64 == 0;
+}
 
 // Plan shared by the workspace query and the launch: returns 0 when the ping-pong kernel does not cover the shape.
 int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_out, int* cfg_out) {
@@ -454,7 +487,8 @@ int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_o
     const double eff = (double)ktiles * tiles / ((double)rounds * 256 * kt) / (1.0 + 24.0 / kt);  // useful / provisioned, with a fixed per-block cost
     if (eff > best_eff * 1.0001) { best_eff = eff; best = s; }
   }
-  const int kt = (ktiles + best - 1) / best;
+  int kt = (ktiles + best - 1) / best;
+  if (wgrad_pp_k64(d, cfg)) kt = (kt + 1) & ~1;   // whole 64-pixel K tiles per split
   *kchunk_out = kt * 32;
   *splits_out = (ktiles + kt - 1) / kt;
   *cfg_out = cfg;
@@ -481,8 +515,8 @@ int dmvae_wgrad_pp_launch(const void* dy, const void* act, float* slab, float* b
   }
   a.mtiles = d->cout / 128; a.ntiles = (a.ngroups + 2) / 3;
   // 3x3 stride 1: the halo form (three taps of one kernel row per block; ntiles = 3 * gpt either way)
-  static const bool halo = [] { const char* e = getenv("DMVAE_WGRAD_PP_HALO"); return e ? atoi(e) != 0 : true; }();
-  if (halo && !s2 && d->ks == 3 && !a.ups) return launch<1, 3, 2, 4, false, true>(a, splits, stream);
+  if (wgrad_pp_k64(d, cfg) && kchunk % 64 == 0) return launch<1, 3, 2, 4, false, true, false, 64>(a, splits, stream);
+  if (wgrad_pp_halo_on() && !s2 && d->ks == 3 && !a.ups) return launch<1, 3, 2, 4, false, true>(a, splits, stream);
   if (a.ups) return launch<1, 3, 2, 4, false, false, true>(a, splits, stream);
   return s2 ? launch<1, 3, 2, 4, true>(a, splits, stream) : launch<1, 3, 2, 4>(a, splits, stream);
 }

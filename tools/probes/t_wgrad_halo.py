@@ -44,6 +44,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "bench":
         bench(*cfg)
 else:
     bad = 0
-    for cfg in [(4, 32, 32, 128, 128), (2, 64, 64, 256, 128), (1, 32, 64, 128, 128, 1), (2, 64, 32, 384, 128), (1, 64, 64, 128, 384), (1, 128, 128, 128, 128), (5, 32, 32, 256, 128)]:
+    for cfg in [(4, 32, 32, 128, 128), (2, 64, 64, 256, 128), (1, 8, 64, 128, 128), (3, 5, 128, 128, 128, 1), (1, 32, 192, 128, 256), (2, 16, 256, 256, 128), (1, 32, 64, 128, 128, 1), (2, 64, 32, 384, 128), (1, 64, 64, 128, 384), (1, 128, 128, 128, 128), (5, 32, 32, 256, 128)]:
         bad += run(*cfg) > 2e-5
     print("BAD", bad)
