@@ -29,7 +29,9 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp), not an IEEE division: `1.0f / y` compiles to v_div_scale x2 + v_rcp + four FMAs + v_div_fmas + v_div_fixup -- ten instructions per element in
+// kernels (GroupNorm backward: 23 of ~37 VALU instructions per element were the two divisions' sequences) whose results are rounded to bf16 anyway.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // XCD-aware block order (MI355X: 8 XCDs with private L2s; the dispatcher places flat block b on XCD b % 8).
 // Maps the flat dispatch index to a logical work index such that each XCD walks ONE contiguous range of logical
