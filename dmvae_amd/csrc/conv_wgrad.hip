@@ -17,6 +17,7 @@
 // order (deterministic, no float atomics) into the PyTorch weight layout [cout][cin][kh][kw].
 #include "common.h"
 #include "dmvae_hip.h"
+#include <cstdlib>
 
 namespace dmvae_conv_wgrad {
 
@@ -229,6 +230,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// T == 1 (Linear layers, 1x1 convs): the slab layout [cout][1][cin] IS the output layout, so the reduce is a flat sum of `splits` vectors -- 16 B per lane, all lanes
+// busy.  The tap-transposing kernel above keeps 16 of its 256 threads loading when T = 1 (one 256-B row per block and split: 40 us per call on LightningDiT's
+// Linear weight gradients, 1.6 TB/s).  Same order of additions (split 0, 1, ...), same bias blocks behind the slab blocks.
+__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ slab, float* __restrict__ out, int splits, size_t total4, int accumulate,
+                                                                int rb, int Cout, const float* __restrict__ bpart, float* __restrict__ dbias, int nparts) {
+  if ((int)blockIdx.x >= rb) {
+    __shared__ float sh[4][64];
+    const int c = ((int)blockIdx.x - rb) * 64 + (threadIdx.x & 63), kl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < Cout)
+      for (int k = kl; k < nparts; k += 4) s += bpart[(size_t)k * Cout + c];
+    sh[kl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (kl == 0 && c < Cout) {
+      const float t = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+      dbias[c] = accumulate ? dbias[c] + t : t;
+    }
+    return;
+  }
+  const f32x4* src = reinterpret_cast<const f32x4*>(slab);
+  f32x4* dst = reinterpret_cast<f32x4*>(out);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)rb * 256) {
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < splits; k++) sum += src[(size_t)k * total4 + i];
+    dst[i] = accumulate ? dst[i] + sum : sum;
+  }
+}
+
 // db[c] (+)= sum_p dy[p][c].  HBM-bound: 16-B loads (8 channels per lane), tp channel-lanes x (256/tp) pixel rows per
 // block iteration, f32 accumulation, LDS block reduce, fixed-order second stage (deterministic).
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ dy, float* __restrict__ part, int M, int C,
@@ -364,10 +394,18 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
     DMVAE_CHECK_LAUNCH();
   }
   const size_t total = (size_t)w.Cout * T * w.Cin;
-  const int rb = w.Cout * ((w.Cin + 63) / 64);   // one block per (cout, 64 input channels)
   const int nb = bias_fused ? (w.Cout + 63) / 64 : 0;  // the ping-pong kernel left per-split column sums of dy behind the weight slabs
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb + nb), dim3(256), 0, stream, w.slab, (float*)dw, splits, w.Cout, T, w.Cin, accumulate, rb,
-                     w.slab + (size_t)splits * total, (float*)dbias, splits * pp_ntiles);
+  static const bool flat_ok = [] { const char* e = getenv("DMVAE_WGRAD_REDUCE_FLAT"); return e ? atoi(e) != 0 : true; }();
+  if (flat_ok && T == 1 && total % 4 == 0) {
+    const size_t total4 = total / 4;
+    const int rbf = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(rbf + nb), dim3(256), 0, stream, w.slab, (float*)dw, splits, total4, accumulate, rbf, w.Cout,
+                       w.slab + (size_t)splits * total, (float*)dbias, splits * pp_ntiles);
+  } else {
+    const int rb = w.Cout * ((w.Cin + 63) / 64);   // one block per (cout, 64 input channels)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb + nb), dim3(256), 0, stream, w.slab, (float*)dw, splits, w.Cout, T, w.Cin, accumulate, rb,
+                       w.slab + (size_t)splits * total, (float*)dbias, splits * pp_ntiles);
+  }
   DMVAE_CHECK_LAUNCH();
   if (!bias_fused && dbias) return colsum_launch(w.dy, (float*)dbias, w.slab + (size_t)splits * total, w.M, w.Cout, accumulate, stream);
   return 0;
