@@ -230,6 +230,48 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// T > 1, one block per (cout, up to 512 input channels): [T][512] of every slab as 16-B pieces with ALL threads loading (the 64-channel form above keeps T * 16 of 256
+// threads busy -- 144 at T = 9 -- and runs 8 x as many blocks of 2.3 KB each), summed over the splits in order, turned through LDS, written as the contiguous [512][T] run.
+__global__ __launch_bounds__(256) void wgrad_reduce_row_kernel(const float* __restrict__ slab, float* __restrict__ out, int splits, int Cout, int T, int Cin,
+                                                               int accumulate, int rb, int cchunks, const float* __restrict__ bpart, float* __restrict__ dbias,
+                                                               int nparts) {
+  if ((int)blockIdx.x >= rb) {
+    __shared__ float sh[4][64];
+    const int c = ((int)blockIdx.x - rb) * 64 + (threadIdx.x & 63), kl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < Cout)
+      for (int k = kl; k < nparts; k += 4) s += bpart[(size_t)k * Cout + c];
+    sh[kl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (kl == 0 && c < Cout) {
+      const float t = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+      dbias[c] = accumulate ? dbias[c] + t : t;
+    }
+    return;
+  }
+  __shared__ float tile[16][516];
+  const int co = (int)blockIdx.x / cchunks, ci0 = ((int)blockIdx.x - co * cchunks) * 512;
+  const int ncol = min(512, Cin - ci0), q4 = ncol >> 2;   // Cin % 4 == 0 (host)
+  const size_t total = (size_t)Cout * T * Cin;
+  for (int e = threadIdx.x; e < T * q4; e += 256) {
+    const int tap = e / q4, c = (e - tap * q4) * 4;
+    const float* src = slab + ((size_t)co * T + tap) * Cin + ci0 + c;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < splits; k++) sum += *reinterpret_cast<const f32x4*>(src + (size_t)k * total);
+    *reinterpret_cast<f32x4*>(&tile[tap][c]) = sum;
+  }
+  __syncthreads();
+  const int nout = ncol * T;
+  const unsigned rcp = (65536u + (unsigned)T - 1u) / (unsigned)T;   // e / T for e < 8192, T <= 16: exact ((e * rcp) >> 16 with e * rcp < 2^32 and error < 1 / T)
+  float* dst = out + ((size_t)co * Cin + ci0) * T;
+  for (int e = threadIdx.x; e < nout; e += 256) {
+    const int c = (int)(((unsigned)e * rcp) >> 16), tap = e - c * T;
+    const float v = tile[tap][c];
+    dst[e] = accumulate ? dst[e] + v : v;
+  }
+}
+
 // T == 1 (Linear layers, 1x1 convs): the slab layout [cout][1][cin] IS the output layout, so the reduce is a flat sum of `splits` vectors -- 16 B per lane, all lanes
 // busy.  The tap-transposing kernel above keeps 16 of its 256 threads loading when T = 1 (one 256-B row per block and split: 40 us per call on LightningDiT's
 // Linear weight gradients, 1.6 TB/s).  Same order of additions (split 0, 1, ...), same bias blocks behind the slab blocks.
@@ -400,6 +442,10 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
     const size_t total4 = total / 4;
     const int rbf = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(rbf + nb), dim3(256), 0, stream, w.slab, (float*)dw, splits, total4, accumulate, rbf, w.Cout,
+                       w.slab + (size_t)splits * total, (float*)dbias, splits * pp_ntiles);
+  } else if (flat_ok && (T == 4 || T == 9 || T == 16) && w.Cin % 4 == 0 && w.Cin >= 128) {   // the reciprocal index split below is exact for these T
+    const int cchunks = (w.Cin + 511) / 512, rb = w.Cout * cchunks;   // one block per (cout, up to 512 input channels)
+    hipLaunchKernelGGL(wgrad_reduce_row_kernel, dim3(rb + nb), dim3(256), 0, stream, w.slab, (float*)dw, splits, w.Cout, T, w.Cin, accumulate, rb, cchunks,
                        w.slab + (size_t)splits * total, (float*)dbias, splits * pp_ntiles);
   } else {
     const int rb = w.Cout * ((w.Cin + 63) / 64);   // one block per (cout, 64 input channels)
