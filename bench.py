@@ -327,6 +327,15 @@ def main():
             traffic_src = "profiles/r2_conv_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, %d launches; FETCH_SIZE x2 per MI355X_MICROARCH.md)" % tp["launches_profiled"]
     except (OSError, ValueError, KeyError):
         pass
+    wg_traffic = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_wgrad_pp_traffic.json")) as f:
+            wt = json.load(f)
+        if args.batch == LOCAL_BATCH:
+            wg_traffic = {"bytes_per_launch": int(wt["hbm_MB_per_launch"] * 1e6), "kernel": wt["kernel"], "launches_profiled": wt["launches_profiled"],
+                          "source": "profiles/r2_wgrad_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command; the 256 x 256 tile's main kernel, 28 of the step's weight-gradient launches)"}
+    except (OSError, ValueError, KeyError):
+        pass
     out = {
         "metric": "images/sec DMVAE train step @256x256",
         "value": round(world * args.batch * args.steps / dt, 2),
@@ -351,7 +360,7 @@ def main():
         # the bias gradient), timed per call like the forward / input-gradient launches
         "roofline_wgrad": {"bound": "mfma", "kernel": "dmvae_wgrad_pp::wgrad_pp_kernel + wgrad_reduce_kernel (conv / Linear weight + bias gradient, whole call)",
                            "achieved": round(wg_ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(wg_ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                           "traffic": None, "launches": wg_n, "avg_launch_us": round(wg_ms * 1e3 / max(1, wg_n), 2),
+                           "traffic": wg_traffic, "launches": wg_n, "avg_launch_us": round(wg_ms * 1e3 / max(1, wg_n), 2),
                            "share_of_step": round(wg_ms / (dt * 1e3 * frac_timed), 3),
                            "small_shape_calls": {"launches": wgs_n, "share_of_step": round(wgs_ms / (dt * 1e3 * frac_timed), 3)}},
     }
