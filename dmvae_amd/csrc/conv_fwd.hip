@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
   static_assert(LW >= 1 && LP >= 1 && IM >= 1 && JN >= 1, "tile too small for four waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // stage s: W tile at s*STAGE, P tile at s*STAGE + WTILE
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the LDS-DMA destination (M0) derives from it -- as a VGPR value every issue became a readfirstlane waterfall loop
   const int wm = WVM == 2 ? wave >> 1 : 0, wn = WVM == 2 ? wave & 1 : wave;
   // flat grid, XCD-aware: cout tiles of one pixel tile are adjacent (they share the activation tile in L2) and each
   // XCD walks a contiguous range of pixel tiles (3x3 halo rows are shared in the same L2)

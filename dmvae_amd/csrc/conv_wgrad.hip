@@ -41,7 +41,8 @@ __device__ __forceinline__ s16x4 tr_read(const char* p) {
 
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the LDS-DMA destination (M0) derives from it -- as a VGPR value every issue became a readfirstlane waterfall loop
   const int wm = wave >> 1, wn = wave & 1;
   const int T = a.ks * a.ks;
   const int ci_tiles = (a.Cin + 127) / 128;
