@@ -31,6 +31,10 @@
 #include <type_traits>
 #include <unordered_map>
 
+#ifndef DMVAE_PP_EXP
+#define DMVAE_PP_EXP 0
+#endif
+
 namespace dmvae_conv_pp {
 
 struct Args {
@@ -269,7 +273,11 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   // issue this wave's pieces of tile `it` into the ring slot at byte offset `slot` (wave-uniform); past the last tile issue
   // all-zero pieces so that the vmcnt bookkeeping stays uniform (an out-of-range piece moves no memory)
   auto issue = [&](int slot) {
+#if DMVAE_PP_EXP & 32
+    const bool live = it < 0;
+#else
     const bool live = it < nK;
+#endif
     if (live && (KO || it_ch == 0)) new_tap();
     unsigned soA = (unsigned)(it_tap * a.Cin + it_ch * 32) * 2u;
     if constexpr (SUB)  // tap (py + 2a, px + 2b) of the 4x4 operand
@@ -281,13 +289,25 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       soA = (unsigned)__builtin_amdgcn_readfirstlane((int)soA);
       soB = (unsigned)__builtin_amdgcn_readfirstlane((int)soB);
     }
+#if DMVAE_PP_EXP & 128   // timing experiment: the same number of DMA instructions moving a quarter of the bytes (4 B per lane)
+#pragma unroll
+    for (int p = 0; p < NPA; p++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + slot + (wave * NPA + p) * 1024), 4, live ? voffA[p] : SENT, soA, 0, 0);
+#pragma unroll
+    for (int p = 0; p < NPB; p++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + TILE_A + (wave * NPB + p) * 1024), 4, live ? selB[p] : SENT, soB, 0, 0);
+#else
 #pragma unroll
     for (int p = 0; p < NPA; p++)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + slot + (wave * NPA + p) * 1024), 16, live ? voffA[p] : SENT, soA, 0, 0);
 #pragma unroll
     for (int p = 0; p < NPB; p++)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + TILE_A + (wave * NPB + p) * 1024), 16, live ? selB[p] : SENT, soB, 0, 0);
+#endif
     it++;
+#if DMVAE_PP_EXP & 64   // timing experiment: every K tile re-loads the tile's FIRST K tile (real L2 -> LDS transfers, no new lines from HBM / the fabric)
+    return;
+#endif
     if (KO) {  // channel chunk outer, tap inner: the nine taps of a chunk re-read (shifted) the same activation lines back to back
       if (++it_tap == T) { it_tap = 0; it_ch++; }
     } else {
@@ -342,6 +362,10 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 
   // ---- main loop ------------------------------------------------------------------------------------------------------
   bf16x8 af[BM16], bfr[BP16];
+#if DMVAE_PP_EXP & 2
+  for (int i = 0; i < BM16; i++) for (int e = 0; e < 8; e++) af[i][e] = (bf16)(0.001f * (float)(lane + i));
+  for (int j = 0; j < BP16; j++) for (int e = 0; e < 8; e++) bfr[j][e] = (bf16)(0.002f * (float)(lane + j));
+#endif
   int slot_rd = 0, slot_wr = PF * SLOT;
 #ifdef DMVAE_PP_TRACE
   unsigned long long trace_w1 = 0, trace_w2 = 0, trace_load = 0, trace_comp = 0, trace_last = __builtin_amdgcn_s_memtime();
@@ -350,11 +374,15 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   for (int t = 0; t < nK; t++) {
     // LOAD interval
     const char* sb = smem + slot_rd;
+#if !(DMVAE_PP_EXP & 2)   // timing experiments (tools/probes/build_variant.sh): 1 = no DMA issue in the K loop, 2 = no fragment reads, 8 = no epilogue stores, 32 = all pieces masked
 #pragma unroll
     for (int j = 0; j < BP16; j++) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + boff[j]);
 #pragma unroll
     for (int i = 0; i < BM16; i++) af[i] = *reinterpret_cast<const bf16x8*>(sb + aoff[i]);
+#endif
+#if !(DMVAE_PP_EXP & 1)
     issue(slot_wr);
+#endif
     slot_rd = slot_rd + SLOT == NBUF * SLOT ? 0 : slot_rd + SLOT;
     slot_wr = slot_wr + SLOT == NBUF * SLOT ? 0 : slot_wr + SLOT;
     wait_vmcnt<(PF - 1) * NP>();  // own pieces of the NEXT tile have landed
@@ -601,7 +629,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
               }
               // non-temporal: the tile is next read by a later kernel, after far more than an L2 of other traffic
               keep[q] = o;
+#if !(DMVAE_PP_EXP & 8)
               __builtin_amdgcn_raw_buffer_store_b128(o, rY, voff, soff, 2);
+#endif
             }
           }
           // gfx950 hazard that hipcc (ROCm 7.2) does not pad: a VALU instruction that directly follows a buffer_store_dwordx4 and writes one of its data
