@@ -59,6 +59,7 @@ constexpr unsigned SENT = 0x80000000u;  // voffset beyond any descriptor's num_r
 // ds_read_b128 serves the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... in one pass each; with the chunk XOR-ed by (-(row >> 2)) & 3 the four lanes of
 // a group that share row % 4 land in four different 16-B slots of the bank row (derivation in DESIGN.md 3.1).
 __device__ __forceinline__ int swz64(int row) { return (0 - (row >> 2)) & 3; }
+__device__ __forceinline__ int hswz(int row) { return (row >> 1) & 2; }   // HALO rows: the key that stays conflict-free under a shift of 0..2 rows
 
 // q = m / d, r = m % d for 0 <= m < 2^24 (exact in f32) via one reciprocal and a +-1 fix-up.  The host declines shapes with 2^24 pixels or more: a plain
 // integer division as the other arm kept its reciprocal sequences alive (and spilled) across the whole kernel.
@@ -95,7 +96,22 @@ __device__ __forceinline__ void wait_vmcnt() {
 // STATS: the epilogue also sums the (bf16-rounded) results and their squares per 4 output channels and pixel tile -- the statistics pass of the GroupNorm
 // that follows most decoder convs (flux_ae.py:62,64,71-76) then has nothing left to read: a finishing kernel combines the partials per (image, group) in
 // f64 (groupnorm.hip::stats_from_quads_kernel).  Its own instantiation: the plain kernel's code is unchanged.
-template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool OUT_F32, bool KO, bool GEN = false, bool SUB = false, bool DYN = false, bool STATS = false>
+// HALO (plain 3x3, stride 1): the three kx taps of a (channel chunk, ky) read the SAME pixels shifted by one, so the activation operand of three consecutive
+// K tiles is staged once, as the TP + 2 flat pixels m0 - 1 .. m0 + TP of source row offset ky - 1 (TP / 16 + 1 pieces instead of 3 * TP / 16), and tap kx
+// reads pixel p's fragment from halo row p + kx.  The timing experiment DMVAE_PP_EXP=256 (the same instruction stream with two of three activation pieces
+// masked) measured +12-14 % on the decoder's shapes: what the L2 -> LDS staging costs this kernel scales with the bytes it moves.
+//   * x edges: the flat neighbour of an image row's first / last pixel belongs to another row; those lanes' fragment addresses point at an all-zero row
+//     of the halo slot instead (rows TP + 2 .. TP + 15 of the last piece are out-of-range lanes of the DMA, which writes zeros for them);
+//   * y edges / ragged M: per-lane validity of the staged pixel per ky, taken from the tile pixel that reads it ("owner": halo row i belongs to pixel
+//     clamp(i - 1)), SENT otherwise;
+//   * LDS: A ring of four slots as before, halo ring of two (slot of group g = g & 1; it is refilled one K tile after its last read, the rule the A ring
+//     follows), laid out [A0 A1 H0 | A2 A3 H1] so that the epilogue's staging region (from GROUP on) stays clear of the next tile's first two K tiles;
+//   * halo rows are swizzled by ((row >> 2) & 1) << 1: conflict-free ds_read_b128 for 16 consecutive rows starting at ANY offset 0..2 of a 16-row block
+//     (searched exhaustively over period-8 keys against the service groups quoted at swz64; the A operand's key is not: 2-way conflicts at shift 1, 2);
+//   * every wave issues TP / 128 + 1 halo pieces with the kx = 0 tile of a group (the last one is real for wave 0 only, the others' all-SENT copy lands
+//     in a dump KiB), so the counted vmcnt waits are compile-time constants per kx: the K loop is unrolled by three.
+template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool OUT_F32, bool KO, bool GEN = false, bool SUB = false, bool DYN = false, bool STATS = false,
+          bool HALO = false>
 __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__  // the host pass only needs the launch stub (hipcc drops the stub when it cannot digest the gfx950 body)
   constexpr int BM = TM / WM / 32, BP = TP / WP / 32;  // 32x32 accumulator blocks per wave
@@ -104,6 +120,13 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   constexpr int NP = NPA + NPB;
   constexpr int PF = NBUF - 1;  // prefetch distance in K tiles
   static_assert(WM * WP == 8 && BM * BP == 8, "8 waves x 8 accumulators");
+  static_assert(!HALO || (!UPS && !GEN && !SUB && KO && NBUF == 4), "HALO: plain 3x3, chunk-outer K order");
+  constexpr int NPH = NPB + 1;                     // halo pieces per wave and (chunk, ky) group
+  constexpr int HALO_B = (TP + 16) * 64;           // halo slot: TP + 2 pixels, rows TP + 2 .. TP + 15 zero
+  constexpr int GROUP = 2 * TILE_A + HALO_B;       // [A0 A1 H0] / [A2 A3 H1]
+  constexpr int EPI_OFF = HALO ? GROUP : 2 * SLOT; // the epilogue's staging region
+  constexpr int EPI_BYTES = 8 * 32 * (((BM >= 4 ? BM / 2 : BM) * 32) * 4 + 16);
+  constexpr int DUMP_OFF = GROUP + (GROUP > EPI_BYTES ? GROUP : EPI_BYTES);
   constexpr int BM16 = BM * 2, BP16 = BP * 2;  // 16x16 MFMA blocks per wave (v_mfma_f32_16x16x32_bf16: measured 5 % less power per flop than 32x32x16,
                                                // tools/probes/probe_wavetile.hip arm D -- and the kernel is power-limited)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -146,6 +169,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   unsigned voffA[NPA];
   unsigned ctrB[NPB], maskB[NPB], selB[NPB];
   unsigned rowo[UPS ? NPB : 1][3], colo[UPS ? NPB : 1][3];
+  unsigned ctrH[HALO ? NPH : 1], mskH[HALO ? NPH : 1];   // HALO: byte offset of the lane's halo pixel (ky = 0 row), bit ky set when that row is inside the image
+  int it_ky = 0;                                         // HALO: the issue state is (it_ch, it_ky) + the compile-time kx
   int it = 0, it_tap = 0, it_ch = 0;  // DMA issue state (wave-uniform): tile `it` = (tap it_tap, channel chunk it_ch)
   unsigned soffB_tap = 0;
   auto setup = [&](unsigned work) {
@@ -160,6 +185,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       n0 = (int)(wid % a.ctiles) * TM;  // first cout
     }
     it = it_tap = it_ch = 0;
+    it_ky = 0;
 #pragma unroll
     for (int p = 0; p < NPA; p++) {
       const int row = (wave * NPA + p) * 16 + (lane >> 2);
@@ -167,6 +193,27 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       const int c = (lane & 3) ^ swz64(row);  // logical 16-B chunk this lane fetches (LDS image stays lane-linear)
       voffA[p] = co < a.Cout ? (unsigned)co * TW * a.Cin * 2u + c * 16u : SENT;
     }
+    if constexpr (HALO) {
+#pragma unroll
+      for (int q = 0; q < NPH; q++) {
+        const int i = (q < NPB ? (wave * NPB + q) * 16 : TP) + (lane >> 2);   // halo row = flat pixel m0 - 1 + i
+        const int own = min(max(i - 1, 0), TP - 1);                            // the tile pixel whose edge rules it follows
+        const int m = m0 + own;
+        const int c = (lane & 3) ^ hswz(i);
+        unsigned mask = 0;
+        if (m < a.M && i < TP + 2 && (q < NPB || wave == 0)) {
+          int n, r, y, x;
+          divmod_small(m, hw, inv_hw, small_m, n, r);
+          divmod_small(r, dvw, inv_wo, small_m, y, x);
+          mask = (y > 0 ? 1u : 0u) | 2u | (y < a.Ho - 1 ? 4u : 0u);
+          // the two outer halo pixels are only ever read from inside the owner's image row; where the flat neighbour belongs to another row it may lie
+          // outside the tensor (the descriptor's range check does not see the scalar offset): not fetched
+          if ((i == 0 && x == 0) || (i == TP + 1 && x == a.Wo - 1)) mask = 0;
+        }
+        ctrH[q] = (unsigned)(m0 + i) * a.Cin * 2u + c * 16u;   // relative to the descriptor base, which sits Wi + 1 pixels in front of the tensor
+        mskH[q] = mask;
+      }
+    } else {
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
     const int row = (wave * NPB + p) * 16 + (lane >> 2);
@@ -229,6 +276,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     maskB[p] = mask;
     selB[p] = SENT;
   }
+    }
   };
 
   // ---- fragment read offsets (bytes inside a slot) ------------------------------------------------------------------
@@ -283,6 +331,11 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     if constexpr (SUB)  // tap (py + 2a, px + 2b) of the 4x4 operand
       soA = (unsigned)(((((par >> 1) + (it_tap & 2)) << 2) + (par & 1) + ((it_tap & 1) << 1)) * a.Cin + it_ch * 32) * 2u;
     unsigned soB = soffB_tap + (unsigned)it_ch * 64u;
+#if DMVAE_PP_EXP & 256   // timing experiment: the traffic of a kx-halo form -- activation pieces move memory for one tap in three, the others are issued masked
+    const bool live_b = it_tap == 0 || it_tap == 3 || it_tap == 6;
+#else
+    constexpr bool live_b = true;
+#endif
     // GEN: the tap offset and the chunk counter end up in VGPRs (phis of VALU-computed values) and every piece issue became a readfirstlane
     // waterfall loop; pin the two wave-uniform offsets to SGPRs (the plain instantiation's code is unchanged)
     if constexpr (GEN) {
@@ -302,7 +355,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + slot + (wave * NPA + p) * 1024), 16, live ? voffA[p] : SENT, soA, 0, 0);
 #pragma unroll
     for (int p = 0; p < NPB; p++)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + TILE_A + (wave * NPB + p) * 1024), 16, live ? selB[p] : SENT, soB, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + TILE_A + (wave * NPB + p) * 1024), 16, (live && live_b) ? selB[p] : SENT, soB, 0, 0);
 #endif
     it++;
 #if DMVAE_PP_EXP & 64   // timing experiment: every K tile re-loads the tile's FIRST K tile (real L2 -> LDS transfers, no new lines from HBM / the fabric)
@@ -314,6 +367,32 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       if (++it_ch == nchunk) { it_ch = 0; it_tap++; }
     }
   };
+
+  // HALO: K tile `it` = (chunk it_ch, ky it_ky, kx KX); its A pieces go to A slot it & 3, the group's halo pieces ride on the kx = 0 tile
+  auto issue_h = [&](auto KXc) __attribute__((always_inline)) {
+    constexpr int KX = decltype(KXc)::value;
+    const bool live = it < nK;
+    const unsigned soA = (unsigned)((it_ky * 3 + KX) * a.Cin + it_ch * 32) * 2u;
+    const int da = ((it >> 1) & 1) * GROUP + (it & 1) * TILE_A;
+#pragma unroll
+    for (int p = 0; p < NPA; p++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + da + (wave * NPA + p) * 1024), 16, live ? voffA[p] : SENT, soA, 0, 0);
+    if constexpr (KX == 0) {
+      const unsigned soH = (unsigned)(it_ky * a.Wi) * a.Cin * 2u + (unsigned)it_ch * 64u;
+      const int dh = ((it_ch + it_ky) & 1) * GROUP + 2 * TILE_A;
+#pragma unroll
+      for (int q = 0; q < NPH; q++) {
+        const unsigned v = (live && ((mskH[HALO ? q : 0] >> it_ky) & 1u)) ? ctrH[HALO ? q : 0] : SENT;
+        const int dst = q < NPB ? dh + (wave * NPB + q) * 1024 : (wave == 0 ? dh + TP * 64 : DUMP_OFF);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + dst), 16, v, soH, 0, 0);
+      }
+    }
+    it++;
+    if constexpr (KX == 2) {
+      if (++it_ky == 3) { it_ky = 0; it_ch++; }
+    }
+  };
+  using K0_ = std::integral_constant<int, 0>; using K1_ = std::integral_constant<int, 1>; using K2_ = std::integral_constant<int, 2>;
 
   // ---- persistent tile loop ---------------------------------------------------------------------------------------------
   auto stamp = [&](unsigned work, int k) {
@@ -340,19 +419,42 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   stamp(blockIdx.x, 0);
   setup(blockIdx.x);
   stamp(blockIdx.x, 1);
+  if constexpr (HALO) {
+    issue_h(K0_{}); issue_h(K1_{}); issue_h(K2_{});
+  } else {
 #pragma unroll
-  for (int u = 0; u < PF; u++) issue(u * SLOT);
+    for (int u = 0; u < PF; u++) issue(u * SLOT);
+  }
   for (unsigned work = blockIdx.x; work < (unsigned)a.total;) {
   const int m0c = m0, n0c = n0;  // the tile being computed (setup() moves m0 / n0 on to the next one before the epilogue)
   const int parc = par;
   if constexpr (DYN) claim();
+  // HALO: fragment offsets of the three kx taps inside a halo slot -- pixel p reads halo row p + kx, or the slot's zero row where the tap leaves the image row
+  int boffk[HALO ? 3 : 1][HALO ? BP16 : 1];
+  if constexpr (HALO) {
+    int lane_h = lane;
+    asm volatile("" : "+v"(lane_h));   // computed here, per tile: not carried across the epilogue
+#pragma unroll
+    for (int j = 0; j < BP16; j++) {
+      const int prow = wp * (TP / WP) + j * 16 + (lane_h & 15);
+      int q, x;
+      divmod_small(m0c + prow, dvw, inv_wo, small_m, q, x);
+      const int zoff = (TP + 2) * 64 + ((lane_h >> 4) << 4);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int h = prow + k;
+        const int off = h * 64 + (((lane_h >> 4) ^ hswz(h)) << 4);
+        boffk[HALO ? k : 0][HALO ? j : 0] = (k == 0 && x == 0) || (k == 2 && x == a.Wo - 1) ? zoff : off;
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < BM16; i++)
 #pragma unroll
     for (int j = 0; j < BP16; j++)
 #pragma unroll
       for (int r = 0; r < 4; r++) acc[i][j][r] = 0.f;
-  wait_vmcnt<(PF - 1) * NP>();
+  wait_vmcnt<HALO ? 2 * NPA : (PF - 1) * NP>();
   __builtin_amdgcn_s_barrier();                // B_0: everybody's pieces of tile 0 have landed
   stamp(work, 2);
 #if DMVAE_PP_PRIO_MODE == 1
@@ -370,6 +472,36 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #ifdef DMVAE_PP_TRACE
   unsigned long long trace_w1 = 0, trace_w2 = 0, trace_load = 0, trace_comp = 0, trace_last = __builtin_amdgcn_s_memtime();
 #endif
+  if constexpr (HALO) {
+    int ka = 0, sh = 2 * TILE_A;   // A slot index and halo slot offset being read
+    auto ktile = [&](auto KXc) __attribute__((always_inline)) {
+      constexpr int KX = decltype(KXc)::value;
+      const char* sa = smem + ((ka >> 1) & 1) * GROUP + (ka & 1) * TILE_A;
+      const char* sb = smem + sh;
+#pragma unroll
+      for (int j = 0; j < BP16; j++) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + boffk[HALO ? KX : 0][HALO ? j : 0]);
+#pragma unroll
+      for (int i = 0; i < BM16; i++) af[i] = *reinterpret_cast<const bf16x8*>(sa + aoff[i]);
+      issue_h(KXc);   // tile t + 3: the same kx
+      ka++;
+      if constexpr (KX == 2) sh = sh == 2 * TILE_A ? GROUP + 2 * TILE_A : 2 * TILE_A;
+      wait_vmcnt<KX == 2 ? 2 * NPA : 2 * NPA + NPH>();  // own pieces of the NEXT tile have landed: what may stay in flight is tiles t + 2 and t + 3
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < BM16; i++)
+#pragma unroll
+        for (int j = 0; j < BP16; j++)
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[i]), "v"(bfr[j]));
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll 1
+    for (int t = 0; t < nK; t += 3) { ktile(K0_{}); ktile(K1_{}); ktile(K2_{}); }
+  } else {
 #pragma unroll 1
   for (int t = 0; t < nK; t++) {
     // LOAD interval
@@ -420,6 +552,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #endif
     __builtin_amdgcn_sched_barrier(0);
   }
+  }
 #ifdef DMVAE_PP_TRACE
   if (a.dbg && (tid == 0 || tid == 256)) {   // per tile: [load, wait after load, compute issue, wait after compute] for wave 0 (slots 8..11) and wave 4 (12..15)
     unsigned long long* q = a.dbg + (size_t)work * 16 + 8 + (tid >> 8) * 4;
@@ -469,7 +602,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     constexpr unsigned ES = OUT_F32 ? 4u : 2u;
     static_assert(!STATS || !OUT_F32, "STATS: statistics of the bf16 result");
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    char* reg = smem + 2 * SLOT + wave * (32 * ROWB);
+    char* reg = smem + EPI_OFF + wave * (32 * ROWB);
     // an opaque copy of the lane index: everything the epilogue derives from it is recomputed per tile instead of being hoisted out of the tile loop and
     // carried (spilled) across the main loop
     int lane_o = lane;
@@ -498,9 +631,10 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       setup(next);
       stamp(next, 1);
     } else {
-      it = nK;
+      it = HALO ? (nK + 3) & ~3 : nK;   // HALO derives the destination from `it`: A slot 0 / halo slot 0, clear of the staging region
+      it_ky = it_ch = 0;
     }
-    issue(0);
+    if constexpr (HALO) issue_h(K0_{}); else issue(0);
     stamp(work, 7);
     float sacc[STATS ? NH : 1][2][2];  // [pass][4-channel half of the lane's 8 couts][sum, sum of squares]
     if constexpr (STATS) {
@@ -669,12 +803,12 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
         }
     }
   }
-  if (has_next) issue(SLOT);
+  if (has_next) { if constexpr (HALO) issue_h(K1_{}); else issue(SLOT); }
   stamp(work, 4);
-  wait_vmcnt<NP>();              // the epilogue's stores share vmcnt with the prefetched K tiles: everything but the second tile's pieces (the newest) has landed
+  wait_vmcnt<HALO ? NPA : NP>();              // the epilogue's stores share vmcnt with the prefetched K tiles: everything but the second tile's pieces (the newest) has landed
   stamp(work, 5);
   __builtin_amdgcn_s_barrier();  // staging reads done before ring slots 2.. are refilled
-  if (has_next) issue(2 * SLOT);
+  if (has_next) { if constexpr (HALO) issue_h(K2_{}); else issue(2 * SLOT); }
   work = next;
   }  // persistent tile loop
   if constexpr (DYN) {
@@ -705,7 +839,8 @@ static unsigned* sched_for(hipStream_t st) {
   return base + (size_t)it->second * SCHED_WORDS;
 }
 
-template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32, bool KO, bool GEN = false, bool SUB = false, bool DYN = false, bool STATS = false>
+template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32, bool KO, bool GEN = false, bool SUB = false, bool DYN = false, bool STATS = false,
+          bool HALO = false>
 int launch(Args a, hipStream_t st) {
   a.ctiles = (a.Cout + TM - 1) / TM;
   a.total = ((a.M + TP - 1) / TP) * a.ctiles * (SUB ? 4 : 1);
@@ -715,19 +850,20 @@ int launch(Args a, hipStream_t st) {
     static const bool dyn = [] { const char* e = getenv("DMVAE_PP_DYNAMIC"); return e ? atoi(e) != 0 : false; }();
     if (dyn && grid == 256u && (unsigned)a.total > grid) {
       a.sched = sched_for(st);
-      if (a.sched) return launch<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, true, STATS>(a, st);
+      if (a.sched) return launch<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, true, STATS, HALO>(a, st);
     }
   }
   constexpr int cwh = (TM / WM / 32 >= 4) ? TM / WM / 2 : TM / WM;    // couts per staging pass (the kernel's CWH)
   constexpr int ring = NBUF * (TM + TP) * 64, epi = 2 * (TM + TP) * 64 + 8 * 32 * (cwh * 4 + 16);
-  constexpr int lds = ring > epi ? ring : epi;
+  constexpr int group = 2 * TM * 64 + (TP + 16) * 64, epi_h = 8 * 32 * (cwh * 4 + 16);   // the kernel's GROUP / EPI_BYTES / DUMP_OFF
+  constexpr int lds = HALO ? group + (group > epi_h ? group : epi_h) + 1024 : (ring > epi ? ring : epi);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, DYN, STATS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, DYN, STATS, HALO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, DYN, STATS>), dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((conv_pp_kernel<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, DYN, STATS, HALO>), dim3(grid), dim3(512), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -751,6 +887,13 @@ int pick(const Args& a, hipStream_t st, bool gen) {
     return launch<256, 256, 2, 4, 4, UPS, F32, false>(a, st);
   } else {
     if constexpr (!F32) {
+      static const int halo = [] { const char* e = getenv("DMVAE_PP_HALO"); return e ? atoi(e) : 1; }();   // 0: every kx tap staged on its own; 1: 256 x 256 tile; 3: + 128 x 512
+      if (halo && ko && a.ks == 3) {   // plain 3x3: the three kx taps of a (chunk, ky) share one staged halo of the pixel tile
+        if (a.Cout > 128) return a.gnpart ? launch<256, 256, 2, 4, 4, false, false, true, false, false, false, true, true>(a, st)
+                                          : launch<256, 256, 2, 4, 4, false, false, true, false, false, false, false, true>(a, st);
+        if (halo & 2) return a.gnpart ? launch<128, 512, 2, 4, 4, false, false, true, false, false, false, true, true>(a, st)
+                                      : launch<128, 512, 2, 4, 4, false, false, true, false, false, false, false, true>(a, st);
+      }
       if (a.gnpart) {  // GroupNorm statistics of the result in the epilogue (chunk-outer K order only)
         if (a.Cout <= 128) return launch<128, 512, 2, 4, 4, false, false, true, false, false, false, true>(a, st);
         return launch<256, 256, 2, 4, 4, false, false, true, false, false, false, true>(a, st);
