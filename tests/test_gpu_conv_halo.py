@@ -1,0 +1,55 @@
+"""The kx-halo form of csrc/conv_pp.hip (template flag HALO: plain 3x3, bf16 result, Cout > 128 -- every decoder ResnetBlock conv with 256 / 512 output
+channels, models/flux_ae.py:63,65, and their input gradients): the three kx taps of a (channel chunk, ky) read one staged halo of the pixel tile.
+What is new there is geometry, so the cases are geometric: image rows shorter / longer than a tile and not dividing it, tiles that span several images,
+ragged pixel counts, odd chunk counts (halo-slot parity, the A-ring slot of the trailing all-zero K tiles), one chunk.  Reference: fp64 conv on the same
+bf16-rounded operands; and bit equality with the f32-output route, which stages every tap on its own (the K order and hence every sum is the same)."""
+import pytest
+import torch
+
+from conftest import rel_err
+from test_gpu_kernels import _conv_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+CASES = [  # N, H, W, Cin, Cout
+    (2, 96, 100, 32, 192),     # W does not divide the tile, ragged last tile, one chunk per tap, ragged cout
+    (128, 12, 12, 64, 256),    # 144-pixel images: every tile spans image boundaries; two chunks (18 K tiles: trailing tiles start at A slot 2)
+    (5, 60, 68, 96, 136),      # odd chunk count, ragged everything
+    (1, 16, 1040, 160, 256),   # rows of four tiles + 16 pixels
+    (72, 16, 16, 128, 512),    # one image per tile, two cout tiles
+    (3, 8, 700, 32, 144),      # short, wide images
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("act,use_res", [(0, False), (1, True)])
+def test_halo_conv_geometry(case, act, use_res):
+    from dmvae_amd import ops
+    n, h, w_, cin, cout = case
+    g = torch.Generator(device="cpu").manual_seed(3 + cin + cout + w_)
+    x = torch.randn(n, h, w_, cin, generator=g).to(DEV).to(BF)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    r = torch.randn(n, h, w_, cout, generator=g).to(DEV).to(BF) if use_res else None
+    wp = ops.pack_conv_weight(w)
+    ref = _conv_ref(x, w.to(BF), b, r, 3, 0, act)
+    y16 = ops.conv2d_nhwc(x, wp, b, r, ks=3, act=act)              # HALO instantiation
+    y32 = ops.conv2d_nhwc(x, wp, b, r, ks=3, act=act, out_f32=True)  # every tap staged on its own
+    assert rel_err(y32.cpu(), ref) < 1e-5
+    assert torch.equal(y16, y32.to(BF))
+    assert torch.equal(y16, ops.conv2d_nhwc(x, wp, b, r, ks=3, act=act))   # rerun: bit-identical
+
+
+def test_halo_conv_edge_columns_are_zero_padded():
+    """An all-ones image and all-ones weights: the result counts the taps inside the image, so a wrapped neighbour row shows up as a wrong integer."""
+    from dmvae_amd import ops
+    n, h, w_, cin, cout = 2, 100, 84, 32, 256
+    x = torch.ones(n, h, w_, cin, device=DEV, dtype=BF)
+    wp = ops.pack_conv_weight(torch.ones(cout, cin, 3, 3, device=DEV))
+    y = ops.conv2d_nhwc(x, wp, ks=3, out_f32=False).float()
+    ry = torch.full((h,), 3.0); ry[0] = ry[-1] = 2.0
+    rx = torch.full((w_,), 3.0); rx[0] = rx[-1] = 2.0
+    want = (ry[:, None] * rx[None, :] * cin).to(DEV)
+    assert torch.equal(y, want[None, :, :, None].expand(n, h, w_, cout))
