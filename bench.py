@@ -301,7 +301,9 @@ def main():
         return
     frac_timed = len(range(0, args.steps, max(1, args.time_every))) / max(1, args.steps)     # share of the timed steps that carried the per-launch events
     # the plain 256x256 instantiation; its dynamic-tile-claiming twin (DYN = true) when more than one rank runs (dmvae_amd/dist.py sets DMVAE_PP_DYNAMIC)
-    DOMINANT = "conv_pp_kernel<256, 256, 2, 4, 4, false, false, true, false, false, %s, false>" % ("true" if os.environ.get("DMVAE_PP_DYNAMIC", "0") not in ("", "0") else "false")
+    # (its kx-halo form, HALO = true, unless DMVAE_PP_HALO=0: the 3x3 launches; the 1x1 launches of the same tile stay on the HALO = false instantiation)
+    DOMINANT = "conv_pp_kernel<256, 256, 2, 4, 4, false, false, true, false, false, %s, false, %s>" % (
+        "true" if os.environ.get("DMVAE_PP_DYNAMIC", "0") not in ("", "0") else "false", "true" if ops._PP_HALO else "false")
     per = {}
     for label, e0, e1, fl in timing:
         a = per.setdefault(label, [0.0, 0.0, 0])
@@ -322,7 +324,7 @@ def main():
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_conv_pp_traffic.json")) as f:
             tp = json.load(f)
-        if tp.get("kernel") == DOMINANT.replace("true, false>", "false, false>") and args.batch == LOCAL_BATCH:      # same kernel body either way
+        if tp.get("kernel") == DOMINANT.replace("true, false, ", "false, false, ") and args.batch == LOCAL_BATCH:      # same kernel body either way
             traffic = int(tp["hbm_MB_per_launch"] * 1e6)
             traffic_src = "profiles/r2_conv_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, %d launches; FETCH_SIZE x2 per MI355X_MICROARCH.md)" % tp["launches_profiled"]
     except (OSError, ValueError, KeyError):

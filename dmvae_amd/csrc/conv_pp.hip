@@ -887,7 +887,7 @@ int pick(const Args& a, hipStream_t st, bool gen) {
     return launch<256, 256, 2, 4, 4, UPS, F32, false>(a, st);
   } else {
     if constexpr (!F32) {
-      static const int halo = [] { const char* e = getenv("DMVAE_PP_HALO"); return e ? atoi(e) : 1; }();   // 0: every kx tap staged on its own; 1: 256 x 256 tile; 3: + 128 x 512
+      static const int halo = [] { const char* e = getenv("DMVAE_PP_HALO"); return e ? atoi(e) : 3; }();   // 0: every kx tap staged on its own; 1: the 256 x 256 tile only; 3: + the 128 x 512 tile
       if (halo && ko && a.ks == 3) {   // plain 3x3: the three kx taps of a (chunk, ky) share one staged halo of the pixel tile
         if (a.Cout > 128) return a.gnpart ? launch<256, 256, 2, 4, 4, false, false, true, false, false, false, true, true>(a, st)
                                           : launch<256, 256, 2, 4, 4, false, false, true, false, false, false, false, true>(a, st);

@@ -48,6 +48,7 @@ _WS = {}
 KERNEL_TIMING = None
 _PP_KORDER = "false" if os.environ.get("DMVAE_PP_KORDER", "1") == "0" else "true"   # csrc/conv_pp.hip::pick
 _PP_SUBPIXEL = os.environ.get("DMVAE_PP_SUBPIXEL", "1") != "0"                        # csrc/conv_pp.hip::dmvae_conv_pp_try
+_PP_HALO = int(os.environ.get("DMVAE_PP_HALO", "3") or "0")                            # csrc/conv_pp.hip::pick
 
 
 def workspace(nbytes: int, device, slot: str = "main") -> torch.Tensor:
@@ -132,8 +133,10 @@ def _conv_label(n, ho, wo, cin, cout, ks, upsample, out_f32, stride, transposed,
         gen = (int(upsample) == 2 or stride == 2 or ks == 4 or bool(transposed)) and not (sub and _PP_SUBPIXEL)   # the general-gather instantiation
         t = lambda f: "true" if f else "false"
         dyn = os.environ.get("DMVAE_PP_DYNAMIC", "0") not in ("", "0") and not ups1 and not out_f32 and (n * ho * wo // (512 if cout <= 128 else 256)) * ((cout + 255) // 256 if cout > 128 else 1) > 256
-        label = "conv_pp_kernel<%s, %s, %s, %s, %s, %s, %s, %s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", t(ups1), t(out_f32),
-                                                                   "false" if ups1 else ("true" if gen else _PP_KORDER), t(gen), t(sub and _PP_SUBPIXEL), t(dyn), t(stats))
+        # the kx-halo form (conv_pp.hip, HALO): plain 3x3 with a bf16 result in the chunk-outer K order; DMVAE_PP_HALO bit 0 = 256 x 256 tile, bit 1 = 128 x 512
+        halo = ks == 3 and not gen and not sub and not ups1 and not out_f32 and _PP_KORDER == "true" and (_PP_HALO != 0 if cout > 128 else bool(_PP_HALO & 2))
+        label = "conv_pp_kernel<%s, %s, %s, %s, %s, %s, %s, %s, %s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", t(ups1), t(out_f32),
+                                                                       "false" if ups1 else ("true" if gen else _PP_KORDER), t(gen), t(sub and _PP_SUBPIXEL), t(dyn), t(stats), t(halo))
     else:
         label = "conv_fwd_kernel"
     return label, 2.0 * n * ho * wo * cout * cin * (4 if sub else ks * ks)

@@ -1,4 +1,4 @@
-"""The kx-halo form of csrc/conv_pp.hip (template flag HALO: plain 3x3, bf16 result, Cout > 128 -- every decoder ResnetBlock conv with 256 / 512 output
+"""The kx-halo form of csrc/conv_pp.hip (template flag HALO: plain 3x3, bf16 result -- every decoder ResnetBlock conv with 256 / 512 output
 channels, models/flux_ae.py:63,65, and their input gradients): the three kx taps of a (channel chunk, ky) read one staged halo of the pixel tile.
 What is new there is geometry, so the cases are geometric: image rows shorter / longer than a tile and not dividing it, tiles that span several images,
 ragged pixel counts, odd chunk counts (halo-slot parity, the A-ring slot of the trailing all-zero K tiles), one chunk.  Reference: fp64 conv on the same
@@ -20,6 +20,9 @@ CASES = [  # N, H, W, Cin, Cout
     (1, 16, 1040, 160, 256),   # rows of four tiles + 16 pixels
     (72, 16, 16, 128, 512),    # one image per tile, two cout tiles
     (3, 8, 700, 32, 144),      # short, wide images
+    (2, 96, 100, 64, 128),     # the 128 x 512 tile (Cout <= 128): 514-pixel halo, 33 pieces
+    (160, 12, 12, 96, 64),     # ... tiles across images, odd chunk count, half of the tile's couts padding
+    (1, 24, 1050, 32, 96),     # ... rows of two tiles + 26 pixels
 ]
 
 
