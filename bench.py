@@ -324,7 +324,8 @@ def main():
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_conv_pp_traffic.json")) as f:
             tp = json.load(f)
-        if tp.get("kernel") == DOMINANT.replace("true, false, ", "false, false, ") and args.batch == LOCAL_BATCH:      # same kernel body either way
+        static_twin = "conv_pp_kernel<256, 256, 2, 4, 4, false, false, true, false, false, false, false, %s>" % ("true" if ops._PP_HALO else "false")
+        if tp.get("kernel") == static_twin and args.batch == LOCAL_BATCH:      # the DYN twin runs the same kernel body
             traffic = int(tp["hbm_MB_per_launch"] * 1e6)
             traffic_src = "profiles/r2_conv_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, %d launches; FETCH_SIZE x2 per MI355X_MICROARCH.md)" % tp["launches_profiled"]
     except (OSError, ValueError, KeyError):
