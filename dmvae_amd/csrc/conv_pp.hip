@@ -116,7 +116,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__  // the host pass only needs the launch stub (hipcc drops the stub when it cannot digest the gfx950 body)
   constexpr int BM = TM / WM / 32, BP = TP / WP / 32;  // 32x32 accumulator blocks per wave
   constexpr int TILE_A = TM * 64, TILE_B = TP * 64, SLOT = TILE_A + TILE_B;
-  constexpr int NPA = TM / 128, NPB = TP / 128;  // 1-KiB DMA pieces per wave per K tile
+  constexpr int NPA = TM >= 128 ? TM / 128 : 1, NPB = TP / 128;  // 1-KiB DMA pieces per wave per K tile (TM = 64: the pieces of waves 4-7 are all padding and land in the dump KiB)
+  static_assert(TM >= 128 || HALO, "the 64-row tile exists in the halo form only");
   constexpr int NP = NPA + NPB;
   constexpr int PF = NBUF - 1;  // prefetch distance in K tiles
   static_assert(WM * WP == 8 && BM * BP == 8, "8 waves x 8 accumulators");
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       const int row = (wave * NPA + p) * 16 + (lane >> 2);
       const int co = n0 + row;
       const int c = (lane & 3) ^ swz64(row);  // logical 16-B chunk this lane fetches (LDS image stays lane-linear)
-      voffA[p] = co < a.Cout ? (unsigned)co * TW * a.Cin * 2u + c * 16u : SENT;
+      voffA[p] = (co < a.Cout && row < TM) ? (unsigned)co * TW * a.Cin * 2u + c * 16u : SENT;
     }
     if constexpr (HALO) {
 #pragma unroll
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     const int da = ((it >> 1) & 1) * GROUP + (it & 1) * TILE_A;
 #pragma unroll
     for (int p = 0; p < NPA; p++)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + da + (wave * NPA + p) * 1024), 16, live ? voffA[p] : SENT, soA, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + ((wave * NPA + p) * 16 < TM ? da + (wave * NPA + p) * 1024 : DUMP_OFF)), 16, live ? voffA[p] : SENT, soA, 0, 0);
     if constexpr (KX == 0) {
       const unsigned soH = (unsigned)(it_ky * a.Wi) * a.Cin * 2u + (unsigned)it_ch * 64u;
       const int dh = ((it_ch + it_ky) & 1) * GROUP + 2 * TILE_A;
@@ -891,6 +892,8 @@ int pick(const Args& a, hipStream_t st, bool gen) {
       if (halo && ko && a.ks == 3) {   // plain 3x3: the three kx taps of a (chunk, ky) share one staged halo of the pixel tile
         if (a.Cout > 128) return a.gnpart ? launch<256, 256, 2, 4, 4, false, false, true, false, false, false, true, true>(a, st)
                                           : launch<256, 256, 2, 4, 4, false, false, true, false, false, false, false, true>(a, st);
+        if ((halo & 2) && !(halo & 8) && a.Cout <= 64 && !a.gnpart)   // LPIPS trunk's 64-channel layers (lpips.py:116-153): a 128-row tile would be half padding
+          return launch<64, 1024, 1, 8, 4, false, false, true, false, false, false, false, true>(a, st);
         if (halo & 2) return a.gnpart ? launch<128, 512, 2, 4, 4, false, false, true, false, false, false, true, true>(a, st)
                                       : launch<128, 512, 2, 4, 4, false, false, true, false, false, false, false, true>(a, st);
       }

@@ -135,7 +135,7 @@ def _conv_label(n, ho, wo, cin, cout, ks, upsample, out_f32, stride, transposed,
         dyn = os.environ.get("DMVAE_PP_DYNAMIC", "0") not in ("", "0") and not ups1 and not out_f32 and (n * ho * wo // (512 if cout <= 128 else 256)) * ((cout + 255) // 256 if cout > 128 else 1) > 256
         # the kx-halo form (conv_pp.hip, HALO): plain 3x3 with a bf16 result in the chunk-outer K order; DMVAE_PP_HALO bit 0 = 256 x 256 tile, bit 1 = 128 x 512
         halo = ks == 3 and not gen and not sub and not ups1 and not out_f32 and _PP_KORDER == "true" and (_PP_HALO != 0 if cout > 128 else bool(_PP_HALO & 2))
-        label = "conv_pp_kernel<%s, %s, %s, %s, %s, %s, %s, %s, %s>" % (("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4", t(ups1), t(out_f32),
+        label = "conv_pp_kernel<%s, %s, %s, %s, %s, %s, %s, %s, %s>" % (("64, 1024, 1, 8, 4" if (halo and cout <= 64 and not stats and not (_PP_HALO & 8)) else ("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4"), t(ups1), t(out_f32),
                                                                        "false" if ups1 else ("true" if gen else _PP_KORDER), t(gen), t(sub and _PP_SUBPIXEL), t(dyn), t(stats), t(halo))
     else:
         label = "conv_fwd_kernel"
