@@ -23,6 +23,9 @@ CASES = [  # N, H, W, Cin, Cout
     (2, 96, 100, 64, 128),     # the 128 x 512 tile (Cout <= 128): 514-pixel halo, 33 pieces
     (160, 12, 12, 96, 64),     # ... tiles across images, odd chunk count, half of the tile's couts padding
     (1, 24, 1050, 32, 96),     # ... rows of two tiles + 26 pixels
+    (8192, 1, 2, 32, 192),     # two-pixel images: every pixel is a left or a right edge, no row above or below
+    (1, 1, 16400, 64, 64),     # one row: the 64 x 1024 tile, only the centre kernel row contributes
+    (40, 20, 21, 32, 64),      # ... odd row length, ragged last tile
 ]
 
 
