@@ -479,11 +479,15 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       constexpr int KX = decltype(KXc)::value;
       const char* sa = smem + ((ka >> 1) & 1) * GROUP + (ka & 1) * TILE_A;
       const char* sb = smem + sh;
+#if !(DMVAE_PP_EXP & 2)   // the timing experiments of the per-tap loop below: 1 = no DMA issue in the K loop, 2 = no fragment reads
 #pragma unroll
       for (int j = 0; j < BP16; j++) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + boffk[HALO ? KX : 0][HALO ? j : 0]);
 #pragma unroll
       for (int i = 0; i < BM16; i++) af[i] = *reinterpret_cast<const bf16x8*>(sa + aoff[i]);
+#endif
+#if !(DMVAE_PP_EXP & 1)
       issue_h(KXc);   // tile t + 3: the same kx
+#endif
       ka++;
       if constexpr (KX == 2) sh = sh == 2 * TILE_A ? GROUP + 2 * TILE_A : 2 * TILE_A;
       wait_vmcnt<KX == 2 ? 2 * NPA : 2 * NPA + NPH>();  // own pieces of the NEXT tile have landed: what may stay in flight is tiles t + 2 and t + 3
