@@ -16,8 +16,11 @@ LIB_PATH = os.environ.get("DMVAE_LIB") or os.path.join(_HERE, "libdmvae_hip.so")
 class ConvDesc(Structure):
     """struct dmvae_conv_desc (include/dmvae_hip.h)."""
     _fields_ = [("n", c_int32), ("h", c_int32), ("w", c_int32), ("cin", c_int32), ("cout", c_int32),
-                ("ks", c_int32), ("upsample", c_int32), ("act", c_int32), ("out_f32", c_int32), ("stride", c_int32), ("transposed", c_int32)]
+                ("ks", c_int32), ("upsample", c_int32), ("act", c_int32), ("out_f32", c_int32), ("stride", c_int32), ("transposed", c_int32),
+                ("w_layout", c_int32)]
 
+
+ABI_VERSION = 2     # include/dmvae_hip.h: dmvae_abi_version
 
 # name -> (restype, argtypes); every symbol include/dmvae_hip.h declares
 SIGNATURES = {
@@ -34,6 +37,8 @@ SIGNATURES = {
     "dmvae_softmax_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dmvae_transpose_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dmvae_pack_conv_weight": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "dmvae_pack_conv_weight_v2": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "dmvae_conv_halo_applies": (c_int, [POINTER(ConvDesc)]),
     "dmvae_subpixel_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dmvae_subpixel_weight_fold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dmvae_colsum_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_int, c_void_p]),
@@ -130,6 +135,8 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
+        if l.dmvae_abi_version() != ABI_VERSION:      # e.g. a DMVAE_LIB variant built before dmvae_conv_desc grew: the structs would not line up
+            raise DmvaeHipError(f"{LIB_PATH}: ABI version {l.dmvae_abi_version()}, this package binds version {ABI_VERSION}; rebuild the library")
         _lib = l
     return _lib
 

@@ -47,6 +47,7 @@ struct Args {
   int ks, act, M, ctiles, total;  // total = pixel tiles x cout tiles
   int so, pd, sd;                 // gather geometry (dmvae_conv_geometry): tap k of output o reads source (o * so - pd + k) / sd when that is an in-range integer
   int Ml;                         // SUB: source pixels N * Hi * Wi (= output pixels of one parity class); M is set to the same value
+  unsigned wsRow, wsTap, wsChunk; // HALO: byte strides of the weight operand per cout row / tap / 32-channel chunk (dmvae_conv_desc.w_layout)
   float* gnpart;                  // STATS: [pixel tile][wave column 0..3][Cout / 4][2] per-tile (sum, sum of squares) of the bf16 results, 4 channels each
   unsigned* sched;                // DYN: this stream's scheduling words -- [0..7] tiles claimed past the static first round, per XCD range; [8] blocks finished;
                                   // [16 + b] the tile block b runs next.  All zero between launches (the last block to finish resets them).
@@ -192,7 +193,11 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       const int row = (wave * NPA + p) * 16 + (lane >> 2);
       const int co = n0 + row;
       const int c = (lane & 3) ^ swz64(row);  // logical 16-B chunk this lane fetches (LDS image stays lane-linear)
-      voffA[p] = (co < a.Cout && row < TM) ? (unsigned)co * TW * a.Cin * 2u + c * 16u : SENT;
+#if DMVAE_PP_EXP & 512   // timing experiment: the weight tile's 64-B rows contiguous in memory (whole 128-B lines; wrong data)
+      voffA[p] = (co < a.Cout && row < TM) ? (unsigned)co * 64u + c * 16u : SENT;
+#else
+      voffA[p] = (co < a.Cout && row < TM) ? (unsigned)co * (HALO ? a.wsRow : (unsigned)(TW * a.Cin) * 2u) + c * 16u : SENT;
+#endif
     }
     if constexpr (HALO) {
 #pragma unroll
@@ -211,7 +216,11 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
           // outside the tensor (the descriptor's range check does not see the scalar offset): not fetched
           if ((i == 0 && x == 0) || (i == TP + 1 && x == a.Wo - 1)) mask = 0;
         }
+#if DMVAE_PP_EXP & 1024   // timing experiment: the halo's 64-B rows contiguous in memory
+        ctrH[q] = (unsigned)(m0 + i) * 64u + c * 16u;
+#else
         ctrH[q] = (unsigned)(m0 + i) * a.Cin * 2u + c * 16u;   // relative to the descriptor base, which sits Wi + 1 pixels in front of the tensor
+#endif
         mskH[q] = mask;
       }
     } else {
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   auto issue_h = [&](auto KXc) __attribute__((always_inline)) {
     constexpr int KX = decltype(KXc)::value;
     const bool live = it < nK;
-    const unsigned soA = (unsigned)((it_ky * 3 + KX) * a.Cin + it_ch * 32) * 2u;
+    const unsigned soA = (unsigned)(it_ky * 3 + KX) * a.wsTap + (unsigned)it_ch * a.wsChunk;
     const int da = ((it >> 1) & 1) * GROUP + (it & 1) * TILE_A;
 #pragma unroll
     for (int p = 0; p < NPA; p++)
@@ -878,6 +887,14 @@ int launch(Args a, hipStream_t st) {
 // tap streams the whole channel depth of the pixel tile (256 KB per CU at Cin = 512) and the next tap finds nothing of it left:
 // FETCH_SIZE per launch 9.0x vs 2.2x the compulsory bytes at 512->512 @128^2 (profiles/r1_conv_hbm_traffic.txt).  The folded-upsample
 // variant keeps the taps outer (its per-tap source selection is too costly to redo every K tile).
+static int halo_mode() { static const int v = [] { const char* e = getenv("DMVAE_PP_HALO"); return e ? atoi(e) : 3; }(); return v; }   // 0: every kx tap staged on its own; bit 0: the 256 x 256 tile; bit 1: + the 128 x 512 and 64 x 1024 tiles; bit 3: no 64 x 1024 tile
+static bool korder_on() { static const bool v = [] { const char* e = getenv("DMVAE_PP_KORDER"); return e ? atoi(e) != 0 : true; }(); return v; }
+// the launches pick() sends to a HALO instantiation (given that dmvae_conv_pp_try takes the shape at all)
+static bool halo_for(int ks, int cout, bool plain, bool ups, bool f32) {
+  const int h = halo_mode();
+  return plain && !ups && !f32 && ks == 3 && h != 0 && korder_on() && (cout > 128 || (h & 2));
+}
+
 template <bool UPS, bool F32>
 int pick(const Args& a, hipStream_t st, bool gen) {
   static const bool ko = [] { const char* e = getenv("DMVAE_PP_KORDER"); return e ? atoi(e) != 0 : true; }();
@@ -892,14 +909,14 @@ int pick(const Args& a, hipStream_t st, bool gen) {
     return launch<256, 256, 2, 4, 4, UPS, F32, false>(a, st);
   } else {
     if constexpr (!F32) {
-      static const int halo = [] { const char* e = getenv("DMVAE_PP_HALO"); return e ? atoi(e) : 3; }();   // 0: every kx tap staged on its own; 1: the 256 x 256 tile only; 3: + the 128 x 512 tile
-      if (halo && ko && a.ks == 3) {   // plain 3x3: the three kx taps of a (chunk, ky) share one staged halo of the pixel tile
+      const int halo = halo_mode();
+      if (halo_for(a.ks, a.Cout, !gen, UPS, F32)) {   // plain 3x3: the three kx taps of a (chunk, ky) share one staged halo of the pixel tile
         if (a.Cout > 128) return a.gnpart ? launch<256, 256, 2, 4, 4, false, false, true, false, false, false, true, true>(a, st)
                                           : launch<256, 256, 2, 4, 4, false, false, true, false, false, false, false, true>(a, st);
         if ((halo & 2) && !(halo & 8) && a.Cout <= 64 && !a.gnpart)   // LPIPS trunk's 64-channel layers (lpips.py:116-153): a 128-row tile would be half padding
           return launch<64, 1024, 1, 8, 4, false, false, true, false, false, false, false, true>(a, st);
-        if (halo & 2) return a.gnpart ? launch<128, 512, 2, 4, 4, false, false, true, false, false, false, true, true>(a, st)
-                                      : launch<128, 512, 2, 4, 4, false, false, true, false, false, false, false, true>(a, st);
+        return a.gnpart ? launch<128, 512, 2, 4, 4, false, false, true, false, false, false, true, true>(a, st)
+                        : launch<128, 512, 2, 4, 4, false, false, true, false, false, false, false, true>(a, st);
       }
       if (a.gnpart) {  // GroupNorm statistics of the result in the epilogue (chunk-outer K order only)
         if (a.Cout <= 128) return launch<128, 512, 2, 4, 4, false, false, true, false, false, false, true>(a, st);
@@ -935,6 +952,23 @@ extern "C" int dmvae_debug_occupy(int blocks, int lds_bytes, int microseconds, h
 
 int dmvae_conv_geometry(const dmvae_conv_desc* d, int* ho, int* wo, int* so, int* pd, int* sd, int* fl);  // conv_fwd.hip
 
+// The gates of dmvae_conv_pp_try below + halo_for(): 1 when the descriptor runs on a HALO instantiation (and may therefore carry w_layout = 1).
+extern "C" int dmvae_conv_halo_applies(const dmvae_conv_desc* d) {
+  using namespace dmvae_conv_pp;
+  if (!d) return 0;
+  static const bool disabled = [] { const char* e = getenv("DMVAE_CONV_V1"); return e && atoi(e) != 0; }();
+  int ho, wo, so, pd, sd, fl;
+  if (disabled || dmvae_conv_geometry(d, &ho, &wo, &so, &pd, &sd, &fl) != 0) return 0;
+  const bool plain = !(d->upsample == 2 || d->stride == 2 || d->ks == 4 || d->transposed);
+  const long long M = (long long)d->n * ho * wo;
+  const long long xbytes = (long long)d->n * d->h * d->w * d->cin * 2;
+  const long long wbytes = (long long)d->cout * d->ks * d->ks * d->cin * 2;
+  static const long long min_m = [] { const char* e = getenv("DMVAE_PP_MINM"); return e ? atoll(e) : 16384ll; }();
+  if (d->cin % 32 != 0 || d->cout < 64 || d->cout % 8 != 0 || M < min_m || xbytes + (1ll << 22) >= (1ll << 31) || wbytes >= (1ll << 31)) return 0;
+  if (M >= (1ll << 24) || M * d->cout * (d->out_f32 ? 4 : 2) >= (1ll << 31)) return 0;
+  return halo_for(d->ks, d->cout, plain, fl != 0, d->out_f32 != 0) ? 1 : 0;
+}
+
 // gnpart / gn_groups: when non-null and the shape allows (bf16 result, plain or per-parity route, whole pixel tiles per image, groups of a multiple of 4
 // channels) the launch also leaves per-tile GroupNorm partials there and *gn_tp is set to the pixel-tile size (else 0: the caller computes the statistics itself).
 int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void* residual, void* y, const dmvae_conv_desc* d,
@@ -958,7 +992,14 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
   if (d->cin % 32 != 0 || d->cout < 64 || d->cout % 8 != 0 || M < min_m || xbytes + (1ll << 22) >= (1ll << 31) || wbytes >= (1ll << 31)) return 1;
   if (M >= (1ll << 24)) return 1;   // divmod_small
   if (M * d->cout * (d->out_f32 ? 4 : 2) >= (1ll << 31)) return 1;   // the epilogue addresses y (and the residual) through 32-bit buffer offsets; SENT must stay out of range
+  if (d->w_layout != 0 && !(d->w_layout == 1 && halo_for(d->ks, d->cout, plain, ups != 0, d->out_f32 != 0))) {
+    dmvae_set_error("conv2d_nhwc_fwd: w_layout %d is only accepted where dmvae_conv_halo_applies(d) is 1", d->w_layout);
+    return -1;
+  }
   Args a;
+  a.wsRow = d->w_layout ? 64u : (unsigned)(d->ks * d->ks * d->cin) * 2u;
+  a.wsTap = d->w_layout ? (unsigned)d->cout * 64u : (unsigned)d->cin * 2u;
+  a.wsChunk = d->w_layout ? (unsigned)(d->ks * d->ks) * (unsigned)d->cout * 64u : 64u;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.res = (const bf16*)residual; a.y = y;
   a.N = d->n; a.Hi = d->h; a.Wi = d->w; a.Cin = d->cin; a.Cout = d->cout;
   a.Ho = ho; a.Wo = wo; a.so = so; a.pd = pd; a.sd = sd;

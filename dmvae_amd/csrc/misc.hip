@@ -7,7 +7,8 @@ namespace dmvae_misc {
 // ---- conv weight packing -------------------------------------------------------------------
 // src: f32 [cout][cin][T] (PyTorch).  mode 0 (forward):  dst bf16 [cout_pad][T][cin_pad], dst[co][t][ci] = src[co][ci][t]
 //                                     mode 1 (dgrad):    dst bf16 [cin_pad][T][cout_pad], dst[ci][T-1-t][co] = src[co][ci][t]
-__global__ void pack_weight_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int cout, int cin, int T, int rows_pad,
+// dst2 (optional): the same values K-tile-major, dst2[col / 32][t][row][col % 32] (dmvae_conv_desc.w_layout = 1)
+__global__ void pack_weight_kernel(const float* __restrict__ src, bf16* __restrict__ dst, bf16* __restrict__ dst2, int cout, int cin, int T, int rows_pad,
                                    int cols_pad, int mode) {
   const size_t total = (size_t)rows_pad * T * cols_pad;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -22,6 +23,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, bf16* __restri
       if (row < cin && col < cout) v = src[((size_t)col * cin + row) * T + (T - 1 - t)];
     }
     dst[i] = (bf16)v;
+    if (dst2) dst2[(((size_t)(col >> 5) * T + t) * rows_pad + row) * 32 + (col & 31)] = (bf16)v;
   }
 }
 
@@ -339,13 +341,20 @@ static inline int grid_for(size_t n, int block = 256, int cap = 4096) {
 }  // namespace dmvae_misc
 using namespace dmvae_misc;
 
+extern "C" int dmvae_pack_conv_weight_v2(const void* w, void* out, void* out_kmajor, int cout, int cin, int ks, int rows_pad, int cols_pad,
+                                         int for_dgrad, hipStream_t stream);
 extern "C" int dmvae_pack_conv_weight(const void* w, void* out, int cout, int cin, int ks, int rows_pad, int cols_pad,
                                       int for_dgrad, hipStream_t stream) {
+  return dmvae_pack_conv_weight_v2(w, out, nullptr, cout, cin, ks, rows_pad, cols_pad, for_dgrad, stream);
+}
+extern "C" int dmvae_pack_conv_weight_v2(const void* w, void* out, void* out_kmajor, int cout, int cin, int ks, int rows_pad, int cols_pad,
+                                         int for_dgrad, hipStream_t stream) {
   DMVAE_CHECK_ARG(w && out && cout > 0 && cin > 0 && ks >= 1 && ks <= 7, "pack_conv_weight: bad argument");
+  DMVAE_CHECK_ARG(!out_kmajor || cols_pad % 32 == 0, "pack_conv_weight: the K-tile-major copy needs a multiple of 32 columns (got %d)", cols_pad);
   DMVAE_CHECK_ARG(rows_pad >= (for_dgrad ? cin : cout) && cols_pad >= (for_dgrad ? cout : cin), "pack_conv_weight: padding smaller than shape");
   const int T = ks * ks;
   const size_t total = (size_t)rows_pad * T * cols_pad;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)w, (bf16*)out, cout, cin, T, rows_pad,
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)w, (bf16*)out, (bf16*)out_kmajor, cout, cin, T, rows_pad,
                      cols_pad, for_dgrad ? 1 : 0);
   DMVAE_CHECK_LAUNCH();
   return 0;

@@ -52,7 +52,8 @@ def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad
     src = w.detach().contiguous()
     if subpixel:
         src = ops.subpixel_weight(src)
-    p = ops.pack_conv_weight(src, for_dgrad, rows_pad, cols_pad)
+    # 3x3 convs: the pack also writes the K-tile-major copy the kx-halo conv kernel reads (whole 128-B lines per weight tile; ops._weight_operand)
+    p = ops.pack_conv_weight(src, for_dgrad, rows_pad, cols_pad, kmajor=(src.dim() == 4 and src.shape[2] == 3 and not transposed and not subpixel))
     if transposed:       # [rows][taps*cols] -> [taps*cols][rows]: the B operand of the im2col convs' input-gradient GEMM
         p = p.view(p.shape[0], -1).t().contiguous()
     cache[key] = (ver, p)

@@ -48,6 +48,7 @@ _WS = {}
 KERNEL_TIMING = None
 _PP_KORDER = "false" if os.environ.get("DMVAE_PP_KORDER", "1") == "0" else "true"   # csrc/conv_pp.hip::pick
 _PP_SUBPIXEL = os.environ.get("DMVAE_PP_SUBPIXEL", "1") != "0"                        # csrc/conv_pp.hip::dmvae_conv_pp_try
+_KMAJOR = os.environ.get("DMVAE_PP_KMAJOR", "1") != "0"                               # 0: the halo conv reads the tap-major weights (A/B)
 _PP_HALO = int(os.environ.get("DMVAE_PP_HALO", "3") or "0")                            # csrc/conv_pp.hip::pick
 
 
@@ -62,8 +63,10 @@ def workspace(nbytes: int, device, slot: str = "main") -> torch.Tensor:
 
 
 # ---- conv / GEMM ------------------------------------------------------------------------------
-def pack_conv_weight(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad: int = 0) -> torch.Tensor:
-    """f32 [cout, cin, ks, ks] (or [out, in] for Linear) -> bf16 [rows, ks*ks, cols] kernel operand (parity mode: [rows, ks*ks, 6*cols])."""
+def pack_conv_weight(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad: int = 0, kmajor: bool = False) -> torch.Tensor:
+    """f32 [cout, cin, ks, ks] (or [out, in] for Linear) -> bf16 [rows, ks*ks, cols] kernel operand (parity mode: [rows, ks*ks, 6*cols]).
+    kmajor: the same launch also writes the K-tile-major copy [cols/32, ks*ks, rows, 32] (include/dmvae_hip.h: dmvae_conv_desc.w_layout = 1) and hangs it on
+    the result as ``_dmvae_kmajor``; conv2d_nhwc / conv2d_nhwc_gnstats hand that copy to the calls the library runs on its kx-halo kernel."""
     if parity.on():
         return parity.pack_conv_weight(w, for_dgrad, rows_pad, cols_pad)
     w = _req(w, f32, "weight")
@@ -74,9 +77,22 @@ def pack_conv_weight(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0
     rows, cols = (cin, cout) if for_dgrad else (cout, cin)
     rows_pad, cols_pad = max(rows_pad, rows), max(cols_pad, cols)
     out = torch.empty(rows_pad, ks * ks, cols_pad, dtype=bf16, device=w.device)
-    check(_lib.lib().dmvae_pack_conv_weight(w.data_ptr(), out.data_ptr(), cout, cin, ks, rows_pad, cols_pad, int(for_dgrad), _stream()),
+    out2 = torch.empty(cols_pad // 32, ks * ks, rows_pad, 32, dtype=bf16, device=w.device) if (kmajor and cols_pad % 32 == 0) else None
+    check(_lib.lib().dmvae_pack_conv_weight_v2(w.data_ptr(), out.data_ptr(), _ptr(out2), cout, cin, ks, rows_pad, cols_pad, int(for_dgrad), _stream()),
           "pack_conv_weight")
+    if out2 is not None:
+        out._dmvae_kmajor = out2
     return out
+
+
+def _weight_operand(w_packed: torch.Tensor, d) -> int:
+    """Address of the weight operand for descriptor d: the K-tile-major copy (and d.w_layout = 1) where the packed tensor carries one and the library says
+    the call runs on the kx-halo kernel (dmvae_conv_halo_applies), else the tap-major tensor itself."""
+    wk = getattr(w_packed, "_dmvae_kmajor", None)
+    if wk is not None and _KMAJOR and _lib.lib().dmvae_conv_halo_applies(ctypes.byref(d)):
+        d.w_layout = 1
+        return wk.data_ptr()
+    return w_packed.data_ptr()
 
 
 def subpixel_weight(w: torch.Tensor) -> torch.Tensor:
@@ -171,7 +187,7 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
     if timing is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_lib.lib().dmvae_conv2d_nhwc_fwd(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(), ctypes.byref(d),
+    check(_lib.lib().dmvae_conv2d_nhwc_fwd(x.data_ptr(), _weight_operand(w_packed, d), _ptr(bias), _ptr(residual), y.data_ptr(), ctypes.byref(d),
                                            _stream()), "conv2d_nhwc_fwd")
     if timing is not None:
         e1 = torch.cuda.Event(enable_timing=True)
@@ -216,7 +232,7 @@ def conv2d_nhwc_gnstats(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[
     if timing is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(L.dmvae_conv2d_nhwc_fwd_gnstats(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(), stats.data_ptr(), ws.data_ptr(),
+    check(L.dmvae_conv2d_nhwc_fwd_gnstats(x.data_ptr(), _weight_operand(w_packed, d), _ptr(bias), _ptr(residual), y.data_ptr(), stats.data_ptr(), ws.data_ptr(),
                                           ws.numel(), groups, float(eps), ctypes.byref(d), _stream()), "conv2d_nhwc_fwd_gnstats")
     if timing is not None:
         e1 = torch.cuda.Event(enable_timing=True)

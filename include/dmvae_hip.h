@@ -28,7 +28,7 @@ extern "C" {
 typedef struct ihipStream_t* dmvae_stream_t; /* == hipStream_t */
 
 const char* dmvae_last_error(void);
-/* ABI version; bumped when a signature changes. */
+/* ABI version; bumped when a signature or a struct changes.  2: dmvae_conv_desc gained its last field, w_layout (zero = the behaviour of version 1). */
 int dmvae_abi_version(void);
 
 /* ---- convolution / GEMM (MFMA-bound) -------------------------------------------------------- */
@@ -50,10 +50,18 @@ typedef struct dmvae_conv_desc {
   int32_t transposed;/* 1 (ks 4, or ks 3 with stride 2): x is the OUTPUT gradient [n,h,w,cin] of the conv described by (ks, stride) and y its
                         input gradient [n, (h-1)*stride+2, ..., cout] (ks 4) / [n, 2h, 2w, cout] (ks 3); weights packed with for_dgrad=1.
                         Forward entry point only. */
+  int32_t w_layout;  /* forward entry points: 0 = w is [cout][ks*ks][cin] (tap-major); 1 = K-tile-major [cin/32][ks*ks][cout][32], the second operand
+                        dmvae_pack_conv_weight_v2 writes -- a (32-channel chunk, tap) tile of the weights is then one contiguous run of whole 128-B lines
+                        (in the tap-major layout it is `cout` half-lines 2*ks*ks*cin bytes apart).  Accepted only where dmvae_conv_halo_applies(d) is 1
+                        (the kx-halo conv kernel); any other shape with w_layout = 1 is an error, not a fallback. */
 } dmvae_conv_desc;
 
+/* 1 when conv2d_nhwc_fwd / _gnstats run descriptor d on the kx-halo kernel (plain 3x3, bf16 result, large shapes: csrc/conv_pp.hip) and therefore accept
+ * w_layout = 1; 0 otherwise.  Pure function of d and of the process's DMVAE_PP_* environment. */
+int dmvae_conv_halo_applies(const dmvae_conv_desc* d);
+
 /* y[n,ho,wo,cout] = act( conv(x, w) + bias + residual ).
- * x: [n,h,w,cin] bf16; w: [cout, ks*ks, cin] bf16 (tap-major, see dmvae_pack_conv_weight);
+ * x: [n,h,w,cin] bf16; w: [cout, ks*ks, cin] bf16 (tap-major, see dmvae_pack_conv_weight; or its K-tile-major copy with d->w_layout = 1);
  * bias: [cout] f32 or NULL; residual: [n,ho,wo,cout] bf16 or NULL.
  * Replaces nn.Conv2d at models/flux_ae.py:32-35,63,65,67,101,237,274 and nn.Linear at
  * models/vae.py:58-62 (ks=1,h=w=1,n=tokens).  dgrad of a stride-1 conv is this same call with
@@ -164,6 +172,10 @@ int dmvae_transpose_bf16(const void* src, void* dst, int batch, int rows, int co
  * Padding rows/cols are zero-filled. */
 int dmvae_pack_conv_weight(const void* w, void* out, int cout, int cin, int ks, int rows_pad, int cols_pad,
                            int for_dgrad, dmvae_stream_t stream);
+/* The same pack, and in the same launch the K-tile-major copy out_kmajor[cols_pad/32][ks*ks][rows_pad][32] (dmvae_conv_desc.w_layout = 1) when
+ * out_kmajor is non-NULL (cols_pad % 32 == 0 then). */
+int dmvae_pack_conv_weight_v2(const void* w, void* out, void* out_kmajor, int cout, int cin, int ks, int rows_pad, int cols_pad,
+                              int for_dgrad, dmvae_stream_t stream);
 /* Sub-pixel form of Upsample's conv (models/flux_ae.py:103-107: conv3x3(F.interpolate(x, 2, 'nearest'))): output pixel (2y+py, 2x+px) only sees the 2x2
  * source pixels around (y, x), so taps that land on one source pixel are added up front --
  *   conv2d(interpolate(x,2), W, padding=1) == conv_transpose2d(x, WD, stride=2, padding=1),

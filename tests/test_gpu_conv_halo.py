@@ -59,3 +59,45 @@ def test_halo_conv_edge_columns_are_zero_padded():
     rx = torch.full((w_,), 3.0); rx[0] = rx[-1] = 2.0
     want = (ry[:, None] * rx[None, :] * cin).to(DEV)
     assert torch.equal(y, want[None, :, :, None].expand(n, h, w_, cout))
+
+
+@pytest.mark.parametrize("case", [(2, 96, 100, 64, 192), (2, 96, 100, 64, 128), (1, 128, 130, 96, 64)])
+@pytest.mark.parametrize("for_dgrad", [False, True])
+def test_halo_conv_kmajor_weights_bit_identical(case, for_dgrad):
+    """The K-tile-major weight copy (dmvae_pack_conv_weight_v2 / dmvae_conv_desc.w_layout = 1) holds the same values: same result, bit for bit."""
+    from dmvae_amd import ops, _lib
+    import ctypes
+    n, h, w_, cin, cout = case
+    g = torch.Generator(device="cpu").manual_seed(17 + cin + cout)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(DEV)
+    if for_dgrad:
+        cin, cout = cout, cin
+    x = torch.randn(n, h, w_, cin, generator=g).to(DEV).to(BF)
+    b = torch.randn(cout, generator=g).to(DEV)
+    w0 = ops.pack_conv_weight(w, for_dgrad)
+    w1 = ops.pack_conv_weight(w, for_dgrad, kmajor=True)
+    assert torch.equal(w0, w1) and hasattr(w1, "_dmvae_kmajor") and not hasattr(w0, "_dmvae_kmajor")
+    T = 9
+    assert torch.equal(w1._dmvae_kmajor, w0.view(cout, T, cin // 32, 32).permute(2, 1, 0, 3).contiguous())
+    d = _lib.ConvDesc(n, h, w_, cin, cout, 3, 0, 0, 0, 1, 0)
+    assert _lib.lib().dmvae_conv_halo_applies(ctypes.byref(d)) == 1
+    assert torch.equal(ops.conv2d_nhwc(x, w1, b, ks=3), ops.conv2d_nhwc(x, w0, b, ks=3))
+    y1, s1 = ops.conv2d_nhwc_gnstats(x, w1, b, ks=3, groups=32 if cout % 32 == 0 else 8)
+    y0, s0 = ops.conv2d_nhwc_gnstats(x, w0, b, ks=3, groups=32 if cout % 32 == 0 else 8)
+    assert torch.equal(y1, y0) and torch.equal(s1, s0)
+
+
+def test_kmajor_layout_is_refused_where_the_halo_kernel_does_not_run():
+    from dmvae_amd import _lib
+    import ctypes
+    L = _lib.lib()
+    x = torch.zeros(1, 16, 16, 64, device=DEV, dtype=BF)
+    w = torch.zeros(64, 9, 64, device=DEV, dtype=BF)
+    y = torch.zeros(1, 16, 16, 64, device=DEV, dtype=BF)
+    for d in (_lib.ConvDesc(1, 16, 16, 64, 64, 3, 0, 0, 0, 1, 0, 1),          # too few pixels for the large-shape kernel
+              _lib.ConvDesc(64, 16, 16, 64, 64, 1, 0, 0, 0, 1, 0, 1)):        # 1x1
+        assert L.dmvae_conv_halo_applies(ctypes.byref(d)) == 0
+        xx = torch.zeros(d.n, 16, 16, 64, device=DEV, dtype=BF); yy = torch.zeros(d.n, 16, 16, 64, device=DEV, dtype=BF)
+        ww = torch.zeros(64, d.ks * d.ks, 64, device=DEV, dtype=BF)
+        assert L.dmvae_conv2d_nhwc_fwd(xx.data_ptr(), ww.data_ptr(), None, None, yy.data_ptr(), ctypes.byref(d), None) != 0
+        assert b"w_layout" in L.dmvae_last_error()
