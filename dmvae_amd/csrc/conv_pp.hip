@@ -16,6 +16,10 @@
 //   * the two waves that share a SIMD (w and w+4) alternate roles every interval: one issues its 12 ds_read_b128 +
 //     LDS-DMA while the other runs its 32 MFMAs (512 cycles) under s_setprio(1); two s_barrier per K tile keep the roles in step.
 //
+//   * plain 3x3 convs with a bf16 result run the HALO instantiations (described at the kernel template): the three kx taps of a (channel chunk, ky) read one
+//     staged halo of the pixel tile, the weights come K-tile-major (dmvae_conv_desc.w_layout = 1) so that a weight tile is whole 128-B lines; tiles 256 x 256,
+//     128 x 512 and, for 64 output channels, 64 x 1024.  What that was worth, and the timing experiments behind it (DMVAE_PP_EXP): DESIGN.md 8.12 / 8.13.
+//
 // Hazards (B_k = k-th workgroup barrier; group 0 = waves 0-3, group 1 = waves 4-7, one barrier behind):
 //   RAW  tile t+1 is read after B_{2t+2}; every wave waits (vmcnt) for its own pieces of t+1 at the end of its LOAD(t),
 //        i.e. before B_{2t+1} (group 0) / B_{2t+2} (group 1).
