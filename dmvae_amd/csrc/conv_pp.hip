@@ -38,6 +38,12 @@
 #ifndef DMVAE_PP_EXP
 #define DMVAE_PP_EXP 0
 #endif
+#ifndef DMVAE_PP_AUXA   // cache-policy bits of the HALO loop's LDS-DMA (weights / activations): 1 = sc0, 2 = nt, 16 = sc1; A/B builds only
+#define DMVAE_PP_AUXA 0
+#endif
+#ifndef DMVAE_PP_AUXB
+#define DMVAE_PP_AUXB 0
+#endif
 
 namespace dmvae_conv_pp {
 
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     const int da = ((it >> 1) & 1) * GROUP + (it & 1) * TILE_A;
 #pragma unroll
     for (int p = 0; p < NPA; p++)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + ((wave * NPA + p) * 16 < TM ? da + (wave * NPA + p) * 1024 : DUMP_OFF)), 16, live ? voffA[p] : SENT, soA, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + ((wave * NPA + p) * 16 < TM ? da + (wave * NPA + p) * 1024 : DUMP_OFF)), 16, live ? voffA[p] : SENT, soA, 0, DMVAE_PP_AUXA);
     if constexpr (KX == 0) {
       const unsigned soH = (unsigned)(it_ky * a.Wi) * a.Cin * 2u + (unsigned)it_ch * 64u;
       const int dh = ((it_ch + it_ky) & 1) * GROUP + 2 * TILE_A;
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       for (int q = 0; q < NPH; q++) {
         const unsigned v = (live && ((mskH[HALO ? q : 0] >> it_ky) & 1u)) ? ctrH[HALO ? q : 0] : SENT;
         const int dst = q < NPB ? dh + (wave * NPB + q) * 1024 : (wave == 0 ? dh + TP * 64 : DUMP_OFF);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + dst), 16, v, soH, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + dst), 16, v, soH, 0, DMVAE_PP_AUXB);
       }
     }
     it++;
