@@ -467,9 +467,11 @@ int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_o
     const double e0 = useful / ((double)m0 * 256 * n0 * 256), e1 = 0.78 * useful / ((double)m1 * 128 * n1 * 384);
     static const bool relax = [] { const char* e = getenv("DMVAE_WGRAD_PP_RAGGED"); return e ? atoi(e) != 0 : true; }();
     const bool exact0 = d->cout % 256 == 0 && (d->cin / 128) % 2 == 0;
-    static const int force = [] { const char* e = getenv("DMVAE_WGRAD_PP_CFG"); return e ? atoi(e) : -1; }();   // A/B: 1 = the 128 x 384 (halo) tile wherever it applies
-    const bool halo_ok = d->ks == 3 && d->stride <= 1 && !d->upsample && !d->transposed && d->w % 64 == 0;
-    if (force == 1 && halo_ok) { cfg = 1; mtiles = m1; ntiles = n1; }
+    // The 128 x 384 tile's halo form with 64-pixel K tiles (190 instead of 128 FLOP per staged byte) also beats the 256 x 256 tile on shapes that tile fits
+    // exactly once the reduction is long: +3-8 % from 2^19 pixels on, +-0 below.  DMVAE_WGRAD_PP_CFG: 0 = never, 1 = wherever it applies.
+    static const int force = [] { const char* e = getenv("DMVAE_WGRAD_PP_CFG"); return e ? atoi(e) : -1; }();
+    const bool halo_ok = d->ks == 3 && d->stride <= 1 && !d->upsample && !d->transposed && d->w % 64 == 0 && wgrad_pp_halo_on();
+    if (halo_ok && (force == 1 || (force < 0 && M >= (1ll << 19)))) { cfg = 1; mtiles = m1; ntiles = n1; }
     else if (exact0 || (relax && e0 > e1)) { cfg = 0; mtiles = m0; ntiles = n0; }
     else { cfg = 1; mtiles = m1; ntiles = n1; }
   }

@@ -27,6 +27,7 @@ SHAPES = [
     (4, 256, 256, 256, 128, 0),
     (4, 64, 64, 512, 512, 1),        # Upsample: nearest x2 folded into the gather, 64^2 -> 128^2
     (32, 64, 64, 512, 512, 0),       # the bench's batch
+    (32, 128, 128, 256, 256, 0),     # ... 2^19 pixels: from here on the weight gradient runs the 128 x 384 halo tile on these channel counts too
 ]
 IDS = ["%dx%d^2_%d-%d%s" % (n, h, ci, co, "_ups" if u else "") for n, h, w, ci, co, u in SHAPES]
 
