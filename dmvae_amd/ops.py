@@ -20,7 +20,7 @@ from ._lib import ConvDesc, check
 bf16 = torch.bfloat16
 f32 = torch.float32
 
-ACT_NONE, ACT_SILU, ACT_RELU, ACT_RELU_GATE, ACT_LEAKY = 0, 1, 2, 3, 4
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_RELU_GATE, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3, 4, 5
 
 
 def _stream() -> int:
@@ -331,6 +331,52 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
                                            m * k if a.dim() == 3 else 0, n * k if b.dim() == 3 else 0, m * n, act, int(out_f32), _stream()),
           "gemm_nt_batched")
     return c
+
+
+def linear_plan(m: int, n: int, k: int) -> Tuple[int, int, int]:
+    """(menu index, tile columns, tile rows) dmvae_linear_bf16 uses for an [m, k] x [n, k]^T problem (csrc/gemm_pp.hip::plan)."""
+    tc, tr = ctypes.c_int(0), ctypes.c_int(0)
+    idx = _lib.lib().dmvae_linear_bf16_plan(m, n, k, ctypes.byref(tc), ctypes.byref(tr))
+    return idx, tc.value, tr.value
+
+
+def linear_supported(m: int, n: int, k: int) -> bool:
+    """Shapes dmvae_linear_bf16 takes: K a multiple of 32, N of 8, every operand below 2 GiB.  Problems with fewer than 64 rows (adaLN / embedder Linears on
+    one row per sample) are left to the small batched NT kernel (gemm_nt): a 128-256-row tile would be nearly all padding."""
+    return k >= 32 and k % 32 == 0 and n % 8 == 0 and m >= 64 and m * max(n, k) * 2 < (1 << 31) and n * k * 2 < (1 << 31)
+
+
+def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, want_pre: bool = False,
+                out_f32: bool = False):
+    """F.linear(x, w, bias) under autocast(bf16) on the hand-written GEMM (csrc/gemm_pp.hip): x [..., K] bf16, w [N, K] bf16 (the parameter's bf16 copy;
+    a [K_in, N_out]-transposed copy makes the same call the input gradient), bias [N] bf16 (autocast's operand) or f32, f32 accumulation, bf16 result
+    [..., N] (f32 with out_f32).  act = ACT_GELU / ACT_SILU fuses the activation on the bf16-rounded pre-activation (bit-identical to the two-kernel route);
+    want_pre additionally returns that pre-activation: (y, y_pre)."""
+    x = _req(x, bf16, "x")
+    w = _req(w, bf16, "w")
+    k = x.shape[-1]
+    n = w.shape[0]
+    assert w.dim() == 2 and w.shape[1] == k, (x.shape, w.shape)
+    m = x.numel() // k
+    bias_bf16 = 0
+    if bias is not None:
+        if bias.dtype == bf16:
+            bias_bf16 = 1
+        _req(bias, bf16 if bias_bf16 else f32, "bias")
+        assert bias.numel() == n
+    y = torch.empty(*x.shape[:-1], n, dtype=f32 if out_f32 else bf16, device=x.device)
+    y_pre = torch.empty(*x.shape[:-1], n, dtype=bf16, device=x.device) if (want_pre and act != ACT_NONE) else None
+    timing = KERNEL_TIMING
+    if timing is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_lib.lib().dmvae_linear_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(y_pre), m, n, k, k, k, n, act, bias_bf16, int(out_f32),
+                                       _stream()), "linear_bf16")
+    if timing is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        timing.append(("gemm_pp_kernel", e0, e1, 2.0 * m * n * k))
+    return (y, y_pre) if want_pre else y
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, out_f32: bool = False) -> torch.Tensor:

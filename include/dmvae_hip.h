@@ -154,6 +154,20 @@ int dmvae_gemm_tn_batched(const void* A, const void* B, void* C, void* workspace
                           int N, int K, int batch, long long a_bs, long long b_bs, long long c_bs, float alpha,
                           int out_f32, dmvae_stream_t stream);
 
+/* nn.Linear under autocast(bf16) for the transformer blocks: Y[M][N] = act(X[M][K] . W[N][K]^T + bias[N]).
+ * Replaces the library GEMM behind F.linear at: timm's ViT blocks reached through models/vae.py:47-53 (attn.qkv / attn.proj / mlp.fc1 + nn.GELU /
+ * mlp.fc2 and the patch embedding as a GEMM over patches), diffusion/lightningdit/lightningdit.py:34-93,173-252 (attn.qkv, attn.proj),
+ * diffusion/lightningdit/swiglu_ffn.py:15-36 (w12, w3); with W := a transposed bf16 copy of the weight it is their input gradient dX = dY . W.
+ * x [M][lda], w [N][ldw], y [M][ldy] row-major bf16 (y f32 when out_f32); leading dimensions in elements, multiples of 8; K % 32 == 0, N % 8 == 0;
+ * every operand below 2 GiB.  bias: f32 [N], or bf16 [N] when bias_bf16 (what autocast hands the library), or NULL.
+ * act: 0 none, 1 SiLU, 5 exact (erf) GELU -- applied to the bf16-ROUNDED pre-activation, so the result is bit-identical to this call with act = 0
+ * followed by dmvae_gelu_fwd / dmvae_silu_fwd; y_pre (bf16 [M][ldy], may be NULL; act != 0 only) also receives that pre-activation.
+ * Tile shape per (M, N, K) from a fixed menu by rounds x tile cost (dmvae_linear_bf16_plan returns the menu index and the tile's columns / rows);
+ * results do not depend on the tile (one f32 accumulation chain per output element, in K order).  csrc/gemm_pp.hip. */
+int dmvae_linear_bf16(const void* x, const void* w, const void* bias, void* y, void* y_pre, int M, int N, int K, int lda, int ldw, int ldy,
+                      int act, int bias_bf16, int out_f32, dmvae_stream_t stream);
+int dmvae_linear_bf16_plan(int M, int N, int K, int* tile_cols, int* tile_rows);
+
 /* P = softmax(scale*S) per row (S f32 [rows][cols] -> P bf16), and its backward
  * dS = scale * P .* (dP - rowsum(dP .* P)) (dP f32, dS bf16).  F.scaled_dot_product_attention's
  * softmax at flux_ae.py:47 (single head, scale = 1/sqrt(C)). */

@@ -1,0 +1,161 @@
+"""Parity of the hand-written Linear GEMM (csrc/gemm_pp.hip, `ops.linear_bf16`) at the shapes of the transformer blocks it serves: ViT-L at batch 32
+(M = 32 x 257 = 8224 tokens: qkv / proj / fc1 + GELU / fc2; models/vae.py:47-53 -> timm blocks), the patch embedding as a GEMM (M = 8192, K = 768), and
+LightningDiT-XL/1 (width 1152: qkv / proj / w12 / w3 at M = 4096 and 16384; diffusion/lightningdit/lightningdit.py:34-93, swiglu_ffn.py:15-36) -- every one of
+them a tile-quantisation edge: M = 8224 leaves a 32-row remainder whatever the tile, N = 1152 is 4.5 tiles of 256 columns.
+
+Reference: the same contraction in fp64 ON THE GPU over the same bf16-rounded operands (rocBLAS dgemm: independent of this build's kernels).  Bars, per assert:
+  * f32 result: max |y - ref| / max |ref| < 1e-5 over EVERY element (f32 accumulation order is all that differs: products of bf16 operands are exact in f32),
+    and on a random 1 % sample, element by element, |y_i - ref_i| <= 1e-4 |ref_i| + 2e-5 rms(ref);
+  * the bf16 result is bit-for-bit the round-to-nearest-even of the f32 result (same kernel, same accumulation chain);
+  * every tile of the menu gives the bit-identical result (one K-ordered accumulation chain per element, whatever the tile);
+  * fused GELU / SiLU epilogue == the act = 0 call followed by the standalone kernel, bit for bit; the saved pre-activation == the act = 0 result;
+  * rows past M / columns past N are never written (the output sits inside a sentinel-filled buffer);
+  * two runs are bit-identical."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+#          M,     N,    K      what
+SHAPES = [
+    (8224, 3072, 1024),    # ViT-L qkv
+    (8224, 1024, 1024),    # ViT-L proj
+    (8224, 4096, 1024),    # ViT-L fc1
+    (8224, 1024, 4096),    # ViT-L fc2
+    (8192, 1024, 768),     # patch embedding over 16 x 16 x 3 patches
+    (4096, 1152, 1152),    # DiT-XL/1 proj, batch 16
+    (4096, 3456, 1152),    # DiT-XL/1 qkv, batch 16
+    (16384, 1152, 1152),   # DiT-XL/1 proj, batch 64
+    (16384, 6144, 1152),   # DiT-XL/1 w12, batch 64
+    (16384, 1152, 3072),   # DiT-XL/1 w3, batch 64
+    (8224, 32, 2048),      # bottleneck MLP's second Linear (N = 32 output columns)
+    (200, 72, 96),         # small and ragged in every dimension
+]
+IDS = ["%dx%dx%d" % s for s in SHAPES]
+
+
+def _operands(m, n, k, seed=0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn(m, k, device=DEV, generator=g).to(BF)
+    w = (torch.randn(n, k, device=DEV, generator=g) * (k ** -0.5)).to(BF)
+    b = torch.randn(n, device=DEV, generator=g)
+    return x, w, b
+
+
+def _ref64(x, w, b):
+    return torch.addmm(b.double(), x.double(), w.double().t())
+
+
+def _check(y, ref, what, seed=0):
+    scale = ref.abs().max().item()
+    err = (y.double() - ref).abs().max().item() / scale
+    assert err < 1e-5, f"{what}: max|d|/max|ref| = {err:.2e}"
+    fy, fr = y.reshape(-1), ref.reshape(-1)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    idx = torch.randint(0, fr.numel(), (max(1000, fr.numel() // 100),), device=DEV, generator=g)
+    rms = ref.pow(2).mean().sqrt().item()
+    d = (fy[idx].double() - fr[idx]).abs()
+    bound = 1e-4 * fr[idx].abs() + 2e-5 * rms
+    assert bool((d <= bound).all()), f"{what}: {(d > bound).sum().item()} of {idx.numel()} sampled elements outside 1e-4 |ref| + 2e-5 rms"
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+def test_linear_vs_fp64(shape):
+    from dmvae_amd import ops
+    m, n, k = shape
+    x, w, b = _operands(m, n, k)
+    ref = _ref64(x, w, b)
+    y32 = ops.linear_bf16(x, w, b, out_f32=True)
+    _check(y32, ref, "f32 result %s" % (shape,))
+    y16 = ops.linear_bf16(x, w, b)
+    assert torch.equal(y16, y32.to(BF)), "bf16 result is not RNE(f32 result)"
+    assert torch.equal(y16, ops.linear_bf16(x, w, b)), "rerun differs"
+    # bf16 bias, the operand autocast hands the library: the bias is widened to f32 and added to the f32 accumulator
+    yb = ops.linear_bf16(x, w, b.to(BF), out_f32=True)
+    _check(yb, _ref64(x, w, b.to(BF).float()), "bf16-bias result %s" % (shape,))
+    # no bias
+    yn = ops.linear_bf16(x, w, None, out_f32=True)
+    _check(yn, x.double() @ w.double().t(), "no-bias result %s" % (shape,))
+
+
+@pytest.mark.parametrize("shape", [(8224, 4096, 1024), (4096, 1152, 1152), (200, 72, 96)], ids=["fc1", "dit_proj", "ragged"])
+def test_fused_activation_is_the_two_kernel_route(shape):
+    from dmvae_amd import ops
+    m, n, k = shape
+    x, w, b = _operands(m, n, k, seed=1)
+    h = ops.linear_bf16(x, w, b.to(BF))
+    g, pre = ops.linear_bf16(x, w, b.to(BF), act=ops.ACT_GELU, want_pre=True)
+    assert torch.equal(pre, h), "saved pre-activation differs from the plain Linear"
+    assert torch.equal(g, ops.gelu(h.view(-1)).view_as(h)), "fused GELU differs from Linear -> gelu kernel"
+    assert torch.equal(ops.linear_bf16(x, w, b.to(BF), act=ops.ACT_GELU), g), "without the second result the first one changed"
+    s = ops.linear_bf16(x, w, b.to(BF), act=ops.ACT_SILU)
+    assert torch.equal(s, ops.silu(h.view(-1)).view_as(h)), "fused SiLU differs from Linear -> silu kernel"
+    # and against fp64 on the bf16-rounded pre-activation: erf-form GELU
+    ref = torch.nn.functional.gelu(h.double())
+    assert ((g.double() - ref).abs() <= 2 ** -7 * ref.abs() + 1e-30).all(), "GELU of the rounded pre-activation is more than a bf16 ulp off"
+
+
+def test_rows_and_columns_past_the_end_are_not_written():
+    """The output sits in the middle of a sentinel-filled buffer; M and N are not multiples of any tile (ragged rows AND columns), and leading dimensions
+    larger than the rows are honoured through the C ABI."""
+    from dmvae_amd import _lib, ops
+    m, n, k = 1000, 200, 64
+    x, w, b = _operands(m, n, k, seed=2)
+    ldy = 208
+    pad = 4096
+    buf = torch.full((pad + m * ldy + pad,), -7.0, device=DEV, dtype=BF)
+    y = buf[pad:pad + m * ldy].view(m, ldy)
+    rc = _lib.lib().dmvae_linear_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None, m, n, k, k, k, ldy, 0, 0, 0,
+                                      torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert bool((buf[:pad] == -7.0).all()) and bool((buf[pad + m * ldy:] == -7.0).all()), "wrote outside the output"
+    assert bool((y[:, n:] == -7.0).all()), "wrote columns past N"
+    assert torch.equal(y[:, :n], ops.linear_bf16(x, w, b)), "strided result differs from the dense one"
+
+
+def test_argument_errors():
+    from dmvae_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros(64, 48, device=DEV, dtype=BF)
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), None, 64, 64, 48, 48, 48, 64, 0, 0, 0, st) != 0      # K % 32
+    assert b"K" in L.dmvae_last_error()
+    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), None, 64, 60, 32, 32, 32, 64, 0, 0, 0, st) != 0      # N % 8
+    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), None, 64, 64, 32, 32, 32, 64, 2, 0, 0, st) != 0      # act
+    assert L.dmvae_linear_bf16(None, x.data_ptr(), None, x.data_ptr(), None, 64, 64, 32, 32, 32, 64, 0, 0, 0, st) != 0
+
+
+_TILE_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from dmvae_amd import ops
+g = torch.Generator(device="cuda").manual_seed(3)
+out = {}
+for m, n, k in [(8224, 1024, 1024), (4096, 1152, 1152), (777, 520, 96)]:
+    x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16)
+    b = torch.randn(n, device="cuda", generator=g)
+    out[(m, n, k)] = ops.linear_bf16(x, w, b, out_f32=True).cpu()
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_every_tile_of_the_menu_gives_the_same_bits(tmp_path):
+    """DMVAE_GEMM_CFG forces one menu entry for the whole process (the plan is latched at first use), so each runs in a fresh process."""
+    res = []
+    for cfg in range(10):
+        f = tmp_path / ("cfg%d.pt" % cfg)
+        env = dict(os.environ, DMVAE_GEMM_CFG=str(cfg))
+        subprocess.run([sys.executable, "-c", _TILE_SCRIPT % ROOT, str(f)], check=True, env=env, timeout=600)
+        res.append(torch.load(f))
+    for cfg in range(1, 10):
+        for key in res[0]:
+            assert torch.equal(res[0][key], res[cfg][key]), f"tile {cfg} differs from tile 0 at {key}"

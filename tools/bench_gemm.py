@@ -1,23 +1,80 @@
 #!/usr/bin/env python
-"""ViT-L GEMM shapes (tokens = 32 x 257): conv_pp as a 1x1 conv vs torch F.linear (hipBLASLt), TFLOP/s."""
-import os, sys
+"""Linear-layer GEMM shapes of the transformer blocks (ViT-L at batch 32: tokens = 32 x 257; LightningDiT-XL/1 at batch 16 / 64): the hand-written GEMM
+(csrc/gemm_pp.hip, `ops.linear_bf16`) vs the vendor library under this build's tuned solution table (F.linear -> hipBLASLt, dmvae_amd/gemm_select.py) vs
+conv_pp as a 1x1 conv.  Random-normal operands, interleaved rounds in one process, median microseconds per call and TFLOP/s.
+  python tools/bench_gemm.py            the planned tile per shape
+  python tools/bench_gemm.py --sweep    every tile of the menu per shape (calibrates csrc/gemm_pp.hip::g_cfg's cost column)
+  python tools/bench_gemm.py --json F   also write the rows to F"""
+import argparse, ctypes, json, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
-from dmvae_amd import ops
-M = 32 * 257
-def timed(fn, reps=20):
-    for _ in range(3): fn()
+from dmvae_amd import _lib, gemm_select, ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--sweep", action="store_true")
+ap.add_argument("--json", default="")
+ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--shapes", default="")
+args = ap.parse_args()
+gemm_select.enable()
+L = _lib.lib()
+dbg = ctypes.CDLL(_lib.LIB_PATH).dmvae_debug_gemm_cfg
+dbg.argtypes, dbg.restype = [ctypes.c_int], None
+
+SHAPES = [("vit qkv", 8224, 3072, 1024), ("vit proj", 8224, 1024, 1024), ("vit fc1", 8224, 4096, 1024), ("vit fc2", 8224, 1024, 4096),
+          ("patch", 8192, 1024, 768),
+          ("dit16 qkv", 4096, 3456, 1152), ("dit16 proj", 4096, 1152, 1152), ("dit16 w12", 4096, 6144, 1152), ("dit16 w3", 4096, 1152, 3072),
+          ("dit64 qkv", 16384, 3456, 1152), ("dit64 proj", 16384, 1152, 1152), ("dit64 w12", 16384, 6144, 1152), ("dit64 w3", 16384, 1152, 3072),
+          ("dit32 qkv", 8192, 3456, 1152), ("dit32 w12", 8192, 6144, 1152)]
+if args.shapes:
+    SHAPES = [s for s in SHAPES if any(t in s[0] for t in args.shapes.split(","))]
+NCFG = 10
+
+
+def once(fn, reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps): fn()
-    e1.record(); torch.cuda.synchronize()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for name, k, n in [("qkv", 1024, 3072), ("proj", 1024, 1024), ("fc1", 1024, 4096), ("fc2", 4096, 1024)]:
-    x = torch.randn(M, k, device="cuda").to(torch.bfloat16)
+
+
+rows = []
+for name, m, n, k in SHAPES:
+    x = torch.randn(m, k, device="cuda").to(torch.bfloat16)
     w = (torch.randn(n, k, device="cuda") * 0.02).to(torch.bfloat16)
     b = torch.randn(n, device="cuda")
     bb = b.to(torch.bfloat16)
-    fl = 2.0 * M * k * n
-    t_mine = timed(lambda: ops.conv2d_nhwc(x.view(1, 1, M, k), w.view(n, 1, k), b, ks=1))
-    t_blas = timed(lambda: F.linear(x, w, bb))
-    print(f"{name:5s} M={M} K={k} N={n}: conv_pp {t_mine:7.1f} us {fl/t_mine/1e6:6.1f} TF/s | hipBLASLt {t_blas:7.1f} us {fl/t_blas/1e6:6.1f} TF/s")
+    fl = 2.0 * m * k * n
+    arms = {"hipblaslt": lambda: F.linear(x, w, bb)}
+    if n >= 64 and k % 32 == 0 and m >= 16384:
+        arms["conv_pp"] = lambda: ops.conv2d_nhwc(x.view(1, 1, m, k), w.view(n, 1, k), b, ks=1)
+    plan_idx, tc, tr = ops.linear_plan(m, n, k)
+
+    def mk(cfg):
+        def f():
+            dbg(cfg)
+            ops.linear_bf16(x, w, bb)
+        return f
+    if args.sweep:
+        for c in range(NCFG):
+            arms["gemm_pp[%d]" % c] = mk(c)
+    else:
+        arms["gemm_pp"] = mk(-1)
+    for f in arms.values():
+        for _ in range(3):
+            f()
+    t = {a: [] for a in arms}
+    for _ in range(args.rounds):
+        for a, f in arms.items():
+            t[a].append(once(f, args.reps))
+    dbg(-1)
+    med = {a: statistics.median(v) for a, v in t.items()}
+    line = f"{name:10s} M={m:5d} N={n:4d} K={k:4d} plan={plan_idx}({tc}x{tr}) | " + " | ".join(f"{a} {med[a]:6.1f}us {fl / med[a] / 1e6:6.0f}TF" for a in arms)
+    print(line, flush=True)
+    rows.append({"name": name, "M": m, "N": n, "K": k, "plan": plan_idx, "tile": [tc, tr], "us": med, "tflops": {a: fl / med[a] / 1e6 for a in arms}})
+if args.json:
+    json.dump(rows, open(args.json, "w"), indent=1)
