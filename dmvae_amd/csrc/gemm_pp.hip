@@ -11,17 +11,20 @@
 // 64 columns x 16 * BP16 rows) or 64 rows (wave grid 2 x 4), and the host picks, per (M, N, K), the instantiation whose round count x tile cost is lowest
 // (dmvae_gemm_pp_plan): e.g. proj (N = 1024) runs 208 tiles of 256 x 160 in ONE round instead of 132 of 256 x 256 on half the chip.
 //
-// Epilogue: + bias (f32, or bf16 the way autocast hands it to the library), optional exact GELU (nn.GELU() of timm's Mlp) applied to the bf16-rounded
-// pre-activation -- bit-identical to the Linear followed by csrc/vit_bwd.hip::gelu_fwd_kernel -- with the pre-activation optionally stored as a second result
-// (the training route saves it for the backward pass), or SiLU; bf16 or f32 result.  Rows past M / columns past N never leave the CU: every store's per-lane
-// offset is out of the descriptor's range for them (the range check does not see the scalar offset, so validity never rides on it).
+// Epilogue: bias (f32, or bf16 the way autocast hands it to the library) as the accumulators' initial value, optional exact GELU (nn.GELU() of timm's Mlp) or
+// SiLU applied to the bf16-rounded pre-activation -- bit-identical to the Linear followed by csrc/vit_bwd.hip::gelu_fwd_kernel / misc.hip::silu_fwd_kernel --,
+// bf16 or f32 result.  Rows past M / columns past N never leave the CU: every store's per-lane offset is out of the descriptor's range for them (the range
+// check does not see the scalar offset, so validity never rides on it).
 #include "common.h"
 #include "dmvae_hip.h"
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef DMVAE_GEMM_EXP   // timing experiments (tools/probes/build_variant.sh): 1 = no epilogue stores, 2 = no staging and no stores, 4 = nt stores
-#define DMVAE_GEMM_EXP 0
+#ifndef DMVAE_GEMM_NOSTORE   // timing experiment: the epilogue's arithmetic without its stores (dropped through an out-of-range offset)
+#define DMVAE_GEMM_NOSTORE 0
+#endif
+#ifndef DMVAE_GEMM_AUX    // cache-policy bits of the epilogue's stores (2 = nt); A/B builds
+#define DMVAE_GEMM_AUX 0
 #endif
 
 namespace dmvae_gemm_pp {
@@ -31,10 +34,11 @@ struct Args {
   const bf16* w;     // [N][ldw]
   const void* bias;  // [N] f32 / bf16, or null
   void* y;           // [M][ldy] bf16 / f32
-  bf16* y2;          // [M][ldy] bf16 or null: the pre-activation (act != 0)
   int M, N, K, lda, ldw, ldy;
   int act, bias_bf16;
   int ntn, total;    // column tiles, tiles
+  float inv_ntn;     // 1 / ntn
+  unsigned long long* dbg;   // optional s_memtime stamps per block (dmvae_debug_gemm_timing): [block][tile 0..3][4], null in production
 };
 
 constexpr unsigned SENT = 0x80000000u;  // voffset beyond any descriptor's num_records: loads return zeros, stores are dropped
@@ -50,244 +54,300 @@ __device__ __forceinline__ void wait_vmcnt() {   // through the builtin: the com
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }   // vit_bwd.hip::gelu_f
 
 // TM: output columns (weight rows) per tile, TP: output rows (tokens) per tile, WM x WP: wave grid over (columns, rows).
+//
+// One continuous K-tile stream per block: the ring does not care which output tile a K tile belongs to, so the last three K steps of a tile issue the first three
+// K tiles of the block's NEXT tile (and its bias slice, one more 1-KiB piece into a two-slot LDS region) and the next tile's loop starts on operands that have
+// already landed.
+//
+// Epilogue straight from the accumulators, no LDS: the MFMA runs with the TOKENS as its rows (D[token][column]: lane (c = lane & 15, g = lane >> 4) holds tokens
+// 4g .. 4g + 3 of a token block at column c of a column block), and the weight rows are DMA'd in a permuted order -- LDS row 16 i + c of a wave's column range
+// holds column CL * c + i (CL = column blocks per wave) -- so that a lane's CL accumulators of one token are CL CONSECUTIVE columns and the 16 lanes of a group
+// hold 16 CL consecutive columns of that token: one store instruction writes 4 rows x 256 contiguous bytes (CL = 8) with consecutive lanes on consecutive bytes.
+// History, measured with s_memtime stamps (tools/probes/time_gemm_pp.py, k-cycles per 256 x 192 tile): staging the tile through LDS in f32 like conv_pp 6-8;
+// columns along the MFMA rows + a DPP exchange between lanes m and m ^ 8 (8 rows x 128 B per instruction, but a row's chunks on lanes 8 apart) 6.5, of which
+// stores 4.0 (42 cycles per store instruction, the same with or without the exchange: what the store path wants is consecutive lanes on consecutive bytes).
+// The bias is the accumulators' initial value (read from the LDS slice in the MFMA layout), not an epilogue add.
+//
+// vmcnt bookkeeping (per wave; P = NP pieces per K tile).  LDS-DMA loads retire in order among themselves, but stores do NOT retire in order with loads (a first
+// version that counted on it -- "[K1'][K2'][S stores][K3]: at most 2P + S outstanding means K1' has landed" -- read K tiles before they had landed whenever the
+// stores were acknowledged first: wrong results on the first call, right ones on a rerun that found the same bytes still in LDS).  So no wait ever leaves a store
+// AND a needed load behind it: a count is only trusted where it forces every store to have retired.
+//   kernel start        [bias K0][K1][K2]                                wait 0
+//   tile entry          K0 .. K2 and the bias slice have landed; the previous tile's stores may be in flight
+//   t = 0, 1            + K3, + K4                                       no wait (K1, K2 landed at the previous tile's end)
+//   t = 2               [S stores in any state][K3][K4][K5]              wait 2P: at most 2P outstanding = every store and K3 retired
+//   t = 3 .. nK - 4     steady state                                     wait 2P
+//   t = nK - 3, nK - 2  + [bias' K0'] (P + 1 pieces), + K1'              wait 2P + 1
+//   t = nK - 1          + K2'                                            wait 0: the next tile's first three K tiles have landed before this tile's stores go out
+// Needs nK >= 6 (K >= 192); the host sends shorter reductions to the small batched kernel.  No scratch: a spilled register's reload is a VMEM load, and
+// the wait the compiler puts behind it drains the whole prefetch queue (measured: 10 k cycles per tile with 31 spilled VGPRs).
 template <int TM, int TP, int WM, int WP, bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__
-  constexpr int NBUF = 4, PF = NBUF - 1;
-  constexpr int BM16 = TM / WM / 16, BP16 = TP / WP / 16;   // 16 x 16 accumulator blocks per wave
-  static_assert(WM * WP == 8 && BM16 * 16 * WM == TM && BP16 * 16 * WP == TP && BM16 * BP16 <= 32, "8 waves, at most 32 accumulators each");
-  constexpr int TILE_A = TM * 64, TILE_B = TP * 64, SLOT = TILE_A + TILE_B;
+  constexpr int NBUF = 4;
+  constexpr int CL = TM / WM / 16, BT = TP / WP / 16;   // 16 x 16 accumulator blocks per wave: CL column blocks (= consecutive columns per lane) x BT token blocks
+  static_assert(WM * WP == 8 && CL * 16 * WM == TM && BT * 16 * WP == TP && CL * BT <= 32 && (CL == 4 || CL == 6 || CL == 8), "8 waves, at most 32 accumulators each");
+  constexpr int TILE_A = TM * 64, TILE_B = TP * 64, SLOT = TILE_A + TILE_B, RING = NBUF * SLOT;
   constexpr int NPA = (TM / 16 + 7) / 8, NPB = (TP / 16 + 7) / 8, NP = NPA + NPB;   // 1-KiB DMA pieces (16 rows x 64 B) per wave and K tile; pieces past the tile go to the dump KiB
-  constexpr int CW = BM16 * 16;                                // output columns per wave
-  constexpr int LPRr = CW / 8, LPR = LPRr <= 4 ? 4 : (LPRr <= 8 ? 8 : 16);   // lanes per staged row (8 columns each), rounded up to a power of two
-  constexpr int RPI = 64 / LPR, NI = 16 / RPI;                 // rows per store instruction, store instructions per 16-row block
-  constexpr int ROWB = CW * 4 + 16;                            // padded f32 row of the staging region
-  constexpr int EPI_OFF = 2 * SLOT, EPI_BYTES = 8 * 16 * ROWB; // staging region: behind ring slots 0-1, which take the next tile's first K tiles meanwhile
-  constexpr int RING = NBUF * SLOT;
-  constexpr int DUMP_OFF = RING > EPI_OFF + EPI_BYTES ? RING : EPI_OFF + EPI_BYTES;   // 1 KiB behind everything else; exists only when a piece can miss the tile
-  constexpr unsigned ES = OUT_F32 ? 4u : 2u;
+  constexpr int CW = CL * 16;                      // output columns per wave
+  constexpr int BIAS_OFF = RING, DUMP_OFF = RING + 2048;
+  constexpr int SPR = OUT_F32 ? (CL + 3) / 4 : 1;  // store instructions per lane and token row
+  constexpr int NST = BT * 4 * SPR;                // ... per lane and tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;
   const int wm = wave / WP, wp = wave % WP;
   const int nK = a.K >> 5;
+  const unsigned bsz = a.bias_bf16 ? 2u : 4u;
+  const float inv_ntn = a.inv_ntn;   // from the host: a kernel argument lives in an SGPR (computed here it sat in a VGPR and was spilled)
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)a.N * (unsigned)a.ldw * 2u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)a.M * (unsigned)a.lda * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)a.N * bsz : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)a.M * (unsigned)a.ldy * (OUT_F32 ? 4u : 2u), 0x00020000);
 
-  int m0 = 0, n0 = 0;
-  unsigned voffA[NPA], voffB[NPB];
-  int it = 0;   // next K tile to issue (wave-uniform)
-  auto setup = [&](unsigned work) {
-    const unsigned wid = xcd_remap(work, a.total);
-    m0 = (int)(wid / a.ntn) * TP;
-    n0 = (int)(wid % a.ntn) * TM;
-    it = 0;
+  // per-lane DMA source offsets of a tile: weight rows in the permuted order, token rows as they are, the bias slice (wave 0; 16 B per lane)
+  auto calc = [&](unsigned work, unsigned (&vA)[NPA], unsigned (&vB)[NPB], unsigned& vBias, int& m0, int& n0) {
+    int lane_c = lane;
+    asm volatile("" : "+v"(lane_c));   // an opaque copy: what calc derives from the lane index is recomputed per tile, not hoisted out of the tile loop and carried (spilled) across the K loop
+    const bool live = work < (unsigned)a.total;
+    const int wid = live ? (int)xcd_remap(work, a.total) : 0;
+    int mt = (int)((float)wid * inv_ntn);            // wid / ntn for wid < 2^24 (the host keeps the tile count below that): one reciprocal and a +-1 fix-up
+    int nt = wid - mt * a.ntn;
+    if (nt < 0) { mt--; nt += a.ntn; }
+    if (nt >= a.ntn) { mt++; nt -= a.ntn; }
+    m0 = __builtin_amdgcn_readfirstlane(mt) * TP;
+    n0 = __builtin_amdgcn_readfirstlane(nt) * TM;
 #pragma unroll
     for (int p = 0; p < NPA; p++) {
-      const int row = (wave * NPA + p) * 16 + (lane >> 2);
-      const int n = n0 + row;
-      const int c = (lane & 3) ^ swz64(row);   // logical 16-B chunk this lane fetches: the LDS image stays lane-linear, the swizzle is on the source address
-      voffA[p] = (row < TM && n < a.N) ? (unsigned)n * (unsigned)a.ldw * 2u + c * 16u : SENT;
+      const int rl = (wave * NPA + p) * 16 + (lane_c >> 2);     // LDS row of the weight tile: wave column range rl / CW, column block i, MFMA column c
+      const int wmr = rl / CW, r = rl % CW, i = r >> 4, c = r & 15;
+      const int n = n0 + wmr * CW + CL * c + i;
+      const int ch = (lane_c & 3) ^ swz64(rl);                  // logical 16-B chunk this lane fetches: the LDS image stays lane-linear, the swizzle is on the source address
+      vA[p] = (live && rl < TM && n < a.N) ? (unsigned)n * (unsigned)a.ldw * 2u + ch * 16u : SENT;
     }
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
-      const int row = (wave * NPB + p) * 16 + (lane >> 2);
-      const int m = m0 + row;
-      const int c = (lane & 3) ^ swz64(row);
-      voffB[p] = (row < TP && m < a.M) ? (unsigned)m * (unsigned)a.lda * 2u + c * 16u : SENT;
+      const int rl = (wave * NPB + p) * 16 + (lane_c >> 2);
+      const int m = m0 + rl;
+      const int ch = (lane_c & 3) ^ swz64(rl);
+      vB[p] = (live && rl < TP && m < a.M) ? (unsigned)m * (unsigned)a.lda * 2u + ch * 16u : SENT;
     }
+    const unsigned e0 = (unsigned)lane_c * (16u / bsz);         // first element of this lane's 16 bytes of the slice
+    vBias = (live && wave == 0 && e0 < (unsigned)TM && (unsigned)n0 + e0 < (unsigned)a.N) ? ((unsigned)n0 + e0) * bsz : SENT;
   };
-  // this wave's pieces of K tile `it` into the ring slot at byte offset `slot`; past the last K tile all-zero pieces (they move no memory) keep the vmcnt bookkeeping uniform
-  auto issue = [&](int slot) {
-    const bool live = it < nK;
-    const unsigned so = (unsigned)it * 64u;
+  auto issue_k = [&](const unsigned (&vA)[NPA], const unsigned (&vB)[NPB], unsigned so, int slot) {
 #pragma unroll
     for (int p = 0; p < NPA; p++) {
       const int g = wave * NPA + p;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + (g * 16 < TM ? slot + g * 1024 : DUMP_OFF)), 16, live ? voffA[p] : SENT, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + (g * 16 < TM ? slot + g * 1024 : DUMP_OFF)), 16, vA[p], so, 0, 0);
     }
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
       const int g = wave * NPB + p;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + (g * 16 < TP ? slot + TILE_A + g * 1024 : DUMP_OFF)), 16, live ? voffB[p] : SENT, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + (g * 16 < TP ? slot + TILE_A + g * 1024 : DUMP_OFF)), 16, vB[p], so, 0, 0);
     }
-    it++;
+  };
+  auto issue_bias = [&](unsigned vBias, int par) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rBias, LPTR(smem + (wave == 0 ? BIAS_OFF + par * 1024 : DUMP_OFF)), 16, vBias, 0, 0, 0);
   };
 
-  // fragment read offsets inside a slot: one 16-B read per lane covers a 16-row x 32-deep fragment
-  int aoff[BM16], boff[BP16];
-#pragma unroll
-  for (int i = 0; i < BM16; i++) {
-    const int row = wm * CW + i * 16 + (lane & 15);
-    aoff[i] = row * 64 + (((lane >> 4) ^ swz64(row)) << 4);
-  }
-#pragma unroll
-  for (int j = 0; j < BP16; j++) {
-    const int row = wp * (TP / WP) + j * 16 + (lane & 15);
-    boff[j] = TILE_A + row * 64 + (((lane >> 4) ^ swz64(row)) << 4);
-  }
+  // fragment reads: lane l takes the 16-B chunk l >> 4 of row l & 15 of a 16-row block; the swizzle key of row 16 b + y is that of row y (swz64 sees y >> 2 mod 4 only),
+  // so every block of a tile is the first block's address + b * 1024 -- one address register per operand and immediate offsets
+  const int fr = (lane & 15) * 64 + (((lane >> 4) ^ swz64(lane & 15)) << 4);
+  const int wbase = wm * (CW * 64) + fr;                       // weight tile: rows wm * CW ..
+  const int tbase = TILE_A + wp * (TP / WP) * 64 + fr;         // token tile:  rows wp * (TP / WP) ..
 
-  f32x4 acc[BM16][BP16];   // acc[i][j][r]: column block i, column 4 * (lane >> 4) + r; row block j, row lane & 15
+  f32x4 acc[CL][BT];   // acc[i][j][r]: token 16 j + 4 (lane >> 4) + r of the wave's rows; column CL * (lane & 15) + i of the wave's columns
+  bf16x8 wf[CL], tf[BT];
+  unsigned vAc[NPA], vBc[NPB], vAn[NPA], vBn[NPB], vBiasN;
+  int m0c, n0c, m0n = 0, n0n = 0;
+  int slot_rd = 0, slot_wr = 3 * SLOT, par = 0;
+  int it = 3;              // next K tile of the current output tile to issue
 
-  setup(blockIdx.x);
+  // one K step: LOAD interval (fragments of the slot being read, DMA issue into the slot being written), barrier, COMPUTE interval, barrier
+  auto kstep = [&](auto WAITc, auto MODEc) __attribute__((always_inline)) {
+    constexpr int WAIT = decltype(WAITc)::value, MODE = decltype(MODEc)::value;   // MODE 0: the current tile's K tile `it`; 1 / 2 / 3: the next tile's K tile 0 (+ bias) / 1 / 2
+    const char* sw = smem + slot_rd + wbase;
+    const char* st = smem + slot_rd + tbase;
 #pragma unroll
-  for (int u = 0; u < PF; u++) issue(u * SLOT);
-
-  for (unsigned work = blockIdx.x; work < (unsigned)a.total;) {
-    const int m0c = m0, n0c = n0;
+    for (int j = 0; j < BT; j++) tf[j] = *reinterpret_cast<const bf16x8*>(st + j * 1024);
 #pragma unroll
-    for (int i = 0; i < BM16; i++)
-#pragma unroll
-      for (int j = 0; j < BP16; j++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) acc[i][j][r] = 0.f;
-    wait_vmcnt<(PF - 1) * NP>();
-    __builtin_amdgcn_s_barrier();                  // B_0: everybody's pieces of K tile 0 have landed
-    if (grp == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-    if (grp == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one interval behind group 0
-
-    bf16x8 af[BM16], bfr[BP16];
-    int slot_rd = 0, slot_wr = PF * SLOT;
-#pragma unroll 1
-    for (int t = 0; t < nK; t++) {
-      // LOAD interval
-      const char* sb = smem + slot_rd;
-#pragma unroll
-      for (int j = 0; j < BP16; j++) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + boff[j]);
-#pragma unroll
-      for (int i = 0; i < BM16; i++) af[i] = *reinterpret_cast<const bf16x8*>(sb + aoff[i]);
-      issue(slot_wr);
-      slot_rd = slot_rd + SLOT == NBUF * SLOT ? 0 : slot_rd + SLOT;
-      slot_wr = slot_wr + SLOT == NBUF * SLOT ? 0 : slot_wr + SLOT;
-      wait_vmcnt<(PF - 1) * NP>();   // own pieces of the NEXT K tile have landed
-      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) through the builtin: the compiler sees the fragments have arrived and puts no waits of its own between the MFMAs
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // COMPUTE interval
-#pragma unroll
-      for (int i = 0; i < BM16; i++)
-#pragma unroll
-        for (int j = 0; j < BP16; j++)
-          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[i]), "v"(bfr[j]));
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < CL; i++) wf[i] = *reinterpret_cast<const bf16x8*>(sw + i * 1024);
+    if constexpr (MODE == 0) { issue_k(vAc, vBc, (unsigned)it * 64u, slot_wr); it++; }
+    else {
+      if constexpr (MODE == 1) issue_bias(vBiasN, par ^ 1);
+      issue_k(vAn, vBn, (unsigned)(MODE - 1) * 64u, slot_wr);
     }
-    if (grp == 0) __builtin_amdgcn_s_barrier();    // matches group 1's extra barrier
-    if (grp == 1) __builtin_amdgcn_s_setprio(0);
-    wait_vmcnt<0>();                               // the trailing all-zero pieces
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA (inline asm, invisible to the hazard recogniser) -> accumulator reads
-    __builtin_amdgcn_s_barrier();                  // every wave's trailing DMA has landed and all fragment reads are done: the ring is free
+    slot_rd = slot_rd + SLOT == RING ? 0 : slot_rd + SLOT;
+    slot_wr = slot_wr + SLOT == RING ? 0 : slot_wr + SLOT;
+    if constexpr (WAIT >= 0) wait_vmcnt<WAIT>();   // own pieces of the NEXT K tile have landed
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) through the builtin: the compiler sees the fragments have arrived and puts no waits of its own between the MFMAs
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < CL; i++)
+#pragma unroll
+      for (int j = 0; j < BT; j++)   // rows = tokens (first operand), columns = weight rows (second operand)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(tf[j]), "v"(wf[i]));
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using W_NO = std::integral_constant<int, -1>; using W_0 = std::integral_constant<int, 0>; using W_2P = std::integral_constant<int, 2 * NP>; using W_2P1 = std::integral_constant<int, 2 * NP + 1>;
+  using M0_ = std::integral_constant<int, 0>; using M1_ = std::integral_constant<int, 1>; using M2_ = std::integral_constant<int, 2>; using M3_ = std::integral_constant<int, 3>;
 
-    // ---- epilogue: accumulators -> LDS (f32, per-wave region) -> whole output rows, 16-B stores ---------------------------------------------------------
-    const unsigned next = work + gridDim.x;
-    const bool has_next = next < (unsigned)a.total;
+  unsigned work = blockIdx.x;
+  {
+    unsigned vBiasC;
+    calc(work, vAc, vBc, vBiasC, m0c, n0c);
+    issue_bias(vBiasC, 0);
+  }
+  issue_k(vAc, vBc, 0u, 0);
+  issue_k(vAc, vBc, 64u, SLOT);
+  issue_k(vAc, vBc, 128u, 2 * SLOT);
+  wait_vmcnt<0>();
+
+  int tix = 0;
+  auto stamp = [&](int k) { if (a.dbg && tid == 0 && tix < 4) a.dbg[((size_t)blockIdx.x * 4 + tix) * 4 + k] = __builtin_amdgcn_s_memtime(); };
+  while (work < (unsigned)a.total) {
+    stamp(0);
+    __builtin_amdgcn_s_barrier();                  // B_0: everybody's pieces of K tiles 0 .. 2 and of the bias slice have landed (each wave waited for its own)
     {
-      int lane_o = lane;
-      asm volatile("" : "+v"(lane_o));   // recomputed per tile, not carried (spilled) across the main loop
-      const int cl = lane_o % LPR, rg = lane_o / LPR;
-      char* reg = smem + EPI_OFF + wave * (16 * ROWB);
-      const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)a.M * (unsigned)a.ldy * ES, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rY2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.y2, 0, a.y2 ? (unsigned)a.M * (unsigned)a.ldy * 2u : 0u, 0x00020000);
-      const int cb = n0c + wm * CW + cl * 8;               // this lane's 8 output columns
-      const bool c_ok = cl < LPRr && cb < a.N;
-      // bias first, while the memory queue is empty (behind the next tile's prefetch its first use would wait for those pieces to land)
-      f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
-      {
-        const __amdgpu_buffer_rsrc_t rBias =
-            __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)a.N * (a.bias_bf16 ? 2u : 4u) : 0u, 0x00020000);
-        if (a.bias_bf16) {
-          const u32x4 b8 = __builtin_amdgcn_raw_buffer_load_b128(rBias, c_ok ? (unsigned)cb * 2u : SENT, 0, 0);
-          const bf16x8 bb = *reinterpret_cast<const bf16x8*>(&b8);
-          b_lo = f32x4{(float)bb[0], (float)bb[1], (float)bb[2], (float)bb[3]};
-          b_hi = f32x4{(float)bb[4], (float)bb[5], (float)bb[6], (float)bb[7]};
-        } else {
-          const unsigned vo = c_ok ? (unsigned)cb * 4u : SENT;
-          const u32x4 b0 = __builtin_amdgcn_raw_buffer_load_b128(rBias, vo, 0, 0), b1 = __builtin_amdgcn_raw_buffer_load_b128(rBias, vo + 16u, 0, 0);
-          b_lo = *reinterpret_cast<const f32x4*>(&b0);
-          b_hi = *reinterpret_cast<const f32x4*>(&b1);
+      // accumulators start at the bias: the lane's CL consecutive columns, the same for every token
+      const char* bl = smem + BIAS_OFF + par * 1024;
+      int lane_b = lane;
+      asm volatile("" : "+v"(lane_b));   // recomputed per tile (see calc)
+      const int col = wm * CW + CL * (lane_b & 15);
+      float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (!a.bias) {   // no bias: the slice's piece was all out of range (whether such a piece writes zeros or nothing is not relied upon)
+      } else if (a.bias_bf16) {
+#pragma unroll
+        for (int h = 0; h < CL / 2; h++) {
+          const bf16x2 b2 = *reinterpret_cast<const bf16x2*>(bl + col * 2 + h * 4);
+          bv[2 * h] = (float)b2[0]; bv[2 * h + 1] = (float)b2[1];
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < CL / 2; h++) {
+          const f32x2 b2 = *reinterpret_cast<const f32x2*>(bl + col * 4 + h * 8);
+          bv[2 * h] = b2[0]; bv[2 * h + 1] = b2[1];
         }
       }
-      if (has_next) setup(next); else it = nK;
-      issue(0);   // the next tile's first K tile goes out before the stores (unconditional: past the last tile all-zero pieces)
-      const int mrow = m0c + wp * (TP / WP) + rg;          // the lane's row in store instruction 0 of row block 0
+#pragma unroll
+      for (int i = 0; i < CL; i++)
+#pragma unroll
+        for (int j = 0; j < BT; j++) acc[i][j] = f32x4{bv[i], bv[i], bv[i], bv[i]};
+    }
+    stamp(1);
+    if (grp == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (grp == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one interval behind group 0
+    it = 3;
+    kstep(W_NO{}, M0_{});
+    kstep(W_NO{}, M0_{});
+    kstep(W_2P{}, M0_{});
+#pragma unroll 1
+    for (int t = 3; t < nK - 3; t++) kstep(W_2P{}, M0_{});
+    const unsigned next = work + gridDim.x;
+    calc(next, vAn, vBn, vBiasN, m0n, n0n);       // all out of range when there is no next tile: its pieces move no memory
+    kstep(W_2P1{}, M1_{});
+    kstep(W_2P1{}, M2_{});
+    kstep(W_0{}, M3_{});
+    if (grp == 0) __builtin_amdgcn_s_barrier();    // matches group 1's extra barrier
+    if (grp == 1) __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA (inline asm, invisible to the hazard recogniser) -> accumulator reads
+    stamp(2);
+
+    // ---- epilogue: straight from the accumulators, NST stores per lane: token row (j, r) of the lane's group, CL consecutive columns ------------------------------
+    {
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));   // recomputed per tile, not carried across the main loop
+      const int col = n0c + wm * CW + CL * (lane_o & 15);
+      const int row0 = m0c + wp * (TP / WP) + 4 * (lane_o >> 4);
+      const bool c_ok = col < a.N;       // N % 8 == 0 and CL | 8 ... the lane's columns are all inside or all outside when N is a multiple of CL; else per element below
       auto body = [&](auto ACTc) __attribute__((always_inline)) {
         constexpr int ACT = decltype(ACTc)::value;
 #pragma unroll
-        for (int j = 0; j < BP16; j++) {
-#if DMVAE_GEMM_EXP & 2
+        for (int j = 0; j < BT; j++)
 #pragma unroll
-          for (int i = 0; i < BM16; i++) asm volatile("" :: "a"(acc[i][j]));
-          continue;
-#endif
+          for (int r = 0; r < 4; r++) {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int i = 0; i < BM16; i++)
-            *reinterpret_cast<f32x4*>(reg + (lane_o & 15) * ROWB + (i * 16 + 4 * (lane_o >> 4)) * 4) = acc[i][j];
-          f32x4 lo[NI], hi[NI];
+            for (int i = 0; i < CL; i++) v[i] = acc[i][j][r];
+            if constexpr (ACT != 0) {   // the activation sees the bf16-rounded pre-activation, as the unfused Linear -> activation pair does
 #pragma unroll
-          for (int q = 0; q < NI; q++) {
-            lo[q] = *reinterpret_cast<const f32x4*>(reg + (q * RPI + rg) * ROWB + cl * 32);
-            hi[q] = *reinterpret_cast<const f32x4*>(reg + (q * RPI + rg) * ROWB + cl * 32 + 16);
-          }
-          u32x4 keep[OUT_F32 ? 2 * NI : NI], keep2[NI];
-#pragma unroll
-          for (int q = 0; q < NI; q++) {
-            const f32x4 v0 = lo[q] + b_lo, v1 = hi[q] + b_hi;
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const int m = mrow + j * 16 + q * RPI;
-            const bool ok = c_ok && m < a.M;
-            const unsigned eo = (unsigned)m * (unsigned)a.ldy + (unsigned)cb;
-            if constexpr (ACT != 0) {
-              // the activation sees the bf16-rounded pre-activation, as the unfused Linear -> activation pair does
-              const u32x4 h = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3]), dmvae_pack_bf16x2(v[4], v[5]), dmvae_pack_bf16x2(v[6], v[7])};
-              keep2[q] = h;
-              __builtin_amdgcn_raw_buffer_store_b128(h, rY2, ok ? eo * 2u : SENT, 0, 2);
-              const bf16x8 hb = *reinterpret_cast<const bf16x8*>(&h);
-#pragma unroll
-              for (int e = 0; e < 8; e++) {
-                const float x = (float)hb[e];
-                v[e] = ACT == 5 ? gelu_f(x) : x * sigmoidf_(x);
+              for (int i = 0; i < CL; i++) {
+                const float x = (float)(bf16)v[i];
+                v[i] = ACT == 5 ? gelu_f(x) : x * sigmoidf_(x);
               }
             }
-            if constexpr (OUT_F32) {
-              const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-              keep[2 * q] = *reinterpret_cast<const u32x4*>(&o0);
-              keep[2 * q + 1] = *reinterpret_cast<const u32x4*>(&o1);
-              __builtin_amdgcn_raw_buffer_store_b128(keep[2 * q], rY, ok ? eo * 4u : SENT, 0, 0);
-              __builtin_amdgcn_raw_buffer_store_b128(keep[2 * q + 1], rY, ok ? eo * 4u + 16u : SENT, 0, 0);
-            } else {
+            const int m = row0 + j * 16 + r;
+            const bool ok = !DMVAE_GEMM_NOSTORE && c_ok && m < a.M;
+            const unsigned eo = (unsigned)m * (unsigned)a.ldy + (unsigned)col;
+            if constexpr (OUT_F32 && CL == 6) {   // column pairs one by one (a lane may straddle N, see the bf16 case below; the f32 result is not a hot path)
+#pragma unroll
+              for (int e = 0; e < 3; e++) {
+                const f32x2 o2 = {v[2 * e], v[2 * e + 1]};
+                const u32x2 k2 = *reinterpret_cast<const u32x2*>(&o2);
+                __builtin_amdgcn_raw_buffer_store_b64(k2, rY, (ok && col + 2 * e < a.N) ? eo * 4u + 8u * e : SENT, 0, 0);
+                asm volatile("s_nop 0" :: "v"(k2));   // gfx950: a VALU write to a store's data VGPR directly behind the store is seen by the store (conv_pp.hip)
+              }
+            } else if constexpr (OUT_F32) {
+              const f32x4 o0 = {v[0], v[1], v[2], v[3]};
+              const u32x4 k0 = *reinterpret_cast<const u32x4*>(&o0);
+              __builtin_amdgcn_raw_buffer_store_b128(k0, rY, ok ? eo * 4u : SENT, 0, 0);
+              if constexpr (CL == 8) {
+                const f32x4 o1 = {v[4], v[5], v[6], v[7]};
+                const u32x4 k1 = *reinterpret_cast<const u32x4*>(&o1);
+                __builtin_amdgcn_raw_buffer_store_b128(k1, rY, ok ? eo * 4u + 16u : SENT, 0, 0);
+                asm volatile("s_nop 0" :: "v"(k0), "v"(k1));
+              } else {
+                asm volatile("s_nop 0" :: "v"(k0));
+              }
+            } else if constexpr (CL == 8) {
               const u32x4 o = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3]), dmvae_pack_bf16x2(v[4], v[5]), dmvae_pack_bf16x2(v[6], v[7])};
-              keep[q] = o;
-#if !(DMVAE_GEMM_EXP & 1)
-              __builtin_amdgcn_raw_buffer_store_b128(o, rY, ok ? eo * 2u : SENT, 0, (DMVAE_GEMM_EXP & 4) ? 2 : 0);
-#endif
+              __builtin_amdgcn_raw_buffer_store_b128(o, rY, ok ? eo * 2u : SENT, 0, DMVAE_GEMM_AUX);
+              asm volatile("s_nop 0" :: "v"(o));
+            } else if constexpr (CL == 6) {
+              // six columns per lane: N (a multiple of 8) need not be a multiple of 6, so one lane per row of the tile on N's edge straddles it -- that lane
+              // stores its column pairs one by one (a wave-uniform branch that only the edge tiles take)
+              const u32x3 o = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3]), dmvae_pack_bf16x2(v[4], v[5])};
+              const bool full = col + 6 <= a.N;
+              __builtin_amdgcn_raw_buffer_store_b96(o, rY, (ok && full) ? eo * 2u : SENT, 0, DMVAE_GEMM_AUX);
+              if (__builtin_amdgcn_ballot_w64(ok && !full) != 0ull) {
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+                  __builtin_amdgcn_raw_buffer_store_b32(o[e], rY, (ok && !full && col + 2 * e < a.N) ? eo * 2u + 4u * e : SENT, 0, DMVAE_GEMM_AUX);
+              }
+              asm volatile("s_nop 0" :: "v"(o));
+            } else {
+              const u32x2 o = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3])};
+              __builtin_amdgcn_raw_buffer_store_b64(o, rY, ok ? eo * 2u : SENT, 0, DMVAE_GEMM_AUX);
+              asm volatile("s_nop 0" :: "v"(o));
             }
           }
-          // gfx950: a VALU write to a store's data VGPR directly behind the store is seen by the store (conv_pp.hip, tools/probes/probe_store_war.hip) --
-          // every packed result stays live up to here
-#pragma unroll
-          for (int q = 0; q < (OUT_F32 ? 2 * NI : NI); q++) asm volatile("s_nop 0" :: "v"(keep[q]));
-          if constexpr (ACT != 0) {
-#pragma unroll
-            for (int q = 0; q < NI; q++) asm volatile("s_nop 0" :: "v"(keep2[q]));
-          }
-        }
       };
       if (a.act == 0) body(std::integral_constant<int, 0>{});
       else if (a.act == 5) body(std::integral_constant<int, 5>{});
       else body(std::integral_constant<int, 1>{});
     }
-    if (has_next) issue(SLOT);
-    wait_vmcnt<NP>();                // the stores share vmcnt with the prefetched K tiles: everything but the newest tile's pieces has landed
-    __builtin_amdgcn_s_barrier();    // staging reads done before ring slots 2.. are refilled
-    if (has_next) issue(2 * SLOT);
+    if (a.dbg) __builtin_amdgcn_s_barrier();   // diagnostics: the stamp then reads when the LAST wave has issued its stores
+    stamp(3);
+    tix++;
     work = next;
+#pragma unroll
+    for (int p = 0; p < NPA; p++) vAc[p] = vAn[p];
+#pragma unroll
+    for (int p = 0; p < NPB; p++) vBc[p] = vBn[p];
+    m0c = m0n; n0c = n0n;
+    par ^= 1;
   }
 #endif
 }
@@ -296,10 +356,9 @@ template <int TM, int TP, int WM, int WP, bool F32>
 int launch(Args a, hipStream_t st) {
   a.ntn = (a.N + TM - 1) / TM;
   a.total = ((a.M + TP - 1) / TP) * a.ntn;
+  a.inv_ntn = 1.0f / (float)a.ntn;
   const unsigned grid = a.total > 256 ? 256u : (unsigned)a.total;
-  constexpr int slot = (TM + TP) * 64, cw = TM / WM, epi = 2 * slot + 8 * 16 * (cw * 4 + 16);
-  constexpr bool dump = ((TM / 16 + 7) / 8) * 128 > TM || ((TP / 16 + 7) / 8) * 128 > TP;   // some wave's piece lies past the tile: it lands in a dump KiB
-  constexpr int lds = (4 * slot > epi ? 4 * slot : epi) + (dump ? 1024 : 0);
+  constexpr int lds = 4 * (TM + TP) * 64 + 3 * 1024;   // ring + two bias slots + the dump KiB
   static_assert(lds <= 160 * 1024, "LDS");
   static bool attr_done = false;
   if (!attr_done) {
@@ -315,7 +374,7 @@ int launch(Args a, hipStream_t st) {
 struct Cfg { int tm, tp; float cost; };
 static const Cfg g_cfg[] = {
     {256, 256, 1.00f}, {256, 224, 0.90f}, {256, 192, 0.79f}, {256, 160, 0.68f}, {256, 128, 0.57f},
-    {128, 512, 1.05f}, {128, 384, 0.80f}, {128, 256, 0.57f}, {192, 256, 0.80f}, {192, 320, 0.98f},
+    {128, 448, 0.95f}, {128, 384, 0.80f}, {128, 256, 0.57f}, {192, 256, 0.80f}, {192, 320, 0.98f},
 };
 constexpr int NCFG = sizeof(g_cfg) / sizeof(g_cfg[0]);
 
@@ -345,7 +404,7 @@ static int dispatch(int cfg, const Args& a, hipStream_t st) {
     case 2: return launch<256, 192, 2, 4, F32>(a, st);
     case 3: return launch<256, 160, 4, 2, F32>(a, st);
     case 4: return launch<256, 128, 4, 2, F32>(a, st);
-    case 5: return launch<128, 512, 2, 4, F32>(a, st);
+    case 5: return launch<128, 448, 2, 4, F32>(a, st);
     case 6: return launch<128, 384, 2, 4, F32>(a, st);
     case 7: return launch<128, 256, 2, 4, F32>(a, st);
     case 8: return launch<192, 256, 2, 4, F32>(a, st);
@@ -355,6 +414,8 @@ static int dispatch(int cfg, const Args& a, hipStream_t st) {
 
 }  // namespace dmvae_gemm_pp
 
+static unsigned long long* g_gemm_dbg = nullptr;
+extern "C" void dmvae_debug_gemm_timing(void* buf) { g_gemm_dbg = (unsigned long long*)buf; }   // diagnostics only (tools/probes/time_gemm_pp.py)
 extern "C" void dmvae_debug_gemm_cfg(int cfg) { dmvae_gemm_pp::g_forced = cfg; }   // diagnostics only (tools/bench_gemm.py): force a menu entry, -1 = plan by cost
 
 extern "C" int dmvae_linear_bf16_plan(int M, int N, int K, int* tile_cols, int* tile_rows) {
@@ -365,20 +426,19 @@ extern "C" int dmvae_linear_bf16_plan(int M, int N, int K, int* tile_cols, int* 
   return c;
 }
 
-extern "C" int dmvae_linear_bf16(const void* x, const void* w, const void* bias, void* y, void* y_pre, int M, int N, int K, int lda, int ldw, int ldy,
+extern "C" int dmvae_linear_bf16(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int lda, int ldw, int ldy,
                                  int act, int bias_bf16, int out_f32, hipStream_t stream) {
   using namespace dmvae_gemm_pp;
   DMVAE_CHECK_ARG(x && w && y, "linear_bf16: null operand");
-  DMVAE_CHECK_ARG(M > 0 && N > 0 && K >= 32 && K % 32 == 0 && N % 8 == 0, "linear_bf16: need K %% 32 == 0 and N %% 8 == 0 (M %d, N %d, K %d)", M, N, K);
+  DMVAE_CHECK_ARG(M > 0 && N > 0 && K >= 192 && K % 32 == 0 && N % 8 == 0, "linear_bf16: need K %% 32 == 0, K >= 192 and N %% 8 == 0 (M %d, N %d, K %d)", M, N, K);
   DMVAE_CHECK_ARG(lda >= K && ldw >= K && ldy >= N && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0, "linear_bf16: leading dimensions must cover the rows and be multiples of 8");
   DMVAE_CHECK_ARG(act == 0 || act == 1 || act == 5, "linear_bf16: act must be 0 (none), 1 (SiLU) or 5 (GELU)");
-  DMVAE_CHECK_ARG(!y_pre || act != 0, "linear_bf16: y_pre (the bf16 pre-activation) needs an activation");
   DMVAE_CHECK_ARG((long long)M * lda * 2 < (1ll << 31) && (long long)N * ldw * 2 < (1ll << 31) && (long long)M * ldy * (out_f32 ? 4 : 2) < (1ll << 31),
                   "linear_bf16: operands are addressed through 32-bit buffer offsets (2 GiB each)");
   Args a;
-  a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.y = y; a.y2 = act != 0 ? (bf16*)y_pre : nullptr;
+  a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.y = y;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldy = ldy;
-  a.act = act; a.bias_bf16 = bias_bf16; a.ntn = 0; a.total = 0;
+  a.act = act; a.bias_bf16 = bias_bf16; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = g_gemm_dbg;
   const int cfg = plan(M, N, K);
   return out_f32 ? dispatch<true>(cfg, a, stream) : dispatch<false>(cfg, a, stream);
 }

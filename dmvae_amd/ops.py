@@ -341,17 +341,15 @@ def linear_plan(m: int, n: int, k: int) -> Tuple[int, int, int]:
 
 
 def linear_supported(m: int, n: int, k: int) -> bool:
-    """Shapes dmvae_linear_bf16 takes: K a multiple of 32, N of 8, every operand below 2 GiB.  Problems with fewer than 64 rows (adaLN / embedder Linears on
-    one row per sample) are left to the small batched NT kernel (gemm_nt): a 128-256-row tile would be nearly all padding."""
-    return k >= 32 and k % 32 == 0 and n % 8 == 0 and m >= 64 and m * max(n, k) * 2 < (1 << 31) and n * k * 2 < (1 << 31)
+    """Shapes dmvae_linear_bf16 takes: K a multiple of 32 and at least 192, N a multiple of 8, every operand below 2 GiB.  Problems with fewer than 64 rows
+    (adaLN / embedder Linears on one row per sample) are left to the small batched NT kernel (gemm_nt): a 128-256-row tile would be nearly all padding."""
+    return k >= 192 and k % 32 == 0 and n % 8 == 0 and m >= 64 and m * max(n, k) * 2 < (1 << 31) and n * k * 2 < (1 << 31)
 
 
-def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, want_pre: bool = False,
-                out_f32: bool = False):
+def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, out_f32: bool = False) -> torch.Tensor:
     """F.linear(x, w, bias) under autocast(bf16) on the hand-written GEMM (csrc/gemm_pp.hip): x [..., K] bf16, w [N, K] bf16 (the parameter's bf16 copy;
     a [K_in, N_out]-transposed copy makes the same call the input gradient), bias [N] bf16 (autocast's operand) or f32, f32 accumulation, bf16 result
-    [..., N] (f32 with out_f32).  act = ACT_GELU / ACT_SILU fuses the activation on the bf16-rounded pre-activation (bit-identical to the two-kernel route);
-    want_pre additionally returns that pre-activation: (y, y_pre)."""
+    [..., N] (f32 with out_f32).  act = ACT_GELU / ACT_SILU fuses the activation on the bf16-rounded pre-activation (bit-identical to the two-kernel route)."""
     x = _req(x, bf16, "x")
     w = _req(w, bf16, "w")
     k = x.shape[-1]
@@ -365,18 +363,17 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         _req(bias, bf16 if bias_bf16 else f32, "bias")
         assert bias.numel() == n
     y = torch.empty(*x.shape[:-1], n, dtype=f32 if out_f32 else bf16, device=x.device)
-    y_pre = torch.empty(*x.shape[:-1], n, dtype=bf16, device=x.device) if (want_pre and act != ACT_NONE) else None
     timing = KERNEL_TIMING
     if timing is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_lib.lib().dmvae_linear_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(y_pre), m, n, k, k, k, n, act, bias_bf16, int(out_f32),
-                                       _stream()), "linear_bf16")
+    check(_lib.lib().dmvae_linear_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), m, n, k, k, k, n, act, bias_bf16, int(out_f32), _stream()),
+          "linear_bf16")
     if timing is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         timing.append(("gemm_pp_kernel", e0, e1, 2.0 * m * n * k))
-    return (y, y_pre) if want_pre else y
+    return y
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, out_f32: bool = False) -> torch.Tensor:

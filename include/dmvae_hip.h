@@ -161,10 +161,11 @@ int dmvae_gemm_tn_batched(const void* A, const void* B, void* C, void* workspace
  * x [M][lda], w [N][ldw], y [M][ldy] row-major bf16 (y f32 when out_f32); leading dimensions in elements, multiples of 8; K % 32 == 0, N % 8 == 0;
  * every operand below 2 GiB.  bias: f32 [N], or bf16 [N] when bias_bf16 (what autocast hands the library), or NULL.
  * act: 0 none, 1 SiLU, 5 exact (erf) GELU -- applied to the bf16-ROUNDED pre-activation, so the result is bit-identical to this call with act = 0
- * followed by dmvae_gelu_fwd / dmvae_silu_fwd; y_pre (bf16 [M][ldy], may be NULL; act != 0 only) also receives that pre-activation.
+ * followed by dmvae_gelu_fwd / dmvae_silu_fwd.  K >= 192 (six K steps: the kernel streams a tile's last three K steps together with the next tile's first
+ * three); shorter reductions go to dmvae_gemm_nt_batched.
  * Tile shape per (M, N, K) from a fixed menu by rounds x tile cost (dmvae_linear_bf16_plan returns the menu index and the tile's columns / rows);
- * results do not depend on the tile (one f32 accumulation chain per output element, in K order).  csrc/gemm_pp.hip. */
-int dmvae_linear_bf16(const void* x, const void* w, const void* bias, void* y, void* y_pre, int M, int N, int K, int lda, int ldw, int ldy,
+ * results do not depend on the tile (one f32 accumulation chain per output element: bias first, then K order).  csrc/gemm_pp.hip. */
+int dmvae_linear_bf16(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int lda, int ldw, int ldy,
                       int act, int bias_bf16, int out_f32, dmvae_stream_t stream);
 int dmvae_linear_bf16_plan(int M, int N, int K, int* tile_cols, int* tile_rows);
 

@@ -8,7 +8,7 @@ Reference: the same contraction in fp64 ON THE GPU over the same bf16-rounded op
     and on a random 1 % sample, element by element, |y_i - ref_i| <= 1e-4 |ref_i| + 2e-5 rms(ref);
   * the bf16 result is bit-for-bit the round-to-nearest-even of the f32 result (same kernel, same accumulation chain);
   * every tile of the menu gives the bit-identical result (one K-ordered accumulation chain per element, whatever the tile);
-  * fused GELU / SiLU epilogue == the act = 0 call followed by the standalone kernel, bit for bit; the saved pre-activation == the act = 0 result;
+  * fused GELU / SiLU epilogue == the act = 0 call followed by the standalone kernel, bit for bit;
   * rows past M / columns past N are never written (the output sits inside a sentinel-filled buffer);
   * two runs are bit-identical."""
 import os
@@ -36,7 +36,7 @@ SHAPES = [
     (16384, 6144, 1152),   # DiT-XL/1 w12, batch 64
     (16384, 1152, 3072),   # DiT-XL/1 w3, batch 64
     (8224, 32, 2048),      # bottleneck MLP's second Linear (N = 32 output columns)
-    (200, 72, 96),         # small and ragged in every dimension
+    (200, 72, 224),        # small and ragged in every dimension
 ]
 IDS = ["%dx%dx%d" % s for s in SHAPES]
 
@@ -85,34 +85,35 @@ def test_linear_vs_fp64(shape):
     _check(yn, x.double() @ w.double().t(), "no-bias result %s" % (shape,))
 
 
-@pytest.mark.parametrize("shape", [(8224, 4096, 1024), (4096, 1152, 1152), (200, 72, 96)], ids=["fc1", "dit_proj", "ragged"])
+@pytest.mark.parametrize("shape", [(8224, 4096, 1024), (4096, 1152, 1152), (200, 72, 224)], ids=["fc1", "dit_proj", "ragged"])
 def test_fused_activation_is_the_two_kernel_route(shape):
     from dmvae_amd import ops
     m, n, k = shape
     x, w, b = _operands(m, n, k, seed=1)
     h = ops.linear_bf16(x, w, b.to(BF))
-    g, pre = ops.linear_bf16(x, w, b.to(BF), act=ops.ACT_GELU, want_pre=True)
-    assert torch.equal(pre, h), "saved pre-activation differs from the plain Linear"
+    g = ops.linear_bf16(x, w, b.to(BF), act=ops.ACT_GELU)
     assert torch.equal(g, ops.gelu(h.view(-1)).view_as(h)), "fused GELU differs from Linear -> gelu kernel"
-    assert torch.equal(ops.linear_bf16(x, w, b.to(BF), act=ops.ACT_GELU), g), "without the second result the first one changed"
     s = ops.linear_bf16(x, w, b.to(BF), act=ops.ACT_SILU)
     assert torch.equal(s, ops.silu(h.view(-1)).view_as(h)), "fused SiLU differs from Linear -> silu kernel"
-    # and against fp64 on the bf16-rounded pre-activation: erf-form GELU
+    # and against fp64 on the bf16-rounded pre-activation: erf-form GELU, one bf16 rounding of the result (2^-8 relative) + the f32 evaluation's
+    # absolute error where 1 + erf cancels (x < -2)
     ref = torch.nn.functional.gelu(h.double())
-    assert ((g.double() - ref).abs() <= 2 ** -7 * ref.abs() + 1e-30).all(), "GELU of the rounded pre-activation is more than a bf16 ulp off"
+    d = (g.double() - ref).abs()
+    bound = 2.0 ** -8 * ref.abs() * 1.01 + 1e-6
+    assert bool((d <= bound).all()), f"fused GELU vs fp64: {(d > bound).sum().item()} elements outside half a bf16 ulp + 1e-6, worst {((d - bound).max().item()):.3e}"
 
 
 def test_rows_and_columns_past_the_end_are_not_written():
     """The output sits in the middle of a sentinel-filled buffer; M and N are not multiples of any tile (ragged rows AND columns), and leading dimensions
     larger than the rows are honoured through the C ABI."""
     from dmvae_amd import _lib, ops
-    m, n, k = 1000, 200, 64
+    m, n, k = 1000, 200, 256
     x, w, b = _operands(m, n, k, seed=2)
     ldy = 208
     pad = 4096
     buf = torch.full((pad + m * ldy + pad,), -7.0, device=DEV, dtype=BF)
     y = buf[pad:pad + m * ldy].view(m, ldy)
-    rc = _lib.lib().dmvae_linear_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None, m, n, k, k, k, ldy, 0, 0, 0,
+    rc = _lib.lib().dmvae_linear_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), m, n, k, k, k, ldy, 0, 0, 0,
                                       torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     torch.cuda.synchronize()
@@ -124,13 +125,14 @@ def test_rows_and_columns_past_the_end_are_not_written():
 def test_argument_errors():
     from dmvae_amd import _lib
     L = _lib.lib()
-    x = torch.zeros(64, 48, device=DEV, dtype=BF)
+    x = torch.zeros(64, 256, device=DEV, dtype=BF)
     st = torch.cuda.current_stream().cuda_stream
-    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), None, 64, 64, 48, 48, 48, 64, 0, 0, 0, st) != 0      # K % 32
+    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 64, 64, 200, 200, 200, 64, 0, 0, 0, st) != 0      # K % 32
     assert b"K" in L.dmvae_last_error()
-    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), None, 64, 60, 32, 32, 32, 64, 0, 0, 0, st) != 0      # N % 8
-    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), None, 64, 64, 32, 32, 32, 64, 2, 0, 0, st) != 0      # act
-    assert L.dmvae_linear_bf16(None, x.data_ptr(), None, x.data_ptr(), None, 64, 64, 32, 32, 32, 64, 0, 0, 0, st) != 0
+    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 64, 64, 160, 160, 160, 64, 0, 0, 0, st) != 0      # K < 192
+    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 64, 60, 256, 256, 256, 64, 0, 0, 0, st) != 0      # N % 8
+    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 64, 64, 256, 256, 256, 64, 2, 0, 0, st) != 0      # act
+    assert L.dmvae_linear_bf16(None, x.data_ptr(), None, x.data_ptr(), 64, 64, 256, 256, 256, 64, 0, 0, 0, st) != 0
 
 
 _TILE_SCRIPT = r"""
@@ -139,7 +141,7 @@ sys.path.insert(0, %r)
 from dmvae_amd import ops
 g = torch.Generator(device="cuda").manual_seed(3)
 out = {}
-for m, n, k in [(8224, 1024, 1024), (4096, 1152, 1152), (777, 520, 96)]:
+for m, n, k in [(8224, 1024, 1024), (4096, 1152, 1152), (777, 520, 192)]:
     x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
     w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16)
     b = torch.randn(n, device="cuda", generator=g)
