@@ -33,6 +33,23 @@ __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 // kernels (GroupNorm backward: 23 of ~37 VALU instructions per element were the two divisions' sequences) whose results are rounded to bf16 anyway.
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// Exact-form GELU 0.5 x (1 + erf(x / sqrt 2)) (nn.GELU() of timm's Mlp, reached through models/vae.py:47-53) with erf from Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7): E = (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), z = |x| / sqrt 2, and 1 + erf(x / sqrt 2) = E for x < 0, 2 - E for x >= 0 --
+// the negative tail is computed without the 1 - erf cancellation.  ~15 VALU instructions, two of them transcendental, no branches; libm's erff is ~45 with two
+// exec-masked branches, which as the epilogue of the fc1 GEMM (33.7 M values per call on ViT-L at batch 32) cost more than the HBM-bound stand-alone kernel
+// it was fused to replace (29 vs 24 us).  Every result is rounded to bf16 (2^-9 relative) by its users, 1000 x coarser than the approximation.  Explicit
+// fmaf: the stand-alone kernel (vit_bwd.hip) and the GEMM epilogue (gemm_pp.hip) give the same bits.
+__device__ __forceinline__ float dmvae_gelu_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float e = p * t * __expf(-z * z);
+  return 0.5f * x * (x < 0.f ? e : 2.0f - e);
+}
+
 // XCD-aware block order (MI355X: 8 XCDs with private L2s; the dispatcher places flat block b on XCD b % 8).
 // Maps the flat dispatch index to a logical work index such that each XCD walks ONE contiguous range of logical
 // indices in dispatch order, so blocks that are neighbours in logical order share an L2.  Bijective for any total.

@@ -23,6 +23,9 @@
 #ifndef DMVAE_GEMM_NOSTORE   // timing experiment: the epilogue's arithmetic without its stores (dropped through an out-of-range offset)
 #define DMVAE_GEMM_NOSTORE 0
 #endif
+#ifndef DMVAE_GEMM_MAXBUF    // ring depth cap (A/B builds); the ring is as deep as LDS allows up to this
+#define DMVAE_GEMM_MAXBUF 6
+#endif
 #ifndef DMVAE_GEMM_AUX    // cache-policy bits of the epilogue's stores (2 = nt); A/B builds
 #define DMVAE_GEMM_AUX 0
 #endif
@@ -31,11 +34,13 @@ namespace dmvae_gemm_pp {
 
 struct Args {
   const bf16* x;     // [M][lda]
-  const bf16* w;     // [N][ldw]
+  const bf16* w;     // [N][ldw], or K-tile-major [K / 32][N][32]
   const void* bias;  // [N] f32 / bf16, or null
   void* y;           // [M][ldy] bf16 / f32
   int M, N, K, lda, ldw, ldy;
   int act, bias_bf16;
+  unsigned wbytes;       // bytes of the weight operand
+  unsigned wsRow, wsK;   // byte strides of the weight operand between rows / between K tiles: row-major (2 ldw, 64), K-tile-major (64, 64 N)
   int ntn, total;    // column tiles, tiles
   float inv_ntn;     // 1 / ntn
   unsigned long long* dbg;   // optional s_memtime stamps per block (dmvae_debug_gemm_timing): [block][tile 0..3][4], null in production
@@ -51,7 +56,7 @@ __device__ __forceinline__ void wait_vmcnt() {   // through the builtin: the com
   asm volatile("" ::: "memory");
 }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }   // vit_bwd.hip::gelu_f
+__device__ __forceinline__ float gelu_f(float x) { return dmvae_gelu_f(x); }   // common.h; vit_bwd.hip::gelu_fwd_kernel computes the same bits
 
 // TM: output columns (weight rows) per tile, TP: output rows (tokens) per tile, WM x WP: wave grid over (columns, rows).
 //
@@ -72,19 +77,22 @@ __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff
 // version that counted on it -- "[K1'][K2'][S stores][K3]: at most 2P + S outstanding means K1' has landed" -- read K tiles before they had landed whenever the
 // stores were acknowledged first: wrong results on the first call, right ones on a rerun that found the same bytes still in LDS).  So no wait ever leaves a store
 // AND a needed load behind it: a count is only trusted where it forces every store to have retired.
-//   kernel start        [bias K0][K1][K2]                                wait 0
-//   tile entry          K0 .. K2 and the bias slice have landed; the previous tile's stores may be in flight
-//   t = 0, 1            + K3, + K4                                       no wait (K1, K2 landed at the previous tile's end)
-//   t = 2               [S stores in any state][K3][K4][K5]              wait 2P: at most 2P outstanding = every store and K3 retired
-//   t = 3 .. nK - 4     steady state                                     wait 2P
-//   t = nK - 3, nK - 2  + [bias' K0'] (P + 1 pieces), + K1'              wait 2P + 1
-//   t = nK - 1          + K2'                                            wait 0: the next tile's first three K tiles have landed before this tile's stores go out
-// Needs nK >= 6 (K >= 192); the host sends shorter reductions to the small batched kernel.  No scratch: a spilled register's reload is a VMEM load, and
+//   kernel start        [bias K0][K1] .. [K(PF-1)]                       wait 0          (PF = NBUF - 1 K tiles ahead: as deep as 160 KB of LDS allow for the tile --
+//                                                                                        three K steps, 1.5 us, do not cover an HBM miss: with inputs the previous
+//                                                                                        kernel wrote instead of inputs the same GEMM just read, the 4-slot ring of the
+//                                                                                        256 x 160 tile measured 81 us on fc2 against 67 warm; tools/bench_gemm.py --cold)
+//   tile entry          K0 .. K(PF-1) and the bias slice have landed; the previous tile's stores may be in flight
+//   t = 0 .. PF - 2     + K(PF + t)                                      no wait (K(t + 1) landed at the previous tile's end)
+//   t = PF - 1          [S stores in any state][K(PF)] .. [K(2PF - 1)]   wait (PF-1) P: at most that many outstanding = every store and K(PF) retired
+//   t = PF .. nK-PF-1   steady state                                     wait (PF-1) P
+//   t = nK-PF .. nK-2   + [bias' K0'] (P + 1 pieces), + K1' ..           wait (PF-1) P + 1
+//   t = nK - 1          + K(PF-1)'                                       wait 0: the next tile's first PF K tiles have landed before this tile's stores go out
+// Needs nK >= 2 PF (the host asks for K >= 384 and sends shorter reductions to the small batched kernel).  No scratch: a spilled register's reload is a VMEM load, and
 // the wait the compiler puts behind it drains the whole prefetch queue (measured: 10 k cycles per tile with 31 spilled VGPRs).
-template <int TM, int TP, int WM, int WP, bool OUT_F32>
+template <int TM, int TP, int WM, int WP, bool OUT_F32, int NBUF>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__
-  constexpr int NBUF = 4;
+  constexpr int PF = NBUF - 1;                     // K tiles in flight ahead of the one being read
   constexpr int CL = TM / WM / 16, BT = TP / WP / 16;   // 16 x 16 accumulator blocks per wave: CL column blocks (= consecutive columns per lane) x BT token blocks
   static_assert(WM * WP == 8 && CL * 16 * WM == TM && BT * 16 * WP == TP && CL * BT <= 32 && (CL == 4 || CL == 6 || CL == 8), "8 waves, at most 32 accumulators each");
   constexpr int TILE_A = TM * 64, TILE_B = TP * 64, SLOT = TILE_A + TILE_B, RING = NBUF * SLOT;
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
   const unsigned bsz = a.bias_bf16 ? 2u : 4u;
   const float inv_ntn = a.inv_ntn;   // from the host: a kernel argument lives in an SGPR (computed here it sat in a VGPR and was spilled)
 
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)a.N * (unsigned)a.ldw * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)a.M * (unsigned)a.lda * 2u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)a.N * bsz : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)a.M * (unsigned)a.ldy * (OUT_F32 ? 4u : 2u), 0x00020000);
@@ -123,13 +131,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
     if (nt >= a.ntn) { mt++; nt -= a.ntn; }
     m0 = __builtin_amdgcn_readfirstlane(mt) * TP;
     n0 = __builtin_amdgcn_readfirstlane(nt) * TM;
+    // Every tile starts its reduction at K tile 0 and the CUs walk K in step: the tiles of one row / column of tiles, running side by side, ask for the same
+    // operand lines at the same time and all but one request hit in L2.  (A per-tile starting K tile, to spread the chip's requests over more addresses, was
+    // measured and destroys exactly that: fc2 70 -> 98 us.)
 #pragma unroll
     for (int p = 0; p < NPA; p++) {
       const int rl = (wave * NPA + p) * 16 + (lane_c >> 2);     // LDS row of the weight tile: wave column range rl / CW, column block i, MFMA column c
       const int wmr = rl / CW, r = rl % CW, i = r >> 4, c = r & 15;
       const int n = n0 + wmr * CW + CL * c + i;
       const int ch = (lane_c & 3) ^ swz64(rl);                  // logical 16-B chunk this lane fetches: the LDS image stays lane-linear, the swizzle is on the source address
-      vA[p] = (live && rl < TM && n < a.N) ? (unsigned)n * (unsigned)a.ldw * 2u + ch * 16u : SENT;
+      vA[p] = (live && rl < TM && n < a.N) ? (unsigned)n * a.wsRow + ch * 16u : SENT;
     }
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
@@ -141,16 +152,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
     const unsigned e0 = (unsigned)lane_c * (16u / bsz);         // first element of this lane's 16 bytes of the slice
     vBias = (live && wave == 0 && e0 < (unsigned)TM && (unsigned)n0 + e0 < (unsigned)a.N) ? ((unsigned)n0 + e0) * bsz : SENT;
   };
-  auto issue_k = [&](const unsigned (&vA)[NPA], const unsigned (&vB)[NPB], unsigned so, int slot) {
+  auto issue_k = [&](const unsigned (&vA)[NPA], const unsigned (&vB)[NPB], unsigned kt, int slot) {   // kt: K tile
 #pragma unroll
     for (int p = 0; p < NPA; p++) {
       const int g = wave * NPA + p;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + (g * 16 < TM ? slot + g * 1024 : DUMP_OFF)), 16, vA[p], so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + (g * 16 < TM ? slot + g * 1024 : DUMP_OFF)), 16, vA[p], kt * a.wsK, 0, 0);
     }
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
       const int g = wave * NPB + p;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + (g * 16 < TP ? slot + TILE_A + g * 1024 : DUMP_OFF)), 16, vB[p], so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + (g * 16 < TP ? slot + TILE_A + g * 1024 : DUMP_OFF)), 16, vB[p], kt * 64u, 0, 0);
     }
   };
   auto issue_bias = [&](unsigned vBias, int par) {
@@ -167,22 +178,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
   bf16x8 wf[CL], tf[BT];
   unsigned vAc[NPA], vBc[NPB], vAn[NPA], vBn[NPB], vBiasN;
   int m0c, n0c, m0n = 0, n0n = 0;
-  int slot_rd = 0, slot_wr = 3 * SLOT, par = 0;
-  int it = 3;              // next K tile of the current output tile to issue
+  int slot_rd = 0, slot_wr = PF * SLOT, par = 0;
+  int it = PF;             // next K step of the current output tile to issue
+
 
   // one K step: LOAD interval (fragments of the slot being read, DMA issue into the slot being written), barrier, COMPUTE interval, barrier
   auto kstep = [&](auto WAITc, auto MODEc) __attribute__((always_inline)) {
-    constexpr int WAIT = decltype(WAITc)::value, MODE = decltype(MODEc)::value;   // MODE 0: the current tile's K tile `it`; 1 / 2 / 3: the next tile's K tile 0 (+ bias) / 1 / 2
+    constexpr int WAIT = decltype(WAITc)::value, MODE = decltype(MODEc)::value;   // MODE 0: the current tile's K tile `it`; j >= 1: the next tile's K tile j - 1 (+ the bias slice with j = 1)
     const char* sw = smem + slot_rd + wbase;
     const char* st = smem + slot_rd + tbase;
 #pragma unroll
     for (int j = 0; j < BT; j++) tf[j] = *reinterpret_cast<const bf16x8*>(st + j * 1024);
 #pragma unroll
     for (int i = 0; i < CL; i++) wf[i] = *reinterpret_cast<const bf16x8*>(sw + i * 1024);
-    if constexpr (MODE == 0) { issue_k(vAc, vBc, (unsigned)it * 64u, slot_wr); it++; }
+    if constexpr (MODE == 0) { issue_k(vAc, vBc, (unsigned)it, slot_wr); it++; }
     else {
       if constexpr (MODE == 1) issue_bias(vBiasN, par ^ 1);
-      issue_k(vAn, vBn, (unsigned)(MODE - 1) * 64u, slot_wr);
+      issue_k(vAn, vBn, (unsigned)(MODE - 1), slot_wr);
     }
     slot_rd = slot_rd + SLOT == RING ? 0 : slot_rd + SLOT;
     slot_wr = slot_wr + SLOT == RING ? 0 : slot_wr + SLOT;
@@ -201,8 +213,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  using W_NO = std::integral_constant<int, -1>; using W_0 = std::integral_constant<int, 0>; using W_2P = std::integral_constant<int, 2 * NP>; using W_2P1 = std::integral_constant<int, 2 * NP + 1>;
-  using M0_ = std::integral_constant<int, 0>; using M1_ = std::integral_constant<int, 1>; using M2_ = std::integral_constant<int, 2>; using M3_ = std::integral_constant<int, 3>;
+  using W_NO = std::integral_constant<int, -1>; using W_0 = std::integral_constant<int, 0>;
+  using W_ST = std::integral_constant<int, (PF - 1) * NP>; using W_TL = std::integral_constant<int, (PF - 1) * NP + 1>;
+  using M0_ = std::integral_constant<int, 0>;
+  static_assert((PF - 1) * NP + 1 < 64, "vmcnt is a 6-bit counter");
 
   unsigned work = blockIdx.x;
   {
@@ -210,9 +224,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
     calc(work, vAc, vBc, vBiasC, m0c, n0c);
     issue_bias(vBiasC, 0);
   }
-  issue_k(vAc, vBc, 0u, 0);
-  issue_k(vAc, vBc, 64u, SLOT);
-  issue_k(vAc, vBc, 128u, 2 * SLOT);
+#pragma unroll
+  for (int u = 0; u < PF; u++) issue_k(vAc, vBc, (unsigned)u, u * SLOT);
   wait_vmcnt<0>();
 
   int tix = 0;
@@ -249,17 +262,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
     stamp(1);
     if (grp == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
     if (grp == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one interval behind group 0
-    it = 3;
-    kstep(W_NO{}, M0_{});
-    kstep(W_NO{}, M0_{});
-    kstep(W_2P{}, M0_{});
+    it = PF;
+    [&]<int... T>(std::integer_sequence<int, T...>) __attribute__((always_inline)) { (((void)T, kstep(W_NO{}, M0_{})), ...); }(std::make_integer_sequence<int, PF - 1>{});
+    kstep(W_ST{}, M0_{});
 #pragma unroll 1
-    for (int t = 3; t < nK - 3; t++) kstep(W_2P{}, M0_{});
+    for (int t = PF; t < nK - PF; t++) kstep(W_ST{}, M0_{});
     const unsigned next = work + gridDim.x;
     calc(next, vAn, vBn, vBiasN, m0n, n0n);       // all out of range when there is no next tile: its pieces move no memory
-    kstep(W_2P1{}, M1_{});
-    kstep(W_2P1{}, M2_{});
-    kstep(W_0{}, M3_{});
+    [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) { (kstep(W_TL{}, std::integral_constant<int, J + 1>{}), ...); }(std::make_integer_sequence<int, PF - 1>{});
+    kstep(W_0{}, std::integral_constant<int, PF>{});
     if (grp == 0) __builtin_amdgcn_s_barrier();    // matches group 1's extra barrier
     if (grp == 1) __builtin_amdgcn_s_setprio(0);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA (inline asm, invisible to the hazard recogniser) -> accumulator reads
@@ -358,27 +369,34 @@ int launch(Args a, hipStream_t st) {
   a.total = ((a.M + TP - 1) / TP) * a.ntn;
   a.inv_ntn = 1.0f / (float)a.ntn;
   const unsigned grid = a.total > 256 ? 256u : (unsigned)a.total;
-  constexpr int lds = 4 * (TM + TP) * 64 + 3 * 1024;   // ring + two bias slots + the dump KiB
-  static_assert(lds <= 160 * 1024, "LDS");
+  constexpr int slot = (TM + TP) * 64;
+  constexpr int fit = (160 * 1024 - 3 * 1024) / slot;          // ring slots that fit beside the two bias slots and the dump KiB
+  constexpr int nbuf = fit > DMVAE_GEMM_MAXBUF ? DMVAE_GEMM_MAXBUF : fit;
+  static_assert(nbuf >= 4, "LDS");
+  constexpr int lds = nbuf * slot + 3 * 1024;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<TM, TP, WM, WP, F32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<TM, TP, WM, WP, F32, nbuf>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<TM, TP, WM, WP, F32>), dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<TM, TP, WM, WP, F32, nbuf>), dim3(grid), dim3(512), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
 
-// The tile menu: (columns, rows, relative cost of one K step of the tile in units of a 256 x 256 tile's -- measured, tools/bench_gemm.py --sweep).
+// The tile menu: (columns, rows, cost of one tile relative to a 256 x 256 tile's at the same K with the whole chip busy -- measured on the 16384 x 6144 x 1152
+// problem, 6 to 12 rounds per entry: tools/bench_gemm.py --sweep --cold --kmajor).  Smaller tiles cost more per flop: 0.80 for 62.5 % of the area.
 struct Cfg { int tm, tp; float cost; };
 static const Cfg g_cfg[] = {
-    {256, 256, 1.00f}, {256, 224, 0.90f}, {256, 192, 0.79f}, {256, 160, 0.68f}, {256, 128, 0.57f},
-    {128, 448, 0.95f}, {128, 384, 0.80f}, {128, 256, 0.57f}, {192, 256, 0.80f}, {192, 320, 0.98f},
+    {256, 256, 1.00f}, {256, 224, 0.94f}, {256, 192, 0.885f}, {256, 160, 0.80f}, {256, 128, 0.67f},
+    {128, 448, 1.02f}, {128, 384, 0.93f}, {128, 256, 0.70f},  {192, 256, 0.90f}, {192, 320, 1.12f},
 };
 constexpr int NCFG = sizeof(g_cfg) / sizeof(g_cfg[0]);
 
 static int g_forced = -2;   // -2: not read yet; -1: plan by cost; >= 0: this menu entry (DMVAE_GEMM_CFG, or dmvae_debug_gemm_cfg from tools/bench_gemm.py)
+// Time model: tiles / 256 rounds of the tile's cost -- FRACTIONAL rounds, because the chip is power-limited: with half of the CUs idle in the last round the
+// busy ones clock higher and the round ends sooner (896 tiles of 256 x 256 = 3.5 rounds measure 3.5 x one round's time, not 4 x) -- but a round never costs
+// less than 0.85 of a full one.  Ragged tiles are whole tiles (their padding rows / columns cost what real ones do).
 static int plan(int M, int N, int K) {
   if (g_forced == -2) { const char* e = getenv("DMVAE_GEMM_CFG"); g_forced = e ? atoi(e) : -1; }
   const int forced = g_forced;
@@ -388,9 +406,8 @@ static int plan(int M, int N, int K) {
   float best_t = 1e30f;
   for (int c = 0; c < NCFG; c++) {
     const long long tiles = (long long)((M + g_cfg[c].tp - 1) / g_cfg[c].tp) * ((N + g_cfg[c].tm - 1) / g_cfg[c].tm);
-    const long long rounds = (tiles + 255) / 256;
-    // padding columns are wasted work inside a tile (N = 1152 on 256-column tiles), padding rows likewise: both are in `tiles`
-    const float t = (float)rounds * g_cfg[c].cost;
+    const float frac = (float)tiles / 256.0f, whole = 0.85f * (float)((tiles + 255) / 256);
+    const float t = (frac > whole ? frac : whole) * g_cfg[c].cost;
     if (t < best_t * 0.999f) { best_t = t; best = c; }
   }
   return best;
@@ -427,18 +444,24 @@ extern "C" int dmvae_linear_bf16_plan(int M, int N, int K, int* tile_cols, int* 
 }
 
 extern "C" int dmvae_linear_bf16(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int lda, int ldw, int ldy,
-                                 int act, int bias_bf16, int out_f32, hipStream_t stream) {
+                                 int act, int bias_bf16, int out_f32, int w_layout, hipStream_t stream) {
   using namespace dmvae_gemm_pp;
   DMVAE_CHECK_ARG(x && w && y, "linear_bf16: null operand");
-  DMVAE_CHECK_ARG(M > 0 && N > 0 && K >= 192 && K % 32 == 0 && N % 8 == 0, "linear_bf16: need K %% 32 == 0, K >= 192 and N %% 8 == 0 (M %d, N %d, K %d)", M, N, K);
-  DMVAE_CHECK_ARG(lda >= K && ldw >= K && ldy >= N && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0, "linear_bf16: leading dimensions must cover the rows and be multiples of 8");
+  DMVAE_CHECK_ARG(M > 0 && N > 0 && K >= 384 && K % 32 == 0 && N % 8 == 0, "linear_bf16: need K %% 32 == 0, K >= 384 and N %% 8 == 0 (M %d, N %d, K %d)", M, N, K);
+  DMVAE_CHECK_ARG(w_layout == 0 || w_layout == 1, "linear_bf16: w_layout must be 0 (row-major [N][ldw]) or 1 (K-tile-major [K / 32][N][32])");
+  DMVAE_CHECK_ARG(lda >= K && (w_layout == 1 || ldw >= K) && ldy >= N && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0,
+                  "linear_bf16: leading dimensions must cover the rows and be multiples of 8");
   DMVAE_CHECK_ARG(act == 0 || act == 1 || act == 5, "linear_bf16: act must be 0 (none), 1 (SiLU) or 5 (GELU)");
-  DMVAE_CHECK_ARG((long long)M * lda * 2 < (1ll << 31) && (long long)N * ldw * 2 < (1ll << 31) && (long long)M * ldy * (out_f32 ? 4 : 2) < (1ll << 31),
+  const long long wb = w_layout == 1 ? (long long)N * K * 2 : (long long)N * ldw * 2;
+  DMVAE_CHECK_ARG((long long)M * lda * 2 < (1ll << 31) && wb < (1ll << 31) && (long long)M * ldy * (out_f32 ? 4 : 2) < (1ll << 31),
                   "linear_bf16: operands are addressed through 32-bit buffer offsets (2 GiB each)");
   Args a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.y = y;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldy = ldy;
   a.act = act; a.bias_bf16 = bias_bf16; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = g_gemm_dbg;
+  a.wbytes = (unsigned)wb;
+  a.wsRow = w_layout == 1 ? 64u : (unsigned)ldw * 2u;
+  a.wsK = w_layout == 1 ? (unsigned)N * 64u : 64u;
   const int cfg = plan(M, N, K);
   return out_f32 ? dispatch<true>(cfg, a, stream) : dispatch<false>(cfg, a, stream);
 }

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __rest
   }
 }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_f(float x) { return dmvae_gelu_f(x); }   // common.h: erf from A&S 7.1.26, the same bits as the GEMM epilogue's
 __device__ __forceinline__ float gelu_grad_f(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }

@@ -32,7 +32,7 @@ def _epoch_of(w) -> int:
 
 
 def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad: int = 0, frozen: bool = False,
-           transposed: bool = False, subpixel: bool = False) -> torch.Tensor:
+           transposed: bool = False, subpixel: bool = False, kmajor: bool = False) -> torch.Tensor:
     """bf16 kernel operand of an f32 conv/linear weight, cached ON the parameter object until the weight changes
     (in-place updates bump ``_version``; raw-pointer optimisers call bump_weight_epoch, which `frozen` weights -- not owned
     by any optimiser, e.g. the LPIPS trunk -- ignore).  subpixel: the operand of the 4x4 stride-2 conv D that Upsample's
@@ -44,16 +44,20 @@ def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad
             w._dmvae_packed = cache
         except AttributeError:      # non-leaf views etc.: no caching
             pass
-    key = (for_dgrad, rows_pad, cols_pad, transposed, parity.on(), subpixel)
-    ver = (w.data_ptr(), w._version, -1 if frozen else _epoch_of(w))
+    key = (for_dgrad, rows_pad, cols_pad, transposed, parity.on(), subpixel, kmajor)
+    ver = (w.data_ptr(), _ver(w), -1 if frozen else _epoch_of(w))      # _ver: inference tensors (a frozen module built under inference_mode) keep no version counter
     hit = cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
     src = w.detach().contiguous()
+    if src.dtype != f32:            # a bf16 shadow module's weight (train.frozen_bf16_shadow): the pack kernel reads f32
+        src = src.float()
     if subpixel:
         src = ops.subpixel_weight(src)
     # 3x3 convs: the pack also writes the K-tile-major copy the kx-halo conv kernel reads (whole 128-B lines per weight tile; ops._weight_operand)
-    p = ops.pack_conv_weight(src, for_dgrad, rows_pad, cols_pad, kmajor=(src.dim() == 4 and src.shape[2] == 3 and not transposed and not subpixel))
+    # kmajor: the same for a Linear weight -- the operand `ops.linear_bf16` reads whole 128-B lines from (csrc/gemm_pp.hip, w_layout = 1)
+    p = ops.pack_conv_weight(src, for_dgrad, rows_pad, cols_pad,
+                             kmajor=(src.dim() == 4 and src.shape[2] == 3 and not transposed and not subpixel) or (kmajor and src.dim() == 2 and not transposed))
     if transposed:       # [rows][taps*cols] -> [taps*cols][rows]: the B operand of the im2col convs' input-gradient GEMM
         p = p.view(p.shape[0], -1).t().contiguous()
     cache[key] = (ver, p)
@@ -468,14 +472,21 @@ class NormConvOutFn(torch.autograd.Function):
         return dx, dnw, dnb, dwp[:cout].contiguous(), dbp[:cout].contiguous()
 
 
+def _nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [M, K] @ w [N, K]^T + bias on the large-tile Linear GEMM where it takes the shape (bf16 operands, outside the fp32 parity mode), else the batched NT kernel."""
+    if x.dtype == bf16 and w.dtype == bf16 and not parity.on() and x.dim() == 2 and ops.linear_supported(x.shape[0], w.shape[0], x.shape[1]):
+        return ops.linear_bf16(x, w, bias)
+    return ops.gemm_nt(x, w, bias)
+
+
 class MLPFn(torch.autograd.Function):
     """Linear -> SiLU -> Linear on tokens (models/vae.py:56-65); x [M, Cin] bf16."""
 
     @staticmethod
     def forward(ctx, x, w0, b0, w2, b2):
-        h = ops.gemm_nt(x, packed(w0).view(w0.shape[0], -1), b0)          # [out, in] (parity mode: [out, 6*in], the split weight-side parts)
+        h = _nt(x, packed(w0).view(w0.shape[0], -1), b0)          # [out, in] (parity mode: [out, 6*in], the split weight-side parts)
         a = ops.silu(h)
-        y = ops.gemm_nt(a, packed(w2).view(w2.shape[0], -1), b2)
+        y = _nt(a, packed(w2).view(w2.shape[0], -1), b2)
         ctx.save_for_backward(x, h, a, w0, w2)
         ctx.bias_params = (b0, b2)
         return y
@@ -488,10 +499,10 @@ class MLPFn(torch.autograd.Function):
         b0, b2 = ctx.bias_params
         v4 = lambda t: None if t is None else t.view(t.shape[0], t.shape[1], 1, 1)
         dw2, db2 = ops.conv2d_nhwc_wgrad(dy.view(1, 1, m, -1), a.view(1, 1, m, -1), 1, dw_out=v4(_dst(w2)), db_out=_dst(b2))
-        da = ops.gemm_nt(dy, packed(w2, True).view(w2.shape[1], -1))
+        da = _nt(dy, packed(w2, True).view(w2.shape[1], -1))
         dh = ops.silu_bwd(h, da)
         dw0, db0 = ops.conv2d_nhwc_wgrad(dh.view(1, 1, m, -1), x.view(1, 1, m, -1), 1, dw_out=v4(_dst(w0)), db_out=_dst(b0))
-        dx = ops.gemm_nt(dh, packed(w0, True).view(w0.shape[1], -1)) if ctx.needs_input_grad[0] else None
+        dx = _nt(dh, packed(w0, True).view(w0.shape[1], -1)) if ctx.needs_input_grad[0] else None
         return dx, dw0.view(w0.shape), db0, dw2.view(w2.shape), db2
 
 
@@ -522,10 +533,62 @@ def _bf(w: torch.Tensor) -> torch.Tensor:
     return v
 
 
+def _bf_t(w: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of the TRANSPOSE [in, out] of a Linear weight [out, in] -- the operand that makes the input gradient dX = dY . W the same NT GEMM as the
+    forward --, cached until the weight changes (the dgrad layout of `packed`: one pack launch per weight version): K-tile-major [out / 32, in, 32] when the
+    reduction length `out` is a multiple of 32 (the same launch writes it), else row-major [in, out]."""
+    cout, cin = w.shape
+    if cout % 32 == 0 and not parity.on():
+        return packed(w, True, kmajor=True)._dmvae_kmajor.view(cout // 32, cin, 32)
+    return packed(w, True).view(cin, cout)
+
+
+def _bf_km(w: torch.Tensor) -> torch.Tensor:
+    """K-tile-major bf16 copy [in / 32, out, 32] of a FROZEN Linear weight [out, in] (f32 parameter or a bf16 shadow module's weight): packed once, then every K
+    tile the GEMM fetches is one contiguous run of whole 128-B lines."""
+    cout, cin = w.shape
+    return packed(w, kmajor=True, frozen=True)._dmvae_kmajor.view(cin // 32, cout, 32)
+
+
+_KMAJOR_FROZEN = os.environ.get("DMVAE_LINEAR_KMAJOR", "1") != "0"     # 0: frozen weights too are read row-major (A/B runs)
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, act: int = ops.ACT_NONE) -> torch.Tensor:
+    """nn.Linear under autocast(bf16) on this build's GEMM kernels (no vendor library): x [..., K] bf16; w [N, K] and b [N] the f32 parameters (their bf16
+    copies are cached / shadowed, `_bf`) or already-bf16 tensors (a frozen bf16 shadow module).  f32 accumulation, bias added in f32, bf16 result, optional
+    fused GELU / SiLU (on the bf16-rounded pre-activation: the reference's Linear -> activation pair).  Shapes the large-tile kernel does not take
+    (csrc/gemm_pp.hip: K < 192 or not a multiple of 32, fewer than 64 rows: the per-sample adaLN / embedder Linears) run on the small batched NT kernel.
+    Reference sites: timm blocks via models/vae.py:47-53; diffusion/lightningdit/lightningdit.py:34-93,173-252; swiglu_ffn.py:15-36."""
+    bb = None if b is None else (b if b.dtype == bf16 else _bf(b))
+    k = x.shape[-1]
+    n = w.shape[0]
+    m = x.numel() // k
+    x = _c(x)
+    if x.dtype != bf16:
+        x = x.to(bf16)
+    if ops.linear_supported(m, n, k):
+        if not w.requires_grad and w.dim() == 2 and _KMAJOR_FROZEN:     # frozen weights: the K-tile-major copy (one pack per weight, ever)
+            return ops.linear_bf16(x, _bf_km(w), bb, act)
+        return ops.linear_bf16(x, (w if w.dtype == bf16 else _bf(w)).view(n, k), bb, act)
+    wb = w if w.dtype == bf16 else _bf(w)
+    x2, w2 = x.view(m, k), wb.view(n, k)
+    if k % 32 != 0 or n % 4 != 0:      # reduced test models (a patch embedding with K = 8): zero-pad the reduction / the output columns up to the kernel's steps
+        kp, np_ = (-k) % 32, (-n) % 4
+        x2 = torch.nn.functional.pad(x2, (0, kp))
+        w2 = torch.nn.functional.pad(w2, (0, kp, 0, np_))
+        bb = None if bb is None else torch.nn.functional.pad(bb, (0, np_))
+    y = ops.gemm_nt(x2, w2, None if bb is None else bb.float())[:, :n]
+    if act == ops.ACT_GELU:
+        y = ops.gelu(y)
+    elif act == ops.ACT_SILU:
+        y = ops.silu(y)
+    return y.reshape(*x.shape[:-1], n)
+
+
 def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Tensor, need_dx: bool = True):
     """Gradients of y = x @ w^T + b for bf16 operands [rows, .]: dW and db from the split-K weight-gradient kernel (f32 results, bias
     gradient fused on the matrix pipe; the 1x1 case of the conv wgrad) when its shape constraints hold, else a library GEMM + column sum;
-    dx = dy @ w as a library GEMM (hipBLASLt through torch.matmul, bf16 like the reference's autocast backward)."""
+    dx = dy @ w on the Linear GEMM kernel against the transposed bf16 copy of w (bf16 like the reference's autocast backward)."""
     rows, cout = dy2.shape
     cin = x2.shape[1]
     if cin % 8 == 0 and cout % 8 == 0:
@@ -535,7 +598,35 @@ def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Te
         dw = dw.view(cout, cin)
     else:
         dw, db = (dy2.t() @ x2).float(), dy2.float().sum(0)
-    return (dy2 @ _bf(w)) if need_dx else None, dw, db
+    if not need_dx:
+        return None, dw, db
+    if ops.linear_supported(rows, cin, cout):
+        return ops.linear_bf16(_c(dy2), _bf_t(w)), dw, db                 # dX = dY . W as an NT GEMM against the transposed copy
+    return ops.gemm_nt(_c(dy2), packed(w, True).view(cin, cout)) if (cout % 32 == 0 and cin % 4 == 0) else (dy2 @ _bf(w)), dw, db
+
+
+class LinearFn(torch.autograd.Function):
+    """nn.Linear under autocast(bf16) with gradients, entirely on this build's kernels: forward `linear`, backward `_lin_grads` (weight / bias gradient from
+    the split-K kernel in f32, input gradient as an NT GEMM against the transposed bf16 weight copy).  x [..., K] (any float dtype: cast to bf16 like autocast
+    does), w [N, K] / b [N] f32 parameters.  For the Linear layers outside the transformer-block Functions: patch embeddings, adaLN modulations, output heads."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xb = _c(x).to(bf16)
+        ctx.save_for_backward(xb, w)
+        ctx.bias = b
+        ctx.x_dtype = x.dtype
+        return linear(xb, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, w = ctx.saved_tensors
+        n, k = w.shape[0], xb.shape[-1]
+        rows = xb.numel() // k
+        dx, dw, db = _lin_grads(_c(dy).to(bf16).view(rows, n), xb.view(rows, k), w.view(n, k), ctx.bias, need_dx=ctx.needs_input_grad[0])
+        if ctx.bias is None:
+            db = None
+        return (None if dx is None else dx.view(xb.shape).to(ctx.x_dtype)), dw.view(w.shape), db
 
 
 def _fused_attn_bwd() -> bool:
@@ -574,8 +665,8 @@ class VitBlockFn(torch.autograd.Function):
     """One pre-norm transformer block on the f32 residual stream t [B,S,C]:
         t += ls1 * proj(MHA(LN1(t)));  t += ls2 * fc2(GELU(fc1(LN2(t))))
     with bf16 Linear operands / results (autocast semantics).  Forward = the frozen path's kernels (LayerNorm -> bf16, fused attention,
-    LayerScale + residual) plus the HIP GELU; backward = csrc/vit_bwd.hip kernels, the GEMM-composed attention backward and library
-    GEMMs for the Linear layers."""
+    LayerScale + residual) plus the HIP GELU; backward = csrc/vit_bwd.hip kernels, the fused attention backward, and for the Linear layers the
+    Linear GEMM kernel (csrc/gemm_pp.hip: forward and input gradient) and the split-K weight-gradient kernel."""
 
     @staticmethod
     def forward(ctx, t, n1w, n1b, qkvw, qkvb, pw, pb, ls1, n2w, n2b, f1w, f1b, f2w, f2b, ls2, heads, eps):
@@ -583,14 +674,14 @@ class VitBlockFn(torch.autograd.Function):
         b, s, c = t.shape
         hd = c // heads
         hn1 = ops.layernorm_bf16(t, n1w, n1b, eps)
-        qkv = F.linear(hn1, _bf(qkvw), _bf(qkvb))
+        qkv = linear(hn1, qkvw, qkvb)
         o = ops.attention_qkv(qkv, heads, hd ** -0.5)
-        o2 = F.linear(o, _bf(pw), _bf(pb))
+        o2 = linear(o, pw, pb)
         t_mid = ops.scale_residual_(t.clone(), o2, ls1)
         hn2 = ops.layernorm_bf16(t_mid, n2w, n2b, eps)
-        h1 = F.linear(hn2, _bf(f1w), _bf(f1b))
+        h1 = linear(hn2, f1w, f1b)
         g = ops.gelu(h1)
-        o3 = F.linear(g, _bf(f2w), _bf(f2b))
+        o3 = linear(g, f2w, f2b)
         t_out = ops.scale_residual_(t_mid.clone(), o3, ls2)
         ctx.save_for_backward(t, hn1, qkv, o, o2, t_mid, hn2, h1, g, o3, n1w, qkvw, pw, ls1, n2w, f1w, f2w, ls2)
         ctx.others = (n1b, qkvb, pb, n2b, f1b, f2b, heads, eps)
@@ -653,7 +744,7 @@ class DitBlockFn(torch.autograd.Function):
         d = c // heads
         mod = _c(mod)
         a1 = ops.rmsnorm_modulate(h, n1w, mod, 0, c, eps)
-        qkv = F.linear(a1, _bf(qkvw), _bf(qkvb))
+        qkv = linear(a1, qkvw, qkvb)
         q, k, v = ops.qknorm_rope(qkv, qnw, knw, cos, sin, heads, eps)
         fused = ops.attention_heads_supported(n, d) and _fused_attn_bwd()
         if fused:       # the inference kernel; its backward recomputes the probabilities in registers (csrc/attention_bwd.hip)
@@ -662,11 +753,11 @@ class DitBlockFn(torch.autograd.Function):
         else:
             p = ops.softmax_rows(ops.gemm_nt(q, k, out_f32=True), d ** -0.5)
             o = ops.gemm_nt(p, ops.transpose_last2(v)).view(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, c)
-        o2 = F.linear(o, _bf(pw), _bf(pb))
+        o2 = linear(o, pw, pb)
         h_mid, a2 = ops.gated_residual_out(h, o2, mod, 2 * c, n2w, mod, 3 * c, 4 * c, eps)       # h itself is saved for the backward pass
-        x12 = F.linear(a2, _bf(w12w), _bf(w12b))
+        x12 = linear(a2, w12w, w12b)
         g = ops.swiglu(x12)
-        o3 = F.linear(g, _bf(w3w), _bf(w3b))
+        o3 = linear(g, w3w, w3b)
         h_out, _ = ops.gated_residual_out(h_mid, o3, mod, 5 * c)
         ctx.save_for_backward(h, mod, a1, qkv, q, k, v, p, o, o2, h_mid, a2, x12, g, o3, n1w, qkvw, qnw, knw, pw, n2w, w12w, w3w, cos, sin)
         ctx.others = (qkvb, pb, w12b, w3b, heads, eps)

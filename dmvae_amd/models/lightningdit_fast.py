@@ -4,7 +4,8 @@
 Same arithmetic as `forward_stock` under autocast(bf16), with bf16 rounding at the sites where the reference's autocast graph rounds (see
 csrc/dit.hip); per block: 1 fused (gated residual +) RMSNorm+modulate, qkv GEMM, 1 fused QK-norm+RoPE+head split, attention in one fused kernel (csrc/vit.hip, head dims 64 and 72
 alike: the staged head dim pads to 96; composed batched QK^T GEMM / f32 softmax / PV GEMM beyond 288 tokens), proj GEMM, 1 gated residual, RMSNorm+modulate, w12 GEMM, SwiGLU gate, w3 GEMM,
-gated residual.  The tiny per-sample pieces (timestep / label embedding, adaLN Linear) stay stock PyTorch under autocast."""
+gated residual -- every Linear on this build's GEMM kernels (`functional.linear`: csrc/gemm_pp.hip, or the small batched NT kernel for the per-sample adaLN rows).
+The timestep / label embedding stays stock PyTorch under autocast."""
 import os
 
 import torch
@@ -55,13 +56,12 @@ def _attention(qkv, blk, rope, heads):
 @torch.no_grad()
 def forward_inference(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """x [B,C,H,W], t [B], y [B] -> velocity [B,C_out,H,W] in bf16 (what the stock modules return under autocast)."""
-    from .. import gemm_select
-    gemm_select.enable()             # fixed hipBLASLt solution table for the Linear GEMMs (dmvae_amd/tuned/)
+    from ..functional import linear
     b, cin, hh, ww = x.shape
     ps, c, heads = model.patch_size, model.hidden_size, model.num_heads
     w = model.x_embedder.proj.weight
     patches = x.view(b, cin, hh // ps, ps, ww // ps, ps).permute(0, 2, 4, 1, 3, 5).reshape(b, -1, cin * ps * ps)
-    h = F.linear(patches.to(_BF), _bf(w).view(w.shape[0], -1), _bf(model.x_embedder.proj.bias)).float() + model.pos_embed
+    h = linear(patches.to(_BF), _bf(w).view(w.shape[0], -1), _bf(model.x_embedder.proj.bias)).float() + model.pos_embed
     h = h.contiguous()
     n = h.shape[1]
     cvec = model.t_embedder(t) + model.y_embedder(y, False)                     # stock modules under the caller's autocast: [B, C] f32
@@ -72,7 +72,7 @@ def forward_inference(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) 
     fl = model.final_layer
 
     def adaln(lin):
-        return F.linear(scb, _bf(lin.weight), _bf(lin.bias)).contiguous()       # [B, 6C]: shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp
+        return linear(scb, lin.weight, lin.bias)                                # [B, 6C]: shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp
 
     pend = None                                                                   # (y, mod) of the previous block's MLP branch, not yet added to h
     for blk in model.blocks:
@@ -81,17 +81,17 @@ def forward_inference(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) 
             a = ops.rmsnorm_modulate(h, blk.norm1.weight, mod, 0, c, blk.norm1.eps)
         else:
             a = ops.gated_residual_rmsnorm_modulate_(h, pend[0], pend[1], 5 * c, blk.norm1.weight, mod, 0, c, blk.norm1.eps)
-        qkv = F.linear(a, _bf(blk.attn.qkv.weight), _bf(blk.attn.qkv.bias))
-        o = F.linear(_attention(qkv, blk, model.feat_rope, heads), _bf(blk.attn.proj.weight), _bf(blk.attn.proj.bias))
+        qkv = linear(a, blk.attn.qkv.weight, blk.attn.qkv.bias)
+        o = linear(_attention(qkv, blk, model.feat_rope, heads), blk.attn.proj.weight, blk.attn.proj.bias)
         a = ops.gated_residual_rmsnorm_modulate_(h, o, mod, 2 * c, blk.norm2.weight, mod, 3 * c, 4 * c, blk.norm2.eps)
-        g = ops.swiglu(F.linear(a, _bf(blk.mlp.w12.weight), _bf(blk.mlp.w12.bias)))
-        pend = (F.linear(g, _bf(blk.mlp.w3.weight), _bf(blk.mlp.w3.bias)), mod)
+        g = ops.swiglu(linear(a, blk.mlp.w12.weight, blk.mlp.w12.bias))
+        pend = (linear(g, blk.mlp.w3.weight, blk.mlp.w3.bias), mod)
     mod = adaln(fl.adaLN_modulation[1])                                           # [B, 2C]: shift | scale
     if pend is None:
         a = ops.rmsnorm_modulate(h, fl.norm_final.weight, mod, 0, c, fl.norm_final.eps)
     else:
         a = ops.gated_residual_rmsnorm_modulate_(h, pend[0], pend[1], 5 * c, fl.norm_final.weight, mod, 0, c, fl.norm_final.eps)
-    out = model.unpatchify(F.linear(a, _bf(fl.linear.weight), _bf(fl.linear.bias)))
+    out = model.unpatchify(linear(a, fl.linear.weight, fl.linear.bias))
     if model.learn_sigma:
         out, _ = out.chunk(2, dim=1)
     return out
@@ -133,27 +133,26 @@ class GraphedInference:
 
 
 def forward_train(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-    """`forward` with gradients (the student's flow-matching turn, train_dmd.py:565-575) under the caller's autocast(bf16): embedders, adaLN Linears
-    and the output Linear through stock autograd (per-sample or single GEMMs), every block as one `functional.DitBlockFn`, the final norm as
-    `RmsnormModulateFn`.  Label dropout as in the module (`y_embedder(y, model.training)`)."""
-    from .. import gemm_select
-    gemm_select.enable()             # fixed hipBLASLt solution table for the Linear GEMMs (dmvae_amd/tuned/)
-    from ..functional import DitBlockFn, RmsnormModulateFn
+    """`forward` with gradients (the student's flow-matching turn, train_dmd.py:565-575) under the caller's autocast(bf16): timestep / label embedders
+    through stock autograd, the patch embedding, adaLN Linears and the output Linear as `functional.LinearFn`, every block as one `functional.DitBlockFn`,
+    the final norm as `RmsnormModulateFn`.  Label dropout as in the module (`y_embedder(y, model.training)`)."""
+    from ..functional import DitBlockFn, LinearFn, RmsnormModulateFn
     b, cin, hh, ww = x.shape
     ps, c, heads = model.patch_size, model.hidden_size, model.num_heads
     w = model.x_embedder.proj.weight
     patches = x.view(b, cin, hh // ps, ps, ww // ps, ps).permute(0, 2, 4, 1, 3, 5).reshape(b, -1, cin * ps * ps)
-    h = (F.linear(patches, w.view(w.shape[0], -1), model.x_embedder.proj.bias).float() + model.pos_embed).contiguous()
+    h = (LinearFn.apply(patches, w.view(w.shape[0], -1), model.x_embedder.proj.bias).float() + model.pos_embed).contiguous()
     cvec = model.t_embedder(t) + model.y_embedder(y, model.training)
     rope = model.feat_rope
+    sc = F.silu(cvec)                                                             # adaLN_modulation = Sequential(SiLU, Linear): the SiLU once (f32, like autocast runs it)
     for blk in model.blocks:
-        mod = blk.adaLN_modulation(cvec)                                          # [B, 6C] bf16 under autocast, stock autograd
+        mod = LinearFn.apply(sc, blk.adaLN_modulation[1].weight, blk.adaLN_modulation[1].bias)     # [B, 6C] bf16
         h = DitBlockFn.apply(h, mod, blk.norm1.weight, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.q_norm.weight, blk.attn.k_norm.weight,
                              blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.mlp.w12.weight, blk.mlp.w12.bias, blk.mlp.w3.weight,
                              blk.mlp.w3.bias, rope.freqs_cos, rope.freqs_sin, heads, blk.norm1.eps)
     fl = model.final_layer
-    a = RmsnormModulateFn.apply(h, fl.norm_final.weight, fl.adaLN_modulation(cvec), 0, c, fl.norm_final.eps)
-    out = model.unpatchify(fl.linear(a))
+    a = RmsnormModulateFn.apply(h, fl.norm_final.weight, LinearFn.apply(sc, fl.adaLN_modulation[1].weight, fl.adaLN_modulation[1].bias), 0, c, fl.norm_final.eps)
+    out = model.unpatchify(LinearFn.apply(a, fl.linear.weight, fl.linear.bias))
     if model.learn_sigma:
         out, _ = out.chunk(2, dim=1)
     return out

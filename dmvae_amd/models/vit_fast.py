@@ -2,8 +2,9 @@
 frozen and runs under no_grad, train_tokenizer.py:295-297): same arithmetic as `vit.DinoV2ViT.forward_features` under
 autocast(bf16), with the elementwise chain on the HIP kernels of csrc/vit.hip -- LayerNorm straight to bf16, LayerScale +
 residual add fused on the f32 residual stream, multi-head attention as one fused MFMA kernel -- and the four Linear GEMMs
-per block through the bf16 weight shadow (hipBLASLt: measured faster than conv_pp on these M = 8224 shapes,
-tools/bench_gemm.py).  SURVEY.md 8(f) rank 3 ("next") -- forward / frozen case only."""
+per block (and the patch embedding) on the hand-written GEMM of csrc/gemm_pp.hip through the bf16 weight shadow, fc1 with its
+GELU in the epilogue (`functional.linear`; tools/bench_gemm.py has the per-call comparison with the vendor library it replaced).
+SURVEY.md 8(f) rank 3 ("next")."""
 import torch
 import torch.nn.functional as F
 
@@ -12,16 +13,18 @@ from .. import ops
 
 def patch_embed_gemm(vit, x: torch.Tensor) -> torch.Tensor:
     """PatchEmbed (Conv2d(kernel = stride = patch), dino_layers/patch_embed.py) as what it is -- one GEMM over non-overlapping patches:
-    [B,3,H,W] -> [B, N, 3*p*p] (channel, row, column order = the conv weight's) @ W^T + b.  Differentiable (views + a library GEMM); avoids
+    [B,3,H,W] -> [B, N, 3*p*p] (channel, row, column order = the conv weight's) @ W^T + b.  Differentiable (views + `functional.LinearFn`); avoids
     MIOpen's convolution search (minutes on the first backward call) and its atomically-accumulated, run-to-run different weight gradient."""
     w = vit.patch_embed.proj.weight
     b_, c, hh, ww = x.shape
     p = w.shape[-1]
     assert hh % p == 0 and ww % p == 0, "image size must be a multiple of the patch size"
     patches = x.view(b_, c, hh // p, p, ww // p, p).permute(0, 2, 4, 1, 3, 5).reshape(b_, (hh // p) * (ww // p), c * p * p)
-    if not torch.is_grad_enabled():          # frozen use: the cached bf16 copies (functional._bf), not a conversion per call
-        return F.linear(patches.to(torch.bfloat16), _w(w).view(w.shape[0], -1), _w(vit.patch_embed.proj.bias))
-    return F.linear(patches.to(torch.bfloat16), w.view(w.shape[0], -1).to(torch.bfloat16), vit.patch_embed.proj.bias.to(torch.bfloat16))
+    if not torch.is_grad_enabled():          # frozen use: the cached bf16 copies (functional._bf), not a conversion per call, on this build's GEMM
+        from ..functional import linear
+        return linear(patches.to(torch.bfloat16), _w(w).view(w.shape[0], -1), _w(vit.patch_embed.proj.bias))
+    from ..functional import LinearFn        # with gradients: the same GEMM forward, the weight gradient from the split-K kernel
+    return LinearFn.apply(patches, w.view(w.shape[0], -1), vit.patch_embed.proj.bias)
 
 
 def _w(p: torch.Tensor) -> torch.Tensor:
@@ -37,8 +40,7 @@ def frozen_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
     """vit: a DinoV2ViT -- either a bf16 shadow (train.frozen_bf16_shadow: Linear / Conv2d weights already bf16) or the f32 module itself, whose
     Linear weights are then served as cached bf16 copies (`functional._bf`, refreshed when a parameter changes); x: [B,3,H,W] f32, already normalised.
     Returns the final-norm tokens [B, 1+N, C] in bf16 (what the bottleneck MLP consumes)."""
-    from .. import gemm_select
-    gemm_select.enable()                                 # fixed hipBLASLt solution table for the four Linear GEMMs (dmvae_amd/tuned/)
+    from ..functional import linear
     t = patch_embed_gemm(vit, x).float()
     t = torch.cat([vit.cls_token.expand(t.shape[0], -1, -1).float(), t], dim=1) + vit.pos_embed.float()
     t = t.contiguous()                                   # f32 residual stream [B, S, C]
@@ -48,18 +50,18 @@ def frozen_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
     for i, blk in enumerate(vit.blocks):
         nh = blk.attn.num_heads
         hd = c // nh
-        qkv = F.linear(hn, _w(blk.attn.qkv.weight), _w(blk.attn.qkv.bias))              # [b, s, 3*c] = [b, s, 3, heads, hd]
+        qkv = linear(hn, _w(blk.attn.qkv.weight), _w(blk.attn.qkv.bias))              # [b, s, 3*c] = [b, s, 3, heads, hd]
         if hd == 64 and s <= 288:
             o = ops.attention_qkv(qkv, nh, hd ** -0.5)                             # fused: nothing of size s x s reaches HBM
         else:
             qkv = qkv.reshape(b, s, 3, nh, hd).permute(2, 0, 3, 1, 4)
             att = ops.softmax_rows_bf16(qkv[0] @ qkv[1].transpose(-2, -1), hd ** -0.5)   # scale, f32 softmax and the casts in one pass
             o = (att @ qkv[2]).transpose(1, 2).reshape(b, s, c)
-        o = F.linear(o, _w(blk.attn.proj.weight), _w(blk.attn.proj.bias))
+        o = linear(o, _w(blk.attn.proj.weight), _w(blk.attn.proj.bias))
         # every LayerScale + residual add is followed by a LayerNorm (this block's norm2, the next block's norm1, the final norm): one pass over the stream
         hn = ops.scale_residual_layernorm_(t, o.contiguous(), blk.ls1.gamma, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-        h = ops.gelu(F.linear(hn, _w(blk.mlp.fc1.weight), _w(blk.mlp.fc1.bias)))
-        o = F.linear(h, _w(blk.mlp.fc2.weight), _w(blk.mlp.fc2.bias))
+        h = linear(hn, _w(blk.mlp.fc1.weight), _w(blk.mlp.fc1.bias), act=ops.ACT_GELU)   # GELU in the GEMM's epilogue (bit-identical to the two kernels)
+        o = linear(h, _w(blk.mlp.fc2.weight), _w(blk.mlp.fc2.bias))
         nxt = vit.blocks[i + 1].norm1 if i + 1 < nblk else vit.norm
         hn = ops.scale_residual_layernorm_(t, o, blk.ls2.gamma, nxt.weight, nxt.bias, nxt.eps)
     return hn
@@ -78,8 +80,6 @@ def trainable_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
     (one GEMM over patches), class token and position embedding through stock autograd, every transformer block as one `VitBlockFn` on the f32
     residual stream, the final LayerNorm as `LayerNormBf16Fn`.  Same arithmetic as the module under autocast(bf16)."""
     from ..functional import LayerNormBf16Fn, VitBlockFn
-    from .. import gemm_select
-    gemm_select.enable()
     t = patch_embed_gemm(vit, x)
     t = torch.cat([vit.cls_token.expand(t.shape[0], -1, -1).float(), t.float()], dim=1) + vit.pos_embed.float()
     t = t.contiguous()

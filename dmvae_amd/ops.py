@@ -341,20 +341,27 @@ def linear_plan(m: int, n: int, k: int) -> Tuple[int, int, int]:
 
 
 def linear_supported(m: int, n: int, k: int) -> bool:
-    """Shapes dmvae_linear_bf16 takes: K a multiple of 32 and at least 192, N a multiple of 8, every operand below 2 GiB.  Problems with fewer than 64 rows
+    """Shapes dmvae_linear_bf16 takes: K a multiple of 32 and at least 384, N a multiple of 8, every operand below 2 GiB.  Problems with fewer than 64 rows
     (adaLN / embedder Linears on one row per sample) are left to the small batched NT kernel (gemm_nt): a 128-256-row tile would be nearly all padding."""
-    return k >= 192 and k % 32 == 0 and n % 8 == 0 and m >= 64 and m * max(n, k) * 2 < (1 << 31) and n * k * 2 < (1 << 31)
+    return k >= 384 and k % 32 == 0 and n % 8 == 0 and m >= 64 and m * max(n, k) * 2 < (1 << 31) and n * k * 2 < (1 << 31)
 
 
 def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, out_f32: bool = False) -> torch.Tensor:
-    """F.linear(x, w, bias) under autocast(bf16) on the hand-written GEMM (csrc/gemm_pp.hip): x [..., K] bf16, w [N, K] bf16 (the parameter's bf16 copy;
-    a [K_in, N_out]-transposed copy makes the same call the input gradient), bias [N] bf16 (autocast's operand) or f32, f32 accumulation, bf16 result
-    [..., N] (f32 with out_f32).  act = ACT_GELU / ACT_SILU fuses the activation on the bf16-rounded pre-activation (bit-identical to the two-kernel route)."""
+    """F.linear(x, w, bias) under autocast(bf16) on the hand-written GEMM (csrc/gemm_pp.hip): x [..., K] bf16; w bf16, either [N, K] (the parameter's bf16 copy;
+    a [K_in, N_out]-transposed copy makes the same call the input gradient) or its K-tile-major copy [K / 32, N, 32] (`pack_conv_weight(..., kmajor=True)`
+    leaves it as `._dmvae_kmajor`; whole 128-B lines per K tile -- what frozen weights are served as); bias [N] bf16 (autocast's operand) or f32; f32
+    accumulation, bf16 result [..., N] (f32 with out_f32).  act = ACT_GELU / ACT_SILU fuses the activation on the bf16-rounded pre-activation (bit-identical
+    to the two-kernel route)."""
     x = _req(x, bf16, "x")
     w = _req(w, bf16, "w")
     k = x.shape[-1]
-    n = w.shape[0]
-    assert w.dim() == 2 and w.shape[1] == k, (x.shape, w.shape)
+    kmajor = w.dim() == 3
+    if kmajor:
+        assert w.shape[2] == 32 and w.shape[0] * 32 == k, (x.shape, w.shape)
+        n = w.shape[1]
+    else:
+        assert w.dim() == 2 and w.shape[1] == k, (x.shape, w.shape)
+        n = w.shape[0]
     m = x.numel() // k
     bias_bf16 = 0
     if bias is not None:
@@ -367,8 +374,8 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     if timing is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_lib.lib().dmvae_linear_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), m, n, k, k, k, n, act, bias_bf16, int(out_f32), _stream()),
-          "linear_bf16")
+    check(_lib.lib().dmvae_linear_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), m, n, k, k, k, n, act, bias_bf16, int(out_f32), int(kmajor),
+                                       _stream()), "linear_bf16")
     if timing is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()

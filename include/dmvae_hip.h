@@ -159,14 +159,16 @@ int dmvae_gemm_tn_batched(const void* A, const void* B, void* C, void* workspace
  * mlp.fc2 and the patch embedding as a GEMM over patches), diffusion/lightningdit/lightningdit.py:34-93,173-252 (attn.qkv, attn.proj),
  * diffusion/lightningdit/swiglu_ffn.py:15-36 (w12, w3); with W := a transposed bf16 copy of the weight it is their input gradient dX = dY . W.
  * x [M][lda], w [N][ldw], y [M][ldy] row-major bf16 (y f32 when out_f32); leading dimensions in elements, multiples of 8; K % 32 == 0, N % 8 == 0;
- * every operand below 2 GiB.  bias: f32 [N], or bf16 [N] when bias_bf16 (what autocast hands the library), or NULL.
+ * every operand below 2 GiB.  w_layout = 1: w is the K-tile-major copy [K / 32][N][32] that dmvae_pack_conv_weight_v2 (ks = 1) writes as out_kmajor -- a
+ * K tile of the weights is then one contiguous run of whole 128-B lines instead of N half lines a row apart, which is what the operand costs when it comes
+ * from HBM rather than from the Infinity Cache (fc2 of ViT-L with cold operands: 84 -> 74 us; tools/bench_gemm.py --cold).  bias: f32 [N], or bf16 [N] when bias_bf16 (what autocast hands the library), or NULL.
  * act: 0 none, 1 SiLU, 5 exact (erf) GELU -- applied to the bf16-ROUNDED pre-activation, so the result is bit-identical to this call with act = 0
- * followed by dmvae_gelu_fwd / dmvae_silu_fwd.  K >= 192 (six K steps: the kernel streams a tile's last three K steps together with the next tile's first
- * three); shorter reductions go to dmvae_gemm_nt_batched.
+ * followed by dmvae_gelu_fwd / dmvae_silu_fwd.  K >= 384 (the kernel streams a tile's last K steps together with the next tile's first ones, up to five
+ * each); shorter reductions go to dmvae_gemm_nt_batched.
  * Tile shape per (M, N, K) from a fixed menu by rounds x tile cost (dmvae_linear_bf16_plan returns the menu index and the tile's columns / rows);
  * results do not depend on the tile (one f32 accumulation chain per output element: bias first, then K order).  csrc/gemm_pp.hip. */
 int dmvae_linear_bf16(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int lda, int ldw, int ldy,
-                      int act, int bias_bf16, int out_f32, dmvae_stream_t stream);
+                      int act, int bias_bf16, int out_f32, int w_layout, dmvae_stream_t stream);
 int dmvae_linear_bf16_plan(int M, int N, int K, int* tile_cols, int* tile_rows);
 
 /* P = softmax(scale*S) per row (S f32 [rows][cols] -> P bf16), and its backward

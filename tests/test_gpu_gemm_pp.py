@@ -36,7 +36,7 @@ SHAPES = [
     (16384, 6144, 1152),   # DiT-XL/1 w12, batch 64
     (16384, 1152, 3072),   # DiT-XL/1 w3, batch 64
     (8224, 32, 2048),      # bottleneck MLP's second Linear (N = 32 output columns)
-    (200, 72, 224),        # small and ragged in every dimension
+    (200, 72, 416),        # small and ragged in every dimension
 ]
 IDS = ["%dx%dx%d" % s for s in SHAPES]
 
@@ -85,7 +85,7 @@ def test_linear_vs_fp64(shape):
     _check(yn, x.double() @ w.double().t(), "no-bias result %s" % (shape,))
 
 
-@pytest.mark.parametrize("shape", [(8224, 4096, 1024), (4096, 1152, 1152), (200, 72, 224)], ids=["fc1", "dit_proj", "ragged"])
+@pytest.mark.parametrize("shape", [(8224, 4096, 1024), (4096, 1152, 1152), (200, 72, 416)], ids=["fc1", "dit_proj", "ragged"])
 def test_fused_activation_is_the_two_kernel_route(shape):
     from dmvae_amd import ops
     m, n, k = shape
@@ -103,17 +103,39 @@ def test_fused_activation_is_the_two_kernel_route(shape):
     assert bool((d <= bound).all()), f"fused GELU vs fp64: {(d > bound).sum().item()} elements outside half a bf16 ulp + 1e-6, worst {((d - bound).max().item()):.3e}"
 
 
+@pytest.mark.parametrize("shape", [(8224, 1024, 4096), (4096, 1152, 1152), (200, 72, 416)], ids=["fc2", "dit_proj", "ragged"])
+def test_kmajor_weight_layout_is_bit_identical(shape):
+    """w_layout = 1: the K-tile-major copy [K / 32][N][32] written by the pack kernel gives the same bits as the row-major operand (same values, same K order);
+    and it is the input-gradient operand: against the K-tile-major copy of the TRANSPOSED weight the call computes dY . W."""
+    from dmvae_amd import ops
+    m, n, k = shape
+    x, w, b = _operands(m, n, k, seed=4)
+    w32 = w.float()                                   # bf16-exact f32 master
+    wp = ops.pack_conv_weight(w32, kmajor=True)
+    wk = wp._dmvae_kmajor.view(k // 32, n, 32)
+    assert torch.equal(wp.view(n, k), w)
+    y0 = ops.linear_bf16(x, w, b, out_f32=True)
+    assert torch.equal(ops.linear_bf16(x, wk, b, out_f32=True), y0), "K-tile-major operand differs from the row-major one"
+    if n % 32 == 0:
+        g = torch.Generator(device=DEV).manual_seed(5)
+        dy = torch.randn(m, n, device=DEV, generator=g).to(BF)
+        wt = ops.pack_conv_weight(w32, for_dgrad=True, kmajor=True)        # [k, 1, n] = W^T, and its K-tile-major copy [n / 32, 1, k, 32]
+        dx = ops.linear_bf16(dy, wt._dmvae_kmajor.view(n // 32, k, 32), out_f32=True)
+        assert torch.equal(dx, ops.linear_bf16(dy, wt.view(k, n), out_f32=True))
+        _check(dx, dy.double() @ w.double(), "input gradient %s" % (shape,))
+
+
 def test_rows_and_columns_past_the_end_are_not_written():
     """The output sits in the middle of a sentinel-filled buffer; M and N are not multiples of any tile (ragged rows AND columns), and leading dimensions
     larger than the rows are honoured through the C ABI."""
     from dmvae_amd import _lib, ops
-    m, n, k = 1000, 200, 256
+    m, n, k = 1000, 200, 512
     x, w, b = _operands(m, n, k, seed=2)
     ldy = 208
     pad = 4096
     buf = torch.full((pad + m * ldy + pad,), -7.0, device=DEV, dtype=BF)
     y = buf[pad:pad + m * ldy].view(m, ldy)
-    rc = _lib.lib().dmvae_linear_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), m, n, k, k, k, ldy, 0, 0, 0,
+    rc = _lib.lib().dmvae_linear_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), m, n, k, k, k, ldy, 0, 0, 0, 0,
                                       torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     torch.cuda.synchronize()
@@ -125,14 +147,14 @@ def test_rows_and_columns_past_the_end_are_not_written():
 def test_argument_errors():
     from dmvae_amd import _lib
     L = _lib.lib()
-    x = torch.zeros(64, 256, device=DEV, dtype=BF)
+    x = torch.zeros(64, 512, device=DEV, dtype=BF)
     st = torch.cuda.current_stream().cuda_stream
-    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 64, 64, 200, 200, 200, 64, 0, 0, 0, st) != 0      # K % 32
+    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 64, 64, 200, 200, 200, 64, 0, 0, 0, 0, st) != 0      # K % 32
     assert b"K" in L.dmvae_last_error()
-    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 64, 64, 160, 160, 160, 64, 0, 0, 0, st) != 0      # K < 192
-    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 64, 60, 256, 256, 256, 64, 0, 0, 0, st) != 0      # N % 8
-    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 64, 64, 256, 256, 256, 64, 2, 0, 0, st) != 0      # act
-    assert L.dmvae_linear_bf16(None, x.data_ptr(), None, x.data_ptr(), 64, 64, 256, 256, 256, 64, 0, 0, 0, st) != 0
+    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 64, 64, 352, 352, 352, 64, 0, 0, 0, 0, st) != 0      # K < 384
+    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 64, 60, 512, 512, 512, 64, 0, 0, 0, 0, st) != 0      # N % 8
+    assert L.dmvae_linear_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 64, 64, 512, 512, 512, 64, 2, 0, 0, 0, st) != 0      # act
+    assert L.dmvae_linear_bf16(None, x.data_ptr(), None, x.data_ptr(), 64, 64, 512, 512, 512, 64, 0, 0, 0, 0, st) != 0
 
 
 _TILE_SCRIPT = r"""
@@ -141,7 +163,7 @@ sys.path.insert(0, %r)
 from dmvae_amd import ops
 g = torch.Generator(device="cuda").manual_seed(3)
 out = {}
-for m, n, k in [(8224, 1024, 1024), (4096, 1152, 1152), (777, 520, 192)]:
+for m, n, k in [(8224, 1024, 1024), (4096, 1152, 1152), (777, 520, 384)]:
     x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
     w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16)
     b = torch.randn(n, device="cuda", generator=g)

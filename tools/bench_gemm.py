@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Linear-layer GEMM shapes of the transformer blocks (ViT-L at batch 32: tokens = 32 x 257; LightningDiT-XL/1 at batch 16 / 64): the hand-written GEMM
-(csrc/gemm_pp.hip, `ops.linear_bf16`) vs the vendor library under this build's tuned solution table (F.linear -> hipBLASLt, dmvae_amd/gemm_select.py) vs
+(csrc/gemm_pp.hip, `ops.linear_bf16`) vs the vendor library under this build's tuned solution table (F.linear -> hipBLASLt, tools/gemm_select.py + tools/tuned/) vs
 conv_pp as a 1x1 conv.  Random-normal operands, interleaved rounds in one process, median microseconds per call and TFLOP/s.
   python tools/bench_gemm.py            the planned tile per shape
   python tools/bench_gemm.py --sweep    every tile of the menu per shape (calibrates csrc/gemm_pp.hip::g_cfg's cost column)
@@ -8,7 +8,9 @@ conv_pp as a 1x1 conv.  Random-normal operands, interleaved rounds in one proces
 import argparse, ctypes, json, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
-from dmvae_amd import _lib, gemm_select, ops
+from dmvae_amd import _lib, ops
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gemm_select
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--sweep", action="store_true")
@@ -16,6 +18,9 @@ ap.add_argument("--json", default="")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--shapes", default="")
+ap.add_argument("--kmajor", action="store_true", help="with --sweep: the weights K-tile-major (what frozen weights are served as)")
+ap.add_argument("--cold", action="store_true", help="rotate over enough distinct activation buffers (> 512 MB) that no call finds its input in the 256-MB Infinity Cache -- "
+                "inside a training step a GEMM's input was written by the previous kernel, not read by the same GEMM 50 us earlier")
 args = ap.parse_args()
 gemm_select.enable()
 L = _lib.lib()
@@ -44,26 +49,42 @@ def once(fn, reps):
 
 rows = []
 for name, m, n, k in SHAPES:
-    x = torch.randn(m, k, device="cuda").to(torch.bfloat16)
+    nbuf = max(2, int(600e6 // (m * k * 2)) + 1) if args.cold else 1
+    xs = [torch.randn(m, k, device="cuda").to(torch.bfloat16) for _ in range(nbuf)]
+    x = xs[0]
+    ctr = [0]
+
+    def nx():
+        ctr[0] = (ctr[0] + 1) % nbuf
+        return xs[ctr[0]]
     w = (torch.randn(n, k, device="cuda") * 0.02).to(torch.bfloat16)
     b = torch.randn(n, device="cuda")
     bb = b.to(torch.bfloat16)
     fl = 2.0 * m * k * n
-    arms = {"hipblaslt": lambda: F.linear(x, w, bb)}
+    arms = {"hipblaslt": lambda: F.linear(nx(), w, bb)}
     if n >= 64 and k % 32 == 0 and m >= 16384:
         arms["conv_pp"] = lambda: ops.conv2d_nhwc(x.view(1, 1, m, k), w.view(n, 1, k), b, ks=1)
     plan_idx, tc, tr = ops.linear_plan(m, n, k)
 
+    wsw = ops.pack_conv_weight(w.float(), kmajor=True)._dmvae_kmajor.view(k // 32, n, 32) if (args.kmajor and k % 32 == 0) else w
+
     def mk(cfg):
         def f():
             dbg(cfg)
-            ops.linear_bf16(x, w, bb)
+            ops.linear_bf16(nx(), wsw, bb)
         return f
     if args.sweep:
         for c in range(NCFG):
             arms["gemm_pp[%d]" % c] = mk(c)
     else:
         arms["gemm_pp"] = mk(-1)
+        if k % 32 == 0:
+            wk = ops.pack_conv_weight(w.float(), kmajor=True)._dmvae_kmajor.view(k // 32, n, 32)     # frozen weights are served K-tile-major
+
+            def fk():
+                dbg(-1)
+                ops.linear_bf16(nx(), wk, bb)
+            arms["gemm_pp_kmajor"] = fk
     for f in arms.values():
         for _ in range(3):
             f()

@@ -1,6 +1,7 @@
-"""hipBLASLt solution selection for the library GEMMs that remain on the path (the four Linear layers per block of the frozen ViT encoder,
-models/vae.py:47-53): PyTorch's TunableOp with tuning OFF and a committed results file, i.e. a fixed shape -> solution table measured on MI355X
-(`PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_FILENAME=... python bench.py`; dmvae_amd/tuned/*.csv).  The library's heuristic pick for
+"""NOT on the product path any more (round 3: every Linear layer runs on csrc/gemm_pp.hip through `functional.linear`).  Kept for tools/bench_gemm.py, whose
+vendor-library arm should be the library at its best (tools/tuned/*.csv): hipBLASLt solution selection for the four Linear shapes per block of the ViT encoder
+(models/vae.py:47-53) through PyTorch's TunableOp with tuning OFF and a committed results file, i.e. a fixed shape -> solution table measured on MI355X
+(`PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 PYTORCH_TUNABLEOP_FILENAME=...`; tools/tuned/*.csv).  The library's heuristic pick for
 fc1 (M = 8224, N = 4096, K = 1024) runs at 0.80 PFLOP/s, the table's at 0.94; the step gains 0.5-0.7 ms.  A table whose validator lines (PyTorch /
 hipBLASLt / rocBLAS versions, gfx arch) do not match the running stack is rejected by TunableOp and the heuristic picks stay in force.
 DMVAE_GEMM_SELECT=0 turns the table off."""
