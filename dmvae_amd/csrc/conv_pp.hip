@@ -38,6 +38,9 @@
 #ifndef DMVAE_PP_EXP
 #define DMVAE_PP_EXP 0
 #endif
+#ifndef DMVAE_PP_LGKM_BUILTIN   // 1: the K loop's lgkmcnt(0) through the builtin (the MFMAs then issue as one run; gemm_pp.hip does the same); 0: inline asm + 8 compiler-placed waits between them
+#define DMVAE_PP_LGKM_BUILTIN 1
+#endif
 #ifndef DMVAE_PP_AUXA   // cache-policy bits of the HALO loop's LDS-DMA (weights / activations): 1 = sc0, 2 = nt, 16 = sc1; A/B builds only
 #define DMVAE_PP_AUXA 0
 #endif
@@ -510,7 +513,12 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       ka++;
       if constexpr (KX == 2) sh = sh == 2 * TILE_A ? GROUP + 2 * TILE_A : 2 * TILE_A;
       wait_vmcnt<KX == 2 ? 2 * NPA : 2 * NPA + NPH>();  // own pieces of the NEXT tile have landed: what may stay in flight is tiles t + 2 and t + 3
+#if DMVAE_PP_LGKM_BUILTIN
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) through the builtin: the compiler sees the fragments have arrived and puts no lgkmcnt waits of its own between the MFMAs
+      asm volatile("" ::: "memory");
+#else
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -542,7 +550,12 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     slot_rd = slot_rd + SLOT == NBUF * SLOT ? 0 : slot_rd + SLOT;
     slot_wr = slot_wr + SLOT == NBUF * SLOT ? 0 : slot_wr + SLOT;
     wait_vmcnt<(PF - 1) * NP>();  // own pieces of the NEXT tile have landed
+#if DMVAE_PP_LGKM_BUILTIN
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    asm volatile("" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #ifdef DMVAE_PP_TRACE
     const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
