@@ -282,6 +282,7 @@ def main():
     # the stream has to retire (measured: ~1 ms per step).  They are recorded on every `--time-every`-th step of the timed region (default 4: the first, the
     # fifth, ...), so the figure is still measured live inside the timed region while the timed region pays a quarter of that cost; 1 = every step.
     timing_all = []
+    tr.sync.time_wait = True
     t0 = time.perf_counter()
     for i in range(args.steps):
         ops.KERNEL_TIMING = timing_all if i % max(1, args.time_every) == 0 else None
@@ -309,7 +310,8 @@ def main():
         a = per.setdefault(label, [0.0, 0.0, 0])
         a[0] += e0.elapsed_time(e1); a[1] += fl; a[2] += 1
     k_ms, k_flop, k_n = per.get(DOMINANT, [0.0, 0.0, 0])
-    conv = {k: v for k, v in per.items() if not k.startswith("wgrad")}
+    conv = {k: v for k, v in per.items() if not k.startswith("wgrad") and k != "gemm_pp_kernel"}
+    lin_ms, lin_flop, lin_n = per.get("gemm_pp_kernel", [0.0, 0.0, 0])      # the encoder's Linear layers (csrc/gemm_pp.hip): their own line below
     all_ms = sum(a[0] for a in conv.values())
     all_flop = sum(a[1] for a in conv.values())
     n_conv = sum(a[2] for a in conv.values())
@@ -367,6 +369,15 @@ def main():
                            "share_of_step": round(wg_ms / (dt * 1e3 * frac_timed), 3),
                            "small_shape_calls": {"launches": wgs_n, "share_of_step": round(wgs_ms / (dt * 1e3 * frac_timed), 3)}},
     }
+    out["linear_gemm"] = {"kernel": "dmvae_gemm_pp::gemm_pp_kernel (the frozen ViT-L encoder's Linear layers: qkv / proj / fc1 + GELU / fc2, patch embedding)",
+                          "launches": lin_n, "achieved_TFLOPs": round(lin_flop / (lin_ms * 1e-3) / 1e12, 1) if lin_ms > 0 else 0.0,
+                          "frac": round(lin_flop / (lin_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if lin_ms > 0 else 0.0,
+                          "avg_launch_us": round(lin_ms * 1e3 / max(1, lin_n), 2), "share_of_step": round(lin_ms / (dt * 1e3 * frac_timed), 3)}
+    if world > 1 or os.environ.get("DMVAE_FORCE_DIST", "0") != "0":
+        # what the gradient exchange looked like from this rank: bytes all-reduced per step, buckets, how many of their collectives were launched from
+        # gradient hooks DURING backward, and the time the compute stream then still spent waiting for them (the un-overlapped remainder)
+        out["comm"] = dict(tr.sync.comm_stats(), backend=str(torch.distributed.get_backend()) if dist.initialized() else None,
+                           bucket_bytes=64 << 20, dynamic_tile_claiming=os.environ.get("DMVAE_PP_DYNAMIC", "0") not in ("", "0"))      # dist.init_distributed_mode sets it when it switches DYN on
     if world == 1:
         out["kl_mmd"] = kl_mmd_roofline(dev)
     if world == 1 and not args.no_cpu_baseline:

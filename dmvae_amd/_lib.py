@@ -33,8 +33,10 @@ SIGNATURES = {
     "dmvae_gemm_nt_batched": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_longlong] * 3 + [c_int, c_int, c_void_p]),
     "dmvae_gemm_tn_batched_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dmvae_gemm_tn_batched": (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 4 + [c_longlong] * 3 + [c_float, c_int, c_void_p]),
+    "dmvae_set_dynamic": (c_int, [c_int]),
     "dmvae_linear_bf16": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     "dmvae_linear_bf16_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "dmvae_linear_weight_t_kmajor": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dmvae_softmax_rows_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dmvae_softmax_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dmvae_transpose_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

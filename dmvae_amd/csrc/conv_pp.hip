@@ -31,6 +31,7 @@
 #define DMVAE_PP_PRIO_MODE 1   // 0: s_setprio 1 / 0 around every COMPUTE interval (round 1); 1: static priority 1 for the second-dispatched wave group; 2: none
 #endif
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
@@ -862,18 +863,39 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 constexpr int SCHED_WORDS = 16 + 512, SCHED_SLOTS = 32;
 __device__ unsigned g_sched[SCHED_SLOTS * SCHED_WORDS];
 
+// Keyed by (device, stream): a __device__ symbol has one address PER DEVICE, and a process that drives several GPUs must not hand one device's kernel the
+// scheduling words of another.
 static unsigned* sched_for(hipStream_t st) {
   static std::mutex mu;
-  static std::unordered_map<hipStream_t, int> slot;
-  static unsigned* base = nullptr;
+  static std::unordered_map<unsigned long long, int> slot;     // (device, stream) -> set index on that device
+  static std::unordered_map<int, unsigned*> base;              // device -> address of g_sched there
+  static std::unordered_map<int, int> used;                    // device -> sets handed out
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   std::lock_guard<std::mutex> lk(mu);
-  if (!base && hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_sched)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  auto it = slot.find(st);
-  if (it == slot.end()) {
-    if ((int)slot.size() >= SCHED_SLOTS) return nullptr;  // more streams than sets: those launches keep the static stride
-    it = slot.emplace(st, (int)slot.size()).first;
+  auto b = base.find(dev);
+  if (b == base.end()) {
+    unsigned* p = nullptr;
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_sched)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    b = base.emplace(dev, p).first;
   }
-  return base + (size_t)it->second * SCHED_WORDS;
+  const unsigned long long key = ((unsigned long long)(unsigned)dev << 56) ^ (unsigned long long)reinterpret_cast<uintptr_t>(st);
+  auto it = slot.find(key);
+  if (it == slot.end()) {
+    int& n = used[dev];
+    if (n >= SCHED_SLOTS) return nullptr;  // more streams than sets on this device: those launches keep the static stride
+    it = slot.emplace(key, n++).first;
+  }
+  return b->second + (size_t)it->second * SCHED_WORDS;
+}
+
+// Dynamic tile claiming on / off for every instantiation at once: -1 = not set (DMVAE_PP_DYNAMIC decides, read once), 0 / 1 = dmvae_set_dynamic.
+static std::atomic<int> g_dynamic{-1};
+static bool dynamic_on() {
+  const int v = g_dynamic.load(std::memory_order_relaxed);
+  if (v >= 0) return v != 0;
+  static const bool env = [] { const char* e = getenv("DMVAE_PP_DYNAMIC"); return e ? atoi(e) != 0 : false; }();
+  return env;
 }
 
 template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32, bool KO, bool GEN = false, bool SUB = false, bool DYN = false, bool STATS = false,
@@ -884,8 +906,7 @@ int launch(Args a, hipStream_t st) {
   static const int persist = [] { const char* e = getenv("DMVAE_PP_GRID"); return e ? atoi(e) : 256; }();  // 0: one block per tile
   const unsigned grid = (persist > 0 && a.total > persist) ? (unsigned)persist : (unsigned)a.total;
   if constexpr (!DYN && !UPS && KO && !F32) {  // the bf16-output, chunk-outer instantiations (every large launch of the training step) have a DYN twin
-    static const bool dyn = [] { const char* e = getenv("DMVAE_PP_DYNAMIC"); return e ? atoi(e) != 0 : false; }();
-    if (dyn && grid == 256u && (unsigned)a.total > grid) {
+    if (dynamic_on() && grid == 256u && (unsigned)a.total > grid) {
       a.sched = sched_for(st);
       if (a.sched) return launch<TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, true, STATS, HALO>(a, st);
     }
@@ -965,6 +986,14 @@ __global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks) {
   const unsigned long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
+// Dynamic tile claiming (DYN) for every conv_pp launch from now on: 1 = on, 0 = off, -1 = back to the DMVAE_PP_DYNAMIC environment default.  One process-wide
+// switch (the first version latched the environment variable per template instantiation at its first launch: instantiations that had run before
+// dmvae_amd.dist set the variable stayed static).  Returns the value in force (0 / 1).
+extern "C" int dmvae_set_dynamic(int on) {
+  dmvae_conv_pp::g_dynamic.store(on < 0 ? -1 : (on != 0), std::memory_order_relaxed);
+  return dmvae_conv_pp::dynamic_on() ? 1 : 0;
+}
+
 extern "C" int dmvae_debug_occupy(int blocks, int lds_bytes, int microseconds, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }

@@ -480,7 +480,7 @@ int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_o
   const int ktiles = (int)(M / 32);
   int best = 1;
   double best_eff = 0;
-  // DMVAE_WGRAD_PP_MIN_ROUNDS=2 (set by dmvae_amd.dist when more than one rank runs): at least two rounds of smaller blocks, so that a block whose CU is held
+  // DMVAE_WGRAD_PP_MIN_ROUNDS=2 (an opt-in; measured and left off): at least two rounds of smaller blocks, so that a block whose CU is held
   // by an overlapped collective's kernel when the launch starts delays the launch by half a block-time instead of a whole one (a block needs 128 KB of LDS
   // and shares its CU with nothing).  Costs one more slab per output element to reduce; not worth it on a single GPU.
   static const int min_rounds = [] { const char* e = getenv("DMVAE_WGRAD_PP_MIN_ROUNDS"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 4 ? 4 : v); }();

@@ -333,6 +333,32 @@ __global__ void transpose_kernel(const bf16* __restrict__ src, bf16* __restrict_
   }
 }
 
+// ---- Linear weight, bf16 [N][K] row-major -> the K-tile-major operand of its TRANSPOSE: dst[N / 32][K][32], dst[(n >> 5)][k][n & 31] = src[n][k] ------------------
+// (the input-gradient operand of csrc/gemm_pp.hip: dX = dY . W is an NT GEMM whose "weight" is W^T [K][N] with the reduction over n; w_layout = 1 of that
+// operand is exactly this array).  One 32-row band of src per block row: a band's result is a K x 32 transpose.  256 threads: a 32 x 64 tile through LDS,
+// 16-B loads (8 columns of one row), 16-B stores (8 rows of one column ... i.e. 8 consecutive n of one k).  Replaces the element-wise f32 pack
+// (35 us per 7-M-element weight: strided reads, 2-byte scattered writes) on the trainable routes, where every weight needs the copy once per step.
+__global__ __launch_bounds__(256) void linear_wt_kmajor_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int N, int K) {
+  __shared__ __attribute__((aligned(16))) bf16 tile[32][64 + 8];     // +8: 16-B-aligned rows, the column reads below then hit distinct banks
+  const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 64;
+  {
+    const int r = threadIdx.x >> 3, c8 = (threadIdx.x & 7) * 8;      // 32 rows x 8 chunks of 8 columns
+    uint4 v = {0u, 0u, 0u, 0u};
+    if (n0 + r < N && k0 + c8 < K) v = *reinterpret_cast<const uint4*>(src + (size_t)(n0 + r) * K + k0 + c8);
+    *reinterpret_cast<uint4*>(&tile[r][c8]) = v;
+  }
+  __syncthreads();
+  {
+    const int k = threadIdx.x >> 2, r8 = (threadIdx.x & 3) * 8;      // 64 columns (k) x 4 chunks of 8 rows (n)
+    if (k0 + k < K) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = tile[r8 + e][k];
+      *reinterpret_cast<bf16x8*>(dst + ((size_t)blockIdx.y * K + k0 + k) * 32 + r8) = o;
+    }
+  }
+}
+
 static inline int grid_for(size_t n, int block = 256, int cap = 4096) {
   size_t g = (n + block - 1) / block;
   return (int)(g > (size_t)cap ? cap : (g < 1 ? 1 : g));
@@ -356,6 +382,13 @@ extern "C" int dmvae_pack_conv_weight_v2(const void* w, void* out, void* out_kma
   const size_t total = (size_t)rows_pad * T * cols_pad;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)w, (bf16*)out, (bf16*)out_kmajor, cout, cin, T, rows_pad,
                      cols_pad, for_dgrad ? 1 : 0);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_linear_weight_t_kmajor(const void* w, void* out, int N, int K, hipStream_t stream) {
+  DMVAE_CHECK_ARG(w && out && N > 0 && K > 0 && N % 32 == 0 && K % 8 == 0, "linear_weight_t_kmajor: need N %% 32 == 0 and K %% 8 == 0 (N %d, K %d)", N, K);
+  hipLaunchKernelGGL(linear_wt_kmajor_kernel, dim3((K + 63) / 64, N / 32), dim3(256), 0, stream, (const bf16*)w, (bf16*)out, N, K);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -38,8 +38,14 @@ def init_distributed_mode(backend: Optional[str] = None, timeout_minutes: int = 
         # From here on the collectives' kernels share the GPU with the persistent conv blocks, which need a whole CU each (128-160 KB of LDS): claim tiles
         # dynamically so that a launch slows down by the fraction of CUs taken instead of a whole block-time (csrc/conv_pp.hip, DYN; measured with a resident
         # side-stream kernel on one GPU, tools/probes/contention.py: 16 CUs taken cost +6..+38 % instead of +48..+75 %; 0.3-1.4 % slower with no contention, which
-        # is why a single rank keeps the static stride).  The library reads the flag at its first conv launch: it has to be in the C environment before that.
-        os.environ.setdefault("DMVAE_PP_DYNAMIC", "1")
+        # is why a single rank keeps the static stride).  One process-wide switch in the library (dmvae_set_dynamic), so it does not matter which convs have
+        # already run; DMVAE_PP_DYNAMIC=0 in the environment keeps it off (A/B runs).  The variable is also set for ops._conv_label / bench.py, which name the
+        # kernel a launch dispatches to.
+        if os.environ.get("DMVAE_PP_DYNAMIC", "1") != "0":
+            os.environ["DMVAE_PP_DYNAMIC"] = "1"
+            if torch.cuda.is_available():
+                from . import _lib
+                _lib.lib().dmvae_set_dynamic(1)
     use_gpu = torch.cuda.is_available()
     if use_gpu:
         torch.cuda.set_device(_local_rank % torch.cuda.device_count())
@@ -185,6 +191,9 @@ class FlatGradSync:
         self._handles = []
         self.hook_launches = 0      # buckets whose all-reduce was started from a gradient hook, i.e. DURING backward, in the last step
         self._in_wait = False
+        self.time_wait = False      # bench.py: bracket wait() with events on the compute stream -- what of the collectives backward did NOT cover
+        self._wait_events: List[tuple] = []
+        self.last_hook_launches = 0
         if self.enabled:
             for i, p in enumerate(params):
                 self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -214,11 +223,31 @@ class FlatGradSync:
             if left > 0:
                 self._launch(b)
         self._in_wait = False
+        timed = self.time_wait and self.flat_grad.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._works:
             w.wait()
+        if timed:
+            e1.record()
+            self._wait_events.append((e0, e1))
         self._works.clear()
         self._pending = [b[2] for b in self.buckets]
         self.last_hook_launches, self.hook_launches = self.hook_launches, 0
+
+    def comm_stats(self) -> dict:
+        """For the bench line of an N > 1 run: gradient bytes all-reduced per step, bucket count, how many buckets' collectives were launched from gradient
+        hooks DURING the last backward (the rest start in wait()), and the mean time the compute stream spent in wait() -- the exposed, un-overlapped part
+        (needs `time_wait = True` before the timed steps; synchronises)."""
+        ms = None
+        if self._wait_events:
+            torch.cuda.synchronize()
+            v = [a.elapsed_time(b) for a, b in self._wait_events]
+            ms = sum(v) / len(v)
+            self._wait_events.clear()
+        return {"bytes": int(self.buckets[-1][1]) * 4 if self.buckets else 0, "buckets": len(self.buckets),
+                "launched_in_backward": int(self.last_hook_launches), "wait_ms": None if ms is None else round(ms, 4)}
 
     def remove(self):
         for h in self._handles:

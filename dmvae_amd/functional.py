@@ -73,12 +73,16 @@ def _dst(param):
     return None if v is None else v.view(v.shape)
 
 
-def _tag_stats(y: torch.Tensor, st: torch.Tensor) -> torch.Tensor:
+_GN_CHECK = os.environ.get("DMVAE_GN_STATS_CHECK", "0") != "0"
+_GN_GROUPS, _GN_EPS = 32, 1e-6     # every GroupNorm of flux_ae.py (Normalize(): num_groups=32, eps=1e-6, flux_ae.py:28) -- what the conv epilogues' statistics are for
+
+
+def _tag_stats(y: torch.Tensor, st: torch.Tensor, groups: int = _GN_GROUPS, eps: float = _GN_EPS) -> torch.Tensor:
     """Leave the GroupNorm(32, eps 1e-6) statistics a conv epilogue computed on its result tensor, for the norm that consumes it next (the modules of
     flux_ae.Decoder hand their outputs straight to each other).  Keyed on the tensor's version and storage: a changed or re-created tensor falls back to the
     statistics pass."""
     try:
-        y._dmvae_gn = (st, _ver(y), y.data_ptr())
+        y._dmvae_gn = (st, _ver(y), y.data_ptr(), groups, eps)
     except AttributeError:
         pass
     return y
@@ -88,11 +92,17 @@ def _ver(t: torch.Tensor) -> int:
     return -1 if t.is_inference() else t._version        # inference tensors keep no version counter
 
 
-def _stats_of(x: torch.Tensor) -> torch.Tensor:
+def _stats_of(x: torch.Tensor, groups: int = _GN_GROUPS, eps: float = _GN_EPS) -> torch.Tensor:
+    """Statistics of x for GroupNorm(groups, eps): the producing conv's by-product when x still carries it for the SAME (groups, eps), version and storage
+    (raw-pointer in-place kernels do not bump `_version`: one applied to a tagged tensor must `del x._dmvae_gn`), else the statistics pass.
+    DMVAE_GN_STATS_CHECK=1 recomputes them and asserts the by-product equals the pass (debugging aid)."""
     tag = getattr(x, "_dmvae_gn", None)
-    if tag is not None and tag[1] == _ver(x) and tag[2] == x.data_ptr() and tag[0].shape[0] == x.shape[0]:
+    if tag is not None and tag[1] == _ver(x) and tag[2] == x.data_ptr() and tag[0].shape[0] == x.shape[0] and tag[3] == groups and tag[4] == eps:
+        if _GN_CHECK:
+            ref = ops.groupnorm_stats(x, groups, eps)
+            assert torch.allclose(tag[0], ref, rtol=1e-4, atol=1e-6), "stale GroupNorm statistics tag"
         return tag[0]
-    return ops.groupnorm_stats(x)
+    return ops.groupnorm_stats(x, groups, eps)
 
 
 def _gn_swish(x, gw, gb, swish=True):
@@ -273,7 +283,7 @@ class ConvInFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         cin = x.shape[1]
         xp = ops.nchw_to_nhwc_bf16(_c(x.float()), c_pad=32)
-        y = ops.conv2d_nhwc(xp, packed(w, False, cols_pad=32), b, ks=3)
+        y = ops.conv2d_nhwc(xp, packed(w, False, cols_pad=32), b, ks=3, flop_channels=(cin, w.shape[0]))
         ctx.save_for_backward(xp, w)
         ctx.bias_param, ctx.cin = b, cin
         return y
@@ -290,7 +300,7 @@ class ConvInFn(torch.autograd.Function):
             dw = dwp[:, :ctx.cin].contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.nhwc_to_nchw_f32(ops.conv2d_nhwc(dy, packed(w, True, rows_pad=32), ks=3), ctx.cin)
+            dx = ops.nhwc_to_nchw_f32(ops.conv2d_nhwc(dy, packed(w, True, rows_pad=32), ks=3, flop_channels=(w.shape[0], ctx.cin)), ctx.cin)
         return dx, dw, db
 
 
@@ -344,7 +354,7 @@ class ConvK4Fn(torch.autograd.Function):
         if b is not None and rows != cout:
             bp = torch.zeros(rows, dtype=f32, device=x.device)
             bp[:cout] = b
-        y = ops.conv2d_nhwc(x, packed(w, False, rows_pad=rows, cols_pad=cp), bp, ks=4, stride=stride, act=act, out_f32=out_f32)
+        y = ops.conv2d_nhwc(x, packed(w, False, rows_pad=rows, cols_pad=cp), bp, ks=4, stride=stride, act=act, out_f32=out_f32, flop_channels=(cin, cout))
         if rows != cout:
             y = y[..., :cout].contiguous()
         ctx.save_for_backward(x, w, y if act == ops.ACT_LEAKY else None)
@@ -433,7 +443,7 @@ class NormConvOutFn(torch.autograd.Function):
         st, a = _gn_swish(x, nw, nb)
         cbp = torch.zeros(4, dtype=f32, device=x.device)
         cbp[:cout] = cb
-        y4 = ops.conv2d_nhwc(a, packed(cw, False, rows_pad=4), cbp, ks=3, out_f32=True)
+        y4 = ops.conv2d_nhwc(a, packed(cw, False, rows_pad=4), cbp, ks=3, out_f32=True, flop_channels=(cw.shape[1], cout))
         ctx.save_for_backward(x, st, a, nw, nb, cw)
         ctx.bias_param = cb
         return ops.nhwc_to_nchw_f32(y4, cout)
@@ -462,7 +472,7 @@ class NormConvOutFn(torch.autograd.Function):
             dbp = gb.view(9, 8)[4]
         else:
             dwp, dbp = ops.conv2d_nhwc_wgrad(dyp, a, 3)
-        da = ops.conv2d_nhwc(dyp, packed(cw, True, cols_pad=32), ks=3)
+        da = ops.conv2d_nhwc(dyp, packed(cw, True, cols_pad=32), ks=3, flop_channels=(cw.shape[0], cw.shape[1]))
         dx, dnw, dnb = ops.groupnorm_bwd(da, x, st, nw, nb, True, dg_out=_dst(nw), db_out=_dst(nb))
         dcw, dcb = _dst(cw), _dst(ctx.bias_param)
         if dcw is not None:
@@ -534,12 +544,21 @@ def _bf(w: torch.Tensor) -> torch.Tensor:
 
 
 def _bf_t(w: torch.Tensor) -> torch.Tensor:
-    """bf16 copy of the TRANSPOSE [in, out] of a Linear weight [out, in] -- the operand that makes the input gradient dX = dY . W the same NT GEMM as the
-    forward --, cached until the weight changes (the dgrad layout of `packed`: one pack launch per weight version): K-tile-major [out / 32, in, 32] when the
-    reduction length `out` is a multiple of 32 (the same launch writes it), else row-major [in, out]."""
+    """bf16 copy of the TRANSPOSE of a Linear weight [out, in] -- the operand that makes the input gradient dX = dY . W the same NT GEMM as the forward --,
+    cached until the weight changes: K-tile-major [out / 32, in, 32], one tiled-transpose launch from the weight's bf16 copy (`_bf`: the optimiser's shadow
+    where there is one) when `out` is a multiple of 32; else row-major [in, out] from the element-wise pack."""
     cout, cin = w.shape
-    if cout % 32 == 0 and not parity.on():
-        return packed(w, True, kmajor=True)._dmvae_kmajor.view(cout // 32, cin, 32)
+    if cout % 32 == 0 and cin % 8 == 0 and not parity.on():
+        cache = getattr(w, "_dmvae_bft", None)
+        ver = (w.data_ptr(), _ver(w), _epoch_of(w))
+        if cache is not None and cache[0] == ver:
+            return cache[1]
+        v = ops.linear_weight_t_kmajor(_bf(w))
+        try:
+            w._dmvae_bft = (ver, v)
+        except AttributeError:
+            pass
+        return v
     return packed(w, True).view(cin, cout)
 
 
@@ -567,7 +586,9 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, a
     if x.dtype != bf16:
         x = x.to(bf16)
     if ops.linear_supported(m, n, k):
-        if not w.requires_grad and w.dim() == 2 and _KMAJOR_FROZEN:     # frozen weights: the K-tile-major copy (one pack per weight, ever)
+        # frozen weights -- not trainable AND not owned by one of this build's optimisers (a student DiT switched to requires_grad False for the DMD
+        # loss's evaluations still changes every few steps: it keeps the row-major shadow its optimiser maintains) -- : the K-tile-major copy, packed once
+        if not w.requires_grad and not hasattr(w, "_dmvae_epoch") and w.dim() == 2 and _KMAJOR_FROZEN:
             return ops.linear_bf16(x, _bf_km(w), bb, act)
         return ops.linear_bf16(x, (w if w.dtype == bf16 else _bf(w)).view(n, k), bb, act)
     wb = w if w.dtype == bf16 else _bf(w)

@@ -199,7 +199,7 @@ class Decoder(nn.Module):
         _, a = Fn._gn_swish(h, self.norm_out.weight, self.norm_out.bias)
         cbp = torch.zeros(4, dtype=torch.float32, device=h.device)
         cbp[:cout] = self.conv_out.bias
-        y4 = ops.conv2d_nhwc(a, Fn.packed(self.conv_out.weight, False, rows_pad=4), cbp, ks=3, out_f32=True)
+        y4 = ops.conv2d_nhwc(a, Fn.packed(self.conv_out.weight, False, rows_pad=4), cbp, ks=3, out_f32=True, flop_channels=(self.conv_out.weight.shape[1], self.conv_out.weight.shape[0]))
         return ops.image_to_u8(y4, cout, round_bf16)
 
     def _body_nhwc(self, z: Tensor) -> Tensor:

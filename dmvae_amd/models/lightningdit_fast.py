@@ -4,8 +4,8 @@
 Same arithmetic as `forward_stock` under autocast(bf16), with bf16 rounding at the sites where the reference's autocast graph rounds (see
 csrc/dit.hip); per block: 1 fused (gated residual +) RMSNorm+modulate, qkv GEMM, 1 fused QK-norm+RoPE+head split, attention in one fused kernel (csrc/vit.hip, head dims 64 and 72
 alike: the staged head dim pads to 96; composed batched QK^T GEMM / f32 softmax / PV GEMM beyond 288 tokens), proj GEMM, 1 gated residual, RMSNorm+modulate, w12 GEMM, SwiGLU gate, w3 GEMM,
-gated residual -- every Linear on this build's GEMM kernels (`functional.linear`: csrc/gemm_pp.hip, or the small batched NT kernel for the per-sample adaLN rows).
-The timestep / label embedding stays stock PyTorch under autocast."""
+gated residual -- every token-level Linear on this build's GEMM kernel (`functional.linear`: csrc/gemm_pp.hip).
+The per-sample pieces (timestep / label embedding, adaLN Linear: one row per sample) stay stock PyTorch under autocast."""
 import os
 
 import torch
@@ -72,7 +72,10 @@ def forward_inference(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) 
     fl = model.final_layer
 
     def adaln(lin):
-        return linear(scb, lin.weight, lin.bias)                                # [B, 6C]: shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp
+        # [B, 6C]: shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp.  One row per SAMPLE (16-64 rows against a 6912 x 1152 weight): a
+        # GEMV-shaped, weight-bandwidth-bound problem that neither of this build's tile kernels is shaped for (measured on the small batched kernel: 62 us per
+        # call against ~5 for the library) -- the per-sample conditioning Linears stay library calls, like the timestep / label embedders
+        return F.linear(scb, _bf(lin.weight), _bf(lin.bias)).contiguous()
 
     pend = None                                                                   # (y, mod) of the previous block's MLP branch, not yet added to h
     for blk in model.blocks:
@@ -134,7 +137,7 @@ class GraphedInference:
 
 def forward_train(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """`forward` with gradients (the student's flow-matching turn, train_dmd.py:565-575) under the caller's autocast(bf16): timestep / label embedders
-    through stock autograd, the patch embedding, adaLN Linears and the output Linear as `functional.LinearFn`, every block as one `functional.DitBlockFn`,
+    and the per-sample adaLN Linears through stock autograd, the patch embedding and the output Linear as `functional.LinearFn`, every block as one `functional.DitBlockFn`,
     the final norm as `RmsnormModulateFn`.  Label dropout as in the module (`y_embedder(y, model.training)`)."""
     from ..functional import DitBlockFn, LinearFn, RmsnormModulateFn
     b, cin, hh, ww = x.shape
@@ -144,14 +147,13 @@ def forward_train(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> t
     h = (LinearFn.apply(patches, w.view(w.shape[0], -1), model.x_embedder.proj.bias).float() + model.pos_embed).contiguous()
     cvec = model.t_embedder(t) + model.y_embedder(y, model.training)
     rope = model.feat_rope
-    sc = F.silu(cvec)                                                             # adaLN_modulation = Sequential(SiLU, Linear): the SiLU once (f32, like autocast runs it)
     for blk in model.blocks:
-        mod = LinearFn.apply(sc, blk.adaLN_modulation[1].weight, blk.adaLN_modulation[1].bias)     # [B, 6C] bf16
+        mod = blk.adaLN_modulation(cvec)                                          # [B, 6C] bf16 under autocast, stock autograd (one row per sample: see forward_inference)
         h = DitBlockFn.apply(h, mod, blk.norm1.weight, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.q_norm.weight, blk.attn.k_norm.weight,
                              blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.mlp.w12.weight, blk.mlp.w12.bias, blk.mlp.w3.weight,
                              blk.mlp.w3.bias, rope.freqs_cos, rope.freqs_sin, heads, blk.norm1.eps)
     fl = model.final_layer
-    a = RmsnormModulateFn.apply(h, fl.norm_final.weight, LinearFn.apply(sc, fl.adaLN_modulation[1].weight, fl.adaLN_modulation[1].bias), 0, c, fl.norm_final.eps)
+    a = RmsnormModulateFn.apply(h, fl.norm_final.weight, fl.adaLN_modulation(cvec), 0, c, fl.norm_final.eps)
     out = model.unpatchify(LinearFn.apply(a, fl.linear.weight, fl.linear.bias))
     if model.learn_sigma:
         out, _ = out.chunk(2, dim=1)

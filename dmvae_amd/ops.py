@@ -160,11 +160,12 @@ def _conv_label(n, ho, wo, cin, cout, ks, upsample, out_f32, stride, transposed,
 
 def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None, ks: int = 3, upsample=False, act: int = ACT_NONE,
-                out_f32: bool = False, stride: int = 1, transposed: bool = False) -> torch.Tensor:
+                out_f32: bool = False, stride: int = 1, transposed: bool = False, flop_channels: Optional[Tuple[int, int]] = None) -> torch.Tensor:
     """y = act(conv(x, w) + bias + residual); x [N,H,W,Cin] bf16, w_packed [Cout, ks*ks, Cin] bf16.
     upsample: False/0 none, True/1 nearest x2 folded into the gather, 2 zero-insertion x2 (dgrad of the stride-2 3x3 conv);
     stride 2 with ks 3: the Downsample conv (input padded bottom/right by one, flux_ae.py:85-95); ks 4 (stride 1 | 2, padding 1): the
-    PatchGAN convs (patchgan.py:125-147); transposed: the input gradient of the ks-4 conv with that stride (w_packed packed for_dgrad)."""
+    PatchGAN convs (patchgan.py:125-147); transposed: the input gradient of the ks-4 conv with that stride (w_packed packed for_dgrad).
+    flop_channels: the layer's true (cin, cout) when the operands are zero-padded -- only used by the bench's FLOP accounting."""
     if x.dtype == f32 and parity.on():
         # f32 activations: the same kernel over the six exact bf16 partial products laid out along the channel (reduction) axis; bias in the
         # kernel's f32 epilogue, residual / activation afterwards in f32
@@ -195,6 +196,8 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
         # which kernel dmvae_conv2d_nhwc_fwd dispatched to (csrc/conv_pp.hip::dmvae_conv_pp_try), so that the bench's per-kernel
         # average can be checked against rocprofv3's per-kernel-name average
         label, fl = _conv_label(n, ho, wo, cin, cout, ks, upsample, out_f32, stride, transposed, False)
+        if flop_channels is not None:       # zero-padded operands (a 3-channel image as 32, 3 output channels as 4): count the model's multiply-adds, not the padding's
+            fl *= (flop_channels[0] * flop_channels[1]) / float(cin * cout)
         timing.append((label, e0, e1, fl))
     return y
 
@@ -381,6 +384,15 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         e1.record()
         timing.append(("gemm_pp_kernel", e0, e1, 2.0 * m * n * k))
     return y
+
+
+def linear_weight_t_kmajor(w: torch.Tensor) -> torch.Tensor:
+    """bf16 Linear weight [N, K] -> [N / 32, K, 32]: the K-tile-major operand of its transpose -- with it `linear_bf16(dy, .)` is the input gradient dY . W."""
+    w = _req(w, bf16, "w")
+    n, k = w.shape
+    out = torch.empty(n // 32, k, 32, dtype=bf16, device=w.device)
+    check(_lib.lib().dmvae_linear_weight_t_kmajor(w.data_ptr(), out.data_ptr(), n, k, _stream()), "linear_weight_t_kmajor")
+    return out
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, out_f32: bool = False) -> torch.Tensor:

@@ -120,8 +120,8 @@ class FlatAdamWEMA:
     def state_dict(self, param_order=None) -> dict:
         """torch.optim.AdamW's layout, so that the entry is interchangeable with the reference's `opt_*` checkpoint entries:
         {"state": {index: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [{..., "params": [indices]}]} with index = position of the parameter in
-        `param_order` (the reference builds its optimisers over `module.parameters()`, frozen ones included: they have no state) -- default: this
-        buffer's own order.  The LambdaLR position is the step counter (`scheduler_state_dict`)."""
+        `param_order` -- the list the reference built THAT optimiser over: the trainable parameters in train_tokenizer.py:381-382, every parameter in
+        train_dmd.py:473-475 / train_diffusion.py:209 (frozen ones then simply have no state) -- default: this buffer's own order.  The LambdaLR position is the step counter (`scheduler_state_dict`)."""
         order = list(param_order) if param_order is not None else self.fp.params
         index = {id(p): i for i, p in enumerate(order)}
         state = {}
@@ -138,6 +138,16 @@ class FlatAdamWEMA:
         """Inverse of `state_dict` (also accepts a reference `torch.optim.AdamW.state_dict()` taken over `param_order`)."""
         order = list(param_order) if param_order is not None else self.fp.params
         index = {id(p): i for i, p in enumerate(order)}
+        missing = [p for p in self.fp.params if id(p) not in index]
+        if missing:
+            raise ValueError(f"FlatAdamWEMA.load_state_dict: {len(missing)} of this optimiser's parameters are not in param_order")
+        g_params = sd["param_groups"][0].get("params")
+        if g_params is not None and len(g_params) != len(order):
+            raise ValueError(f"FlatAdamWEMA.load_state_dict: the entry was taken over {len(g_params)} parameters, param_order has {len(order)} -- "
+                             "the optimiser it comes from was built over another parameter list (e.g. trainable-only vs all parameters)")
+        have = [sd["state"].get(index[id(p)]) is not None for p in self.fp.params]
+        if any(have) and not all(have):
+            raise ValueError(f"FlatAdamWEMA.load_state_dict: {have.count(False)} of {len(have)} trainable parameters have no state while the others do")
         steps = set()
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
@@ -146,6 +156,8 @@ class FlatAdamWEMA:
             if st is None:
                 continue
             n = p.numel()
+            if st["exp_avg"].numel() != n:
+                raise ValueError(f"FlatAdamWEMA.load_state_dict: state {index[id(p)]} has {st['exp_avg'].numel()} elements, the parameter {n}")
             self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
             self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
             steps.add(int(float(st["step"])))

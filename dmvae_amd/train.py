@@ -102,6 +102,24 @@ class _AdversarialBranch:
         return {"d_loss": v[0], "bcr_loss": v[1], "acc_real": v[2], "acc_fake": v[3], "acc_mean": 0.5 * (v[2] + v[3]), "disc_norm": v[4]}
 
 
+def _rng_state() -> dict:
+    """CPU and current-device generator states: what DiffAug (utils/diffaug.py: `torch.rand(3)` on the CPU, `torch.rand(7, B, 1, 1)` on the device) and the
+    transport's sampling (`randn_like` on the device, `rand` on the CPU) consume.  Saved with every checkpoint so that a resumed run draws what the
+    uninterrupted one would have."""
+    st = {"cpu": torch.get_rng_state()}
+    if torch.cuda.is_available():
+        st["cuda"] = torch.cuda.get_rng_state()
+    return st
+
+
+def _set_rng_state(st) -> None:
+    if not st:
+        return
+    torch.set_rng_state(st["cpu"].cpu())
+    if "cuda" in st and torch.cuda.is_available():
+        torch.cuda.set_rng_state(st["cuda"].cpu())
+
+
 class TokenizerTrainer(_AdversarialBranch):
     def __init__(self, vae: VAE, lpips: Optional[LPIPS], lr: float = 1e-4, l1: float = 1.0, l2: float = 0.0, lpips_w: float = 1.0,
                  kl_w: float = 0.0, mmd_w: float = 0.0, warmup_steps: int = 1000, ema_decay: float = 0.9999, max_norm: float = 1.0,
@@ -201,21 +219,29 @@ class TokenizerTrainer(_AdversarialBranch):
         v = self.log.tolist()       # the single D2H sync
         return {"L1": v[0], "L2": v[1], "LPIPS": v[2], "rec_loss": v[3], "vae_norm": v[4], "KL": v[5], "MMD": v[6], "d_weight": v[7]}
 
+    def _opt_param_order(self):
+        """The parameter list the reference builds `optimizer_vae` over in THIS stage: `[p for p in vae_wo_ddp.parameters() if p.requires_grad]`
+        (train_tokenizer.py:381-382, after `requires_grad(vae.encoder, False)` at :297) -- indices 0 .. n_trainable - 1, the frozen encoder's ~300 tensors
+        are not part of it.  (train_dmd.py:474 and train_diffusion.py:209 build theirs over every parameter.)"""
+        return [p for p in self.vae.parameters() if p.requires_grad]
+
     def checkpoint(self) -> dict:
-        """The reference's checkpoint dict (train_tokenizer.py:440-450): vae_wo_ddp / vae_ema / disc_wo_ddp state_dicts, opt_vae / opt_disc in
-        torch.optim.AdamW's layout over `module.parameters()`, scheduler_vae / scheduler_disc, steps.  `torch.save` it as `{step:07d}.pt`;
-        `VAE.load_pretrained` reads the first two entries."""
+        """The reference's checkpoint dict (train_tokenizer.py:440-450): vae_wo_ddp / vae_ema / disc_wo_ddp state_dicts, opt_vae in torch.optim.AdamW's
+        layout over the TRAINABLE parameters (`_opt_param_order`), opt_disc over `disc.parameters()`, scheduler_vae / scheduler_disc, steps, and -- beyond the
+        reference -- the CPU / device generator states (`rng`: DiffAug's and the transport's draws continue where they stopped).  `torch.save` it as
+        `{step:07d}.pt`; `VAE.load_pretrained` reads the first two entries."""
         sd = {k: v.detach().clone() for k, v in self.vae.state_dict().items()}
         ema = dict(sd)
         names = {id(p): n for n, p in self.vae.named_parameters()}
         for p, e in zip(self.fp.params, self.fp.ema_state()):
             ema[names[id(p)]] = e.detach().clone()
-        out = {"vae_wo_ddp": sd, "vae_ema": ema, "steps": self.global_step, "opt_vae": self.opt.state_dict(list(self.vae.parameters())),
+        out = {"vae_wo_ddp": sd, "vae_ema": ema, "steps": self.global_step, "opt_vae": self.opt.state_dict(self._opt_param_order()),
                "scheduler_vae": self.opt.scheduler_state_dict(), "disc_wo_ddp": None, "opt_disc": None, "scheduler_disc": None}
         if self.disc is not None:
             out["disc_wo_ddp"] = {k: v.detach().clone() for k, v in self.disc.state_dict().items()}
             out["opt_disc"] = self.dopt.state_dict(list(self.disc.parameters()))
             out["scheduler_disc"] = self.dopt.scheduler_state_dict()
+        out["rng"] = _rng_state()
         return out
 
     def load(self, ckpt: dict) -> None:
@@ -228,7 +254,7 @@ class TokenizerTrainer(_AdversarialBranch):
             for p, e in zip(self.fp.params, self.fp.ema_state()):
                 e.copy_(ema_sd[names[id(p)]])
         if ckpt.get("opt_vae") is not None:
-            self.opt.load_state_dict(ckpt["opt_vae"], list(self.vae.parameters()))
+            self.opt.load_state_dict(ckpt["opt_vae"], self._opt_param_order())
         if self.disc is not None and ckpt.get("disc_wo_ddp") is not None:
             self.disc.load_state_dict(ckpt["disc_wo_ddp"], strict=True)
             if ckpt.get("opt_disc") is not None:
@@ -237,6 +263,7 @@ class TokenizerTrainer(_AdversarialBranch):
         self.global_step = int(ckpt.get("steps", 0))
         self.fp.after_external_update()
         self.refresh_frozen_shadows()
+        _set_rng_state(ckpt.get("rng"))
 
 
 def backward_order_params_full(vae: VAE):
@@ -281,6 +308,7 @@ class DMDTrainer(_AdversarialBranch):
         self._init_disc(disc, disc_weight, disc_start_step, disc_lr, disc_wd, warmup_steps, max_norm, bcr, bcr_cut, bucket_bytes)     # train_dmd.py:92-93,475
         self.w = dict(l1=l1, l2=l2, lpips=lpips_w)
         self.dmd_weight, self.cfg, self.num_classes = dmd_weight, dmd_cfg_scale, num_classes
+        self.batch_cfg = os.environ.get("DMVAE_DMD_BATCH_CFG", "1") != "0"      # 0: four B-sized velocity evaluations as the reference writes them (A/B)
         self.t0, self.t1, self.latent_mean, self.latent_scale = t0, t1, latent_mean, latent_scale
         self.vae_train_every, self.time_dist_shift, self.max_norm = vae_train_every, time_dist_shift, max_norm
         for p in vae.parameters():
@@ -349,11 +377,21 @@ class DMDTrainer(_AdversarialBranch):
         t = (t * (self.t1 - self.t0) + self.t0)
         xt = losses.dmd_make_xt(latents, x0, t)
         with torch.no_grad():
-            vt, vs = self.teacher(xt, t, labels), self.student(xt, t, labels)
-            vtu = vsu = None
-            if self.cfg > 1:
-                un = torch.ones_like(labels) * self.num_classes
-                vtu, vsu = self.teacher(xt, t, un), self.student(xt, t, un)
+            if self.cfg > 1 and self.batch_cfg:
+                # the conditional and the unconditional evaluation of a model as ONE call on 2B samples: every op of the velocity
+                # model is per sample (per token row, per (sample, head)), so each half equals the B-sized call; twice the rows per GEMM fill the chip
+                # (B = 16: 4096 -> 8192 token rows) and half the launches
+                b = xt.shape[0]
+                x2, t2 = torch.cat([xt, xt]), torch.cat([t, t])
+                y2 = torch.cat([labels, torch.ones_like(labels) * self.num_classes])
+                v2t, v2s = self.teacher(x2, t2, y2), self.student(x2, t2, y2)
+                vt, vtu, vs, vsu = v2t[:b], v2t[b:], v2s[:b], v2s[b:]
+            else:
+                vt, vs = self.teacher(xt, t, labels), self.student(xt, t, labels)
+                vtu = vsu = None
+                if self.cfg > 1:
+                    un = torch.ones_like(labels) * self.num_classes
+                    vtu, vsu = self.teacher(xt, t, un), self.student(xt, t, un)
         return losses.dmd_loss(latents, xt, t, vt, vs, vtu, vsu, cfg=self.cfg)
 
     def step(self, images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
@@ -440,22 +478,29 @@ class DMDTrainer(_AdversarialBranch):
                "disc_wo_ddp": clone(self.disc) if self.disc is not None else None,
                "opt_sit": self.sopt.state_dict(list(self.student.parameters())) if self.sopt is not None else None,
                "opt_vae": self.opt.state_dict(list(self.vae.parameters())),
-               "opt_disc": self.dopt.state_dict(list(self.disc.parameters())) if self.disc is not None else None, "steps": self.global_step}
+               "opt_disc": self.dopt.state_dict(list(self.disc.parameters())) if self.disc is not None else None, "steps": self.global_step,
+               "rng": _rng_state()}
         return out
 
     def load(self, ckpt: dict) -> None:
+        """Resume from `checkpoint()` (or a reference checkpoint, train_dmd.py:577-590); entries the checkpoint holds as None (absent branches) are skipped.
+        The warm-up position comes back with the optimiser steps; the generator states (`rng`) when the checkpoint has them."""
         self.vae.load_state_dict(ckpt["vae_wo_ddp"], strict=True)
-        self.opt.load_state_dict(ckpt["opt_vae"], list(self.vae.parameters()))
+        if ckpt.get("opt_vae") is not None:
+            self.opt.load_state_dict(ckpt["opt_vae"], list(self.vae.parameters()))
         self.fp.after_external_update()
         if self.sopt is not None and ckpt.get("model") is not None:
             self.student.load_state_dict(ckpt["model"], strict=True)
-            self.sopt.load_state_dict(ckpt["opt_sit"], list(self.student.parameters()))
+            if ckpt.get("opt_sit") is not None:
+                self.sopt.load_state_dict(ckpt["opt_sit"], list(self.student.parameters()))
             self.sfp.after_external_update()
         if self.disc is not None and ckpt.get("disc_wo_ddp") is not None:
             self.disc.load_state_dict(ckpt["disc_wo_ddp"], strict=True)
-            self.dopt.load_state_dict(ckpt["opt_disc"], list(self.disc.parameters()))
+            if ckpt.get("opt_disc") is not None:
+                self.dopt.load_state_dict(ckpt["opt_disc"], list(self.disc.parameters()))
             self.dfp.after_external_update()
         self.global_step = int(ckpt.get("steps", 0))
+        _set_rng_state(ckpt.get("rng"))
 
     def read_log(self) -> Dict[str, float]:
         v = self.log.tolist()

@@ -154,6 +154,12 @@ int dmvae_gemm_tn_batched(const void* A, const void* B, void* C, void* workspace
                           int N, int K, int batch, long long a_bs, long long b_bs, long long c_bs, float alpha,
                           int out_f32, dmvae_stream_t stream);
 
+/* Dynamic tile claiming in the large-shape conv kernel (blocks claim tiles from per-XCD counters instead of a static stride, so that a launch next to another
+ * stream's resident kernel -- an RCCL all-reduce overlapped with backward, utils/dist.py / train_tokenizer.py:302 -- slows down by the fraction of CUs taken
+ * instead of a whole block-time): on = 1 / 0 for every launch from now on, -1 = the DMVAE_PP_DYNAMIC environment default.  Returns the value in force.
+ * Results do not depend on it. */
+int dmvae_set_dynamic(int on);
+
 /* nn.Linear under autocast(bf16) for the transformer blocks: Y[M][N] = act(X[M][K] . W[N][K]^T + bias[N]).
  * Replaces the library GEMM behind F.linear at: timm's ViT blocks reached through models/vae.py:47-53 (attn.qkv / attn.proj / mlp.fc1 + nn.GELU /
  * mlp.fc2 and the patch embedding as a GEMM over patches), diffusion/lightningdit/lightningdit.py:34-93,173-252 (attn.qkv, attn.proj),
@@ -170,6 +176,12 @@ int dmvae_gemm_tn_batched(const void* A, const void* B, void* C, void* workspace
 int dmvae_linear_bf16(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int lda, int ldw, int ldy,
                       int act, int bias_bf16, int out_f32, int w_layout, dmvae_stream_t stream);
 int dmvae_linear_bf16_plan(int M, int N, int K, int* tile_cols, int* tile_rows);
+/* The input-gradient operand of dmvae_linear_bf16 from a Linear weight's bf16 copy: w bf16 [N][K] row-major (nn.Linear.weight: N = out_features, K = in_features)
+ * -> out bf16 [N / 32][K][32], out[n >> 5][k][n & 31] = w[n][k], i.e. the K-tile-major layout (w_layout = 1) of W^T [K][N] with the reduction over n:
+ * dmvae_linear_bf16(dy [M][N], out, NULL, dx, M, K, N, ..., w_layout = 1) is dX = dY . W.  N % 32 == 0, K % 8 == 0.  One tiled-transpose launch per weight
+ * version on the routes where the weight trains (timm blocks via models/vae.py:47-53 with the encoder trainable, train_dmd.py:519; LightningDiT student,
+ * train_dmd.py:565-575, train_diffusion.py:290-297). */
+int dmvae_linear_weight_t_kmajor(const void* w, void* out, int N, int K, dmvae_stream_t stream);
 
 /* P = softmax(scale*S) per row (S f32 [rows][cols] -> P bf16), and its backward
  * dS = scale * P .* (dP - rowsum(dP .* P)) (dP f32, dS bf16).  F.scaled_dot_product_attention's

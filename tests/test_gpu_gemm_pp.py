@@ -122,6 +122,7 @@ def test_kmajor_weight_layout_is_bit_identical(shape):
         wt = ops.pack_conv_weight(w32, for_dgrad=True, kmajor=True)        # [k, 1, n] = W^T, and its K-tile-major copy [n / 32, 1, k, 32]
         dx = ops.linear_bf16(dy, wt._dmvae_kmajor.view(n // 32, k, 32), out_f32=True)
         assert torch.equal(dx, ops.linear_bf16(dy, wt.view(k, n), out_f32=True))
+        assert torch.equal(ops.linear_weight_t_kmajor(w), wt._dmvae_kmajor.view(n // 32, k, 32)), "tiled transpose != the element-wise pack's K-tile-major copy"
         _check(dx, dy.double() @ w.double(), "input gradient %s" % (shape,))
 
 

@@ -305,6 +305,7 @@ def test_dmd_trainer_student_modes_and_adversarial_branch():
     images = torch.rand(2, 3, 256, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0)) * 2 - 1
     labels = torch.tensor([3, 7], device="cuda")
     student.eval()                                     # the reference's pre-loop state (train_dmd.py:501)
+    tr.batch_cfg = False                               # the reference's call structure: conditional and unconditional evaluation as two B-sized calls
     tr.step(images, labels)                            # step 0: VAE turn (DMD: two student evaluations with CFG), then the student's turn
     assert student.calls == [(False, False), (False, False), (True, True)], student.calls
     assert tr.read_log()["d_weight"] == 0.0 and torch.equal(torch.cat([p.detach().flatten() for p in disc.parameters()]), d0)    # before disc_start_step
@@ -312,8 +313,9 @@ def test_dmd_trainer_student_modes_and_adversarial_branch():
     tr.step(images, labels)                            # step 1: student only
     assert student.calls == [(True, True)]
     student.calls.clear()
+    tr.batch_cfg = True                                # the default: both evaluations as ONE call on 2B samples
     tr.step(images, labels)                            # step 2: VAE turn again, adversarial branch active now
-    assert student.calls == [(False, False), (False, False), (True, True)], student.calls
+    assert student.calls == [(False, False), (True, True)], student.calls
     log, dlog = tr.read_log(), tr.read_disc_log()
     assert log["d_weight"] > 0 and dlog["d_loss"] > 0 and dlog["disc_norm"] > 0
     assert all(v == v and abs(v) < 1e6 for v in log.values())
@@ -343,7 +345,13 @@ def test_tokenizer_trainer_checkpoint_resume_is_bit_exact():
         b.step(images)
     assert torch.equal(a.fp.flat, b.fp.flat) and torch.equal(a.fp.ema, b.fp.ema)
     assert torch.equal(a.opt.exp_avg, b.opt.exp_avg) and torch.equal(a.opt.exp_avg_sq, b.opt.exp_avg_sq)
-    ref_opt = torch.optim.AdamW(list(a.vae.parameters()), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.005)
-    ref_opt.load_state_dict(ck["opt_vae"])                       # the reference's resume path accepts the entry
-    p_last = list(a.vae.parameters())[-1]
-    assert float(ref_opt.state[p_last]["step"]) == 3.0
+    # the reference builds optimizer_vae over the TRAINABLE parameters (train_tokenizer.py:381-382): its resume path accepts the entry, and every state lands
+    # on the parameter it belongs to
+    trainable = [p for p in a.vae.parameters() if p.requires_grad]
+    assert len(trainable) < len(list(a.vae.parameters())) and len(ck["opt_vae"]["param_groups"][0]["params"]) == len(trainable)
+    ref_opt = torch.optim.AdamW(trainable, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.005)
+    ref_opt.load_state_dict(ck["opt_vae"])
+    assert float(ref_opt.state[trainable[-1]]["step"]) == 3.0
+    assert all(ref_opt.state[p]["exp_avg"].shape == p.shape for p in trainable)
+    with pytest.raises(ValueError):                              # an entry taken over another parameter list is refused, not silently mis-assigned
+        b.opt.load_state_dict(ck["opt_vae"], list(b.vae.parameters()))
