@@ -197,6 +197,12 @@ __global__ void dmd_final_kernel(const float* __restrict__ out_s, float* __restr
 // Launches: kl_moments (grid-stride, 16-B loads) -> kl_final -> mmd_pair (one workgroup per (group, pair-type, 128-row
 // tile)) -> kl_mmd_final.  Everything is fixed-order (no float atomics): run-to-run bit-exact.
 constexpr int MMD_D = 32;
+#ifndef DMVAE_KL_UNROLL
+#define DMVAE_KL_UNROLL 4
+#endif
+#ifndef DMVAE_KL_ALLNT
+#define DMVAE_KL_ALLNT 0
+#endif
 constexpr int MMD_ROWS = 128;   // rows per workgroup: 2 per lane
 constexpr int MMD_CCH = 256;    // columns staged in LDS per chunk
 constexpr int MMD_NQ = 4;       // column slices = waves per workgroup (2 workgroups share a CU: one stages / reduces while the other computes)
@@ -212,17 +218,18 @@ __global__ __launch_bounds__(256) void kl_moments_kernel(const float* __restrict
   // 256 MB Infinity Cache for it), everything before with streaming loads (faster, and it would be evicted anyway).
   const size_t keep_rows = ((size_t)192 << 20) / (MMD_D * sizeof(float));
   const size_t nt_rows = R > keep_rows ? R - keep_rows : 0;
-  for (; r + 3 * stride < R; r += 4 * stride) {  // four independent 16-B loads in flight per lane
-    f32x4 v[4];
-    if (r + 3 * stride < nt_rows) {
+  constexpr int U = DMVAE_KL_UNROLL;
+  for (; r + (U - 1) * stride < R; r += U * stride) {  // U independent 16-B loads in flight per lane
+    f32x4 v[U];
+    if (DMVAE_KL_ALLNT || r + (U - 1) * stride < nt_rows) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + (r + u * stride) * MMD_D + cq * 4));
+      for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + (r + u * stride) * MMD_D + cq * 4));
     } else {
 #pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const f32x4*>(z + (r + u * stride) * MMD_D + cq * 4);
+      for (int u = 0; u < U; u++) v[u] = *reinterpret_cast<const f32x4*>(z + (r + u * stride) * MMD_D + cq * 4);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 0; u < U; u++)
 #pragma unroll
       for (int e = 0; e < 4; e++) { s[e] += v[u][e]; ss[e] += v[u][e] * v[u][e]; }
   }
@@ -250,6 +257,15 @@ __global__ __launch_bounds__(1024) void kl_final_kernel(const float* __restrict_
   const int cm = threadIdx.x & 63, pl = threadIdx.x >> 6;  // cm = channel*2 + moment (the partials' inner layout)
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   int g = pl;
+  // sixteen independent loads in flight per lane (the same rows into the same four accumulators in the same order as four at a time: the kernel is one
+  // block walking 512 KB of partials, i.e. pure load latency -- 14 us with four in flight, a tenth of the whole 268 MB KL pass)
+  for (; g + 240 < nparts; g += 256) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) v[u] = mom[(size_t)(g + 16 * u) * 64 + cm];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) { a0 += v[u]; a1 += v[u + 1]; a2 += v[u + 2]; a3 += v[u + 3]; }
+  }
   for (; g + 48 < nparts; g += 64) {
     const float v0 = mom[(size_t)g * 64 + cm], v1 = mom[(size_t)(g + 16) * 64 + cm], v2 = mom[(size_t)(g + 32) * 64 + cm],
                 v3 = mom[(size_t)(g + 48) * 64 + cm];
@@ -813,7 +829,8 @@ static inline void kl_mmd_plan(int groups, int n, int m, int* tx, int* ty, int* 
   *ty = (m + MMD_ROWS - 1) / MMD_ROWS;
   size_t R = (size_t)groups * n;
   size_t nb = (R + 255) / 256;  // >= 8 row sweeps per block
-  *nmom = (int)(nb > 2048 ? 2048 : (nb < 1 ? 1 : nb));
+  static const int cap = [] { const char* e = getenv("DMVAE_KL_NMOM"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();
+  *nmom = (int)(nb > (size_t)cap ? (size_t)cap : (nb < 1 ? 1 : nb));
 }
 // Column split of the two-launch path: enough workgroups for two per CU (two waves per SIMD) on a 256-CU part, at most 4 splits; 1 otherwise.
 static inline int kl_mmd_csplit(int groups, int tx, int ty) {
