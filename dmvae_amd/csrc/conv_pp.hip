@@ -39,6 +39,9 @@
 #ifndef DMVAE_PP_EXP
 #define DMVAE_PP_EXP 0
 #endif
+#ifndef DMVAE_PP_DIRECT   // 1: the HALO instantiations store straight from the accumulators (pixels as MFMA rows, permuted weight rows; see the kernel); 0: LDS-staged epilogue (A/B builds)
+#define DMVAE_PP_DIRECT 1
+#endif
 #ifndef DMVAE_PP_LGKM_BUILTIN   // 1: the K loop's lgkmcnt(0) through the builtin (the MFMAs then issue as one run; gemm_pp.hip does the same); 0: inline asm + 8 compiler-placed waits between them
 #define DMVAE_PP_LGKM_BUILTIN 1
 #endif
@@ -143,6 +146,13 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   constexpr int EPI_OFF = HALO ? GROUP : 2 * SLOT; // the epilogue's staging region
   constexpr int EPI_BYTES = 8 * 32 * (((BM >= 4 ? BM / 2 : BM) * 32) * 4 + 16);
   constexpr int DUMP_OFF = GROUP + (GROUP > EPI_BYTES ? GROUP : EPI_BYTES);
+  // DIRECT (the HALO instantiations): the epilogue stores straight from the accumulators.  The MFMA runs with the PIXELS as its rows (D[pixel][cout]: lane
+  // (c = lane & 15, g = lane >> 4) holds pixels 4g .. 4g + 3 of a 16-pixel block at cout column c of a 16-cout block) and the weight rows are DMA'd in a
+  // permuted order (setup) so that a lane's BM16 accumulators of one pixel are BM16 consecutive couts and the 16 lanes of a group hold 16 BM16 consecutive
+  // couts of that pixel: one store instruction writes 4 pixel rows x 256 (128) contiguous bytes with consecutive lanes on consecutive bytes -- no LDS
+  // round trip (the staged epilogue wrote and re-read the tile in f32: 256 + 256 KB of LDS traffic and ~12 k cycles per 256 x 256 tile; first built and
+  // measured in gemm_pp.hip, whose header has the numbers).  Same sums in the same order: results are bit-identical to the staged epilogue's.
+  constexpr bool DIRECT = HALO && !OUT_F32 && DMVAE_PP_DIRECT;
   constexpr int BM16 = BM * 2, BP16 = BP * 2;  // 16x16 MFMA blocks per wave (v_mfma_f32_16x16x32_bf16: measured 5 % less power per flop than 32x32x16,
                                                // tools/probes/probe_wavetile.hip arm D -- and the kernel is power-limited)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -190,6 +200,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   int it = 0, it_tap = 0, it_ch = 0;  // DMA issue state (wave-uniform): tile `it` = (tap it_tap, channel chunk it_ch)
   unsigned soffB_tap = 0;
   auto setup = [&](unsigned work) {
+    int lane_s = lane;
+    if constexpr (DIRECT) asm volatile("" : "+v"(lane_s));   // what setup derives from the lane index is recomputed per tile, not hoisted out of the tile loop and spilled
     const unsigned wid = xcd_remap(work, a.total);
     if constexpr (SUB) {  // order: source region, parity class, cout tile
       const unsigned q = wid / a.ctiles;
@@ -204,9 +216,14 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     it_ky = 0;
 #pragma unroll
     for (int p = 0; p < NPA; p++) {
-      const int row = (wave * NPA + p) * 16 + (lane >> 2);
-      const int co = n0 + row;
-      const int c = (lane & 3) ^ swz64(row);  // logical 16-B chunk this lane fetches (LDS image stays lane-linear)
+      const int row = (wave * NPA + p) * 16 + (lane_s >> 2);
+      int co = n0 + row;
+      if constexpr (DIRECT) {   // LDS row 16 i + c of a wave's cout range holds cout BM16 * c + i: a lane's BM16 accumulators of one pixel are then consecutive couts
+        constexpr int CW_ = TM / WM;
+        const int wmr = row / CW_, rr = row % CW_;
+        co = n0 + wmr * CW_ + BM16 * (rr & 15) + (rr >> 4);
+      }
+      const int c = (lane_s & 3) ^ swz64(row);  // logical 16-B chunk this lane fetches (LDS image stays lane-linear)
 #if DMVAE_PP_EXP & 512   // timing experiment: the weight tile's 64-B rows contiguous in memory (whole 128-B lines; wrong data)
       voffA[p] = (co < a.Cout && row < TM) ? (unsigned)co * 64u + c * 16u : SENT;
 #else
@@ -216,10 +233,10 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     if constexpr (HALO) {
 #pragma unroll
       for (int q = 0; q < NPH; q++) {
-        const int i = (q < NPB ? (wave * NPB + q) * 16 : TP) + (lane >> 2);   // halo row = flat pixel m0 - 1 + i
+        const int i = (q < NPB ? (wave * NPB + q) * 16 : TP) + (lane_s >> 2);   // halo row = flat pixel m0 - 1 + i
         const int own = min(max(i - 1, 0), TP - 1);                            // the tile pixel whose edge rules it follows
         const int m = m0 + own;
-        const int c = (lane & 3) ^ hswz(i);
+        const int c = (lane_s & 3) ^ hswz(i);
         unsigned mask = 0;
         if (m < a.M && i < TP + 2 && (q < NPB || wave == 0)) {
           int n, r, y, x;
@@ -240,9 +257,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     } else {
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
-    const int row = (wave * NPB + p) * 16 + (lane >> 2);
+    const int row = (wave * NPB + p) * 16 + (lane_s >> 2);
     const int m = m0 + row;
-    const int c = (lane & 3) ^ swz64(row);
+    const int c = (lane_s & 3) ^ swz64(row);
     unsigned mask = 0;
     ctrB[p] = 0;
     if (m < a.M) {
@@ -526,8 +543,10 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #pragma unroll
       for (int i = 0; i < BM16; i++)
 #pragma unroll
-        for (int j = 0; j < BP16; j++)
-          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[i]), "v"(bfr[j]));
+        for (int j = 0; j < BP16; j++) {
+          if constexpr (DIRECT) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(bfr[j]), "v"(af[i]));   // rows = pixels
+          else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[i]), "v"(bfr[j]));
+        }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -615,7 +634,161 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   stamp(work, 6);
   const unsigned next = DYN ? (unsigned)__builtin_amdgcn_readfirstlane((int)next_dyn) : work + gridDim.x;
   const bool has_next = next < (unsigned)a.total;
-  {
+  if constexpr (DIRECT) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    constexpr int CL = BM16;               // consecutive couts per lane: 8 (256-row tile) or 4
+    constexpr int NQD = CL / 4;            // 4-channel quads per lane (GroupNorm statistics)
+    static_assert(CL == 8 || CL == 4, "DIRECT: 8 or 4 couts per lane");
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));       // recomputed per tile, not carried (spilled) across the main loop
+    const int cc = lane_o & 15, gq = lane_o >> 4;
+    const int col = n0c + wm * (TM / WM) + CL * cc;
+    const bool c_ok = col < a.Cout;        // Cout % 8 == 0: a lane's couts are all inside or all outside
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)a.M * (unsigned)a.Cout * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)a.Cout * 4u : 0u, 0x00020000);
+    // bias first, while the memory queue is empty (behind the next tile's prefetch its first use would wait for those pieces to land)
+    float bsv[CL];
+    {
+      const unsigned vo = c_ok ? (unsigned)col * 4u : SENT;
+#pragma unroll
+      for (int h = 0; h < NQD; h++) {
+        const u32x4 b4 = __builtin_amdgcn_raw_buffer_load_b128(rBias, vo == SENT ? SENT : vo + 16u * h, 0, 0);
+        const f32x4 bf = *reinterpret_cast<const f32x4*>(&b4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) bsv[4 * h + e] = bf[e];
+      }
+    }
+    if (has_next) {
+      stamp(next, 0);
+      setup(next);
+      stamp(next, 1);
+    } else {
+      it = (nK + 3) & ~3;   // destination derived from `it`: A slot 0 / halo slot 0
+      it_ky = it_ch = 0;
+    }
+    issue_h(K0_{});
+    stamp(work, 7);
+    float s1[STATS ? NQD : 1], s2[STATS ? NQD : 1];
+    if constexpr (STATS) {
+#pragma unroll
+      for (int h = 0; h < NQD; h++) { s1[h] = 0.f; s2[h] = 0.f; }
+    }
+    // the lane's first row (pixel block 0, r = 0) as a byte offset -- out of range when its couts are -- and the wave-uniform step of one pixel row
+    const unsigned vbase = c_ok ? ((unsigned)(m0c + wp * (TP / WP) + 4 * gq) * (unsigned)a.Cout + (unsigned)col) * 2u : SENT;
+    const unsigned rstep = (unsigned)a.Cout * 2u;
+    auto body = [&](auto RESc, auto ACTc) __attribute__((always_inline)) {
+      constexpr bool RES = decltype(RESc)::value;
+      constexpr int ACTC = decltype(ACTc)::value;   // < 0: a.act is read at run time (the activations that are not hot)
+      const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, RES ? (unsigned)a.M * (unsigned)a.Cout * 2u : 0u, 0x00020000);
+      // residual / gate operand: the four rows of pixel block j + 1 are fetched while block j is converted and stored
+      typedef std::conditional_t<CL == 8, u32x4, u32x2> rvec;
+      rvec rnx[RES ? 4 : 1];   // a rolling window of four rows: row r of block j + 1 is requested as soon as row r of block j has been consumed
+      auto fetch = [&](int j, int r) {
+        if constexpr (RES) {
+          if constexpr (CL == 8) rnx[RES ? r : 0] = __builtin_amdgcn_raw_buffer_load_b128(rR, vbase, (unsigned)(j * 16 + r) * rstep, 2);
+          else rnx[RES ? r : 0] = __builtin_amdgcn_raw_buffer_load_b64(rR, vbase, (unsigned)(j * 16 + r) * rstep, 2);
+        }
+      };
+#pragma unroll
+      for (int r = 0; r < 4; r++) fetch(0, r);
+#pragma unroll
+      for (int j = 0; j < BP16; j++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          float v[CL];
+#pragma unroll
+          for (int i = 0; i < CL; i++) {
+            // read where it is used: left to itself the compiler hoists the accumulator reads every variant of `body` shares in front of the variant
+            // dispatch -- dozens of values live across the whole epilogue, spilled to scratch, and every scratch reload is a VMEM load whose wait drains the
+            // next tile's prefetch queue
+            float x;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[i][j][r]));
+            v[i] = x + bsv[i];
+          }
+          const int act = ACTC >= 0 ? ACTC : a.act;
+          if constexpr (RES) {
+            float rf[CL];
+            {
+              const rvec rv = rnx[RES ? r : 0];
+#pragma unroll
+              for (int h = 0; h < CL / 2; h++) {
+                const unsigned wd = rv[h];
+                const bf16x2 b2 = *reinterpret_cast<const bf16x2*>(&wd);
+                rf[2 * h] = (float)b2[0]; rf[2 * h + 1] = (float)b2[1];
+              }
+            }
+            if (j + 1 < BP16) fetch(j + 1, r);
+            if (act == 3) {   // ReLU-backward gate: `res` is the saved activation, not an addend
+#pragma unroll
+              for (int e = 0; e < CL; e++) v[e] = rf[e] > 0.f ? v[e] : 0.f;
+            } else {
+#pragma unroll
+              for (int e = 0; e < CL; e++) v[e] += rf[e];
+            }
+          }
+          if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < CL; e++) v[e] = v[e] * sigmoidf_(v[e]);
+          } else if (act == 2) {
+#pragma unroll
+            for (int e = 0; e < CL; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          } else if (act == 4) {
+#pragma unroll
+            for (int e = 0; e < CL; e++) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+          }
+          const unsigned so = (unsigned)(j * 16 + r) * rstep;   // wave-uniform row step; rows past M fall off the descriptor's end (tests/test_gpu_conv_bounds.py)
+          unsigned pk[CL / 2];
+#pragma unroll
+          for (int h = 0; h < CL / 2; h++) pk[h] = dmvae_pack_bf16x2(v[2 * h], v[2 * h + 1]);
+          if constexpr (STATS) {   // v_dot2c_f32_bf16 on the packed result: rows past M do not occur (whole pixel tiles per image), couts past Cout carry exact zeros
+            const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+            for (int h = 0; h < CL / 2; h++) {
+              const bf16x2 p2 = *reinterpret_cast<const bf16x2*>(&pk[h]);
+              s1[STATS ? h >> 1 : 0] = __builtin_amdgcn_fdot2_f32_bf16(p2, one2, s1[STATS ? h >> 1 : 0], false);
+              s2[STATS ? h >> 1 : 0] = __builtin_amdgcn_fdot2_f32_bf16(p2, p2, s2[STATS ? h >> 1 : 0], false);
+            }
+          }
+          // non-temporal: the tile is next read by a later kernel, after far more than an L2 of other traffic
+          if constexpr (CL == 8) {
+            const u32x4 o = {pk[0], pk[1], pk[2], pk[3]};
+#if !(DMVAE_PP_EXP & 8)
+            __builtin_amdgcn_raw_buffer_store_b128(o, rY, vbase, so, 2);
+#endif
+            asm volatile("s_nop 0" :: "v"(o));   // gfx950: a VALU write to a store's data VGPR directly behind the store is seen by the store (see the staged epilogue)
+          } else {
+            const u32x2 o = {pk[0], pk[1]};
+#if !(DMVAE_PP_EXP & 8)
+            __builtin_amdgcn_raw_buffer_store_b64(o, rY, vbase, so, 2);
+#endif
+            asm volatile("s_nop 0" :: "v"(o));
+          }
+        }
+      }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    if (a.res) {
+      if (a.act == 0) body(T_{}, std::integral_constant<int, 0>{});
+      else if (a.act == 3) body(T_{}, std::integral_constant<int, 3>{});
+      else body(T_{}, std::integral_constant<int, -1>{});
+    } else {
+      if (a.act == 0) body(F_{}, std::integral_constant<int, 0>{});
+      else if (a.act == 2) body(F_{}, std::integral_constant<int, 2>{});
+      else body(F_{}, std::integral_constant<int, -1>{});
+    }
+    if constexpr (STATS) {   // the four lane groups hold different pixel rows of the same couts: fold them, then one partial per (pixel tile, wave column, quad)
+      const size_t trow = (size_t)(m0c / TP) * WP + wp;
+#pragma unroll
+      for (int h = 0; h < NQD; h++) {
+        float t1 = s1[STATS ? h : 0], t2 = s2[STATS ? h : 0];
+        t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
+        t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+        const int cq = col + 4 * h;
+        if (gq == 0 && cq < a.Cout) *reinterpret_cast<f32x2*>(a.gnpart + (trow * (a.Cout >> 2) + (cq >> 2)) * 2) = f32x2{t1, t2};
+      }
+    }
+  } else {
     // 64 couts (two 32-cout blocks) per staging pass: a store instruction then writes 8 pixel rows x 128 contiguous bytes.  The 128-row tile (one wave =
     // 64 couts) used to take them in two passes of 32 -- 16 rows x 64 B per store instruction, i.e. twice the cache lines per instruction -- and now takes
     // them in one (DMVAE_PP_EPI_HALF restores the two passes for A/B builds).
