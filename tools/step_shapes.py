@@ -13,6 +13,9 @@ class ShapeLog(list):
     """ops.* append (label, e0, e1, flop); the shape is read from the caller's frame."""
     def append(self, item):
         f = sys._getframe(1).f_locals
+        if item[0] == "gemm_pp_kernel":       # ops.linear_bf16: the encoder's Linear layers
+            list.append(self, ("gemm_pp", "%dx%dx%d%s" % (f["m"], f["n"], f["k"], " act%d" % f["act"] if f.get("act") else "")) + tuple(item[1:]))
+            return
         shape = "%dx%dx%d %d>%d k%d%s%s%s" % (f["n"], f.get("ho", 0) or f["dy"].shape[1], f.get("wo", 0) or f["dy"].shape[2], f["cin"], f["cout"], f["ks"],
                                             " ups%d" % int(f["upsample"]) if f.get("upsample") else "", " s%d" % f["stride"] if f.get("stride", 1) != 1 else "",
                                             " T" if f.get("transposed") else "")
