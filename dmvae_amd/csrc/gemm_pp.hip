@@ -39,6 +39,7 @@ struct Args {
   void* y;           // [M][ldy] bf16 / f32
   int M, N, K, lda, ldw, ldy;
   int act, bias_bf16;
+  int H;             // act 6 (SwiGLU): N = 2 H weight rows [x1 | x2], H output columns
   unsigned wbytes;       // bytes of the weight operand
   unsigned wsRow, wsK;   // byte strides of the weight operand between rows / between K tiles: row-major (2 ldw, 64), K-tile-major (64, 64 N)
   int ntn, total;    // column tiles, tiles
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
   const int wm = wave / WP, wp = wave % WP;
   const int nK = a.K >> 5;
   const unsigned bsz = a.bias_bf16 ? 2u : 4u;
+  const bool gated = a.act == 6;
   const float inv_ntn = a.inv_ntn;   // from the host: a kernel argument lives in an SGPR (computed here it sat in a VGPR and was spilled)
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
@@ -138,9 +140,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
     for (int p = 0; p < NPA; p++) {
       const int rl = (wave * NPA + p) * 16 + (lane_c >> 2);     // LDS row of the weight tile: wave column range rl / CW, column block i, MFMA column c
       const int wmr = rl / CW, r = rl % CW, i = r >> 4, c = r & 15;
-      const int n = n0 + wmr * CW + CL * c + i;
+      int n = n0 + wmr * CW + CL * c + i;
+      bool n_ok = n < a.N;
+      if (gated) {   // a lane's CL accumulators: x1 of CL / 2 consecutive hidden units, then x2 of the same units (weight rows H + unit)
+        const int hid = (n0 >> 1) + wmr * (CW / 2) + (CL / 2) * c + (i % (CL / 2));
+        n = (i < CL / 2 ? 0 : a.H) + hid;
+        n_ok = hid < a.H;
+      }
       const int ch = (lane_c & 3) ^ swz64(rl);                  // logical 16-B chunk this lane fetches: the LDS image stays lane-linear, the swizzle is on the source address
-      vA[p] = (live && rl < TM && n < a.N) ? (unsigned)n * a.wsRow + ch * 16u : SENT;
+      vA[p] = (live && rl < TM && n_ok) ? (unsigned)n * a.wsRow + ch * 16u : SENT;
     }
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
@@ -150,7 +158,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
       vB[p] = (live && rl < TP && m < a.M) ? (unsigned)m * (unsigned)a.lda * 2u + ch * 16u : SENT;
     }
     const unsigned e0 = (unsigned)lane_c * (16u / bsz);         // first element of this lane's 16 bytes of the slice
-    vBias = (live && wave == 0 && e0 < (unsigned)TM && (unsigned)n0 + e0 < (unsigned)a.N) ? ((unsigned)n0 + e0) * bsz : SENT;
+    if (gated) {   // slice = [x1 biases of the tile's TM / 2 hidden units][x2 biases of the same units]
+      const unsigned eh = e0 < (unsigned)(TM / 2) ? e0 : e0 - (unsigned)(TM / 2);
+      const unsigned hid = (unsigned)(n0 >> 1) + eh;
+      vBias = (live && wave == 0 && e0 < (unsigned)TM && hid < (unsigned)a.H) ? ((e0 < (unsigned)(TM / 2) ? 0u : (unsigned)a.H) + hid) * bsz : SENT;
+    } else {
+      vBias = (live && wave == 0 && e0 < (unsigned)TM && (unsigned)n0 + e0 < (unsigned)a.N) ? ((unsigned)n0 + e0) * bsz : SENT;
+    }
   };
   auto issue_k = [&](const unsigned (&vA)[NPA], const unsigned (&vB)[NPB], unsigned kt, int slot) {   // kt: K tile
 #pragma unroll
@@ -238,19 +252,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
       const char* bl = smem + BIAS_OFF + par * 1024;
       int lane_b = lane;
       asm volatile("" : "+v"(lane_b));   // recomputed per tile (see calc)
-      const int col = wm * CW + CL * (lane_b & 15);
+      const int col = gated ? wm * (CW / 2) + (CL / 2) * (lane_b & 15) : wm * CW + CL * (lane_b & 15);
+      const int hop = gated ? TM / 2 - CL / 2 : 0;   // gated: the second half of the lane's columns sits TM / 2 entries further (the x2 half of the slice)
       float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (!a.bias) {   // no bias: the slice's piece was all out of range (whether such a piece writes zeros or nothing is not relied upon)
       } else if (a.bias_bf16) {
 #pragma unroll
         for (int h = 0; h < CL / 2; h++) {
-          const bf16x2 b2 = *reinterpret_cast<const bf16x2*>(bl + col * 2 + h * 4);
+          const bf16x2 b2 = *reinterpret_cast<const bf16x2*>(bl + (col + (h >= CL / 4 ? hop : 0)) * 2 + h * 4);
           bv[2 * h] = (float)b2[0]; bv[2 * h + 1] = (float)b2[1];
         }
       } else {
 #pragma unroll
         for (int h = 0; h < CL / 2; h++) {
-          const f32x2 b2 = *reinterpret_cast<const f32x2*>(bl + col * 4 + h * 8);
+          const f32x2 b2 = *reinterpret_cast<const f32x2*>(bl + (col + (h >= CL / 4 ? hop : 0)) * 4 + h * 8);
           bv[2 * h] = b2[0]; bv[2 * h + 1] = b2[1];
         }
       }
@@ -280,9 +295,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
     {
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));   // recomputed per tile, not carried across the main loop
-      const int col = n0c + wm * CW + CL * (lane_o & 15);
+      const int col = gated ? (n0c >> 1) + wm * (CW / 2) + (CL / 2) * (lane_o & 15) : n0c + wm * CW + CL * (lane_o & 15);
       const int row0 = m0c + wp * (TP / WP) + 4 * (lane_o >> 4);
-      const bool c_ok = col < a.N;       // N % 8 == 0 and CL | 8 ... the lane's columns are all inside or all outside when N is a multiple of CL; else per element below
+      const bool c_ok = col < (gated ? a.H : a.N);       // N % 8 == 0 and CL | 8 ... the lane's columns are all inside or all outside when N is a multiple of CL; else per element below
       auto body = [&](auto ACTc) __attribute__((always_inline)) {
         constexpr int ACT = decltype(ACTc)::value;
 #pragma unroll
@@ -291,8 +306,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
           for (int r = 0; r < 4; r++) {
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < CL; i++) v[i] = acc[i][j][r];
-            if constexpr (ACT != 0) {   // the activation sees the bf16-rounded pre-activation, as the unfused Linear -> activation pair does
+            for (int i = 0; i < CL; i++)   // pinned where they are used: left to the scheduler, the reads of later rows are hoisted and their values spilled (conv_pp.hip)
+              asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[i]) : "a"(acc[i][j][r]));
+            if constexpr (ACT == 6) {   // SwiGLU (swiglu_ffn.py:32-35): silu(x1) * x2 on the bf16-rounded halves, the product of bf16 values -- dit.hip::swiglu_kernel's bits
+#pragma unroll
+              for (int i = 0; i < CL / 2; i++) {
+                const float x1 = (float)(bf16)v[i], x2 = (float)(bf16)v[CL / 2 + i];
+                v[i] = (float)(bf16)(x1 * sigmoidf_(x1)) * x2;
+              }
+            } else if constexpr (ACT != 0) {   // the activation sees the bf16-rounded pre-activation, as the unfused Linear -> activation pair does
 #pragma unroll
               for (int i = 0; i < CL; i++) {
                 const float x = (float)(bf16)v[i];
@@ -302,7 +324,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
             const int m = row0 + j * 16 + r;
             const bool ok = !DMVAE_GEMM_NOSTORE && c_ok && m < a.M;
             const unsigned eo = (unsigned)m * (unsigned)a.ldy + (unsigned)col;
-            if constexpr (OUT_F32 && CL == 6) {   // column pairs one by one (a lane may straddle N, see the bf16 case below; the f32 result is not a hot path)
+            if constexpr (ACT == 6) {
+              if constexpr (CL == 8 && !OUT_F32) {
+                const u32x2 o = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3])};
+                __builtin_amdgcn_raw_buffer_store_b64(o, rY, ok ? eo * 2u : SENT, 0, DMVAE_GEMM_AUX);
+                asm volatile("s_nop 0" :: "v"(o));
+              } else if constexpr (CL == 4 && !OUT_F32) {
+                const unsigned o = dmvae_pack_bf16x2(v[0], v[1]);
+                __builtin_amdgcn_raw_buffer_store_b32(o, rY, ok ? eo * 2u : SENT, 0, DMVAE_GEMM_AUX);
+                asm volatile("s_nop 0" :: "v"(o));
+              }   // other instantiations are never dispatched with act 6
+            } else if constexpr (OUT_F32 && CL == 6) {   // column pairs one by one (a lane may straddle N, see the bf16 case below; the f32 result is not a hot path)
 #pragma unroll
               for (int e = 0; e < 3; e++) {
                 const f32x2 o2 = {v[2 * e], v[2 * e + 1]};
@@ -347,6 +379,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(Args a) {
       };
       if (a.act == 0) body(std::integral_constant<int, 0>{});
       else if (a.act == 5) body(std::integral_constant<int, 5>{});
+      else if (a.act == 6) body(std::integral_constant<int, 6>{});
       else body(std::integral_constant<int, 1>{});
     }
     if (a.dbg) __builtin_amdgcn_s_barrier();   // diagnostics: the stamp then reads when the LAST wave has issued its stores
@@ -397,14 +430,15 @@ static int g_forced = -2;   // -2: not read yet; -1: plan by cost; >= 0: this me
 // Time model: tiles / 256 rounds of the tile's cost -- FRACTIONAL rounds, because the chip is power-limited: with half of the CUs idle in the last round the
 // busy ones clock higher and the round ends sooner (896 tiles of 256 x 256 = 3.5 rounds measure 3.5 x one round's time, not 4 x) -- but a round never costs
 // less than 0.85 of a full one.  Ragged tiles are whole tiles (their padding rows / columns cost what real ones do).
-static int plan(int M, int N, int K) {
+static int plan(int M, int N, int K, bool gated = false) {
   if (g_forced == -2) { const char* e = getenv("DMVAE_GEMM_CFG"); g_forced = e ? atoi(e) : -1; }
   const int forced = g_forced;
-  if (forced >= 0 && forced < NCFG) return forced;
+  if (forced >= 0 && forced < NCFG && !(gated && g_cfg[forced].tm == 192)) return forced;
   (void)K;
   int best = 0;
   float best_t = 1e30f;
   for (int c = 0; c < NCFG; c++) {
+    if (gated && g_cfg[c].tm == 192) continue;   // the gated epilogue pairs the halves of a lane's 4 or 8 columns
     const long long tiles = (long long)((M + g_cfg[c].tp - 1) / g_cfg[c].tp) * ((N + g_cfg[c].tm - 1) / g_cfg[c].tm);
     const float frac = (float)tiles / 256.0f, whole = 0.85f * (float)((tiles + 255) / 256);
     const float t = (frac > whole ? frac : whole) * g_cfg[c].cost;
@@ -449,19 +483,20 @@ extern "C" int dmvae_linear_bf16(const void* x, const void* w, const void* bias,
   DMVAE_CHECK_ARG(x && w && y, "linear_bf16: null operand");
   DMVAE_CHECK_ARG(M > 0 && N > 0 && K >= 384 && K % 32 == 0 && N % 8 == 0, "linear_bf16: need K %% 32 == 0, K >= 384 and N %% 8 == 0 (M %d, N %d, K %d)", M, N, K);
   DMVAE_CHECK_ARG(w_layout == 0 || w_layout == 1, "linear_bf16: w_layout must be 0 (row-major [N][ldw]) or 1 (K-tile-major [K / 32][N][32])");
-  DMVAE_CHECK_ARG(lda >= K && (w_layout == 1 || ldw >= K) && ldy >= N && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0,
+  DMVAE_CHECK_ARG(lda >= K && (w_layout == 1 || ldw >= K) && ldy >= (act == 6 ? N / 2 : N) && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0,
                   "linear_bf16: leading dimensions must cover the rows and be multiples of 8");
-  DMVAE_CHECK_ARG(act == 0 || act == 1 || act == 5, "linear_bf16: act must be 0 (none), 1 (SiLU) or 5 (GELU)");
+  DMVAE_CHECK_ARG(act == 0 || act == 1 || act == 5 || act == 6, "linear_bf16: act must be 0 (none), 1 (SiLU), 5 (GELU) or 6 (SwiGLU over the [x1 | x2] halves of N)");
+  DMVAE_CHECK_ARG(act != 6 || (!out_f32 && N % 16 == 0), "linear_bf16: the SwiGLU epilogue writes bf16 and needs N %% 16 == 0");
   const long long wb = w_layout == 1 ? (long long)N * K * 2 : (long long)N * ldw * 2;
   DMVAE_CHECK_ARG((long long)M * lda * 2 < (1ll << 31) && wb < (1ll << 31) && (long long)M * ldy * (out_f32 ? 4 : 2) < (1ll << 31),
                   "linear_bf16: operands are addressed through 32-bit buffer offsets (2 GiB each)");
   Args a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.y = y;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldy = ldy;
-  a.act = act; a.bias_bf16 = bias_bf16; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = g_gemm_dbg;
+  a.act = act; a.bias_bf16 = bias_bf16; a.H = N / 2; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = g_gemm_dbg;
   a.wbytes = (unsigned)wb;
   a.wsRow = w_layout == 1 ? 64u : (unsigned)ldw * 2u;
   a.wsK = w_layout == 1 ? (unsigned)N * 64u : 64u;
-  const int cfg = plan(M, N, K);
+  const int cfg = plan(M, N, K, act == 6);
   return out_f32 ? dispatch<true>(cfg, a, stream) : dispatch<false>(cfg, a, stream);
 }

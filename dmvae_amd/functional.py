@@ -585,7 +585,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, a
     x = _c(x)
     if x.dtype != bf16:
         x = x.to(bf16)
-    if ops.linear_supported(m, n, k):
+    if ops.linear_supported(m, n, k) and (act != ops.ACT_SWIGLU or n % 16 == 0):
         # frozen weights -- not trainable AND not owned by one of this build's optimisers (a student DiT switched to requires_grad False for the DMD
         # loss's evaluations still changes every few steps: it keeps the row-major shadow its optimiser maintains) -- : the K-tile-major copy, packed once
         if not w.requires_grad and not hasattr(w, "_dmvae_epoch") and w.dim() == 2 and _KMAJOR_FROZEN:
@@ -603,7 +603,9 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, a
         y = ops.gelu(y)
     elif act == ops.ACT_SILU:
         y = ops.silu(y)
-    return y.reshape(*x.shape[:-1], n)
+    elif act == ops.ACT_SWIGLU:
+        y = ops.swiglu(_c(y))
+    return y.reshape(*x.shape[:-1], y.shape[-1])
 
 
 def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Tensor, need_dx: bool = True):

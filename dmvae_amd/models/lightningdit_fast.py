@@ -87,7 +87,7 @@ def forward_inference(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) 
         qkv = linear(a, blk.attn.qkv.weight, blk.attn.qkv.bias)
         o = linear(_attention(qkv, blk, model.feat_rope, heads), blk.attn.proj.weight, blk.attn.proj.bias)
         a = ops.gated_residual_rmsnorm_modulate_(h, o, mod, 2 * c, blk.norm2.weight, mod, 3 * c, 4 * c, blk.norm2.eps)
-        g = ops.swiglu(linear(a, blk.mlp.w12.weight, blk.mlp.w12.bias))
+        g = linear(a, blk.mlp.w12.weight, blk.mlp.w12.bias, ops.ACT_SWIGLU)        # silu(x1) * x2 in the GEMM's epilogue: x12 never reaches HBM
         pend = (linear(g, blk.mlp.w3.weight, blk.mlp.w3.bias), mod)
     mod = adaln(fl.adaLN_modulation[1])                                           # [B, 2C]: shift | scale
     if pend is None:

@@ -21,6 +21,7 @@ bf16 = torch.bfloat16
 f32 = torch.float32
 
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_RELU_GATE, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3, 4, 5
+ACT_SWIGLU = 6     # linear_bf16 only: N = 2 H columns [x1 | x2] -> H columns silu(x1) * x2 (swiglu_ffn.py:32-35)
 
 
 def _stream() -> int:
@@ -354,7 +355,7 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     a [K_in, N_out]-transposed copy makes the same call the input gradient) or its K-tile-major copy [K / 32, N, 32] (`pack_conv_weight(..., kmajor=True)`
     leaves it as `._dmvae_kmajor`; whole 128-B lines per K tile -- what frozen weights are served as); bias [N] bf16 (autocast's operand) or f32; f32
     accumulation, bf16 result [..., N] (f32 with out_f32).  act = ACT_GELU / ACT_SILU fuses the activation on the bf16-rounded pre-activation (bit-identical
-    to the two-kernel route)."""
+    to the two-kernel route); act = ACT_SWIGLU writes [..., N / 2]: silu(x1) * x2 of the [x1 | x2] halves of the bf16-rounded columns, the bits of `swiglu(linear(.))`."""
     x = _req(x, bf16, "x")
     w = _req(w, bf16, "w")
     k = x.shape[-1]
@@ -372,12 +373,13 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
             bias_bf16 = 1
         _req(bias, bf16 if bias_bf16 else f32, "bias")
         assert bias.numel() == n
-    y = torch.empty(*x.shape[:-1], n, dtype=f32 if out_f32 else bf16, device=x.device)
+    ny = n // 2 if act == ACT_SWIGLU else n
+    y = torch.empty(*x.shape[:-1], ny, dtype=f32 if out_f32 else bf16, device=x.device)
     timing = KERNEL_TIMING
     if timing is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_lib.lib().dmvae_linear_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), m, n, k, k, k, n, act, bias_bf16, int(out_f32), int(kmajor),
+    check(_lib.lib().dmvae_linear_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), m, n, k, k, k, ny, act, bias_bf16, int(out_f32), int(kmajor),
                                        _stream()), "linear_bf16")
     if timing is not None:
         e1 = torch.cuda.Event(enable_timing=True)

@@ -103,6 +103,44 @@ def test_fused_activation_is_the_two_kernel_route(shape):
     assert bool((d <= bound).all()), f"fused GELU vs fp64: {(d > bound).sum().item()} elements outside half a bf16 ulp + 1e-6, worst {((d - bound).max().item()):.3e}"
 
 
+@pytest.mark.parametrize("shape", [(4096, 6144, 1152), (16384, 6144, 1152), (1000, 6144, 1152), (200, 80, 416), (300, 528, 384)],
+                         ids=["dit16_w12", "dit64_w12", "ragged_rows", "ragged_small", "half_tile_columns"])
+@pytest.mark.parametrize("bias", ["bf16", "f32", "none"])
+def test_fused_swiglu_is_the_two_kernel_route(shape, bias):
+    """act = ACT_SWIGLU (swiglu_ffn.py:32-35: x1, x2 = w12(x).chunk(2); silu(x1) * x2): the epilogue pairs column h with column H + h of the bf16-rounded
+    Linear output -- bit-identical to `swiglu(linear(.))`, row-major and K-tile-major weights, and against fp64 within one bf16 rounding of silu and one of the product."""
+    from dmvae_amd import ops
+    m, n, k = shape
+    x, w, b = _operands(m, n, k, seed=7)
+    bb = None if bias == "none" else (b.to(BF) if bias == "bf16" else b)
+    h = ops.linear_bf16(x, w, bb)
+    want = ops.swiglu(h)
+    got = ops.linear_bf16(x, w, bb, act=ops.ACT_SWIGLU)
+    assert got.shape == (m, n // 2)
+    assert torch.equal(got, want), f"fused SwiGLU differs from Linear -> swiglu kernel in {(got != want).sum().item()} elements"
+    wk = ops.pack_conv_weight(w.float(), kmajor=True)._dmvae_kmajor.view(k // 32, n, 32)
+    assert torch.equal(ops.linear_bf16(x, wk, bb, act=ops.ACT_SWIGLU), want), "K-tile-major weights"
+    x1, x2 = h.double().chunk(2, dim=-1)
+    ref = torch.nn.functional.silu(x1) * x2
+    d = (got.double() - ref).abs()
+    bound = 2.0 ** -7 * ref.abs() * 1.01 + 1e-6
+    assert bool((d <= bound).all()), f"fused SwiGLU vs fp64: {(d > bound).sum().item()} elements outside two bf16 roundings"
+
+
+def test_fused_swiglu_writes_nothing_past_its_rows_and_columns():
+    from dmvae_amd import _lib, ops
+    m, n, k = 200, 80, 416
+    x, w, b = _operands(m, n, k, seed=8)
+    want = ops.swiglu(ops.linear_bf16(x, w, b.to(BF)))
+    ldy = 56                                      # H = 40 columns of a 56-wide row: the pad columns and the rows after M keep their sentinel
+    buf = torch.full((m + 64, ldy), -7.0, device=DEV, dtype=BF)
+    bbf = b.to(BF)
+    ops.check(_lib.lib().dmvae_linear_bf16(x.data_ptr(), w.data_ptr(), bbf.data_ptr(), buf.data_ptr(), m, n, k, k, k, ldy, ops.ACT_SWIGLU, 1, 0, 0, ops._stream()), "linear_bf16")
+    torch.cuda.synchronize()
+    assert torch.equal(buf[:m, : n // 2], want)
+    assert bool((buf[:m, n // 2:] == -7.0).all()) and bool((buf[m:] == -7.0).all())
+
+
 @pytest.mark.parametrize("shape", [(8224, 1024, 4096), (4096, 1152, 1152), (200, 72, 416)], ids=["fc2", "dit_proj", "ragged"])
 def test_kmajor_weight_layout_is_bit_identical(shape):
     """w_layout = 1: the K-tile-major copy [K / 32][N][32] written by the pack kernel gives the same bits as the row-major operand (same values, same K order);
@@ -164,11 +202,13 @@ sys.path.insert(0, %r)
 from dmvae_amd import ops
 g = torch.Generator(device="cuda").manual_seed(3)
 out = {}
-for m, n, k in [(8224, 1024, 1024), (4096, 1152, 1152), (777, 520, 384)]:
+for m, n, k in [(8224, 1024, 1024), (4096, 1152, 1152), (777, 520, 384), (777, 544, 384)]:
     x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
     w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16)
     b = torch.randn(n, device="cuda", generator=g)
     out[(m, n, k)] = ops.linear_bf16(x, w, b, out_f32=True).cpu()
+    if n %% 16 == 0:
+        out[("swiglu", m, n, k)] = ops.linear_bf16(x, w, b.to(torch.bfloat16), act=ops.ACT_SWIGLU).cpu()
 torch.save(out, sys.argv[1])
 """
 
