@@ -85,6 +85,8 @@ def install_stubs():
         kwargs = dict(patch_size=patch_size, img_size=img_size, init_values=1e-5, block_chunks=0)
         if arch == "vit_tiny":  # reduced stand-in for small fixtures
             return TimmLike(dinov2.DinoVisionTransformer(embed_dim=64, depth=2, num_heads=4, mlp_ratio=4, **kwargs))
+        if arch == "vit_w256":  # reduced stand-in inside the bf16 encoder kernels' range (heads of 64 channels): capture_golden_step.py --width 256
+            return TimmLike(dinov2.DinoVisionTransformer(embed_dim=256, depth=2, num_heads=4, mlp_ratio=4, **kwargs))
         return TimmLike(getattr(dinov2, arch)(**kwargs))
 
     timm, tm, vt = (types.ModuleType(n) for n in ("timm", "timm.models", "timm.models.vision_transformer"))

@@ -3,7 +3,10 @@ loss trajectory + parameter / EMA checksums + the complete update of a few small
 (dmvae_amd.train.TokenizerTrainer and the oracle's restatement of the loop) end to end: model forward, loss assembly,
 backward, clip_grad_norm_, AdamW, LambdaLR warm-up, update_ema -- in the order of train_tokenizer.py:403-437.
 
-Run:  TORCHDYNAMO_DISABLE=1 python oracle/capture_golden_step.py            (CPU, ~2 minutes)
+Run:  TORCHDYNAMO_DISABLE=1 python oracle/capture_golden_step.py            (CPU, ~2 minutes)            -> tests/golden/step_small.npz
+      TORCHDYNAMO_DISABLE=1 python oracle/capture_golden_step.py --width 256                             -> tests/golden/step_small_w256.npz
+      (the reduced ViT stand-in at embed 256 = 4 heads x 64: the width from which the build's bf16 encoder KERNELS run, so that the bf16 step test
+      takes the whole step -- encoder included -- through the HIP path; the width-64 capture needs stock modules for its encoder there)
 
 What runs is the reference: models/vae.py::VAE (frozen encoder = the reduced ViT stand-in of capture_golden.py, bottleneck MLP, the
 full-width flux decoder), utils/lpips.py::LPIPS, train_tokenizer.py::VAELossFunction.forward_generator (called unbound, as in
@@ -42,15 +45,19 @@ def stats(t, t0):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=64, choices=(64, 256))
+    width = ap.parse_args().width
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     install_stubs()
-    os.environ["DMVAE_GOLDEN_VIT"] = "vit_tiny"
+    os.environ["DMVAE_GOLDEN_VIT"] = "vit_tiny" if width == 64 else "vit_w256"
     vae_mod = sys.modules["models.vae"]
 
     class TinyDINO(vae_mod.DINOEncoder):
         def __init__(self, model_size="base", patch_size=16, image_size=256):
             super().__init__(model_size, patch_size, image_size)
-            self.dim = 64
+            self.dim = width
 
     saved = vae_mod.DINOEncoder
     vae_mod.DINOEncoder = TinyDINO
@@ -89,7 +96,7 @@ def main():
     names = [n_ for n_, p_ in vae.named_parameters() if p_.requires_grad]
     p0 = {n_: p_.detach().clone() for n_, p_ in vae.named_parameters() if p_.requires_grad}
     out = {"images_seed": np.array(SEED_IMG), "vae_seed": np.array(SEED_VAE), "vgg_seed": np.array(SEED_VGG), "warmup_steps": np.array(WARMUP),
-           "batch": np.array(BATCH), "base_lr": np.array(BASE_LR), "names": np.array(names)}
+           "batch": np.array(BATCH), "base_lr": np.array(BASE_LR), "names": np.array(names), "width": np.array(width)}
     for k, v in lp.state_dict().items():
         if k.startswith("lin"):
             out["lp." + k] = v.numpy()
@@ -124,7 +131,7 @@ def main():
     out["encoder_moved"] = np.array(max(float((a - b).abs().max()) for a, b in zip(vae.encoder.parameters(), ema.encoder.parameters())))
     for k, v in logs.items():
         out[k] = np.array(v, dtype=np.float64)
-    save("step_small", **out)
+    save("step_small" if width == 64 else "step_small_w%d" % width, **out)
 
 
 if __name__ == "__main__":

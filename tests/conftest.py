@@ -57,3 +57,11 @@ def golden():
 def rel_err(a, b):
     a, b = a.double(), b.double()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def elem_err(a, b):
+    """Element-wise form of rel_err: max over the elements of |a - b| / (|b| + rms(b)) -- every element is held to the tolerance at ITS OWN magnitude
+    (floored by the tensor's RMS, so that elements near zero are not asked for more digits than f32 accumulation has), not at the tensor's largest one."""
+    a, b = a.double(), b.double()
+    rms = b.pow(2).mean().sqrt().clamp_min(1e-30)
+    return ((a - b).abs() / (b.abs() + rms)).max().item()

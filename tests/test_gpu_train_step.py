@@ -232,21 +232,20 @@ def test_dmd_stage_step_harness():
     assert torch.equal(Fn._bf(w), w.detach().to(torch.bfloat16))
 
 
-def test_step_small_vs_reference_capture(allow_stock):
-    """(allow_stock: the capture's reduced ViT -- width 64, 4 heads -- is outside the bf16 encoder kernels' range; the fp32 parity mode runs the same
-    fixture with the encoder on the MFMA GEMM route at 1e-4, tests/test_gpu_parity_fp32.py, and tests/test_gpu_vit_pin.py pins the bf16 encoder routes.)
-    G12: four steps of TokenizerTrainer on the HIP path against four steps of the REFERENCE's own modules and optimiser
-    (tests/golden/step_small.npz, captured by oracle/capture_golden_step.py in fp32 on the CPU; tests/test_oracle_step.py holds the oracle to the
-    same fixture at f32 tolerances).  Same name-seeded weights, same two images, same lr schedule.  The HIP path computes in bf16 where the
-    reference's CUDA autocast would, the capture is fp32, so the bars are the bf16 floor of a 60-layer forward + backward: losses 2 %, gradient
-    norm 5 %; the optimiser tail is then checked through what it did to the weights -- per-tensor sum|update| (lr x Adam direction + decay) for
-    all 140 trainable tensors, and the direction of the complete update of eight small tensors."""
+def test_step_small_vs_reference_capture():
+    """G12: four steps of TokenizerTrainer ENTIRELY on the HIP path -- the encoder too: the capture's reduced ViT is 256 wide (4 heads of
+    64 channels, oracle/capture_golden_step.py --width 256), inside the bf16 encoder kernels' range, and no stock-module route is allowed -- against four
+    steps of the REFERENCE's own modules and optimiser (tests/golden/step_small_w256.npz, captured in fp32 on the CPU; tests/test_oracle_step.py holds the
+    oracle to the same fixture at f32 tolerances, tests/test_gpu_parity_fp32.py the fp32 parity mode at 1e-4).  Same name-seeded weights, same two images,
+    same lr schedule.  The HIP path computes in bf16 where the reference's CUDA autocast would, the capture is fp32, so the bars are the bf16 floor of a
+    60-layer forward + backward: losses 2 %, gradient norm 5 %; the optimiser tail is then checked through what it did to the weights -- per-tensor
+    sum|update| (lr x Adam direction + decay) for all 140 trainable tensors, and the direction of the complete update of eight small tensors."""
     from conftest import load_golden
     from test_oracle_golden import lpips_params
     from test_oracle_step import check_step_small, step_small_inputs
     from dmvae_amd.train import TokenizerTrainer
     from dmvae_amd.utils.lpips import LPIPS
-    g = load_golden("step_small")
+    g = load_golden("step_small_w256")
     p, vae, names, images = step_small_inputs(g)
     vae.load_state_dict(p, strict=True)
     vae = vae.cuda()

@@ -122,13 +122,13 @@ def test_mlp():
         assert rel_err(v, g.t("g." + k[len("bottle_neck."):])) < TOL
 
 
-def vae_tiny_params(seed=33):
+def vae_tiny_params(seed=33, width=64):
     """Parameters of the tiny-ViT VAE fixture, regenerated from the capture's names (reference adapter inserts 'vit.')."""
     from dmvae_amd.models.vae import VAE
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=64, depth=2, num_heads=4))
+        vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=width, depth=2, num_heads=4))
     p = {}
     params = dict(vae.named_parameters())
     for k, v in vae.state_dict().items():

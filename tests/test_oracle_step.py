@@ -4,6 +4,7 @@ oracle/capture_golden_step.py -- loss trajectory, gradient norms, learning rates
 update of eight small tensors after every step.  CPU, fp32 both sides: tolerances are f32 summation order.  Three of the four captured steps
 are replayed here (each costs ~30 s on 8 cores); tests/test_gpu_train_step.py replays all four on the HIP path."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden, rel_err
@@ -16,7 +17,7 @@ SMALL = ("decoder.conv_out.weight", "decoder.conv_out.bias", "decoder.norm_out.w
 
 def step_small_inputs(g):
     """Weights (name-seeded fill), trainable names in the reference's order, and the batch of the capture."""
-    p, vae = vae_tiny_params(seed=int(g["vae_seed"]))
+    p, vae = vae_tiny_params(seed=int(g["vae_seed"]), width=int(g["width"]) if "width" in g else 64)
     names = [str(n) for n in g["names"]]
     assert names == [n for n, _ in vae.named_parameters() if not n.startswith("encoder.")]       # same trainable set, same order as the reference
     images = torch.rand(int(g["batch"]), 3, 256, 256, generator=torch.Generator().manual_seed(int(g["images_seed"]))) * 2 - 1
@@ -50,8 +51,10 @@ def check_step_small(g, logs, p0, p1, ema, names, last, tol_loss, tol_norm, tol_
         assert (de - eref).abs().max() < 3e-7 + tol_ema * eref.abs().max(), k       # within an ulp or two of O(0.1 .. 1.6) weights
 
 
-def test_step_small_trajectory_matches_reference_capture():
-    g = load_golden("step_small")
+@pytest.mark.parametrize("fixture", ["step_small", "step_small_w256"])
+def test_step_small_trajectory_matches_reference_capture(fixture):
+    """Both captures of oracle/capture_golden_step.py: the ViT stand-in at embed 64 and at embed 256 (--width 256: the width the bf16 step test needs)."""
+    g = load_golden(fixture)
     p, _, names, images = step_small_inputs(g)
     lp = lpips_params(g, "lp.")
     p0 = {k: p[k].clone() for k in names}
