@@ -324,21 +324,24 @@ def main():
     # and committed under profiles/; null when the committed profile is for a different kernel
     traffic, traffic_src = None, None
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_conv_pp_traffic.json")) as f:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_conv_pp_traffic.json")) as f:
             tp = json.load(f)
         static_twin = "conv_pp_kernel<256, 256, 2, 4, 4, false, false, true, false, false, false, false, %s>" % ("true" if ops._PP_HALO else "false")
         if tp.get("kernel") == static_twin and args.batch == LOCAL_BATCH:      # the DYN twin runs the same kernel body
             traffic = int(tp["hbm_MB_per_launch"] * 1e6)
-            traffic_src = "profiles/r2_conv_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, %d launches; FETCH_SIZE x2 per MI355X_MICROARCH.md)" % tp["launches_profiled"]
+            traffic_src = "profiles/r3_conv_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, %d launches; FETCH_SIZE x2 per MI355X_MICROARCH.md)" % tp["launches_profiled"]
     except (OSError, ValueError, KeyError):
         pass
     wg_traffic = None
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_wgrad_pp_traffic.json")) as f:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_wgrad_pp_traffic.json")) as f:
             wt = json.load(f)
         if args.batch == LOCAL_BATCH:
+            # both instantiations that carry the weight-gradient time: the 256 x 256 tile (plain 3x3 / 1x1 form) and the 128 x 384 halo tile of the >= 2^19-pixel shapes
             wg_traffic = {"bytes_per_launch": int(wt["hbm_MB_per_launch"] * 1e6), "kernel": wt["kernel"], "launches_profiled": wt["launches_profiled"],
-                          "source": "profiles/r2_wgrad_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command; the 256 x 256 tile's main kernel, 28 of the step's weight-gradient launches)"}
+                          "per_kernel": [{"kernel": k["kernel"], "bytes_per_launch": int(k["hbm_MB_per_launch"] * 1e6), "read_MB": k["hbm_read_MB_per_launch"],
+                                          "write_MB": k["hbm_write_MB_per_launch"], "launches_profiled": k["launches_profiled"]} for k in wt.get("kernels", [])],
+                          "source": "profiles/r3_wgrad_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, tools/pmc_traffic_r3.sh; FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
     except (OSError, ValueError, KeyError):
         pass
     out = {
