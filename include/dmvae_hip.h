@@ -169,7 +169,9 @@ int dmvae_set_dynamic(int on);
  * K tile of the weights is then one contiguous run of whole 128-B lines instead of N half lines a row apart, which is what the operand costs when it comes
  * from HBM rather than from the Infinity Cache (fc2 of ViT-L with cold operands: 84 -> 74 us; tools/bench_gemm.py --cold).  bias: f32 [N], or bf16 [N] when bias_bf16 (what autocast hands the library), or NULL.
  * act: 0 none, 1 SiLU, 5 exact (erf) GELU -- applied to the bf16-ROUNDED pre-activation, so the result is bit-identical to this call with act = 0
- * followed by dmvae_gelu_fwd / dmvae_silu_fwd.  K >= 384 (the kernel streams a tile's last K steps together with the next tile's first ones, up to five
+ * followed by dmvae_gelu_fwd / dmvae_silu_fwd.  act 6 = SwiGLU (swiglu_ffn.py:32-35: x1, x2 = w12(x).chunk(2, -1); silu(x1) * x2): N = 2 H weight rows [x1 | x2]
+ * (N % 16 == 0, bf16 result only), y is [M][ldy >= H] and receives silu(x1) * x2 of the bf16-rounded halves -- bit-identical to act = 0 followed by
+ * dmvae_swiglu_bf16, without x12 ever reaching HBM (the no-grad LightningDiT forward; the training route keeps x12 for its backward).  K >= 384 (the kernel streams a tile's last K steps together with the next tile's first ones, up to five
  * each); shorter reductions go to dmvae_gemm_nt_batched.
  * Tile shape per (M, N, K) from a fixed menu by rounds x tile cost (dmvae_linear_bf16_plan returns the menu index and the tile's columns / rows);
  * results do not depend on the tile (one f32 accumulation chain per output element: bias first, then K order).  csrc/gemm_pp.hip. */
