@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DMVAE_LIB") or os.path.join(_HERE, "libdmvae_hip.so")      # DMVAE_LIB: another build of the same ABI (kernel A/B runs on one box)
@@ -18,6 +18,13 @@ class ConvDesc(Structure):
     _fields_ = [("n", c_int32), ("h", c_int32), ("w", c_int32), ("cin", c_int32), ("cout", c_int32),
                 ("ks", c_int32), ("upsample", c_int32), ("act", c_int32), ("out_f32", c_int32), ("stride", c_int32), ("transposed", c_int32),
                 ("w_layout", c_int32)]
+
+
+class PackEntry(Structure):
+    """struct dmvae_pack_entry (include/dmvae_hip.h)."""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("dst2", c_void_p),
+                ("cout", c_int32), ("cin", c_int32), ("T", c_int32), ("rows_pad", c_int32), ("cols_pad", c_int32), ("mode", c_int32), ("subpixel", c_int32),
+                ("reserved", c_int32), ("start", c_ulonglong), ("count", c_ulonglong)]
 
 
 ABI_VERSION = 2     # include/dmvae_hip.h: dmvae_abi_version
@@ -37,6 +44,8 @@ SIGNATURES = {
     "dmvae_linear_bf16": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     "dmvae_linear_bf16_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "dmvae_linear_weight_t_kmajor": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dmvae_pack_entry_bytes": (c_size_t, []),
+    "dmvae_pack_weights_batched": (c_int, [c_void_p, c_int, c_ulonglong, c_int, c_void_p]),
     "dmvae_softmax_rows_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dmvae_softmax_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dmvae_transpose_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

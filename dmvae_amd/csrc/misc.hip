@@ -1,5 +1,8 @@
 // Layout, packing and small elementwise kernels around the conv/GEMM hot path (all HBM-bound).
 #include "common.h"
+#ifndef DMVAE_PACK_TILED   // 1: single-weight pack calls on the tiled kernel too (measured slower there: a 512 x 512 weight is 256 blocks, one per CU, each a serial load -> store;
+#define DMVAE_PACK_TILED 0  // the element-wise kernel spreads the same weight over 9 x as many blocks) -- the tiled kernel is for the one-launch table
+#endif
 #include "dmvae_hip.h"
 
 namespace dmvae_misc {
@@ -25,6 +28,110 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, bf16* __restri
     dst[i] = (bf16)v;
     if (dst2) dst2[(((size_t)(col >> 5) * T + t) * rows_pad + row) * 32 + (col & 31)] = (bf16)v;
   }
+}
+
+// Tiled weight pack.  One block moves a 32 x 32 tile of (cout, cin) pairs with all their taps: the f32 source tile is read as 32 contiguous runs (coalesced),
+// kept in LDS, and written out as 64-B runs of the bf16 operand (and 2-KiB runs of its K-tile-major copy) in either orientation.  The element-wise kernel above
+// reads with a stride of T floats and scatters its second copy: 0.6 TB/s; one launch of it per weight and direction is 84 launches of 6-15 us per tokenizer step.
+// A table of entries (device memory) makes it ONE launch for all of a model's stale operands after an optimiser step; entry e is one
+// dmvae_pack_conv_weight_v2 call -- optionally on the sub-pixel weight WD of subpixel_weight_kernel, computed on the fly with the same summation order --
+// and owns tiles [start, start + count).  Bit-identical to the element-wise kernel (same f32 source values, same rounding).
+struct PackEntry {
+  const float* src; bf16* dst; bf16* dst2;
+  int cout, cin, T, rows_pad, cols_pad, mode, subpixel, pad0;      // cout / cin / T: of the tensor being packed (WD [cin_w][cout_w][16] for subpixel)
+  unsigned long long start, count;                                 // tiles: count = ceil(rows_pad / 32) * ceil(cols_pad / 32)
+};
+constexpr int PACK_TMAX = 16;
+__global__ __launch_bounds__(256) void pack_tiled_kernel(const PackEntry* __restrict__ tab, int n, PackEntry single) {
+  extern __shared__ float S[];      // 32 rows x (32 Tm + 1) floats, Tm <= 16 (sized by the host for the largest entry)
+  PackEntry e = single;
+  unsigned long long tix = blockIdx.x;
+  if (n > 0) {   // the entry that owns this block's tile: the last one whose start is <= blockIdx.x
+    int l = 0, r = n - 1;
+    while (l < r) { const int m = (l + r + 1) >> 1; if (tab[m].start <= tix) l = m; else r = m - 1; }
+    e = tab[l];
+    tix -= e.start;
+  }
+  const int T = e.T;
+  // (a, b) index the tensor being packed, [a][b][T]; the memory tensor is M[X][Y][Tm]: the same for a plain weight, W[b][a][9] for the sub-pixel form
+  const int a_ext = e.mode == 0 ? e.rows_pad : e.cols_pad, b_ext = e.mode == 0 ? e.cols_pad : e.rows_pad;
+  const int X = e.subpixel ? e.cin : e.cout, Y = e.subpixel ? e.cout : e.cin, Tm = e.subpixel ? 9 : T;
+  const int y_ext = e.subpixel ? a_ext : b_ext;
+  const int tyn = (y_ext + 31) >> 5;
+  const int x0 = (int)(tix / tyn) * 32, y0 = (int)(tix % tyn) * 32;
+  const int a0 = e.subpixel ? y0 : x0, b0 = e.subpixel ? x0 : y0;
+  const int RS = 32 * Tm + 1;     // odd row stride: lanes running over the slow LDS index hit different banks
+  const int run = 32 * Tm;        // floats of one source row inside the tile: contiguous in memory
+  const float* __restrict__ src = e.src;
+  // load: four loads in flight per thread before the first LDS store
+  for (int j0 = threadIdx.x; j0 < 32 * run; j0 += 1024) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = j0 + u * 256;
+      const int xl = j / run, rem = j - xl * run;
+      const int yl = rem / Tm;
+      v[u] = (j < 32 * run && x0 + xl < X && y0 + yl < Y) ? src[((size_t)(x0 + xl) * Y + y0) * Tm + rem] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = j0 + u * 256;
+      const int xl = j / run, rem = j - xl * run;
+      if (j < 32 * run) S[xl * RS + rem] = v[u];
+    }
+  }
+  __syncthreads();
+  auto fetch = [&](int al, int bl, int t) -> float {
+    if (!e.subpixel) return S[al * RS + bl * Tm + t];
+    // WD[ci = a][co = b][r][s] = sum over the taps of W[co][ci] that land on source pixel (r, s): subpixel_weight_kernel's order
+    const int sx = t & 3, r = t >> 2;
+    const float* w = S + bl * RS + al * 9;
+    float v = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++)
+        if (r + ky >= 2 && r + ky <= 3 && sx + kx >= 2 && sx + kx <= 3) v += w[ky * 3 + kx];
+    return v;
+  };
+  // store: 16 lanes x 2 adjacent columns per (row, tap): 4-byte stores, 64 B per row of the operand and of its K-tile-major copy
+  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const bool pairs = (e.cols_pad & 1) == 0;
+  for (int pr = grp; pr < 32 * T; pr += 16) {
+    const int rl = pr / T, to = pr - rl * T;            // local row of the operand, output tap
+    const int t = e.mode == 0 ? to : T - 1 - to;        // source tap
+    float v2[2];
+    int row = 0, col0 = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int cl = 2 * l16 + h;
+      const int al = e.mode == 0 ? rl : cl, bl = e.mode == 0 ? cl : rl;
+      const int a = a0 + al, b = b0 + bl;
+      row = e.mode == 0 ? a : b;
+      if (h == 0) col0 = e.mode == 0 ? b : a;
+      v2[h] = (a < e.cout && b < e.cin) ? fetch(al, bl, t) : 0.f;
+    }
+    if (row >= e.rows_pad) continue;
+    const size_t o = ((size_t)row * T + to) * e.cols_pad + col0;
+    const size_t o2 = (((size_t)(col0 >> 5) * T + to) * e.rows_pad + row) * 32 + (col0 & 31);
+    if (pairs && col0 + 1 < e.cols_pad) {
+      const unsigned pk = dmvae_pack_bf16x2(v2[0], v2[1]);
+      *reinterpret_cast<unsigned*>(e.dst + o) = pk;
+      if (e.dst2) *reinterpret_cast<unsigned*>(e.dst2 + o2) = pk;
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+        if (col0 + h < e.cols_pad) {
+          e.dst[o + h] = (bf16)v2[h];
+          if (e.dst2) e.dst2[(((size_t)((col0 + h) >> 5) * T + to) * e.rows_pad + row) * 32 + ((col0 + h) & 31)] = (bf16)v2[h];
+        }
+    }
+  }
+}
+static inline size_t pack_lds_bytes(int Tm) { return (size_t)32 * (32 * Tm + 1) * sizeof(float); }
+static inline void pack_attr() {   // 16 taps need 65.7 KB of dynamic LDS: above the 64-KB default
+  static bool done = false;
+  if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pack_lds_bytes(PACK_TMAX)); done = true; }
 }
 
 // ---- sub-pixel form of Upsample's conv (flux_ae.py:103-107: conv3x3(nearest-x2(x))) -----------------------------------
@@ -380,8 +487,28 @@ extern "C" int dmvae_pack_conv_weight_v2(const void* w, void* out, void* out_kma
   DMVAE_CHECK_ARG(rows_pad >= (for_dgrad ? cin : cout) && cols_pad >= (for_dgrad ? cout : cin), "pack_conv_weight: padding smaller than shape");
   const int T = ks * ks;
   const size_t total = (size_t)rows_pad * T * cols_pad;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)w, (bf16*)out, (bf16*)out_kmajor, cout, cin, T, rows_pad,
-                     cols_pad, for_dgrad ? 1 : 0);
+  if (T <= PACK_TMAX && DMVAE_PACK_TILED) {
+    PackEntry e = {};
+    e.src = (const float*)w; e.dst = (bf16*)out; e.dst2 = (bf16*)out_kmajor;
+    e.cout = cout; e.cin = cin; e.T = T; e.rows_pad = rows_pad; e.cols_pad = cols_pad; e.mode = for_dgrad ? 1 : 0; e.subpixel = 0;
+    e.start = 0; e.count = (unsigned long long)((rows_pad + 31) / 32) * ((cols_pad + 31) / 32);
+    pack_attr();
+    hipLaunchKernelGGL(pack_tiled_kernel, dim3((unsigned)e.count), dim3(256), pack_lds_bytes(T), stream, (const PackEntry*)nullptr, 0, e);
+  } else {
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)w, (bf16*)out, (bf16*)out_kmajor, cout, cin, T, rows_pad,
+                       cols_pad, for_dgrad ? 1 : 0);
+  }
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t dmvae_pack_entry_bytes(void) { return sizeof(PackEntry); }
+extern "C" int dmvae_pack_weights_batched(const void* table, int n_entries, unsigned long long total_tiles, int max_taps, hipStream_t stream) {
+  DMVAE_CHECK_ARG(table && n_entries > 0 && total_tiles > 0 && total_tiles < (1ull << 31), "pack_weights_batched: empty or oversized table");
+  DMVAE_CHECK_ARG(max_taps >= 1 && max_taps <= PACK_TMAX, "pack_weights_batched: max_taps (the largest ks * ks of the table; 9 for a sub-pixel entry) must be 1 .. 16");
+  PackEntry none = {};
+  pack_attr();
+  hipLaunchKernelGGL(pack_tiled_kernel, dim3((unsigned)total_tiles), dim3(256), pack_lds_bytes(max_taps), stream, (const PackEntry*)table, n_entries, none);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -61,7 +61,70 @@ def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad
     if transposed:       # [rows][taps*cols] -> [taps*cols][rows]: the B operand of the im2col convs' input-gradient GEMM
         p = p.view(p.shape[0], -1).t().contiguous()
     cache[key] = (ver, p)
+    reg = getattr(w, "_dmvae_pack_reg", None)
+    if reg is not None and _PACK_BATCHED and not frozen and not transposed and not parity.on() and w.dtype == f32 and w.is_contiguous():
+        # a weight of an optimiser-owned flat buffer: from now on its operands are rewritten in place by the ONE launch that follows the optimiser step (repack_all)
+        reg["entries"][(id(w), key)] = (w, key, p, bool(for_dgrad), bool(subpixel), w.data_ptr())
+        reg["dirty"] = True
     return p
+
+
+_PACK_BATCHED = os.environ.get("DMVAE_PACK_BATCHED", "1") != "0"
+
+
+def new_pack_registry() -> dict:
+    """Per flat parameter buffer (optim.FlatParams): the packed operands `packed` has produced for its weights, so that they can all be refreshed by one launch."""
+    return {"entries": {}, "dirty": True, "table": None, "n": 0, "total": 0}
+
+
+def repack_all(reg: dict, epoch: list) -> None:
+    """Rewrite, IN PLACE and in one launch (dmvae_pack_weights_batched), every packed weight operand registered for a flat parameter buffer, and mark the
+    cache entries current.  Called by the fused optimiser step right after it has changed the weights (the per-weight route: one pack launch per weight and
+    direction on its next use -- 84 launches per tokenizer step).  Entries whose parameter moved or whose cached operand was replaced are dropped (the lazy
+    route repacks and re-registers them)."""
+    import ctypes
+    from . import _lib
+    ents = reg["entries"]
+    if not ents or not _PACK_BATCHED or parity.on():
+        return
+    live = {}
+    for k, (w, key, p, for_dgrad, subpixel, ptr) in ents.items():
+        hit = getattr(w, "_dmvae_packed", {}).get(key)
+        if hit is None or hit[1] is not p or w.data_ptr() != ptr:
+            reg["dirty"] = True
+            continue
+        live[k] = ents[k]
+    if len(live) != len(ents):
+        reg["entries"] = ents = live
+    if not ents:
+        return
+    if reg["dirty"]:
+        arr = (_lib.PackEntry * len(ents))()
+        start, taps = 0, 1
+        for i, (w, key, p, for_dgrad, subpixel, ptr) in enumerate(ents.values()):
+            if w.dim() == 2:
+                cout, cin, T = w.shape[0], w.shape[1], 1
+            else:
+                cout, cin, T = w.shape[0], w.shape[1], w.shape[2] * w.shape[2]
+            if subpixel:         # the tensor being packed is WD [cin_w][cout_w][4][4]
+                cout, cin, T = cin, cout, 16
+            rows_pad, cols_pad = p.shape[0], p.shape[2]
+            assert p.shape[1] == T and p.is_contiguous()
+            p2 = getattr(p, "_dmvae_kmajor", None)
+            e = arr[i]
+            e.src, e.dst, e.dst2 = ptr, p.data_ptr(), (p2.data_ptr() if p2 is not None else None)
+            e.cout, e.cin, e.T, e.rows_pad, e.cols_pad, e.mode, e.subpixel = cout, cin, T, rows_pad, cols_pad, int(for_dgrad), int(subpixel)
+            e.start, e.count = start, ((rows_pad + 31) // 32) * ((cols_pad + 31) // 32)      # 32 x 32 tiles of (row, column) pairs, all taps
+            start += e.count
+            taps = max(taps, 9 if subpixel else T)
+        assert ctypes.sizeof(_lib.PackEntry) == _lib.lib().dmvae_pack_entry_bytes()
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        dev = next(iter(ents.values()))[0].device
+        reg["table"], reg["n"], reg["total"], reg["taps"], reg["dirty"] = host.to(dev), len(ents), start, taps, False
+    ops.check(_lib.lib().dmvae_pack_weights_batched(reg["table"].data_ptr(), reg["n"], reg["total"], reg["taps"], ops._stream()), "pack_weights_batched")
+    ep = epoch[0]
+    for (w, key, p, for_dgrad, subpixel, ptr) in ents.values():
+        w._dmvae_packed[key] = ((ptr, _ver(w), ep), p)
 
 
 def _dst(param):

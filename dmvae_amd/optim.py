@@ -32,8 +32,10 @@ class FlatParams:
             p.grad = self.grad[off:off + p.numel()].view(p.shape)
         self.ema = self.flat.clone() if with_ema else None
         self.epoch = [0]                      # bumped whenever the flat buffer is updated through raw pointers (functional.packed / _bf caches)
+        self.pack_reg = Fn.new_pack_registry()   # the packed conv operands of these weights: refreshed by ONE launch after every optimiser step (functional.repack_all)
         for p in self.params:
             p._dmvae_epoch = self.epoch
+            p._dmvae_pack_reg = self.pack_reg
 
     def zero_grad(self):
         self.grad.zero_()
@@ -113,7 +115,8 @@ class FlatAdamWEMA:
         ops.grad_norm(self.fp.grad, self.max_norm, norm_out=self.norm)
         ops.adamw_ema_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.fp.ema, self.norm if self.max_norm > 0 else None,
                            lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, self.ema_decay, shadow=getattr(self.fp, "shadow", None))
-        self.fp.epoch[0] += 1       # weights changed through raw pointers: the cached bf16 operands of THESE parameters are stale
+        self.fp.epoch[0] += 1       # weights changed through raw pointers: the cached bf16 operands of THESE parameters are stale ...
+        Fn.repack_all(self.fp.pack_reg, self.fp.epoch)     # ... and the packed conv operands among them are rewritten here, in one launch
         return self.norm            # device tensor; no host sync
 
     # ---- checkpoint / resume (train_tokenizer.py:440-450 saves opt_vae / opt_disc / scheduler_*; train_dmd.py:577-590; train_diffusion.py:318-325) ----

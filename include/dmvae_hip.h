@@ -207,6 +207,21 @@ int dmvae_pack_conv_weight(const void* w, void* out, int cout, int cin, int ks, 
  * out_kmajor is non-NULL (cols_pad % 32 == 0 then). */
 int dmvae_pack_conv_weight_v2(const void* w, void* out, void* out_kmajor, int cout, int cin, int ks, int rows_pad, int cols_pad,
                               int for_dgrad, dmvae_stream_t stream);
+/* Every stale weight operand of a model in ONE launch: after an optimiser step (train_tokenizer.py:416-417 `optimizer_vae.step()`) the bf16 operands of all
+ * trainable conv weights have to be rewritten; one dmvae_pack_conv_weight_v2 launch per weight and direction is ~84 launches of 6-15 us per step for the
+ * tokenizer.  `table` is a DEVICE array of n_entries dmvae_pack_entry (dmvae_pack_entry_bytes() each): entry e is one dmvae_pack_conv_weight_v2 call
+ * (src, dst, dst2 = out_kmajor or NULL, cout / cin / T = ks*ks of the f32 tensor being packed, rows_pad, cols_pad, mode = for_dgrad) -- with subpixel = 1 the
+ * tensor being packed is the sub-pixel weight WD [cin_w][cout_w][4][4] of dmvae_subpixel_weight, computed on the fly from src = W [cout_w][cin_w][3][3]
+ * (cout = cin_w, cin = cout_w, T = 16) -- and owns blocks [start, start + count) of the launch, count = ceil(rows_pad / 32) * ceil(cols_pad / 32) (one block
+ * packs a 32 x 32 tile of (row, column) pairs with all taps through LDS), starts ascending and contiguous from 0; total = their sum; max_taps = the largest number of taps of the memory tensors (T, 9 for a sub-pixel entry) <= 16.  Results are
+ * bit-identical to the per-weight calls. */
+typedef struct {
+  const float* src; void* dst; void* dst2;
+  int32_t cout, cin, T, rows_pad, cols_pad, mode, subpixel, reserved;
+  uint64_t start, count;
+} dmvae_pack_entry;
+size_t dmvae_pack_entry_bytes(void);
+int dmvae_pack_weights_batched(const void* table, int n_entries, unsigned long long total, int max_taps, dmvae_stream_t stream);
 /* Sub-pixel form of Upsample's conv (models/flux_ae.py:103-107: conv3x3(F.interpolate(x, 2, 'nearest'))): output pixel (2y+py, 2x+px) only sees the 2x2
  * source pixels around (y, x), so taps that land on one source pixel are added up front --
  *   conv2d(interpolate(x,2), W, padding=1) == conv_transpose2d(x, WD, stride=2, padding=1),
