@@ -268,7 +268,18 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const bf16* __restrict__
                                                         const bf16* __restrict__ dres, const float* __restrict__ stats,
                                                         const float* __restrict__ S, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, bf16* __restrict__ dx, Geom g, float inv_count,
-                                                        float* __restrict__ colpart = nullptr) {
+                                                        float* __restrict__ colpart = nullptr, const float* __restrict__ AB = nullptr,
+                                                        float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr, int N = 0, int accumulate = 0) {
+  if (AB && blockIdx.x == 0 && blockIdx.y == 0) {
+    // the parameter gradients ride on this launch (bwd_param_kernel's arithmetic, one block of the thousands this grid has): one launch + one dispatch gap
+    // less per GroupNorm backward, 30 of them per tokenizer step
+    for (int c = threadIdx.x; c < g.C; c += 256) {
+      double a = 0.0, b = 0.0;
+      for (int n = 0; n < N; n++) { a += AB[((size_t)n * g.C + c) * 2]; b += AB[((size_t)n * g.C + c) * 2 + 1]; }
+      dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)a;
+      dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)b;
+    }
+  }
   const int tp = 1 << g.tp_shift;
   const int lane_c = threadIdx.x & (tp - 1), prow = threadIdx.x >> g.tp_shift;
   if (!COLS && lane_c * 8 >= g.C) return;
@@ -403,9 +414,16 @@ extern "C" int dmvae_groupnorm_apply(const void* x, const void* stats, const voi
 }
 
 // Reduction half of the backward: sums[n][groups][2] = (sum g, sum g*x_hat) with g = da*act'(.)*gamma, plus dgamma / dbeta.
+static int bwd_reduce_impl(const void* da, const void* x, const void* stats, const void* gamma, const void* beta, void* sums, void* dgamma, void* dbeta,
+                           void* workspace, size_t workspace_bytes, int n, int hw, int c, int groups, int act, int accumulate, bool with_param, hipStream_t stream);
 extern "C" int dmvae_groupnorm_bwd_reduce(const void* da, const void* x, const void* stats, const void* gamma, const void* beta,
                                           void* sums, void* dgamma, void* dbeta, void* workspace, size_t workspace_bytes, int n, int hw,
                                           int c, int groups, int act, int accumulate, hipStream_t stream) {
+  return bwd_reduce_impl(da, x, stats, gamma, beta, sums, dgamma, dbeta, workspace, workspace_bytes, n, hw, c, groups, act, accumulate, true, stream);
+}
+// with_param = false: the caller's apply launch computes dgamma / dbeta from AB (bwd_apply_kernel's prologue)
+static int bwd_reduce_impl(const void* da, const void* x, const void* stats, const void* gamma, const void* beta, void* sums, void* dgamma, void* dbeta,
+                           void* workspace, size_t workspace_bytes, int n, int hw, int c, int groups, int act, int accumulate, bool with_param, hipStream_t stream) {
   Geom g;
   DMVAE_CHECK_ARG(da && x && stats && gamma && beta && sums && workspace, "groupnorm_bwd_reduce: null pointer");
   DMVAE_CHECK_ARG(act >= 0 && act <= 2, "groupnorm_bwd_reduce: act must be 0, 1 or 2");
@@ -422,7 +440,7 @@ extern "C" int dmvae_groupnorm_bwd_reduce(const void* da, const void* x, const v
   const int waves = n * groups;
   hipLaunchKernelGGL(bwd_final_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, part, (const float*)gamma, AB, (float*)sums, g, n);
   DMVAE_CHECK_LAUNCH();
-  if (dgamma && dbeta) {
+  if (dgamma && dbeta && with_param) {
     hipLaunchKernelGGL(bwd_param_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, AB, (float*)dgamma, (float*)dbeta, n, c, accumulate);
     DMVAE_CHECK_LAUNCH();
   }
@@ -451,12 +469,22 @@ extern "C" int dmvae_groupnorm_bwd(const void* da, const void* x, const void* dr
                                    int n, int hw, int c, int groups, int act, int accumulate, hipStream_t stream) {
   Geom g;
   DMVAE_CHECK_ARG(da && x && stats && gamma && beta && dx && workspace, "groupnorm_bwd: null pointer");
+  DMVAE_CHECK_ARG(act >= 0 && act <= 2, "groupnorm_bwd: act must be 0, 1 or 2");
   DMVAE_CHECK_ARG(make_geom(g, n, hw, c, groups) == 0, "groupnorm_bwd: unsupported shape n=%d hw=%d c=%d groups=%d", n, hw, c, groups);
   DMVAE_CHECK_ARG(workspace_bytes >= dmvae_groupnorm_workspace(n, hw, c, groups), "groupnorm_bwd: workspace too small");
-  float* S = (float*)workspace + (size_t)n * g.nchunk * c * 2 + (size_t)n * c * 2;
-  int rc = dmvae_groupnorm_bwd_reduce(da, x, stats, gamma, beta, S, dgamma, dbeta, workspace, workspace_bytes, n, hw, c, groups, act, accumulate, stream);
+  float* AB = (float*)workspace + (size_t)n * g.nchunk * c * 2;
+  float* S = AB + (size_t)n * c * 2;
+  int rc = bwd_reduce_impl(da, x, stats, gamma, beta, S, dgamma, dbeta, workspace, workspace_bytes, n, hw, c, groups, act, accumulate, false, stream);
   if (rc) return rc;
-  return dmvae_groupnorm_bwd_apply(da, x, dres, stats, S, gamma, beta, dx, n, hw, c, groups, act, 0.f, stream);
+  const bool par = dgamma && dbeta;
+  const dim3 grid(g.nchunk, n);
+#define DMVAE_GN_BAPPLYP(A) hipLaunchKernelGGL((bwd_apply_kernel<A, false>), grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)x, (const bf16*)dres, \
+                                               (const float*)stats, (const float*)S, (const float*)gamma, (const float*)beta, (bf16*)dx, g, 0.f, (float*)nullptr, \
+                                               par ? (const float*)AB : (const float*)nullptr, (float*)dgamma, (float*)dbeta, n, accumulate)
+  if (act == 1) DMVAE_GN_BAPPLYP(1); else if (act == 2) DMVAE_GN_BAPPLYP(2); else DMVAE_GN_BAPPLYP(0);
+#undef DMVAE_GN_BAPPLYP
+  DMVAE_CHECK_LAUNCH();
+  return 0;
 }
 
 int dmvae_colsum_final(const float* part, float* out, int nparts, int C, int accumulate, hipStream_t stream);  // conv_wgrad.hip
@@ -470,13 +498,16 @@ extern "C" int dmvae_groupnorm_bwd_colsum(const void* da, const void* x, const v
   DMVAE_CHECK_ARG(act >= 0 && act <= 2, "groupnorm_bwd_colsum: act must be 0, 1 or 2");
   DMVAE_CHECK_ARG(make_geom(g, n, hw, c, groups) == 0, "groupnorm_bwd_colsum: unsupported shape n=%d hw=%d c=%d groups=%d", n, hw, c, groups);
   DMVAE_CHECK_ARG(workspace_bytes >= dmvae_groupnorm_workspace(n, hw, c, groups), "groupnorm_bwd_colsum: workspace too small");
-  float* S = (float*)workspace + (size_t)n * g.nchunk * c * 2 + (size_t)n * c * 2;
-  int rc = dmvae_groupnorm_bwd_reduce(da, x, stats, gamma, beta, S, dgamma, dbeta, workspace, workspace_bytes, n, hw, c, groups, act, accumulate, stream);
+  float* AB = (float*)workspace + (size_t)n * g.nchunk * c * 2;
+  float* S = AB + (size_t)n * c * 2;
+  int rc = bwd_reduce_impl(da, x, stats, gamma, beta, S, dgamma, dbeta, workspace, workspace_bytes, n, hw, c, groups, act, accumulate, false, stream);
   if (rc) return rc;
-  float* colpart = (float*)workspace;   // the reduce half's partials are consumed by now (stream order): their space takes the column partials
+  const bool par = dgamma && dbeta;
+  float* colpart = (float*)workspace;   // the reduce half's partials are consumed by now (stream order): their space takes the column partials (AB lies behind them)
   const dim3 grid(g.nchunk, n);
 #define DMVAE_GN_BAPPLYC(A) hipLaunchKernelGGL((bwd_apply_kernel<A, true>), grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)x, (const bf16*)dres, \
-                                               (const float*)stats, (const float*)S, (const float*)gamma, (const float*)beta, (bf16*)dx, g, 0.f, colpart)
+                                               (const float*)stats, (const float*)S, (const float*)gamma, (const float*)beta, (bf16*)dx, g, 0.f, colpart, \
+                                               par ? (const float*)AB : (const float*)nullptr, (float*)dgamma, (float*)dbeta, n, accumulate)
   if (act == 1) DMVAE_GN_BAPPLYC(1); else if (act == 2) DMVAE_GN_BAPPLYC(2); else DMVAE_GN_BAPPLYC(0);
 #undef DMVAE_GN_BAPPLYC
   DMVAE_CHECK_LAUNCH();
