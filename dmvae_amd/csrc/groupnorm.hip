@@ -273,9 +273,18 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const bf16* __restrict__
   if (AB && blockIdx.x == 0 && blockIdx.y == 0) {
     // the parameter gradients ride on this launch (bwd_param_kernel's arithmetic, one block of the thousands this grid has): one launch + one dispatch gap
     // less per GroupNorm backward, 30 of them per tokenizer step
+    // (eight samples' loads in flight at a time, added in sample order: this block's extra time is on the launch's critical path when the whole grid is resident)
     for (int c = threadIdx.x; c < g.C; c += 256) {
       double a = 0.0, b = 0.0;
-      for (int n = 0; n < N; n++) { a += AB[((size_t)n * g.C + c) * 2]; b += AB[((size_t)n * g.C + c) * 2 + 1]; }
+      int n = 0;
+      for (; n + 8 <= N; n += 8) {
+        f32x2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const f32x2*>(AB + ((size_t)(n + u) * g.C + c) * 2);
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a += v[u][0]; b += v[u][1]; }
+      }
+      for (; n < N; n++) { a += AB[((size_t)n * g.C + c) * 2]; b += AB[((size_t)n * g.C + c) * 2 + 1]; }
       dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)a;
       dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)b;
     }

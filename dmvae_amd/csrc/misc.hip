@@ -45,7 +45,7 @@ constexpr int PACK_TMAX = 16;
 __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackEntry* __restrict__ tab, int n, PackEntry single) {
   extern __shared__ float S[];      // 32 rows x (32 Tm + 1) floats, Tm <= 16 (sized by the host for the largest entry)
   PackEntry e = single;
-  unsigned long long tix = blockIdx.x;
+  unsigned long long tix = blockIdx.x;   // dispatch order (an XCD-aware order -- row-neighbour tiles on one XCD so that the two halves of a 128-B line meet in one L2 -- measured slower: 317 -> 422 us)
   if (n > 0) {   // the entry that owns this block's tile: the last one whose start is <= blockIdx.x
     int l = 0, r = n - 1;
     while (l < r) { const int m = (l + r + 1) >> 1; if (tab[m].start <= tix) l = m; else r = m - 1; }
@@ -63,18 +63,19 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackEntry* __rest
   const int RS = 32 * Tm + 1;     // odd row stride: lanes running over the slow LDS index hit different banks
   const int run = 32 * Tm;        // floats of one source row inside the tile: contiguous in memory
   const float* __restrict__ src = e.src;
-  // load: four loads in flight per thread before the first LDS store
-  for (int j0 = threadIdx.x; j0 < 32 * run; j0 += 1024) {
-    float v[4];
+  // load: twelve loads in flight per thread before the first LDS store (a 3x3 weight's tile is 36 floats per thread: three rounds)
+  constexpr int PU = 12;
+  for (int j0 = threadIdx.x; j0 < 32 * run; j0 += 256 * PU) {
+    float v[PU];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < PU; u++) {
       const int j = j0 + u * 256;
       const int xl = j / run, rem = j - xl * run;
       const int yl = rem / Tm;
       v[u] = (j < 32 * run && x0 + xl < X && y0 + yl < Y) ? src[((size_t)(x0 + xl) * Y + y0) * Tm + rem] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < PU; u++) {
       const int j = j0 + u * 256;
       const int xl = j / run, rem = j - xl * run;
       if (j < 32 * run) S[xl * RS + rem] = v[u];
