@@ -202,7 +202,7 @@ sys.path.insert(0, %r)
 from dmvae_amd import ops
 g = torch.Generator(device="cuda").manual_seed(3)
 out = {}
-for m, n, k in [(8224, 1024, 1024), (4096, 1152, 1152), (777, 520, 384), (777, 544, 384)]:
+for m, n, k in [(8224, 1024, 1024), (4096, 1152, 1152), (777, 520, 384), (777, 544, 384), (300, 264, 416)]:
     x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
     w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16)
     b = torch.randn(n, device="cuda", generator=g)
@@ -224,3 +224,12 @@ def test_every_tile_of_the_menu_gives_the_same_bits(tmp_path):
     for cfg in range(1, 10):
         for key in res[0]:
             assert torch.equal(res[0][key], res[cfg][key]), f"tile {cfg} differs from tile 0 at {key}"
+    # the other main loop (DMVAE_GEMM_LOOP=1: one hand-pipelined instruction stream per wave, one barrier per K tile) on tiles with more / as many / fewer token
+    # blocks than column blocks, and the four-wave 128 x 128 wave-tile entry that only exists with that loop: same bits (odd and even K-tile counts are both in the shapes)
+    for cfg in (0, 1, 3, 4, 10):
+        f = tmp_path / ("loop1_cfg%d.pt" % cfg)
+        env = dict(os.environ, DMVAE_GEMM_CFG=str(cfg), DMVAE_GEMM_LOOP="1")
+        subprocess.run([sys.executable, "-c", _TILE_SCRIPT % ROOT, str(f)], check=True, env=env, timeout=600)
+        got = torch.load(f)
+        for key in res[0]:
+            assert torch.equal(res[0][key], got[key]), f"pipelined loop, tile {cfg}, differs from the ping-pong loop at {key}"
