@@ -307,10 +307,13 @@ __global__ __launch_bounds__(DMVAE_ATTN_THREADS) void attention_kernel(AttnArgs 
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + key * KROW + ((((kk * 2 + kg)) ^ (key & 7)) << 4));
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st, 0, 0, 0);
       }
+      // raw scores: the scale is folded into the exponential's argument below; only a block that reaches past the last key needs the mask
+      if (kb * 32 + 32 > S) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int key_r = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        st[r] = key_r < S ? st[r] * a.scale : -INFINITY;
+        for (int r = 0; r < 16; r++) {
+          const int key_r = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+          st[r] = key_r < S ? st[r] : -INFINITY;
+        }
       }
       return st;
     };
@@ -322,6 +325,7 @@ __global__ __launch_bounds__(DMVAE_ATTN_THREADS) void attention_kernel(AttnArgs 
       for (int r = 0; r < 16; r++) m = fmaxf(m, st[r]);
     }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float ec = a.scale * 1.4426950408889634f, emc = m * ec;      // exp(scale * (s - m)) = 2^(s * ec - m * ec): one fma + v_exp_f32 per score (scale > 0)
     float sum = 0.f;
     f32x16 o[DB];
 #pragma unroll
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(DMVAE_ATTN_THREADS) void attention_kernel(AttnArgs 
     for (int kb = 0; kb < nkb; kb++) {
       f32x16 st = scores(kb);
 #pragma unroll
-      for (int r = 0; r < 16; r++) { st[r] = __expf(st[r] - m); sum += st[r]; }
+      for (int r = 0; r < 16; r++) { st[r] = __builtin_amdgcn_exp2f(fmaf(st[r], ec, -emc)); sum += st[r]; }
 #pragma unroll
       for (int half = 0; half < 2; half++) {  // 16-key step: registers r = half*8 .. half*8+7 of this block
         unsigned p0 = pack_bf16(st[half * 8 + 0], st[half * 8 + 1]);
@@ -349,24 +353,31 @@ __global__ __launch_bounds__(DMVAE_ATTN_THREADS) void attention_kernel(AttnArgs 
           union { bf16x8 v; s16x4 hlf[2]; } vf;
           vf.hlf[0] = tr_read_v(vs + ksn * (16 * VROW) + voff[db]);
           vf.hlf[1] = tr_read_v(vs + ksn * (16 * VROW) + voff[db] + 4 * VROW);
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.v, vf.v, o[db], 0, 0, 0);
+          // O^T = V^T P^T: the V fragment as the row operand (a lane's 8 keys of channel d are the same registers either way), so that the accumulators hold
+          // channels along the registers and ONE query per lane: the row's 1 / sum is the lane's own value and a lane stores 4 consecutive channels at a time
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pa.v, o[db], 0, 0, 0);
         }
       }
     }
     sum += __shfl_xor(sum, 32, 64);
-    // the output's rows are queries along the REGISTERS (C layout), the sums live per query along the LANES: fetch each row's 1 / sum from the lane that owns it
-    const float inv = 1.f / sum;
-    // ---- store [B][S][H*D]: rows q = qb*32 + (r&3) + 8*(r>>2) + 4*kg, column d = db*32 + (lane & 31) ----------------------------------
+    const float inv = 1.f / sum;      // both halves of the wave hold query (lane & 31)'s sum
+    // ---- store [B][S][H*D]: lane = query q = qb*32 + (lane & 31); registers r = 4 r4 .. 4 r4 + 3 are channels db*32 + 8 r4 + 4 kg + 0..3: 8-byte stores ----
     const int C = H * a.D;
+    if (q < S) {
+      bf16* orow = a.out + ((size_t)b * S + q) * C + h * a.D;
 #pragma unroll
-    for (int db = 0; db < DB; db++)
+      for (int db = 0; db < DB; db++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int qo = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        const int dcol = db * 32 + ql;
-        const float invr = __shfl(inv, (r & 3) + 8 * (r >> 2) + 4 * kg, 64);      // lane l < 32 holds the sum of query qb*32 + l
-        if (qo < S && dcol < a.D) a.out[((size_t)b * S + qo) * C + h * a.D + dcol] = (bf16)(o[db][r] * invr);
-      }
+        for (int r4 = 0; r4 < 4; r4++) {
+          const int d0 = db * 32 + 8 * r4 + 4 * kg;
+          if (d0 < a.D) {      // D % 8 == 0: the four channels are inside together
+            uint2 pk;
+            pk.x = pack_bf16(o[db][4 * r4 + 0] * inv, o[db][4 * r4 + 1] * inv);
+            pk.y = pack_bf16(o[db][4 * r4 + 2] * inv, o[db][4 * r4 + 3] * inv);
+            *reinterpret_cast<uint2*>(orow + d0) = pk;
+          }
+        }
+    }
   }
 #endif
 }
