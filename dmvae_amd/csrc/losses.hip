@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void lpips_diff_kernel(const bf16* __restrict_
     const size_t off = ((size_t)n * HW + p) * C + lane_c * 8;
     float a[8], b[8];
     if (active) {
-      const bf16x8 va = *reinterpret_cast<const bf16x8*>(f0 + off);
-      const bf16x8 vb = *reinterpret_cast<const bf16x8*>(f1 + off);
+      const bf16x8 va = dmvae_ldnt8(f0 + off);
+      const bf16x8 vb = dmvae_ldnt8(f1 + off);
 #pragma unroll
       for (int e = 0; e < 8; e++) { a[e] = (float)va[e]; b[e] = (float)vb[e]; }
     } else {

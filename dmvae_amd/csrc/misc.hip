@@ -208,10 +208,10 @@ __global__ void maxpool2x2_kernel(const bf16* __restrict__ x, bf16* __restrict__
     const int yo = r % H;
     const int n = r / H;
     const bf16* base = x + (((size_t)n * 2 * H + 2 * yo) * 2 * W + 2 * xo) * C + cc * 8;
-    bf16x8 m = *reinterpret_cast<const bf16x8*>(base);
+    bf16x8 m = dmvae_ldnt8(base);
 #pragma unroll
     for (int k = 1; k < 4; k++) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + ((size_t)(k >> 1) * 2 * W + (k & 1)) * C);
+      const bf16x8 v = dmvae_ldnt8(base + ((size_t)(k >> 1) * 2 * W + (k & 1)) * C);
 #pragma unroll
       for (int e = 0; e < 8; e++) m[e] = (float)v[e] > (float)m[e] ? v[e] : m[e];
     }
@@ -233,11 +233,11 @@ __global__ void maxpool2x2_relu_bwd_kernel(const bf16* __restrict__ dpool, const
     const size_t b0 = (((size_t)n * 2 * H + 2 * yo) * 2 * W + 2 * xo) * C + cc * 8;
     bf16x8 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const bf16x8*>(x + b0 + ((size_t)(k >> 1) * 2 * W + (k & 1)) * C);
+    for (int k = 0; k < 4; k++) v[k] = dmvae_ldnt8(x + b0 + ((size_t)(k >> 1) * 2 * W + (k & 1)) * C);
     bf16x8 g;
 #pragma unroll
     for (int e = 0; e < 8; e++) g[e] = (bf16)0.f;
-    if (dpool) g = *reinterpret_cast<const bf16x8*>(dpool + i * 8);
+    if (dpool) g = dmvae_ldnt8(dpool + i * 8);
     int arg[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) {
