@@ -45,6 +45,12 @@
 #ifndef DMVAE_PP_LGKM_BUILTIN   // 1: the K loop's lgkmcnt(0) through the builtin (the MFMAs then issue as one run; gemm_pp.hip does the same); 0: inline asm + 8 compiler-placed waits between them
 #define DMVAE_PP_LGKM_BUILTIN 1
 #endif
+// 1: the halo + direct-epilogue instantiations run ONE continuous K-tile stream per block (see STREAM below).  Built, bit-identical (the conv tests pass on it), and
+// measured step-neutral (66.01 / 66.19 vs 65.98 / 66.16 ms): what a tile boundary costs is the WRITE BURST -- all 256 CUs reach their epilogues together, 32 MB of
+// stores queue on HBM for ~10 k cycles, and the first counted vmcnt wait of the next tile (stores and loads share the counter) sits behind them wherever it is put.
+#ifndef DMVAE_PP_STREAM
+#define DMVAE_PP_STREAM 0
+#endif
 #ifndef DMVAE_PP_AUXA   // cache-policy bits of the HALO loop's LDS-DMA (weights / activations): 1 = sc0, 2 = nt, 16 = sc1; A/B builds only
 #define DMVAE_PP_AUXA 0
 #endif
@@ -153,6 +159,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   // round trip (the staged epilogue wrote and re-read the tile in f32: 256 + 256 KB of LDS traffic and ~12 k cycles per 256 x 256 tile; first built and
   // measured in gemm_pp.hip, whose header has the numbers).  Same sums in the same order: results are bit-identical to the staged epilogue's.
   constexpr bool DIRECT = HALO && !OUT_F32 && DMVAE_PP_DIRECT;
+  // STREAM: one continuous K-tile stream per block (gemm_pp.hip): the last three K steps of a tile issue the NEXT tile's first three K tiles, everything has landed
+  // before the stores go out, and nothing at the tile boundary waits for the stores to retire (DMVAE_PP_STREAM=0 restores the issue-around-the-epilogue form)
+  constexpr bool STREAM = DIRECT && DMVAE_PP_STREAM;
   constexpr int BM16 = BM * 2, BP16 = BP * 2;  // 16x16 MFMA blocks per wave (v_mfma_f32_16x16x32_bf16: measured 5 % less power per flop than 32x32x16,
                                                // tools/probes/probe_wavetile.hip arm D -- and the kernel is power-limited)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -197,6 +206,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   unsigned rowo[UPS ? NPB : 1][3], colo[UPS ? NPB : 1][3];
   unsigned ctrH[HALO ? NPH : 1], mskH[HALO ? NPH : 1];   // HALO: byte offset of the lane's halo pixel (ky = 0 row), bit ky set when that row is inside the image
   int it_ky = 0;                                         // HALO: the issue state is (it_ch, it_ky) + the compile-time kx
+  int iss = 0, ish = 0;                                  // STREAM: A slot / halo slot the next issued K tile goes to (continuous across tiles)
+  int ka_s = 0, sh_s = 2 * TILE_A;                       // STREAM: A slot index / halo slot offset the next K step reads
   int it = 0, it_tap = 0, it_ch = 0;  // DMA issue state (wave-uniform): tile `it` = (tap it_tap, channel chunk it_ch)
   unsigned soffB_tap = 0;
   auto setup = [&](unsigned work) {
@@ -414,13 +425,16 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     constexpr int KX = decltype(KXc)::value;
     const bool live = it < nK;
     const unsigned soA = (unsigned)(it_ky * 3 + KX) * a.wsTap + (unsigned)it_ch * a.wsChunk;
-    const int da = ((it >> 1) & 1) * GROUP + (it & 1) * TILE_A;
+    const int isl = STREAM ? iss : it;      // STREAM: the A-slot counter runs on across tiles (a tile issues exactly as many K tiles as it reads)
+    const int da = ((isl >> 1) & 1) * GROUP + (isl & 1) * TILE_A;
+    if constexpr (STREAM) iss = (iss + 1) & 3;
 #pragma unroll
     for (int p = 0; p < NPA; p++)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + ((wave * NPA + p) * 16 < TM ? da + (wave * NPA + p) * 1024 : DUMP_OFF)), 16, live ? voffA[p] : SENT, soA, 0, DMVAE_PP_AUXA);
     if constexpr (KX == 0) {
       const unsigned soH = (unsigned)(it_ky * a.Wi) * a.Cin * 2u + (unsigned)it_ch * 64u;
-      const int dh = ((it_ch + it_ky) & 1) * GROUP + 2 * TILE_A;
+      const int dh = (STREAM ? ish : ((it_ch + it_ky) & 1)) * GROUP + 2 * TILE_A;
+      if constexpr (STREAM) ish ^= 1;
 #pragma unroll
       for (int q = 0; q < NPH; q++) {
         const unsigned v = (live && ((mskH[HALO ? q : 0] >> it_ky) & 1u)) ? ctrH[HALO ? q : 0] : SENT;
@@ -462,6 +476,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   stamp(blockIdx.x, 1);
   if constexpr (HALO) {
     issue_h(K0_{}); issue_h(K1_{}); issue_h(K2_{});
+    if constexpr (STREAM) wait_vmcnt<0>();   // every tile starts with its first three K tiles landed (later ones: the previous tile's loop end)
   } else {
 #pragma unroll
     for (int u = 0; u < PF; u++) issue(u * SLOT);
@@ -495,7 +510,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     for (int j = 0; j < BP16; j++)
 #pragma unroll
       for (int r = 0; r < 4; r++) acc[i][j][r] = 0.f;
-  wait_vmcnt<HALO ? 2 * NPA : (PF - 1) * NP>();
+  if constexpr (!STREAM) wait_vmcnt<HALO ? 2 * NPA : (PF - 1) * NP>();   // STREAM: landed already, and a wait here would be a wait for the previous tile's stores
   __builtin_amdgcn_s_barrier();                // B_0: everybody's pieces of tile 0 have landed
   stamp(work, 2);
 #if DMVAE_PP_PRIO_MODE == 1
@@ -513,10 +528,14 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #ifdef DMVAE_PP_TRACE
   unsigned long long trace_w1 = 0, trace_w2 = 0, trace_load = 0, trace_comp = 0, trace_last = __builtin_amdgcn_s_memtime();
 #endif
+  unsigned next_dyn = 0;
+  unsigned next_s = 0;       // STREAM: the next tile is known (and set up) three K steps before the loop ends
+  bool has_next_s = false;
   if constexpr (HALO) {
-    int ka = 0, sh = 2 * TILE_A;   // A slot index and halo slot offset being read
-    auto ktile = [&](auto KXc) __attribute__((always_inline)) {
+    int ka = STREAM ? ka_s : 0, sh = STREAM ? sh_s : 2 * TILE_A;   // A slot index and halo slot offset being read
+    auto ktile = [&](auto KXc, auto NOWAITc) __attribute__((always_inline)) {
       constexpr int KX = decltype(KXc)::value;
+      constexpr bool NOWAIT = decltype(NOWAITc)::value;
       const char* sa = smem + ((ka >> 1) & 1) * GROUP + (ka & 1) * TILE_A;
       const char* sb = smem + sh;
 #if !(DMVAE_PP_EXP & 2)   // the timing experiments of the per-tap loop below: 1 = no DMA issue in the K loop, 2 = no fragment reads
@@ -530,7 +549,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #endif
       ka++;
       if constexpr (KX == 2) sh = sh == 2 * TILE_A ? GROUP + 2 * TILE_A : 2 * TILE_A;
-      wait_vmcnt<KX == 2 ? 2 * NPA : 2 * NPA + NPH>();  // own pieces of the NEXT tile have landed: what may stay in flight is tiles t + 2 and t + 3
+      if constexpr (!NOWAIT) wait_vmcnt<KX == 2 ? 2 * NPA : 2 * NPA + NPH>();  // own pieces of the NEXT tile have landed: what may stay in flight is tiles t + 2 and t + 3
 #if DMVAE_PP_LGKM_BUILTIN
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) through the builtin: the compiler sees the fragments have arrived and puts no lgkmcnt waits of its own between the MFMAs
       asm volatile("" ::: "memory");
@@ -551,8 +570,30 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     };
+    using W_ = std::false_type; using NW_ = std::true_type;
+    if constexpr (STREAM) {
+      // K tiles 1 and 2 landed before the tile began: the first two steps wait for nothing -- a counted wait there would count the previous tile's stores.  The
+      // third step's wait is the first one that forces them to have retired, two K steps after they were issued.
+      ktile(K0_{}, NW_{}); ktile(K1_{}, NW_{}); ktile(K2_{}, W_{});
 #pragma unroll 1
-    for (int t = 0; t < nK; t += 3) { ktile(K0_{}); ktile(K1_{}); ktile(K2_{}); }
+      for (int t = 3; t < nK - 3; t += 3) { ktile(K0_{}, W_{}); ktile(K1_{}, W_{}); ktile(K2_{}, W_{}); }
+      if constexpr (DYN) next_dyn = __hip_atomic_load(a.sched + 16 + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);  // published >= one barrier ago
+      next_s = DYN ? (unsigned)__builtin_amdgcn_readfirstlane((int)next_dyn) : work + gridDim.x;
+      has_next_s = next_s < (unsigned)a.total;
+      if (has_next_s) {
+        stamp(next_s, 0);
+        setup(next_s);          // this tile has issued all of its K tiles: the issue state moves on to the next tile
+        stamp(next_s, 1);
+      } else {
+        it = nK;                // nothing follows: the last three steps issue out-of-range pieces
+        it_ky = it_ch = 0;
+      }
+      ktile(K0_{}, W_{}); ktile(K1_{}, W_{}); ktile(K2_{}, W_{});      // ... and the next tile's K tiles 0, 1, 2
+      ka_s = ka & 3; sh_s = sh;
+    } else {
+#pragma unroll 1
+      for (int t = 0; t < nK; t += 3) { ktile(K0_{}, W_{}); ktile(K1_{}, W_{}); ktile(K2_{}, W_{}); }
+    }
   } else {
 #pragma unroll 1
   for (int t = 0; t < nK; t++) {
@@ -618,9 +659,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #endif
   stamp(work, 3);
   if (grp == 0) __builtin_amdgcn_s_barrier();  // matches group 1's extra barrier
-  unsigned next_dyn = 0;
-  if constexpr (DYN) next_dyn = __hip_atomic_load(a.sched + 16 + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);  // published >= one barrier ago
-  wait_vmcnt<0>();                             // the trailing all-zero pieces
+  if constexpr (DYN && !STREAM) next_dyn = __hip_atomic_load(a.sched + 16 + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);  // published >= one barrier ago
+  wait_vmcnt<0>();                             // the trailing all-zero pieces; STREAM: the next tile's first three K tiles -- landed before this tile's stores go out
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA (inline asm, invisible to the hazard recognizer) -> accumulator reads
 
   // ---- epilogue: accumulators -> LDS (f32, per-wave region) -> whole pixel rows, 16-B coalesced stores --------------------------
@@ -632,8 +672,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   // stores 6.4 k, drain 0.4 k; the staging uses ring slots 2.. in half-cout passes and leaves slots 0-1 to that DMA.
   __builtin_amdgcn_s_barrier();  // every wave's trailing DMA has landed and all fragment reads are done: the ring is free
   stamp(work, 6);
-  const unsigned next = DYN ? (unsigned)__builtin_amdgcn_readfirstlane((int)next_dyn) : work + gridDim.x;
-  const bool has_next = next < (unsigned)a.total;
+  const unsigned next = STREAM ? next_s : (DYN ? (unsigned)__builtin_amdgcn_readfirstlane((int)next_dyn) : work + gridDim.x);
+  const bool has_next = STREAM ? has_next_s : next < (unsigned)a.total;
   if constexpr (DIRECT) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -659,15 +699,17 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
         for (int e = 0; e < 4; e++) bsv[4 * h + e] = bf[e];
       }
     }
-    if (has_next) {
-      stamp(next, 0);
-      setup(next);
-      stamp(next, 1);
-    } else {
-      it = (nK + 3) & ~3;   // destination derived from `it`: A slot 0 / halo slot 0
-      it_ky = it_ch = 0;
+    if constexpr (!STREAM) {
+      if (has_next) {
+        stamp(next, 0);
+        setup(next);
+        stamp(next, 1);
+      } else {
+        it = (nK + 3) & ~3;   // destination derived from `it`: A slot 0 / halo slot 0
+        it_ky = it_ch = 0;
+      }
+      issue_h(K0_{});
     }
-    issue_h(K0_{});
     stamp(work, 7);
     float s1[STATS ? NQD : 1], s2[STATS ? NQD : 1];
     if constexpr (STATS) {
@@ -1014,12 +1056,17 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
         }
     }
   }
+  if constexpr (STREAM) {       // nothing to issue, nothing to wait for: the stores drain under the next tile's first K steps
+    stamp(work, 4);
+    stamp(work, 5);
+  } else {
   if (has_next) { if constexpr (HALO) issue_h(K1_{}); else issue(SLOT); }
   stamp(work, 4);
   wait_vmcnt<HALO ? NPA : NP>();              // the epilogue's stores share vmcnt with the prefetched K tiles: everything but the second tile's pieces (the newest) has landed
   stamp(work, 5);
   __builtin_amdgcn_s_barrier();  // staging reads done before ring slots 2.. are refilled
   if (has_next) { if constexpr (HALO) issue_h(K2_{}); else issue(2 * SLOT); }
+  }
   work = next;
   }  // persistent tile loop
   if constexpr (DYN) {
