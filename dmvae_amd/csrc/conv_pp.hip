@@ -51,6 +51,9 @@
 #ifndef DMVAE_PP_STREAM
 #define DMVAE_PP_STREAM 0
 #endif
+#ifndef DMVAE_PP_ST_AUX   // cache-policy bits of the direct epilogue's output stores: 1 = sc0, 2 = nt, 16 = sc1 (A/B builds)
+#define DMVAE_PP_ST_AUX 2
+#endif
 #ifndef DMVAE_PP_AUXA   // cache-policy bits of the HALO loop's LDS-DMA (weights / activations): 1 = sc0, 2 = nt, 16 = sc1; A/B builds only
 #define DMVAE_PP_AUXA 0
 #endif
@@ -796,13 +799,13 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
           if constexpr (CL == 8) {
             const u32x4 o = {pk[0], pk[1], pk[2], pk[3]};
 #if !(DMVAE_PP_EXP & 8)
-            __builtin_amdgcn_raw_buffer_store_b128(o, rY, vbase, so, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rY, vbase, so, DMVAE_PP_ST_AUX);
 #endif
             asm volatile("s_nop 0" :: "v"(o));   // gfx950: a VALU write to a store's data VGPR directly behind the store is seen by the store (see the staged epilogue)
           } else {
             const u32x2 o = {pk[0], pk[1]};
 #if !(DMVAE_PP_EXP & 8)
-            __builtin_amdgcn_raw_buffer_store_b64(o, rY, vbase, so, 2);
+            __builtin_amdgcn_raw_buffer_store_b64(o, rY, vbase, so, DMVAE_PP_ST_AUX);
 #endif
             asm volatile("s_nop 0" :: "v"(o));
           }
