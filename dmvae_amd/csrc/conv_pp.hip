@@ -51,6 +51,9 @@
 #ifndef DMVAE_PP_STREAM
 #define DMVAE_PP_STREAM 0
 #endif
+#ifndef DMVAE_PP_STAGGER
+#define DMVAE_PP_STAGGER 0
+#endif
 #ifndef DMVAE_PP_ST_AUX   // cache-policy bits of the direct epilogue's output stores: 1 = sc0, 2 = nt, 16 = sc1 (A/B builds)
 #define DMVAE_PP_ST_AUX 2
 #endif
@@ -474,6 +477,12 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       __hip_atomic_store(a.sched + 16 + blockIdx.x, flat, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // read back by this block's own waves only
     }
   };
+#if DMVAE_PP_STAGGER   // experiment: offset the XCDs' start by DMVAE_PP_STAGGER x 64 cycles each, so that the chip's epilogue write bursts do not all begin together
+  if constexpr (HALO) {
+    const unsigned xs = blockIdx.x & 7u;
+    for (unsigned k = 0; k < xs; k++) __builtin_amdgcn_s_sleep(DMVAE_PP_STAGGER);
+  }
+#endif
   stamp(blockIdx.x, 0);
   setup(blockIdx.x);
   stamp(blockIdx.x, 1);
