@@ -52,6 +52,7 @@ SIGNATURES = {
     "dmvae_pack_conv_weight": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "dmvae_pack_conv_weight_v2": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "dmvae_conv_halo_applies": (c_int, [POINTER(ConvDesc)]),
+    "dmvae_conv_kmajor_applies": (c_int, [POINTER(ConvDesc)]),
     "dmvae_subpixel_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dmvae_subpixel_weight_fold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dmvae_colsum_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_int, c_void_p]),

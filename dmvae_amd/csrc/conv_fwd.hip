@@ -305,7 +305,7 @@ extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* b
     const int r = dmvae_conv_pp_try(x, w, bias, residual, y, d, stream, nullptr, 0, nullptr);  // large shapes: the ping-pong kernel
     if (r <= 0) return r;
   }
-  DMVAE_CHECK_ARG(d->w_layout == 0, "conv2d_nhwc_fwd: w_layout %d is only accepted where dmvae_conv_halo_applies(d) is 1", d->w_layout);
+  DMVAE_CHECK_ARG(d->w_layout == 0, "conv2d_nhwc_fwd: w_layout %d is only accepted where dmvae_conv_kmajor_applies(d) is 1", d->w_layout);
   {
     const int r = dmvae_conv_thin_try(x, w, bias, residual, y, d, stream);  // 3x3 to four f32 output channels: the halo-tile kernel
     if (r <= 0) return r;

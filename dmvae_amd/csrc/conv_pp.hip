@@ -76,7 +76,7 @@ struct Args {
   int ks, act, M, ctiles, total;  // total = pixel tiles x cout tiles
   int so, pd, sd;                 // gather geometry (dmvae_conv_geometry): tap k of output o reads source (o * so - pd + k) / sd when that is an in-range integer
   int Ml;                         // SUB: source pixels N * Hi * Wi (= output pixels of one parity class); M is set to the same value
-  unsigned wsRow, wsTap, wsChunk; // HALO: byte strides of the weight operand per cout row / tap / 32-channel chunk (dmvae_conv_desc.w_layout)
+  unsigned wsRow, wsTap, wsChunk; // byte strides of the weight operand per cout row / tap / 32-channel chunk (dmvae_conv_desc.w_layout)
   float* gnpart;                  // STATS: [pixel tile][wave column 0..3][Cout / 4][2] per-tile (sum, sum of squares) of the bf16 results, 4 channels each
   unsigned* sched;                // DYN: this stream's scheduling words -- [0..7] tiles claimed past the static first round, per XCD range; [8] blocks finished;
                                   // [16 + b] the tile block b runs next.  All zero between launches (the last block to finish resets them).
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 #if DMVAE_PP_EXP & 512   // timing experiment: the weight tile's 64-B rows contiguous in memory (whole 128-B lines; wrong data)
       voffA[p] = (co < a.Cout && row < TM) ? (unsigned)co * 64u + c * 16u : SENT;
 #else
-      voffA[p] = (co < a.Cout && row < TM) ? (unsigned)co * (HALO ? a.wsRow : (unsigned)(TW * a.Cin) * 2u) + c * 16u : SENT;
+      voffA[p] = (co < a.Cout && row < TM) ? (unsigned)co * a.wsRow + c * 16u : SENT;     // wsRow / wsTap / wsChunk: tap-major [cout][T][cin] or K-tile-major [cin / 32][T][cout][32]
 #endif
     }
     if constexpr (HALO) {
@@ -385,9 +385,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     const bool live = it < nK;
 #endif
     if (live && (KO || it_ch == 0)) new_tap();
-    unsigned soA = (unsigned)(it_tap * a.Cin + it_ch * 32) * 2u;
+    unsigned soA = (unsigned)it_tap * a.wsTap + (unsigned)it_ch * a.wsChunk;
     if constexpr (SUB)  // tap (py + 2a, px + 2b) of the 4x4 operand
-      soA = (unsigned)(((((par >> 1) + (it_tap & 2)) << 2) + (par & 1) + ((it_tap & 1) << 1)) * a.Cin + it_ch * 32) * 2u;
+      soA = (unsigned)((((par >> 1) + (it_tap & 2)) << 2) + (par & 1) + ((it_tap & 1) << 1)) * a.wsTap + (unsigned)it_ch * a.wsChunk;
     unsigned soB = soffB_tap + (unsigned)it_ch * 64u;
 #if DMVAE_PP_EXP & 256   // timing experiment: the traffic of a kx-halo form -- activation pieces move memory for one tap in three, the others are issued masked
     const bool live_b = it_tap == 0 || it_tap == 3 || it_tap == 6;
@@ -1253,6 +1253,26 @@ extern "C" int dmvae_conv_halo_applies(const dmvae_conv_desc* d) {
   return halo_for(d->ks, d->cout, plain, fl != 0, d->out_f32 != 0) ? 1 : 0;
 }
 
+// 1 when the descriptor runs on this file's kernel at all (any instantiation): it may then carry w_layout = 1 -- the per-parity / general-gather / 4x4 instantiations
+// read the K-tile-major operand through the same three strides as the halo ones.  (ks = 1 operands have no K-tile-major copy on the host side.)
+extern "C" int dmvae_conv_kmajor_applies(const dmvae_conv_desc* d) {
+  using namespace dmvae_conv_pp;
+  if (!d) return 0;
+  static const bool disabled = [] { const char* e = getenv("DMVAE_CONV_V1"); return e && atoi(e) != 0; }();
+  static const bool general = [] { const char* e = getenv("DMVAE_PP_GENERAL"); return e ? atoi(e) != 0 : true; }();
+  int ho, wo, so, pd, sd, fl;
+  if (disabled || dmvae_conv_geometry(d, &ho, &wo, &so, &pd, &sd, &fl) != 0) return 0;
+  const bool plain = !(d->upsample == 2 || d->stride == 2 || d->ks == 4 || d->transposed);
+  if (!plain && !general) return 0;
+  const long long M = (long long)d->n * ho * wo;
+  const long long xbytes = (long long)d->n * d->h * d->w * d->cin * 2;
+  const long long wbytes = (long long)d->cout * d->ks * d->ks * d->cin * 2;
+  static const long long min_m = [] { const char* e = getenv("DMVAE_PP_MINM"); return e ? atoll(e) : 16384ll; }();
+  if (d->cin % 32 != 0 || d->cout < 64 || d->cout % 8 != 0 || M < min_m || xbytes + (1ll << 22) >= (1ll << 31) || wbytes >= (1ll << 31)) return 0;
+  if (M >= (1ll << 24) || M * d->cout * (d->out_f32 ? 4 : 2) >= (1ll << 31)) return 0;
+  return 1;
+}
+
 // gnpart / gn_groups: when non-null and the shape allows (bf16 result, plain or per-parity route, whole pixel tiles per image, groups of a multiple of 4
 // channels) the launch also leaves per-tile GroupNorm partials there and *gn_tp is set to the pixel-tile size (else 0: the caller computes the statistics itself).
 int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void* residual, void* y, const dmvae_conv_desc* d,
@@ -1276,8 +1296,8 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
   if (d->cin % 32 != 0 || d->cout < 64 || d->cout % 8 != 0 || M < min_m || xbytes + (1ll << 22) >= (1ll << 31) || wbytes >= (1ll << 31)) return 1;
   if (M >= (1ll << 24)) return 1;   // divmod_small
   if (M * d->cout * (d->out_f32 ? 4 : 2) >= (1ll << 31)) return 1;   // the epilogue addresses y (and the residual) through 32-bit buffer offsets; SENT must stay out of range
-  if (d->w_layout != 0 && !(d->w_layout == 1 && halo_for(d->ks, d->cout, plain, ups != 0, d->out_f32 != 0))) {
-    dmvae_set_error("conv2d_nhwc_fwd: w_layout %d is only accepted where dmvae_conv_halo_applies(d) is 1", d->w_layout);
+  if (d->w_layout != 0 && d->w_layout != 1) {
+    dmvae_set_error("conv2d_nhwc_fwd: w_layout %d (0 = tap-major, 1 = K-tile-major where dmvae_conv_kmajor_applies(d) is 1)", d->w_layout);
     return -1;
   }
   Args a;

@@ -54,10 +54,10 @@ def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad
         src = src.float()
     if subpixel:
         src = ops.subpixel_weight(src)
-    # 3x3 convs: the pack also writes the K-tile-major copy the kx-halo conv kernel reads (whole 128-B lines per weight tile; ops._weight_operand)
+    # 3x3 / 4x4 convs (Upsample's sub-pixel operand included): the pack also writes the K-tile-major copy the large-tile conv kernel reads (whole 128-B lines per weight tile; ops._weight_operand)
     # kmajor: the same for a Linear weight -- the operand `ops.linear_bf16` reads whole 128-B lines from (csrc/gemm_pp.hip, w_layout = 1)
     p = ops.pack_conv_weight(src, for_dgrad, rows_pad, cols_pad,
-                             kmajor=(src.dim() == 4 and src.shape[2] == 3 and not transposed and not subpixel) or (kmajor and src.dim() == 2 and not transposed))
+                             kmajor=(src.dim() == 4 and src.shape[2] in (3, 4) and not transposed) or (kmajor and src.dim() == 2 and not transposed))
     if transposed:       # [rows][taps*cols] -> [taps*cols][rows]: the B operand of the im2col convs' input-gradient GEMM
         p = p.view(p.shape[0], -1).t().contiguous()
     cache[key] = (ver, p)

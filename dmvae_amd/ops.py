@@ -86,11 +86,14 @@ def pack_conv_weight(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0
     return out
 
 
+_KMAJOR_ALL = os.environ.get("DMVAE_PP_KMAJOR_ALL", "1") != "0"     # 0: K-tile-major weights only on the kx-halo instantiations (round 2's state)
+
+
 def _weight_operand(w_packed: torch.Tensor, d) -> int:
     """Address of the weight operand for descriptor d: the K-tile-major copy (and d.w_layout = 1) where the packed tensor carries one and the library says
     the call runs on the kx-halo kernel (dmvae_conv_halo_applies), else the tap-major tensor itself."""
     wk = getattr(w_packed, "_dmvae_kmajor", None)
-    if wk is not None and _KMAJOR and _lib.lib().dmvae_conv_halo_applies(ctypes.byref(d)):
+    if wk is not None and _KMAJOR and (_lib.lib().dmvae_conv_kmajor_applies(ctypes.byref(d)) if _KMAJOR_ALL else _lib.lib().dmvae_conv_halo_applies(ctypes.byref(d))):
         d.w_layout = 1
         return wk.data_ptr()
     return w_packed.data_ptr()

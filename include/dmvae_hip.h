@@ -52,13 +52,16 @@ typedef struct dmvae_conv_desc {
                         Forward entry point only. */
   int32_t w_layout;  /* forward entry points: 0 = w is [cout][ks*ks][cin] (tap-major); 1 = K-tile-major [cin/32][ks*ks][cout][32], the second operand
                         dmvae_pack_conv_weight_v2 writes -- a (32-channel chunk, tap) tile of the weights is then one contiguous run of whole 128-B lines
-                        (in the tap-major layout it is `cout` half-lines 2*ks*ks*cin bytes apart).  Accepted only where dmvae_conv_halo_applies(d) is 1
-                        (the kx-halo conv kernel); any other shape with w_layout = 1 is an error, not a fallback. */
+                        (in the tap-major layout it is `cout` half-lines 2*ks*ks*cin bytes apart).  Accepted only where dmvae_conv_kmajor_applies(d) is 1
+                        (the large-tile conv kernel); any other shape with w_layout = 1 is an error, not a fallback. */
 } dmvae_conv_desc;
 
 /* 1 when conv2d_nhwc_fwd / _gnstats run descriptor d on the kx-halo kernel (plain 3x3, bf16 result, large shapes: csrc/conv_pp.hip) and therefore accept
  * w_layout = 1; 0 otherwise.  Pure function of d and of the process's DMVAE_PP_* environment. */
 int dmvae_conv_halo_applies(const dmvae_conv_desc* d);
+/* 1 when the call runs on the large-tile conv kernel at all (csrc/conv_pp.hip, any instantiation: plain 3x3, 1x1, the 4x4 stride-2 conv and its per-parity
+ * transpose, Upsample's folded gather) and may therefore carry w_layout = 1; dmvae_conv_halo_applies(d) = 1 is the subset that runs the kx-halo form. */
+int dmvae_conv_kmajor_applies(const dmvae_conv_desc* d);
 
 /* y[n,ho,wo,cout] = act( conv(x, w) + bias + residual ).
  * x: [n,h,w,cin] bf16; w: [cout, ks*ks, cin] bf16 (tap-major, see dmvae_pack_conv_weight; or its K-tile-major copy with d->w_layout = 1);

@@ -47,7 +47,7 @@ def _fresh(w, for_dgrad=False, rows_pad=0, cols_pad=0, subpixel=False, kmajor=Fa
     full = torch.zeros(rp, T, cp, device=src.device)
     full[:rows, :, :cols] = out
     full = full.to(torch.bfloat16)
-    want_km = (w.dim() == 4 and w.shape[2] == 3 and not subpixel) or (kmajor and w.dim() == 2)
+    want_km = (w.dim() == 4 and ks in (3, 4)) or (kmajor and w.dim() == 2)      # functional.packed: 3x3 / 4x4 operands (the sub-pixel one is 4x4) and frozen Linear weights
     if want_km and cp % 32 == 0:
         full._dmvae_kmajor = full.view(rp, T, cp // 32, 32).permute(2, 1, 0, 3).contiguous()
     return full
