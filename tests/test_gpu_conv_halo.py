@@ -87,17 +87,69 @@ def test_halo_conv_kmajor_weights_bit_identical(case, for_dgrad):
     assert torch.equal(y1, y0) and torch.equal(s1, s0)
 
 
-def test_kmajor_layout_is_refused_where_the_halo_kernel_does_not_run():
+def test_kmajor_layout_is_refused_where_the_large_tile_kernel_does_not_run():
+    """w_layout = 1 is an error -- never a silent fallback -- for a call the first-generation kernel serves (dmvae_conv_kmajor_applies = 0); where the large-tile
+    kernel runs without the halo form (1x1 here) the K-tile-major operand is accepted since round 3 (dmvae_conv_kmajor_applies = 1, dmvae_conv_halo_applies = 0)."""
     from dmvae_amd import _lib
     import ctypes
     L = _lib.lib()
-    x = torch.zeros(1, 16, 16, 64, device=DEV, dtype=BF)
-    w = torch.zeros(64, 9, 64, device=DEV, dtype=BF)
-    y = torch.zeros(1, 16, 16, 64, device=DEV, dtype=BF)
-    for d in (_lib.ConvDesc(1, 16, 16, 64, 64, 3, 0, 0, 0, 1, 0, 1),          # too few pixels for the large-shape kernel
-              _lib.ConvDesc(64, 16, 16, 64, 64, 1, 0, 0, 0, 1, 0, 1)):        # 1x1
-        assert L.dmvae_conv_halo_applies(ctypes.byref(d)) == 0
-        xx = torch.zeros(d.n, 16, 16, 64, device=DEV, dtype=BF); yy = torch.zeros(d.n, 16, 16, 64, device=DEV, dtype=BF)
-        ww = torch.zeros(64, d.ks * d.ks, 64, device=DEV, dtype=BF)
-        assert L.dmvae_conv2d_nhwc_fwd(xx.data_ptr(), ww.data_ptr(), None, None, yy.data_ptr(), ctypes.byref(d), None) != 0
-        assert b"w_layout" in L.dmvae_last_error()
+    small = _lib.ConvDesc(1, 16, 16, 64, 64, 3, 0, 0, 0, 1, 0, 1)            # too few pixels for the large-tile kernel
+    assert L.dmvae_conv_halo_applies(ctypes.byref(small)) == 0 and L.dmvae_conv_kmajor_applies(ctypes.byref(small)) == 0
+    xx = torch.zeros(1, 16, 16, 64, device=DEV, dtype=BF); yy = torch.zeros(1, 16, 16, 64, device=DEV, dtype=BF)
+    ww = torch.zeros(64, 9, 64, device=DEV, dtype=BF)
+    assert L.dmvae_conv2d_nhwc_fwd(xx.data_ptr(), ww.data_ptr(), None, None, yy.data_ptr(), ctypes.byref(small), None) != 0
+    assert b"w_layout" in L.dmvae_last_error()
+    bad = _lib.ConvDesc(64, 16, 16, 64, 64, 1, 0, 0, 0, 1, 0, 2)             # no such layout
+    assert L.dmvae_conv2d_nhwc_fwd(xx.data_ptr(), ww.data_ptr(), None, None, yy.data_ptr(), ctypes.byref(bad), None) != 0
+    one = _lib.ConvDesc(64, 16, 16, 64, 64, 1, 0, 0, 0, 1, 0, 1)             # 1x1 on the large-tile kernel: not the halo form, K-tile-major accepted
+    assert L.dmvae_conv_halo_applies(ctypes.byref(one)) == 0 and L.dmvae_conv_kmajor_applies(ctypes.byref(one)) == 1
+
+
+def _kmajor_copy(wp):
+    """[rows][T][cols] tap-major operand -> its K-tile-major copy [cols / 32][T][rows][32] by plain indexing."""
+    rows, T, cols = wp.shape
+    return wp.view(rows, T, cols // 32, 32).permute(2, 1, 0, 3).contiguous()
+
+
+@pytest.mark.parametrize("kind", ["1x1", "4x4_stride2", "4x4_transposed", "4x4_transposed_gnstats"])
+def test_kmajor_weights_bit_identical_on_the_non_halo_instantiations(kind):
+    """Round 3: the per-parity (sub-pixel transpose), general-gather (4x4 stride 2) and 1x1 instantiations read the weight operand through the same three strides as
+    the halo form, so they take the K-tile-major copy too: same values, same K order -> the same bits as with the tap-major operand (raw C-ABI calls, both layouts)."""
+    from dmvae_amd import _lib, ops
+    import ctypes
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(23)
+    n, h, w_, cin, cout = 4, 64, 64, 128, 256
+    if kind == "1x1":
+        ks, stride, transposed = 1, 0, 0
+        ho, wo = h, w_
+    elif kind == "4x4_stride2":
+        ks, stride, transposed = 4, 2, 0
+        n = 16                                   # 16 x 32 x 32 output pixels: the large-tile kernel's minimum
+        ho, wo = h // 2, w_ // 2
+    else:
+        ks, stride, transposed = 4, 2, 1
+        ho, wo = 2 * h, 2 * w_
+    x = torch.randn(n, h, w_, cin, generator=g).to(DEV).to(BF)
+    wp = (torch.randn(cout, ks * ks, cin, generator=g) * 0.05).to(DEV).to(BF)     # any values: the two layouts only have to agree
+    wk = _kmajor_copy(wp)
+    b = torch.randn(cout, generator=g).to(DEV)
+    outs = []
+    for layout, wt in ((0, wp), (1, wk)):
+        d = _lib.ConvDesc(n, h, w_, cin, cout, ks, 0, 0, 0, stride, transposed, layout)
+        assert L.dmvae_conv_kmajor_applies(ctypes.byref(d)) == 1 and L.dmvae_conv_halo_applies(ctypes.byref(d)) == 0
+        y = torch.full((n, ho, wo, cout), 7.0, device=DEV, dtype=BF)
+        if kind.endswith("gnstats"):
+            wsb = L.dmvae_conv2d_nhwc_fwd_gnstats_workspace(ctypes.byref(d), 32)
+            ws = torch.zeros(max(wsb, 4) // 4, device=DEV)
+            st = torch.zeros(n, 32, 2, device=DEV)
+            ops.check(L.dmvae_conv2d_nhwc_fwd_gnstats(x.data_ptr(), wt.data_ptr(), b.data_ptr(), None, y.data_ptr(), st.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                                      32, 1e-6, ctypes.byref(d), ops._stream()), "conv2d_nhwc_fwd_gnstats")
+            outs.append((y, st))
+        else:
+            ops.check(L.dmvae_conv2d_nhwc_fwd(x.data_ptr(), wt.data_ptr(), b.data_ptr(), None, y.data_ptr(), ctypes.byref(d), ops._stream()), "conv2d_nhwc_fwd")
+            outs.append((y,))
+    torch.cuda.synchronize()
+    for t0, t1 in zip(outs[0], outs[1]):
+        assert torch.equal(t0, t1), kind
+    assert float(outs[0][0].float().abs().max()) > 0.1 and not bool((outs[0][0] == 7.0).all())      # something was computed
