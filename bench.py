@@ -299,6 +299,7 @@ def main():
     dt = tdt.item()
     log = tr.read_log()
     if rank != 0:
+        _emit("", rank0=False)      # leave the group together with rank 0 (it prints the line after everybody's native output is out)
         return
     frac_timed = len(range(0, args.steps, max(1, args.time_every))) / max(1, args.steps)     # share of the timed steps that carried the per-launch events
     # the plain 256x256 instantiation; its dynamic-tile-claiming twin (DYN = true) when more than one rank runs (dmvae_amd/dist.py sets DMVAE_PP_DYNAMIC)
@@ -387,7 +388,28 @@ def main():
         del tr, images
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(out), flush=True)
+    _emit(json.dumps(out), rank0=True)
+
+
+def _flush_c_stdio() -> None:
+    """RCCL prints its version banner through C stdio; with stdout a pipe that text sits in libc's buffer until the process exits -- i.e. it would come out AFTER the
+    JSON line, which has to be the last thing this command prints.  Flushing libc's streams puts it where it was written."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
+def _emit(line: str, rank0: bool) -> None:
+    """The ONE JSON line, as the last line on stdout: every rank first leaves the process group and flushes whatever native libraries buffered, then rank 0 prints."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    _flush_c_stdio()
+    sys.stdout.flush()
+    if rank0:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

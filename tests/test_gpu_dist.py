@@ -167,3 +167,20 @@ def test_tokenizer_trainer_two_gpus_rccl():
         assert tb == "", tb
         assert err < 1e-6, (rank, err)
         assert same, rank
+
+
+def test_bench_json_is_the_last_stdout_line_under_rccl():
+    """The driver reads ONE JSON line from `bench.py`.  Under RCCL the library prints a version banner through C stdio, which (stdout being a pipe) used to come out
+    at process exit -- AFTER the JSON line.  One rank with a real RCCL process group (DMVAE_FORCE_DIST=1: the collective path on a single GPU): the last line of
+    stdout must parse, and carry the `comm` dictionary of an N > 1 line (bucket count, bytes, collectives launched during backward, exposed wait)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", DMVAE_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    d = json.loads(lines[-1])                                     # the LAST line, whatever native libraries printed before it
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["metric"].startswith("images/sec")
+    c = d["comm"]
+    assert c["backend"] == "nccl" and c["buckets"] >= 3 and c["bytes"] > 200e6 and c["launched_in_backward"] == c["buckets"] and c["wait_ms"] is not None
