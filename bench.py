@@ -268,7 +268,8 @@ def main():
         if os.environ.get("DMVAE_DIST_BACKEND") != "gloo" and len({d for _, d in ids}) != world:
             raise SystemExit(f"bench.py: ranks share devices: {ids}")
         if rank == 0:
-            print(f"bench.py: {torch.distributed.get_backend()} (RCCL) world={world}, devices {[d for _, d in ids]}", file=sys.stderr, flush=True)
+            be = torch.distributed.get_backend()
+            print(f"bench.py: backend {be}{' (RCCL)' if be == 'nccl' else ''} world={world}, devices {[d for _, d in ids]}", file=sys.stderr, flush=True)
 
     tr = build_tokenizer_trainer(device=dev, seed=42)
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
