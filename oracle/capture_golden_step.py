@@ -96,7 +96,9 @@ def main():
     names = [n_ for n_, p_ in vae.named_parameters() if p_.requires_grad]
     p0 = {n_: p_.detach().clone() for n_, p_ in vae.named_parameters() if p_.requires_grad}
     out = {"images_seed": np.array(SEED_IMG), "vae_seed": np.array(SEED_VAE), "vgg_seed": np.array(SEED_VGG), "warmup_steps": np.array(WARMUP),
-           "batch": np.array(BATCH), "base_lr": np.array(BASE_LR), "names": np.array(names), "width": np.array(width)}
+           "batch": np.array(BATCH), "base_lr": np.array(BASE_LR), "names": np.array(names)}
+    if width != 64:
+        out["width"] = np.array(width)          # the default capture keeps exactly the committed step_small.npz's keys (it regenerates byte for byte)
     for k, v in lp.state_dict().items():
         if k.startswith("lin"):
             out["lp." + k] = v.numpy()
