@@ -279,6 +279,7 @@ def main():
         tr.step(images)
     dist.barrier()
     torch.cuda.synchronize()
+    _flush_c_stdio()      # every rank: whatever the collective library printed while its communicators came up (RCCL's version banner) leaves libc's buffer NOW, long before rank 0's JSON line
     # Per-launch HIP events (roofline) bracket every conv / weight-gradient call of the steps they are on: ~290 event records per step, each a marker packet
     # the stream has to retire (measured: ~1 ms per step).  They are recorded on every `--time-every`-th step of the timed region (default 4: the first, the
     # fifth, ...), so the figure is still measured live inside the timed region while the timed region pays a quarter of that cost; 1 = every step.
