@@ -103,10 +103,10 @@ __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0
 template <int TM, int TP, int WM, int WP, bool OUT_F32, int NBUF, int LOOP = 0>
 __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__
-  constexpr int PF = NBUF - 1;                     // K tiles in flight ahead of the one being read
+  constexpr int PF = LOOP == 2 ? NBUF - 2 : NBUF - 1;   // K tiles in flight ahead of the one being read (LOOP 2 keeps one slot of slack: its waves may be a step apart)
   constexpr int CL = TM / WM / 16, BT = TP / WP / 16;   // 16 x 16 accumulator blocks per wave: CL column blocks (= consecutive columns per lane) x BT token blocks
   constexpr int NW = WM * WP;   // waves: 8 (two per SIMD), or 4 with the single-stream loop (one per SIMD, up to 64 accumulator blocks each: a 128 x 128 wave tile)
-  static_assert((NW == 8 || (NW == 4 && LOOP == 1)) && CL * 16 * WM == TM && BT * 16 * WP == TP && CL * BT <= (NW == 8 ? 32 : 64) && (CL == 4 || CL == 6 || CL == 8), "wave grid");
+  static_assert((NW == 8 || (NW == 4 && LOOP >= 1)) && CL * 16 * WM == TM && BT * 16 * WP == TP && CL * BT <= (NW == 8 ? 32 : 64) && (CL == 4 || CL == 6 || CL == 8), "wave grid");
   constexpr int TILE_A = TM * 64, TILE_B = TP * 64, SLOT = TILE_A + TILE_B, RING = NBUF * SLOT;
   constexpr int NPA = (TM / 16 + NW - 1) / NW, NPB = (TP / 16 + NW - 1) / NW, NP = NPA + NPB;   // 1-KiB DMA pieces (16 rows x 64 B) per wave and K tile; pieces past the tile go to the dump KiB
   constexpr int CW = CL * 16;                      // output columns per wave
@@ -313,8 +313,9 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
         [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) { (lds_read128<I * 1024>(wf[I], sw_), ...); }(std::make_integer_sequence<int, CL>{});
       };
       // one step: MODE as in kstep; PRE: prefetch the next K tile's fragments; PAR: which half of tfb the MFMAs read; WAIT: vmcnt allowed outstanding at the step's end (-1: none)
-      auto pstep = [&](auto WAITc, auto MODEc, auto PREc, auto PARc) __attribute__((always_inline)) {
+      auto pstep = [&](auto WAITc, auto MODEc, auto PREc, auto PARc, auto BARc) __attribute__((always_inline)) {
         constexpr int WAIT = decltype(WAITc)::value, MODE = decltype(MODEc)::value, PRE = decltype(PREc)::value, PAR = decltype(PARc)::value;
+        constexpr bool BAR = decltype(BARc)::value;     // false (LOOP 2, first step of a steady pair): no counted wait and no barrier at the step's end
         auto dma = [&]() __attribute__((always_inline)) {      // this step's DMA issue: behind the first MFMA group, so that the matrix pipe starts at once
           if constexpr (MODE == 0) { issue_k(vAc, vBc, (unsigned)it, slot_wr); it++; }
           else {
@@ -347,18 +348,22 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
         };
         static_assert(BT <= 2 * CL, "token fragments are prefetched at most two per weight group");
         [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) { (group.template operator()<I>(), ...); }(std::make_integer_sequence<int, CL>{});
-        if constexpr (WAIT >= 0) wait_vmcnt<WAIT>();
+        if constexpr (WAIT >= 0 && BAR) wait_vmcnt<WAIT>();
         // next step's first group needs every token fragment and wf[0]: the last token read sits in group (BT <= CL ? BT - 1 : CL - 1); behind it only weight reads
         if constexpr (PRE == 1) wait_lgkm<(BT <= CL ? CL - BT : 0)>();
         if constexpr (PRE == 2) wait_lgkm<0>();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (BAR) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       };
       using P1 = std::integral_constant<int, 1>; using P0 = std::integral_constant<int, 0>;
-      using V_ST = std::integral_constant<int, (PF - 2) * NP>; using V_TL = std::integral_constant<int, (PF - 2) * NP + 1>;
-      static_assert(PF >= 3, "ring");
+      using B1 = std::true_type; using B0 = std::false_type;
+      // LOOP 1: at the end of step t K tile t + 2 has landed (what step t + 1 reads).  LOOP 2: K tiles t + 2 AND t + 3 -- a steady pair of steps runs without a barrier
+      // between them and reads two K tiles' fragments -- so one K tile less may stay in flight.
+      constexpr int AHEAD = LOOP == 2 ? 3 : 2;
+      using V_ST = std::integral_constant<int, (PF - AHEAD) * NP>;
+      static_assert(PF >= AHEAD + 1, "ring");
       {   // prologue: K tile 0's fragments (everything of the first PF K tiles has landed: B_0)
         const unsigned sw_ = lbase + (unsigned)(slot_rd + wbase), st_ = lbase + (unsigned)(slot_rd + tbase);
         read_all(sw_, st_, tfb[0]);
@@ -374,19 +379,22 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
       // own = [one parity-preserving step if own is odd] + PREN prefix steps (an even number) + pairs.  Step t needs no wait while K tile t + 2 <= PF - 1; with the
       // optional first step in front, prefix step T is step T or T + 1: it waits unless T + 4 <= PF.
       constexpr int PREN = PRE0 + (PRE0 & 1);
-      if (own & 1) pstep(W_NO{}, M0_{}, P2{}, P0{});      // K tile 2 has landed (PF >= 3)
+      if (own & 1) pstep(W_NO{}, M0_{}, P2{}, P0{}, B1{});      // K tile 2 has landed (PF >= 3); LOOP 2: K tile 3 too (PF >= 4)
       [&]<int... T>(std::integer_sequence<int, T...>) __attribute__((always_inline)) {
-        (pstep(std::integral_constant<int, (T + 4 <= PF ? -1 : (PF - 2) * NP)>{}, M0_{}, P1{}, std::integral_constant<int, (T & 1)>{}), ...);
+        (pstep(std::integral_constant<int, (T + AHEAD + 2 <= PF ? -1 : (PF - AHEAD) * NP)>{}, M0_{}, P1{}, std::integral_constant<int, (T & 1)>{}, B1{}), ...);
       }(std::make_integer_sequence<int, PREN>{});
       const int pairs = (own - PREN) >> 1;      // nK >= 2 PF: own >= PF >= PREN + 1
 #pragma unroll 1
-      for (int q = 0; q < pairs; q++) { pstep(V_ST{}, M0_{}, P1{}, P0{}); pstep(V_ST{}, M0_{}, P1{}, P1{}); }
+      for (int q = 0; q < pairs; q++) {
+        if constexpr (LOOP == 2) { pstep(W_NO{}, M0_{}, P1{}, P0{}, B0{}); pstep(V_ST{}, M0_{}, P1{}, P1{}, B1{}); }
+        else { pstep(V_ST{}, M0_{}, P1{}, P0{}, B1{}); pstep(V_ST{}, M0_{}, P1{}, P1{}, B1{}); }
+      }
       calc(next, vAn, vBn, vBiasN, m0n, n0n);
       // the last PF steps issue the next tile's first K tiles (+ its bias piece with the first of them); the very last one prefetches no fragments and waits for everything
       [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) {
-        (pstep(std::integral_constant<int, (PF - 2) * NP + (J + 1 <= PF - 2 ? 1 : 0)>{}, std::integral_constant<int, J + 1>{}, P1{}, std::integral_constant<int, (J & 1)>{}), ...);
+        (pstep(std::integral_constant<int, (PF - AHEAD) * NP + (J + 1 <= PF - AHEAD ? 1 : 0)>{}, std::integral_constant<int, J + 1>{}, P1{}, std::integral_constant<int, (J & 1)>{}, B1{}), ...);
       }(std::make_integer_sequence<int, PF - 1>{});
-      pstep(W_0{}, std::integral_constant<int, PF>{}, P0{}, std::integral_constant<int, ((PF - 1) & 1)>{});
+      pstep(W_0{}, std::integral_constant<int, PF>{}, P0{}, std::integral_constant<int, ((PF - 1) & 1)>{}, B1{});
       // the ring's read pointer now stands one past the tile's last K tile = on the next tile's K tile 0 (the last step advanced it without reading)
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA (inline asm, invisible to the hazard recogniser) -> accumulator reads
@@ -522,6 +530,10 @@ int launch_l(Args a, hipStream_t st) {
 template <int TM, int TP, int WM, int WP, bool F32>
 int launch(Args a, hipStream_t st) {
   if (g_loop == -2) { const char* e = getenv("DMVAE_GEMM_LOOP"); g_loop = e ? atoi(e) : DMVAE_GEMM_LOOP_DEFAULT; }
+  constexpr int slot_ = (TM + TP) * 64, fit_ = (160 * 1024 - 3 * 1024) / slot_;
+  if constexpr (fit_ >= 6 && DMVAE_GEMM_MAXBUF >= 6) {      // LOOP 2 (a barrier every second K step) needs a six-slot ring: four K tiles ahead + one slot of slack
+    if (g_loop == 2) return launch_l<TM, TP, WM, WP, F32, 2>(a, st);
+  }
   return g_loop == 1 ? launch_l<TM, TP, WM, WP, F32, 1>(a, st) : launch_l<TM, TP, WM, WP, F32, 0>(a, st);
 }
 

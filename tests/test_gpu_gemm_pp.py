@@ -233,3 +233,10 @@ def test_every_tile_of_the_menu_gives_the_same_bits(tmp_path):
         got = torch.load(f)
         for key in res[0]:
             assert torch.equal(res[0][key], got[key]), f"pipelined loop, tile {cfg}, differs from the ping-pong loop at {key}"
+    for cfg in (3, 4):      # DMVAE_GEMM_LOOP=2: the pipelined loop with a barrier every second K step (six-slot rings only)
+        f = tmp_path / ("loop2_cfg%d.pt" % cfg)
+        env = dict(os.environ, DMVAE_GEMM_CFG=str(cfg), DMVAE_GEMM_LOOP="2")
+        subprocess.run([sys.executable, "-c", _TILE_SCRIPT % ROOT, str(f)], check=True, env=env, timeout=600)
+        got = torch.load(f)
+        for key in res[0]:
+            assert torch.equal(res[0][key], got[key]), f"two-step pipelined loop, tile {cfg}, differs from the ping-pong loop at {key}"

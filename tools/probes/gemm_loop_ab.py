@@ -6,6 +6,7 @@ from dmvae_amd import _lib, ops
 L = ctypes.CDLL(_lib.LIB_PATH)
 L.dmvae_debug_gemm_cfg.argtypes = [ctypes.c_int]; L.dmvae_debug_gemm_loop.argtypes = [ctypes.c_int]
 cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "4,7").split(",")]
+LB = int(sys.argv[2]) if len(sys.argv) > 2 else 1      # the loop compared with loop 0 (1: pipelined single stream, 2: the same with a barrier every second K step)
 SHAPES = [("vit fc2", 8224, 1024, 4096), ("vit proj", 8224, 1024, 1024), ("vit qkv", 8224, 3072, 1024), ("vit fc1", 8224, 4096, 1024), ("dit16 w3", 4096, 1152, 3072),
           ("dit64 w12", 16384, 6144, 1152), ("sq 8192", 8192, 8192, 4096), ("ragged", 777, 520, 384)]
 def once(fn, reps):
@@ -24,11 +25,11 @@ for name, m, n, k in SHAPES:
     for cfg in cfgs:
         L.dmvae_debug_gemm_cfg(cfg)
         L.dmvae_debug_gemm_loop(0); y0 = ops.linear_bf16(xs[0], wk, b, out_f32=True)
-        L.dmvae_debug_gemm_loop(1); y1 = ops.linear_bf16(xs[0], wk, b, out_f32=True); y1b = ops.linear_bf16(xs[0], wk, b, out_f32=True)
+        L.dmvae_debug_gemm_loop(LB); y1 = ops.linear_bf16(xs[0], wk, b, out_f32=True); y1b = ops.linear_bf16(xs[0], wk, b, out_f32=True)
         torch.cuda.synchronize()
         ok = torch.equal(y0, y1) and torch.equal(y1, y1b)
         ts = {}
-        for loop in (0, 1):
+        for loop in (0, LB):
             ctr = [0]
             def f():
                 ctr[0] = (ctr[0] + 1) % nbuf
@@ -37,11 +38,11 @@ for name, m, n, k in SHAPES:
             for _ in range(3): f()
             ts[loop] = []
         for _ in range(5):
-            for loop in (0, 1):
+            for loop in (0, LB):
                 L.dmvae_debug_gemm_loop(loop)
                 ts[loop].append(once(f, 20))
         fl = 2.0 * m * n * k
-        t0, t1 = statistics.median(ts[0]), statistics.median(ts[1])
-        line += f" | cfg{cfg} {'OK ' if ok else 'BAD'} loop0 {t0:6.1f}us {fl/t0/1e6:5.0f}TF  loop1 {t1:6.1f}us {fl/t1/1e6:5.0f}TF"
+        t0, t1 = statistics.median(ts[0]), statistics.median(ts[LB])
+        line += f" | cfg{cfg} {'OK ' if ok else 'BAD'} loop0 {t0:6.1f}us {fl/t0/1e6:5.0f}TF  loopB {t1:6.1f}us {fl/t1/1e6:5.0f}TF"
     print(line, flush=True)
 L.dmvae_debug_gemm_cfg(-1); L.dmvae_debug_gemm_loop(0)
