@@ -309,3 +309,28 @@ def test_lightningdit_train_route_matches_stock_autocast(tag):
         out2 = m(xc, t, y)
     (out2.float() * dy).sum().backward()
     assert torch.equal(out, out2) and torch.equal(xa.grad, xc.grad)
+
+
+@pytest.mark.parametrize("tag", ["dit_small_hd64w", "dit_small_hd72"])      # the two fixtures inside the HIP kernels' range (dit_small_hd64's SwiGLU width 341 is refused loudly)
+def test_cond_and_uncond_as_one_2b_call_equals_two_b_calls(tag):
+    """train_dmd.py:211-217 evaluates a velocity model twice per DMD loss (labels, then the null class); DMDTrainer batches the two evaluations into ONE call on
+    2B samples.  Every op of the HIP LightningDiT forward is per sample / per token row and the GEMM's result does not depend on the tile the
+    planner picks for the larger M, so the halves of the 2B call must equal the B-sized calls BIT FOR BIT -- and the DMD loss and gradient built from them with it."""
+    from dmvae_amd import losses
+    g = load_golden(tag)
+    m = build(tag, g).to(DEV).requires_grad_(False)
+    x, t = g.t("x").to(DEV), g.t("t").to(DEV)
+    y = torch.from_numpy(np.asarray(g["y"])).to(DEV)
+    null = torch.full_like(y, CFGS[tag]["num_classes"])
+    with torch.no_grad(), torch.autocast("cuda", dtype=BF):
+        vc, vu = m(x, t, y), m(x, t, null)
+        v2 = m(torch.cat([x, x]), torch.cat([t, t]), torch.cat([y, null]))
+    b = x.shape[0]
+    assert torch.equal(v2[:b], vc) and torch.equal(v2[b:], vu)
+    assert not torch.equal(vc, vu)                                   # the label embedding does change the output: the comparison above is not vacuous
+    # the loss assembled either way (the "student" here is the same model scaled: only the plumbing is under test)
+    lat = torch.randn_like(x.float())
+    xt = losses.dmd_make_xt(lat, torch.randn_like(lat), t.float())
+    a = losses.dmd_loss(lat, xt, t.float(), vc, (vc * 0.5).to(vc.dtype), vu, (vu * 0.5).to(vu.dtype), cfg=2.0)
+    c = losses.dmd_loss(lat, xt, t.float(), v2[:b], (v2[:b] * 0.5).to(vc.dtype), v2[b:], (v2[b:] * 0.5).to(vc.dtype), cfg=2.0)
+    assert torch.equal(a[0], c[0])
