@@ -27,7 +27,7 @@ class PackEntry(Structure):
                 ("reserved", c_int32), ("start", c_ulonglong), ("count", c_ulonglong)]
 
 
-ABI_VERSION = 2     # include/dmvae_hip.h: dmvae_abi_version
+ABI_VERSION = 3     # include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*)
 
 # name -> (restype, argtypes); every symbol include/dmvae_hip.h declares
 SIGNATURES = {
@@ -146,11 +146,16 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C dmvae_amd/csrc` (there is no CPU fallback)")
         l = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
-            fn.restype, fn.argtypes = res, args
-        if l.dmvae_abi_version() != ABI_VERSION:      # e.g. a DMVAE_LIB variant built before dmvae_conv_desc grew: the structs would not line up
+        # the version gate comes BEFORE the symbols are bound: an older build handed in through DMVAE_LIB must say "rebuild", not die on a missing name,
+        # and a build that does export every name must still not be called with structs laid out for another version
+        l.dmvae_abi_version.restype, l.dmvae_abi_version.argtypes = c_int, []
+        if l.dmvae_abi_version() != ABI_VERSION:
             raise DmvaeHipError(f"{LIB_PATH}: ABI version {l.dmvae_abi_version()}, this package binds version {ABI_VERSION}; rebuild the library")
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name, None)
+            if fn is None:
+                raise DmvaeHipError(f"{LIB_PATH} does not export {name} (declared in include/dmvae_hip.h); rebuild the library")
+            fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
 

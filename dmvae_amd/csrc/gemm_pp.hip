@@ -511,6 +511,7 @@ template <int TM, int TP, int WM, int WP, bool F32, int LOOP>
 int launch_l(Args a, hipStream_t st) {
   a.ntn = (a.N + TM - 1) / TM;
   a.total = ((a.M + TP - 1) / TP) * a.ntn;
+  DMVAE_CHECK_ARG(a.total > 0 && a.total < (1 << 24), "linear_bf16: %d output tiles (the kernel's tile index arithmetic is exact below 2^24)", a.total);
   a.inv_ntn = 1.0f / (float)a.ntn;
   const unsigned grid = a.total > 256 ? 256u : (unsigned)a.total;
   constexpr int slot = (TM + TP) * 64;

@@ -639,7 +639,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, a
     """nn.Linear under autocast(bf16) on this build's GEMM kernels (no vendor library): x [..., K] bf16; w [N, K] and b [N] the f32 parameters (their bf16
     copies are cached / shadowed, `_bf`) or already-bf16 tensors (a frozen bf16 shadow module).  f32 accumulation, bias added in f32, bf16 result, optional
     fused GELU / SiLU (on the bf16-rounded pre-activation: the reference's Linear -> activation pair).  Shapes the large-tile kernel does not take
-    (csrc/gemm_pp.hip: K < 192 or not a multiple of 32, fewer than 64 rows: the per-sample adaLN / embedder Linears) run on the small batched NT kernel.
+    (csrc/gemm_pp.hip: K < 384 or not a multiple of 32, N not a multiple of 8, fewer than 64 rows) run on the small batched NT kernel.
     Reference sites: timm blocks via models/vae.py:47-53; diffusion/lightningdit/lightningdit.py:34-93,173-252; swiglu_ffn.py:15-36."""
     bb = None if b is None else (b if b.dtype == bf16 else _bf(b))
     k = x.shape[-1]
@@ -649,9 +649,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, a
     if x.dtype != bf16:
         x = x.to(bf16)
     if ops.linear_supported(m, n, k) and (act != ops.ACT_SWIGLU or n % 16 == 0):
-        # frozen weights -- not trainable AND not owned by one of this build's optimisers (a student DiT switched to requires_grad False for the DMD
-        # loss's evaluations still changes every few steps: it keeps the row-major shadow its optimiser maintains) -- : the K-tile-major copy, packed once
-        if not w.requires_grad and not hasattr(w, "_dmvae_epoch") and w.dim() == 2 and _KMAJOR_FROZEN:
+        # frozen weights -- an nn.Parameter that is not trainable AND not owned by one of this build's optimisers (a student DiT switched to requires_grad
+        # False for the DMD loss's evaluations still changes every few steps: it keeps the row-major shadow its optimiser maintains) -- : the K-tile-major
+        # copy, packed once per (storage, version).  Anything that is not the parameter object itself -- a view of an optimiser's bf16 shadow, which the fused
+        # AdamW step rewrites through raw pointers without moving data_ptr or _version -- is read as it is, live.
+        if isinstance(w, torch.nn.Parameter) and not w.requires_grad and not hasattr(w, "_dmvae_epoch") and w.dim() == 2 and _KMAJOR_FROZEN:
             return ops.linear_bf16(x, _bf_km(w), bb, act)
         return ops.linear_bf16(x, (w if w.dtype == bf16 else _bf(w)).view(n, k), bb, act)
     wb = w if w.dtype == bf16 else _bf(w)
@@ -686,7 +688,7 @@ def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Te
         dw, db = (dy2.t() @ x2).float(), dy2.float().sum(0)
     if not need_dx:
         return None, dw, db
-    if ops.linear_supported(rows, cin, cout):
+    if ops.linear_supported(rows, cin, cout) and not parity.on():
         return ops.linear_bf16(_c(dy2), _bf_t(w)), dw, db                 # dX = dY . W as an NT GEMM against the transposed copy
     return ops.gemm_nt(_c(dy2), packed(w, True).view(cin, cout)) if (cout % 32 == 0 and cin % 4 == 0) else (dy2 @ _bf(w)), dw, db
 

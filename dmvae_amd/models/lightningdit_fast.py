@@ -16,16 +16,21 @@ from .. import ops
 _BF = torch.bfloat16
 
 
-def supported(model, x: torch.Tensor) -> bool:
+def structurally_supported(model) -> bool:
+    """The configuration the DiT kernels cover (what `supported` checks besides the call's tensor and autocast state).  On this route every op is per sample
+    -- per token row, per (sample, head) -- so a 2B-sample call equals two B-sample calls bit for bit (train.DMDTrainer's batched cond / uncond evaluation)."""
     from .lightningdit import RMSNorm, SwiGLUFFN
-    if not (x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == _BF):
-        return False
     blk = model.blocks[0]
     c, hd = model.hidden_size, model.hidden_size // model.num_heads
     tokens = model.x_embedder.num_patches
-    return (model.use_rope and model.use_rmsnorm and isinstance(blk.attn.q_norm, RMSNorm) and isinstance(blk.mlp, SwiGLUFFN) and not blk.wo_shift
-            and c % 8 == 0 and c <= 2048 and hd % 2 == 0 and hd <= 128 and tokens % 32 == 0 and blk.mlp.w3.in_features % 8 == 0
-            and x.shape[-1] * x.shape[-2] == tokens * model.patch_size ** 2)
+    return bool(model.use_rope and model.use_rmsnorm and isinstance(blk.attn.q_norm, RMSNorm) and isinstance(blk.mlp, SwiGLUFFN) and not blk.wo_shift
+                and c % 8 == 0 and c <= 2048 and hd % 2 == 0 and hd <= 128 and tokens % 32 == 0 and blk.mlp.w3.in_features % 8 == 0)
+
+
+def supported(model, x: torch.Tensor) -> bool:
+    if not (x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == _BF):
+        return False
+    return structurally_supported(model) and x.shape[-1] * x.shape[-2] == model.x_embedder.num_patches * model.patch_size ** 2
 
 
 def _bf(p):

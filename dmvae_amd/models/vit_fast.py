@@ -50,18 +50,20 @@ def frozen_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
     for i, blk in enumerate(vit.blocks):
         nh = blk.attn.num_heads
         hd = c // nh
-        qkv = linear(hn, _w(blk.attn.qkv.weight), _w(blk.attn.qkv.bias))              # [b, s, 3*c] = [b, s, 3, heads, hd]
+        # the PARAMETERS go to `linear`, not their bf16 copies: it serves a frozen one from the K-tile-major pack and one that an optimiser of this build
+        # owns (DMDTrainer's encoder between its VAE turns: vae.encode under no_grad) from the live bf16 shadow that optimiser maintains
+        qkv = linear(hn, blk.attn.qkv.weight, blk.attn.qkv.bias)                       # [b, s, 3*c] = [b, s, 3, heads, hd]
         if hd == 64 and s <= 288:
             o = ops.attention_qkv(qkv, nh, hd ** -0.5)                             # fused: nothing of size s x s reaches HBM
         else:
             qkv = qkv.reshape(b, s, 3, nh, hd).permute(2, 0, 3, 1, 4)
             att = ops.softmax_rows_bf16(qkv[0] @ qkv[1].transpose(-2, -1), hd ** -0.5)   # scale, f32 softmax and the casts in one pass
             o = (att @ qkv[2]).transpose(1, 2).reshape(b, s, c)
-        o = linear(o, _w(blk.attn.proj.weight), _w(blk.attn.proj.bias))
+        o = linear(o, blk.attn.proj.weight, blk.attn.proj.bias)
         # every LayerScale + residual add is followed by a LayerNorm (this block's norm2, the next block's norm1, the final norm): one pass over the stream
         hn = ops.scale_residual_layernorm_(t, o.contiguous(), blk.ls1.gamma, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-        h = linear(hn, _w(blk.mlp.fc1.weight), _w(blk.mlp.fc1.bias), act=ops.ACT_GELU)   # GELU in the GEMM's epilogue (bit-identical to the two kernels)
-        o = linear(h, _w(blk.mlp.fc2.weight), _w(blk.mlp.fc2.bias))
+        h = linear(hn, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=ops.ACT_GELU)   # GELU in the GEMM's epilogue (bit-identical to the two kernels)
+        o = linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias)
         nxt = vit.blocks[i + 1].norm1 if i + 1 < nblk else vit.norm
         hn = ops.scale_residual_layernorm_(t, o, blk.ls2.gamma, nxt.weight, nxt.bias, nxt.eps)
     return hn

@@ -102,22 +102,42 @@ class _AdversarialBranch:
         return {"d_loss": v[0], "bcr_loss": v[1], "acc_real": v[2], "acc_fake": v[3], "acc_mean": 0.5 * (v[2] + v[3]), "disc_norm": v[4]}
 
 
-def _rng_state() -> dict:
-    """CPU and current-device generator states: what DiffAug (utils/diffaug.py: `torch.rand(3)` on the CPU, `torch.rand(7, B, 1, 1)` on the device) and the
-    transport's sampling (`randn_like` on the device, `rand` on the CPU) consume.  Saved with every checkpoint so that a resumed run draws what the
-    uninterrupted one would have."""
-    st = {"cpu": torch.get_rng_state()}
+def _rng_state(all_ranks: bool = False) -> dict:
+    """CPU and current-device generator states of THIS rank, labelled with (rank, world): what DiffAug (utils/diffaug.py: `torch.rand(3)` on the CPU,
+    `torch.rand(7, B, 1, 1)` on the device) and the transport's sampling (`randn_like` on the device, `rand` on the CPU) consume.  The reference seeds rank r
+    with seed + 10000 r (train_dmd.py:140-146) and writes checkpoints from the master only (train_tokenizer.py:438), so one rank's generators are NOT the
+    job's: `all_ranks=True` (a collective -- every rank must call it) gathers every rank's states into `ranks`, so that each rank of a resumed run of the
+    same world size draws what it would have drawn uninterrupted; without it the entry restores the rank that wrote it and leaves the others alone."""
+    st = {"rank": dist.get_rank(), "world": dist.get_world_size(), "cpu": torch.get_rng_state()}
     if torch.cuda.is_available():
         st["cuda"] = torch.cuda.get_rng_state()
+    if all_ranks and dist.initialized() and st["world"] > 1:
+        import torch.distributed as tdist
+        mine = {k: v for k, v in st.items() if k in ("cpu", "cuda")}
+        got = [None] * st["world"]
+        tdist.all_gather_object(got, mine)
+        st["ranks"] = {r: g for r, g in enumerate(got)}
     return st
 
 
-def _set_rng_state(st) -> None:
+def _set_rng_state(st) -> bool:
+    """Install the generator states a checkpoint holds FOR THIS RANK: its entry of `ranks` when the checkpoint was gathered over the same world size, the
+    single entry when this rank (of the same world size) wrote it; a checkpoint without labels is a single-process one (rank 0 of 1).  Any other rank keeps
+    the generators it was seeded with (seed + 10000 rank): installing rank 0's state everywhere would make every rank draw the same DiffAug parameters, DMD
+    timesteps / noise and label drop-outs on different data shards.  Returns whether a state was installed."""
     if not st:
-        return
-    torch.set_rng_state(st["cpu"].cpu())
-    if "cuda" in st and torch.cuda.is_available():
-        torch.cuda.set_rng_state(st["cuda"].cpu())
+        return False
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if st.get("ranks") is not None and int(st.get("world", 1)) == world and rank in st["ranks"]:
+        mine = st["ranks"][rank]
+    elif int(st.get("rank", 0)) == rank and int(st.get("world", 1)) == world:
+        mine = st
+    else:
+        return False
+    torch.set_rng_state(mine["cpu"].cpu())
+    if "cuda" in mine and torch.cuda.is_available():
+        torch.cuda.set_rng_state(mine["cuda"].cpu())
+    return True
 
 
 class TokenizerTrainer(_AdversarialBranch):
@@ -225,7 +245,7 @@ class TokenizerTrainer(_AdversarialBranch):
         are not part of it.  (train_dmd.py:474 and train_diffusion.py:209 build theirs over every parameter.)"""
         return [p for p in self.vae.parameters() if p.requires_grad]
 
-    def checkpoint(self) -> dict:
+    def checkpoint(self, all_ranks_rng: bool = False) -> dict:
         """The reference's checkpoint dict (train_tokenizer.py:440-450): vae_wo_ddp / vae_ema / disc_wo_ddp state_dicts, opt_vae in torch.optim.AdamW's
         layout over the TRAINABLE parameters (`_opt_param_order`), opt_disc over `disc.parameters()`, scheduler_vae / scheduler_disc, steps, and -- beyond the
         reference -- the CPU / device generator states (`rng`: DiffAug's and the transport's draws continue where they stopped).  `torch.save` it as
@@ -241,7 +261,7 @@ class TokenizerTrainer(_AdversarialBranch):
             out["disc_wo_ddp"] = {k: v.detach().clone() for k, v in self.disc.state_dict().items()}
             out["opt_disc"] = self.dopt.state_dict(list(self.disc.parameters()))
             out["scheduler_disc"] = self.dopt.scheduler_state_dict()
-        out["rng"] = _rng_state()
+        out["rng"] = _rng_state(all_ranks_rng)      # all_ranks_rng: a collective (every rank calls checkpoint()); else this rank's generators only
         return out
 
     def load(self, ckpt: dict) -> None:
@@ -285,6 +305,14 @@ def backward_order_params_full(vae: VAE):
     return params
 
 
+def _batchable(model) -> bool:
+    """A velocity model whose 2B-sample call equals two B-sample calls: this build's LightningDiT on its HIP route (every op per sample), not drawing label
+    drop-outs (eval mode)."""
+    from .models.lightningdit import LightningDiT
+    from .models import lightningdit_fast
+    return isinstance(model, LightningDiT) and not model.training and lightningdit_fast.structurally_supported(model)
+
+
 class DMDTrainer(_AdversarialBranch):
     """Step harness of the distribution-matching stage (train_dmd.py:506-575): every `vae_train_every`-th step the whole VAE (encoder
     included, :519) trains on  rec_loss + [from `disc_start_step` on, with a discriminator attached] the adaptive-weight adversarial term
@@ -303,12 +331,16 @@ class DMDTrainer(_AdversarialBranch):
                  t0: float = 0.0, t1: float = 1.0, latent_mean: float = 0.0, latent_scale: float = 1.0, vae_train_every: int = 5,
                  time_dist_shift: float = 1.0, warmup_steps: int = 1000, max_norm: float = 1.0, bucket_bytes: int = 64 << 20,
                  disc: Optional[torch.nn.Module] = None, disc_weight: float = 0.5, disc_start_step: int = 0, disc_lr: float = 1e-4,
-                 disc_wd: float = 0.0005, bcr: float = 1.0, bcr_cut: float = 0.2):
+                 disc_wd: float = 0.0005, bcr: float = 1.0, bcr_cut: float = 0.2, batch_cfg: Optional[bool] = None):
         self.vae, self.lpips, self.teacher, self.student = vae, lpips, teacher, student
         self._init_disc(disc, disc_weight, disc_start_step, disc_lr, disc_wd, warmup_steps, max_norm, bcr, bcr_cut, bucket_bytes)     # train_dmd.py:92-93,475
         self.w = dict(l1=l1, l2=l2, lpips=lpips_w)
         self.dmd_weight, self.cfg, self.num_classes = dmd_weight, dmd_cfg_scale, num_classes
-        self.batch_cfg = os.environ.get("DMVAE_DMD_BATCH_CFG", "1") != "0"      # 0: four B-sized velocity evaluations as the reference writes them (A/B)
+        # Conditional + unconditional evaluation of a velocity model as ONE 2B-sample call.  None (default): only when BOTH models are this build's
+        # LightningDiT on its per-sample HIP route and in eval mode at the call (`_batchable`) -- any other callable / nn.Module (a graph captured at
+        # batch B, batch-coupled ops, a per-call RNG draw such as label drop-out in train mode) gets the reference's four B-sized calls
+        # (train_dmd.py:211-217).  True: the caller vouches that its models are per-sample; False / DMVAE_DMD_BATCH_CFG=0: never.
+        self.batch_cfg = False if os.environ.get("DMVAE_DMD_BATCH_CFG", "1") == "0" else batch_cfg
         self.t0, self.t1, self.latent_mean, self.latent_scale = t0, t1, latent_mean, latent_scale
         self.vae_train_every, self.time_dist_shift, self.max_norm = vae_train_every, time_dist_shift, max_norm
         for p in vae.parameters():
@@ -377,7 +409,7 @@ class DMDTrainer(_AdversarialBranch):
         t = (t * (self.t1 - self.t0) + self.t0)
         xt = losses.dmd_make_xt(latents, x0, t)
         with torch.no_grad():
-            if self.cfg > 1 and self.batch_cfg:
+            if self.cfg > 1 and (self.batch_cfg if self.batch_cfg is not None else (_batchable(self.teacher) and _batchable(self.student))):
                 # the conditional and the unconditional evaluation of a model as ONE call on 2B samples: every op of the velocity
                 # model is per sample (per token row, per (sample, head)), so each half equals the B-sized call; twice the rows per GEMM fill the chip
                 # (B = 16: 4096 -> 8192 token rows) and half the launches
@@ -471,15 +503,16 @@ class DMDTrainer(_AdversarialBranch):
         self.global_step += 1
         return (loss if vae_turn else sloss).detach()
 
-    def checkpoint(self) -> dict:
-        """train_dmd.py:577-590: model (the student) / vae_wo_ddp / disc_wo_ddp state_dicts, opt_sit / opt_vae / opt_disc, steps."""
+    def checkpoint(self, all_ranks_rng: bool = False) -> dict:
+        """train_dmd.py:577-590: model (the student) / vae_wo_ddp / disc_wo_ddp state_dicts, opt_sit / opt_vae / opt_disc, steps; `rng` = this rank's
+        generator states, or every rank's with all_ranks_rng (a collective: every rank calls checkpoint())."""
         clone = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
         out = {"model": clone(self.student) if isinstance(self.student, torch.nn.Module) else None, "vae_wo_ddp": clone(self.vae),
                "disc_wo_ddp": clone(self.disc) if self.disc is not None else None,
                "opt_sit": self.sopt.state_dict(list(self.student.parameters())) if self.sopt is not None else None,
                "opt_vae": self.opt.state_dict(list(self.vae.parameters())),
                "opt_disc": self.dopt.state_dict(list(self.disc.parameters())) if self.disc is not None else None, "steps": self.global_step,
-               "rng": _rng_state()}
+               "rng": _rng_state(all_ranks_rng)}
         return out
 
     def load(self, ckpt: dict) -> None:

@@ -178,3 +178,57 @@ def test_bench_refuses_to_measure_fewer_gpus_than_asked():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env2,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout) and '"n_gpus"' not in r.stdout
+
+
+def _rng_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from dmvae_amd import dist, train
+    dist.init_distributed_mode(backend="gloo")
+    torch.manual_seed(1234 + 10000 * rank)                    # the reference's per-rank seeding (train_dmd.py:140-146)
+    torch.rand(3)
+    gathered = train._rng_state(all_ranks=True)               # collective: every rank's generators, keyed by rank
+    single = train._rng_state()                               # this rank's only (what a master-only checkpoint holds)
+    want = torch.rand(5)                                      # what the uninterrupted run draws next on THIS rank
+    # resume from the gathered entry: every rank gets its own stream back
+    torch.manual_seed(999)
+    ok_g = train._set_rng_state(gathered) and torch.equal(torch.rand(5), want)
+    # resume from rank 0's single entry: rank 0 is restored, rank 1 must NOT be given rank 0's generators
+    obj = [single]
+    torch.distributed.broadcast_object_list(obj, src=0)
+    torch.manual_seed(4321 + 10000 * rank)
+    before = torch.get_rng_state().clone()
+    installed = train._set_rng_state(obj[0])
+    ok_s = (installed and torch.equal(torch.rand(5), want)) if rank == 0 else (not installed and torch.equal(torch.get_rng_state(), before))
+    # a checkpoint gathered at another world size restores nobody
+    other = dict(gathered, world=world + 1)
+    ok_w = not train._set_rng_state(other)
+    dist.barrier()
+    q.put((rank, bool(ok_g and ok_s and ok_w), want.tolist()))
+    torch.distributed.destroy_process_group()
+
+
+def test_checkpoint_rng_is_per_rank_two_ranks_gloo():
+    """a checkpoint's `rng` entry must give each rank ITS generators back (or leave it alone), never rank 0's to everybody."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rng_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] != res[1][2], "the two ranks drew the same numbers"
+
+
+def test_checkpoint_rng_single_process_round_trip():
+    from dmvae_amd import train
+    torch.manual_seed(7)
+    st = train._rng_state()
+    want = torch.rand(4)
+    torch.manual_seed(8)
+    assert train._set_rng_state(st) and torch.equal(torch.rand(4), want)
+    legacy = {"cpu": st["cpu"]}                               # round 3's unlabelled entry: a single-process checkpoint
+    torch.manual_seed(9)
+    assert train._set_rng_state(legacy) and torch.equal(torch.rand(4), want)

@@ -327,6 +327,10 @@ def test_cond_and_uncond_as_one_2b_call_equals_two_b_calls(tag):
         v2 = m(torch.cat([x, x]), torch.cat([t, t]), torch.cat([y, null]))
     b = x.shape[0]
     assert torch.equal(v2[:b], vc) and torch.equal(v2[b:], vu)
+    # what DMDTrainer's automatic switch keys on: this build's LightningDiT on the per-sample HIP route, not drawing label drop-outs
+    from dmvae_amd.train import _batchable
+    assert _batchable(m.eval()) and not _batchable(m.train()) and not _batchable(torch.nn.Linear(2, 2))
+    m.eval()
     assert not torch.equal(vc, vu)                                   # the label embedding does change the output: the comparison above is not vacuous
     # the loss assembled either way (the "student" here is the same model scaled: only the plumbing is under test)
     lat = torch.randn_like(x.float())

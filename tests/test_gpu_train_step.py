@@ -304,7 +304,8 @@ def test_dmd_trainer_student_modes_and_adversarial_branch():
     images = torch.rand(2, 3, 256, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0)) * 2 - 1
     labels = torch.tensor([3, 7], device="cuda")
     student.eval()                                     # the reference's pre-loop state (train_dmd.py:501)
-    tr.batch_cfg = False                               # the reference's call structure: conditional and unconditional evaluation as two B-sized calls
+    assert tr.batch_cfg is None                        # the default: automatic -- a velocity model that is not this build's per-sample HIP LightningDiT
+    # (here: a plain nn.Module) gets the reference's call structure, conditional and unconditional evaluation as two B-sized calls (train_dmd.py:211-217)
     tr.step(images, labels)                            # step 0: VAE turn (DMD: two student evaluations with CFG), then the student's turn
     assert student.calls == [(False, False), (False, False), (True, True)], student.calls
     assert tr.read_log()["d_weight"] == 0.0 and torch.equal(torch.cat([p.detach().flatten() for p in disc.parameters()]), d0)    # before disc_start_step
@@ -312,7 +313,7 @@ def test_dmd_trainer_student_modes_and_adversarial_branch():
     tr.step(images, labels)                            # step 1: student only
     assert student.calls == [(True, True)]
     student.calls.clear()
-    tr.batch_cfg = True                                # the default: both evaluations as ONE call on 2B samples
+    tr.batch_cfg = True                                # the caller vouches its models are per-sample: both evaluations as ONE call on 2B samples
     tr.step(images, labels)                            # step 2: VAE turn again, adversarial branch active now
     assert student.calls == [(False, False), (True, True)], student.calls
     log, dlog = tr.read_log(), tr.read_disc_log()

@@ -143,3 +143,35 @@ def test_vae_forward_with_trainable_encoder():
     g = vae.encoder.model.blocks[0].attn.qkv.weight.grad
     assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
     assert vae.encoder.model.pos_embed.grad is not None and vae.encoder.model.patch_embed.proj.weight.grad is not None
+
+
+def test_no_grad_encoder_reads_the_live_shadow_after_optimiser_steps():
+    """An encoder whose parameters live in an optimiser's flat buffer with a bf16 shadow (DMDTrainer's VAE, train_dmd.py:518-524): between its training
+    turns `vae.encode` runs it under no_grad through `frozen_forward_features`.  The fused AdamW step rewrites the shadow through raw pointers (neither
+    data_ptr nor _version of a shadow view moves), so a Linear that cached a K-tile-major pack of that view would keep serving pre-step weights.  After
+    every optimiser step the no-grad forward must equal the forward of a freshly built copy of the updated module, bit for bit."""
+    import copy
+    from dmvae_amd.models import vit_fast
+    from dmvae_amd.optim import FlatAdamWEMA, FlatParams
+    vit = _vit(512, 2, 8, 64, seed=7)                    # width 512: K >= 384, so the Linear layers take csrc/gemm_pp.hip (the route with the frozen pack)
+    fp = FlatParams(list(vit.parameters()), with_ema=False)
+    fp.enable_bf16_shadow()
+    opt = FlatAdamWEMA(fp, lr=0.05, warmup_steps=0, max_norm=0.0, weight_decay=0.0)
+    x = torch.randn(5, 3, 64, 64, generator=torch.Generator().manual_seed(3)).to(DEV)
+    prev = None
+    for step in range(3):
+        with torch.no_grad():
+            y = vit_fast.frozen_forward_features(vit, x).clone()
+            fresh = copy.deepcopy(vit)                   # new parameter objects: no cached operand, no shadow -- converted from the current f32 weights
+            for p in fresh.parameters():
+                for a in ("_dmvae_shadow", "_dmvae_shadow_ver", "_dmvae_epoch", "_dmvae_pack_reg", "_dmvae_packed", "_dmvae_bf16", "_dmvae_grad_view"):
+                    if hasattr(p, a):
+                        delattr(p, a)
+            y_ref = vit_fast.frozen_forward_features(fresh, x)
+        assert torch.equal(y, y_ref), f"step {step}: stale weights in the no-grad encoder forward"
+        if prev is not None:
+            assert not torch.equal(y, prev), "the optimiser step did not change the output: the test would not see stale weights"
+        prev = y
+        fp.begin_step()
+        fp.grad.copy_(torch.randn(fp.numel, generator=torch.Generator().manual_seed(10 + step)).to(DEV))
+        opt.step()
