@@ -74,6 +74,101 @@ def host_cores():
     return logical, usable, max(1, min(physical, usable))
 
 
+class GpuEnvSampler:
+    """Clock / power / temperature of the device during the timed region, sampled from sysfs by a side thread (no subprocess, nothing on the stream): the MFMA
+    kernels run at whatever clock the package's power and thermal state allows, so two boxes -- or one box at two times -- differ by 2-4 % on the same build;
+    with these in the line a 2 % difference between two bench lines can be attributed.  Every field is null where the node does not expose it."""
+
+    def __init__(self, device_index: int = 0, period_s: float = 0.05):
+        import glob
+        import threading
+        self.period, self.samples, self._stop, self._thread = period_s, {"sclk_mhz": [], "power_w": [], "temp_c": []}, threading.Event(), None
+        self.card, self.hwmon, self.uid = None, None, None
+        # the device's sysfs node by its PCI address (a node exposes one drm card per GPU / partition of the whole host: the visible device is not card0)
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            node = os.path.join("/sys/bus/pci/devices", bdf)
+            if os.path.isdir(node):
+                self.card = node
+        except (AttributeError, RuntimeError, AssertionError):
+            pass
+        if self.card is None:       # no PCI address from the runtime: the only AMD card, if there is exactly one
+            cards = []
+            for c in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+                try:
+                    with open(os.path.join(c, "device", "vendor")) as f:
+                        if f.read().strip() == "0x1002":
+                            cards.append(os.path.join(c, "device"))
+                except OSError:
+                    continue
+            if len(cards) == 1:
+                self.card = cards[0]
+        if self.card:
+            hw = sorted(glob.glob(os.path.join(self.card, "hwmon", "hwmon*")))
+            self.hwmon = hw[0] if hw else None
+            try:
+                import hashlib
+                with open(os.path.join(self.card, "unique_id")) as f:
+                    self.uid = hashlib.sha1(f.read().strip().encode()).hexdigest()[:10]
+            except OSError:
+                pass
+
+    @staticmethod
+    def _num(path):
+        try:
+            with open(path) as f:
+                return float(f.read().split()[0])
+        except (OSError, ValueError, IndexError):
+            return None
+
+    def _sclk(self):
+        v = self._num(os.path.join(self.hwmon, "freq1_input")) if self.hwmon else None
+        if v is not None:
+            return v / 1e6
+        try:                                    # pp_dpm_sclk: "N: 2100Mhz *" marks the current level
+            with open(os.path.join(self.card, "pp_dpm_sclk")) as f:
+                for ln in f:
+                    if "*" in ln:
+                        return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError, TypeError):
+            pass
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            if self.card:
+                s = self._sclk()
+                p = None
+                if self.hwmon:
+                    p = self._num(os.path.join(self.hwmon, "power1_average")) or self._num(os.path.join(self.hwmon, "power1_input"))
+                t = None
+                if self.hwmon:
+                    for name in ("temp2_input", "temp1_input"):        # junction where there is one, else edge
+                        t = self._num(os.path.join(self.hwmon, name))
+                        if t is not None:
+                            break
+                for k, v in (("sclk_mhz", s), ("power_w", None if p is None else p / 1e6), ("temp_c", None if t is None else t / 1e3)):
+                    if v is not None:
+                        self.samples[k].append(v)
+            self._stop.wait(self.period)
+
+    def start(self):
+        import threading
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def stop(self) -> dict:
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=2.0)
+        avg = lambda v: round(sum(v) / len(v), 1) if v else None
+        s = self.samples
+        return {"sclk_mhz_avg": avg(s["sclk_mhz"]), "sclk_mhz_min": round(min(s["sclk_mhz"]), 1) if s["sclk_mhz"] else None, "power_w_avg": avg(s["power_w"]),
+                "power_w_max": round(max(s["power_w"]), 1) if s["power_w"] else None, "temp_c": avg(s["temp_c"]), "gpu_uuid_hash": self.uid,
+                "samples": len(s["sclk_mhz"]) or len(s["power_w"]) or len(s["temp_c"]), "sysfs_node": self.card, "source": "sysfs hwmon of the device, sampled every %d ms by a side thread during the timed region" % int(self.period * 1e3)}
+
+
 def cpu_baseline_worker(threads: int, batch: int) -> None:
     """Child process of `cpu_baseline`: ONE whole fp32 tokenizer train step of the CPU oracle (oracle/ref_cpu.py::tokenizer_train_steps -- VAE forward with
     the frozen ViT-L encoder, L1 + MSE + LPIPS, backward, clip_grad_norm_, AdamW, EMA; train_tokenizer.py:403-437) at batch `batch` on `threads` threads.
@@ -285,15 +380,29 @@ def main():
     # fifth, ...), so the figure is still measured live inside the timed region while the timed region pays a quarter of that cost; 1 = every step.
     timing_all = []
     tr.sync.time_wait = True
+    # The timed region is EXACTLY --steps steps between the two barrier + synchronize brackets (the contract); inside it, events on the compute stream at the
+    # third-points split those same steps into three windows, so that the line also says how much the step time moved within the run (no extra steps, no sync)
+    marks = sorted({0, args.steps // 3, (2 * args.steps) // 3, args.steps})
+    win_ev = {}
+    sampler = GpuEnvSampler(torch.cuda.current_device()) if rank == 0 else None
+    if sampler is not None:
+        sampler.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if i in marks:
+            win_ev[i] = torch.cuda.Event(enable_timing=True)
+            win_ev[i].record()
         ops.KERNEL_TIMING = timing_all if i % max(1, args.time_every) == 0 else None
         tr.step(images)
+    win_ev[args.steps] = torch.cuda.Event(enable_timing=True)
+    win_ev[args.steps].record()
     ops.KERNEL_TIMING = timing_all
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    env_stats = sampler.stop() if sampler is not None else None
+    windows = [round(win_ev[a].elapsed_time(win_ev[b]) / (b - a), 3) for a, b in zip(marks, marks[1:]) if b > a]
     timing, ops.KERNEL_TIMING = timing_all, None
     tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist.initialized():
@@ -353,6 +462,10 @@ def main():
         "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
+        # the same timed steps in three consecutive windows (stream events at the third-points, rank 0's device): spread within the run
+        "ms_per_step_windows": windows, "ms_per_step_min": min(windows) if windows else None, "ms_per_step_max": max(windows) if windows else None,
+        "ms_per_step_median": sorted(windows)[len(windows) // 2] if windows else None,
+        "env": env_stats,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "train_tokenizer.py VAE pretrain step (C2): ViT-L/16 frozen encoder + MLP + flux decoder, L1 + LPIPS, "

@@ -2,8 +2,10 @@
 reference's own modules and (b) the CPU oracle evaluated with bf16 rounding at the HIP path's storage points.
 
 Tolerances (relative to the tensor's max-abs):
-  * vs oracle-with-bf16-sites: 1e-2 -- both sides round activations to bf16 at the same sites, so differences are
-    f32 accumulation order plus rare 1-ulp bf16 flips (2^-8) that propagate;
+  * vs oracle-with-bf16-sites: per module, 2-3 x what MI355X measures (round 4: ResnetBlock y 6e-5 / dx 1e-4 / parameter gradients 9e-6; Upsample and
+    Downsample exact; AttnBlock y 2e-4 / dx 4e-3 / q.weight 3e-3 -- its softmax probabilities are one more bf16 site the S x S scores pass through) -- both
+    sides round activations to bf16 at the same sites, so differences are f32 accumulation order plus rare 1-spacing bf16 flips (2^-8) that propagate
+    (`test_resnet_block_stage_by_stage_on_the_production_kernels` counts them: 2e-5 ... 2e-4 of the elements per stage);
   * vs the reference's pure-f32 goldens: 3e-2 -- bf16 autocast-level agreement (the reference itself trains under
     autocast(bf16), train_tokenizer.py:410).
 The 1e-4 f32 bar is enforced per kernel on identical inputs in test_gpu_kernels.py."""
@@ -19,7 +21,7 @@ from oracle.detweights import det_tensor
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 Q = R.bf16_round
-TOL_Q, TOL_REF = 1e-2, 3e-2
+TOL_Q, TOL_REF = 1e-2, 3e-2        # TOL_Q: the deep stacks (flux Encoder: 9 convs / 8 GroupNorms); single modules pass their own bar to _run_block
 
 
 def rel_l2(a, b):
@@ -36,7 +38,7 @@ def _load(mod, params):
     return mod.to(DEV)
 
 
-def _run_block(mod, g, oracle_fn):
+def _run_block(mod, g, oracle_fn, tol_q=TOL_Q):
     p = g.sub("p.")
     _load(mod, p)
     x = g.t("x").to(DEV).requires_grad_(True)
@@ -47,38 +49,41 @@ def _run_block(mod, g, oracle_fn):
     xo = g.t("x").requires_grad_(True)
     yo = oracle_fn(Q(xo), po, "", Q)
     yo.backward(Q(g.t("dy")))
-    assert rel_err(y.float().cpu(), yo.detach()) < TOL_Q
+    pg = [(n, rel_err(prm.grad.cpu(), po[n].grad)) for n, prm in mod.named_parameters() if g.t("g." + n).abs().max() >= 1e-4]
+    print(f"{type(mod).__name__}: vs bf16-site oracle: y {rel_err(y.float().cpu(), yo.detach()):.2e}  dx {rel_err(x.grad.cpu(), xo.grad):.2e}  "
+          f"worst parameter gradient {max(pg, key=lambda t: t[1])}")
+    assert rel_err(y.float().cpu(), yo.detach()) < tol_q
     assert rel_err(y.float().cpu(), g.t("y")) < TOL_REF
-    assert rel_err(x.grad.cpu(), xo.grad) < TOL_Q
+    assert rel_err(x.grad.cpu(), xo.grad) < tol_q
     assert rel_err(x.grad.cpu(), g.t("dx")) < TOL_REF
     for n, prm in mod.named_parameters():
         ref, orc = g.t("g." + n), po[n].grad
         if ref.abs().max() < 1e-4:      # exactly-zero gradients (see test_oracle_golden): noise on both sides
             assert prm.grad.abs().max() < 1e-2
             continue
-        assert rel_err(prm.grad.cpu(), orc) < TOL_Q, n
+        assert rel_err(prm.grad.cpu(), orc) < tol_q, n
         assert rel_err(prm.grad.cpu(), ref) < TOL_REF, n
 
 
 @pytest.mark.parametrize("name,cin,cout", [("resblock_same", 64, 64), ("resblock_short", 128, 64)])
 def test_resnet_block(name, cin, cout):
     from dmvae_amd.models.flux_ae import ResnetBlock
-    _run_block(ResnetBlock(cin, cout), load_golden(name), R.resnet_block)
+    _run_block(ResnetBlock(cin, cout), load_golden(name), R.resnet_block, tol_q=5e-4)      # VERDICT round 3 asked for <= 2e-3
 
 
 def test_attn_block():
     from dmvae_amd.models.flux_ae import AttnBlock
-    _run_block(AttnBlock(64), load_golden("attnblock"), R.attn_block)
+    _run_block(AttnBlock(64), load_golden("attnblock"), R.attn_block, tol_q=8e-3)
 
 
 def test_upsample():
     from dmvae_amd.models.flux_ae import Upsample
-    _run_block(Upsample(32), load_golden("upsample"), R.upsample)
+    _run_block(Upsample(32), load_golden("upsample"), R.upsample, tol_q=1e-5)
 
 
 def test_downsample():
     from dmvae_amd.models.flux_ae import Downsample
-    _run_block(Downsample(32), load_golden("downsample"), R.downsample)
+    _run_block(Downsample(32), load_golden("downsample"), R.downsample, tol_q=1e-5)
 
 
 def test_flux_encoder_small_fwd_bwd():
@@ -172,7 +177,7 @@ def test_decoder_small_fwd_bwd():
     # re-rolls their rounding, so two correct bf16 pipelines decorrelate to the bf16 noise floor (measured stage by
     # stage with tools/probes/t_dec.py; single blocks match the bf16-site oracle bit-for-bit, see _run_block).
     # Criterion: the HIP path must be as close to the reference's f32 result as the bf16-site oracle is.
-    def floor(hip, orc, ref, what, slack=1.5, abs_floor=1e-3):
+    def floor(hip, orc, ref, what, slack=1.15, abs_floor=1e-3):      # measured on MI355X (round 4): e_hip / e_orc = 0.89 ... 1.04 over y, dz and the captured parameter gradients
         e_hip, e_orc = rel_l2(hip, ref), rel_l2(orc, ref)
         print(f"decoder_small {what}: rel-L2 to f32 reference -- HIP {e_hip:.2e}, bf16-site oracle {e_orc:.2e}")
         assert e_hip < slack * e_orc + abs_floor, what
@@ -248,3 +253,125 @@ def test_conv_out_weight_gradient_via_gradient_im2col():
     dw_ref, db_ref = ops.conv2d_nhwc_wgrad(dyp, a, 3)
     assert rel_err(cw.grad, dw_ref[:3]) < 1e-5
     assert rel_err(cb.grad, db_ref[:3]) < 1e-5
+
+
+def _ulp_bf16(v):
+    """bf16 spacing at |v| (8 significant bits): 2^(floor(log2 |v|) - 7), with the normal-range floor."""
+    return torch.exp2(torch.floor(torch.log2(v.abs().clamp_min(2.0 ** -120))) - 7)
+
+
+def _assert_bf16_of(hip, ref64, what, max_flip_frac=2e-3, slack=1e-4):
+    """`hip` (bf16, from a production kernel) must be the bf16 rounding of the oracle's f64 result `ref64` computed from the SAME inputs: equal to RNE(ref64)
+    except for a small fraction of elements (f32 accumulation order puts a value on the other side of a rounding boundary), and those within one bf16 spacing of
+    ref64 -- i.e. every element is a correct rounding of a value within f32 accumulation error of the oracle's."""
+    h = hip.double().cpu()
+    r = ref64.to(torch.float32).to(torch.bfloat16).double()
+    flips = h != r
+    frac = flips.double().mean().item()
+    worst = ((h - ref64).abs() / (_ulp_bf16(ref64) + slack * ref64.abs().max())).max().item()
+    assert frac <= max_flip_frac, f"{what}: {frac:.2e} of the elements differ from RNE(oracle)"
+    assert worst <= 1.0, f"{what}: an element is {worst:.2f} bf16 spacings from the oracle"
+    return frac
+
+
+def test_resnet_block_stage_by_stage_on_the_production_kernels():
+    """Where the module-level tolerance comes from, and the only place where the PRODUCTION bf16 GroupNorm / swish / conv-epilogue kernels meet the oracle inside a
+    module: ResnetBlock(256 -> 128) at 4 x 64 x 64 (large enough for the kernels the C2 step runs: conv_pp with the GroupNorm-statistics epilogue, wgrad_pp, the
+    chunked GroupNorm passes), forward and backward replayed call by call exactly as functional.ResnetBlockFn issues them, each call's result compared with the
+    oracle's arithmetic (oracle/ref_cpu.py: group_norm, swish, conv2d; flux_ae.py:55-82) evaluated in f64 on THAT call's actual inputs.  Every bf16 result must be
+    the correct rounding of the oracle's value (<= 1 spacing, and != RNE(oracle) for at most 0.2 % of the elements), every f32 result within 1e-5.  The block-level
+    comparison (`test_resnet_block`) then differs from the oracle only through those rare one-spacing flips propagating -- which is what its bar measures."""
+    import torch.nn.functional as F
+    from dmvae_amd import ops
+    from dmvae_amd.functional import packed
+    from conftest import elem_err
+    n, hh, ww, cin, cout = 4, 64, 64, 256, 128
+    g = torch.Generator().manual_seed(77)
+    rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    x = (rn(n, hh, ww, cin) * 1.3 + 0.2).to(torch.bfloat16)
+    dy = rn(n, hh, ww, cout, sc=0.7).to(torch.bfloat16)
+    P = {"n1w": 1 + 0.3 * rn(cin), "n1b": 0.2 * rn(cin), "c1w": rn(cout, cin, 3, 3, sc=0.03), "c1b": 0.1 * rn(cout),
+         "n2w": 1 + 0.3 * rn(cout), "n2b": 0.2 * rn(cout), "c2w": rn(cout, cout, 3, 3, sc=0.04), "c2b": 0.1 * rn(cout),
+         "sw": rn(cout, cin, 1, 1, sc=0.06), "sb": 0.1 * rn(cout)}
+    D = {k: v.to(DEV) for k, v in P.items()}
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    nchw = lambda t: t.double().cpu().permute(0, 3, 1, 2)            # NHWC device tensor -> NCHW f64 on the CPU (the oracle's layout)
+    wq = lambda k: P[k].to(torch.bfloat16).double()                  # the bf16 operand the kernels read (functional.packed rounds the f32 master RNE)
+
+    def stats64(t):                                                  # (mean, rstd) per (sample, group) like the kernels' [n, 32, 2]
+        v = nchw(t).reshape(n, 32, -1)
+        m = v.mean(2)
+        return torch.stack([m, 1.0 / torch.sqrt(((v - m[..., None]) ** 2).mean(2) + 1e-6)], 2)
+
+    def gn_swish64(t, w, b):                                         # the oracle's own functions, f64
+        return R.swish(R.group_norm(nchw(t), P[w].double(), P[b].double()))
+
+    # ---- forward, as ResnetBlockFn.forward
+    st1 = ops.groupnorm_stats(xd)
+    assert rel_err(st1.cpu(), stats64(xd)) < 1e-5
+    a1 = ops.groupnorm_apply(xd, st1, D["n1w"], D["n1b"], True)
+    f1 = _assert_bf16_of(a1.permute(0, 3, 1, 2), gn_swish64(xd, "n1w", "n1b"), "a1 = swish(GN(x))")
+    h1, st2 = ops.conv2d_nhwc_gnstats(a1, packed(D["c1w"]), D["c1b"], ks=3)
+    f2 = _assert_bf16_of(h1.permute(0, 3, 1, 2), F.conv2d(nchw(a1), wq("c1w"), P["c1b"].double(), padding=1), "h1 = conv1(a1)")
+    assert rel_err(st2.cpu(), stats64(h1)) < 1e-5                     # the conv epilogue's statistics are those of the bf16 tensor it stored
+    a2 = ops.groupnorm_apply(h1, st2, D["n2w"], D["n2b"], True)
+    _assert_bf16_of(a2.permute(0, 3, 1, 2), gn_swish64(h1, "n2w", "n2b"), "a2 = swish(GN(h1))")
+    xs = ops.conv2d_nhwc(xd, packed(D["sw"]), D["sb"], ks=1)
+    _assert_bf16_of(xs.permute(0, 3, 1, 2), F.conv2d(nchw(xd), wq("sw"), P["sb"].double()), "xs = nin_shortcut(x)")
+    y, sty = ops.conv2d_nhwc_gnstats(a2, packed(D["c2w"]), D["c2b"], residual=xs, ks=3)
+    _assert_bf16_of(y.permute(0, 3, 1, 2), F.conv2d(nchw(a2), wq("c2w"), P["c2b"].double(), padding=1) + nchw(xs), "y = conv2(a2) + xs")
+    assert rel_err(sty.cpu(), stats64(y)) < 1e-5
+
+    # ---- backward, as ResnetBlockFn.backward
+    def conv_grads64(inp, wkey, dout, pad):                          # f64 autograd of the oracle's conv on this call's operands
+        i = nchw(inp).requires_grad_(True)
+        w = wq(wkey).requires_grad_(True)
+        b = P[wkey[:-1] + "b"].double().requires_grad_(True)
+        return torch.autograd.grad(F.conv2d(i, w, b, padding=pad), (i, w, b), nchw(dout))
+
+    def gn_grads64(inp, w, b, dout, dres=None):
+        i = nchw(inp).requires_grad_(True)
+        ww_, bb_ = P[w].double().requires_grad_(True), P[b].double().requires_grad_(True)
+        gi, gw, gb = torch.autograd.grad(R.swish(R.group_norm(i, ww_, bb_)), (i, ww_, bb_), nchw(dout))
+        return (gi if dres is None else gi + nchw(dres)), gw, gb
+
+    def f32_close(a, b, what):
+        assert rel_err(a.cpu(), b) < 1e-5 and elem_err(a.cpu(), b) < 1e-4, what
+
+    dc2w, dc2b = ops.conv2d_nhwc_wgrad(dyd, a2, 3)
+    gi, gw, gb = conv_grads64(a2, "c2w", dyd, 1)
+    f32_close(dc2w, gw, "dW(conv2)"); f32_close(dc2b, gb, "db(conv2)")
+    da2 = ops.conv2d_nhwc(dyd, packed(D["c2w"], True), ks=3)
+    _assert_bf16_of(da2.permute(0, 3, 1, 2), gi, "da2 = dgrad(conv2)")
+    dh1, dn2w, dn2b = ops.groupnorm_bwd(da2, h1, st2, D["n2w"], D["n2b"], True)
+    gi, gw, gb = gn_grads64(h1, "n2w", "n2b", da2)
+    f3 = _assert_bf16_of(dh1.permute(0, 3, 1, 2), gi, "dh1 = GN2 backward")
+    f32_close(dn2w, gw, "dgamma(norm2)"); f32_close(dn2b, gb, "dbeta(norm2)")
+    dc1w, dc1b = ops.conv2d_nhwc_wgrad(dh1, a1, 3)
+    gi, gw, gb = conv_grads64(a1, "c1w", dh1, 1)
+    f32_close(dc1w, gw, "dW(conv1)"); f32_close(dc1b, gb, "db(conv1)")
+    da1 = ops.conv2d_nhwc(dh1, packed(D["c1w"], True), ks=3)
+    _assert_bf16_of(da1.permute(0, 3, 1, 2), gi, "da1 = dgrad(conv1)")
+    dsw, dsb = ops.conv2d_nhwc_wgrad(dyd, xd, 1)
+    gi, gw, gb = conv_grads64(xd, "sw", dyd, 0)
+    f32_close(dsw, gw, "dW(nin_shortcut)"); f32_close(dsb, gb, "db(nin_shortcut)")
+    dxs = ops.conv2d_nhwc(dyd, packed(D["sw"], True), ks=1)
+    _assert_bf16_of(dxs.permute(0, 3, 1, 2), gi, "dxs = dgrad(nin_shortcut)")
+    dx, dn1w, dn1b = ops.groupnorm_bwd(da1, xd, st1, D["n1w"], D["n1b"], True, dres=dxs)
+    gi, gw, gb = gn_grads64(xd, "n1w", "n1b", da1, dres=dxs)
+    _assert_bf16_of(dx.permute(0, 3, 1, 2), gi, "dx = GN1 backward + dxs")
+    f32_close(dn1w, gw, "dgamma(norm1)"); f32_close(dn1b, gb, "dbeta(norm1)")
+    print(f"stage-by-stage: fraction of elements != RNE(oracle): a1 {f1:.1e}, h1 {f2:.1e}, dh1 {f3:.1e}")
+
+    # ---- and the module as a whole (autograd Function, same kernels) equals this replay bit for bit
+    from dmvae_amd.models.flux_ae import ResnetBlock
+    blk = ResnetBlock(cin, cout).to(DEV)
+    with torch.no_grad():
+        for k, t in (("norm1.weight", "n1w"), ("norm1.bias", "n1b"), ("conv1.weight", "c1w"), ("conv1.bias", "c1b"), ("norm2.weight", "n2w"), ("norm2.bias", "n2b"),
+                     ("conv2.weight", "c2w"), ("conv2.bias", "c2b"), ("nin_shortcut.weight", "sw"), ("nin_shortcut.bias", "sb")):
+            dict(blk.named_parameters())[k].copy_(D[t])
+    xin = xd.permute(0, 3, 1, 2).float().requires_grad_(True)
+    ym = blk(xin)
+    ym.backward(dyd.permute(0, 3, 1, 2).float())
+    assert torch.equal(ym.to(torch.bfloat16), y.permute(0, 3, 1, 2)) and torch.equal(xin.grad.to(torch.bfloat16), dx.permute(0, 3, 1, 2))
+    assert torch.equal(blk.conv1.weight.grad, dc1w) and torch.equal(blk.norm2.weight.grad, dn2w)
