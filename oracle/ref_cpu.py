@@ -791,3 +791,31 @@ def dit_output_to_latents(samples: Tensor, latent_mean: float, latent_scale: flo
     """sample_50k.py:143-148: [B, C, h, w] -> [B, h*w, C] tokens / scale + mean."""
     b, c, h, w = samples.shape
     return samples.permute(0, 2, 3, 1).reshape(b, h * w, c) / latent_scale + latent_mean
+
+
+# --------------------------------------------------------------------------------------------
+# train_tokenizer.py:324-367 eval() without the FID (evaluation/fid.py needs Inception weights that are not in the repo)
+# --------------------------------------------------------------------------------------------
+def psnr_sum(img1: Tensor, img2: Tensor) -> Tensor:
+    """evaluation/metrics.py:6-13 with reduce="sum": images [B, C, H, W] in [0, 1]; -10 log10 of the per-sample mean squared error, summed over the batch."""
+    mse = torch.mean((img1 - img2) ** 2, dim=(1, 2, 3))
+    return torch.sum(-10 * torch.log10(mse))
+
+
+def eval_metrics(encode: Callable, decode: Callable, batches, num_samples: int) -> dict:
+    """The numbers eval() logs (train_tokenizer.py:340-360) at world size 1: per batch `latent = encode(x)`, `x_rec = decode(latent)`;
+    latent_mean += latent.float().mean(); latent_scale += 1 / (latent.float().std() + 1e-8) (std over every element of the batch's latent, unbiased);
+    psnr += PSNR((x_rec + 1) / 2, (x + 1) / 2, "sum"); then psnr / num_samples (the dataset's size, not the images seen) and the two latent sums / batches."""
+    psnr = torch.zeros((), dtype=torch.float64)
+    mean = torch.zeros((), dtype=torch.float64)
+    scale = torch.zeros((), dtype=torch.float64)
+    nb = 0
+    for x in batches:
+        lat = encode(x)
+        rec = decode(lat)
+        lf = lat.float()
+        mean += lf.mean().double()
+        scale += (1 / (lf.std() + 1e-8)).double()
+        psnr += psnr_sum((rec + 1) / 2, (x + 1) / 2).double()
+        nb += 1
+    return {"PSNR": (psnr / num_samples).item(), "latent_mean": (mean / nb).item(), "latent_scale": (scale / nb).item()}

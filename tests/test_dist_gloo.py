@@ -232,3 +232,41 @@ def test_checkpoint_rng_single_process_round_trip():
     legacy = {"cpu": st["cpu"]}                               # round 3's unlabelled entry: a single-process checkpoint
     torch.manual_seed(9)
     assert train._set_rng_state(legacy) and torch.equal(torch.rand(4), want)
+
+
+def _eval_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dmvae_amd import dist, evaluate as E
+    from oracle.capture_golden_eval import StandInVAE, batches
+    dist.init_distributed_mode(backend="gloo")
+    vae = StandInVAE(5)
+    data = batches(6, [2, 3, 2, 1])                           # the evaluation set: four batches, eight images
+    mine = data[rank::world]                                  # each rank evaluates its shard (DistributedSampler-style)
+    r = E.evaluate(vae, mine, num_samples=8)
+    dist.barrier()
+    q.put((rank, r["PSNR"], r["latent_mean"], r["latent_scale"], r["batches"]))
+    torch.distributed.destroy_process_group()
+
+
+def test_evaluate_all_reduces_like_the_reference_two_ranks_gloo():
+    """train_tokenizer.py:357: psnr, latent_mean, latent_scale and the batch count are summed over the ranks before the divisions -- two ranks over two
+    shards must report what one process reports over the whole set."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dmvae_amd import evaluate as E
+    from oracle.capture_golden_eval import StandInVAE, batches
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    whole = E.evaluate(StandInVAE(5), batches(6, [2, 3, 2, 1]), num_samples=8)
+    for _, ps, lm, ls, nb in res:
+        assert nb == 4
+        assert abs(ps - whole["PSNR"]) < 1e-9 * abs(whole["PSNR"]) + 1e-12 and abs(lm - whole["latent_mean"]) < 1e-12 and abs(ls - whole["latent_scale"]) < 1e-9 * whole["latent_scale"]

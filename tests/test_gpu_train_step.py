@@ -390,3 +390,34 @@ def test_tokenizer_step_calls_no_library_gemm(monkeypatch):
         tr.step(x)
     log = tr.read_log()
     assert not called and log["rec_loss"] == log["rec_loss"]          # finite, and nothing tripped the guard
+
+
+def test_evaluate_on_the_hip_path_matches_the_oracle_reductions():
+    """dmvae_amd.evaluate.evaluate (train_tokenizer.py:324-367 without FID) with the real VAE on the HIP kernels under autocast: PSNR / latent_mean / latent_scale
+    equal the oracle's reductions (oracle/ref_cpu.py::eval_metrics) over the same encode / decode calls; the result feeds DMDTrainer / SamplePipeline."""
+    from dmvae_amd import evaluate as E
+    from dmvae_amd.models.vae import VAE
+    from oracle import ref_cpu as R
+    torch.manual_seed(41)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=256, depth=1, num_heads=4)).cuda()
+    g = torch.Generator().manual_seed(3)
+    data = [(torch.rand(b, 3, 256, 256, generator=g) * 2 - 1, torch.zeros(b, dtype=torch.long)) for b in (2, 1)]
+    r = E.evaluate(vae, data, num_samples=3)
+    assert vae.training and r["batches"] == 2 and r["images"] == 3
+
+    def enc(x):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return vae.encode(x)
+
+    def dec(z):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return vae.decode(z)
+    ro = R.eval_metrics(enc, dec, [x.cuda() for x, _ in data], 3)
+    for k in ("PSNR", "latent_mean", "latent_scale"):
+        assert abs(r[k] - ro[k]) <= 1e-5 * abs(ro[k]) + 1e-7, (k, r[k], ro[k])
+    assert r["PSNR"] == r["PSNR"] and 0 < r["latent_scale"] < 1e4
+    kw = E.latent_stats(r)
+    from dmvae_amd.sample import SamplePipeline  # noqa: F401  (the keywords are SamplePipeline's / DMDTrainer's constructor arguments: tests/test_oracle_eval.py)
+    assert set(kw) == {"latent_mean", "latent_scale"}
