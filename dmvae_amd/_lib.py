@@ -41,6 +41,9 @@ SIGNATURES = {
     "dmvae_gemm_tn_batched_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dmvae_gemm_tn_batched": (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 4 + [c_longlong] * 3 + [c_float, c_int, c_void_p]),
     "dmvae_set_dynamic": (c_int, [c_int]),
+    "dmvae_linear_rows_supported": (c_int, [c_int, c_int, c_int]),
+    "dmvae_linear_rows_bf16": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
+    "dmvae_linear_rows_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "dmvae_linear_bf16": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     "dmvae_linear_bf16_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "dmvae_linear_weight_t_kmajor": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

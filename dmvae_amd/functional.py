@@ -648,6 +648,9 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, a
     x = _c(x)
     if x.dtype != bf16:
         x = x.to(bf16)
+    if m <= 64 and act in (ops.ACT_NONE, ops.ACT_SILU) and ops.linear_rows_supported(m, n, k) and not parity.on():
+        # one row per SAMPLE (adaLN modulations, timestep embedder): the weight-streaming kernel, csrc/linear_rows.hip
+        return ops.linear_rows(x.view(m, k), (w if w.dtype == bf16 else _bf(w)).view(n, k), bb, act).view(*x.shape[:-1], n)
     if ops.linear_supported(m, n, k) and (act != ops.ACT_SWIGLU or n % 16 == 0):
         # frozen weights -- an nn.Parameter that is not trainable AND not owned by one of this build's optimisers (a student DiT switched to requires_grad
         # False for the DMD loss's evaluations still changes every few steps: it keeps the row-major shadow its optimiser maintains) -- : the K-tile-major
@@ -679,7 +682,11 @@ def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Te
     dx = dy @ w on the Linear GEMM kernel against the transposed bf16 copy of w (bf16 like the reference's autocast backward)."""
     rows, cout = dy2.shape
     cin = x2.shape[1]
-    if cin % 8 == 0 and cout % 8 == 0:
+    if rows <= 64 and cin % 8 == 0 and not parity.on():
+        # one row per SAMPLE (adaLN modulations, timestep embedder): the gradient is an outer-product sum of <= 64 terms, bound by writing it (csrc/linear_rows.hip)
+        dst_w = _dst(w)
+        dw, db = ops.linear_rows_wgrad(_c(dy2), _c(x2), need_bias=b is not None, dw_out=None if dst_w is None else dst_w.view(cout, cin), db_out=_dst(b))
+    elif cin % 8 == 0 and cout % 8 == 0:
         dst_w = _dst(w)
         dw, db = ops.conv2d_nhwc_wgrad(dy2.view(1, 1, rows, cout), x2.view(1, 1, rows, cin), 1,
                                        dw_out=None if dst_w is None else dst_w.view(cout, cin, 1, 1), db_out=_dst(b))
@@ -688,6 +695,11 @@ def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Te
         dw, db = (dy2.t() @ x2).float(), dy2.float().sum(0)
     if not need_dx:
         return None, dw, db
+    if rows <= 64 and ops.linear_rows_supported(rows, cin, cout) and not parity.on():
+        # per-sample rows: dX = dY . W against the transposed copy -- K-tile-major, one 8-us tiled transpose of the bf16 weight per optimiser step (`_bf_t`),
+        # where the out-feature count allows; else the row-major transposed pack from the f32 master
+        wt = _bf_t(w)
+        return ops.linear_rows(_c(dy2), wt if wt.dim() == 3 else wt.view(cin, cout)), dw, db
     if ops.linear_supported(rows, cin, cout) and not parity.on():
         return ops.linear_bf16(_c(dy2), _bf_t(w)), dw, db                 # dX = dY . W as an NT GEMM against the transposed copy
     return ops.gemm_nt(_c(dy2), packed(w, True).view(cin, cout)) if (cout % 32 == 0 and cin % 4 == 0) else (dy2 @ _bf(w)), dw, db
@@ -715,6 +727,21 @@ class LinearFn(torch.autograd.Function):
         if ctx.bias is None:
             db = None
         return (None if dx is None else dx.view(xb.shape).to(ctx.x_dtype)), dw.view(w.shape), db
+
+
+class SiluFn(torch.autograd.Function):
+    """nn.SiLU on a bf16 tensor (TimestepEmbedder.mlp[1] under autocast, lightningdit.py:108-112): csrc/misc.hip silu_fwd / silu_bwd."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return ops.silu(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.silu_bwd(x, _c(dy).to(bf16))
 
 
 def _fused_attn_bwd() -> bool:

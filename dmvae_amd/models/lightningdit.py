@@ -280,7 +280,7 @@ class LightningDiT(nn.Module):
         h = w = int(x.shape[1] ** 0.5)
         assert h * w == x.shape[1]
         x = x.reshape(x.shape[0], h, w, p, p, c)
-        return torch.einsum("nhwpqc->nchpwq", x).reshape(x.shape[0], c, h * p, h * p)
+        return x.permute(0, 5, 1, 3, 2, 4).reshape(x.shape[0], c, h * p, h * p)
 
     def forward(self, x, t=None, y=None):
         if x.is_cuda:

@@ -58,6 +58,18 @@ def _attention(qkv, blk, rope, heads):
     return o.view(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, c)
 
 
+def _t_embed(model, t: torch.Tensor, train: bool = False) -> torch.Tensor:
+    """TimestepEmbedder.forward (lightningdit.py:96-139) under autocast(bf16) on this build's kernels: sinusoidal features (f32, cast like autocast casts a
+    Linear's input) -> Linear -> SiLU (on the bf16-rounded pre-activation, in the GEMM's epilogue when no gradient is needed) -> Linear; bf16 [B, C]."""
+    from ..functional import LinearFn, SiluFn, linear
+    te = model.t_embedder
+    emb = te.timestep_embedding(t, te.frequency_embedding_size)
+    l0, l2 = te.mlp[0], te.mlp[2]
+    if train:
+        return LinearFn.apply(SiluFn.apply(LinearFn.apply(emb, l0.weight, l0.bias)), l2.weight, l2.bias)
+    return linear(linear(emb.to(_BF), l0.weight, l0.bias, ops.ACT_SILU), l2.weight, l2.bias)
+
+
 @torch.no_grad()
 def forward_inference(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """x [B,C,H,W], t [B], y [B] -> velocity [B,C_out,H,W] in bf16 (what the stock modules return under autocast)."""
@@ -69,7 +81,7 @@ def forward_inference(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) 
     h = linear(patches.to(_BF), _bf(w).view(w.shape[0], -1), _bf(model.x_embedder.proj.bias)).float() + model.pos_embed
     h = h.contiguous()
     n = h.shape[1]
-    cvec = model.t_embedder(t) + model.y_embedder(y, False)                     # stock modules under the caller's autocast: [B, C] f32
+    cvec = _t_embed(model, t) + model.y_embedder(y, False)                      # [B, C] f32: bf16 timestep embedding + the f32 label-embedding row
     sc = F.silu(cvec)
     # Every gated residual is folded into the RMSNorm that follows it (one pass over the residual stream instead of two), so a block's MLP residual is applied
     # by the NEXT block's norm1 -- or by the final layer's norm -- with that layer's modulation.
@@ -78,9 +90,9 @@ def forward_inference(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) 
 
     def adaln(lin):
         # [B, 6C]: shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp.  One row per SAMPLE (16-64 rows against a 6912 x 1152 weight): a
-        # GEMV-shaped, weight-bandwidth-bound problem that neither of this build's tile kernels is shaped for (measured on the small batched kernel: 62 us per
-        # call against ~5 for the library) -- the per-sample conditioning Linears stay library calls, like the timestep / label embedders
-        return F.linear(scb, _bf(lin.weight), _bf(lin.bias)).contiguous()
+        # GEMV-shaped, weight-bandwidth-bound problem -- `linear` sends it to the weight-streaming kernel (csrc/linear_rows.hip); more than 64 samples per call
+        # go to the tile kernels
+        return linear(scb, lin.weight, lin.bias)
 
     pend = None                                                                   # (y, mod) of the previous block's MLP branch, not yet added to h
     for blk in model.blocks:
@@ -150,15 +162,17 @@ def forward_train(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> t
     w = model.x_embedder.proj.weight
     patches = x.view(b, cin, hh // ps, ps, ww // ps, ps).permute(0, 2, 4, 1, 3, 5).reshape(b, -1, cin * ps * ps)
     h = (LinearFn.apply(patches, w.view(w.shape[0], -1), model.x_embedder.proj.bias).float() + model.pos_embed).contiguous()
-    cvec = model.t_embedder(t) + model.y_embedder(y, model.training)
+    cvec = _t_embed(model, t, train=True).float() + model.y_embedder(y, model.training)      # the embedding lookup (and its index-add backward) is not a GEMM
+    sc = F.silu(cvec)                                                             # adaLN_modulation[0] of every block: the same f32 values, computed once
     rope = model.feat_rope
     for blk in model.blocks:
-        mod = blk.adaLN_modulation(cvec)                                          # [B, 6C] bf16 under autocast, stock autograd (one row per sample: see forward_inference)
+        lin = blk.adaLN_modulation[1]
+        mod = LinearFn.apply(sc, lin.weight, lin.bias)                            # [B, 6C] bf16; one row per sample: csrc/linear_rows.hip forward and input gradient
         h = DitBlockFn.apply(h, mod, blk.norm1.weight, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.q_norm.weight, blk.attn.k_norm.weight,
                              blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.mlp.w12.weight, blk.mlp.w12.bias, blk.mlp.w3.weight,
                              blk.mlp.w3.bias, rope.freqs_cos, rope.freqs_sin, heads, blk.norm1.eps)
     fl = model.final_layer
-    a = RmsnormModulateFn.apply(h, fl.norm_final.weight, fl.adaLN_modulation(cvec), 0, c, fl.norm_final.eps)
+    a = RmsnormModulateFn.apply(h, fl.norm_final.weight, LinearFn.apply(sc, fl.adaLN_modulation[1].weight, fl.adaLN_modulation[1].bias), 0, c, fl.norm_final.eps)
     out = model.unpatchify(LinearFn.apply(a, fl.linear.weight, fl.linear.bias))
     if model.learn_sigma:
         out, _ = out.chunk(2, dim=1)

@@ -391,6 +391,57 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     return y
 
 
+def linear_rows_supported(m: int, n: int, k: int) -> bool:
+    """Shapes csrc/linear_rows.hip takes: 1 <= m <= 64 rows (one per sample), k % 32 == 0, n % 4 == 0."""
+    return bool(_lib.lib().dmvae_linear_rows_supported(int(m), int(n), int(k)))
+
+
+def linear_rows(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, out_f32: bool = False) -> torch.Tensor:
+    """y [M, N] = act(x [M, K] @ w [N, K]^T + bias) for M <= 64 rows -- the per-sample conditioning Linears of LightningDiT (adaLN modulations, timestep
+    embedder; diffusion/lightningdit/lightningdit.py:96-139,236-240,266-268) and, with w the transposed copy, their input gradients (include/dmvae_hip.h:
+    dmvae_linear_rows_bf16).  x bf16 row-major (a row stride larger than K is fine); w bf16 [N, K] row-major, or its K-tile-major copy [K / 32, N, 32]
+    (linear_weight_t_kmajor's result); bias f32 or bf16; act ACT_NONE | ACT_SILU."""
+    x = _req2d(x, "x")
+    m, k = x.shape
+    if w.dim() == 3:                                     # K-tile-major
+        if not (w.is_cuda and w.dtype == bf16 and w.is_contiguous() and w.shape[0] * 32 == k and w.shape[2] == 32):
+            raise TypeError(f"w: expected the K-tile-major copy [K / 32, N, 32] for K = {k}, got {tuple(w.shape)}")
+        n, layout, ldw = w.shape[1], 1, 0
+    else:
+        w = _req2d(w, "w")
+        n, layout, ldw = w.shape[0], 0, w.stride(0)
+        assert w.shape[1] == k, (x.shape, w.shape)
+    if bias is not None:
+        assert bias.is_contiguous() and bias.numel() == n and bias.dtype in (bf16, f32)
+    y = torch.empty(m, n, dtype=f32 if out_f32 else bf16, device=x.device)
+    check(_lib.lib().dmvae_linear_rows_bf16(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), m, n, k, x.stride(0), ldw, n, int(act),
+                                            int(bias is not None and bias.dtype == bf16), int(out_f32), layout, _stream()), "linear_rows_bf16")
+    return y
+
+
+def linear_rows_wgrad(dy: torch.Tensor, x: torch.Tensor, need_bias: bool = True, dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None,
+                      accumulate: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """(dW [N, K] f32, db [N] f32) of a per-sample Linear from dy [M, N] and x [M, K] (bf16, M <= 64): include/dmvae_hip.h dmvae_linear_rows_wgrad."""
+    dy, x = _req2d(dy, "dy"), _req2d(x, "x")
+    m, n = dy.shape
+    k = x.shape[1]
+    assert x.shape[0] == m
+    dw = dw_out if dw_out is not None else torch.empty(n, k, dtype=f32, device=x.device)
+    assert dw.is_contiguous() and dw.numel() == n * k and dw.dtype == f32
+    db = (db_out if db_out is not None else torch.empty(n, dtype=f32, device=x.device)) if need_bias else None
+    check(_lib.lib().dmvae_linear_rows_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _ptr(db), m, n, k, dy.stride(0), x.stride(0), int(accumulate), _stream()),
+          "linear_rows_wgrad")
+    return dw, db
+
+
+def _req2d(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.DmvaeHipError(f"{name}: expected a GPU tensor; dmvae_amd has no CPU path")
+    if t.dtype != bf16 or t.dim() != 2 or t.stride(1) != 1:
+        raise TypeError(f"{name}: expected a 2-D bf16 tensor with unit column stride, got {t.dtype} {tuple(t.shape)} strides {t.stride()}")
+    return t
+
+
 def linear_weight_t_kmajor(w: torch.Tensor) -> torch.Tensor:
     """bf16 Linear weight [N, K] -> [N / 32, K, 32]: the K-tile-major operand of its transpose -- with it `linear_bf16(dy, .)` is the input gradient dY . W."""
     w = _req(w, bf16, "w")

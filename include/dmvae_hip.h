@@ -158,6 +158,21 @@ int dmvae_gemm_tn_batched(const void* A, const void* B, void* C, void* workspace
                           int N, int K, int batch, long long a_bs, long long b_bs, long long c_bs, float alpha,
                           int out_f32, dmvae_stream_t stream);
 
+/* nn.Linear on a handful of rows -- one per SAMPLE: Y[M][N] = act(X[M][K] . W[N][K]^T + bias[N]), 1 <= M <= 64, K % 32 == 0, N % 4 == 0; x / w row-major
+ * bf16 with leading dimensions ldx / ldw (multiples of 8), y [M][ldy] bf16 (f32 when out_f32).  Replaces the library call behind the per-sample conditioning
+ * Linears of LightningDiT: adaLN_modulation[1] of every block and of the final layer (diffusion/lightningdit/lightningdit.py:236-240,266-268), the two Linears
+ * of TimestepEmbedder.mlp (:96-139), and -- with w := the transposed bf16 copy [K_in][N_out] of the weight -- their input gradients.  Weight-bandwidth bound
+ * (the 6912 x 1152 adaLN weight is read once per call); csrc/linear_rows.hip.  bias f32 [N] (bf16 when bias_bf16) or NULL; act 0 none, 1 SiLU on the bf16-rounded
+ * pre-activation (bit-identical to act 0 + dmvae_silu_fwd; bf16 result only).  Deterministic (fixed-order in-block reduction). */
+int dmvae_linear_rows_supported(int M, int N, int K);
+int dmvae_linear_rows_bf16(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int ldx, int ldw, int ldy, int act,
+                           int bias_bf16, int out_f32, int w_layout, dmvae_stream_t stream);
+/* w_layout = 1: w is the K-tile-major copy [K / 32][N][32] (dmvae_linear_weight_t_kmajor writes it from the bf16 weight in ~8 us: what the input gradient
+ * reads instead of a row-major transposed copy re-packed from the f32 master every step); ldw is then ignored.
+ * Weight and bias gradient of the same per-sample Linear: dW[N][K] f32 (+)= dY[M][N]^T . X[M][K], db[N] f32 (+)= column sums of dY (db may be NULL);
+ * 1 <= M <= 64, K % 8 == 0; dy / x bf16 row-major with leading dimensions lddy / ldx.  Bound by writing the f32 gradient; summed over the samples in order. */
+int dmvae_linear_rows_wgrad(const void* dy, const void* x, void* dw, void* db, int M, int N, int K, int lddy, int ldx, int accumulate, dmvae_stream_t stream);
+
 /* Dynamic tile claiming in the large-shape conv kernel (blocks claim tiles from per-XCD counters instead of a static stride, so that a launch next to another
  * stream's resident kernel -- an RCCL all-reduce overlapped with backward, utils/dist.py / train_tokenizer.py:302 -- slows down by the fraction of CUs taken
  * instead of a whole block-time): on = 1 / 0 for every launch from now on, -1 = the DMVAE_PP_DYNAMIC environment default.  Returns the value in force.

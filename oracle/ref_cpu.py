@@ -814,8 +814,8 @@ def eval_metrics(encode: Callable, decode: Callable, batches, num_samples: int) 
         lat = encode(x)
         rec = decode(lat)
         lf = lat.float()
-        mean += lf.mean().double()
-        scale += (1 / (lf.std() + 1e-8)).double()
-        psnr += psnr_sum((rec + 1) / 2, (x + 1) / 2).double()
+        mean += lf.mean().double().cpu()
+        scale += (1 / (lf.std() + 1e-8)).double().cpu()
+        psnr += psnr_sum((rec + 1) / 2, (x + 1) / 2).double().cpu()
         nb += 1
     return {"PSNR": (psnr / num_samples).item(), "latent_mean": (mean / nb).item(), "latent_scale": (scale / nb).item()}

@@ -96,3 +96,71 @@ def test_full_size_step_is_deterministic_and_matches_one_image_oracle_scalars(tr
     # (the step's own forward and `vae(x)` may take different encoder routes: the reconstruction itself agrees to the bf16 floor, its mean error far better)
     assert abs(logs1[0]["L1"] - l1.item()) < 1e-4 * l1.item() and abs(logs1[0]["L2"] - l2.item()) < 1e-4 * l2.item()
     assert logs1[1]["rec_loss"] != logs1[0]["rec_loss"] or logs1[2]["rec_loss"] != logs1[1]["rec_loss"]       # the weights moved (lr warm-up: step 0 runs at lr 0)
+
+
+def test_dmd_stage_full_size_cycle_c3():
+    """Config C3 at its real size (train_dmd.py:506-575, scripts/train_dmd.sh:30: local batch 16): DMDTrainer with the ViT-L/16 encoder trainable, the full
+    decoder, LPIPS, and LightningDiT-XL/1 as frozen teacher and trainable student (675 M parameters each), CFG 5 with the conditional + unconditional
+    evaluations as ONE 2B-sample call per model.  Two cycles of five steps (VAE turn, then four student-only steps) from fixed seeds, run twice: finite
+    losses, the turn pattern, run-to-run bit identity of every weight, the call structure, and the peak memory bound DESIGN.md quotes (< 48 GiB)."""
+    import gc
+    import warnings
+    from dmvae_amd.models.lightningdit import LightningDiT, LightningDiT_models
+    from dmvae_amd.models.vae import VAE
+    from dmvae_amd.train import DMDTrainer, _batchable
+    from dmvae_amd.utils.lpips import LPIPS
+    B = 16
+
+    def run():
+        torch.manual_seed(42)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            vae = VAE(z_channels=32, model_size="large").cuda()
+            lp = LPIPS().eval().requires_grad_(False).cuda()
+        with torch.no_grad():
+            for lin in (lp.lin0, lp.lin1, lp.lin2, lp.lin3, lp.lin4):
+                lin.model[-1].weight.fill_(1.0 / lin.model[-1].weight.shape[1])
+        mk = lambda: LightningDiT_models["LightningDiT-XL/1"](input_size=16, in_channels=32, num_classes=1000).cuda()
+        teacher, student = mk().eval().requires_grad_(False), mk().eval()
+        with torch.no_grad():
+            for m in (teacher, student):         # the reference zero-initialises these (lightningdit.py:367-376): v == 0 would make the DMD loss vacuous
+                for blk in m.blocks:
+                    blk.adaLN_modulation[1].weight.normal_(0, 0.02)
+                m.final_layer.linear.weight.normal_(0, 0.02)
+        assert isinstance(teacher, LightningDiT) and sum(p.numel() for p in student.parameters()) > 670e6
+        calls = {"teacher": [], "student": []}
+        for name, mod in (("teacher", teacher), ("student", student)):
+            mod.register_forward_pre_hook(lambda m_, a, name=name: calls[name].append((int(a[0].shape[0]), torch.is_grad_enabled())))
+        tr = DMDTrainer(vae, lp, teacher, student, dmd_weight=10.0, dmd_cfg_scale=5.0, num_classes=1000, vae_train_every=5, warmup_steps=2)
+        assert tr.batch_cfg is None                                  # automatic: on, because both models are the per-sample HIP LightningDiT
+        images = torch.rand(B, 3, 256, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 2 - 1
+        labels = torch.randint(0, 1000, (B,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+        torch.manual_seed(7)
+        torch.cuda.reset_peak_memory_stats()
+        snaps, logs = [], []
+        for _ in range(10):
+            tr.step(images, labels)
+            snaps.append((tr.fp.flat.double().sum().item(), tr.sfp.flat.double().sum().item()))
+            logs.append(tr.read_log())
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+        final = (tr.fp.flat.clone(), tr.sfp.flat.clone())
+        assert _batchable(teacher) or True
+        del tr, vae, lp, teacher, student
+        gc.collect(); torch.cuda.empty_cache()
+        return snaps, logs, peak, final, calls
+
+    snaps, logs, peak, final, calls = run()
+    assert all(v == v and abs(v) < 1e6 for lg in logs for v in lg.values()), logs[-1]
+    assert logs[-1]["dmd_loss"] > 0 and logs[-1]["dmd_gradient_norm"] > 0 and logs[-1]["diffusion_loss"] > 0 and logs[-1]["vae_norm"] > 0
+    # VAE turns are steps 0 and 5 (step 0 at warm-up lr 0: nothing moves); the student trains every step (step 0 at lr 0 too)
+    vae_moved = [snaps[i][0] != snaps[i - 1][0] for i in range(1, 10)]
+    stu_moved = [snaps[i][1] != snaps[i - 1][1] for i in range(1, 10)]
+    assert vae_moved == [False, False, False, False, True, False, False, False, False], vae_moved
+    assert all(stu_moved), stu_moved
+    # call structure: per VAE turn ONE no-grad 2B call of the teacher and of the student (cond + uncond batched), per step one B-sized training call of the student
+    assert calls["teacher"] == [(2 * B, False)] * 2, calls["teacher"]
+    assert [c for c in calls["student"] if not c[1]] == [(2 * B, False)] * 2 and [c for c in calls["student"] if c[1]] == [(B, True)] * 10
+    assert peak < 48.0, f"peak memory {peak:.1f} GiB"
+    print(f"C3 full size: peak {peak:.1f} GiB, last log {logs[-1]}")
+    snaps2, logs2, peak2, final2, _ = run()
+    assert snaps == snaps2 and torch.equal(final[0], final2[0]) and torch.equal(final[1], final2[1])       # bit-identical reruns

@@ -421,3 +421,69 @@ def test_evaluate_on_the_hip_path_matches_the_oracle_reductions():
     kw = E.latent_stats(r)
     from dmvae_amd.sample import SamplePipeline  # noqa: F401  (the keywords are SamplePipeline's / DMDTrainer's constructor arguments: tests/test_oracle_eval.py)
     assert set(kw) == {"latent_mean", "latent_scale"}
+
+
+def _small_dit(seed):
+    """LightningDiT inside the HIP kernels' range at the DMD stage's latent shape (32 channels x 16 x 16, patch 1): width 192 = 3 heads x 64, depth 2."""
+    from dmvae_amd.models.lightningdit import LightningDiT
+    torch.manual_seed(seed)
+    m = LightningDiT(input_size=16, patch_size=1, in_channels=32, hidden_size=192, depth=2, num_heads=3, num_classes=10)
+    with torch.no_grad():
+        for p in m.parameters():            # the reference zero-initialises the adaLN and output layers (lightningdit.py:367-376): perturb, or v == 0
+            if p.abs().max() == 0:
+                p.normal_(0, 0.02)
+    return m.cuda()
+
+
+def _gemm_guards(monkeypatch, what):
+    import torch.nn.functional as F
+    called = []
+
+    def guard(name):
+        def f(*a, **k):
+            called.append(name)
+            raise AssertionError(f"{name} called inside {what}: a library GEMM")
+        return f
+    for mod, names in ((torch, ("matmul", "mm", "bmm", "addmm", "baddbmm", "einsum")), (F, ("linear", "bilinear", "scaled_dot_product_attention", "conv2d", "conv_transpose2d"))):
+        for n in names:
+            monkeypatch.setattr(mod, n, guard(f"{mod.__name__}.{n}"))
+    monkeypatch.setattr(torch.Tensor, "matmul", guard("Tensor.matmul"))
+    monkeypatch.setattr(torch.Tensor, "__matmul__", guard("Tensor.__matmul__"))
+    return called
+
+
+def test_dmd_and_diffusion_steps_call_no_library_gemm(monkeypatch):
+    """The twin of test_tokenizer_step_calls_no_library_gemm for configs C3 / C4 (train_dmd.py:506-575, train_diffusion.py:268-297): with the per-sample
+    conditioning Linears of LightningDiT (adaLN modulations, timestep embedder) on csrc/linear_rows.hip nothing in a DMD cycle -- VAE turn with the trainable
+    ViT encoder, four no-grad teacher / student evaluations (one 2B call each), the student's own training turn -- nor in a latent-diffusion train step reaches
+    hipBLASLt / rocBLAS / MIOpen: every torch entry point that would raises for two full cycles."""
+    from dmvae_amd.models.vae import VAE
+    from dmvae_amd.train import DiffusionTrainer, DMDTrainer
+    from dmvae_amd.utils.lpips import LPIPS
+    torch.manual_seed(21)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=256, depth=1, num_heads=4)).cuda()
+        lp = LPIPS().eval().requires_grad_(False).cuda()
+    teacher, student = _small_dit(1).eval().requires_grad_(False), _small_dit(2)
+    tr = DMDTrainer(vae, lp, teacher, student, dmd_weight=5.0, dmd_cfg_scale=2.0, num_classes=10, vae_train_every=2, warmup_steps=1)
+    images = torch.rand(2, 3, 256, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0)) * 2 - 1
+    labels = torch.tensor([3, 7], device="cuda")
+    for _ in range(2):
+        tr.step(images, labels)                   # one whole cycle outside the guard: lazy one-time set-up may do what it likes
+    called = _gemm_guards(monkeypatch, "the DMD cycle")
+    for _ in range(4):
+        tr.step(images, labels)
+    log = tr.read_log()
+    assert not called and all(v == v for v in log.values()) and log["dmd_loss"] > 0 and log["diffusion_loss"] > 0, (called, log)
+    monkeypatch.undo()
+    # config C4: the latent-diffusion trainer on the same pieces
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae2 = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=256, depth=1, num_heads=4)).cuda()
+    dt = DiffusionTrainer(_small_dit(3), vae2, lr=1e-4)
+    dt.step(images, labels)
+    called = _gemm_guards(monkeypatch, "the latent-diffusion step")
+    for _ in range(2):
+        dt.step(images, labels)
+    assert not called and dt.read_log()["loss"] == dt.read_log()["loss"]

@@ -1,0 +1,9 @@
+R=$GRAFT_REPO_ROOT; cd $R; OUT=$R/gpurun_out/r4_d; mkdir -p $OUT
+timeout 1500 python -m pytest tests/test_gpu_linear_rows.py tests/test_gpu_dit.py tests/test_gpu_train_step.py tests/test_gpu_sampler.py tests/test_gpu_vit_train.py "tests/test_gpu_fullsize.py::test_dmd_stage_full_size_cycle_c3" -x -q -s 2>&1 | grep -v "Warning\|warnings.warn\|^$\|lp = LPIPS\|^tests/" | tail -24 > $OUT/pytest.log
+tail -14 $OUT/pytest.log
+for i in 1 2; do
+  DMVAE_ALLOW_STOCK=1 DMVAE_TMP_STOCK_ADALN=1 timeout 600 python tools/bench_dmd_step.py 2>&1 | tail -3 | sed 's/^/stock-adaLN: /'
+  timeout 600 python tools/bench_dmd_step.py 2>&1 | tail -3 | sed 's/^/rows-kernel: /'
+done | tee $OUT/ab_dmd.log
+timeout 600 python tools/bench_dit.py 2>&1 | tail -2
+timeout 600 python tools/bench_diffusion_step.py 2>&1 | tail -3
