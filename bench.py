@@ -414,7 +414,7 @@ def main():
         return
     frac_timed = len(range(0, args.steps, max(1, args.time_every))) / max(1, args.steps)     # share of the timed steps that carried the per-launch events
     # the plain 256x256 instantiation; its dynamic-tile-claiming twin (DYN = true) when more than one rank runs (dmvae_amd/dist.py sets DMVAE_PP_DYNAMIC)
-    # (its kx-halo form, HALO = true, unless DMVAE_PP_HALO=0: the 3x3 launches; the 1x1 launches of the same tile stay on the HALO = false instantiation)
+    # (its kx-halo form, HALO = true: the 3x3 launches; the 1x1 launches of the same tile stay on the HALO = false instantiation)
     DOMINANT = "conv_pp_kernel<256, 256, 2, 4, 4, false, false, true, false, false, %s, false, %s>" % (
         "true" if os.environ.get("DMVAE_PP_DYNAMIC", "0") not in ("", "0") else "false", "true" if ops._PP_HALO else "false")
     per = {}

@@ -61,13 +61,9 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned flat, unsigned total) {
 }
 
 // 16-B load of a tensor this kernel reads ONCE: non-temporal, so that a streaming pass does not push the conv kernels' re-read operands out of L2 / the Infinity
-// Cache (csrc/groupnorm.hip: -0.46 ms per step and 7-10 % on the passes themselves).  DMVAE_STREAM_NT=0 restores plain loads (A/B builds).
-#ifndef DMVAE_STREAM_NT
-#define DMVAE_STREAM_NT 1
-#endif
+// Cache (csrc/groupnorm.hip: -0.46 ms per step and 7-10 % on the passes themselves).
 __device__ __forceinline__ bf16x8 dmvae_ldnt8(const bf16* p) {
-  if constexpr (DMVAE_STREAM_NT) return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
-  else return *reinterpret_cast<const bf16x8*>(p);
+  return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
 }
 __device__ __forceinline__ unsigned dmvae_pack_bf16x2(float a, float b) {
   bf16x2 t = {(bf16)a, (bf16)b};

@@ -231,7 +231,7 @@ template <int BK, bool F32, int TMk = 128, int TPk = 128>
 int launch(const ConvArgs& a_in, hipStream_t st, int batch = 1) {
   ConvArgs a = a_in;
   a.ctiles = (a.Cout + TMk - 1) / TMk;
-  { const char* e = getenv("DMVAE_KORDER"); a.korder = e ? atoi(e) : 1; }
+  a.korder = 1;      // channel chunk outer, tap inner
   dim3 grid(((a.M + TPk - 1) / TPk) * a.ctiles, 1, batch);
   const int lds = 2 * (TMk + TPk) * Geo<BK>::ROWB;
   static bool attr_done = false;
@@ -326,7 +326,7 @@ extern "C" int dmvae_conv2d_nhwc_fwd(const void* x, const void* w, const void* b
   DMVAE_CHECK_ARG(M < (1ll << 31) / 4, "conv2d_nhwc_fwd: too many pixels");
   a.M = (int)M;
   const bool f32 = d->out_f32 != 0;
-  static const bool narrow_ok = [] { const char* e = getenv("DMVAE_CONV_NARROW"); return e ? atoi(e) != 0 : true; }();
+  constexpr bool narrow_ok = true;
   if (narrow_ok && a.Cout <= 32 && a.Cin % 64 == 0 && a.M >= 4096)   // a handful of output channels: 32-row cout tile
     return f32 ? launch<64, true, 32, 256>(a, stream) : launch<64, false, 32, 256>(a, stream);
   if (a.Cin % 64 == 0) return f32 ? launch<64, true>(a, stream) : launch<64, false>(a, stream);
@@ -353,7 +353,7 @@ extern "C" int dmvae_conv2d_nhwc_fwd_gnstats(const void* x, const void* w, const
   DMVAE_CHECK_ARG(dmvae_conv_geometry(d, &ho, &wo, &g0, &g1, &g2, &g3) == 0, "conv2d_nhwc_fwd_gnstats: unsupported conv descriptor");
   DMVAE_CHECK_ARG(workspace_bytes >= dmvae_conv2d_nhwc_fwd_gnstats_workspace(d, groups) && dmvae_groupnorm_workspace(d->n, ho * wo, d->cout, groups) > 0,
                   "conv2d_nhwc_fwd_gnstats: workspace too small or unsupported GroupNorm shape (n=%d hw=%d c=%d groups=%d)", d->n, ho * wo, d->cout, groups);
-  static const bool fuse = [] { const char* e = getenv("DMVAE_GN_STATS_FUSED"); return e ? atoi(e) != 0 : true; }();
+  constexpr bool fuse = true;
   if (fuse && d->ks != 0 && d->cin % 32 == 0 && d->cout % 4 == 0 && d->act >= 0 && d->act <= 4 && (d->act != 3 || residual)) {
     int tp = 0;
     const int r = dmvae_conv_pp_try(x, w, bias, residual, y, d, stream, (float*)workspace, groups, &tp);

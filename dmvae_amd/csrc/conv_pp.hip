@@ -18,7 +18,7 @@
 //
 //   * plain 3x3 convs with a bf16 result run the HALO instantiations (described at the kernel template): the three kx taps of a (channel chunk, ky) read one
 //     staged halo of the pixel tile, the weights come K-tile-major (dmvae_conv_desc.w_layout = 1) so that a weight tile is whole 128-B lines; tiles 256 x 256,
-//     128 x 512 and, for 64 output channels, 64 x 1024.  What that was worth, and the timing experiments behind it (DMVAE_PP_EXP): DESIGN.md 8.12 / 8.13.
+//     128 x 512 and, for 64 output channels, 64 x 1024.  What that was worth, and the timing experiments behind it: DESIGN.md 8.12 / 8.13.
 //
 // Hazards (B_k = k-th workgroup barrier; group 0 = waves 0-3, group 1 = waves 4-7, one barrier behind):
 //   RAW  tile t+1 is read after B_{2t+2}; every wave waits (vmcnt) for its own pieces of t+1 at the end of its LOAD(t),
@@ -27,42 +27,15 @@
 //        retired by lgkmcnt(0) before B_{2t}.
 #include "common.h"
 #include "dmvae_hip.h"
-#ifndef DMVAE_PP_PRIO_MODE
-#define DMVAE_PP_PRIO_MODE 1   // 0: s_setprio 1 / 0 around every COMPUTE interval (round 1); 1: static priority 1 for the second-dispatched wave group; 2: none
-#endif
 #include <cstdlib>
 #include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
 
-#ifndef DMVAE_PP_EXP
-#define DMVAE_PP_EXP 0
-#endif
-#ifndef DMVAE_PP_DIRECT   // 1: the HALO instantiations store straight from the accumulators (pixels as MFMA rows, permuted weight rows; see the kernel); 0: LDS-staged epilogue (A/B builds)
-#define DMVAE_PP_DIRECT 1
-#endif
-#ifndef DMVAE_PP_LGKM_BUILTIN   // 1: the K loop's lgkmcnt(0) through the builtin (the MFMAs then issue as one run; gemm_pp.hip does the same); 0: inline asm + 8 compiler-placed waits between them
-#define DMVAE_PP_LGKM_BUILTIN 1
-#endif
-// 1: the halo + direct-epilogue instantiations run ONE continuous K-tile stream per block (see STREAM below).  Built, bit-identical (the conv tests pass on it), and
-// measured step-neutral (66.01 / 66.19 vs 65.98 / 66.16 ms): what a tile boundary costs is the WRITE BURST -- all 256 CUs reach their epilogues together, 32 MB of
-// stores queue on HBM for ~10 k cycles, and the first counted vmcnt wait of the next tile (stores and loads share the counter) sits behind them wherever it is put.
-#ifndef DMVAE_PP_STREAM
-#define DMVAE_PP_STREAM 0
-#endif
-#ifndef DMVAE_PP_STAGGER
-#define DMVAE_PP_STAGGER 0
-#endif
-#ifndef DMVAE_PP_ST_AUX   // cache-policy bits of the direct epilogue's output stores: 1 = sc0, 2 = nt, 16 = sc1 (A/B builds)
-#define DMVAE_PP_ST_AUX 2
-#endif
-#ifndef DMVAE_PP_AUXA   // cache-policy bits of the HALO loop's LDS-DMA (weights / activations): 1 = sc0, 2 = nt, 16 = sc1; A/B builds only
-#define DMVAE_PP_AUXA 0
-#endif
-#ifndef DMVAE_PP_AUXB
-#define DMVAE_PP_AUXB 0
-#endif
+// What was measured on this kernel and not adopted (each a source variant at the time, bit-identical where it computed the same thing) is kept as text, not as
+// code: DESIGN.md 8.12 / 8.13 (the timing experiments behind the kx-halo form), 9.3 (LDS-staged against direct epilogue), 9.6 (one continuous K-tile stream per block,
+// staggered XCD starts, cache-policy bits of the epilogue's stores and of the LDS-DMA: nt stores, plain DMA).
 
 namespace dmvae_conv_pp {
 
@@ -128,7 +101,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // f64 (groupnorm.hip::stats_from_quads_kernel).  Its own instantiation: the plain kernel's code is unchanged.
 // HALO (plain 3x3, stride 1): the three kx taps of a (channel chunk, ky) read the SAME pixels shifted by one, so the activation operand of three consecutive
 // K tiles is staged once, as the TP + 2 flat pixels m0 - 1 .. m0 + TP of source row offset ky - 1 (TP / 16 + 1 pieces instead of 3 * TP / 16), and tap kx
-// reads pixel p's fragment from halo row p + kx.  The timing experiment DMVAE_PP_EXP=256 (the same instruction stream with two of three activation pieces
+// reads pixel p's fragment from halo row p + kx.  A timing experiment (the same instruction stream with two of three activation pieces
 // masked) measured +12-14 % on the decoder's shapes: what the L2 -> LDS staging costs this kernel scales with the bytes it moves.
 //   * x edges: the flat neighbour of an image row's first / last pixel belongs to another row; those lanes' fragment addresses point at an all-zero row
 //     of the halo slot instead (rows TP + 2 .. TP + 15 of the last piece are out-of-range lanes of the DMA, which writes zeros for them);
@@ -164,10 +137,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   // couts of that pixel: one store instruction writes 4 pixel rows x 256 (128) contiguous bytes with consecutive lanes on consecutive bytes -- no LDS
   // round trip (the staged epilogue wrote and re-read the tile in f32: 256 + 256 KB of LDS traffic and ~12 k cycles per 256 x 256 tile; first built and
   // measured in gemm_pp.hip, whose header has the numbers).  Same sums in the same order: results are bit-identical to the staged epilogue's.
-  constexpr bool DIRECT = HALO && !OUT_F32 && DMVAE_PP_DIRECT;
-  // STREAM: one continuous K-tile stream per block (gemm_pp.hip): the last three K steps of a tile issue the NEXT tile's first three K tiles, everything has landed
-  // before the stores go out, and nothing at the tile boundary waits for the stores to retire (DMVAE_PP_STREAM=0 restores the issue-around-the-epilogue form)
-  constexpr bool STREAM = DIRECT && DMVAE_PP_STREAM;
+  constexpr bool DIRECT = HALO && !OUT_F32;   // the HALO instantiations store straight from the accumulators (pixels as MFMA rows, permuted weight rows); the others stage through LDS
   constexpr int BM16 = BM * 2, BP16 = BP * 2;  // 16x16 MFMA blocks per wave (v_mfma_f32_16x16x32_bf16: measured 5 % less power per flop than 32x32x16,
                                                // tools/probes/probe_wavetile.hip arm D -- and the kernel is power-limited)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -212,8 +182,6 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   unsigned rowo[UPS ? NPB : 1][3], colo[UPS ? NPB : 1][3];
   unsigned ctrH[HALO ? NPH : 1], mskH[HALO ? NPH : 1];   // HALO: byte offset of the lane's halo pixel (ky = 0 row), bit ky set when that row is inside the image
   int it_ky = 0;                                         // HALO: the issue state is (it_ch, it_ky) + the compile-time kx
-  int iss = 0, ish = 0;                                  // STREAM: A slot / halo slot the next issued K tile goes to (continuous across tiles)
-  int ka_s = 0, sh_s = 2 * TILE_A;                       // STREAM: A slot index / halo slot offset the next K step reads
   int it = 0, it_tap = 0, it_ch = 0;  // DMA issue state (wave-uniform): tile `it` = (tap it_tap, channel chunk it_ch)
   unsigned soffB_tap = 0;
   auto setup = [&](unsigned work) {
@@ -241,11 +209,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
         co = n0 + wmr * CW_ + BM16 * (rr & 15) + (rr >> 4);
       }
       const int c = (lane_s & 3) ^ swz64(row);  // logical 16-B chunk this lane fetches (LDS image stays lane-linear)
-#if DMVAE_PP_EXP & 512   // timing experiment: the weight tile's 64-B rows contiguous in memory (whole 128-B lines; wrong data)
-      voffA[p] = (co < a.Cout && row < TM) ? (unsigned)co * 64u + c * 16u : SENT;
-#else
       voffA[p] = (co < a.Cout && row < TM) ? (unsigned)co * a.wsRow + c * 16u : SENT;     // wsRow / wsTap / wsChunk: tap-major [cout][T][cin] or K-tile-major [cin / 32][T][cout][32]
-#endif
     }
     if constexpr (HALO) {
 #pragma unroll
@@ -264,11 +228,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
           // outside the tensor (the descriptor's range check does not see the scalar offset): not fetched
           if ((i == 0 && x == 0) || (i == TP + 1 && x == a.Wo - 1)) mask = 0;
         }
-#if DMVAE_PP_EXP & 1024   // timing experiment: the halo's 64-B rows contiguous in memory
-        ctrH[q] = (unsigned)(m0 + i) * 64u + c * 16u;
-#else
         ctrH[q] = (unsigned)(m0 + i) * a.Cin * 2u + c * 16u;   // relative to the descriptor base, which sits Wi + 1 pixels in front of the tensor
-#endif
         mskH[q] = mask;
       }
     } else {
@@ -379,46 +339,26 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   // issue this wave's pieces of tile `it` into the ring slot at byte offset `slot` (wave-uniform); past the last tile issue
   // all-zero pieces so that the vmcnt bookkeeping stays uniform (an out-of-range piece moves no memory)
   auto issue = [&](int slot) {
-#if DMVAE_PP_EXP & 32
-    const bool live = it < 0;
-#else
     const bool live = it < nK;
-#endif
     if (live && (KO || it_ch == 0)) new_tap();
     unsigned soA = (unsigned)it_tap * a.wsTap + (unsigned)it_ch * a.wsChunk;
     if constexpr (SUB)  // tap (py + 2a, px + 2b) of the 4x4 operand
       soA = (unsigned)((((par >> 1) + (it_tap & 2)) << 2) + (par & 1) + ((it_tap & 1) << 1)) * a.wsTap + (unsigned)it_ch * a.wsChunk;
     unsigned soB = soffB_tap + (unsigned)it_ch * 64u;
-#if DMVAE_PP_EXP & 256   // timing experiment: the traffic of a kx-halo form -- activation pieces move memory for one tap in three, the others are issued masked
-    const bool live_b = it_tap == 0 || it_tap == 3 || it_tap == 6;
-#else
     constexpr bool live_b = true;
-#endif
     // GEN: the tap offset and the chunk counter end up in VGPRs (phis of VALU-computed values) and every piece issue became a readfirstlane
     // waterfall loop; pin the two wave-uniform offsets to SGPRs (the plain instantiation's code is unchanged)
     if constexpr (GEN) {
       soA = (unsigned)__builtin_amdgcn_readfirstlane((int)soA);
       soB = (unsigned)__builtin_amdgcn_readfirstlane((int)soB);
     }
-#if DMVAE_PP_EXP & 128   // timing experiment: the same number of DMA instructions moving a quarter of the bytes (4 B per lane)
-#pragma unroll
-    for (int p = 0; p < NPA; p++)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + slot + (wave * NPA + p) * 1024), 4, live ? voffA[p] : SENT, soA, 0, 0);
-#pragma unroll
-    for (int p = 0; p < NPB; p++)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + TILE_A + (wave * NPB + p) * 1024), 4, live ? selB[p] : SENT, soB, 0, 0);
-#else
 #pragma unroll
     for (int p = 0; p < NPA; p++)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + slot + (wave * NPA + p) * 1024), 16, live ? voffA[p] : SENT, soA, 0, 0);
 #pragma unroll
     for (int p = 0; p < NPB; p++)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + TILE_A + (wave * NPB + p) * 1024), 16, (live && live_b) ? selB[p] : SENT, soB, 0, 0);
-#endif
     it++;
-#if DMVAE_PP_EXP & 64   // timing experiment: every K tile re-loads the tile's FIRST K tile (real L2 -> LDS transfers, no new lines from HBM / the fabric)
-    return;
-#endif
     if (KO) {  // channel chunk outer, tap inner: the nine taps of a chunk re-read (shifted) the same activation lines back to back
       if (++it_tap == T) { it_tap = 0; it_ch++; }
     } else {
@@ -431,21 +371,19 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     constexpr int KX = decltype(KXc)::value;
     const bool live = it < nK;
     const unsigned soA = (unsigned)(it_ky * 3 + KX) * a.wsTap + (unsigned)it_ch * a.wsChunk;
-    const int isl = STREAM ? iss : it;      // STREAM: the A-slot counter runs on across tiles (a tile issues exactly as many K tiles as it reads)
+    const int isl = it;
     const int da = ((isl >> 1) & 1) * GROUP + (isl & 1) * TILE_A;
-    if constexpr (STREAM) iss = (iss + 1) & 3;
 #pragma unroll
     for (int p = 0; p < NPA; p++)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + ((wave * NPA + p) * 16 < TM ? da + (wave * NPA + p) * 1024 : DUMP_OFF)), 16, live ? voffA[p] : SENT, soA, 0, DMVAE_PP_AUXA);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + ((wave * NPA + p) * 16 < TM ? da + (wave * NPA + p) * 1024 : DUMP_OFF)), 16, live ? voffA[p] : SENT, soA, 0, 0);
     if constexpr (KX == 0) {
       const unsigned soH = (unsigned)(it_ky * a.Wi) * a.Cin * 2u + (unsigned)it_ch * 64u;
-      const int dh = (STREAM ? ish : ((it_ch + it_ky) & 1)) * GROUP + 2 * TILE_A;
-      if constexpr (STREAM) ish ^= 1;
+      const int dh = ((it_ch + it_ky) & 1) * GROUP + 2 * TILE_A;
 #pragma unroll
       for (int q = 0; q < NPH; q++) {
         const unsigned v = (live && ((mskH[HALO ? q : 0] >> it_ky) & 1u)) ? ctrH[HALO ? q : 0] : SENT;
         const int dst = q < NPB ? dh + (wave * NPB + q) * 1024 : (wave == 0 ? dh + TP * 64 : DUMP_OFF);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + dst), 16, v, soH, 0, DMVAE_PP_AUXB);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + dst), 16, v, soH, 0, 0);
       }
     }
     it++;
@@ -457,11 +395,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
 
   // ---- persistent tile loop ---------------------------------------------------------------------------------------------
   auto stamp = [&](unsigned work, int k) {
-    #ifdef DMVAE_PP_TRACE
-    if (a.dbg && tid == 0) a.dbg[(size_t)work * 16 + k] = __builtin_amdgcn_s_memtime();
-#else
     if (a.dbg && tid == 0) a.dbg[(size_t)work * 8 + k] = __builtin_amdgcn_s_memtime();
-#endif
   };
   // DYN: thread 0 claims the tile AFTER the one being started and publishes it; every wave picks it up with the trailing DMA wait of the main loop
   auto claim = [&]() {
@@ -477,18 +411,11 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       __hip_atomic_store(a.sched + 16 + blockIdx.x, flat, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // read back by this block's own waves only
     }
   };
-#if DMVAE_PP_STAGGER   // experiment: offset the XCDs' start by DMVAE_PP_STAGGER x 64 cycles each, so that the chip's epilogue write bursts do not all begin together
-  if constexpr (HALO) {
-    const unsigned xs = blockIdx.x & 7u;
-    for (unsigned k = 0; k < xs; k++) __builtin_amdgcn_s_sleep(DMVAE_PP_STAGGER);
-  }
-#endif
   stamp(blockIdx.x, 0);
   setup(blockIdx.x);
   stamp(blockIdx.x, 1);
   if constexpr (HALO) {
     issue_h(K0_{}); issue_h(K1_{}); issue_h(K2_{});
-    if constexpr (STREAM) wait_vmcnt<0>();   // every tile starts with its first three K tiles landed (later ones: the previous tile's loop end)
   } else {
 #pragma unroll
     for (int u = 0; u < PF; u++) issue(u * SLOT);
@@ -522,52 +449,32 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     for (int j = 0; j < BP16; j++)
 #pragma unroll
       for (int r = 0; r < 4; r++) acc[i][j][r] = 0.f;
-  if constexpr (!STREAM) wait_vmcnt<HALO ? 2 * NPA : (PF - 1) * NP>();   // STREAM: landed already, and a wait here would be a wait for the previous tile's stores
+  wait_vmcnt<HALO ? 2 * NPA : (PF - 1) * NP>();
   __builtin_amdgcn_s_barrier();                // B_0: everybody's pieces of tile 0 have landed
   stamp(work, 2);
-#if DMVAE_PP_PRIO_MODE == 1
   if (grp == 1) __builtin_amdgcn_s_setprio(1);  // static priority for the second-dispatched half, no per-interval flips (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-#endif
   if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger group 1 by one interval
 
   // ---- main loop ------------------------------------------------------------------------------------------------------
   bf16x8 af[BM16], bfr[BP16];
-#if DMVAE_PP_EXP & 2
-  for (int i = 0; i < BM16; i++) for (int e = 0; e < 8; e++) af[i][e] = (bf16)(0.001f * (float)(lane + i));
-  for (int j = 0; j < BP16; j++) for (int e = 0; e < 8; e++) bfr[j][e] = (bf16)(0.002f * (float)(lane + j));
-#endif
   int slot_rd = 0, slot_wr = PF * SLOT;
-#ifdef DMVAE_PP_TRACE
-  unsigned long long trace_w1 = 0, trace_w2 = 0, trace_load = 0, trace_comp = 0, trace_last = __builtin_amdgcn_s_memtime();
-#endif
   unsigned next_dyn = 0;
-  unsigned next_s = 0;       // STREAM: the next tile is known (and set up) three K steps before the loop ends
-  bool has_next_s = false;
   if constexpr (HALO) {
-    int ka = STREAM ? ka_s : 0, sh = STREAM ? sh_s : 2 * TILE_A;   // A slot index and halo slot offset being read
-    auto ktile = [&](auto KXc, auto NOWAITc) __attribute__((always_inline)) {
+    int ka = 0, sh = 2 * TILE_A;   // A slot index and halo slot offset being read
+    auto ktile = [&](auto KXc) __attribute__((always_inline)) {
       constexpr int KX = decltype(KXc)::value;
-      constexpr bool NOWAIT = decltype(NOWAITc)::value;
       const char* sa = smem + ((ka >> 1) & 1) * GROUP + (ka & 1) * TILE_A;
       const char* sb = smem + sh;
-#if !(DMVAE_PP_EXP & 2)   // the timing experiments of the per-tap loop below: 1 = no DMA issue in the K loop, 2 = no fragment reads
 #pragma unroll
       for (int j = 0; j < BP16; j++) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + boffk[HALO ? KX : 0][HALO ? j : 0]);
 #pragma unroll
       for (int i = 0; i < BM16; i++) af[i] = *reinterpret_cast<const bf16x8*>(sa + aoff[i]);
-#endif
-#if !(DMVAE_PP_EXP & 1)
       issue_h(KXc);   // tile t + 3: the same kx
-#endif
       ka++;
       if constexpr (KX == 2) sh = sh == 2 * TILE_A ? GROUP + 2 * TILE_A : 2 * TILE_A;
-      if constexpr (!NOWAIT) wait_vmcnt<KX == 2 ? 2 * NPA : 2 * NPA + NPH>();  // own pieces of the NEXT tile have landed: what may stay in flight is tiles t + 2 and t + 3
-#if DMVAE_PP_LGKM_BUILTIN
+      wait_vmcnt<KX == 2 ? 2 * NPA : 2 * NPA + NPH>();  // own pieces of the NEXT tile have landed: what may stay in flight is tiles t + 2 and t + 3
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) through the builtin: the compiler sees the fragments have arrived and puts no lgkmcnt waits of its own between the MFMAs
       asm volatile("" ::: "memory");
-#else
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -582,97 +489,41 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     };
-    using W_ = std::false_type; using NW_ = std::true_type;
-    if constexpr (STREAM) {
-      // K tiles 1 and 2 landed before the tile began: the first two steps wait for nothing -- a counted wait there would count the previous tile's stores.  The
-      // third step's wait is the first one that forces them to have retired, two K steps after they were issued.
-      ktile(K0_{}, NW_{}); ktile(K1_{}, NW_{}); ktile(K2_{}, W_{});
 #pragma unroll 1
-      for (int t = 3; t < nK - 3; t += 3) { ktile(K0_{}, W_{}); ktile(K1_{}, W_{}); ktile(K2_{}, W_{}); }
-      if constexpr (DYN) next_dyn = __hip_atomic_load(a.sched + 16 + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);  // published >= one barrier ago
-      next_s = DYN ? (unsigned)__builtin_amdgcn_readfirstlane((int)next_dyn) : work + gridDim.x;
-      has_next_s = next_s < (unsigned)a.total;
-      if (has_next_s) {
-        stamp(next_s, 0);
-        setup(next_s);          // this tile has issued all of its K tiles: the issue state moves on to the next tile
-        stamp(next_s, 1);
-      } else {
-        it = nK;                // nothing follows: the last three steps issue out-of-range pieces
-        it_ky = it_ch = 0;
-      }
-      ktile(K0_{}, W_{}); ktile(K1_{}, W_{}); ktile(K2_{}, W_{});      // ... and the next tile's K tiles 0, 1, 2
-      ka_s = ka & 3; sh_s = sh;
-    } else {
-#pragma unroll 1
-      for (int t = 0; t < nK; t += 3) { ktile(K0_{}, W_{}); ktile(K1_{}, W_{}); ktile(K2_{}, W_{}); }
-    }
+    for (int t = 0; t < nK; t += 3) { ktile(K0_{}); ktile(K1_{}); ktile(K2_{}); }
   } else {
 #pragma unroll 1
   for (int t = 0; t < nK; t++) {
     // LOAD interval
     const char* sb = smem + slot_rd;
-#if !(DMVAE_PP_EXP & 2)   // timing experiments (tools/probes/build_variant.sh): 1 = no DMA issue in the K loop, 2 = no fragment reads, 8 = no epilogue stores, 32 = all pieces masked
 #pragma unroll
     for (int j = 0; j < BP16; j++) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + boff[j]);
 #pragma unroll
     for (int i = 0; i < BM16; i++) af[i] = *reinterpret_cast<const bf16x8*>(sb + aoff[i]);
-#endif
-#if !(DMVAE_PP_EXP & 1)
     issue(slot_wr);
-#endif
     slot_rd = slot_rd + SLOT == NBUF * SLOT ? 0 : slot_rd + SLOT;
     slot_wr = slot_wr + SLOT == NBUF * SLOT ? 0 : slot_wr + SLOT;
     wait_vmcnt<(PF - 1) * NP>();  // own pieces of the NEXT tile have landed
-#if DMVAE_PP_LGKM_BUILTIN
     __builtin_amdgcn_s_waitcnt(0xC07F);
     asm volatile("" ::: "memory");
-#else
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
     __builtin_amdgcn_sched_barrier(0);
-#ifdef DMVAE_PP_TRACE
-    const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
-#endif
     __builtin_amdgcn_s_barrier();
-#ifdef DMVAE_PP_TRACE
-    const unsigned long long tb1 = __builtin_amdgcn_s_memtime();
-    trace_w1 += tb1 - tb0; trace_load += tb0 - trace_last; trace_last = tb1;
-#endif
     __builtin_amdgcn_sched_barrier(0);
     // COMPUTE interval (issuing the DMA from here, in the MFMA shadow, measured 5-8 % slower than from the LOAD interval)
-#if DMVAE_PP_PRIO_MODE == 0
-    __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
     for (int i = 0; i < BM16; i++)
 #pragma unroll
       for (int j = 0; j < BP16; j++)  // in-place accumulate in the AGPR half of the register file
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[i]), "v"(bfr[j]));
-#if DMVAE_PP_PRIO_MODE == 0
-    __builtin_amdgcn_s_setprio(0);
-#endif
     __builtin_amdgcn_sched_barrier(0);
-#ifdef DMVAE_PP_TRACE
-    const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
-#endif
     __builtin_amdgcn_s_barrier();
-#ifdef DMVAE_PP_TRACE
-    const unsigned long long tc1 = __builtin_amdgcn_s_memtime();
-    trace_w2 += tc1 - tc0; trace_comp += tc0 - trace_last; trace_last = tc1;
-#endif
     __builtin_amdgcn_sched_barrier(0);
   }
   }
-#ifdef DMVAE_PP_TRACE
-  if (a.dbg && (tid == 0 || tid == 256)) {   // per tile: [load, wait after load, compute issue, wait after compute] for wave 0 (slots 8..11) and wave 4 (12..15)
-    unsigned long long* q = a.dbg + (size_t)work * 16 + 8 + (tid >> 8) * 4;
-    q[0] = trace_load; q[1] = trace_w1; q[2] = trace_comp; q[3] = trace_w2;
-  }
-#endif
   stamp(work, 3);
   if (grp == 0) __builtin_amdgcn_s_barrier();  // matches group 1's extra barrier
-  if constexpr (DYN && !STREAM) next_dyn = __hip_atomic_load(a.sched + 16 + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);  // published >= one barrier ago
-  wait_vmcnt<0>();                             // the trailing all-zero pieces; STREAM: the next tile's first three K tiles -- landed before this tile's stores go out
+  if constexpr (DYN) next_dyn = __hip_atomic_load(a.sched + 16 + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);  // published >= one barrier ago
+  wait_vmcnt<0>();                             // the trailing all-zero pieces
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA (inline asm, invisible to the hazard recognizer) -> accumulator reads
 
   // ---- epilogue: accumulators -> LDS (f32, per-wave region) -> whole pixel rows, 16-B coalesced stores --------------------------
@@ -684,8 +535,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   // stores 6.4 k, drain 0.4 k; the staging uses ring slots 2.. in half-cout passes and leaves slots 0-1 to that DMA.
   __builtin_amdgcn_s_barrier();  // every wave's trailing DMA has landed and all fragment reads are done: the ring is free
   stamp(work, 6);
-  const unsigned next = STREAM ? next_s : (DYN ? (unsigned)__builtin_amdgcn_readfirstlane((int)next_dyn) : work + gridDim.x);
-  const bool has_next = STREAM ? has_next_s : next < (unsigned)a.total;
+  const unsigned next = DYN ? (unsigned)__builtin_amdgcn_readfirstlane((int)next_dyn) : work + gridDim.x;
+  const bool has_next = next < (unsigned)a.total;
   if constexpr (DIRECT) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -711,17 +562,15 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
         for (int e = 0; e < 4; e++) bsv[4 * h + e] = bf[e];
       }
     }
-    if constexpr (!STREAM) {
-      if (has_next) {
-        stamp(next, 0);
-        setup(next);
-        stamp(next, 1);
-      } else {
-        it = (nK + 3) & ~3;   // destination derived from `it`: A slot 0 / halo slot 0
-        it_ky = it_ch = 0;
-      }
-      issue_h(K0_{});
+    if (has_next) {
+      stamp(next, 0);
+      setup(next);
+      stamp(next, 1);
+    } else {
+      it = (nK + 3) & ~3;   // destination derived from `it`: A slot 0 / halo slot 0
+      it_ky = it_ch = 0;
     }
+    issue_h(K0_{});
     stamp(work, 7);
     float s1[STATS ? NQD : 1], s2[STATS ? NQD : 1];
     if constexpr (STATS) {
@@ -807,15 +656,11 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
           // non-temporal: the tile is next read by a later kernel, after far more than an L2 of other traffic
           if constexpr (CL == 8) {
             const u32x4 o = {pk[0], pk[1], pk[2], pk[3]};
-#if !(DMVAE_PP_EXP & 8)
-            __builtin_amdgcn_raw_buffer_store_b128(o, rY, vbase, so, DMVAE_PP_ST_AUX);
-#endif
+            __builtin_amdgcn_raw_buffer_store_b128(o, rY, vbase, so, 2 /* nt */);
             asm volatile("s_nop 0" :: "v"(o));   // gfx950: a VALU write to a store's data VGPR directly behind the store is seen by the store (see the staged epilogue)
           } else {
             const u32x2 o = {pk[0], pk[1]};
-#if !(DMVAE_PP_EXP & 8)
-            __builtin_amdgcn_raw_buffer_store_b64(o, rY, vbase, so, DMVAE_PP_ST_AUX);
-#endif
+            __builtin_amdgcn_raw_buffer_store_b64(o, rY, vbase, so, 2 /* nt */);
             asm volatile("s_nop 0" :: "v"(o));
           }
         }
@@ -845,7 +690,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
   } else {
     // 64 couts (two 32-cout blocks) per staging pass: a store instruction then writes 8 pixel rows x 128 contiguous bytes.  The 128-row tile (one wave =
     // 64 couts) used to take them in two passes of 32 -- 16 rows x 64 B per store instruction, i.e. twice the cache lines per instruction -- and now takes
-    // them in one (DMVAE_PP_EPI_HALF restores the two passes for A/B builds).
+    // them in one.
     //
     // Straight-line code, no exec-masked branches: rows past M / couts past Cout are out-of-range offsets of buffer descriptors (stores dropped, loads
     // return 0), the residual operand and the activation are compile-time cases.  The first form of this epilogue tested `m < M && c_ok` around each
@@ -854,11 +699,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
     // acknowledgement from memory (17-19 k cycles per 128 KB tile, 12-24 % of the kernel; the stores themselves need ~3 k at the rate
     // tools/probes/probe_store_bw.hip measures with every CU bursting).  A wave's LDS operations execute in order, so the staging region needs no
     // waits of its own either: the next round's accumulators are written right behind this round's reads.
-#ifdef DMVAE_PP_EPI_HALF
-    constexpr int EH = BM / 2;
-#else
     constexpr int EH = BM >= 4 ? BM / 2 : BM;   // cout blocks per staging pass
-#endif
     constexpr int NH = BM / EH;              // staging passes over the wave's couts
     constexpr int CWH = EH * 32;             // couts per wave per pass
     constexpr int ROWB = CWH * 4 + 16;       // padded f32 row (bank-conflict-free ds_write_b128)
@@ -1028,9 +869,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
               }
               // non-temporal: the tile is next read by a later kernel, after far more than an L2 of other traffic
               keep[q] = o;
-#if !(DMVAE_PP_EXP & 8)
               __builtin_amdgcn_raw_buffer_store_b128(o, rY, voff, soff, 2);
-#endif
             }
           }
           // gfx950 hazard that hipcc (ROCm 7.2) does not pad: a VALU instruction that directly follows a buffer_store_dwordx4 and writes one of its data
@@ -1068,17 +907,12 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(Args a) {
         }
     }
   }
-  if constexpr (STREAM) {       // nothing to issue, nothing to wait for: the stores drain under the next tile's first K steps
-    stamp(work, 4);
-    stamp(work, 5);
-  } else {
   if (has_next) { if constexpr (HALO) issue_h(K1_{}); else issue(SLOT); }
   stamp(work, 4);
   wait_vmcnt<HALO ? NPA : NP>();              // the epilogue's stores share vmcnt with the prefetched K tiles: everything but the second tile's pieces (the newest) has landed
   stamp(work, 5);
   __builtin_amdgcn_s_barrier();  // staging reads done before ring slots 2.. are refilled
   if (has_next) { if constexpr (HALO) issue_h(K2_{}); else issue(2 * SLOT); }
-  }
   work = next;
   }  // persistent tile loop
   if constexpr (DYN) {
@@ -1135,7 +969,7 @@ template <int TM, int TP, int WM, int WP, int NBUF, bool UPS, bool F32, bool KO,
 int launch(Args a, hipStream_t st) {
   a.ctiles = (a.Cout + TM - 1) / TM;
   a.total = ((a.M + TP - 1) / TP) * a.ctiles * (SUB ? 4 : 1);
-  static const int persist = [] { const char* e = getenv("DMVAE_PP_GRID"); return e ? atoi(e) : 256; }();  // 0: one block per tile
+  constexpr int persist = 256;      // persistent blocks: one per CU
   const unsigned grid = (persist > 0 && a.total > persist) ? (unsigned)persist : (unsigned)a.total;
   if constexpr (!DYN && !UPS && KO && !F32) {  // the bf16-output, chunk-outer instantiations (every large launch of the training step) have a DYN twin
     if (dynamic_on() && grid == 256u && (unsigned)a.total > grid) {
@@ -1163,8 +997,8 @@ int launch(Args a, hipStream_t st) {
 // tap streams the whole channel depth of the pixel tile (256 KB per CU at Cin = 512) and the next tap finds nothing of it left:
 // FETCH_SIZE per launch 9.0x vs 2.2x the compulsory bytes at 512->512 @128^2 (profiles/r1_conv_hbm_traffic.txt).  The folded-upsample
 // variant keeps the taps outer (its per-tap source selection is too costly to redo every K tile).
-static int halo_mode() { static const int v = [] { const char* e = getenv("DMVAE_PP_HALO"); return e ? atoi(e) : 3; }(); return v; }   // 0: every kx tap staged on its own; bit 0: the 256 x 256 tile; bit 1: + the 128 x 512 and 64 x 1024 tiles; bit 3: no 64 x 1024 tile
-static bool korder_on() { static const bool v = [] { const char* e = getenv("DMVAE_PP_KORDER"); return e ? atoi(e) != 0 : true; }(); return v; }
+static constexpr int halo_mode() { return 3; }   // bit 0: the 256 x 256 tile, bit 1: + the 128 x 512 and 64 x 1024 tiles run the kx-halo form
+static constexpr bool korder_on() { return true; }   // channel chunk outer, tap inner (the taps-outer order re-fetched the input 9x from HBM)
 // the launches pick() sends to a HALO instantiation (given that dmvae_conv_pp_try takes the shape at all)
 static bool halo_for(int ks, int cout, bool plain, bool ups, bool f32) {
   const int h = halo_mode();
@@ -1173,7 +1007,6 @@ static bool halo_for(int ks, int cout, bool plain, bool ups, bool f32) {
 
 template <bool UPS, bool F32>
 int pick(const Args& a, hipStream_t st, bool gen) {
-  static const bool ko = [] { const char* e = getenv("DMVAE_PP_KORDER"); return e ? atoi(e) != 0 : true; }();
   if constexpr (!UPS) {
     if (gen) {  // strided / 4x4 / zero-insertion gathers: chunk-outer K order only
       if (a.Cout <= 128) return launch<128, 512, 2, 4, 4, false, F32, true, true>(a, st);
@@ -1185,11 +1018,10 @@ int pick(const Args& a, hipStream_t st, bool gen) {
     return launch<256, 256, 2, 4, 4, UPS, F32, false>(a, st);
   } else {
     if constexpr (!F32) {
-      const int halo = halo_mode();
       if (halo_for(a.ks, a.Cout, !gen, UPS, F32)) {   // plain 3x3: the three kx taps of a (chunk, ky) share one staged halo of the pixel tile
         if (a.Cout > 128) return a.gnpart ? launch<256, 256, 2, 4, 4, false, false, true, false, false, false, true, true>(a, st)
                                           : launch<256, 256, 2, 4, 4, false, false, true, false, false, false, false, true>(a, st);
-        if ((halo & 2) && !(halo & 8) && a.Cout <= 64 && !a.gnpart)   // LPIPS trunk's 64-channel layers (lpips.py:116-153): a 128-row tile would be half padding
+        if (a.Cout <= 64 && !a.gnpart)   // LPIPS trunk's 64-channel layers (lpips.py:116-153): a 128-row tile would be half padding
           return launch<64, 1024, 1, 8, 4, false, false, true, false, false, false, false, true>(a, st);
         return a.gnpart ? launch<128, 512, 2, 4, 4, false, false, true, false, false, false, true, true>(a, st)
                         : launch<128, 512, 2, 4, 4, false, false, true, false, false, false, false, true>(a, st);
@@ -1199,8 +1031,8 @@ int pick(const Args& a, hipStream_t st, bool gen) {
         return launch<256, 256, 2, 4, 4, false, false, true, false, false, false, true>(a, st);
       }
     }
-    if (a.Cout <= 128) return ko ? launch<128, 512, 2, 4, 4, UPS, F32, true>(a, st) : launch<128, 512, 2, 4, 4, UPS, F32, false>(a, st);  // 160 KiB of LDS: the whole CU
-    return ko ? launch<256, 256, 2, 4, 4, UPS, F32, true>(a, st) : launch<256, 256, 2, 4, 4, UPS, F32, false>(a, st);
+    if (a.Cout <= 128) return launch<128, 512, 2, 4, 4, UPS, F32, true>(a, st);  // 160 KiB of LDS: the whole CU
+    return launch<256, 256, 2, 4, 4, UPS, F32, true>(a, st);
   }
 }
 
@@ -1240,14 +1072,13 @@ int dmvae_conv_geometry(const dmvae_conv_desc* d, int* ho, int* wo, int* so, int
 extern "C" int dmvae_conv_halo_applies(const dmvae_conv_desc* d) {
   using namespace dmvae_conv_pp;
   if (!d) return 0;
-  static const bool disabled = [] { const char* e = getenv("DMVAE_CONV_V1"); return e && atoi(e) != 0; }();
   int ho, wo, so, pd, sd, fl;
-  if (disabled || dmvae_conv_geometry(d, &ho, &wo, &so, &pd, &sd, &fl) != 0) return 0;
+  if (dmvae_conv_geometry(d, &ho, &wo, &so, &pd, &sd, &fl) != 0) return 0;
   const bool plain = !(d->upsample == 2 || d->stride == 2 || d->ks == 4 || d->transposed);
   const long long M = (long long)d->n * ho * wo;
   const long long xbytes = (long long)d->n * d->h * d->w * d->cin * 2;
   const long long wbytes = (long long)d->cout * d->ks * d->ks * d->cin * 2;
-  static const long long min_m = [] { const char* e = getenv("DMVAE_PP_MINM"); return e ? atoll(e) : 16384ll; }();
+  constexpr long long min_m = 16384;      // smaller problems: conv_fwd.hip
   if (d->cin % 32 != 0 || d->cout < 64 || d->cout % 8 != 0 || M < min_m || xbytes + (1ll << 22) >= (1ll << 31) || wbytes >= (1ll << 31)) return 0;
   if (M >= (1ll << 24) || M * d->cout * (d->out_f32 ? 4 : 2) >= (1ll << 31)) return 0;
   return halo_for(d->ks, d->cout, plain, fl != 0, d->out_f32 != 0) ? 1 : 0;
@@ -1258,16 +1089,13 @@ extern "C" int dmvae_conv_halo_applies(const dmvae_conv_desc* d) {
 extern "C" int dmvae_conv_kmajor_applies(const dmvae_conv_desc* d) {
   using namespace dmvae_conv_pp;
   if (!d) return 0;
-  static const bool disabled = [] { const char* e = getenv("DMVAE_CONV_V1"); return e && atoi(e) != 0; }();
-  static const bool general = [] { const char* e = getenv("DMVAE_PP_GENERAL"); return e ? atoi(e) != 0 : true; }();
   int ho, wo, so, pd, sd, fl;
-  if (disabled || dmvae_conv_geometry(d, &ho, &wo, &so, &pd, &sd, &fl) != 0) return 0;
+  if (dmvae_conv_geometry(d, &ho, &wo, &so, &pd, &sd, &fl) != 0) return 0;
   const bool plain = !(d->upsample == 2 || d->stride == 2 || d->ks == 4 || d->transposed);
-  if (!plain && !general) return 0;
   const long long M = (long long)d->n * ho * wo;
   const long long xbytes = (long long)d->n * d->h * d->w * d->cin * 2;
   const long long wbytes = (long long)d->cout * d->ks * d->ks * d->cin * 2;
-  static const long long min_m = [] { const char* e = getenv("DMVAE_PP_MINM"); return e ? atoll(e) : 16384ll; }();
+  constexpr long long min_m = 16384;      // smaller problems: conv_fwd.hip
   if (d->cin % 32 != 0 || d->cout < 64 || d->cout % 8 != 0 || M < min_m || xbytes + (1ll << 22) >= (1ll << 31) || wbytes >= (1ll << 31)) return 0;
   if (M >= (1ll << 24) || M * d->cout * (d->out_f32 ? 4 : 2) >= (1ll << 31)) return 0;
   return 1;
@@ -1279,20 +1107,15 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
                       hipStream_t stream, float* gnpart, int gn_groups, int* gn_tp) {
   if (gn_tp) *gn_tp = 0;
   using namespace dmvae_conv_pp;
-  static const bool disabled = [] { const char* e = getenv("DMVAE_CONV_V1"); return e && atoi(e) != 0; }();
-  if (disabled) return 1;
-  static const bool general = [] { const char* e = getenv("DMVAE_PP_GENERAL"); return e ? atoi(e) != 0 : true; }();  // 0: strided / zero-insertion / 4x4 gathers stay on conv_fwd.hip
   int ho, wo, so, pd, sd, fl;
   if (dmvae_conv_geometry(d, &ho, &wo, &so, &pd, &sd, &fl) != 0) return 1;
   const bool plain = !(d->upsample == 2 || d->stride == 2 || d->ks == 4 || d->transposed);
-  if (!plain && !general) return 1;
-  static const bool subpix = [] { const char* e = getenv("DMVAE_PP_SUBPIXEL"); return e ? atoi(e) != 0 : true; }();  // 0: the zero-insertion gather (GEN)
-  const bool sub = subpix && d->transposed && d->ks == 4 && d->stride == 2;
+  const bool sub = d->transposed && d->ks == 4 && d->stride == 2;
   const int ups = fl ? 1 : 0;      // nearest x2 folded into the gather: its own template variant
   const long long M = (long long)d->n * ho * wo;
   const long long xbytes = (long long)d->n * d->h * d->w * d->cin * 2;
   const long long wbytes = (long long)d->cout * d->ks * d->ks * d->cin * 2;
-  static const long long min_m = [] { const char* e = getenv("DMVAE_PP_MINM"); return e ? atoll(e) : 16384ll; }();
+  constexpr long long min_m = 16384;      // smaller problems: conv_fwd.hip
   if (d->cin % 32 != 0 || d->cout < 64 || d->cout % 8 != 0 || M < min_m || xbytes + (1ll << 22) >= (1ll << 31) || wbytes >= (1ll << 31)) return 1;
   if (M >= (1ll << 24)) return 1;   // divmod_small
   if (M * d->cout * (d->out_f32 ? 4 : 2) >= (1ll << 31)) return 1;   // the epilogue addresses y (and the residual) through 32-bit buffer offsets; SENT must stay out of range
@@ -1311,10 +1134,9 @@ int dmvae_conv_pp_try(const void* x, const void* w, const void* bias, const void
   a.Ml = d->n * d->h * d->w;
   a.gnpart = nullptr;
   if (gnpart && gn_tp && !d->out_f32 && (plain || sub) && !ups && gn_groups > 0 && d->cout % gn_groups == 0 && (d->cout / gn_groups) % 4 == 0) {
-    static const bool ko1 = [] { const char* e = getenv("DMVAE_PP_KORDER"); return e ? atoi(e) != 0 : true; }();
     const int tp = d->cout <= 128 ? 512 : 256;
     const long long per_image = sub ? (long long)d->h * d->w : (long long)ho * wo;   // pixels of one image per pixel-tile sequence (per parity class for SUB)
-    if (ko1 && per_image % tp == 0) { a.gnpart = gnpart; *gn_tp = tp; }
+    if (per_image % tp == 0) { a.gnpart = gnpart; *gn_tp = tp; }
   }
   a.sched = nullptr;
   const bool f32 = d->out_f32 != 0;

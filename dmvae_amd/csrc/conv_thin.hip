@@ -144,7 +144,7 @@ int launch(const Args& a, hipStream_t st) {
 
 // 0: launched; 1: not this kernel's shape (the caller goes on to the general kernel); < 0: error.
 int dmvae_conv_thin_try(const void* x, const void* w, const void* bias, const void* residual, void* y, const dmvae_conv_desc* d, hipStream_t stream) {
-  static const bool on = [] { const char* e = getenv("DMVAE_CONV_THIN"); return e ? atoi(e) != 0 : true; }();
+  constexpr bool on = true;
   if (!on || d->ks != 3 || d->stride > 1 || d->upsample || d->transposed || !d->out_f32 || d->cout != 4 || (d->cin != 64 && d->cin != 128) || d->act != 0 ||
       residual || d->h % 4 != 0 || d->w % 32 != 0)
     return 1;

@@ -438,7 +438,7 @@ extern "C" int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, 
   }
   const size_t total = (size_t)w.Cout * T * w.Cin;
   const int nb = bias_fused ? (w.Cout + 63) / 64 : 0;  // the ping-pong kernel left per-split column sums of dy behind the weight slabs
-  static const bool flat_ok = [] { const char* e = getenv("DMVAE_WGRAD_REDUCE_FLAT"); return e ? atoi(e) != 0 : true; }();
+  constexpr bool flat_ok = true;
   if (flat_ok && T == 1 && total % 4 == 0) {
     const size_t total4 = total / 4;
     const int rbf = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);

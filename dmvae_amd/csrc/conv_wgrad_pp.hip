@@ -28,19 +28,8 @@
 // a K tile's 32 pixels sit two source pixels apart (per-lane offsets doubled) and the row test reads 2y - 1 + ky; sixteen taps instead of nine.
 #include "common.h"
 #include "dmvae_hip.h"
-#ifndef DMVAE_PP_PRIO_MODE
-#define DMVAE_PP_PRIO_MODE 1   // 0: s_setprio 1 / 0 around every COMPUTE interval (round 1); 1: static priority 1 for the second-dispatched wave group; 2: none
-#endif
 #include <cstdlib>
-#ifndef DMVAE_WG_EXP
-#define DMVAE_WG_EXP 0
-#endif
-#ifndef DMVAE_WG_HALO_NBUF
-#define DMVAE_WG_HALO_NBUF 4
-#endif
-#ifndef DMVAE_WG_NBUF
-#define DMVAE_WG_NBUF 4
-#endif
+constexpr int WG_NBUF = 4;   // ring depth (K tiles in LDS), both forms
 
 namespace dmvae_wgrad_pp {
 
@@ -95,7 +84,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   constexpr int BSZ = HALO ? HROWS * 256 : GB * SUB;
   constexpr int ASZ = GA * KH * SUB;
   constexpr int SLOT = ASZ + BSZ;
-  constexpr int NBUF = HALO ? (KH == 2 ? 4 : DMVAE_WG_HALO_NBUF) : DMVAE_WG_NBUF, PF = NBUF - 1;
+  constexpr int NBUF = HALO ? (KH == 2 ? 4 : WG_NBUF) : WG_NBUF, PF = NBUF - 1;
   constexpr int NQ = HROWS / 4, FP = (NQ - 1) / 8;   // HALO: pieces of the halo tile; FP per wave + the last one, which is wave 7's
   constexpr int NPA = GA * KH, NPB = HALO ? FP + 1 : GB;  // 1-KiB pieces per wave per K tile (8 pieces per sub-tile, 8 waves)
   constexpr int NP = NPA + NPB;
@@ -239,11 +228,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
     px0 = r - py * a.Wo;
   }
   auto issue = [&](int slot) {
-#if DMVAE_WG_EXP & 32
-    const bool live = it < 0;     // timing experiment: every piece fully masked (issue + LDS write, no L2 / HBM traffic)
-#else
     const bool live = it < nK;
-#endif
     const unsigned soA = (unsigned)pt * a.Cout * 2u;
 #pragma unroll
     for (int p = 0; p < NPA; p++) {
@@ -288,7 +273,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   };
 
   auto wait_ring = [&]() {  // all but the newest PF - 1 tiles' pieces of this wave have landed
-    constexpr int AH = (DMVAE_WG_EXP & 16) ? PF - 2 : PF - 1;
+    constexpr int AH = PF - 1;
     if constexpr (HALO) {
       if (wave == 7) wait_vmcnt<AH * NP>(); else wait_vmcnt<AH * (NP - 1)>();
     } else {
@@ -299,27 +284,15 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   for (int u = 0; u < PF; u++) issue(u * SLOT);
   wait_ring();
   __builtin_amdgcn_s_barrier();
-#if DMVAE_PP_PRIO_MODE == 1
   if (grp == 1) __builtin_amdgcn_s_setprio(1);
-#endif
   if (grp == 1) __builtin_amdgcn_s_barrier();
 
   union Frag { bf16x8 v; s16x4 h[2]; };
   Frag af[KH][BM], bfr[KH][BN];
-#if DMVAE_WG_EXP & 2
-  for (int h = 0; h < KH; h++) {
-    for (int i = 0; i < BM; i++) af[h][i].v = ones;
-    for (int j = 0; j < BN; j++) bfr[h][j].v = ones;
-  }
-#endif
   int slot_rd = 0, slot_wr = PF * SLOT;
 #pragma unroll 1
   for (int t = 0; t < nK; t++) {
     const unsigned sb = (unsigned)(size_t)LPTR(smem) + (unsigned)slot_rd;
-#if DMVAE_WG_EXP & 8
-    issue(slot_wr);
-#endif
-#if !(DMVAE_WG_EXP & 2)   // timing experiments (tools/probes/build_variant.sh): 1 = no DMA issue in the loop, 2 = no fragment reads, 4 = no barriers
 #pragma unroll
     for (int j = 0; j < BN; j++) {
       bfr[0][j].h[0] = tr_read<0>(sb + boff[j]);
@@ -342,22 +315,14 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
         af[KH - 1][i].h[1] = tr_read<SUB + 1024>(sb + aoff[i]);
       }
     }
-#endif
-#if !(DMVAE_WG_EXP & (1 | 8 | 16))
     issue(slot_wr);
-#endif
     slot_rd = slot_rd + SLOT == NBUF * SLOT ? 0 : slot_rd + SLOT;
     slot_wr = slot_wr + SLOT == NBUF * SLOT ? 0 : slot_wr + SLOT;
     wait_ring();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-#if !(DMVAE_WG_EXP & 4)
     __builtin_amdgcn_s_barrier();
-#endif
     __builtin_amdgcn_sched_barrier(0);
-#if DMVAE_PP_PRIO_MODE == 0
-    __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
     for (int h = 0; h < KH; h++)
 #pragma unroll
@@ -365,9 +330,6 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 #pragma unroll
       for (int j = 0; j < BN; j++) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[h][i].v), "v"(bfr[h][j].v));
-#if DMVAE_WG_EXP & 16
-        if (h == 0 && i == 0 && j == 3) issue((slot_wr == 0 ? NBUF * SLOT : slot_wr) - SLOT);
-#endif
       }
     const bool bias_now = do_bias && bias_cnt == 0;
     bias_cnt = bias_cnt == 0 ? a.ntiles - 1 : bias_cnt - 1;
@@ -380,13 +342,8 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
           // s_nop: the compiler rematerialises `ones` with v_mov right before the statement and pads nothing for inline asm
           asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accb[i & 1]) : "v"(af[h][i].v), "v"(ones));
     }
-#if DMVAE_PP_PRIO_MODE == 0
-    __builtin_amdgcn_s_setprio(0);
-#endif
     __builtin_amdgcn_sched_barrier(0);
-#if !(DMVAE_WG_EXP & 4)
     __builtin_amdgcn_s_barrier();
-#endif
     __builtin_amdgcn_sched_barrier(0);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
@@ -423,7 +380,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 
 template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false, bool UPS = false, int KP = 32>
 int launch(const Args& a, int splits, hipStream_t st) {
-  constexpr int lds = (HALO ? (KP == 64 ? 4 : DMVAE_WG_HALO_NBUF) : DMVAE_WG_NBUF) * (GA * KP + (HALO ? KP + 4 : GB * 32)) * 256;
+  constexpr int lds = (HALO ? (KP == 64 ? 4 : WG_NBUF) : WG_NBUF) * (GA * KP + (HALO ? KP + 4 : GB * 32)) * 256;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_kernel<GA, GB, WM, WN, S2, HALO, UPS, KP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -437,18 +394,15 @@ int launch(const Args& a, int splits, hipStream_t st) {
 }  // namespace dmvae_wgrad_pp
 
 // The 128 x 384 tile's halo form with 64-pixel K tiles: 3x3 stride 1, output rows of a multiple of 64 pixels (a K tile never straddles a row).
-static bool wgrad_pp_halo_on() { static const bool v = [] { const char* e = getenv("DMVAE_WGRAD_PP_HALO"); return e ? atoi(e) != 0 : true; }(); return v; }
+static constexpr bool wgrad_pp_halo_on() { return true; }
 static bool wgrad_pp_k64(const dmvae_conv_desc* d, int cfg) {
-  static const bool on = [] { const char* e = getenv("DMVAE_WGRAD_PP_K64"); return e ? atoi(e) != 0 : true; }();
+  constexpr bool on = true;
   return on && wgrad_pp_halo_on() && cfg == 1 && d->ks == 3 && d->stride <= 1 && !d->upsample && !d->transposed && d->w % 64 == 0;
 }
 
 // Plan shared by the workspace query and the launch: returns 0 when the ping-pong kernel does not cover the shape.
 int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_out, int* cfg_out) {
-  static const bool disabled = [] { const char* e = getenv("DMVAE_WGRAD_V1"); return e && atoi(e) != 0; }();
-  if (disabled) return 0;
-  static const bool s2_ok = [] { const char* e = getenv("DMVAE_WGRAD_PP_S2"); return e ? atoi(e) != 0 : true; }();
-  const bool s2 = s2_ok && d->ks == 4 && d->stride == 2 && !d->upsample && !d->transposed && d->h % 2 == 0 && d->w % 2 == 0;  // 4x4 stride 2: its own instantiation
+  const bool s2 = d->ks == 4 && d->stride == 2 && !d->upsample && !d->transposed && d->h % 2 == 0 && d->w % 2 == 0;  // 4x4 stride 2: its own instantiation
   if (!s2 && (d->stride == 2 || d->upsample == 2 || d->ks == 4 || d->transposed)) return 0;  // other strided / 4x4 gathers: the general kernel (conv_wgrad.hip)
   const int ups = d->upsample ? 1 : 0;
   const int wo = s2 ? d->w / 2 : (ups ? 2 * d->w : d->w);
@@ -465,11 +419,11 @@ int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_o
     const int m0 = (d->cout + 255) / 256, n0 = (ngroups + 1) / 2, m1 = d->cout / 128, n1 = (ngroups + 2) / 3;
     const double useful = (double)d->cout * ngroups * 128;
     const double e0 = useful / ((double)m0 * 256 * n0 * 256), e1 = 0.78 * useful / ((double)m1 * 128 * n1 * 384);
-    static const bool relax = [] { const char* e = getenv("DMVAE_WGRAD_PP_RAGGED"); return e ? atoi(e) != 0 : true; }();
+    constexpr bool relax = true;
     const bool exact0 = d->cout % 256 == 0 && (d->cin / 128) % 2 == 0;
     // The 128 x 384 tile's halo form with 64-pixel K tiles (190 instead of 128 FLOP per staged byte) also beats the 256 x 256 tile on shapes that tile fits
-    // exactly once the reduction is long: +3-8 % from 2^19 pixels on, +-0 below.  DMVAE_WGRAD_PP_CFG: 0 = never, 1 = wherever it applies.
-    static const int force = [] { const char* e = getenv("DMVAE_WGRAD_PP_CFG"); return e ? atoi(e) : -1; }();
+    // exactly once the reduction is long: +3-8 % from 2^19 pixels on, +-0 below.
+    constexpr int force = -1;
     const bool halo_ok = d->ks == 3 && d->stride <= 1 && !d->upsample && !d->transposed && d->w % 64 == 0 && wgrad_pp_halo_on();
     if (halo_ok && (force == 1 || (force < 0 && M >= (1ll << 19)))) { cfg = 1; mtiles = m1; ntiles = n1; }
     else if (exact0 || (relax && e0 > e1)) { cfg = 0; mtiles = m0; ntiles = n0; }
@@ -480,10 +434,8 @@ int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_o
   const int ktiles = (int)(M / 32);
   int best = 1;
   double best_eff = 0;
-  // DMVAE_WGRAD_PP_MIN_ROUNDS=2 (an opt-in; measured and left off): at least two rounds of smaller blocks, so that a block whose CU is held
-  // by an overlapped collective's kernel when the launch starts delays the launch by half a block-time instead of a whole one (a block needs 128 KB of LDS
-  // and shares its CU with nothing).  Costs one more slab per output element to reduce; not worth it on a single GPU.
-  static const int min_rounds = [] { const char* e = getenv("DMVAE_WGRAD_PP_MIN_ROUNDS"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+  // (at least two rounds of smaller blocks, for launches next to an overlapped collective's resident kernel, was measured and not adopted: DESIGN.md 8.6)
+  constexpr int min_rounds = 1;
   for (int s = 1; s <= ktiles / 16 && s * tiles <= 4096; s++) {
     const int blocks = s * tiles;
     const int rounds = (blocks + 255) / 256;

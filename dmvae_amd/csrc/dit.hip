@@ -626,7 +626,7 @@ extern "C" int dmvae_rmsnorm_modulate_bwd(const void* da, const void* x, const v
   // next to the rows a block walks -- 32 at batch 16 (2 rows per wave at 256 tokens), 16 at batch 64
   int bps = 1024 / batch;
   bps = bps > RM_BPS ? RM_BPS : (bps < 4 ? 4 : bps);
-  static const bool split_ok = [] { const char* e = getenv("DMVAE_RMS_BWD_SPLIT"); return e ? atoi(e) != 0 : true; }();
+  constexpr bool split_ok = true;
   if (split_ok && seq <= RM_MAX_SEQ) {
     float2* rowstat = reinterpret_cast<float2*>((float*)workspace + ((size_t)batch * RM_BPS * 3 + batch) * (size_t)c);
     const int rows = batch * seq;

@@ -20,18 +20,9 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef DMVAE_GEMM_NOSTORE   // timing experiment: the epilogue's arithmetic without its stores (dropped through an out-of-range offset)
-#define DMVAE_GEMM_NOSTORE 0
-#endif
-#ifndef DMVAE_GEMM_MAXBUF    // ring depth cap (A/B builds); the ring is as deep as LDS allows up to this
-#define DMVAE_GEMM_MAXBUF 6
-#endif
-#ifndef DMVAE_GEMM_LOOP_DEFAULT   // main loop: 0 = two waves per SIMD in ping-pong (two barriers per K tile), 1 = one hand-pipelined stream per wave (one barrier per K tile)
-#define DMVAE_GEMM_LOOP_DEFAULT 0
-#endif
-#ifndef DMVAE_GEMM_AUX    // cache-policy bits of the epilogue's stores (2 = nt); A/B builds
-#define DMVAE_GEMM_AUX 0
-#endif
+// Measured on this kernel and not adopted (kept as text): a hand-pipelined single-stream main loop with one barrier per K tile (and with one every
+// second K tile), a four-wave 128 x 128 wave tile, a deeper / shallower ring, nt stores in the epilogue.
+constexpr int GEMM_MAXBUF = 6;   // ring depth cap; the ring is as deep as LDS allows up to this
 
 namespace dmvae_gemm_pp {
 
@@ -93,20 +84,13 @@ __device__ __forceinline__ float gelu_f(float x) { return dmvae_gelu_f(x); }   /
 //   t = nK - 1          + K(PF-1)'                                       wait 0: the next tile's first PF K tiles have landed before this tile's stores go out
 // Needs nK >= 2 PF (the host asks for K >= 384 and sends shorter reductions to the small batched kernel).  No scratch: a spilled register's reload is a VMEM load, and
 // the wait the compiler puts behind it drains the whole prefetch queue (measured: 10 k cycles per tile with 31 spilled VGPRs).
-template <int OFF>
-__device__ __forceinline__ void lds_read128(bf16x8& dst, unsigned lds_addr) {   // no memory operand: the compiler's wait-count pass does not see it (conv_wgrad_pp.hip::tr_read)
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF));
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); }
-
-template <int TM, int TP, int WM, int WP, bool OUT_F32, int NBUF, int LOOP = 0>
+template <int TM, int TP, int WM, int WP, bool OUT_F32, int NBUF>
 __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__
-  constexpr int PF = LOOP == 2 ? NBUF - 2 : NBUF - 1;   // K tiles in flight ahead of the one being read (LOOP 2 keeps one slot of slack: its waves may be a step apart)
+  constexpr int PF = NBUF - 1;   // K tiles in flight ahead of the one being read
   constexpr int CL = TM / WM / 16, BT = TP / WP / 16;   // 16 x 16 accumulator blocks per wave: CL column blocks (= consecutive columns per lane) x BT token blocks
   constexpr int NW = WM * WP;   // waves: 8 (two per SIMD), or 4 with the single-stream loop (one per SIMD, up to 64 accumulator blocks each: a 128 x 128 wave tile)
-  static_assert((NW == 8 || (NW == 4 && LOOP >= 1)) && CL * 16 * WM == TM && BT * 16 * WP == TP && CL * BT <= (NW == 8 ? 32 : 64) && (CL == 4 || CL == 6 || CL == 8), "wave grid");
+  static_assert(NW == 8 && CL * 16 * WM == TM && BT * 16 * WP == TP && CL * BT <= 32 && (CL == 4 || CL == 6 || CL == 8), "wave grid");
   constexpr int TILE_A = TM * 64, TILE_B = TP * 64, SLOT = TILE_A + TILE_B, RING = NBUF * SLOT;
   constexpr int NPA = (TM / 16 + NW - 1) / NW, NPB = (TP / 16 + NW - 1) / NW, NP = NPA + NPB;   // 1-KiB DMA pieces (16 rows x 64 B) per wave and K tile; pieces past the tile go to the dump KiB
   constexpr int CW = CL * 16;                      // output columns per wave
@@ -287,7 +271,6 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
     }
     stamp(1);
     const unsigned next = work + gridDim.x;
-    if constexpr (LOOP == 0) {
     if (grp == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
     if (grp == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one interval behind group 0
     it = PF;
@@ -300,103 +283,6 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
     kstep(W_0{}, std::integral_constant<int, PF>{});
     if (grp == 0) __builtin_amdgcn_s_barrier();    // matches group 1's extra barrier
     if (grp == 1) __builtin_amdgcn_s_setprio(0);
-    } else {
-      // ---- LOOP 1: one instruction stream per wave, software-pipelined by hand; ONE barrier per K tile ---------------------------------------------------------
-      // Step t runs the CL x BT MFMAs of K tile t on fragments already in registers and, between them, reads K tile t + 1's fragments from the next ring slot:
-      // a weight fragment wf[i] is re-read right after the last MFMA that uses it (column-block-major order: its next use is a whole step away), the token
-      // fragments into the other half of a double buffer.  DMA issue, counted vmcnt and the barrier at the step's end as in the ping-pong loop, one K tile
-      // deeper: what lands by the end of step t is K tile t + 2 (read during step t + 1).
-      const unsigned lbase = (unsigned)(size_t)LPTR(smem);
-      bf16x8 tfb[2][BT];
-      auto read_all = [&](unsigned sw_, unsigned st_, bf16x8 (&tfd)[BT]) __attribute__((always_inline)) {
-        [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) { (lds_read128<J * 1024>(tfd[J], st_), ...); }(std::make_integer_sequence<int, BT>{});
-        [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) { (lds_read128<I * 1024>(wf[I], sw_), ...); }(std::make_integer_sequence<int, CL>{});
-      };
-      // one step: MODE as in kstep; PRE: prefetch the next K tile's fragments; PAR: which half of tfb the MFMAs read; WAIT: vmcnt allowed outstanding at the step's end (-1: none)
-      auto pstep = [&](auto WAITc, auto MODEc, auto PREc, auto PARc, auto BARc) __attribute__((always_inline)) {
-        constexpr int WAIT = decltype(WAITc)::value, MODE = decltype(MODEc)::value, PRE = decltype(PREc)::value, PAR = decltype(PARc)::value;
-        constexpr bool BAR = decltype(BARc)::value;     // false (LOOP 2, first step of a steady pair): no counted wait and no barrier at the step's end
-        auto dma = [&]() __attribute__((always_inline)) {      // this step's DMA issue: behind the first MFMA group, so that the matrix pipe starts at once
-          if constexpr (MODE == 0) { issue_k(vAc, vBc, (unsigned)it, slot_wr); it++; }
-          else {
-            if constexpr (MODE == 1) issue_bias(vBiasN, par ^ 1);
-            issue_k(vAn, vBn, (unsigned)(MODE - 1), slot_wr);
-          }
-          slot_wr = slot_wr + SLOT == RING ? 0 : slot_wr + SLOT;
-        };
-        slot_rd = slot_rd + SLOT == RING ? 0 : slot_rd + SLOT;      // the slot of K tile t + 1
-        const unsigned sw_ = lbase + (unsigned)(slot_rd + wbase), st_ = lbase + (unsigned)(slot_rd + tbase);
-        // Issue order of a step's fragment reads: for each column block I: wf[I], then the token fragments j = I, I + CL, .. (< BT).  pos(I) = reads of the step in front
-        // of wf[I].  LDS returns in order, so "wf[I] of the previous step has landed" = at most (LIST - 1 - pos(I)) + (reads this step has issued so far = pos(I))
-        // = LIST - 1 reads outstanding when this step prefetches, LIST - 1 - pos(I) when it does not.  At entry tfb[PAR] and wf[0] have landed (previous step's last wait).
-        auto group = [&]<int I>() __attribute__((always_inline)) {
-          constexpr int pos = I + (I > BT ? BT : I) + ((BT > CL && I > 0) ? (BT - CL < I ? BT - CL : I) : 0);   // token reads in front: j < BT with j % CL < I
-          if constexpr (I > 0) wait_lgkm<PRE == 1 ? CL + BT - 1 : PRE == 2 ? CL + BT - 1 - pos + I : CL + BT - 1 - pos>();
-#pragma unroll
-          for (int j = 0; j < BT; j++)
-            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][j]) : "v"(tfb[PAR][j]), "v"(wf[I]));
-          if constexpr (I == 0) dma();
-          if constexpr (PRE == 1) {
-            lds_read128<I * 1024>(wf[I], sw_);
-            if constexpr (I < BT) lds_read128<I * 1024>(tfb[PAR ^ 1][I], st_);
-            if constexpr (I + CL < BT) lds_read128<(I + CL) * 1024>(tfb[PAR ^ 1][I + CL], st_);
-          } else if constexpr (PRE == 2) {   // parity-preserving step (once per tile at most): the token fragments go back into the half just used, behind its last use
-            lds_read128<I * 1024>(wf[I], sw_);
-            if constexpr (I == CL - 1)
-              [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) { (lds_read128<J * 1024>(tfb[PAR][J], st_), ...); }(std::make_integer_sequence<int, BT>{});
-          }
-        };
-        static_assert(BT <= 2 * CL, "token fragments are prefetched at most two per weight group");
-        [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) { (group.template operator()<I>(), ...); }(std::make_integer_sequence<int, CL>{});
-        if constexpr (WAIT >= 0 && BAR) wait_vmcnt<WAIT>();
-        // next step's first group needs every token fragment and wf[0]: the last token read sits in group (BT <= CL ? BT - 1 : CL - 1); behind it only weight reads
-        if constexpr (PRE == 1) wait_lgkm<(BT <= CL ? CL - BT : 0)>();
-        if constexpr (PRE == 2) wait_lgkm<0>();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (BAR) __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      using P1 = std::integral_constant<int, 1>; using P0 = std::integral_constant<int, 0>;
-      using B1 = std::true_type; using B0 = std::false_type;
-      // LOOP 1: at the end of step t K tile t + 2 has landed (what step t + 1 reads).  LOOP 2: K tiles t + 2 AND t + 3 -- a steady pair of steps runs without a barrier
-      // between them and reads two K tiles' fragments -- so one K tile less may stay in flight.
-      constexpr int AHEAD = LOOP == 2 ? 3 : 2;
-      using V_ST = std::integral_constant<int, (PF - AHEAD) * NP>;
-      static_assert(PF >= AHEAD + 1, "ring");
-      {   // prologue: K tile 0's fragments (everything of the first PF K tiles has landed: B_0)
-        const unsigned sw_ = lbase + (unsigned)(slot_rd + wbase), st_ = lbase + (unsigned)(slot_rd + tbase);
-        read_all(sw_, st_, tfb[0]);
-        wait_lgkm<0>();
-      }
-      it = PF;
-      // Step t reads the token fragments from tfb[t & 1]: the parity is STATIC everywhere (the prefix is unrolled, the steady loop runs in pairs from an even t, and the
-      // tail exists twice, for an even and an odd number of steps in front of it -- with the parity a run-time value the compiler merged the two halves of the double
-      // buffer through scratch at every step of the tail).  Steps 0 .. PF - 3 need no wait (K tile t + 2 <= PF - 1 landed before the tile began); then the steady wait.
-      const int own = nK - PF;          // steps that issue this tile's own K tiles
-      constexpr int PRE0 = PF - 2;      // unrolled prefix without waits
-      using P2 = std::integral_constant<int, 2>;
-      // own = [one parity-preserving step if own is odd] + PREN prefix steps (an even number) + pairs.  Step t needs no wait while K tile t + 2 <= PF - 1; with the
-      // optional first step in front, prefix step T is step T or T + 1: it waits unless T + 4 <= PF.
-      constexpr int PREN = PRE0 + (PRE0 & 1);
-      if (own & 1) pstep(W_NO{}, M0_{}, P2{}, P0{}, B1{});      // K tile 2 has landed (PF >= 3); LOOP 2: K tile 3 too (PF >= 4)
-      [&]<int... T>(std::integer_sequence<int, T...>) __attribute__((always_inline)) {
-        (pstep(std::integral_constant<int, (T + AHEAD + 2 <= PF ? -1 : (PF - AHEAD) * NP)>{}, M0_{}, P1{}, std::integral_constant<int, (T & 1)>{}, B1{}), ...);
-      }(std::make_integer_sequence<int, PREN>{});
-      const int pairs = (own - PREN) >> 1;      // nK >= 2 PF: own >= PF >= PREN + 1
-#pragma unroll 1
-      for (int q = 0; q < pairs; q++) {
-        if constexpr (LOOP == 2) { pstep(W_NO{}, M0_{}, P1{}, P0{}, B0{}); pstep(V_ST{}, M0_{}, P1{}, P1{}, B1{}); }
-        else { pstep(V_ST{}, M0_{}, P1{}, P0{}, B1{}); pstep(V_ST{}, M0_{}, P1{}, P1{}, B1{}); }
-      }
-      calc(next, vAn, vBn, vBiasN, m0n, n0n);
-      // the last PF steps issue the next tile's first K tiles (+ its bias piece with the first of them); the very last one prefetches no fragments and waits for everything
-      [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) {
-        (pstep(std::integral_constant<int, (PF - AHEAD) * NP + (J + 1 <= PF - AHEAD ? 1 : 0)>{}, std::integral_constant<int, J + 1>{}, P1{}, std::integral_constant<int, (J & 1)>{}, B1{}), ...);
-      }(std::make_integer_sequence<int, PF - 1>{});
-      pstep(W_0{}, std::integral_constant<int, PF>{}, P0{}, std::integral_constant<int, ((PF - 1) & 1)>{}, B1{});
-      // the ring's read pointer now stands one past the tile's last K tile = on the next tile's K tile 0 (the last step advanced it without reading)
-    }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA (inline asm, invisible to the hazard recogniser) -> accumulator reads
     stamp(2);
 
@@ -431,16 +317,16 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
               }
             }
             const int m = row0 + j * 16 + r;
-            const bool ok = !DMVAE_GEMM_NOSTORE && c_ok && m < a.M;
+            const bool ok = c_ok && m < a.M;
             const unsigned eo = (unsigned)m * (unsigned)a.ldy + (unsigned)col;
             if constexpr (ACT == 6) {
               if constexpr (CL == 8 && !OUT_F32) {
                 const u32x2 o = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3])};
-                __builtin_amdgcn_raw_buffer_store_b64(o, rY, ok ? eo * 2u : SENT, 0, DMVAE_GEMM_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(o, rY, ok ? eo * 2u : SENT, 0, 0);
                 asm volatile("s_nop 0" :: "v"(o));
               } else if constexpr (CL == 4 && !OUT_F32) {
                 const unsigned o = dmvae_pack_bf16x2(v[0], v[1]);
-                __builtin_amdgcn_raw_buffer_store_b32(o, rY, ok ? eo * 2u : SENT, 0, DMVAE_GEMM_AUX);
+                __builtin_amdgcn_raw_buffer_store_b32(o, rY, ok ? eo * 2u : SENT, 0, 0);
                 asm volatile("s_nop 0" :: "v"(o));
               }   // other instantiations are never dispatched with act 6
             } else if constexpr (OUT_F32 && CL == 6) {   // column pairs one by one (a lane may straddle N, see the bf16 case below; the f32 result is not a hot path)
@@ -465,23 +351,23 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
               }
             } else if constexpr (CL == 8) {
               const u32x4 o = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3]), dmvae_pack_bf16x2(v[4], v[5]), dmvae_pack_bf16x2(v[6], v[7])};
-              __builtin_amdgcn_raw_buffer_store_b128(o, rY, ok ? eo * 2u : SENT, 0, DMVAE_GEMM_AUX);
+              __builtin_amdgcn_raw_buffer_store_b128(o, rY, ok ? eo * 2u : SENT, 0, 0);
               asm volatile("s_nop 0" :: "v"(o));
             } else if constexpr (CL == 6) {
               // six columns per lane: N (a multiple of 8) need not be a multiple of 6, so one lane per row of the tile on N's edge straddles it -- that lane
               // stores its column pairs one by one (a wave-uniform branch that only the edge tiles take)
               const u32x3 o = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3]), dmvae_pack_bf16x2(v[4], v[5])};
               const bool full = col + 6 <= a.N;
-              __builtin_amdgcn_raw_buffer_store_b96(o, rY, (ok && full) ? eo * 2u : SENT, 0, DMVAE_GEMM_AUX);
+              __builtin_amdgcn_raw_buffer_store_b96(o, rY, (ok && full) ? eo * 2u : SENT, 0, 0);
               if (__builtin_amdgcn_ballot_w64(ok && !full) != 0ull) {
 #pragma unroll
                 for (int e = 0; e < 2; e++)
-                  __builtin_amdgcn_raw_buffer_store_b32(o[e], rY, (ok && !full && col + 2 * e < a.N) ? eo * 2u + 4u * e : SENT, 0, DMVAE_GEMM_AUX);
+                  __builtin_amdgcn_raw_buffer_store_b32(o[e], rY, (ok && !full && col + 2 * e < a.N) ? eo * 2u + 4u * e : SENT, 0, 0);
               }
               asm volatile("s_nop 0" :: "v"(o));
             } else {
               const u32x2 o = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3])};
-              __builtin_amdgcn_raw_buffer_store_b64(o, rY, ok ? eo * 2u : SENT, 0, DMVAE_GEMM_AUX);
+              __builtin_amdgcn_raw_buffer_store_b64(o, rY, ok ? eo * 2u : SENT, 0, 0);
               asm volatile("s_nop 0" :: "v"(o));
             }
           }
@@ -505,10 +391,8 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
 #endif
 }
 
-static int g_loop = -2;   // -2: not read yet; 0: ping-pong loop; 1: single-stream pipelined loop (DMVAE_GEMM_LOOP / dmvae_debug_gemm_loop)
-
-template <int TM, int TP, int WM, int WP, bool F32, int LOOP>
-int launch_l(Args a, hipStream_t st) {
+template <int TM, int TP, int WM, int WP, bool F32>
+int launch(Args a, hipStream_t st) {
   a.ntn = (a.N + TM - 1) / TM;
   a.total = ((a.M + TP - 1) / TP) * a.ntn;
   DMVAE_CHECK_ARG(a.total > 0 && a.total < (1 << 24), "linear_bf16: %d output tiles (the kernel's tile index arithmetic is exact below 2^24)", a.total);
@@ -516,44 +400,32 @@ int launch_l(Args a, hipStream_t st) {
   const unsigned grid = a.total > 256 ? 256u : (unsigned)a.total;
   constexpr int slot = (TM + TP) * 64;
   constexpr int fit = (160 * 1024 - 3 * 1024) / slot;          // ring slots that fit beside the two bias slots and the dump KiB
-  constexpr int nbuf = fit > DMVAE_GEMM_MAXBUF ? DMVAE_GEMM_MAXBUF : fit;
+  constexpr int nbuf = fit > GEMM_MAXBUF ? GEMM_MAXBUF : fit;
   static_assert(nbuf >= 4, "LDS");
   constexpr int lds = nbuf * slot + 3 * 1024;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<TM, TP, WM, WP, F32, nbuf, LOOP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<TM, TP, WM, WP, F32, nbuf>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<TM, TP, WM, WP, F32, nbuf, LOOP>), dim3(grid), dim3(WM * WP * 64), lds, st, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<TM, TP, WM, WP, F32, nbuf>), dim3(grid), dim3(WM * WP * 64), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
-template <int TM, int TP, int WM, int WP, bool F32>
-int launch(Args a, hipStream_t st) {
-  if (g_loop == -2) { const char* e = getenv("DMVAE_GEMM_LOOP"); g_loop = e ? atoi(e) : DMVAE_GEMM_LOOP_DEFAULT; }
-  constexpr int slot_ = (TM + TP) * 64, fit_ = (160 * 1024 - 3 * 1024) / slot_;
-  if constexpr (fit_ >= 6 && DMVAE_GEMM_MAXBUF >= 6) {      // LOOP 2 (a barrier every second K step) needs a six-slot ring: four K tiles ahead + one slot of slack
-    if (g_loop == 2) return launch_l<TM, TP, WM, WP, F32, 2>(a, st);
-  }
-  return g_loop == 1 ? launch_l<TM, TP, WM, WP, F32, 1>(a, st) : launch_l<TM, TP, WM, WP, F32, 0>(a, st);
-}
-
 // The tile menu: (columns, rows, cost of one tile relative to a 256 x 256 tile's at the same K with the whole chip busy -- measured on the 16384 x 6144 x 1152
 // problem, 6 to 12 rounds per entry: tools/bench_gemm.py --sweep --cold --kmajor).  Smaller tiles cost more per flop: 0.80 for 62.5 % of the area.
 struct Cfg { int tm, tp; float cost; };
 static const Cfg g_cfg[] = {
     {256, 256, 1.00f}, {256, 224, 0.94f}, {256, 192, 0.885f}, {256, 160, 0.80f}, {256, 128, 0.67f},
     {128, 448, 1.02f}, {128, 384, 0.93f}, {128, 256, 0.70f},  {192, 256, 0.90f}, {192, 320, 1.12f},
-    {256, 256, 1.00f},   // [10] FOUR waves, 128 x 128 wave tiles, single-stream loop: experiment (DMVAE_GEMM_CFG=10 / dmvae_debug_gemm_cfg), never planned
 };
 constexpr int NCFG = sizeof(g_cfg) / sizeof(g_cfg[0]), NPLAN = 10;
 
-static int g_forced = -2;   // -2: not read yet; -1: plan by cost; >= 0: this menu entry (DMVAE_GEMM_CFG, or dmvae_debug_gemm_cfg from tools/bench_gemm.py)
+static int g_forced = -1;   // -1: plan by cost; >= 0: this menu entry (dmvae_debug_gemm_cfg: tools/bench_gemm.py's sweep, tests/test_gpu_gemm_pp.py)
 // Time model: tiles / 256 rounds of the tile's cost -- FRACTIONAL rounds, because the chip is power-limited: with half of the CUs idle in the last round the
 // busy ones clock higher and the round ends sooner (896 tiles of 256 x 256 = 3.5 rounds measure 3.5 x one round's time, not 4 x) -- but a round never costs
 // less than 0.85 of a full one.  Ragged tiles are whole tiles (their padding rows / columns cost what real ones do).
 static int plan(int M, int N, int K, bool gated = false) {
-  if (g_forced == -2) { const char* e = getenv("DMVAE_GEMM_CFG"); g_forced = e ? atoi(e) : -1; }
   const int forced = g_forced;
   if (forced >= 0 && forced < NCFG && !(gated && g_cfg[forced].tm == 192)) return forced;
   (void)K;
@@ -581,7 +453,6 @@ static int dispatch(int cfg, const Args& a, hipStream_t st) {
     case 6: return launch<128, 384, 2, 4, F32>(a, st);
     case 7: return launch<128, 256, 2, 4, F32>(a, st);
     case 8: return launch<192, 256, 2, 4, F32>(a, st);
-    case 10: return launch_l<256, 256, 2, 2, F32, 1>(a, st);
     default: return launch<192, 320, 2, 4, F32>(a, st);
   }
 }
@@ -590,8 +461,7 @@ static int dispatch(int cfg, const Args& a, hipStream_t st) {
 
 static unsigned long long* g_gemm_dbg = nullptr;
 extern "C" void dmvae_debug_gemm_timing(void* buf) { g_gemm_dbg = (unsigned long long*)buf; }   // diagnostics only (tools/probes/time_gemm_pp.py)
-extern "C" void dmvae_debug_gemm_cfg(int cfg) { dmvae_gemm_pp::g_forced = cfg; }
-extern "C" void dmvae_debug_gemm_loop(int loop) { dmvae_gemm_pp::g_loop = loop; }   // diagnostics only: 0 ping-pong, 1 pipelined single stream   // diagnostics only (tools/bench_gemm.py): force a menu entry, -1 = plan by cost
+extern "C" void dmvae_debug_gemm_cfg(int cfg) { dmvae_gemm_pp::g_forced = cfg; }   // diagnostics only: force a menu entry (0 .. 9), -1 = plan by cost
 
 extern "C" int dmvae_linear_bf16_plan(int M, int N, int K, int* tile_cols, int* tile_rows) {
   using namespace dmvae_gemm_pp;

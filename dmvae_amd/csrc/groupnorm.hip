@@ -26,15 +26,11 @@ __device__ __forceinline__ void load8(const bf16* p, float (&v)[8]) {
 }
 // Raw 16-B load / later conversion, so that a loop can put the loads of TWO pixel rows in flight before it touches either: with one row per
 // iteration and 5 (backward) to 8 waves per SIMD a CU holds 20-40 KB of reads in flight against the ~64 KB that 8 TB/s x ~2 us of latency asks of it.
-// bit 0 = non-temporal loads of the streamed tensors (default: every pass here reads its operands once, 134-1074 MB of them; without the hint they push the conv
-// kernels' operands out of L2 / the Infinity Cache -- same-box A/B of the whole step, three rounds: 67.18 / 66.99 / 67.00 -> 66.65 / 66.45 / 66.69 ms), bit 1 =
-// non-temporal stores (measured: +0.2 ms alone, nothing on top of bit 0)
-#ifndef DMVAE_GN_NT
-#define DMVAE_GN_NT 1
-#endif
+// Loads of the streamed tensors are non-temporal: every pass here reads its operands once, 134-1074 MB of them, and without the hint they push the conv kernels'
+// operands out of L2 / the Infinity Cache (same-box A/B of the whole step, three rounds: 67.18 / 66.99 / 67.00 -> 66.65 / 66.45 / 66.69 ms).  Stores stay plain
+// (non-temporal stores measured +0.2 ms: the consumer conv wants the normalised tensor where plain stores leave it).
 __device__ __forceinline__ bf16x8 ldraw(const bf16* p) {
-  if constexpr (DMVAE_GN_NT & 1) return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
-  else return *reinterpret_cast<const bf16x8*>(p);
+  return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
 }
 __device__ __forceinline__ void cvt8(const bf16x8& t, float (&v)[8]) {
 #pragma unroll
@@ -44,8 +40,7 @@ __device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
   bf16x8 t;
 #pragma unroll
   for (int e = 0; e < 8; e++) t[e] = (bf16)v[e];
-  if constexpr (DMVAE_GN_NT & 2) __builtin_nontemporal_store(t, reinterpret_cast<bf16x8*>(p));
-  else *reinterpret_cast<bf16x8*>(p) = t;
+  *reinterpret_cast<bf16x8*>(p) = t;
 }
 
 // Reduce per-thread 2x8 channel accumulators over the block's pixel rows and write

@@ -197,12 +197,6 @@ __global__ void dmd_final_kernel(const float* __restrict__ out_s, float* __restr
 // Launches: kl_moments (grid-stride, 16-B loads) -> kl_final -> mmd_pair (one workgroup per (group, pair-type, 128-row
 // tile)) -> kl_mmd_final.  Everything is fixed-order (no float atomics): run-to-run bit-exact.
 constexpr int MMD_D = 32;
-#ifndef DMVAE_KL_UNROLL
-#define DMVAE_KL_UNROLL 4
-#endif
-#ifndef DMVAE_KL_ALLNT
-#define DMVAE_KL_ALLNT 0
-#endif
 constexpr int MMD_ROWS = 128;   // rows per workgroup: 2 per lane
 constexpr int MMD_CCH = 256;    // columns staged in LDS per chunk
 constexpr int MMD_NQ = 4;       // column slices = waves per workgroup (2 workgroups share a CU: one stages / reduces while the other computes)
@@ -218,10 +212,10 @@ __global__ __launch_bounds__(256) void kl_moments_kernel(const float* __restrict
   // 256 MB Infinity Cache for it), everything before with streaming loads (faster, and it would be evicted anyway).
   const size_t keep_rows = ((size_t)192 << 20) / (MMD_D * sizeof(float));
   const size_t nt_rows = R > keep_rows ? R - keep_rows : 0;
-  constexpr int U = DMVAE_KL_UNROLL;
+  constexpr int U = 4;
   for (; r + (U - 1) * stride < R; r += U * stride) {  // U independent 16-B loads in flight per lane
     f32x4 v[U];
-    if (DMVAE_KL_ALLNT || r + (U - 1) * stride < nt_rows) {
+    if (r + (U - 1) * stride < nt_rows) {
 #pragma unroll
       for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + (r + u * stride) * MMD_D + cq * 4));
     } else {
@@ -829,13 +823,13 @@ static inline void kl_mmd_plan(int groups, int n, int m, int* tx, int* ty, int* 
   *ty = (m + MMD_ROWS - 1) / MMD_ROWS;
   size_t R = (size_t)groups * n;
   size_t nb = (R + 255) / 256;  // >= 8 row sweeps per block
-  static const int cap = [] { const char* e = getenv("DMVAE_KL_NMOM"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();
+  constexpr int cap = 1024;
   *nmom = (int)(nb > (size_t)cap ? (size_t)cap : (nb < 1 ? 1 : nb));
 }
 // Column split of the two-launch path: enough workgroups for two per CU (two waves per SIMD) on a 256-CU part, at most 4 splits; 1 otherwise.
+static int g_dbg_fused = -1, g_dbg_csplit = -1, g_dbg_mfma = -1;    // dmvae_debug_kl_mmd: tests / A/B runs force a path; -1 = the planner's choice
 static inline int kl_mmd_csplit(int groups, int tx, int ty) {
-  const char* e = getenv("DMVAE_KLMMD_CSPLIT");
-  if (e && atoi(e) > 0) return atoi(e) > 4 ? 4 : atoi(e);
+  if (g_dbg_csplit > 0) return g_dbg_csplit > 4 ? 4 : g_dbg_csplit;
   const long long blocks = (long long)groups * (2 * tx + ty);
   if ((size_t)groups * tx > 1024 || blocks >= 512) return 1;
   int cs = (int)((512 + blocks - 1) / blocks);
@@ -869,9 +863,8 @@ extern "C" int dmvae_kl_mmd(const void* z, const void* y, void* kl, void* mmd, v
   float* gpart = ksum + (size_t)csplit_ws * groups * (2 * tx + ty);
   // Small problems (the training step's own shape: 32 images x 256 tokens) are launch-bound: two launches -- pair kernel with the KL moment partials
   // folded in, then one finishing kernel -- instead of five.  Large ones keep the streaming moment pass (HBM-bound, its own roofline) and the
-  // single-block final reduce.  DMVAE_KLMMD_FUSED=0 forces the five-launch path (A/B, tests).
-  const char* fenv = getenv("DMVAE_KLMMD_FUSED");          // read per call (two getenv-free paths would need a second entry point; this one is not on the measured step)
-  const bool fused_ok = !(fenv && atoi(fenv) == 0);
+  // single-block final reduce.  dmvae_debug_kl_mmd(0, ..) forces the five-launch path (tests).
+  const bool fused_ok = g_dbg_fused != 0;
   const bool fused = fused_ok && !kl_only && (size_t)groups * tx <= 1024;
   if (!fused) {
     hipLaunchKernelGGL(kl_moments_kernel, dim3(nmom), dim3(256), 0, stream, (const float*)z, mom, (size_t)groups * n);
@@ -900,7 +893,7 @@ extern "C" int dmvae_kl_mmd(const void* z, const void* y, void* kl, void* mmd, v
   const int csplit = fused ? csplit_ws : 1;
   const dim3 grid((2 * tx + ty) * csplit, groups);
   float* klpart = fused ? mom : nullptr;
-  static const bool mfma_ok = [] { const char* e = getenv("DMVAE_KLMMD_MFMA"); return e ? atoi(e) != 0 : true; }();   // 0: the scalar-FMA pair kernel (A/B, tests)
+  const bool mfma_ok = g_dbg_mfma != 0;   // 0: the scalar-FMA pair kernel (tests)
   if (fused && mfma_ok && n <= 1024 && m <= 1024) {  // launch-bound shapes: the two contractions of every pair on the matrix cores
     const int nmax = n > m ? n : m;
     const int cper = csplit > 1 ? ((nmax + csplit - 1) / csplit + 31) & ~31 : (nmax + 31) & ~31;
@@ -942,3 +935,7 @@ extern "C" int dmvae_kl_mmd(const void* z, const void* y, void* kl, void* mmd, v
   }
   return 0;
 }
+
+// diagnostics only (tests/test_gpu_kernels.py): fused = 0 forces the five-launch path, csplit > 0 the column split of the two-launch path, mfma = 0 the
+// scalar-FMA pair kernel; -1 each = the planner's choice.  Results agree to f32 summation order either way.
+extern "C" void dmvae_debug_kl_mmd(int fused, int csplit, int mfma) { g_dbg_fused = fused; g_dbg_csplit = csplit; g_dbg_mfma = mfma; }

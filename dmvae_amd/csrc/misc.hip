@@ -1,8 +1,5 @@
 // Layout, packing and small elementwise kernels around the conv/GEMM hot path (all HBM-bound).
 #include "common.h"
-#ifndef DMVAE_PACK_TILED   // 1: single-weight pack calls on the tiled kernel too (measured slower there: a 512 x 512 weight is 256 blocks, one per CU, each a serial load -> store;
-#define DMVAE_PACK_TILED 0  // the element-wise kernel spreads the same weight over 9 x as many blocks) -- the tiled kernel is for the one-launch table
-#endif
 #include "dmvae_hip.h"
 
 namespace dmvae_misc {
@@ -488,14 +485,9 @@ extern "C" int dmvae_pack_conv_weight_v2(const void* w, void* out, void* out_kma
   DMVAE_CHECK_ARG(rows_pad >= (for_dgrad ? cin : cout) && cols_pad >= (for_dgrad ? cout : cin), "pack_conv_weight: padding smaller than shape");
   const int T = ks * ks;
   const size_t total = (size_t)rows_pad * T * cols_pad;
-  if (T <= PACK_TMAX && DMVAE_PACK_TILED) {
-    PackEntry e = {};
-    e.src = (const float*)w; e.dst = (bf16*)out; e.dst2 = (bf16*)out_kmajor;
-    e.cout = cout; e.cin = cin; e.T = T; e.rows_pad = rows_pad; e.cols_pad = cols_pad; e.mode = for_dgrad ? 1 : 0; e.subpixel = 0;
-    e.start = 0; e.count = (unsigned long long)((rows_pad + 31) / 32) * ((cols_pad + 31) / 32);
-    pack_attr();
-    hipLaunchKernelGGL(pack_tiled_kernel, dim3((unsigned)e.count), dim3(256), pack_lds_bytes(T), stream, (const PackEntry*)nullptr, 0, e);
-  } else {
+  // single-weight calls stay on the element-wise kernel: the tiled kernel (the one-launch table, dmvae_pack_weights_batched) measured 1.5 x slower here -- a
+  // 512 x 512 weight is 256 tiles, one block per CU, each a serial load -> store; the element-wise kernel spreads the same weight over 9 x as many blocks
+  {
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)w, (bf16*)out, (bf16*)out_kmajor, cout, cin, T, rows_pad,
                        cols_pad, for_dgrad ? 1 : 0);
   }

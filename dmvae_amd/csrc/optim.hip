@@ -3,9 +3,6 @@
 // update_ema's per-tensor Python loop (train_tokenizer.py:140-150,382,415-419,437).  HBM-bound:
 // reads p,g,m,v,ema and writes p,m,v,ema once (36 B/param) + one 4 B/param norm pass.
 #include "common.h"
-#ifndef DMVAE_OPT_NT   // A/B builds: 1 = non-temporal accesses to the one-touch optimiser streams
-#define DMVAE_OPT_NT 0
-#endif
 #include "dmvae_hip.h"
 
 namespace dmvae_optim {
@@ -48,17 +45,6 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, c
   const float coef = clip ? clip[1] : 1.f;
   const float step = lr / bc1;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-#if DMVAE_OPT_NT
-    // gradients, moments and the EMA are touched once per step: streamed past the caches (the weights themselves are re-read by the re-pack launch that follows)
-    const float gi = __builtin_nontemporal_load(g + i) * coef;
-    float pi = p[i] * (1.f - lr * wd);
-    const float mi = b1 * __builtin_nontemporal_load(m + i) + (1.f - b1) * gi;
-    const float vi = b2 * __builtin_nontemporal_load(v + i) + (1.f - b2) * gi * gi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    pi -= step * mi / denom;
-    p[i] = pi; __builtin_nontemporal_store(mi, m + i); __builtin_nontemporal_store(vi, v + i);
-    if (ema) __builtin_nontemporal_store(__builtin_nontemporal_load(ema + i) * decay + pi * (1.f - decay), ema + i);
-#else
     const float gi = g[i] * coef;
     float pi = p[i] * (1.f - lr * wd);
     const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -67,7 +53,6 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, c
     pi -= step * mi / denom;
     p[i] = pi; m[i] = mi; v[i] = vi;
     if (ema) ema[i] = ema[i] * decay + pi * (1.f - decay);
-#endif
     if (shadow) shadow[i] = (bf16)pi;   // the bf16 copy autocast would make of the new weight (RNE), for the next forward's GEMM operands
   }
 }

@@ -184,7 +184,6 @@ struct AttnArgs {
   int q_rs, k_rs, v_rs;
   int S, H, D;
   float scale;
-  int lone;        // 1: the last query of every (batch, head) -- S = 32 k + 1: ViT's 256 patches + class token -- is served by extra single-query waves, not by a ninth 32-query block
   int BH;          // batch * heads: blocks past it are the single-query blocks (eight (batch, head) pairs each)
   // NR variant: per-head RMSNorm (bf16 result) * weight and the 2-D rotary embedding are applied to q and k on their way in
   const float *qw, *kw, *cosb, *sinb;   // [D], [D], [S][D], [S][D]
@@ -193,19 +192,12 @@ struct AttnArgs {
 
 // NT threads: 512 = two waves per SIMD.  One wave's softmax (the kernel's VALU-bound part: 144 exponentials and their bookkeeping per lane and query block)
 // then runs under the other's matrix work and memory latency; with 256 threads the query blocks of a head were three serial rounds of load -> MFMA ->
-// softmax -> MFMA -> store per wave.  (DMVAE_ATTN_THREADS=256 at build time restores the one-wave-per-SIMD form.)
-#ifndef DMVAE_ATTN_THREADS
-#define DMVAE_ATTN_THREADS 512
-#endif
-// 1: with S = 32 k + 1 (ViT: 256 patches + class token) the last query of every head is served by extra single-query waves (64 more workgroups) instead of a
-// ninth 32-query block.  Measured SLOWER: 31.0 -> 42.4 us per call -- the extra workgroups cannot be resident next to the 512 that fill the chip, and dispatching
-// 64 more costs more than the 5 us the ninth block does (correct, tests pass on it; compiled out).
-#ifndef DMVAE_ATTN_LONE
-#define DMVAE_ATTN_LONE 0
-#endif
+// softmax -> MFMA -> store per wave.  
+constexpr int ATTN_THREADS = 512;
+// (Serving the class token's query -- S = 32 k + 1 -- by extra single-query workgroups instead of a ninth 32-query block was built and measured slower: DESIGN.md 9.8-6.)
 template <int DP, bool NR>
-__global__ __launch_bounds__(DMVAE_ATTN_THREADS) void attention_kernel(AttnArgs a) {
-  constexpr int NT = DMVAE_ATTN_THREADS;
+__global__ __launch_bounds__(ATTN_THREADS) void attention_kernel(AttnArgs a) {
+  constexpr int NT = ATTN_THREADS;
 #if __HIP_DEVICE_COMPILE__
   constexpr int KROW = DP == 64 ? 128 : 256;   // bytes per K row in LDS (8 or 16 chunks of 16 B, XOR-swizzled by key & 7)
   constexpr int KSTEPS = DP / 16, DB = DP / 32;
@@ -220,82 +212,7 @@ __global__ __launch_bounds__(DMVAE_ATTN_THREADS) void attention_kernel(AttnArgs 
                                                         : key * 256 + ((((c >> 2) ^ (key & 3))) << 6) + ((c & 3) << 4); };
   const int S = a.S, H = a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if constexpr (DP == 64 && !NR && NT == 512 && DMVAE_ATTN_LONE) {
-    if (a.lone && (int)blockIdx.x >= a.BH) {
-      // ---- one query (index S - 1) of one (batch, head) per wave, on the vector ALU: scores over the keys along the lanes, P V with the channels along the lanes.
-      // With S = 257 the 32-query blocks are nine for eight waves: one wave of each head ran a second round for ONE query while seven idled (5 of 31 us per call).
-      const int bh = ((int)blockIdx.x - a.BH) * (NT / 64) + wave;
-      if (bh >= a.BH) return;
-      const int b1 = bh / H, h1 = bh % H, qi = S - 1;
-      const bf16* q1 = a.q + b1 * a.q_bs + h1 * a.q_hs + (size_t)qi * a.q_rs;
-      const bf16* k1 = a.k + b1 * a.k_bs + h1 * a.k_hs;
-      const bf16* v1 = a.v + b1 * a.v_bs + h1 * a.v_hs;
-      uint4 qv[8];
-#pragma unroll
-      for (int c = 0; c < 8; c++) qv[c] = *reinterpret_cast<const uint4*>(q1 + c * 8);
-      constexpr int KJ = (ATT_KEYS + 63) / 64;      // keys per lane: lane + 64 j
-      float sc[KJ];
-#pragma unroll
-      for (int j = 0; j < KJ; j++) {
-        const int key = lane + 64 * j, keyc = key < S ? key : S - 1;   // loads are unconditional (a VMEM load under an exec-masked branch gets a vmcnt(0) of its own: 76 serial round trips)
-        float acc = 0.f;
-        uint4 kv[8];
-#pragma unroll
-        for (int c = 0; c < 8; c++) kv[c] = *reinterpret_cast<const uint4*>(k1 + (size_t)keyc * a.k_rs + c * 8);
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-          const bf16x8 kq = *reinterpret_cast<const bf16x8*>(&kv[c]), qq = *reinterpret_cast<const bf16x8*>(&qv[c]);
-#pragma unroll
-          for (int e = 0; e < 8; e++) acc = fmaf((float)kq[e], (float)qq[e], acc);
-        }
-        sc[j] = key < S ? acc : -INFINITY;
-      }
-      float m = sc[0];
-#pragma unroll
-      for (int j = 1; j < KJ; j++) m = fmaxf(m, sc[j]);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-      const float ec = a.scale * 1.4426950408889634f, emc = m * ec;
-      float* sp = reinterpret_cast<float*>(smem) + wave * (KJ * 64);      // this wave's P row (bf16-rounded, as the matrix path feeds it to the second product)
-      float sum = 0.f;
-#pragma unroll
-      for (int j = 0; j < KJ; j++) {
-        const float e = __builtin_amdgcn_exp2f(fmaf(sc[j], ec, -emc));
-        sum += e;
-        sp[lane + 64 * j] = (float)(bf16)e;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-      __builtin_amdgcn_s_waitcnt(0xC07F);      // own LDS writes done (one wave reads only what it wrote)
-      // P V: lane = (key group g = lane >> 3, 8-channel chunk c = lane & 7); keys g, g + 8, ..: 16-B loads, four in flight; then the eight groups are folded
-      const int g = lane >> 3, c = lane & 7;
-      float od[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const bf16* vch = v1 + c * 8;
-      constexpr int NIT = (ATT_KEYS + 7) / 8;      // 36
-#pragma unroll 4
-      for (int i = 0; i < NIT; i++) {
-        const int key = g + 8 * i, keyc = key < S ? key : S - 1;
-        const uint4 vv = *reinterpret_cast<const uint4*>(vch + (size_t)keyc * a.v_rs);
-        const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(&vv);
-        const float pk = key < S ? sp[keyc] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; e++) od[e] = fmaf(pk, (float)v8[e], od[e]);
-      }
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        od[e] += __shfl_xor(od[e], 8, 64); od[e] += __shfl_xor(od[e], 16, 64); od[e] += __shfl_xor(od[e], 32, 64);
-      }
-      if (g == 0) {
-        const float inv1 = 1.f / sum;
-        uint4 o4;
-        o4.x = pack_bf16(od[0] * inv1, od[1] * inv1); o4.y = pack_bf16(od[2] * inv1, od[3] * inv1);
-        o4.z = pack_bf16(od[4] * inv1, od[5] * inv1); o4.w = pack_bf16(od[6] * inv1, od[7] * inv1);
-        *reinterpret_cast<uint4*>(a.out + ((size_t)b1 * S + qi) * (H * a.D) + h1 * a.D + c * 8) = o4;
-      }
-      return;
-    }
-  }
-  const int Sq = (DP == 64 && !NR && NT == 512 && DMVAE_ATTN_LONE && a.lone) ? S - 1 : S;      // queries the 32-query blocks cover
+  const int Sq = S;      // queries the 32-query blocks cover
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const bf16* qb_ = a.q + b * a.q_bs + h * a.q_hs;
   const bf16* kb_ = a.k + b * a.k_bs + h * a.k_hs;
@@ -476,9 +393,7 @@ static int launch_attention(const AttnArgs& a, int batch, hipStream_t stream) {
   }
   AttnArgs b_ = a;
   b_.BH = batch * a.H;
-  const int extra = (DP == 64 && !NR && DMVAE_ATTN_THREADS == 512 && a.lone) ? (b_.BH + 7) / 8 : 0;
-  if (!extra) b_.lone = 0;
-  hipLaunchKernelGGL((attention_kernel<DP, NR>), dim3(batch * a.H + extra), dim3(DMVAE_ATTN_THREADS), lds, stream, b_);
+  hipLaunchKernelGGL((attention_kernel<DP, NR>), dim3(batch * a.H), dim3(ATTN_THREADS), lds, stream, b_);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -496,7 +411,6 @@ extern "C" int dmvae_attention_qkv_bf16(const void* qkv, void* out, int batch, i
   a.q_bs = a.k_bs = a.v_bs = (long long)seq * 3 * C; a.q_hs = a.k_hs = a.v_hs = head_dim;
   a.q_rs = a.k_rs = a.v_rs = (int)(3 * C);
   a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale;
-  a.lone = (DMVAE_ATTN_LONE && seq > 32 && seq % 32 == 1) ? 1 : 0;
   return launch_attention<64>(a, batch, stream);
 }
 

@@ -69,7 +69,7 @@ def packed(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0, cols_pad
     return p
 
 
-_PACK_BATCHED = os.environ.get("DMVAE_PACK_BATCHED", "1") != "0"
+_PACK_BATCHED = True      # tests/test_gpu_pack_batched.py switches it off to compare with the per-weight lazy route
 
 
 def new_pack_registry() -> dict:
@@ -256,12 +256,14 @@ class AttnBlockFn(torch.autograd.Function):
         return dx, dnw, dnb, dqw, dqb, dkw, dkb, dvw, dvb, dpw, dpb
 
 
+UPS_SUBPIXEL = None      # None: the default below; True / False: tests force a route (tests/test_gpu_subpixel.py, test_gpu_parity_fp32.py)
+
+
 def _subpixel_upsample() -> bool:
-    """DMVAE_UPS_SUBPIXEL=0: Upsample's conv as nine taps per output pixel gathered from the half-resolution image (the first implementation; A/B runs).
-    Unset: on, except in the fp32 parity mode, which keeps the reference's own evaluation order (the layer agrees to 1e-4 either way --
-    tests/test_gpu_parity_fp32.py -- but the four-step Adam trajectory test amplifies any reordering of f32 sums past that bar); =1 forces it on there too."""
-    v = os.environ.get("DMVAE_UPS_SUBPIXEL", "")
-    return (not parity.on()) if v == "" else v != "0"
+    """Upsample's conv in its sub-pixel form -- on, except in the fp32 parity mode, which keeps the reference's own evaluation order: nine taps
+    per output pixel gathered from the half-resolution image (the layer agrees to 1e-4 either way -- tests/test_gpu_parity_fp32.py -- but the four-step Adam
+    trajectory test amplifies any reordering of f32 sums past that bar)."""
+    return (not parity.on()) if UPS_SUBPIXEL is None else bool(UPS_SUBPIXEL)
 
 
 class ConvFn(torch.autograd.Function):
@@ -517,12 +519,12 @@ class NormConvOutFn(torch.autograd.Function):
         cout = cw.shape[0]
         dyf = _c(dy.float())
         dyp = ops.nchw_to_nhwc_bf16(dyf, c_pad=32)                 # the input-gradient conv's reduction dimension: 32-channel K steps
-        if os.environ.get("DMVAE_CONVOUT_THIN", "1") != "0" and not parity.on() and ops.conv_out_wgrad_supported(a.shape[0], a.shape[1], a.shape[2], a.shape[3], cout):
+        if not parity.on() and ops.conv_out_wgrad_supported(a.shape[0], a.shape[1], a.shape[2], a.shape[3], cout):
             # three output channels: `a` is read once against three x-shifted planar copies of the gradient (csrc/wgrad_thin.hip: 570 -> ~150 us at B = 32);
             # the bias gradient is the plain sum of the gradient
             dwp = ops.conv_out_wgrad(dyf, a)
             dbp = dyf.sum(dim=(0, 2, 3))
-        elif cout <= 8 and a.numel() // a.shape[-1] >= 16384 and os.environ.get("DMVAE_CONVOUT_IM2COL", "1") != "0" and not parity.on():
+        elif cout <= 8 and a.numel() // a.shape[-1] >= 16384 and not parity.on():
             # With 3 output channels a 128-row weight-gradient tile is 98 % padding (1.4 ms at B = 32).  Instead: im2col of the GRADIENT
             # (8 padded channels x 9 taps = 72 columns, col[q][t*8+co] = dy[q + off(t)][co]) and ONE 1x1 weight-gradient GEMM against `a`:
             #   G[(t, co)][ci] = sum_q dy[q + off(t)][co] * a[q][ci]  =  dW[co][ci][8 - t]   (the tap seen from the other side),
@@ -632,9 +634,6 @@ def _bf_km(w: torch.Tensor) -> torch.Tensor:
     return packed(w, kmajor=True, frozen=True)._dmvae_kmajor.view(cin // 32, cout, 32)
 
 
-_KMAJOR_FROZEN = os.environ.get("DMVAE_LINEAR_KMAJOR", "1") != "0"     # 0: frozen weights too are read row-major (A/B runs)
-
-
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, act: int = ops.ACT_NONE) -> torch.Tensor:
     """nn.Linear under autocast(bf16) on this build's GEMM kernels (no vendor library): x [..., K] bf16; w [N, K] and b [N] the f32 parameters (their bf16
     copies are cached / shadowed, `_bf`) or already-bf16 tensors (a frozen bf16 shadow module).  f32 accumulation, bias added in f32, bf16 result, optional
@@ -656,7 +655,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, a
         # False for the DMD loss's evaluations still changes every few steps: it keeps the row-major shadow its optimiser maintains) -- : the K-tile-major
         # copy, packed once per (storage, version).  Anything that is not the parameter object itself -- a view of an optimiser's bf16 shadow, which the fused
         # AdamW step rewrites through raw pointers without moving data_ptr or _version -- is read as it is, live.
-        if isinstance(w, torch.nn.Parameter) and not w.requires_grad and not hasattr(w, "_dmvae_epoch") and w.dim() == 2 and _KMAJOR_FROZEN:
+        if isinstance(w, torch.nn.Parameter) and not w.requires_grad and not hasattr(w, "_dmvae_epoch") and w.dim() == 2:
             return ops.linear_bf16(x, _bf_km(w), bb, act)
         return ops.linear_bf16(x, (w if w.dtype == bf16 else _bf(w)).view(n, k), bb, act)
     wb = w if w.dtype == bf16 else _bf(w)
@@ -744,9 +743,11 @@ class SiluFn(torch.autograd.Function):
         return ops.silu_bwd(x, _c(dy).to(bf16))
 
 
+ATTN_BWD_FUSED = True      # False: the GEMM-composed attention backward (probabilities through HBM; the first implementation) -- tests compare the two
+
+
 def _fused_attn_bwd() -> bool:
-    """DMVAE_ATTN_BWD_FUSED=0: the GEMM-composed attention backward (probabilities through HBM; the first implementation, kept for A/B runs and tests)."""
-    return os.environ.get("DMVAE_ATTN_BWD_FUSED", "1") != "0"
+    return ATTN_BWD_FUSED
 
 
 def _attention_bwd(qkv: torch.Tensor, do: torch.Tensor, heads: int, scale: float) -> torch.Tensor:

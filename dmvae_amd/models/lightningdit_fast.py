@@ -40,8 +40,8 @@ def _bf(p):
     return cached(p)
 
 
-_FUSED_ATTN = os.environ.get("DMVAE_DIT_FUSED_ATTN", "1") != "0"
-_FUSED_QKNORM = os.environ.get("DMVAE_DIT_FUSED_QKNORM", "1") != "0"      # QK-norm + RoPE inside the attention kernel
+_FUSED_ATTN = True        # False: attention composed from batched GEMMs + softmax (tests compare)
+_FUSED_QKNORM = True      # QK-norm + RoPE inside the attention kernel
 
 
 def _attention(qkv, blk, rope, heads):

@@ -47,10 +47,7 @@ _WS = {}
 # bench.py sets this to a list to time the dominant kernel with HIP events on the launch stream:
 # entries are (name, start_event, end_event, algorithmic_flops)
 KERNEL_TIMING = None
-_PP_KORDER = "false" if os.environ.get("DMVAE_PP_KORDER", "1") == "0" else "true"   # csrc/conv_pp.hip::pick
-_PP_SUBPIXEL = os.environ.get("DMVAE_PP_SUBPIXEL", "1") != "0"                        # csrc/conv_pp.hip::dmvae_conv_pp_try
-_KMAJOR = os.environ.get("DMVAE_PP_KMAJOR", "1") != "0"                               # 0: the halo conv reads the tap-major weights (A/B)
-_PP_HALO = int(os.environ.get("DMVAE_PP_HALO", "3") or "0")                            # csrc/conv_pp.hip::pick
+_PP_HALO = 3          # csrc/conv_pp.hip::halo_mode: both tile shapes run the kx-halo form (bench.py names the dominant instantiation with it)
 
 
 def workspace(nbytes: int, device, slot: str = "main") -> torch.Tensor:
@@ -86,14 +83,11 @@ def pack_conv_weight(w: torch.Tensor, for_dgrad: bool = False, rows_pad: int = 0
     return out
 
 
-_KMAJOR_ALL = os.environ.get("DMVAE_PP_KMAJOR_ALL", "1") != "0"     # 0: K-tile-major weights only on the kx-halo instantiations (round 2's state)
-
-
 def _weight_operand(w_packed: torch.Tensor, d) -> int:
     """Address of the weight operand for descriptor d: the K-tile-major copy (and d.w_layout = 1) where the packed tensor carries one and the library says
-    the call runs on the kx-halo kernel (dmvae_conv_halo_applies), else the tap-major tensor itself."""
+    the call runs on the large-shape kernel (dmvae_conv_kmajor_applies), else the tap-major tensor itself."""
     wk = getattr(w_packed, "_dmvae_kmajor", None)
-    if wk is not None and _KMAJOR and (_lib.lib().dmvae_conv_kmajor_applies(ctypes.byref(d)) if _KMAJOR_ALL else _lib.lib().dmvae_conv_halo_applies(ctypes.byref(d))):
+    if wk is not None and _lib.lib().dmvae_conv_kmajor_applies(ctypes.byref(d)):
         d.w_layout = 1
         return wk.data_ptr()
     return w_packed.data_ptr()
@@ -150,13 +144,13 @@ def _conv_label(n, ho, wo, cin, cout, ks, upsample, out_f32, stride, transposed,
     sub = bool(transposed) and ks == 4 and stride == 2    # per-parity 2x2 decomposition: 4 of the 16 taps per output pixel are multiply-adds
     if cin % 32 == 0 and cout >= 64 and cout % 8 == 0 and n * ho * wo >= 16384:
         ups1 = int(upsample) == 1                  # nearest x2 folded into the gather: its own template variant
-        gen = (int(upsample) == 2 or stride == 2 or ks == 4 or bool(transposed)) and not (sub and _PP_SUBPIXEL)   # the general-gather instantiation
+        gen = (int(upsample) == 2 or stride == 2 or ks == 4 or bool(transposed)) and not sub   # the general-gather instantiation
         t = lambda f: "true" if f else "false"
         dyn = os.environ.get("DMVAE_PP_DYNAMIC", "0") not in ("", "0") and not ups1 and not out_f32 and (n * ho * wo // (512 if cout <= 128 else 256)) * ((cout + 255) // 256 if cout > 128 else 1) > 256
-        # the kx-halo form (conv_pp.hip, HALO): plain 3x3 with a bf16 result in the chunk-outer K order; DMVAE_PP_HALO bit 0 = 256 x 256 tile, bit 1 = 128 x 512
-        halo = ks == 3 and not gen and not sub and not ups1 and not out_f32 and _PP_KORDER == "true" and (_PP_HALO != 0 if cout > 128 else bool(_PP_HALO & 2))
-        label = "conv_pp_kernel<%s, %s, %s, %s, %s, %s, %s, %s, %s>" % (("64, 1024, 1, 8, 4" if (halo and cout <= 64 and not stats and not (_PP_HALO & 8)) else ("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4"), t(ups1), t(out_f32),
-                                                                       "false" if ups1 else ("true" if gen else _PP_KORDER), t(gen), t(sub and _PP_SUBPIXEL), t(dyn), t(stats), t(halo))
+        # the kx-halo form (conv_pp.hip, HALO): plain 3x3 with a bf16 result in the chunk-outer K order
+        halo = ks == 3 and not gen and not sub and not ups1 and not out_f32
+        label = "conv_pp_kernel<%s, %s, %s, %s, %s, %s, %s, %s, %s>" % (("64, 1024, 1, 8, 4" if (halo and cout <= 64 and not stats) else ("128, 512" if cout <= 128 else "256, 256") + ", 2, 4, 4"), t(ups1), t(out_f32),
+                                                                       "false" if ups1 else "true", t(gen), t(sub), t(dyn), t(stats), t(halo))
     else:
         label = "conv_fwd_kernel"
     return label, 2.0 * n * ho * wo * cout * cin * (4 if sub else ks * ks)
@@ -206,14 +200,11 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
     return y
 
 
-_GN_FUSED = os.environ.get("DMVAE_GN_STATS_FUSED", "1") != "0"      # csrc/conv_fwd.hip::dmvae_conv2d_nhwc_fwd_gnstats
-
-
 def conv2d_nhwc_gnstats(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, ks: int = 3,
                         act: int = ACT_NONE, stride: int = 1, transposed: bool = False, groups: int = 32, eps: float = 1e-6):
     """(y, stats): conv2d_nhwc plus the GroupNorm statistics [N, groups, 2] = (mean, rstd) of its bf16 result, which the large-shape conv kernel sums in its
     epilogue (no separate pass over y); other shapes / the f32 parity mode: the conv followed by groupnorm_stats."""
-    if (x.dtype == f32 and parity.on()) or not _GN_FUSED:
+    if x.dtype == f32 and parity.on():
         y = conv2d_nhwc(x, w_packed, bias, residual, ks=ks, act=act, stride=stride, transposed=transposed)
         return y, groupnorm_stats(y, groups, eps)
     x = _req(x, bf16, "x")
@@ -247,7 +238,7 @@ def conv2d_nhwc_gnstats(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[
         sub = bool(transposed) and ks == 4 and stride == 2
         plain = ks in (1, 3) and stride == 1 and not transposed
         tp = 512 if cout <= 128 else 256
-        fused = (plain or (sub and _PP_SUBPIXEL)) and cout % groups == 0 and (cout // groups) % 4 == 0 and ((h * w_) if sub else (ho * wo)) % tp == 0 and _PP_KORDER == "true"
+        fused = (plain or sub) and cout % groups == 0 and (cout // groups) % 4 == 0 and ((h * w_) if sub else (ho * wo)) % tp == 0
         label, fl = _conv_label(n, ho, wo, cin, cout, ks, 0, False, stride, transposed, fused)
         timing.append((label + (" + gn stats" if label == "conv_fwd_kernel" or not fused else ""), e0, e1, fl))
     return y, stats

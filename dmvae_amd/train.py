@@ -331,7 +331,7 @@ class DMDTrainer(_AdversarialBranch):
                  t0: float = 0.0, t1: float = 1.0, latent_mean: float = 0.0, latent_scale: float = 1.0, vae_train_every: int = 5,
                  time_dist_shift: float = 1.0, warmup_steps: int = 1000, max_norm: float = 1.0, bucket_bytes: int = 64 << 20,
                  disc: Optional[torch.nn.Module] = None, disc_weight: float = 0.5, disc_start_step: int = 0, disc_lr: float = 1e-4,
-                 disc_wd: float = 0.0005, bcr: float = 1.0, bcr_cut: float = 0.2, batch_cfg: Optional[bool] = None):
+                 disc_wd: float = 0.0005, bcr: float = 1.0, bcr_cut: float = 0.2, batch_cfg: Optional[bool] = None, direct_grads: bool = True):
         self.vae, self.lpips, self.teacher, self.student = vae, lpips, teacher, student
         self._init_disc(disc, disc_weight, disc_start_step, disc_lr, disc_wd, warmup_steps, max_norm, bcr, bcr_cut, bucket_bytes)     # train_dmd.py:92-93,475
         self.w = dict(l1=l1, l2=l2, lpips=lpips_w)
@@ -339,8 +339,8 @@ class DMDTrainer(_AdversarialBranch):
         # Conditional + unconditional evaluation of a velocity model as ONE 2B-sample call.  None (default): only when BOTH models are this build's
         # LightningDiT on its per-sample HIP route and in eval mode at the call (`_batchable`) -- any other callable / nn.Module (a graph captured at
         # batch B, batch-coupled ops, a per-call RNG draw such as label drop-out in train mode) gets the reference's four B-sized calls
-        # (train_dmd.py:211-217).  True: the caller vouches that its models are per-sample; False / DMVAE_DMD_BATCH_CFG=0: never.
-        self.batch_cfg = False if os.environ.get("DMVAE_DMD_BATCH_CFG", "1") == "0" else batch_cfg
+        # (train_dmd.py:211-217).  True: the caller vouches that its models are per-sample; False: never.
+        self.batch_cfg = batch_cfg
         self.t0, self.t1, self.latent_mean, self.latent_scale = t0, t1, latent_mean, latent_scale
         self.vae_train_every, self.time_dist_shift, self.max_norm = vae_train_every, time_dist_shift, max_norm
         for p in vae.parameters():
@@ -350,7 +350,7 @@ class DMDTrainer(_AdversarialBranch):
         # decoder, bottleneck and encoder-block gradients are written by the HIP Functions straight into the flat buffer (each of those parameters
         # receives exactly one gradient per backward); the embeddings' gradients arrive through stock autograd and accumulate into their zeroed views
         self.fp = FlatParams(params, with_ema=False)
-        if os.environ.get("DMVAE_DMD_DIRECT_GRADS", "1") != "0":
+        if direct_grads:
             from .models.vit_fast import hip_path_supported
             vit = vae.encoder.model
             pre = ("decoder.", "bottle_neck.")

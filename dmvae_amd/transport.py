@@ -20,7 +20,7 @@ import torch as th
 
 from . import ops
 
-FUSED_STATE_UPDATE = os.environ.get("DMVAE_SAMPLER_FUSED", "1") != "0"      # A/B switch: 0 composes the Euler-Maruyama update from tensor ops
+FUSED_STATE_UPDATE = True      # False composes the Euler-Maruyama update from tensor ops (tests/test_gpu_sampler.py compares the two)
 
 
 class ModelType(enum.Enum):

@@ -58,7 +58,7 @@ typedef struct dmvae_conv_desc {
 } dmvae_conv_desc;
 
 /* 1 when conv2d_nhwc_fwd / _gnstats run descriptor d on the kx-halo kernel (plain 3x3, bf16 result, large shapes: csrc/conv_pp.hip) and therefore accept
- * w_layout = 1; 0 otherwise.  Pure function of d and of the process's DMVAE_PP_* environment. */
+ * w_layout = 1; 0 otherwise.  Pure function of d. */
 int dmvae_conv_halo_applies(const dmvae_conv_desc* d);
 /* 1 when the call runs on the large-tile conv kernel at all (csrc/conv_pp.hip, any instantiation: plain 3x3, 1x1, the 4x4 stride-2 conv and its per-parity
  * transpose, Upsample's folded gather) and may therefore carry w_layout = 1; dmvae_conv_halo_applies(d) = 1 is the subset that runs the kx-halo form. */

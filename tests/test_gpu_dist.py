@@ -184,3 +184,28 @@ def test_bench_json_is_the_last_stdout_line_under_rccl():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["metric"].startswith("images/sec")
     c = d["comm"]
     assert c["backend"] == "nccl" and c["buckets"] >= 3 and c["bytes"] > 200e6 and c["launched_in_backward"] == c["buckets"] and c["wait_ms"] is not None
+
+
+def test_bench_line_labels_the_dynamic_instantiation_when_more_than_one_rank_would_run():
+    """What the first real multi-GPU run will print, exercised on one GPU: the collective path (DMVAE_FORCE_DIST=1: a real RCCL group of one rank) WITH dynamic tile
+    claiming on (what dist.init_distributed_mode switches on for world > 1).  `roofline.kernel` must name the DYN instantiation of the dominant conv kernel and
+    carry launches (a label that matches no launched kernel would report zeros), the `comm` dictionary must show every bucket but at most the last launched from a
+    gradient hook during backward, an exposed wait, and `dynamic_tile_claiming`; `env` and the three windows are in the line."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", DMVAE_FORCE_DIST="1", DMVAE_PP_DYNAMIC="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--time-every", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "\n".join(l for l in r.stderr.splitlines() if not l.startswith("frame #"))[:3000]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    rf = d["roofline"]
+    # template arguments <TM, TP, WM, WP, NBUF, UPS, F32, KO, GEN, SUB, DYN, STATS, HALO>: DYN is the third from the end
+    args = rf["kernel"].split("<")[1].split(">")[0].replace(" ", "").split(",")
+    assert args[-3] == "true", rf["kernel"]
+    assert rf["launches"] > 0 and rf["achieved"] > 0 and 0 < rf["frac"] < 1, rf
+    assert d["roofline_wgrad"]["launches"] > 0 and d["linear_gemm"]["launches"] > 0
+    c = d["comm"]
+    assert c["backend"] == "nccl" and c["dynamic_tile_claiming"] is True
+    assert c["buckets"] >= 3 and c["launched_in_backward"] >= c["buckets"] - 1 and c["wait_ms"] is not None and c["wait_ms"] >= 0
+    assert len(d["ms_per_step_windows"]) == 3 and d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"]
+    assert set(d["env"]) >= {"sclk_mhz_avg", "power_w_avg", "temp_c", "gpu_uuid_hash"}

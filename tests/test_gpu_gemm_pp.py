@@ -199,7 +199,8 @@ def test_argument_errors():
 _TILE_SCRIPT = r"""
 import sys, torch
 sys.path.insert(0, %r)
-from dmvae_amd import ops
+from dmvae_amd import ops, _lib
+_lib.lib().dmvae_debug_gemm_cfg(int(sys.argv[2]))       # force one menu entry for the whole process
 g = torch.Generator(device="cuda").manual_seed(3)
 out = {}
 for m, n, k in [(8224, 1024, 1024), (4096, 1152, 1152), (777, 520, 384), (777, 544, 384), (300, 264, 416)]:
@@ -214,29 +215,12 @@ torch.save(out, sys.argv[1])
 
 
 def test_every_tile_of_the_menu_gives_the_same_bits(tmp_path):
-    """DMVAE_GEMM_CFG forces one menu entry for the whole process (the plan is latched at first use), so each runs in a fresh process."""
+    """dmvae_debug_gemm_cfg forces one menu entry; each runs in a fresh process (first-launch attributes, caches)."""
     res = []
     for cfg in range(10):
         f = tmp_path / ("cfg%d.pt" % cfg)
-        env = dict(os.environ, DMVAE_GEMM_CFG=str(cfg))
-        subprocess.run([sys.executable, "-c", _TILE_SCRIPT % ROOT, str(f)], check=True, env=env, timeout=600)
+        subprocess.run([sys.executable, "-c", _TILE_SCRIPT % ROOT, str(f), str(cfg)], check=True, timeout=600)
         res.append(torch.load(f))
     for cfg in range(1, 10):
         for key in res[0]:
             assert torch.equal(res[0][key], res[cfg][key]), f"tile {cfg} differs from tile 0 at {key}"
-    # the other main loop (DMVAE_GEMM_LOOP=1: one hand-pipelined instruction stream per wave, one barrier per K tile) on tiles with more / as many / fewer token
-    # blocks than column blocks, and the four-wave 128 x 128 wave-tile entry that only exists with that loop: same bits (odd and even K-tile counts are both in the shapes)
-    for cfg in (0, 1, 3, 4, 10):
-        f = tmp_path / ("loop1_cfg%d.pt" % cfg)
-        env = dict(os.environ, DMVAE_GEMM_CFG=str(cfg), DMVAE_GEMM_LOOP="1")
-        subprocess.run([sys.executable, "-c", _TILE_SCRIPT % ROOT, str(f)], check=True, env=env, timeout=600)
-        got = torch.load(f)
-        for key in res[0]:
-            assert torch.equal(res[0][key], got[key]), f"pipelined loop, tile {cfg}, differs from the ping-pong loop at {key}"
-    for cfg in (3, 4):      # DMVAE_GEMM_LOOP=2: the pipelined loop with a barrier every second K step (six-slot rings only)
-        f = tmp_path / ("loop2_cfg%d.pt" % cfg)
-        env = dict(os.environ, DMVAE_GEMM_CFG=str(cfg), DMVAE_GEMM_LOOP="2")
-        subprocess.run([sys.executable, "-c", _TILE_SCRIPT % ROOT, str(f)], check=True, env=env, timeout=600)
-        got = torch.load(f)
-        for key in res[0]:
-            assert torch.equal(res[0][key], got[key]), f"two-step pipelined loop, tile {cfg}, differs from the ping-pong loop at {key}"

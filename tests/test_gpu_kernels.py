@@ -364,20 +364,30 @@ def test_kl_mmd_ragged_tiles_and_chunks(shape):
     assert torch.equal(dz3, dz) and torch.equal(mmd3, mmd)          # deterministic
 
 
-def test_kl_mmd_two_launch_path_matches_five_launch_path(monkeypatch):
+@pytest.fixture
+def kl_debug_reset():
+    """dmvae_debug_kl_mmd forces a path for the whole process: back to the planner's choice whatever the test did."""
+    yield
+    from dmvae_amd import _lib
+    _lib.lib().dmvae_debug_kl_mmd(-1, -1, -1)
+
+
+def test_kl_mmd_two_launch_path_matches_five_launch_path(kl_debug_reset):
     """At the training step's own shape (32 images x 256 tokens vs 256 prior samples) the op runs as TWO launches (pair kernel with the KL moment partials
-    folded in + one finishing kernel); DMVAE_KLMMD_FUSED=0 selects the five-launch path (streaming moment pass, single-block final, pair kernel, MMD
+    folded in + one finishing kernel); dmvae_debug_kl_mmd(0, -1, -1) selects the five-launch path (streaming moment pass, single-block final, pair kernel, MMD
     final, gradient pass).  Same results to f32 summation order (the two-launch path shares the columns of a row tile out over up to four workgroups at this size, so its
-    fixed summation order is a different one), both deterministic, both vs the f64 spec; with DMVAE_KLMMD_CSPLIT=1 the MMD part agrees bit for bit."""
+    fixed summation order is a different one), both deterministic, both vs the f64 spec; without the column split the MMD part agrees to the same bar."""
     ops = _ops()
     gen = torch.Generator().manual_seed(3)
     z = (torch.randn(32, 256, 32, generator=gen) * 0.8 + 0.1).to(DEV)
     y = torch.randn(32, 256, 32, generator=gen).to(DEV)
-    monkeypatch.setenv("DMVAE_KLMMD_FUSED", "1")
+    from dmvae_amd import _lib
+    dbg = _lib.lib().dmvae_debug_kl_mmd          # (fused, csplit, mfma), -1 = the planner's choice
+    dbg(1, -1, -1)
     kl_a, mmd_a, dz_a = ops.kl_mmd(z, y, w_kl=0.7, w_mmd=1.5)
     kl_a2, mmd_a2, dz_a2 = ops.kl_mmd(z, y, w_kl=0.7, w_mmd=1.5)
     assert torch.equal(kl_a, kl_a2) and torch.equal(mmd_a, mmd_a2) and torch.equal(dz_a, dz_a2)
-    monkeypatch.setenv("DMVAE_KLMMD_FUSED", "0")
+    dbg(0, -1, -1)
     kl_b, mmd_b, dz_b = ops.kl_mmd(z, y, w_kl=0.7, w_mmd=1.5)
     # MMD^2 = kxx/n^2 + kyy/m^2 - 2 kxy/(n m) cancels ~two digits: 1e-7 on the three f32 sums shows as ~1e-5 on the difference
     assert rel_err(mmd_a, mmd_b) < 5e-5 and rel_err(kl_a, kl_b) < 1e-6 and rel_err(dz_a, dz_b) < 1e-6
@@ -387,13 +397,19 @@ def test_kl_mmd_two_launch_path_matches_five_launch_path(monkeypatch):
     (0.7 * klm + 1.5 * mr.mean()).backward()
     assert rel_err(kl_a[:32].cpu(), klr) < 1e-4 and rel_err(mmd_a.cpu(), mr) < 1e-4 and rel_err(dz_a.cpu(), zr.grad) < 1e-4
     _, mmd_v, none = ops.kl_mmd(z, y, need_grad=False)                     # value-only call on the two-launch path
-    monkeypatch.setenv("DMVAE_KLMMD_FUSED", "1")
+    dbg(1, -1, -1)
     kl_v, mmd_v2, none2 = ops.kl_mmd(z, y, need_grad=False)
     assert none is None and none2 is None and rel_err(mmd_v, mmd_v2) < 5e-5 and rel_err(kl_v, kl_a) < 1e-6
-    monkeypatch.setenv("DMVAE_KLMMD_CSPLIT", "1")                         # no column split: same per-tile order as the five-launch path
-    _, mmd_c, dz_c = ops.kl_mmd(z, y, w_kl=0.7, w_mmd=1.5)                # (pair sums on the matrix cores: another fixed order, same bar as above)
-    assert rel_err(mmd_c, mmd_b) < 5e-5 and rel_err(dz_c, dz_b) < 1e-6
-    assert rel_err(mmd_c.cpu(), mr) < 1e-4 and rel_err(dz_c.cpu(), zr.grad) < 1e-4
+    try:
+        dbg(1, 1, -1)                                                     # no column split: same per-tile order as the five-launch path
+        _, mmd_c, dz_c = ops.kl_mmd(z, y, w_kl=0.7, w_mmd=1.5)            # (pair sums on the matrix cores: another fixed order, same bar as above)
+        assert rel_err(mmd_c, mmd_b) < 5e-5 and rel_err(dz_c, dz_b) < 1e-6
+        assert rel_err(mmd_c.cpu(), mr) < 1e-4 and rel_err(dz_c.cpu(), zr.grad) < 1e-4
+        dbg(1, -1, 0)                                                     # the scalar-FMA pair kernel instead of the matrix-core one
+        _, mmd_s, dz_s = ops.kl_mmd(z, y, w_kl=0.7, w_mmd=1.5)
+        assert rel_err(mmd_s, mmd_b) < 5e-5 and rel_err(dz_s, dz_b) < 1e-6
+    finally:
+        dbg(-1, -1, -1)
 
 
 def test_adamw_ema_golden():

@@ -66,12 +66,13 @@ def test_attn_block_vs_reference_f32():
     _run_block(AttnBlock(64), load_golden("attnblock"))
 
 
-@pytest.mark.parametrize("subpixel", ["0", "1"])
+@pytest.mark.parametrize("subpixel", [False, True])
 def test_upsample_vs_reference_f32(subpixel, monkeypatch):
     """Both evaluation orders of the layer: the reference's two-step form (what the mode uses by default) and the sub-pixel form the bf16 path uses
     (dmvae_amd/functional.py::ConvFn) -- the same function of (x, W), here both within 1e-4 of the reference's f32 capture."""
     from dmvae_amd.models.flux_ae import Upsample
-    monkeypatch.setenv("DMVAE_UPS_SUBPIXEL", subpixel)
+    from dmvae_amd import functional as Fn
+    monkeypatch.setattr(Fn, "UPS_SUBPIXEL", subpixel)
     _run_block(Upsample(32), load_golden("upsample"))
 
 

@@ -110,7 +110,7 @@ def test_subpixel_upsample_conv_vs_two_step_fp64(case):
 
 @pytest.mark.parametrize("case", [(1, 20, 28, 64, 96), (2, 64, 64, 128, 256)])
 def test_subpixel_route_vs_gather_route(case, monkeypatch):
-    """Arbitrary weights: the sub-pixel route and the first implementation (DMVAE_UPS_SUBPIXEL=0) differ only by where bf16 rounding falls on the weights."""
+    """Arbitrary weights: the sub-pixel route and the first implementation (functional.UPS_SUBPIXEL = False) differ only by where bf16 rounding falls on the weights."""
     from dmvae_amd import functional as Fn
     n, h, w_, cin, cout = case
     g = torch.Generator().manual_seed(7)
@@ -119,8 +119,8 @@ def test_subpixel_route_vs_gather_route(case, monkeypatch):
     b = torch.randn(cout, generator=g).to(DEV)
     dy = torch.randn(n, 2 * h, 2 * w_, cout, generator=g).to(BF).to(DEV)
     res = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("DMVAE_UPS_SUBPIXEL", flag)
+    for flag in (True, False):
+        monkeypatch.setattr(Fn, "UPS_SUBPIXEL", flag)
         xg, wg, bg = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
         y = Fn.ConvFn.apply(xg, wg, bg, 3, True)
         y.backward(dy)

@@ -178,7 +178,7 @@ def test_dmd_stage_step_harness():
     from dmvae_amd.train import DMDTrainer
     from dmvae_amd.utils.lpips import LPIPS
 
-    def run():
+    def run(direct_grads=True):
         torch.manual_seed(21)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -190,7 +190,7 @@ def test_dmd_stage_step_harness():
             for lin in (lp.lin0, lp.lin1, lp.lin2, lp.lin3, lp.lin4):
                 lin.model[-1].weight.fill_(1.0 / lin.model[-1].weight.shape[1])
         teacher, student = _TinyVelocity().cuda().requires_grad_(False), _TinyVelocity().cuda()
-        tr = DMDTrainer(vae, lp, teacher, student, dmd_weight=5.0, dmd_cfg_scale=2.0, num_classes=10, vae_train_every=2, warmup_steps=2)
+        tr = DMDTrainer(vae, lp, teacher, student, dmd_weight=5.0, dmd_cfg_scale=2.0, num_classes=10, vae_train_every=2, warmup_steps=2, direct_grads=direct_grads)
         g = torch.Generator(device="cuda").manual_seed(0)
         images = torch.rand(2, 3, 256, 256, device="cuda", generator=g) * 2 - 1
         labels = torch.tensor([3, 7], device="cuda")
@@ -215,11 +215,7 @@ def test_dmd_stage_step_harness():
     tr2, snaps2 = run()
     assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(snaps, snaps2))
     # direct gradient writes (decoder, bottleneck, encoder blocks) change no bit against plain autograd accumulation into the zeroed flat buffer
-    os.environ["DMVAE_DMD_DIRECT_GRADS"] = "0"
-    try:
-        tr3, snaps3 = run()
-    finally:
-        del os.environ["DMVAE_DMD_DIRECT_GRADS"]
+    tr3, snaps3 = run(direct_grads=False)
     assert getattr(tr, "fp").direct and not getattr(tr3.fp, "direct", False)
     assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(snaps, snaps3))
     # the bf16 shadows the fused optimiser step maintains are what a fresh conversion would give, and functional._bf serves them
