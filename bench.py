@@ -436,24 +436,24 @@ def main():
     # and committed under profiles/; null when the committed profile is for a different kernel
     traffic, traffic_src = None, None
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_conv_pp_traffic.json")) as f:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4_conv_pp_traffic.json")) as f:
             tp = json.load(f)
         static_twin = "conv_pp_kernel<256, 256, 2, 4, 4, false, false, true, false, false, false, false, %s>" % ("true" if ops._PP_HALO else "false")
         if tp.get("kernel") == static_twin and args.batch == LOCAL_BATCH:      # the DYN twin runs the same kernel body
             traffic = int(tp["hbm_MB_per_launch"] * 1e6)
-            traffic_src = "profiles/r3_conv_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, %d launches; FETCH_SIZE x2 per MI355X_MICROARCH.md)" % tp["launches_profiled"]
+            traffic_src = "profiles/r4_conv_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, %d launches; FETCH_SIZE x2 per MI355X_MICROARCH.md)" % tp["launches_profiled"]
     except (OSError, ValueError, KeyError):
         pass
     wg_traffic = None
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_wgrad_pp_traffic.json")) as f:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4_wgrad_pp_traffic.json")) as f:
             wt = json.load(f)
         if args.batch == LOCAL_BATCH:
             # both instantiations that carry the weight-gradient time: the 256 x 256 tile (plain 3x3 / 1x1 form) and the 128 x 384 halo tile of the >= 2^19-pixel shapes
             wg_traffic = {"bytes_per_launch": int(wt["hbm_MB_per_launch"] * 1e6), "kernel": wt["kernel"], "launches_profiled": wt["launches_profiled"],
                           "per_kernel": [{"kernel": k["kernel"], "bytes_per_launch": int(k["hbm_MB_per_launch"] * 1e6), "read_MB": k["hbm_read_MB_per_launch"],
                                           "write_MB": k["hbm_write_MB_per_launch"], "launches_profiled": k["launches_profiled"]} for k in wt.get("kernels", [])],
-                          "source": "profiles/r3_wgrad_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, tools/pmc_traffic_r3.sh; FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
+                          "source": "profiles/r4_wgrad_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, tools/pmc_traffic_r3.sh; FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
     except (OSError, ValueError, KeyError):
         pass
     out = {
@@ -517,19 +517,26 @@ def _flush_c_stdio() -> None:
 
 
 def _emit(line: str, rank0: bool) -> None:
-    """The ONE JSON line, as the last line on stdout: every rank first leaves the process group and flushes whatever native libraries buffered, then rank 0 prints."""
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
+    """The ONE JSON line, as the last line on stdout.  With a process group: every rank finishes its device work, meets the others, flushes whatever native
+    libraries buffered (RCCL's banner), rank 0 prints, and the process LEAVES WITHOUT TEARING THE GROUP DOWN (`os._exit`): `destroy_process_group()` / interpreter
+    shutdown race ProcessGroupNCCL's watchdog thread, which then aborts the process (rc -6, seen twice in ~12 runs of this command under a real RCCL group in round 4:
+    `c10d::ProcessGroupNCCL::Watchdog::run` rethrowing a HIP error from an event query) -- after the measurement, but before / instead of the line.  Nothing is lost
+    by not running destructors: the line is out, the OS reclaims the rest."""
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if grouped:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
     _flush_c_stdio()
     sys.stdout.flush()
     if rank0:
         print(line, flush=True)
+    if grouped:
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
-    try:
-        main()
-    finally:
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            torch.distributed.destroy_process_group()
+    main()

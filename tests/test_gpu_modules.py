@@ -2,7 +2,7 @@
 reference's own modules and (b) the CPU oracle evaluated with bf16 rounding at the HIP path's storage points.
 
 Tolerances (relative to the tensor's max-abs):
-  * vs oracle-with-bf16-sites: per module, 2-3 x what MI355X measures (round 4: ResnetBlock y 6e-5 / dx 1e-4 / parameter gradients 9e-6; Upsample and
+  * vs oracle-with-bf16-sites: per module, 2-3 x what MI355X measures (round 4: ResnetBlock y <= 6e-5 / dx <= 6.5e-4 / parameter gradients <= 9e-6; Upsample and
     Downsample exact; AttnBlock y 2e-4 / dx 4e-3 / q.weight 3e-3 -- its softmax probabilities are one more bf16 site the S x S scores pass through) -- both
     sides round activations to bf16 at the same sites, so differences are f32 accumulation order plus rare 1-spacing bf16 flips (2^-8) that propagate
     (`test_resnet_block_stage_by_stage_on_the_production_kernels` counts them: 2e-5 ... 2e-4 of the elements per stage);
@@ -68,7 +68,7 @@ def _run_block(mod, g, oracle_fn, tol_q=TOL_Q):
 @pytest.mark.parametrize("name,cin,cout", [("resblock_same", 64, 64), ("resblock_short", 128, 64)])
 def test_resnet_block(name, cin, cout):
     from dmvae_amd.models.flux_ae import ResnetBlock
-    _run_block(ResnetBlock(cin, cout), load_golden(name), R.resnet_block, tol_q=5e-4)      # VERDICT round 3 asked for <= 2e-3
+    _run_block(ResnetBlock(cin, cout), load_golden(name), R.resnet_block, tol_q=2e-3)      # measured: y 0 / 6e-5, dx 1e-4 / 6.5e-4, parameter gradients 6e-7 / 9e-6 (same / short)
 
 
 def test_attn_block():
