@@ -27,7 +27,7 @@ class PackEntry(Structure):
                 ("reserved", c_int32), ("start", c_ulonglong), ("count", c_ulonglong)]
 
 
-ABI_VERSION = 3     # include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*)
+ABI_VERSION = 4     # include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*; 4: dmvae_norm_conv_out_bwd*)
 
 # name -> (restype, argtypes); every symbol include/dmvae_hip.h declares
 SIGNATURES = {
@@ -118,6 +118,9 @@ SIGNATURES = {
     "dmvae_groupnorm_bwd_colsum": (c_int, [c_void_p] * 11 + [c_size_t] + [c_int] * 7 + [c_void_p]),
     "dmvae_groupnorm_bwd_reduce": (c_int, [c_void_p] * 9 + [c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_groupnorm_bwd_apply": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "dmvae_norm_conv_out_bwd_supported": (c_int, [c_int] * 6),
+    "dmvae_norm_conv_out_bwd_workspace": (c_size_t, [c_int] * 5),
+    "dmvae_norm_conv_out_bwd": (c_int, [c_void_p] * 10 + [c_size_t] + [c_int] * 7 + [c_void_p]),
     "dmvae_conv2d_nhwc_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(ConvDesc), c_int, c_void_p]),
     # fp32 parity mode (csrc/parity.hip)
     "dmvae_split3_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_size_t, c_size_t, c_size_t, c_size_t, c_int, c_void_p]),

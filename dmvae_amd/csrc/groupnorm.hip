@@ -363,6 +363,183 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const bf16* __restrict__
   }
 }
 
+// ---- conv_out(swish(norm_out(x))) backward with respect to x, gamma, beta (flux_ae.py:266-268) -----------------------------------------------------------
+// The decoder's last GroupNorm sits on its largest tensor ([N, 256, 256, 128]: 537 MB at B = 32) and its output gradient `da` is the input gradient of a conv with
+// THREE output channels: da[q][ci] = sum over (tap, co) of dy[q + off(tap)][co] * W[co][ci][tap] -- 27 multiply-adds per element from 54 bytes of dy per pixel.
+// Stored, `da` is written once (by an input-gradient conv whose reduction dimension is 89 % zero padding: 203 us) and read twice (by the two GroupNorm backward
+// passes): 1.6 GB.  Here both passes evaluate it in place on the matrix cores from a zero-bordered 4-channel bf16 copy of dy ([N][H + 2][W + 2][4], 17 MB,
+// cache-resident: convout_pad_kernel; the same rounding of dy as the stored-operand route) and round the result to bf16 where the stored tensor would have been:
+// the passes read x only.
+//   A wave owns 16-pixel runs of an image row.  Per run: 16 x (taps 0-7 x 4 channels) as the B operand of eight v_mfma_f32_16x16x32_bf16 (one per 16 channels;
+// lane (p, kg) supplies the 8-B pixels of taps 2 kg and 2 kg + 1 of pixel p: unconditional loads, the border is in the copy) plus eight v_mfma_f32_16x16x16_bf16
+// for tap 8; the weights (A operands) sit in LDS as the lanes read them (12 KB per block, converted from the f32 parameter at block start).  D comes out as
+// lane (p, kg) <-> pixel p, channels 16 f + 4 kg + i; it goes through a 16 x 128 bf16 tile in LDS (per wave, rows padded to 272 B) and comes back in the
+// elementwise kernels' layout -- lane <-> pixel 4 r + (lane >> 4), channels 8 (lane & 15) + 0..7 -- in which x is loaded and dx is stored as 1-KB contiguous
+// wave accesses, and from there on the arithmetic IS bwd_partial_kernel's / bwd_apply_kernel's.  (First version: lane <-> the MFMA's own layout, 64-B pieces of
+// 16 rows per access, a block's four waves on four channel quarters of the same pixels: 217 + 310 us, no faster with the MFMA, the sigmoid and the dy loads
+// all compiled out -- the access pattern was the cost.)
+__global__ void convout_pad_kernel(const float* __restrict__ dy, bf16* __restrict__ out, int N, int H, int W) {
+  const size_t total = (size_t)N * (H + 2) * (W + 2);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % (W + 2)) - 1;
+    const size_t r = i / (W + 2);
+    const int yy = (int)(r % (H + 2)) - 1, n = (int)(r / (H + 2));
+    bf16x4 v = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+      const float* s = dy + ((size_t)n * 3 * H + yy) * W + xx;
+      v[0] = (bf16)s[0]; v[1] = (bf16)s[(size_t)H * W]; v[2] = (bf16)s[(size_t)2 * H * W];
+    }
+    *reinterpret_cast<bf16x4*>(out + i * 4) = v;
+  }
+}
+
+constexpr int CO_ROW = 272;                               // bytes per pixel row of a wave's tile: 256 + 16 (b64 writes of 16 rows: 2-way conflicts at most)
+constexpr int CO_W1 = 8 * 64 * 16, CO_W2 = 8 * 64 * 8;    // A operands of the two steps, [fragment][lane]
+constexpr int CO_LDS = CO_W1 + CO_W2 + 4 * 16 * CO_ROW;   // 29696 B; the partial pass's block reduction (16 KB) reuses it
+
+template <bool APPLY>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void convout_bwd_kernel(const bf16* __restrict__ dyp, const float* __restrict__ wt, const bf16* __restrict__ x,
+                                                          const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ part, const float* __restrict__ S, bf16* __restrict__ dx, Geom g, int H, int W,
+                                                          const float* __restrict__ AB, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int accumulate) {
+  __shared__ __attribute__((aligned(16))) char smem[CO_LDS];
+  if (APPLY && AB && blockIdx.x == 0 && blockIdx.y == 0) {   // the parameter gradients ride on this launch, as in bwd_apply_kernel
+    for (int c = threadIdx.x; c < g.C; c += 256) {
+      double a = 0.0, b = 0.0;
+      for (int n = 0; n < N; n++) { a += AB[((size_t)n * g.C + c) * 2]; b += AB[((size_t)n * g.C + c) * 2 + 1]; }
+      dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)a;
+      dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)b;
+    }
+  }
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, p = l & 15, kg = l >> 4;
+  const int n = blockIdx.y, C = g.C;
+  // A operands: row r = lane & 15 of fragment f is channel 16 f + r; step 1: k = 8 kg + kk <-> tap 2 kg + (kk >> 2), output channel kk & 3; step 2 (K = 16):
+  // k = 4 kg + kk <-> tap 8 + kg (tap 8 only), output channel kk
+  for (int i = threadIdx.x; i < 8 * 64; i += 256) {
+    const int f = i >> 6, ll = i & 63, ch = 16 * f + (ll & 15), k8 = ll >> 4;
+    bf16x8 a;
+    bf16x4 a2;
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+      const int co = kk & 3, tap = 2 * k8 + (kk >> 2);
+      a[kk] = (bf16)(co < 3 ? wt[((size_t)co * C + ch) * 9 + tap] : 0.f);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) a2[kk] = (bf16)((kk < 3 && k8 == 0) ? wt[((size_t)kk * C + ch) * 9 + 8] : 0.f);
+    *reinterpret_cast<bf16x8*>(smem + i * 16) = a;
+    *reinterpret_cast<bf16x4*>(smem + CO_W1 + i * 8) = a2;
+  }
+  __syncthreads();
+  char* tile = smem + CO_W1 + CO_W2 + wv * 16 * CO_ROW;
+  const int cb = 8 * p;                                   // elementwise layout: this lane's eight channels (and pixel 4 r + kg of a run)
+  // per-group values once per channel PAIR (cpg is even: a pair never straddles two groups)
+  float mu[4], rs[4], s1[APPLY ? 4 : 1], s2[APPLY ? 4 : 1];
+  f32x2 ga[4], be[4];
+  const float inv_m = 1.0f / ((float)g.cpg * (float)g.HW);
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int c = cb + 2 * e;
+    const size_t gi = ((size_t)n * g.G + c / g.cpg) * 2;
+    mu[e] = stats[gi]; rs[e] = stats[gi + 1];
+    ga[e] = f32x2{gamma[c], gamma[c + 1]}; be[e] = f32x2{beta[c], beta[c + 1]};
+    if constexpr (APPLY) { s1[e] = S[gi] * inv_m; s2[e] = S[gi + 1] * inv_m; }
+  }
+  f32x2 A[4], B[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) { A[e] = f32x2{0.f, 0.f}; B[e] = f32x2{0.f, 0.f}; }
+  // tap t = (ky, kx) = (t / 3, t % 3) reads dy at (y + 1 - ky, x + 1 - kx): element offsets inside the bordered copy, relative to the pixel itself
+  const int Wp = W + 2;
+  const int t0 = 2 * kg, t1 = 2 * kg + 1;
+  const int lo0 = ((1 - t0 / 3) * Wp + (1 - t0 % 3)) * 4, lo1 = ((1 - t1 / 3) * Wp + (1 - t1 % 3)) * 4, lo8 = (-Wp - 1) * 4;
+  const bf16* dn = dyp + ((size_t)n * (H + 2) * Wp + Wp + 1 + p) * 4;      // pixel (0, p) of image n
+  const bf16* xn = x + ((size_t)n * g.HW + kg) * C + cb;
+  bf16* dxn = APPLY ? dx + ((size_t)n * g.HW + kg) * C + cb : nullptr;
+  const int p0 = blockIdx.x * g.ppc, p1 = min(p0 + g.ppc, g.HW);     // ppc % 16 == 0, HW % 16 == 0, W % 16 == 0: whole runs inside one image row
+  for (int q = p0 + 16 * wv; q < p1; q += 64) {
+    bf16x8 xr[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) xr[r] = ldraw(xn + (size_t)(q + 4 * r) * C);
+    const int y = q / W, x0 = q - y * W;
+    const bf16* d = dn + (y * Wp + x0) * 4;
+    const bf16x4 d0 = *reinterpret_cast<const bf16x4*>(d + lo0), d1 = *reinterpret_cast<const bf16x4*>(d + lo1);
+    const bf16x4 d8 = *reinterpret_cast<const bf16x4*>(d + lo8);      // every lane loads it; only k group 0's weights are non-zero there
+    // The sixteen MFMAs of a run are issued as inline assembly, four fragments at a time: four independent 16x16x32 products (C = 0) into early-clobber
+    // results, then the four tap-8 products (16x16x16) accumulated in place.  Through the builtins, fragment by fragment, hipcc emitted
+    //     v_mfma_f32_16x16x32_bf16 D, A, B, 0 ; v_mfma_f32_16x16x16_bf16 D, A2, B2, D
+    // back to back: an accumulate chain through two DIFFERENT opcodes gets no wait states from this toolchain and no interlock from the hardware -- the second
+    // read C before the first (8 passes) had written it and the first product was lost (tools/check_mfma_chain.py audits every kernel's assembly for the pair).
+    // In this order every dependent instruction is three MFMAs (>= 96 cycles) behind its producer; the trailing s_nop covers the last one before the VALU reads it.
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    union { bf16x8 v; i32x4 r; } b0;
+    union { bf16x4 v; i32x2 r; } b1;
+    b0.v = __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7);
+    b1.v = d8;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int f = 0; f < 4; f++) {
+        union { bf16x8 v; i32x4 r; } a;
+        a.v = *reinterpret_cast<const bf16x8*>(smem + ((4 * h + f) * 64 + l) * 16);
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[f]) : "v"(a.r), "v"(b0.r));
+      }
+#pragma unroll
+      for (int f = 0; f < 4; f++) {
+        union { bf16x4 v; i32x2 r; } a2;
+        a2.v = *reinterpret_cast<const bf16x4*>(smem + CO_W1 + ((4 * h + f) * 64 + l) * 8);
+        asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(acc[f]) : "v"(a2.r), "v"(b1.r));
+      }
+      asm volatile("s_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+#pragma unroll
+      for (int f = 0; f < 4; f++) {
+        const bf16x4 o = {(bf16)acc[f][0], (bf16)acc[f][1], (bf16)acc[f][2], (bf16)acc[f][3]};      // the stored tensor's rounding site
+        *reinterpret_cast<bf16x4*>(tile + p * CO_ROW + (16 * (4 * h + f) + 4 * kg) * 2) = o;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const bf16x8 dr = *reinterpret_cast<const bf16x8*>(tile + (4 * r + kg) * CO_ROW + cb * 2);
+      bf16x8 ob;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const f32x2 v = {(float)xr[r][2 * e], (float)xr[r][2 * e + 1]};
+        const f32x2 dd = {(float)dr[2 * e], (float)dr[2 * e + 1]};
+        const f32x2 xh = (v - f32x2{mu[e], mu[e]}) * f32x2{rs[e], rs[e]};
+        const f32x2 t = xh * ga[e] + be[e];
+        const f32x2 sg = {sigmoidf_(t[0]), sigmoidf_(t[1])};
+        const f32x2 dy = dd * (sg * (1.f + t * (1.f - sg)));
+        if constexpr (APPLY) {
+          const f32x2 o = f32x2{rs[e], rs[e]} * (dy * ga[e] - f32x2{s1[e], s1[e]} - xh * f32x2{s2[e], s2[e]});
+          ob[2 * e] = (bf16)o[0]; ob[2 * e + 1] = (bf16)o[1];
+        } else {
+          A[e] += dy; B[e] += dy * xh;
+        }
+      }
+      if constexpr (APPLY) *reinterpret_cast<bf16x8*>(dxn + (size_t)(q + 4 * r) * C) = ob;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the tile is rewritten by the next run
+    __builtin_amdgcn_wave_barrier();
+  }
+  if constexpr (!APPLY) {   // block_reduce_store's fold in this kernel's LDS: [thread][16] -> per channel over the 16 threads that hold it, in thread order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; e++) { red[threadIdx.x * 16 + e] = A[e >> 1][e & 1]; red[threadIdx.x * 16 + 8 + e] = B[e >> 1][e & 1]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int c = threadIdx.x, lc = c >> 3, e = c & 7;
+      float a = 0.f, b = 0.f;
+      for (int r = 0; r < 16; r++) { const float* qq = red + ((r * 16 + lc) * 16); a += qq[e]; b += qq[8 + e]; }
+      float* o = part + ((size_t)(n * g.nchunk + blockIdx.x) * C + c) * 2;
+      o[0] = a; o[1] = b;
+    }
+  }
+}
+
 static int make_geom(Geom& g, int N, int HW, int C, int G) {
   if (C <= 0 || C % 8 != 0 || C > 512 || G <= 0 || C % G != 0 || HW <= 0 || N <= 0) return -1;
   g.HW = HW; g.C = C; g.G = G; g.cpg = C / G;
@@ -526,4 +703,55 @@ extern "C" int dmvae_groupnorm_bwd_colsum(const void* da, const void* x, const v
 #undef DMVAE_GN_BAPPLYC
   DMVAE_CHECK_LAUNCH();
   return dmvae_colsum_final(colpart, (float*)colsum, n * g.nchunk, c, colsum_accumulate, stream);
+}
+
+// ---- conv_out(swish(norm_out(x))) backward: see convout_bwd_kernel ----
+static int convout_geom(Geom& g, int n, int h, int w, int c, int groups) {
+  if (n <= 0 || h <= 0 || w <= 0 || c != 128 || groups <= 0 || c % groups != 0 || (c / groups) % 2 != 0 || w % 16 != 0) return -1;
+  const long long hw = (long long)h * w;
+  if (hw * c * n >= (1ll << 40) || hw >= (1ll << 30)) return -1;
+  g.HW = (int)hw; g.C = c; g.G = groups; g.cpg = c / groups; g.tp_shift = 4; g.rows = 16;
+  int nchunk = (2048 + n - 1) / n;                    // ~2048 blocks, like make_geom
+  int ppc = (int)((hw + nchunk - 1) / nchunk);
+  ppc = (ppc + 15) / 16 * 16;
+  if (ppc < 64) ppc = 64;
+  g.ppc = ppc; g.nchunk = (int)((hw + ppc - 1) / ppc);
+  return 0;
+}
+extern "C" int dmvae_norm_conv_out_bwd_supported(int n, int h, int w, int c, int groups, int cout) {
+  Geom g;
+  return (cout == 3 && convout_geom(g, n, h, w, c, groups) == 0) ? 1 : 0;
+}
+extern "C" size_t dmvae_norm_conv_out_bwd_workspace(int n, int h, int w, int c, int groups) {
+  Geom g;
+  if (convout_geom(g, n, h, w, c, groups)) return 0;
+  return ((size_t)n * g.nchunk * c * 2 + (size_t)n * c * 2 + (size_t)n * groups * 2) * sizeof(float) + (size_t)n * (h + 2) * (w + 2) * 4 * sizeof(bf16);
+}
+extern "C" int dmvae_norm_conv_out_bwd(const void* dy, const void* w, const void* x, const void* stats, const void* gamma, const void* beta, void* dx, void* dgamma,
+                                       void* dbeta, void* workspace, size_t workspace_bytes, int n, int h, int wd, int c, int groups, int cout, int accumulate,
+                                       hipStream_t stream) {
+  Geom g;
+  DMVAE_CHECK_ARG(dy && w && x && stats && gamma && beta && dx && workspace, "norm_conv_out_bwd: null pointer");
+  DMVAE_CHECK_ARG(cout == 3 && convout_geom(g, n, h, wd, c, groups) == 0,
+                  "norm_conv_out_bwd: unsupported shape n=%d h=%d w=%d c=%d groups=%d cout=%d (c = 128, w %% 16 == 0, cout = 3)", n, h, wd, c, groups, cout);
+  DMVAE_CHECK_ARG(workspace_bytes >= dmvae_norm_conv_out_bwd_workspace(n, h, wd, c, groups), "norm_conv_out_bwd: workspace too small");
+  DMVAE_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "norm_conv_out_bwd: dgamma and dbeta go together");
+  float* part = (float*)workspace;
+  float* AB = part + (size_t)n * g.nchunk * c * 2;
+  float* S = AB + (size_t)n * c * 2;
+  bf16* dyp = (bf16*)(S + (size_t)n * groups * 2);       // 8-B pixels: every section before it is a multiple of 8 bytes
+  const dim3 grid(g.nchunk, n);
+  hipLaunchKernelGGL(convout_pad_kernel, dim3((unsigned)(((size_t)n * (h + 2) * (wd + 2) + 255) / 256)), dim3(256), 0, stream, (const float*)dy, dyp, n, h, wd);
+  DMVAE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(convout_bwd_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)dyp, (const float*)w, (const bf16*)x, (const float*)stats, (const float*)gamma,
+                     (const float*)beta, part, (const float*)nullptr, (bf16*)nullptr, g, h, wd, (const float*)nullptr, (float*)nullptr, (float*)nullptr, n, 0);
+  DMVAE_CHECK_LAUNCH();
+  const int waves = n * groups;
+  hipLaunchKernelGGL(bwd_final_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, part, (const float*)gamma, AB, S, g, n);
+  DMVAE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(convout_bwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)dyp, (const float*)w, (const bf16*)x, (const float*)stats, (const float*)gamma,
+                     (const float*)beta, (float*)nullptr, (const float*)S, (bf16*)dx, g, h, wd, dgamma ? (const float*)AB : (const float*)nullptr, (float*)dgamma,
+                     (float*)dbeta, n, accumulate);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
 }

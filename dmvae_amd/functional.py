@@ -518,7 +518,9 @@ class NormConvOutFn(torch.autograd.Function):
         x, st, a, nw, nb, cw = ctx.saved_tensors
         cout = cw.shape[0]
         dyf = _c(dy.float())
-        dyp = ops.nchw_to_nhwc_bf16(dyf, c_pad=32)                 # the input-gradient conv's reduction dimension: 32-channel K steps
+        fused = NORM_CONV_OUT_FUSED_BWD and not parity.on() and ops.norm_conv_out_bwd_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout)
+        # the stored-operand route's gradient operand: the input-gradient conv's reduction dimension in 32-channel K steps
+        dyp = None if fused else ops.nchw_to_nhwc_bf16(dyf, c_pad=32)
         if not parity.on() and ops.conv_out_wgrad_supported(a.shape[0], a.shape[1], a.shape[2], a.shape[3], cout):
             # three output channels: `a` is read once against three x-shifted planar copies of the gradient (csrc/wgrad_thin.hip: 570 -> ~150 us at B = 32);
             # the bias gradient is the plain sum of the gradient
@@ -536,9 +538,14 @@ class NormConvOutFn(torch.autograd.Function):
             dwp = g_.view(9, 8, c_).flip(0).permute(1, 2, 0).reshape(8, c_, 3, 3)
             dbp = gb.view(9, 8)[4]
         else:
-            dwp, dbp = ops.conv2d_nhwc_wgrad(dyp, a, 3)
-        da = ops.conv2d_nhwc(dyp, packed(cw, True, cols_pad=32), ks=3, flop_channels=(cw.shape[0], cw.shape[1]))
-        dx, dnw, dnb = ops.groupnorm_bwd(da, x, st, nw, nb, True, dg_out=_dst(nw), db_out=_dst(nb))
+            dwp, dbp = ops.conv2d_nhwc_wgrad(dyp if dyp is not None else ops.nchw_to_nhwc_bf16(dyf, c_pad=32), a, 3)
+        if fused:
+            # the 3 -> C input-gradient conv inside both GroupNorm backward passes (csrc/groupnorm.hip::convout_bwd_kernel): its result is 537 MB at B = 32,
+            # written once and read twice on the stored-operand route
+            dx, dnw, dnb = ops.norm_conv_out_bwd(dyf, cw, x, st, nw, nb, dg_out=_dst(nw), db_out=_dst(nb))
+        else:
+            da = ops.conv2d_nhwc(dyp, packed(cw, True, cols_pad=32), ks=3, flop_channels=(cw.shape[0], cw.shape[1]))
+            dx, dnw, dnb = ops.groupnorm_bwd(da, x, st, nw, nb, True, dg_out=_dst(nw), db_out=_dst(nb))
         dcw, dcb = _dst(cw), _dst(ctx.bias_param)
         if dcw is not None:
             dcw.copy_(dwp[:cout])
@@ -744,6 +751,7 @@ class SiluFn(torch.autograd.Function):
 
 
 ATTN_BWD_FUSED = True      # False: the GEMM-composed attention backward (probabilities through HBM; the first implementation) -- tests compare the two
+NORM_CONV_OUT_FUSED_BWD = True      # NormConvOutFn.backward: ops.norm_conv_out_bwd where the shape allows (tests compare it with the stored-operand route)
 
 
 def _fused_attn_bwd() -> bool:

@@ -550,6 +550,34 @@ def groupnorm_bwd(da: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma:
     return dx, dg, db
 
 
+def norm_conv_out_bwd_supported(n: int, h: int, w: int, c: int, cout: int, groups: int = 32) -> bool:
+    return bool(_lib.lib().dmvae_norm_conv_out_bwd_supported(n, h, w, c, groups, cout))
+
+
+def norm_conv_out_bwd(dy: torch.Tensor, w: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32,
+                      dg_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None):
+    """-> (dx, dgamma, dbeta) of conv_out(swish(norm_out(x))) (flux_ae.py:266-268) given the image gradient dy f32 [N, 3, H, W] (NCHW), conv_out.weight w f32
+    [3, C, 3, 3], norm_out's input x bf16 [N, H, W, C] and its statistics: the 3 -> C input-gradient conv runs inside both GroupNorm backward passes
+    (include/dmvae_hip.h: dmvae_norm_conv_out_bwd) -- the gradient of the activation never exists in memory."""
+    dy = _req(dy, f32, "dy")
+    w = _req(w, f32, "weight")
+    x = _req(x, bf16, "x")
+    n, h, wd, c = x.shape
+    cout = w.shape[0]
+    assert tuple(dy.shape) == (n, cout, h, wd) and tuple(w.shape) == (cout, c, 3, 3), (dy.shape, w.shape, x.shape)
+    L = _lib.lib()
+    wsb = L.dmvae_norm_conv_out_bwd_workspace(n, h, wd, c, groups)
+    if wsb == 0 or not L.dmvae_norm_conv_out_bwd_supported(n, h, wd, c, groups, cout):
+        raise ValueError(f"norm_conv_out_bwd: unsupported shape x {tuple(x.shape)}, cout {cout}, {groups} groups")
+    ws = workspace(wsb, x.device)
+    dx = torch.empty_like(x)
+    dg = dg_out if dg_out is not None else torch.empty(c, dtype=f32, device=x.device)
+    db = db_out if db_out is not None else torch.empty(c, dtype=f32, device=x.device)
+    check(L.dmvae_norm_conv_out_bwd(dy.data_ptr(), w.data_ptr(), x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dx.data_ptr(), dg.data_ptr(),
+                                    db.data_ptr(), ws.data_ptr(), ws.numel(), n, h, wd, c, groups, cout, 0, _stream()), "norm_conv_out_bwd")
+    return dx, dg, db
+
+
 def groupnorm_bwd_reduce(da: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: int,
                          groups: int = 32, need_param_grads: bool = True, dg_out: Optional[torch.Tensor] = None,
                          db_out: Optional[torch.Tensor] = None):

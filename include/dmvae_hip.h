@@ -29,7 +29,8 @@ typedef struct ihipStream_t* dmvae_stream_t; /* == hipStream_t */
 
 const char* dmvae_last_error(void);
 /* ABI version; bumped when a signature or a struct changes.  2: dmvae_conv_desc gained its last field, w_layout (zero = the behaviour of version 1).
- * 3: struct dmvae_pack_entry and the entry points that take it (dmvae_pack_weights_batched), dmvae_linear_bf16 / _plan / dmvae_linear_weight_t_kmajor. */
+ * 3: struct dmvae_pack_entry and the entry points that take it (dmvae_pack_weights_batched), dmvae_linear_bf16 / _plan / dmvae_linear_weight_t_kmajor.
+ * 4: dmvae_norm_conv_out_bwd / _supported / _workspace. */
 int dmvae_abi_version(void);
 
 /* ---- convolution / GEMM (MFMA-bound) -------------------------------------------------------- */
@@ -141,6 +142,19 @@ int dmvae_groupnorm_bwd_reduce(const void* da, const void* x, const void* stats,
 int dmvae_groupnorm_bwd_apply(const void* da, const void* x, const void* dres, const void* stats, const void* sums,
                               const void* gamma, const void* beta, void* dx, int n, int hw, int c, int groups, int act,
                               float inv_count, dmvae_stream_t stream);
+
+/* Backward of the decoder's tail, conv_out(swish(norm_out(x))) (flux_ae.py:266-268), with respect to x / gamma / beta in two passes over x: the
+ * input-gradient conv (3 -> c channels, 27 multiply-adds per element) is evaluated on the matrix cores INSIDE both GroupNorm backward passes instead of being
+ * stored by one kernel and read by two (csrc/groupnorm.hip::convout_bwd_kernel).  dy: the image gradient f32 [n][3][h][w] (NCHW, as autograd hands it over;
+ * rounded to bf16 like the stored-operand route's), w: conv_out.weight f32 [3][c][3][3], x: norm_out's input bf16 [n][h][w][c], stats from
+ * dmvae_groupnorm_stats; dx bf16 like x; dgamma / dbeta [c] f32 (both or neither; accumulate != 0 adds).  Shapes: c = 128, w % 16 == 0, cout = 3
+ * (dmvae_norm_conv_out_bwd_supported); equals dmvae_conv2d_nhwc_fwd (the input-gradient form) followed by dmvae_groupnorm_bwd up to the summation order inside
+ * one bf16 rounding of the intermediate. */
+int dmvae_norm_conv_out_bwd_supported(int n, int h, int w, int c, int groups, int cout);
+size_t dmvae_norm_conv_out_bwd_workspace(int n, int h, int w, int c, int groups);
+int dmvae_norm_conv_out_bwd(const void* dy, const void* w, const void* x, const void* stats, const void* gamma, const void* beta, void* dx, void* dgamma,
+                            void* dbeta, void* workspace, size_t workspace_bytes, int n, int h, int wd, int c, int groups, int cout, int accumulate,
+                            dmvae_stream_t stream);
 
 /* ---- batched GEMMs on the same MFMA cores (decoder self-attention, flux_ae.py:37-49) --------- */
 

@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Audit of the compiler-scheduled MFMAs in the gfx950 assembly of csrc/*.hip for the pattern that produced wrong results in the first build of
+csrc/groupnorm.hip::convout_bwd_kernel: an accumulate chain through TWO DIFFERENT MFMA opcodes issued back to back --
+    v_mfma_f32_16x16x32_bf16 D, A, B, 0        (8 passes)
+    v_mfma_f32_16x16x16_bf16 D, A2, B2, D      (reads D as its C operand)
+hipcc (ROCm 7.2) pads no wait states between the two and the hardware does not interlock the pair: the second reads C before the first has written it
+(measured: the first product is lost; with the two opcodes equal the back-to-back chain is the supported one).  Flagged: a v_mfma whose C operand overlaps
+the destination of one of the previous 3 MFMAs of a DIFFERENT opcode with fewer than 8 wait states (s_nop N = N + 1, any other instruction = 1) between
+them.  (A destination on top of the A / B operand, which the same build also had, is legal and common: vit.hip, linear_rows.hip.)
+usage: python tools/check_mfma_chain.py [files...]   (exit 1 on a finding)"""
+import glob
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "dmvae_amd/csrc", "*.hip")))
+
+
+def rng(tok):
+    m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", tok)
+    if m:
+        return (m.group(1), set(range(int(m.group(2)), int(m.group(3)) + 1)))
+    m = re.fullmatch(r"([va])(\d+)", tok)
+    if m:
+        return (m.group(1), {int(m.group(2))})
+    return None
+
+
+bad = 0
+for f in files:
+    out = tempfile.mktemp(suffix=".s")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(f),
+                    "-Wno-unused-value", "-Wno-c++20-extensions", "-S", "--cuda-device-only", f, "-o", out], check=True, stderr=subprocess.DEVNULL)
+    ins = [l.strip() for l in open(out) if l.strip() and not l.strip().startswith((";", ".")) and not l.strip().endswith(":")]
+    os.unlink(out)
+    n = 0
+    recent = []          # (index, opcode, destination) of the last MFMAs
+    for k, l in enumerate(ins):
+        if not l.startswith("v_mfma"):
+            continue
+        n += 1
+        op = l.split()[0]
+        ops = [t.strip() for t in l.split(None, 1)[1].split(",")]
+        d, c = rng(ops[0]), (rng(ops[3]) if len(ops) > 3 else None)
+        if c:
+            for (j, opj, dj) in recent[-3:]:
+                if opj != op and dj[0] == c[0] and (dj[1] & c[1]):
+                    states = sum(int(q.split()[1]) + 1 if q.startswith("s_nop") else 1 for q in ins[j + 1:k])
+                    if states < 8:
+                        bad += 1
+                        print(f"{os.path.basename(f)}: mixed accumulate chain, {states} wait states: {ins[j][:64]}  ->  {l[:80]}")
+        if d:
+            recent.append((k, op, d))
+    print(f"{os.path.basename(f)}: {n} MFMAs audited")
+sys.exit(1 if bad else 0)
