@@ -60,9 +60,29 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackEntry* __rest
   const int RS = 32 * Tm + 1;     // odd row stride: lanes running over the slow LDS index hit different banks
   const int run = 32 * Tm;        // floats of one source row inside the tile: contiguous in memory
   const float* __restrict__ src = e.src;
+  // load, interior tiles whose rows are 16-B aligned (every tile of a conv weight with a multiple of 32 channels either way): eight lanes per source row, 16 B
+  // per lane and round, all of a lane's rounds in flight before the first LDS store -- no index divisions (the element-wise form below spends two runtime
+  // integer divisions per float, twice: the kernel was bound by them, not by its 0.9 GB)
+  const bool fast = x0 + 32 <= X && y0 + 32 <= Y && ((Y * Tm) & 3) == 0 && ((run & 3) == 0) && ((reinterpret_cast<size_t>(src) & 15) == 0) && run <= 32 * PACK_TMAX;
+  if (fast) {
+    const int xl = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    const f32x4* rowp = reinterpret_cast<const f32x4*>(src + ((size_t)(x0 + xl) * Y + y0) * Tm);
+    constexpr int RMAX = (32 * PACK_TMAX / 4 + 7) / 8;      // 16 rounds of 8 x 16 B cover a 16-tap row
+    f32x4 v[RMAX];
+    const int n4 = run >> 2;
+#pragma unroll
+    for (int u = 0; u < RMAX; u++)
+      if (l8 + 8 * u < n4) v[u] = rowp[l8 + 8 * u];
+#pragma unroll
+    for (int u = 0; u < RMAX; u++)
+      if (l8 + 8 * u < n4) {
+        float* d = S + xl * RS + 4 * (l8 + 8 * u);
+        d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+      }
+  } else
   // load: twelve loads in flight per thread before the first LDS store (a 3x3 weight's tile is 36 floats per thread: three rounds)
-  constexpr int PU = 12;
-  for (int j0 = threadIdx.x; j0 < 32 * run; j0 += 256 * PU) {
+  for (int j0 = threadIdx.x; j0 < 32 * run; j0 += 256 * 12) {
+    constexpr int PU = 12;
     float v[PU];
 #pragma unroll
     for (int u = 0; u < PU; u++) {
@@ -92,7 +112,29 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackEntry* __rest
         if (r + ky >= 2 && r + ky <= 3 && sx + kx >= 2 && sx + kx <= 3) v += w[ky * 3 + kx];
     return v;
   };
-  // store: 16 lanes x 2 adjacent columns per (row, tap): 4-byte stores, 64 B per row of the operand and of its K-tile-major copy
+  // store: 4 lanes x 8 adjacent columns per (row, tap): one 16-B store per lane and copy, 64 B per row of the operand and of its K-tile-major copy.  (The first
+  // form stored 4 B per lane -- 16 lanes per run: the kernel was bound by the number of store instructions, 288 per tile, not by their bytes: 315 us per
+  // tokenizer step for 0.9 GB.)  Operands whose padded width is not a multiple of 8 columns keep the 2-column form below.
+  if ((e.cols_pad & 7) == 0) {
+    const int l4 = threadIdx.x & 3, grp = threadIdx.x >> 2;
+    for (int pr = grp; pr < 32 * T; pr += 64) {
+      const int rl = pr / T, to = pr - rl * T;            // local row of the operand, output tap
+      const int t = e.mode == 0 ? to : T - 1 - to;        // source tap
+      const int row = (e.mode == 0 ? a0 : b0) + rl, col0 = (e.mode == 0 ? b0 : a0) + 8 * l4;
+      if (row >= e.rows_pad || col0 >= e.cols_pad) continue;
+      bf16x8 o8;
+#pragma unroll
+      for (int h = 0; h < 8; h++) {
+        const int cl = 8 * l4 + h;
+        const int al = e.mode == 0 ? rl : cl, bl = e.mode == 0 ? cl : rl;
+        const int a = a0 + al, b = b0 + bl;
+        o8[h] = (bf16)((a < e.cout && b < e.cin) ? fetch(al, bl, t) : 0.f);
+      }
+      *reinterpret_cast<bf16x8*>(e.dst + ((size_t)row * T + to) * e.cols_pad + col0) = o8;
+      if (e.dst2) *reinterpret_cast<bf16x8*>(e.dst2 + (((size_t)(col0 >> 5) * T + to) * e.rows_pad + row) * 32 + (col0 & 31)) = o8;
+    }
+    return;
+  }
   const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const bool pairs = (e.cols_pad & 1) == 0;
   for (int pr = grp; pr < 32 * T; pr += 16) {
