@@ -118,6 +118,9 @@ SIGNATURES = {
     "dmvae_groupnorm_bwd_colsum": (c_int, [c_void_p] * 11 + [c_size_t] + [c_int] * 7 + [c_void_p]),
     "dmvae_groupnorm_bwd_reduce": (c_int, [c_void_p] * 9 + [c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_groupnorm_bwd_apply": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "dmvae_conv_in3_supported": (c_int, [c_int] * 4),
+    "dmvae_conv_in3_workspace": (c_size_t, [c_int] * 3),
+    "dmvae_conv_in3": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_size_t] + [c_int] * 5 + [c_void_p]),
     "dmvae_norm_conv_out_bwd_supported": (c_int, [c_int] * 6),
     "dmvae_norm_conv_out_bwd_workspace": (c_size_t, [c_int] * 5),
     "dmvae_norm_conv_out_bwd": (c_int, [c_void_p] * 10 + [c_size_t] + [c_int] * 7 + [c_void_p]),

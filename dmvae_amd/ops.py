@@ -550,6 +550,40 @@ def groupnorm_bwd(da: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma:
     return dx, dg, db
 
 
+def conv_in3_supported(n: int, h: int, w: int, cout: int) -> bool:
+    return bool(_lib.lib().dmvae_conv_in3_supported(n, h, w, cout))
+
+
+def conv_in3(x0: torch.Tensor, x1: Optional[torch.Tensor], w: torch.Tensor, bias: Optional[torch.Tensor], shift: Optional[torch.Tensor] = None,
+             scale: Optional[torch.Tensor] = None, act: int = ACT_NONE) -> torch.Tensor:
+    """act(conv3x3((cat(x0, x1) - shift) / scale, w) + bias) -> NHWC bf16 [N0 + N1, H, W, cout] from NCHW f32 images with THREE channels (x1 optional), cout 64 /
+    128: the LPIPS trunk's first layer with its ScalingLayer and the concatenation of the two branches folded in (include/dmvae_hip.h: dmvae_conv_in3)."""
+    x0 = _req(x0, f32, "x0")
+    w = _req(w, f32, "weight")
+    n0, c, h, wd = x0.shape
+    n1 = 0
+    if x1 is not None:
+        x1 = _req(x1, f32, "x1")
+        assert tuple(x1.shape[1:]) == (c, h, wd), (x0.shape, x1.shape)
+        n1 = x1.shape[0]
+    cout = w.shape[0]
+    assert c == 3 and tuple(w.shape) == (cout, 3, 3, 3), (x0.shape, w.shape)
+    n = n0 + n1
+    L = _lib.lib()
+    if not L.dmvae_conv_in3_supported(n, h, wd, cout):
+        raise ValueError(f"conv_in3: unsupported shape {n} x {h} x {wd} -> {cout}")
+    if bias is not None:
+        bias = _req(bias, f32, "bias")
+    if shift is not None:
+        shift, scale = _req(shift.reshape(-1), f32, "shift"), _req(scale.reshape(-1), f32, "scale")
+        assert shift.numel() == 3 and scale.numel() == 3
+    ws = workspace(L.dmvae_conv_in3_workspace(n, h, wd), x0.device, slot="conv_in3")
+    y = torch.empty(n, h, wd, cout, dtype=bf16, device=x0.device)
+    check(L.dmvae_conv_in3(x0.data_ptr(), _ptr(x1), n0, _ptr(shift), _ptr(scale), w.data_ptr(), _ptr(bias), y.data_ptr(), ws.data_ptr(), ws.numel(), n, h, wd,
+                           cout, act, _stream()), "conv_in3")
+    return y
+
+
 def norm_conv_out_bwd_supported(n: int, h: int, w: int, c: int, cout: int, groups: int = 32) -> bool:
     return bool(_lib.lib().dmvae_norm_conv_out_bwd_supported(n, h, w, c, groups, cout))
 

@@ -13,7 +13,9 @@ import warnings
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, parity
+
+FIRST_LAYER_FUSED = True      # _VggLpips.forward: csrc/conv_in3.hip for ScalingLayer + cat + conv1_1 + ReLU (tests compare it with the padded 32-channel route)
 
 _CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512)
 _SLICE_BOUNDS = (4, 9, 16, 23, 30)
@@ -122,12 +124,21 @@ class _VggLpips(torch.autograd.Function):
         from .. import functional as Fn
         b = inp.shape[0]
         shift, scale = mod.scaling_layer.shift, mod.scaling_layer.scale
-        x = torch.cat([(inp.detach().float() - shift) / scale, (tgt.detach().float() - shift) / scale], 0).contiguous()
-        h = ops.nchw_to_nhwc_bf16(x, c_pad=32)                       # [2B, H, W, 32] (3 real channels)
+        convs = [m for sl in (mod.net.slice1, mod.net.slice2, mod.net.slice3, mod.net.slice4, mod.net.slice5) for m in sl if isinstance(m, nn.Conv2d)]
+        # first layer: ScalingLayer, the concatenation of the two branches and conv1_1 + ReLU in one kernel on the three real channels (csrc/conv_in3.hip) where the
+        # shape allows; else the ScalingLayer in ATen and the image zero-padded to one 32-channel K step of the general kernel
+        first = None
+        if FIRST_LAYER_FUSED and not parity.on() and inp.shape[1] == 3 and ops.conv_in3_supported(2 * b, inp.shape[2], inp.shape[3], convs[0].weight.shape[0]) \
+                and convs[0].weight.dtype == torch.float32:
+            first = ops.conv_in3(inp.detach().float().contiguous(), tgt.detach().float().contiguous(), convs[0].weight.detach().contiguous(),
+                                 convs[0].bias.detach().float(), shift.float(), scale.float(), act=ops.ACT_RELU)
+            h = None
+        else:
+            x = torch.cat([(inp.detach().float() - shift) / scale, (tgt.detach().float() - shift) / scale], 0).contiguous()
+            h = ops.nchw_to_nhwc_bf16(x, c_pad=32)                   # [2B, H, W, 32] (3 real channels)
         need = tgt.requires_grad
         lin_ws = [l.model[-1].weight.detach().reshape(-1).float().contiguous() for l in (mod.lin0, mod.lin1, mod.lin2, mod.lin3, mod.lin4)]
         out = torch.zeros(1, dtype=torch.float32, device=inp.device)
-        convs = [m for sl in (mod.net.slice1, mod.net.slice2, mod.net.slice3, mod.net.slice4, mod.net.slice5) for m in sl if isinstance(m, nn.Conv2d)]
         tape, ci, level = [], 0, 0                                    # tape: ("conv", conv, y_tgt_half, df1 | None) / ("pool",)
         taps = {1, 3, 6, 9, 12}                                        # conv indices whose ReLU output is an LPIPS feature
         for v in _CFG:
@@ -136,8 +147,11 @@ class _VggLpips(torch.autograd.Function):
                 tape.append(("pool",))
                 continue
             conv = convs[ci]
-            wp = Fn.packed(conv.weight, False, 0, 32 if conv.weight.shape[1] < 32 else 0, frozen=True)
-            h = ops.conv2d_nhwc(h, wp, conv.bias.detach().float(), ks=3, act=ops.ACT_RELU)
+            if ci == 0 and first is not None:
+                h = first
+            else:
+                wp = Fn.packed(conv.weight, False, 0, 32 if conv.weight.shape[1] < 32 else 0, frozen=True)
+                h = ops.conv2d_nhwc(h, wp, conv.bias.detach().float(), ks=3, act=ops.ACT_RELU)
             df1 = None
             if ci in taps:
                 n, hh, ww, _ = h.shape

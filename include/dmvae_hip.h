@@ -30,7 +30,7 @@ typedef struct ihipStream_t* dmvae_stream_t; /* == hipStream_t */
 const char* dmvae_last_error(void);
 /* ABI version; bumped when a signature or a struct changes.  2: dmvae_conv_desc gained its last field, w_layout (zero = the behaviour of version 1).
  * 3: struct dmvae_pack_entry and the entry points that take it (dmvae_pack_weights_batched), dmvae_linear_bf16 / _plan / dmvae_linear_weight_t_kmajor.
- * 4: dmvae_norm_conv_out_bwd / _supported / _workspace. */
+ * 4: dmvae_norm_conv_out_bwd / _supported / _workspace, dmvae_conv_in3 / _supported / _workspace. */
 int dmvae_abi_version(void);
 
 /* ---- convolution / GEMM (MFMA-bound) -------------------------------------------------------- */
@@ -155,6 +155,17 @@ size_t dmvae_norm_conv_out_bwd_workspace(int n, int h, int w, int c, int groups)
 int dmvae_norm_conv_out_bwd(const void* dy, const void* w, const void* x, const void* stats, const void* gamma, const void* beta, void* dx, void* dgamma,
                             void* dbeta, void* workspace, size_t workspace_bytes, int n, int h, int wd, int c, int groups, int cout, int accumulate,
                             dmvae_stream_t stream);
+
+/* 3x3 stride-1 conv FROM THREE input channels (an NCHW f32 image) to cout = 64 / 128 channels with bias and ReLU, NHWC bf16 result: the first layer of the
+ * LPIPS trunk behind its ScalingLayer (utils/lpips.py:81-104,116-135: VGG16 conv1_1 on both branches).  The n images come from one or two tensors (x0: the first
+ * n0 images, x1: the rest; x1 may be NULL when n0 == n) -- no concatenated copy; shift / scale: device pointers to the ScalingLayer's three values each, applied
+ * as (x - shift) / scale in f32 before the bf16 rounding of the operand, or both NULL.  w: f32 [cout][3][3][3] (the nn.Conv2d parameter), bias f32 [cout] or
+ * NULL, act 0 (none) / 2 (ReLU).  Equals the zero-padded 32-channel route (nchw_to_nhwc + dmvae_conv2d_nhwc_fwd) up to the f32 summation order inside the
+ * bf16 rounding of the result.  Shapes: w % 16 == 0 (dmvae_conv_in3_supported); workspace: the zero-bordered 4-channel bf16 copy of the images. */
+int dmvae_conv_in3_supported(int n, int h, int w, int cout);
+size_t dmvae_conv_in3_workspace(int n, int h, int w);
+int dmvae_conv_in3(const void* x0, const void* x1, int n0, const void* shift, const void* scale, const void* w, const void* bias, void* y,
+                   void* workspace, size_t workspace_bytes, int n, int h, int wd, int cout, int act, dmvae_stream_t stream);
 
 /* ---- batched GEMMs on the same MFMA cores (decoder self-attention, flux_ae.py:37-49) --------- */
 

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r4_cin3; mkdir -p $OUT; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_conv_in3.py tests/test_gpu_lpips.py -x -q 2>&1 | tail -12
+cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o step -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_prof.log 2>&1; cd $GRAFT_REPO_ROOT
+python tools/trace_summary.py $(find $OUT/prof -name '*kernel_trace.csv' | head -1) > $OUT/trace_summary.txt 2>&1; find $OUT/prof -name '*kernel_trace.csv' -delete
+grep -n "steady\|conv_in3\|cin3\|nchw_to_nhwc" $OUT/trace_summary.txt | cut -c1-150
+
