@@ -71,6 +71,7 @@ SIGNATURES = {
     "dmvae_diffaug_fwd": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "dmvae_diffaug_bwd": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "dmvae_im2col_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "dmvae_im2col_nhwc_taps": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "dmvae_col2im_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "dmvae_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_nhwc_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -121,6 +122,8 @@ SIGNATURES = {
     "dmvae_conv_in3_supported": (c_int, [c_int] * 4),
     "dmvae_conv_in3_workspace": (c_size_t, [c_int] * 3),
     "dmvae_conv_in3": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_size_t] + [c_int] * 5 + [c_void_p]),
+    "dmvae_norm_conv_out_fwd_supported": (c_int, [c_int] * 6),
+    "dmvae_norm_conv_out_fwd": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
     "dmvae_norm_conv_out_bwd_supported": (c_int, [c_int] * 6),
     "dmvae_norm_conv_out_bwd_workspace": (c_size_t, [c_int] * 5),
     "dmvae_norm_conv_out_bwd": (c_int, [c_void_p] * 10 + [c_size_t] + [c_int] * 7 + [c_void_p]),

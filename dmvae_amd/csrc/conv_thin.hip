@@ -27,11 +27,16 @@ struct Args {
   float* y;           // [N, H, W, 4]
   int N, H, W;
   int tiles_x, tiles_y;
+  // NORM instantiation (the decoder's tail forward, flux_ae.py:266-268): x is norm_out's INPUT; the tile is normalised + swished on its way into LDS and its
+  // interior is also written out as `aout` (what the weight gradient reads later); y is the NCHW f32 image with `cout` channels
+  const float* stats; const float* gamma; const float* beta;
+  bf16* aout;
+  int G, cout;
 };
 
 constexpr unsigned SENT = 0x80000000u;
 
-template <int CIN>
+template <int CIN, bool NORM = false>
 __global__ __launch_bounds__(256) void conv_thin_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int TR = 4, TC = 32;              // output tile
@@ -60,16 +65,64 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(Args a) {
   // ---- stage the halo tile -------------------------------------------------------------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)a.N * a.H * a.W * PIXB, 0x00020000);
   const unsigned img = (unsigned)n * a.H * a.W * PIXB;
+  constexpr int NJ = (NPX * CPP + 255) / 256;      // NORM: 16-B chunks per thread (13 at CIN = 128); thread <-> chunk tid % CPP of pixels tid / CPP + (256 / CPP) j
+  if constexpr (NORM) {
+    // through registers: GroupNorm + swish applied once per element on the way in (the halo's share, 1.6 x the tile, is recomputed by the neighbours), zero
+    // padding applied AFTER the activation, the tile's own 4 x 32 pixels also stored as the activation tensor the backward reads.  Two halves, each with all of
+    // its loads in flight first (one batch of 13 costs 52 registers next to the weight fragments and the accumulators: two waves per SIMD).
+    const int cp = tid % CPP;
+    float sc[8], sh[8];
 #pragma unroll
-  for (int j = 0; j < (NPIECE + 3) / 4; j++) {
-    const int p = wave + 4 * j;
-    if (p >= NPIECE) break;  // wave-uniform
-    const int q = p * PPP + lane / CPP, cp = lane % CPP;
-    const int r = q / HC, c = q - r * HC;
-    const int yy = y0 - 1 + r, xx = x0 - 1 + c;
-    const bool ok = q < NPX && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-    const unsigned vo = ok ? (unsigned)(yy * a.W + xx) * PIXB + (unsigned)((cp ^ key(q)) * 16) : SENT;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, LPTR(smem + p * 1024), 16, vo, img, 0, 0);
+    for (int e = 0; e < 8; e++) {
+      const int c = cp * 8 + e;
+      const float* st = a.stats + ((size_t)n * a.G + c / (CIN / a.G)) * 2;
+      sc[e] = st[1] * a.gamma[c];
+      sh[e] = a.beta[c] - st[0] * sc[e];                  // apply_kernel's arithmetic (csrc/groupnorm.hip): the same bits as the stand-alone pass
+    }
+    constexpr int HALF = (NJ + 1) / 2;
+#pragma unroll
+    for (int h0 = 0; h0 < NJ; h0 += HALF) {
+      bf16x8 xin[HALF];
+#pragma unroll
+      for (int u = 0; u < HALF; u++) {
+        const int j = h0 + u;
+        const int idx = tid + 256 * j, q = idx / CPP;
+        const int r = q / HC, c = q - r * HC;
+        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        const bool ok = j < NJ && q < NPX && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        const unsigned vo = ok ? (unsigned)(yy * a.W + xx) * PIXB + (unsigned)(cp * 16) : SENT;
+        xin[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rX, vo, img, 0));
+      }
+#pragma unroll
+      for (int u = 0; u < HALF; u++) {
+        const int j = h0 + u;
+        const int idx = tid + 256 * j, q = idx / CPP;
+        if (j >= NJ || q >= NPX) break;
+        const int r = q / HC, c = q - r * HC;
+        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float t = (float)xin[u][e] * sc[e] + sh[e];
+          o[e] = ok ? (bf16)(t * sigmoidf_(t)) : (bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(smem + q * PIXB + ((cp ^ key(q)) * 16)) = o;
+        if (r >= 1 && r <= TR && c >= 1 && c <= TC) *reinterpret_cast<bf16x8*>(a.aout + ((size_t)(n * a.H + yy) * a.W + xx) * CIN + cp * 8) = o;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < (NPIECE + 3) / 4; j++) {
+      const int p = wave + 4 * j;
+      if (p >= NPIECE) break;  // wave-uniform
+      const int q = p * PPP + lane / CPP, cp = lane % CPP;
+      const int r = q / HC, c = q - r * HC;
+      const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+      const bool ok = q < NPX && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+      const unsigned vo = ok ? (unsigned)(yy * a.W + xx) * PIXB + (unsigned)((cp ^ key(q)) * 16) : SENT;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, LPTR(smem + p * 1024), 16, vo, img, 0, 0);
+    }
   }
 
   // ---- this wave's weight fragments (couts >= 4: zeros) while the tile is in flight ------------------------------------------------------------------
@@ -93,7 +146,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(Args a) {
 #pragma unroll
     for (int r = 0; r < 4; r++) acc[g][r] = 0.f;
 
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces have landed
+  if constexpr (!NORM) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces have landed
   __syncthreads();
 
   // ---- nine taps from the one tile ---------------------------------------------------------------------------------------------------------------------
@@ -124,18 +177,24 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(Args a) {
     f32x4 s = part[tid];
 #pragma unroll
     for (int w2 = 1; w2 < 4; w2++) s += part[w2 * 128 + tid];   // fixed order
-    if (a.bias) s += *reinterpret_cast<const f32x4*>(a.bias);
     const int row = tid >> 5, col = tid & 31;
-    *reinterpret_cast<f32x4*>(a.y + ((size_t)(n * a.H + y0 + row) * a.W + x0 + col) * 4) = s;
+    if constexpr (NORM) {      // the image itself: NCHW f32, `cout` planes, 128 B contiguous per tile row and plane
+#pragma unroll
+      for (int co = 0; co < 4; co++)
+        if (co < a.cout) a.y[((size_t)(n * a.cout + co) * a.H + y0 + row) * a.W + x0 + col] = s[co] + (a.bias ? a.bias[co] : 0.f);
+    } else {
+      if (a.bias) s += *reinterpret_cast<const f32x4*>(a.bias);
+      *reinterpret_cast<f32x4*>(a.y + ((size_t)(n * a.H + y0 + row) * a.W + x0 + col) * 4) = s;
+    }
   }
 #endif
 }
 
-template <int CIN>
+template <int CIN, bool NORM = false>
 int launch(const Args& a, hipStream_t st) {
   constexpr int lds = ((6 * 34 + 1024 / (CIN * 2) - 1) / (1024 / (CIN * 2))) * 1024;
   static_assert(lds >= 8192, "partial sums reuse the tile");
-  hipLaunchKernelGGL((conv_thin_kernel<CIN>), dim3((unsigned)(a.N * a.tiles_x * a.tiles_y)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_thin_kernel<CIN, NORM>), dim3((unsigned)(a.N * a.tiles_x * a.tiles_y)), dim3(256), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -153,5 +212,24 @@ int dmvae_conv_thin_try(const void* x, const void* w, const void* bias, const vo
   Args a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.y = (float*)y;
   a.N = d->n; a.H = d->h; a.W = d->w; a.tiles_x = d->w / 32; a.tiles_y = d->h / 4;
+  a.stats = a.gamma = a.beta = nullptr; a.aout = nullptr; a.G = 0; a.cout = 4;
   return d->cin == 128 ? launch<128>(a, stream) : launch<64>(a, stream);
+}
+
+// ---- the decoder's tail forward, conv_out(swish(norm_out(x))) (flux_ae.py:266-268), in one launch: see the NORM members of Args ----
+extern "C" int dmvae_norm_conv_out_fwd_supported(int n, int h, int w, int c, int groups, int cout) {
+  return (n > 0 && h > 0 && w > 0 && c == 128 && groups > 0 && c % groups == 0 && cout >= 1 && cout <= 4 && h % 4 == 0 && w % 32 == 0 &&
+          (long long)n * h * w * c * 2 < (1ll << 31)) ? 1 : 0;
+}
+extern "C" int dmvae_norm_conv_out_fwd(const void* x, const void* stats, const void* gamma, const void* beta, const void* w, const void* bias, void* aout, void* y,
+                                       int n, int h, int wd, int c, int groups, int cout, hipStream_t stream) {
+  DMVAE_CHECK_ARG(x && stats && gamma && beta && w && aout && y, "norm_conv_out_fwd: null pointer");
+  DMVAE_CHECK_ARG(dmvae_norm_conv_out_fwd_supported(n, h, wd, c, groups, cout),
+                  "norm_conv_out_fwd: unsupported shape n=%d h=%d w=%d c=%d groups=%d cout=%d (c = 128, h %% 4 == 0, w %% 32 == 0, cout <= 4)", n, h, wd, c, groups, cout);
+  using namespace dmvae_conv_thin;
+  Args a;
+  a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.y = (float*)y;
+  a.N = n; a.H = h; a.W = wd; a.tiles_x = wd / 32; a.tiles_y = h / 4;
+  a.stats = (const float*)stats; a.gamma = (const float*)gamma; a.beta = (const float*)beta; a.aout = (bf16*)aout; a.G = groups; a.cout = cout;
+  return launch<128, true>(a, stream);
 }

@@ -317,9 +317,10 @@ __global__ void relu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restr
 // ---- im2col / col2im for the PatchGAN convs (models/patchgan.py:125-147: 4x4, stride 2 or 1, padding 1) --------------------------
 // col[n, oy, ox, (ky*ks + kx)*C + c] = x[n, oy*stride - pad + ky, ox*stride - pad + kx, c] (0 outside): the conv becomes the
 // [M, ks*ks*C] x [Cout, ks*ks*C]^T GEMM of the 1x1 path.  One thread per (output pixel, tap, 8 channels): 16-B loads and stores.
+// Tp >= ks * ks: taps past the last one are columns of zeros (the reduction dimension padded to what the consumer's tile wants).
 __global__ void im2col_kernel(const bf16* __restrict__ x, bf16* __restrict__ col, int N, int H, int W, int C, int Ho, int Wo, int ks,
-                              int stride, int pad) {
-  const int c8 = C / 8, T = ks * ks;
+                              int stride, int pad, int Tp) {
+  const int c8 = C / 8, T = Tp, Treal = ks * ks;
   const size_t total = (size_t)N * Ho * Wo * T * c8;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int cc = i % c8;
@@ -332,7 +333,7 @@ __global__ void im2col_kernel(const bf16* __restrict__ x, bf16* __restrict__ col
     bf16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; e++) v[e] = (bf16)0.f;
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const bf16x8*>(x + (((size_t)n * H + iy) * W + ix) * C + cc * 8);
+    if (t < Treal && iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const bf16x8*>(x + (((size_t)n * H + iy) * W + ix) * C + cc * 8);
     reinterpret_cast<bf16x8*>(col)[i] = v;
   }
 }
@@ -609,14 +610,18 @@ static bool im2col_geom(int h, int w, int ks, int stride, int pad, int* ho, int*
   *ho = (h + 2 * pad - ks) / stride + 1; *wo = (w + 2 * pad - ks) / stride + 1;
   return h + 2 * pad >= ks && w + 2 * pad >= ks;
 }
-extern "C" int dmvae_im2col_nhwc(const void* x, void* col, int n, int h, int w, int c, int ks, int stride, int pad, hipStream_t stream) {
+extern "C" int dmvae_im2col_nhwc_taps(const void* x, void* col, int n, int h, int w, int c, int ks, int stride, int pad, int taps_pad, hipStream_t stream) {
   int ho, wo;
   DMVAE_CHECK_ARG(x && col && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && im2col_geom(h, w, ks, stride, pad, &ho, &wo),
                   "im2col_nhwc: bad argument (c must be a multiple of 8; ks 1..7, stride 1..4, pad < ks)");
-  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((size_t)n * ho * wo * ks * ks * (c / 8))), dim3(256), 0, stream, (const bf16*)x, (bf16*)col, n, h, w, c,
-                     ho, wo, ks, stride, pad);
+  DMVAE_CHECK_ARG(taps_pad >= ks * ks && taps_pad <= 64, "im2col_nhwc: taps_pad %d below ks * ks = %d (or above 64)", taps_pad, ks * ks);
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((size_t)n * ho * wo * taps_pad * (c / 8))), dim3(256), 0, stream, (const bf16*)x, (bf16*)col, n, h, w, c,
+                     ho, wo, ks, stride, pad, taps_pad);
   DMVAE_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int dmvae_im2col_nhwc(const void* x, void* col, int n, int h, int w, int c, int ks, int stride, int pad, hipStream_t stream) {
+  return dmvae_im2col_nhwc_taps(x, col, n, h, w, c, ks, stride, pad, ks * ks, stream);
 }
 extern "C" int dmvae_col2im_nhwc(const void* dcol, void* dx, int n, int h, int w, int c, int ks, int stride, int pad, int in_f32,
                                  hipStream_t stream) {

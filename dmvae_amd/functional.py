@@ -311,6 +311,26 @@ class ConvFn(torch.autograd.Function):
                     db = ops.colsum(dy, out=dst)
             dx = ops.conv2d_nhwc(dy, packed(w, False, subpixel=True), ks=4, stride=2) if ctx.needs_input_grad[0] else None
             return dx, dw, db, None, None
+        cout, cin = w.shape[0], w.shape[1]
+        m = dy.numel() // cout
+        if THIN_CIN_BWD_AS_GEMM and ctx.ks == 3 and not ctx.upsample and not parity.on() and cin in (32, 64) and cout % 128 == 0 and m >= 16384 and m % 32 == 0 \
+                and dy.dtype == bf16 and w.dtype == f32 and ops.linear_supported(m, 9 * cin, cout):
+            # A 3x3 conv FROM few channels (the decoder's conv_in: z_channels = 32 -> 512 at 32 x 32, flux_ae.py:196): its weight gradient has 288 columns -- the
+            # large weight-gradient kernel's 128-column tiles do not take it and the small-shape kernel runs it at 70 TFLOP/s (138 us); its input gradient has 32
+            # output channels (101 us on the general kernel).  Both as GEMMs on the im2col form instead: col [M, 12 taps x cin] (three taps of zeros) against dy
+            # through the 1x1 weight-gradient kernel, and dy [M, cout] x W [cout, 9 cin] on the Linear GEMM followed by the gather adjoint of im2col in f32.
+            n, h, wd, _ = x.shape
+            col = ops.im2col(x, 3, 1, 1, taps_pad=12)
+            g2, db = ops.conv2d_nhwc_wgrad(dy.view(1, 1, m, cout), col.view(1, 1, m, 12 * cin), 1, db_out=_dst(ctx.bias_param), need_bias=ctx.bias_param is not None)
+            dwv = g2.view(cout, 12, cin)[:, :9].permute(0, 2, 1).reshape(cout, cin, 3, 3)
+            dw = _dst(w)
+            dw = dw.copy_(dwv) if dw is not None else dwv.contiguous()
+            dx = None
+            if ctx.needs_input_grad[0]:
+                wl = w.detach().permute(2, 3, 1, 0).reshape(9 * cin, cout).to(bf16)          # [(tap, ci)][co]
+                dcol = ops.linear_bf16(dy.view(m, cout), wl, None, out_f32=True)              # [M, 9 cin] f32: no rounding before the taps are summed
+                dx = ops.col2im(dcol.view(n, h, wd, 9 * cin), h, wd, 3, 1, 1)
+            return dx, dw, db, None, None
         dw, db = ops.conv2d_nhwc_wgrad(dy, x, ctx.ks, upsample=ctx.upsample, dw_out=_dst(w), db_out=_dst(ctx.bias_param))
         dx = None
         if ctx.needs_input_grad[0]:
@@ -505,6 +525,13 @@ class NormConvOutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, nw, nb, cw, cb):
         cout = cw.shape[0]
+        if NORM_CONV_OUT_FUSED_FWD and not parity.on() and x.dtype == bf16 and ops.norm_conv_out_fwd_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout):
+            # GroupNorm + swish on the way into the conv's halo tile, the NCHW image straight out of its epilogue: one launch for five (csrc/conv_thin.hip, NORM)
+            st = _stats_of(x)
+            a, y = ops.norm_conv_out_fwd(x, st, nw, nb, packed(cw, False, rows_pad=4), cb, cout)
+            ctx.save_for_backward(x, st, a, nw, nb, cw)
+            ctx.bias_param = cb
+            return y
         st, a = _gn_swish(x, nw, nb)
         cbp = torch.zeros(4, dtype=f32, device=x.device)
         cbp[:cout] = cb
@@ -751,6 +778,8 @@ class SiluFn(torch.autograd.Function):
 
 
 ATTN_BWD_FUSED = True      # False: the GEMM-composed attention backward (probabilities through HBM; the first implementation) -- tests compare the two
+THIN_CIN_BWD_AS_GEMM = True      # ConvFn.backward of a 3x3 conv from 32 / 64 channels: weight and input gradient as GEMMs on the im2col form
+NORM_CONV_OUT_FUSED_FWD = True      # NormConvOutFn.forward: ops.norm_conv_out_fwd where the shape allows
 NORM_CONV_OUT_FUSED_BWD = True      # NormConvOutFn.backward: ops.norm_conv_out_bwd where the shape allows (tests compare it with the stored-operand route)
 
 

@@ -584,6 +584,31 @@ def conv_in3(x0: torch.Tensor, x1: Optional[torch.Tensor], w: torch.Tensor, bias
     return y
 
 
+def norm_conv_out_fwd_supported(n: int, h: int, w: int, c: int, cout: int, groups: int = 32) -> bool:
+    return bool(_lib.lib().dmvae_norm_conv_out_fwd_supported(n, h, w, c, groups, cout))
+
+
+def norm_conv_out_fwd(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor],
+                      cout: int, groups: int = 32):
+    """-> (a, y): a = swish(GroupNorm(x)) bf16 [N, H, W, C] and y = conv3x3(a, conv_out) + bias as the NCHW f32 image [N, cout, H, W] in ONE launch
+    (flux_ae.py:266-268; include/dmvae_hip.h: dmvae_norm_conv_out_fwd).  w_packed: pack_conv_weight(conv_out.weight, rows_pad=4) -- bf16 [4, 9, C]."""
+    x = _req(x, bf16, "x")
+    w_packed = _req(w_packed, bf16, "w_packed")
+    n, h, wd, c = x.shape
+    assert tuple(w_packed.shape) == (4, 9, c), w_packed.shape
+    if bias is not None:
+        bias = _req(bias, f32, "bias")
+        assert bias.numel() == cout
+    L = _lib.lib()
+    if not L.dmvae_norm_conv_out_fwd_supported(n, h, wd, c, groups, cout):
+        raise ValueError(f"norm_conv_out_fwd: unsupported shape x {tuple(x.shape)}, cout {cout}, {groups} groups")
+    a = torch.empty_like(x)
+    y = torch.empty(n, cout, h, wd, dtype=f32, device=x.device)
+    check(L.dmvae_norm_conv_out_fwd(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w_packed.data_ptr(), _ptr(bias), a.data_ptr(), y.data_ptr(),
+                                    n, h, wd, c, groups, cout, _stream()), "norm_conv_out_fwd")
+    return a, y
+
+
 def norm_conv_out_bwd_supported(n: int, h: int, w: int, c: int, cout: int, groups: int = 32) -> bool:
     return bool(_lib.lib().dmvae_norm_conv_out_bwd_supported(n, h, w, c, groups, cout))
 
@@ -648,13 +673,15 @@ def _im2col_out(h, w, ks, stride, pad):
     return (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
 
 
-def im2col(x: torch.Tensor, ks: int, stride: int, pad: int) -> torch.Tensor:
-    """[N,H,W,C] bf16 -> [N,Ho,Wo,ks*ks*C] (tap-major, zero padding): the PatchGAN convs as GEMMs (models/patchgan.py:125-147)."""
+def im2col(x: torch.Tensor, ks: int, stride: int, pad: int, taps_pad: int = 0) -> torch.Tensor:
+    """[N,H,W,C] bf16 -> [N,Ho,Wo,ks*ks*C] (tap-major, zero padding): the PatchGAN convs as GEMMs (models/patchgan.py:125-147).  taps_pad > ks*ks: that many
+    taps per pixel, the extra ones columns of zeros (a reduction dimension padded to the consumer's tile: dmvae_im2col_nhwc_taps)."""
     x = _req(x, bf16, "x")
     n, h, w, c = x.shape
     ho, wo = _im2col_out(h, w, ks, stride, pad)
-    col = torch.empty(n, ho, wo, ks * ks * c, dtype=bf16, device=x.device)
-    check(_lib.lib().dmvae_im2col_nhwc(x.data_ptr(), col.data_ptr(), n, h, w, c, ks, stride, pad, _stream()), "im2col_nhwc")
+    tp = max(int(taps_pad), ks * ks)
+    col = torch.empty(n, ho, wo, tp * c, dtype=bf16, device=x.device)
+    check(_lib.lib().dmvae_im2col_nhwc_taps(x.data_ptr(), col.data_ptr(), n, h, w, c, ks, stride, pad, tp, _stream()), "im2col_nhwc")
     return col
 
 

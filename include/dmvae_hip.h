@@ -30,7 +30,7 @@ typedef struct ihipStream_t* dmvae_stream_t; /* == hipStream_t */
 const char* dmvae_last_error(void);
 /* ABI version; bumped when a signature or a struct changes.  2: dmvae_conv_desc gained its last field, w_layout (zero = the behaviour of version 1).
  * 3: struct dmvae_pack_entry and the entry points that take it (dmvae_pack_weights_batched), dmvae_linear_bf16 / _plan / dmvae_linear_weight_t_kmajor.
- * 4: dmvae_norm_conv_out_bwd / _supported / _workspace, dmvae_conv_in3 / _supported / _workspace. */
+ * 4: dmvae_norm_conv_out_bwd / _supported / _workspace, dmvae_norm_conv_out_fwd / _supported, dmvae_conv_in3 / _supported / _workspace, dmvae_im2col_nhwc_taps. */
 int dmvae_abi_version(void);
 
 /* ---- convolution / GEMM (MFMA-bound) -------------------------------------------------------- */
@@ -150,6 +150,13 @@ int dmvae_groupnorm_bwd_apply(const void* da, const void* x, const void* dres, c
  * dmvae_groupnorm_stats; dx bf16 like x; dgamma / dbeta [c] f32 (both or neither; accumulate != 0 adds).  Shapes: c = 128, w % 16 == 0, cout = 3
  * (dmvae_norm_conv_out_bwd_supported); equals dmvae_conv2d_nhwc_fwd (the input-gradient form) followed by dmvae_groupnorm_bwd up to the summation order inside
  * one bf16 rounding of the intermediate. */
+/* Forward of the same tail in one launch (csrc/conv_thin.hip, NORM instantiation): a = swish(GroupNorm(x)) is computed on the way into the conv's halo tile and
+ * written out once (bf16 [n][h][w][c]: what the weight gradient of conv_out reads in the backward), y = conv_out(a) + bias leaves as the NCHW f32 image
+ * [n][cout][h][w].  w: conv_out's packed bf16 operand [4][9][c] (dmvae_pack_conv_weight, rows_pad 4), bias f32 [cout] or NULL.  Shapes: c = 128, h % 4 == 0,
+ * w % 32 == 0, cout <= 4.  Same bits as dmvae_groupnorm_apply -> dmvae_conv2d_nhwc_fwd (out_f32) -> dmvae_nhwc_to_nchw_f32. */
+int dmvae_norm_conv_out_fwd_supported(int n, int h, int w, int c, int groups, int cout);
+int dmvae_norm_conv_out_fwd(const void* x, const void* stats, const void* gamma, const void* beta, const void* w, const void* bias, void* a, void* y,
+                            int n, int h, int wd, int c, int groups, int cout, dmvae_stream_t stream);
 int dmvae_norm_conv_out_bwd_supported(int n, int h, int w, int c, int groups, int cout);
 size_t dmvae_norm_conv_out_bwd_workspace(int n, int h, int w, int c, int groups);
 int dmvae_norm_conv_out_bwd(const void* dy, const void* w, const void* x, const void* stats, const void* gamma, const void* beta, void* dx, void* dgamma,
@@ -292,6 +299,9 @@ int dmvae_sumpool2x2_nhwc(const void* dy, void* dx, int n, int h, int w, int c, 
  * in_f32 -- the GEMM's f32 result summed without an intermediate rounding, as a direct dgrad conv would).  bf16 x/col/dx, c%8==0.
  * The weight operand [cout][ks*ks][c] comes from dmvae_pack_conv_weight (ks up to 7). */
 int dmvae_im2col_nhwc(const void* x, void* col, int n, int h, int w, int c, int ks, int stride, int pad, dmvae_stream_t stream);
+/* The same with the tap count padded to taps_pad >= ks * ks: col is [n, ho, wo, taps_pad * c], taps past the last one are columns of zeros -- a 3x3 conv over 32
+ * channels becomes a 384-column operand (12 x 32), which the 1x1 weight-gradient kernel's 128-column tiles take (the decoder's conv_in, flux_ae.py:196). */
+int dmvae_im2col_nhwc_taps(const void* x, void* col, int n, int h, int w, int c, int ks, int stride, int pad, int taps_pad, dmvae_stream_t stream);
 int dmvae_col2im_nhwc(const void* dcol, void* dx, int n, int h, int w, int c, int ks, int stride, int pad, int in_f32,
                       dmvae_stream_t stream);
 /* dx = y > 0 ? dy : slope*dy  (nn.LeakyReLU(0.2) backward from the saved OUTPUT, patchgan.py:125,136,144). bf16, n%8==0. */

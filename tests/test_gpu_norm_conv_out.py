@@ -124,3 +124,35 @@ def test_norm_conv_out_fn_backward_with_and_without_the_fused_route(monkeypatch)
     assert torch.equal(y1, y0)
     assert rel_err(g1[0], g0[0]) < 2e-3 and rel_err(g1[1], g0[1]) < 1e-3 and rel_err(g1[2], g0[2]) < 1e-3
     assert torch.equal(g1[3], g0[3]) and torch.equal(g1[4], g0[4])
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 32, 64), (3, 8, 32), (1, 64, 32)])
+def test_fused_tail_forward_gives_the_bits_of_the_five_launch_route(n, h, w, monkeypatch):
+    """csrc/conv_thin.hip, NORM instantiation: GroupNorm + swish on the way into the conv's halo tile, the NCHW image out of its epilogue -- the saved activation
+    and the image must be the bits of groupnorm_apply -> conv2d_nhwc (f32 result) -> nhwc_to_nchw (same arithmetic, same summation order), with zero padding
+    applied after the activation (a beta that makes swish(GroupNorm(0)) non-zero would show a mistake there)."""
+    from dmvae_amd import functional as Fn, ops
+    assert ops.norm_conv_out_fwd_supported(n, h, w, 128, 3)
+    x, gamma, beta, cw, _ = _case(n, h, w, seed=21)
+    beta = beta + 0.7
+    cb = torch.tensor([0.3, -0.2, 0.1], device=DEV)
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(Fn, "NORM_CONV_OUT_FUSED_FWD", fused)
+
+        class Ctx:
+            def save_for_backward(self, *t):
+                self.saved = t
+        ctx = Ctx()
+        y = Fn.NormConvOutFn.forward(ctx, x, gamma, beta, cw, cb)
+        outs.append((y, ctx.saved[2], ctx.saved[1]))
+    (y1, a1, st1), (y0, a0, st0) = outs
+    assert y1.shape == (n, 3, h, w) and y1.dtype == torch.float32
+    assert torch.equal(st1, st0) and torch.equal(a1, a0) and torch.equal(y1, y0)
+    # and the module-level function end to end (forward + backward) with both switches on
+    monkeypatch.setattr(Fn, "NORM_CONV_OUT_FUSED_FWD", True)
+    leaves = [t.clone().requires_grad_(True) for t in (x.float(), gamma, beta, cw, cb)]
+    yy = Fn.NormConvOutFn.apply(leaves[0].to(BF), *leaves[1:])
+    assert torch.equal(yy.detach(), y0)
+    yy.backward(torch.ones_like(yy))
+    assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in leaves)
