@@ -238,6 +238,30 @@ def test_gemm_nt_tn_softmax_transpose():
     assert torch.equal(t, a.transpose(1, 2).contiguous())                     # pure index op: bit-exact
 
 
+@pytest.mark.parametrize("cols", [256, 512, 1024, 2048])
+def test_softmax_rows_register_resident_forms(cols):
+    """cols = 256 NV: the row in registers (16-B loads, one exponential per element, 8-B stores: the decoder attention's S = 1024) against f64 -- every element
+    within bf16 rounding of the f64 softmax, rows summing to 1 within their 2^-9 elements' worth -- and against the three-pass form on a neighbouring width."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(cols)
+    s = (torch.randn(3, 37, cols, generator=g) * 4).to(DEV)
+    pr = ops.softmax_rows(s, 0.3)
+    ref = torch.softmax(s.cpu().double() * 0.3, -1)
+    assert pr.dtype == BF and ((pr.float().cpu().double() - ref).abs() <= 2.0 ** -8 * ref + 1e-30).all()
+    assert (pr.float().sum(-1) - 1).abs().max().item() < 3e-3
+    dp = torch.randn(3, 37, cols, generator=g).to(DEV)
+    ds = ops.softmax_rows_bwd(dp, pr, 0.3)
+    pd = pr.float().cpu().double()
+    refds = 0.3 * pd * (dp.cpu().double() - (dp.cpu().double() * pd).sum(-1, keepdim=True))
+    assert ((ds.float().cpu().double() - refds).abs() <= 2.0 ** -8 * refds.abs() + 1e-6 * refds.abs().max()).all()
+    # the generic (three-pass) kernel on the same rows with eight extra columns of very negative scores: the same probabilities on the first `cols` columns
+    s2 = torch.cat([s, torch.full((3, 37, 8), -1e4, device=DEV)], -1).contiguous()
+    p2 = ops.softmax_rows(s2, 0.3)
+    assert not p2[..., cols:].any() and (p2[..., :cols].float() - pr.float()).abs().max().item() <= 2.0 ** -8 * pr.float().max().item()
+    for _ in range(2):
+        assert torch.equal(ops.softmax_rows(s, 0.3), pr) and torch.equal(ops.softmax_rows_bwd(dp, pr, 0.3), ds)
+
+
 def test_layout_ops_bit_exact():
     ops = _ops()
     g = torch.Generator().manual_seed(6)
