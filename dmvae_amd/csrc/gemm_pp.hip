@@ -38,6 +38,11 @@ struct Args {
   unsigned wsRow, wsK;   // byte strides of the weight operand between rows / between K tiles: row-major (2 ldw, 64), K-tile-major (64, 64 N)
   int ntn, total;    // column tiles, tiles
   float inv_ntn;     // 1 / ntn
+  // BATCHED instantiations (dmvae_linear_bf16_batched: `batch` independent products y_b = x_b w_b^T, e.g. the decoder attention's q k^T per sample): tile index ->
+  // (b, tile of one product); byte strides between the products' operands; the buffer descriptors span the whole batch
+  int tpb;           // tiles per product
+  float inv_tpb;
+  unsigned sA, sB, sY, xbytes, ybytes;
   unsigned long long* dbg;   // optional s_memtime stamps per block (dmvae_debug_gemm_timing): [block][tile 0..3][4], null in production
 };
 
@@ -84,7 +89,7 @@ __device__ __forceinline__ float gelu_f(float x) { return dmvae_gelu_f(x); }   /
 //   t = nK - 1          + K(PF-1)'                                       wait 0: the next tile's first PF K tiles have landed before this tile's stores go out
 // Needs nK >= 2 PF (the host asks for K >= 384 and sends shorter reductions to the small batched kernel).  No scratch: a spilled register's reload is a VMEM load, and
 // the wait the compiler puts behind it drains the whole prefetch queue (measured: 10 k cycles per tile with 31 spilled VGPRs).
-template <int TM, int TP, int WM, int WP, bool OUT_F32, int NBUF>
+template <int TM, int TP, int WM, int WP, bool OUT_F32, int NBUF, bool BATCHED = false>
 __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int PF = NBUF - 1;   // K tiles in flight ahead of the one being read
@@ -112,16 +117,27 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
   const float inv_ntn = a.inv_ntn;   // from the host: a kernel argument lives in an SGPR (computed here it sat in a VGPR and was spilled)
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)a.M * (unsigned)a.lda * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, BATCHED ? a.xbytes : (unsigned)a.M * (unsigned)a.lda * 2u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)a.N * bsz : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)a.M * (unsigned)a.ldy * (OUT_F32 ? 4u : 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, BATCHED ? a.ybytes : (unsigned)a.M * (unsigned)a.ldy * (OUT_F32 ? 4u : 2u), 0x00020000);
 
   // per-lane DMA source offsets of a tile: weight rows in the permuted order, token rows as they are, the bias slice (wave 0; 16 B per lane)
-  auto calc = [&](unsigned work, unsigned (&vA)[NPA], unsigned (&vB)[NPB], unsigned& vBias, int& m0, int& n0) {
+  auto calc = [&](unsigned work, unsigned (&vA)[NPA], unsigned (&vB)[NPB], unsigned& vBias, int& m0, int& n0, int& b0) {
     int lane_c = lane;
     asm volatile("" : "+v"(lane_c));   // an opaque copy: what calc derives from the lane index is recomputed per tile, not hoisted out of the tile loop and carried (spilled) across the K loop
     const bool live = work < (unsigned)a.total;
-    const int wid = live ? (int)xcd_remap(work, a.total) : 0;
+    int wid = live ? (int)xcd_remap(work, a.total) : 0;
+    unsigned offA = 0, offB = 0;
+    b0 = 0;
+    if constexpr (BATCHED) {   // product b, its tile wid - b tpb (the same reciprocal + fix-up as below)
+      int b = (int)((float)wid * a.inv_tpb);
+      int r = wid - b * a.tpb;
+      if (r < 0) { b--; r += a.tpb; }
+      if (r >= a.tpb) { b++; r -= a.tpb; }
+      b0 = __builtin_amdgcn_readfirstlane(b);
+      wid = r;
+      offA = (unsigned)b0 * a.sA; offB = (unsigned)b0 * a.sB;
+    }
     int mt = (int)((float)wid * inv_ntn);            // wid / ntn for wid < 2^24 (the host keeps the tile count below that): one reciprocal and a +-1 fix-up
     int nt = wid - mt * a.ntn;
     if (nt < 0) { mt--; nt += a.ntn; }
@@ -143,14 +159,14 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
         n_ok = hid < a.H;
       }
       const int ch = (lane_c & 3) ^ swz64(rl);                  // logical 16-B chunk this lane fetches: the LDS image stays lane-linear, the swizzle is on the source address
-      vA[p] = (live && rl < TM && n_ok) ? (unsigned)n * a.wsRow + ch * 16u : SENT;
+      vA[p] = (live && rl < TM && n_ok) ? (unsigned)n * a.wsRow + ch * 16u + offA : SENT;
     }
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
       const int rl = (wave * NPB + p) * 16 + (lane_c >> 2);
       const int m = m0 + rl;
       const int ch = (lane_c & 3) ^ swz64(rl);
-      vB[p] = (live && rl < TP && m < a.M) ? (unsigned)m * (unsigned)a.lda * 2u + ch * 16u : SENT;
+      vB[p] = (live && rl < TP && m < a.M) ? (unsigned)m * (unsigned)a.lda * 2u + ch * 16u + offB : SENT;
     }
     const unsigned e0 = (unsigned)lane_c * (16u / bsz);         // first element of this lane's 16 bytes of the slice
     if (gated) {   // slice = [x1 biases of the tile's TM / 2 hidden units][x2 biases of the same units]
@@ -186,7 +202,7 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
   f32x4 acc[CL][BT];   // acc[i][j][r]: token 16 j + 4 (lane >> 4) + r of the wave's rows; column CL * (lane & 15) + i of the wave's columns
   bf16x8 wf[CL], tf[BT];
   unsigned vAc[NPA], vBc[NPB], vAn[NPA], vBn[NPB], vBiasN;
-  int m0c, n0c, m0n = 0, n0n = 0;
+  int m0c, n0c, m0n = 0, n0n = 0, b0c = 0, b0n = 0;
   int slot_rd = 0, slot_wr = PF * SLOT, par = 0;
   int it = PF;             // next K step of the current output tile to issue
 
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
   unsigned work = blockIdx.x;
   {
     unsigned vBiasC;
-    calc(work, vAc, vBc, vBiasC, m0c, n0c);
+    calc(work, vAc, vBc, vBiasC, m0c, n0c, b0c);
     issue_bias(vBiasC, 0);
   }
 #pragma unroll
@@ -278,7 +294,7 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
     kstep(W_ST{}, M0_{});
 #pragma unroll 1
     for (int t = PF; t < nK - PF; t++) kstep(W_ST{}, M0_{});
-    calc(next, vAn, vBn, vBiasN, m0n, n0n);       // all out of range when there is no next tile: its pieces move no memory
+    calc(next, vAn, vBn, vBiasN, m0n, n0n, b0n);       // all out of range when there is no next tile: its pieces move no memory
     [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) { (kstep(W_TL{}, std::integral_constant<int, J + 1>{}), ...); }(std::make_integer_sequence<int, PF - 1>{});
     kstep(W_0{}, std::integral_constant<int, PF>{});
     if (grp == 0) __builtin_amdgcn_s_barrier();    // matches group 1's extra barrier
@@ -292,6 +308,7 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
       asm volatile("" : "+v"(lane_o));   // recomputed per tile, not carried across the main loop
       const int col = gated ? (n0c >> 1) + wm * (CW / 2) + (CL / 2) * (lane_o & 15) : n0c + wm * CW + CL * (lane_o & 15);
       const int row0 = m0c + wp * (TP / WP) + 4 * (lane_o >> 4);
+      const unsigned ysoff = BATCHED ? (unsigned)b0c * a.sY : 0u;   // the product's y: scalar offset of every store below (outside the descriptor's range check, like the K-tile offsets of the loads)
       const bool c_ok = col < (gated ? a.H : a.N);       // N % 8 == 0 and CL | 8 ... the lane's columns are all inside or all outside when N is a multiple of CL; else per element below
       auto body = [&](auto ACTc) __attribute__((always_inline)) {
         constexpr int ACT = decltype(ACTc)::value;
@@ -322,11 +339,11 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
             if constexpr (ACT == 6) {
               if constexpr (CL == 8 && !OUT_F32) {
                 const u32x2 o = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3])};
-                __builtin_amdgcn_raw_buffer_store_b64(o, rY, ok ? eo * 2u : SENT, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(o, rY, ok ? eo * 2u : SENT, ysoff, 0);
                 asm volatile("s_nop 0" :: "v"(o));
               } else if constexpr (CL == 4 && !OUT_F32) {
                 const unsigned o = dmvae_pack_bf16x2(v[0], v[1]);
-                __builtin_amdgcn_raw_buffer_store_b32(o, rY, ok ? eo * 2u : SENT, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(o, rY, ok ? eo * 2u : SENT, ysoff, 0);
                 asm volatile("s_nop 0" :: "v"(o));
               }   // other instantiations are never dispatched with act 6
             } else if constexpr (OUT_F32 && CL == 6) {   // column pairs one by one (a lane may straddle N, see the bf16 case below; the f32 result is not a hot path)
@@ -334,40 +351,40 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
               for (int e = 0; e < 3; e++) {
                 const f32x2 o2 = {v[2 * e], v[2 * e + 1]};
                 const u32x2 k2 = *reinterpret_cast<const u32x2*>(&o2);
-                __builtin_amdgcn_raw_buffer_store_b64(k2, rY, (ok && col + 2 * e < a.N) ? eo * 4u + 8u * e : SENT, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(k2, rY, (ok && col + 2 * e < a.N) ? eo * 4u + 8u * e : SENT, ysoff, 0);
                 asm volatile("s_nop 0" :: "v"(k2));   // gfx950: a VALU write to a store's data VGPR directly behind the store is seen by the store (conv_pp.hip)
               }
             } else if constexpr (OUT_F32) {
               const f32x4 o0 = {v[0], v[1], v[2], v[3]};
               const u32x4 k0 = *reinterpret_cast<const u32x4*>(&o0);
-              __builtin_amdgcn_raw_buffer_store_b128(k0, rY, ok ? eo * 4u : SENT, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(k0, rY, ok ? eo * 4u : SENT, ysoff, 0);
               if constexpr (CL == 8) {
                 const f32x4 o1 = {v[4], v[5], v[6], v[7]};
                 const u32x4 k1 = *reinterpret_cast<const u32x4*>(&o1);
-                __builtin_amdgcn_raw_buffer_store_b128(k1, rY, ok ? eo * 4u + 16u : SENT, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(k1, rY, ok ? eo * 4u + 16u : SENT, ysoff, 0);
                 asm volatile("s_nop 0" :: "v"(k0), "v"(k1));
               } else {
                 asm volatile("s_nop 0" :: "v"(k0));
               }
             } else if constexpr (CL == 8) {
               const u32x4 o = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3]), dmvae_pack_bf16x2(v[4], v[5]), dmvae_pack_bf16x2(v[6], v[7])};
-              __builtin_amdgcn_raw_buffer_store_b128(o, rY, ok ? eo * 2u : SENT, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(o, rY, ok ? eo * 2u : SENT, ysoff, 0);
               asm volatile("s_nop 0" :: "v"(o));
             } else if constexpr (CL == 6) {
               // six columns per lane: N (a multiple of 8) need not be a multiple of 6, so one lane per row of the tile on N's edge straddles it -- that lane
               // stores its column pairs one by one (a wave-uniform branch that only the edge tiles take)
               const u32x3 o = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3]), dmvae_pack_bf16x2(v[4], v[5])};
               const bool full = col + 6 <= a.N;
-              __builtin_amdgcn_raw_buffer_store_b96(o, rY, (ok && full) ? eo * 2u : SENT, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b96(o, rY, (ok && full) ? eo * 2u : SENT, ysoff, 0);
               if (__builtin_amdgcn_ballot_w64(ok && !full) != 0ull) {
 #pragma unroll
                 for (int e = 0; e < 2; e++)
-                  __builtin_amdgcn_raw_buffer_store_b32(o[e], rY, (ok && !full && col + 2 * e < a.N) ? eo * 2u + 4u * e : SENT, 0, 0);
+                  __builtin_amdgcn_raw_buffer_store_b32(o[e], rY, (ok && !full && col + 2 * e < a.N) ? eo * 2u + 4u * e : SENT, ysoff, 0);
               }
               asm volatile("s_nop 0" :: "v"(o));
             } else {
               const u32x2 o = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3])};
-              __builtin_amdgcn_raw_buffer_store_b64(o, rY, ok ? eo * 2u : SENT, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b64(o, rY, ok ? eo * 2u : SENT, ysoff, 0);
               asm volatile("s_nop 0" :: "v"(o));
             }
           }
@@ -385,18 +402,21 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
     for (int p = 0; p < NPA; p++) vAc[p] = vAn[p];
 #pragma unroll
     for (int p = 0; p < NPB; p++) vBc[p] = vBn[p];
-    m0c = m0n; n0c = n0n;
+    m0c = m0n; n0c = n0n; b0c = b0n;
     par ^= 1;
   }
 #endif
 }
 
-template <int TM, int TP, int WM, int WP, bool F32>
-int launch(Args a, hipStream_t st) {
+template <int TM, int TP, int WM, int WP, bool F32, bool BATCHED = false>
+int launch(Args a, hipStream_t st, int batch = 1) {
   a.ntn = (a.N + TM - 1) / TM;
-  a.total = ((a.M + TP - 1) / TP) * a.ntn;
-  DMVAE_CHECK_ARG(a.total > 0 && a.total < (1 << 24), "linear_bf16: %d output tiles (the kernel's tile index arithmetic is exact below 2^24)", a.total);
+  a.tpb = ((a.M + TP - 1) / TP) * a.ntn;
+  a.total = a.tpb * batch;
+  DMVAE_CHECK_ARG(a.total > 0 && a.total < (1 << 24) && (long long)a.tpb * batch < (1 << 24),
+                  "linear_bf16: %lld output tiles (the kernel's tile index arithmetic is exact below 2^24)", (long long)a.tpb * batch);
   a.inv_ntn = 1.0f / (float)a.ntn;
+  a.inv_tpb = 1.0f / (float)a.tpb;
   const unsigned grid = a.total > 256 ? 256u : (unsigned)a.total;
   constexpr int slot = (TM + TP) * 64;
   constexpr int fit = (160 * 1024 - 3 * 1024) / slot;          // ring slots that fit beside the two bias slots and the dump KiB
@@ -405,10 +425,10 @@ int launch(Args a, hipStream_t st) {
   constexpr int lds = nbuf * slot + 3 * 1024;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<TM, TP, WM, WP, F32, nbuf>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<TM, TP, WM, WP, F32, nbuf, BATCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<TM, TP, WM, WP, F32, nbuf>), dim3(grid), dim3(WM * WP * 64), lds, st, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<TM, TP, WM, WP, F32, nbuf, BATCHED>), dim3(grid), dim3(WM * WP * 64), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -471,6 +491,51 @@ extern "C" int dmvae_linear_bf16_plan(int M, int N, int K, int* tile_cols, int* 
   return c;
 }
 
+// `batch` independent products y_b [M][ldy] = x_b [M][lda] w_b [N][ldw]^T on the same kernel (BATCHED instantiations): the decoder attention's per-sample GEMMs
+// (flux_ae.py:37-49: q k^T, p v, and their input gradients), 16 to 8 tiles of 256 x 256 per sample.  Element strides between the products; no bias, no activation.
+extern "C" int dmvae_linear_bf16_batched_supported(int batch, int M, int N, int K) {
+  return (batch > 0 && M >= 64 && N > 0 && N % 8 == 0 && K >= 384 && K % 32 == 0) ? 1 : 0;
+}
+extern "C" int dmvae_linear_bf16_batched(const void* x, const void* w, void* y, int batch, int M, int N, int K, int lda, int ldw, int ldy, long long sx, long long sw,
+                                         long long sy, int out_f32, hipStream_t stream) {
+  using namespace dmvae_gemm_pp;
+  DMVAE_CHECK_ARG(x && w && y, "linear_bf16_batched: null operand");
+  DMVAE_CHECK_ARG(dmvae_linear_bf16_batched_supported(batch, M, N, K), "linear_bf16_batched: need K %% 32 == 0, K >= 384, N %% 8 == 0, M >= 64 (batch %d, M %d, N %d, K %d)",
+                  batch, M, N, K);
+  DMVAE_CHECK_ARG(lda >= K && ldw >= K && ldy >= N && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0, "linear_bf16_batched: leading dimensions must cover the rows and be multiples of 8");
+  DMVAE_CHECK_ARG(sx >= (long long)M * lda && sw >= (long long)N * ldw && sy >= (long long)M * ldy && sx % 8 == 0 && sw % 8 == 0 && sy % 8 == 0,
+                  "linear_bf16_batched: batch strides must cover one product's operand and be multiples of 8 elements");
+  const long long xb = ((long long)(batch - 1) * sx + (long long)M * lda) * 2, wb = ((long long)(batch - 1) * sw + (long long)N * ldw) * 2;
+  const long long yb = ((long long)(batch - 1) * sy + (long long)M * ldy) * (out_f32 ? 4 : 2);
+  DMVAE_CHECK_ARG(xb < (1ll << 31) && wb < (1ll << 31) && yb < (1ll << 31), "linear_bf16_batched: operands are addressed through 32-bit buffer offsets (2 GiB each over the whole batch)");
+  Args a;
+  a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = nullptr; a.y = y;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldy = ldy;
+  a.act = 0; a.bias_bf16 = 0; a.H = N / 2; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = nullptr;
+  a.wbytes = (unsigned)wb; a.xbytes = (unsigned)xb; a.ybytes = (unsigned)yb;
+  a.wsRow = (unsigned)ldw * 2u; a.wsK = 64u;
+  a.sA = (unsigned)(sw * 2); a.sB = (unsigned)(sx * 2); a.sY = (unsigned)(sy * (out_f32 ? 4 : 2));
+  // three of the menu's tiles: rounds x cost over the whole batch's tiles (plan()'s model)
+  static const int cand[3] = {0, 4, 7};
+  int best = 0;
+  float best_t = 1e30f;
+  for (int i = 0; i < 3; i++) {
+    const Cfg& c = g_cfg[cand[i]];
+    const long long tiles = (long long)batch * ((M + c.tp - 1) / c.tp) * ((N + c.tm - 1) / c.tm);
+    const float frac = (float)tiles / 256.0f, whole = 0.85f * (float)((tiles + 255) / 256);
+    const float t = (frac > whole ? frac : whole) * c.cost;
+    if (t < best_t * 0.999f) { best_t = t; best = cand[i]; }
+  }
+  if (out_f32) {
+    if (best == 0) return launch<256, 256, 2, 4, true, true>(a, stream, batch);
+    if (best == 4) return launch<256, 128, 4, 2, true, true>(a, stream, batch);
+    return launch<128, 256, 2, 4, true, true>(a, stream, batch);
+  }
+  if (best == 0) return launch<256, 256, 2, 4, false, true>(a, stream, batch);
+  if (best == 4) return launch<256, 128, 4, 2, false, true>(a, stream, batch);
+  return launch<128, 256, 2, 4, false, true>(a, stream, batch);
+}
+
 extern "C" int dmvae_linear_bf16(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int lda, int ldw, int ldy,
                                  int act, int bias_bf16, int out_f32, int w_layout, hipStream_t stream) {
   using namespace dmvae_gemm_pp;
@@ -488,7 +553,7 @@ extern "C" int dmvae_linear_bf16(const void* x, const void* w, const void* bias,
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.y = y;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldy = ldy;
   a.act = act; a.bias_bf16 = bias_bf16; a.H = N / 2; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = g_gemm_dbg;
-  a.wbytes = (unsigned)wb;
+  a.wbytes = (unsigned)wb; a.tpb = 0; a.inv_tpb = 0.f; a.sA = a.sB = a.sY = a.xbytes = a.ybytes = 0u;
   a.wsRow = w_layout == 1 ? 64u : (unsigned)ldw * 2u;
   a.wsK = w_layout == 1 ? (unsigned)N * 64u : 64u;
   const int cfg = plan(M, N, K, act == 6);

@@ -309,6 +309,9 @@ def conv_out_wgrad(dy_nchw: torch.Tensor, a: torch.Tensor, dw_out: Optional[torc
     return dw
 
 
+GEMM_NT_LARGE_TILES = True      # gemm_nt: batched products with K >= 384 on csrc/gemm_pp.hip's BATCHED instantiations (tests compare the two kernels)
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
             act: int = ACT_NONE, out_f32: bool = False) -> torch.Tensor:
     """C[..., m, n] = act(A[..., m, k] @ B[..., n, k]^T + bias + residual).  A/B bf16; a 2-D operand is shared by the batch."""
@@ -325,6 +328,14 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     c = torch.empty(shape, dtype=f32 if out_f32 else bf16, device=a.device)
     if residual is not None:
         _req(residual, bf16, "residual")
+    L = _lib.lib()
+    if GEMM_NT_LARGE_TILES and a.dim() == 3 and b.dim() == 3 and bias is None and residual is None and act == ACT_NONE and m >= 256 and n >= 128 \
+            and L.dmvae_linear_bf16_batched_supported(batch, m, n, k) and batch * m * max(n, k) * (4 if out_f32 else 2) < (1 << 31) and batch * n * k * 2 < (1 << 31):
+        # per-sample products with a deep reduction (the decoder attention's q k^T, p v and their input gradients: 1024 x 1024 x 512 per sample): the large-tile
+        # Linear GEMM with a batch index in its tile decode (csrc/gemm_pp.hip, BATCHED) instead of the 128 x 128-tile kernel (~ 2.3 x its rate)
+        check(L.dmvae_linear_bf16_batched(a.data_ptr(), b.data_ptr(), c.data_ptr(), batch, m, n, k, k, k, n, m * k, n * k, m * n, int(out_f32), _stream()),
+              "linear_bf16_batched")
+        return c
     check(_lib.lib().dmvae_gemm_nt_batched(a.data_ptr(), b.data_ptr(), _ptr(bias), _ptr(residual), c.data_ptr(), m, n, k, batch,
                                            m * k if a.dim() == 3 else 0, n * k if b.dim() == 3 else 0, m * n, act, int(out_f32), _stream()),
           "gemm_nt_batched")

@@ -30,7 +30,7 @@ typedef struct ihipStream_t* dmvae_stream_t; /* == hipStream_t */
 const char* dmvae_last_error(void);
 /* ABI version; bumped when a signature or a struct changes.  2: dmvae_conv_desc gained its last field, w_layout (zero = the behaviour of version 1).
  * 3: struct dmvae_pack_entry and the entry points that take it (dmvae_pack_weights_batched), dmvae_linear_bf16 / _plan / dmvae_linear_weight_t_kmajor.
- * 4: dmvae_norm_conv_out_bwd / _supported / _workspace, dmvae_norm_conv_out_fwd / _supported, dmvae_conv_in3 / _supported / _workspace, dmvae_im2col_nhwc_taps. */
+ * 4: dmvae_norm_conv_out_bwd / _supported / _workspace, dmvae_norm_conv_out_fwd / _supported, dmvae_conv_in3 / _supported / _workspace, dmvae_im2col_nhwc_taps, dmvae_linear_bf16_batched / _supported. */
 int dmvae_abi_version(void);
 
 /* ---- convolution / GEMM (MFMA-bound) -------------------------------------------------------- */
@@ -229,6 +229,13 @@ int dmvae_set_dynamic(int on);
 int dmvae_linear_bf16(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int lda, int ldw, int ldy,
                       int act, int bias_bf16, int out_f32, int w_layout, dmvae_stream_t stream);
 int dmvae_linear_bf16_plan(int M, int N, int K, int* tile_cols, int* tile_rows);
+/* `batch` independent products y_b [M][ldy] = x_b [M][lda] w_b [N][ldw]^T on the same kernel (a batch index in its tile decode): the decoder attention's per-sample
+ * GEMMs (flux_ae.py:37-49: q k^T, p v and their input gradients -- 1024 x 1024 x 512 per sample, 8-16 tiles of 256 x 256 each).  bf16 row-major operands, f32
+ * accumulation in K order, bf16 or f32 result; sx / sw / sy: element strides between the products; no bias, no activation.  K % 32 == 0, K >= 384, N % 8 == 0,
+ * M >= 64, every operand below 2 GiB over the whole batch. */
+int dmvae_linear_bf16_batched_supported(int batch, int M, int N, int K);
+int dmvae_linear_bf16_batched(const void* x, const void* w, void* y, int batch, int M, int N, int K, int lda, int ldw, int ldy, long long sx, long long sw,
+                              long long sy, int out_f32, dmvae_stream_t stream);
 /* The input-gradient operand of dmvae_linear_bf16 from a Linear weight's bf16 copy: w bf16 [N][K] row-major (nn.Linear.weight: N = out_features, K = in_features)
  * -> out bf16 [N / 32][K][32], out[n >> 5][k][n & 31] = w[n][k], i.e. the K-tile-major layout (w_layout = 1) of W^T [K][N] with the reduction over n:
  * dmvae_linear_bf16(dy [M][N], out, NULL, dx, M, K, N, ..., w_layout = 1) is dX = dY . W.  N % 32 == 0, K % 8 == 0.  One tiled-transpose launch per weight

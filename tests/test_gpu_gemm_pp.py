@@ -224,3 +224,28 @@ def test_every_tile_of_the_menu_gives_the_same_bits(tmp_path):
     for cfg in range(1, 10):
         for key in res[0]:
             assert torch.equal(res[0][key], res[cfg][key]), f"tile {cfg} differs from tile 0 at {key}"
+
+
+@pytest.mark.parametrize("batch,m,n,k,out_f32", [(4, 1024, 1024, 512, True), (3, 1024, 512, 1024, False), (2, 300, 136, 384, True), (5, 256, 128, 512, False),
+                                                 (33, 512, 512, 512, False)])
+def test_batched_products_on_the_large_tile_kernel(batch, m, n, k, out_f32, monkeypatch):
+    """ops.gemm_nt on csrc/gemm_pp.hip's BATCHED instantiations (a batch index in the tile decode: the decoder attention's per-sample GEMMs, flux_ae.py:37-49)
+    against f64 on the same bf16 operands and against the 128 x 128-tile kernel it replaces; ragged rows / columns per product; rows past M of one product must not
+    leak into the next one's result (sentinel check: each product against ITS OWN operands only)."""
+    from conftest import rel_err
+    from dmvae_amd import ops
+    g = torch.Generator().manual_seed(batch * 1000 + m + n + k)
+    a = torch.randn(batch, m, k, generator=g).to("cuda").to(torch.bfloat16)
+    b = (torch.randn(batch, n, k, generator=g) * 0.1).to("cuda").to(torch.bfloat16)
+    monkeypatch.setattr(ops, "GEMM_NT_LARGE_TILES", True)
+    c1 = ops.gemm_nt(a, b, out_f32=out_f32)
+    monkeypatch.setattr(ops, "GEMM_NT_LARGE_TILES", False)
+    c0 = ops.gemm_nt(a, b, out_f32=out_f32)
+    ref = a.double() @ b.double().transpose(1, 2)
+    assert c1.shape == (batch, m, n) and c1.dtype == (torch.float32 if out_f32 else torch.bfloat16)
+    tol = 1e-5 if out_f32 else 2 ** -8
+    for i in range(batch):
+        assert rel_err(c1[i].double(), ref[i]) < tol, i
+    assert rel_err(c1.double(), c0.double()) < (1e-5 if out_f32 else 2 ** -7)
+    monkeypatch.setattr(ops, "GEMM_NT_LARGE_TILES", True)
+    assert torch.equal(ops.gemm_nt(a, b, out_f32=out_f32), c1)
