@@ -247,8 +247,11 @@ __global__ void bwd_final_kernel(const float* __restrict__ part, const float* __
   if (wid >= N * g.G) return;
   const int n = wid / g.G, grp = wid % g.G;
   double s1 = 0.0, s2 = 0.0;
-  // eight channels at a time: their loads in flight together and their butterflies interleaved, every channel summed exactly as one at a time (16 channels
-  // per group at 512 channels were 16 dependent L2 round trips: 12 us per launch, 17 of them per step)
+  // Eight channels at a time: 16 per-lane f64 partial sums (over the lane's chunks, in order) are turned through LDS -- value v of lane l at [v][l], rows padded to
+  // 65 doubles -- and lane 16 q + v adds the 16 lanes of quarter q in lane order; two shuffles add the quarters.  (The first form ran a six-step f64 butterfly on
+  // all 16 values: ~ 200 cross-lane moves per batch through the LDS crossbar, 12 us per launch at 512 channels.)  Fixed order: deterministic.
+  __shared__ double red[4][16][65];
+  double (*rw)[65] = red[threadIdx.x >> 6];
   for (int c0 = 0; c0 < g.cpg; c0 += 8) {
     double a[8], b[8];
 #pragma unroll
@@ -262,18 +265,30 @@ __global__ void bwd_final_kernel(const float* __restrict__ part, const float* __
       for (int u = 0; u < 8; u++) { a[u] += v[u][0]; b[u] += v[u][1]; }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int u = 0; u < 8; u++) { rw[2 * u][lane] = a[u]; rw[2 * u + 1][lane] = b[u]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int v = lane & 15, q = lane >> 4;
+    double t = 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; u++) { a[u] += __shfl_xor(a[u], o, 64); b[u] += __shfl_xor(b[u], o, 64); }
+    for (int i = 0; i < 16; i++) t += rw[v][16 * q + i];
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);                            // every lane: the total of value (lane & 15) = (channel c0 + (v >> 1), sum A / B)
+    {
+      const int u = v >> 1, c = grp * g.cpg + c0 + u;
+      if (lane < 16 && c0 + u < g.cpg) AB[((size_t)n * g.C + c) * 2 + (v & 1)] = (float)t;
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
+      const double au = __shfl(t, 2 * u, 64), bu = __shfl(t, 2 * u + 1, 64);
       if (c0 + u < g.cpg) {
         const int c = grp * g.cpg + c0 + u;
-        if (lane == 0) { AB[((size_t)n * g.C + c) * 2] = (float)a[u]; AB[((size_t)n * g.C + c) * 2 + 1] = (float)b[u]; }
-        s1 += (double)gamma[c] * a[u]; s2 += (double)gamma[c] * b[u];
+        s1 += (double)gamma[c] * au; s2 += (double)gamma[c] * bu;
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the rows are rewritten by the next batch
+    __builtin_amdgcn_wave_barrier();
   }
   if (lane == 0) { S[wid * 2] = (float)s1; S[wid * 2 + 1] = (float)s2; }
 }
