@@ -124,6 +124,8 @@ SIGNATURES = {
     "dmvae_conv_in3_supported": (c_int, [c_int] * 4),
     "dmvae_conv_in3_workspace": (c_size_t, [c_int] * 3),
     "dmvae_conv_in3": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_size_t] + [c_int] * 5 + [c_void_p]),
+    "dmvae_conv_to_image_supported": (c_int, [c_int] * 5),
+    "dmvae_conv_to_image": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "dmvae_norm_conv_out_fwd_supported": (c_int, [c_int] * 6),
     "dmvae_norm_conv_out_fwd": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
     "dmvae_norm_conv_out_bwd_supported": (c_int, [c_int] * 6),

@@ -32,6 +32,10 @@ struct Args {
   const float* stats; const float* gamma; const float* beta;
   bf16* aout;
   int G, cout;
+  // nchw: y is [N][cout][H][W] f32 (cout <= 4 planes) instead of [N][H][W][4]; mul: optional per-output-channel multiplier applied last (device, [cout]) -- the
+  // LPIPS trunk's image gradient leaves as the NCHW tensor autograd wants, already divided by the ScalingLayer's scale and multiplied by the incoming gradient
+  int nchw;
+  const float* mul;
 };
 
 constexpr unsigned SENT = 0x80000000u;
@@ -178,10 +182,13 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(Args a) {
 #pragma unroll
     for (int w2 = 1; w2 < 4; w2++) s += part[w2 * 128 + tid];   // fixed order
     const int row = tid >> 5, col = tid & 31;
-    if constexpr (NORM) {      // the image itself: NCHW f32, `cout` planes, 128 B contiguous per tile row and plane
+    if (NORM || a.nchw) {      // the image itself: NCHW f32, `cout` planes, 128 B contiguous per tile row and plane
 #pragma unroll
       for (int co = 0; co < 4; co++)
-        if (co < a.cout) a.y[((size_t)(n * a.cout + co) * a.H + y0 + row) * a.W + x0 + col] = s[co] + (a.bias ? a.bias[co] : 0.f);
+        if (co < a.cout) {
+          const float v = s[co] + (a.bias ? a.bias[co] : 0.f);
+          a.y[((size_t)(n * a.cout + co) * a.H + y0 + row) * a.W + x0 + col] = a.mul ? v * a.mul[co] : v;
+        }
     } else {
       if (a.bias) s += *reinterpret_cast<const f32x4*>(a.bias);
       *reinterpret_cast<f32x4*>(a.y + ((size_t)(n * a.H + y0 + row) * a.W + x0 + col) * 4) = s;
@@ -212,7 +219,7 @@ int dmvae_conv_thin_try(const void* x, const void* w, const void* bias, const vo
   Args a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.y = (float*)y;
   a.N = d->n; a.H = d->h; a.W = d->w; a.tiles_x = d->w / 32; a.tiles_y = d->h / 4;
-  a.stats = a.gamma = a.beta = nullptr; a.aout = nullptr; a.G = 0; a.cout = 4;
+  a.stats = a.gamma = a.beta = nullptr; a.aout = nullptr; a.G = 0; a.cout = 4; a.nchw = 0; a.mul = nullptr;
   return d->cin == 128 ? launch<128>(a, stream) : launch<64>(a, stream);
 }
 
@@ -230,6 +237,24 @@ extern "C" int dmvae_norm_conv_out_fwd(const void* x, const void* stats, const v
   Args a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.y = (float*)y;
   a.N = n; a.H = h; a.W = wd; a.tiles_x = wd / 32; a.tiles_y = h / 4;
-  a.stats = (const float*)stats; a.gamma = (const float*)gamma; a.beta = (const float*)beta; a.aout = (bf16*)aout; a.G = groups; a.cout = cout;
+  a.stats = (const float*)stats; a.gamma = (const float*)gamma; a.beta = (const float*)beta; a.aout = (bf16*)aout; a.G = groups; a.cout = cout; a.nchw = 1; a.mul = nullptr;
   return launch<128, true>(a, stream);
+}
+
+
+// 3x3 conv to cout <= 4 channels with the result as an NCHW f32 image, optionally scaled per channel: the input gradient of the LPIPS trunk's first layer
+// (utils/lpips.py:81-104 backward: 64 -> 3 channels, then / ScalingLayer.scale and * the incoming gradient) in one launch instead of four.
+extern "C" int dmvae_conv_to_image_supported(int n, int h, int w, int cin, int cout) {
+  return (n > 0 && h > 0 && w > 0 && (cin == 64 || cin == 128) && cout >= 1 && cout <= 4 && h % 4 == 0 && w % 32 == 0 && (long long)n * h * w * cin * 2 < (1ll << 31)) ? 1 : 0;
+}
+extern "C" int dmvae_conv_to_image(const void* x, const void* w, const void* bias, const void* mul, void* y, int n, int h, int wd, int cin, int cout, hipStream_t stream) {
+  DMVAE_CHECK_ARG(x && w && y, "conv_to_image: null pointer");
+  DMVAE_CHECK_ARG(dmvae_conv_to_image_supported(n, h, wd, cin, cout), "conv_to_image: unsupported shape n=%d h=%d w=%d cin=%d cout=%d (cin 64 / 128, h %% 4 == 0, w %% 32 == 0, cout <= 4)",
+                  n, h, wd, cin, cout);
+  using namespace dmvae_conv_thin;
+  Args a;
+  a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const float*)bias; a.y = (float*)y;
+  a.N = n; a.H = h; a.W = wd; a.tiles_x = wd / 32; a.tiles_y = h / 4;
+  a.stats = a.gamma = a.beta = nullptr; a.aout = nullptr; a.G = 0; a.cout = cout; a.nchw = 1; a.mul = (const float*)mul;
+  return cin == 128 ? launch<128>(a, stream) : launch<64>(a, stream);
 }

@@ -595,6 +595,30 @@ def conv_in3(x0: torch.Tensor, x1: Optional[torch.Tensor], w: torch.Tensor, bias
     return y
 
 
+def conv_to_image_supported(n: int, h: int, w: int, cin: int, cout: int) -> bool:
+    return bool(_lib.lib().dmvae_conv_to_image_supported(n, h, w, cin, cout))
+
+
+def conv_to_image(x: torch.Tensor, w_packed: torch.Tensor, cout: int, bias: Optional[torch.Tensor] = None, mul: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv3x3(x [N, H, W, Cin] bf16, Cin = 64 / 128) -> NCHW f32 image [N, cout, H, W] (cout <= 4), times mul[cout] when given: include/dmvae_hip.h
+    dmvae_conv_to_image.  w_packed: bf16 [4, 9, Cin] (pack_conv_weight with rows_pad = 4)."""
+    x = _req(x, bf16, "x")
+    w_packed = _req(w_packed, bf16, "w_packed")
+    n, h, wd, cin = x.shape
+    assert tuple(w_packed.shape) == (4, 9, cin), w_packed.shape
+    if bias is not None:
+        bias = _req(bias, f32, "bias")
+    if mul is not None:
+        mul = _req(mul, f32, "mul")
+        assert mul.numel() == cout
+    L = _lib.lib()
+    if not L.dmvae_conv_to_image_supported(n, h, wd, cin, cout):
+        raise ValueError(f"conv_to_image: unsupported shape {tuple(x.shape)} -> {cout}")
+    y = torch.empty(n, cout, h, wd, dtype=f32, device=x.device)
+    check(L.dmvae_conv_to_image(x.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(mul), y.data_ptr(), n, h, wd, cin, cout, _stream()), "conv_to_image")
+    return y
+
+
 def norm_conv_out_fwd_supported(n: int, h: int, w: int, c: int, cout: int, groups: int = 32) -> bool:
     return bool(_lib.lib().dmvae_norm_conv_out_fwd_supported(n, h, w, c, groups, cout))
 

@@ -188,6 +188,11 @@ class _VggLpips(torch.autograd.Function):
             cin = conv.weight.shape[1]
             wd = Fn.packed(conv.weight, True, 4 if cin < 4 else 0, 0, frozen=True)
             if below is None:
+                if FIRST_LAYER_FUSED and not parity.on() and dpre.dtype == torch.bfloat16 and tuple(wd.shape[:2]) == (4, 9) \
+                        and ops.conv_to_image_supported(dpre.shape[0], dpre.shape[1], dpre.shape[2], dpre.shape[3], cin):
+                    # the image gradient straight out of the conv's epilogue: NCHW f32, x gout / scale per channel (one launch for four)
+                    mul = (gout.float().reshape(1) / ctx.scale.reshape(-1).float()).contiguous()
+                    return None, ops.conv_to_image(dpre, wd, cin, mul=mul), None
                 dimg = ops.conv2d_nhwc(dpre, wd, ks=3, out_f32=True)                      # [B, H, W, 4]
                 g = ops.nhwc_to_nchw_f32(dimg, cin) / ctx.scale * gout
                 return None, g, None

@@ -30,7 +30,7 @@ typedef struct ihipStream_t* dmvae_stream_t; /* == hipStream_t */
 const char* dmvae_last_error(void);
 /* ABI version; bumped when a signature or a struct changes.  2: dmvae_conv_desc gained its last field, w_layout (zero = the behaviour of version 1).
  * 3: struct dmvae_pack_entry and the entry points that take it (dmvae_pack_weights_batched), dmvae_linear_bf16 / _plan / dmvae_linear_weight_t_kmajor.
- * 4: dmvae_norm_conv_out_bwd / _supported / _workspace, dmvae_norm_conv_out_fwd / _supported, dmvae_conv_in3 / _supported / _workspace, dmvae_im2col_nhwc_taps, dmvae_linear_bf16_batched / _supported. */
+ * 4: dmvae_norm_conv_out_bwd / _supported / _workspace, dmvae_norm_conv_out_fwd / _supported, dmvae_conv_in3 / _supported / _workspace, dmvae_im2col_nhwc_taps, dmvae_linear_bf16_batched / _supported, dmvae_conv_to_image / _supported. */
 int dmvae_abi_version(void);
 
 /* ---- convolution / GEMM (MFMA-bound) -------------------------------------------------------- */
@@ -157,6 +157,11 @@ int dmvae_groupnorm_bwd_apply(const void* da, const void* x, const void* dres, c
 int dmvae_norm_conv_out_fwd_supported(int n, int h, int w, int c, int groups, int cout);
 int dmvae_norm_conv_out_fwd(const void* x, const void* stats, const void* gamma, const void* beta, const void* w, const void* bias, void* a, void* y,
                             int n, int h, int wd, int c, int groups, int cout, dmvae_stream_t stream);
+/* 3x3 stride-1 conv of an NHWC bf16 tensor (cin = 64 / 128) to cout <= 4 channels with the result as an NCHW f32 image [n][cout][h][w], optionally multiplied per
+ * output channel by mul[cout] (device) last: the LPIPS trunk's image gradient (utils/lpips.py:81-104 backward: VGG conv1_1's input gradient, / ScalingLayer.scale,
+ * x the incoming gradient) in one launch.  w: the packed bf16 operand [4][9][cin] (dmvae_pack_conv_weight, rows_pad 4); bias f32 [cout] or NULL. */
+int dmvae_conv_to_image_supported(int n, int h, int w, int cin, int cout);
+int dmvae_conv_to_image(const void* x, const void* w, const void* bias, const void* mul, void* y, int n, int h, int wd, int cin, int cout, dmvae_stream_t stream);
 int dmvae_norm_conv_out_bwd_supported(int n, int h, int w, int c, int groups, int cout);
 size_t dmvae_norm_conv_out_bwd_workspace(int n, int h, int w, int c, int groups);
 int dmvae_norm_conv_out_bwd(const void* dy, const void* w, const void* x, const void* stats, const void* gamma, const void* beta, void* dx, void* dgamma,

@@ -96,3 +96,20 @@ def test_lpips_with_and_without_the_fused_first_layer(monkeypatch):
     # agrees in the L2 sense to well under a percent and everywhere within the bf16 trunk's own noise floor (tests/test_gpu_lpips.py holds it to 3e-2 of the oracle)
     assert rel_err(v1, v0) < 2e-3
     assert ((g1 - g0).norm() / g0.norm()).item() < 1e-2 and rel_err(g1, g0) < 5e-2
+
+
+@pytest.mark.parametrize("cin", [64, 128])
+def test_conv_to_image_is_the_four_launch_route(cin):
+    """dmvae_conv_to_image: the thin conv's result as an NCHW f32 image with a per-channel multiplier applied last (the LPIPS image gradient) against
+    conv2d_nhwc (f32 NHWC) -> nhwc_to_nchw -> * multiplier: the same sums, one f32 multiplication instead of a division and a multiplication."""
+    from dmvae_amd import ops
+    g = torch.Generator().manual_seed(cin)
+    x = torch.randn(3, 16, 32, cin, generator=g).to(DEV).to(BF)
+    w = (torch.randn(4, 9, cin, generator=g) * 0.1).to(DEV).to(BF)
+    w[3] = 0
+    mul = torch.tensor([0.7, -1.3, 2.1], device=DEV)
+    assert ops.conv_to_image_supported(3, 16, 32, cin, 3)
+    y = ops.conv_to_image(x, w, 3, mul=mul)
+    y0 = ops.nhwc_to_nchw_f32(ops.conv2d_nhwc(x, w, ks=3, out_f32=True), 3)
+    assert tuple(y.shape) == (3, 3, 16, 32) and torch.equal(ops.conv_to_image(x, w, 3), y0)
+    assert torch.equal(y, y0 * mul.view(1, 3, 1, 1))
