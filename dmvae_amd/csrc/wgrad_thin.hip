@@ -53,18 +53,36 @@ __device__ __forceinline__ bf16x8 lds_read16(unsigned lds_addr) {
 }
 
 // dy [N][C][H][W] f32 (C <= 4 real channels) -> sh [3][N][4][H + 2][W] bf16
+// One thread per eight consecutive x of one (n, co, row): the gradient row is read ONCE (two aligned 16-B loads + the two neighbours) and all three x-shifted
+// copies are written from it as 16-B stores.  (First form: one element of one copy per thread -- four runtime integer divisions and a 4-B load per 2-B store,
+// the gradient read three times: 52 us for 25 M elements.)  W % 32 == 0 (host).
 __global__ __launch_bounds__(256) void wgrad_thin_pack_kernel(const float* __restrict__ dy, bf16* __restrict__ sh, int N, int C, int H, int W) {
-  const unsigned total = 3u * N * 4u * (H + 2) * W;     // < 2^31 (host check)
-  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-    const unsigned x = i % (unsigned)W;
-    unsigned r = i / (unsigned)W;
+  const unsigned w8 = (unsigned)W >> 3;
+  const unsigned per = (unsigned)N * 4u * (H + 2) * w8;     // 16-B pieces of one copy; 3 per < 2^31 / 8 (host check)
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < per; i += gridDim.x * 256u) {
+    const unsigned x0 = (i % w8) * 8u;
+    unsigned r = i / w8;
     const unsigned yy = r % (unsigned)(H + 2); r /= (unsigned)(H + 2);
-    const unsigned co = r & 3u; r >>= 2;
-    const unsigned n = r % (unsigned)N, kx = r / (unsigned)N;
-    const int y = (int)yy - 1, xs = (int)x - (int)kx + 1;
-    float v = 0.f;
-    if ((int)co < C && (unsigned)y < (unsigned)H && (unsigned)xs < (unsigned)W) v = dy[(((size_t)n * C + co) * H + y) * W + xs];
-    sh[i] = (bf16)v;
+    const unsigned co = r & 3u, n = r >> 2;
+    const int y = (int)yy - 1;
+    float v[10];      // v[1 + e] = dy[x0 + e], v[0] / v[9]: the neighbours (zero outside the row)
+#pragma unroll
+    for (int e = 0; e < 10; e++) v[e] = 0.f;
+    if ((int)co < C && (unsigned)y < (unsigned)H) {
+      const float* row = dy + (((size_t)n * C + co) * H + y) * W + x0;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(row), hi = *reinterpret_cast<const f32x4*>(row + 4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) { v[1 + e] = lo[e]; v[5 + e] = hi[e]; }
+      if (x0 > 0) v[0] = row[-1];
+      if (x0 + 8 < (unsigned)W) v[9] = row[8];
+    }
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) {      // sh[kx][..][x] = dy[x - kx + 1]
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = (bf16)v[1 + e - kx + 1];
+      reinterpret_cast<bf16x8*>(sh)[(size_t)kx * per + i] = o;
+    }
   }
 }
 
