@@ -27,7 +27,7 @@ class PackEntry(Structure):
                 ("reserved", c_int32), ("start", c_ulonglong), ("count", c_ulonglong)]
 
 
-ABI_VERSION = 4     # include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*; 4: dmvae_norm_conv_out_bwd*)
+ABI_VERSION = 5     # 5: dmvae_groupnorm_*_short; include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*; 4: dmvae_norm_conv_out_bwd*)
 
 # name -> (restype, argtypes); every symbol include/dmvae_hip.h declares
 SIGNATURES = {
@@ -121,6 +121,10 @@ SIGNATURES = {
     "dmvae_groupnorm_bwd_colsum": (c_int, [c_void_p] * 11 + [c_size_t] + [c_int] * 7 + [c_void_p]),
     "dmvae_groupnorm_bwd_reduce": (c_int, [c_void_p] * 9 + [c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_groupnorm_bwd_apply": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "dmvae_groupnorm_short_supported": (c_int, [c_int] * 5),
+    "dmvae_groupnorm_apply_short": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
+    "dmvae_groupnorm_bwd_short_workspace": (c_size_t, [c_int] * 5),
+    "dmvae_groupnorm_bwd_short": (c_int, [c_void_p] * 12 + [c_size_t] + [c_int] * 8 + [c_void_p]),
     "dmvae_conv_in3_supported": (c_int, [c_int] * 4),
     "dmvae_conv_in3_workspace": (c_size_t, [c_int] * 3),
     "dmvae_conv_in3": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_size_t] + [c_int] * 5 + [c_void_p]),

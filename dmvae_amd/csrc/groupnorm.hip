@@ -677,6 +677,17 @@ static int bwd_reduce_impl(const void* da, const void* x, const void* stats, con
   return 0;
 }
 
+// The reduction half for an apply launch that lives in another file (norm_short.hip): partials -> AB [n][c][2] and S [n][groups][2] inside `workspace`
+// (dmvae_groupnorm_workspace bytes), no parameter-gradient launch (the caller's apply launch adds AB up).
+int dmvae_gn_bwd_reduce_parts(const void* da, const void* x, const void* stats, const void* gamma, const void* beta, void* workspace, size_t workspace_bytes,
+                              int n, int hw, int c, int groups, int act, float** AB, float** S, hipStream_t stream) {
+  Geom g;
+  DMVAE_CHECK_ARG(make_geom(g, n, hw, c, groups) == 0, "groupnorm_bwd_reduce: unsupported shape n=%d hw=%d c=%d groups=%d", n, hw, c, groups);
+  *AB = (float*)workspace + (size_t)n * g.nchunk * c * 2;
+  *S = *AB + (size_t)n * c * 2;
+  return bwd_reduce_impl(da, x, stats, gamma, beta, *S, nullptr, nullptr, workspace, workspace_bytes, n, hw, c, groups, act, 0, false, stream);
+}
+
 // Elementwise half: dx = rstd*(g - (s1 + x_hat*s2)*inv_count) [+ dres]; inv_count <= 0 selects 1/(hw*c/groups).
 extern "C" int dmvae_groupnorm_bwd_apply(const void* da, const void* x, const void* dres, const void* stats, const void* sums,
                                          const void* gamma, const void* beta, void* dx, int n, int hw, int c, int groups, int act,

@@ -177,15 +177,30 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+SHORTCUT_IN_NORM = True      # tests/test_gpu_norm_short.py switches it off to compare with the stored-operand route
+
+
+def _shortcut_in_norm(x: torch.Tensor, sw) -> bool:
+    if sw is None or not SHORTCUT_IN_NORM or parity.on() or x.dtype != bf16 or sw.dim() != 4 or sw.shape[2] != 1:
+        return False
+    n, c = x.shape[0], x.shape[-1]
+    return sw.shape[1] == c and ops.groupnorm_short_supported(n, x.numel() // (n * c), c, sw.shape[0])
+
+
 class ResnetBlockFn(torch.autograd.Function):
     """x + conv2(swish(GN(conv1(swish(GN(x)))))) with optional 1x1 shortcut (flux_ae.py:69-82)."""
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, sw, sb):
-        st1, a1 = _gn_swish(x, n1w, n1b)
+        ctx.short = _shortcut_in_norm(x, sw)
+        if ctx.short:        # norm1 and the 1x1 shortcut from one read of x (csrc/norm_short.hip)
+            st1 = _stats_of(x)
+            a1, xs = ops.groupnorm_apply_short(x, st1, n1w, n1b, packed(sw), sb)
+        else:
+            st1, a1 = _gn_swish(x, n1w, n1b)
+            xs = x if sw is None else ops.conv2d_nhwc(x, packed(sw), sb, ks=1)
         h1, st2 = ops.conv2d_nhwc_gnstats(a1, packed(c1w), c1b, ks=3)             # norm2's statistics from conv1's epilogue
         a2 = ops.groupnorm_apply(h1, st2, n2w, n2b, True)
-        xs = x if sw is None else ops.conv2d_nhwc(x, packed(sw), sb, ks=1)
         y, sty = ops.conv2d_nhwc_gnstats(a2, packed(c2w), c2b, residual=xs, ks=3)   # ... and the next module's norm from conv2's
         ctx.save_for_backward(x, st1, a1, h1, st2, a2, n1w, n1b, c1w, n2w, n2b, c2w, sw)
         ctx.bias_params = (c1b, c2b, sb)     # only for their gradient destinations
@@ -206,6 +221,10 @@ class ResnetBlockFn(torch.autograd.Function):
             dxs, dsw, dsb = dy, None, None
         else:
             dsw, dsb = ops.conv2d_nhwc_wgrad(dy, x, 1, dw_out=_dst(sw), db_out=_dst(sb))
+            if ctx.short:    # the shortcut's input gradient is formed inside norm1's backward apply pass: the stored gradient (twice x's channels) never exists
+                dx, dn1w, dn1b = ops.groupnorm_bwd_short(da1, x, dy, packed(sw, True), st1, n1w, n1b, True, dg_out=_dst(n1w), db_out=_dst(n1b),
+                                                         want_colsum=ctx.want_colsum)
+                return dx, dn1w, dn1b, dc1w, dc1b, dn2w, dn2b, dc2w, dc2b, dsw, dsb
             dxs = ops.conv2d_nhwc(dy, packed(sw, True), ks=1)
         dx, dn1w, dn1b = ops.groupnorm_bwd(da1, x, st1, n1w, n1b, True, dres=dxs, dg_out=_dst(n1w), db_out=_dst(n1b), want_colsum=ctx.want_colsum)
         return dx, dn1w, dn1b, dc1w, dc1b, dn2w, dn2b, dc2w, dc2b, dsw, dsb

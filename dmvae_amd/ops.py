@@ -672,6 +672,63 @@ def norm_conv_out_bwd(dy: torch.Tensor, w: torch.Tensor, x: torch.Tensor, stats:
     return dx, dg, db
 
 
+def groupnorm_short_supported(n: int, hw: int, c: int, cs: int, groups: int = 32) -> bool:
+    """The shapes whose 1x1 shortcut rides on the GroupNorm passes (csrc/norm_short.hip): c = 256 channels of the block input, cs = 128 of its output, hw % 16 == 0."""
+    return bool(_lib.lib().dmvae_groupnorm_short_supported(n, hw, c, cs, groups))
+
+
+def groupnorm_apply_short(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
+                          swish: bool = True, groups: int = 32):
+    """-> (a, xs): a = act(GroupNorm(x)) and xs = conv1x1(x, w) + bias from ONE read of x -- a ResnetBlock's norm1 and its nin_shortcut (flux_ae.py:67,71,77-82).
+    w: the shortcut's packed forward operand bf16 [cs, 1, c] (functional.packed)."""
+    x = _req(x, bf16, "x")
+    w = _req(w, bf16, "packed weight")
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    cs = w.shape[0]
+    assert w.numel() == cs * c, (w.shape, x.shape)
+    L = _lib.lib()
+    if not L.dmvae_groupnorm_short_supported(n, hw, c, cs, groups):
+        raise ValueError(f"groupnorm_apply_short: unsupported shape x {tuple(x.shape)} -> {cs} channels, {groups} groups")
+    if bias is not None:
+        bias = _req(bias, f32, "bias")
+    a = torch.empty_like(x)
+    xs = torch.empty(*x.shape[:-1], cs, dtype=bf16, device=x.device)
+    check(L.dmvae_groupnorm_apply_short(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), _ptr(bias), a.data_ptr(), xs.data_ptr(),
+                                        n, hw, c, cs, groups, int(swish), _stream()), "groupnorm_apply_short")
+    return a, xs
+
+
+def groupnorm_bwd_short(da: torch.Tensor, x: torch.Tensor, dys: torch.Tensor, wt: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                        swish: bool = True, groups: int = 32, dg_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None,
+                        want_colsum: bool = False):
+    """groupnorm_bwd(da, x, ..., dres = conv1x1 input gradient of dys) without the stored gradient: dys bf16 [N, H, W, cs] is the ResnetBlock's output gradient,
+    wt the shortcut's packed input-gradient operand bf16 [c, 1, cs] (functional.packed(sw, True)).  -> (dx, dgamma, dbeta); want_colsum as in groupnorm_bwd."""
+    da = _req(da, bf16, "da")
+    x = _req(x, bf16, "x")
+    dys = _req(dys, bf16, "dys")
+    wt = _req(wt, bf16, "packed weight")
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    cs = dys.shape[-1]
+    assert wt.numel() == cs * c and wt.shape[0] == c and dys.numel() == n * hw * cs and da.shape == x.shape, (wt.shape, dys.shape, x.shape)
+    L = _lib.lib()
+    wsb = L.dmvae_groupnorm_bwd_short_workspace(n, hw, c, cs, groups)
+    if wsb == 0:
+        raise ValueError(f"groupnorm_bwd_short: unsupported shape x {tuple(x.shape)}, dys {tuple(dys.shape)}, {groups} groups")
+    ws = workspace(wsb, x.device)
+    dx = torch.empty_like(x)
+    dg = dg_out if dg_out is not None else torch.empty(c, dtype=f32, device=x.device)
+    db = db_out if db_out is not None else torch.empty(c, dtype=f32, device=x.device)
+    cs_t = torch.empty(c, dtype=f32, device=x.device) if want_colsum else None
+    check(L.dmvae_groupnorm_bwd_short(da.data_ptr(), x.data_ptr(), dys.data_ptr(), wt.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dx.data_ptr(),
+                                      dg.data_ptr(), db.data_ptr(), _ptr(cs_t), ws.data_ptr(), ws.numel(), n, hw, c, cs, groups, int(swish), 0, 0, _stream()),
+          "groupnorm_bwd_short")
+    if want_colsum:
+        dx._dmvae_colsum = (cs_t, dx._version, dx.data_ptr())
+    return dx, dg, db
+
+
 def groupnorm_bwd_reduce(da: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: int,
                          groups: int = 32, need_param_grads: bool = True, dg_out: Optional[torch.Tensor] = None,
                          db_out: Optional[torch.Tensor] = None):

@@ -30,7 +30,8 @@ typedef struct ihipStream_t* dmvae_stream_t; /* == hipStream_t */
 const char* dmvae_last_error(void);
 /* ABI version; bumped when a signature or a struct changes.  2: dmvae_conv_desc gained its last field, w_layout (zero = the behaviour of version 1).
  * 3: struct dmvae_pack_entry and the entry points that take it (dmvae_pack_weights_batched), dmvae_linear_bf16 / _plan / dmvae_linear_weight_t_kmajor.
- * 4: dmvae_norm_conv_out_bwd / _supported / _workspace, dmvae_norm_conv_out_fwd / _supported, dmvae_conv_in3 / _supported / _workspace, dmvae_im2col_nhwc_taps, dmvae_linear_bf16_batched / _supported, dmvae_conv_to_image / _supported. */
+ * 4: dmvae_norm_conv_out_bwd / _supported / _workspace, dmvae_norm_conv_out_fwd / _supported, dmvae_conv_in3 / _supported / _workspace, dmvae_im2col_nhwc_taps, dmvae_linear_bf16_batched / _supported, dmvae_conv_to_image / _supported.
+ * 5: dmvae_groupnorm_apply_short / _bwd_short / _short_supported / _bwd_short_workspace. */
 int dmvae_abi_version(void);
 
 /* ---- convolution / GEMM (MFMA-bound) -------------------------------------------------------- */
@@ -167,6 +168,23 @@ size_t dmvae_norm_conv_out_bwd_workspace(int n, int h, int w, int c, int groups)
 int dmvae_norm_conv_out_bwd(const void* dy, const void* w, const void* x, const void* stats, const void* gamma, const void* beta, void* dx, void* dgamma,
                             void* dbeta, void* workspace, size_t workspace_bytes, int n, int h, int wd, int c, int groups, int cout, int accumulate,
                             dmvae_stream_t stream);
+
+/* A ResnetBlock's 1x1 nin_shortcut (models/flux_ae.py:67,77-82) evaluated on the matrix cores inside the block's first GroupNorm passes (csrc/norm_short.hip) instead
+ * of as launches of its own over tensors those passes stream anyway.  Shapes: c = 256 channels of the block input, cs = 128 of the block output, hw % 16 == 0
+ * (dmvae_groupnorm_short_supported).
+ *   dmvae_groupnorm_apply_short: a = act(GroupNorm(x)) (bf16 [n][hw][c], dmvae_groupnorm_apply's arithmetic) and xs = bf16(x W^T + bias) (bf16 [n][hw][cs]) from one
+ *     read of x; w: the shortcut's packed forward operand bf16 [cs][c] (dmvae_pack_conv_weight, for_dgrad = 0), bias f32 [cs] or NULL.  xs equals
+ *     dmvae_conv2d_nhwc_fwd (ks 1) up to the f32 summation order inside its bf16 rounding.
+ *   dmvae_groupnorm_bwd_short: dmvae_groupnorm_bwd (dmvae_groupnorm_bwd_colsum when colsum != NULL) with dres = bf16(dys W) computed in place: dys is the block's
+ *     output gradient bf16 [n][hw][cs], wt the shortcut's packed input-gradient operand bf16 [c][cs] (for_dgrad = 1).  Equals the ks-1 input-gradient conv followed by
+ *     dmvae_groupnorm_bwd(_colsum) up to the summation order inside the bf16 rounding of the shortcut gradient (colsum: and the order of its f32 partial sums). */
+int dmvae_groupnorm_short_supported(int n, int hw, int c, int cs, int groups);
+int dmvae_groupnorm_apply_short(const void* x, const void* stats, const void* gamma, const void* beta, const void* w, const void* bias, void* a, void* xs,
+                                int n, int hw, int c, int cs, int groups, int act, dmvae_stream_t stream);
+size_t dmvae_groupnorm_bwd_short_workspace(int n, int hw, int c, int cs, int groups);
+int dmvae_groupnorm_bwd_short(const void* da, const void* x, const void* dys, const void* wt, const void* stats, const void* gamma, const void* beta,
+                              void* dx, void* dgamma, void* dbeta, void* colsum, void* workspace, size_t workspace_bytes, int n, int hw, int c, int cs,
+                              int groups, int act, int accumulate, int colsum_accumulate, dmvae_stream_t stream);
 
 /* 3x3 stride-1 conv FROM THREE input channels (an NCHW f32 image) to cout = 64 / 128 channels with bias and ReLU, NHWC bf16 result: the first layer of the
  * LPIPS trunk behind its ScalingLayer (utils/lpips.py:81-104,116-135: VGG16 conv1_1 on both branches).  The n images come from one or two tensors (x0: the first
