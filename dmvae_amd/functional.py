@@ -178,12 +178,15 @@ def _c(t):
 
 
 SHORTCUT_IN_NORM = True      # tests/test_gpu_norm_short.py switches it off to compare with the stored-operand route
+SHORTCUT_IN_NORM_512 = True  # ... the 512 -> 256 block's alone (its kernels differ: csrc/norm_short.hip, namespace coop)
 
 
 def _shortcut_in_norm(x: torch.Tensor, sw) -> bool:
     if sw is None or not SHORTCUT_IN_NORM or parity.on() or x.dtype != bf16 or sw.dim() != 4 or sw.shape[2] != 1:
         return False
     n, c = x.shape[0], x.shape[-1]
+    if c == 512 and not SHORTCUT_IN_NORM_512:
+        return False
     return sw.shape[1] == c and ops.groupnorm_short_supported(n, x.numel() // (n * c), c, sw.shape[0])
 
 

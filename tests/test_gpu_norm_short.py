@@ -11,13 +11,14 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 BF = torch.bfloat16
-C, CS = 256, 128
+PAIRS = [(256, 128), (512, 256)]      # (channels of the block input, of its output): up[0]'s first block (weight in LDS, a wave per run), up[1]'s (weight in registers, a block per run)
 
 SHAPES = [(2, 16, 16), (1, 24, 32), (3, 8, 18), (2, 4, 4), (1, 48, 48)]      # (n, h, w): hw % 16 == 0; 144 / 768 / 2304 pixels are ragged against the 128-pixel rounds
+CASES = [(c, cs, n, h, w) for (c, cs) in PAIRS for (n, h, w) in SHAPES]
 
 
-def _case(n, h, w, seed=0):
-    g = torch.Generator().manual_seed(1000 * n + 10 * h + w + seed)
+def _case(n, h, w, seed=0, C=256, CS=128):
+    g = torch.Generator().manual_seed(1000 * n + 10 * h + w + seed + C)
     x = (torch.randn(n, h, w, C, generator=g) * 1.5 + 0.3).to(DEV).to(BF)
     gamma = (1.0 + 0.2 * torch.randn(C, generator=g)).to(DEV)
     beta = (0.1 * torch.randn(C, generator=g)).to(DEV)
@@ -36,12 +37,12 @@ def _close_up_to_rounding(got, ref, frac=0.05):
     assert (d > 0).float().mean().item() < frac, (d > 0).float().mean().item()
 
 
-@pytest.mark.parametrize("n,h,w", SHAPES)
-def test_forward_equals_apply_and_the_1x1_conv(n, h, w):
+@pytest.mark.parametrize("C,CS,n,h,w", CASES)
+def test_forward_equals_apply_and_the_1x1_conv(C, CS, n, h, w):
     from dmvae_amd import ops
     from dmvae_amd.functional import packed
     assert ops.groupnorm_short_supported(n, h * w, C, CS)
-    x, gamma, beta, sw, sb, _, _ = _case(n, h, w)
+    x, gamma, beta, sw, sb, _, _ = _case(n, h, w, C=C, CS=CS)
     st = ops.groupnorm_stats(x, 32, 1e-6)
     a0 = ops.groupnorm_apply(x, st, gamma, beta, True)
     xs0 = ops.conv2d_nhwc(x, packed(sw), sb, ks=1)
@@ -59,11 +60,11 @@ def test_forward_equals_apply_and_the_1x1_conv(n, h, w):
 
 
 @pytest.mark.parametrize("colsum", [False, True])
-@pytest.mark.parametrize("n,h,w", SHAPES)
-def test_backward_equals_the_stored_gradient_route(n, h, w, colsum):
+@pytest.mark.parametrize("C,CS,n,h,w", CASES)
+def test_backward_equals_the_stored_gradient_route(C, CS, n, h, w, colsum):
     from dmvae_amd import ops
     from dmvae_amd.functional import packed
-    x, gamma, beta, sw, sb, da, dy = _case(n, h, w, seed=3)
+    x, gamma, beta, sw, sb, da, dy = _case(n, h, w, seed=3, C=C, CS=CS)
     st = ops.groupnorm_stats(x, 32, 1e-6)
     dxs = ops.conv2d_nhwc(dy, packed(sw, True), ks=1)
     dx0, dg0, db0 = ops.groupnorm_bwd(da, x, st, gamma, beta, True, dres=dxs, want_colsum=colsum)
@@ -84,14 +85,15 @@ def test_backward_equals_the_stored_gradient_route(n, h, w, colsum):
             assert torch.equal(dx2._dmvae_colsum[0], dx._dmvae_colsum[0])
 
 
+@pytest.mark.parametrize("C,CS", PAIRS)
 @pytest.mark.parametrize("n,h,w", SHAPES[:3])
-def test_backward_vs_f64_autograd_of_the_oracle(n, h, w):
+def test_backward_vs_f64_autograd_of_the_oracle(n, h, w, C, CS):
     """f64 autograd through oracle.ref_cpu's group_norm -> swish on the HIP path's operands plus the shortcut's dy W in f64: what is left is the bf16 rounding of
     the shortcut gradient and of dx itself."""
     from dmvae_amd import ops
     from dmvae_amd.functional import packed
     from oracle import ref_cpu
-    x, gamma, beta, sw, sb, da, dy = _case(n, h, w, seed=7)
+    x, gamma, beta, sw, sb, da, dy = _case(n, h, w, seed=7, C=C, CS=CS)
     st = ops.groupnorm_stats(x, 32, 1e-6)
     dx, dg, db = ops.groupnorm_bwd_short(da, x, dy, packed(sw, True), st, gamma, beta, True)
     xd = x.double().permute(0, 3, 1, 2).cpu().requires_grad_(True)
@@ -106,12 +108,13 @@ def test_backward_vs_f64_autograd_of_the_oracle(n, h, w):
     assert rel_err(dg.double().cpu(), gd.grad) < 5e-3 and rel_err(db.double().cpu(), bd.grad) < 5e-3
 
 
-def test_outputs_stay_inside_their_buffers():
+@pytest.mark.parametrize("C,CS", PAIRS)
+def test_outputs_stay_inside_their_buffers(C, CS):
     """raw C-ABI calls on outputs carved out of sentinel-filled buffers: nothing before or behind them is written"""
     from dmvae_amd import _lib, ops
     from dmvae_amd.functional import packed
     n, h, w = 2, 8, 18
-    x, gamma, beta, sw, sb, da, dy = _case(n, h, w, seed=11)
+    x, gamma, beta, sw, sb, da, dy = _case(n, h, w, seed=11, C=C, CS=CS)
     st = ops.groupnorm_stats(x, 32, 1e-6)
     L = _lib.lib()
     guard = 4096
@@ -139,17 +142,19 @@ def test_outputs_stay_inside_their_buffers():
 
 def test_unsupported_shapes_are_refused():
     from dmvae_amd import ops
-    assert not ops.groupnorm_short_supported(2, 64, 512, 256)        # up[1]'s 512 -> 256: its 256-KB weight does not fit the kernel's LDS form
+    assert not ops.groupnorm_short_supported(2, 64, 512, 128)
     assert not ops.groupnorm_short_supported(2, 72, 256, 128)        # hw % 16
     assert not ops.groupnorm_short_supported(2, 64, 256, 64)
-    x = torch.zeros(1, 4, 4, 512, dtype=BF, device=DEV)
+    assert not ops.groupnorm_short_supported(2, 64, 128, 64)
+    x = torch.zeros(1, 4, 4, 128, dtype=BF, device=DEV)
     st = ops.groupnorm_stats(x, 32, 1e-6)
     with pytest.raises(ValueError):
-        ops.groupnorm_apply_short(x, st, torch.ones(512, device=DEV), torch.zeros(512, device=DEV), torch.zeros(256, 1, 512, dtype=BF, device=DEV), None)
+        ops.groupnorm_apply_short(x, st, torch.ones(128, device=DEV), torch.zeros(128, device=DEV), torch.zeros(64, 1, 128, dtype=BF, device=DEV), None)
 
 
-def test_resnet_block_with_the_switch_on_and_off(monkeypatch):
-    """ResnetBlock(256 -> 128) forward + backward through `ResnetBlockFn`: the fused route is the one taken by default, and it agrees with the stored-operand route."""
+@pytest.mark.parametrize("C,CS", PAIRS)
+def test_resnet_block_with_the_switch_on_and_off(monkeypatch, C, CS):
+    """ResnetBlock(256 -> 128 / 512 -> 256) forward + backward through `ResnetBlockFn`: the fused route is the one taken by default, and it agrees with the stored-operand route."""
     from dmvae_amd import functional as Fn, ops
     from dmvae_amd.models.flux_ae import ResnetBlock
     torch.manual_seed(0)
