@@ -107,6 +107,7 @@ SIGNATURES = {
     "dmvae_loss_workspace": (c_size_t, []),
     "dmvae_l1_mse": (c_int, [c_void_p] * 5 + [c_size_t, c_size_t, c_float, c_float, c_void_p]),
     "dmvae_lpips_diff": (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "dmvae_lpips_diff_pool": (c_int, [c_void_p] * 8 + [c_size_t, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dmvae_dmd_pre": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "dmvae_dmd_post": (c_int, [c_void_p] * 10 + [c_size_t, c_int, c_int, c_float, c_int, c_void_p]),
     "dmvae_kl_mmd_workspace": (c_size_t, [c_int, c_int, c_int]),

@@ -115,6 +115,83 @@ __global__ __launch_bounds__(256) void lpips_diff_kernel(const bf16* __restrict_
   acc = block_sum_256(acc, sh);
   if (threadIdx.x == 0) part[(size_t)n * gridDim.x + blockIdx.x] = acc;
 }
+// The same level value and gradient, plus the 2x2 max pool of BOTH branches that follows every tapped level but the last in the VGG16 trunk (utils/lpips.py:126-135,
+// _CFG "M"): the pool re-read the 2B feature maps the diff had just streamed (537 MB at relu1_2 with B = 32).  A pixel group walks pooled pixels and visits the four
+// source pixels of each (all eight loads in flight first); per source pixel the arithmetic is lpips_diff_kernel's, the maximum is maxpool2x2_kernel's (first
+// maximum in scan order).  pool0 / pool1: [N][H2][W2][C] halves of the pooled 2N-image tensor.
+__global__ __launch_bounds__(256) void lpips_diff_pool_kernel(const bf16* __restrict__ f0, const bf16* __restrict__ f1, const float* __restrict__ w,
+                                                              bf16* __restrict__ df1, float* __restrict__ part, bf16* __restrict__ pool0,
+                                                              bf16* __restrict__ pool1, int H2, int W2, int C, int lpp_shift, int ppc, float gscale, float eps) {
+  __shared__ float sh[4];
+  const int lpp = 1 << lpp_shift;
+  const int lane_c = threadIdx.x & (lpp - 1), prow = threadIdx.x >> lpp_shift;
+  const int rows = 256 >> lpp_shift;
+  const int n = blockIdx.y;
+  const int HWp = H2 * W2;
+  const int p0 = blockIdx.x * ppc, p1 = min(p0 + ppc, HWp);
+  const bool active = lane_c * 8 < C;
+  float wv[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) wv[e] = active ? w[lane_c * 8 + e] : 0.f;
+  float acc = 0.f;
+  const bf16x8 z8 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+  for (int pp = p0 + prow; pp < p1; pp += rows) {
+    const int yo = pp / W2, xo = pp - yo * W2;
+    const size_t src = (((size_t)n * 2 * H2 + 2 * yo) * 2 * W2 + 2 * xo) * C + lane_c * 8;      // source pixel (2 yo, 2 xo)
+    bf16x8 va[4], vb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const size_t off = src + ((size_t)(k >> 1) * 2 * W2 + (k & 1)) * C;
+      va[k] = active ? dmvae_ldnt8(f0 + off) : z8;
+      vb[k] = active ? dmvae_ldnt8(f1 + off) : z8;
+    }
+    bf16x8 ma = va[0], mb = vb[0];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      float a[8], b[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) { a[e] = (float)va[k][e]; b[e] = (float)vb[k][e]; }
+      if (k > 0) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { ma[e] = a[e] > (float)ma[e] ? va[k][e] : ma[e]; mb[e] = b[e] > (float)mb[e] ? vb[k][e] : mb[e]; }
+      }
+      float sa = 0.f, sb = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) { sa += a[e] * a[e]; sb += b[e] * b[e]; }
+      for (int o = lpp >> 1; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+      const float ra = sqrtf(sa), rb = sqrtf(sb);
+      const float ia = 1.f / (ra + eps), ib = 1.f / (rb + eps);
+      float g[8], v = 0.f, gdot = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+#pragma clang fp contract(off)  // as in lpips_diff_kernel: LPIPS(x, x) has to be exactly 0
+        const float pa = a[e] * ia, pb = b[e] * ib;
+        const float d = pa - pb;
+        v += wv[e] * d * d;
+        g[e] = -2.f * wv[e] * d;
+        gdot += g[e] * b[e];
+      }
+      acc += v;
+      if (df1) {
+        for (int o = lpp >> 1; o > 0; o >>= 1) gdot += __shfl_xor(gdot, o, 64);
+        const float k2 = rb > 0.f ? gdot * ib * ib / rb : 0.f;
+        if (active) {
+          bf16x8 o8;
+#pragma unroll
+          for (int e = 0; e < 8; e++) o8[e] = (bf16)(gscale * (g[e] * ib - b[e] * k2));
+          *reinterpret_cast<bf16x8*>(df1 + src + ((size_t)(k >> 1) * 2 * W2 + (k & 1)) * C) = o8;
+        }
+      }
+    }
+    if (active) {
+      const size_t po = ((size_t)n * HWp + pp) * C + lane_c * 8;
+      *reinterpret_cast<bf16x8*>(pool0 + po) = ma;
+      *reinterpret_cast<bf16x8*>(pool1 + po) = mb;
+    }
+  }
+  acc = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) part[(size_t)n * gridDim.x + blockIdx.x] = acc;
+}
 // out[0] += scale * sum(part)   (scale = 1/(HW*N)); zero_first: overwrite
 __global__ void scalar_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int n, double scale, int accumulate) {
   double a = 0.0;
@@ -788,6 +865,33 @@ extern "C" int dmvae_lpips_diff(const void* f0, const void* f1, const void* lin_
                      (bf16*)df1, part, hw, c, sh, ppc, gscale, 1e-10f);
   DMVAE_CHECK_LAUNCH();
   hipLaunchKernelGGL(scalar_sum_kernel, dim3(1), dim3(64), 0, stream, part, (float*)out, nchunk * n, 1.0 / ((double)hw * n), accumulate);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+// dmvae_lpips_diff + the 2x2 max pool of both branches in one pass (lpips_diff_pool_kernel): h, w = the features' (even) height and width
+extern "C" int dmvae_lpips_diff_pool(const void* f0, const void* f1, const void* lin_w, void* df1, void* out, void* pool0, void* pool1, void* workspace,
+                                     size_t workspace_bytes, int n, int h, int w, int c, float gscale, int accumulate, hipStream_t stream) {
+  DMVAE_CHECK_ARG(f0 && f1 && lin_w && out && pool0 && pool1 && workspace, "lpips_diff_pool: null pointer");
+  DMVAE_CHECK_ARG(n > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0 && c > 0 && c % 8 == 0 && c <= 512 && (long long)h * w < (1ll << 30),
+                  "lpips_diff_pool: h, w even, c a multiple of 8 and <= 512 (got h=%d w=%d c=%d)", h, w, c);
+  DMVAE_CHECK_ARG(workspace_bytes >= dmvae_loss_workspace(), "lpips_diff_pool: workspace too small");
+  int lpp = 1, sh = 0;
+  while (lpp < c / 8) { lpp <<= 1; sh++; }
+  const int rows = 256 / lpp, hwp = (h / 2) * (w / 2);
+  int nchunk = (2048 + n - 1) / n;
+  const int maxc = (hwp + rows - 1) / rows;
+  if (nchunk > maxc) nchunk = maxc;
+  if (nchunk * n > 65536) nchunk = 65536 / n;
+  if (nchunk < 1) nchunk = 1;
+  const int ppc = (hwp + nchunk - 1) / nchunk;
+  nchunk = (hwp + ppc - 1) / ppc;
+  DMVAE_CHECK_ARG((size_t)nchunk * n <= 65536, "lpips_diff_pool: batch too large");
+  float* part = (float*)workspace + 2 * 4096;
+  hipLaunchKernelGGL(lpips_diff_pool_kernel, dim3(nchunk, n), dim3(256), 0, stream, (const bf16*)f0, (const bf16*)f1, (const float*)lin_w, (bf16*)df1, part,
+                     (bf16*)pool0, (bf16*)pool1, h / 2, w / 2, c, sh, ppc, gscale, 1e-10f);
+  DMVAE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(scalar_sum_kernel, dim3(1), dim3(64), 0, stream, part, (float*)out, nchunk * n, 1.0 / ((double)h * w * n), accumulate);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }

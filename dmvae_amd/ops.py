@@ -1245,6 +1245,20 @@ def lpips_diff(f0: torch.Tensor, f1: torch.Tensor, lin_w: torch.Tensor, out: tor
     return df1
 
 
+def lpips_diff_pool(h: torch.Tensor, b: int, lin_w: torch.Tensor, out: torch.Tensor, gscale: float, need_grad: bool, accumulate: bool):
+    """lpips_diff(h[:b], h[b:]) and maxpool2x2(h) from one read of the 2b-image feature tensor h [2b, H, W, C] (H, W even) -> (d/d h[b:] or None, pooled)."""
+    h = _req(h, bf16, "h")
+    n2, hh, ww, c = h.shape
+    assert n2 == 2 * b and hh % 2 == 0 and ww % 2 == 0, h.shape
+    ws = _loss_ws(h.device)
+    f0, f1 = h[:b], h[b:]
+    df1 = torch.empty_like(f1) if need_grad else None
+    pooled = torch.empty(n2, hh // 2, ww // 2, c, dtype=bf16, device=h.device)
+    check(_lib.lib().dmvae_lpips_diff_pool(f0.data_ptr(), f1.data_ptr(), _req(lin_w, f32, "lin_w").data_ptr(), _ptr(df1), out.data_ptr(), pooled[:b].data_ptr(),
+                                           pooled[b:].data_ptr(), ws.data_ptr(), ws.numel(), b, hh, ww, c, float(gscale), int(accumulate), _stream()), "lpips_diff_pool")
+    return df1, pooled
+
+
 def dmd_pre(x1: torch.Tensor, x0: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
     x1 = _req(x1, f32, "x1")
     x0 = _req(x0, f32, "x0")

@@ -17,6 +17,8 @@ from .. import ops, parity
 
 FIRST_LAYER_FUSED = True      # _VggLpips.forward: csrc/conv_in3.hip for ScalingLayer + cat + conv1_1 + ReLU (tests compare it with the padded 32-channel route)
 
+DIFF_POOL_FUSED = True        # a tapped level's feature diff and the max pool behind it in one pass (tests compare it with the two launches)
+
 _CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512)
 _SLICE_BOUNDS = (4, 9, 16, 23, 30)
 
@@ -141,9 +143,11 @@ class _VggLpips(torch.autograd.Function):
         out = torch.zeros(1, dtype=torch.float32, device=inp.device)
         tape, ci, level = [], 0, 0                                    # tape: ("conv", conv, y_tgt_half, df1 | None) / ("pool",)
         taps = {1, 3, 6, 9, 12}                                        # conv indices whose ReLU output is an LPIPS feature
-        for v in _CFG:
+        pooled = None
+        for pos, v in enumerate(_CFG):
             if v == "M":
-                h = ops.maxpool2x2(h)
+                h = pooled if pooled is not None else ops.maxpool2x2(h)      # the tapped level in front of it pooled on the way (ops.lpips_diff_pool)
+                pooled = None
                 tape.append(("pool",))
                 continue
             conv = convs[ci]
@@ -155,7 +159,10 @@ class _VggLpips(torch.autograd.Function):
             df1 = None
             if ci in taps:
                 n, hh, ww, _ = h.shape
-                df1 = ops.lpips_diff(h[:b], h[b:], lin_ws[level], out, 1.0 / (hh * ww * b), need, accumulate=level > 0)
+                if DIFF_POOL_FUSED and not parity.on() and pos + 1 < len(_CFG) and _CFG[pos + 1] == "M" and hh % 2 == 0 and ww % 2 == 0 and h.dtype == torch.bfloat16:
+                    df1, pooled = ops.lpips_diff_pool(h, b, lin_ws[level], out, 1.0 / (hh * ww * b), need, accumulate=level > 0)
+                else:
+                    df1 = ops.lpips_diff(h[:b], h[b:], lin_ws[level], out, 1.0 / (hh * ww * b), need, accumulate=level > 0)
                 level += 1
             tape.append(("conv", conv, h[b:] if need else None, df1))
             ci += 1

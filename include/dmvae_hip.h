@@ -31,7 +31,7 @@ const char* dmvae_last_error(void);
 /* ABI version; bumped when a signature or a struct changes.  2: dmvae_conv_desc gained its last field, w_layout (zero = the behaviour of version 1).
  * 3: struct dmvae_pack_entry and the entry points that take it (dmvae_pack_weights_batched), dmvae_linear_bf16 / _plan / dmvae_linear_weight_t_kmajor.
  * 4: dmvae_norm_conv_out_bwd / _supported / _workspace, dmvae_norm_conv_out_fwd / _supported, dmvae_conv_in3 / _supported / _workspace, dmvae_im2col_nhwc_taps, dmvae_linear_bf16_batched / _supported, dmvae_conv_to_image / _supported.
- * 5: dmvae_groupnorm_apply_short / _bwd_short / _short_supported / _bwd_short_workspace. */
+ * 5: dmvae_groupnorm_apply_short / _bwd_short / _short_supported / _bwd_short_workspace, dmvae_lpips_diff_pool. */
 int dmvae_abi_version(void);
 
 /* ---- convolution / GEMM (MFMA-bound) -------------------------------------------------------- */
@@ -476,6 +476,11 @@ int dmvae_l1_mse(const void* recon, const void* images, void* grad, void* out2, 
 int dmvae_lpips_diff(const void* f0, const void* f1, const void* lin_w, void* df1, void* out, void* workspace,
                      size_t workspace_bytes, int n, int hw, int c, float gscale, int accumulate,
                      dmvae_stream_t stream);
+/* dmvae_lpips_diff plus the 2x2 max pool that follows the tapped level in the VGG16 trunk (utils/lpips.py:126-135), of BOTH branches, from the one read of the
+ * features: pool0 / pool1 = the pooled f0 / f1, bf16 [n][h/2][w/2][c] each (the two halves of the trunk's 2n-image tensor); h, w even.  Same df1 and pooled
+ * values as the two separate calls; the level value differs by the order of its f32 partial sums only. */
+int dmvae_lpips_diff_pool(const void* f0, const void* f1, const void* lin_w, void* df1, void* out, void* pool0, void* pool1, void* workspace,
+                          size_t workspace_bytes, int n, int h, int w, int c, float gscale, int accumulate, dmvae_stream_t stream);
 
 /* DMD score-gradient loss (train_dmd.py:204-230; toy_example_2d/dmd.py:349-360), f32 [batch][per_sample]:
  * pre : xt = t*x1 + (1-t)*x0                                       (ICPlan, path.py:114-136)

@@ -65,3 +65,46 @@ def test_maxpool_and_relu_gate_bit_exact():
     assert torch.equal(dx.float(), ref)
     dy = torch.randn(2, 8, 12, 16, generator=g).cuda().to(torch.bfloat16)
     assert torch.equal(ops.relu_bwd(dy, x).float(), dy.float() * (x.float() > 0))
+
+
+@pytest.mark.parametrize("b,hh,ww,c", [(2, 16, 16, 64), (1, 8, 24, 128), (3, 4, 6, 256), (2, 2, 2, 512), (1, 6, 10, 72)])
+def test_diff_and_pool_in_one_pass_equals_the_two_launches(b, hh, ww, c):
+    """ops.lpips_diff_pool (losses.hip::lpips_diff_pool_kernel): the feature gradient and the pooled features bit for bit, the level value up to the order of its
+    f32 partial sums; with and without the gradient; accumulating; reruns identical."""
+    from dmvae_amd import ops
+    g = torch.Generator().manual_seed(7 * b + hh + c)
+    h = torch.relu(torch.randn(2 * b, hh, ww, c, generator=g)).cuda().to(torch.bfloat16)
+    lin = torch.rand(c, generator=g).cuda()
+    for need in (True, False):
+        out0 = torch.full((1,), 0.25, device="cuda")
+        out1 = out0.clone()
+        df0 = ops.lpips_diff(h[:b], h[b:], lin, out0, 1.0 / (hh * ww * b), need, accumulate=True)
+        pool0 = ops.maxpool2x2(h)
+        df1, pool1 = ops.lpips_diff_pool(h, b, lin, out1, 1.0 / (hh * ww * b), need, accumulate=True)
+        assert torch.equal(pool1, pool0)
+        assert (df1 is None) == (not need) and (df0 is None or torch.equal(df1, df0))
+        assert abs(out1.item() - out0.item()) <= 2e-6 * abs(out0.item())
+        out2 = torch.full((1,), 0.25, device="cuda")
+        df2, pool2 = ops.lpips_diff_pool(h, b, lin, out2, 1.0 / (hh * ww * b), need, accumulate=True)
+        assert torch.equal(out2, out1) and torch.equal(pool2, pool1) and (df1 is None or torch.equal(df2, df1))
+    same = torch.cat([h[:b], h[:b]])
+    out = torch.zeros(1, device="cuda")
+    ops.lpips_diff_pool(same, b, lin, out, 1.0 / (hh * ww * b), False, accumulate=False)
+    assert out.item() == 0.0                                   # LPIPS(x, x) is exactly zero
+
+
+def test_lpips_module_with_the_fused_pool_on_and_off(monkeypatch):
+    from dmvae_amd.utils import lpips as L
+    lp = _lpips().cuda()
+    g = torch.Generator().manual_seed(3)
+    img = (torch.rand(2, 3, 64, 96, generator=g) * 2 - 1).cuda()
+    rec0 = (img + 0.3 * torch.randn(2, 3, 64, 96, generator=g).cuda()).clamp(-1, 1)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(L, "DIFF_POOL_FUSED", on)
+        rec = rec0.clone().requires_grad_(True)
+        v = lp(img, rec)
+        v.backward()
+        res[on] = (v.detach(), rec.grad.clone())
+    assert abs(res[True][0].item() - res[False][0].item()) <= 1e-5 * abs(res[False][0].item())
+    assert torch.equal(res[True][1], res[False][1])            # the pooled features and the feature gradients are the same bits: so is everything downstream
