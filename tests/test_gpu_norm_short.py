@@ -182,3 +182,30 @@ def test_resnet_block_with_the_switch_on_and_off(monkeypatch, C, CS):
     _close_up_to_rounding(dx1, dx0)
     for k in g0:
         assert rel_err(g1[k], g0[k]) < 2e-3, k
+
+
+@pytest.mark.parametrize("C,CS,n,h,w", [(256, 128, 32, 256, 256), (512, 256, 32, 128, 128)])
+def test_training_shapes_equal_the_stored_routes(C, CS, n, h, w):
+    """the two shapes of configuration C2 at B = 32 (up[0].block[0], up[1].block[0]): 24 chunks per image, byte offsets past 2^31"""
+    from dmvae_amd import ops
+    from dmvae_amd.functional import packed
+    g = torch.Generator(device=DEV).manual_seed(C)
+    x = (torch.randn(n, h, w, C, generator=g, device=DEV) * 1.5 + 0.3).to(BF)
+    da = torch.randn(n, h, w, C, generator=g, device=DEV).to(BF)
+    dy = torch.randn(n, h, w, CS, generator=g, device=DEV).to(BF)
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g, device=DEV)
+    beta = 0.1 * torch.randn(C, generator=g, device=DEV)
+    sw = torch.randn(CS, C, 1, 1, generator=g, device=DEV) * 0.06
+    sb = 0.1 * torch.randn(CS, generator=g, device=DEV)
+    st = ops.groupnorm_stats(x, 32, 1e-6)
+    a, xs = ops.groupnorm_apply_short(x, st, gamma, beta, packed(sw), sb)
+    assert torch.equal(a, ops.groupnorm_apply(x, st, gamma, beta, True))
+    xs0 = ops.conv2d_nhwc(x, packed(sw), sb, ks=1)
+    _close_up_to_rounding(xs, xs0)
+    del a, xs0
+    dx, dg, db = ops.groupnorm_bwd_short(da, x, dy, packed(sw, True), st, gamma, beta, True, want_colsum=True)
+    dxs = ops.conv2d_nhwc(dy, packed(sw, True), ks=1)
+    dx0, dg0, db0 = ops.groupnorm_bwd(da, x, st, gamma, beta, True, dres=dxs, want_colsum=True)
+    _close_up_to_rounding(dx, dx0)
+    assert torch.equal(dg, dg0) and torch.equal(db, db0)
+    assert rel_err(dx._dmvae_colsum[0], dx0._dmvae_colsum[0]) < 2e-3
