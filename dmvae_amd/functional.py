@@ -778,7 +778,9 @@ class LinearFn(torch.autograd.Function):
         xb, w = ctx.saved_tensors
         n, k = w.shape[0], xb.shape[-1]
         rows = xb.numel() // k
-        dx, dw, db = _lin_grads(_c(dy).to(bf16).view(rows, n), xb.view(rows, k), w.view(n, k), ctx.bias, need_dx=ctx.needs_input_grad[0])
+        # the PARAMETER itself where it is 2-D: a view would shed what is tagged on it -- the optimiser's bf16 shadow (a view's transposed operand is cast and
+        # transposed again on every call: 28 casts of a 6912 x 1152 weight per DiT step), the flat-buffer gradient destination, the cached operands
+        dx, dw, db = _lin_grads(_c(dy).to(bf16).view(rows, n), xb.view(rows, k), w if w.dim() == 2 else w.view(n, k), ctx.bias, need_dx=ctx.needs_input_grad[0])
         if ctx.bias is None:
             db = None
         return (None if dx is None else dx.view(xb.shape).to(ctx.x_dtype)), dw.view(w.shape), db
@@ -857,7 +859,8 @@ class VitBlockFn(torch.autograd.Function):
         h1 = linear(hn2, f1w, f1b)
         g = ops.gelu(h1)
         o3 = linear(g, f2w, f2b)
-        t_out = ops.scale_residual_(t_mid.clone(), o3, ls2)
+        # graph-free call (the DMD stage's student-only steps run the trainable encoder's forward under no_grad): t_mid is nobody's saved tensor, update it in place
+        t_out = ops.scale_residual_(t_mid if not any(ctx.needs_input_grad) else t_mid.clone(), o3, ls2)
         ctx.save_for_backward(t, hn1, qkv, o, o2, t_mid, hn2, h1, g, o3, n1w, qkvw, pw, ls1, n2w, f1w, f2w, ls2)
         ctx.others = (n1b, qkvb, pb, n2b, f1b, f2b, heads, eps)
         return t_out

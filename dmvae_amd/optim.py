@@ -62,11 +62,26 @@ class FlatParams:
                 p._dmvae_grad_view = self.grad[off:off + p.numel()].view(p.shape)
         self.direct = True
         self.partial = ids is not None        # the other parameters keep accumulating into their (zeroed) flat views through autograd
+        # what begin_step has to zero in that case: the slices of the parameters WITHOUT a direct view, as maximal contiguous runs (the student DiT: the embedders
+        # in front of the blocks and the output layer behind them -- zeroing all 2.7 GB of its gradient buffer was 0.43 ms per step)
+        runs = []
+        for p, off in zip(self.params, self.offsets):
+            if not hasattr(p, "_dmvae_grad_view"):
+                end = off + (p.numel() + 3) // 4 * 4
+                if runs and runs[-1][1] == off:
+                    runs[-1][1] = end
+                else:
+                    runs.append([off, end])
+        self.accum_runs = [(a, min(b, self.numel)) for a, b in runs]
 
     def begin_step(self) -> None:
         if getattr(self, "direct", False):
             if getattr(self, "partial", False):
-                self.grad.zero_()
+                if len(self.accum_runs) <= 16:
+                    for a, b in self.accum_runs:
+                        self.grad[a:b].zero_()
+                else:
+                    self.grad.zero_()
             for p, off in zip(self.params, self.offsets):
                 if hasattr(p, "_dmvae_grad_view"):
                     p.grad = None      # autograd adopts the returned flat-buffer view (no accumulation kernel)

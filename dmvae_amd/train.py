@@ -367,7 +367,9 @@ class DMDTrainer(_AdversarialBranch):
         if sp:
             self.sfp = FlatParams(sp, with_ema=False)
             self.sfp.enable_bf16_shadow()
-            direct = [p for n_, p in student.named_parameters() if p.requires_grad and n_.startswith("blocks.") and "adaLN_modulation" not in n_]
+            # every block parameter, the adaLN modulation Linears included (functional.LinearFn on csrc/linear_rows.hip writes their gradients in place too: a
+            # third of the model's parameters, 28 x 32 MB of accumulate launches per step before); one gradient per parameter and backward: the student's own turn
+            direct = [p for n_, p in student.named_parameters() if p.requires_grad and n_.startswith("blocks.")]
             from .models.lightningdit import LightningDiT
             if isinstance(student, LightningDiT) and direct:
                 self.sfp.enable_direct_grads(only=direct)
@@ -566,7 +568,7 @@ class DiffusionTrainer:
         params = [p for p in model.parameters() if p.requires_grad]
         self.fp = FlatParams(params, with_ema=True)
         self.fp.enable_bf16_shadow()
-        direct = [p for n_, p in model.named_parameters() if p.requires_grad and n_.startswith("blocks.") and "adaLN_modulation" not in n_]
+        direct = [p for n_, p in model.named_parameters() if p.requires_grad and n_.startswith("blocks.")]      # adaLN modulations included: see DMDTrainer
         if isinstance(model, LightningDiT) and direct:
             self.fp.enable_direct_grads(only=direct)
         self.opt = FlatAdamWEMA(self.fp, lr=lr, betas=(0.9, 0.95), weight_decay=0.0, warmup_steps=0, max_norm=max_norm, ema_decay=ema_decay)

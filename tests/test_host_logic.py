@@ -84,6 +84,30 @@ def test_flat_params_and_backward_order():
     assert all(o % 4 == 0 for o in fp.offsets)
 
 
+def test_partial_direct_gradients_zero_only_what_accumulates():
+    """FlatParams.enable_direct_grads(only=...): begin_step() clears the slices of the parameters that still accumulate through autograd -- as contiguous runs, not
+    the whole buffer -- and hands the direct ones to autograd as None (their kernels overwrite the flat views)."""
+    from dmvae_amd.optim import FlatParams
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 16, 7, 8, 3)]          # offsets 0, 8, 24, 32, 40 (16-B alignment)
+    fp = FlatParams(ps, with_ema=False)
+    fp.enable_direct_grads(only=[ps[1], ps[2]])
+    assert fp.partial and fp.accum_runs == [(0, 8), (32, 44)]
+    fp.grad.fill_(3.0)
+    fp.begin_step()
+    assert fp.grad[:8].eq(0).all() and fp.grad[32:].eq(0).all() and fp.grad[8:32].eq(3).all()        # the direct slices are left to their kernels
+    assert ps[1].grad is None and ps[2].grad is None
+    for i in (0, 3, 4):
+        assert ps[i].grad.data_ptr() == fp.grad.data_ptr() + fp.offsets[i] * 4
+    (ps[0].sum() * 2 + ps[3].sum()).backward()
+    assert fp.grad[:5].eq(2).all() and fp.grad[32:40].eq(1).all()
+    fp2 = FlatParams([torch.nn.Parameter(torch.randn(4)) for _ in range(40)], with_ema=False)
+    fp2.enable_direct_grads(only=fp2.params[1::2])                                  # many runs: one fill of the whole buffer instead
+    assert len(fp2.accum_runs) == 20
+    fp2.grad.fill_(1.0)
+    fp2.begin_step()
+    assert fp2.grad.eq(0).all()
+
+
 def test_lambda_lr_warmup_matches_reference_schedule():
     from dmvae_amd.optim import FlatAdamWEMA, FlatParams
     p = torch.nn.Parameter(torch.zeros(8))
