@@ -247,12 +247,17 @@ def kl_mmd_roofline(dev):
     def timed_graph(fn, reps):
         """The same `reps` calls recorded once into a HIP graph and replayed: what the op costs on its stream when the host is not the limit (issuing the
         two launches from Python takes longer than they run; inside the training step the host runs ahead of the stream anyway)."""
+        # Not next to a live process group: stream capture in its default (global) mode makes EVERY thread's event queries illegal while it lasts, and RCCL's
+        # watchdog thread polls its work events all the time -- "HIP error: operation not permitted when stream is capturing" in the watchdog, process abort
+        # (seen once per few dozen runs of the one-rank RCCL test; with N ranks each of them rolls that die).  There the eager figure is reported.
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            return None
         try:
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other threads (the env sampler, a profiler) keep their API calls
                 for _ in range(reps):
                     fn()
             g.replay()

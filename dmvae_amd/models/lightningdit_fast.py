@@ -137,7 +137,9 @@ class GraphedInference:
                 forward_inference(model, self.x, self.t, self.y)
         cur.wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        # thread-local capture mode: in the default (global) mode every OTHER thread's event query is illegal while the capture lasts -- RCCL's watchdog thread
+        # polls its work events all the time (sample_50k.py runs under torchrun) and aborts the process with "operation not permitted when stream is capturing"
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
             self.out = forward_inference(model, self.x, self.t, self.y)
 
     def matches(self, x, t, y) -> bool:
