@@ -445,6 +445,9 @@ class ImageToNhwcFn(torch.autograd.Function):
         return ops.nhwc_to_nchw_f32(_c(dy), ctx.c), None
 
 
+K4_WGRAD_AS_GEMM = (1,)      # strides of the 4x4 convs whose weight gradient runs on the im2col form (ConvK4Fn.backward); () = never (tests compare the routes)
+
+
 class ConvK4Fn(torch.autograd.Function):
     """nn.Conv2d(kernel 4, stride 1|2, padding 1) on NHWC bf16 (models/patchgan.py:125-147) as a strided 16-tap gather in the implicit-GEMM
     conv kernel -- no im2col tensor.  x: [N,H,W,Cp] with Cp >= w.shape[1] zero-padded channels (Cp % 32 == 0); act: ops.ACT_NONE |
@@ -482,12 +485,24 @@ class ConvK4Fn(torch.autograd.Function):
             dyp = torch.zeros(dy.shape[0], dy.shape[1], dy.shape[2], cpad, dtype=bf16, device=dy.device)
             dyp[..., :cout] = dy
             dy = dyp
-        dwp, dbp = ops.conv2d_nhwc_wgrad(dy, x, 4, stride=stride, need_bias=b is not None)       # [cpad, cp, 4, 4]
+        ho, wo = dy.shape[1], dy.shape[2]
+        m = n * ho * wo
+        if K4_WGRAD_AS_GEMM and not parity.on() and stride in K4_WGRAD_AS_GEMM and cpad == cout and cout % 128 == 0 and (16 * cp) % 128 == 0 and m % 32 == 0 and m >= 4096:
+            # The large weight-gradient kernel takes 4x4 convs with stride 2 and 128-channel groups only; the 256 -> 512 stride-1 layer of the PatchGAN
+            # (models/patchgan.py:125-147, 31 x 31 outputs: no 32-pixel K tiles either) ran on the small-shape kernel at ~130 TFLOP/s -- a millisecond per
+            # discriminator pass, four passes per step.  On the im2col form it is the 1x1 weight gradient of a [rows, 16 cp] operand: one gather pass
+            # (252 MB at B = 32) + the large kernel.
+            col = ops.im2col(x, 4, stride, 1)
+            g2, dbp = ops.conv2d_nhwc_wgrad(dy.view(1, 1, m, cout), col.view(1, 1, m, 16 * cp), 1, need_bias=b is not None)
+            dwv = g2.view(cout, 16, cp)[:, :, :cin].permute(0, 2, 1).reshape(cout, cin, 4, 4)
+        else:
+            dwp, dbp = ops.conv2d_nhwc_wgrad(dy, x, 4, stride=stride, need_bias=b is not None)       # [cpad, cp, 4, 4]
+            dwv = dwp[:cout, :cin]
         dw, db = _dst(w), None
         if dw is not None:
-            dw.copy_(dwp[:cout, :cin])
+            dw.copy_(dwv)
         else:
-            dw = dwp[:cout, :cin].contiguous()
+            dw = dwv.contiguous()
         if b is not None:
             db = _dst(b)
             if db is not None:

@@ -260,3 +260,35 @@ def test_gan_loss_terms_vs_reference_fixture():
             assert abs(prm.grad.double().norm().item() - gn) < 6e-2 * gn, n
     for k, v in g.sub("dg.").items():
         assert rl2(dict(disc.named_parameters())[k].grad.cpu(), v) < 0.12, k
+
+
+@pytest.mark.parametrize("n,hw,cin,cout", [(32, 14, 64, 128), (32, 32, 256, 512)])
+def test_k4_stride1_weight_gradient_on_the_im2col_form(n, hw, cin, cout, monkeypatch):
+    """functional.ConvK4Fn.backward: the 4x4 stride-1 conv's weight gradient as the 1x1 weight gradient of the im2col operand on the large kernel (the PatchGAN's
+    256 -> 512 layer, models/patchgan.py:125-147) against the gather route through the small-shape kernel, and (small case) against fp64 autograd."""
+    import torch.nn.functional as F
+    from dmvae_amd import functional as Fn, ops
+    g = torch.Generator().manual_seed(cin + hw)
+    x0 = torch.randn(n, hw, hw, cin, generator=g).cuda().to(torch.bfloat16)
+    w = (torch.randn(cout, cin, 4, 4, generator=g) * 0.05).cuda().requires_grad_(True)
+    b = torch.randn(cout, generator=g).cuda().requires_grad_(True)
+    dy = torch.randn(n, hw - 1, hw - 1, cout, generator=g).cuda().to(torch.bfloat16)
+    res = {}
+    for route in ((1,), ()):
+        monkeypatch.setattr(Fn, "K4_WGRAD_AS_GEMM", route)
+        w.grad = b.grad = None
+        x = x0.clone().requires_grad_(True)
+        y = Fn.ConvK4Fn.apply(x, w, b, 1, ops.ACT_LEAKY, False)
+        y.backward(dy)
+        res[route] = (y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+    for a, c in zip(res[(1,)][:2], res[()][:2]):
+        assert torch.equal(a, c)                                  # forward and input gradient do not depend on the route
+    assert rel_err(res[(1,)][2], res[()][2]) < 1e-5 and rel_err(res[(1,)][3], res[()][3]) < 1e-5
+    if n * (hw - 1) ** 2 * cout * cin < 10 ** 9:
+        xr = x0.float().cpu().double().permute(0, 3, 1, 2)
+        wr = w.detach().to(torch.bfloat16).float().cpu().double().requires_grad_(True)
+        br = b.detach().cpu().double().requires_grad_(True)
+        yr = F.conv2d(xr, wr, br, stride=1, padding=1)
+        gy = (dy.float() * torch.where(res[(1,)][0].float() > 0, 1.0, 0.2)).to(torch.bfloat16).float().cpu().double().permute(0, 3, 1, 2)      # the gate's bf16 result
+        yr.backward(gy)
+        assert rel_err(res[(1,)][2].cpu(), wr.grad) < 1e-4 and rel_err(res[(1,)][3].cpu(), br.grad) < 1e-4
