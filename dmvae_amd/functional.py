@@ -487,7 +487,12 @@ class ConvK4Fn(torch.autograd.Function):
             dy = dyp
         ho, wo = dy.shape[1], dy.shape[2]
         m = n * ho * wo
-        if K4_WGRAD_AS_GEMM and not parity.on() and stride in K4_WGRAD_AS_GEMM and cpad == cout and cout % 128 == 0 and (16 * cp) % 128 == 0 and m % 32 == 0 and m >= 4096:
+        # The generator's adversarial term runs through a FROZEN discriminator (losses.generator_gan_term: requires_grad False on its parameters), twice per step
+        # (the adaptive weight's autograd.grad and the final backward): no weight / bias gradient is wanted there -- computing them anyway was 2 x 1.1 ms per step
+        want_w = ctx.needs_input_grad[1] or (b is not None and ctx.needs_input_grad[2])
+        if not want_w:
+            dwv = dbp = None
+        elif K4_WGRAD_AS_GEMM and not parity.on() and stride in K4_WGRAD_AS_GEMM and cpad == cout and cout % 128 == 0 and (16 * cp) % 128 == 0 and m % 32 == 0 and m >= 4096:
             # The large weight-gradient kernel takes 4x4 convs with stride 2 and 128-channel groups only; the 256 -> 512 stride-1 layer of the PatchGAN
             # (models/patchgan.py:125-147, 31 x 31 outputs: no 32-pixel K tiles either) ran on the small-shape kernel at ~130 TFLOP/s -- a millisecond per
             # discriminator pass, four passes per step.  On the im2col form it is the 1x1 weight gradient of a [rows, 16 cp] operand: one gather pass
@@ -498,12 +503,14 @@ class ConvK4Fn(torch.autograd.Function):
         else:
             dwp, dbp = ops.conv2d_nhwc_wgrad(dy, x, 4, stride=stride, need_bias=b is not None)       # [cpad, cp, 4, 4]
             dwv = dwp[:cout, :cin]
-        dw, db = _dst(w), None
-        if dw is not None:
+        dw, db = (_dst(w) if want_w else None), None
+        if not want_w:
+            pass
+        elif dw is not None:
             dw.copy_(dwv)
         else:
             dw = dwv.contiguous()
-        if b is not None:
+        if b is not None and want_w:
             db = _dst(b)
             if db is not None:
                 db.copy_(dbp[:cout])

@@ -292,3 +292,26 @@ def test_k4_stride1_weight_gradient_on_the_im2col_form(n, hw, cin, cout, monkeyp
         gy = (dy.float() * torch.where(res[(1,)][0].float() > 0, 1.0, 0.2)).to(torch.bfloat16).float().cpu().double().permute(0, 3, 1, 2)      # the gate's bf16 result
         yr.backward(gy)
         assert rel_err(res[(1,)][2].cpu(), wr.grad) < 1e-4 and rel_err(res[(1,)][3].cpu(), br.grad) < 1e-4
+
+
+def test_k4_conv_computes_no_weight_gradient_for_a_frozen_discriminator(monkeypatch):
+    """losses.generator_gan_term runs the generator's adversarial term through a frozen discriminator (train_tokenizer.py:190-203), twice per step: ConvK4Fn.backward
+    must then launch no weight-gradient kernel (it did: 2 x 1.1 ms per step) and return the same input gradient."""
+    from dmvae_amd import functional as Fn, ops
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(4, 16, 16, 64, generator=g).cuda().to(torch.bfloat16)
+    w = (torch.randn(128, 64, 4, 4, generator=g) * 0.05).cuda()
+    b = torch.randn(128, generator=g).cuda()
+    dy = torch.randn(4, 8, 8, 128, generator=g).cuda().to(torch.bfloat16)
+    xa = x0.clone().requires_grad_(True)
+    wa, ba = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    Fn.ConvK4Fn.apply(xa, wa, ba, 2, ops.ACT_LEAKY, False).backward(dy)
+    assert wa.grad is not None and ba.grad is not None
+
+    def boom(*a, **k):
+        raise AssertionError("weight gradient computed for frozen parameters")
+    monkeypatch.setattr(ops, "conv2d_nhwc_wgrad", boom)
+    monkeypatch.setattr(ops, "im2col", boom)
+    xb = x0.clone().requires_grad_(True)
+    Fn.ConvK4Fn.apply(xb, w, b, 2, ops.ACT_LEAKY, False).backward(dy)
+    assert torch.equal(xb.grad, xa.grad)
