@@ -112,6 +112,41 @@ def generator_gan_term(rec_loss: torch.Tensor, recon: torch.Tensor, disc: torch.
     return rec_loss + g_loss * d_weight, d_weight
 
 
+GAN_SINGLE_PASS = True      # TokenizerTrainer.step: generator_gan_backward instead of generator_gan_term + loss.backward() (tests compare the two)
+
+
+def generator_gan_backward(rec_loss: torch.Tensor, recon: torch.Tensor, disc: torch.nn.Module, daug, last_layer: torch.Tensor, disc_weight: float = 0.5,
+                           extra: Optional[torch.Tensor] = None):
+    """The generator's step of the adversarial phase, BACKWARD INCLUDED, with one pass through each loss network: what `generator_gan_term` followed by
+    `loss.backward()` computes (train_tokenizer.py:190-203 + :414) -- gradients of rec_loss + d_weight * g with d_weight = disc_weight * clamp(|d rec / d last| /
+    (|d g / d last| + 1e-6), 0, 1e4) held constant -- evaluated as
+
+        g_rec = d rec_loss / d recon          (ONE backward through LPIPS / L1 / MSE)
+        g_gan = d g / d recon                 (ONE backward through the frozen discriminator and DiffAug)
+        |d . / d last| from recon's own backward node, fed g_rec and g_gan in turn        (the decoder's last layer: two launches of its weight gradient)
+        backward of the decoder from  g_rec + d_weight * g_gan  (+ `extra`, a scalar term that does not run through recon: KL / MMD)
+
+    instead of the reference's three backward sweeps over the loss networks (autograd.grad twice, then backward): the gradients are linear in the image
+    gradient, so the sums are the same -- up to where d_weight multiplies (the image gradient here, the scalar loss there: the discriminator's bf16 backward
+    rounds a scaled copy of the same numbers).  `extra` joins the final backward.  Returns (rec_loss + d_weight * g, d_weight), both detached."""
+    disc.eval()
+    for p in disc.parameters():
+        p.requires_grad_(False)
+    g_loss = -disc(daug.aug(recon, 0)).float().mean()
+    g_rec = torch.autograd.grad(rec_loss, recon, retain_graph=True)[0]
+    g_gan = torch.autograd.grad(g_loss, recon)[0]
+    # with direct flat-buffer gradients each call leaves its result in `last_layer`'s gradient slot: reduced to its norm before the next call overwrites it
+    n_rec = torch.autograd.grad(recon, last_layer, grad_outputs=g_rec, retain_graph=True)[0].detach().norm()
+    n_gan = torch.autograd.grad(recon, last_layer, grad_outputs=g_gan, retain_graph=True)[0].detach().norm()
+    d_weight = (n_rec / (n_gan + 1e-6)).clamp_(0.0, 1e4) * disc_weight
+    total = g_rec + g_gan * d_weight
+    if extra is not None:
+        torch.autograd.backward([recon, extra], [total, torch.ones_like(extra)])
+    else:
+        recon.backward(total)
+    return rec_loss.detach() + g_loss.detach() * d_weight, d_weight
+
+
 def discriminator_loss(images: torch.Tensor, recon: torch.Tensor, disc: torch.nn.Module, daug, bcr_strong_aug, bcr_weight: float = 1.0):
     """VAELossFunction.forward_discriminator (train_tokenizer.py:207-227): hinge loss on D(aug([images; recon])) plus
     bcr_weight * mse(D(strong_aug(.)), D(aug(.))), the discriminator in train mode for both passes.  Returns (loss, log) with the log

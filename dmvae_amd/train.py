@@ -209,15 +209,19 @@ class TokenizerTrainer(_AdversarialBranch):
             if self.lpips is not None and w["lpips"] != 0:
                 lp = self._lpips(images, recon)
                 loss = loss + lp * w["lpips"]
-            kl = None
+            kl = dm = None
             if w["kl"] != 0 or w["mmd"] != 0:
                 dm, kl, mmd = losses.kl_mmd_loss(latent, w_kl=w["kl"], w_mmd=w["mmd"])
                 loss = loss + dm
             rec_loss = loss
             gan = self._gan_active()
-            if gan:
+            single = gan and losses.GAN_SINGLE_PASS and not parity.on()
+            if single:      # forward of the adversarial term AND the whole backward, one sweep through LPIPS and through the discriminator (losses.generator_gan_backward)
+                loss, d_weight = losses.generator_gan_backward(rec_loss, recon, self.disc, self.daug, self.vae.decoder.get_last_layer(), self.disc_weight, extra=dm)
+            elif gan:
                 loss, d_weight = self._generator_gan_term(rec_loss, recon)
-        loss.backward()
+        if not single:
+            loss.backward()
         self.sync.wait()
         norm = self.opt.step()
         with torch.no_grad():

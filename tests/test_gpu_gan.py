@@ -315,3 +315,50 @@ def test_k4_conv_computes_no_weight_gradient_for_a_frozen_discriminator(monkeypa
     xb = x0.clone().requires_grad_(True)
     Fn.ConvK4Fn.apply(xb, w, b, 2, ops.ACT_LEAKY, False).backward(dy)
     assert torch.equal(xb.grad, xa.grad)
+
+
+def test_single_pass_generator_backward_equals_the_three_sweeps():
+    """losses.generator_gan_backward (one backward through LPIPS and one through the frozen discriminator, the adaptive weight from the last layer's own backward
+    node) against losses.generator_gan_term + backward (the reference's autograd.grad twice + backward, train_tokenizer.py:190-203,414) on the captured inputs and
+    DiffAug draws: same loss value and adaptive weight, the same gradients up to the bf16 rounding of a scaled gradient inside the discriminator's backward."""
+    from dmvae_amd import losses
+    from dmvae_amd.utils.diffaug import DiffAug
+    from dmvae_amd.utils.lpips import LPIPS
+    from test_oracle_golden import lpips_params
+    g = load_golden("gan_losses")
+    lp = LPIPS().eval().requires_grad_(False)
+    sd = lp.state_dict()
+    for k, v in lpips_params(g).items():
+        sd[k] = v.reshape(sd[k].shape)
+    lp.load_state_dict(sd)
+    lp = lp.to(DEV)
+    disc = _disc(patchgan_params(g, int(g["disc_seed"])))
+    img = g.t("images").to(DEV)
+    B = img.shape[0]
+    res = {}
+    for single in (False, True):
+        feat = g.t("feat").to(DEV).requires_grad_(True)
+        last = g.t("last").to(DEV).requires_grad_(True)
+        side = torch.zeros(3, device=DEV, requires_grad=True)             # a term that does not run through recon (the KL / MMD stand-in)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            recon = (F.conv2d(feat, last, padding=1) + 0.9 * img).float()
+            l1, l2 = losses.l1_mse(recon, img, 1.0, 0.0)
+            extra = (side * torch.tensor([1.0, -2.0, 0.5], device=DEV)).sum()
+            rec_loss = l1 + lp(img, recon) + extra
+            with _RandQueue([torch.zeros(3), g.t("gen_rand01").view(7, B, 1, 1)]):
+                if single:
+                    total, d_weight = losses.generator_gan_backward(rec_loss, recon, disc, DiffAug(prob=1.0, cutout=0.2), last, 0.5, extra=extra)
+                else:
+                    total, d_weight = losses.generator_gan_term(rec_loss, recon, disc, DiffAug(prob=1.0, cutout=0.2), last, 0.5)
+        if not single:
+            total.backward()
+        res[single] = (total.detach().item(), d_weight.item(), last.grad.clone(), feat.grad.clone(), side.grad.clone())
+    (t0, w0, gl0, gf0, gs0), (t1, w1, gl1, gf1, gs1) = res[False], res[True]
+    rl2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
+    assert abs(t1 - t0) <= 1e-5 * abs(t0) and abs(w1 - w0) <= 1e-4 * abs(w0), (t0, t1, w0, w1)        # same forward, same two norms
+    # the discriminator's backward rounds its gradients to bf16 at five layers; the two evaluations feed it the same gradient at two scales (1 and d_weight), so its
+    # roundings differ: 3e-3 / 7e-3 measured -- a tenth of what either is from the reference's fp32 gradient (the 8e-2 bar of the fixture test above, held here too)
+    assert rl2(gl1, gl0) < 2e-2 and rl2(gf1, gf0) < 2e-2, (rl2(gl1, gl0), rl2(gf1, gf0))
+    assert rl2(gl1.cpu(), g.t("g_last")) < 8e-2 and rl2(gl1.cpu(), g.t("g_last")) < 1.1 * rl2(gl0.cpu(), g.t("g_last")) + 1e-3
+    assert torch.equal(gs1, gs0)                                          # the term outside recon takes part in the final backward
+    assert abs(w1 - float(g["d_weight"])) < 8e-2 * float(g["d_weight"])  # and it is the reference's adaptive weight
