@@ -445,6 +445,7 @@ class ImageToNhwcFn(torch.autograd.Function):
         return ops.nhwc_to_nchw_f32(_c(dy), ctx.c), None
 
 
+K4_WGRAD_THIN_CIN = True      # the <= 8-input-channel 4x4 conv's weight gradient on the im2col form of an 8-channel copy (ConvK4Fn.backward)
 K4_WGRAD_AS_GEMM = (1,)      # strides of the 4x4 convs whose weight gradient runs on the im2col form (ConvK4Fn.backward); () = never (tests compare the routes)
 
 
@@ -500,6 +501,14 @@ class ConvK4Fn(torch.autograd.Function):
             col = ops.im2col(x, 4, stride, 1)
             g2, dbp = ops.conv2d_nhwc_wgrad(dy.view(1, 1, m, cout), col.view(1, 1, m, 16 * cp), 1, need_bias=b is not None)
             dwv = g2.view(cout, 16, cp)[:, :, :cin].permute(0, 2, 1).reshape(cout, cin, 4, 4)
+        elif K4_WGRAD_THIN_CIN and not parity.on() and cin <= 8 and cp >= 8 and cpad <= 128 and dy.dtype == bf16 and m % 32 == 0 and m >= 16384:
+            # The PatchGAN's first layer (3 -> 64, stride 2, models/patchgan.py:125): its input travels zero-padded to 32 channels and the small-shape kernel spent
+            # 0.95 ms per discriminator pass (B = 64) on a weight gradient with 3 real input channels.  On the im2col form of an EIGHT-channel copy -- 16 taps x 8 =
+            # one 128-channel group -- against the output gradient zero-padded to one group it is the large kernel's 1x1 case, bound by reading ~0.5 GB.
+            col = ops.im2col(x[..., :8].contiguous(), 4, stride, 1)
+            dy128 = dy if cpad == 128 else torch.nn.functional.pad(dy, (0, 128 - cpad))
+            g2, dbp = ops.conv2d_nhwc_wgrad(dy128.view(1, 1, m, 128), col.view(1, 1, m, 128), 1, need_bias=b is not None)
+            dwv = g2.view(128, 16, 8)[:cout, :, :cin].permute(0, 2, 1).reshape(cout, cin, 4, 4)
         else:
             dwp, dbp = ops.conv2d_nhwc_wgrad(dy, x, 4, stride=stride, need_bias=b is not None)       # [cpad, cp, 4, 4]
             dwv = dwp[:cout, :cin]

@@ -294,6 +294,34 @@ def test_k4_stride1_weight_gradient_on_the_im2col_form(n, hw, cin, cout, monkeyp
         assert rel_err(res[(1,)][2].cpu(), wr.grad) < 1e-4 and rel_err(res[(1,)][3].cpu(), br.grad) < 1e-4
 
 
+def test_k4_first_layer_weight_gradient_on_the_eight_channel_im2col_form(monkeypatch):
+    """ConvK4Fn.backward for the PatchGAN's first layer (3 real input channels in a 32-channel tensor, stride 2): the im2col route on an 8-channel copy through the
+    large kernel against the gather route through the small-shape kernel and against fp64 autograd."""
+    from dmvae_amd import functional as Fn, ops
+    g = torch.Generator().manual_seed(11)
+    n, hw, cin, cout = 16, 64, 3, 64
+    x0 = torch.zeros(n, hw, hw, 32)
+    x0[..., :cin] = torch.randn(n, hw, hw, cin, generator=g)
+    x0 = x0.cuda().to(torch.bfloat16)
+    w = (torch.randn(cout, cin, 4, 4, generator=g) * 0.1).cuda().requires_grad_(True)
+    b = torch.randn(cout, generator=g).cuda().requires_grad_(True)
+    dy = torch.randn(n, hw // 2, hw // 2, cout, generator=g).cuda().to(torch.bfloat16)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(Fn, "K4_WGRAD_THIN_CIN", on)
+        w.grad = b.grad = None
+        y = Fn.ConvK4Fn.apply(x0, w, b, 2, ops.ACT_NONE, False)
+        y.backward(dy)
+        res[on] = (y.detach().clone(), w.grad.clone(), b.grad.clone())
+    assert torch.equal(res[True][0], res[False][0])
+    assert rel_err(res[True][1], res[False][1]) < 1e-5 and rel_err(res[True][2], res[False][2]) < 1e-5
+    xr = x0[..., :cin].float().cpu().double().permute(0, 3, 1, 2)
+    wr = w.detach().to(torch.bfloat16).float().cpu().double().requires_grad_(True)
+    br = b.detach().cpu().double().requires_grad_(True)
+    F.conv2d(xr, wr, br, stride=2, padding=1).backward(dy.float().cpu().double().permute(0, 3, 1, 2))
+    assert rel_err(res[True][1].cpu(), wr.grad) < 1e-5 and rel_err(res[True][2].cpu(), br.grad) < 1e-5
+
+
 def test_k4_conv_computes_no_weight_gradient_for_a_frozen_discriminator(monkeypatch):
     """losses.generator_gan_term runs the generator's adversarial term through a frozen discriminator (train_tokenizer.py:190-203), twice per step: ConvK4Fn.backward
     must then launch no weight-gradient kernel (it did: 2 x 1.1 ms per step) and return the same input gradient."""
