@@ -127,11 +127,16 @@ def repack_all(reg: dict, epoch: list) -> None:
         w._dmvae_packed[key] = ((ptr, _ver(w), ep), p)
 
 
+DIRECT_GRAD_WRITES = None     # a dict while optim.FlatParams.check_direct_writes counts destination hand-outs (debug mode, DMVAE_CHECK_DIRECT_GRADS=1)
+
+
 def _dst(param):
     """Destination view for a parameter's gradient when its owner enabled direct flat-buffer gradients (optim.FlatParams)."""
     if param is None:
         return None
     v = getattr(param, "_dmvae_grad_view", None)
+    if v is not None and DIRECT_GRAD_WRITES is not None:      # debug: which direct-gradient parameters a backward wrote (optim.FlatParams.check_direct_writes)
+        DIRECT_GRAD_WRITES[id(param)] = DIRECT_GRAD_WRITES.get(id(param), 0) + 1
     # a FRESH view object per use: AccumulateGrad adopts a gradient without copying only if nobody else holds its TensorImpl
     return None if v is None else v.view(v.shape)
 
@@ -778,6 +783,9 @@ def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Te
                                        dw_out=None if dst_w is None else dst_w.view(cout, cin, 1, 1), db_out=_dst(b))
         dw = dw.view(cout, cin)
     else:
+        # widths that are not multiples of 8: no kernel of this build takes them -- a library GEMM only behind the explicit opt-in (no silent rocBLAS)
+        from ._stock import require_opt_in
+        require_opt_in("functional._lin_grads (weight gradient)", f"Linear {cout} x {cin}: in / out features must be multiples of 8 for the weight-gradient kernels")
         dw, db = (dy2.t() @ x2).float(), dy2.float().sum(0)
     if not need_dx:
         return None, dw, db
@@ -788,7 +796,11 @@ def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Te
         return ops.linear_rows(_c(dy2), wt if wt.dim() == 3 else wt.view(cin, cout)), dw, db
     if ops.linear_supported(rows, cin, cout) and not parity.on():
         return ops.linear_bf16(_c(dy2), _bf_t(w)), dw, db                 # dX = dY . W as an NT GEMM against the transposed copy
-    return ops.gemm_nt(_c(dy2), packed(w, True).view(cin, cout)) if (cout % 32 == 0 and cin % 4 == 0) else (dy2 @ _bf(w)), dw, db
+    if cout % 32 == 0 and cin % 4 == 0:
+        return ops.gemm_nt(_c(dy2), packed(w, True).view(cin, cout)), dw, db
+    from ._stock import require_opt_in
+    require_opt_in("functional._lin_grads (input gradient)", f"Linear {cout} x {cin}: the input-gradient GEMM kernels need out features % 32 == 0 and in features % 4 == 0")
+    return dy2 @ _bf(w), dw, db
 
 
 class LinearFn(torch.autograd.Function):
@@ -891,7 +903,7 @@ class VitBlockFn(torch.autograd.Function):
         g = ops.gelu(h1)
         o3 = linear(g, f2w, f2b)
         # graph-free call (the DMD stage's student-only steps run the trainable encoder's forward under no_grad): t_mid is nobody's saved tensor, update it in place
-        t_out = ops.scale_residual_(t_mid if not any(ctx.needs_input_grad) else t_mid.clone(), o3, ls2)
+        t_out = ops.scale_residual_(t_mid if (not torch.is_grad_enabled() or not any(ctx.needs_input_grad)) else t_mid.clone(), o3, ls2)
         ctx.save_for_backward(t, hn1, qkv, o, o2, t_mid, hn2, h1, g, o3, n1w, qkvw, pw, ls1, n2w, f1w, f2w, ls2)
         ctx.others = (n1b, qkvb, pb, n2b, f1b, f2b, heads, eps)
         return t_out

@@ -56,6 +56,10 @@ def frozen_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
         if hd == 64 and s <= 288:
             o = ops.attention_qkv(qkv, nh, hd ** -0.5)                             # fused: nothing of size s x s reaches HBM
         else:
+            # head dims / sequence lengths the fused kernel does not take (hip_path_supported keeps the reference's shapes off this branch): library batched
+            # GEMMs, only behind the explicit opt-in
+            from .._stock import require_opt_in
+            require_opt_in("vit_fast.forward_features (attention)", f"head dim {hd}, {s} tokens: the fused attention kernel takes head dim 64 and <= 288 tokens")
             qkv = qkv.reshape(b, s, 3, nh, hd).permute(2, 0, 3, 1, 4)
             att = ops.softmax_rows_bf16(qkv[0] @ qkv[1].transpose(-2, -1), hd ** -0.5)   # scale, f32 softmax and the casts in one pass
             o = (att @ qkv[2]).transpose(1, 2).reshape(b, s, c)

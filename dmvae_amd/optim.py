@@ -8,10 +8,15 @@ from __future__ import annotations
 
 from typing import List, Sequence
 
+import os
+
 import torch
 
 from . import functional as Fn
 from . import ops
+
+
+_CHECK_DIRECT = os.environ.get("DMVAE_CHECK_DIRECT_GRADS", "0") not in ("", "0")
 
 
 class FlatParams:
@@ -75,8 +80,17 @@ class FlatParams:
         self.accum_runs = [(a, min(b, self.numel)) for a, b in runs]
 
     def begin_step(self) -> None:
+        """Start of a step.  INVARIANT of the direct-gradient mode: every parameter with a `_dmvae_grad_view` is WRITTEN (not accumulated into) exactly once per
+        backward by the Function that owns it, so its slice of the gradient buffer is not zeroed here -- a direct parameter that a backward skips (an unused or
+        conditional block, a Function returning None) would keep the previous step's gradient and AdamW / grad_norm would consume it silently.  No such
+        parameter exists in the VAE or the DiT routes; DMVAE_CHECK_DIRECT_GRADS=1 (or `check_direct_writes`) verifies it per step, and a trainer that cannot
+        guarantee it sets `self.zero_all = True` to fall back to zeroing the whole buffer."""
+        if _CHECK_DIRECT and getattr(self, "direct", False):
+            self.check_direct_writes()
         if getattr(self, "direct", False):
-            if getattr(self, "partial", False):
+            if getattr(self, "zero_all", False):
+                self.grad.zero_()
+            elif getattr(self, "partial", False):
                 if len(self.accum_runs) <= 16:
                     for a, b in self.accum_runs:
                         self.grad[a:b].zero_()
@@ -89,6 +103,23 @@ class FlatParams:
                     p.grad = self.grad[off:off + p.numel()].view(p.shape)
         else:
             self.zero_grad()
+
+    def check_direct_writes(self) -> None:
+        """Debug mode of the invariant above (DMVAE_CHECK_DIRECT_GRADS=1, or called by hand at the start of a step): raises if the backward(s) since the previous
+        call handed out the destination view of some direct parameter of THIS buffer zero times while others of it were written (functional._dst counts;
+        a step in which none of this buffer's parameters took part -- another trainer's turn -- is not judged)."""
+        from . import functional
+        if functional.DIRECT_GRAD_WRITES is None:
+            functional.DIRECT_GRAD_WRITES = {}
+            return
+        seen = functional.DIRECT_GRAD_WRITES
+        mine = [(i, seen.pop(id(p), 0)) for i, p in enumerate(self.params) if hasattr(p, "_dmvae_grad_view")]
+        if not any(n for _, n in mine):
+            return
+        bad = [i for i, n in mine if n == 0]
+        if bad:
+            raise RuntimeError(f"FlatParams: {len(bad)} direct-gradient parameter(s) were not written by the last backward (indices {bad[:8]} ...): "
+                               "their gradient slices hold the previous step's values; set `zero_all = True` on this FlatParams or exclude them from enable_direct_grads")
 
     def after_external_update(self, reset_ema: bool = False) -> None:
         """The flat buffer was written by something other than the fused optimiser step (initial broadcast from rank 0, checkpoint load):

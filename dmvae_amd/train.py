@@ -125,14 +125,17 @@ def _set_rng_state(st) -> bool:
     single entry when this rank (of the same world size) wrote it; a checkpoint without labels is a single-process one (rank 0 of 1).  Any other rank keeps
     the generators it was seeded with (seed + 10000 rank): installing rank 0's state everywhere would make every rank draw the same DiffAug parameters, DMD
     timesteps / noise and label drop-outs on different data shards.  Returns whether a state was installed."""
+    rank, world = dist.get_rank(), dist.get_world_size()
     if not st:
         return False
-    rank, world = dist.get_rank(), dist.get_world_size()
     if st.get("ranks") is not None and int(st.get("world", 1)) == world and rank in st["ranks"]:
         mine = st["ranks"][rank]
     elif int(st.get("rank", 0)) == rank and int(st.get("world", 1)) == world:
         mine = st
     else:
+        if world > 1:       # a resumed N-rank job whose checkpoint holds only the master's generators: this rank replays its seed + 10000 rank stream from the start
+            warnings.warn(f"checkpoint holds no generator state for rank {rank} of {world} (written with all_ranks_rng=False?): this rank restarts its seeded "
+                          "RNG streams (DiffAug draws, DMD noise / timesteps, label drop-outs) instead of resuming them", stacklevel=3)
         return False
     torch.set_rng_state(mine["cpu"].cpu())
     if "cuda" in mine and torch.cuda.is_available():
@@ -249,7 +252,7 @@ class TokenizerTrainer(_AdversarialBranch):
         are not part of it.  (train_dmd.py:474 and train_diffusion.py:209 build theirs over every parameter.)"""
         return [p for p in self.vae.parameters() if p.requires_grad]
 
-    def checkpoint(self, all_ranks_rng: bool = False) -> dict:
+    def checkpoint(self, all_ranks_rng: Optional[bool] = None) -> dict:
         """The reference's checkpoint dict (train_tokenizer.py:440-450): vae_wo_ddp / vae_ema / disc_wo_ddp state_dicts, opt_vae in torch.optim.AdamW's
         layout over the TRAINABLE parameters (`_opt_param_order`), opt_disc over `disc.parameters()`, scheduler_vae / scheduler_disc, steps, and -- beyond the
         reference -- the CPU / device generator states (`rng`: DiffAug's and the transport's draws continue where they stopped).  `torch.save` it as
@@ -265,7 +268,7 @@ class TokenizerTrainer(_AdversarialBranch):
             out["disc_wo_ddp"] = {k: v.detach().clone() for k, v in self.disc.state_dict().items()}
             out["opt_disc"] = self.dopt.state_dict(list(self.disc.parameters()))
             out["scheduler_disc"] = self.dopt.scheduler_state_dict()
-        out["rng"] = _rng_state(all_ranks_rng)      # all_ranks_rng: a collective (every rank calls checkpoint()); else this rank's generators only
+        out["rng"] = _rng_state(dist.get_world_size() > 1 if all_ranks_rng is None else all_ranks_rng)      # all_ranks_rng: a collective (every rank calls checkpoint()); else this rank's generators only
         return out
 
     def load(self, ckpt: dict) -> None:
@@ -509,7 +512,7 @@ class DMDTrainer(_AdversarialBranch):
         self.global_step += 1
         return (loss if vae_turn else sloss).detach()
 
-    def checkpoint(self, all_ranks_rng: bool = False) -> dict:
+    def checkpoint(self, all_ranks_rng: Optional[bool] = None) -> dict:
         """train_dmd.py:577-590: model (the student) / vae_wo_ddp / disc_wo_ddp state_dicts, opt_sit / opt_vae / opt_disc, steps; `rng` = this rank's
         generator states, or every rank's with all_ranks_rng (a collective: every rank calls checkpoint())."""
         clone = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
@@ -518,7 +521,7 @@ class DMDTrainer(_AdversarialBranch):
                "opt_sit": self.sopt.state_dict(list(self.student.parameters())) if self.sopt is not None else None,
                "opt_vae": self.opt.state_dict(list(self.vae.parameters())),
                "opt_disc": self.dopt.state_dict(list(self.disc.parameters())) if self.disc is not None else None, "steps": self.global_step,
-               "rng": _rng_state(all_ranks_rng)}
+               "rng": _rng_state(dist.get_world_size() > 1 if all_ranks_rng is None else all_ranks_rng)}
         return out
 
     def load(self, ckpt: dict) -> None:
@@ -653,3 +656,44 @@ def build_tokenizer_trainer(device="cuda", z_channels=32, model_size="large", se
         init_weights(disc, 0.02)
         kw["disc"] = disc.to(device)
     return TokenizerTrainer(vae, lp, **kw)
+
+
+def _randomised_dit(device, seed_offset: int = 0):
+    """LightningDiT-XL/1 at the DMD stage's shape (16 x 16 latent tokens of 32 channels, 1000 classes) with the reference's zero-initialised adaLN / output
+    layers (lightningdit.py:367-376) drawn from N(0, 0.02) instead: with them at zero v == 0 and every DMD / flow-matching quantity is vacuous."""
+    from .models.lightningdit import LightningDiT_models
+    m = LightningDiT_models["LightningDiT-XL/1"](input_size=16, in_channels=32, num_classes=1000).to(device)
+    with torch.no_grad():
+        for blk in m.blocks:
+            blk.adaLN_modulation[1].weight.normal_(0, 0.02)
+        m.final_layer.linear.weight.normal_(0, 0.02)
+    return m
+
+
+def build_dmd_trainer(device="cuda", seed=42, **kw) -> DMDTrainer:
+    """Config C3 at its real size (train_dmd.py:506-575, scripts/train_dmd.sh:16-35): VAE(large, z = 32) with the ViT-L/16 encoder trainable, LPIPS, LightningDiT-XL/1
+    as frozen teacher and trainable student, CFG 5, dmd_weight 10, the VAE on every 5th step -- random-init weights in the reference's constructor order under
+    torch.manual_seed(seed) (what tests/test_gpu_fullsize.py::test_dmd_stage_full_size_cycle_c3 builds)."""
+    torch.manual_seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae = VAE(z_channels=32, model_size="large").to(device)
+        lp = LPIPS().eval().requires_grad_(False).to(device)
+    with torch.no_grad():
+        for lin in (lp.lin0, lp.lin1, lp.lin2, lp.lin3, lp.lin4):
+            lin.model[-1].weight.fill_(1.0 / lin.model[-1].weight.shape[1])
+    teacher, student = _randomised_dit(device).eval().requires_grad_(False), _randomised_dit(device).eval()
+    cfg = dict(dmd_weight=10.0, dmd_cfg_scale=5.0, num_classes=1000, vae_train_every=5, warmup_steps=10, lr=2e-5, diff_lr=2e-5)
+    cfg.update(kw)
+    return DMDTrainer(vae, lp, teacher, student, **cfg)
+
+
+def build_diffusion_trainer(device="cuda", seed=0, **kw) -> DiffusionTrainer:
+    """Config C4 (train_diffusion.py:268-297, scripts/train_diffusion.sh:19-20): LightningDiT-XL/1 on the frozen VAE(large, z = 32)'s latents, lr 2e-4."""
+    torch.manual_seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae = VAE(z_channels=32, model_size="large").to(device).eval().requires_grad_(False)
+    cfg = dict(lr=2e-4)
+    cfg.update(kw)
+    return DiffusionTrainer(_randomised_dit(device), vae, **cfg)
