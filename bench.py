@@ -308,6 +308,95 @@ def kl_mmd_roofline(dev):
     return out
 
 
+# Work per image of the secondary configurations (GFLOP, forward; BASELINE.md section 2 -- measured with hooks on the reference's modules): backward = 2 x forward
+_GF = {"vit": 155.6 + 6.5, "mlp": 1.1, "dec": 620.3 + 2.1, "vgg": 40.1, "dit": 228.8 + 8.5}
+
+
+def secondary_stages(dev, which=("c3", "c4", "gan")) -> dict:
+    """The other stages of the reference's recipe at their script configurations, timed on this device AFTER the C2 headline (same process, rank 0, N = 1; the
+    headline `value` stays C2): `c3_dmd_cycle` = train_dmd.py's step (config C3: local batch 16, ViT-L/16 trainable, LightningDiT-XL/1 teacher + student, CFG 5,
+    the VAE on every 5th step: train.build_dmd_trainer = what tests/test_gpu_fullsize.py::test_dmd_stage_full_size_cycle_c3 builds) over two 5-step cycles;
+    `c4_diffusion_step` = train_diffusion.py's step (config C4: local batch 64, frozen VAE, LightningDiT-XL/1, AdamW + EMA); `gan_step` = the tokenizer step from
+    `disc_start_step` on (generator's adaptive-weight GAN term + the PatchGAN discriminator's hinge / BCR step).  Wall clock between device synchronisations;
+    `frac_of_peak` = algorithmic TFLOP per step (BASELINE.md section 2 x batch; backward = 2 x forward) / time / 2.5 PFLOP/s."""
+    import gc
+    from dmvae_amd.train import build_diffusion_trainer, build_dmd_trainer, build_tokenizer_trainer
+    out = {}
+
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def free():
+        gc.collect()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+
+    if "c3" in which:
+        free()
+        B = 16
+        tr = build_dmd_trainer(device=dev)
+        images = torch.rand(B, 3, 256, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) * 2 - 1
+        labels = torch.randint(0, 1000, (B,), device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+        for _ in range(5):
+            tr.step(images, labels)          # one whole cycle: warm
+        turn, stud = [], []
+        t_all = time.perf_counter()
+        for _ in range(10):                  # two cycles, every step timed on its own AND the ten together
+            (turn if tr.global_step % tr.vae_train_every == 0 else stud).append(timed(lambda: tr.step(images, labels), 1))
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t_all) / 10 * 1e3
+        tf_student = B * (_GF["vit"] + _GF["mlp"] + 3 * _GF["dit"]) / 1e3
+        tf_turn = B * (3 * _GF["vit"] + 3 * _GF["mlp"] + 3 * _GF["dec"] + 3 * _GF["vgg"] + 4 * _GF["dit"] + 3 * _GF["dit"]) / 1e3
+        tf_cycle = (tf_turn + 4 * tf_student) / 5
+        log = tr.read_log()
+        out["c3_dmd_cycle"] = {
+            "workload": "train_dmd.py step (C3): VAE(large, z 32) with the ViT-L/16 encoder trainable + LPIPS + DMD loss (LightningDiT-XL/1 teacher + student, CFG 5, cond + uncond as one 2B call) "
+                        "every 5th step; the student's flow-matching step (forward + backward + clip + AdamW on 675 M parameters) every step",
+            "local_batch": B, "steps_timed": 10, "ms_per_step": round(ms, 2), "vae_turn_ms": round(sum(turn) / len(turn), 2), "student_ms": round(sum(stud) / len(stud), 2),
+            "images_per_sec": round(B / ms * 1e3, 1), "tflop_per_step": round(tf_cycle, 2), "tflop_vae_turn": round(tf_turn, 2), "tflop_student_step": round(tf_student, 2),
+            "frac_of_peak": round(tf_cycle / ms / MFMA_BF16_PEAK_TFLOPS * 1e3, 4), "frac_of_peak_student_step": round(tf_student / (sum(stud) / len(stud)) / MFMA_BF16_PEAK_TFLOPS * 1e3, 4),
+            "frac_of_peak_vae_turn": round(tf_turn / (sum(turn) / len(turn)) / MFMA_BF16_PEAK_TFLOPS * 1e3, 4),
+            "peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "dtype": "bf16", "data": "synthetic",
+            "log_after_run": {k: round(v, 5) for k, v in log.items() if k in ("rec_loss", "dmd_loss", "diffusion_loss")}}
+        del tr, images, labels
+    if "c4" in which:
+        free()
+        B = 64
+        tr = build_diffusion_trainer(device=dev)
+        images = torch.rand(B, 3, 256, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) * 2 - 1
+        labels = torch.randint(0, 1000, (B,), device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+        for _ in range(3):
+            tr.step(images, labels)
+        ms = timed(lambda: tr.step(images, labels), 8)
+        tf = B * (_GF["vit"] + _GF["mlp"] + 3 * _GF["dit"]) / 1e3
+        out["c4_diffusion_step"] = {
+            "workload": "train_diffusion.py step (C4): frozen VAE.encode (ViT-L/16 + bottleneck) -> flow-matching loss on LightningDiT-XL/1 -> clip -> AdamW -> EMA",
+            "B": B, "steps_timed": 8, "ms": round(ms, 2), "images_per_sec": round(B / ms * 1e3, 1), "tflop_per_step": round(tf, 2),
+            "frac": round(tf / ms / MFMA_BF16_PEAK_TFLOPS * 1e3, 4), "peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "dtype": "bf16",
+            "data": "synthetic", "loss_after_run": round(tr.read_log()["loss"], 5)}
+        del tr, images, labels
+    if "gan" in which:
+        free()
+        B = LOCAL_BATCH
+        tr = build_tokenizer_trainer(device=dev, seed=42, with_disc=True, disc_start_step=0)
+        images = torch.rand(B, 3, 256, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(42)) * 2 - 1
+        for _ in range(3):
+            tr.step(images)
+        ms = timed(lambda: tr.step(images), 10)
+        lg, dl = tr.read_log(), tr.read_disc_log()
+        out["gan_step"] = {"workload": "train_tokenizer.py step from disc_start_step on: C2's step + the generator's adaptive-weight adversarial term + the PatchGAN discriminator's hinge / BCR update",
+                           "local_batch": B, "steps_timed": 10, "ms": round(ms, 2), "images_per_sec": round(B / ms * 1e3, 1), "d_weight": round(lg.get("d_weight", 0.0), 5),
+                           "d_loss": round(dl["d_loss"], 5)}
+        del tr, images
+    free()
+    return out
+
+
 def self_launch(n_gpus: int) -> int:
     """No RANK in the env and --gpus N > 1: become the launcher.  One rank per device over RCCL, rendezvous on 127.0.0.1, a free port; the
     ranks' stdout/stderr pass straight through (rank 0 prints the JSON line).  Returns the exit code of the job."""
@@ -338,6 +427,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=LOCAL_BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the c3_dmd_cycle / c4_diffusion_step / gan_step keys (N = 1 only; ~1.5 min of model construction and steps)")
+    ap.add_argument("--secondary", default="c3,c4,gan", help="which of the secondary stage keys to measure")
     ap.add_argument("--time-every", type=int, default=4, help="record the per-launch roofline events on every n-th timed step (1 = all)")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -504,8 +595,14 @@ def main():
                            bucket_bytes=64 << 20, dynamic_tile_claiming=os.environ.get("DMVAE_PP_DYNAMIC", "0") not in ("", "0"))      # dist.init_distributed_mode sets it when it switches DYN on
     if world == 1:
         out["kl_mmd"] = kl_mmd_roofline(dev)
+    del tr, images
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_secondary:
+        try:
+            out.update(secondary_stages(dev, tuple(x for x in args.secondary.split(",") if x)))
+        except Exception as e:      # noqa: BLE001 -- the headline line must still come out; the failure is reported in it
+            out["secondary_error"] = f"{type(e).__name__}: {e}"[:400]
     if world == 1 and not args.no_cpu_baseline:
-        del tr, images
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline()
     _emit(json.dumps(out), rank0=True)

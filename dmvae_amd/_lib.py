@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t, c_ulonglong, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t, c_uint, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DMVAE_LIB") or os.path.join(_HERE, "libdmvae_hip.so")      # DMVAE_LIB: another build of the same ABI (kernel A/B runs on one box)
@@ -27,7 +27,12 @@ class PackEntry(Structure):
                 ("reserved", c_int32), ("start", c_ulonglong), ("count", c_ulonglong)]
 
 
-ABI_VERSION = 5     # 5: dmvae_groupnorm_*_short; include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*; 4: dmvae_norm_conv_out_bwd*)
+class WtEntry(Structure):
+    """record of dmvae_linear_weight_t_kmajor_batched's table (include/dmvae_hip.h)."""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("N", c_int32), ("K", c_int32), ("start", c_uint), ("tiles_x", c_uint)]
+
+
+ABI_VERSION = 6     # 6: dmvae_dit_stack_* / dmvae_dit_boundary_bwd / batched rows Linears / batched weight transposes; 5: dmvae_groupnorm_*_short; include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*; 4: dmvae_norm_conv_out_bwd*)
 
 # name -> (restype, argtypes); every symbol include/dmvae_hip.h declares
 SIGNATURES = {
@@ -103,6 +108,18 @@ SIGNATURES = {
     "dmvae_swiglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "dmvae_rmsnorm_modulate_bwd": (c_int, [c_void_p] * 8 + [c_size_t] + [c_int] * 6 + [c_float, c_int, c_void_p]),
     "dmvae_qknorm_rope_bwd": (c_int, [c_void_p] * 12 + [c_size_t] + [c_int] * 5 + [c_float, c_int, c_void_p]),
+    "dmvae_qknorm_rope_bwd_nblk": (c_int, [c_int] * 5),
+    "dmvae_qknorm_rope_bwd_partial": (c_int, [c_void_p] * 10 + [c_size_t] + [c_int] * 5 + [c_float, c_void_p]),
+    "dmvae_dit_stack_bps": (c_int, [c_int]),
+    "dmvae_dit_stack_part_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dmvae_dit_stack_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dmvae_dit_boundary_bwd": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dmvae_dit_stack_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "dmvae_colsum2_batched": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "dmvae_linear_rows_batched_bf16": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong] + [c_int] * 11 + [c_void_p]),
+    "dmvae_linear_rows_wgrad_batched": (c_int, [c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "dmvae_wt_entry_bytes": (c_size_t, []),
+    "dmvae_linear_weight_t_kmajor_batched": (c_int, [c_void_p, c_int, c_uint, c_void_p]),
     "dmvae_gated_residual_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_loss_workspace": (c_size_t, []),
     "dmvae_l1_mse": (c_int, [c_void_p] * 5 + [c_size_t, c_size_t, c_float, c_float, c_void_p]),

@@ -446,8 +446,10 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ 
   const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + col;
   float a = 0.f;
-  if (i < 2 * D)
-    for (int b = grp; b < nblk; b += 16) a += part[(size_t)b * 2 * D + i];
+  if (i < 2 * D) {
+#pragma unroll 8
+    for (int b = grp; b < nblk; b += 16) a += part[(size_t)b * 2 * D + i];   // independent loads: eight in flight per thread (was one: 34 us for 1.2 MB)
+  }
   red[grp][col] = a;
   __syncthreads();
   if (threadIdx.x < 16 && i < 2 * D) {
@@ -754,29 +756,62 @@ __global__ __launch_bounds__(256) void qknorm_rope16_bwd_kernel(const bf16* __re
 }
 }  // namespace dmvae_dit
 
+static int qk_bwd_nblk(int batch, int seq, int heads, int head_dim, int head_dim_padded) {
+  const int tokens = batch * seq;
+  int nblk = (tokens * heads + 3) / 4; if (nblk > 2048) nblk = 2048;   // eight blocks per CU: the rows are short (4-B lanes, four wave reductions each) and latency-bound
+  if (head_dim % 8 == 0 && head_dim_padded % 8 == 0 && 2 * head_dim <= 256) {
+    nblk = (tokens * heads + 15) / 16; if (nblk > 2048) nblk = 2048;
+  }
+  return nblk;
+}
+// blocks of the first stage = rows of its partial-sum array [nblk][2][head_dim] f32 (the workspace of dmvae_qknorm_rope_bwd; `part` of dmvae_qknorm_rope_bwd_partial)
+extern "C" int dmvae_qknorm_rope_bwd_nblk(int batch, int seq, int heads, int head_dim, int head_dim_padded) {
+  return qk_bwd_nblk(batch, seq, heads, head_dim, head_dim_padded);
+}
+
+static int qk_bwd_launch(const void* dq, const void* dk, const void* dv, const void* qkv, const void* q_weight, const void* k_weight, const void* cos_table,
+                         const void* sin_table, void* dqkv, void* part, size_t part_bytes, int batch, int seq, int heads, int head_dim, int head_dim_padded, float eps,
+                         hipStream_t stream, int* nblk_out) {
+  DMVAE_CHECK_ARG(dq && dk && dv && qkv && q_weight && k_weight && cos_table && sin_table && dqkv && part && batch > 0 && seq > 0 && heads > 0,
+                  "qknorm_rope_bwd: bad argument");
+  DMVAE_CHECK_ARG(head_dim % 2 == 0 && head_dim >= 2 && head_dim_padded >= head_dim && head_dim_padded <= 128,
+                  "qknorm_rope_bwd: head dim must be even, padded head dim <= 128 (got %d, %d)", head_dim, head_dim_padded);
+  const int tokens = batch * seq;
+  const int nblk = qk_bwd_nblk(batch, seq, heads, head_dim, head_dim_padded);
+  DMVAE_CHECK_ARG(part_bytes >= (size_t)nblk * 2 * head_dim * sizeof(float), "qknorm_rope_bwd: workspace too small");
+  if (head_dim % 8 == 0 && head_dim_padded % 8 == 0 && 2 * head_dim <= 256) {
+    hipLaunchKernelGGL(qknorm_rope16_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (const bf16*)qkv,
+                       (const float*)q_weight, (const float*)k_weight, (const float*)cos_table, (const float*)sin_table, (bf16*)dqkv, (float*)part,
+                       tokens, seq, heads, head_dim, head_dim_padded, eps);
+  } else
+  hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (const bf16*)qkv,
+                     (const float*)q_weight, (const float*)k_weight, (const float*)cos_table, (const float*)sin_table, (bf16*)dqkv, (float*)part,
+                     tokens, seq, heads, head_dim, head_dim_padded, eps);
+  DMVAE_CHECK_LAUNCH();
+  *nblk_out = nblk;
+  return 0;
+}
+
 extern "C" int dmvae_qknorm_rope_bwd(const void* dq, const void* dk, const void* dv, const void* qkv, const void* q_weight, const void* k_weight,
                                      const void* cos_table, const void* sin_table, void* dqkv, void* dq_weight, void* dk_weight, void* workspace,
                                      size_t workspace_bytes, int batch, int seq, int heads, int head_dim, int head_dim_padded, float eps, int accumulate,
                                      hipStream_t stream) {
-  DMVAE_CHECK_ARG(dq && dk && dv && qkv && q_weight && k_weight && cos_table && sin_table && dqkv && dq_weight && dk_weight && workspace && batch > 0 &&
-                      seq > 0 && heads > 0, "qknorm_rope_bwd: bad argument");
-  DMVAE_CHECK_ARG(head_dim % 2 == 0 && head_dim >= 2 && head_dim_padded >= head_dim && head_dim_padded <= 128,
-                  "qknorm_rope_bwd: head dim must be even, padded head dim <= 128 (got %d, %d)", head_dim, head_dim_padded);
-  const int tokens = batch * seq;
-  int nblk = (tokens * heads + 3) / 4; if (nblk > 2048) nblk = 2048;   // eight blocks per CU: the rows are short (4-B lanes, four wave reductions each) and latency-bound
-  DMVAE_CHECK_ARG(workspace_bytes >= (size_t)nblk * 2 * head_dim * sizeof(float), "qknorm_rope_bwd: workspace too small");
-  if (head_dim % 8 == 0 && head_dim_padded % 8 == 0 && 2 * head_dim <= 256) {
-    nblk = (tokens * heads + 15) / 16; if (nblk > 2048) nblk = 2048;
-    hipLaunchKernelGGL(qknorm_rope16_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (const bf16*)qkv,
-                       (const float*)q_weight, (const float*)k_weight, (const float*)cos_table, (const float*)sin_table, (bf16*)dqkv, (float*)workspace,
-                       tokens, seq, heads, head_dim, head_dim_padded, eps);
-  } else
-  hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3(nblk), dim3(256), 0, stream, (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (const bf16*)qkv,
-                     (const float*)q_weight, (const float*)k_weight, (const float*)cos_table, (const float*)sin_table, (bf16*)dqkv, (float*)workspace,
-                     tokens, seq, heads, head_dim, head_dim_padded, eps);
-  DMVAE_CHECK_LAUNCH();
+  DMVAE_CHECK_ARG(dq_weight && dk_weight, "qknorm_rope_bwd: bad argument");
+  int nblk = 0;
+  const int rc = qk_bwd_launch(dq, dk, dv, qkv, q_weight, k_weight, cos_table, sin_table, dqkv, workspace, workspace_bytes, batch, seq, heads, head_dim, head_dim_padded, eps,
+                               stream, &nblk);
+  if (rc) return rc;
   hipLaunchKernelGGL(colsum2_kernel, dim3((2 * head_dim + 15) / 16), dim3(256), 0, stream, (const float*)workspace, (float*)dq_weight, (float*)dk_weight,
                      nblk, head_dim, accumulate);
   DMVAE_CHECK_LAUNCH();
   return 0;
+}
+
+// First stage only: the per-block partial sums of the two norm-weight gradients stay in `part` ([dmvae_qknorm_rope_bwd_nblk][2][head_dim] f32) for a reduction the
+// caller batches over layers (dmvae_colsum2_batched, csrc/dit_stack.hip).
+extern "C" int dmvae_qknorm_rope_bwd_partial(const void* dq, const void* dk, const void* dv, const void* qkv, const void* q_weight, const void* k_weight,
+                                             const void* cos_table, const void* sin_table, void* dqkv, void* part, size_t part_bytes, int batch, int seq, int heads,
+                                             int head_dim, int head_dim_padded, float eps, hipStream_t stream) {
+  int nblk = 0;
+  return qk_bwd_launch(dq, dk, dv, qkv, q_weight, k_weight, cos_table, sin_table, dqkv, part, part_bytes, batch, seq, heads, head_dim, head_dim_padded, eps, stream, &nblk);
 }

@@ -438,8 +438,11 @@ struct Cfg { int tm, tp; float cost; };
 static const Cfg g_cfg[] = {
     {256, 256, 1.00f}, {256, 224, 0.94f}, {256, 192, 0.885f}, {256, 160, 0.80f}, {256, 128, 0.67f},
     {128, 448, 1.02f}, {128, 384, 0.93f}, {128, 256, 0.70f},  {192, 256, 0.90f}, {192, 320, 1.12f},
+    // round 5: the M = 4096 .. 4112 problems of the DMD stage (batch 16: LightningDiT-XL/1's N = 1152 Linears and their input gradients, ViT-L's N = 1024 ones) are
+    // 160 / 132 tiles of 256 x 128 -- half to two thirds of the chip; these split them into 192 / 198 smaller tiles
+    {192, 128, 0.54f}, {128, 192, 0.54f},
 };
-constexpr int NCFG = sizeof(g_cfg) / sizeof(g_cfg[0]), NPLAN = 10;
+constexpr int NCFG = sizeof(g_cfg) / sizeof(g_cfg[0]), NPLAN = 12;
 
 static int g_forced = -1;   // -1: plan by cost; >= 0: this menu entry (dmvae_debug_gemm_cfg: tools/bench_gemm.py's sweep, tests/test_gpu_gemm_pp.py)
 // Time model: tiles / 256 rounds of the tile's cost -- FRACTIONAL rounds, because the chip is power-limited: with half of the CUs idle in the last round the
@@ -473,7 +476,9 @@ static int dispatch(int cfg, const Args& a, hipStream_t st) {
     case 6: return launch<128, 384, 2, 4, F32>(a, st);
     case 7: return launch<128, 256, 2, 4, F32>(a, st);
     case 8: return launch<192, 256, 2, 4, F32>(a, st);
-    default: return launch<192, 320, 2, 4, F32>(a, st);
+    case 9: return launch<192, 320, 2, 4, F32>(a, st);
+    case 10: return launch<192, 128, 2, 4, F32>(a, st);
+    default: return launch<128, 192, 2, 4, F32>(a, st);
   }
 }
 

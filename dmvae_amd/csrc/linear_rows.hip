@@ -22,6 +22,9 @@ constexpr int MAXSTEPS = 16;  // K steps per wave and pass (all of their weight 
 struct Args {
   const bf16* x; const bf16* w; const void* bias; void* y;
   int M, N, K, ldx, ldw, ldy, act, bias_bf16, out_f32, w_layout;
+  // batched form (dmvae_linear_rows_batched_bf16: blockIdx.y = layer; the adaLN Linears of every block in one launch): per-layer weight / bias pointers,
+  // element strides between the layers' x and y (xs = 0: one x for all layers)
+  const void* const* wtab; const void* const* btab; long long xs, ys;
 };
 
 // G = row groups of 16 (M <= 64); WAVES = waves of the workgroup that share the K steps: 4 when N / 16 workgroups already fill the chip several times over
@@ -32,6 +35,13 @@ __global__ __launch_bounds__(WAVES * 64) void linear_rows_kernel(Args a) {
   __shared__ float red[WAVES][G][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * 16;
+  if (a.wtab) {   // layer blockIdx.y of the batched form (block-uniform)
+    const int l = blockIdx.y;
+    a.w = (const bf16*)a.wtab[l];
+    a.bias = a.btab ? a.btab[l] : nullptr;
+    a.x += (size_t)l * a.xs;
+    a.y = a.out_f32 ? (void*)((float*)a.y + (size_t)l * a.ys) : (void*)((bf16*)a.y + (size_t)l * a.ys);
+  }
   const int r = lane & 15, kc = (lane >> 4) * 8;
   const int nrow = n0 + r < a.N ? n0 + r : a.N - 1;            // rows past N (N % 16 != 0): read a valid row, never stored
   // w_layout 1: K-tile-major [K / 32][N][32] (dmvae_linear_weight_t_kmajor / dmvae_pack_conv_weight_v2's second copy): the 16 rows of a K step are one
@@ -176,10 +186,38 @@ extern "C" int dmvae_linear_rows_bf16(const void* x, const void* w, const void* 
   DMVAE_CHECK_ARG(w_layout == 0 || w_layout == 1, "linear_rows_bf16: w_layout must be 0 (row-major) or 1 (K-tile-major)");
   DMVAE_CHECK_ARG(act == 0 || (act == 1 && !out_f32), "linear_rows_bf16: act must be 0 (none) or 1 (SiLU, bf16 result)");
   DMVAE_CHECK_ARG(((uintptr_t)x | (uintptr_t)w) % 16 == 0 && (uintptr_t)y % 8 == 0, "linear_rows_bf16: operands must be 16-byte aligned");
-  Args a{(const bf16*)x, (const bf16*)w, bias, y, M, N, K, ldx, ldw, ldy, act, bias_bf16, out_f32, w_layout};
+  Args a{(const bf16*)x, (const bf16*)w, bias, y, M, N, K, ldx, ldw, ldy, act, bias_bf16, out_f32, w_layout, nullptr, nullptr, 0, 0};
   const dim3 grid((N + 15) / 16);
   const int G = (M + 15) / 16;
   const bool deep = (N + 15) / 16 < 256 && K >= 1024;      // few workgroups, long reduction: more waves per workgroup share the K steps
+#define DMVAE_LR(GG, WW) hipLaunchKernelGGL((linear_rows_kernel<GG, WW>), grid, dim3(WW * 64), 0, stream, a)
+  switch (G) {
+    case 1: if (deep) DMVAE_LR(1, 16); else DMVAE_LR(1, 4); break;
+    case 2: if (deep) DMVAE_LR(2, 16); else DMVAE_LR(2, 4); break;
+    case 3: if (deep) DMVAE_LR(3, 8); else DMVAE_LR(3, 4); break;
+    default: if (deep) DMVAE_LR(4, 8); else DMVAE_LR(4, 4); break;
+  }
+#undef DMVAE_LR
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dmvae_linear_rows_batched_bf16(const void* x, long long x_layer_stride, const void* w_table, const void* bias_table, void* y, long long y_layer_stride,
+                                              int layers, int M, int N, int K, int ldx, int ldw, int ldy, int act, int bias_bf16, int out_f32, int w_layout,
+                                              hipStream_t stream) {
+  using namespace dmvae_linear_rows;
+  DMVAE_CHECK_ARG(x && w_table && y && layers > 0 && layers <= 65535, "linear_rows_batched_bf16: null pointer or bad layer count");
+  DMVAE_CHECK_ARG(dmvae_linear_rows_supported(M, N, K), "linear_rows_batched_bf16: M=%d N=%d K=%d (1 <= M <= 64, N %% 4 == 0, K %% 32 == 0)", M, N, K);
+  DMVAE_CHECK_ARG(ldx >= K && (w_layout == 1 || (ldw >= K && ldw % 8 == 0)) && ldy >= N && ldx % 8 == 0 && ldy % 4 == 0 && x_layer_stride % 8 == 0 && y_layer_stride % 4 == 0,
+                  "linear_rows_batched_bf16: leading dimensions ldx=%d ldw=%d ldy=%d", ldx, ldw, ldy);
+  DMVAE_CHECK_ARG(w_layout == 0 || w_layout == 1, "linear_rows_batched_bf16: w_layout must be 0 (row-major) or 1 (K-tile-major)");
+  DMVAE_CHECK_ARG(act == 0 || (act == 1 && !out_f32), "linear_rows_batched_bf16: act must be 0 (none) or 1 (SiLU, bf16 result)");
+  DMVAE_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)y % 8 == 0, "linear_rows_batched_bf16: operands must be 16-byte aligned");
+  Args a{(const bf16*)x, nullptr, nullptr, y, M, N, K, ldx, ldw, ldy, act, bias_bf16, out_f32, w_layout, (const void* const*)w_table, (const void* const*)bias_table,
+         x_layer_stride, y_layer_stride};
+  const dim3 grid((N + 15) / 16, layers);
+  const int G = (M + 15) / 16;
+  const bool deep = (long long)((N + 15) / 16) * layers < 256 && K >= 1024;
 #define DMVAE_LR(GG, WW) hipLaunchKernelGGL((linear_rows_kernel<GG, WW>), grid, dim3(WW * 64), 0, stream, a)
   switch (G) {
     case 1: if (deep) DMVAE_LR(1, 16); else DMVAE_LR(1, 4); break;

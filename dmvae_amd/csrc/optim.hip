@@ -38,22 +38,53 @@ __global__ void norm_final_kernel(const float* __restrict__ part, float* __restr
   }
 }
 
+// One element's update: torch.optim.AdamW's arithmetic (decoupled decay, bias corrections, IEEE sqrt and division) + the EMA; shared by the vector body and the tail.
+__device__ __forceinline__ void adamw_one(float& pi, const float g, float& mi, float& vi, float* ema_i, const float coef, const float lr, const float b1, const float b2,
+                                          const float eps, const float wd, const float step, const float bc2_sqrt, const float decay) {
+  const float gi = g * coef;
+  pi = pi * (1.f - lr * wd);
+  mi = b1 * mi + (1.f - b1) * gi;
+  vi = b2 * vi + (1.f - b2) * gi * gi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  pi -= step * mi / denom;
+  if (ema_i) *ema_i = *ema_i * decay + pi * (1.f - decay);
+}
+
+// 16 B per lane and stream (the scalar form moved 4 B per lane: 4.8 TB/s over the student's 20 GB per step); the same per-element arithmetic, so the same bits.
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, float* __restrict__ ema,
                                                         const float* __restrict__ clip, size_t n, float lr, float b1, float b2,
                                                         float eps, float wd, float bc1, float bc2_sqrt, float decay, bf16* __restrict__ shadow) {
   const float coef = clip ? clip[1] : 1.f;
   const float step = lr / bc1;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float gi = g[i] * coef;
-    float pi = p[i] * (1.f - lr * wd);
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    pi -= step * mi / denom;
-    p[i] = pi; m[i] = mi; v[i] = vi;
-    if (ema) ema[i] = ema[i] * decay + pi * (1.f - decay);
-    if (shadow) shadow[i] = (bf16)pi;   // the bf16 copy autocast would make of the new weight (RNE), for the next forward's GEMM operands
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 pv = reinterpret_cast<const f32x4*>(p)[i], mv = reinterpret_cast<const f32x4*>(m)[i], vv = reinterpret_cast<const f32x4*>(v)[i];
+    const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+    f32x4 ev = {0.f, 0.f, 0.f, 0.f};
+    if (ema) ev = reinterpret_cast<const f32x4*>(ema)[i];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float pe = pv[e], me = mv[e], ve = vv[e], ee = ev[e];
+      adamw_one(pe, gv[e], me, ve, ema ? &ee : nullptr, coef, lr, b1, b2, eps, wd, step, bc2_sqrt, decay);
+      pv[e] = pe; mv[e] = me; vv[e] = ve; ev[e] = ee;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (ema) reinterpret_cast<f32x4*>(ema)[i] = ev;
+    if (shadow) {   // the bf16 copy autocast would make of the new weight (RNE), for the next forward's GEMM operands
+      const bf16x4 sv = {(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
+      reinterpret_cast<bf16x4*>(shadow)[i] = sv;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    float pe = p[i], me = m[i], ve = v[i], ee = ema ? ema[i] : 0.f;
+    adamw_one(pe, g[i], me, ve, ema ? &ee : nullptr, coef, lr, b1, b2, eps, wd, step, bc2_sqrt, decay);
+    p[i] = pe; m[i] = me; v[i] = ve;
+    if (ema) ema[i] = ee;
+    if (shadow) shadow[i] = (bf16)pe;
   }
 }
 
@@ -79,7 +110,9 @@ static int adamw_launch(void* params, const void* grads, void* exp_avg, void* ex
   if (n == 0) return 0;
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
-  size_t nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
+  size_t nb = (n / 4 + 255) / 256; if (nb > 8192) nb = 8192; if (nb < 1) nb = 1;
+  DMVAE_CHECK_ARG(((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)ema) % 16 == 0 && (uintptr_t)shadow % 8 == 0,
+                  "adamw_ema_step: buffers must be 16-byte aligned (8 for the bf16 shadow)");
   hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (float*)params, (const float*)grads, (float*)exp_avg,
                      (float*)exp_avg_sq, (float*)ema, (const float*)norm_out3, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), ema_decay,
                      (bf16*)shadow);

@@ -706,6 +706,9 @@ def _bf_t(w: torch.Tensor) -> torch.Tensor:
     where there is one) when `out` is a multiple of 32; else row-major [in, out] from the element-wise pack."""
     cout, cin = w.shape
     if cout % 32 == 0 and cin % 8 == 0 and not parity.on():
+        st = getattr(w, "_dmvae_shadow_t", None)
+        if st is not None and w._dmvae_shadow_t_key == (w.data_ptr(), w._version, _epoch_of(w)):
+            return st                                    # optim.FlatParams.enable_transposed_shadow: refreshed by one batched launch after the optimiser step
         cache = getattr(w, "_dmvae_bft", None)
         ver = (w.data_ptr(), _ver(w), _epoch_of(w))
         if cache is not None and cache[0] == ver:
@@ -798,8 +801,13 @@ def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Te
         return ops.linear_bf16(_c(dy2), _bf_t(w)), dw, db                 # dX = dY . W as an NT GEMM against the transposed copy
     if cout % 32 == 0 and cin % 4 == 0:
         return ops.gemm_nt(_c(dy2), packed(w, True).view(cin, cout)), dw, db
+    if cin % 4 == 0:
+        # few out features (the reduced test models' 8-channel output head): the reduction zero-padded to the small batched kernel's 32-wide K step
+        pad = (-cout) % 32
+        wt = torch.nn.functional.pad(_bf(w).t(), (0, pad)).contiguous()                   # [in, out + pad]
+        return ops.gemm_nt(torch.nn.functional.pad(_c(dy2), (0, pad)), wt), dw, db
     from ._stock import require_opt_in
-    require_opt_in("functional._lin_grads (input gradient)", f"Linear {cout} x {cin}: the input-gradient GEMM kernels need out features % 32 == 0 and in features % 4 == 0")
+    require_opt_in("functional._lin_grads (input gradient)", f"Linear {cout} x {cin}: the input-gradient GEMM kernels need in features % 4 == 0")
     return dy2 @ _bf(w), dw, db
 
 
@@ -902,8 +910,10 @@ class VitBlockFn(torch.autograd.Function):
         h1 = linear(hn2, f1w, f1b)
         g = ops.gelu(h1)
         o3 = linear(g, f2w, f2b)
-        # graph-free call (the DMD stage's student-only steps run the trainable encoder's forward under no_grad): t_mid is nobody's saved tensor, update it in place
-        t_out = ops.scale_residual_(t_mid if (not torch.is_grad_enabled() or not any(ctx.needs_input_grad)) else t_mid.clone(), o3, ls2)
+        # nothing requires a gradient: t_mid is nobody's saved tensor, update it in place.  (The outer grad mode cannot be read here -- Function.forward always runs with
+        # grad mode off -- so a no_grad call with trainable weights still clones; such calls no longer come here: vit_fast.trainable_forward_features sends them to
+        # the frozen route's fused launches.)
+        t_out = ops.scale_residual_(t_mid if not any(ctx.needs_input_grad) else t_mid.clone(), o3, ls2)
         ctx.save_for_backward(t, hn1, qkv, o, o2, t_mid, hn2, h1, g, o3, n1w, qkvw, pw, ls1, n2w, f1w, f2w, ls2)
         ctx.others = (n1b, qkvb, pb, n2b, f1b, f2b, heads, eps)
         return t_out
@@ -1020,6 +1030,130 @@ class DitBlockFn(torch.autograd.Function):
         return (dt, dmod.to(mod.dtype), dn1w, dqkvw, dqkvb, dqnw, dknw, dpw, dpb, dn2w, dw12, db12, dw3, db3, None, None, None, None)
 
 
+# gradient tensors this build's backward Functions created and handed to autograd for the f32 residual stream: the next Function down the chain may update such a
+# tensor in place instead of cloning it (nobody else holds it: autograd's input buffer passes a single incoming gradient through as it is).  A strong reference is
+# kept until the tensor is taken, so its address cannot be reused by another tensor in between; cleared at the start of every training forward.
+_OWNED_GRADS = {}
+
+
+def _own(t: torch.Tensor) -> torch.Tensor:
+    _OWNED_GRADS[t.data_ptr()] = t
+    return t
+
+
+def _take_owned(t: torch.Tensor) -> bool:
+    o = _OWNED_GRADS.pop(t.data_ptr(), None)
+    return o is not None and o.shape == t.shape and t.dtype == f32 and o.dtype == f32 and t.is_contiguous() and o.untyped_storage().data_ptr() == t.untyped_storage().data_ptr()
+
+
+DIT_STACK_PARAMS_PER_BLOCK = 14
+
+
+def dit_stack_supported(b: int, n: int, c: int, heads: int) -> bool:
+    """Shapes `DitStackFn` takes (else the per-block `DitBlockFn` route): the fused attention kernels' token / head-dim range, at most 64 samples per call (the
+    per-sample Linears' row limit), outside the fp32 parity mode."""
+    return bool(ops.attention_heads_supported(n, c // heads) and _fused_attn_bwd() and b <= 64 and c % 32 == 0 and not parity.on())
+
+
+class DitStackFn(torch.autograd.Function):
+    """ALL LightningDiT blocks (lightningdit.py:236-250 x depth, with each block's adaLN_modulation Linear, :236-240) as ONE autograd node on the f32 residual stream
+    h [B,N,C]; `sc` = SiLU(conditioning) [B,C] f32 (adaLN_modulation[0] of every block: the same values).  Same arithmetic as a chain of `DitBlockFn` fed by `LinearFn`
+    modulations; what the single node buys is launch structure:
+      forward   the 28 adaLN Linears as one batched launch; a block's closing gated residual folded into the next block's RMSNorm + modulate (dit.hip, as on the inference route);
+      backward  one pass over the residual-stream gradient per sub-layer boundary (RMSNorm backward + the next gated residual's backward: csrc/dit_stack.hip) with ALL
+                per-sample / per-channel reductions deferred to one finalize launch; the adaLN weight gradients of all blocks in one MFMA launch, their input gradient
+                in one batched launch; no per-block clone / cast / zero-fill.
+    Parameters per block, in order: norm1.weight, qkv.weight, qkv.bias, q_norm.weight, k_norm.weight, proj.weight, proj.bias, norm2.weight, w12.weight, w12.bias,
+    w3.weight, w3.bias, adaLN_modulation[1].weight, adaLN_modulation[1].bias."""
+
+    @staticmethod
+    def forward(ctx, h, sc, cos, sin, heads, eps, *params):
+        P = DIT_STACK_PARAMS_PER_BLOCK
+        nl = len(params) // P
+        b, n, c = h.shape
+        d = c // heads
+        h = _c(h)
+        scb = _c(sc).to(bf16)
+        blocks = [params[i * P:(i + 1) * P] for i in range(nl)]
+        mod_all = ops.linear_rows_batched(scb, [_bf(bp[12]) for bp in blocks], [_bf(bp[13]) for bp in blocks])          # [L, B, 6C] bf16
+        saved = []
+        h_in, h_mid, o3 = h, None, None
+        for i, (n1w, qkvw, qkvb, qnw, knw, pw, pb, n2w, w12w, w12b, w3w, w3b, _aw, _ab) in enumerate(blocks):
+            mod = mod_all[i]
+            if i == 0:
+                a1 = ops.rmsnorm_modulate(h_in, n1w, mod, 0, c, eps)
+            else:
+                h_in, a1 = ops.gated_residual_out(h_mid, o3, mod_all[i - 1], 5 * c, n1w, mod, 0, c, eps)
+            qkv = linear(a1, qkvw, qkvb)
+            q, k, v = ops.qknorm_rope(qkv, qnw, knw, cos, sin, heads, eps)
+            o = ops.attention_heads(q, k, v, b, d ** -0.5)
+            o2 = linear(o, pw, pb)
+            h_mid, a2 = ops.gated_residual_out(h_in, o2, mod, 2 * c, n2w, mod, 3 * c, 4 * c, eps)
+            x12 = linear(a2, w12w, w12b)
+            g = ops.swiglu(x12)
+            o3 = linear(g, w3w, w3b)
+            saved += [h_in, a1, qkv, q, k, v, o, o2, h_mid, a2, x12, g, o3]
+        h_out, _ = ops.gated_residual_out(h_mid, o3, mod_all[nl - 1], 5 * c)
+        ctx.save_for_backward(scb, mod_all, cos, sin, *saved, *params)
+        ctx.cfg = (nl, heads, eps, sc.dtype)
+        return h_out
+
+    @staticmethod
+    def backward(ctx, dh_out):
+        P = DIT_STACK_PARAMS_PER_BLOCK
+        nl, heads, eps, sc_dtype = ctx.cfg
+        scb, mod_all, cos, sin = ctx.saved_tensors[:4]
+        acts = ctx.saved_tensors[4:4 + 13 * nl]
+        params = ctx.saved_tensors[4 + 13 * nl:]
+        b, n, c = acts[0].shape
+        d, rows = c // heads, b * n
+        dt = dh_out if _take_owned(dh_out) else _c(dh_out).float().clone()      # becomes d(h_mid), d(h) of every block in turn
+        S = ops.DitStackBwd(nl, b, n, c, heads, dt.device)
+        grads = [None] * (P * nl)
+        fresh = lambda p: _dst(p) if _dst(p) is not None else torch.empty(p.shape, dtype=f32, device=dt.device)
+        norm_dws, qn_dws, kn_dws = [None] * (2 * nl), [None] * nl, [None] * nl
+        do3 = S.boundary(2 * nl, dt, y=acts[13 * (nl - 1) + 12], gate_mod=mod_all[nl - 1], gate_off=5 * c)
+        for i in range(nl - 1, -1, -1):
+            h_in, a1, qkv, q, k, v, o, o2, h_mid, a2, x12, g, o3 = acts[13 * i:13 * i + 13]
+            n1w, qkvw, qkvb, qnw, knw, pw, pb, n2w, w12w, w12b, w3w, w3b, _aw, _ab = params[P * i:P * i + P]
+            mod = mod_all[i]
+            G = grads
+            dg, G[P * i + 10], G[P * i + 11] = _lin_grads(do3.view(rows, c), g.view(rows, -1), w3w, w3b)
+            dx12 = ops.swiglu_bwd(dg.view_as(g), x12)
+            da2, G[P * i + 8], G[P * i + 9] = _lin_grads(dx12.view(rows, -1), a2.view(rows, c), w12w, w12b)
+            do2 = S.boundary(2 * i + 1, dt, da=da2.view(b, n, c), x=h_mid, w=n2w, mod=mod, scale_off=4 * c, eps=eps, y=o2, gate_mod=mod, gate_off=2 * c)
+            do, G[P * i + 5], G[P * i + 6] = _lin_grads(do2.view(rows, c), o.view(rows, c), pw, pb)
+            dq, dk, dv = ops.attention_bwd_heads(q, k, v, o, do.view(b, n, c), b, d ** -0.5)
+            dqkv = S.qknorm_rope_bwd(i, dq, dk, dv, qkv, qnw, knw, cos, sin, eps)
+            da1, G[P * i + 1], G[P * i + 2] = _lin_grads(dqkv.view(rows, 3 * c), a1.view(rows, c), qkvw, qkvb)
+            if i > 0:
+                do3 = S.boundary(2 * i, dt, da=da1.view(b, n, c), x=h_in, w=n1w, mod=mod, scale_off=c, eps=eps, y=acts[13 * (i - 1) + 12], gate_mod=mod_all[i - 1],
+                                 gate_off=5 * c)
+            else:
+                S.boundary(0, dt, da=da1.view(b, n, c), x=h_in, w=n1w, mod=mod, scale_off=c, eps=eps)
+            norm_dws[2 * i], norm_dws[2 * i + 1], qn_dws[i], kn_dws[i] = fresh(n1w), fresh(n2w), fresh(qnw), fresh(knw)
+            G[P * i + 0], G[P * i + 7], G[P * i + 3], G[P * i + 4] = norm_dws[2 * i], norm_dws[2 * i + 1], qn_dws[i], kn_dws[i]
+        dmod = torch.empty_like(mod_all)
+        S.finalize(dmod, norm_dws, qn_dws, kn_dws)
+        # the adaLN Linears of every block: weight / bias gradients in one launch, the input gradient d sc = sum_l d mod_l . W_l as one batched launch + a sum over layers
+        aws = [params[P * i + 12] for i in range(nl)]
+        abs_ = [params[P * i + 13] for i in range(nl)]
+        dws, dbs = [fresh(w) for w in aws], [fresh(bb) for bb in abs_]
+        ops.linear_rows_wgrad_batched(dmod, ops.rows_transposed(scb), [t.view(t.shape[0], -1) for t in dws], dbs)
+        for i in range(nl):
+            grads[P * i + 12], grads[P * i + 13] = dws[i], dbs[i]
+        dsc = None
+        if ctx.needs_input_grad[1]:
+            wts = [_bf_t(w) for w in aws]
+            if all(t.dim() == 3 for t in wts):
+                dsc = ops.linear_rows_batched(dmod, wts, None, out_f32=True).sum(0).to(sc_dtype)
+            else:      # out features not a multiple of 32: no K-tile-major copy -- per layer on the row-major transposed pack
+                dsc = sum(ops.linear_rows(dmod[i], wts[i].view(c, -1), out_f32=True) for i in range(nl)).to(sc_dtype)
+        return (_own(dt), dsc, None, None, None, None, *grads)
+
+
+
+
 class RmsnormModulateFn(torch.autograd.Function):
     """bf16( RMSNorm(h) * bf16(1 + scale) + shift ) with gradients to h, the norm weight and the adaLN chunks (FinalLayer, lightningdit.py:266-273)."""
 
@@ -1037,7 +1171,7 @@ class RmsnormModulateFn(torch.autograd.Function):
         dt = torch.zeros_like(h)
         dmod = torch.zeros(mod.shape, dtype=f32, device=h.device)
         dw = ops.rmsnorm_modulate_bwd_(dt, _c(da).to(bf16), h, w, mod, dmod, shift_off, scale_off, eps, dw_out=_dst(w))
-        return dt, dw, dmod.to(mod.dtype), None, None, None
+        return _own(dt), dw, dmod.to(mod.dtype), None, None, None
 
 
 def to_nhwc_bf16(x: torch.Tensor) -> torch.Tensor:

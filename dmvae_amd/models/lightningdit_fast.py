@@ -154,11 +154,16 @@ class GraphedInference:
         return self.out
 
 
+STACK_FN = True      # forward_train: all blocks as one functional.DitStackFn node (False: one DitBlockFn per block + LinearFn modulations; tests compare the two)
+
+
 def forward_train(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """`forward` with gradients (the student's flow-matching turn, train_dmd.py:565-575) under the caller's autocast(bf16): timestep / label embedders
     and the per-sample adaLN Linears through stock autograd, the patch embedding and the output Linear as `functional.LinearFn`, every block as one `functional.DitBlockFn`,
     the final norm as `RmsnormModulateFn`.  Label dropout as in the module (`y_embedder(y, model.training)`)."""
-    from ..functional import DitBlockFn, LinearFn, RmsnormModulateFn
+    from .. import functional as Fn
+    from ..functional import DitBlockFn, DitStackFn, LinearFn, RmsnormModulateFn
+    Fn._OWNED_GRADS.clear()
     b, cin, hh, ww = x.shape
     ps, c, heads = model.patch_size, model.hidden_size, model.num_heads
     w = model.x_embedder.proj.weight
@@ -167,7 +172,15 @@ def forward_train(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> t
     cvec = _t_embed(model, t, train=True).float() + model.y_embedder(y, model.training)      # the embedding lookup (and its index-add backward) is not a GEMM
     sc = F.silu(cvec)                                                             # adaLN_modulation[0] of every block: the same f32 values, computed once
     rope = model.feat_rope
-    for blk in model.blocks:
+    stack = STACK_FN and Fn.dit_stack_supported(b, h.shape[1], c, heads)
+    if stack:
+        params = []
+        for blk in model.blocks:
+            params += [blk.norm1.weight, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.q_norm.weight, blk.attn.k_norm.weight, blk.attn.proj.weight, blk.attn.proj.bias,
+                       blk.norm2.weight, blk.mlp.w12.weight, blk.mlp.w12.bias, blk.mlp.w3.weight, blk.mlp.w3.bias, blk.adaLN_modulation[1].weight,
+                       blk.adaLN_modulation[1].bias]
+        h = DitStackFn.apply(h, sc, rope.freqs_cos, rope.freqs_sin, heads, model.blocks[0].norm1.eps, *params)
+    for blk in (() if stack else model.blocks):
         lin = blk.adaLN_modulation[1]
         mod = LinearFn.apply(sc, lin.weight, lin.bias)                            # [B, 6C] bf16; one row per sample: csrc/linear_rows.hip forward and input gradient
         h = DitBlockFn.apply(h, mod, blk.norm1.weight, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.q_norm.weight, blk.attn.k_norm.weight,

@@ -81,11 +81,19 @@ def hip_path_supported(vit, seq_len: int) -> bool:
     return c in (256, 512, 768, 1024, 1280, 1536) and c // nh == 64 and seq_len <= 288
 
 
+NOGRAD_FUSED = True      # trainable_forward_features under no_grad takes the frozen route's fused kernels (False: the block Functions' forward; tests compare)
+
+
 def trainable_forward_features(vit, x: torch.Tensor) -> torch.Tensor:
     """`DinoV2ViT.forward_features` with gradients, for the stages where the encoder trains (train_dmd.py:349,519): patch embedding
     (one GEMM over patches), class token and position embedding through stock autograd, every transformer block as one `VitBlockFn` on the f32
     residual stream, the final LayerNorm as `LayerNormBf16Fn`.  Same arithmetic as the module under autocast(bf16)."""
     from ..functional import LayerNormBf16Fn, VitBlockFn
+    if not torch.is_grad_enabled() and NOGRAD_FUSED:
+        # graph-free call (the DMD stage's student-only steps, train_dmd.py:520-523: four of five steps): the frozen route's fused launches -- GELU in the fc1
+        # GEMM's epilogue, LayerScale + residual + the next LayerNorm as one pass -- on the live parameters (`functional.linear` reads the bf16 shadow their
+        # optimiser maintains); the same bits as the block Functions' forward (tests/test_gpu_vit_train.py)
+        return frozen_forward_features(vit, x)
     t = patch_embed_gemm(vit, x)
     t = torch.cat([vit.cls_token.expand(t.shape[0], -1, -1).float(), t.float()], dim=1) + vit.pos_embed.float()
     t = t.contiguous()

@@ -1186,6 +1186,145 @@ def qknorm_rope_bwd(dq, dk, dv, qkv, qw, kw, cos, sin, heads: int, eps: float = 
     return dqkv, dqw, dkw
 
 
+# ---- whole-stack LightningDiT backward + batched per-sample Linears (csrc/dit_stack.hip, linear_rows.hip) ---------------------------
+_PTR_TABLES = {}
+
+
+def ptr_table(tensors) -> torch.Tensor:
+    """Device array of the tensors' data pointers (int64), cached per pointer tuple: the per-layer weight / destination tables of the batched entry points.
+    The pointers of a model's parameters, of an optimiser's flat-buffer views and of cached operands are stable across steps, so a table is uploaded once."""
+    key = tuple(0 if t is None else t.data_ptr() for t in tensors)
+    dev = next(t for t in tensors if t is not None).device
+    hit = _PTR_TABLES.get((key, dev))
+    if hit is None:
+        if len(_PTR_TABLES) > 4096:
+            _PTR_TABLES.clear()
+        hit = torch.tensor(key, dtype=torch.int64).to(dev)
+        _PTR_TABLES[(key, dev)] = hit
+    return hit
+
+
+def linear_rows_batched(x: torch.Tensor, ws, biases=None, act: int = ACT_NONE, out_f32: bool = False) -> torch.Tensor:
+    """y [L, M, N] = act(x_l @ ws[l]^T + biases[l]) for L per-sample Linears of one shape in ONE launch (include/dmvae_hip.h dmvae_linear_rows_batched_bf16): x [M, K]
+    (one input for all layers) or [L, M, K] bf16; ws: L bf16 weights, all [N, K] row-major or all K-tile-major [K / 32, N, 32]; biases: L f32 / bf16 vectors or None."""
+    nl = len(ws)
+    if x.dim() == 2:
+        xs, x2 = 0, _req2d(x, "x")
+        m, k = x2.shape
+        ldx = x2.stride(0)
+    else:
+        x = _req(x, bf16, "x")
+        assert x.dim() == 3 and x.shape[0] == nl
+        m, k = x.shape[1], x.shape[2]
+        xs, ldx, x2 = m * k, k, x
+    w0 = ws[0]
+    if w0.dim() == 3:
+        n, layout, ldw = w0.shape[1], 1, 0
+        assert all(w.dtype == bf16 and w.is_contiguous() and w.shape == w0.shape for w in ws) and w0.shape[0] * 32 == k and w0.shape[2] == 32
+    else:
+        n, layout, ldw = w0.shape[0], 0, w0.stride(0)
+        assert all(w.dtype == bf16 and w.shape == w0.shape and w.stride() == w0.stride() and w.stride(1) == 1 for w in ws) and w0.shape[1] == k
+    bias_bf16 = 0
+    if biases is not None:
+        assert len(biases) == nl and all(b.is_contiguous() and b.numel() == n and b.dtype == biases[0].dtype for b in biases) and biases[0].dtype in (bf16, f32)
+        bias_bf16 = int(biases[0].dtype == bf16)
+    y = torch.empty(nl, m, n, dtype=f32 if out_f32 else bf16, device=x.device)
+    check(_lib.lib().dmvae_linear_rows_batched_bf16(x2.data_ptr(), xs, ptr_table(ws).data_ptr(), None if biases is None else ptr_table(biases).data_ptr(), y.data_ptr(),
+                                                    m * n, nl, m, n, k, ldx, ldw, n, int(act), bias_bf16, int(out_f32), layout, _stream()), "linear_rows_batched_bf16")
+    return y
+
+
+def rows_transposed(x: torch.Tensor) -> torch.Tensor:
+    """x [M, K] (M <= 64) -> bf16 [K, mp] with mp = 32 or 64 and zeros beyond M: the shared-input operand of `linear_rows_wgrad_batched`."""
+    m, k = x.shape
+    mp = 32 if m <= 32 else 64
+    xt = torch.zeros(k, mp, dtype=bf16, device=x.device)
+    xt[:, :m] = x.t()
+    return xt
+
+
+def linear_rows_wgrad_batched(dy: torch.Tensor, xt: torch.Tensor, dws, dbs=None, accumulate: bool = False) -> None:
+    """dws[l] [N, K] f32 (+)= dy[l]^T @ x, dbs[l] [N] f32 (+)= column sums of dy[l]: the weight / bias gradients of L per-sample Linears sharing their input x, in one
+    launch on the matrix cores.  dy [L, M, N] bf16; xt = rows_transposed(x)."""
+    dy = _req(dy, bf16, "dy")
+    nl, m, n = dy.shape
+    k, mp = xt.shape
+    assert xt.dtype == bf16 and xt.is_contiguous() and mp in (32, 64) and mp >= m and len(dws) == nl
+    assert all(w.dtype == f32 and w.is_contiguous() and w.numel() == n * k for w in dws)
+    if dbs is not None:
+        assert len(dbs) == nl and all(b.dtype == f32 and b.is_contiguous() and b.numel() == n for b in dbs)
+    check(_lib.lib().dmvae_linear_rows_wgrad_batched(dy.data_ptr(), m * n, xt.data_ptr(), mp, ptr_table(dws).data_ptr(), None if dbs is None else ptr_table(dbs).data_ptr(),
+                                                     None, None, nl, m, n, k, n, int(accumulate), _stream()), "linear_rows_wgrad_batched")
+
+
+def linear_weight_t_kmajor_batched(pairs) -> None:
+    """`linear_weight_t_kmajor` for a list of (src bf16 [N, K], dst bf16 [N / 32, K, 32]) in ONE launch; the table lives on the device, cached per pointer set."""
+    key = ("wt",) + tuple((s_.data_ptr(), d_.data_ptr()) for s_, d_ in pairs)
+    dev = pairs[0][0].device
+    hit = _PTR_TABLES.get((key, dev))
+    if hit is None:
+        import ctypes
+        assert _lib.lib().dmvae_wt_entry_bytes() == ctypes.sizeof(_lib.WtEntry)
+        arr = (_lib.WtEntry * len(pairs))()
+        start = 0
+        for i, (src, dst) in enumerate(pairs):
+            n, k = src.shape
+            assert src.dtype == bf16 and dst.dtype == bf16 and src.is_contiguous() and dst.is_contiguous() and n % 32 == 0 and k % 8 == 0 and dst.numel() == n * k
+            tx = (k + 63) // 64
+            arr[i] = _lib.WtEntry(src.data_ptr(), dst.data_ptr(), n, k, start, tx)
+            start += tx * (n // 32)
+        tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        hit = (tab, len(pairs), start)
+        _PTR_TABLES[(key, dev)] = hit
+    tab, cnt, total = hit
+    check(_lib.lib().dmvae_linear_weight_t_kmajor_batched(tab.data_ptr(), cnt, total, _stream()), "linear_weight_t_kmajor_batched")
+
+
+class DitStackBwd:
+    """Scratch of one whole-stack backward pass (functional.DitStackFn.backward): the boundary slots' partial sums, the deferred norm-weight partials of the QK-norm,
+    the row statistics -- see include/dmvae_hip.h (dmvae_dit_boundary_bwd, dmvae_dit_stack_finalize, dmvae_colsum2_batched)."""
+
+    def __init__(self, layers: int, batch: int, seq: int, c: int, heads: int, device):
+        L = _lib.lib()
+        self.layers, self.batch, self.seq, self.c, self.heads = layers, batch, seq, c, heads
+        self.d = c // heads
+        self.dp = (self.d + 31) // 32 * 32
+        self.bps = L.dmvae_dit_stack_bps(batch)
+        self.slot_elems = batch * self.bps * 4 * c
+        self.part = workspace(L.dmvae_dit_stack_part_bytes(layers, batch, c), device, "dit_stack_part").view(torch.float32)
+        self.ws_bytes = L.dmvae_dit_stack_workspace(layers, batch, seq, c)
+        self.ws = workspace(self.ws_bytes, device, "dit_stack_ws")
+        self.rowstat_ptr = self.ws.data_ptr() + 2 * layers * batch * c * 4
+        self.nblk = L.dmvae_qknorm_rope_bwd_nblk(batch, seq, heads, self.d, self.dp)
+        self.qk_part = workspace(layers * self.nblk * 2 * self.d * 4, device, "dit_stack_qk").view(torch.float32)
+
+    def boundary(self, slot: int, dt: torch.Tensor, da=None, x=None, w=None, mod=None, scale_off: int = 0, eps: float = 1e-6, y=None, gate_mod=None, gate_off: int = 0):
+        """The pass over dt at boundary `slot`: norm half when `da` is given, gate half (-> dy) when `y` is given."""
+        dy = torch.empty_like(y) if y is not None else None
+        check(_lib.lib().dmvae_dit_boundary_bwd(_ptr(da), _ptr(x), _ptr(w), _ptr(mod), mod.shape[-1] if mod is not None else 0, int(scale_off), float(eps), dt.data_ptr(),
+                                                _ptr(y), _ptr(gate_mod), gate_mod.shape[-1] if gate_mod is not None else 0, int(gate_off), _ptr(dy),
+                                                self.part.data_ptr() + slot * self.slot_elems * 4, self.rowstat_ptr, self.batch, self.seq, self.c, _stream()),
+              "dit_boundary_bwd")
+        return dy
+
+    def qknorm_rope_bwd(self, layer: int, dq, dk, dv, qkv, qw, kw, cos, sin, eps: float) -> torch.Tensor:
+        dqkv = torch.empty_like(qkv)
+        nbytes = self.nblk * 2 * self.d * 4
+        check(_lib.lib().dmvae_qknorm_rope_bwd_partial(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), qkv.data_ptr(), qw.data_ptr(), kw.data_ptr(), cos.data_ptr(),
+                                                       sin.data_ptr(), dqkv.data_ptr(), self.qk_part.data_ptr() + layer * nbytes, nbytes, self.batch, self.seq,
+                                                       self.heads, self.d, dq.shape[-1], float(eps), _stream()), "qknorm_rope_bwd_partial")
+        return dqkv
+
+    def finalize(self, dmod: torch.Tensor, norm_dws, qn_dws, kn_dws) -> None:
+        """dmod bf16 [L, B, 6C] <- every boundary's sums; norm_dws: 2 L f32 [C] destinations (norm1, norm2 of block 0, 1, ...); qn_dws / kn_dws: L f32 [D] each."""
+        L = _lib.lib()
+        assert dmod.dtype == bf16 and dmod.is_contiguous() and dmod.shape == (self.layers, self.batch, 6 * self.c) and len(norm_dws) == 2 * self.layers
+        check(L.dmvae_dit_stack_finalize(self.part.data_ptr(), dmod.data_ptr(), self.ws.data_ptr(), self.ws_bytes, ptr_table(norm_dws).data_ptr(), self.layers,
+                                         self.batch, self.seq, self.c, 0, _stream()), "dit_stack_finalize")
+        check(L.dmvae_colsum2_batched(self.qk_part.data_ptr(), ptr_table(qn_dws).data_ptr(), ptr_table(kn_dws).data_ptr(), self.layers, self.nblk, self.d, 0,
+                                      _stream()), "colsum2_batched")
+
+
 # ---- downstream consumers (sampler state update, image -> uint8) ---------------------------------------
 def sde_euler_step(x: torch.Tensor, v: torch.Tensor, w: Optional[torch.Tensor], rar: float, var: float, diff: float, dt: float, sqrt_2diff: float,
                    sqrt_dt: float, need_mean: bool = False):

@@ -56,6 +56,30 @@ class FlatParams:
             p._dmvae_shadow = self.shadow[off:off + p.numel()].view(p.shape)
             p._dmvae_shadow_ver = (p.data_ptr(), p._version)
 
+    def enable_transposed_shadow(self, only=None) -> None:
+        """Keep, next to the bf16 shadow, the K-tile-major bf16 copy of the TRANSPOSE of every 2-D Linear weight [out, in] (out % 32 == 0, in % 8 == 0) -- the operand
+        of its input gradient dX = dY . W (`functional._bf_t`) -- refreshed by ONE batched transpose launch after every optimiser step (`refresh_transposed`), instead
+        of one ~6.6-us launch per weight on its first use in the backward pass (142 per step for LightningDiT-XL/1).  Needs `enable_bf16_shadow` first."""
+        assert getattr(self, "shadow", None) is not None, "enable_bf16_shadow() first"
+        ids = None if only is None else {id(p) for p in only}
+        self.shadow_t = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat.device)
+        self._t_pairs, self._t_params = [], []
+        for p, off in zip(self.params, self.offsets):
+            if p.dim() == 2 and p.shape[0] % 32 == 0 and p.shape[1] % 8 == 0 and (ids is None or id(p) in ids):
+                dst = self.shadow_t[off:off + p.numel()].view(p.shape[0] // 32, p.shape[1], 32)
+                self._t_pairs.append((self.shadow[off:off + p.numel()].view(p.shape), dst))
+                self._t_params.append(p)
+                p._dmvae_shadow_t = dst
+                p._dmvae_shadow_t_key = None
+        self.refresh_transposed()
+
+    def refresh_transposed(self) -> None:
+        if not getattr(self, "_t_pairs", None):
+            return
+        ops.linear_weight_t_kmajor_batched(self._t_pairs)
+        for p in self._t_params:
+            p._dmvae_shadow_t_key = (p.data_ptr(), p._version, self.epoch[0])
+
     def enable_direct_grads(self, only=None) -> None:
         """The HIP backward Functions (dmvae_amd.functional) then WRITE each parameter gradient straight into its slice of the
         flat buffer and hand that view to autograd, instead of returning a fresh tensor that AccumulateGrad adds into `.grad`
@@ -129,6 +153,7 @@ class FlatParams:
             self.shadow.copy_(self.flat)
             for p in self.params:
                 p._dmvae_shadow_ver = (p.data_ptr(), p._version)
+            self.refresh_transposed()
         if reset_ema and self.ema is not None:
             self.ema.copy_(self.flat)
 
@@ -163,6 +188,7 @@ class FlatAdamWEMA:
                            lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, self.ema_decay, shadow=getattr(self.fp, "shadow", None))
         self.fp.epoch[0] += 1       # weights changed through raw pointers: the cached bf16 operands of THESE parameters are stale ...
         Fn.repack_all(self.fp.pack_reg, self.fp.epoch)     # ... and the packed conv operands among them are rewritten here, in one launch
+        self.fp.refresh_transposed()                       # ... like the transposed Linear operands (when enabled)
         return self.norm            # device tensor; no host sync
 
     # ---- checkpoint / resume (train_tokenizer.py:440-450 saves opt_vae / opt_disc / scheduler_*; train_dmd.py:577-590; train_diffusion.py:318-325) ----

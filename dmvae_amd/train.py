@@ -365,6 +365,7 @@ class DMDTrainer(_AdversarialBranch):
                 pre += ("encoder.model.blocks.", "encoder.model.norm.")      # else the encoder runs on the stock modules and autograd owns its gradients
             self.fp.enable_direct_grads(only=[p for n_, p in vae.named_parameters() if p.requires_grad and n_.startswith(pre)])
         self.fp.enable_bf16_shadow()          # Linear weights of the trainable ViT / bottleneck: bf16 GEMM operands written by the optimiser step
+        self.fp.enable_transposed_shadow()    # ... and their transposed copies (the input-gradient operands) by one batched launch after it
         self.opt = FlatAdamWEMA(self.fp, lr=lr, weight_decay=wd, warmup_steps=warmup_steps, max_norm=max_norm)
         self.sync = dist.FlatGradSync(params, self.fp.grad, self.fp.offsets, bucket_bytes=bucket_bytes)
         # the student's AdamW (train_dmd.py:473, :565-575) on flat buffers like the VAE's: one norm pass + one fused update instead of torch's
@@ -374,6 +375,7 @@ class DMDTrainer(_AdversarialBranch):
         if sp:
             self.sfp = FlatParams(sp, with_ema=False)
             self.sfp.enable_bf16_shadow()
+            self.sfp.enable_transposed_shadow()      # 142 Linear weights of LightningDiT-XL/1: one transpose launch per step instead of one per weight
             # every block parameter, the adaLN modulation Linears included (functional.LinearFn on csrc/linear_rows.hip writes their gradients in place too: a
             # third of the model's parameters, 28 x 32 MB of accumulate launches per step before); one gradient per parameter and backward: the student's own turn
             direct = [p for n_, p in student.named_parameters() if p.requires_grad and n_.startswith("blocks.")]
@@ -575,6 +577,7 @@ class DiffusionTrainer:
         params = [p for p in model.parameters() if p.requires_grad]
         self.fp = FlatParams(params, with_ema=True)
         self.fp.enable_bf16_shadow()
+        self.fp.enable_transposed_shadow()
         direct = [p for n_, p in model.named_parameters() if p.requires_grad and n_.startswith("blocks.")]      # adaLN modulations included: see DMDTrainer
         if isinstance(model, LightningDiT) and direct:
             self.fp.enable_direct_grads(only=direct)

@@ -31,7 +31,9 @@ const char* dmvae_last_error(void);
 /* ABI version; bumped when a signature or a struct changes.  2: dmvae_conv_desc gained its last field, w_layout (zero = the behaviour of version 1).
  * 3: struct dmvae_pack_entry and the entry points that take it (dmvae_pack_weights_batched), dmvae_linear_bf16 / _plan / dmvae_linear_weight_t_kmajor.
  * 4: dmvae_norm_conv_out_bwd / _supported / _workspace, dmvae_norm_conv_out_fwd / _supported, dmvae_conv_in3 / _supported / _workspace, dmvae_im2col_nhwc_taps, dmvae_linear_bf16_batched / _supported, dmvae_conv_to_image / _supported.
- * 5: dmvae_groupnorm_apply_short / _bwd_short / _short_supported / _bwd_short_workspace, dmvae_lpips_diff_pool. */
+ * 5: dmvae_groupnorm_apply_short / _bwd_short / _short_supported / _bwd_short_workspace, dmvae_lpips_diff_pool.
+ * 6: the whole-stack LightningDiT backward (dmvae_dit_boundary_bwd, dmvae_dit_stack_*, dmvae_colsum2_batched, dmvae_qknorm_rope_bwd_partial / _nblk), the batched
+ *    per-sample Linears (dmvae_linear_rows_batched_bf16, dmvae_linear_rows_wgrad_batched), dmvae_linear_weight_t_kmajor_batched / dmvae_wt_entry_bytes. */
 int dmvae_abi_version(void);
 
 /* ---- convolution / GEMM (MFMA-bound) -------------------------------------------------------- */
@@ -461,6 +463,52 @@ int dmvae_qknorm_rope_bwd(const void* dq, const void* dk, const void* dv, const 
                           const void* cos_table, const void* sin_table, void* dqkv, void* dq_weight, void* dk_weight, void* workspace,
                           size_t workspace_bytes, int batch, int seq, int heads, int head_dim, int head_dim_padded, float eps, int accumulate,
                           dmvae_stream_t stream);
+
+/* First stage of dmvae_qknorm_rope_bwd only: dqkv is written, the per-block partial sums of the two norm-weight gradients stay in `part`
+ * ([dmvae_qknorm_rope_bwd_nblk(...)][2][head_dim] f32) for a reduction batched over layers (dmvae_colsum2_batched). */
+int dmvae_qknorm_rope_bwd_nblk(int batch, int seq, int heads, int head_dim, int head_dim_padded);
+int dmvae_qknorm_rope_bwd_partial(const void* dq, const void* dk, const void* dv, const void* qkv, const void* q_weight, const void* k_weight,
+                                  const void* cos_table, const void* sin_table, void* dqkv, void* part, size_t part_bytes, int batch, int seq, int heads,
+                                  int head_dim, int head_dim_padded, float eps, dmvae_stream_t stream);
+
+/* Whole-stack backward of LightningDiT's blocks (diffusion/lightningdit/lightningdit.py:236-250 x depth; the student's flow-matching step, train_dmd.py:565-575,
+ * train_diffusion.py:290-297) -- csrc/dit_stack.hip, driven by dmvae_amd/functional.py::DitStackFn.
+ * dmvae_dit_boundary_bwd: one pass over the f32 residual-stream gradient dx_io [B][seq][c] at a sub-layer boundary.  Norm half (da != NULL): dx_io += backward of
+ *   a = bf16(RMSNorm(x) * w * bf16(1 + scale[b]) + shift[b]) for the incoming da (bf16), x the stream the norm read (f32), mod bf16 [B][mod_stride] with the scale
+ *   chunk at scale_off; per-sample partial sums of d shift, d scale, d w.  Gate half (y != NULL): dy = bf16(gate[b] * dx_io) and the partial sums of
+ *   d gate[b] = sum_n dx_io * y for the gated residual x_out = x + bf16(gate * y) met NEXT on the way back (y its branch output, bf16; gate_mod bf16 [B][gate_stride]
+ *   with the gate chunk at gate_off), computed from the UPDATED dx_io.  part_slot: this boundary's [B][dmvae_dit_stack_bps(B)][4][c] f32 slice of the stack's
+ *   partial-sum array (slot order below); rowstat: B * seq float2 scratch (the tail of dmvae_dit_stack_workspace).
+ * dmvae_dit_stack_finalize: after the last boundary, ONE reduction of all 2 L + 1 slots -- slot 2 l: norm1 of block l (+ the MLP gate of block l - 1 for l > 0),
+ *   slot 2 l + 1: norm2 of block l + the attention gate of block l, slot 2 L: the MLP gate of block L - 1 alone -- into dmod bf16 [L][B][6 c] (adaLN chunk order:
+ *   shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp) and the norm-weight gradients dw_table[2 l] (norm1 of block l) / [2 l + 1] (norm2): device array
+ *   of 2 L pointers to f32 [c] (accumulate != 0 adds).  Two-stage, fixed order: deterministic. */
+int dmvae_dit_stack_bps(int batch);
+size_t dmvae_dit_stack_part_bytes(int layers, int batch, int c);
+size_t dmvae_dit_stack_workspace(int layers, int batch, int seq, int c);
+int dmvae_dit_boundary_bwd(const void* da, const void* x, const void* w, const void* mod, int mod_stride, int scale_off, float eps, void* dx_io, const void* y,
+                           const void* gate_mod, int gate_stride, int gate_off, void* dy, void* part_slot, void* rowstat, int batch, int seq, int c,
+                           dmvae_stream_t stream);
+int dmvae_dit_stack_finalize(const void* part, void* dmod, void* workspace, size_t workspace_bytes, const void* dw_table, int layers, int batch, int seq, int c,
+                             int accumulate, dmvae_stream_t stream);
+/* part [layers][nblk][2][d] f32 -> o0_table[l][d], o1_table[l][d] (device arrays of `layers` pointers to f32 [d]): the second stage of
+ * dmvae_qknorm_rope_bwd_partial for every layer in one launch. */
+int dmvae_colsum2_batched(const void* part, const void* o0_table, const void* o1_table, int layers, int nblk, int d, int accumulate, dmvae_stream_t stream);
+/* dmvae_linear_rows_bf16 for `layers` Linears of one shape in one launch (adaLN_modulation[1] of every block: lightningdit.py:236-240): w_table / bias_table device
+ * arrays of `layers` pointers (bias_table may be NULL), x / y advanced by x_layer_stride / y_layer_stride ELEMENTS per layer (x_layer_stride 0: one x for all). */
+int dmvae_linear_rows_batched_bf16(const void* x, long long x_layer_stride, const void* w_table, const void* bias_table, void* y, long long y_layer_stride, int layers,
+                                   int M, int N, int K, int ldx, int ldw, int ldy, int act, int bias_bf16, int out_f32, int w_layout, dmvae_stream_t stream);
+/* Weight + bias gradients of `layers` per-sample Linears sharing their input, on the matrix cores: dW_l [N][K] f32 (+)= dY_l [M][N]^T . X [M][K], db_l [N] f32 (+)=
+ * column sums of dY_l; dy bf16 [layers][M][lddy] (dy_layer_stride elements apart), xT = X TRANSPOSED, bf16 [K][mp] with mp = 32 or 64 >= M and zeros beyond M;
+ * dw_table / db_table: device arrays of `layers` pointers (db_table may be NULL), or NULL tables with layers = 1 and dw / db given directly.  1 <= M <= 64, K % 8 == 0.
+ * Bound by writing the f32 gradients; deterministic. */
+int dmvae_linear_rows_wgrad_batched(const void* dy, long long dy_layer_stride, const void* xT, int mp, const void* dw_table, const void* db_table, void* dw, void* db,
+                                    int layers, int M, int N, int K, int lddy, int accumulate, dmvae_stream_t stream);
+/* dmvae_linear_weight_t_kmajor for a table of weights in one launch (every Linear weight of a trainable transformer after its optimiser step).  table: device array of
+ * n_entries records {const void* src; void* dst; int32 N, K; uint32 start, tiles_x} (dmvae_wt_entry_bytes() bytes each), entry e owning the flat tiles
+ * [start_e, start_e + tiles_x * N / 32), tiles_x = ceil(K / 64); total_tiles = their sum. */
+size_t dmvae_wt_entry_bytes(void);
+int dmvae_linear_weight_t_kmajor_batched(const void* table, int n_entries, unsigned total_tiles, dmvae_stream_t stream);
 
 /* ---- losses (HBM-bound reductions) ------------------------------------------------------------- */
 

@@ -54,7 +54,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.dmvae_groupnorm_workspace(2, 64, 128, 32) > 0
     assert lib.dmvae_kl_mmd(p, p, p, p, None, p, 1 << 20, 2, 16, 16, 16, 1.0, 1.0, None) == -22   # d != 32
     assert lib.dmvae_adamw_ema_step(p, p, p, p, None, None, 4, 1e-4, 0.9, 0.95, 1e-8, 0.0, 0, 0.999, None) == -22  # step 0
-    assert lib.dmvae_abi_version() == 5
+    assert lib.dmvae_abi_version() == 6
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -101,7 +101,7 @@ assert lib.dmvae_groupnorm_workspace(2, 64, 100, 32) == 0 and lib.dmvae_groupnor
 assert lib.dmvae_conv_out_wgrad_workspace(32, 256, 256, 128, 3) > 0
 assert lib.dmvae_gemm_tn_batched_workspace(64, 64, 4096, 8) >= 0
 assert lib.dmvae_vit_bwd_workspace(1024) > 0
-assert lib.dmvae_abi_version() == 5
+assert lib.dmvae_abi_version() == 6
 print("asan-ok")
 """
 

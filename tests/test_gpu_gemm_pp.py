@@ -217,11 +217,11 @@ torch.save(out, sys.argv[1])
 def test_every_tile_of_the_menu_gives_the_same_bits(tmp_path):
     """dmvae_debug_gemm_cfg forces one menu entry; each runs in a fresh process (first-launch attributes, caches)."""
     res = []
-    for cfg in range(10):
+    for cfg in range(12):
         f = tmp_path / ("cfg%d.pt" % cfg)
         subprocess.run([sys.executable, "-c", _TILE_SCRIPT % ROOT, str(f), str(cfg)], check=True, timeout=600)
         res.append(torch.load(f))
-    for cfg in range(1, 10):
+    for cfg in range(1, 12):
         for key in res[0]:
             assert torch.equal(res[0][key], res[cfg][key]), f"tile {cfg} differs from tile 0 at {key}"
 

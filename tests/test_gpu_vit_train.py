@@ -175,3 +175,22 @@ def test_no_grad_encoder_reads_the_live_shadow_after_optimiser_steps():
         fp.begin_step()
         fp.grad.copy_(torch.randn(fp.numel, generator=torch.Generator().manual_seed(10 + step)).to(DEV))
         opt.step()
+
+
+def test_no_grad_trainable_forward_takes_the_fused_route_with_the_same_bits():
+    """`trainable_forward_features` under no_grad (the DMD stage's student-only steps, train_dmd.py:520-523) runs the frozen route's fused launches (GELU in the
+    fc1 epilogue, LayerScale + residual + next LayerNorm in one pass): the same tokens, bit for bit, as the block Functions' forward it replaces there."""
+    from dmvae_amd.models import vit_fast
+    vit = _vit(1024, 2, 16, 256, seed=11)
+    x = torch.randn(3, 3, 256, 256, generator=torch.Generator().manual_seed(5)).to(DEV)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        vit_fast.NOGRAD_FUSED = False
+        try:
+            y_fn = vit_fast.trainable_forward_features(vit, x).clone()
+        finally:
+            vit_fast.NOGRAD_FUSED = True
+        y_fused = vit_fast.trainable_forward_features(vit, x)
+    assert y_fn.dtype == y_fused.dtype and torch.equal(y_fn, y_fused)
+    with torch.autocast("cuda", dtype=torch.bfloat16):          # with gradients enabled nothing changes: the Function route, a graph
+        y_g = vit_fast.trainable_forward_features(vit, x)
+    assert y_g.requires_grad and torch.equal(y_g.detach(), y_fused)
