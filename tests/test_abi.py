@@ -91,7 +91,7 @@ for m in (64, 257, 4096, 8224, 16384, 524288):
     for n in (8, 72, 1024, 1152, 3456, 6144):
         for k in (384, 1024, 3072):
             c = lib.dmvae_linear_bf16_plan(m, n, k, ctypes.byref(tc), ctypes.byref(tr))
-            assert 0 <= c < 10 and tc.value in (128, 192, 256) and tr.value %% 32 == 0
+            assert 0 <= c < 12 and tc.value in (128, 192, 256) and tr.value %% 32 == 0
 for (n, h, w, ci, co, ks) in [(32, 16, 16, 512, 512, 3), (32, 256, 256, 128, 128, 3), (2, 64, 64, 256, 512, 1), (1, 8, 8, 32, 64, 3), (32, 128, 128, 512, 256, 3)]:
     d = ConvDesc(n, h, w, ci, co, ks, 0, 0, 0)
     assert lib.dmvae_conv_halo_applies(ctypes.byref(d)) in (0, 1)
@@ -101,6 +101,18 @@ assert lib.dmvae_groupnorm_workspace(2, 64, 100, 32) == 0 and lib.dmvae_groupnor
 assert lib.dmvae_conv_out_wgrad_workspace(32, 256, 256, 128, 3) > 0
 assert lib.dmvae_gemm_tn_batched_workspace(64, 64, 4096, 8) >= 0
 assert lib.dmvae_vit_bwd_workspace(1024) > 0
+# round 5: the whole-stack DiT backward's sizing functions and the batched entry points' argument validation
+for bsz in (1, 16, 64, 2048):
+    assert 4 <= lib.dmvae_dit_stack_bps(bsz) <= 32
+    assert lib.dmvae_dit_stack_part_bytes(28, bsz, 1152) == (2 * 28 + 1) * bsz * lib.dmvae_dit_stack_bps(bsz) * 4 * 1152 * 4
+    assert lib.dmvae_dit_stack_workspace(28, bsz, 256, 1152) > 0
+assert 0 < lib.dmvae_qknorm_rope_bwd_nblk(16, 256, 16, 72, 96) <= 2048
+assert lib.dmvae_dit_boundary_bwd(None, None, None, None, 0, 0, 1e-6, p, None, None, 0, 0, None, p, p, 2, 8, 64, None) == -22      # neither half requested
+assert lib.dmvae_dit_boundary_bwd(p, p, p, p, 384, 65, 1e-6, p, None, None, 0, 0, None, p, p, 2, 8, 64, None) == -22                # scale offset not a multiple of 4
+assert lib.dmvae_linear_rows_wgrad_batched(p, 0, p, 48, p, None, None, None, 2, 16, 64, 64, 64, 0, None) == -22                      # mp must be 32 or 64
+assert lib.dmvae_linear_rows_batched_bf16(p, 0, p, None, p, 0, 2, 65, 64, 64, 64, 64, 64, 0, 0, 0, 0, None) == -22                   # more than 64 rows
+assert lib.dmvae_linear_weight_t_kmajor_batched(None, 0, 0, None) == -22
+assert lib.dmvae_wt_entry_bytes() == 32
 assert lib.dmvae_abi_version() == 6
 print("asan-ok")
 """
