@@ -120,6 +120,12 @@ SIGNATURES = {
     "dmvae_linear_rows_wgrad_batched": (c_int, [c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "dmvae_wt_entry_bytes": (c_size_t, []),
     "dmvae_linear_weight_t_kmajor_batched": (c_int, [c_void_p, c_int, c_uint, c_void_p]),
+    "dmvae_linear_wgrad_grouped_entry_bytes": (c_size_t, []),
+    "dmvae_linear_wgrad_grouped_bias_entry_bytes": (c_size_t, []),
+    "dmvae_linear_wgrad_grouped_supported": (c_int, [c_int] * 3),
+    "dmvae_linear_wgrad_grouped_bias_parts": (c_int, [c_int]),
+    "dmvae_linear_wgrad_grouped_fill": (c_int, [c_void_p] * 7 + [c_int] * 3 + [POINTER(c_uint), POINTER(c_uint)]),
+    "dmvae_linear_wgrad_grouped": (c_int, [c_void_p, c_int, c_uint, c_int, c_void_p, c_int, c_uint, c_void_p]),
     "dmvae_gated_residual_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_loss_workspace": (c_size_t, []),
     "dmvae_l1_mse": (c_int, [c_void_p] * 5 + [c_size_t, c_size_t, c_float, c_float, c_void_p]),

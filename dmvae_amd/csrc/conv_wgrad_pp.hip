@@ -73,8 +73,10 @@ __device__ __forceinline__ s16x4 tr_read(unsigned lds_addr) {
 // wave between barriers against the 256 x 256 tile's 32 with the same four DMA issues per wave, and its LOAD interval, not its COMPUTE interval, set the pace.
 // KP = 64 (HALO only): a K tile is 64 pixels -- two 32-pixel halves of the dy operand and one 66-pixel halo tile (68 LDS rows, 17 pieces); 48 MFMAs per wave between
 // barriers instead of 24 against 40 fragment reads and 4-5 DMA issues: the 24-MFMA COMPUTE interval (384 cycles) sat under a ~600-cycle LOAD interval.
-template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false, bool UPS = false, int KP = 32>
-__global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
+// RAGGED (the grouped Linear form only): M need not be a multiple of 32 -- the rows of the last K tile past M are masked per lane (the descriptors' range check does
+// not see the scalar K-tile offset, so it cannot do it)
+template <int GA, int GB, int WM, int WN, bool S2, bool HALO, bool UPS, int KP, bool RAGGED>
+__device__ __forceinline__ void wgrad_pp_body(const Args& a, const unsigned flat_block, const unsigned total_blocks) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int TM = GA * 128, TN = GB * 128;
   constexpr int BM = TM / WM / 16, BN = TN / WN / 16;  // 16 x 16 output blocks per wave
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   const int wm = wave / WN, wn = wave % WN;
   const int T = a.ks * a.ks;
 
-  const unsigned wid = (unsigned)uni((int)xcd_remap(blockIdx.x, gridDim.x));
+  const unsigned wid = (unsigned)uni((int)xcd_remap(flat_block, total_blocks));
   const int tiles = a.mtiles * a.ntiles;
   const int split = uni((int)(wid / tiles));
   const int tile = uni((int)(wid - (unsigned)split * tiles));
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   const int g0 = (tile - mt * a.ntiles) * GB;  // first column group of this block
   const int k0 = split * a.kchunk;
   const int k1 = min(k0 + a.kchunk, a.M);
-  const int nK = (k1 - k0) / KP;
+  const int nK = RAGGED ? (k1 - k0 + KP - 1) / KP : (k1 - k0) / KP;
 
   // ---- descriptors: dy is linear in the pixel index; the activation base is shifted so every tap offset is >= 0 -------
   const unsigned dybytes = (unsigned)a.M * a.Cout * 2u;
@@ -123,10 +125,12 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   // piece pb (0 .. 8*G-1): sub-tile pb / 8, pixel rows 4*(pb % 8) .. +3; lane -> row + lane/16, physical 16-B chunk lane%16
   const int cphys = lane & 15;
   unsigned voffA[NPA];
+  int rowA[NPA];   // RAGGED: the piece's pixel row inside the K tile
 #pragma unroll
   for (int p = 0; p < NPA; p++) {
     const int pb = wave * NPA + p;
     const int sub = pb >> 3, row = (pb & 7) * 4 + (lane >> 4);
+    rowA[p] = (KH == 2 ? sub * 32 : 0) + row;
     const int clog = ((((cphys >> 1) ^ (((row & 3) << 1) | ((row >> 3) & 1))) << 1) | (cphys & 1)) * 8;
     // KH == 1: sub-tile = 128-channel group of the block's couts; KH == 2 (GA == 1): sub-tile = 32-pixel half of the K tile
     const int co = co0 + (KH == 2 ? 0 : sub * 128) + clog;
@@ -230,10 +234,11 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
   auto issue = [&](int slot) {
     const bool live = it < nK;
     const unsigned soA = (unsigned)pt * a.Cout * 2u;
+    const int left = a.M - pt;   // RAGGED: rows of this K tile that exist
 #pragma unroll
     for (int p = 0; p < NPA; p++) {
       const int pb = wave * NPA + p;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + slot + pb * 1024), 16, live ? voffA[p] : SENT, soA, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LPTR(smem + slot + pb * 1024), 16, (live && (!RAGGED || rowA[p] < left)) ? voffA[p] : SENT, soA, 0, 0);
     }
 #pragma unroll
     for (int p = 0; p < NPB; p++) {
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
       } else {
         so = (unsigned)pt * a.Cin * 2u + tapoB[p];
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + ASZ + pb * 1024), 16, (live && yok) ? v : SENT, yok ? so : 0u, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LPTR(smem + slot + ASZ + pb * 1024), 16, (live && yok && (!RAGGED || rowB[p] < left)) ? v : SENT, yok ? so : 0u, 0, 0);
     }
     it++;
     pt += KP;
@@ -379,6 +384,43 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
 }
 
 template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false, bool UPS = false, int KP = 32>
+__global__ __launch_bounds__(512) void wgrad_pp_kernel(Args a) {
+  wgrad_pp_body<GA, GB, WM, WN, S2, HALO, UPS, KP, false>(a, blockIdx.x, gridDim.x);
+}
+
+// Grouped form: ONE launch for a table of independent Linear weight gradients dW_p [Cout_p][Cin_p] = dY_p^T . X_p (ks = 1), every problem unsplit (its whole
+// reduction in one block per 256 x 256 output tile, written straight to its destination: no slabs, no reduce launch) -- for call sites that hold many of them at
+// once: the four Linears x 28 blocks of LightningDiT's backward pass (7700 tiles = 30 full rounds of the chip, where one weight gradient at batch 16 is 25-120 tiles
+// and needed a 2- to 8-way split-K plus a slab reduce to fill it), the four Linears of a ViT block.  Entry p owns the flat blocks [start_p, start_p + mtiles_p * ntiles_p).
+struct GEntry { Args a; unsigned start, blocks; };
+template <bool RAGGED>
+__global__ __launch_bounds__(512) void wgrad_pp_grouped_kernel(const GEntry* __restrict__ tab, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {   // last entry whose start <= blockIdx.x (block-uniform: scalar loads)
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].start <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int p = __builtin_amdgcn_readfirstlane(lo);
+  const Args a = tab[p].a;
+  wgrad_pp_body<2, 2, 2, 4, false, false, false, 32, RAGGED>(a, blockIdx.x - tab[p].start, tab[p].blocks);
+}
+// bias gradients of the grouped launch: db_p[c] = sum over the problem's ntiles_p partial rows (the bias sums ride the matrix pipe round-robin over a cout tile's blocks)
+struct GBias { const float* part; float* out; int nparts, C; unsigned start; };
+__global__ __launch_bounds__(256) void wgrad_grouped_bias_kernel(const GBias* __restrict__ tab, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].start <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const GBias e = tab[lo];
+  const int c = (int)(blockIdx.x - e.start) * 256 + threadIdx.x;
+  if (c >= e.C) return;
+  float s = 0.f;
+  for (int k = 0; k < e.nparts; k++) s += e.part[(size_t)k * e.C + c];
+  e.out[c] = s;
+}
+
+template <int GA, int GB, int WM, int WN, bool S2 = false, bool HALO = false, bool UPS = false, int KP = 32>
 int launch(const Args& a, int splits, hipStream_t st) {
   constexpr int lds = (HALO ? (KP == 64 ? 4 : WG_NBUF) : WG_NBUF) * (GA * KP + (HALO ? KP + 4 : GB * 32)) * 256;
   static bool attr_done = false;
@@ -476,4 +518,59 @@ int dmvae_wgrad_pp_launch(const void* dy, const void* act, float* slab, float* b
   if (wgrad_pp_halo_on() && !s2 && d->ks == 3 && !a.ups) return launch<1, 3, 2, 4, false, true>(a, splits, stream);
   if (a.ups) return launch<1, 3, 2, 4, false, false, true>(a, splits, stream);
   return s2 ? launch<1, 3, 2, 4, true>(a, splits, stream) : launch<1, 3, 2, 4>(a, splits, stream);
+}
+
+
+// ---- grouped Linear weight gradients (see wgrad_pp_grouped_kernel) ---------------------------------------------------------------------------------
+extern "C" size_t dmvae_linear_wgrad_grouped_entry_bytes(void) { return sizeof(dmvae_wgrad_pp::GEntry); }
+extern "C" size_t dmvae_linear_wgrad_grouped_bias_entry_bytes(void) { return sizeof(dmvae_wgrad_pp::GBias); }
+extern "C" int dmvae_linear_wgrad_grouped_supported(int M, int cout, int cin) {
+  return (M >= 32 && cout >= 128 && cin >= 128 && cout % 128 == 0 && cin % 128 == 0 && (long long)M * cout * 2 < (1ll << 31) && (long long)M * cin * 2 + (1ll << 22) < (1ll << 31)) ? 1 : 0;
+}
+// Fill host-side table records for one problem: dy [M][cout], x [M][cin] bf16 row-major, dw f32 [cout][cin] (written, not accumulated), bias_part f32 scratch of
+// dmvae_linear_wgrad_grouped_bias_parts(cin) * cout floats and db f32 [cout] (both NULL: no bias gradient).  *start is advanced by the problem's block count, *bias_start
+// by its bias blocks.  Returns 0, or -22 on a shape the kernel does not take.
+extern "C" int dmvae_linear_wgrad_grouped_bias_parts(int cin) { return ((cin / 128) + 1) / 2; }
+extern "C" int dmvae_linear_wgrad_grouped_fill(void* entry, void* bias_entry, const void* dy, const void* x, void* dw, void* bias_part, void* db, int M, int cout, int cin,
+                                               unsigned* start, unsigned* bias_start) {
+  using namespace dmvae_wgrad_pp;
+  DMVAE_CHECK_ARG(entry && dy && x && dw && start && bias_start && (!db || (bias_part && bias_entry)), "linear_wgrad_grouped_fill: null pointer");
+  DMVAE_CHECK_ARG(dmvae_linear_wgrad_grouped_supported(M, cout, cin), "linear_wgrad_grouped_fill: M=%d cout=%d cin=%d (M >= 32, cout / cin multiples of 128, operands < 2 GiB)", M, cout, cin);
+  GEntry g;
+  Args& a = g.a;
+  a.dy = (const bf16*)dy; a.a = (const bf16*)x; a.slab = (float*)dw; a.bslab = db ? (float*)bias_part : nullptr;
+  a.N = 1; a.Hi = 1; a.Wi = M; a.Cin = cin; a.Ho = 1; a.Wo = M; a.Cout = cout; a.ks = 1; a.ups = 0; a.M = M;
+  a.kchunk = (M + 31) / 32 * 32;
+  a.gpt = cin / 128; a.ngroups = a.gpt;
+  a.mtiles = (cout + 255) / 256; a.ntiles = (a.ngroups + 1) / 2;
+  g.blocks = (unsigned)(a.mtiles * a.ntiles);
+  g.start = *start;
+  *start += g.blocks;
+  *reinterpret_cast<GEntry*>(entry) = g;
+  if (db) {
+    GBias b{(const float*)bias_part, (float*)db, a.ntiles, cout, *bias_start};
+    *bias_start += (unsigned)((cout + 255) / 256);
+    *reinterpret_cast<GBias*>(bias_entry) = b;
+  }
+  return 0;
+}
+extern "C" int dmvae_linear_wgrad_grouped(const void* table, int n, unsigned total_blocks, int ragged, const void* bias_table, int n_bias, unsigned bias_blocks,
+                                          hipStream_t stream) {
+  using namespace dmvae_wgrad_pp;
+  DMVAE_CHECK_ARG(table && n > 0 && total_blocks > 0, "linear_wgrad_grouped: empty table");
+  constexpr int lds = WG_NBUF * (2 * 32 + 2 * 32) * 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_grouped_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_grouped_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  if (ragged) hipLaunchKernelGGL(wgrad_pp_grouped_kernel<true>, dim3(total_blocks), dim3(512), lds, stream, (const GEntry*)table, n);
+  else hipLaunchKernelGGL(wgrad_pp_grouped_kernel<false>, dim3(total_blocks), dim3(512), lds, stream, (const GEntry*)table, n);
+  DMVAE_CHECK_LAUNCH();
+  if (bias_table && n_bias > 0 && bias_blocks > 0) {
+    hipLaunchKernelGGL(wgrad_grouped_bias_kernel, dim3(bias_blocks), dim3(256), 0, stream, (const GBias*)bias_table, n_bias);
+    DMVAE_CHECK_LAUNCH();
+  }
+  return 0;
 }

@@ -442,7 +442,7 @@ static const Cfg g_cfg[] = {
     // 160 / 132 tiles of 256 x 128 -- half to two thirds of the chip; these split them into 192 / 198 smaller tiles
     {192, 128, 0.54f}, {128, 192, 0.54f},
 };
-constexpr int NCFG = sizeof(g_cfg) / sizeof(g_cfg[0]), NPLAN = 12;
+constexpr int NCFG = sizeof(g_cfg) / sizeof(g_cfg[0]);
 
 static int g_forced = -1;   // -1: plan by cost; >= 0: this menu entry (dmvae_debug_gemm_cfg: tools/bench_gemm.py's sweep, tests/test_gpu_gemm_pp.py)
 // Time model: tiles / 256 rounds of the tile's cost -- FRACTIONAL rounds, because the chip is power-limited: with half of the CUs idle in the last round the
@@ -452,9 +452,13 @@ static int plan(int M, int N, int K, bool gated = false) {
   const int forced = g_forced;
   if (forced >= 0 && forced < NCFG && !(gated && g_cfg[forced].tm == 192)) return forced;
   (void)K;
+  // the two round-5 tiles (entries 10, 11) are in the menu but not in the plan by default: isolated (tools/bench_gemm.py --sweep --cold, profiles/r5_gemm_sweep_m4096.txt) they
+  // win ViT-L's N = 1024 Linears at 16 x 257 tokens by 13-17 %, inside the DMD stage's step the same launches ran 1.2 ms per step SLOWER than on 256 x 128
+  // (profiles/r5_dmd_tiles_ab.txt) -- DMVAE_GEMM_NPLAN=12 plans over them
+  static const int nplan = [] { const char* e = getenv("DMVAE_GEMM_NPLAN"); const int v = e ? atoi(e) : 10; return v < 1 ? 1 : (v > NCFG ? NCFG : v); }();
   int best = 0;
   float best_t = 1e30f;
-  for (int c = 0; c < NPLAN; c++) {
+  for (int c = 0; c < nplan; c++) {
     if (gated && g_cfg[c].tm == 192) continue;   // the gated epilogue pairs the halves of a lane's 4 or 8 columns
     const long long tiles = (long long)((M + g_cfg[c].tp - 1) / g_cfg[c].tp) * ((N + g_cfg[c].tm - 1) / g_cfg[c].tm);
     const float frac = (float)tiles / 256.0f, whole = 0.85f * (float)((tiles + 255) / 256);

@@ -770,13 +770,22 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, a
     return y.reshape(*x.shape[:-1], y.shape[-1])
 
 
-def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Tensor, need_dx: bool = True):
+WGRAD_GROUPED = True      # DitStackFn / VitBlockFn: the Linear weight gradients of a stack / block as ONE grouped launch (ops.linear_wgrad_grouped) instead of one split-K call each
+
+
+def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Tensor, need_dx: bool = True, defer: Optional[list] = None):
     """Gradients of y = x @ w^T + b for bf16 operands [rows, .]: dW and db from the split-K weight-gradient kernel (f32 results, bias
     gradient fused on the matrix pipe; the 1x1 case of the conv wgrad) when its shape constraints hold, else a library GEMM + column sum;
     dx = dy @ w on the Linear GEMM kernel against the transposed bf16 copy of w (bf16 like the reference's autocast backward)."""
     rows, cout = dy2.shape
     cin = x2.shape[1]
-    if rows <= 64 and cin % 8 == 0 and not parity.on():
+    if defer is not None and WGRAD_GROUPED and not parity.on() and ops.linear_wgrad_grouped_supported(rows, cout, cin):
+        # the caller collects (dy, x, dW, db) and launches ALL of them together when its backward pass ends: the destinations are returned now, filled then
+        dst_w, dst_b = _dst(w), _dst(b)
+        dw = dst_w.view(cout, cin) if dst_w is not None else torch.empty(cout, cin, dtype=f32, device=dy2.device)
+        db = None if b is None else (dst_b if dst_b is not None else torch.empty(cout, dtype=f32, device=dy2.device))
+        defer.append((_c(dy2), _c(x2), dw, db))
+    elif rows <= 64 and cin % 8 == 0 and not parity.on():
         # one row per SAMPLE (adaLN modulations, timestep embedder): the gradient is an outer-product sum of <= 64 terms, bound by writing it (csrc/linear_rows.hip)
         dst_w = _dst(w)
         dw, db = ops.linear_rows_wgrad(_c(dy2), _c(x2), need_bias=b is not None, dw_out=None if dst_w is None else dst_w.view(cout, cin), db_out=_dst(b))
@@ -927,19 +936,22 @@ class VitBlockFn(torch.autograd.Function):
         dt = dt_out.float().clone()                                   # becomes d(t_mid), then d(t)
         # MLP branch
         do3, dls2 = ops.layerscale_bwd(dt, o3, ls2, dg_out=_dst(ls2))
-        dg, df2w, df2b = _lin_grads(do3.view(rows, c), g.view(rows, -1), f2w, f2b)
+        pend = []                                                     # this block's four weight gradients: one grouped launch at the end (ops.linear_wgrad_grouped)
+        dg, df2w, df2b = _lin_grads(do3.view(rows, c), g.view(rows, -1), f2w, f2b, defer=pend)
         dh1 = ops.gelu_bwd(dg.view_as(h1), h1)
-        dhn2, df1w, df1b = _lin_grads(dh1.view(rows, -1), hn2.view(rows, c), f1w, f1b)
+        dhn2, df1w, df1b = _lin_grads(dh1.view(rows, -1), hn2.view(rows, c), f1w, f1b, defer=pend)
         dn2w, dn2b = ops.layernorm_bwd_(dt, dhn2.view(b, s, c), t_mid, n2w, eps, dg_out=_dst(n2w), db_out=_dst(n2b))
         # attention branch
         do2, dls1 = ops.layerscale_bwd(dt, o2, ls1, dg_out=_dst(ls1))
-        do, dpw, dpb = _lin_grads(do2.view(rows, c), o.view(rows, c), pw, pb)
+        do, dpw, dpb = _lin_grads(do2.view(rows, c), o.view(rows, c), pw, pb, defer=pend)
         if c // heads == 64 and s <= 288 and _fused_attn_bwd():
             dqkv = ops.attention_bwd_qkv(qkv, o, do.view(b, s, c), heads, (c // heads) ** -0.5)      # one kernel, nothing S x S in HBM
         else:
             dqkv = _attention_bwd(qkv, do.view(b, s, c), heads, (c // heads) ** -0.5)
-        dhn1, dqkvw, dqkvb = _lin_grads(dqkv.view(rows, 3 * c), hn1.view(rows, c), qkvw, qkvb)
+        dhn1, dqkvw, dqkvb = _lin_grads(dqkv.view(rows, 3 * c), hn1.view(rows, c), qkvw, qkvb, defer=pend)
         dn1w, dn1b = ops.layernorm_bwd_(dt, dhn1.view(b, s, c), t, n1w, eps, dg_out=_dst(n1w), db_out=_dst(n1b))
+        if pend:
+            ops.linear_wgrad_grouped(pend)
         return dt, dn1w, dn1b, dqkvw, dqkvb, dpw, dpb, dls1, dn2w, dn2b, df1w, df1b, df2w, df2b, dls2, None, None
 
 
@@ -1112,20 +1124,21 @@ class DitStackFn(torch.autograd.Function):
         grads = [None] * (P * nl)
         fresh = lambda p: _dst(p) if _dst(p) is not None else torch.empty(p.shape, dtype=f32, device=dt.device)
         norm_dws, qn_dws, kn_dws = [None] * (2 * nl), [None] * nl, [None] * nl
+        pend = []      # (dy, x, dW, db) of every block Linear: ONE grouped weight-gradient launch when the chain is done -- 4 x depth problems, each unsplit, fill the chip
         do3 = S.boundary(2 * nl, dt, y=acts[13 * (nl - 1) + 12], gate_mod=mod_all[nl - 1], gate_off=5 * c)
         for i in range(nl - 1, -1, -1):
             h_in, a1, qkv, q, k, v, o, o2, h_mid, a2, x12, g, o3 = acts[13 * i:13 * i + 13]
             n1w, qkvw, qkvb, qnw, knw, pw, pb, n2w, w12w, w12b, w3w, w3b, _aw, _ab = params[P * i:P * i + P]
             mod = mod_all[i]
             G = grads
-            dg, G[P * i + 10], G[P * i + 11] = _lin_grads(do3.view(rows, c), g.view(rows, -1), w3w, w3b)
+            dg, G[P * i + 10], G[P * i + 11] = _lin_grads(do3.view(rows, c), g.view(rows, -1), w3w, w3b, defer=pend)
             dx12 = ops.swiglu_bwd(dg.view_as(g), x12)
-            da2, G[P * i + 8], G[P * i + 9] = _lin_grads(dx12.view(rows, -1), a2.view(rows, c), w12w, w12b)
+            da2, G[P * i + 8], G[P * i + 9] = _lin_grads(dx12.view(rows, -1), a2.view(rows, c), w12w, w12b, defer=pend)
             do2 = S.boundary(2 * i + 1, dt, da=da2.view(b, n, c), x=h_mid, w=n2w, mod=mod, scale_off=4 * c, eps=eps, y=o2, gate_mod=mod, gate_off=2 * c)
-            do, G[P * i + 5], G[P * i + 6] = _lin_grads(do2.view(rows, c), o.view(rows, c), pw, pb)
+            do, G[P * i + 5], G[P * i + 6] = _lin_grads(do2.view(rows, c), o.view(rows, c), pw, pb, defer=pend)
             dq, dk, dv = ops.attention_bwd_heads(q, k, v, o, do.view(b, n, c), b, d ** -0.5)
             dqkv = S.qknorm_rope_bwd(i, dq, dk, dv, qkv, qnw, knw, cos, sin, eps)
-            da1, G[P * i + 1], G[P * i + 2] = _lin_grads(dqkv.view(rows, 3 * c), a1.view(rows, c), qkvw, qkvb)
+            da1, G[P * i + 1], G[P * i + 2] = _lin_grads(dqkv.view(rows, 3 * c), a1.view(rows, c), qkvw, qkvb, defer=pend)
             if i > 0:
                 do3 = S.boundary(2 * i, dt, da=da1.view(b, n, c), x=h_in, w=n1w, mod=mod, scale_off=c, eps=eps, y=acts[13 * (i - 1) + 12], gate_mod=mod_all[i - 1],
                                  gate_off=5 * c)
@@ -1133,6 +1146,8 @@ class DitStackFn(torch.autograd.Function):
                 S.boundary(0, dt, da=da1.view(b, n, c), x=h_in, w=n1w, mod=mod, scale_off=c, eps=eps)
             norm_dws[2 * i], norm_dws[2 * i + 1], qn_dws[i], kn_dws[i] = fresh(n1w), fresh(n2w), fresh(qnw), fresh(knw)
             G[P * i + 0], G[P * i + 7], G[P * i + 3], G[P * i + 4] = norm_dws[2 * i], norm_dws[2 * i + 1], qn_dws[i], kn_dws[i]
+        if pend:
+            ops.linear_wgrad_grouped(pend)
         dmod = torch.empty_like(mod_all)
         S.finalize(dmod, norm_dws, qn_dws, kn_dws)
         # the adaLN Linears of every block: weight / bias gradients in one launch, the input gradient d sc = sum_l d mod_l . W_l as one batched launch + a sum over layers

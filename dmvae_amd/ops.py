@@ -1280,6 +1280,56 @@ def linear_weight_t_kmajor_batched(pairs) -> None:
     check(_lib.lib().dmvae_linear_weight_t_kmajor_batched(tab.data_ptr(), cnt, total, _stream()), "linear_weight_t_kmajor_batched")
 
 
+def linear_wgrad_grouped_supported(m: int, cout: int, cin: int) -> bool:
+    return bool(_lib.lib().dmvae_linear_wgrad_grouped_supported(int(m), int(cout), int(cin)))
+
+
+def linear_wgrad_grouped(problems) -> None:
+    """Weight (+ bias) gradients of a LIST of independent Linears in one launch (include/dmvae_hip.h dmvae_linear_wgrad_grouped): problems = [(dy [M, cout] bf16,
+    x [M, cin] bf16, dw f32 [cout, cin] (written), db f32 [cout] or None), ...]; each problem unsplit, results written straight to dw / db."""
+    import ctypes
+    L = _lib.lib()
+    dev = problems[0][0].device
+    key = ("wg",) + tuple((dy.data_ptr(), x.data_ptr(), dw.data_ptr(), 0 if db is None else db.data_ptr(), dy.shape[0]) for dy, x, dw, db in problems)
+    hit = _PTR_TABLES.get((key, dev))
+    if hit is None:
+        if len(_PTR_TABLES) > 4096:
+            _PTR_TABLES.clear()
+        eb, bb = L.dmvae_linear_wgrad_grouped_entry_bytes(), L.dmvae_linear_wgrad_grouped_bias_entry_bytes()
+        n = len(problems)
+        tab = ctypes.create_string_buffer(eb * n)
+        btab = ctypes.create_string_buffer(bb * n)
+        start, bstart = ctypes.c_uint(0), ctypes.c_uint(0)
+        nb, ragged, part_floats = 0, 0, 0
+        for dy, x, dw, db in problems:
+            if db is not None:
+                part_floats += L.dmvae_linear_wgrad_grouped_bias_parts(x.shape[1]) * dy.shape[1]
+        part = workspace(max(part_floats, 1) * 4, dev, "wgrad_grouped_bias")
+        off = 0
+        for i, (dy, x, dw, db) in enumerate(problems):
+            dy, x = _req2d(dy, "dy"), _req2d(x, "x")
+            m, cout = dy.shape
+            cin = x.shape[1]
+            assert x.shape[0] == m and dy.is_contiguous() and x.is_contiguous() and dw.dtype == f32 and dw.is_contiguous() and dw.numel() == cout * cin
+            assert db is None or (db.dtype == f32 and db.is_contiguous() and db.numel() == cout)
+            ragged |= int(m % 32 != 0)
+            check(L.dmvae_linear_wgrad_grouped_fill(ctypes.addressof(tab) + i * eb, ctypes.addressof(btab) + nb * bb if db is not None else None, dy.data_ptr(), x.data_ptr(),
+                                                    dw.data_ptr(), part.data_ptr() + off * 4 if db is not None else None, _ptr(db), m, cout, cin, ctypes.byref(start),
+                                                    ctypes.byref(bstart)), "linear_wgrad_grouped_fill")
+            if db is not None:
+                off += L.dmvae_linear_wgrad_grouped_bias_parts(cin) * cout
+                nb += 1
+        dtab = torch.frombuffer(bytearray(tab.raw), dtype=torch.uint8).to(dev)
+        dbtab = torch.frombuffer(bytearray(btab.raw[:max(nb, 1) * bb]), dtype=torch.uint8).to(dev)
+        hit = (dtab, n, start.value, ragged, dbtab, nb, bstart.value, part.data_ptr())
+        _PTR_TABLES[(key, dev)] = hit
+    dtab, n, total, ragged, dbtab, nb, btotal, part_ptr = hit
+    if nb and workspace(1, dev, "wgrad_grouped_bias").data_ptr() != part_ptr:      # the workspace slot grew since this table was built: its bias-partial pointers are stale
+        del _PTR_TABLES[(key, dev)]
+        return linear_wgrad_grouped(problems)
+    check(L.dmvae_linear_wgrad_grouped(dtab.data_ptr(), n, total, ragged, dbtab.data_ptr() if nb else None, nb, btotal, _stream()), "linear_wgrad_grouped")
+
+
 class DitStackBwd:
     """Scratch of one whole-stack backward pass (functional.DitStackFn.backward): the boundary slots' partial sums, the deferred norm-weight partials of the QK-norm,
     the row statistics -- see include/dmvae_hip.h (dmvae_dit_boundary_bwd, dmvae_dit_stack_finalize, dmvae_colsum2_batched)."""

@@ -109,6 +109,9 @@ class FlatParams:
         conditional block, a Function returning None) would keep the previous step's gradient and AdamW / grad_norm would consume it silently.  No such
         parameter exists in the VAE or the DiT routes; DMVAE_CHECK_DIRECT_GRADS=1 (or `check_direct_writes`) verifies it per step, and a trainer that cannot
         guarantee it sets `self.zero_all = True` to fall back to zeroing the whole buffer."""
+        opt = getattr(self, "_opt", None)
+        if opt is not None:
+            opt.wait()            # an overlapped optimiser step still reads the gradient buffer
         if _CHECK_DIRECT and getattr(self, "direct", False):
             self.check_direct_writes()
         if getattr(self, "direct", False):
@@ -172,6 +175,23 @@ class FlatAdamWEMA:
         self.exp_avg_sq = torch.zeros_like(fp.flat)
         self.norm = torch.zeros(3, dtype=torch.float32, device=fp.flat.device)   # [norm, clip coef, sumsq] stays on device
         self.t = 0
+        self.side, self._done = None, None
+        fp._opt = self
+
+    def enable_overlap(self) -> None:
+        """Run `step` on a side HIP stream: the HBM-bound update (norm pass + fused AdamW + the operand refreshes: 20 GB of traffic for LightningDiT-XL/1) then overlaps
+        whatever the caller's stream does next that does not touch these weights -- the next step's encoder forward, another model's turn -- instead of serialising
+        behind the backward pass.  Everything that reads the weights (or their bf16 / packed / transposed operands) or writes the gradient buffer must come after
+        `wait()`: `FlatParams.begin_step` does it, the trainers do it before a forward of the model; `step(then=...)` runs a callback (log writes that read the norm)
+        on the side stream too."""
+        if self.fp.flat.is_cuda and self.side is None:
+            self.side = torch.cuda.Stream(device=self.fp.flat.device)
+
+    def wait(self) -> None:
+        """The caller's current stream waits for the last overlapped `step` (no-op without one)."""
+        if self._done is not None:
+            torch.cuda.current_stream(self.fp.flat.device).wait_event(self._done)
+            self._done = None
 
     def current_lr(self) -> float:
         """The reference's LambdaLR (train_tokenizer.py:385-392): lr_lambda(s) = s / warmup if s < warmup else 1, evaluated at the
@@ -180,7 +200,25 @@ class FlatAdamWEMA:
             return self.lr * (self.t / self.warmup_steps)
         return self.lr
 
-    def step(self):
+    def step(self, then=None):
+        """One optimiser step; `then(norm)` (optional) runs right behind it on the same stream.  With `enable_overlap` both go to the side stream, ordered after
+        everything the current stream has queued so far (the backward pass, the gradient all-reduce's wait)."""
+        if self.side is None:
+            norm = self._step()
+            if then is not None:
+                then(norm)
+            return norm
+        self.wait()
+        self.side.wait_stream(torch.cuda.current_stream(self.fp.flat.device))
+        with torch.cuda.stream(self.side):
+            norm = self._step()
+            if then is not None:
+                then(norm)
+            self._done = torch.cuda.Event()
+            self._done.record(self.side)
+        return norm
+
+    def _step(self):
         lr = self.current_lr()
         self.t += 1
         ops.grad_norm(self.fp.grad, self.max_norm, norm_out=self.norm)

@@ -338,7 +338,8 @@ class DMDTrainer(_AdversarialBranch):
                  t0: float = 0.0, t1: float = 1.0, latent_mean: float = 0.0, latent_scale: float = 1.0, vae_train_every: int = 5,
                  time_dist_shift: float = 1.0, warmup_steps: int = 1000, max_norm: float = 1.0, bucket_bytes: int = 64 << 20,
                  disc: Optional[torch.nn.Module] = None, disc_weight: float = 0.5, disc_start_step: int = 0, disc_lr: float = 1e-4,
-                 disc_wd: float = 0.0005, bcr: float = 1.0, bcr_cut: float = 0.2, batch_cfg: Optional[bool] = None, direct_grads: bool = True):
+                 disc_wd: float = 0.0005, bcr: float = 1.0, bcr_cut: float = 0.2, batch_cfg: Optional[bool] = None, direct_grads: bool = True,
+                 overlap_optimizer: bool = False):
         self.vae, self.lpips, self.teacher, self.student = vae, lpips, teacher, student
         self._init_disc(disc, disc_weight, disc_start_step, disc_lr, disc_wd, warmup_steps, max_norm, bcr, bcr_cut, bucket_bytes)     # train_dmd.py:92-93,475
         self.w = dict(l1=l1, l2=l2, lpips=lpips_w)
@@ -388,6 +389,18 @@ class DMDTrainer(_AdversarialBranch):
         self.log = torch.zeros(10, dtype=torch.float32, device=self.fp.flat.device)
         self.global_step = 0
         self.sync_initial_state()
+        if overlap_optimizer:
+            # the two AdamW updates leave the critical path (optim.FlatAdamWEMA.enable_overlap): the VAE's runs beside the student's turn of the same step, the
+            # student's (20 GB of HBM traffic, ~4 ms) beside the NEXT step's encoder forward -- neither of which touches the weights being updated
+            self.opt.enable_overlap()
+            if self.sopt is not None:
+                self.sopt.enable_overlap()
+
+    def wait_optimizers(self) -> None:
+        """Current stream waits for any optimiser step still running on its side stream: call before reading weights / flat buffers outside `step`."""
+        self.opt.wait()
+        if self.sopt is not None:
+            self.sopt.wait()
 
     def sync_initial_state(self) -> int:
         """DDP's constructor-time broadcast for vae_ddp / sit_ddp (train_dmd.py:348,355) plus the frozen teacher and LPIPS."""
@@ -416,6 +429,8 @@ class DMDTrainer(_AdversarialBranch):
 
     def _dmd(self, latents: torch.Tensor, labels: torch.Tensor):
         """compute_distribution_matching_loss (train_dmd.py:204-230)."""
+        if self.sopt is not None:
+            self.sopt.wait()                      # the student's weights: its last update may still be on the side stream
         t, x0 = self._sample(latents)
         t = (t * (self.t1 - self.t0) + self.t0)
         xt = losses.dmd_make_xt(latents, x0, t)
@@ -441,6 +456,7 @@ class DMDTrainer(_AdversarialBranch):
         vae, w = self.vae, self.w
         vae_turn = self.global_step % self.vae_train_every == 0
         student_is_module = isinstance(self.student, torch.nn.Module)
+        self.opt.wait()                           # the encoder's weights (every step reads them)
         for p in getattr(self.student, "parameters", lambda: [])():
             p.requires_grad_(False)
         if vae_turn and student_is_module:
@@ -479,15 +495,17 @@ class DMDTrainer(_AdversarialBranch):
         if vae_turn:
             loss.backward()
             self.sync.wait()
-            norm = self.opt.step()
-            with torch.no_grad():
-                self.log[0], self.log[1], self.log[3], self.log[4] = l1.detach(), l2.detach(), rec_loss.detach(), norm[0]
-                if lp is not None:
-                    self.log[2] = lp.detach()
-                if dlog is not None:
-                    self.log[5], self.log[6] = dlog[0], dlog[1]
-                if gan:
-                    self.log[9] = d_weight
+
+            def vae_log(norm):
+                with torch.no_grad():
+                    self.log[0], self.log[1], self.log[3], self.log[4] = l1.detach(), l2.detach(), rec_loss.detach(), norm[0]
+                    if lp is not None:
+                        self.log[2] = lp.detach()
+                    if dlog is not None:
+                        self.log[5], self.log[6] = dlog[0], dlog[1]
+                    if gan:
+                        self.log[9] = d_weight
+            self.opt.step(then=vae_log)
             if gan:                                                   # :546-556
                 with torch.autocast("cuda", dtype=torch.bfloat16):
                     self._discriminator_step(images, recon.detach())
@@ -508,15 +526,18 @@ class DMDTrainer(_AdversarialBranch):
                 sloss = ((out.float() - ut) ** 2).flatten(1).mean(1).mean()
             sloss.backward()
             self.ssync.wait()
-            snorm = self.sopt.step()
-            with torch.no_grad():
-                self.log[7], self.log[8] = sloss.detach(), snorm[0]
+
+            def student_log(snorm):
+                with torch.no_grad():
+                    self.log[7], self.log[8] = sloss.detach(), snorm[0]
+            self.sopt.step(then=student_log)
         self.global_step += 1
         return (loss if vae_turn else sloss).detach()
 
     def checkpoint(self, all_ranks_rng: Optional[bool] = None) -> dict:
         """train_dmd.py:577-590: model (the student) / vae_wo_ddp / disc_wo_ddp state_dicts, opt_sit / opt_vae / opt_disc, steps; `rng` = this rank's
         generator states, or every rank's with all_ranks_rng (a collective: every rank calls checkpoint())."""
+        self.wait_optimizers()
         clone = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
         out = {"model": clone(self.student) if isinstance(self.student, torch.nn.Module) else None, "vae_wo_ddp": clone(self.vae),
                "disc_wo_ddp": clone(self.disc) if self.disc is not None else None,
@@ -529,6 +550,7 @@ class DMDTrainer(_AdversarialBranch):
     def load(self, ckpt: dict) -> None:
         """Resume from `checkpoint()` (or a reference checkpoint, train_dmd.py:577-590); entries the checkpoint holds as None (absent branches) are skipped.
         The warm-up position comes back with the optimiser steps; the generator states (`rng`) when the checkpoint has them."""
+        self.wait_optimizers()
         self.vae.load_state_dict(ckpt["vae_wo_ddp"], strict=True)
         if ckpt.get("opt_vae") is not None:
             self.opt.load_state_dict(ckpt["opt_vae"], list(self.vae.parameters()))
@@ -547,6 +569,7 @@ class DMDTrainer(_AdversarialBranch):
         _set_rng_state(ckpt.get("rng"))
 
     def read_log(self) -> Dict[str, float]:
+        self.wait_optimizers()
         v = self.log.tolist()
         return {"L1": v[0], "L2": v[1], "LPIPS": v[2], "rec_loss": v[3], "vae_norm": v[4], "dmd_loss": v[5], "dmd_gradient_norm": v[6],
                 "diffusion_loss": v[7], "sit_norm": v[8], "d_weight": v[9]}
@@ -565,7 +588,7 @@ class DiffusionTrainer:
 
     def __init__(self, model, vae: VAE, lr: float = 1e-4, latent_mean: float = 0.0, latent_scale: float = 1.0, max_norm: float = 1.0,
                  ema_decay: float = 0.9999, path_type: str = "Linear", prediction: str = "velocity", loss_weight=None, train_eps=0.0, sample_eps=0.0,
-                 bucket_bytes: int = 64 << 20):
+                 bucket_bytes: int = 64 << 20, overlap_optimizer: bool = False):
         from .transport import create_transport
         from .models.lightningdit import LightningDiT
         self.model, self.vae = model, vae
@@ -587,6 +610,11 @@ class DiffusionTrainer:
         self.train_steps = 0
         if dist.broadcast_module_state(self.model, self.vae, extra=[self.fp.flat, self.fp.ema, self.opt.exp_avg, self.opt.exp_avg_sq]):
             self.fp.after_external_update()
+        if overlap_optimizer:
+            self.opt.enable_overlap()             # the update (norm + AdamW + EMA + operand refresh: 23 GB) runs beside the NEXT step's frozen encoder forward
+
+    def wait_optimizers(self) -> None:
+        self.opt.wait()
 
     def latents(self, images: torch.Tensor) -> torch.Tensor:
         """train_diffusion.py:276-287."""
@@ -597,21 +625,24 @@ class DiffusionTrainer:
 
     def step(self, images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         self.model.train()                                                  # label dropout for classifier-free guidance (:232)
-        self.fp.begin_step()
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            x = self.latents(images)
+            x = self.latents(images)                                        # frozen encoder: does not touch the model's weights (an overlapped update may still run)
+            self.fp.begin_step()                                            # waits for it
             _, terms = self.transport.training_losses(self.model, x, dict(y=labels))
         loss = terms["loss"].mean().float()
         loss.backward()
         self.sync.wait()
-        norm = self.opt.step()
-        with torch.no_grad():
-            self.log[0], self.log[1] = loss.detach(), norm[0]
+
+        def log(norm):
+            with torch.no_grad():
+                self.log[0], self.log[1] = loss.detach(), norm[0]
+        self.opt.step(then=log)
         self.train_steps += 1
         return loss.detach()
 
     def ema_state_dict(self):
         """The `ema` entry of the reference's checkpoint (:316-323): the model's state_dict with the trainable parameters replaced by their averages."""
+        self.opt.wait()
         sd = {k: v.clone() for k, v in self.model.state_dict().items()}
         names = {id(p): n for n, p in self.model.named_parameters()}
         for p, e in zip(self.fp.params, self.fp.ema_state()):
@@ -620,10 +651,12 @@ class DiffusionTrainer:
 
     def checkpoint(self) -> dict:
         """train_diffusion.py:318-325: model / ema state_dicts, opt (torch.optim.AdamW layout over model.parameters()), steps."""
+        self.opt.wait()
         return {"model": {k: v.detach().clone() for k, v in self.model.state_dict().items()}, "ema": self.ema_state_dict(),
                 "opt": self.opt.state_dict(list(self.model.parameters())), "steps": self.train_steps}
 
     def load(self, ckpt: dict) -> None:
+        self.opt.wait()
         self.model.load_state_dict(ckpt["model"], strict=True)
         names = {id(p): n for n, p in self.model.named_parameters()}
         with torch.no_grad():
@@ -634,6 +667,7 @@ class DiffusionTrainer:
         self.fp.after_external_update()
 
     def read_log(self) -> Dict[str, float]:
+        self.opt.wait()
         v = self.log.tolist()
         return {"loss": v[0], "grad_norm": v[1]}
 

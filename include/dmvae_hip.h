@@ -33,7 +33,8 @@ const char* dmvae_last_error(void);
  * 4: dmvae_norm_conv_out_bwd / _supported / _workspace, dmvae_norm_conv_out_fwd / _supported, dmvae_conv_in3 / _supported / _workspace, dmvae_im2col_nhwc_taps, dmvae_linear_bf16_batched / _supported, dmvae_conv_to_image / _supported.
  * 5: dmvae_groupnorm_apply_short / _bwd_short / _short_supported / _bwd_short_workspace, dmvae_lpips_diff_pool.
  * 6: the whole-stack LightningDiT backward (dmvae_dit_boundary_bwd, dmvae_dit_stack_*, dmvae_colsum2_batched, dmvae_qknorm_rope_bwd_partial / _nblk), the batched
- *    per-sample Linears (dmvae_linear_rows_batched_bf16, dmvae_linear_rows_wgrad_batched), dmvae_linear_weight_t_kmajor_batched / dmvae_wt_entry_bytes. */
+ *    per-sample Linears (dmvae_linear_rows_batched_bf16, dmvae_linear_rows_wgrad_batched), dmvae_linear_weight_t_kmajor_batched / dmvae_wt_entry_bytes, the grouped
+ *    Linear weight gradients (dmvae_linear_wgrad_grouped*). */
 int dmvae_abi_version(void);
 
 /* ---- convolution / GEMM (MFMA-bound) -------------------------------------------------------- */
@@ -509,6 +510,24 @@ int dmvae_linear_rows_wgrad_batched(const void* dy, long long dy_layer_stride, c
  * [start_e, start_e + tiles_x * N / 32), tiles_x = ceil(K / 64); total_tiles = their sum. */
 size_t dmvae_wt_entry_bytes(void);
 int dmvae_linear_weight_t_kmajor_batched(const void* table, int n_entries, unsigned total_tiles, dmvae_stream_t stream);
+
+/* Grouped Linear weight gradients: ONE launch for a table of independent problems dW_p [cout_p][cin_p] f32 = dY_p [M_p][cout_p]^T . X_p [M_p][cin_p] (bf16 row-major
+ * operands; nn.Linear's weight gradient under autocast), each problem unsplit -- its whole reduction in one workgroup per 256 x 256 output tile, written straight to dw
+ * (no slabs, no reduce launch) -- plus their bias gradients db_p [cout_p] = column sums of dY_p.  For call sites that hold many at once: the 4 x 28 Linears of
+ * LightningDiT's backward pass (diffusion/lightningdit/lightningdit.py:173-252, swiglu_ffn.py:15-36), the four of a ViT block (timm blocks via models/vae.py:47-53).
+ * The table is built on the host, record by record, with dmvae_linear_wgrad_grouped_fill (entry: dmvae_linear_wgrad_grouped_entry_bytes() bytes; bias_entry:
+ * ..._bias_entry_bytes() bytes, only for problems with db != NULL, which also need bias_part: f32 scratch of dmvae_linear_wgrad_grouped_bias_parts(cin) * cout
+ * floats); *start / *bias_start accumulate the launch's block counts.  Then copy both tables to the device and call dmvae_linear_wgrad_grouped(table, n, total_blocks,
+ * ragged, bias_table, n_bias, bias_blocks): ragged != 0 when some M_p is not a multiple of 32 (the last K tile's missing rows are masked per lane).
+ * M >= 32, cout and cin multiples of 128, every operand below 2 GiB.  Deterministic (fixed accumulation order per tile). */
+size_t dmvae_linear_wgrad_grouped_entry_bytes(void);
+size_t dmvae_linear_wgrad_grouped_bias_entry_bytes(void);
+int dmvae_linear_wgrad_grouped_supported(int M, int cout, int cin);
+int dmvae_linear_wgrad_grouped_bias_parts(int cin);
+int dmvae_linear_wgrad_grouped_fill(void* entry, void* bias_entry, const void* dy, const void* x, void* dw, void* bias_part, void* db, int M, int cout, int cin,
+                                    unsigned* start, unsigned* bias_start);
+int dmvae_linear_wgrad_grouped(const void* table, int n, unsigned total_blocks, int ragged, const void* bias_table, int n_bias, unsigned bias_blocks,
+                               dmvae_stream_t stream);
 
 /* ---- losses (HBM-bound reductions) ------------------------------------------------------------- */
 

@@ -199,3 +199,34 @@ def test_stack_route_equals_block_route(tag):
     for n_, p in pa.items():
         if n_ in first:
             assert torch.equal(p.grad, first[n_]), n_
+
+
+@pytest.mark.parametrize("shapes", [[(4096, 1152, 1152), (4096, 3456, 1152), (4096, 1152, 3072)], [(4112, 1024, 1024), (4112, 3072, 1024), (4112, 1024, 4096)],
+                                    [(64, 128, 128), (33, 256, 128), (200, 128, 384)]])
+def test_grouped_linear_weight_gradients(shapes):
+    """ops.linear_wgrad_grouped: every problem's dW = dY^T X and db = column sums against fp64 and against the split-K kernel it replaces; ragged M (not a multiple
+    of 32) included; a second call (cached table) and a rerun give the same bits."""
+    from dmvae_amd import ops
+    g = torch.Generator().manual_seed(len(shapes) + shapes[0][0])
+    probs, refs = [], []
+    for i, (m, cout, cin) in enumerate(shapes):
+        dy = torch.randn(m, cout, generator=g).to(DEV).to(BF)
+        x = torch.randn(m, cin, generator=g).to(DEV).to(BF)
+        dw = torch.full((cout, cin), 3.0, device=DEV)
+        db = torch.full((cout,), 3.0, device=DEV) if i != 1 else None
+        probs.append((dy, x, dw, db))
+        refs.append((dy.double().t() @ x.double(), dy.double().sum(0)))
+    ops.linear_wgrad_grouped(probs)
+    first = [(p[2].clone(), None if p[3] is None else p[3].clone()) for p in probs]
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw, rw) < 2e-6
+        if db is not None:
+            assert rel_err(db, rb) < 2e-6
+        if dy.shape[0] % 32 == 0 and dy.shape[0] >= 4096:
+            dw2, db2 = ops.conv2d_nhwc_wgrad(dy.view(1, 1, *dy.shape), x.view(1, 1, *x.shape), 1)
+            assert rel_err(dw, dw2.view_as(dw)) < 2e-6 and rel_err(db if db is not None else db2, db2) < 2e-6
+    for p in probs:
+        p[2].zero_()
+    ops.linear_wgrad_grouped(probs)
+    for p, f in zip(probs, first):
+        assert torch.equal(p[2], f[0]) and (p[3] is None or torch.equal(p[3], f[1]))

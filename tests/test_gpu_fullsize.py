@@ -140,9 +140,11 @@ def test_dmd_stage_full_size_cycle_c3():
         snaps, logs = [], []
         for _ in range(10):
             tr.step(images, labels)
+            tr.wait_optimizers()                       # both updates run on side streams; the buffers are read after them
             snaps.append((tr.fp.flat.double().sum().item(), tr.sfp.flat.double().sum().item()))
             logs.append(tr.read_log())
         peak = torch.cuda.max_memory_allocated() / 2 ** 30
+        tr.wait_optimizers()
         final = (tr.fp.flat.clone(), tr.sfp.flat.clone())
         assert _batchable(teacher) or True
         del tr, vae, lp, teacher, student

@@ -198,6 +198,7 @@ def test_dmd_stage_step_harness():
         snaps = []
         for _ in range(5):
             tr.step(images, labels)
+            tr.wait_optimizers()                       # the two updates run on side streams (optim.FlatAdamWEMA.enable_overlap): reading the buffers comes after them
             snaps.append((tr.fp.flat.clone(), torch.cat([p.detach().flatten() for p in student.parameters()]).clone()))
         return tr, snaps
 
@@ -220,6 +221,7 @@ def test_dmd_stage_step_harness():
     assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(snaps, snaps3))
     # the bf16 shadows the fused optimiser step maintains are what a fresh conversion would give, and functional._bf serves them
     from dmvae_amd import functional as Fn
+    tr.wait_optimizers()
     assert torch.equal(tr.fp.shadow, tr.fp.flat.to(torch.bfloat16))
     w = tr.vae.encoder.model.blocks[0].attn.qkv.weight
     assert Fn._bf(w).data_ptr() == w._dmvae_shadow.data_ptr() and torch.equal(Fn._bf(w), w.detach().to(torch.bfloat16))
