@@ -93,6 +93,10 @@ SIGNATURES = {
     "dmvae_attention_qknorm_rope_bf16": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_float, c_float, c_void_p]),
     "dmvae_attention_bwd_qkv_bf16": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_float, c_void_p]),
     "dmvae_attention_bwd_heads_bf16": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),
+    "dmvae_attention_qkv_lse_bf16": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float, c_void_p]),
+    "dmvae_attention_heads_lse_bf16": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_float, c_void_p]),
+    "dmvae_attention_bwd_qkv_lse_bf16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_float, c_void_p]),
+    "dmvae_attention_bwd_heads_lse_bf16": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_void_p]),
     "dmvae_vit_bwd_workspace": (c_size_t, [c_int]),
     "dmvae_layernorm_bwd_f32": (c_int, [c_void_p] * 7 + [c_size_t, c_int, c_int, c_float, c_int, c_void_p]),
     "dmvae_layerscale_bwd": (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_int, c_int, c_void_p]),

@@ -35,6 +35,7 @@ struct Args {
   int q_rs, k_rs, v_rs;
   int S, H, D;
   float scale;
+  const float* lse;              // attention_bwd_lse_kernel: [B * H][S] f32, scale * max + log(sum) of every query's scaled scores (the forward kernel writes it)
 };
 
 __device__ __forceinline__ s16x4 tr_read(const char* p) {
@@ -296,6 +297,215 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Args a) {
 #endif
 }
 
+// The same backward with the forward kernel's row statistics handed in (lse) and two waves per SIMD.  The kernel above keeps all nine S^T blocks of a query block
+// in registers between its max / sum pass and its dS pass (144 registers; 460 in all: one wave per SIMD, so every exponential, every permlane swap and every
+// LDS round trip of a wave sits between its own MFMAs -- 72 us for the 2 832 MFMAs of a (batch, head) at S = 256, D = 72: 15 % of the matrix pipe).  With
+// L_q = scale max + log(sum) known, P = exp(scale s - L) needs no pass of its own: phase A walks the key blocks once with 16 + 16 score registers, a workgroup is
+// eight waves -- one 32-query block each in phase A, one 32-key block each in phase B at S = 256 -- and the softmax arithmetic of one wave runs under the other's
+// matrix work.  Key blocks past S are skipped (eight instead of nine at S = 256).  Same sums in the same order per output element: deterministic.
+template <int DP>
+__global__ __launch_bounds__(512) void attention_bwd_lse_kernel(Args a) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int KSTEPS = DP / 16, DB = DP / 32, CH = DP / 8, NT = 512, NW = NT / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* buf0 = smem;                    // phase A: K, phase B: Q
+  char* buf1 = smem + BUF;              // phase A: V, phase B: dO
+  float* Ls = reinterpret_cast<float*>(smem + 2 * BUF);  // [288] L_q; +inf for padded queries
+  float* Ds = Ls + KEYS;                                  // [288] delta
+  const int S = a.S, H = a.H, D = a.D, C = H * D;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16* qg = a.q + b * a.q_bs + h * a.q_hs;
+  const bf16* kg_ = a.k + b * a.k_bs + h * a.k_hs;
+  const bf16* vg = a.v + b * a.v_bs + h * a.v_hs;
+  const bf16* og = a.o + (size_t)b * S * C + h * D;
+  const bf16* dog = a.dout + (size_t)b * S * C + h * D;
+  const float* lse = a.lse + (size_t)blockIdx.x * S;
+  const int dchunks = D / 8;
+  const int nblk = (S + 31) >> 5;
+  const int rows_staged = nblk * 32;
+
+  auto stage = [&](const bf16* s0, int rs0, int ch0, const bf16* s1, int rs1, int ch1) {
+    for (int i = tid; i < rows_staged * CH; i += NT) {
+      const int row = i / CH, c = i - row * CH;
+      uint4 x = {0, 0, 0, 0}, y = {0, 0, 0, 0};
+      if (row < S) {
+        if (c < ch0) x = *reinterpret_cast<const uint4*>(s0 + (size_t)row * rs0 + c * 8);
+        if (c < ch1) y = *reinterpret_cast<const uint4*>(s1 + (size_t)row * rs1 + c * 8);
+      }
+      const int off = lds_off(row, c);
+      *reinterpret_cast<uint4*>(buf0 + off) = x;
+      *reinterpret_cast<uint4*>(buf1 + off) = y;
+    }
+  };
+  stage(kg_, a.k_rs, CH, vg, a.v_rs, dchunks);
+  for (int i = tid; i < KEYS; i += NT) Ls[i] = i < S ? lse[i] : INFINITY;
+  __syncthreads();
+
+  const int kg = lane >> 5, ql = lane & 31;
+  const int g16 = (lane >> 4) & 1, rr = (lane & 15) >> 2, qq = lane & 3;
+  int toff0[DB], toff1[DB];
+#pragma unroll
+  for (int db = 0; db < DB; db++) {
+    const int chunk = db * 4 + g16 * 2 + (qq >> 1);
+    toff0[db] = lds_off(kg * 8 + rr, chunk) + (qq & 1) * 8;
+    toff1[db] = lds_off(kg * 8 + rr + 4, chunk) + (qq & 1) * 8;
+  }
+  const float scale = a.scale;
+
+  // ================= phase A: per 32-query block -- delta, dQ ========================================================================================
+  for (int qb = wave; qb < nblk; qb += NW) {
+    const int q = qb * 32 + ql;
+    bf16x8 qf[KSTEPS], dof[KSTEPS];
+    float delta = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++) {
+      uint4 tq = {0, 0, 0, 0}, td = {0, 0, 0, 0}, to = {0, 0, 0, 0};
+      const int d0 = kk * 16 + kg * 8;
+      if (q < S) {
+        tq = *reinterpret_cast<const uint4*>(qg + (size_t)q * a.q_rs + d0);
+        if (d0 < D) {
+          td = *reinterpret_cast<const uint4*>(dog + (size_t)q * C + d0);
+          to = *reinterpret_cast<const uint4*>(og + (size_t)q * C + d0);
+        }
+      }
+      qf[kk] = *reinterpret_cast<bf16x8*>(&tq);
+      dof[kk] = *reinterpret_cast<bf16x8*>(&td);
+      delta += dot8(td, to);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    if (kg == 0) Ds[q] = delta;
+    const float Lq = Ls[q];                 // +inf for a padded query: every P of its column is 0
+    f32x16 dq[DB];
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) dq[db][r] = 0.f;
+    for (int kb = 0; kb < nblk; kb++) {
+      f32x16 st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { st[r] = 0.f; dpt[r] = 0.f; }
+      const int key = kb * 32 + ql;
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; kk++) {
+        const int off = lds_off(key, kk * 2 + kg);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(buf0 + off);
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(buf1 + off);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], dpt, 0, 0, 0);
+      }
+      const bool tail = kb * 32 + 32 > S;   // only the last block can hold keys past S (their K rows are zero: score 0, not -inf)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float p = __expf(st[r] * scale - Lq);
+        if (tail && kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg >= S) p = 0.f;
+        dpt[r] = p * (dpt[r] - delta) * scale;
+      }
+      bf16x8 af[2];
+      to_afrag(dpt, af);
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const char* base = buf0 + (kb * 2 + half) * 16 * PITCH;
+#pragma unroll
+        for (int db = 0; db < DB; db++) {
+          union { bf16x8 v; s16x4 hlf[2]; } kf;
+          kf.hlf[0] = tr_read(base + toff0[db]);
+          kf.hlf[1] = tr_read(base + toff1[db]);
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[half], kf.v, dq[db], 0, 0, 0);
+        }
+      }
+    }
+    bf16* dqg = a.dq + b * a.q_bs + h * a.q_hs;
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int qo = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (qo < S) dqg[(size_t)qo * a.q_rs + db * 32 + ql] = (bf16)dq[db][r];
+      }
+  }
+  __syncthreads();
+  // ================= phase B: Q and dO resident; per 32-key block -- dK, dV ===========================================================================
+  stage(qg, a.q_rs, CH, dog, C, dchunks);
+  __syncthreads();
+  for (int kb = wave; kb < nblk; kb += NW) {
+    const int key = kb * 32 + ql;
+    bf16x8 kfb[KSTEPS], vfb[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++) {
+      uint4 tk = {0, 0, 0, 0}, tv = {0, 0, 0, 0};
+      const int d0 = kk * 16 + kg * 8;
+      if (key < S) {
+        tk = *reinterpret_cast<const uint4*>(kg_ + (size_t)key * a.k_rs + d0);
+        if (d0 < D) tv = *reinterpret_cast<const uint4*>(vg + (size_t)key * a.v_rs + d0);
+      }
+      kfb[kk] = *reinterpret_cast<bf16x8*>(&tk);
+      vfb[kk] = *reinterpret_cast<bf16x8*>(&tv);
+    }
+    f32x16 dk[DB], dv[DB];
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    for (int qb = 0; qb < nblk; qb++) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+      const int qrow = qb * 32 + ql;
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; kk++) {
+        const int off = lds_off(qrow, kk * 2 + kg);
+        const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(buf0 + off);
+        const bf16x8 dor = *reinterpret_cast<const bf16x8*>(buf1 + off);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kfb[kk], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dor, vfb[kk], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++) {
+        const f32x4 Lv = *reinterpret_cast<const f32x4*>(Ls + qb * 32 + 8 * r4 + 4 * kg);
+        const f32x4 Dv = *reinterpret_cast<const f32x4*>(Ds + qb * 32 + 8 * r4 + 4 * kg);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float p = key < S ? __expf(s[r4 * 4 + r] * scale - Lv[r]) : 0.f;
+          s[r4 * 4 + r] = p;
+          dp[r4 * 4 + r] = p * (dp[r4 * 4 + r] - Dv[r]) * scale;
+        }
+      }
+      bf16x8 pf[2], dsf[2];
+      to_afrag(s, pf);
+      to_afrag(dp, dsf);
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const int rbase = (qb * 2 + half) * 16 * PITCH;
+#pragma unroll
+        for (int db = 0; db < DB; db++) {
+          union { bf16x8 v; s16x4 hlf[2]; } df, qf2;
+          df.hlf[0] = tr_read(buf1 + rbase + toff0[db]);
+          df.hlf[1] = tr_read(buf1 + rbase + toff1[db]);
+          qf2.hlf[0] = tr_read(buf0 + rbase + toff0[db]);
+          qf2.hlf[1] = tr_read(buf0 + rbase + toff1[db]);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[half], df.v, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf[half], qf2.v, dk[db], 0, 0, 0);
+        }
+      }
+    }
+    bf16* dkg = a.dk + b * a.k_bs + h * a.k_hs;
+    bf16* dvg = a.dv + b * a.v_bs + h * a.v_hs;
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        const int dcol = db * 32 + ql;
+        if (ko < S) {
+          dkg[(size_t)ko * a.k_rs + dcol] = (bf16)dk[db][r];
+          if (dcol < D) dvg[(size_t)ko * a.v_rs + dcol] = (bf16)dv[db][r];
+        }
+      }
+  }
+#endif
+}
+
 template <int DP>
 static int launch(const Args& a, int batch, hipStream_t stream) {
   constexpr int lds = 2 * BUF + 2 * KEYS * (int)sizeof(float);
@@ -304,15 +514,30 @@ static int launch(const Args& a, int batch, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel<DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((attention_bwd_kernel<DP>), dim3(batch * a.H), dim3(256), lds, stream, a);
+  if (a.lse) {
+    static bool attr2_done = false;
+    if (!attr2_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_lse_kernel<DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr2_done = true;
+    }
+    hipLaunchKernelGGL((attention_bwd_lse_kernel<DP>), dim3(batch * a.H), dim3(512), lds, stream, a);
+  } else {
+    hipLaunchKernelGGL((attention_bwd_kernel<DP>), dim3(batch * a.H), dim3(256), lds, stream, a);
+  }
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
 
 }  // namespace dmvae_attn_bwd
 
+extern "C" int dmvae_attention_bwd_qkv_lse_bf16(const void* qkv, const void* out, const void* dout, const void* lse, void* dqkv, int batch, int seq, int heads,
+                                                int head_dim, float scale, hipStream_t stream);
 extern "C" int dmvae_attention_bwd_qkv_bf16(const void* qkv, const void* out, const void* dout, void* dqkv, int batch, int seq, int heads, int head_dim,
                                             float scale, hipStream_t stream) {
+  return dmvae_attention_bwd_qkv_lse_bf16(qkv, out, dout, nullptr, dqkv, batch, seq, heads, head_dim, scale, stream);
+}
+extern "C" int dmvae_attention_bwd_qkv_lse_bf16(const void* qkv, const void* out, const void* dout, const void* lse, void* dqkv, int batch, int seq, int heads,
+                                                int head_dim, float scale, hipStream_t stream) {
   using namespace dmvae_attn_bwd;
   DMVAE_CHECK_ARG(qkv && out && dout && dqkv && batch > 0 && heads > 0 && seq > 0, "attention_bwd_qkv_bf16: bad argument");
   DMVAE_CHECK_ARG(head_dim == 64 && seq <= KEYS, "attention_bwd_qkv_bf16: needs head_dim 64 and seq <= 288 (got %d, %d)", head_dim, seq);
@@ -323,12 +548,18 @@ extern "C" int dmvae_attention_bwd_qkv_bf16(const void* qkv, const void* out, co
   a.o = (const bf16*)out; a.dout = (const bf16*)dout;
   a.q_bs = a.k_bs = a.v_bs = (long long)seq * 3 * C; a.q_hs = a.k_hs = a.v_hs = head_dim;
   a.q_rs = a.k_rs = a.v_rs = (int)(3 * C);
-  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale;
+  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale; a.lse = (const float*)lse;
   return launch<64>(a, batch, stream);
 }
 
+extern "C" int dmvae_attention_bwd_heads_lse_bf16(const void* q, const void* k, const void* v, const void* out, const void* dout, const void* lse, void* dq, void* dk,
+                                                  void* dv, int batch, int seq, int heads, int head_dim, int head_dim_padded, float scale, hipStream_t stream);
 extern "C" int dmvae_attention_bwd_heads_bf16(const void* q, const void* k, const void* v, const void* out, const void* dout, void* dq, void* dk, void* dv,
                                               int batch, int seq, int heads, int head_dim, int head_dim_padded, float scale, hipStream_t stream) {
+  return dmvae_attention_bwd_heads_lse_bf16(q, k, v, out, dout, nullptr, dq, dk, dv, batch, seq, heads, head_dim, head_dim_padded, scale, stream);
+}
+extern "C" int dmvae_attention_bwd_heads_lse_bf16(const void* q, const void* k, const void* v, const void* out, const void* dout, const void* lse, void* dq, void* dk,
+                                                  void* dv, int batch, int seq, int heads, int head_dim, int head_dim_padded, float scale, hipStream_t stream) {
   using namespace dmvae_attn_bwd;
   DMVAE_CHECK_ARG(q && k && v && out && dout && dq && dk && dv && batch > 0 && heads > 0 && seq > 0, "attention_bwd_heads_bf16: bad argument");
   DMVAE_CHECK_ARG(seq <= KEYS && head_dim % 8 == 0 && head_dim <= head_dim_padded && (head_dim_padded == 64 || head_dim_padded == 96),
@@ -339,6 +570,6 @@ extern "C" int dmvae_attention_bwd_heads_bf16(const void* q, const void* k, cons
   a.q_hs = a.k_hs = (long long)seq * head_dim_padded; a.q_bs = a.k_bs = a.q_hs * heads;
   a.v_hs = (long long)seq * head_dim; a.v_bs = a.v_hs * heads;
   a.q_rs = a.k_rs = head_dim_padded; a.v_rs = head_dim;
-  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale;
+  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale; a.lse = (const float*)lse;
   return head_dim_padded == 64 ? launch<64>(a, batch, stream) : launch<96>(a, batch, stream);
 }

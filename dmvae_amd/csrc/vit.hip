@@ -188,6 +188,7 @@ struct AttnArgs {
   // NR variant: per-head RMSNorm (bf16 result) * weight and the 2-D rotary embedding are applied to q and k on their way in
   const float *qw, *kw, *cosb, *sinb;   // [D], [D], [S][D], [S][D]
   float eps;
+  float* lse;      // optional [B * H][S] f32: scale * max + log(sum) of every query's scaled scores -- what the backward kernel needs to rebuild P without a pass of its own
 };
 
 // NT threads: 512 = two waves per SIMD.  One wave's softmax (the kernel's VALU-bound part: 144 exponentials and their bookkeeping per lane and query block)
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attention_kernel(AttnArgs a) {
     }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.f / sum;      // both halves of the wave hold query (lane & 31)'s sum
+    if (a.lse && kg == 0 && q < Sq) a.lse[(size_t)blockIdx.x * S + q] = m * a.scale + __logf(sum);
     // ---- store [B][S][H*D]: lane = query q = qb*32 + (lane & 31); registers r = 4 r4 .. 4 r4 + 3 are channels db*32 + 8 r4 + 4 kg + 0..3: 8-byte stores ----
     const int C = H * a.D;
     if (q < Sq) {
@@ -400,8 +402,12 @@ static int launch_attention(const AttnArgs& a, int batch, hipStream_t stream) {
 
 }  // namespace dmvae_vit
 
+extern "C" int dmvae_attention_qkv_lse_bf16(const void* qkv, void* out, void* lse, int batch, int seq, int heads, int head_dim, float scale, hipStream_t stream);
 extern "C" int dmvae_attention_qkv_bf16(const void* qkv, void* out, int batch, int seq, int heads, int head_dim, float scale,
                                         hipStream_t stream) {
+  return dmvae_attention_qkv_lse_bf16(qkv, out, nullptr, batch, seq, heads, head_dim, scale, stream);
+}
+extern "C" int dmvae_attention_qkv_lse_bf16(const void* qkv, void* out, void* lse, int batch, int seq, int heads, int head_dim, float scale, hipStream_t stream) {
   using namespace dmvae_vit;
   DMVAE_CHECK_ARG(qkv && out && batch > 0 && heads > 0 && seq > 0, "attention_qkv_bf16: bad argument");
   DMVAE_CHECK_ARG(head_dim == ATT_D && seq <= ATT_KEYS, "attention_qkv_bf16: needs head_dim 64 and seq <= 288 (got %d, %d)", head_dim, seq);
@@ -410,13 +416,19 @@ extern "C" int dmvae_attention_qkv_bf16(const void* qkv, void* out, int batch, i
   a.q = (const bf16*)qkv; a.k = a.q + C; a.v = a.q + 2 * C; a.out = (bf16*)out;
   a.q_bs = a.k_bs = a.v_bs = (long long)seq * 3 * C; a.q_hs = a.k_hs = a.v_hs = head_dim;
   a.q_rs = a.k_rs = a.v_rs = (int)(3 * C);
-  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale;
+  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale; a.lse = (float*)lse;
   return launch_attention<64>(a, batch, stream);
 }
 
 // Same kernel on head-major operands (q, k: [B*H][S][Dp], v: [B*H][S][D]; LightningDiT after QK-norm + RoPE, head dim 64 or 72 -> Dp 64 / 96).
+extern "C" int dmvae_attention_heads_lse_bf16(const void* q, const void* k, const void* v, void* out, void* lse, int batch, int seq, int heads, int head_dim,
+                                              int head_dim_padded, float scale, hipStream_t stream);
 extern "C" int dmvae_attention_heads_bf16(const void* q, const void* k, const void* v, void* out, int batch, int seq, int heads, int head_dim,
                                           int head_dim_padded, float scale, hipStream_t stream) {
+  return dmvae_attention_heads_lse_bf16(q, k, v, out, nullptr, batch, seq, heads, head_dim, head_dim_padded, scale, stream);
+}
+extern "C" int dmvae_attention_heads_lse_bf16(const void* q, const void* k, const void* v, void* out, void* lse, int batch, int seq, int heads, int head_dim,
+                                              int head_dim_padded, float scale, hipStream_t stream) {
   using namespace dmvae_vit;
   DMVAE_CHECK_ARG(q && k && v && out && batch > 0 && heads > 0 && seq > 0, "attention_heads_bf16: bad argument");
   DMVAE_CHECK_ARG(seq <= ATT_KEYS && head_dim % 8 == 0 && head_dim <= head_dim_padded && (head_dim_padded == 64 || head_dim_padded == 96),
@@ -426,7 +438,7 @@ extern "C" int dmvae_attention_heads_bf16(const void* q, const void* k, const vo
   a.q_hs = a.k_hs = (long long)seq * head_dim_padded; a.q_bs = a.k_bs = a.q_hs * heads;
   a.v_hs = (long long)seq * head_dim; a.v_bs = a.v_hs * heads;
   a.q_rs = a.k_rs = head_dim_padded; a.v_rs = head_dim;
-  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale;
+  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale; a.lse = (float*)lse;
   return head_dim_padded == 64 ? launch_attention<64>(a, batch, stream) : launch_attention<96>(a, batch, stream);
 }
 

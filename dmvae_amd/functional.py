@@ -861,6 +861,7 @@ class SiluFn(torch.autograd.Function):
         return ops.silu_bwd(x, _c(dy).to(bf16))
 
 
+ATTN_BWD_LSE = True        # the forward attention kernels also write the row statistics and the backward takes the eight-wave form built on them (False: recomputed; tests compare)
 ATTN_BWD_FUSED = True      # False: the GEMM-composed attention backward (probabilities through HBM; the first implementation) -- tests compare the two
 THIN_CIN_BWD_AS_GEMM = True      # ConvFn.backward of a 3x3 conv from 32 / 64 channels: weight and input gradient as GEMMs on the im2col form
 NORM_CONV_OUT_FUSED_FWD = True      # NormConvOutFn.forward: ops.norm_conv_out_fwd where the shape allows
@@ -912,7 +913,11 @@ class VitBlockFn(torch.autograd.Function):
         hd = c // heads
         hn1 = ops.layernorm_bf16(t, n1w, n1b, eps)
         qkv = linear(hn1, qkvw, qkvb)
-        o = ops.attention_qkv(qkv, heads, hd ** -0.5)
+        lse = None
+        if ATTN_BWD_LSE and hd == 64 and s <= 288 and any(ctx.needs_input_grad):
+            o, lse = ops.attention_qkv(qkv, heads, hd ** -0.5, need_lse=True)      # + the row statistics the backward kernel rebuilds P from
+        else:
+            o = ops.attention_qkv(qkv, heads, hd ** -0.5)
         o2 = linear(o, pw, pb)
         t_mid = ops.scale_residual_(t.clone(), o2, ls1)
         hn2 = ops.layernorm_bf16(t_mid, n2w, n2b, eps)
@@ -925,6 +930,7 @@ class VitBlockFn(torch.autograd.Function):
         t_out = ops.scale_residual_(t_mid if not any(ctx.needs_input_grad) else t_mid.clone(), o3, ls2)
         ctx.save_for_backward(t, hn1, qkv, o, o2, t_mid, hn2, h1, g, o3, n1w, qkvw, pw, ls1, n2w, f1w, f2w, ls2)
         ctx.others = (n1b, qkvb, pb, n2b, f1b, f2b, heads, eps)
+        ctx.lse = lse
         return t_out
 
     @staticmethod
@@ -945,7 +951,7 @@ class VitBlockFn(torch.autograd.Function):
         do2, dls1 = ops.layerscale_bwd(dt, o2, ls1, dg_out=_dst(ls1))
         do, dpw, dpb = _lin_grads(do2.view(rows, c), o.view(rows, c), pw, pb, defer=pend)
         if c // heads == 64 and s <= 288 and _fused_attn_bwd():
-            dqkv = ops.attention_bwd_qkv(qkv, o, do.view(b, s, c), heads, (c // heads) ** -0.5)      # one kernel, nothing S x S in HBM
+            dqkv = ops.attention_bwd_qkv(qkv, o, do.view(b, s, c), heads, (c // heads) ** -0.5, lse=ctx.lse)      # one kernel, nothing S x S in HBM
         else:
             dqkv = _attention_bwd(qkv, do.view(b, s, c), heads, (c // heads) ** -0.5)
         dhn1, dqkvw, dqkvb = _lin_grads(dqkv.view(rows, 3 * c), hn1.view(rows, c), qkvw, qkvb, defer=pend)
@@ -1088,7 +1094,7 @@ class DitStackFn(torch.autograd.Function):
         scb = _c(sc).to(bf16)
         blocks = [params[i * P:(i + 1) * P] for i in range(nl)]
         mod_all = ops.linear_rows_batched(scb, [_bf(bp[12]) for bp in blocks], [_bf(bp[13]) for bp in blocks])          # [L, B, 6C] bf16
-        saved = []
+        saved, lses = [], []
         h_in, h_mid, o3 = h, None, None
         for i, (n1w, qkvw, qkvb, qnw, knw, pw, pb, n2w, w12w, w12b, w3w, w3b, _aw, _ab) in enumerate(blocks):
             mod = mod_all[i]
@@ -1098,7 +1104,11 @@ class DitStackFn(torch.autograd.Function):
                 h_in, a1 = ops.gated_residual_out(h_mid, o3, mod_all[i - 1], 5 * c, n1w, mod, 0, c, eps)
             qkv = linear(a1, qkvw, qkvb)
             q, k, v = ops.qknorm_rope(qkv, qnw, knw, cos, sin, heads, eps)
-            o = ops.attention_heads(q, k, v, b, d ** -0.5)
+            if ATTN_BWD_LSE:
+                o, lse = ops.attention_heads(q, k, v, b, d ** -0.5, need_lse=True)
+                lses.append(lse)
+            else:
+                o = ops.attention_heads(q, k, v, b, d ** -0.5)
             o2 = linear(o, pw, pb)
             h_mid, a2 = ops.gated_residual_out(h_in, o2, mod, 2 * c, n2w, mod, 3 * c, 4 * c, eps)
             x12 = linear(a2, w12w, w12b)
@@ -1108,6 +1118,7 @@ class DitStackFn(torch.autograd.Function):
         h_out, _ = ops.gated_residual_out(h_mid, o3, mod_all[nl - 1], 5 * c)
         ctx.save_for_backward(scb, mod_all, cos, sin, *saved, *params)
         ctx.cfg = (nl, heads, eps, sc.dtype)
+        ctx.lses = lses
         return h_out
 
     @staticmethod
@@ -1136,7 +1147,7 @@ class DitStackFn(torch.autograd.Function):
             da2, G[P * i + 8], G[P * i + 9] = _lin_grads(dx12.view(rows, -1), a2.view(rows, c), w12w, w12b, defer=pend)
             do2 = S.boundary(2 * i + 1, dt, da=da2.view(b, n, c), x=h_mid, w=n2w, mod=mod, scale_off=4 * c, eps=eps, y=o2, gate_mod=mod, gate_off=2 * c)
             do, G[P * i + 5], G[P * i + 6] = _lin_grads(do2.view(rows, c), o.view(rows, c), pw, pb, defer=pend)
-            dq, dk, dv = ops.attention_bwd_heads(q, k, v, o, do.view(b, n, c), b, d ** -0.5)
+            dq, dk, dv = ops.attention_bwd_heads(q, k, v, o, do.view(b, n, c), b, d ** -0.5, lse=ctx.lses[i] if ctx.lses else None)
             dqkv = S.qknorm_rope_bwd(i, dq, dk, dv, qkv, qnw, knw, cos, sin, eps)
             da1, G[P * i + 1], G[P * i + 2] = _lin_grads(dqkv.view(rows, 3 * c), a1.view(rows, c), qkvw, qkvb, defer=pend)
             if i > 0:

@@ -927,26 +927,30 @@ def softmax_rows_bf16(s: torch.Tensor, scale: float) -> torch.Tensor:
     return p
 
 
-def attention_qkv(qkv: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
-    """Fused multi-head self-attention on the qkv Linear's output [B, S, 3*heads*64] (bf16) -> [B, S, heads*64]."""
+def attention_qkv(qkv: torch.Tensor, heads: int, scale: float, need_lse: bool = False):
+    """Fused multi-head self-attention on the qkv Linear's output [B, S, 3*heads*64] (bf16) -> [B, S, heads*64]; with need_lse also the row statistics
+    lse [B*heads, S] f32 (scale * max + log(sum) per query) for `attention_bwd_qkv`."""
     qkv = _req(qkv, bf16, "qkv")
     b, s, c3 = qkv.shape
     c = c3 // 3
     out = torch.empty(b, s, c, dtype=bf16, device=qkv.device)
-    check(_lib.lib().dmvae_attention_qkv_bf16(qkv.data_ptr(), out.data_ptr(), b, s, heads, c // heads, float(scale), _stream()), "attention_qkv_bf16")
-    return out
+    lse = torch.empty(b * heads, s, dtype=f32, device=qkv.device) if need_lse else None
+    check(_lib.lib().dmvae_attention_qkv_lse_bf16(qkv.data_ptr(), out.data_ptr(), _ptr(lse), b, s, heads, c // heads, float(scale), _stream()), "attention_qkv_bf16")
+    return (out, lse) if need_lse else out
 
 
-def attention_heads(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, scale: float) -> torch.Tensor:
-    """q, k [B*H, N, Dp], v [B*H, N, D] (bf16, as `qknorm_rope` returns them) -> softmax(scale q k^T) v as [B, N, H*D] bf16, one fused kernel."""
+def attention_heads(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, scale: float, need_lse: bool = False):
+    """q, k [B*H, N, Dp], v [B*H, N, D] (bf16, as `qknorm_rope` returns them) -> softmax(scale q k^T) v as [B, N, H*D] bf16, one fused kernel; with need_lse also
+    lse [B*H, N] f32 for `attention_bwd_heads`."""
     q = _req(q, bf16, "q"); k = _req(k, bf16, "k"); v = _req(v, bf16, "v")
     bh, n, dp = q.shape
     d = v.shape[-1]
     heads = bh // batch
     out = torch.empty(batch, n, heads * d, dtype=bf16, device=q.device)
-    check(_lib.lib().dmvae_attention_heads_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), batch, n, heads, d, dp, float(scale),
-                                                _stream()), "attention_heads_bf16")
-    return out
+    lse = torch.empty(bh, n, dtype=f32, device=q.device) if need_lse else None
+    check(_lib.lib().dmvae_attention_heads_lse_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(lse), batch, n, heads, d, dp, float(scale),
+                                                    _stream()), "attention_heads_bf16")
+    return (out, lse) if need_lse else out
 
 
 def attention_qknorm_rope(qkv: torch.Tensor, qw: torch.Tensor, kw: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, eps: float,
@@ -962,19 +966,22 @@ def attention_qknorm_rope(qkv: torch.Tensor, qw: torch.Tensor, kw: torch.Tensor,
     return out
 
 
-def attention_bwd_qkv(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
-    """d(qkv) [B,S,3*C] of `attention_qkv` from its input, its result `out` [B,S,C] and d(out) (bf16): one fused kernel (csrc/attention_bwd.hip)."""
+def attention_bwd_qkv(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, heads: int, scale: float, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d(qkv) [B,S,3*C] of `attention_qkv` from its input, its result `out` [B,S,C] and d(out) (bf16): one fused kernel (csrc/attention_bwd.hip); with the forward's
+    `lse` the eight-wave form that rebuilds the probabilities from it."""
     qkv = _req(qkv, bf16, "qkv"); out = _req(out, bf16, "out"); dout = _req(dout, bf16, "dout")
     b, s, c3 = qkv.shape
     c = c3 // 3
     assert out.shape == (b, s, c) and dout.shape == (b, s, c)
     dqkv = torch.empty_like(qkv)
-    check(_lib.lib().dmvae_attention_bwd_qkv_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), b, s, heads, c // heads, float(scale),
-                                                  _stream()), "attention_bwd_qkv_bf16")
+    assert lse is None or (lse.dtype == f32 and lse.is_contiguous() and lse.shape == (b * heads, s))
+    check(_lib.lib().dmvae_attention_bwd_qkv_lse_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), _ptr(lse), dqkv.data_ptr(), b, s, heads, c // heads, float(scale),
+                                                      _stream()), "attention_bwd_qkv_bf16")
     return dqkv
 
 
-def attention_bwd_heads(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, batch: int, scale: float):
+def attention_bwd_heads(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, batch: int, scale: float,
+                        lse: Optional[torch.Tensor] = None):
     """(dq, dk [B*H,N,Dp], dv [B*H,N,D]) of `attention_heads` from its operands, its result `out` [B,N,H*D] and d(out)."""
     q = _req(q, bf16, "q"); k = _req(k, bf16, "k"); v = _req(v, bf16, "v"); out = _req(out, bf16, "out"); dout = _req(dout, bf16, "dout")
     bh, n, dp = q.shape
@@ -982,8 +989,9 @@ def attention_bwd_heads(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: 
     heads = bh // batch
     assert out.shape == (batch, n, heads * d) and dout.shape == out.shape
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    check(_lib.lib().dmvae_attention_bwd_heads_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-                                                    dv.data_ptr(), batch, n, heads, d, dp, float(scale), _stream()), "attention_bwd_heads_bf16")
+    assert lse is None or (lse.dtype == f32 and lse.is_contiguous() and lse.shape == (bh, n))
+    check(_lib.lib().dmvae_attention_bwd_heads_lse_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), _ptr(lse), dq.data_ptr(),
+                                                        dk.data_ptr(), dv.data_ptr(), batch, n, heads, d, dp, float(scale), _stream()), "attention_bwd_heads_bf16")
     return dq, dk, dv
 
 

@@ -388,6 +388,11 @@ int dmvae_attention_qkv_bf16(const void* qkv, void* out, int batch, int seq, int
  * seq <= 288. */
 int dmvae_attention_heads_bf16(const void* q, const void* k, const void* v, void* out, int batch, int seq, int heads, int head_dim,
                                int head_dim_padded, float scale, dmvae_stream_t stream);
+/* The two kernels above with the row statistics written out: lse f32 [batch * heads][seq] = scale * max_k(q.k) + log(sum_k exp(scale (q.k - max))) per query -- what
+ * dmvae_attention_bwd_*_lse_bf16 rebuild the probabilities from (lse may be NULL: the plain calls). */
+int dmvae_attention_qkv_lse_bf16(const void* qkv, void* out, void* lse, int batch, int seq, int heads, int head_dim, float scale, dmvae_stream_t stream);
+int dmvae_attention_heads_lse_bf16(const void* q, const void* k, const void* v, void* out, void* lse, int batch, int seq, int heads, int head_dim,
+                                   int head_dim_padded, float scale, dmvae_stream_t stream);
 /* The whole attention of a LightningDiT block from the qkv Linear's output [batch][seq][3][heads][head_dim] bf16: per-head RMSNorm (bf16 result) * weight
  * and the 2-D rotary embedding (the arithmetic of dmvae_qknorm_rope_bf16; cos / sin tables [seq][head_dim] f32) are applied to q and k as they enter the
  * fused kernel -> out [batch][seq][heads*head_dim].  lightningdit.py:66-88 in one launch, no head-major q / k / v in HBM.  head_dim % 8 == 0, <= 96; seq <= 288. */
@@ -404,6 +409,12 @@ int dmvae_attention_bwd_qkv_bf16(const void* qkv, const void* out, const void* d
                                  float scale, dmvae_stream_t stream);
 int dmvae_attention_bwd_heads_bf16(const void* q, const void* k, const void* v, const void* out, const void* dout, void* dq, void* dk, void* dv,
                                    int batch, int seq, int heads, int head_dim, int head_dim_padded, float scale, dmvae_stream_t stream);
+/* The same with the forward's row statistics handed in (lse from dmvae_attention_*_lse_bf16; NULL = the calls above): the probabilities are rebuilt as
+ * exp(scale q.k - lse) without a max / sum pass, which frees the registers for two waves per SIMD (eight-wave workgroups). */
+int dmvae_attention_bwd_qkv_lse_bf16(const void* qkv, const void* out, const void* dout, const void* lse, void* dqkv, int batch, int seq, int heads, int head_dim,
+                                     float scale, dmvae_stream_t stream);
+int dmvae_attention_bwd_heads_lse_bf16(const void* q, const void* k, const void* v, const void* out, const void* dout, const void* lse, void* dq, void* dk,
+                                       void* dv, int batch, int seq, int heads, int head_dim, int head_dim_padded, float scale, dmvae_stream_t stream);
 
 /* Backward side of the same encoder block, for the stages where the encoder trains (train_dmd.py:349,519).  Residual stream f32,
  * Linear operands / results bf16 (autocast).  workspace: dmvae_vit_bwd_workspace(c) bytes.

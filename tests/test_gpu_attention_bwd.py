@@ -51,6 +51,20 @@ def test_attention_bwd_qkv_layout(b, s, h, monkeypatch):
         assert _rl2(got, ref) < 1.2e-2, (name, _rl2(got, ref))
         assert rel_err(got, ref) < 3e-2, name
     assert torch.equal(dqkv, ops.attention_bwd_qkv(qkv_g, o, do_g, h, scale))                    # fixed summation order
+    # the eight-wave form on the forward's row statistics: lse against fp64, the same bars on the gradients, rerun-identical, and the same output bits as the plain forward
+    o2, lse = ops.attention_qkv(qkv_g, h, scale, need_lse=True)
+    assert torch.equal(o2, o)
+    lse_r = torch.logsumexp(scale * q @ k.transpose(-1, -2), dim=-1).reshape(b * h, s)
+    assert (lse.double().cpu() - lse_r).abs().max() < 2e-3
+    dqkv2 = ops.attention_bwd_qkv(qkv_g, o, do_g, h, scale, lse=lse)
+    assert torch.isfinite(dqkv2.float()).all() and torch.equal(dqkv2, ops.attention_bwd_qkv(qkv_g, o, do_g, h, scale, lse=lse))
+    for i, name in enumerate("qkv"):
+        got = dqkv2.view(b, s, 3, c)[:, :, i].float().cpu()
+        ref = want.view(b, s, 3, c)[:, :, i]
+        if s == 1 and name != "v":
+            assert got.abs().max() < 1e-5
+            continue
+        assert _rl2(got, ref) < 1.2e-2 and rel_err(got, ref) < 3e-2, ("lse", name, _rl2(got, ref))
     comp = Fn._attention_bwd(qkv_g, do_g, h, scale)                                               # the GEMM-composed route: same bar, and close to the fused one
     if s > 1:
         assert _rl2(comp.float().cpu(), want) < 1.2e-2 and _rl2(dqkv.float(), comp.float()) < 1.2e-2
@@ -74,8 +88,14 @@ def test_attention_bwd_heads_layout(b, n, h, d):
     assert _rl2(o.cpu(), o_r.permute(0, 2, 1, 3).reshape(b, n, h * d)) < 6e-3
     dq, dk, dv = ops.attention_bwd_heads(qg, kg, vg, o, dog, b, scale)
     assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
-    for got, ref, name in ((dq, dq_r, "dq"), (dk, dk_r, "dk"), (dv, dv_r, "dv")):
+    o2, lse = ops.attention_heads(qg, kg, vg, b, scale, need_lse=True)
+    assert torch.equal(o2, o)
+    assert (lse.double().cpu() - torch.logsumexp(scale * f(q) @ f(k).transpose(-1, -2), dim=-1).reshape(b * h, n)).abs().max() < 2e-3
+    dq2, dk2, dv2 = ops.attention_bwd_heads(qg, kg, vg, o, dog, b, scale, lse=lse)
+    for got, ref, name in ((dq, dq_r, "dq"), (dk, dk_r, "dk"), (dv, dv_r, "dv"), (dq2, dq_r, "dq (lse)"), (dk2, dk_r, "dk (lse)"), (dv2, dv_r, "dv (lse)")):
         gf = got.float().cpu()
         assert _rl2(gf[..., :d], ref.reshape(b * h, n, d)) < 1.2e-2, name
         if gf.shape[-1] > d:
             assert gf[..., d:].abs().max() == 0, name + ": padded channels"
+    again = ops.attention_bwd_heads(qg, kg, vg, o, dog, b, scale, lse=lse)
+    assert all(torch.equal(x, y) for x, y in zip((dq2, dk2, dv2), again))
