@@ -20,7 +20,8 @@ constexpr int MAX_SWEEPS = 8;  // C <= 2048
 
 // one wave per row; mod: [B][stride] bf16 (the adaLN Linear's output), shift_off < 0: no shift
 // RES: first x[row] += bf16(gate[b] * r[row]) (the previous sub-layer's gated residual, written back), then the norm of the updated row.
-template <bool RES>
+// SW = ceil(C / 256) sweeps per row (register arrays sized by the width: 5 at LightningDiT-XL's 1152)
+template <bool RES, int SW>
 __global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(const float* x, const float* __restrict__ w, const bf16* __restrict__ mod,
                                                                bf16* __restrict__ y, int rows, int rows_per_sample, int C, int stride, int shift_off,
                                                                int scale_off, float eps, const bf16* __restrict__ r, const bf16* __restrict__ gmod,
@@ -29,10 +30,10 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(const float* x, c
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + (size_t)row * C;
-  f32x4 v[MAX_SWEEPS];
+  f32x4 v[SW];
   float ss = 0.f;
 #pragma unroll
-  for (int k = 0; k < MAX_SWEEPS; k++) {
+  for (int k = 0; k < SW; k++) {
     const int c = k * 256 + lane * 4;
     if (c < C) {
       v[k] = *reinterpret_cast<const f32x4*>(xr + c);
@@ -47,17 +48,29 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(const float* x, c
     }
   }
   if (RES && !y) return;                       // gated residual only (wave-uniform)
-  const float rs = rsqrtf(wave_sum(ss) / (float)C + eps);
+  // the norm's own operands (weight, scale, shift: L2-resident vectors) are requested BEFORE the row reduction: their round trip overlaps the butterfly instead of
+  // following it (one memory latency less on a kernel that is a single round of waves)
   const bf16* mrow = mod + (size_t)(row / rows_per_sample) * stride;
-  bf16* yr = y + (size_t)row * C;
+  f32x4 gv[SW];
+  bf16x4 scv[SW], shv[SW];
 #pragma unroll
-  for (int k = 0; k < MAX_SWEEPS; k++) {
+  for (int k = 0; k < SW; k++) {
     const int c = k * 256 + lane * 4;
     if (c < C) {
-      const f32x4 g = *reinterpret_cast<const f32x4*>(w + c);
-      const bf16x4 sc = *reinterpret_cast<const bf16x4*>(mrow + scale_off + c);
-      bf16x4 sh = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-      if (shift_off >= 0) sh = *reinterpret_cast<const bf16x4*>(mrow + shift_off + c);
+      gv[k] = *reinterpret_cast<const f32x4*>(w + c);
+      scv[k] = *reinterpret_cast<const bf16x4*>(mrow + scale_off + c);
+      shv[k] = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+      if (shift_off >= 0) shv[k] = *reinterpret_cast<const bf16x4*>(mrow + shift_off + c);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(ss) / (float)C + eps);
+  bf16* yr = y + (size_t)row * C;
+#pragma unroll
+  for (int k = 0; k < SW; k++) {
+    const int c = k * 256 + lane * 4;
+    if (c < C) {
+      const f32x4 g = gv[k];
+      const bf16x4 sc = scv[k], sh = shv[k];
       bf16x4 o;
 #pragma unroll
       for (int e = 0; e < 4; e++)  // `1 + scale` is a bf16 tensor in the reference's autocast graph (bf16 scale): rounded before it multiplies
@@ -476,8 +489,22 @@ extern "C" int dmvae_rmsnorm_modulate_bf16(const void* x, const void* w, const v
   DMVAE_CHECK_ARG(c % 4 == 0 && c >= 4 && c <= MAX_SWEEPS * 256, "rmsnorm_modulate_bf16: width must be a multiple of 4 up to 2048 (got %d)", c);
   DMVAE_CHECK_ARG(scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride,
                   "rmsnorm_modulate_bf16: modulation offsets must be multiples of 4 inside the row");
-  hipLaunchKernelGGL(rmsnorm_modulate_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
-                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr);
+  switch ((c + 255) / 256) {
+    case 1: hipLaunchKernelGGL((rmsnorm_modulate_kernel<false, 1>), dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
+                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr); break;
+    case 2: hipLaunchKernelGGL((rmsnorm_modulate_kernel<false, 2>), dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
+                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr); break;
+    case 3: hipLaunchKernelGGL((rmsnorm_modulate_kernel<false, 3>), dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
+                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr); break;
+    case 4: hipLaunchKernelGGL((rmsnorm_modulate_kernel<false, 4>), dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
+                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr); break;
+    case 5: hipLaunchKernelGGL((rmsnorm_modulate_kernel<false, 5>), dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
+                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr); break;
+    case 6: hipLaunchKernelGGL((rmsnorm_modulate_kernel<false, 6>), dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
+                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr); break;
+    default: hipLaunchKernelGGL((rmsnorm_modulate_kernel<false, 8>), dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
+                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr); break;
+  }
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -490,8 +517,22 @@ extern "C" int dmvae_gated_residual_rmsnorm_modulate(void* x, const void* r, con
   DMVAE_CHECK_ARG(scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride &&
                       gate_off >= 0 && gate_off % 4 == 0 && gate_stride % 4 == 0 && gate_off + c <= gate_stride,
                   "gated_residual_rmsnorm_modulate: modulation offsets must be multiples of 4 inside the row");
-  hipLaunchKernelGGL(rmsnorm_modulate_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
-                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x);
+  switch ((c + 255) / 256) {
+    case 1: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 1>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
+                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x); break;
+    case 2: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 2>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
+                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x); break;
+    case 3: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 3>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
+                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x); break;
+    case 4: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 4>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
+                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x); break;
+    case 5: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 5>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
+                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x); break;
+    case 6: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 6>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
+                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x); break;
+    default: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 8>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
+                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x); break;
+  }
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -506,8 +547,22 @@ extern "C" int dmvae_gated_residual_out(const void* x_in, void* x_out, const voi
   DMVAE_CHECK_ARG(gate_off >= 0 && gate_off % 4 == 0 && gate_stride % 4 == 0 && gate_off + c <= gate_stride &&
                       (!y || (scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride)),
                   "gated_residual_out: modulation offsets must be multiples of 4 inside the row");
-  hipLaunchKernelGGL(rmsnorm_modulate_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
-                     rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out);
+  switch ((c + 255) / 256) {
+    case 1: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 1>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
+                     rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out); break;
+    case 2: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 2>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
+                     rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out); break;
+    case 3: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 3>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
+                     rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out); break;
+    case 4: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 4>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
+                     rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out); break;
+    case 5: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 5>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
+                     rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out); break;
+    case 6: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 6>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
+                     rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out); break;
+    default: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 8>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
+                     rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out); break;
+  }
   DMVAE_CHECK_LAUNCH();
   return 0;
 }

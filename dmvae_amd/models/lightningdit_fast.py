@@ -40,6 +40,14 @@ def _bf(p):
     return cached(p)
 
 
+BATCHED_ADALN = True      # forward_inference: every block's adaLN modulation Linear in one launch (False: one launch per block; tests compare)
+
+
+def _parity_on() -> bool:
+    from .. import parity
+    return parity.on()
+
+
 _FUSED_ATTN = True        # False: attention composed from batched GEMMs + softmax (tests compare)
 _FUSED_QKNORM = True      # QK-norm + RoPE inside the attention kernel
 
@@ -94,9 +102,16 @@ def forward_inference(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) 
         # go to the tile kernels
         return linear(scb, lin.weight, lin.bias)
 
+    # the adaLN Linears of ALL blocks as one batched launch (csrc/linear_rows.hip, blockIdx.y = block): the same kernel and the same bits as one call per block
+    lins = [blk.adaLN_modulation[1] for blk in model.blocks]
+    mods = None
+    if BATCHED_ADALN and lins and b <= 64 and ops.linear_rows_supported(b, lins[0].weight.shape[0], c) and not _parity_on():
+        wb = [ww if ww.dtype == _BF else _bf(ww) for ww in (l.weight for l in lins)]
+        bb = [bv if bv.dtype == _BF else _bf(bv) for bv in (l.bias for l in lins)]
+        mods = ops.linear_rows_batched(scb, wb, bb)                               # [L, B, 6C]
     pend = None                                                                   # (y, mod) of the previous block's MLP branch, not yet added to h
-    for blk in model.blocks:
-        mod = adaln(blk.adaLN_modulation[1])
+    for i, blk in enumerate(model.blocks):
+        mod = mods[i] if mods is not None else adaln(blk.adaLN_modulation[1])
         if pend is None:
             a = ops.rmsnorm_modulate(h, blk.norm1.weight, mod, 0, c, blk.norm1.eps)
         else:

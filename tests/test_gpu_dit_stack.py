@@ -230,3 +230,20 @@ def test_grouped_linear_weight_gradients(shapes):
     ops.linear_wgrad_grouped(probs)
     for p, f in zip(probs, first):
         assert torch.equal(p[2], f[0]) and (p[3] is None or torch.equal(p[3], f[1]))
+
+
+@pytest.mark.parametrize("tag", ["dit_small_hd64w", "dit_small_hd72"])
+def test_inference_forward_with_batched_adaln_is_bit_identical(tag):
+    """forward_inference with every block's adaLN Linear in one launch = one launch per block, bit for bit (the same kernel, blockIdx.y = block)."""
+    from dmvae_amd.models import lightningdit_fast as lf
+    g = load_golden(tag)
+    m = build(tag, g).to(DEV).requires_grad_(False)
+    x, t, y = g.t("x").to(DEV), g.t("t").to(DEV), torch.from_numpy(np.asarray(g["y"])).to(DEV)
+    with torch.no_grad(), torch.autocast("cuda", dtype=BF):
+        a = m(x, t, y)
+        lf.BATCHED_ADALN = False
+        try:
+            b_ = m(x, t, y)
+        finally:
+            lf.BATCHED_ADALN = True
+    assert torch.equal(a, b_)
