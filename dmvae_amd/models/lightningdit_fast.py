@@ -169,6 +169,8 @@ class GraphedInference:
         return self.out
 
 
+STACK_SEGMENTS = 1        # autograd nodes the block stack is cut into in a single process
+STACK_SEGMENTS_DP = 4     # ... and with more than one rank (gradient buckets become ready per segment: the all-reduce overlaps the rest of the backward pass)
 STACK_FN = True      # forward_train: all blocks as one functional.DitStackFn node (False: one DitBlockFn per block + LinearFn modulations; tests compare the two)
 
 
@@ -189,12 +191,19 @@ def forward_train(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> t
     rope = model.feat_rope
     stack = STACK_FN and Fn.dit_stack_supported(b, h.shape[1], c, heads)
     if stack:
-        params = []
-        for blk in model.blocks:
-            params += [blk.norm1.weight, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.q_norm.weight, blk.attn.k_norm.weight, blk.attn.proj.weight, blk.attn.proj.bias,
-                       blk.norm2.weight, blk.mlp.w12.weight, blk.mlp.w12.bias, blk.mlp.w3.weight, blk.mlp.w3.bias, blk.adaLN_modulation[1].weight,
-                       blk.adaLN_modulation[1].bias]
-        h = DitStackFn.apply(h, sc, rope.freqs_cos, rope.freqs_sin, heads, model.blocks[0].norm1.eps, *params)
+        # One node per SEGMENT of blocks.  A single process takes all blocks as one segment; under data parallelism the gradients of a node reach autograd -- and
+        # FlatGradSync's post-accumulate hooks, which start a bucket's all-reduce -- only when the node returns, so the stack is cut into STACK_SEGMENTS_DP nodes:
+        # the collectives of the later blocks then run beside the backward pass of the earlier ones (2.7 GB of gradients for LightningDiT-XL/1, train_dmd.py:355)
+        from .. import dist as _dist
+        nseg = max(1, min(len(model.blocks), STACK_SEGMENTS_DP if _dist.get_world_size() > 1 else STACK_SEGMENTS))
+        per = (len(model.blocks) + nseg - 1) // nseg
+        for s0 in range(0, len(model.blocks), per):
+            params = []
+            for blk in model.blocks[s0:s0 + per]:
+                params += [blk.norm1.weight, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.q_norm.weight, blk.attn.k_norm.weight, blk.attn.proj.weight,
+                           blk.attn.proj.bias, blk.norm2.weight, blk.mlp.w12.weight, blk.mlp.w12.bias, blk.mlp.w3.weight, blk.mlp.w3.bias,
+                           blk.adaLN_modulation[1].weight, blk.adaLN_modulation[1].bias]
+            h = DitStackFn.apply(h, sc, rope.freqs_cos, rope.freqs_sin, heads, model.blocks[0].norm1.eps, *params)
     for blk in (() if stack else model.blocks):
         lin = blk.adaLN_modulation[1]
         mod = LinearFn.apply(sc, lin.weight, lin.bias)                            # [B, 6C] bf16; one row per sample: csrc/linear_rows.hip forward and input gradient

@@ -47,23 +47,32 @@ def _worker(rank, world, port, q):
                 acc[off:off + g.numel()] += g.reshape(-1) / world
         refs.append(acc)
     ok = all(torch.allclose(a, b, rtol=1e-5, atol=1e-7) for a, b in zip(results, refs))
+    # bucket bookkeeping: contiguous, covering the whole buffer in order; every bucket's collective was started from a gradient hook (during backward), none in wait()
+    b = sync.buckets
+    ok = ok and b[0][0] == 0 and all(b[i][1] <= b[i + 1][0] for i in range(len(b) - 1)) and b[-1][1] == fp.offsets[-1] + params[-1].numel()
+    ok = ok and sum(x[2] for x in b) == len(params) and sync.last_hook_launches == len(b)
+    stats = sync.comm_stats()
+    ok = ok and stats["buckets"] == len(b) and stats["launched_in_backward"] == len(b) and stats["bytes"] == b[-1][1] * 4
     dist.barrier()
     q.put((rank, ok))
     torch.distributed.destroy_process_group()
 
 
-def test_flat_grad_sync_two_ranks_gloo():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_flat_grad_sync_two_ranks_gloo(world):
+    """world 2, 4 and 8 (the node sizes the reference's launch scripts use: scripts/train_tokenizer.sh:20-38): averaging, bucket boundaries, every collective started
+    from a gradient hook."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(240)
         assert p.exitcode == 0
-    got = sorted(q.get(timeout=5) for _ in range(2))
-    assert got == [(0, True), (1, True)]
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(r, True) for r in range(world)]
 
 
 def test_single_process_is_noop():

@@ -209,3 +209,80 @@ def test_bench_line_labels_the_dynamic_instantiation_when_more_than_one_rank_wou
     assert c["buckets"] >= 3 and c["launched_in_backward"] >= c["buckets"] - 1 and c["wait_ms"] is not None and c["wait_ms"] >= 0
     assert len(d["ms_per_step_windows"]) == 3 and d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"]
     assert set(d["env"]) >= {"sclk_mhz_avg", "power_w_avg", "temp_c", "gpu_uuid_hash"}
+
+
+def _dmd_trainer(seed):
+    from dmvae_amd.models.lightningdit import LightningDiT
+    from dmvae_amd.models.vae import VAE
+    from dmvae_amd.train import DMDTrainer
+    torch.manual_seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=256, depth=1, num_heads=4)).cuda()
+
+    def dit(s):
+        torch.manual_seed(s)
+        m = LightningDiT(input_size=16, patch_size=1, in_channels=32, hidden_size=192, depth=4, num_heads=3, num_classes=10)
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.abs().max() == 0:
+                    p.normal_(0, 0.02)
+        return m.cuda()
+    teacher, student = dit(seed + 1).eval().requires_grad_(False), dit(seed + 2)
+    return DMDTrainer(vae, None, teacher, student, dmd_weight=5.0, dmd_cfg_scale=2.0, num_classes=10, vae_train_every=2, warmup_steps=1, bucket_bytes=1 << 20)
+
+
+def _dmd_worker(rank, world, port, q):
+    try:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch.distributed as tdist
+        from dmvae_amd import dist
+        from dmvae_amd.models import lightningdit_fast as lf
+        dist.init_distributed_mode(backend="gloo")
+        tr = _dmd_trainer(seed=11 + 5 * rank)                  # different seeds per rank: the constructor-time broadcast equalises VAE, student, teacher
+        assert tr.sync.enabled and tr.ssync.enabled and len(tr.ssync.buckets) >= 3 and lf.STACK_SEGMENTS_DP > 1
+        cat = lambda: torch.cat([tr.fp.flat, tr.sfp.flat, torch.cat([p.detach().reshape(-1) for p in tr.teacher.parameters()])])
+        both = [torch.empty_like(cat()) for _ in range(world)]
+        tdist.all_gather(both, cat())
+        assert torch.equal(both[0], both[1]), "initial broadcast did not equalise the ranks"
+        x = torch.rand(2, 3, 256, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(100 + rank)) * 2 - 1
+        y = torch.tensor([3, 7], device="cuda") + rank
+        torch.manual_seed(1000 + rank)                          # per-rank noise / timestep draws, like the reference's seed + 10000 rank
+        hooks = []
+        for step in range(4):                                  # two cycles of (VAE turn, student-only step)
+            tr.step(x, y)
+            hooks.append((tr.ssync.last_hook_launches, len(tr.ssync.buckets), tr.sync.last_hook_launches if step % 2 == 0 else None, len(tr.sync.buckets)))
+        tr.wait_optimizers()
+        flats = [torch.empty_like(cat()) for _ in range(world)]
+        tdist.all_gather(flats, cat())
+        same = torch.equal(flats[0], flats[1])
+        moved = not torch.equal(flats[0], both[0])
+        # the student's gradient buckets were started from hooks while its backward pass was still running: all but (at most) the segment that finishes last
+        early = all(h[0] >= h[1] - 1 for h in hooks)
+        log = tr.read_log()
+        finite = all(v == v and abs(v) < 1e6 for v in log.values())
+        dist.barrier()
+        q.put((rank, same and moved and early and finite, f"same {same} moved {moved} hooks {hooks} log {log}", ""))
+        tdist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, False, "", traceback.format_exc()[-2000:]))
+        raise e
+
+
+def test_dmd_trainer_two_ranks_share_one_gpu():
+    """train_dmd.py's stage under data parallelism (train_dmd.py:348,355: vae_ddp and sit_ddp): BOTH FlatGradSync instances (the VAE's, the student's), the
+    turn pattern, the student's block stack cut into segments so that its buckets' all-reduces start during its backward pass -- two gloo ranks on cuda:0 with
+    different images / labels / noise end every cycle with bit-identical VAE, student and teacher weights."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dmd_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    for rank, ok, info, tb in res:
+        assert tb == "", tb
+        assert ok, (rank, info)

@@ -201,6 +201,36 @@ def test_decoder_full_b1_tokens():
     assert abs(y.double().abs().sum().item() - g["y_sum"][1]) < 2e-2 * g["y_sum"][1]
 
 
+def test_decoder_full_b1_backward_production_path():
+    """The FULL-width decoder's backward on the PRODUCTION bf16 path against the reference's f32 capture (oracle/capture_golden_bwd.py), by the same criterion as
+    `test_decoder_small_fwd_bwd`: as close to the reference as the bf16-site oracle is (d z, the six captured gradient slices), every parameter-gradient norm
+    within 5 % -- the large-tile conv / weight-gradient / GroupNorm instantiations through a whole module."""
+    from oracle.capture_golden_bwd import SLICES
+    g = load_golden("decoder_full_b1_bwd")
+    dec, params = _decoder(128, 22)
+    z0 = load_golden("decoder_full_b1").t("z")
+    dy = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(23))
+    z = z0.to(DEV).requires_grad_(True)
+    y = dec(z)
+    y.backward(dy.to(DEV))
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    zo = z0.clone().requires_grad_(True)
+    yo = R.decoder_forward(zo, po, q=Q)
+    yo.backward(dy)
+
+    def floor(hip, orc, ref, what, slack=1.15, abs_floor=1e-3):
+        e_hip, e_orc = rel_l2(hip, ref), rel_l2(orc, ref)
+        print(f"decoder_full_b1 {what}: rel-L2 to f32 reference -- HIP {e_hip:.2e}, bf16-site oracle {e_orc:.2e}")
+        assert e_hip < slack * e_orc + abs_floor, what
+    floor(z.grad.cpu(), zo.grad, g.t("dz"), "dz")
+    for n, prm in dec.named_parameters():
+        if "g." + n in g:
+            floor(prm.grad[SLICES[n]].cpu(), po[n].grad[SLICES[n]], g.t("g." + n), "grad " + n)
+        gn = g["gn." + n][0]
+        if gn > 1e-3:
+            assert abs(prm.grad.double().norm().item() - gn) < 5e-2 * gn, n
+
+
 def test_vae_forward_tiny_and_api(allow_stock):
     # allow_stock: the capture's reduced ViT (width 64, 4 heads) is outside the bf16 encoder kernels' range; the fp32 parity mode runs this fixture with
     # the encoder on the MFMA GEMM route (tests/test_gpu_parity_fp32.py) and tests/test_gpu_vit_pin.py pins the bf16 encoder routes to the reference
@@ -375,3 +405,77 @@ def test_resnet_block_stage_by_stage_on_the_production_kernels():
     ym.backward(dyd.permute(0, 3, 1, 2).float())
     assert torch.equal(ym.to(torch.bfloat16), y.permute(0, 3, 1, 2)) and torch.equal(xin.grad.to(torch.bfloat16), dx.permute(0, 3, 1, 2))
     assert torch.equal(blk.conv1.weight.grad, dc1w) and torch.equal(blk.norm2.weight.grad, dn2w)
+
+
+@pytest.mark.parametrize("n,hh,ww,cin,cout", [(2, 128, 128, 512, 256), (1, 256, 256, 256, 128)])
+def test_shortcut_in_norm_routes_stage_by_stage_on_the_production_kernels(n, hh, ww, cin, cout):
+    """The stage-by-stage comparison of `test_resnet_block_stage_by_stage_on_the_production_kernels` for the two ResnetBlocks whose 1 x 1 shortcut rides on the
+    GroupNorm passes (csrc/norm_short.hip: 512 -> 256 at 128 x 128 with the weight resident in the accumulation registers, `coop`; 256 -> 128 at 256 x 256 with
+    the weight in LDS; flux_ae.py:67,71,77-82): `groupnorm_apply_short` (a1 AND xs from one read of x) and `groupnorm_bwd_short` (dx = GN1' + dy . Ws) against the
+    oracle's arithmetic in f64 on the calls' own inputs -- every bf16 result a correct rounding (<= 1 spacing; != RNE(oracle) for <= 0.2 % / 5 % of the elements:
+    the shortcut sums run in another f32 order inside one bf16 rounding, tests/test_gpu_norm_short.py), dgamma / dbeta within 1e-5."""
+    import torch.nn.functional as F
+    from dmvae_amd import ops
+    from dmvae_amd.functional import packed
+    from conftest import elem_err
+    assert ops.groupnorm_short_supported(n, hh * ww, cin, cout)
+    g = torch.Generator().manual_seed(cin + hh)
+    rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    x = (rn(n, hh, ww, cin) * 1.3 + 0.2).to(torch.bfloat16)
+    dy = rn(n, hh, ww, cout, sc=0.7).to(torch.bfloat16)
+    da1 = rn(n, hh, ww, cin, sc=0.5).to(torch.bfloat16)
+    P = {"n1w": 1 + 0.3 * rn(cin), "n1b": 0.2 * rn(cin), "sw": rn(cout, cin, 1, 1, sc=0.06), "sb": 0.1 * rn(cout)}
+    D = {k: v.to(DEV) for k, v in P.items()}
+    xd, dyd, da1d = x.to(DEV), dy.to(DEV), da1.to(DEV)
+    nchw = lambda t: t.double().cpu().permute(0, 3, 1, 2)
+    wq = P["sw"].to(torch.bfloat16).double()
+    st1 = ops.groupnorm_stats(xd)
+    a1, xs = ops.groupnorm_apply_short(xd, st1, D["n1w"], D["n1b"], packed(D["sw"]), D["sb"])
+    _assert_bf16_of(a1.permute(0, 3, 1, 2), R.swish(R.group_norm(nchw(xd), P["n1w"].double(), P["n1b"].double())), "a1 = swish(GN(x)) [short]")
+    _assert_bf16_of(xs.permute(0, 3, 1, 2), F.conv2d(nchw(xd), wq, P["sb"].double()), "xs = nin_shortcut(x) [short]", max_flip_frac=5e-2)
+    # the stored-operand route gives the same a1 bits
+    assert torch.equal(a1, ops.groupnorm_apply(xd, st1, D["n1w"], D["n1b"], True))
+    dx, dn1w, dn1b = ops.groupnorm_bwd_short(da1d, xd, dyd, packed(D["sw"], True), st1, D["n1w"], D["n1b"], True)
+    i = nchw(xd).requires_grad_(True)
+    gw_, gb_ = P["n1w"].double().requires_grad_(True), P["n1b"].double().requires_grad_(True)
+    gi, gw, gb = torch.autograd.grad(R.swish(R.group_norm(i, gw_, gb_)), (i, gw_, gb_), nchw(da1d))
+    dxs64 = F.conv_transpose2d(nchw(dyd), wq)                                           # dy . Ws, the 1 x 1 conv's input gradient
+    dxs64 = dxs64.to(torch.float32).to(torch.bfloat16).double()                         # rounded to bf16 before it is added (the stored route's tensor)
+    _assert_bf16_of(dx.permute(0, 3, 1, 2), gi + dxs64, "dx = GN1 backward + dy . Ws [short]", max_flip_frac=5e-2)
+    assert rel_err(dn1w.cpu(), gw) < 1e-5 and rel_err(dn1b.cpu(), gb) < 1e-5 and elem_err(dn1w.cpu(), gw) < 1e-4
+
+
+def test_decoder_tail_stage_by_stage_on_the_production_kernels():
+    """norm_out -> swish -> conv_out (flux_ae.py:266-268) at the C2 width on the fused production kernels (`norm_conv_out_fwd` / `norm_conv_out_bwd`: the 128 -> 3
+    conv inside the GroupNorm passes) against the oracle in f64 on the same inputs: a = swish(GN(x)) a correct bf16 rounding, the f32 image within 2e-3 of the f64
+    conv of the bf16 activation (bf16 operands, f32 accumulation), dx a correct bf16 rounding of GN'(conv_out^T dy), dgamma / dbeta within 1e-4."""
+    import torch.nn.functional as F
+    from dmvae_amd import ops
+    from dmvae_amd.functional import packed
+    n, hh, ww, c, cout = 2, 256, 256, 128, 3
+    if not (ops.norm_conv_out_fwd_supported(n, hh, ww, c, cout) and ops.norm_conv_out_bwd_supported(n, hh, ww, c, cout)):
+        pytest.skip("fused decoder tail not supported at this shape")
+    g = torch.Generator().manual_seed(5)
+    rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    x = (rn(n, hh, ww, c) * 1.2 + 0.1).to(torch.bfloat16)
+    dy = rn(n, cout, hh, ww, sc=0.8)
+    P = {"nw": 1 + 0.3 * rn(c), "nb": 0.2 * rn(c), "cw": rn(cout, c, 3, 3, sc=0.05), "cb": 0.1 * rn(cout)}
+    D = {k: v.to(DEV) for k, v in P.items()}
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    nchw = lambda t: t.double().cpu().permute(0, 3, 1, 2)
+    wq = P["cw"].to(torch.bfloat16).double()
+    st = ops.groupnorm_stats(xd)
+    a, y = ops.norm_conv_out_fwd(xd, st, D["nw"], D["nb"], packed(D["cw"], False, rows_pad=4), D["cb"], cout)
+    a64 = R.swish(R.group_norm(nchw(xd), P["nw"].double(), P["nb"].double()))
+    _assert_bf16_of(a.permute(0, 3, 1, 2), a64, "a = swish(norm_out(x)) [tail]")
+    y64 = F.conv2d(nchw(a), wq, P["cb"].double(), padding=1)
+    assert rel_err(y.cpu(), y64) < 1e-5, rel_err(y.cpu(), y64)
+    dx, dnw, dnb = ops.norm_conv_out_bwd(dyd, D["cw"], xd, st, D["nw"], D["nb"])
+    da64 = F.conv_transpose2d(dy.double(), wq, padding=1)                               # conv_out's input gradient, never materialised by the kernel
+    i = nchw(xd).requires_grad_(True)
+    gw_, gb_ = P["nw"].double().requires_grad_(True), P["nb"].double().requires_grad_(True)
+    gi, gw, gb = torch.autograd.grad(R.swish(R.group_norm(i, gw_, gb_)), (i, gw_, gb_), da64)
+    # the kernel forms d a from bf16 operands (dy rounded to bf16 at the matrix cores) in f32: dx is a bf16 rounding of a value within that operand noise of the oracle's
+    e = ((dx.permute(0, 3, 1, 2).double().cpu() - gi).norm() / gi.norm()).item()
+    assert e < 6e-3, e
+    assert rel_err(dnw.cpu(), gw) < 5e-3 and rel_err(dnb.cpu(), gb) < 5e-3

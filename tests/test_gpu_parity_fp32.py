@@ -144,6 +144,34 @@ def test_decoder_full_width_b1_vs_reference_f32():
     assert abs(y.double().abs().sum().item() - g["y_sum"][1]) < TOL * g["y_sum"][1]
 
 
+def test_decoder_full_width_b1_backward_vs_reference_f32():
+    """The FULL-width decoder forward AND backward (the 256 x 256 halo / 128 x 512 conv tiles, the split-K weight gradients at 65 536 pixels, the large GroupNorm
+    passes) against the reference's f32 capture (oracle/capture_golden_bwd.py): d z, every parameter-gradient norm, six gradient slices -- at 1e-4."""
+    from oracle.capture_golden_bwd import SLICES
+    from oracle.detweights import det_tensor
+    from dmvae_amd.models.flux_ae import Decoder
+    g = load_golden("decoder_full_b1_bwd")
+    dec = Decoder(ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_channels=3, resolution=256, z_channels=16)
+    dec.post_init(z_channels=32)
+    _load(dec, {k: det_tensor(k, v.shape, 22) for k, v in dec.state_dict().items()})
+    z = load_golden("decoder_full_b1").t("z").to(DEV).requires_grad_(True)
+    dy = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(23)).to(DEV)
+    y = dec(z)
+    y.backward(dy)
+    assert abs(y.double().abs().sum().item() - g["y_sum"][1]) < TOL * g["y_sum"][1]
+    assert rel_err(z.grad.cpu(), g.t("dz")) < TOL and elem_err(z.grad.cpu(), g.t("dz")) < TOL
+    full, norms = 0, 0
+    for n, prm in dec.named_parameters():
+        gn = float(g["gn." + n][0])
+        if gn > 1e-3:
+            assert abs(prm.grad.double().norm().item() - gn) < TOL * gn, n       # every parameter: gradient norm
+            norms += 1
+        if "g." + n in g:
+            assert rel_err(prm.grad[SLICES[n]].cpu(), g.t("g." + n)) < TOL, n     # the captured slices: element by element
+            full += 1
+    assert full == 6 and norms >= 100
+
+
 def test_generator_loss_vs_reference_f32():
     """VAELossFunction.forward_generator (train_tokenizer.py:179-204; L1 + MSE + LPIPS with its VGG16 trunk) value and d rec_loss / d recon."""
     from test_oracle_golden import lpips_params

@@ -102,6 +102,27 @@ def test_decoder_full_b1():
     assert abs(y.double().abs().sum().item() - g["y_sum"][1]) < 1e-5 * g["y_sum"][1]
 
 
+def test_decoder_full_b1_backward():
+    """The oracle at FULL width, forward and backward, against the reference's capture (oracle/capture_golden_bwd.py): d z, every parameter-gradient norm, six
+    gradient slices.  dy is regenerated from its seed."""
+    from oracle.capture_golden_bwd import SLICES
+    g = load_golden("decoder_full_b1_bwd")
+    p = decoder_params(_decoder_shapes(128, 32), 22)
+    keys = list(p.keys())
+    z = load_golden("decoder_full_b1").t("z").requires_grad_(True)
+    ps = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    y = R.decoder_forward(z, ps)
+    dy = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(23))
+    gr = torch.autograd.grad(y, [z] + [ps[k] for k in keys], dy)
+    assert abs(y.double().abs().sum().item() - g["y_sum"][1]) < 1e-5 * g["y_sum"][1]
+    assert rel_err(gr[0], g.t("dz")) < 5e-5
+    for k, v in zip(keys, gr[1:]):
+        gn = g["gn." + k]
+        assert abs(v.double().norm().item() - gn[0]) <= 5e-5 * gn[0] + 2e-5, k
+        if "g." + k in g:
+            assert rel_err(v[SLICES[k]], g.t("g." + k)) < 5e-5, k
+
+
 def test_flux_encoder_small():
     g = load_golden("flux_encoder_small")
     with torch.no_grad():
