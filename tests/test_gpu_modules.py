@@ -439,9 +439,17 @@ def test_shortcut_in_norm_routes_stage_by_stage_on_the_production_kernels(n, hh,
     i = nchw(xd).requires_grad_(True)
     gw_, gb_ = P["n1w"].double().requires_grad_(True), P["n1b"].double().requires_grad_(True)
     gi, gw, gb = torch.autograd.grad(R.swish(R.group_norm(i, gw_, gb_)), (i, gw_, gb_), nchw(da1d))
-    dxs64 = F.conv_transpose2d(nchw(dyd), wq)                                           # dy . Ws, the 1 x 1 conv's input gradient
-    dxs64 = dxs64.to(torch.float32).to(torch.bfloat16).double()                         # rounded to bf16 before it is added (the stored route's tensor)
-    _assert_bf16_of(dx.permute(0, 3, 1, 2), gi + dxs64, "dx = GN1 backward + dy . Ws [short]", max_flip_frac=5e-2)
+    dxs_exact = F.conv_transpose2d(nchw(dyd), wq)                                       # dy . Ws, the 1 x 1 conv's input gradient
+    dxs64 = dxs_exact.to(torch.float32).to(torch.bfloat16).double()                     # rounded to bf16 before it is added (the stored route's tensor)
+    # dx = bf16(GN1' + bf16(dy . Ws)): the shortcut term is rounded on its own first, in the kernel from an f32 sum in another order -- where that flips (a few % of the
+    # elements) dx moves by one spacing OF THE SHORTCUT TERM, which is several spacings of dx wherever the two terms nearly cancel.  So: every element within one
+    # spacing of dx plus one spacing of the shortcut term, and all but 10 % exactly RNE of the oracle's value
+    ref = gi + dxs64
+    h = dx.permute(0, 3, 1, 2).double().cpu()
+    err = (h - ref).abs()
+    allowed = _ulp_bf16(ref) + _ulp_bf16(dxs_exact) + 1e-4 * ref.abs().max()
+    assert bool((err <= allowed).all()), float((err / allowed).max())
+    assert (h != ref.to(torch.float32).to(torch.bfloat16).double()).double().mean().item() < 0.10
     assert rel_err(dn1w.cpu(), gw) < 1e-5 and rel_err(dn1b.cpu(), gb) < 1e-5 and elem_err(dn1w.cpu(), gw) < 1e-4
 
 

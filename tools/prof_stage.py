@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Driver for rocprofv3 over the DMD stage (C3) or the latent-diffusion step (C4): runs warm steps, then `CYCLES` cycles with a MARKER launch
 (`sde_euler_kernel` on 64 elements: a kernel neither stage uses) before every step, so tools/stage_trace_summary.py can cut the kernel trace into steps.
-    STAGE=dmd|diffusion  CYCLES=2  python tools/prof_stage.py"""
+    STAGE=dmd|diffusion|gan  CYCLES=2  python tools/prof_stage.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -28,6 +28,18 @@ if STAGE == "dmd":
     for _ in range(5 * CYCLES):
         marker()
         tr.step(images, labels)
+    marker()
+elif STAGE == "gan":
+    from dmvae_amd.train import build_tokenizer_trainer
+    B = int(os.environ.get("B", "32"))
+    tr = build_tokenizer_trainer(device="cuda", seed=42, with_disc=True, disc_start_step=0)
+    images = torch.rand(B, 3, 256, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(42)) * 2 - 1
+    for _ in range(3):
+        tr.step(images)
+    torch.cuda.synchronize()
+    for _ in range(3 * CYCLES):
+        marker()
+        tr.step(images)
     marker()
 else:
     B = int(os.environ.get("B", "64"))
