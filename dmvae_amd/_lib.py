@@ -75,6 +75,7 @@ SIGNATURES = {
     "dmvae_leaky_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
     "dmvae_sde_euler_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t] + [c_float] * 6 + [c_void_p]),
     "dmvae_image_to_u8": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
+    "dmvae_batchnorm_running_update": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p]),
     "dmvae_diffaug_fwd": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "dmvae_diffaug_bwd": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "dmvae_im2col_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),

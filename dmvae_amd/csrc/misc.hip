@@ -640,6 +640,25 @@ extern "C" int dmvae_linear_weight_t_kmajor(const void* w, void* out, int N, int
   return 0;
 }
 
+// nn.BatchNorm2d's running-estimate update from this batch's (mean, rstd) pairs: running_mean = (1 - m) running_mean + m mean, running_var = (1 - m) running_var +
+// m unbias var with var = max(1 / rstd^2 - eps, 0) -- one launch for the nine ATen launches per BatchNorm layer and discriminator pass (models/patchgan.py).
+__global__ void bn_running_update_kernel(const float* __restrict__ st, float* __restrict__ rm, float* __restrict__ rv, int C, float eps, float mom, float unbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mean = st[2 * c], rstd = st[2 * c + 1];
+  const float var = fmaxf(1.0f / (rstd * rstd) - eps, 0.f);
+  rm[c] = rm[c] * (1.f - mom) + mean * mom;
+  rv[c] = rv[c] * (1.f - mom) + (var * unbias) * mom;
+}
+extern "C" int dmvae_batchnorm_running_update(const void* stats, void* running_mean, void* running_var, int c, float eps, float momentum, float unbias,
+                                              hipStream_t stream) {
+  DMVAE_CHECK_ARG(stats && running_mean && running_var && c > 0, "batchnorm_running_update: bad argument");
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, (const float*)stats, (float*)running_mean, (float*)running_var, c, eps,
+                     momentum, unbias);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" size_t dmvae_wt_entry_bytes(void) { return sizeof(WtEntry); }
 extern "C" int dmvae_linear_weight_t_kmajor_batched(const void* table, int n_entries, unsigned total_tiles, hipStream_t stream) {
   DMVAE_CHECK_ARG(table && n_entries > 0 && total_tiles > 0, "linear_weight_t_kmajor_batched: empty table");

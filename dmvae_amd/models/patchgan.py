@@ -51,6 +51,15 @@ def _bn_stats(bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor):
         return st, False, count, None
     st = ops.groupnorm_stats(x.view(1, -1, c), groups=c, eps=bn.eps)
     group = None
+    synced = isinstance(bn, nn.SyncBatchNorm) and torch.distributed.is_available() and torch.distributed.is_initialized() \
+        and torch.distributed.get_world_size(bn.process_group) > 1
+    if not synced and bn.running_mean is not None and bn.running_mean.dtype == torch.float32 and bn.momentum is not None:
+        # single rank: the whole running-estimate update as ONE launch (was nine 4-us ATen launches per layer and discriminator pass)
+        if bn.training and bn.track_running_stats:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+                ops.batchnorm_running_update(st, bn.running_mean, bn.running_var, bn.eps, bn.momentum, count / max(count - 1, 1))
+        return st, True, count, None
     with torch.no_grad():
         mean, rstd = st[0, :, 0], st[0, :, 1]
         var = (1.0 / (rstd * rstd) - bn.eps).clamp_min_(0.0)           # biased variance of this rank's batch

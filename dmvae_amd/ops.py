@@ -788,12 +788,20 @@ def col2im(dcol: torch.Tensor, h: int, w: int, ks: int, stride: int, pad: int) -
     return dx
 
 
+def batchnorm_running_update(stats: torch.Tensor, running_mean: torch.Tensor, running_var: torch.Tensor, eps: float, momentum: float, unbias: float) -> None:
+    """nn.BatchNorm2d's running-estimate update from (mean, rstd) pairs stats [..., C, 2] f32, in place, one launch (include/dmvae_hip.h)."""
+    c = running_mean.numel()
+    assert stats.dtype == f32 and stats.is_contiguous() and stats.numel() == 2 * c and running_mean.dtype == f32 and running_var.dtype == f32
+    check(_lib.lib().dmvae_batchnorm_running_update(stats.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), c, float(eps), float(momentum), float(unbias),
+                                                    _stream()), "batchnorm_running_update")
+
+
 def _diffaug_args(x, rand01, flags, cutout):
     assert x.dtype == f32 and x.is_cuda and x.is_contiguous() and x.dim() == 4
     b, c, h, w = x.shape
     rand01 = _req(rand01, f32, "rand01")
     assert rand01.numel() == 7 * b
-    ws = torch.empty(b, dtype=f32, device=x.device)
+    ws = torch.empty(36 * b, dtype=f32, device=x.device)      # b means + 16 f64 partials per image (include/dmvae_hip.h)
     # Python round() on the same float expressions as utils/diffaug.py:73-75,92-94
     return rand01, ws, (b, c, h, w, int(flags), round(h * 0.125), round(w * 0.125), round(h * cutout), round(w * cutout))
 

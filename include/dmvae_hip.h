@@ -339,11 +339,16 @@ int dmvae_col2im_nhwc(const void* dcol, void* dx, int n, int h, int w, int c, in
                       dmvae_stream_t stream);
 /* dx = y > 0 ? dy : slope*dy  (nn.LeakyReLU(0.2) backward from the saved OUTPUT, patchgan.py:125,136,144). bf16, n%8==0. */
 int dmvae_leaky_relu_bwd(const void* dy, const void* y, void* dx, size_t n, float slope, dmvae_stream_t stream);
+/* nn.BatchNorm2d's running-estimate update (models/patchgan.py:125-147's norm layers in training mode) from the batch statistics this build's kernels keep as
+ * (mean, rstd) pairs, stats f32 [c][2]: var = max(1 / rstd^2 - eps, 0); running_mean = (1 - momentum) running_mean + momentum mean; running_var = (1 - momentum)
+ * running_var + momentum * unbias * var (unbias = n / (n - 1)).  f32 running buffers, in place. */
+int dmvae_batchnorm_running_update(const void* stats, void* running_mean, void* running_var, int c, float eps, float momentum, float unbias, dmvae_stream_t stream);
 /* DiffAug (utils/diffaug.py:43-114) on NCHW f32 images [b,c<=8,h,w], blur warm-up off (schedule 0 at every reference call site):
  * translate by th,tw = floor(r0|r1*(2*delta+1)) - delta with zero fill; brightness r2-0.5, per-pixel saturation 2*r3, per-image
  * contrast r4+0.5; zero the cut_h x cut_w rectangle centred at floor(r5|r6*(size+1-cut%2)), clamped at the border.
  * rand01: device f32 [7][b] = torch.rand(7,b,1,1) (:69); flags: bit 0 translate, bit 1 colour, bit 2 cut-out (torch.rand(3) <= prob,
- * :66); delta_* = round(size*0.125), cut_* = round(size*cutout) (:73-75,:92-94).  workspace: b floats.  bwd is the exact adjoint. */
+ * :66); delta_* = round(size*0.125), cut_* = round(size*cutout) (:73-75,:92-94).  workspace: 36 * b floats, 8-byte aligned (the b per-image means + the
+ * two-stage reduction's f64 partials).  bwd is the exact adjoint. */
 int dmvae_diffaug_fwd(const void* x, const void* rand01, void* y, void* workspace, int b, int c, int h, int w, int flags,
                       int delta_h, int delta_w, int cut_h, int cut_w, dmvae_stream_t stream);
 int dmvae_diffaug_bwd(const void* dy, const void* rand01, void* dx, void* workspace, int b, int c, int h, int w, int flags,
