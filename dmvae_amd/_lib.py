@@ -50,6 +50,9 @@ SIGNATURES = {
     "dmvae_linear_rows_bf16": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     "dmvae_linear_rows_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "dmvae_linear_bf16": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
+    "dmvae_linear_bf16_splitk_supported": (c_int, [c_int] * 4),
+    "dmvae_linear_bf16_splitk": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
+    "dmvae_splitk_sum_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "dmvae_linear_bf16_batched_supported": (c_int, [c_int] * 4),
     "dmvae_linear_bf16_batched": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_longlong] * 3 + [c_int, c_void_p]),
     "dmvae_linear_bf16_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),

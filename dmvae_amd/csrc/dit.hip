@@ -80,6 +80,74 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(const float* x, c
   }
 }
 
+// The same kernel with EIGHT channels per lane (C % 8 == 0): 32-B f32 and 16-B bf16 accesses per lane -- half the memory instructions, and the bf16 result leaves
+// in 16-B stores (1 KiB per wave-instruction; the 4-channel form's 8-B stores are store-issue-bound on the large calls: 2.95 TB/s at batch 64).
+// SW8 = ceil(C / 512).  Per-row arithmetic as above; the sum of squares is taken in this kernel's own lane order, so the two forms differ in the last f32 bit of rs.
+template <bool RES, int SW8>
+__global__ __launch_bounds__(256) void rmsnorm_modulate8_kernel(const float* x, const float* __restrict__ w, const bf16* __restrict__ mod,
+                                                                bf16* __restrict__ y, int rows, int rows_per_sample, int C, int stride, int shift_off,
+                                                                int scale_off, float eps, const bf16* __restrict__ r, const bf16* __restrict__ gmod,
+                                                                int gstride, int gate_off, float* xo) {
+#pragma clang fp contract(off)
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * C;
+  f32x4 v0[SW8], v1[SW8];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < SW8; k++) {
+    const int c = k * 512 + lane * 8;
+    if (c < C) {
+      v0[k] = *reinterpret_cast<const f32x4*>(xr + c);
+      v1[k] = *reinterpret_cast<const f32x4*>(xr + c + 4);
+      if constexpr (RES) {
+        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(r + (size_t)row * C + c);
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(gmod + (size_t)(row / rows_per_sample) * gstride + gate_off + c);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          v0[k][e] += (float)(bf16)((float)g[e] * (float)rv[e]);
+          v1[k][e] += (float)(bf16)((float)g[4 + e] * (float)rv[4 + e]);
+        }
+        *reinterpret_cast<f32x4*>(xo + (size_t)row * C + c) = v0[k];
+        *reinterpret_cast<f32x4*>(xo + (size_t)row * C + c + 4) = v1[k];
+      }
+      ss += ((v0[k][0] * v0[k][0] + v0[k][1] * v0[k][1]) + (v0[k][2] * v0[k][2] + v0[k][3] * v0[k][3])) +
+            ((v1[k][0] * v1[k][0] + v1[k][1] * v1[k][1]) + (v1[k][2] * v1[k][2] + v1[k][3] * v1[k][3]));
+    }
+  }
+  if (RES && !y) return;
+  const bf16* mrow = mod + (size_t)(row / rows_per_sample) * stride;
+  f32x4 g0[SW8], g1[SW8];
+  bf16x8 scv[SW8], shv[SW8];
+#pragma unroll
+  for (int k = 0; k < SW8; k++) {
+    const int c = k * 512 + lane * 8;
+    if (c < C) {
+      g0[k] = *reinterpret_cast<const f32x4*>(w + c);
+      g1[k] = *reinterpret_cast<const f32x4*>(w + c + 4);
+      scv[k] = *reinterpret_cast<const bf16x8*>(mrow + scale_off + c);
+#pragma unroll
+      for (int e = 0; e < 8; e++) shv[k][e] = (bf16)0.f;
+      if (shift_off >= 0) shv[k] = *reinterpret_cast<const bf16x8*>(mrow + shift_off + c);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(ss) / (float)C + eps);
+  bf16* yr = y + (size_t)row * C;
+#pragma unroll
+  for (int k = 0; k < SW8; k++) {
+    const int c = k * 512 + lane * 8;
+    if (c < C) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        o[e] = (bf16)(v0[k][e] * rs * g0[k][e] * (float)(bf16)(1.f + (float)scv[k][e]) + (float)shv[k][e]);
+        o[4 + e] = (bf16)(v1[k][e] * rs * g1[k][e] * (float)(bf16)(1.f + (float)scv[k][4 + e]) + (float)shv[k][4 + e]);
+      }
+      *reinterpret_cast<bf16x8*>(yr + c) = o;
+    }
+  }
+}
+
 // one wave per (token, head); lane j < D/2 owns the feature pair (2j, 2j+1)
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(const bf16* __restrict__ qkv, const float* __restrict__ qw, const float* __restrict__ kw,
                                                           const float* __restrict__ cosb, const float* __restrict__ sinb, bf16* __restrict__ qo,
@@ -483,12 +551,28 @@ static inline int grid_for(size_t n, int block = 256, int cap = 4096) {
 }  // namespace dmvae_dit
 using namespace dmvae_dit;
 
+// The eight-channel kernels from 8192 rows on (batch 32+: 46.9 vs 51.1 us at batch 64, profiles/r5_dit_norm_passes.txt; at batch 16 the four-channel form is the faster by
+// a microsecond); DMVAE_RM8=0: the four-channel kernels everywhere (A/B runs)
+static bool rm8_on() { static const bool v = [] { const char* e = getenv("DMVAE_RM8"); return !(e && e[0] == '0'); }(); return v; }
+
 extern "C" int dmvae_rmsnorm_modulate_bf16(const void* x, const void* w, const void* mod, void* y, int rows, int rows_per_sample, int c, int mod_stride,
                                            int shift_off, int scale_off, float eps, hipStream_t stream) {
   DMVAE_CHECK_ARG(x && w && mod && y && rows > 0 && rows_per_sample > 0, "rmsnorm_modulate_bf16: bad argument");
   DMVAE_CHECK_ARG(c % 4 == 0 && c >= 4 && c <= MAX_SWEEPS * 256, "rmsnorm_modulate_bf16: width must be a multiple of 4 up to 2048 (got %d)", c);
   DMVAE_CHECK_ARG(scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride,
                   "rmsnorm_modulate_bf16: modulation offsets must be multiples of 4 inside the row");
+  if (c % 8 == 0 && mod_stride % 8 == 0 && scale_off % 8 == 0 && (shift_off < 0 || shift_off % 8 == 0) && rows >= 8192 && rm8_on()) {
+    switch ((c + 511) / 512) {
+      case 1: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<false, 1>), dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
+                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr); break;
+      case 2: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<false, 2>), dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
+                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr); break;
+      case 3: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<false, 3>), dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
+                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr); break;
+      default: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<false, 4>), dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
+                     (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr); break;
+    }
+  } else
   switch ((c + 255) / 256) {
     case 1: hipLaunchKernelGGL((rmsnorm_modulate_kernel<false, 1>), dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
                      (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr); break;
@@ -517,6 +601,18 @@ extern "C" int dmvae_gated_residual_rmsnorm_modulate(void* x, const void* r, con
   DMVAE_CHECK_ARG(scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride &&
                       gate_off >= 0 && gate_off % 4 == 0 && gate_stride % 4 == 0 && gate_off + c <= gate_stride,
                   "gated_residual_rmsnorm_modulate: modulation offsets must be multiples of 4 inside the row");
+  if (c % 8 == 0 && mod_stride % 8 == 0 && scale_off % 8 == 0 && (shift_off < 0 || shift_off % 8 == 0) && gate_off % 8 == 0 && gate_stride % 8 == 0 && rows >= 8192 && rm8_on()) {
+    switch ((c + 511) / 512) {
+      case 1: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<true, 1>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
+                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x); break;
+      case 2: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<true, 2>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
+                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x); break;
+      case 3: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<true, 3>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
+                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x); break;
+      default: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<true, 4>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
+                     rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x); break;
+    }
+  } else
   switch ((c + 255) / 256) {
     case 1: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 1>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
                      rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x); break;
@@ -547,6 +643,18 @@ extern "C" int dmvae_gated_residual_out(const void* x_in, void* x_out, const voi
   DMVAE_CHECK_ARG(gate_off >= 0 && gate_off % 4 == 0 && gate_stride % 4 == 0 && gate_off + c <= gate_stride &&
                       (!y || (scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride)),
                   "gated_residual_out: modulation offsets must be multiples of 4 inside the row");
+  if (c % 8 == 0 && mod_stride % 8 == 0 && scale_off % 8 == 0 && (shift_off < 0 || shift_off % 8 == 0) && gate_off % 8 == 0 && gate_stride % 8 == 0 && rows >= 8192 && rm8_on()) {
+    switch ((c + 511) / 512) {
+      case 1: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<true, 1>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
+                     rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out); break;
+      case 2: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<true, 2>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
+                     rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out); break;
+      case 3: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<true, 3>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
+                     rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out); break;
+      default: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<true, 4>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
+                     rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out); break;
+    }
+  } else
   switch ((c + 255) / 256) {
     case 1: hipLaunchKernelGGL((rmsnorm_modulate_kernel<true, 1>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
                      rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out); break;

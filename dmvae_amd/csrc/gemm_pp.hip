@@ -545,6 +545,70 @@ extern "C" int dmvae_linear_bf16_batched(const void* x, const void* w, void* y, 
   return launch<128, 256, 2, 4, false, true>(a, stream, batch);
 }
 
+// Split-K form for few-tile, deep-K problems (LightningDiT at batch 16: M = 4096, N = 1152 is 18 tiles of 256 x 256 -- w3's K = 3072, the input gradients of qkv /
+// w12 with K = 3456 / 6144): the reduction is cut into `splits` equal parts, each part is one "product" of the BATCHED 256 x 256 instantiation (its operand offsets
+// select the K range: x by splits * 64-byte columns, w by the same columns (row-major) or by whole K tiles (K-tile-major); its y offset the part's f32 slab), so that
+// 80 tiles become 240 work units of a third of the length.  slabs: f32 [splits][M][N]; the caller sums them (dmvae_splitk_sum_bf16) -- fixed order, deterministic.
+extern "C" int dmvae_linear_bf16_splitk_supported(int M, int N, int K, int splits) {
+  return (splits >= 2 && splits <= 8 && M >= 64 && N > 0 && N % 8 == 0 && K % (32 * splits) == 0 && K / splits >= 384 &&
+          (long long)splits * M * N * 4 < (1ll << 31)) ? 1 : 0;
+}
+extern "C" int dmvae_linear_bf16_splitk(const void* x, const void* w, void* slabs, int splits, int M, int N, int K, int lda, int ldw, int w_layout, hipStream_t stream) {
+  using namespace dmvae_gemm_pp;
+  DMVAE_CHECK_ARG(x && w && slabs, "linear_bf16_splitk: null operand");
+  DMVAE_CHECK_ARG(dmvae_linear_bf16_splitk_supported(M, N, K, splits), "linear_bf16_splitk: M %d N %d K %d splits %d (K %% (32 splits) == 0, K / splits >= 384, N %% 8 == 0)", M, N, K, splits);
+  DMVAE_CHECK_ARG(w_layout == 0 || w_layout == 1, "linear_bf16_splitk: w_layout must be 0 or 1");
+  DMVAE_CHECK_ARG(lda >= K && (w_layout == 1 || ldw >= K) && lda % 8 == 0 && ldw % 8 == 0, "linear_bf16_splitk: leading dimensions must cover the rows and be multiples of 8");
+  const long long wb = w_layout == 1 ? (long long)N * K * 2 : (long long)N * ldw * 2;
+  DMVAE_CHECK_ARG((long long)M * lda * 2 < (1ll << 31) && wb < (1ll << 31), "linear_bf16_splitk: operands are addressed through 32-bit buffer offsets (2 GiB each)");
+  const int Ks = K / splits;
+  Args a;
+  a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = nullptr; a.y = slabs;
+  a.M = M; a.N = N; a.K = Ks; a.lda = lda; a.ldw = ldw; a.ldy = N;
+  a.act = 0; a.bias_bf16 = 0; a.H = N / 2; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = nullptr;
+  a.wbytes = (unsigned)wb; a.xbytes = (unsigned)((long long)M * lda * 2); a.ybytes = (unsigned)((long long)splits * M * N * 4);
+  a.wsRow = w_layout == 1 ? 64u : (unsigned)ldw * 2u;
+  a.wsK = w_layout == 1 ? (unsigned)N * 64u : 64u;
+  a.sB = (unsigned)Ks * 2u;                                                      // x: Ks columns further per part
+  a.sA = w_layout == 1 ? (unsigned)(Ks / 32) * (unsigned)N * 64u : (unsigned)Ks * 2u;   // w: whole K tiles (K-tile-major) or Ks columns (row-major)
+  a.sY = (unsigned)((long long)M * N * 4);
+  return launch<256, 256, 2, 4, true, true>(a, stream, splits);
+}
+// y bf16 [n] = bf16(sum_s slabs[s][n] + bias[col]) (bias f32 / bf16 [N] or null; n = M * N): the fixed-order sum of dmvae_linear_bf16_splitk's parts, rounded once.
+namespace dmvae_gemm_pp {
+__global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict__ slabs, const void* __restrict__ bias, int bias_bf16, bf16* __restrict__ y, size_t n8,
+                                                         size_t slab, int S, int N) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(slabs + i * 8), a1 = *reinterpret_cast<const f32x4*>(slabs + i * 8 + 4);
+    for (int s = 1; s < S; s++) {
+      a0 += *reinterpret_cast<const f32x4*>(slabs + s * slab + i * 8);
+      a1 += *reinterpret_cast<const f32x4*>(slabs + s * slab + i * 8 + 4);
+    }
+    if (bias) {
+      const int c = (int)((i * 8) % (size_t)N);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        a0[e] += bias_bf16 ? (float)((const bf16*)bias)[c + e] : ((const float*)bias)[c + e];
+        a1[e] += bias_bf16 ? (float)((const bf16*)bias)[c + 4 + e] : ((const float*)bias)[c + 4 + e];
+      }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { o[e] = (bf16)a0[e]; o[4 + e] = (bf16)a1[e]; }
+    *reinterpret_cast<bf16x8*>(y + i * 8) = o;
+  }
+}
+}  // namespace dmvae_gemm_pp
+extern "C" int dmvae_splitk_sum_bf16(const void* slabs, int splits, const void* bias, int bias_bf16, void* y, int M, int N, hipStream_t stream) {
+  using namespace dmvae_gemm_pp;
+  DMVAE_CHECK_ARG(slabs && y && splits >= 1 && M > 0 && N > 0 && N % 8 == 0, "splitk_sum_bf16: bad argument (N %% 8 == 0)");
+  const size_t n8 = (size_t)M * N / 8;
+  const unsigned grid = (unsigned)((n8 + 255) / 256 > 4096 ? 4096 : (n8 + 255) / 256);
+  hipLaunchKernelGGL(splitk_sum_kernel, dim3(grid), dim3(256), 0, stream, (const float*)slabs, bias, bias_bf16, (bf16*)y, n8, (size_t)M * N, splits, N);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int dmvae_linear_bf16(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int lda, int ldw, int ldy,
                                  int act, int bias_bf16, int out_f32, int w_layout, hipStream_t stream) {
   using namespace dmvae_gemm_pp;

@@ -729,6 +729,24 @@ def _bf_km(w: torch.Tensor) -> torch.Tensor:
     return packed(w, kmajor=True, frozen=True)._dmvae_kmajor.view(cin // 32, cout, 32)
 
 
+SPLITK = int(os.environ.get("DMVAE_SPLITK", "3"))                # DitStackFn: parts of the reduction for its few-tile deep-K GEMMs (0: off; tests compare)
+SPLITK_MIN_K = int(os.environ.get("DMVAE_SPLITK_MINK", "3072"))
+_SPLITK_ACTIVE = [0]      # > 0 only inside DitStackFn's forward / backward: the inference route keeps one accumulation order for every batch size
+
+
+def _use_splitk(m: int, n: int, k: int) -> int:
+    """Parts to cut this GEMM's reduction into: LightningDiT-XL/1 at batch 16 -- M = 4096 rows x N = 1152 columns are 80 tiles of 256 x 256 (160 of 256 x 128: 60 % of the
+    chip for the whole reduction); with K >= 3072 three parts make 240 work units of a third of the length (w3: 47 -> ~41 us incl. the slab sum, the input gradient of
+    w12: 88 -> ~70)."""
+    s_ = _SPLITK_ACTIVE[0]
+    if s_ < 2 or parity.on() or not (2048 <= m <= 6144) or k < SPLITK_MIN_K:
+        return 0
+    tiles = ((m + 255) // 256) * ((n + 255) // 256)
+    if tiles > 100 or not ops.linear_splitk_supported(m, n, k, s_):
+        return 0
+    return s_
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, act: int = ops.ACT_NONE) -> torch.Tensor:
     """nn.Linear under autocast(bf16) on this build's GEMM kernels (no vendor library): x [..., K] bf16; w [N, K] and b [N] the f32 parameters (their bf16
     copies are cached / shadowed, `_bf`) or already-bf16 tensors (a frozen bf16 shadow module).  f32 accumulation, bias added in f32, bf16 result, optional
@@ -745,6 +763,9 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, a
     if m <= 64 and act in (ops.ACT_NONE, ops.ACT_SILU) and ops.linear_rows_supported(m, n, k) and not parity.on():
         # one row per SAMPLE (adaLN modulations, timestep embedder): the weight-streaming kernel, csrc/linear_rows.hip
         return ops.linear_rows(x.view(m, k), (w if w.dtype == bf16 else _bf(w)).view(n, k), bb, act).view(*x.shape[:-1], n)
+    sk = _use_splitk(m, n, k) if act == ops.ACT_NONE else 0
+    if sk:
+        return ops.linear_splitk(x.view(m, k), (w if w.dtype == bf16 else _bf(w)).view(n, k), bb, sk).view(*x.shape[:-1], n)
     if ops.linear_supported(m, n, k) and (act != ops.ACT_SWIGLU or n % 16 == 0):
         # frozen weights -- an nn.Parameter that is not trainable AND not owned by one of this build's optimisers (a student DiT switched to requires_grad
         # False for the DMD loss's evaluations still changes every few steps: it keeps the row-major shadow its optimiser maintains) -- : the K-tile-major
@@ -807,6 +828,9 @@ def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Te
         wt = _bf_t(w)
         return ops.linear_rows(_c(dy2), wt if wt.dim() == 3 else wt.view(cin, cout)), dw, db
     if ops.linear_supported(rows, cin, cout) and not parity.on():
+        sk = _use_splitk(rows, cin, cout)
+        if sk:
+            return ops.linear_splitk(_c(dy2), _bf_t(w), None, sk), dw, db
         return ops.linear_bf16(_c(dy2), _bf_t(w)), dw, db                 # dX = dY . W as an NT GEMM against the transposed copy
     if cout % 32 == 0 and cin % 4 == 0:
         return ops.gemm_nt(_c(dy2), packed(w, True).view(cin, cout)), dw, db
@@ -1092,6 +1116,7 @@ class DitStackFn(torch.autograd.Function):
         d = c // heads
         h = _c(h)
         scb = _c(sc).to(bf16)
+        _SPLITK_ACTIVE[0] = SPLITK
         blocks = [params[i * P:(i + 1) * P] for i in range(nl)]
         mod_all = ops.linear_rows_batched(scb, [_bf(bp[12]) for bp in blocks], [_bf(bp[13]) for bp in blocks])          # [L, B, 6C] bf16
         saved, lses = [], []
@@ -1116,6 +1141,7 @@ class DitStackFn(torch.autograd.Function):
             o3 = linear(g, w3w, w3b)
             saved += [h_in, a1, qkv, q, k, v, o, o2, h_mid, a2, x12, g, o3]
         h_out, _ = ops.gated_residual_out(h_mid, o3, mod_all[nl - 1], 5 * c)
+        _SPLITK_ACTIVE[0] = 0
         ctx.save_for_backward(scb, mod_all, cos, sin, *saved, *params)
         ctx.cfg = (nl, heads, eps, sc.dtype)
         ctx.lses = lses
@@ -1136,6 +1162,7 @@ class DitStackFn(torch.autograd.Function):
         fresh = lambda p: _dst(p) if _dst(p) is not None else torch.empty(p.shape, dtype=f32, device=dt.device)
         norm_dws, qn_dws, kn_dws = [None] * (2 * nl), [None] * nl, [None] * nl
         pend = []      # (dy, x, dW, db) of every block Linear: ONE grouped weight-gradient launch when the chain is done -- 4 x depth problems, each unsplit, fill the chip
+        _SPLITK_ACTIVE[0] = SPLITK
         do3 = S.boundary(2 * nl, dt, y=acts[13 * (nl - 1) + 12], gate_mod=mod_all[nl - 1], gate_off=5 * c)
         for i in range(nl - 1, -1, -1):
             h_in, a1, qkv, q, k, v, o, o2, h_mid, a2, x12, g, o3 = acts[13 * i:13 * i + 13]
@@ -1157,6 +1184,7 @@ class DitStackFn(torch.autograd.Function):
                 S.boundary(0, dt, da=da1.view(b, n, c), x=h_in, w=n1w, mod=mod, scale_off=c, eps=eps)
             norm_dws[2 * i], norm_dws[2 * i + 1], qn_dws[i], kn_dws[i] = fresh(n1w), fresh(n2w), fresh(qnw), fresh(knw)
             G[P * i + 0], G[P * i + 7], G[P * i + 3], G[P * i + 4] = norm_dws[2 * i], norm_dws[2 * i + 1], qn_dws[i], kn_dws[i]
+        _SPLITK_ACTIVE[0] = 0
         if pend:
             ops.linear_wgrad_grouped(pend)
         dmod = torch.empty_like(mod_all)

@@ -393,6 +393,32 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     return y
 
 
+def linear_splitk_supported(m: int, n: int, k: int, splits: int) -> bool:
+    return bool(_lib.lib().dmvae_linear_bf16_splitk_supported(int(m), int(n), int(k), int(splits)))
+
+
+def linear_splitk(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, splits: int = 3) -> torch.Tensor:
+    """y [M, N] bf16 = x [M, K] @ w^T + bias with the reduction cut into `splits` parts computed as independent work units (f32 slabs) and summed in order
+    (include/dmvae_hip.h dmvae_linear_bf16_splitk / dmvae_splitk_sum_bf16): for few-tile, deep-K problems.  w bf16 [N, K] row-major or K-tile-major [K / 32, N, 32]."""
+    x = _req2d(x, "x")
+    m, k = x.shape
+    if w.dim() == 3:
+        assert w.dtype == bf16 and w.is_contiguous() and w.shape[0] * 32 == k and w.shape[2] == 32
+        n, layout, ldw = w.shape[1], 1, k
+    else:
+        w = _req2d(w, "w")
+        n, layout, ldw = w.shape[0], 0, w.stride(0)
+        assert w.shape[1] == k
+    L = _lib.lib()
+    slabs = workspace(splits * m * n * 4, x.device, "splitk_slabs")
+    y = torch.empty(m, n, dtype=bf16, device=x.device)
+    check(L.dmvae_linear_bf16_splitk(x.data_ptr(), w.data_ptr(), slabs.data_ptr(), int(splits), m, n, k, x.stride(0), ldw, layout, _stream()), "linear_bf16_splitk")
+    if bias is not None:
+        assert bias.is_contiguous() and bias.numel() == n and bias.dtype in (bf16, f32)
+    check(L.dmvae_splitk_sum_bf16(slabs.data_ptr(), int(splits), _ptr(bias), int(bias is not None and bias.dtype == bf16), y.data_ptr(), m, n, _stream()), "splitk_sum_bf16")
+    return y
+
+
 def linear_rows_supported(m: int, n: int, k: int) -> bool:
     """Shapes csrc/linear_rows.hip takes: 1 <= m <= 64 rows (one per sample), k % 32 == 0, n % 4 == 0."""
     return bool(_lib.lib().dmvae_linear_rows_supported(int(m), int(n), int(k)))

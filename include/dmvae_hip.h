@@ -262,6 +262,13 @@ int dmvae_linear_bf16_plan(int M, int N, int K, int* tile_cols, int* tile_rows);
 int dmvae_linear_bf16_batched_supported(int batch, int M, int N, int K);
 int dmvae_linear_bf16_batched(const void* x, const void* w, void* y, int batch, int M, int N, int K, int lda, int ldw, int ldy, long long sx, long long sw,
                               long long sy, int out_f32, dmvae_stream_t stream);
+/* Split-K form of dmvae_linear_bf16 for few-tile, deep-K problems (LightningDiT at batch 16: M = 4096 x N = 1152 is 18 tiles of 256 x 256; K = 3072 ... 6144):
+ * the reduction cut into `splits` equal parts computed as independent work units into f32 slabs [splits][M][N] (no bias, no activation), then
+ * dmvae_splitk_sum_bf16: y bf16 [M][N] = bf16(slab_0 + slab_1 + ... + bias) in that order (bias f32, or bf16 when bias_bf16; may be NULL).
+ * K % (32 splits) == 0, K / splits >= 384, N % 8 == 0; w row-major [N][ldw] (w_layout 0) or K-tile-major (1).  Deterministic. */
+int dmvae_linear_bf16_splitk_supported(int M, int N, int K, int splits);
+int dmvae_linear_bf16_splitk(const void* x, const void* w, void* slabs, int splits, int M, int N, int K, int lda, int ldw, int w_layout, dmvae_stream_t stream);
+int dmvae_splitk_sum_bf16(const void* slabs, int splits, const void* bias, int bias_bf16, void* y, int M, int N, dmvae_stream_t stream);
 /* The input-gradient operand of dmvae_linear_bf16 from a Linear weight's bf16 copy: w bf16 [N][K] row-major (nn.Linear.weight: N = out_features, K = in_features)
  * -> out bf16 [N / 32][K][32], out[n >> 5][k][n & 31] = w[n][k], i.e. the K-tile-major layout (w_layout = 1) of W^T [K][N] with the reduction over n:
  * dmvae_linear_bf16(dy [M][N], out, NULL, dx, M, K, N, ..., w_layout = 1) is dX = dY . W.  N % 32 == 0, K % 8 == 0.  One tiled-transpose launch per weight

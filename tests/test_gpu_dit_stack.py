@@ -247,3 +247,26 @@ def test_inference_forward_with_batched_adaln_is_bit_identical(tag):
         finally:
             lf.BATCHED_ADALN = True
     assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("m,n,k,splits,kmajor", [(4096, 1152, 3072, 3, False), (4096, 1152, 6144, 3, True), (4096, 1152, 3456, 3, True), (300, 72, 768, 2, False),
+                                                 (257, 1152, 1536, 4, True)])
+def test_splitk_linear(m, n, k, splits, kmajor):
+    """ops.linear_splitk = x w^T + bias with the reduction in `splits` parts: against fp64 at the bf16 result's rounding, against the unsplit kernel to a flip of the
+    last bf16 bit on a few elements (another f32 summation order), rerun-identical."""
+    from dmvae_amd import ops
+    g = torch.Generator().manual_seed(m + n + k)
+    x = torch.randn(m, k, generator=g).to(DEV).to(BF)
+    w = (0.03 * torch.randn(n, k, generator=g)).to(DEV).to(BF)
+    b = torch.randn(n, generator=g).to(DEV)
+    assert ops.linear_splitk_supported(m, n, k, splits)
+    wk = ops.pack_conv_weight(w.float(), kmajor=True)._dmvae_kmajor.view(k // 32, n, 32) if kmajor else w
+    y = ops.linear_splitk(x, wk, b, splits)
+    ref = x.double() @ w.double().t() + b.double()
+    assert _rl2(y, ref) < 3e-3
+    y0 = ops.linear_bf16(x, wk, b) if ops.linear_supported(m, n, k) else None
+    if y0 is not None:
+        assert (y != y0).float().mean().item() < 2e-2 and _rl2(y, y0.double()) < 2e-3
+    assert torch.equal(y, ops.linear_splitk(x, wk, b, splits))
+    y2 = ops.linear_splitk(x, wk, None, splits)
+    assert _rl2(y2, ref - b.double()) < 3e-3
