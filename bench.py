@@ -288,7 +288,7 @@ def kl_mmd_roofline(dev):
                         "Gpair_per_s": round(pairs / us / 1e3, 1),
                         # this shape runs the matrix-core pair kernel: 64 FLOP (a.b) per pair + 64 FLOP (sum w b) for the two thirds of the pairs that carry a gradient
                         "mfma_f32_TFLOPs": round(pairs * (64.0 + 64.0 * 2 / 3) / us / 1e6, 2), "mfma_f32_frac": round(pairs * (64.0 + 64.0 * 2 / 3) / us / 1e6 / 157.3, 4),
-                        "bound": "latency (two launches of ~5 us floor each) + f32 matrix cores / exp, not HBM (3 MB of traffic against 6.3 M kernel evaluations): see DESIGN.md 3.4"}
+                        "bound": "latency (two launches of ~5 us floor each) + f32 matrix cores / exp, not HBM (3 MB of traffic against 6.3 M kernel evaluations): see DESIGN_HISTORY.md 3.4"}
     zl = torch.randn(8192, 256, 32, device=dev)       # 268 MB
     us = timed(lambda: ops.kl_mmd(zl, None, need_grad=True), 10)
     byt = 3 * zl.numel() * 4

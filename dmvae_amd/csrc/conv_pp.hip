@@ -18,7 +18,7 @@
 //
 //   * plain 3x3 convs with a bf16 result run the HALO instantiations (described at the kernel template): the three kx taps of a (channel chunk, ky) read one
 //     staged halo of the pixel tile, the weights come K-tile-major (dmvae_conv_desc.w_layout = 1) so that a weight tile is whole 128-B lines; tiles 256 x 256,
-//     128 x 512 and, for 64 output channels, 64 x 1024.  What that was worth, and the timing experiments behind it: DESIGN.md 8.12 / 8.13.
+//     128 x 512 and, for 64 output channels, 64 x 1024.  What that was worth, and the timing experiments behind it: DESIGN_HISTORY.md 8.12 / 8.13.
 //
 // Hazards (B_k = k-th workgroup barrier; group 0 = waves 0-3, group 1 = waves 4-7, one barrier behind):
 //   RAW  tile t+1 is read after B_{2t+2}; every wave waits (vmcnt) for its own pieces of t+1 at the end of its LOAD(t),
@@ -34,7 +34,7 @@
 #include <unordered_map>
 
 // What was measured on this kernel and not adopted (each a source variant at the time, bit-identical where it computed the same thing) is kept as text, not as
-// code: DESIGN.md 8.12 / 8.13 (the timing experiments behind the kx-halo form), 9.3 (LDS-staged against direct epilogue), 9.6 (one continuous K-tile stream per block,
+// code: DESIGN_HISTORY.md 8.12 / 8.13 (the timing experiments behind the kx-halo form), 9.3 (LDS-staged against direct epilogue), 9.6 (one continuous K-tile stream per block,
 // staggered XCD starts, cache-policy bits of the epilogue's stores and of the LDS-DMA: nt stores, plain DMA).
 
 namespace dmvae_conv_pp {
@@ -60,7 +60,7 @@ constexpr unsigned SENT = 0x80000000u;  // voffset beyond any descriptor's num_r
 
 // 64-B rows, 4 rows per 256-B bank row.  Fragments are read for v_mfma_f32_16x16x32_bf16: lane l takes the 16-B chunk l >> 4 of row (l & 15), and
 // ds_read_b128 serves the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... in one pass each; with the chunk XOR-ed by (-(row >> 2)) & 3 the four lanes of
-// a group that share row % 4 land in four different 16-B slots of the bank row (derivation in DESIGN.md 3.1).
+// a group that share row % 4 land in four different 16-B slots of the bank row (derivation in DESIGN_HISTORY.md 3.1).
 __device__ __forceinline__ int swz64(int row) { return (0 - (row >> 2)) & 3; }
 __device__ __forceinline__ int hswz(int row) { return (row >> 1) & 2; }   // HALO rows: the key that stays conflict-free under a shift of 0..2 rows
 
@@ -102,7 +102,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // HALO (plain 3x3, stride 1): the three kx taps of a (channel chunk, ky) read the SAME pixels shifted by one, so the activation operand of three consecutive
 // K tiles is staged once, as the TP + 2 flat pixels m0 - 1 .. m0 + TP of source row offset ky - 1 (TP / 16 + 1 pieces instead of 3 * TP / 16), and tap kx
 // reads pixel p's fragment from halo row p + kx.  A timing experiment (the same instruction stream with two of three activation pieces
-// masked) measured +12-14 % on the decoder's shapes: what the L2 -> LDS staging costs this kernel scales with the bytes it moves.
+// masked) measured +12-14 % on the decoder's shapes: what the L2 -> LDS staging costs this kernel scales with the bytes it moves (DESIGN_HISTORY.md 8.12).
 //   * x edges: the flat neighbour of an image row's first / last pixel belongs to another row; those lanes' fragment addresses point at an all-zero row
 //     of the halo slot instead (rows TP + 2 .. TP + 15 of the last piece are out-of-range lanes of the DMA, which writes zeros for them);
 //   * y edges / ragged M: per-lane validity of the staged pixel per ky, taken from the tile pixel that reads it ("owner": halo row i belongs to pixel
@@ -998,7 +998,7 @@ int launch(Args a, hipStream_t st) {
 // FETCH_SIZE per launch 9.0x vs 2.2x the compulsory bytes at 512->512 @128^2 (profiles/r1_conv_hbm_traffic.txt).  The folded-upsample
 // variant keeps the taps outer (its per-tap source selection is too costly to redo every K tile).
 static constexpr int halo_mode() { return 3; }   // bit 0: the 256 x 256 tile, bit 1: + the 128 x 512 and 64 x 1024 tiles run the kx-halo form
-static constexpr bool korder_on() { return true; }   // channel chunk outer, tap inner (the taps-outer order re-fetched the input 9x from HBM)
+static constexpr bool korder_on() { return true; }   // channel chunk outer, tap inner (DESIGN_HISTORY.md 3.1: the taps-outer order re-fetched the input 9x from HBM)
 // the launches pick() sends to a HALO instantiation (given that dmvae_conv_pp_try takes the shape at all)
 static bool halo_for(int ks, int cout, bool plain, bool ups, bool f32) {
   const int h = halo_mode();

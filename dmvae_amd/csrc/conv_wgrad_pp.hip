@@ -57,7 +57,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // Transpose read as inline asm, not __builtin_amdgcn_ds_read_tr16_b64: the compiler's wait-count pass orders every LDS read it can see behind every earlier LDS-DMA
 // (it cannot prove the ring slots disjoint) and put an s_waitcnt vmcnt(0) at the head of the K loop -- the three-tile prefetch queue was drained once per K tile and
-// the loop ran at the latency of the newest piece (tools/loop_waits.py shows the skeleton; 128->128 @256^2: 815 -> see DESIGN.md 8.12).  The asm form carries no memory
+// the loop ran at the latency of the newest piece (tools/loop_waits.py shows the skeleton; 128->128 @256^2: 815 -> see DESIGN_HISTORY.md 8.12).  The asm form carries no memory
 // operand; the loop's own counted vmcnt + barrier protocol is what orders the reads behind the pieces they need, and lgkmcnt(0) ahead of the barrier covers the results.
 template <int OFF>
 __device__ __forceinline__ s16x4 tr_read(unsigned lds_addr) {
@@ -464,7 +464,7 @@ int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_o
     constexpr bool relax = true;
     const bool exact0 = d->cout % 256 == 0 && (d->cin / 128) % 2 == 0;
     // The 128 x 384 tile's halo form with 64-pixel K tiles (190 instead of 128 FLOP per staged byte) also beats the 256 x 256 tile on shapes that tile fits
-    // exactly once the reduction is long: +3-8 % from 2^19 pixels on, +-0 below.
+    // exactly once the reduction is long: +3-8 % from 2^19 pixels on, +-0 below (DESIGN_HISTORY.md 8.13).
     constexpr int force = -1;
     const bool halo_ok = d->ks == 3 && d->stride <= 1 && !d->upsample && !d->transposed && d->w % 64 == 0 && wgrad_pp_halo_on();
     if (halo_ok && (force == 1 || (force < 0 && M >= (1ll << 19)))) { cfg = 1; mtiles = m1; ntiles = n1; }
@@ -476,7 +476,7 @@ int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_o
   const int ktiles = (int)(M / 32);
   int best = 1;
   double best_eff = 0;
-  // (at least two rounds of smaller blocks, for launches next to an overlapped collective's resident kernel, was measured and not adopted: DESIGN.md 8.6)
+  // (at least two rounds of smaller blocks, for launches next to an overlapped collective's resident kernel, was measured and not adopted: DESIGN_HISTORY.md 8.6)
   constexpr int min_rounds = 1;
   for (int s = 1; s <= ktiles / 16 && s * tiles <= 4096; s++) {
     const int blocks = s * tiles;

@@ -7,7 +7,7 @@
 // the two waves of a SIMD alternating LOAD and COMPUTE intervals, persistent blocks (one per CU) walking an XCD-aware tile order, an LDS-staged epilogue that
 // writes whole output rows.  What is new is the TILE: these GEMMs have few tiles per CU (M = batch x tokens = 8224 for ViT-L at batch 32 is 32.125 tiles of
 // 256 rows, N = 1024 is four tiles of 256 columns: 132 tiles for 256 CUs), so what a call costs is decided by tile quantisation -- the vendor library's picks
-// measure exactly "rounds x one 256 x 256 tile" (DESIGN.md 8.12).  Here the tile height is a template parameter in steps of 32 rows (wave grid 4 x 2, each wave
+// measure exactly "rounds x one 256 x 256 tile" (DESIGN_HISTORY.md 8.12).  Here the tile height is a template parameter in steps of 32 rows (wave grid 4 x 2, each wave
 // 64 columns x 16 * BP16 rows) or 64 rows (wave grid 2 x 4), and the host picks, per (M, N, K), the instantiation whose round count x tile cost is lowest
 // (dmvae_gemm_pp_plan): e.g. proj (N = 1024) runs 208 tiles of 256 x 160 in ONE round instead of 132 of 256 x 256 on half the chip.
 //
@@ -20,7 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-// Measured on this kernel and not adopted (kept as text): a hand-pipelined single-stream main loop with one barrier per K tile (and with one every
+// Measured on this kernel and not adopted (kept as text, DESIGN_HISTORY.md 9.1): a hand-pipelined single-stream main loop with one barrier per K tile (and with one every
 // second K tile), a four-wave 128 x 128 wave tile, a deeper / shallower ring, nt stores in the epilogue.
 constexpr int GEMM_MAXBUF = 6;   // ring depth cap; the ring is as deep as LDS allows up to this
 

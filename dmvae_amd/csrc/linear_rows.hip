@@ -5,7 +5,7 @@
 //   TimestepEmbedder.mlp = Linear(256, C) -> SiLU -> Linear(C, C) (:96-139),
 // and, against a transposed copy of the weight, their input gradients.  B = 16 ... 64 rows against a 6912 x 1152 weight: the weight is read once and nothing
 // is reused -- bound by streaming W from HBM (15.9 MB per adaLN call = 3.2 us at 5 TB/s), which neither tile kernel of this build is shaped for (the 256-row
-// GEMM tile is 94 % padding; the small batched kernel measured 62 us per call against ~5 for the vendor library).
+// GEMM tile is 94 % padding; the small batched kernel measured 62 us per call against ~5 for the vendor library, DESIGN_HISTORY.md 9.6).
 //
 // One workgroup (4 waves) owns 16 output columns; its waves split the K steps round-robin (so that ~7 waves per CU keep ~60 KB of weight reads in flight with
 // N / 16 workgroups over 256 CUs), every wave issues ALL of its W loads up front, multiplies on the matrix cores (v_mfma_f32_16x16x32_bf16: W rows as the A operand

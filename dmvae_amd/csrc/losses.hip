@@ -267,7 +267,7 @@ __global__ void dmd_final_kernel(const float* __restrict__ out_s, float* __restr
 //   kl[c]  = 0.5*(mu_c^2 + var_c - 1 - ln var_c), moments over all G*n rows of z [G][n][32]          (HBM-bound pass)
 //   mmd[g] = mean k(x,x) + mean k(y,y) - 2 mean k(x,y),  k(a,b) = mean_j exp(-|a-b|^2 / (2*mult_j*d)), mult = {.5,1,2,4,8}
 //   dz     = w_kl * d mean_c(kl_c)/dz + w_mmd * d mean_g(mmd_g)/dz
-// Roofline note: compulsory traffic is (G*n + G*m + G*n)*32*4 B, but the pair work is G*(n^2+nm+m^2) kernel
+// Roofline note (DESIGN_HISTORY.md 3.4): compulsory traffic is (G*n + G*m + G*n)*32*4 B, but the pair work is G*(n^2+nm+m^2) kernel
 // evaluations of ~46-78 VALU lane-ops each: at n = m = 256 the kernel is VALU/exp-bound, not HBM-bound; only the moments
 // pass (and MMD with small groups) can approach the HBM roofline.
 //
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256) void mmd_pair_mfma_kernel(const float* __restr
   const float inv16d = 1.f / (16.f * MMD_D), invd = 1.f / (float)MMD_D;
   // G^T of the next column block is issued before this block's VALU work (the matrix pipe runs it underneath).  An explicitly interleaved version (gradient
   // product of block jb - 1 and G^T of block jb + 1 alternating with the VALU work of block jb via sched_group_barrier) measured no faster: at the
-  // training shape the launch is latency-, not issue-bound.
+  // training shape the launch is latency-, not issue-bound (DESIGN_HISTORY.md 3.4).
   auto gram = [&](int jb) {
     const int j = jb * 32 + il;
     f32x16 c;

@@ -195,7 +195,7 @@ struct AttnArgs {
 // then runs under the other's matrix work and memory latency; with 256 threads the query blocks of a head were three serial rounds of load -> MFMA ->
 // softmax -> MFMA -> store per wave.  
 constexpr int ATTN_THREADS = 512;
-// (Serving the class token's query -- S = 32 k + 1 -- by extra single-query workgroups instead of a ninth 32-query block was built and measured slower: DESIGN.md 9.8-6.)
+// (Serving the class token's query -- S = 32 k + 1 -- by extra single-query workgroups instead of a ninth 32-query block was built and measured slower: DESIGN_HISTORY.md 9.8-6.)
 template <int DP, bool NR>
 __global__ __launch_bounds__(ATTN_THREADS) void attention_kernel(AttnArgs a) {
   constexpr int NT = ATTN_THREADS;

@@ -287,7 +287,7 @@ UPS_SUBPIXEL = None      # None: the default below; True / False: tests force a 
 
 
 def _subpixel_upsample() -> bool:
-    """Upsample's conv in its sub-pixel form -- on, except in the fp32 parity mode, which keeps the reference's own evaluation order: nine taps
+    """Upsample's conv in its sub-pixel form (DESIGN_HISTORY.md 8.1) -- on, except in the fp32 parity mode, which keeps the reference's own evaluation order: nine taps
     per output pixel gathered from the half-resolution image (the layer agrees to 1e-4 either way -- tests/test_gpu_parity_fp32.py -- but the four-step Adam
     trajectory test amplifies any reordering of f32 sums past that bar)."""
     return (not parity.on()) if UPS_SUBPIXEL is None else bool(UPS_SUBPIXEL)

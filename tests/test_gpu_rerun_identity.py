@@ -1,5 +1,5 @@
 """Bit-identical reruns of the kernels whose LDS fragment reads are inline asm (csrc/conv_wgrad_pp.hip, wgrad_thin.hip: the compiler inserts no waits between the
-LDS-DMA pieces and those reads -- the counted vmcnt + barrier protocol alone orders them) and of the other kernels added with them.  A race would show
+LDS-DMA pieces and those reads -- the counted vmcnt + barrier protocol alone orders them, DESIGN_HISTORY.md 8.12) and of the other kernels added with them.  A race would show
 as a run-to-run difference; tools/probes/stress_wgrad.py is the long form."""
 import pytest
 import torch

@@ -1,7 +1,7 @@
 """Build-time check of the weight-gradient kernels' K loops (CPU: hipcc cross-compiles without a GPU).
 
 The loops keep a counted LDS-DMA prefetch queue in flight (s_waitcnt vmcnt(N > 0)); a compiler-inserted `s_waitcnt vmcnt(0)` inside them drains it once per
-K tile -- that happened silently when the fragment reads were the ds_read_tr16 builtin (the wait-count pass orders every LDS read it can see
+K tile -- that happened silently when the fragment reads were the ds_read_tr16 builtin (DESIGN_HISTORY.md 8.12: the wait-count pass orders every LDS read it can see
 behind every earlier LDS-DMA) and cost the 128-row tile 20 %.  tools/loop_waits.py extracts each MFMA loop's wait / barrier / DMA skeleton from the listing."""
 import os
 import subprocess

@@ -3,7 +3,7 @@
 //   A) as conv_pp.hip does it: 8 waves (2 x 4), 128x64 per wave (8 accumulators), 32-channel K tiles, two waves per SIMD alternating LOAD / COMPUTE;
 //   B) 4 waves (2 x 2), 128x128 per wave (16 accumulators = 256 AGPRs), 64-channel K tiles, one wave per SIMD, fragments double-buffered in registers:
 //      one third less LDS read traffic per MFMA, half the barriers.
-// Prints sustained TFLOP/s for each (the chip is power-limited with random operands: DESIGN.md 3.5).
+// Prints sustained TFLOP/s for each (the chip is power-limited with random operands: DESIGN_HISTORY.md 3.5).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
