@@ -1301,7 +1301,7 @@ def linear_rows_wgrad_batched(dy: torch.Tensor, xt: torch.Tensor, dws, dbs=None,
 
 def linear_weight_t_kmajor_batched(pairs) -> None:
     """`linear_weight_t_kmajor` for a list of (src bf16 [N, K], dst bf16 [N / 32, K, 32]) in ONE launch; the table lives on the device, cached per pointer set."""
-    key = ("wt",) + tuple((s_.data_ptr(), d_.data_ptr()) for s_, d_ in pairs)
+    key = ("wt",) + tuple((s_.data_ptr(), d_.data_ptr(), s_.shape[0], s_.shape[1]) for s_, d_ in pairs)
     dev = pairs[0][0].device
     hit = _PTR_TABLES.get((key, dev))
     if hit is None:
@@ -1332,7 +1332,7 @@ def linear_wgrad_grouped(problems) -> None:
     import ctypes
     L = _lib.lib()
     dev = problems[0][0].device
-    key = ("wg",) + tuple((dy.data_ptr(), x.data_ptr(), dw.data_ptr(), 0 if db is None else db.data_ptr(), dy.shape[0]) for dy, x, dw, db in problems)
+    key = ("wg",) + tuple((dy.data_ptr(), x.data_ptr(), dw.data_ptr(), 0 if db is None else db.data_ptr(), dy.shape[0], dy.shape[1], x.shape[1]) for dy, x, dw, db in problems)
     hit = _PTR_TABLES.get((key, dev))
     if hit is None:
         if len(_PTR_TABLES) > 4096:
