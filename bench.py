@@ -397,6 +397,20 @@ def secondary_stages(dev, which=("c3", "c4", "gan")) -> dict:
     return out
 
 
+def _latest_profile(suffix: str) -> str:
+    """The newest round's `profiles/rN_<suffix>` (the PMC passes are re-collected on each round's build: the figure read back belongs to the kernels that run)."""
+    import re
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    best = None
+    for f in os.listdir(d):
+        m = re.match(r"r(\d+)_" + re.escape(suffix) + "$", f)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        raise OSError("no profiles/rN_" + suffix)
+    return best[1]
+
+
 def self_launch(n_gpus: int) -> int:
     """No RANK in the env and --gpus N > 1: become the launcher.  One rank per device over RCCL, rendezvous on 127.0.0.1, a free port; the
     ranks' stdout/stderr pass straight through (rank 0 prints the JSON line).  Returns the exit code of the job."""
@@ -532,24 +546,27 @@ def main():
     # and committed under profiles/; null when the committed profile is for a different kernel
     traffic, traffic_src = None, None
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4_conv_pp_traffic.json")) as f:
+        tname = _latest_profile("conv_pp_traffic.json")
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname)) as f:
             tp = json.load(f)
         static_twin = "conv_pp_kernel<256, 256, 2, 4, 4, false, false, true, false, false, false, false, %s>" % ("true" if ops._PP_HALO else "false")
         if tp.get("kernel") == static_twin and args.batch == LOCAL_BATCH:      # the DYN twin runs the same kernel body
             traffic = int(tp["hbm_MB_per_launch"] * 1e6)
-            traffic_src = "profiles/r4_conv_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, %d launches; FETCH_SIZE x2 per MI355X_MICROARCH.md)" % tp["launches_profiled"]
+            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command in round %s, %d launches; FETCH_SIZE x2 per MI355X_MICROARCH.md)" % (
+                tname, tp.get("round"), tp["launches_profiled"])
     except (OSError, ValueError, KeyError):
         pass
     wg_traffic = None
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4_wgrad_pp_traffic.json")) as f:
+        wname = _latest_profile("wgrad_pp_traffic.json")
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", wname)) as f:
             wt = json.load(f)
         if args.batch == LOCAL_BATCH:
             # both instantiations that carry the weight-gradient time: the 256 x 256 tile (plain 3x3 / 1x1 form) and the 128 x 384 halo tile of the >= 2^19-pixel shapes
             wg_traffic = {"bytes_per_launch": int(wt["hbm_MB_per_launch"] * 1e6), "kernel": wt["kernel"], "launches_profiled": wt["launches_profiled"],
                           "per_kernel": [{"kernel": k["kernel"], "bytes_per_launch": int(k["hbm_MB_per_launch"] * 1e6), "read_MB": k["hbm_read_MB_per_launch"],
                                           "write_MB": k["hbm_write_MB_per_launch"], "launches_profiled": k["launches_profiled"]} for k in wt.get("kernels", [])],
-                          "source": "profiles/r4_wgrad_pp_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, tools/pmc_traffic_r3.sh; FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
+                          "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command, tools/pmc_traffic_r3.sh; FETCH_SIZE x2 per MI355X_MICROARCH.md)" % wname}
     except (OSError, ValueError, KeyError):
         pass
     out = {

@@ -401,8 +401,12 @@ __global__ __launch_bounds__(512) void wgrad_pp_grouped_kernel(const GEntry* __r
     if (tab[mid].start <= blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const int p = __builtin_amdgcn_readfirstlane(lo);
+  // every problem starts at a multiple of 8 flat blocks (dmvae_linear_wgrad_grouped_fill), so that (flat - start) & 7 is still the XCD the hardware put this block on
+  // and xcd_remap keeps a problem's neighbouring tiles -- the ones that share a dY row panel -- on one XCD's L2; the up to 7 padding blocks behind a problem leave here
+  const unsigned local = blockIdx.x - tab[p].start;
+  if (local >= tab[p].blocks) return;
   const Args a = tab[p].a;
-  wgrad_pp_body<2, 2, 2, 4, false, false, false, 32, RAGGED>(a, blockIdx.x - tab[p].start, tab[p].blocks);
+  wgrad_pp_body<2, 2, 2, 4, false, false, false, 32, RAGGED>(a, local, tab[p].blocks);
 }
 // bias gradients of the grouped launch: db_p[c] = sum over the problem's ntiles_p partial rows (the bias sums ride the matrix pipe round-robin over a cout tile's blocks)
 struct GBias { const float* part; float* out; int nparts, C; unsigned start; };
@@ -544,8 +548,8 @@ extern "C" int dmvae_linear_wgrad_grouped_fill(void* entry, void* bias_entry, co
   a.gpt = cin / 128; a.ngroups = a.gpt;
   a.mtiles = (cout + 255) / 256; a.ntiles = (a.ngroups + 1) / 2;
   g.blocks = (unsigned)(a.mtiles * a.ntiles);
-  g.start = *start;
-  *start += g.blocks;
+  g.start = *start;                                  // a multiple of 8: see wgrad_pp_grouped_kernel
+  *start += (g.blocks + 7u) & ~7u;
   *reinterpret_cast<GEntry*>(entry) = g;
   if (db) {
     GBias b{(const float*)bias_part, (float*)db, a.ntiles, cout, *bias_start};

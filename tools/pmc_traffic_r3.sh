@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT; TAG=$1; ROUND=${2:-3}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 RX='conv_pp_kernel<256, 256, 2, 4, 4, false, false, true, false, false, false, false, true>|wgrad_pp_kernel<2, 2, 2, 4, false, false, false, 32>|wgrad_pp_kernel<1, 3, 2, 4, false, true, false, 64>'
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "$RX" --output-format csv -d $OUT/$C -o t -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$C.log 2>&1
+  timeout 400 rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "$RX" --output-format csv -d $OUT/$C -o t -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/$C.log 2>&1
   echo "$C rc=$?"
 done
 cd $R && python tools/pmc_traffic_json.py $OUT $ROUND | tee $OUT/traffic_summary.txt

@@ -8,16 +8,16 @@ import re
 import sys
 
 FAMILIES = [
-    ("GEMM fwd/dgrad (gemm_pp)", r"gemm_pp_kernel"),
+    ("GEMM fwd/dgrad (gemm_pp + split-K sum)", r"gemm_pp_kernel|splitk_sum"),
     ("GEMM wgrad (wgrad_pp + reduce)", r"wgrad_pp_kernel|wgrad_pp_grouped|wgrad_grouped_bias|rows_wgrad_mfma|linear_rows_wgrad|wgrad_reduce|wgrad_kernel|wgrad_small|wgrad_thin|colsum_kernel|colsum_partial|colsum_final"),
     ("rows Linear (adaLN / embedders)", r"linear_rows"),
     ("conv fwd/dgrad (conv_pp etc.)", r"conv_pp_kernel|conv_fwd|conv_thin|conv_in3|conv_to_image|convout"),
     ("attention fwd", r"attention_kernel"),
-    ("attention bwd", r"attention_bwd_kernel"),
-    ("norm + modulate / LayerNorm (fwd)", r"rmsnorm_modulate_kernel|gated_residual_kernel|gated_norm|layernorm_kernel|scale_residual_kernel|qknorm_rope_kernel|qknorm_rope16_kernel|rmsnorm_rowstat"),
+    ("attention bwd", r"attention_bwd"),
+    ("norm + modulate / LayerNorm (fwd)", r"rmsnorm_modulate_kernel|rmsnorm_modulate8_kernel|gated_residual_kernel|gated_norm|layernorm_kernel|scale_residual_kernel|qknorm_rope_kernel|qknorm_rope16_kernel|rmsnorm_rowstat"),
     ("norm + modulate / LayerNorm (bwd)", r"rmsnorm_modulate_bwd|gated_residual_bwd|layernorm_bwd|layerscale_bwd|qknorm_rope_bwd|qknorm_rope16_bwd|colsum2|colsum_parts|dit_.*bwd|rms_gate_bwd|rowstat_kernel|dit_bwd_"),
     ("GroupNorm (decoder)", r"groupnorm|gn_|apply_kernel|bwd_partial|bwd_final|stats_from|short_|coop_"),
-    ("elementwise (swiglu / gelu / silu / casts of ours)", r"swiglu|gelu|silu|transpose_kernel|linear_wt_kmajor|pack_|nchw_to_nhwc|nhwc_to_nchw|im2col|col2im|maxpool|sumpool|relu_bwd|subpixel|diffaug"),
+    ("elementwise (swiglu / gelu / silu / casts of ours)", r"swiglu|gelu|silu|transpose_kernel|linear_wt_kmajor|bn_running|pack_|nchw_to_nhwc|nhwc_to_nchw|im2col|col2im|maxpool|sumpool|relu_bwd|subpixel|diffaug"),
     ("losses (l1 / lpips / dmd / kl)", r"l1_mse|lpips|dmd_|kl_|mmd_|scalar_sum"),
     ("optimiser (sumsq + adamw)", r"sumsq_partial|norm_final|adamw_ema"),
     ("ATen / other", r".*"),
