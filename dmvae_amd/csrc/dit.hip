@@ -551,8 +551,9 @@ static inline int grid_for(size_t n, int block = 256, int cap = 4096) {
 }  // namespace dmvae_dit
 using namespace dmvae_dit;
 
-// The eight-channel kernels from 8192 rows on (batch 32+: 46.9 vs 51.1 us at batch 64, profiles/r5_dit_norm_passes.txt; at batch 16 the four-channel form is the faster by
-// a microsecond); DMVAE_RM8=0: the four-channel kernels everywhere (A/B runs)
+// The eight-channel kernels whenever the width allows -- chosen by the WIDTH only, never by the row count: a 2B-sample call must equal two B-sample calls bit for bit
+// (train.DMDTrainer's batched cond / uncond evaluation), and the two forms sum a row's squares in different lane orders.  46.9 vs 51.1 us at batch 64, 15.6 vs 14.7 at
+// batch 16 (profiles/r5_dit_norm_passes.txt).  DMVAE_RM8=0: the four-channel kernels everywhere (A/B runs)
 static bool rm8_on() { static const bool v = [] { const char* e = getenv("DMVAE_RM8"); return !(e && e[0] == '0'); }(); return v; }
 
 extern "C" int dmvae_rmsnorm_modulate_bf16(const void* x, const void* w, const void* mod, void* y, int rows, int rows_per_sample, int c, int mod_stride,
@@ -561,7 +562,7 @@ extern "C" int dmvae_rmsnorm_modulate_bf16(const void* x, const void* w, const v
   DMVAE_CHECK_ARG(c % 4 == 0 && c >= 4 && c <= MAX_SWEEPS * 256, "rmsnorm_modulate_bf16: width must be a multiple of 4 up to 2048 (got %d)", c);
   DMVAE_CHECK_ARG(scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride,
                   "rmsnorm_modulate_bf16: modulation offsets must be multiples of 4 inside the row");
-  if (c % 8 == 0 && mod_stride % 8 == 0 && scale_off % 8 == 0 && (shift_off < 0 || shift_off % 8 == 0) && rows >= 8192 && rm8_on()) {
+  if (c % 8 == 0 && mod_stride % 8 == 0 && scale_off % 8 == 0 && (shift_off < 0 || shift_off % 8 == 0) && rm8_on()) {
     switch ((c + 511) / 512) {
       case 1: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<false, 1>), dim3((rows + 3) / 4), dim3(256), 0, stream, (float*)const_cast<void*>(x), (const float*)w,
                      (const bf16*)mod, (bf16*)y, rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)nullptr, (const bf16*)nullptr, 0, 0, (float*)nullptr); break;
@@ -601,7 +602,7 @@ extern "C" int dmvae_gated_residual_rmsnorm_modulate(void* x, const void* r, con
   DMVAE_CHECK_ARG(scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride &&
                       gate_off >= 0 && gate_off % 4 == 0 && gate_stride % 4 == 0 && gate_off + c <= gate_stride,
                   "gated_residual_rmsnorm_modulate: modulation offsets must be multiples of 4 inside the row");
-  if (c % 8 == 0 && mod_stride % 8 == 0 && scale_off % 8 == 0 && (shift_off < 0 || shift_off % 8 == 0) && gate_off % 8 == 0 && gate_stride % 8 == 0 && rows >= 8192 && rm8_on()) {
+  if (c % 8 == 0 && mod_stride % 8 == 0 && scale_off % 8 == 0 && (shift_off < 0 || shift_off % 8 == 0) && gate_off % 8 == 0 && gate_stride % 8 == 0 && rm8_on()) {
     switch ((c + 511) / 512) {
       case 1: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<true, 1>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x, (const float*)w, (const bf16*)mod, (bf16*)y, rows,
                      rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x); break;
@@ -643,7 +644,7 @@ extern "C" int dmvae_gated_residual_out(const void* x_in, void* x_out, const voi
   DMVAE_CHECK_ARG(gate_off >= 0 && gate_off % 4 == 0 && gate_stride % 4 == 0 && gate_off + c <= gate_stride &&
                       (!y || (scale_off >= 0 && scale_off % 4 == 0 && (shift_off < 0 || shift_off % 4 == 0) && mod_stride % 4 == 0 && scale_off + c <= mod_stride)),
                   "gated_residual_out: modulation offsets must be multiples of 4 inside the row");
-  if (c % 8 == 0 && mod_stride % 8 == 0 && scale_off % 8 == 0 && (shift_off < 0 || shift_off % 8 == 0) && gate_off % 8 == 0 && gate_stride % 8 == 0 && rows >= 8192 && rm8_on()) {
+  if (c % 8 == 0 && mod_stride % 8 == 0 && scale_off % 8 == 0 && (shift_off < 0 || shift_off % 8 == 0) && gate_off % 8 == 0 && gate_stride % 8 == 0 && rm8_on()) {
     switch ((c + 511) / 512) {
       case 1: hipLaunchKernelGGL((rmsnorm_modulate8_kernel<true, 1>), dim3((rows + 3) / 4), dim3(256), 0, stream, (const float*)x_in, (const float*)w, (const bf16*)mod, (bf16*)y,
                      rows, rows_per_sample, c, mod_stride, shift_off, scale_off, eps, (const bf16*)r, (const bf16*)gate_mod, gate_stride, gate_off, (float*)x_out); break;
