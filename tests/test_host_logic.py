@@ -108,6 +108,35 @@ def test_partial_direct_gradients_zero_only_what_accumulates():
     assert fp2.grad.eq(0).all()
 
 
+def test_direct_gradient_invariant_is_checked_and_can_be_opted_out_of():
+    """The direct-gradient mode leaves a direct parameter's slice to the kernel that writes it; a backward that skips one (an unused block, a Function returning None)
+    would feed AdamW the previous step's gradient.  `FlatParams.check_direct_writes` (DMVAE_CHECK_DIRECT_GRADS=1) raises on exactly that, does not judge a step in
+    which none of this buffer's parameters took part, and `zero_all` falls back to zeroing the whole buffer; the all-ranks RNG default follows the world size."""
+    from dmvae_amd import functional as Fn
+    from dmvae_amd.optim import FlatParams
+    ps = [torch.nn.Parameter(torch.randn(8)) for _ in range(3)]
+    fp = FlatParams(ps, with_ema=False)
+    fp.enable_direct_grads()
+    old = Fn.DIRECT_GRAD_WRITES
+    try:
+        Fn.DIRECT_GRAD_WRITES = None
+        fp.check_direct_writes()                              # first call: starts counting
+        assert Fn.DIRECT_GRAD_WRITES == {}
+        for p in ps:
+            assert Fn._dst(p) is not None                     # a backward that writes all three
+        fp.check_direct_writes()                              # fine
+        fp.check_direct_writes()                              # a step in which this buffer took no part: not judged
+        Fn._dst(ps[0]); Fn._dst(ps[2])                        # a backward that skips ps[1]
+        with pytest.raises(RuntimeError, match="not written"):
+            fp.check_direct_writes()
+    finally:
+        Fn.DIRECT_GRAD_WRITES = old
+    fp.zero_all = True
+    fp.grad.fill_(5.0)
+    fp.begin_step()
+    assert fp.grad.eq(0).all()
+
+
 def test_lambda_lr_warmup_matches_reference_schedule():
     from dmvae_amd.optim import FlatAdamWEMA, FlatParams
     p = torch.nn.Parameter(torch.zeros(8))
