@@ -344,12 +344,10 @@ def secondary_stages(dev, which=("c3", "c4", "gan")) -> dict:
         labels = torch.randint(0, 1000, (B,), device=dev, generator=torch.Generator(device=dev).manual_seed(2))
         for _ in range(5):
             tr.step(images, labels)          # one whole cycle: warm
+        ms = timed(lambda: tr.step(images, labels), 10)      # two whole cycles between two synchronisations: the figure a training run sees
         turn, stud = [], []
-        t_all = time.perf_counter()
-        for _ in range(10):                  # two cycles, every step timed on its own AND the ten together
+        for _ in range(10):                  # two more cycles, every step between its own synchronisations: the split by step kind
             (turn if tr.global_step % tr.vae_train_every == 0 else stud).append(timed(lambda: tr.step(images, labels), 1))
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t_all) / 10 * 1e3
         tf_student = B * (_GF["vit"] + _GF["mlp"] + 3 * _GF["dit"]) / 1e3
         tf_turn = B * (3 * _GF["vit"] + 3 * _GF["mlp"] + 3 * _GF["dec"] + 3 * _GF["vgg"] + 4 * _GF["dit"] + 3 * _GF["dit"]) / 1e3
         tf_cycle = (tf_turn + 4 * tf_student) / 5
@@ -357,7 +355,7 @@ def secondary_stages(dev, which=("c3", "c4", "gan")) -> dict:
         out["c3_dmd_cycle"] = {
             "workload": "train_dmd.py step (C3): VAE(large, z 32) with the ViT-L/16 encoder trainable + LPIPS + DMD loss (LightningDiT-XL/1 teacher + student, CFG 5, cond + uncond as one 2B call) "
                         "every 5th step; the student's flow-matching step (forward + backward + clip + AdamW on 675 M parameters) every step",
-            "local_batch": B, "steps_timed": 10, "ms_per_step": round(ms, 2), "vae_turn_ms": round(sum(turn) / len(turn), 2), "student_ms": round(sum(stud) / len(stud), 2),
+            "local_batch": B, "steps_timed": 10, "ms_per_step": round(ms, 2), "timing": "ms_per_step: ten consecutive steps (two cycles) between two device synchronisations; vae_turn_ms / student_ms: ten further steps, each between its own", "vae_turn_ms": round(sum(turn) / len(turn), 2), "student_ms": round(sum(stud) / len(stud), 2),
             "images_per_sec": round(B / ms * 1e3, 1), "tflop_per_step": round(tf_cycle, 2), "tflop_vae_turn": round(tf_turn, 2), "tflop_student_step": round(tf_student, 2),
             "frac_of_peak": round(tf_cycle / ms / MFMA_BF16_PEAK_TFLOPS * 1e3, 4), "frac_of_peak_student_step": round(tf_student / (sum(stud) / len(stud)) / MFMA_BF16_PEAK_TFLOPS * 1e3, 4),
             "frac_of_peak_vae_turn": round(tf_turn / (sum(turn) / len(turn)) / MFMA_BF16_PEAK_TFLOPS * 1e3, 4),
