@@ -1230,6 +1230,7 @@ def qknorm_rope_bwd(dq, dk, dv, qkv, qw, kw, cos, sin, heads: int, eps: float = 
 
 # ---- whole-stack LightningDiT backward + batched per-sample Linears (csrc/dit_stack.hip, linear_rows.hip) ---------------------------
 _PTR_TABLES = {}
+TABLE_BUILDS = [0]      # device tables built so far (each build is a small synchronous host-to-device copy): stays flat once the allocator's address pattern has settled
 
 
 def ptr_table(tensors) -> torch.Tensor:
@@ -1242,6 +1243,7 @@ def ptr_table(tensors) -> torch.Tensor:
         if len(_PTR_TABLES) > 4096:
             _PTR_TABLES.clear()
         hit = torch.tensor(key, dtype=torch.int64).to(dev)
+        TABLE_BUILDS[0] += 1
         _PTR_TABLES[(key, dev)] = hit
     return hit
 
@@ -1316,6 +1318,7 @@ def linear_weight_t_kmajor_batched(pairs) -> None:
             arr[i] = _lib.WtEntry(src.data_ptr(), dst.data_ptr(), n, k, start, tx)
             start += tx * (n // 32)
         tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        TABLE_BUILDS[0] += 1
         hit = (tab, len(pairs), start)
         _PTR_TABLES[(key, dev)] = hit
     tab, cnt, total = hit
@@ -1361,6 +1364,7 @@ def linear_wgrad_grouped(problems) -> None:
             if db is not None:
                 off += L.dmvae_linear_wgrad_grouped_bias_parts(cin) * cout
                 nb += 1
+        TABLE_BUILDS[0] += 1
         dtab = torch.frombuffer(bytearray(tab.raw), dtype=torch.uint8).to(dev)
         dbtab = torch.frombuffer(bytearray(btab.raw[:max(nb, 1) * bb]), dtype=torch.uint8).to(dev)
         hit = (dtab, n, start.value, ragged, dbtab, nb, bstart.value, part.data_ptr())

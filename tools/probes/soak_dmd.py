@@ -30,5 +30,5 @@ for it in range(N):
         log = tr.read_log()
         ok = all(v == v and abs(v) < 1e6 for v in log.values())
         print(f"step {it+1}: " + " ".join(f"{k} {v:.4f}" for k, v in log.items() if k in ("rec_loss", "dmd_loss", "diffusion_loss", "vae_norm", "sit_norm")) +
-              f" finite={ok} peak {torch.cuda.max_memory_allocated()/2**30:.1f} GiB {(time.time()-t0)/(it+1)*1e3:.0f} ms/step", flush=True)
+              f" finite={ok} tables {__import__('dmvae_amd.ops', fromlist=['x']).TABLE_BUILDS[0]} peak {torch.cuda.max_memory_allocated()/2**30:.1f} GiB {(time.time()-t0)/(it+1)*1e3:.0f} ms/step", flush=True)
         assert ok
