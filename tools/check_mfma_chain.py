@@ -5,8 +5,10 @@ csrc/groupnorm.hip::convout_bwd_kernel (DESIGN.md section 10.8): an accumulate c
     v_mfma_f32_16x16x16_bf16 D, A2, B2, D      (reads D as its C operand)
 hipcc (ROCm 7.2) pads no wait states between the two and the hardware does not interlock the pair: the second reads C before the first has written it
 (measured: the first product is lost; with the two opcodes equal the back-to-back chain is the supported one).  Flagged: a v_mfma whose C operand overlaps
-the destination of one of the previous 3 MFMAs of a DIFFERENT opcode with fewer than 8 wait states (s_nop N = N + 1, any other instruction = 1) between
-them.  (A destination on top of the A / B operand, which the same build also had, is legal and common: vit.hip, linear_rows.hip.)
+the destination of one of the previous 8 MFMAs of a DIFFERENT opcode with fewer than 11 wait states between them (an 8-pass producer + 3; s_nop N = N + 1,
+an intervening MFMA = 4, the shortest one's passes, any other instruction = 1).  The -S output carries inline assembly expanded, so the hand-ordered block of
+convout_bwd_kernel (four 16x16x32 products, then their four 16x16x16 accumulations: 3 MFMAs = 12 states between every pair) is audited like compiler output:
+reordering or shrinking that block below the distance fails here before it fails on the GPU.  (A destination on top of the A / B operand, which the same build also had, is legal and common: vit.hip, linear_rows.hip.)
 usage: python tools/check_mfma_chain.py [files...]   (exit 1 on a finding)"""
 import glob
 import os
@@ -46,10 +48,10 @@ for f in files:
         ops = [t.strip() for t in l.split(None, 1)[1].split(",")]
         d, c = rng(ops[0]), (rng(ops[3]) if len(ops) > 3 else None)
         if c:
-            for (j, opj, dj) in recent[-3:]:
+            for (j, opj, dj) in recent[-8:]:
                 if opj != op and dj[0] == c[0] and (dj[1] & c[1]):
-                    states = sum(int(q.split()[1]) + 1 if q.startswith("s_nop") else 1 for q in ins[j + 1:k])
-                    if states < 8:
+                    states = sum(int(q.split()[1]) + 1 if q.startswith("s_nop") else 4 if q.startswith("v_mfma") else 1 for q in ins[j + 1:k])
+                    if states < 11:
                         bad += 1
                         print(f"{os.path.basename(f)}: mixed accumulate chain, {states} wait states: {ins[j][:64]}  ->  {l[:80]}")
         if d:
