@@ -36,6 +36,7 @@ struct Args {
   int S, H, D;
   float scale;
   const float* lse;              // attention_bwd_lse_kernel: [B * H][S] f32, scale * max + log(sum) of every query's scaled scores (the forward kernel writes it)
+  int xcd;                       // 1: block -> (batch, head) through xcd_remap (vit.hip::AttnArgs::xcd)
 };
 
 __device__ __forceinline__ s16x4 tr_read(const char* p) {
@@ -313,29 +314,41 @@ __global__ __launch_bounds__(512) void attention_bwd_lse_kernel(Args a) {
   float* Ls = reinterpret_cast<float*>(smem + 2 * BUF);  // [288] L_q; +inf for padded queries
   float* Ds = Ls + KEYS;                                  // [288] delta
   const int S = a.S, H = a.H, D = a.D, C = H * D;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int bh = a.xcd ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = bh / H, h = bh % H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bf16* qg = a.q + b * a.q_bs + h * a.q_hs;
   const bf16* kg_ = a.k + b * a.k_bs + h * a.k_hs;
   const bf16* vg = a.v + b * a.v_bs + h * a.v_hs;
   const bf16* og = a.o + (size_t)b * S * C + h * D;
   const bf16* dog = a.dout + (size_t)b * S * C + h * D;
-  const float* lse = a.lse + (size_t)blockIdx.x * S;
+  const float* lse = a.lse + (size_t)bh * S;
   const int dchunks = D / 8;
   const int nblk = (S + 31) >> 5;
   const int rows_staged = nblk * 32;
 
+  // every global load of a staging is issued before its first LDS store (vit.hip's forward staging: the loop form waits for each sweep's loads before issuing the
+  // next sweep's -- seven serial memory round trips per staging at DP = 96)
+  constexpr int SWEEPS = (KEYS * CH + NT - 1) / NT;
   auto stage = [&](const bf16* s0, int rs0, int ch0, const bf16* s1, int rs1, int ch1) {
-    for (int i = tid; i < rows_staged * CH; i += NT) {
-      const int row = i / CH, c = i - row * CH;
-      uint4 x = {0, 0, 0, 0}, y = {0, 0, 0, 0};
+    uint4 x[SWEEPS], y[SWEEPS];
+#pragma unroll
+    for (int it = 0; it < SWEEPS; it++) {
+      const int i = tid + it * NT, row = i / CH, c = i - row * CH;
+      x[it] = uint4{0, 0, 0, 0}; y[it] = uint4{0, 0, 0, 0};
       if (row < S) {
-        if (c < ch0) x = *reinterpret_cast<const uint4*>(s0 + (size_t)row * rs0 + c * 8);
-        if (c < ch1) y = *reinterpret_cast<const uint4*>(s1 + (size_t)row * rs1 + c * 8);
+        if (c < ch0) x[it] = *reinterpret_cast<const uint4*>(s0 + (size_t)row * rs0 + c * 8);
+        if (c < ch1) y[it] = *reinterpret_cast<const uint4*>(s1 + (size_t)row * rs1 + c * 8);
       }
-      const int off = lds_off(row, c);
-      *reinterpret_cast<uint4*>(buf0 + off) = x;
-      *reinterpret_cast<uint4*>(buf1 + off) = y;
+    }
+#pragma unroll
+    for (int it = 0; it < SWEEPS; it++) {
+      const int i = tid + it * NT, row = i / CH, c = i - row * CH;
+      if (row < rows_staged) {
+        const int off = lds_off(row, c);
+        *reinterpret_cast<uint4*>(buf0 + off) = x[it];
+        *reinterpret_cast<uint4*>(buf1 + off) = y[it];
+      }
     }
   };
   stage(kg_, a.k_rs, CH, vg, a.v_rs, dchunks);
@@ -381,39 +394,58 @@ __global__ __launch_bounds__(512) void attention_bwd_lse_kernel(Args a) {
     for (int db = 0; db < DB; db++)
 #pragma unroll
       for (int r = 0; r < 16; r++) dq[db][r] = 0.f;
+    // A key block's LDS reads are issued in two groups ahead of their matrix products (all K / V row fragments; then, behind the S^T / dP^T products, the six K^T
+    // fragments of the dQ product, which land under the softmax arithmetic): left to the scheduler, every pair of products sat behind its own LDS round trip --
+    // twelve exposed latencies per key block, more than the products and the exponentials together.  Same operations on the same values: same bits.
     for (int kb = 0; kb < nblk; kb++) {
       f32x16 st, dpt;
 #pragma unroll
       for (int r = 0; r < 16; r++) { st[r] = 0.f; dpt[r] = 0.f; }
       const int key = kb * 32 + ql;
+      bf16x8 kf[KSTEPS], vf[KSTEPS];
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; kk++) {
         const int off = lds_off(key, kk * 2 + kg);
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(buf0 + off);
-        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(buf1 + off);
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st, 0, 0, 0);
-        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], dpt, 0, 0, 0);
+        kf[kk] = *reinterpret_cast<const bf16x8*>(buf0 + off);
+        vf[kk] = *reinterpret_cast<const bf16x8*>(buf1 + off);
       }
-      const bool tail = kb * 32 + 32 > S;   // only the last block can hold keys past S (their K rows are zero: score 0, not -inf)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float p = __expf(st[r] * scale - Lq);
-        if (tail && kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg >= S) p = 0.f;
-        dpt[r] = p * (dpt[r] - delta) * scale;
+      for (int kk = 0; kk < KSTEPS; kk++) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk], dof[kk], dpt, 0, 0, 0);
       }
-      bf16x8 af[2];
-      to_afrag(dpt, af);
+      union { bf16x8 v; s16x4 hlf[2]; } ktr[2][DB];
 #pragma unroll
       for (int half = 0; half < 2; half++) {
         const char* base = buf0 + (kb * 2 + half) * 16 * PITCH;
 #pragma unroll
         for (int db = 0; db < DB; db++) {
-          union { bf16x8 v; s16x4 hlf[2]; } kf;
-          kf.hlf[0] = tr_read(base + toff0[db]);
-          kf.hlf[1] = tr_read(base + toff1[db]);
-          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[half], kf.v, dq[db], 0, 0, 0);
+          ktr[half][db].hlf[0] = tr_read(base + toff0[db]);
+          ktr[half][db].hlf[1] = tr_read(base + toff1[db]);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kb * 32 + 32 > S) {   // only the last block can hold keys past S (their K rows are zero: score 0, not -inf): a wave-uniform branch
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          float p = __expf(st[r] * scale - Lq);
+          if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg >= S) p = 0.f;
+          dpt[r] = p * (dpt[r] - delta) * scale;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float p = __expf(st[r] * scale - Lq);
+          dpt[r] = p * (dpt[r] - delta) * scale;
+        }
+      }
+      bf16x8 af[2];
+      to_afrag(dpt, af);
+#pragma unroll
+      for (int half = 0; half < 2; half++)
+#pragma unroll
+        for (int db = 0; db < DB; db++) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[half], ktr[half][db].v, dq[db], 0, 0, 0);
     }
     bf16* dqg = a.dq + b * a.q_bs + h * a.q_hs;
 #pragma unroll
@@ -424,70 +456,108 @@ __global__ __launch_bounds__(512) void attention_bwd_lse_kernel(Args a) {
         if (qo < S) dqg[(size_t)qo * a.q_rs + db * 32 + ql] = (bf16)dq[db][r];
       }
   }
-  __syncthreads();
   // ================= phase B: Q and dO resident; per 32-key block -- dK, dV ===========================================================================
+  // The wave's first key block takes its K / V fragments from the LDS image of phase A before Q / dO are staged over it (the same values the global rows hold:
+  // zero rows past S, zero V channels past D) -- no second trip to memory for them; a second key block (S > 256: wave 0 only) reads global.
+  bf16x8 kfb[KSTEPS], vfb[KSTEPS];
+  {
+    const int key = wave * 32 + ql;     // wave < NB: inside the buffers whether or not the block is live
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++) {
+      const int off = lds_off(key, kk * 2 + kg);
+      kfb[kk] = *reinterpret_cast<const bf16x8*>(buf0 + off);
+      vfb[kk] = *reinterpret_cast<const bf16x8*>(buf1 + off);
+    }
+  }
+  __syncthreads();
   stage(qg, a.q_rs, CH, dog, C, dchunks);
   __syncthreads();
   for (int kb = wave; kb < nblk; kb += NW) {
     const int key = kb * 32 + ql;
-    bf16x8 kfb[KSTEPS], vfb[KSTEPS];
+    if (kb != wave) {
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; kk++) {
-      uint4 tk = {0, 0, 0, 0}, tv = {0, 0, 0, 0};
-      const int d0 = kk * 16 + kg * 8;
-      if (key < S) {
-        tk = *reinterpret_cast<const uint4*>(kg_ + (size_t)key * a.k_rs + d0);
-        if (d0 < D) tv = *reinterpret_cast<const uint4*>(vg + (size_t)key * a.v_rs + d0);
+      for (int kk = 0; kk < KSTEPS; kk++) {
+        uint4 tk = {0, 0, 0, 0}, tv = {0, 0, 0, 0};
+        const int d0 = kk * 16 + kg * 8;
+        if (key < S) {
+          tk = *reinterpret_cast<const uint4*>(kg_ + (size_t)key * a.k_rs + d0);
+          if (d0 < D) tv = *reinterpret_cast<const uint4*>(vg + (size_t)key * a.v_rs + d0);
+        }
+        kfb[kk] = *reinterpret_cast<bf16x8*>(&tk);
+        vfb[kk] = *reinterpret_cast<bf16x8*>(&tv);
       }
-      kfb[kk] = *reinterpret_cast<bf16x8*>(&tk);
-      vfb[kk] = *reinterpret_cast<bf16x8*>(&tv);
     }
     f32x16 dk[DB], dv[DB];
 #pragma unroll
     for (int db = 0; db < DB; db++)
 #pragma unroll
       for (int r = 0; r < 16; r++) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    const bool live = kb * 32 + 32 <= S;   // every key of the block is a real one (wave-uniform): the common case takes no per-element select
     for (int qb = 0; qb < nblk; qb++) {
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
       const int qrow = qb * 32 + ql;
+      bf16x8 qfr[KSTEPS], dor[KSTEPS];
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; kk++) {
         const int off = lds_off(qrow, kk * 2 + kg);
-        const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(buf0 + off);
-        const bf16x8 dor = *reinterpret_cast<const bf16x8*>(buf1 + off);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kfb[kk], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dor, vfb[kk], dp, 0, 0, 0);
+        qfr[kk] = *reinterpret_cast<const bf16x8*>(buf0 + off);
+        dor[kk] = *reinterpret_cast<const bf16x8*>(buf1 + off);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; kk++) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[kk], kfb[kk], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dor[kk], vfb[kk], dp, 0, 0, 0);
+      }
+      // behind the products: the row statistics of the 32 queries (under way while the products run); behind the exponentials: the transposed dO / Q fragments
+      // of both 16-query halves, the first group under the bf16 packing of P / dS -- one exposed LDS latency per query block where the interleaved form had twelve
+      f32x4 Lv[4], Dv[4];
 #pragma unroll
       for (int r4 = 0; r4 < 4; r4++) {
-        const f32x4 Lv = *reinterpret_cast<const f32x4*>(Ls + qb * 32 + 8 * r4 + 4 * kg);
-        const f32x4 Dv = *reinterpret_cast<const f32x4*>(Ds + qb * 32 + 8 * r4 + 4 * kg);
+        Lv[r4] = *reinterpret_cast<const f32x4*>(Ls + qb * 32 + 8 * r4 + 4 * kg);
+        Dv[r4] = *reinterpret_cast<const f32x4*>(Ds + qb * 32 + 8 * r4 + 4 * kg);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const float p = key < S ? __expf(s[r4 * 4 + r] * scale - Lv[r]) : 0.f;
+          float p = __expf(s[r4 * 4 + r] * scale - Lv[r4][r]);
+          if (!live && key >= S) p = 0.f;
           s[r4 * 4 + r] = p;
-          dp[r4 * 4 + r] = p * (dp[r4 * 4 + r] - Dv[r]) * scale;
+          dp[r4 * 4 + r] = p * (dp[r4 * 4 + r] - Dv[r4][r]) * scale;
         }
+      union { bf16x8 v; s16x4 hlf[2]; } dft[2][DB], qft[2][DB];
+#pragma unroll
+      for (int db = 0; db < DB; db++) {
+        const int rbase = (qb * 2) * 16 * PITCH;
+        dft[0][db].hlf[0] = tr_read(buf1 + rbase + toff0[db]);
+        dft[0][db].hlf[1] = tr_read(buf1 + rbase + toff1[db]);
+        qft[0][db].hlf[0] = tr_read(buf0 + rbase + toff0[db]);
+        qft[0][db].hlf[1] = tr_read(buf0 + rbase + toff1[db]);
       }
+      __builtin_amdgcn_sched_barrier(0);
       bf16x8 pf[2], dsf[2];
       to_afrag(s, pf);
       to_afrag(dp, dsf);
 #pragma unroll
-      for (int half = 0; half < 2; half++) {
-        const int rbase = (qb * 2 + half) * 16 * PITCH;
+      for (int db = 0; db < DB; db++) {
+        const int rbase = (qb * 2 + 1) * 16 * PITCH;
+        dft[1][db].hlf[0] = tr_read(buf1 + rbase + toff0[db]);
+        dft[1][db].hlf[1] = tr_read(buf1 + rbase + toff1[db]);
+        qft[1][db].hlf[0] = tr_read(buf0 + rbase + toff0[db]);
+        qft[1][db].hlf[1] = tr_read(buf0 + rbase + toff1[db]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int half = 0; half < 2; half++)
 #pragma unroll
         for (int db = 0; db < DB; db++) {
-          union { bf16x8 v; s16x4 hlf[2]; } df, qf2;
-          df.hlf[0] = tr_read(buf1 + rbase + toff0[db]);
-          df.hlf[1] = tr_read(buf1 + rbase + toff1[db]);
-          qf2.hlf[0] = tr_read(buf0 + rbase + toff0[db]);
-          qf2.hlf[1] = tr_read(buf0 + rbase + toff1[db]);
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[half], df.v, dv[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf[half], qf2.v, dk[db], 0, 0, 0);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[half], dft[half][db].v, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf[half], qft[half][db].v, dk[db], 0, 0, 0);
         }
-      }
     }
     bf16* dkg = a.dk + b * a.k_bs + h * a.k_hs;
     bf16* dvg = a.dv + b * a.v_bs + h * a.v_hs;
@@ -520,7 +590,10 @@ static int launch(const Args& a, int batch, hipStream_t stream) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_lse_kernel<DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr2_done = true;
     }
-    hipLaunchKernelGGL((attention_bwd_lse_kernel<DP>), dim3(batch * a.H), dim3(512), lds, stream, a);
+    static const int xcd = [] { const char* e = getenv("DMVAE_ATTN_XCD"); return !(e && e[0] == '0') ? 1 : 0; }();
+    Args b_ = a;
+    b_.xcd = xcd;
+    hipLaunchKernelGGL((attention_bwd_lse_kernel<DP>), dim3(batch * a.H), dim3(512), lds, stream, b_);
   } else {
     hipLaunchKernelGGL((attention_bwd_kernel<DP>), dim3(batch * a.H), dim3(256), lds, stream, a);
   }
