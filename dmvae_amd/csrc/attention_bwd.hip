@@ -298,6 +298,142 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Args a) {
 #endif
 }
 
+// dQ of one 32-query block (phase A of the lse kernels): K in buf0, V in buf1 (LDS images), the block's Q / dO fragments, L and delta of the lane's query.
+  // A key block's LDS reads are issued in two groups ahead of their matrix products (all K / V row fragments; then, behind the S^T / dP^T products, the six K^T
+  // fragments of the dQ product, which land under the softmax arithmetic): left to the scheduler, every pair of products sat behind its own LDS round trip --
+  // twelve exposed latencies per key block, more than the products and the exponentials together.  Same operations on the same values: same bits.
+template <int DP>
+__device__ __forceinline__ void lse_dq_block(const char* buf0, const char* buf1, const bf16x8 (&qf)[DP / 16], const bf16x8 (&dof)[DP / 16], float Lq, float delta, float scale,
+                                             int S, int nblk, int kg, int ql, const int (&toff0)[DP / 32], const int (&toff1)[DP / 32], f32x16 (&dq)[DP / 32]) {
+  constexpr int KSTEPS = DP / 16, DB = DP / 32;
+  for (int kb = 0; kb < nblk; kb++) {
+    f32x16 st, dpt;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { st[r] = 0.f; dpt[r] = 0.f; }
+    const int key = kb * 32 + ql;
+    bf16x8 kf[KSTEPS], vf[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++) {
+      const int off = lds_off(key, kk * 2 + kg);
+      kf[kk] = *reinterpret_cast<const bf16x8*>(buf0 + off);
+      vf[kk] = *reinterpret_cast<const bf16x8*>(buf1 + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], st, 0, 0, 0);
+      dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk], dof[kk], dpt, 0, 0, 0);
+    }
+    union { bf16x8 v; s16x4 hlf[2]; } ktr[2][DB];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const char* base = buf0 + (kb * 2 + half) * 16 * PITCH;
+#pragma unroll
+      for (int db = 0; db < DB; db++) {
+        ktr[half][db].hlf[0] = tr_read(base + toff0[db]);
+        ktr[half][db].hlf[1] = tr_read(base + toff1[db]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kb * 32 + 32 > S) {   // only the last block can hold keys past S (their K rows are zero: score 0, not -inf): a wave-uniform branch
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float p = __expf(st[r] * scale - Lq);
+        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg >= S) p = 0.f;
+        dpt[r] = p * (dpt[r] - delta) * scale;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float p = __expf(st[r] * scale - Lq);
+        dpt[r] = p * (dpt[r] - delta) * scale;
+      }
+    }
+    bf16x8 af[2];
+    to_afrag(dpt, af);
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+#pragma unroll
+      for (int db = 0; db < DB; db++) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[half], ktr[half][db].v, dq[db], 0, 0, 0);
+  }
+}
+
+// dK / dV of one 32-key block (phase B): Q in bufq, dO in bufd (LDS images), the block's K / V fragments, L and delta of every query in Ls / Ds.
+template <int DP>
+__device__ __forceinline__ void lse_dkdv_block(const char* bufq, const char* bufd, const float* Ls, const float* Ds, const bf16x8 (&kfb)[DP / 16], const bf16x8 (&vfb)[DP / 16],
+                                               float scale, int S, int nblk, int kb, int kg, int ql, const int (&toff0)[DP / 32], const int (&toff1)[DP / 32],
+                                               f32x16 (&dk)[DP / 32], f32x16 (&dv)[DP / 32]) {
+  constexpr int KSTEPS = DP / 16, DB = DP / 32;
+  const int key = kb * 32 + ql;
+  const bool live = kb * 32 + 32 <= S;   // every key of the block is a real one (wave-uniform): the common case takes no per-element select
+  for (int qb = 0; qb < nblk; qb++) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+    const int qrow = qb * 32 + ql;
+    bf16x8 qfr[KSTEPS], dor[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++) {
+      const int off = lds_off(qrow, kk * 2 + kg);
+      qfr[kk] = *reinterpret_cast<const bf16x8*>(bufq + off);
+      dor[kk] = *reinterpret_cast<const bf16x8*>(bufd + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[kk], kfb[kk], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dor[kk], vfb[kk], dp, 0, 0, 0);
+    }
+    // behind the products: the row statistics of the 32 queries (under way while the products run); behind the exponentials: the transposed dO / Q fragments
+    // of both 16-query halves, the first group under the bf16 packing of P / dS -- one exposed LDS latency per query block where the interleaved form had twelve
+    f32x4 Lv[4], Dv[4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++) {
+      Lv[r4] = *reinterpret_cast<const f32x4*>(Ls + qb * 32 + 8 * r4 + 4 * kg);
+      Dv[r4] = *reinterpret_cast<const f32x4*>(Ds + qb * 32 + 8 * r4 + 4 * kg);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float p = __expf(s[r4 * 4 + r] * scale - Lv[r4][r]);
+        if (!live && key >= S) p = 0.f;
+        s[r4 * 4 + r] = p;
+        dp[r4 * 4 + r] = p * (dp[r4 * 4 + r] - Dv[r4][r]) * scale;
+      }
+    union { bf16x8 v; s16x4 hlf[2]; } dft[2][DB], qft[2][DB];
+#pragma unroll
+    for (int db = 0; db < DB; db++) {
+      const int rbase = (qb * 2) * 16 * PITCH;
+      dft[0][db].hlf[0] = tr_read(bufd + rbase + toff0[db]);
+      dft[0][db].hlf[1] = tr_read(bufd + rbase + toff1[db]);
+      qft[0][db].hlf[0] = tr_read(bufq + rbase + toff0[db]);
+      qft[0][db].hlf[1] = tr_read(bufq + rbase + toff1[db]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 pf[2], dsf[2];
+    to_afrag(s, pf);
+    to_afrag(dp, dsf);
+#pragma unroll
+    for (int db = 0; db < DB; db++) {
+      const int rbase = (qb * 2 + 1) * 16 * PITCH;
+      dft[1][db].hlf[0] = tr_read(bufd + rbase + toff0[db]);
+      dft[1][db].hlf[1] = tr_read(bufd + rbase + toff1[db]);
+      qft[1][db].hlf[0] = tr_read(bufq + rbase + toff0[db]);
+      qft[1][db].hlf[1] = tr_read(bufq + rbase + toff1[db]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+#pragma unroll
+      for (int db = 0; db < DB; db++) {
+        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[half], dft[half][db].v, dv[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf[half], qft[half][db].v, dk[db], 0, 0, 0);
+      }
+  }
+}
+
 // The same backward with the forward kernel's row statistics handed in (lse) and two waves per SIMD.  The kernel above keeps all nine S^T blocks of a query block
 // in registers between its max / sum pass and its dS pass (144 registers; 460 in all: one wave per SIMD, so every exponential, every permlane swap and every
 // LDS round trip of a wave sits between its own MFMAs -- 72 us for the 2 832 MFMAs of a (batch, head) at S = 256, D = 72: 15 % of the matrix pipe).  With
@@ -394,59 +530,7 @@ __global__ __launch_bounds__(512) void attention_bwd_lse_kernel(Args a) {
     for (int db = 0; db < DB; db++)
 #pragma unroll
       for (int r = 0; r < 16; r++) dq[db][r] = 0.f;
-    // A key block's LDS reads are issued in two groups ahead of their matrix products (all K / V row fragments; then, behind the S^T / dP^T products, the six K^T
-    // fragments of the dQ product, which land under the softmax arithmetic): left to the scheduler, every pair of products sat behind its own LDS round trip --
-    // twelve exposed latencies per key block, more than the products and the exponentials together.  Same operations on the same values: same bits.
-    for (int kb = 0; kb < nblk; kb++) {
-      f32x16 st, dpt;
-#pragma unroll
-      for (int r = 0; r < 16; r++) { st[r] = 0.f; dpt[r] = 0.f; }
-      const int key = kb * 32 + ql;
-      bf16x8 kf[KSTEPS], vf[KSTEPS];
-#pragma unroll
-      for (int kk = 0; kk < KSTEPS; kk++) {
-        const int off = lds_off(key, kk * 2 + kg);
-        kf[kk] = *reinterpret_cast<const bf16x8*>(buf0 + off);
-        vf[kk] = *reinterpret_cast<const bf16x8*>(buf1 + off);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kk = 0; kk < KSTEPS; kk++) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], st, 0, 0, 0);
-        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk], dof[kk], dpt, 0, 0, 0);
-      }
-      union { bf16x8 v; s16x4 hlf[2]; } ktr[2][DB];
-#pragma unroll
-      for (int half = 0; half < 2; half++) {
-        const char* base = buf0 + (kb * 2 + half) * 16 * PITCH;
-#pragma unroll
-        for (int db = 0; db < DB; db++) {
-          ktr[half][db].hlf[0] = tr_read(base + toff0[db]);
-          ktr[half][db].hlf[1] = tr_read(base + toff1[db]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (kb * 32 + 32 > S) {   // only the last block can hold keys past S (their K rows are zero: score 0, not -inf): a wave-uniform branch
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          float p = __expf(st[r] * scale - Lq);
-          if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg >= S) p = 0.f;
-          dpt[r] = p * (dpt[r] - delta) * scale;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const float p = __expf(st[r] * scale - Lq);
-          dpt[r] = p * (dpt[r] - delta) * scale;
-        }
-      }
-      bf16x8 af[2];
-      to_afrag(dpt, af);
-#pragma unroll
-      for (int half = 0; half < 2; half++)
-#pragma unroll
-        for (int db = 0; db < DB; db++) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[half], ktr[half][db].v, dq[db], 0, 0, 0);
-    }
+    lse_dq_block<DP>(buf0, buf1, qf, dof, Lq, delta, scale, S, nblk, kg, ql, toff0, toff1, dq);
     bf16* dqg = a.dq + b * a.q_bs + h * a.q_hs;
 #pragma unroll
     for (int db = 0; db < DB; db++)
@@ -492,73 +576,168 @@ __global__ __launch_bounds__(512) void attention_bwd_lse_kernel(Args a) {
     for (int db = 0; db < DB; db++)
 #pragma unroll
       for (int r = 0; r < 16; r++) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
-    const bool live = kb * 32 + 32 <= S;   // every key of the block is a real one (wave-uniform): the common case takes no per-element select
-    for (int qb = 0; qb < nblk; qb++) {
-      f32x16 s, dp;
+    lse_dkdv_block<DP>(buf0, buf1, Ls, Ds, kfb, vfb, scale, S, nblk, kb, kg, ql, toff0, toff1, dk, dv);
+    bf16* dkg = a.dk + b * a.k_bs + h * a.k_hs;
+    bf16* dvg = a.dv + b * a.v_bs + h * a.v_hs;
 #pragma unroll
-      for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
-      const int qrow = qb * 32 + ql;
-      bf16x8 qfr[KSTEPS], dor[KSTEPS];
+    for (int db = 0; db < DB; db++)
 #pragma unroll
-      for (int kk = 0; kk < KSTEPS; kk++) {
-        const int off = lds_off(qrow, kk * 2 + kg);
-        qfr[kk] = *reinterpret_cast<const bf16x8*>(buf0 + off);
-        dor[kk] = *reinterpret_cast<const bf16x8*>(buf1 + off);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kk = 0; kk < KSTEPS; kk++) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[kk], kfb[kk], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dor[kk], vfb[kk], dp, 0, 0, 0);
-      }
-      // behind the products: the row statistics of the 32 queries (under way while the products run); behind the exponentials: the transposed dO / Q fragments
-      // of both 16-query halves, the first group under the bf16 packing of P / dS -- one exposed LDS latency per query block where the interleaved form had twelve
-      f32x4 Lv[4], Dv[4];
-#pragma unroll
-      for (int r4 = 0; r4 < 4; r4++) {
-        Lv[r4] = *reinterpret_cast<const f32x4*>(Ls + qb * 32 + 8 * r4 + 4 * kg);
-        Dv[r4] = *reinterpret_cast<const f32x4*>(Ds + qb * 32 + 8 * r4 + 4 * kg);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r4 = 0; r4 < 4; r4++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          float p = __expf(s[r4 * 4 + r] * scale - Lv[r4][r]);
-          if (!live && key >= S) p = 0.f;
-          s[r4 * 4 + r] = p;
-          dp[r4 * 4 + r] = p * (dp[r4 * 4 + r] - Dv[r4][r]) * scale;
+      for (int r = 0; r < 16; r++) {
+        const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        const int dcol = db * 32 + ql;
+        if (ko < S) {
+          dkg[(size_t)ko * a.k_rs + dcol] = (bf16)dk[db][r];
+          if (dcol < D) dvg[(size_t)ko * a.v_rs + dcol] = (bf16)dv[db][r];
         }
-      union { bf16x8 v; s16x4 hlf[2]; } dft[2][DB], qft[2][DB];
-#pragma unroll
-      for (int db = 0; db < DB; db++) {
-        const int rbase = (qb * 2) * 16 * PITCH;
-        dft[0][db].hlf[0] = tr_read(buf1 + rbase + toff0[db]);
-        dft[0][db].hlf[1] = tr_read(buf1 + rbase + toff1[db]);
-        qft[0][db].hlf[0] = tr_read(buf0 + rbase + toff0[db]);
-        qft[0][db].hlf[1] = tr_read(buf0 + rbase + toff1[db]);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      bf16x8 pf[2], dsf[2];
-      to_afrag(s, pf);
-      to_afrag(dp, dsf);
+  }
+#endif
+}
+
+// S <= 256: the same backward with THREE resident operand images (256 rows each: 3 x 48 KiB + the row statistics = 146 KiB) and every global load issued ahead of
+// the work that hides it.  s_memtime stamps of the two-buffer kernel at LightningDiT-XL/1's shape (B = 64; 86 k cycles per (batch, head)): 38 % in the two loops,
+// the rest in memory phases nothing overlapped -- K / V staging 13 k, the waves' own Q / dO / O fragment loads (16-B pieces of 2 304-B rows) 15 k, the Q / dO
+// staging 11 k, the stores 13 k -- with every CU in the same phase at the same time, so HBM alternates between saturated and idle.  Here: K, V and dO are staged
+// together (dO once: phase A reads its fragments from the image, phase B its transposed ones), the wave's Q / O fragments are in flight under the staging, and the
+// Q image of phase B is loaded into registers BEFORE phase A's loop and written over K after it.  Per (batch, head): Q twice, K / V / dO / O once (258 KB, was
+// 381 KB).  Same operations on the same values as attention_bwd_lse_kernel: same bits.
+constexpr int ROWS3 = 256, BUF3 = ROWS3 * PITCH;
+template <int DP>
+__global__ __launch_bounds__(512) void attention_bwd_lse3_kernel(Args a) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int KSTEPS = DP / 16, DB = DP / 32, CH = DP / 8, NT = 512, SW = (ROWS3 * CH + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* buf0 = smem;                    // phase A: K, phase B: Q
+  char* buf1 = smem + BUF3;             // V
+  char* buf2 = smem + 2 * BUF3;         // dO
+  float* Ls = reinterpret_cast<float*>(smem + 3 * BUF3);  // [256] L_q; +inf for padded queries
+  float* Ds = Ls + ROWS3;                                  // [256] delta
+  const int S = a.S, H = a.H, D = a.D, C = H * D;
+  const int bh = a.xcd ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kg = lane >> 5, ql = lane & 31;
+  const bf16* qg = a.q + b * a.q_bs + h * a.q_hs;
+  const bf16* kg_ = a.k + b * a.k_bs + h * a.k_hs;
+  const bf16* vg = a.v + b * a.v_bs + h * a.v_hs;
+  const bf16* og = a.o + (size_t)b * S * C + h * D;
+  const bf16* dog = a.dout + (size_t)b * S * C + h * D;
+  const float* lse = a.lse + (size_t)bh * S;
+  const int dchunks = D / 8;
+  const int nblk = (S + 31) >> 5;          // <= 8: one query block (phase A) and one key block (phase B) per wave
+  const int rows_staged = nblk * 32;
+  const int q = wave * 32 + ql;            // the lane's query in phase A
+
+  // ---- every load of the first part: the three images, then the wave's own Q / O fragments ----------------------------------------------------------
+  uint4 xk[SW], xv[SW], xd[SW];
 #pragma unroll
-      for (int db = 0; db < DB; db++) {
-        const int rbase = (qb * 2 + 1) * 16 * PITCH;
-        dft[1][db].hlf[0] = tr_read(buf1 + rbase + toff0[db]);
-        dft[1][db].hlf[1] = tr_read(buf1 + rbase + toff1[db]);
-        qft[1][db].hlf[0] = tr_read(buf0 + rbase + toff0[db]);
-        qft[1][db].hlf[1] = tr_read(buf0 + rbase + toff1[db]);
+  for (int it = 0; it < SW; it++) {
+    const int i = tid + it * NT, row = i / CH, c = i - row * CH;
+    xk[it] = uint4{0, 0, 0, 0}; xv[it] = uint4{0, 0, 0, 0}; xd[it] = uint4{0, 0, 0, 0};
+    if (row < S) {
+      xk[it] = *reinterpret_cast<const uint4*>(kg_ + (size_t)row * a.k_rs + c * 8);
+      if (c < dchunks) {
+        xv[it] = *reinterpret_cast<const uint4*>(vg + (size_t)row * a.v_rs + c * 8);
+        xd[it] = *reinterpret_cast<const uint4*>(dog + (size_t)row * C + c * 8);
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int half = 0; half < 2; half++)
-#pragma unroll
-        for (int db = 0; db < DB; db++) {
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[half], dft[half][db].v, dv[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf[half], qft[half][db].v, dk[db], 0, 0, 0);
-        }
     }
+  }
+  uint4 tq[KSTEPS], to[KSTEPS];
+#pragma unroll
+  for (int kk = 0; kk < KSTEPS; kk++) {
+    const int d0 = kk * 16 + kg * 8;
+    tq[kk] = uint4{0, 0, 0, 0}; to[kk] = uint4{0, 0, 0, 0};
+    if (q < S) {
+      tq[kk] = *reinterpret_cast<const uint4*>(qg + (size_t)q * a.q_rs + d0);
+      if (d0 < D) to[kk] = *reinterpret_cast<const uint4*>(og + (size_t)q * C + d0);
+    }
+  }
+  for (int i = tid; i < ROWS3; i += NT) Ls[i] = i < S ? lse[i] : INFINITY;
+#pragma unroll
+  for (int it = 0; it < SW; it++) {
+    const int i = tid + it * NT, row = i / CH, c = i - row * CH;
+    if (row < rows_staged) {
+      const int off = lds_off(row, c);
+      *reinterpret_cast<uint4*>(buf0 + off) = xk[it];
+      *reinterpret_cast<uint4*>(buf1 + off) = xv[it];
+      *reinterpret_cast<uint4*>(buf2 + off) = xd[it];
+    }
+  }
+  __syncthreads();
+  // ---- phase B's Q image: on its way while phase A runs ------------------------------------------------------------------------------------------------
+  uint4 xq[SW];
+#pragma unroll
+  for (int it = 0; it < SW; it++) {
+    const int i = tid + it * NT, row = i / CH, c = i - row * CH;
+    xq[it] = uint4{0, 0, 0, 0};
+    if (row < S) xq[it] = *reinterpret_cast<const uint4*>(qg + (size_t)row * a.q_rs + c * 8);
+  }
+
+  const int g16 = (lane >> 4) & 1, rr = (lane & 15) >> 2, qq = lane & 3;
+  int toff0[DB], toff1[DB];
+#pragma unroll
+  for (int db = 0; db < DB; db++) {
+    const int chunk = db * 4 + g16 * 2 + (qq >> 1);
+    toff0[db] = lds_off(kg * 8 + rr, chunk) + (qq & 1) * 8;
+    toff1[db] = lds_off(kg * 8 + rr + 4, chunk) + (qq & 1) * 8;
+  }
+  const float scale = a.scale;
+
+  // ================= phase A: the wave's 32-query block -- delta, dQ ==================================================================================
+  if (wave < nblk) {
+    bf16x8 qf[KSTEPS], dof[KSTEPS];
+    float delta = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++) {
+      const uint4 td = *reinterpret_cast<const uint4*>(buf2 + lds_off(q, kk * 2 + kg));    // the dO row as staged: zero past S and past D, as the masked global load was
+      qf[kk] = *reinterpret_cast<bf16x8*>(&tq[kk]);
+      dof[kk] = *reinterpret_cast<const bf16x8*>(&td);
+      delta += dot8(td, to[kk]);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    if (kg == 0) Ds[q] = delta;
+    const float Lq = Ls[q];
+    f32x16 dq[DB];
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) dq[db][r] = 0.f;
+    lse_dq_block<DP>(buf0, buf1, qf, dof, Lq, delta, scale, S, nblk, kg, ql, toff0, toff1, dq);
+    bf16* dqg = a.dq + b * a.q_bs + h * a.q_hs;
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int qo = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (qo < S) dqg[(size_t)qo * a.q_rs + db * 32 + ql] = (bf16)dq[db][r];
+      }
+  }
+  // ================= phase B: the wave's 32-key block -- dK, dV; its K / V fragments from the images before Q goes over K ================================
+  bf16x8 kfb[KSTEPS], vfb[KSTEPS];
+  {
+    const int key = wave * 32 + ql;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++) {
+      const int off = lds_off(key, kk * 2 + kg);
+      kfb[kk] = *reinterpret_cast<const bf16x8*>(buf0 + off);
+      vfb[kk] = *reinterpret_cast<const bf16x8*>(buf1 + off);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < SW; it++) {
+    const int i = tid + it * NT, row = i / CH, c = i - row * CH;
+    if (row < rows_staged) *reinterpret_cast<uint4*>(buf0 + lds_off(row, c)) = xq[it];
+  }
+  __syncthreads();
+  if (wave < nblk) {
+    const int kb = wave;
+    f32x16 dk[DB], dv[DB];
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    lse_dkdv_block<DP>(buf0, buf2, Ls, Ds, kfb, vfb, scale, S, nblk, kb, kg, ql, toff0, toff1, dk, dv);
     bf16* dkg = a.dk + b * a.k_bs + h * a.k_hs;
     bf16* dvg = a.dv + b * a.v_bs + h * a.v_hs;
 #pragma unroll
@@ -591,9 +770,22 @@ static int launch(const Args& a, int batch, hipStream_t stream) {
       attr2_done = true;
     }
     static const int xcd = [] { const char* e = getenv("DMVAE_ATTN_XCD"); return !(e && e[0] == '0') ? 1 : 0; }();
+    static const int three = [] { const char* e = getenv("DMVAE_ATTN_3BUF"); return !(e && e[0] == '0') ? 1 : 0; }();
     Args b_ = a;
     b_.xcd = xcd;
-    hipLaunchKernelGGL((attention_bwd_lse_kernel<DP>), dim3(batch * a.H), dim3(512), lds, stream, b_);
+    // measured (profiles/r5_attention_3buf_ab.txt): 5 % faster at 256 and 512 (batch, head) blocks, 4 % slower at 1 024 -- with four rounds per CU the kernel is in
+    // its bandwidth-bound regime and the larger load burst at the head of every block costs more than the hidden latency returns
+    if (three && a.S <= ROWS3 && batch * a.H <= 512) {
+      constexpr int lds3 = 3 * BUF3 + 2 * ROWS3 * (int)sizeof(float);
+      static bool attr3_done = false;
+      if (!attr3_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_lse3_kernel<DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+        attr3_done = true;
+      }
+      hipLaunchKernelGGL((attention_bwd_lse3_kernel<DP>), dim3(batch * a.H), dim3(512), lds3, stream, b_);
+    } else {
+      hipLaunchKernelGGL((attention_bwd_lse_kernel<DP>), dim3(batch * a.H), dim3(512), lds, stream, b_);
+    }
   } else {
     hipLaunchKernelGGL((attention_bwd_kernel<DP>), dim3(batch * a.H), dim3(256), lds, stream, a);
   }

@@ -23,7 +23,7 @@ def timed(fn, n=50):
 
 g = torch.Generator(device="cuda").manual_seed(0)
 print(f"DMVAE_ATTN_XCD={os.environ.get('DMVAE_ATTN_XCD', '1 (default)')}")
-for B in (16, 64):
+for B in (16, 32, 64):
     H, N, D, DP = 16, 256, 72, 96
     q = torch.zeros(B * H, N, DP, device="cuda", dtype=BF); k = torch.zeros_like(q)
     q[..., :D] = torch.randn(B * H, N, D, device="cuda", generator=g).to(BF); k[..., :D] = torch.randn(B * H, N, D, device="cuda", generator=g).to(BF)

@@ -18,6 +18,8 @@ RULES = [
     (r"power_ceiling\.txt$", "hipBLASLt 8192^3 bf16, random vs zero data: the practical MFMA ceiling"),
     (r"probe|microbench|bound|per_launch|_us\.txt$", "kernel micro-benchmark / probe output"),
     (r"sample50k", "sampler loop (250-step SDE + decode) timings"),
+    (r"soak", "long run of a stage: losses finite, memory and device-table count flat"),
+    (r"after_|passes", "kernel micro-benchmark after the named change (tools/bench_*.py)"),
 ]
 def describe(name):
     for pat, d in RULES:
