@@ -20,6 +20,7 @@ from typing import Dict, Optional
 import torch
 
 from . import dist, losses, parity
+from .transport import cpu_rand_like_batch
 from .models.vae import VAE
 from .optim import FlatAdamWEMA, FlatParams
 from .utils.lpips import LPIPS
@@ -422,7 +423,7 @@ class DMDTrainer(_AdversarialBranch):
     def _sample(self, x1: torch.Tensor):
         """Transport.sample (transport.py:105-116): x0 on the device generator, t on the CPU generator, optional time shift."""
         x0 = torch.randn_like(x1)
-        t = torch.rand((x1.shape[0],)).to(x1)
+        t = cpu_rand_like_batch(x1).to(x1)        # the CPU generator's draw, copied without stalling the launch queue
         s = self.time_dist_shift
         t = 1 - s * (1 - t) / (1 + (s - 1) * (1 - t))
         return t, x0

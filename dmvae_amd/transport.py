@@ -126,6 +126,32 @@ class ICPlan:
         return t, xt, self.compute_ut(t, x0, x1, xt)
 
 
+_RAND_RING = {}
+
+
+def cpu_rand_like_batch(x1):
+    """`th.rand((B,)).to(x1)` (transport.py:110-111): the batch's times drawn on the CPU generator, like the reference, and handed to x1's device WITHOUT stalling
+    the launch queue: the draw lands in one of four pinned staging buffers and is copied with non_blocking (a pageable copy waits for the stream -- once per
+    training step the host then stood still until the device had caught up, and every kernel after it was launched with the device on its heels:
+    tools/probes/host_ahead.py; the sampler's `_noise` does the same for its per-step noise)."""
+    n = x1.shape[0]
+    if not x1.is_cuda:
+        return th.rand((n,))
+    key = (n, x1.device)
+    ring = _RAND_RING.get(key)
+    if ring is None:
+        ring = _RAND_RING[key] = [[[th.empty((n,), dtype=th.float32).pin_memory(), None] for _ in range(4)], 0]
+    slot = ring[0][ring[1]]
+    ring[1] = (ring[1] + 1) % len(ring[0])
+    if slot[1] is not None:
+        slot[1].synchronize()                        # the copy that last used this buffer (four draws ago) has finished
+    th.rand((n,), out=slot[0])
+    t = slot[0].to(device=x1.device, non_blocking=True)
+    slot[1] = th.cuda.Event()
+    slot[1].record()
+    return t                                          # f32 on x1's device: the caller casts where the reference's `.to(x1)` stands
+
+
 class Transport:
     """transport.py:39-221 for the Linear path."""
 
@@ -158,7 +184,7 @@ class Transport:
         """transport.py:105-116: x0 on x1's device generator, t on the CPU generator, then the time shift."""
         x0 = th.randn_like(x1)
         t0, t1 = self.check_interval(self.train_eps, self.sample_eps)
-        t = th.rand((x1.shape[0],)) * (t1 - t0) + t0
+        t = cpu_rand_like_batch(x1) * (t1 - t0) + t0
         t = t.to(x1)
         t = 1 - self.time_dist_shift * (1 - t) / (1 + (self.time_dist_shift - 1) * (1 - t))
         return t, x0, x1

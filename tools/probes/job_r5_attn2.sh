@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r5_attn2
-for i in 1 2 3; do
-DMVAE_ATTN_3BUF=0 python tools/bench_attention.py 2>&1 | grep "DiT"
-python tools/bench_attention.py 2>&1 | grep "DiT"
-done | tee gpurun_out/r5_attn2/bench3.txt
+python -m pytest tests/test_gpu_attention_bwd.py tests/test_gpu_vit_train.py tests/test_gpu_vit_pin.py tests/test_gpu_dit.py tests/test_gpu_dit_stack.py tests/test_gpu_modules.py -x -q -m gpu 2>&1 | tail -3
+for i in 1 2; do
+python tools/bench_attention.py 2>&1 | grep -v amdgpu
+done | tee gpurun_out/r5_attn2/bench4.txt
