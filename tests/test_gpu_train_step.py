@@ -485,3 +485,19 @@ def test_dmd_and_diffusion_steps_call_no_library_gemm(monkeypatch):
     for _ in range(2):
         dt.step(images, labels)
     assert not called and dt.read_log()["loss"] == dt.read_log()["loss"]
+
+
+@pytest.mark.gpu
+def test_transport_times_on_the_device_equal_the_pageable_copy():
+    """The pinned, non-blocking hand-over of the CPU-drawn times (transport.cpu_rand_like_batch) gives the device the values `th.rand((B,)).to(x1)` gives it, draw after
+    draw (more draws than staging buffers), and leaves the CPU generator where th.rand leaves it."""
+    from dmvae_amd import transport as T
+    x1 = torch.zeros(16, 32, 16, 16, device="cuda")
+    torch.manual_seed(11)
+    ref = [torch.rand((16,)).to(x1) for _ in range(7)]
+    end_ref = torch.rand(3)
+    torch.manual_seed(11)
+    got = [T.cpu_rand_like_batch(x1).to(x1) for _ in range(7)]
+    end = torch.rand(3)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(ref, got)) and torch.equal(end, end_ref)

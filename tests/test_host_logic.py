@@ -297,3 +297,22 @@ print("shadow ok")
     assert r.returncode == 0 and "shadow ok" in r.stdout, r.stderr[-2000:]
     r = subprocess.run([sys.executable, os.path.join(root, "run_on_mi355x.py"), "--check"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "models.vae" in r.stdout and "dmvae_amd.transport" in r.stdout, r.stderr[-2000:]
+
+
+def test_transport_times_consume_the_cpu_generator_like_the_reference():
+    """transport.cpu_rand_like_batch (the pinned, non-blocking form of `th.rand((B,)).to(x1)`, transport.py:110-111) draws from the CPU generator exactly what
+    th.rand draws -- two consecutive draws, and Transport.sample's t on a CPU tensor equals the reference expression."""
+    from dmvae_amd import transport as T
+    torch.manual_seed(5)
+    a, b = torch.rand((7,)), torch.rand((7,))
+    torch.manual_seed(5)
+    a2, b2 = T.cpu_rand_like_batch(torch.zeros(7, 3)), T.cpu_rand_like_batch(torch.zeros(7, 3))
+    assert torch.equal(a, a2) and torch.equal(b, b2)
+    tr = T.create_transport("Linear", "velocity", None, 0.0, 0.0)
+    x1 = torch.zeros(5, 2, 4)
+    torch.manual_seed(9)
+    t, x0, _ = tr.sample(x1)
+    torch.manual_seed(9)
+    x0_ref = torch.randn_like(x1)
+    t_ref = torch.rand((5,)).to(x1)
+    assert torch.equal(t, t_ref) and torch.equal(x0, x0_ref)
