@@ -32,7 +32,7 @@ class WtEntry(Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("N", c_int32), ("K", c_int32), ("start", c_uint), ("tiles_x", c_uint)]
 
 
-ABI_VERSION = 6     # 6: dmvae_dit_stack_* / dmvae_dit_boundary_bwd / batched rows Linears / batched weight transposes; 5: dmvae_groupnorm_*_short; include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*; 4: dmvae_norm_conv_out_bwd*)
+ABI_VERSION = 7     # 7: dmvae_linear_wgrad_grouped_plan / _xcd; 6: dmvae_dit_stack_* / dmvae_dit_boundary_bwd / batched rows Linears / batched weight transposes; 5: dmvae_groupnorm_*_short; include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*; 4: dmvae_norm_conv_out_bwd*)
 
 # name -> (restype, argtypes); every symbol include/dmvae_hip.h declares
 SIGNATURES = {
@@ -134,6 +134,9 @@ SIGNATURES = {
     "dmvae_linear_wgrad_grouped_bias_parts": (c_int, [c_int]),
     "dmvae_linear_wgrad_grouped_fill": (c_int, [c_void_p] * 7 + [c_int] * 3 + [POINTER(c_uint), POINTER(c_uint)]),
     "dmvae_linear_wgrad_grouped": (c_int, [c_void_p, c_int, c_uint, c_int, c_void_p, c_int, c_uint, c_void_p]),
+    "dmvae_linear_wgrad_grouped_chunk_bytes": (c_size_t, []),
+    "dmvae_linear_wgrad_grouped_plan": (c_int, [c_void_p, c_int, c_void_p, c_int, POINTER(c_int), POINTER(c_uint), POINTER(c_uint)]),
+    "dmvae_linear_wgrad_grouped_xcd": (c_int, [c_void_p, c_void_p, POINTER(c_uint), c_uint, c_int, c_void_p, c_int, c_uint, c_void_p]),
     "dmvae_gated_residual_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_loss_workspace": (c_size_t, []),
     "dmvae_l1_mse": (c_int, [c_void_p] * 5 + [c_size_t, c_size_t, c_float, c_float, c_void_p]),

@@ -26,6 +26,8 @@
 // S2 instantiation: the 4x4 stride-2 padding-1 conv (models/patchgan.py:125-133; and, with the operands' roles exchanged, the weight gradient of Upsample's
 // conv in its sub-pixel form -- include/dmvae_hip.h, dmvae_subpixel_weight): tap (ky, kx) of output pixel (y, x) reads source (2y - 1 + ky, 2x - 1 + kx), so
 // a K tile's 32 pixels sit two source pixels apart (per-lane offsets doubled) and the row test reads 2y - 1 + ky; sixteen taps instead of nine.
+#include <algorithm>
+#include <vector>
 #include "common.h"
 #include "dmvae_hip.h"
 #include <cstdlib>
@@ -102,7 +104,7 @@ __device__ __forceinline__ void wgrad_pp_body(const Args& a, const unsigned flat
   const int wm = wave / WN, wn = wave % WN;
   const int T = a.ks * a.ks;
 
-  const unsigned wid = (unsigned)uni((int)xcd_remap(flat_block, total_blocks));
+  const unsigned wid = (unsigned)uni((int)(total_blocks ? xcd_remap(flat_block, total_blocks) : flat_block));   // total_blocks == 0: the caller placed this block itself (grouped launch by XCD)
   const int tiles = a.mtiles * a.ntiles;
   const int split = uni((int)(wid / tiles));
   const int tile = uni((int)(wid - (unsigned)split * tiles));
@@ -408,6 +410,29 @@ __global__ __launch_bounds__(512) void wgrad_pp_grouped_kernel(const GEntry* __r
   const Args a = tab[p].a;
   wgrad_pp_body<2, 2, 2, 4, false, false, false, 32, RAGGED>(a, local, tab[p].blocks);
 }
+// The same launch with the tiles PLACED: a problem's tiles are cut into chunks of whole cout-tile rows of about 32 tiles (one round of an XCD's 32 CUs) and every
+// chunk is given to ONE XCD (dmvae_linear_wgrad_grouped_plan: longest chunk first to the least loaded XCD); flat block f runs position f >> 3 of XCD f & 7's list
+// (the hardware deals consecutive workgroups round-robin over the XCDs).  The 32 tiles an XCD runs at a time are then rows_per_chunk x ntiles tiles of ONE problem:
+// rows + ntiles operand panels in that XCD's L2 for 32 tiles.  The first form spread every problem over all eight XCDs (an eighth of its tiles each, nine of
+// LightningDiT's qkv gradient's 70): every x panel fetched by eight L2s, two or three thin problems sharing an XCD -- 16 GB read per launch at batch 16 where
+// the operands are 4.2 GB, at 4.9 TB/s of fabric traffic: bandwidth-bound at 1.0 PFLOP/s (profiles/r5_dmd_stage_traffic_pmc.txt).
+struct GChunk { unsigned entry, tile0, start, blocks; };
+struct GPlan { unsigned xoff[9]; };
+template <bool RAGGED>
+__global__ __launch_bounds__(512) void wgrad_pp_grouped_xcd_kernel(const GEntry* __restrict__ tab, const GChunk* __restrict__ ch, GPlan plan) {
+  const unsigned x = blockIdx.x & 7u, pos = blockIdx.x >> 3;
+  int lo = (int)plan.xoff[x], hi = (int)plan.xoff[x + 1] - 1;
+  if (hi < lo) return;
+  while (lo < hi) {   // last chunk of this XCD's list whose start <= pos (block-uniform: scalar loads)
+    const int mid = (lo + hi + 1) >> 1;
+    if (ch[mid].start <= pos) lo = mid; else hi = mid - 1;
+  }
+  const int c = __builtin_amdgcn_readfirstlane(lo);
+  const unsigned local = pos - ch[c].start;
+  if (local >= ch[c].blocks) return;      // behind the XCD's last chunk
+  const Args a = tab[ch[c].entry].a;
+  wgrad_pp_body<2, 2, 2, 4, false, false, false, 32, RAGGED>(a, ch[c].tile0 + local, 0u);
+}
 // bias gradients of the grouped launch: db_p[c] = sum over the problem's ntiles_p partial rows (the bias sums ride the matrix pipe round-robin over a cout tile's blocks)
 struct GBias { const float* part; float* out; int nparts, C; unsigned start; };
 __global__ __launch_bounds__(256) void wgrad_grouped_bias_kernel(const GBias* __restrict__ tab, int n) {
@@ -555,6 +580,67 @@ extern "C" int dmvae_linear_wgrad_grouped_fill(void* entry, void* bias_entry, co
     GBias b{(const float*)bias_part, (float*)db, a.ntiles, cout, *bias_start};
     *bias_start += (unsigned)((cout + 255) / 256);
     *reinterpret_cast<GBias*>(bias_entry) = b;
+  }
+  return 0;
+}
+// Placement of a filled table's tiles on the XCDs (wgrad_pp_grouped_xcd_kernel): chunks_out receives up to max_chunks records of dmvae_linear_wgrad_grouped_chunk_bytes(),
+// grouped by XCD (xoff[x] .. xoff[x + 1]), *grid the launch's block count.  Host-only; returns 0, or -22 when max_chunks is too small.
+extern "C" size_t dmvae_linear_wgrad_grouped_chunk_bytes(void) { return sizeof(dmvae_wgrad_pp::GChunk); }
+extern "C" int dmvae_linear_wgrad_grouped_plan(const void* table, int n, void* chunks_out, int max_chunks, int* n_chunks, unsigned* xoff, unsigned* grid) {
+  using namespace dmvae_wgrad_pp;
+  DMVAE_CHECK_ARG(table && n > 0 && chunks_out && n_chunks && xoff && grid, "linear_wgrad_grouped_plan: null pointer");
+  const GEntry* tab = (const GEntry*)table;
+  struct C { unsigned entry, tile0, blocks; int xcd; };
+  std::vector<C> cs;
+  for (int p = 0; p < n; p++) {
+    const int nt = tab[p].a.ntiles, mt = tab[p].a.mtiles;
+    const int rows = std::max(1, (32 + nt / 2) / nt);            // whole cout-tile rows of about 32 tiles
+    for (int r0 = 0; r0 < mt; r0 += rows) cs.push_back(C{(unsigned)p, (unsigned)(r0 * nt), (unsigned)(std::min(rows, mt - r0) * nt), 0});
+  }
+  DMVAE_CHECK_ARG((int)cs.size() <= max_chunks, "linear_wgrad_grouped_plan: %d chunks, room for %d", (int)cs.size(), max_chunks);
+  std::vector<int> order(cs.size());
+  for (size_t i = 0; i < cs.size(); i++) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cs[a].blocks > cs[b].blocks; });
+  unsigned load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i : order) {                                            // longest first to the least loaded XCD (lowest index on ties: deterministic)
+    int best = 0;
+    for (int x = 1; x < 8; x++) if (load[x] < load[best]) best = x;
+    cs[i].xcd = best;
+    load[best] += cs[i].blocks;
+  }
+  GChunk* out = (GChunk*)chunks_out;
+  unsigned k = 0, longest = 0;
+  for (int x = 0; x < 8; x++) {                                    // problem order inside an XCD's list
+    xoff[x] = k;
+    unsigned pos = 0;
+    for (size_t i = 0; i < cs.size(); i++)
+      if (cs[i].xcd == x) { out[k++] = GChunk{cs[i].entry, cs[i].tile0, pos, cs[i].blocks}; pos += cs[i].blocks; }
+    longest = std::max(longest, pos);
+  }
+  xoff[8] = k;
+  *n_chunks = (int)k;
+  *grid = longest * 8u;
+  return 0;
+}
+extern "C" int dmvae_linear_wgrad_grouped_xcd(const void* table, const void* chunks, const unsigned* xoff, unsigned grid, int ragged, const void* bias_table, int n_bias,
+                                              unsigned bias_blocks, hipStream_t stream) {
+  using namespace dmvae_wgrad_pp;
+  DMVAE_CHECK_ARG(table && chunks && xoff && grid > 0, "linear_wgrad_grouped_xcd: empty plan");
+  constexpr int lds = WG_NBUF * (2 * 32 + 2 * 32) * 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_grouped_xcd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pp_grouped_xcd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  GPlan plan;
+  for (int i = 0; i < 9; i++) plan.xoff[i] = xoff[i];
+  if (ragged) hipLaunchKernelGGL(wgrad_pp_grouped_xcd_kernel<true>, dim3(grid), dim3(512), lds, stream, (const GEntry*)table, (const GChunk*)chunks, plan);
+  else hipLaunchKernelGGL(wgrad_pp_grouped_xcd_kernel<false>, dim3(grid), dim3(512), lds, stream, (const GEntry*)table, (const GChunk*)chunks, plan);
+  DMVAE_CHECK_LAUNCH();
+  if (bias_table && n_bias > 0 && bias_blocks > 0) {
+    hipLaunchKernelGGL(wgrad_grouped_bias_kernel, dim3(bias_blocks), dim3(256), 0, stream, (const GBias*)bias_table, n_bias);
+    DMVAE_CHECK_LAUNCH();
   }
   return 0;
 }

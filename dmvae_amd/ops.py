@@ -1329,6 +1329,10 @@ def linear_wgrad_grouped_supported(m: int, cout: int, cin: int) -> bool:
     return bool(_lib.lib().dmvae_linear_wgrad_grouped_supported(int(m), int(cout), int(cin)))
 
 
+WGRAD_GROUPED_XCD_MIN = 16     # problems: below it the first form (a ViT block's four problems are 11 chunks for 8 XCDs -- measured 8 % slower placed, profiles/r5_grouped_wgrad_placed_ab.txt)
+WGRAD_GROUPED_XCD = os.environ.get("DMVAE_WGRAD_GROUPED_XCD", "1") != "0"      # grouped weight gradients: tiles placed on the XCDs (0: the first form, every problem spread over all eight)
+
+
 def linear_wgrad_grouped(problems) -> None:
     """Weight (+ bias) gradients of a LIST of independent Linears in one launch (include/dmvae_hip.h dmvae_linear_wgrad_grouped): problems = [(dy [M, cout] bf16,
     x [M, cin] bf16, dw f32 [cout, cin] (written), db f32 [cout] or None), ...]; each problem unsplit, results written straight to dw / db."""
@@ -1367,12 +1371,24 @@ def linear_wgrad_grouped(problems) -> None:
         TABLE_BUILDS[0] += 1
         dtab = torch.frombuffer(bytearray(tab.raw), dtype=torch.uint8).to(dev)
         dbtab = torch.frombuffer(bytearray(btab.raw[:max(nb, 1) * bb]), dtype=torch.uint8).to(dev)
-        hit = (dtab, n, start.value, ragged, dbtab, nb, bstart.value, part.data_ptr())
+        plan = None
+        if WGRAD_GROUPED_XCD and n >= WGRAD_GROUPED_XCD_MIN:       # every tile placed on an XCD (include/dmvae_hip.h dmvae_linear_wgrad_grouped_plan): chunk records + the XCDs' ranges
+            cb = L.dmvae_linear_wgrad_grouped_chunk_bytes()
+            chunks = ctypes.create_string_buffer(cb * n * 64)
+            nch, grid = ctypes.c_int(0), ctypes.c_uint(0)
+            xoff = (ctypes.c_uint * 9)()
+            check(L.dmvae_linear_wgrad_grouped_plan(ctypes.addressof(tab), n, ctypes.addressof(chunks), n * 64, ctypes.byref(nch), xoff, ctypes.byref(grid)), "linear_wgrad_grouped_plan")
+            plan = (torch.frombuffer(bytearray(chunks.raw[:nch.value * cb]), dtype=torch.uint8).to(dev), xoff, grid.value)
+        hit = (dtab, n, start.value, ragged, dbtab, nb, bstart.value, part.data_ptr(), plan)
         _PTR_TABLES[(key, dev)] = hit
-    dtab, n, total, ragged, dbtab, nb, btotal, part_ptr = hit
+    dtab, n, total, ragged, dbtab, nb, btotal, part_ptr, plan = hit
     if nb and workspace(1, dev, "wgrad_grouped_bias").data_ptr() != part_ptr:      # the workspace slot grew since this table was built: its bias-partial pointers are stale
         del _PTR_TABLES[(key, dev)]
         return linear_wgrad_grouped(problems)
+    if plan is not None:
+        check(L.dmvae_linear_wgrad_grouped_xcd(dtab.data_ptr(), plan[0].data_ptr(), plan[1], plan[2], ragged, dbtab.data_ptr() if nb else None, nb, btotal, _stream()),
+              "linear_wgrad_grouped_xcd")
+        return
     check(L.dmvae_linear_wgrad_grouped(dtab.data_ptr(), n, total, ragged, dbtab.data_ptr() if nb else None, nb, btotal, _stream()), "linear_wgrad_grouped")
 
 

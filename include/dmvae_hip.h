@@ -551,6 +551,16 @@ int dmvae_linear_wgrad_grouped_fill(void* entry, void* bias_entry, const void* d
                                     unsigned* start, unsigned* bias_start);
 int dmvae_linear_wgrad_grouped(const void* table, int n, unsigned total_blocks, int ragged, const void* bias_table, int n_bias, unsigned bias_blocks,
                                dmvae_stream_t stream);
+/* The same launch with every tile placed on an XCD: dmvae_linear_wgrad_grouped_plan (host only) cuts the n problems of a filled table into chunks of whole cout-tile
+ * rows of about 32 tiles -- one round of an XCD's 32 CUs -- and deals them to the eight XCDs, longest first to the least loaded; chunks_out receives *n_chunks
+ * records of dmvae_linear_wgrad_grouped_chunk_bytes() (room for max_chunks; n * 64 is always enough), xoff[0..8] the XCDs' ranges in it, *grid the block count.
+ * Copy the chunk records to the device too and launch with dmvae_linear_wgrad_grouped_xcd(table, chunks, xoff (host), grid, ragged, bias_table, n_bias, bias_blocks).
+ * The tiles an XCD works on at a time then share their operand panels in that XCD's L2 (the first form spread each problem over all XCDs: 16 GB read where
+ * the operands are 4.2 GB at LightningDiT-XL/1, batch 16).  Same tiles, same accumulation order per tile: same bits as dmvae_linear_wgrad_grouped. */
+size_t dmvae_linear_wgrad_grouped_chunk_bytes(void);
+int dmvae_linear_wgrad_grouped_plan(const void* table, int n, void* chunks_out, int max_chunks, int* n_chunks, unsigned* xoff, unsigned* grid);
+int dmvae_linear_wgrad_grouped_xcd(const void* table, const void* chunks, const unsigned* xoff, unsigned grid, int ragged, const void* bias_table, int n_bias,
+                                   unsigned bias_blocks, dmvae_stream_t stream);
 
 /* ---- losses (HBM-bound reductions) ------------------------------------------------------------- */
 

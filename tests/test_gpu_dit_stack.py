@@ -230,6 +230,22 @@ def test_grouped_linear_weight_gradients(shapes):
     ops.linear_wgrad_grouped(probs)
     for p, f in zip(probs, first):
         assert torch.equal(p[2], f[0]) and (p[3] is None or torch.equal(p[3], f[1]))
+    # both placements of the same tiles (every problem spread over all XCDs / every chunk of ~32 tiles on one XCD: dmvae_linear_wgrad_grouped_plan): the same bits
+    keep = (ops.WGRAD_GROUPED_XCD, ops.WGRAD_GROUPED_XCD_MIN)
+    try:
+        for placed in (True, False):
+            ops.WGRAD_GROUPED_XCD, ops.WGRAD_GROUPED_XCD_MIN = placed, 1
+            ops._PTR_TABLES.clear()
+            for p in probs:
+                p[2].fill_(5.0)
+                if p[3] is not None:
+                    p[3].fill_(5.0)
+            ops.linear_wgrad_grouped(probs)
+            for p, f in zip(probs, first):
+                assert torch.equal(p[2], f[0]) and (p[3] is None or torch.equal(p[3], f[1])), placed
+    finally:
+        ops.WGRAD_GROUPED_XCD, ops.WGRAD_GROUPED_XCD_MIN = keep
+        ops._PTR_TABLES.clear()
 
 
 @pytest.mark.parametrize("tag", ["dit_small_hd64w", "dit_small_hd72"])
