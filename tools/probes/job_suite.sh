@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/suite
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 | tee gpurun_out/suite/gpu_suite.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
