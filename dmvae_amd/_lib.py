@@ -32,7 +32,7 @@ class WtEntry(Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("N", c_int32), ("K", c_int32), ("start", c_uint), ("tiles_x", c_uint)]
 
 
-ABI_VERSION = 7     # 7: dmvae_linear_wgrad_grouped_plan / _xcd; 6: dmvae_dit_stack_* / dmvae_dit_boundary_bwd / batched rows Linears / batched weight transposes; 5: dmvae_groupnorm_*_short; include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*; 4: dmvae_norm_conv_out_bwd*)
+ABI_VERSION = 7     # 7: dmvae_linear_wgrad_grouped_plan / _xcd, dmvae_conv_k4c1_*; 6: dmvae_dit_stack_* / dmvae_dit_boundary_bwd / batched rows Linears / batched weight transposes; 5: dmvae_groupnorm_*_short; include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*; 4: dmvae_norm_conv_out_bwd*)
 
 # name -> (restype, argtypes); every symbol include/dmvae_hip.h declares
 SIGNATURES = {
@@ -160,6 +160,11 @@ SIGNATURES = {
     "dmvae_groupnorm_apply_short": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
     "dmvae_groupnorm_bwd_short_workspace": (c_size_t, [c_int] * 5),
     "dmvae_groupnorm_bwd_short": (c_int, [c_void_p] * 12 + [c_size_t] + [c_int] * 8 + [c_void_p]),
+    "dmvae_conv_k4c1_supported": (c_int, [c_int] * 4),
+    "dmvae_conv_k4c1_wgrad_workspace": (c_size_t, [c_int]),
+    "dmvae_conv_k4c1_fwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "dmvae_conv_k4c1_dgrad": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "dmvae_conv_k4c1_wgrad": (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 4 + [c_void_p]),
     "dmvae_conv_in3_supported": (c_int, [c_int] * 4),
     "dmvae_conv_in3_workspace": (c_size_t, [c_int] * 3),
     "dmvae_conv_in3": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_size_t] + [c_int] * 5 + [c_void_p]),

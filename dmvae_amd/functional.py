@@ -450,6 +450,7 @@ class ImageToNhwcFn(torch.autograd.Function):
         return ops.nhwc_to_nchw_f32(_c(dy), ctx.c), None
 
 
+K4_COUT1 = os.environ.get("DMVAE_K4_COUT1", "1") != "0"      # the one-output-channel 4x4 conv (PatchGAN logits) on csrc/conv_c1.hip's vector-unit kernels
 K4_WGRAD_THIN_CIN = True      # the <= 8-input-channel 4x4 conv's weight gradient on the im2col form of an 8-channel copy (ConvK4Fn.backward)
 K4_WGRAD_AS_GEMM = (1,)      # strides of the 4x4 convs whose weight gradient runs on the im2col form (ConvK4Fn.backward); () = never (tests compare the routes)
 
@@ -465,6 +466,16 @@ class ConvK4Fn(torch.autograd.Function):
     def forward(ctx, x, w, b, stride, act, out_f32):
         cout, cin = w.shape[0], w.shape[1]
         cp = x.shape[-1]
+        if (K4_COUT1 and cout == 1 and stride == 1 and out_f32 and act == ops.ACT_NONE and cp == cin and not parity.on() and x.dtype == bf16
+                and ops.conv_k4c1_supported(x.shape[0], x.shape[1], x.shape[2], cp)):
+            # the logits layer (models/patchgan.py:146): one output channel -- vector-unit kernels bound by one pass over the map (csrc/conv_c1.hip), not a
+            # matrix product with one useful row
+            y = ops.conv_k4c1_fwd(x, w, b)
+            ctx.save_for_backward(x, w, None)
+            ctx.cfg = (stride, act, b)
+            ctx.c1 = True
+            return y
+        ctx.c1 = False
         rows = cout if cout % 4 == 0 else (cout + 3) // 4 * 4
         bp = b
         if b is not None and rows != cout:
@@ -484,6 +495,14 @@ class ConvK4Fn(torch.autograd.Function):
         cout, cin = w.shape[0], w.shape[1]
         n, h, wd, cp = x.shape
         dy = _c(dy)
+        if ctx.c1:
+            dy = dy if dy.dtype == f32 else dy.float()
+            dw = db = None
+            if ctx.needs_input_grad[1] or (b is not None and ctx.needs_input_grad[2]):       # a frozen discriminator (the generator's term) wants neither
+                dw, db = _dst(w), (_dst(b) if b is not None else None)
+                dw, db = ops.conv_k4c1_wgrad(x, dy, dw, db, need_bias=b is not None)
+            dx = ops.conv_k4c1_dgrad(dy, w, h) if ctx.needs_input_grad[0] else None
+            return dx, dw, db, None, None, None
         if act == ops.ACT_LEAKY:
             dy = ops.leaky_relu_bwd(dy, y)
         cpad = cout if cout % 32 == 0 else (cout + 31) // 32 * 32

@@ -621,6 +621,45 @@ def conv_in3(x0: torch.Tensor, x1: Optional[torch.Tensor], w: torch.Tensor, bias
     return y
 
 
+def conv_k4c1_supported(n: int, h: int, w: int, c: int) -> bool:
+    return bool(_lib.lib().dmvae_conv_k4c1_supported(n, h, w, c))
+
+
+def conv_k4c1_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """nn.Conv2d(C, 1, 4, 1, 1) on NHWC bf16 x [N, H, 31, C] with the f32 parameter w [1, C, 4, 4] -> f32 logits [N, H - 1, 30, 1] (include/dmvae_hip.h dmvae_conv_k4c1_fwd)."""
+    x = _req(x, bf16, "x"); w = _req(w, f32, "weight")
+    n, h, wd, c = x.shape
+    assert tuple(w.shape) == (1, c, 4, 4), (x.shape, w.shape)
+    out = torch.empty(n, h - 1, wd - 1, 1, dtype=f32, device=x.device)
+    check(_lib.lib().dmvae_conv_k4c1_fwd(x.data_ptr(), w.data_ptr(), _ptr(None if bias is None else _req(bias, f32, "bias")), out.data_ptr(), n, h, wd, c, _stream()), "conv_k4c1_fwd")
+    return out
+
+
+def conv_k4c1_dgrad(dy: torch.Tensor, w: torch.Tensor, h: int) -> torch.Tensor:
+    """Input gradient of `conv_k4c1_fwd`: dy f32 [N, H - 1, 30, 1] -> dx bf16 [N, H, 31, C]."""
+    dy = _req(dy, f32, "dy"); w = _req(w, f32, "weight")
+    n, c = dy.shape[0], w.shape[1]
+    assert dy.shape[1] == h - 1 and dy.shape[2] == 30
+    dx = torch.empty(n, h, 31, c, dtype=bf16, device=dy.device)
+    check(_lib.lib().dmvae_conv_k4c1_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), n, h, 31, c, _stream()), "conv_k4c1_dgrad")
+    return dx
+
+
+def conv_k4c1_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None, need_bias: bool = True):
+    """Weight / bias gradient of `conv_k4c1_fwd`: (dw f32 [1, C, 4, 4], db f32 [1] or None), written into dw / db when given (flat-buffer views)."""
+    x = _req(x, bf16, "x"); dy = _req(dy, f32, "dy")
+    n, h, wd, c = x.shape
+    L = _lib.lib()
+    if dw is None:
+        dw = torch.empty(1, c, 4, 4, dtype=f32, device=x.device)
+    if db is None and need_bias:
+        db = torch.empty(1, dtype=f32, device=x.device)
+    assert dw.dtype == f32 and dw.is_contiguous() and dw.numel() == 16 * c and (db is None or (db.dtype == f32 and db.numel() == 1))
+    ws = workspace(L.dmvae_conv_k4c1_wgrad_workspace(c), x.device, slot="conv_k4c1")
+    check(L.dmvae_conv_k4c1_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel(), n, h, wd, c, _stream()), "conv_k4c1_wgrad")
+    return dw, db
+
+
 def conv_to_image_supported(n: int, h: int, w: int, cin: int, cout: int) -> bool:
     return bool(_lib.lib().dmvae_conv_to_image_supported(n, h, w, cin, cout))
 

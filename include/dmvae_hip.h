@@ -30,6 +30,7 @@ typedef struct ihipStream_t* dmvae_stream_t; /* == hipStream_t */
 const char* dmvae_last_error(void);
 /* ABI version; bumped when a signature or a struct changes.  2: dmvae_conv_desc gained its last field, w_layout (zero = the behaviour of version 1).
  * 3: struct dmvae_pack_entry and the entry points that take it (dmvae_pack_weights_batched), dmvae_linear_bf16 / _plan / dmvae_linear_weight_t_kmajor.
+ * 7: dmvae_linear_wgrad_grouped_plan / _xcd / _chunk_bytes, dmvae_conv_k4c1_*.
  * 4: dmvae_norm_conv_out_bwd / _supported / _workspace, dmvae_norm_conv_out_fwd / _supported, dmvae_conv_in3 / _supported / _workspace, dmvae_im2col_nhwc_taps, dmvae_linear_bf16_batched / _supported, dmvae_conv_to_image / _supported.
  * 5: dmvae_groupnorm_apply_short / _bwd_short / _short_supported / _bwd_short_workspace, dmvae_lpips_diff_pool.
  * 6: the whole-stack LightningDiT backward (dmvae_dit_boundary_bwd, dmvae_dit_stack_*, dmvae_colsum2_batched, dmvae_qknorm_rope_bwd_partial / _nblk), the batched
@@ -561,6 +562,18 @@ size_t dmvae_linear_wgrad_grouped_chunk_bytes(void);
 int dmvae_linear_wgrad_grouped_plan(const void* table, int n, void* chunks_out, int max_chunks, int* n_chunks, unsigned* xoff, unsigned* grid);
 int dmvae_linear_wgrad_grouped_xcd(const void* table, const void* chunks, const unsigned* xoff, unsigned grid, int ragged, const void* bias_table, int n_bias,
                                    unsigned bias_blocks, dmvae_stream_t stream);
+
+/* 4x4 stride-1 padding-1 convolution to ONE output channel: the PatchGAN's logits layer (models/patchgan.py:146, nn.Conv2d(8 ndf = 512, 1, 4, 1, 1)), forward and both
+ * gradients on the vector units -- by its bytes the layer is one pass over the activation map (csrc/conv_c1.hip).  x, dx: NHWC bf16 [n][h][31][c]; w: the f32
+ * parameter [1][c][4][4] (rounded to bf16 in registers: the autocast conv's operand), bias f32 [1] or NULL; out, dy: f32 [n][h - 1][30]; dw f32 [1][c][4][4] and
+ * db f32 [1] (or NULL) are WRITTEN.  workspace: dmvae_conv_k4c1_wgrad_workspace(c) bytes.  Shapes: w == 31, c a multiple of 512 (dmvae_conv_k4c1_supported);
+ * others run on dmvae_conv2d_nhwc_*.  f32 products and sums in a fixed order: deterministic. */
+int dmvae_conv_k4c1_supported(int n, int h, int w, int c);
+size_t dmvae_conv_k4c1_wgrad_workspace(int c);
+int dmvae_conv_k4c1_fwd(const void* x, const void* w, const void* bias, void* out, int n, int h, int wdt, int c, dmvae_stream_t stream);
+int dmvae_conv_k4c1_dgrad(const void* dy, const void* w, void* dx, int n, int h, int wdt, int c, dmvae_stream_t stream);
+int dmvae_conv_k4c1_wgrad(const void* x, const void* dy, void* dw, void* db, void* workspace, size_t workspace_bytes, int n, int h, int wdt, int c,
+                          dmvae_stream_t stream);
 
 /* ---- losses (HBM-bound reductions) ------------------------------------------------------------- */
 

@@ -390,3 +390,48 @@ def test_single_pass_generator_backward_equals_the_three_sweeps():
     assert rl2(gl1.cpu(), g.t("g_last")) < 8e-2 and rl2(gl1.cpu(), g.t("g_last")) < 1.1 * rl2(gl0.cpu(), g.t("g_last")) + 1e-3
     assert torch.equal(gs1, gs0)                                          # the term outside recon takes part in the final backward
     assert abs(w1 - float(g["d_weight"])) < 8e-2 * float(g["d_weight"])  # and it is the reference's adaptive weight
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,h,c", [(3, 31, 512), (2, 9, 1024), (64, 31, 512)])
+def test_k4_logits_layer_on_the_vector_unit_kernels(n, h, c, monkeypatch):
+    """functional.ConvK4Fn for the one-output-channel 4x4 stride-1 conv (the PatchGAN's logits layer, models/patchgan.py:146) on csrc/conv_c1.hip: forward, input
+    gradient, weight and bias gradient against fp64 autograd on the bf16-rounded operands and against the matrix-core route it replaces; frozen parameters get no
+    weight gradient; two runs give the same bits."""
+    from dmvae_amd import functional as Fn, ops
+    g = torch.Generator().manual_seed(n + h + c)
+    x0 = torch.randn(n, h, 31, c, generator=g).cuda().to(BF)
+    w = (torch.randn(1, c, 4, 4, generator=g) * 0.02).cuda().requires_grad_(True)
+    b = torch.randn(1, generator=g).cuda().requires_grad_(True)
+    dy = torch.randn(n, h - 1, 30, 1, generator=g).cuda()
+    res = {}
+    for on in (True, False, True):
+        monkeypatch.setattr(Fn, "K4_COUT1", on)
+        w.grad = b.grad = None
+        x = x0.clone().requires_grad_(True)
+        y = Fn.ConvK4Fn.apply(x, w, b, 1, ops.ACT_NONE, True)
+        assert y.dtype == torch.float32 and y.shape == (n, h - 1, 30, 1)
+        y.backward(dy)
+        cur = (y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+        if on and True in res:
+            assert all(torch.equal(a, c_) for a, c_ in zip(cur, res[True]))
+        res[on] = cur
+    xr = x0.float().cpu().double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.detach().to(BF).float().cpu().double().requires_grad_(True)
+    br = b.detach().cpu().double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=1, padding=1)
+    yr.backward(dy.cpu().double().permute(0, 3, 1, 2))
+    new, old = res[True], res[False]
+    assert rel_err(new[0].cpu().permute(0, 3, 1, 2), yr.detach()) < 2e-6
+    assert rel_err(new[1].float().cpu().permute(0, 3, 1, 2), xr.grad) < 5e-3          # bf16 result: 2^-9 per element
+    assert rel_err(new[2].cpu(), wr.grad) < 2e-6 and rel_err(new[3].cpu(), br.grad) < 2e-6
+    assert rel_err(new[0], old[0]) < 1e-5 and rel_err(new[1].float(), old[1].float()) < 8e-3 and rel_err(new[2], old[2]) < 4e-3 and rel_err(new[3], old[3]) < 2e-2      # the old route rounds dy to bf16 on its way into the matrix kernels
+    # frozen parameters: no weight-gradient launch, the same input gradient
+    monkeypatch.setattr(Fn, "K4_COUT1", True)
+
+    def boom(*a, **k):
+        raise AssertionError("weight gradient computed for frozen parameters")
+    monkeypatch.setattr(ops, "conv_k4c1_wgrad", boom)
+    xb = x0.clone().requires_grad_(True)
+    Fn.ConvK4Fn.apply(xb, w.detach(), b.detach(), 1, ops.ACT_NONE, True).backward(dy)
+    assert torch.equal(xb.grad, new[1])
