@@ -64,10 +64,10 @@ typedef struct dmvae_conv_desc {
 } dmvae_conv_desc;
 
 /* 1 when conv2d_nhwc_fwd / _gnstats run descriptor d on the kx-halo kernel (plain 3x3, bf16 result, large shapes: csrc/conv_pp.hip) and therefore accept
- * w_layout = 1; 0 otherwise.  Pure function of d. */
+ * w_layout = 1; 0 otherwise.  Pure function of d.  Reference: Helper of dmvae_conv2d_nhwc_fwd (every nn.Conv2d of models/flux_ae.py:21-107,239-269 and of the LPIPS trunk utils/lpips.py:116-153). */
 int dmvae_conv_halo_applies(const dmvae_conv_desc* d);
 /* 1 when the call runs on the large-tile conv kernel at all (csrc/conv_pp.hip, any instantiation: plain 3x3, 1x1, the 4x4 stride-2 conv and its per-parity
- * transpose, Upsample's folded gather) and may therefore carry w_layout = 1; dmvae_conv_halo_applies(d) = 1 is the subset that runs the kx-halo form. */
+ * transpose, Upsample's folded gather) and may therefore carry w_layout = 1; dmvae_conv_halo_applies(d) = 1 is the subset that runs the kx-halo form.  Reference: Helper of dmvae_conv2d_nhwc_fwd (every nn.Conv2d of models/flux_ae.py:21-107,239-269 and of the LPIPS trunk utils/lpips.py:116-153). */
 int dmvae_conv_kmajor_applies(const dmvae_conv_desc* d);
 
 /* y[n,ho,wo,cout] = act( conv(x, w) + bias + residual ).
@@ -93,7 +93,7 @@ int dmvae_conv2d_nhwc_fwd_gnstats(const void* x, const void* w, const void* bias
  * dw: [cout][cin][ks][ks] f32 (PyTorch nn.Conv2d.weight layout); dbias: [cout] f32 or NULL.
  * accumulate=1 adds into dw/dbias (autograd .grad accumulation), 0 overwrites.
  * workspace: >= dmvae_conv2d_nhwc_wgrad_workspace(d) bytes, caller-owned.  d->act/out_f32 ignored.
- * Replaces autograd's conv/linear weight-gradient for the call sites listed at conv2d_nhwc_fwd. */
+ * Replaces autograd's conv/linear weight-gradient for the call sites listed at conv2d_nhwc_fwd.  Reference: Replaces autograd's weight / bias gradient of every nn.Conv2d of models/flux_ae.py:21-107,239-269 and of the LPIPS trunk utils/lpips.py:116-153 (loss.backward(), train_tokenizer.py:382). */
 size_t dmvae_conv2d_nhwc_wgrad_workspace(const dmvae_conv_desc* d);
 int dmvae_conv2d_nhwc_wgrad(const void* dy, const void* a, void* dw, void* dbias, void* workspace,
                             size_t workspace_bytes, const dmvae_conv_desc* d, int accumulate,
@@ -110,7 +110,7 @@ int dmvae_conv_out_wgrad(const void* dy, const void* a, void* dw, void* workspac
 /* ---- GroupNorm(+swish) on NHWC bf16 (HBM-bound) --------------------------------------------- */
 
 /* Workspace bytes needed by groupnorm_stats / groupnorm_bwd for x: [n, hw, c]; 0 if unsupported
- * (c must be a multiple of 8 and <= 512, c % groups == 0). */
+ * (c must be a multiple of 8 and <= 512, c % groups == 0).  Reference: Normalize() = GroupNorm(32, eps 1e-6), models/flux_ae.py:28, at :62,64,236. */
 size_t dmvae_groupnorm_workspace(int n, int hw, int c, int groups);
 
 /* stats[n][groups][2] = (mean, rstd) over (hw, c/groups) of x [n,hw,c] bf16, f32 accumulation.
@@ -128,7 +128,7 @@ int dmvae_groupnorm_apply(const void* x, const void* stats, const void* gamma, c
 
 /* Backward of y=act(GN(x)): given da=dL/dy (bf16), x, stats, gamma, beta computes
  * dx (bf16) = GN/act backward [+ dres when dres != NULL, fusing the residual-branch add],
- * dgamma/dbeta ([c] f32, accumulate!=0 adds) -- both may be NULL to skip.  = bwd_reduce followed by bwd_apply. */
+ * dgamma/dbeta ([c] f32, accumulate!=0 adds) -- both may be NULL to skip.  = bwd_reduce followed by bwd_apply.  Reference: Autograd of swish(Normalize(x)), models/flux_ae.py:24,28,62-65,236. */
 int dmvae_groupnorm_bwd(const void* da, const void* x, const void* dres, const void* stats, const void* gamma,
                         const void* beta, void* dx, void* dgamma, void* dbeta, void* workspace,
                         size_t workspace_bytes, int n, int hw, int c, int groups, int act, int accumulate,
@@ -140,7 +140,7 @@ int dmvae_groupnorm_bwd_colsum(const void* da, const void* x, const void* dres, 
                                int accumulate, int colsum_accumulate, dmvae_stream_t stream);
 /* The two halves, for callers that own the statistics (SyncBatchNorm: all-reduce `sums` over ranks in between and pass
  * inv_count = 1 / global element count; eval-mode BatchNorm: skip the reduce and pass zero sums).
- * sums: [n][groups][2] f32 = (sum g, sum g*x_hat), g = da*act'(.)*gamma.  inv_count <= 0 selects 1/(hw*c/groups). */
+ * sums: [n][groups][2] f32 = (sum g, sum g*x_hat), g = da*act'(.)*gamma.  inv_count <= 0 selects 1/(hw*c/groups).  Reference: nn.BatchNorm2d / SyncBatchNorm backward of the discriminator, models/patchgan.py:133,141 (train_tokenizer.py:283-285). */
 int dmvae_groupnorm_bwd_reduce(const void* da, const void* x, const void* stats, const void* gamma, const void* beta,
                                void* sums, void* dgamma, void* dbeta, void* workspace, size_t workspace_bytes, int n,
                                int hw, int c, int groups, int act, int accumulate, dmvae_stream_t stream);
@@ -158,7 +158,7 @@ int dmvae_groupnorm_bwd_apply(const void* da, const void* x, const void* dres, c
 /* Forward of the same tail in one launch (csrc/conv_thin.hip, NORM instantiation): a = swish(GroupNorm(x)) is computed on the way into the conv's halo tile and
  * written out once (bf16 [n][h][w][c]: what the weight gradient of conv_out reads in the backward), y = conv_out(a) + bias leaves as the NCHW f32 image
  * [n][cout][h][w].  w: conv_out's packed bf16 operand [4][9][c] (dmvae_pack_conv_weight, rows_pad 4), bias f32 [cout] or NULL.  Shapes: c = 128, h % 4 == 0,
- * w % 32 == 0, cout <= 4.  Same bits as dmvae_groupnorm_apply -> dmvae_conv2d_nhwc_fwd (out_f32) -> dmvae_nhwc_to_nchw_f32. */
+ * w % 32 == 0, cout <= 4.  Same bits as dmvae_groupnorm_apply -> dmvae_conv2d_nhwc_fwd (out_f32) -> dmvae_nhwc_to_nchw_f32.  Reference: models/flux_ae.py:266-268. */
 int dmvae_norm_conv_out_fwd_supported(int n, int h, int w, int c, int groups, int cout);
 int dmvae_norm_conv_out_fwd(const void* x, const void* stats, const void* gamma, const void* beta, const void* w, const void* bias, void* a, void* y,
                             int n, int h, int wd, int c, int groups, int cout, dmvae_stream_t stream);
@@ -205,13 +205,13 @@ int dmvae_conv_in3(const void* x0, const void* x1, int n0, const void* shift, co
 
 /* C[b][m][n] = act( sum_k A[b][m][k]*B[b][n][k] + bias[n] + R[b][m][n] ); row-major bf16, both
  * operands K-contiguous; *_bs are element strides between batch items (0 = shared operand);
- * C/R share c_bs.  K%32==0, N%4==0.  act as in dmvae_conv_desc; out_f32 selects C's type. */
+ * C/R share c_bs.  K%32==0, N%4==0.  act as in dmvae_conv_desc; out_f32 selects C's type.  Reference: AttnBlock's q k^T / p v and the 1x1 convs around them, models/flux_ae.py:37-49; timm Mlp's fc1 / fc2 through models/vae.py:47-53. */
 int dmvae_gemm_nt_batched(const void* A, const void* B, const void* bias, const void* R, void* C, int M, int N,
                           int K, int batch, long long a_bs, long long b_bs, long long c_bs, int act, int out_f32,
                           dmvae_stream_t stream);
 
 /* C[b][m][n] = alpha * sum_k A[b][k][m]*B[b][k][n]  (A:[K][M], B:[K][N] row-major bf16; the
- * reduction dim is the slow one -> LDS transpose reads).  M%8==0, N%8==0.  Split-K, deterministic. */
+ * reduction dim is the slow one -> LDS transpose reads).  M%8==0, N%8==0.  Split-K, deterministic.  Reference: The weight-gradient products of the same layers (autograd of models/flux_ae.py:37-49, models/vae.py:47-53). */
 size_t dmvae_gemm_tn_batched_workspace(int M, int N, int K, int batch);
 int dmvae_gemm_tn_batched(const void* A, const void* B, void* C, void* workspace, size_t workspace_bytes, int M,
                           int N, int K, int batch, long long a_bs, long long b_bs, long long c_bs, float alpha,
@@ -229,7 +229,7 @@ int dmvae_linear_rows_bf16(const void* x, const void* w, const void* bias, void*
 /* w_layout = 1: w is the K-tile-major copy [K / 32][N][32] (dmvae_linear_weight_t_kmajor writes it from the bf16 weight in ~8 us: what the input gradient
  * reads instead of a row-major transposed copy re-packed from the f32 master every step); ldw is then ignored.
  * Weight and bias gradient of the same per-sample Linear: dW[N][K] f32 (+)= dY[M][N]^T . X[M][K], db[N] f32 (+)= column sums of dY (db may be NULL);
- * 1 <= M <= 64, K % 8 == 0; dy / x bf16 row-major with leading dimensions lddy / ldx.  Bound by writing the f32 gradient; summed over the samples in order. */
+ * 1 <= M <= 64, K % 8 == 0; dy / x bf16 row-major with leading dimensions lddy / ldx.  Bound by writing the f32 gradient; summed over the samples in order.  Reference: Autograd of adaLN_modulation[1] / the embedders' Linears, diffusion/lightningdit/lightningdit.py:236-250,262-264. */
 int dmvae_linear_rows_wgrad(const void* dy, const void* x, void* dw, void* db, int M, int N, int K, int lddy, int ldx, int accumulate, dmvae_stream_t stream);
 
 /* Dynamic tile claiming in the large-shape conv kernel (blocks claim tiles from per-XCD counters instead of a static stride, so that a launch next to another
@@ -266,7 +266,7 @@ int dmvae_linear_bf16_batched(const void* x, const void* w, void* y, int batch, 
 /* Split-K form of dmvae_linear_bf16 for few-tile, deep-K problems (LightningDiT at batch 16: M = 4096 x N = 1152 is 18 tiles of 256 x 256; K = 3072 ... 6144):
  * the reduction cut into `splits` equal parts computed as independent work units into f32 slabs [splits][M][N] (no bias, no activation), then
  * dmvae_splitk_sum_bf16: y bf16 [M][N] = bf16(slab_0 + slab_1 + ... + bias) in that order (bias f32, or bf16 when bias_bf16; may be NULL).
- * K % (32 splits) == 0, K / splits >= 384, N % 8 == 0; w row-major [N][ldw] (w_layout 0) or K-tile-major (1).  Deterministic. */
+ * K % (32 splits) == 0, K / splits >= 384, N % 8 == 0; w row-major [N][ldw] (w_layout 0) or K-tile-major (1).  Deterministic.  Reference: LightningDiTBlock's Linears, diffusion/lightningdit/lightningdit.py:173-252, swiglu_ffn.py:15-36. */
 int dmvae_linear_bf16_splitk_supported(int M, int N, int K, int splits);
 int dmvae_linear_bf16_splitk(const void* x, const void* w, void* slabs, int splits, int M, int N, int K, int lda, int ldw, int w_layout, dmvae_stream_t stream);
 int dmvae_splitk_sum_bf16(const void* slabs, int splits, const void* bias, int bias_bf16, void* y, int M, int N, dmvae_stream_t stream);
@@ -283,7 +283,7 @@ int dmvae_linear_weight_t_kmajor(const void* w, void* out, int N, int K, dmvae_s
 int dmvae_softmax_rows_fwd(const void* s, void* p, int rows, int cols, float scale, dmvae_stream_t stream);
 int dmvae_softmax_rows_bwd(const void* dp, const void* p, void* ds, int rows, int cols, float scale,
                            dmvae_stream_t stream);
-/* dst[b][c][r] = src[b][r][c], bf16 */
+/* dst[b][c][r] = src[b][r][c], bf16.  Reference: Operand layout for AttnBlock's products, models/flux_ae.py:37-49. */
 int dmvae_transpose_bf16(const void* src, void* dst, int batch, int rows, int cols, dmvae_stream_t stream);
 
 /* ---- layout / packing ------------------------------------------------------------------------- */
@@ -292,11 +292,11 @@ int dmvae_transpose_bf16(const void* src, void* dst, int batch, int rows, int co
  * for_dgrad=0: out[rows_pad=cout..][ks*ks][cols_pad=cin..], out[co][t][ci]       = w[co][ci][t]
  * for_dgrad=1: out[rows_pad=cin..][ks*ks][cols_pad=cout..], out[ci][T-1-t][co]   = w[co][ci][t]
  * (tap-flipped transpose: conv2d_nhwc_fwd on dy with this operand is the input gradient).
- * Padding rows/cols are zero-filled. */
+ * Padding rows/cols are zero-filled.  Reference: The bf16 copy torch.autocast makes of the weight of every nn.Conv2d of models/flux_ae.py:21-107,239-269 and of the LPIPS trunk utils/lpips.py:116-153 on every forward. */
 int dmvae_pack_conv_weight(const void* w, void* out, int cout, int cin, int ks, int rows_pad, int cols_pad,
                            int for_dgrad, dmvae_stream_t stream);
 /* The same pack, and in the same launch the K-tile-major copy out_kmajor[cols_pad/32][ks*ks][rows_pad][32] (dmvae_conv_desc.w_layout = 1) when
- * out_kmajor is non-NULL (cols_pad % 32 == 0 then). */
+ * out_kmajor is non-NULL (cols_pad % 32 == 0 then).  Reference: The bf16 copy torch.autocast makes of the weight of every nn.Conv2d of models/flux_ae.py:21-107,239-269 and of the LPIPS trunk utils/lpips.py:116-153 on every forward. */
 int dmvae_pack_conv_weight_v2(const void* w, void* out, void* out_kmajor, int cout, int cin, int ks, int rows_pad, int cols_pad,
                               int for_dgrad, dmvae_stream_t stream);
 /* Every stale weight operand of a model in ONE launch: after an optimiser step (train_tokenizer.py:416-417 `optimizer_vae.step()`) the bf16 operands of all
@@ -325,10 +325,10 @@ int dmvae_pack_weights_batched(const void* table, int n_entries, unsigned long l
  *                 dL/dbias = colsum_bf16(dy).
  * w: f32 [cout][cin][3][3]; wd: f32 [cin][cout][4][4]. */
 int dmvae_subpixel_weight(const void* w, void* wd, int cout, int cin, dmvae_stream_t stream);
-/* dw[co][ci][ky][kx] (+)= sum_{r in {2-ky,3-ky}, s in {2-kx,3-kx}} dwd[ci][co][r][s] -- the transpose of the map above (f32, fixed order). */
+/* dw[co][ci][ky][kx] (+)= sum_{r in {2-ky,3-ky}, s in {2-kx,3-kx}} dwd[ci][co][r][s] -- the transpose of the map above (f32, fixed order).  Reference: Upsample = nearest x2 + conv3x3, models/flux_ae.py:98-107. */
 int dmvae_subpixel_weight_fold(const void* dwd, void* dw, int cout, int cin, int accumulate, dmvae_stream_t stream);
 /* out[c] (+)= sum_r x[r][c], x row-major bf16 [rows][cols], out f32 [cols]; two-stage, fixed order.  workspace >= 512*cols*4 bytes.
- * The bias gradient of nn.Conv2d on its own (autograd's sum over N,H,W of the output gradient). */
+ * The bias gradient of nn.Conv2d on its own (autograd's sum over N,H,W of the output gradient).  Reference: Bias gradient of every nn.Conv2d of models/flux_ae.py:21-107,239-269 and of the LPIPS trunk utils/lpips.py:116-153. */
 int dmvae_colsum_bf16(const void* x, void* out, void* workspace, size_t workspace_bytes, size_t rows, int cols, int accumulate,
                       dmvae_stream_t stream);
 /* dx[n,h,w,c] = sum of the 2x2 block of dy[n,2h,2w,c]: backward of F.interpolate(scale=2,'nearest')
@@ -369,7 +369,7 @@ int dmvae_maxpool2x2_nhwc(const void* x, void* y, int n, int h, int w, int c, dm
 int dmvae_maxpool2x2_relu_bwd_nhwc(const void* dpool, const void* x, const void* extra, void* dx, int n, int h, int w, int c,
                                    dmvae_stream_t stream);
 int dmvae_relu_bwd(const void* dy, const void* y, void* dx, size_t n, dmvae_stream_t stream);
-/* image layout conversion at the Decoder boundary (reference tensors are NCHW f32). */
+/* image layout conversion at the Decoder boundary (reference tensors are NCHW f32).  Reference: models/vae.py:56-65 (decode / forward hand NCHW f32 images to and from the Decoder). */
 int dmvae_nchw_f32_to_nhwc_bf16(const void* src, void* dst, int n, int c, int hw, int c_pad, dmvae_stream_t stream);
 int dmvae_nhwc_to_nchw_f32(const void* src, void* dst, int n, int c, int hw, int c_pad, int src_f32,
                            dmvae_stream_t stream);
@@ -380,16 +380,16 @@ int dmvae_silu_bwd(const void* x, const void* dy, void* dx, size_t n, dmvae_stre
 /* ---- frozen ViT encoder forward, elementwise part (models/vae.py:52-53; timm / dino_layers block algebra) ------------------- */
 
 /* y[rows][c] (bf16) = LayerNorm(x[rows][c] f32; gamma, beta f32, eps): nn.LayerNorm under autocast (f32) + the bf16 cast in front
- * of the following Linear.  c in {256, 512, ..., 1536}. */
+ * of the following Linear.  c in {256, 512, ..., 1536}.  Reference: timm VisionTransformer blocks' norm1 / norm2 / norm through models/vae.py:47-53. */
 int dmvae_layernorm_f32_bf16(const void* x, const void* gamma, const void* beta, void* y, int rows, int c, float eps,
                              dmvae_stream_t stream);
 /* The two calls below fused, for every LayerNorm that follows a LayerScale + residual add (all but a block's first): x += ls_gamma * r (in place, f32), then
- * y = bf16(LayerNorm(x)); one pass over the residual stream, bit-identical to scale_residual_f32 followed by layernorm_f32_bf16. */
+ * y = bf16(LayerNorm(x)); one pass over the residual stream, bit-identical to scale_residual_f32 followed by layernorm_f32_bf16.  Reference: timm Block: x + ls(attn(norm1(x))), x + ls(mlp(norm2(x))) through models/vae.py:47-53; LayerScale models/dino_layers/layer_scale.py:18-27. */
 int dmvae_scale_residual_layernorm(void* x, const void* r, const void* ls_gamma, const void* gamma, const void* beta, void* y, int rows, int c, float eps,
                                    dmvae_stream_t stream);
 /* x[rows][c] (f32, in place) += gamma[c] * y[rows][c] (bf16): LayerScale (dino_layers/layer_scale.py:15-26) + residual add. c%8==0. */
 int dmvae_scale_residual_f32(void* x, const void* y, const void* gamma, size_t rows, int c, dmvae_stream_t stream);
-/* p[rows][cols] (bf16) = softmax(scale * s[rows][cols]) with bf16 scores, f32 inside; cols <= 512 (encoder attention, S = 257). */
+/* p[rows][cols] (bf16) = softmax(scale * s[rows][cols]) with bf16 scores, f32 inside; cols <= 512 (encoder attention, S = 257).  Reference: models/dino_layers/attention.py:56-69 (unfused path). */
 int dmvae_softmax_rows_bf16(const void* s, void* p, size_t rows, int cols, float scale, dmvae_stream_t stream);
 /* out[b][s][h*64+d] = softmax_k(scale * q.k) v for qkv [b][s][3][h][64] bf16 (the qkv Linear's output layout): the encoder's
  * multi-head self-attention (timm Attention; dino_layers/attention.py:56-69) fused in one kernel.  head_dim 64, seq <= 288. */
@@ -402,7 +402,7 @@ int dmvae_attention_qkv_bf16(const void* qkv, void* out, int batch, int seq, int
 int dmvae_attention_heads_bf16(const void* q, const void* k, const void* v, void* out, int batch, int seq, int heads, int head_dim,
                                int head_dim_padded, float scale, dmvae_stream_t stream);
 /* The two kernels above with the row statistics written out: lse f32 [batch * heads][seq] = scale * max_k(q.k) + log(sum_k exp(scale (q.k - max))) per query -- what
- * dmvae_attention_bwd_*_lse_bf16 rebuild the probabilities from (lse may be NULL: the plain calls). */
+ * dmvae_attention_bwd_*_lse_bf16 rebuild the probabilities from (lse may be NULL: the plain calls).  Reference: models/dino_layers/attention.py:56-69; diffusion/lightningdit/lightningdit.py:76-88 (F.scaled_dot_product_attention). */
 int dmvae_attention_qkv_lse_bf16(const void* qkv, void* out, void* lse, int batch, int seq, int heads, int head_dim, float scale, dmvae_stream_t stream);
 int dmvae_attention_heads_lse_bf16(const void* q, const void* k, const void* v, void* out, void* lse, int batch, int seq, int heads, int head_dim,
                                    int head_dim_padded, float scale, dmvae_stream_t stream);
@@ -423,7 +423,7 @@ int dmvae_attention_bwd_qkv_bf16(const void* qkv, const void* out, const void* d
 int dmvae_attention_bwd_heads_bf16(const void* q, const void* k, const void* v, const void* out, const void* dout, void* dq, void* dk, void* dv,
                                    int batch, int seq, int heads, int head_dim, int head_dim_padded, float scale, dmvae_stream_t stream);
 /* The same with the forward's row statistics handed in (lse from dmvae_attention_*_lse_bf16; NULL = the calls above): the probabilities are rebuilt as
- * exp(scale q.k - lse) without a max / sum pass, which frees the registers for two waves per SIMD (eight-wave workgroups). */
+ * exp(scale q.k - lse) without a max / sum pass, which frees the registers for two waves per SIMD (eight-wave workgroups).  Reference: Autograd of models/dino_layers/attention.py:56-69 and diffusion/lightningdit/lightningdit.py:76-88 (train_dmd.py:565-575). */
 int dmvae_attention_bwd_qkv_lse_bf16(const void* qkv, const void* out, const void* dout, const void* lse, void* dqkv, int batch, int seq, int heads, int head_dim,
                                      float scale, dmvae_stream_t stream);
 int dmvae_attention_bwd_heads_lse_bf16(const void* q, const void* k, const void* v, const void* out, const void* dout, const void* lse, void* dq, void* dk,
@@ -459,7 +459,7 @@ int dmvae_gated_residual_rmsnorm_modulate(void* x, const void* r, const void* ga
                                           const void* mod, void* y, int rows, int rows_per_sample, int c, int mod_stride, int shift_off,
                                           int scale_off, float eps, dmvae_stream_t stream);
 /* Out-of-place form (the training route keeps the residual stream before the update for its backward): x_out = x_in + bf16(gate[b] * r); y != NULL: also
- * y = rmsnorm_modulate(x_out) in the same pass (w, mod and the offsets are then required), y == NULL: the residual update alone. */
+ * y = rmsnorm_modulate(x_out) in the same pass (w, mod and the offsets are then required), y == NULL: the residual update alone.  Reference: diffusion/lightningdit/lightningdit.py:27-31,66-75,236-250; swiglu_ffn.py:32-35; rms_norm.py:52-76. */
 int dmvae_gated_residual_out(const void* x_in, void* x_out, const void* r, const void* gate_mod, int gate_stride, int gate_off, const void* w,
                              const void* mod, void* y, int rows, int rows_per_sample, int c, int mod_stride, int shift_off, int scale_off,
                              float eps, dmvae_stream_t stream);
@@ -490,7 +490,7 @@ int dmvae_qknorm_rope_bwd(const void* dq, const void* dk, const void* dv, const 
                           dmvae_stream_t stream);
 
 /* First stage of dmvae_qknorm_rope_bwd only: dqkv is written, the per-block partial sums of the two norm-weight gradients stay in `part`
- * ([dmvae_qknorm_rope_bwd_nblk(...)][2][head_dim] f32) for a reduction batched over layers (dmvae_colsum2_batched). */
+ * ([dmvae_qknorm_rope_bwd_nblk(...)][2][head_dim] f32) for a reduction batched over layers (dmvae_colsum2_batched).  Reference: Autograd of q_norm / k_norm + rotary embedding, diffusion/lightningdit/lightningdit.py:66-75 (train_dmd.py:565-575). */
 int dmvae_qknorm_rope_bwd_nblk(int batch, int seq, int heads, int head_dim, int head_dim_padded);
 int dmvae_qknorm_rope_bwd_partial(const void* dq, const void* dk, const void* dv, const void* qkv, const void* q_weight, const void* k_weight,
                                   const void* cos_table, const void* sin_table, void* dqkv, void* part, size_t part_bytes, int batch, int seq, int heads,
@@ -517,7 +517,7 @@ int dmvae_dit_boundary_bwd(const void* da, const void* x, const void* w, const v
 int dmvae_dit_stack_finalize(const void* part, void* dmod, void* workspace, size_t workspace_bytes, const void* dw_table, int layers, int batch, int seq, int c,
                              int accumulate, dmvae_stream_t stream);
 /* part [layers][nblk][2][d] f32 -> o0_table[l][d], o1_table[l][d] (device arrays of `layers` pointers to f32 [d]): the second stage of
- * dmvae_qknorm_rope_bwd_partial for every layer in one launch. */
+ * dmvae_qknorm_rope_bwd_partial for every layer in one launch.  Reference: Autograd of q_norm / k_norm weights, diffusion/lightningdit/lightningdit.py:66-75. */
 int dmvae_colsum2_batched(const void* part, const void* o0_table, const void* o1_table, int layers, int nblk, int d, int accumulate, dmvae_stream_t stream);
 /* dmvae_linear_rows_bf16 for `layers` Linears of one shape in one launch (adaLN_modulation[1] of every block: lightningdit.py:236-240): w_table / bias_table device
  * arrays of `layers` pointers (bias_table may be NULL), x / y advanced by x_layer_stride / y_layer_stride ELEMENTS per layer (x_layer_stride 0: one x for all). */
@@ -526,12 +526,12 @@ int dmvae_linear_rows_batched_bf16(const void* x, long long x_layer_stride, cons
 /* Weight + bias gradients of `layers` per-sample Linears sharing their input, on the matrix cores: dW_l [N][K] f32 (+)= dY_l [M][N]^T . X [M][K], db_l [N] f32 (+)=
  * column sums of dY_l; dy bf16 [layers][M][lddy] (dy_layer_stride elements apart), xT = X TRANSPOSED, bf16 [K][mp] with mp = 32 or 64 >= M and zeros beyond M;
  * dw_table / db_table: device arrays of `layers` pointers (db_table may be NULL), or NULL tables with layers = 1 and dw / db given directly.  1 <= M <= 64, K % 8 == 0.
- * Bound by writing the f32 gradients; deterministic. */
+ * Bound by writing the f32 gradients; deterministic.  Reference: Autograd of every block's adaLN_modulation[1], diffusion/lightningdit/lightningdit.py:236-250. */
 int dmvae_linear_rows_wgrad_batched(const void* dy, long long dy_layer_stride, const void* xT, int mp, const void* dw_table, const void* db_table, void* dw, void* db,
                                     int layers, int M, int N, int K, int lddy, int accumulate, dmvae_stream_t stream);
 /* dmvae_linear_weight_t_kmajor for a table of weights in one launch (every Linear weight of a trainable transformer after its optimiser step).  table: device array of
  * n_entries records {const void* src; void* dst; int32 N, K; uint32 start, tiles_x} (dmvae_wt_entry_bytes() bytes each), entry e owning the flat tiles
- * [start_e, start_e + tiles_x * N / 32), tiles_x = ceil(K / 64); total_tiles = their sum. */
+ * [start_e, start_e + tiles_x * N / 32), tiles_x = ceil(K / 64); total_tiles = their sum.  Reference: The bf16 copy torch.autocast makes of every nn.Linear weight (diffusion/lightningdit/lightningdit.py:173-252; timm blocks via models/vae.py:47-53), as the input gradient's operand. */
 size_t dmvae_wt_entry_bytes(void);
 int dmvae_linear_weight_t_kmajor_batched(const void* table, int n_entries, unsigned total_tiles, dmvae_stream_t stream);
 
@@ -557,7 +557,7 @@ int dmvae_linear_wgrad_grouped(const void* table, int n, unsigned total_blocks, 
  * records of dmvae_linear_wgrad_grouped_chunk_bytes() (room for max_chunks; n * 64 is always enough), xoff[0..8] the XCDs' ranges in it, *grid the block count.
  * Copy the chunk records to the device too and launch with dmvae_linear_wgrad_grouped_xcd(table, chunks, xoff (host), grid, ragged, bias_table, n_bias, bias_blocks).
  * The tiles an XCD works on at a time then share their operand panels in that XCD's L2 (the first form spread each problem over all XCDs: 16 GB read where
- * the operands are 4.2 GB at LightningDiT-XL/1, batch 16).  Same tiles, same accumulation order per tile: same bits as dmvae_linear_wgrad_grouped. */
+ * the operands are 4.2 GB at LightningDiT-XL/1, batch 16).  Same tiles, same accumulation order per tile: same bits as dmvae_linear_wgrad_grouped.  Reference: diffusion/lightningdit/lightningdit.py:173-252, swiglu_ffn.py:15-36. */
 size_t dmvae_linear_wgrad_grouped_chunk_bytes(void);
 int dmvae_linear_wgrad_grouped_plan(const void* table, int n, void* chunks_out, int max_chunks, int* n_chunks, unsigned* xoff, unsigned* grid);
 int dmvae_linear_wgrad_grouped_xcd(const void* table, const void* chunks, const unsigned* xoff, unsigned grid, int ragged, const void* bias_table, int n_bias,
@@ -575,7 +575,7 @@ int dmvae_conv_k4c1_dgrad(const void* dy, const void* w, void* dx, int n, int h,
 int dmvae_conv_k4c1_wgrad(const void* x, const void* dy, void* dw, void* db, void* workspace, size_t workspace_bytes, int n, int h, int wdt, int c,
                           dmvae_stream_t stream);
 
-/* ---- losses (HBM-bound reductions) ------------------------------------------------------------- */
+/* ---- losses (HBM-bound reductions) -------------------------------------------------------------  Reference: F.l1_loss / F.mse_loss / LPIPS of train_tokenizer.py:180-186. */
 
 size_t dmvae_loss_workspace(void);
 
@@ -620,16 +620,16 @@ int dmvae_kl_mmd(const void* z, const void* y, void* kl, void* mmd, void* dz, vo
 /* ---- optimiser tail on flat f32 buffers (train_tokenizer.py:140-150,382,415-419) ---------------- */
 
 /* norm_out3 = { ||g||_2, min(1, max_norm/(norm+1e-6)), sum of squares }; accumulate_prev!=0 adds the
- * previous call's sum of squares (norm over several buffers).  workspace >= 8 KiB. */
+ * previous call's sum of squares (norm over several buffers).  workspace >= 8 KiB.  Reference: clip_grad_norm_, train_tokenizer.py:382 (train_dmd.py:545,573). */
 int dmvae_grad_norm(const void* grads, void* norm_out3, void* workspace, size_t workspace_bytes, size_t n,
                     float max_norm, int accumulate_prev, dmvae_stream_t stream);
 /* p,m,v (and ema when non-NULL) updated in place: g*=clip (norm_out3[1], NULL = no clip); decoupled
- * weight decay; bias-corrected Adam (torch.optim.AdamW semantics); ema = ema*decay + p*(1-decay). */
+ * weight decay; bias-corrected Adam (torch.optim.AdamW semantics); ema = ema*decay + p*(1-decay).  Reference: torch.optim.AdamW.step + update_ema, train_tokenizer.py:140-150,415-419. */
 int dmvae_adamw_ema_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, void* ema,
                          const void* norm_out3, size_t n, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int step, float ema_decay, dmvae_stream_t stream);
 /* Same step, also writing bf16_shadow[i] = bf16(params[i]) (round to nearest even): the copy torch.autocast(bfloat16) makes of every Linear weight
- * on every forward (`weight.to(bfloat16)`), produced once per optimiser step in the pass that already holds the new value. */
+ * on every forward (`weight.to(bfloat16)`), produced once per optimiser step in the pass that already holds the new value.  Reference: torch.optim.AdamW.step + update_ema, train_tokenizer.py:140-150,415-419. */
 int dmvae_adamw_ema_step_shadow(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, void* ema, void* bf16_shadow,
                                 const void* norm_out3, size_t n, float lr, float beta1, float beta2, float eps,
                                 float weight_decay, int step, float ema_decay, dmvae_stream_t stream);
@@ -659,7 +659,7 @@ int dmvae_image_to_u8(const void* y, void* out, size_t npix, int c, int c_stride
 
 /* x [rows][cols] f32 -> bf16 parts; part q of element (r, c) is written to
  *   out[(r / rows_per_batch) * batch_stride + q * part_stride + (r % rows_per_batch) * row_stride + c],  q = 0..5
- * pattern 0 (activation side): [hi, mid, lo, hi, mid, hi];  pattern 1 (weight side): [hi, hi, hi, mid, mid, lo]. */
+ * pattern 0 (activation side): [hi, mid, lo, hi, mid, hi];  pattern 1 (weight side): [hi, hi, hi, mid, mid, lo].  Reference: Parity mode only: operands of the f32-emulating products for models/flux_ae.py:21-107,239-269. */
 int dmvae_split3_bf16(const void* x, void* out, size_t rows, int cols, size_t rows_per_batch, size_t batch_stride, size_t part_stride,
                       size_t row_stride, int pattern, dmvae_stream_t stream);
 /* GroupNorm on f32 NHWC (statistics accumulated in f64); act as dmvae_groupnorm_apply.  nn.GroupNorm at flux_ae.py:28,62,64,236. */
@@ -667,23 +667,25 @@ int dmvae_groupnorm_stats_f32(const void* x, void* stats, int n, int hw, int c, 
 int dmvae_groupnorm_apply_f32(const void* x, const void* stats, const void* gamma, const void* beta, void* y, int n, int hw, int c,
                               int groups, int act, dmvae_stream_t stream);
 size_t dmvae_groupnorm_f32_workspace(int n, int c, int groups);
-/* dx = GroupNorm backward of da (+ dres), dgamma / dbeta (NULL to skip); inv_count <= 0 selects 1 / (hw * c / groups). */
+/* dx = GroupNorm backward of da (+ dres), dgamma / dbeta (NULL to skip); inv_count <= 0 selects 1 / (hw * c / groups).  Reference: Parity mode: autograd of Normalize(), models/flux_ae.py:28. */
 int dmvae_groupnorm_bwd_f32(const void* da, const void* x, const void* dres, const void* stats, const void* gamma, const void* beta, void* dx,
                             void* dgamma, void* dbeta, void* workspace, size_t workspace_bytes, int n, int hw, int c, int groups, int act,
                             int accumulate, float inv_count, dmvae_stream_t stream);
 /* Elementwise f32 family.  op 0: out = act(a + b) (b may be NULL; act 0 none, 1 SiLU, 2 ReLU, 4 LeakyReLU(param), 3: out = b > 0 ? a : 0);
  * 1: SiLU(a); 2: b * SiLU'(a); 3: a * (b > 0 ? 1 : param) (ReLU / LeakyReLU backward from the saved output b); 4: GELU(a) (erf form);
- * 5: b * GELU'(a); 6: a + b * g[i % cols] (LayerScale + residual); 7: a * param. */
+ * 5: b * GELU'(a); 6: a + b * g[i % cols] (LayerScale + residual); 7: a * param.  Reference: Parity mode: swish models/flux_ae.py:24, residual adds :75,82, nn.ReLU utils/lpips.py:116-153, LeakyReLU models/patchgan.py:125-147. */
 int dmvae_eltwise_f32(int op, const void* a, const void* b, const void* g, void* out, size_t n, int cols, int act, float param,
                       dmvae_stream_t stream);
 /* Row softmax with f32 probabilities (flux_ae.py:47) and its backward dS = scale * P .* (dP - sum(dP .* P)). */
 int dmvae_softmax_rows_fwd_f32(const void* s, void* p, int rows, int cols, float scale, dmvae_stream_t stream);
 int dmvae_softmax_rows_bwd_f32(const void* dp, const void* p, void* ds, int rows, int cols, float scale, dmvae_stream_t stream);
 /* 2x2 pools on f32 NHWC; n, h, w = POOLED size.  op 0: sum (backward of nearest x2, flux_ae.py:104); 1: max (lpips.py VGG trunk);
- * 2: out [n,2h,2w,c] = ReLU-masked max-pool backward of a (may be NULL) at the argmax of x's window, plus extra (may be NULL). */
+ * 2: out [n,2h,2w,c] = ReLU-masked max-pool backward of a (may be NULL) at the argmax of x's window, plus extra (may be NULL).  Reference: models/flux_ae.py:104;
+ * utils/lpips.py:126-135. */
 int dmvae_pool2x2_f32(int op, const void* a, const void* x, const void* extra, void* out, int n, int h, int w, int c, dmvae_stream_t stream);
+/* Parity mode: the NCHW f32 image / latent as an f32 NHWC operand (channels zero-padded to c_pad), models/vae.py:56-65. */
 int dmvae_nchw_f32_to_nhwc_f32(const void* src, void* dst, int n, int c, int hw, int c_pad, dmvae_stream_t stream);
-/* dmvae_lpips_diff on f32 features; workspace >= 2048 * 8 bytes. */
+/* dmvae_lpips_diff on f32 features; workspace >= 2048 * 8 bytes.  Reference: Parity mode: utils/lpips.py:86-94,107-113,156-162. */
 int dmvae_lpips_diff_f32(const void* f0, const void* f1, const void* lin_w, void* df1, void* out, void* workspace, size_t workspace_bytes, int n,
                          int hw, int c, float gscale, int accumulate, dmvae_stream_t stream);
 /* LayerNorm over the last dimension, f32 in / f32 out (timm ViT block reached through models/vae.py:47-53). */

@@ -316,3 +316,13 @@ def test_transport_times_consume_the_cpu_generator_like_the_reference():
     x0_ref = torch.randn_like(x1)
     t_ref = torch.rand((5,)).to(x1)
     assert torch.equal(t, t_ref) and torch.equal(x0, x0_ref)
+
+
+def test_every_entry_point_is_mapped_to_reference_lines_in_integration_md():
+    """tools/integration_index.py: every declaration of include/dmvae_hip.h occurs in INTEGRATION.md (Appendix A is generated from the header's comments) and only the two
+    plumbing entries (error string, ABI version) are without a reference citation."""
+    import subprocess, sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "integration_index.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 not in INTEGRATION.md, 0 without a citation" in r.stdout, r.stdout
