@@ -83,6 +83,7 @@ SIGNATURES = {
     "dmvae_diffaug_bwd": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "dmvae_im2col_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "dmvae_im2col_nhwc_taps": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "dmvae_im2col_nhwc_sub": (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "dmvae_col2im_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "dmvae_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dmvae_nhwc_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

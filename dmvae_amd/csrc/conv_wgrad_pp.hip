@@ -478,7 +478,10 @@ int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_o
   const int ups = d->upsample ? 1 : 0;
   const int wo = s2 ? d->w / 2 : (ups ? 2 * d->w : d->w);
   const long long M = s2 ? (long long)d->n * (d->h / 2) * (d->w / 2) : (long long)d->n * d->h * d->w * (ups ? 4 : 1);
-  if (d->cin % 128 != 0 || d->cout % 128 != 0 || wo % 32 != 0 || M < 4096) return 0;
+  // Cout = 64 on the 1x1 form (the PatchGAN's first layer on its im2col: functional.ConvK4Fn): rows past Cout are masked, so a quarter-full 256-row tile serves it --
+  // the launch is bound by reading the two operands once, and a zero-padded 128-channel copy of dY (fill + copy + twice the read) cost more than the idle rows
+  const bool c64 = d->ks == 1 && d->cout == 64;
+  if (d->cin % 128 != 0 || (d->cout % 128 != 0 && !c64) || wo % 32 != 0 || M < 4096) return 0;
   if ((long long)M * d->cout * 2 >= (1ll << 31) || (long long)d->n * d->h * d->w * d->cin * 2 + (1ll << 22) >= (1ll << 31)) return 0;
   const int T = d->ks * d->ks;
   const int ngroups = T * (d->cin / 128);
@@ -496,7 +499,8 @@ int dmvae_wgrad_pp_plan(const dmvae_conv_desc* d, int* splits_out, int* kchunk_o
     // exactly once the reduction is long: +3-8 % from 2^19 pixels on, +-0 below (DESIGN_HISTORY.md 8.13).
     constexpr int force = -1;
     const bool halo_ok = d->ks == 3 && d->stride <= 1 && !d->upsample && !d->transposed && d->w % 64 == 0 && wgrad_pp_halo_on();
-    if (halo_ok && (force == 1 || (force < 0 && M >= (1ll << 19)))) { cfg = 1; mtiles = m1; ntiles = n1; }
+    if (c64) { cfg = 0; mtiles = m0; ntiles = n0; }
+    else if (halo_ok && (force == 1 || (force < 0 && M >= (1ll << 19)))) { cfg = 1; mtiles = m1; ntiles = n1; }
     else if (exact0 || (relax && e0 > e1)) { cfg = 0; mtiles = m0; ntiles = n0; }
     else { cfg = 1; mtiles = m1; ntiles = n1; }
   }

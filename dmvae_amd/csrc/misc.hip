@@ -318,7 +318,9 @@ __global__ void relu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restr
 // col[n, oy, ox, (ky*ks + kx)*C + c] = x[n, oy*stride - pad + ky, ox*stride - pad + kx, c] (0 outside): the conv becomes the
 // [M, ks*ks*C] x [Cout, ks*ks*C]^T GEMM of the 1x1 path.  One thread per (output pixel, tap, 8 channels): 16-B loads and stores.
 // Tp >= ks * ks: taps past the last one are columns of zeros (the reduction dimension padded to what the consumer's tile wants).
-__global__ void im2col_kernel(const bf16* __restrict__ x, bf16* __restrict__ col, int N, int H, int W, int C, int Ho, int Wo, int ks,
+// Cs >= C: channel stride of the SOURCE pixels (the first C of Cs channels are taken: the PatchGAN's first layer travels zero-padded to 32 channels, its weight
+// gradient wants an 8-channel im2col -- without a sliced copy of the input in between).
+__global__ void im2col_kernel(const bf16* __restrict__ x, bf16* __restrict__ col, int N, int H, int W, int C, int Cs, int Ho, int Wo, int ks,
                               int stride, int pad, int Tp) {
   const int c8 = C / 8, T = Tp, Treal = ks * ks;
   const size_t total = (size_t)N * Ho * Wo * T * c8;
@@ -333,7 +335,7 @@ __global__ void im2col_kernel(const bf16* __restrict__ x, bf16* __restrict__ col
     bf16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; e++) v[e] = (bf16)0.f;
-    if (t < Treal && iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const bf16x8*>(x + (((size_t)n * H + iy) * W + ix) * C + cc * 8);
+    if (t < Treal && iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const bf16x8*>(x + (((size_t)n * H + iy) * W + ix) * Cs + cc * 8);
     reinterpret_cast<bf16x8*>(col)[i] = v;
   }
 }
@@ -722,12 +724,16 @@ static bool im2col_geom(int h, int w, int ks, int stride, int pad, int* ho, int*
   return h + 2 * pad >= ks && w + 2 * pad >= ks;
 }
 extern "C" int dmvae_im2col_nhwc_taps(const void* x, void* col, int n, int h, int w, int c, int ks, int stride, int pad, int taps_pad, hipStream_t stream) {
+  return dmvae_im2col_nhwc_sub(x, col, n, h, w, c, c, ks, stride, pad, taps_pad, stream);
+}
+extern "C" int dmvae_im2col_nhwc_sub(const void* x, void* col, int n, int h, int w, int c_src, int c, int ks, int stride, int pad, int taps_pad, hipStream_t stream) {
   int ho, wo;
+  DMVAE_CHECK_ARG(c_src >= c && c_src % 8 == 0, "im2col_nhwc_sub: the source's %d channels must be a multiple of 8 and at least the %d taken", c_src, c);
   DMVAE_CHECK_ARG(x && col && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && im2col_geom(h, w, ks, stride, pad, &ho, &wo),
                   "im2col_nhwc: bad argument (c must be a multiple of 8; ks 1..7, stride 1..4, pad < ks)");
   DMVAE_CHECK_ARG(taps_pad >= ks * ks && taps_pad <= 64, "im2col_nhwc: taps_pad %d below ks * ks = %d (or above 64)", taps_pad, ks * ks);
   hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((size_t)n * ho * wo * taps_pad * (c / 8))), dim3(256), 0, stream, (const bf16*)x, (bf16*)col, n, h, w, c,
-                     ho, wo, ks, stride, pad, taps_pad);
+                     c_src, ho, wo, ks, stride, pad, taps_pad);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }

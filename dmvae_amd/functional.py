@@ -450,6 +450,7 @@ class ImageToNhwcFn(torch.autograd.Function):
         return ops.nhwc_to_nchw_f32(_c(dy), ctx.c), None
 
 
+K4_L1_LEAN = os.environ.get("DMVAE_K4_L1_LEAN", "1") != "0"      # first PatchGAN layer's weight gradient without the sliced copy of x / the padded copy of dY (0: with them, for A/B)
 K4_COUT1 = os.environ.get("DMVAE_K4_COUT1", "1") != "0"      # the one-output-channel 4x4 conv (PatchGAN logits) on csrc/conv_c1.hip's vector-unit kernels
 K4_WGRAD_THIN_CIN = True      # the <= 8-input-channel 4x4 conv's weight gradient on the im2col form of an 8-channel copy (ConvK4Fn.backward)
 K4_WGRAD_AS_GEMM = (1,)      # strides of the 4x4 convs whose weight gradient runs on the im2col form (ConvK4Fn.backward); () = never (tests compare the routes)
@@ -529,10 +530,13 @@ class ConvK4Fn(torch.autograd.Function):
             # The PatchGAN's first layer (3 -> 64, stride 2, models/patchgan.py:125): its input travels zero-padded to 32 channels and the small-shape kernel spent
             # 0.95 ms per discriminator pass (B = 64) on a weight gradient with 3 real input channels.  On the im2col form of an EIGHT-channel copy -- 16 taps x 8 =
             # one 128-channel group -- against the output gradient zero-padded to one group it is the large kernel's 1x1 case, bound by reading ~0.5 GB.
-            col = ops.im2col(x[..., :8].contiguous(), 4, stride, 1)
-            dy128 = dy if cpad == 128 else torch.nn.functional.pad(dy, (0, 128 - cpad))
-            g2, dbp = ops.conv2d_nhwc_wgrad(dy128.view(1, 1, m, 128), col.view(1, 1, m, 128), 1, need_bias=b is not None)
-            dwv = g2.view(128, 16, 8)[:cout, :, :cin].permute(0, 2, 1).reshape(cout, cin, 4, 4)
+            # (the 8-channel im2col straight from the 32-channel tensor, and dY as it is when it has 64 channels -- the kernel masks the rows past Cout: the sliced
+            # copy of x, the zero-padded copy of dY and half of dY's read were 0.33 ms per step)
+            col = ops.im2col(x, 4, stride, 1, c_take=8) if K4_L1_LEAN else ops.im2col(x[..., :8].contiguous(), 4, stride, 1)
+            cg = cpad if cpad in ((64, 128) if K4_L1_LEAN else (128,)) else 128
+            dyg = dy if cpad == cg else torch.nn.functional.pad(dy, (0, cg - cpad))
+            g2, dbp = ops.conv2d_nhwc_wgrad(dyg.view(1, 1, m, cg), col.view(1, 1, m, 128), 1, need_bias=b is not None)
+            dwv = g2.view(cg, 16, 8)[:cout, :, :cin].permute(0, 2, 1).reshape(cout, cin, 4, 4)
         else:
             dwp, dbp = ops.conv2d_nhwc_wgrad(dy, x, 4, stride=stride, need_bias=b is not None)       # [cpad, cp, 4, 4]
             dwv = dwp[:cout, :cin]

@@ -830,15 +830,17 @@ def _im2col_out(h, w, ks, stride, pad):
     return (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
 
 
-def im2col(x: torch.Tensor, ks: int, stride: int, pad: int, taps_pad: int = 0) -> torch.Tensor:
+def im2col(x: torch.Tensor, ks: int, stride: int, pad: int, taps_pad: int = 0, c_take: int = 0) -> torch.Tensor:
     """[N,H,W,C] bf16 -> [N,Ho,Wo,ks*ks*C] (tap-major, zero padding): the PatchGAN convs as GEMMs (models/patchgan.py:125-147).  taps_pad > ks*ks: that many
-    taps per pixel, the extra ones columns of zeros (a reduction dimension padded to the consumer's tile: dmvae_im2col_nhwc_taps)."""
+    taps per pixel, the extra ones columns of zeros (a reduction dimension padded to the consumer's tile: dmvae_im2col_nhwc_taps).  c_take: only the first
+    c_take channels of every pixel (dmvae_im2col_nhwc_sub)."""
     x = _req(x, bf16, "x")
-    n, h, w, c = x.shape
+    n, h, w, cs = x.shape
+    c = int(c_take) or cs
     ho, wo = _im2col_out(h, w, ks, stride, pad)
     tp = max(int(taps_pad), ks * ks)
     col = torch.empty(n, ho, wo, tp * c, dtype=bf16, device=x.device)
-    check(_lib.lib().dmvae_im2col_nhwc_taps(x.data_ptr(), col.data_ptr(), n, h, w, c, ks, stride, pad, tp, _stream()), "im2col_nhwc")
+    check(_lib.lib().dmvae_im2col_nhwc_sub(x.data_ptr(), col.data_ptr(), n, h, w, cs, c, ks, stride, pad, tp, _stream()), "im2col_nhwc")
     return col
 
 

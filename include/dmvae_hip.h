@@ -343,6 +343,9 @@ int dmvae_im2col_nhwc(const void* x, void* col, int n, int h, int w, int c, int 
 /* The same with the tap count padded to taps_pad >= ks * ks: col is [n, ho, wo, taps_pad * c], taps past the last one are columns of zeros -- a 3x3 conv over 32
  * channels becomes a 384-column operand (12 x 32), which the 1x1 weight-gradient kernel's 128-column tiles take (the decoder's conv_in, flux_ae.py:196). */
 int dmvae_im2col_nhwc_taps(const void* x, void* col, int n, int h, int w, int c, int ks, int stride, int pad, int taps_pad, dmvae_stream_t stream);
+/* The same from the first c of c_src channels of every source pixel (c_src % 8 == 0, c_src >= c): the 8-channel im2col of the first PatchGAN layer's 32-channel
+ * padded input (models/patchgan.py:125) without a sliced copy in between. */
+int dmvae_im2col_nhwc_sub(const void* x, void* col, int n, int h, int w, int c_src, int c, int ks, int stride, int pad, int taps_pad, dmvae_stream_t stream);
 int dmvae_col2im_nhwc(const void* dcol, void* dx, int n, int h, int w, int c, int ks, int stride, int pad, int in_f32,
                       dmvae_stream_t stream);
 /* dx = y > 0 ? dy : slope*dy  (nn.LeakyReLU(0.2) backward from the saved OUTPUT, patchgan.py:125,136,144). bf16, n%8==0. */
