@@ -450,6 +450,23 @@ class ImageToNhwcFn(torch.autograd.Function):
         return ops.nhwc_to_nchw_f32(_c(dy), ctx.c), None
 
 
+_TAIL_WEIGHT_ONLY = [False]
+
+
+class tail_weight_only:
+    """Context: the decoder tail's backward node (NormConvOutFn) returns only conv_out's weight gradient (see its backward).  DMVAE_TAIL_WEIGHT_ONLY=0 disables it."""
+    ON = os.environ.get("DMVAE_TAIL_WEIGHT_ONLY", "1") != "0"
+
+    def __enter__(self):
+        self.prev = _TAIL_WEIGHT_ONLY[0]
+        _TAIL_WEIGHT_ONLY[0] = self.ON
+        return self
+
+    def __exit__(self, *exc):
+        _TAIL_WEIGHT_ONLY[0] = self.prev
+        return False
+
+
 K4_L1_LEAN = os.environ.get("DMVAE_K4_L1_LEAN", "1") != "0"      # first PatchGAN layer's weight gradient without the sliced copy of x / the padded copy of dY (0: with them, for A/B)
 K4_COUT1 = os.environ.get("DMVAE_K4_COUT1", "1") != "0"      # the one-output-channel 4x4 conv (PatchGAN logits) on csrc/conv_c1.hip's vector-unit kernels
 K4_WGRAD_THIN_CIN = True      # the <= 8-input-channel 4x4 conv's weight gradient on the im2col form of an 8-channel copy (ConvK4Fn.backward)
@@ -626,6 +643,16 @@ class NormConvOutFn(torch.autograd.Function):
         x, st, a, nw, nb, cw = ctx.saved_tensors
         cout = cw.shape[0]
         dyf = _c(dy.float())
+        if _TAIL_WEIGHT_ONLY[0] and not parity.on() and ops.conv_out_wgrad_supported(a.shape[0], a.shape[1], a.shape[2], a.shape[3], cout):
+            # losses.generator_gan_backward asks this node for the LAST LAYER's weight gradient alone, twice per step (the adaptive weight's two norms,
+            # train_tokenizer.py:190-203): autograd cannot tell a Function which of its gradients are wanted (needs_input_grad is fixed at forward), so the caller
+            # says so -- the input gradient through conv_out + norm_out (two passes over the 537 MB map) and the bias sum were computed and dropped
+            dwp = ops.conv_out_wgrad(dyf, a)
+            dcw = _dst(cw)
+            if dcw is not None:
+                dcw.copy_(dwp[:cout])
+                return None, None, None, dcw, None
+            return None, None, None, dwp[:cout].contiguous(), None
         fused = NORM_CONV_OUT_FUSED_BWD and not parity.on() and ops.norm_conv_out_bwd_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout)
         # the stored-operand route's gradient operand: the input-gradient conv's reduction dimension in 32-channel K steps
         dyp = None if fused else ops.nchw_to_nhwc_bf16(dyf, c_pad=32)

@@ -136,8 +136,10 @@ def generator_gan_backward(rec_loss: torch.Tensor, recon: torch.Tensor, disc: to
     g_rec = torch.autograd.grad(rec_loss, recon, retain_graph=True)[0]
     g_gan = torch.autograd.grad(g_loss, recon)[0]
     # with direct flat-buffer gradients each call leaves its result in `last_layer`'s gradient slot: reduced to its norm before the next call overwrites it
-    n_rec = torch.autograd.grad(recon, last_layer, grad_outputs=g_rec, retain_graph=True)[0].detach().norm()
-    n_gan = torch.autograd.grad(recon, last_layer, grad_outputs=g_gan, retain_graph=True)[0].detach().norm()
+    from . import functional as _Fn
+    with _Fn.tail_weight_only():      # recon's node computes the last layer's weight gradient and nothing else for these two calls
+        n_rec = torch.autograd.grad(recon, last_layer, grad_outputs=g_rec, retain_graph=True)[0].detach().norm()
+        n_gan = torch.autograd.grad(recon, last_layer, grad_outputs=g_gan, retain_graph=True)[0].detach().norm()
     d_weight = (n_rec / (n_gan + 1e-6)).clamp_(0.0, 1e4) * disc_weight
     total = g_rec + g_gan * d_weight
     if extra is not None:

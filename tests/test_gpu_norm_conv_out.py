@@ -126,6 +126,29 @@ def test_norm_conv_out_fn_backward_with_and_without_the_fused_route(monkeypatch)
     assert torch.equal(g1[3], g0[3]) and torch.equal(g1[4], g0[4])
 
 
+def test_tail_node_asked_for_the_last_layers_weight_gradient_alone(monkeypatch):
+    """functional.tail_weight_only (losses.generator_gan_backward's two adaptive-weight norms, train_tokenizer.py:190-203): inside the context NormConvOutFn's
+    backward returns conv_out's weight gradient -- the bits of the full backward's -- and launches neither the input-gradient / norm backward nor the bias sum."""
+    from dmvae_amd import functional as Fn, ops
+    n, h, w = 2, 32, 64
+    x, gamma, beta, cw, dy = _case(n, h, w, seed=5)
+    if not ops.conv_out_wgrad_supported(n, h, w, x.shape[-1], 3):
+        pytest.skip("shape not on the thin weight-gradient kernel")
+    cb = torch.randn(3, device=DEV) * 0.1
+    leaves = [t.clone().requires_grad_(True) for t in (x.float(), gamma, beta, cw, cb)]
+    y = Fn.NormConvOutFn.apply(leaves[0].to(BF), *leaves[1:])
+    full = torch.autograd.grad(y, leaves[3], grad_outputs=dy, retain_graph=True)[0].clone()
+
+    def boom(*a, **k):
+        raise AssertionError("the input gradient was computed for a weight-gradient-only request")
+    monkeypatch.setattr(ops, "norm_conv_out_bwd", boom)
+    monkeypatch.setattr(ops, "groupnorm_bwd", boom)
+    with Fn.tail_weight_only():
+        only = torch.autograd.grad(y, leaves[3], grad_outputs=dy, retain_graph=True)[0]
+    assert torch.equal(only, full)
+    assert not Fn._TAIL_WEIGHT_ONLY[0]
+
+
 @pytest.mark.parametrize("n,h,w", [(2, 32, 64), (3, 8, 32), (1, 64, 32)])
 def test_fused_tail_forward_gives_the_bits_of_the_five_launch_route(n, h, w, monkeypatch):
     """csrc/conv_thin.hip, NORM instantiation: GroupNorm + swish on the way into the conv's halo tile, the NCHW image out of its epilogue -- the saved activation
