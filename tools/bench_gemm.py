@@ -34,6 +34,7 @@ SHAPES = [("vit qkv", 8224, 3072, 1024), ("vit proj", 8224, 1024, 1024), ("vit f
           ("dit32 qkv", 8192, 3456, 1152), ("dit32 w12", 8192, 6144, 1152),
           # round 5: the DMD stage's batch-16 problems incl. the input-gradient shapes (N = in features, K = out features) and the ViT-L encoder at 16 x 257 tokens
           ("dit16 d_qkv", 4096, 1152, 3456), ("dit16 d_w12", 4096, 1152, 6144), ("dit16 d_w3", 4096, 3072, 1152),
+          ("dit64 d_qkv", 16384, 1152, 3456), ("dit64 d_w12", 16384, 1152, 6144), ("dit64 d_w3", 16384, 3072, 1152),
           ("vit16 qkv", 4112, 3072, 1024), ("vit16 proj", 4112, 1024, 1024), ("vit16 fc1", 4112, 4096, 1024), ("vit16 fc2", 4112, 1024, 4096)]
 if args.shapes:
     SHAPES = [s for s in SHAPES if any(t in s[0] for t in args.shapes.split(","))]
