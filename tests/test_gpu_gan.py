@@ -435,3 +435,25 @@ def test_k4_logits_layer_on_the_vector_unit_kernels(n, h, c, monkeypatch):
     xb = x0.clone().requires_grad_(True)
     Fn.ConvK4Fn.apply(xb, w.detach(), b.detach(), 1, ops.ACT_NONE, True).backward(dy)
     assert torch.equal(xb.grad, new[1])
+
+
+@pytest.mark.gpu
+def test_k4_logits_layer_kernels_are_adjoint_at_full_size():
+    """Size-independent property at the training shape (B = 64, 31 x 31 x 512): the three kernels of csrc/conv_c1.hip compute one bilinear form,
+    <conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(x, dy)>, up to the bf16 rounding of dgrad's result and f32 summation."""
+    from dmvae_amd import ops
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(64, 31, 31, 512, generator=g).cuda().to(BF)
+    w = (torch.randn(1, 512, 4, 4, generator=g) * 0.02).cuda()
+    dy = torch.randn(64, 30, 30, 1, generator=g).cuda()
+    y = ops.conv_k4c1_fwd(x, w, None)
+    dx = ops.conv_k4c1_dgrad(dy, w, 31)
+    dw, db = ops.conv_k4c1_wgrad(x, dy)
+    wb = w.to(BF).double()                                   # the kernels multiply by the bf16-rounded weight
+    a = (y.double() * dy.double()).sum().item()
+    b = (x.double() * dx.double()).sum().item()
+    c = (wb * dw.double()).sum().item()
+    scale = (y.double().abs() * dy.double().abs()).sum().item()
+    assert abs(a - c) < 1e-5 * scale, (a, c)
+    assert abs(a - b) < 3e-4 * scale, (a, b)                  # dx is rounded to bf16 element by element
+    assert abs(db.item() - dy.double().sum().item()) < 1e-5 * dy.double().abs().sum().item()
