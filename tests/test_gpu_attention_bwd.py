@@ -99,3 +99,28 @@ def test_attention_bwd_heads_layout(b, n, h, d):
             assert gf[..., d:].abs().max() == 0, name + ": padded channels"
     again = ops.attention_bwd_heads(qg, kg, vg, o, dog, b, scale, lse=lse)
     assert all(torch.equal(x, y) for x, y in zip((dq2, dk2, dv2), again))
+
+
+@pytest.mark.parametrize("n,d", [(256, 72), (200, 72), (256, 64)])
+def test_attention_kernels_give_the_same_bits_in_every_launch_form(n, d):
+    """The launch forms chosen by the NUMBER of (sample, head) blocks -- the three-image backward at <= 512 blocks, the two-image one above; the XCD-aware block order
+    at any grid -- compute the same sums in the same order: samples 0..7 of a 40-sample call (640 blocks) must equal the 8-sample call (128 blocks) bit for bit,
+    forward output, row statistics and all three gradients.  LightningDiT-XL/1's head geometry (16 x 72, padded to 96) and a 64-wide one."""
+    from dmvae_amd import ops
+    h, dp = 16, (d + 31) // 32 * 32
+    g = torch.Generator().manual_seed(n + d)
+    big, small = 40, 8
+    q = torch.zeros(big * h, n, dp); k = torch.zeros(big * h, n, dp)
+    q[..., :d] = torch.randn(big * h, n, d, generator=g); k[..., :d] = torch.randn(big * h, n, d, generator=g)
+    v = torch.randn(big * h, n, d, generator=g)
+    q, k, v = (t.to(DEV).to(BF) for t in (q, k, v))
+    do = torch.randn(big, n, h * d, generator=g).to(DEV).to(BF)
+    scale = d ** -0.5
+    outs = []
+    for b in (big, small):
+        qq, kk, vv, dd = q[:b * h].contiguous(), k[:b * h].contiguous(), v[:b * h].contiguous(), do[:b].contiguous()
+        o, lse = ops.attention_heads(qq, kk, vv, b, scale, need_lse=True)
+        dq, dk, dv = ops.attention_bwd_heads(qq, kk, vv, o, dd, b, scale, lse=lse)
+        outs.append((o, lse, dq, dk, dv))
+    for a, c, rows in zip(outs[0], outs[1], (small, small * h, small * h, small * h, small * h)):
+        assert torch.equal(a[:rows], c), "launch form changed the bits"
