@@ -326,3 +326,11 @@ def test_every_entry_point_is_mapped_to_reference_lines_in_integration_md():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "integration_index.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert " 0 not in INTEGRATION.md, 0 without a citation" in r.stdout, r.stdout
+
+
+def test_every_profiles_file_is_cited_once_in_design_md():
+    """tools/design_profiles_index.py: every file under profiles/ occurs exactly once in DESIGN.md (Appendix P) and every [P:key] of the text names a file."""
+    import subprocess, sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_profiles_index.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
