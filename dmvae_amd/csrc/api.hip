@@ -14,4 +14,4 @@ void dmvae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dmvae_last_error(void) { return g_err; }
-extern "C" int dmvae_abi_version(void) { return 7; }   // 7: the XCD-placed grouped weight-gradient launch (dmvae_linear_wgrad_grouped_plan / _xcd); 6: the whole-stack DiT backward + batched per-sample Linears + batched weight transposes; 5: the shortcut-in-GroupNorm entry points (dmvae_groupnorm_*_short); 2: dmvae_conv_desc gained w_layout; 3: dmvae_pack_entry + the batched pack / Linear GEMM entry points; 4: the decoder-tail entry points (dmvae_norm_conv_out_*)
+extern "C" int dmvae_abi_version(void) { return 8; }   // 8: dmvae_reparam_kl_* (the reparameterise hook + posterior-form KL); 7: the XCD-placed grouped weight-gradient launch (dmvae_linear_wgrad_grouped_plan / _xcd); 6: the whole-stack DiT backward + batched per-sample Linears + batched weight transposes; 5: the shortcut-in-GroupNorm entry points (dmvae_groupnorm_*_short); 2: dmvae_conv_desc gained w_layout; 3: dmvae_pack_entry + the batched pack / Linear GEMM entry points; 4: the decoder-tail entry points (dmvae_norm_conv_out_*)

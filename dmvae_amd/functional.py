@@ -13,6 +13,8 @@ from __future__ import annotations
 from typing import Optional
 import os
 
+import weakref
+
 import torch
 
 from . import ops, parity
@@ -723,6 +725,29 @@ class MLPFn(torch.autograd.Function):
         return dx, dw0.view(w0.shape), db0, dw2.view(w2.shape), db2
 
 
+class ReparamKLFn(torch.autograd.Function):
+    """Reparameterised sample and posterior-form KL of a (mu | logvar) bottleneck head, one HIP pass each way (csrc/reparam.hip).  BUILD-DEFINED: the reference's
+    VAE.forward has no such step (models/vae.py:90-98); models/vae.py VAE(reparameterize=True) is the caller.  moments [rows, 2C], eps [rows, C] f32 or None
+    (posterior mode) -> (z [rows, C], kl scalar = mean over latents of mean over rows, per-latent kl [C+1] detached)."""
+
+    @staticmethod
+    def forward(ctx, moments, eps):
+        moments = _c(moments)
+        z, kl = ops.reparam_kl_fwd(moments, eps)
+        ctx.save_for_backward(moments, eps)
+        ctx.mark_non_differentiable(kl)
+        return z, kl[-1].clone(), kl
+
+    @staticmethod
+    def backward(ctx, dz, g_kl, _):
+        moments, eps = ctx.saved_tensors
+        dz = None if dz is None else _c(dz.to(moments.dtype))
+        g = None if g_kl is None else g_kl.detach().float().reshape(1).contiguous()
+        if dz is None and g is None:
+            return torch.zeros_like(moments), None
+        return ops.reparam_kl_bwd(moments, eps, dz, g, 1.0 if g is not None else 0.0), None
+
+
 # ---- trainable ViT encoder block (timm VisionTransformer block reached through models/vae.py:47-53; stages with a trainable encoder:
 # train_dmd.py:349,519) ------------------------------------------------------------------------------------------------------------
 def _bf(w: torch.Tensor) -> torch.Tensor:
@@ -1129,13 +1154,48 @@ _OWNED_GRADS = {}
 
 
 def _own(t: torch.Tensor) -> torch.Tensor:
+    if not _OWNED_GRADS:      # first hand-over of this backward pass: drop whatever is left when the pass ends (the last segment's d h_in is taken by nobody)
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_OWNED_GRADS.clear)
+        except RuntimeError:  # not inside a backward pass (a test calling backward() of a Function by hand)
+            pass
     _OWNED_GRADS[t.data_ptr()] = t
     return t
 
 
-def _take_owned(t: torch.Tensor) -> bool:
+def _observed(out_ref) -> bool:
+    """Whether somebody besides the consuming node can see the gradient of the tensor `out_ref` (a weakref to a Function's output) points at: a tensor hook or
+    retain_grad() on it hands the SAME gradient tensor to user code, which an in-place update would then overwrite with d(input)."""
+    out = out_ref() if out_ref is not None else None
+    if out is None:
+        return False
+    return bool(getattr(out, "retains_grad", False)) or bool(getattr(out, "_backward_hooks", None)) or bool(getattr(out, "_post_accumulate_grad_hooks", None))
+
+
+def _take_owned(t: torch.Tensor, out_ref=None) -> bool:
+    """True when `t` is a gradient buffer THIS build produced for the node that now receives it (`_own`) and nobody else can observe it: the caller may then update
+    it in place instead of cloning (B x N x C x 4 bytes per segment).  Autograd's rule is that backward must not modify its incoming gradients; the cases where that
+    is observable -- hooks / retain_grad on the producing Function's output -- are excluded through `out_ref`, and `torch.autograd.grad(..., inputs=[h])` on the
+    stack's output is not part of any route of this package (lightningdit_fast.forward_train feeds it to the next segment or the final layer only)."""
     o = _OWNED_GRADS.pop(t.data_ptr(), None)
-    return o is not None and o.shape == t.shape and t.dtype == f32 and o.dtype == f32 and t.is_contiguous() and o.untyped_storage().data_ptr() == t.untyped_storage().data_ptr()
+    if o is None or _observed(out_ref):
+        return False
+    return o.shape == t.shape and t.dtype == f32 and o.dtype == f32 and t.is_contiguous() and o.untyped_storage().data_ptr() == t.untyped_storage().data_ptr()
+
+
+def _with_splitk(fn):
+    """Run `fn` with DitStackFn's split-K choice active and ALWAYS switch it off again -- an exception inside (out of memory, a failed check()) must not leave the
+    process-wide flag set: functional.linear on the inference route would then change accumulation order with M and break '2B call == two B calls' bit for bit."""
+    import functools
+
+    @functools.wraps(fn)
+    def scoped(*a, **kw):
+        _SPLITK_ACTIVE[0] = SPLITK
+        try:
+            return fn(*a, **kw)
+        finally:
+            _SPLITK_ACTIVE[0] = 0
+    return scoped
 
 
 DIT_STACK_PARAMS_PER_BLOCK = 14
@@ -1159,6 +1219,7 @@ class DitStackFn(torch.autograd.Function):
     w3.weight, w3.bias, adaLN_modulation[1].weight, adaLN_modulation[1].bias."""
 
     @staticmethod
+    @_with_splitk
     def forward(ctx, h, sc, cos, sin, heads, eps, *params):
         P = DIT_STACK_PARAMS_PER_BLOCK
         nl = len(params) // P
@@ -1166,7 +1227,6 @@ class DitStackFn(torch.autograd.Function):
         d = c // heads
         h = _c(h)
         scb = _c(sc).to(bf16)
-        _SPLITK_ACTIVE[0] = SPLITK
         blocks = [params[i * P:(i + 1) * P] for i in range(nl)]
         mod_all = ops.linear_rows_batched(scb, [_bf(bp[12]) for bp in blocks], [_bf(bp[13]) for bp in blocks])          # [L, B, 6C] bf16
         saved, lses = [], []
@@ -1191,13 +1251,14 @@ class DitStackFn(torch.autograd.Function):
             o3 = linear(g, w3w, w3b)
             saved += [h_in, a1, qkv, q, k, v, o, o2, h_mid, a2, x12, g, o3]
         h_out, _ = ops.gated_residual_out(h_mid, o3, mod_all[nl - 1], 5 * c)
-        _SPLITK_ACTIVE[0] = 0
         ctx.save_for_backward(scb, mod_all, cos, sin, *saved, *params)
         ctx.cfg = (nl, heads, eps, sc.dtype)
         ctx.lses = lses
+        ctx.out_ref = weakref.ref(h_out)
         return h_out
 
     @staticmethod
+    @_with_splitk
     def backward(ctx, dh_out):
         P = DIT_STACK_PARAMS_PER_BLOCK
         nl, heads, eps, sc_dtype = ctx.cfg
@@ -1206,13 +1267,12 @@ class DitStackFn(torch.autograd.Function):
         params = ctx.saved_tensors[4 + 13 * nl:]
         b, n, c = acts[0].shape
         d, rows = c // heads, b * n
-        dt = dh_out if _take_owned(dh_out) else _c(dh_out).float().clone()      # becomes d(h_mid), d(h) of every block in turn
+        dt = dh_out if _take_owned(dh_out, ctx.out_ref) else _c(dh_out).float().clone()      # becomes d(h_mid), d(h) of every block in turn
         S = ops.DitStackBwd(nl, b, n, c, heads, dt.device)
         grads = [None] * (P * nl)
         fresh = lambda p: _dst(p) if _dst(p) is not None else torch.empty(p.shape, dtype=f32, device=dt.device)
         norm_dws, qn_dws, kn_dws = [None] * (2 * nl), [None] * nl, [None] * nl
         pend = []      # (dy, x, dW, db) of every block Linear: ONE grouped weight-gradient launch when the chain is done -- 4 x depth problems, each unsplit, fill the chip
-        _SPLITK_ACTIVE[0] = SPLITK
         do3 = S.boundary(2 * nl, dt, y=acts[13 * (nl - 1) + 12], gate_mod=mod_all[nl - 1], gate_off=5 * c)
         for i in range(nl - 1, -1, -1):
             h_in, a1, qkv, q, k, v, o, o2, h_mid, a2, x12, g, o3 = acts[13 * i:13 * i + 13]
@@ -1234,7 +1294,6 @@ class DitStackFn(torch.autograd.Function):
                 S.boundary(0, dt, da=da1.view(b, n, c), x=h_in, w=n1w, mod=mod, scale_off=c, eps=eps)
             norm_dws[2 * i], norm_dws[2 * i + 1], qn_dws[i], kn_dws[i] = fresh(n1w), fresh(n2w), fresh(qnw), fresh(knw)
             G[P * i + 0], G[P * i + 7], G[P * i + 3], G[P * i + 4] = norm_dws[2 * i], norm_dws[2 * i + 1], qn_dws[i], kn_dws[i]
-        _SPLITK_ACTIVE[0] = 0
         if pend:
             ops.linear_wgrad_grouped(pend)
         dmod = torch.empty_like(mod_all)

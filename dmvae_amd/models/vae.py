@@ -8,6 +8,11 @@ arguments, ``forward(x, freeze_encoder=False, return_latent=False)``, ``encode``
 ``vae.pt`` loads with strict=True.  What differs is everything underneath: the bottleneck runs as one autograd Function over
 two MFMA GEMMs (functional.MLPFn), the decoder is NHWC bf16 end to end (models/flux_ae.py), and ``decode_uint8`` goes
 straight from the output conv to bytes.
+
+Beyond the reference (BUILD-DEFINED, off by default): ``VAE(..., reparameterize=True)`` gives the bottleneck a (mu | logvar) head and samples
+z = mu + exp(logvar / 2) * eps between encoder and decoder, with the posterior-form KL 0.5 * (mu^2 + exp(logvar) - 1 - logvar) per latent (SURVEY.md 0 and
+8a row a15; BASELINE.json's "encoder -> reparameterise -> decoder").  The reference's forward is deterministic (vae.py:90-98); with the keyword at its
+default nothing of this is constructed or run and forward() is the reference's, bit for bit.
 """
 import os
 
@@ -102,14 +107,20 @@ def _read_checkpoint(path):
 
 class VAE(nn.Module):
     def __init__(self, z_channels: int = 16, image_size: int = 256, model_size: str = "base", patch_size: int = 16,
-                 conv_std_or_gain: float = 0.02, encoder_kwargs=None):
+                 conv_std_or_gain: float = 0.02, encoder_kwargs=None, reparameterize: bool = False):
         super().__init__()
+        # build-defined hook, NOT in the reference (module docstring): False = the reference's deterministic forward, same modules, same generator consumption
+        self.reparameterize = bool(reparameterize)
+        self.z_channels = z_channels
+        self.posterior_kl = None               # scalar (differentiable) and per-latent [z + 1] KL of the last training-mode forward with the hook on
+        self.posterior_kl_per_latent = None
+        self.reparam_generator = None          # optional torch.Generator (device) for eps
         # construction order = the reference's (encoder, decoder, post_init, bottleneck, three init_weights calls): under a fixed seed the random
         # initialisation then consumes the generator identically.  As there, `image_size` does not reach the encoder.
         self.encoder = DINOEncoder(model_size, patch_size=patch_size, **(encoder_kwargs or {}))
         self.decoder = Decoder(**_DECODER_CFG)
         self.decoder.post_init(z_channels=z_channels)
-        self.bottle_neck = MLP(in_dim=self.encoder.dim, out_dim=z_channels)
+        self.bottle_neck = MLP(in_dim=self.encoder.dim, out_dim=2 * z_channels if self.reparameterize else z_channels)
         for part in (self.decoder.conv_in, self.bottle_neck, self.decoder):
             init_weights(part, conv_std_or_gain)
 
@@ -118,7 +129,24 @@ class VAE(nn.Module):
         """Latent tokens [B, 256, z]; with `freeze_encoder` the ViT runs without a graph (train_tokenizer.py keeps it frozen)."""
         with torch.set_grad_enabled(torch.is_grad_enabled() and not freeze_encoder):
             feats = self.encoder(x)
-        return self.bottle_neck(feats)
+        return self.latent(feats)
+
+    def latent(self, feats, eps=None):
+        """Encoder tokens [B, T, width] -> latent tokens [B, T, z].  Hook off (default): the bottleneck's output, as in the reference (vae.py:94).  Hook on:
+        the bottleneck emits (mu | logvar); in training mode z = mu + exp(logvar / 2) * eps (eps drawn here unless given) and `posterior_kl` /
+        `posterior_kl_per_latent` hold the KL of this call; in eval mode z = mu (the posterior mode) and eps is not drawn."""
+        out = self.bottle_neck(feats)
+        if not self.reparameterize:
+            return out
+        lead, zc = out.shape[:-1], self.z_channels
+        moments = out.reshape(-1, 2 * zc)
+        if self.training and eps is None:
+            eps = torch.randn(moments.shape[0], zc, device=moments.device, dtype=torch.float32, generator=self.reparam_generator)
+        elif eps is not None:
+            eps = eps.reshape(-1, zc).float().contiguous()
+        z, kl, per_latent = Fn.ReparamKLFn.apply(moments, eps)
+        self.posterior_kl, self.posterior_kl_per_latent = kl, per_latent
+        return z.reshape(*lead, zc)
 
     def forward(self, x, freeze_encoder=False, return_latent=False):
         latent_tokens = self.tokens(x, freeze_encoder)

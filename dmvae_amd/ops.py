@@ -1270,7 +1270,49 @@ def qknorm_rope_bwd(dq, dk, dv, qkv, qw, kw, cos, sin, heads: int, eps: float = 
 
 
 # ---- whole-stack LightningDiT backward + batched per-sample Linears (csrc/dit_stack.hip, linear_rows.hip) ---------------------------
-_PTR_TABLES = {}
+class _TableCache(dict):
+    """key -> device table(s) that LAUNCHED KERNELS READ (pointer tables of the batched / grouped entry points).  Dropping an entry frees device memory a kernel in
+    flight -- or a captured hipGraph, which has the table's address baked in (sample.GraphedInference with batched adaLN) -- may still read, so eviction is
+    restricted:
+      * an entry is PINNED, never evicted, once it is looked up a second time (tables over parameter / flat-buffer / cached-operand pointers recur every step;
+        the ones an unsettled allocator produces from activation pointers are used once) or when it was built or used during stream capture;
+      * when more than LIMIT unpinned entries have piled up, they leave the dict but their tensors move to `grave`, which is only released at the NEXT eviction
+        -- thousands of table builds later, each of them a blocking host-to-device copy behind every kernel that could have read the old table.
+    `clear()` (tests) keeps dict semantics."""
+    LIMIT = 4096
+
+    def __init__(self):
+        super().__init__()
+        self.pinned = set()
+        self.grave = []
+
+    def lookup(self, key):
+        hit = self.get(key)
+        if hit is not None and key not in self.pinned:
+            self.pinned.add(key)
+        return hit
+
+    def store(self, key, value):
+        if len(self) - len(self.pinned) > self.LIMIT:
+            victims = [k for k in self if k not in self.pinned]
+            self.grave = [self.pop(k) for k in victims]          # the previous generation is released here; this one stays allocated until the next eviction
+        self[key] = value
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            self.pinned.add(key)
+
+    def discard(self, key):
+        v = self.pop(key, None)
+        self.pinned.discard(key)
+        if v is not None:
+            self.grave.append(v)
+
+    def clear(self):
+        super().clear()
+        self.pinned.clear()
+        self.grave = []
+
+
+_PTR_TABLES = _TableCache()
 TABLE_BUILDS = [0]      # device tables built so far (each build is a small synchronous host-to-device copy): stays flat once the allocator's address pattern has settled
 
 
@@ -1279,13 +1321,11 @@ def ptr_table(tensors) -> torch.Tensor:
     The pointers of a model's parameters, of an optimiser's flat-buffer views and of cached operands are stable across steps, so a table is uploaded once."""
     key = tuple(0 if t is None else t.data_ptr() for t in tensors)
     dev = next(t for t in tensors if t is not None).device
-    hit = _PTR_TABLES.get((key, dev))
+    hit = _PTR_TABLES.lookup((key, dev))
     if hit is None:
-        if len(_PTR_TABLES) > 4096:
-            _PTR_TABLES.clear()
         hit = torch.tensor(key, dtype=torch.int64).to(dev)
         TABLE_BUILDS[0] += 1
-        _PTR_TABLES[(key, dev)] = hit
+        _PTR_TABLES.store((key, dev), hit)
     return hit
 
 
@@ -1346,7 +1386,7 @@ def linear_weight_t_kmajor_batched(pairs) -> None:
     """`linear_weight_t_kmajor` for a list of (src bf16 [N, K], dst bf16 [N / 32, K, 32]) in ONE launch; the table lives on the device, cached per pointer set."""
     key = ("wt",) + tuple((s_.data_ptr(), d_.data_ptr(), s_.shape[0], s_.shape[1]) for s_, d_ in pairs)
     dev = pairs[0][0].device
-    hit = _PTR_TABLES.get((key, dev))
+    hit = _PTR_TABLES.lookup((key, dev))
     if hit is None:
         import ctypes
         assert _lib.lib().dmvae_wt_entry_bytes() == ctypes.sizeof(_lib.WtEntry)
@@ -1361,7 +1401,7 @@ def linear_weight_t_kmajor_batched(pairs) -> None:
         tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         TABLE_BUILDS[0] += 1
         hit = (tab, len(pairs), start)
-        _PTR_TABLES[(key, dev)] = hit
+        _PTR_TABLES.store((key, dev), hit)
     tab, cnt, total = hit
     check(_lib.lib().dmvae_linear_weight_t_kmajor_batched(tab.data_ptr(), cnt, total, _stream()), "linear_weight_t_kmajor_batched")
 
@@ -1381,10 +1421,8 @@ def linear_wgrad_grouped(problems) -> None:
     L = _lib.lib()
     dev = problems[0][0].device
     key = ("wg",) + tuple((dy.data_ptr(), x.data_ptr(), dw.data_ptr(), 0 if db is None else db.data_ptr(), dy.shape[0], dy.shape[1], x.shape[1]) for dy, x, dw, db in problems)
-    hit = _PTR_TABLES.get((key, dev))
+    hit = _PTR_TABLES.lookup((key, dev))
     if hit is None:
-        if len(_PTR_TABLES) > 4096:
-            _PTR_TABLES.clear()
         eb, bb = L.dmvae_linear_wgrad_grouped_entry_bytes(), L.dmvae_linear_wgrad_grouped_bias_entry_bytes()
         n = len(problems)
         tab = ctypes.create_string_buffer(eb * n)
@@ -1421,10 +1459,10 @@ def linear_wgrad_grouped(problems) -> None:
             check(L.dmvae_linear_wgrad_grouped_plan(ctypes.addressof(tab), n, ctypes.addressof(chunks), n * 64, ctypes.byref(nch), xoff, ctypes.byref(grid)), "linear_wgrad_grouped_plan")
             plan = (torch.frombuffer(bytearray(chunks.raw[:nch.value * cb]), dtype=torch.uint8).to(dev), xoff, grid.value)
         hit = (dtab, n, start.value, ragged, dbtab, nb, bstart.value, part.data_ptr(), plan)
-        _PTR_TABLES[(key, dev)] = hit
+        _PTR_TABLES.store((key, dev), hit)
     dtab, n, total, ragged, dbtab, nb, btotal, part_ptr, plan = hit
     if nb and workspace(1, dev, "wgrad_grouped_bias").data_ptr() != part_ptr:      # the workspace slot grew since this table was built: its bias-partial pointers are stale
-        del _PTR_TABLES[(key, dev)]
+        _PTR_TABLES.discard((key, dev))
         return linear_wgrad_grouped(problems)
     if plan is not None:
         check(L.dmvae_linear_wgrad_grouped_xcd(dtab.data_ptr(), plan[0].data_ptr(), plan[1], plan[2], ragged, dbtab.data_ptr() if nb else None, nb, btotal, _stream()),
@@ -1591,6 +1629,41 @@ def kl_mmd(z: torch.Tensor, y: Optional[torch.Tensor], w_kl: float = 1.0, w_mmd:
     check(L.dmvae_kl_mmd(z.data_ptr(), _ptr(y), kl.data_ptr(), _ptr(mmd), _ptr(dz), ws.data_ptr(), ws.numel(), g, n, m, d,
                          float(w_kl), float(w_mmd), _stream()), "kl_mmd")
     return kl, mmd, dz
+
+
+def reparam_kl_fwd(moments: torch.Tensor, eps: Optional[torch.Tensor], need_z: bool = True):
+    """moments [rows, 2C] (mu | logvar; f32 or bf16), eps [rows, C] f32 or None (posterior mode) -> (z [rows, C] or None, kl [C+1] f32: per-latent + mean).
+    Build-defined (models/vae.py VAE(reparameterize=True)); the reference's forward is deterministic (models/vae.py:90-98)."""
+    if moments.dtype not in (f32, bf16):
+        raise TypeError(f"moments: expected float32 or bfloat16, got {moments.dtype}")
+    moments = _req(moments, moments.dtype, "moments")
+    rows, c2 = moments.shape
+    c = c2 // 2
+    if eps is not None:
+        eps = _req(eps, f32, "eps")
+        assert eps.shape == (rows, c), f"eps: expected {(rows, c)}, got {tuple(eps.shape)}"
+    L = _lib.lib()
+    ws = workspace(max(L.dmvae_reparam_kl_workspace(rows, c), 16), moments.device, slot="reparam")
+    z = torch.empty(rows, c, dtype=moments.dtype, device=moments.device) if need_z else None
+    kl = torch.empty(c + 1, dtype=f32, device=moments.device)
+    check(L.dmvae_reparam_kl_fwd(moments.data_ptr(), _ptr(eps), _ptr(z), kl.data_ptr(), ws.data_ptr(), ws.numel(), rows, c, int(moments.dtype == bf16),
+                                 _stream()), "reparam_kl_fwd")
+    return z, kl
+
+
+def reparam_kl_bwd(moments: torch.Tensor, eps: Optional[torch.Tensor], dz: Optional[torch.Tensor], g_kl: Optional[torch.Tensor], w_kl: float = 1.0):
+    """-> d moments [rows, 2C]; dz [rows, C] (dtype of moments) or None, g_kl a one-element f32 device tensor (gradient of kl[C]) or None (= 1)."""
+    moments = _req(moments, moments.dtype, "moments")
+    rows, c2 = moments.shape
+    c = c2 // 2
+    if dz is not None:
+        dz = _req(dz, moments.dtype, "dz")
+    if g_kl is not None:
+        g_kl = _req(g_kl, f32, "g_kl")
+    out = torch.empty_like(moments)
+    check(_lib.lib().dmvae_reparam_kl_bwd(moments.data_ptr(), _ptr(eps), _ptr(dz), _ptr(g_kl), float(w_kl), out.data_ptr(), rows, c,
+                                          int(moments.dtype == bf16), _stream()), "reparam_kl_bwd")
+    return out
 
 
 # ---- optimiser tail -----------------------------------------------------------------------------

@@ -175,23 +175,37 @@ class FlatAdamWEMA:
         self.exp_avg_sq = torch.zeros_like(fp.flat)
         self.norm = torch.zeros(3, dtype=torch.float32, device=fp.flat.device)   # [norm, clip coef, sumsq] stays on device
         self.t = 0
-        self.side, self._done = None, None
+        self.side, self._done, self._then = None, None, None
         fp._opt = self
+
+    _SIDE = {}      # device index -> THE side stream of this process: every overlapped optimiser shares it
 
     def enable_overlap(self) -> None:
         """Run `step` on a side HIP stream: the HBM-bound update (norm pass + fused AdamW + the operand refreshes: 20 GB of traffic for LightningDiT-XL/1) then overlaps
         whatever the caller's stream does next that does not touch these weights -- the next step's encoder forward, another model's turn -- instead of serialising
         behind the backward pass.  Everything that reads the weights (or their bf16 / packed / transposed operands) or writes the gradient buffer must come after
-        `wait()`: `FlatParams.begin_step` does it, the trainers do it before a forward of the model; `step(then=...)` runs a callback (log writes that read the norm)
-        on the side stream too."""
+        `wait()`: `FlatParams.begin_step` does it, the trainers do it before a forward of the model.
+
+        Two rules keep this race-free.  ONE side stream per device for all optimisers: the updates of two optimisers are ordered against each
+        other, so the `ops.workspace()` slots they share (norm partials, repack / transpose tables; keyed by stream) are never written by two streams at once.
+        And `step(then=...)` callbacks are NOT run on the side stream: they read tensors the caller's stream allocated (losses, norms of other terms), which the
+        caching allocator may hand out again once the closure is gone while the side stream is still reading; they run in `wait()`, on the caller's stream, behind
+        the event of the update they belong to -- the closure keeps its tensors alive until then."""
         if self.fp.flat.is_cuda and self.side is None:
-            self.side = torch.cuda.Stream(device=self.fp.flat.device)
+            dev = self.fp.flat.device
+            key = dev.index if dev.index is not None else torch.cuda.current_device()
+            if key not in FlatAdamWEMA._SIDE:
+                FlatAdamWEMA._SIDE[key] = torch.cuda.Stream(device=dev)
+            self.side = FlatAdamWEMA._SIDE[key]
 
     def wait(self) -> None:
-        """The caller's current stream waits for the last overlapped `step` (no-op without one)."""
+        """The caller's current stream waits for the last overlapped `step`, then runs that step's deferred `then` callback (no-op without one)."""
         if self._done is not None:
             torch.cuda.current_stream(self.fp.flat.device).wait_event(self._done)
             self._done = None
+        then, self._then = self._then, None
+        if then is not None:
+            then(self.norm)
 
     def current_lr(self) -> float:
         """The reference's LambdaLR (train_tokenizer.py:385-392): lr_lambda(s) = s / warmup if s < warmup else 1, evaluated at the
@@ -201,8 +215,8 @@ class FlatAdamWEMA:
         return self.lr
 
     def step(self, then=None):
-        """One optimiser step; `then(norm)` (optional) runs right behind it on the same stream.  With `enable_overlap` both go to the side stream, ordered after
-        everything the current stream has queued so far (the backward pass, the gradient all-reduce's wait)."""
+        """One optimiser step; `then(norm)` (optional) runs right behind it on the caller's stream.  With `enable_overlap` the step goes to the side stream, ordered
+        after everything the current stream has queued so far (the backward pass, the gradient all-reduce's wait), and `then` is deferred to `wait()`."""
         if self.side is None:
             norm = self._step()
             if then is not None:
@@ -212,10 +226,9 @@ class FlatAdamWEMA:
         self.side.wait_stream(torch.cuda.current_stream(self.fp.flat.device))
         with torch.cuda.stream(self.side):
             norm = self._step()
-            if then is not None:
-                then(norm)
             self._done = torch.cuda.Event()
             self._done.record(self.side)
+        self._then = then
         return norm
 
     def _step(self):

@@ -149,8 +149,13 @@ class TokenizerTrainer(_AdversarialBranch):
                  kl_w: float = 0.0, mmd_w: float = 0.0, warmup_steps: int = 1000, ema_decay: float = 0.9999, max_norm: float = 1.0,
                  bucket_bytes: int = 64 << 20, disc: Optional[torch.nn.Module] = None, disc_weight: float = 0.5,
                  disc_start_step: int = 5000, disc_lr: float = 1e-4, disc_wd: float = 0.0005, disc_warmup_steps: Optional[int] = None,
-                 bcr: float = 1.0, bcr_cut: float = 0.2):
+                 bcr: float = 1.0, bcr_cut: float = 0.2, posterior_kl_w: float = 0.0):
+        """`kl_w`, `mmd_w`, `posterior_kl_w` weigh BUILD-DEFINED terms the reference does not have (all 0 by default = the reference's
+        loss): batch-moment KL, RBF-mixture MMD, and -- for a `VAE(reparameterize=True)` -- the posterior-form KL of the sampled latent."""
         self.vae, self.lpips = vae, lpips
+        self.posterior_kl_w = float(posterior_kl_w)
+        if self.posterior_kl_w != 0 and not getattr(vae, "reparameterize", False):
+            raise ValueError("posterior_kl_w needs a VAE built with reparameterize=True (the reference's VAE has no (mu, logvar) head: models/vae.py:90-98)")
         self._init_disc(disc, disc_weight, disc_start_step, disc_lr, disc_wd, warmup_steps if disc_warmup_steps is None else disc_warmup_steps,
                         max_norm, bcr, bcr_cut, bucket_bytes)
         self.w = dict(l1=l1, l2=l2, lpips=lpips_w, kl=kl_w, mmd=mmd_w)
@@ -205,7 +210,7 @@ class TokenizerTrainer(_AdversarialBranch):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not parity.on()):      # the reference's autocast (train_tokenizer.py:410); off in the fp32 parity mode
             with torch.no_grad():
                 tokens = self._encode(images)
-            latent = vae.bottle_neck(tokens)
+            latent = vae.latent(tokens)          # = vae.bottle_neck(tokens) unless the build-defined reparameterise hook is on
             recon = vae.decoder(latent).float()
             l1, l2 = losses.l1_mse(recon, images, w["l1"], w["l2"])
             loss = l1 * w["l1"] + l2 * w["l2"]
@@ -217,6 +222,10 @@ class TokenizerTrainer(_AdversarialBranch):
             if w["kl"] != 0 or w["mmd"] != 0:
                 dm, kl, mmd = losses.kl_mmd_loss(latent, w_kl=w["kl"], w_mmd=w["mmd"])
                 loss = loss + dm
+            if self.posterior_kl_w != 0:
+                pk = vae.posterior_kl * self.posterior_kl_w
+                loss = loss + pk
+                dm = pk if dm is None else dm + pk          # `extra` of the single-pass adversarial backward: terms that do not run through recon
             rec_loss = loss
             gan = self._gan_active()
             single = gan and losses.GAN_SINGLE_PASS and not parity.on()
@@ -253,8 +262,12 @@ class TokenizerTrainer(_AdversarialBranch):
         are not part of it.  (train_dmd.py:474 and train_diffusion.py:209 build theirs over every parameter.)"""
         return [p for p in self.vae.parameters() if p.requires_grad]
 
-    def checkpoint(self, all_ranks_rng: Optional[bool] = None) -> dict:
-        """The reference's checkpoint dict (train_tokenizer.py:440-450): vae_wo_ddp / vae_ema / disc_wo_ddp state_dicts, opt_vae in torch.optim.AdamW's
+    def checkpoint(self, all_ranks_rng: bool = False) -> dict:
+        """NOT a collective by default: callable from the master alone, the way the reference writes checkpoints (`if dist.is_master() and ...`,
+        train_tokenizer.py:439).  `all_ranks_rng=True` is the opt-in that gathers EVERY rank's generator states (`tdist.all_gather_object`): then every rank
+        must call checkpoint(), whoever writes the file.
+
+        The reference's checkpoint dict (train_tokenizer.py:440-450): vae_wo_ddp / vae_ema / disc_wo_ddp state_dicts, opt_vae in torch.optim.AdamW's
         layout over the TRAINABLE parameters (`_opt_param_order`), opt_disc over `disc.parameters()`, scheduler_vae / scheduler_disc, steps, and -- beyond the
         reference -- the CPU / device generator states (`rng`: DiffAug's and the transport's draws continue where they stopped).  `torch.save` it as
         `{step:07d}.pt`; `VAE.load_pretrained` reads the first two entries."""
@@ -269,7 +282,7 @@ class TokenizerTrainer(_AdversarialBranch):
             out["disc_wo_ddp"] = {k: v.detach().clone() for k, v in self.disc.state_dict().items()}
             out["opt_disc"] = self.dopt.state_dict(list(self.disc.parameters()))
             out["scheduler_disc"] = self.dopt.scheduler_state_dict()
-        out["rng"] = _rng_state(dist.get_world_size() > 1 if all_ranks_rng is None else all_ranks_rng)      # all_ranks_rng: a collective (every rank calls checkpoint()); else this rank's generators only
+        out["rng"] = _rng_state(bool(all_ranks_rng))      # all_ranks_rng: a collective (every rank calls checkpoint()); default: this rank's generators only
         return out
 
     def load(self, ckpt: dict) -> None:
@@ -535,9 +548,10 @@ class DMDTrainer(_AdversarialBranch):
         self.global_step += 1
         return (loss if vae_turn else sloss).detach()
 
-    def checkpoint(self, all_ranks_rng: Optional[bool] = None) -> dict:
+    def checkpoint(self, all_ranks_rng: bool = False) -> dict:
         """train_dmd.py:577-590: model (the student) / vae_wo_ddp / disc_wo_ddp state_dicts, opt_sit / opt_vae / opt_disc, steps; `rng` = this rank's
-        generator states, or every rank's with all_ranks_rng (a collective: every rank calls checkpoint())."""
+        generator states.  NOT a collective by default -- the reference writes from the master only (train_dmd.py:593) --; all_ranks_rng=True gathers every
+        rank's generator states instead and is then a collective: every rank calls checkpoint()."""
         self.wait_optimizers()
         clone = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
         out = {"model": clone(self.student) if isinstance(self.student, torch.nn.Module) else None, "vae_wo_ddp": clone(self.vae),
@@ -545,7 +559,7 @@ class DMDTrainer(_AdversarialBranch):
                "opt_sit": self.sopt.state_dict(list(self.student.parameters())) if self.sopt is not None else None,
                "opt_vae": self.opt.state_dict(list(self.vae.parameters())),
                "opt_disc": self.dopt.state_dict(list(self.disc.parameters())) if self.disc is not None else None, "steps": self.global_step,
-               "rng": _rng_state(dist.get_world_size() > 1 if all_ranks_rng is None else all_ranks_rng)}
+               "rng": _rng_state(bool(all_ranks_rng))}
         return out
 
     def load(self, ckpt: dict) -> None:

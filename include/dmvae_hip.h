@@ -620,6 +620,20 @@ int dmvae_kl_mmd(const void* z, const void* y, void* kl, void* mmd, void* dz, vo
                  size_t workspace_bytes, int groups, int n, int m, int d, float w_kl, float w_mmd,
                  dmvae_stream_t stream);
 
+/* Reparameterised sample + posterior-form KL of a diagonal-Gaussian latent head.  BUILD-DEFINED, parity unpinned: the reference's VAE.forward is
+ * deterministic (models/vae.py:90-98, no mean / log-variance split); BASELINE.json's north_star names the hook ("encoder -> reparameterise -> decoder",
+ * "per-latent KL"), SURVEY.md 0 asks for it OFF by default, 8a row a15 gives the posterior form.  Host caller: models/vae.py VAE(reparameterize=True).
+ * moments [rows][2C] = (mu | logvar) per row, f32 or bf16 (bf16_io); eps [rows][C] f32 caller-drawn N(0,1), NULL = the posterior mode (z = mu);
+ * z [rows][C] (type of moments; may be NULL) = mu + exp(logvar/2)*eps; kl [C+1] f32: kl[c] = mean_r 0.5*(mu^2 + exp(lv) - 1 - lv), kl[C] = mean_c.
+ * C a power of two in [4, 256]; workspace >= dmvae_reparam_kl_workspace(rows, C).  Deterministic (fixed-order reductions). */
+size_t dmvae_reparam_kl_workspace(size_t rows, int C);
+int dmvae_reparam_kl_fwd(const void* moments, const void* eps, void* z, void* kl, void* workspace, size_t workspace_bytes,
+                         size_t rows, int C, int bf16_io, dmvae_stream_t stream);
+/* d moments [rows][2C] = (dz + g*mu/(rows*C) | dz*0.5*exp(lv/2)*eps + g*0.5*(exp(lv)-1)/(rows*C)), g = w_kl * (g_kl ? *g_kl : 1) with g_kl a DEVICE
+ * pointer to one f32 (the upstream gradient of kl[C]); dz [rows][C] (type of moments) may be NULL (KL term only).  Same build-defined status as above. */
+int dmvae_reparam_kl_bwd(const void* moments, const void* eps, const void* dz, const void* g_kl, float w_kl, void* dmoments,
+                         size_t rows, int C, int bf16_io, dmvae_stream_t stream);
+
 /* ---- optimiser tail on flat f32 buffers (train_tokenizer.py:140-150,382,415-419) ---------------- */
 
 /* norm_out3 = { ||g||_2, min(1, max_norm/(norm+1e-6)), sum of squares }; accumulate_prev!=0 adds the

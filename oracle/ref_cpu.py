@@ -635,6 +635,16 @@ def kl_moment(z: Tensor) -> Tuple[Tensor, Tensor]:
     return kl.to(z.dtype), kl.mean().to(z.dtype)
 
 
+def reparam_kl(moments: Tensor, eps: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+    """Build-defined reparameterise hook + posterior-form KL (the reference's forward is deterministic, models/vae.py:90-98 --
+    PARITY UNPINNED).  moments [..., 2C] = torch.chunk -> (mu, logvar); z = mu + exp(logvar / 2) * eps (eps None: z = mu);
+    kl_c = mean over rows of 0.5 * (mu^2 + exp(logvar) - 1 - logvar).  -> (z [..., C], per-latent kl [C], mean scalar)."""
+    mu, lv = moments.chunk(2, dim=-1)
+    z = mu if eps is None else mu + torch.exp(0.5 * lv) * eps.reshape(mu.shape)
+    kl = (0.5 * (mu * mu + torch.exp(lv) - 1.0 - lv)).reshape(-1, mu.shape[-1]).mean(dim=0)
+    return z, kl, kl.mean()
+
+
 MMD_BANDWIDTH_MULTS = (0.5, 1.0, 2.0, 4.0, 8.0)
 
 

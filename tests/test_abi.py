@@ -54,7 +54,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.dmvae_groupnorm_workspace(2, 64, 128, 32) > 0
     assert lib.dmvae_kl_mmd(p, p, p, p, None, p, 1 << 20, 2, 16, 16, 16, 1.0, 1.0, None) == -22   # d != 32
     assert lib.dmvae_adamw_ema_step(p, p, p, p, None, None, 4, 1e-4, 0.9, 0.95, 1e-8, 0.0, 0, 0.999, None) == -22  # step 0
-    assert lib.dmvae_abi_version() == 7
+    assert lib.dmvae_abi_version() == 8
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -113,7 +113,7 @@ assert lib.dmvae_linear_rows_wgrad_batched(p, 0, p, 48, p, None, None, None, 2, 
 assert lib.dmvae_linear_rows_batched_bf16(p, 0, p, None, p, 0, 2, 65, 64, 64, 64, 64, 64, 0, 0, 0, 0, None) == -22                   # more than 64 rows
 assert lib.dmvae_linear_weight_t_kmajor_batched(None, 0, 0, None) == -22
 assert lib.dmvae_wt_entry_bytes() == 32
-assert lib.dmvae_abi_version() == 7
+assert lib.dmvae_abi_version() == 8
 print("asan-ok")
 """
 

@@ -69,6 +69,18 @@ def _worker(rank, world, port, q):
         flats = [torch.empty_like(tr.fp.flat) for _ in range(world)]
         tdist.all_gather(flats, tr.fp.flat)
         same = torch.equal(flats[0], flats[1]) and not torch.equal(tr.fp.flat, local.fp.flat)
+        # checkpoint() the way the reference writes one -- from the master ALONE (`if dist.is_master()`, train_tokenizer.py:439): the default must not be a
+        # collective (it was, and this call would hang rank 0 in an all_gather_object), and the next collective must still line up
+        ck = [tr.checkpoint() if rank == 0 else None]
+        tdist.broadcast_object_list(ck, src=0)
+        assert "ranks" not in ck[0]["rng"] and ck[0]["rng"]["rank"] == 0
+        tr.step(x)
+        tr.load(ck[0])                                      # every rank resumes from the master's file: weights / EMA / optimiser back to the step-4 state
+        flats = [torch.empty_like(tr.fp.flat) for _ in range(world)]
+        tdist.all_gather(flats, tr.fp.flat)
+        same = same and torch.equal(flats[0], flats[1]) and tr.global_step == 4
+        gathered = tr.checkpoint(all_ranks_rng=True)        # the opt-in collective form: every rank calls it
+        same = same and sorted(gathered["rng"]["ranks"]) == [0, 1]
         dist.barrier()
         q.put((rank, err, same, ""))
         tdist.destroy_process_group()

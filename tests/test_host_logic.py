@@ -334,3 +334,40 @@ def test_every_profiles_file_is_cited_once_in_design_md():
     from conftest import ROOT
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_profiles_index.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_pointer_table_cache_never_drops_recurring_or_captured_tables():
+    """ops._TableCache: device tables that launched kernels / captured graphs read are evicted only when they were used ONCE (an unsettled
+    allocator's activation pointers), and even those stay allocated for one more generation; a table looked up twice (parameter / flat-buffer pointers) stays."""
+    from dmvae_amd import ops
+    c = ops._TableCache()
+    c.LIMIT = 8
+    c.store("param", "P")
+    assert c.lookup("param") == "P" and "param" in c.pinned           # second use: pinned
+    for i in range(40):
+        c.store(("act", i), f"A{i}")
+    assert "param" in c and c.lookup("param") == "P"
+    assert len(c) - len(c.pinned) <= c.LIMIT + 1                      # the single-use entries were trimmed ...
+    assert c.grave and all(isinstance(g, str) for g in c.grave)       # ... but the last trimmed generation is still referenced (deferred free)
+    assert ("act", 39) in c
+    c.discard(("act", 39))
+    assert ("act", 39) not in c and "A39" in c.grave
+    c.clear()
+    assert not c and not c.pinned and not c.grave
+
+
+def test_reparam_kl_spec_closed_forms():
+    """oracle.ref_cpu.reparam_kl -- the build's own spec of the reparameterise hook (parity unpinned: no reference counterpart, models/vae.py:90-98 is
+    deterministic): N(0, 1) posterior has KL 0 and z = eps; constant (m, s^2) has KL 0.5 (m^2 + s^2 - 1 - ln s^2); eps None is the mode; gradient of the KL."""
+    from oracle import ref_cpu as R
+    eps = torch.randn(50, 8, dtype=torch.float64)
+    z, kl, klm = R.reparam_kl(torch.zeros(50, 16, dtype=torch.float64), eps)
+    assert torch.equal(z, eps) and kl.abs().max() == 0 and klm == 0
+    m, s2 = 0.3, 1.7
+    mom = torch.cat([torch.full((50, 8), m, dtype=torch.float64), torch.full((50, 8), s2, dtype=torch.float64).log()], 1).requires_grad_(True)
+    z, kl, klm = R.reparam_kl(mom, None)
+    want = 0.5 * (m * m + s2 - 1 - np.log(s2))
+    assert torch.equal(z, mom[:, :8]) and abs(klm.item() - want) < 1e-12 and (kl - want).abs().max() < 1e-12
+    klm.backward()
+    g = mom.grad
+    assert (g[:, :8] - m / 400).abs().max() < 1e-15 and (g[:, 8:] - 0.5 * (s2 - 1) / 400).abs().max() < 1e-15
