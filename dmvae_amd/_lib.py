@@ -32,7 +32,7 @@ class WtEntry(Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("N", c_int32), ("K", c_int32), ("start", c_uint), ("tiles_x", c_uint)]
 
 
-ABI_VERSION = 8     # 8: dmvae_reparam_kl_*; 7: dmvae_linear_wgrad_grouped_plan / _xcd, dmvae_conv_k4c1_*; 6: dmvae_dit_stack_* / dmvae_dit_boundary_bwd / batched rows Linears / batched weight transposes; 5: dmvae_groupnorm_*_short; include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*; 4: dmvae_norm_conv_out_bwd*)
+ABI_VERSION = 8     # 8: dmvae_reparam_kl_*, dmvae_linear_bf16_sk*; 7: dmvae_linear_wgrad_grouped_plan / _xcd, dmvae_conv_k4c1_*; 6: dmvae_dit_stack_* / dmvae_dit_boundary_bwd / batched rows Linears / batched weight transposes; 5: dmvae_groupnorm_*_short; include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*; 4: dmvae_norm_conv_out_bwd*)
 
 # name -> (restype, argtypes); every symbol include/dmvae_hip.h declares
 SIGNATURES = {
@@ -56,6 +56,10 @@ SIGNATURES = {
     "dmvae_linear_bf16_splitk_supported": (c_int, [c_int] * 4),
     "dmvae_linear_bf16_splitk": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
     "dmvae_splitk_sum_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "dmvae_linear_bf16_sk_supported": (c_int, [c_int] * 4),
+    "dmvae_linear_bf16_sk_counter_bytes": (c_size_t, []),
+    "dmvae_linear_bf16_sk_workspace": (c_size_t, [c_int] * 4),
+    "dmvae_linear_bf16_sk": (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 10 + [c_void_p]),
     "dmvae_linear_bf16_batched_supported": (c_int, [c_int] * 4),
     "dmvae_linear_bf16_batched": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_longlong] * 3 + [c_int, c_void_p]),
     "dmvae_linear_bf16_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),

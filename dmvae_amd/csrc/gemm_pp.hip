@@ -44,8 +44,20 @@ struct Args {
   float inv_tpb;
   unsigned sA, sB, sY, xbytes, ybytes;
   unsigned long long* dbg;   // optional s_memtime stamps per block (dmvae_debug_gemm_timing): [block][tile 0..3][4], null in production
+  // SK instantiations (dmvae_linear_bf16_sk): the flattened (tile, K step) space -- T = tiles x K / 32 steps -- is cut into V contiguous ranges ("virtual
+  // blocks"), each walked by one workgroup; a range that ends inside a tile leaves a PARTIAL tile, and the last of a tile's parts to arrive sums them in
+  // K order (see the kernel).  skS > 0: V = tiles x skS uniform parts per tile (the cut depends on N and K only); skS = 0: stream-K, V equal ranges.
+  int V, skS, T;
+  float* slabs;              // [2 V][TM x TP] f32 partial tiles, each in its writer's register layout
+  unsigned* counters;        // [tiles][8 waves] arrival counts; zero on entry, left zero
+  unsigned slab_bytes;
 };
 
+// Cache policy of the SK instantiation's partial-tile traffic (aux bits of the buffer builtins on gfx940+: 1 = sc0, 16 = sc1): sc0 sc1 = system scope -- the store
+// is written through this XCD's L2 to memory and the load misses in the reader's L2 --, so a part written on one XCD is read correctly on another WITHOUT
+// whole-cache maintenance.  A first version used __threadfence() on both sides (buffer_wbl2 / buffer_inv, i.e. one L2 write-back + invalidate per wave and part):
+// 1 900 cache-wide operations in a 30-us kernel serialised per XCD and made it 3-5 x slower than the unsplit form (profiles/r6_gemm_sk_first_fences.txt).
+constexpr int SK_COHERENT = 1 | 16;
 constexpr unsigned SENT = 0x80000000u;  // voffset beyond any descriptor's num_records: loads return zeros, stores are dropped
 
 __device__ __forceinline__ int swz64(int row) { return (0 - (row >> 2)) & 3; }   // conv_pp.hip: the 64-B-row chunk key that keeps ds_read_b128 fragments conflict-free
@@ -89,10 +101,22 @@ __device__ __forceinline__ float gelu_f(float x) { return dmvae_gelu_f(x); }   /
 //   t = nK - 1          + K(PF-1)'                                       wait 0: the next tile's first PF K tiles have landed before this tile's stores go out
 // Needs nK >= 2 PF (the host asks for K >= 384 and sends shorter reductions to the small batched kernel).  No scratch: a spilled register's reload is a VMEM load, and
 // the wait the compiler puts behind it drains the whole prefetch queue (measured: 10 k cycles per tile with 31 spilled VGPRs).
-template <int TM, int TP, int WM, int WP, bool OUT_F32, int NBUF, bool BATCHED = false>
+//
+// SK (stream-K / fused split-K; round 6).  Few-tile deep-K problems leave CUs idle (M 4096 x N 1152 is 80 tiles of 256 x 256 for 256 CUs) and problems of
+// 1.x rounds waste most of the last round.  Here a workgroup walks a contiguous RANGE of the flattened (tile, K step) space instead of whole tiles: a unit of
+// work is (tile, first K step kb, nk steps).  The loop below is unchanged -- it already streams K tiles across tile boundaries; a unit's K offset rides on the
+// scalar offset of its loads.  A unit with nk < K / 32 is a PART of its tile: its accumulators go to a slab slot in the wave's own register layout (1 KiB per
+// store instruction, written through to memory), then -- once the stores are acknowledged -- one atomic per wave on the tile's arrival counter; the wave that
+// arrives LAST sums the parts in K
+// order -- its own from the accumulators, the others from their slots: (((bias + p0) + p1) + p2 ...), the same order whoever arrives last, so results are
+// run-to-run identical -- and runs the ordinary epilogue.  Nobody ever waits for another workgroup (no co-residency assumption, no spinning).  Cuts: uniform
+// (skS parts per tile; depends on N, K only -- an output row's bits do not depend on M, which the DMD loss's batched cond / uncond evaluation relies on) or
+// stream-K (V = grid equal ranges, each cut kept MINSEG steps away from tile edges).
+template <int TM, int TP, int WM, int WP, bool OUT_F32, int NBUF, bool BATCHED = false, bool SK = false>
 __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int PF = NBUF - 1;   // K tiles in flight ahead of the one being read
+  static_assert(!(SK && BATCHED) && !(SK && OUT_F32), "SK: single product, bf16 result");
   constexpr int CL = TM / WM / 16, BT = TP / WP / 16;   // 16 x 16 accumulator blocks per wave: CL column blocks (= consecutive columns per lane) x BT token blocks
   constexpr int NW = WM * WP;   // waves: 8 (two per SIMD), or 4 with the single-stream loop (one per SIMD, up to 64 accumulator blocks each: a 128 x 128 wave tile)
   static_assert(NW == 8 && CL * 16 * WM == TM && BT * 16 * WP == TP && CL * BT <= 32 && (CL == 4 || CL == 6 || CL == 8), "wave grid");
@@ -126,7 +150,7 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
     int lane_c = lane;
     asm volatile("" : "+v"(lane_c));   // an opaque copy: what calc derives from the lane index is recomputed per tile, not hoisted out of the tile loop and carried (spilled) across the K loop
     const bool live = work < (unsigned)a.total;
-    int wid = live ? (int)xcd_remap(work, a.total) : 0;
+    int wid = live ? (SK ? (int)work : (int)xcd_remap(work, a.total)) : 0;   // SK: `work` is the unit's tile (the XCD-aware order is applied to the virtual blocks)
     unsigned offA = 0, offB = 0;
     b0 = 0;
     if constexpr (BATCHED) {   // product b, its tile wid - b tpb (the same reciprocal + fix-up as below)
@@ -199,6 +223,52 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
   const int wbase = wm * (CW * 64) + fr;                       // weight tile: rows wm * CW ..
   const int tbase = TILE_A + wp * (TP / WP) * 64 + fr;         // token tile:  rows wp * (TP / WP) ..
 
+  // ---- SK: units of work ------------------------------------------------------------------------------------------------------------------------------
+  constexpr int MINSEG = 2 * PF + 2;   // shortest part of a tile (K steps): the loop below needs >= 2 PF, two more keep a part from being all prologue
+  struct Unit { int tile, kb, nk, p, P, i1; };   // tile; first K step and K steps of this unit; part index / parts of the tile; index of the tile's first interior cut
+  auto bnd = [&](int v) -> int {       // flattened step at which virtual block v begins (v = V: the end)
+    if (a.skS > 0) {
+      const int t = v / a.skS, p = v - t * a.skS;
+      return t * nK + (p * nK) / a.skS;
+    }
+    int b = (int)((long long)v * (long long)a.T / (long long)a.V);
+    const int r = b % nK;
+    if (r < MINSEG) b -= r;
+    else if (nK - r < MINSEG) b += nK - r;
+    return b;
+  };
+  unsigned sk_work = blockIdx.x;   // position in the list of virtual blocks this workgroup walks: blockIdx.x, + gridDim.x, ...
+  int sk_pos = 0, sk_end = 0, sk_v = 0;
+  bool sk_started = false;
+  auto next_unit = [&]() -> Unit {
+    Unit u = {a.total, 0, 2 * PF, 0, 1, 0};          // tile = total: not live (its pieces move no memory; the loop shape stays valid)
+    while (sk_pos >= sk_end) {
+      if (sk_started) sk_work += gridDim.x;
+      sk_started = true;
+      if (sk_work >= (unsigned)a.V) return u;
+      sk_v = (int)xcd_remap(sk_work, (unsigned)a.V);
+      sk_pos = bnd(sk_v); sk_end = bnd(sk_v + 1);
+    }
+    const int tile = sk_pos / nK, lo = tile * nK, hi = lo + nK;
+    u.tile = tile; u.kb = sk_pos - lo;
+    const int ke = sk_end < hi ? sk_end - lo : nK;
+    u.nk = ke - u.kb;
+    sk_pos += u.nk;
+    if (u.nk != nK) {                                // a part: the tile's interior cuts are bnd(i1) .. bnd(w - 1), consecutive virtual blocks
+      int v = sk_v;
+      while (v >= 1 && bnd(v) > lo) v--;
+      u.i1 = v + 1;
+      int w = sk_v + 1;
+      while (w < a.V && bnd(w) < hi) w++;
+      u.P = w - u.i1 + 1;
+      u.p = u.kb == 0 ? 0 : sk_v - u.i1 + 1;
+    }
+    u.tile = __builtin_amdgcn_readfirstlane(u.tile); u.kb = __builtin_amdgcn_readfirstlane(u.kb); u.nk = __builtin_amdgcn_readfirstlane(u.nk);
+    u.p = __builtin_amdgcn_readfirstlane(u.p); u.P = __builtin_amdgcn_readfirstlane(u.P); u.i1 = __builtin_amdgcn_readfirstlane(u.i1);
+    return u;
+  };
+  Unit uc = {0, 0, nK, 0, 1, 0}, un = uc;            // current / next unit (non-SK: every unit is a whole tile)
+
   f32x4 acc[CL][BT];   // acc[i][j][r]: token 16 j + 4 (lane >> 4) + r of the wave's rows; column CL * (lane & 15) + i of the wave's columns
   bf16x8 wf[CL], tf[BT];
   unsigned vAc[NPA], vBc[NPB], vAn[NPA], vBn[NPB], vBiasN;
@@ -216,10 +286,10 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
     for (int j = 0; j < BT; j++) tf[j] = *reinterpret_cast<const bf16x8*>(st + j * 1024);
 #pragma unroll
     for (int i = 0; i < CL; i++) wf[i] = *reinterpret_cast<const bf16x8*>(sw + i * 1024);
-    if constexpr (MODE == 0) { issue_k(vAc, vBc, (unsigned)it, slot_wr); it++; }
+    if constexpr (MODE == 0) { issue_k(vAc, vBc, (unsigned)(it + (SK ? uc.kb : 0)), slot_wr); it++; }
     else {
       if constexpr (MODE == 1) issue_bias(vBiasN, par ^ 1);
-      issue_k(vAn, vBn, (unsigned)(MODE - 1), slot_wr);
+      issue_k(vAn, vBn, (unsigned)(MODE - 1 + (SK ? un.kb : 0)), slot_wr);
     }
     slot_rd = slot_rd + SLOT == RING ? 0 : slot_rd + SLOT;
     slot_wr = slot_wr + SLOT == RING ? 0 : slot_wr + SLOT;
@@ -244,13 +314,14 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
   static_assert((PF - 1) * NP + 1 < 64, "vmcnt is a 6-bit counter");
 
   unsigned work = blockIdx.x;
+  if constexpr (SK) { uc = next_unit(); work = (unsigned)uc.tile; }
   {
     unsigned vBiasC;
     calc(work, vAc, vBc, vBiasC, m0c, n0c, b0c);
     issue_bias(vBiasC, 0);
   }
 #pragma unroll
-  for (int u = 0; u < PF; u++) issue_k(vAc, vBc, (unsigned)u, u * SLOT);
+  for (int u = 0; u < PF; u++) issue_k(vAc, vBc, (unsigned)(u + (SK ? uc.kb : 0)), u * SLOT);
   wait_vmcnt<0>();
 
   int tix = 0;
@@ -266,7 +337,7 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
       const int col = gated ? wm * (CW / 2) + (CL / 2) * (lane_b & 15) : wm * CW + CL * (lane_b & 15);
       const int hop = gated ? TM / 2 - CL / 2 : 0;   // gated: the second half of the lane's columns sits TM / 2 entries further (the x2 half of the slice)
       float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (!a.bias) {   // no bias: the slice's piece was all out of range (whether such a piece writes zeros or nothing is not relied upon)
+      if (!a.bias || (SK && uc.p != 0)) {   // no bias: the slice's piece was all out of range (whether such a piece writes zeros or nothing is not relied upon); SK: the bias starts part 0 only
       } else if (a.bias_bf16) {
 #pragma unroll
         for (int h = 0; h < CL / 2; h++) {
@@ -286,14 +357,16 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
         for (int j = 0; j < BT; j++) acc[i][j] = f32x4{bv[i], bv[i], bv[i], bv[i]};
     }
     stamp(1);
-    const unsigned next = work + gridDim.x;
+    unsigned next = work + gridDim.x;
+    const int nkc = SK ? uc.nk : nK;               // K steps of this unit
     if (grp == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
     if (grp == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one interval behind group 0
     it = PF;
     [&]<int... T>(std::integer_sequence<int, T...>) __attribute__((always_inline)) { (((void)T, kstep(W_NO{}, M0_{})), ...); }(std::make_integer_sequence<int, PF - 1>{});
     kstep(W_ST{}, M0_{});
 #pragma unroll 1
-    for (int t = PF; t < nK - PF; t++) kstep(W_ST{}, M0_{});
+    for (int t = PF; t < nkc - PF; t++) kstep(W_ST{}, M0_{});
+    if constexpr (SK) { un = next_unit(); next = (unsigned)un.tile; }
     calc(next, vAn, vBn, vBiasN, m0n, n0n, b0n);       // all out of range when there is no next tile: its pieces move no memory
     [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) { (kstep(W_TL{}, std::integral_constant<int, J + 1>{}), ...); }(std::make_integer_sequence<int, PF - 1>{});
     kstep(W_0{}, std::integral_constant<int, PF>{});
@@ -302,24 +375,107 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA (inline asm, invisible to the hazard recogniser) -> accumulator reads
     stamp(2);
 
-    // ---- epilogue: straight from the accumulators, NST stores per lane: token row (j, r) of the lane's group, CL consecutive columns ------------------------------
-    {
-      int lane_o = lane;
-      asm volatile("" : "+v"(lane_o));   // recomputed per tile, not carried across the main loop
-      const int col = gated ? (n0c >> 1) + wm * (CW / 2) + (CL / 2) * (lane_o & 15) : n0c + wm * CW + CL * (lane_o & 15);
-      const int row0 = m0c + wp * (TP / WP) + 4 * (lane_o >> 4);
-      const unsigned ysoff = BATCHED ? (unsigned)b0c * a.sY : 0u;   // the product's y: scalar offset of every store below (outside the descriptor's range check, like the K-tile offsets of the loads)
-      const bool c_ok = col < (gated ? a.H : a.N);       // N % 8 == 0 and CL | 8 ... the lane's columns are all inside or all outside when N is a multiple of CL; else per element below
-      auto body = [&](auto ACTc) __attribute__((always_inline)) {
-        constexpr int ACT = decltype(ACTc)::value;
+    // ---- SK: a PART of a tile -> its slab slot; the wave that arrives last at the tile's counter sums the parts (K order) and goes on to the epilogue ---------------
+    bool sk_final = true;                          // this wave writes the tile's result (always, outside SK)
+    unsigned sk_base = 0;                          // byte offset of this wave's region inside a slab slot
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)a.slabs, 0, SK ? a.slab_bytes : 0u, 0x00020000);
+    constexpr unsigned SLOT_BYTES = (unsigned)TM * (unsigned)TP * 4u, WREG = (unsigned)CL * BT * 4u * 64u * 4u;   // one partial tile; one wave's CL x BT x 4 floats per lane
+    if constexpr (SK) {
+      if (uc.P > 1) {
+        static_assert(!SK || CL % 4 == 0, "SK: 16-B pieces of a lane's columns");
+        sk_base = (unsigned)wave * WREG;
+        const unsigned own = (uc.p == 0 ? (unsigned)(a.V + uc.i1) : (unsigned)(uc.i1 + uc.p - 1)) * SLOT_BYTES + sk_base;
+        int lane_s = lane;
+        asm volatile("" : "+v"(lane_s));
+        const unsigned vo = (unsigned)lane_s * 16u;
 #pragma unroll
         for (int j = 0; j < BT; j++)
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < CL; i++)   // pinned where they are used: left to the scheduler, the reads of later rows are hoisted and their values spilled (conv_pp.hip)
-              asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[i]) : "a"(acc[i][j][r]));
+            for (int i = 0; i < CL; i++) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[i]) : "a"(acc[i][j][r]));
+#pragma unroll
+            for (int h = 0; h < CL / 4; h++) {
+              const f32x4 o4 = {v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+              const u32x4 k4 = *reinterpret_cast<const u32x4*>(&o4);
+              __builtin_amdgcn_raw_buffer_store_b128(k4, rS, vo, own + (unsigned)(((j * 4 + r) * (CL / 4) + h) * 1024), SK_COHERENT);
+              asm volatile("s_nop 0" :: "v"(k4));
+            }
+          }
+        wait_vmcnt<0>();                           // the part has been written THROUGH to memory (sc0 sc1 stores are acknowledged from there) before the arrival is counted
+        unsigned old = 0;
+        unsigned* cnt = a.counters + (size_t)uc.tile * 8 + wave;
+        if (lane_s == 0) old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+        sk_final = old == (unsigned)(uc.P - 1);
+        if (sk_final) {
+          if (lane_s == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left zero for the next launch
+        }
+      }
+    }
+
+    // ---- epilogue: straight from the accumulators, NST stores per lane: token row (j, r) of the lane's group, CL consecutive columns ------------------------------
+    if (sk_final) {
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));   // recomputed per tile, not carried across the main loop
+      const int col = gated ? (n0c >> 1) + wm * (CW / 2) + (CL / 2) * (lane_o & 15) : n0c + wm * CW + CL * (lane_o & 15);
+      const int row0 = m0c + wp * (TP / WP) + 4 * (lane_o >> 4);
+      const unsigned ysoff = BATCHED ? (unsigned)b0c * a.sY : 0u;   // the product's y: scalar offset of every store below (outside the descriptor's range check, like the K-tile offsets of the loads)
+      const bool c_ok = col < (gated ? a.H : a.N);       // N % 8 == 0 and CL | 8 ... the lane's columns are all inside or all outside when N is a multiple of CL; else per element below
+      auto body = [&](auto ACTc, auto SUMc) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(ACTc)::value;
+        constexpr bool SUM = decltype(SUMc)::value;   // SK, last arriver of a tile in parts: a row's values are the K-ordered sum of the parts
+#pragma unroll
+        for (int j = 0; j < BT; j++) {
+          [[maybe_unused]] float sm[4][8];
+          if constexpr (SUM) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+              for (int i = 0; i < 8; i++) sm[r][i] = 0.f;     // 0 + p0 is p0 exactly: the order is ((p0 + p1) + p2) ... whoever sums
+            const unsigned vo = (unsigned)lane_o * 16u;
+#pragma unroll 1
+            for (int q = 0; q < uc.P; q++) {
+              if (q == uc.p) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                  for (int i = 0; i < CL; i++) {
+                    float t;
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[i][j][r]));
+                    sm[r][i] += t;
+                  }
+              } else {
+                const unsigned src = (q == 0 ? (unsigned)(a.V + uc.i1) : (unsigned)(uc.i1 + q - 1)) * SLOT_BYTES + sk_base;
+                u32x4 ld[4][CL / 4];
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                  for (int h = 0; h < CL / 4; h++)
+                    ld[r][h] = __builtin_amdgcn_raw_buffer_load_b128(rS, vo, src + (unsigned)(((j * 4 + r) * (CL / 4) + h) * 1024), SK_COHERENT);
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                  for (int h = 0; h < CL / 4; h++) {
+                    const f32x4 f = *reinterpret_cast<const f32x4*>(&ld[r][h]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) sm[r][4 * h + e] += f[e];
+                  }
+              }
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if constexpr (SUM) {
+#pragma unroll
+              for (int i = 0; i < CL; i++) v[i] = sm[r][i];
+            } else {
+#pragma unroll
+              for (int i = 0; i < CL; i++)   // pinned where they are used: left to the scheduler, the reads of later rows are hoisted and their values spilled (conv_pp.hip)
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[i]) : "a"(acc[i][j][r]));
+            }
             if constexpr (ACT == 6) {   // SwiGLU (swiglu_ffn.py:32-35): silu(x1) * x2 on the bf16-rounded halves, the product of bf16 values -- dit.hip::swiglu_kernel's bits
 #pragma unroll
               for (int i = 0; i < CL / 2; i++) {
@@ -388,11 +544,20 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
               asm volatile("s_nop 0" :: "v"(o));
             }
           }
+        }
       };
-      if (a.act == 0) body(std::integral_constant<int, 0>{});
-      else if (a.act == 5) body(std::integral_constant<int, 5>{});
-      else if (a.act == 6) body(std::integral_constant<int, 6>{});
-      else body(std::integral_constant<int, 1>{});
+      auto by_act = [&](auto SUMc) __attribute__((always_inline)) {
+        if (a.act == 0) body(std::integral_constant<int, 0>{}, SUMc);
+        else if (a.act == 5) body(std::integral_constant<int, 5>{}, SUMc);
+        else if (a.act == 6) body(std::integral_constant<int, 6>{}, SUMc);
+        else body(std::integral_constant<int, 1>{}, SUMc);
+      };
+      if constexpr (SK) {
+        if (uc.P > 1) by_act(std::true_type{});
+        else by_act(std::false_type{});
+      } else {
+        by_act(std::false_type{});
+      }
     }
     if (a.dbg) __builtin_amdgcn_s_barrier();   // diagnostics: the stamp then reads when the LAST wave has issued its stores
     stamp(3);
@@ -403,6 +568,7 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
 #pragma unroll
     for (int p = 0; p < NPB; p++) vBc[p] = vBn[p];
     m0c = m0n; n0c = n0n; b0c = b0n;
+    if constexpr (SK) uc = un;
     par ^= 1;
   }
 #endif
@@ -432,6 +598,43 @@ int launch(Args a, hipStream_t st, int batch = 1) {
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
+// SK launch: the 256 x 256 tile only (the N = 1152 / 1024 problems this is for are 4.5 / 4 tile columns of it; its ring is 4 deep: parts of >= 8 K steps).
+constexpr int SK_GRID = 256, SK_MAX_TILES = 2048, SK_COUNTER_BYTES = SK_MAX_TILES * 8 * 4;
+static int launch_sk(Args a, int splits, hipStream_t st) {
+  constexpr int TM = 256, TP = 256;
+  a.ntn = (a.N + TM - 1) / TM;
+  a.tpb = ((a.M + TP - 1) / TP) * a.ntn;
+  a.total = a.tpb;
+  a.inv_ntn = 1.0f / (float)a.ntn;
+  a.inv_tpb = 1.0f / (float)a.tpb;
+  a.skS = splits;
+  a.V = splits > 0 ? a.total * splits : SK_GRID;
+  a.T = a.total * (a.K >> 5);
+  const unsigned grid = a.V > SK_GRID ? (unsigned)SK_GRID : (unsigned)a.V;
+  constexpr int slot = (TM + TP) * 64;
+  constexpr int fit = (160 * 1024 - 3 * 1024) / slot;
+  constexpr int nbuf = fit > GEMM_MAXBUF ? GEMM_MAXBUF : fit;
+  constexpr int lds = nbuf * slot + 3 * 1024;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<TM, TP, 2, 4, false, nbuf, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_pp_kernel<TM, TP, 2, 4, false, nbuf, false, true>), dim3(grid), dim3(512), lds, st, a);
+  DMVAE_CHECK_LAUNCH();
+  return 0;
+}
+// What dmvae_linear_bf16_sk needs of (M, N, K, splits): splits 0 = stream-K (ranges of T / 256 steps, at least 2 MINSEG each so that no cut collapses), else
+// uniform parts of >= MINSEG steps.  MINSEG of the 256 x 256 instantiation = 2 * 3 + 2.
+static bool sk_ok(int M, int N, int K, int splits) {
+  if (!(M >= 64 && N > 0 && N % 8 == 0 && K % 32 == 0 && K >= 384 && splits >= 0 && splits <= 8)) return false;
+  const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  const int nK = K >> 5;
+  if (tiles > SK_MAX_TILES || tiles * nK >= (1ll << 30)) return false;
+  if (splits == 0) return tiles * nK / SK_GRID >= 16 && nK >= 16;
+  return nK / splits >= 8 && tiles * splits <= 4096;
+}
+
 // The tile menu: (columns, rows, cost of one tile relative to a 256 x 256 tile's at the same K with the whole chip busy -- measured on the 16384 x 6144 x 1152
 // problem, 6 to 12 rounds per entry: tools/bench_gemm.py --sweep --cold --kmajor).  Smaller tiles cost more per flop: 0.80 for 62.5 % of the area.
 struct Cfg { int tm, tp; float cost; };
@@ -521,6 +724,7 @@ extern "C" int dmvae_linear_bf16_batched(const void* x, const void* w, void* y, 
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = nullptr; a.y = y;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldy = ldy;
   a.act = 0; a.bias_bf16 = 0; a.H = N / 2; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = nullptr;
+  a.V = a.skS = a.T = 0; a.slabs = nullptr; a.counters = nullptr; a.slab_bytes = 0u;
   a.wbytes = (unsigned)wb; a.xbytes = (unsigned)xb; a.ybytes = (unsigned)yb;
   a.wsRow = (unsigned)ldw * 2u; a.wsK = 64u;
   a.sA = (unsigned)(sw * 2); a.sB = (unsigned)(sx * 2); a.sY = (unsigned)(sy * (out_f32 ? 4 : 2));
@@ -566,6 +770,7 @@ extern "C" int dmvae_linear_bf16_splitk(const void* x, const void* w, void* slab
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = nullptr; a.y = slabs;
   a.M = M; a.N = N; a.K = Ks; a.lda = lda; a.ldw = ldw; a.ldy = N;
   a.act = 0; a.bias_bf16 = 0; a.H = N / 2; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = nullptr;
+  a.V = a.skS = a.T = 0; a.slabs = nullptr; a.counters = nullptr; a.slab_bytes = 0u;
   a.wbytes = (unsigned)wb; a.xbytes = (unsigned)((long long)M * lda * 2); a.ybytes = (unsigned)((long long)splits * M * N * 4);
   a.wsRow = w_layout == 1 ? 64u : (unsigned)ldw * 2u;
   a.wsK = w_layout == 1 ? (unsigned)N * 64u : 64u;
@@ -609,6 +814,47 @@ extern "C" int dmvae_splitk_sum_bf16(const void* slabs, int splits, const void* 
   return 0;
 }
 
+// Stream-K / fused split-K Linear (the SK instantiation above): y bf16 = act(x w^T + bias) with the reduction cut across workgroups and summed in K order by the
+// last part to arrive -- one launch, no slab pass.  splits = 0: stream-K (256 equal ranges of the (tile, K step) space: the cut depends on M); splits >= 2: that
+// many uniform parts per tile (depends on N, K only: a row's bits do not depend on how many rows the call has).  workspace: dmvae_linear_bf16_sk_workspace bytes,
+// whose FIRST dmvae_linear_bf16_sk_counter_bytes() bytes must be zero on entry (the kernel leaves them zero; zero the buffer once).
+extern "C" int dmvae_linear_bf16_sk_supported(int M, int N, int K, int splits) { return dmvae_gemm_pp::sk_ok(M, N, K, splits) ? 1 : 0; }
+extern "C" size_t dmvae_linear_bf16_sk_counter_bytes(void) { return (size_t)dmvae_gemm_pp::SK_COUNTER_BYTES; }
+extern "C" size_t dmvae_linear_bf16_sk_workspace(int M, int N, int K, int splits) {
+  using namespace dmvae_gemm_pp;
+  if (!sk_ok(M, N, K, splits)) return 0;
+  const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  const long long V = splits > 0 ? tiles * splits : SK_GRID;
+  return (size_t)SK_COUNTER_BYTES + (size_t)(2 * V) * 256 * 256 * 4;
+}
+extern "C" int dmvae_linear_bf16_sk(const void* x, const void* w, const void* bias, void* y, void* workspace, size_t workspace_bytes, int splits, int M, int N, int K,
+                                    int lda, int ldw, int ldy, int act, int bias_bf16, int w_layout, hipStream_t stream) {
+  using namespace dmvae_gemm_pp;
+  DMVAE_CHECK_ARG(x && w && y && workspace, "linear_bf16_sk: null operand");
+  DMVAE_CHECK_ARG(sk_ok(M, N, K, splits), "linear_bf16_sk: M %d N %d K %d splits %d not taken (dmvae_linear_bf16_sk_supported)", M, N, K, splits);
+  DMVAE_CHECK_ARG(w_layout == 0 || w_layout == 1, "linear_bf16_sk: w_layout must be 0 (row-major [N][ldw]) or 1 (K-tile-major [K / 32][N][32])");
+  DMVAE_CHECK_ARG(lda >= K && (w_layout == 1 || ldw >= K) && ldy >= (act == 6 ? N / 2 : N) && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0,
+                  "linear_bf16_sk: leading dimensions must cover the rows and be multiples of 8");
+  DMVAE_CHECK_ARG(act == 0 || act == 1 || act == 5 || act == 6, "linear_bf16_sk: act must be 0 (none), 1 (SiLU), 5 (GELU) or 6 (SwiGLU over the [x1 | x2] halves of N)");
+  DMVAE_CHECK_ARG(act != 6 || N % 16 == 0, "linear_bf16_sk: the SwiGLU epilogue needs N %% 16 == 0");
+  const long long wb = w_layout == 1 ? (long long)N * K * 2 : (long long)N * ldw * 2;
+  DMVAE_CHECK_ARG((long long)M * lda * 2 < (1ll << 31) && wb < (1ll << 31) && (long long)M * ldy * 2 < (1ll << 31),
+                  "linear_bf16_sk: operands are addressed through 32-bit buffer offsets (2 GiB each)");
+  const size_t need = dmvae_linear_bf16_sk_workspace(M, N, K, splits);
+  DMVAE_CHECK_ARG(workspace_bytes >= need && need - SK_COUNTER_BYTES < (1ull << 32), "linear_bf16_sk: workspace too small (need %zu bytes, see dmvae_linear_bf16_sk_workspace)", need);
+  Args a;
+  a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.y = y;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldy = ldy;
+  a.act = act; a.bias_bf16 = bias_bf16; a.H = N / 2; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = nullptr;
+  a.wbytes = (unsigned)wb; a.tpb = 0; a.inv_tpb = 0.f; a.sA = a.sB = a.sY = a.xbytes = a.ybytes = 0u;
+  a.wsRow = w_layout == 1 ? 64u : (unsigned)ldw * 2u;
+  a.wsK = w_layout == 1 ? (unsigned)N * 64u : 64u;
+  a.counters = (unsigned*)workspace;
+  a.slabs = (float*)((char*)workspace + SK_COUNTER_BYTES);
+  a.slab_bytes = (unsigned)(need - SK_COUNTER_BYTES);
+  return launch_sk(a, splits, stream);
+}
+
 extern "C" int dmvae_linear_bf16(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int lda, int ldw, int ldy,
                                  int act, int bias_bf16, int out_f32, int w_layout, hipStream_t stream) {
   using namespace dmvae_gemm_pp;
@@ -626,6 +872,7 @@ extern "C" int dmvae_linear_bf16(const void* x, const void* w, const void* bias,
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.y = y;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldy = ldy;
   a.act = act; a.bias_bf16 = bias_bf16; a.H = N / 2; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = g_gemm_dbg;
+  a.V = a.skS = a.T = 0; a.slabs = nullptr; a.counters = nullptr; a.slab_bytes = 0u;
   a.wbytes = (unsigned)wb; a.tpb = 0; a.inv_tpb = 0.f; a.sA = a.sB = a.sY = a.xbytes = a.ybytes = 0u;
   a.wsRow = w_layout == 1 ? 64u : (unsigned)ldw * 2u;
   a.wsK = w_layout == 1 ? (unsigned)N * 64u : 64u;

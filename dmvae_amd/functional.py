@@ -806,6 +806,7 @@ def _bf_km(w: torch.Tensor) -> torch.Tensor:
 
 SPLITK = int(os.environ.get("DMVAE_SPLITK", "3"))                # DitStackFn: parts of the reduction for its few-tile deep-K GEMMs (0: off; tests compare)
 SPLITK_MIN_K = int(os.environ.get("DMVAE_SPLITK_MINK", "3072"))
+SPLITK_FUSED = os.environ.get("DMVAE_SPLITK_FUSED", "1") != "0"  # the parts summed inside the GEMM by the last one to arrive (ops.linear_sk, round 6) instead of slabs + a sum pass (ops.linear_splitk)
 _SPLITK_ACTIVE = [0]      # > 0 only inside DitStackFn's forward / backward: the inference route keeps one accumulation order for every batch size
 
 
@@ -817,9 +818,15 @@ def _use_splitk(m: int, n: int, k: int) -> int:
     if s_ < 2 or parity.on() or not (2048 <= m <= 6144) or k < SPLITK_MIN_K:
         return 0
     tiles = ((m + 255) // 256) * ((n + 255) // 256)
-    if tiles > 100 or not ops.linear_splitk_supported(m, n, k, s_):
+    if tiles > 100:
         return 0
-    return s_
+    if SPLITK_FUSED:
+        return s_ if ops.linear_sk_supported(m, n, k, s_) else 0
+    return s_ if ops.linear_splitk_supported(m, n, k, s_) else 0
+
+
+def _splitk_linear(x2: torch.Tensor, w: torch.Tensor, bias, parts: int) -> torch.Tensor:
+    return ops.linear_sk(x2, w, bias, splits=parts) if SPLITK_FUSED else ops.linear_splitk(x2, w, bias, parts)
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, act: int = ops.ACT_NONE) -> torch.Tensor:
@@ -840,7 +847,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, a
         return ops.linear_rows(x.view(m, k), (w if w.dtype == bf16 else _bf(w)).view(n, k), bb, act).view(*x.shape[:-1], n)
     sk = _use_splitk(m, n, k) if act == ops.ACT_NONE else 0
     if sk:
-        return ops.linear_splitk(x.view(m, k), (w if w.dtype == bf16 else _bf(w)).view(n, k), bb, sk).view(*x.shape[:-1], n)
+        return _splitk_linear(x.view(m, k), (w if w.dtype == bf16 else _bf(w)).view(n, k), bb, sk).view(*x.shape[:-1], n)
     if ops.linear_supported(m, n, k) and (act != ops.ACT_SWIGLU or n % 16 == 0):
         # frozen weights -- an nn.Parameter that is not trainable AND not owned by one of this build's optimisers (a student DiT switched to requires_grad
         # False for the DMD loss's evaluations still changes every few steps: it keeps the row-major shadow its optimiser maintains) -- : the K-tile-major
@@ -905,7 +912,7 @@ def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Te
     if ops.linear_supported(rows, cin, cout) and not parity.on():
         sk = _use_splitk(rows, cin, cout)
         if sk:
-            return ops.linear_splitk(_c(dy2), _bf_t(w), None, sk), dw, db
+            return _splitk_linear(_c(dy2), _bf_t(w), None, sk), dw, db
         return ops.linear_bf16(_c(dy2), _bf_t(w)), dw, db                 # dX = dY . W as an NT GEMM against the transposed copy
     if cout % 32 == 0 and cin % 4 == 0:
         return ops.gemm_nt(_c(dy2), packed(w, True).view(cin, cout)), dw, db

@@ -393,6 +393,47 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     return y
 
 
+_SK_WS = {}
+
+
+def _sk_workspace(nbytes: int, device) -> torch.Tensor:
+    """Scratch of `linear_sk`, per (device, stream): ZERO-initialised when (re)allocated -- its first 64 KB are the tiles' arrival counters, which the kernel expects
+    zero and leaves zero; the partial-tile slots behind them are written before they are read."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    ws = _SK_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        _SK_WS[key] = ws
+    return ws
+
+
+def linear_sk_supported(m: int, n: int, k: int, splits: int = 0) -> bool:
+    return bool(_lib.lib().dmvae_linear_bf16_sk_supported(int(m), int(n), int(k), int(splits)))
+
+
+def linear_sk(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0, splits: int = 0) -> torch.Tensor:
+    """y bf16 [M, N] = act(x @ w^T + bias) on the stream-K (splits = 0) / fused split-K (splits >= 2 uniform parts per tile) instantiation of the Linear GEMM
+    (include/dmvae_hip.h dmvae_linear_bf16_sk): ONE launch, the parts of a tile summed in K order by the last one to arrive.  w bf16 [N, K] row-major or
+    K-tile-major [K / 32, N, 32]."""
+    x = _req2d(x, "x")
+    m, k = x.shape
+    if w.dim() == 3:
+        w = _req(w, bf16, "w")
+        assert w.shape[0] * 32 == k and w.shape[2] == 32, f"K-tile-major weight {tuple(w.shape)} does not match K = {k}"
+        n, layout, ldw = w.shape[1], 1, k
+    else:
+        w = _req2d(w, "w")
+        n, layout, ldw = w.shape[0], 0, w.stride(0)
+        assert w.shape[1] == k
+    L = _lib.lib()
+    ws = _sk_workspace(L.dmvae_linear_bf16_sk_workspace(m, n, k, int(splits)), x.device)
+    nout = n // 2 if act == ACT_SWIGLU else n
+    y = torch.empty(m, nout, dtype=bf16, device=x.device)
+    check(L.dmvae_linear_bf16_sk(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), ws.data_ptr(), ws.numel(), int(splits), m, n, k, x.stride(0), ldw, nout,
+                                 int(act), int(bias is not None and bias.dtype == bf16), layout, _stream()), "linear_bf16_sk")
+    return y
+
+
 def linear_splitk_supported(m: int, n: int, k: int, splits: int) -> bool:
     return bool(_lib.lib().dmvae_linear_bf16_splitk_supported(int(m), int(n), int(k), int(splits)))
 

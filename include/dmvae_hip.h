@@ -270,6 +270,20 @@ int dmvae_linear_bf16_batched(const void* x, const void* w, void* y, int batch, 
 int dmvae_linear_bf16_splitk_supported(int M, int N, int K, int splits);
 int dmvae_linear_bf16_splitk(const void* x, const void* w, void* slabs, int splits, int M, int N, int K, int lda, int ldw, int w_layout, dmvae_stream_t stream);
 int dmvae_splitk_sum_bf16(const void* slabs, int splits, const void* bias, int bias_bf16, void* y, int M, int N, dmvae_stream_t stream);
+
+/* Stream-K / fused split-K Linear: y bf16 [M][ldy] = act(x [M][lda] w^T + bias), the reduction cut ACROSS workgroups and summed in K order by the last part of a
+ * tile to arrive -- one launch, no slab pass (csrc/gemm_pp.hip, SK instantiation; 256 x 256 tiles).  For few-tile deep-K problems (LightningDiT-XL/1 at batch 16:
+ * M 4096 x N 1152 is 80 tiles for 256 CUs; K = 3072 .. 6144) and problems of 1.x rounds of tiles.  splits = 0: stream-K -- 256 equal ranges of the flattened
+ * (tile, K step) space, the cut depends on M; splits 2 .. 8: that many uniform parts per tile -- the cut depends on N and K only, so a row's bits do not depend
+ * on the number of rows in the call (train_dmd.py:212-217 evaluated as one 2B call = two B calls).  Run-to-run identical either way (fixed summation order).
+ * act / bias / w_layout as dmvae_linear_bf16.  workspace >= dmvae_linear_bf16_sk_workspace(M, N, K, splits) bytes whose FIRST dmvae_linear_bf16_sk_counter_bytes()
+ * bytes are zero on entry (arrival counters; the kernel leaves them zero: zero the buffer once).  Reference: nn.Linear under autocast,
+ * diffusion/lightningdit/lightningdit.py:66-75,236-250, swiglu_ffn.py:15-36, train_dmd.py:563-575 (their backward: dX = dY W). */
+int dmvae_linear_bf16_sk_supported(int M, int N, int K, int splits);
+size_t dmvae_linear_bf16_sk_counter_bytes(void);
+size_t dmvae_linear_bf16_sk_workspace(int M, int N, int K, int splits);
+int dmvae_linear_bf16_sk(const void* x, const void* w, const void* bias, void* y, void* workspace, size_t workspace_bytes, int splits,
+                         int M, int N, int K, int lda, int ldw, int ldy, int act, int bias_bf16, int w_layout, dmvae_stream_t stream);
 /* The input-gradient operand of dmvae_linear_bf16 from a Linear weight's bf16 copy: w bf16 [N][K] row-major (nn.Linear.weight: N = out_features, K = in_features)
  * -> out bf16 [N / 32][K][32], out[n >> 5][k][n & 31] = w[n][k], i.e. the K-tile-major layout (w_layout = 1) of W^T [K][N] with the reduction over n:
  * dmvae_linear_bf16(dy [M][N], out, NULL, dx, M, K, N, ..., w_layout = 1) is dX = dY . W.  N % 32 == 0, K % 8 == 0.  One tiled-transpose launch per weight

@@ -19,6 +19,7 @@ ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--shapes", default="")
 ap.add_argument("--kmajor", action="store_true", help="with --sweep: the weights K-tile-major (what frozen weights are served as)")
+ap.add_argument("--sk", action="store_true", help="also the stream-K (sk0) / fused split-K (sk2, sk3, sk4) instantiation where it takes the shape")
 ap.add_argument("--cold", action="store_true", help="rotate over enough distinct activation buffers (> 512 MB) that no call finds its input in the 256-MB Infinity Cache -- "
                 "inside a training step a GEMM's input was written by the previous kernel, not read by the same GEMM 50 us earlier")
 args = ap.parse_args()
@@ -89,6 +90,10 @@ for name, m, n, k in SHAPES:
                 dbg(-1)
                 ops.linear_bf16(nx(), wk, bb)
             arms["gemm_pp_kmajor"] = fk
+    if args.sk:
+        for sp in (0, 2, 3, 4):
+            if ops.linear_sk_supported(m, n, k, sp):
+                arms["sk%d" % sp] = (lambda sp_: (lambda: ops.linear_sk(nx(), wsw if args.sweep else w, bb, splits=sp_)))(sp)
     for f in arms.values():
         for _ in range(3):
             f()
