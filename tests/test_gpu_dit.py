@@ -311,6 +311,51 @@ def test_lightningdit_train_route_matches_stock_autocast(tag):
     assert torch.equal(out, out2) and torch.equal(xa.grad, xc.grad)
 
 
+@pytest.mark.parametrize("tag", ["dit_small_hd64w", "dit_small_hd72"])
+def test_lightningdit_train_route_vs_reference_capture_by_the_bf16_site_oracle(tag):
+    """The production bf16 training route (lightningdit_fast.forward_train: DitStackFn, grouped weight gradients, fused boundary passes) against the REFERENCE's
+    own f32 capture (oracle/capture_golden_dit.py: out, dx, six full parameter gradients, norm + sum of every parameter gradient), by the criterion of
+    test_gpu_modules.py: as close to the f32 reference as the CPU oracle with bf16 rounding at exactly the autocast sites is (x 1.15 + 1e-3).  The oracle's
+    backward is torch autograd over oracle.ref_cpu.lightningdit_forward (differentiable: straight-through rounding hooks) -- nothing of this comparison involves
+    stock PyTorch on the GPU, so an error the HIP route shared with stock autocast would show here."""
+    g = load_golden(tag)
+    m = build(tag, g).to(DEV)
+    x, t, y = g.t("x"), g.t("t"), torch.from_numpy(np.asarray(g["y"]))
+    dy = g.t("dy")
+    xa = x.to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=BF):
+        out = m(xa, t.to(DEV), y.to(DEV))
+    (out.float() * dy.to(DEV)).sum().backward()
+    names = [n for n, _ in m.named_parameters()]
+    po = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for n in names:
+        po[n].requires_grad_(True)
+    xo = x.clone().requires_grad_(True)
+    yo = R.lightningdit_forward(xo, t, y, po, CFGS[tag]["num_heads"], CFGS[tag]["patch_size"], q=Q)
+    yo.backward(dy)
+
+    def floor(hip, orc, ref, what, slack=1.15, abs_floor=1e-3):
+        e_hip, e_orc = _rl2(hip, ref), _rl2(orc, ref)
+        print(f"{tag} {what}: rel-L2 to the f32 reference -- HIP {e_hip:.2e}, bf16-site oracle {e_orc:.2e}")
+        assert e_hip < slack * e_orc + abs_floor, (what, e_hip, e_orc)
+    floor(out.float().cpu(), yo.detach(), g.t("out"), "out")
+    floor(xa.grad.cpu(), xo.grad, g.t("dx"), "dx")
+    pa = dict(m.named_parameters())
+    full = [k[2:] for k in g.keys() if k.startswith("g.")]
+    assert len(full) >= 6
+    for n in full:
+        floor(pa[n].grad.cpu(), po[n].grad, g.t("g." + n), "grad " + n)
+    for n in names:                      # EVERY parameter: gradient norm and sum against the reference's, to the oracle's own distance
+        if n == "pos_embed" or "gn." + n not in g:
+            continue
+        want_norm = float(g["gn." + n][0])
+        if want_norm < 1e-3:
+            continue
+        e_hip = abs(pa[n].grad.double().norm().item() - want_norm) / want_norm
+        e_orc = abs(po[n].grad.double().norm().item() - want_norm) / want_norm
+        assert e_hip < 1.15 * e_orc + 1e-2, (n, e_hip, e_orc)
+
+
 @pytest.mark.parametrize("tag", ["dit_small_hd64w", "dit_small_hd72"])      # the two fixtures inside the HIP kernels' range (dit_small_hd64's SwiGLU width 341 is refused loudly)
 def test_cond_and_uncond_as_one_2b_call_equals_two_b_calls(tag):
     """train_dmd.py:211-217 evaluates a velocity model twice per DMD loss (labels, then the null class); DMDTrainer batches the two evaluations into ONE call on

@@ -1,0 +1,18 @@
+#!/usr/bin/env python
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection CSVs (one pass each) of tools/bench_kl_shapes.py -> per (kernel, grid): mean HBM read / write bytes per
+launch.  Units and corrections as tools/pmc_traffic_summary.py (MI355X_MICROARCH.md "HBM": KiB; FETCH_SIZE doubled for 16-B-per-lane reads on gfx950)."""
+import collections, csv, sys
+agg = collections.OrderedDict()
+for path in sys.argv[1:]:
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"]
+        if not any(t in name for t in ("kl_", "mmd_")):
+            continue
+        key = (name.split("(")[0][-60:], int(r["Grid_Size"]))
+        v = agg.setdefault(key, {}).setdefault(r["Counter_Name"], [0.0, 0])
+        v[0] += float(r["Counter_Value"]); v[1] += 1
+for (k, grid), d in agg.items():
+    rd = 2.0 * 1024.0 * d["FETCH_SIZE"][0] / d["FETCH_SIZE"][1] if "FETCH_SIZE" in d else float("nan")
+    wr = 1024.0 * d["WRITE_SIZE"][0] / d["WRITE_SIZE"][1] if "WRITE_SIZE" in d else float("nan")
+    n = d.get("FETCH_SIZE", d.get("WRITE_SIZE"))[1]
+    print(f"{k} grid={grid}: launches {n}, HBM read {rd/1e6:.2f} MB, write {wr/1e6:.2f} MB per launch")
