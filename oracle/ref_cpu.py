@@ -797,6 +797,36 @@ def latents_to_dit_input(tokens: Tensor, latent_mean: float, latent_scale: float
     return x.reshape(b, h, h, c).permute(0, 3, 1, 2)
 
 
+def diffusion_train_steps(latents: Tensor, labels: Tensor, p: P, trainable: Sequence[str], draws: Sequence[Tuple[Tensor, Tensor, Tensor]], num_heads: int,
+                          num_classes: int, lr: float = 1e-4, max_norm: float = 1.0, ema_decay: float = 0.9999, q: Q = None,
+                          on_grads: Optional[Callable[[int, Dict[str, Tensor]], None]] = None):
+    """The loop body of train_diffusion.py:288-297 on given latents (the frozen encode + normalisation of :276-287 is `latents_to_dit_input`), once per entry of
+    `draws` = (t, x0, dropped): transport.training_losses (transport.py:119-164: ICPlan xt / ut, the model in train mode -- a dropped label becomes the
+    unconditional class `num_classes`, lightningdit.py:156-163 --, per-sample mean squared error) -> mean over the batch (:290) -> backward -> clip_grad_norm_ (:293)
+    -> AdamW(betas (0.9, 0.95), eps 1e-8, weight_decay 0; :209) at a constant rate -> update_ema (:137-147).  p is updated functionally; returns
+    (per-step (loss, gradient norm), parameters, EMA of the trainable parameters).  Pinned by tests/golden/diffusion_step_small.npz."""
+    p = dict(p)
+    m = {k: torch.zeros_like(p[k]) for k in trainable}
+    v = {k: torch.zeros_like(p[k]) for k in trainable}
+    ema = {k: p[k].detach().clone() for k in trainable}
+    logs = []
+    for step, (t, x0, dropped) in enumerate(draws):
+        pp = {k: (val.detach().clone().requires_grad_(True) if k in trainable else val) for k, val in p.items()}
+        y = torch.where(dropped, torch.full_like(labels, num_classes), labels)
+        xt, _ = transport_plan(t, x0, latents)
+        out = lightningdit_forward(xt, t, y, pp, num_heads, 1, q=q)
+        loss = transport_loss(out, t, x0, latents).mean()
+        grads = torch.autograd.grad(loss, [pp[k] for k in trainable])
+        if on_grads is not None:
+            on_grads(step, dict(zip(trainable, grads)))
+        total, clipped = clip_grad_norm(grads, max_norm)
+        for k, g_ in zip(trainable, clipped):
+            p[k], m[k], v[k] = adamw_step(p[k], g_, m[k], v[k], step + 1, lr, wd=0.0)
+            ema[k] = ema_update(ema[k], p[k], ema_decay)
+        logs.append((float(loss.detach()), float(total)))
+    return logs, p, ema
+
+
 def dit_output_to_latents(samples: Tensor, latent_mean: float, latent_scale: float) -> Tensor:
     """sample_50k.py:143-148: [B, C, h, w] -> [B, h*w, C] tokens / scale + mean."""
     b, c, h, w = samples.shape

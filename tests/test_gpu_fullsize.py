@@ -166,3 +166,77 @@ def test_dmd_stage_full_size_cycle_c3():
     print(f"C3 full size: peak {peak:.1f} GiB, last log {logs[-1]}")
     snaps2, logs2, peak2, final2, _ = run()
     assert snaps == snaps2 and torch.equal(final[0], final2[0]) and torch.equal(final[1], final2[1])       # bit-identical reruns
+
+
+def test_diffusion_stage_full_size_c4():
+    """Config C4 at its real size (train_diffusion.py:268-297; scripts/train_diffusion.sh: local batch 64): `DiffusionTrainer` with the ViT-L/16 encoder frozen and
+    LightningDiT-XL/1 (675 M parameters) trained on its latents.  Three steps from fixed seeds, run twice: finite losses that fall, a positive gradient norm, the
+    weights moving every step, bit-identical reruns, the peak memory DESIGN.md quotes (< 56 GiB); and ADDITIVITY of the gradient over the batch: the flat
+    gradient of one B = 64 step equals the mean of the two B = 32 half-batch gradients at the same weights and draws (every loss term is a per-sample mean,
+    transport.py:143 -- a kernel that mixed samples, mis-scaled the batch mean or dropped a row block would break it) to bf16 accumulation-order accuracy."""
+    import gc
+    import warnings
+    from dmvae_amd.models.lightningdit import LightningDiT_models
+    from dmvae_amd.models.vae import VAE
+    from dmvae_amd.train import DiffusionTrainer
+    B = 64
+
+    def build():
+        torch.manual_seed(42)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            vae = VAE(z_channels=32, model_size="large").cuda().eval()
+        dit = LightningDiT_models["LightningDiT-XL/1"](input_size=16, in_channels=32, num_classes=1000, use_checkpoint=True).cuda()      # :62,188 (accepted; see INTEGRATION.md)
+        with torch.no_grad():
+            for blk in dit.blocks:
+                blk.adaLN_modulation[1].weight.normal_(0, 0.02)
+            dit.final_layer.linear.weight.normal_(0, 0.02)
+        return DiffusionTrainer(dit, vae, lr=1e-4, latent_mean=0.0685, latent_scale=0.1763)
+
+    images = torch.rand(B, 3, 256, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 2 - 1
+    labels = torch.randint(0, 1000, (B,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+
+    def run():
+        tr = build()
+        torch.manual_seed(7)
+        torch.cuda.reset_peak_memory_stats()
+        logs, sums = [], []
+        for _ in range(3):
+            tr.step(images, labels)
+            tr.wait_optimizers()
+            logs.append(tr.read_log())
+            sums.append(tr.fp.flat.double().sum().item())
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+        final = tr.fp.flat.clone()
+        del tr
+        gc.collect(); torch.cuda.empty_cache()
+        return logs, sums, peak, final
+
+    logs, sums, peak, final = run()
+    assert all(v == v and 0 < v < 1e4 for lg in logs for v in lg.values()), logs
+    assert logs[2]["loss"] < logs[0]["loss"] and len(set(sums)) == 3
+    assert peak < 56.0, f"peak memory {peak:.1f} GiB"
+    print(f"C4 full size: peak {peak:.1f} GiB, logs {logs}")
+    logs2, sums2, _, final2 = run()
+    assert sums == sums2 and torch.equal(final, final2) and logs == logs2            # bit-identical reruns
+    del final, final2
+    # ---- additivity over two half batches (lr 0: the weights stay put; label drop-out off so that the halves draw nothing the whole does not) ----
+    tr = build()
+    tr.opt.lr = 0.0
+    tr.model.y_embedder.dropout_prob = 0.0
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x0 = torch.randn(B, 32, 16, 16, device="cuda", generator=g)
+    t = torch.rand(B, device="cuda", generator=g)
+    orig = tr.transport.sample
+
+    def grads_of(sl):
+        tr.transport.sample = lambda x1: (t[sl].to(x1), x0[sl].to(x1), x1)
+        tr.step(images[sl], labels[sl])
+        tr.wait_optimizers()
+        return tr.fp.grad.clone()
+    whole = grads_of(slice(0, B))
+    halves = 0.5 * (grads_of(slice(0, B // 2)).double() + grads_of(slice(B // 2, B)).double())
+    tr.transport.sample = orig
+    rel = ((whole.double() - halves).norm() / halves.norm()).item()
+    print(f"C4 full size: |g(B) - mean(g(B/2), g(B/2))| / |.| = {rel:.2e}")
+    assert rel < 5e-3, rel          # bf16 gradients, f32 accumulation in another order (M = 16384 against two of 8192: other tiles, other split points)
