@@ -32,12 +32,21 @@ class WtEntry(Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("N", c_int32), ("K", c_int32), ("start", c_uint), ("tiles_x", c_uint)]
 
 
-ABI_VERSION = 8     # 8: dmvae_reparam_kl_*, dmvae_linear_bf16_sk*; 7: dmvae_linear_wgrad_grouped_plan / _xcd, dmvae_conv_k4c1_*; 6: dmvae_dit_stack_* / dmvae_dit_boundary_bwd / batched rows Linears / batched weight transposes; 5: dmvae_groupnorm_*_short; include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*; 4: dmvae_norm_conv_out_bwd*)
+ABI_VERSION = 8     # 8: dmvae_reparam_kl_*, dmvae_linear_bf16_sk*, the f32 transformer steps of csrc/parity_dit.hip; 7: dmvae_linear_wgrad_grouped_plan / _xcd, dmvae_conv_k4c1_*; 6: dmvae_dit_stack_* / dmvae_dit_boundary_bwd / batched rows Linears / batched weight transposes; 5: dmvae_groupnorm_*_short; include/dmvae_hip.h: dmvae_abi_version (3: struct dmvae_pack_entry, dmvae_pack_weights_batched, dmvae_linear_bf16*; 4: dmvae_norm_conv_out_bwd*)
 
 # name -> (restype, argtypes); every symbol include/dmvae_hip.h declares
 SIGNATURES = {
     "dmvae_last_error": (c_char_p, []),
     "dmvae_abi_version": (c_int, []),
+    "dmvae_rms_modulate_fwd_f32": (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_int, c_int, c_float, c_void_p]),
+    "dmvae_rms_modulate_bwd_f32": (c_int, [c_void_p] * 8 + [c_size_t, c_int, c_int, c_int, c_void_p]),
+    "dmvae_layernorm_bwd_full_f32": (c_int, [c_void_p] * 5 + [c_size_t, c_int, c_float, c_void_p]),
+    "dmvae_bcast_rows_f32": (c_int, [c_int] + [c_void_p] * 4 + [c_size_t, c_int, c_int, c_int, c_void_p]),
+    "dmvae_colsum_groups_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dmvae_swiglu_fwd_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "dmvae_swiglu_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "dmvae_qknorm_rope_fwd_f32": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_void_p]),
+    "dmvae_qknorm_rope_bwd_f32": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p]),
     "dmvae_reparam_kl_workspace": (c_size_t, [c_size_t, c_int]),
     "dmvae_reparam_kl_fwd": (c_int, [c_void_p] * 5 + [c_size_t, c_size_t, c_int, c_int, c_void_p]),
     "dmvae_reparam_kl_bwd": (c_int, [c_void_p] * 4 + [c_float, c_void_p, c_size_t, c_int, c_int, c_void_p]),

@@ -526,8 +526,9 @@ class ConvK4Fn(torch.autograd.Function):
         if act == ops.ACT_LEAKY:
             dy = ops.leaky_relu_bwd(dy, y)
         cpad = cout if cout % 32 == 0 else (cout + 31) // 32 * 32
-        if cpad != cout or dy.dtype != bf16:
-            dyp = torch.zeros(dy.shape[0], dy.shape[1], dy.shape[2], cpad, dtype=bf16, device=dy.device)
+        adt = parity.act_dtype()                    # bf16; f32 in the fp32 parity mode (the gradient operand is split exactly there, not rounded)
+        if cpad != cout or dy.dtype != adt:
+            dyp = torch.zeros(dy.shape[0], dy.shape[1], dy.shape[2], cpad, dtype=adt, device=dy.device)
             dyp[..., :cout] = dy
             dy = dyp
         ho, wo = dy.shape[1], dy.shape[2]
@@ -604,6 +605,14 @@ class BatchNormActFn(torch.autograd.Function):
         dy3, x3 = _c(dy).view(1, -1, c), x.view(1, -1, c)
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dg = db = None
+        if parity.on():
+            # fp32 parity mode: the f32 GroupNorm backward (one "image", one channel per group) -- batch statistics of ONE rank only (the cross-rank sums and the
+            # constant-statistics form of an eval-mode discriminator are not needed by the 1e-4 tests and are refused rather than approximated)
+            if not batch_stats or group is not None:
+                raise NotImplementedError("BatchNormActFn backward in the fp32 parity mode: batch statistics on a single rank only")
+            dx, dg, db = parity.groupnorm_bwd(dy3.float(), x3, stats, gamma, beta, act, groups=c, need_param_grads=need_p, dg_out=_dst(gamma) if need_p else None,
+                                              db_out=_dst(beta) if need_p else None, inv_count=1.0 / count)
+            return (dx.view(x.shape) if ctx.needs_input_grad[0] else None), dg, db, None, None, None, None, None
         if batch_stats or need_p:
             sums, dg, db = ops.groupnorm_bwd_reduce(dy3, x3, stats, gamma, beta, act, groups=c, need_param_grads=need_p,
                                                     dg_out=_dst(gamma) if need_p else None, db_out=_dst(beta) if need_p else None)

@@ -284,6 +284,11 @@ class LightningDiT(nn.Module):
 
     def forward(self, x, t=None, y=None):
         if x.is_cuda:
+            from .. import parity
+            if parity.on():          # fp32 parity mode: f32 activations, split-operand GEMMs, f32 elementwise kernels -- forward and backward (lightningdit_parity.py)
+                from . import lightningdit_parity
+                if lightningdit_parity.structurally_supported(self):
+                    return lightningdit_parity.forward_parity(self, x, t, y)
             from . import lightningdit_fast
             if lightningdit_fast.supported(self, x):
                 if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):

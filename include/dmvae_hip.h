@@ -722,6 +722,34 @@ int dmvae_lpips_diff_f32(const void* f0, const void* f1, const void* lin_w, void
 /* LayerNorm over the last dimension, f32 in / f32 out (timm ViT block reached through models/vae.py:47-53). */
 int dmvae_layernorm_f32(const void* x, const void* gamma, const void* beta, void* y, int rows, int cols, float eps, dmvae_stream_t stream);
 
+/* ---- fp32 parity mode, transformer rows (csrc/parity_dit.hip): the elementwise / normalisation steps of LightningDiT and of the trainable ViT block, forward and
+ * backward, f32 in / f32 out with f64 row statistics -- with them (and the split-operand GEMMs) dmvae_amd/models/lightningdit_parity.py reaches 1e-4 against the
+ * reference's f32 captures.  A verification mode, not a training mode.  `shift` / `scale` / `g` are chunks of an adaLN output [B][ld_mod] (pointer at the chunk). */
+
+/* y = x * rstd * w * (1 + scale[b]) + shift[b], rstd [rows] kept (scale / shift may be NULL).  Reference: rms_norm.py:52-76 + modulate, lightningdit.py:27-31,241-250. */
+int dmvae_rms_modulate_fwd_f32(const void* x, const void* w, const void* shift, const void* scale, void* y, void* rstd, size_t rows, int c,
+                               int rows_per_sample, int ld_mod, float eps, dmvae_stream_t stream);
+/* dx; gw = dy * xh * (1 + scale) (column sum = d w); gs = dy * xh * w (per-sample column sum = d scale; with scale).  Reference: the backward of rms_norm.py:52-76 / lightningdit.py:27-31. */
+int dmvae_rms_modulate_bwd_f32(const void* dy, const void* x, const void* w, const void* scale, const void* rstd, void* dx, void* gw, void* gs,
+                               size_t rows, int c, int rows_per_sample, int ld_mod, dmvae_stream_t stream);
+/* LayerNorm backward: dx, gw = dy * xh (column sum = d gamma; d beta = column sum of dy).  Reference: timm Block's norm1 / norm2 through models/vae.py:47-53, trained at train_dmd.py:518-520. */
+int dmvae_layernorm_bwd_full_f32(const void* dy, const void* x, const void* gamma, void* dx, void* gw, size_t rows, int c, float eps, dmvae_stream_t stream);
+/* op 0: out = a + g[b] * b (gated residual, lightningdit.py:245,249)   op 1: out = g[b] * a   op 2: out = a * b. */
+int dmvae_bcast_rows_f32(int op, const void* a, const void* b, const void* g, void* out, size_t rows, int c, int rows_per_sample, int ld_mod,
+                         dmvae_stream_t stream);
+/* out [groups][c] (+)= sum over the rows of x [groups][rows][c], f64, row order: the per-sample / per-parameter sums of the backward (lightningdit.py:241-250 adaLN chunks, norm weights). */
+int dmvae_colsum_groups_f32(const void* x, void* out, int groups, int rows, int c, int accumulate, dmvae_stream_t stream);
+/* g = silu(x1) * x2 over [rows][2 hidden] = [x1 | x2], and its backward.  Reference: swiglu_ffn.py:31-36. */
+int dmvae_swiglu_fwd_f32(const void* x12, void* g, size_t rows, int hidden, dmvae_stream_t stream);
+int dmvae_swiglu_bwd_f32(const void* dg, const void* x12, void* dx12, size_t rows, int hidden, dmvae_stream_t stream);
+/* QK RMSNorm + RoPE: qkv [B][N][3][H][D] -> q, k, v [B*H][N][d_pad] (zero columns past D), rstd [2][B*N*H]; backward -> dqkv, gwq / gwk [B*N*H][D] (column sums = d w).
+ * Reference: lightningdit.py:66-88 (q_norm / k_norm, rope), pos_embed.py:37-41,135. */
+int dmvae_qknorm_rope_fwd_f32(const void* qkv, const void* wq, const void* wk, const void* cosb, const void* sinb, void* q, void* k, void* v, void* rstd,
+                              int batch, int tokens, int heads, int d, int d_pad, float eps, dmvae_stream_t stream);
+int dmvae_qknorm_rope_bwd_f32(const void* dq, const void* dk, const void* dv, const void* qkv, const void* wq, const void* wk, const void* cosb,
+                              const void* sinb, const void* rstd, void* dqkv, void* gwq, void* gwk, int batch, int tokens, int heads, int d, int d_pad,
+                              dmvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -244,3 +244,135 @@ def test_step_small_vs_reference_f32(fixture):
     # tol_ema: after four steps the EMA differs from the initial weights by ONE f32 ulp (4.8e-7 at |w| >= 4) in a handful of entries; whether that ulp
     # flips depends on the blend being one fused multiply-add (csrc/optim.hip) or two rounded operations (torch's mul_ / add_): allow that one ulp
     check_step_small(g, logs, p0, p1, ema, names, steps - 1, tol_loss=TOL, tol_norm=TOL, tol_abs_delta=2e-3, tol_signed=2e-2, min_cos=0.999, tol_ema=1.0)
+
+
+# ---- transformer and discriminator rows at 1e-4: LightningDiT forward + backward, the C4 step's forward / backward, PatchGAN ----
+@pytest.mark.parametrize("tag", ["dit_small_hd64w", "dit_small_hd72"])
+def test_lightningdit_fwd_bwd_vs_reference_f32(tag):
+    """LightningDiT.forward and its whole backward (lightningdit.py:173-252,393-421) on the fp32 parity route (models/lightningdit_parity.py: split-operand MFMA
+    GEMMs for every Linear and both attention contractions, the f32 kernels of csrc/parity_dit.hip for RMSNorm + modulate, the gated residual, QK-norm + RoPE,
+    SwiGLU and their backward) against the reference's own capture (oracle/capture_golden_dit.py): output, input gradient, the six fully captured parameter
+    gradients element by element, and the norm AND sum of EVERY parameter's gradient -- all at 1e-4."""
+    import numpy as np
+    from test_oracle_dit import build
+    g = load_golden(tag)
+    m = build(tag, g).to(DEV)
+    x = g.t("x").to(DEV).requires_grad_(True)
+    out = m(x, g.t("t").to(DEV), torch.from_numpy(np.asarray(g["y"])).to(DEV))          # no autocast: the parity route is f32 end to end
+    assert out.dtype == torch.float32
+    out.backward(g.t("dy").to(DEV))
+    assert rel_err(out.detach().cpu(), g.t("out")) < TOL and elem_err(out.detach().cpu(), g.t("out")) < TOL
+    assert rel_err(x.grad.cpu(), g.t("dx")) < TOL and elem_err(x.grad.cpu(), g.t("dx")) < TOL
+    grads = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    full = [k[2:] for k in g.keys() if k.startswith("g.")]
+    assert len(full) >= 6
+    for n in full:
+        assert rel_err(grads[n].cpu(), g.t("g." + n)) < TOL, n
+        assert elem_err(grads[n].cpu(), g.t("g." + n)) < TOL, n
+    checked = 0
+    for n, p in m.named_parameters():
+        if "gn." + n not in g:
+            continue
+        norm, ssum = float(g["gn." + n][0]), float(g["gn." + n][1])
+        if norm < 1e-6:
+            continue
+        gd = grads[n].double()
+        assert abs(gd.norm().item() - norm) < TOL * norm, (n, gd.norm().item(), norm)
+        assert abs(gd.sum().item() - ssum) < TOL * max(abs(ssum), norm), (n, gd.sum().item(), ssum)      # a sum of mixed signs: relative to the gradient's size
+        checked += 1
+    assert checked >= 30
+
+
+def test_diffusion_step_forward_backward_vs_reference_f32():
+    """Config C4's forward / backward (train_diffusion.py:276-292 as captured by oracle/capture_golden_diffusion.py: frozen encode -> latent normalisation ->
+    transport.training_losses with LightningDiT in train mode -> backward) in the parity mode: the normalised latents (encoder on the split-operand route), the
+    per-sample losses and the batch loss, the nine fully captured gradients and the gradient norm + sum of every parameter at 1e-4; then the whole first step
+    through DiffusionTrainer (clip, AdamW, EMA on the kernels) at the tolerances tests/test_oracle_diffusion.py holds the CPU oracle to."""
+    import numpy as np
+    from dmvae_amd.models.vae import VAE
+    from dmvae_amd.train import DiffusionTrainer
+    from test_oracle_diffusion import DIT_KW as KW, SMALL, check_diffusion_steps, diffusion_step_inputs
+    g = load_golden("diffusion_step_small")
+    pv, dit, images, labels, draws = diffusion_step_inputs(g)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vae = VAE(z_channels=32, model_size="base", encoder_kwargs=dict(embed_dim=256, depth=2, num_heads=4))
+    vae.load_state_dict(pv, strict=True)
+    vae, dit = vae.to(DEV).eval(), dit.to(DEV)
+    names = [str(n) for n in g["names"]]
+    p0 = {k: v.detach().cpu().clone() for k, v in dit.named_parameters()}
+    tr = DiffusionTrainer(dit, vae, lr=float(g["lr"]), latent_mean=float(g["latent_mean"]), latent_scale=float(g["latent_scale"]))
+    x = tr.latents(images.to(DEV))
+    assert x.dtype == torch.float32 and rel_err(x.cpu(), g.t("latents")) < TOL
+    logs = []
+    orig_sample, orig_drop = tr.transport.sample, dit.y_embedder.token_drop
+    for step, (t, x0, dropped) in enumerate(draws):
+        tr.transport.sample = lambda x1, t=t, x0=x0: (t.to(x1), x0.to(x1), x1)
+        dit.y_embedder.token_drop = lambda lab, force_drop_ids=None, d=dropped: torch.where(d.to(lab.device), torch.full_like(lab, KW["num_classes"]), lab)
+        if step == 0:        # the forward / backward alone first: per-sample losses and every gradient
+            dit.train()
+            _, terms = tr.transport.training_losses(dit, x, dict(y=labels.to(DEV)))
+            assert rel_err(terms["loss"].detach().cpu(), g.t("loss_per_sample0")) < TOL
+            assert rel_err(terms["pred"].detach()[:, ::4, ::4, ::4].cpu(), g.t("pred0_slice")) < TOL
+            grads = torch.autograd.grad(terms["loss"].mean(), [p for p in dit.parameters() if p.requires_grad])
+            gmap = dict(zip([n for n, p in dit.named_parameters() if p.requires_grad], grads))
+            for k in SMALL:
+                assert rel_err(gmap[k].cpu(), g.t("g0." + k)) < TOL, k
+                assert elem_err(gmap[k].cpu(), g.t("g0." + k)) < TOL, k
+            for k, gr in gmap.items():
+                norm, ssum = float(g["gn0." + k][0]), float(g["gn0." + k][1])
+                if norm > 1e-6:
+                    assert abs(gr.double().norm().item() - norm) < TOL * norm, k
+                    assert abs(gr.double().sum().item() - ssum) < TOL * max(abs(ssum), norm), k
+        tr.step(images.to(DEV), labels.to(DEV))
+        lg = tr.read_log()
+        logs.append((lg["loss"], lg["grad_norm"]))
+    tr.transport.sample, dit.y_embedder.token_drop = orig_sample, orig_drop
+    by_id = {id(q): n for n, q in dit.named_parameters()}
+    p1 = {k: q.detach().cpu() for k, q in dit.named_parameters()}
+    ema = {by_id[id(q)]: e.detach().cpu() for q, e in zip(tr.fp.params, tr.fp.ema_state())}
+    check_diffusion_steps(g, logs, p0, p1, ema, names, tol_loss=TOL, tol_norm=TOL, tol_abs_delta=2e-3, tol_signed=2e-2, min_cos=0.999, tol_ema=1.0)
+
+
+def test_patchgan_vs_reference_f32():
+    """NLayerDiscriminator (models/patchgan.py:125-147) in the parity mode against the reference's capture: eval-mode logits (running statistics), train-mode
+    logits (batch statistics), the running-estimate update, the input gradient and every captured parameter gradient at 1e-4 -- 4x4 stride-2 / stride-1 convs and
+    their input / weight gradients on the split-operand conv kernels, BatchNorm + LeakyReLU forward and backward on the f32 GroupNorm kernels."""
+    from test_oracle_gan import patchgan_params
+    from dmvae_amd.models.patchgan import NLayerDiscriminator
+    g = load_golden("patchgan_small")
+    p = patchgan_params(g, int(g["seed"]))
+    disc = NLayerDiscriminator()
+    sd = disc.state_dict()
+    for k in sd:
+        if k in p:
+            sd[k] = p[k].clone()
+    disc.load_state_dict(sd, strict=True)
+    disc = disc.to(DEV)
+    x = g.t("x").to(DEV)
+    disc.eval()
+    with torch.no_grad():
+        y_eval = disc(x)
+    assert rel_err(y_eval.cpu(), g.t("y_eval")) < TOL
+    disc.train()
+    xg = x.clone().requires_grad_(True)
+    y = disc(xg)
+    y.backward(g.t("dy").to(DEV))
+    assert rel_err(y.detach().cpu(), g.t("y")) < TOL and elem_err(y.detach().cpu(), g.t("y")) < TOL
+    assert rel_err(xg.grad.cpu(), g.t("dx")) < TOL
+    sd = disc.state_dict()
+    for k in [k[5:] for k in g.keys() if k.startswith("buf1.") and "num_batches" not in k]:
+        assert rel_err(sd[k].cpu(), g.t("buf1." + k)) < TOL, k
+    checked = 0
+    for n, prm in disc.named_parameters():
+        if "g." + n in g:
+            ref = g.t("g." + n)
+            if ref.abs().max() < 1e-5:       # a conv bias in front of a BatchNorm (main.2 / 5 / 8): its gradient is analytically zero, rounding noise on both sides
+                assert prm.grad.abs().max() < 1e-5, n
+                continue
+            assert rel_err(prm.grad.cpu(), ref) < TOL, n
+            checked += 1
+        if "gn." + n in g and float(g["gn." + n][0]) > 1e-5:
+            norm = float(g["gn." + n][0])
+            assert abs(prm.grad.double().norm().item() - norm) < TOL * norm, n
+    assert checked >= 5
