@@ -99,9 +99,10 @@ class DinoV2ViT(nn.Module):
             from .vit_fast import frozen_forward_features, hip_path_supported, trainable_forward_features
             from .. import parity
             if parity.on():
-                # fp32 parity mode: f32 activations, every contraction on the MFMA kernels over exactly-split operands (any width); forward only
+                # fp32 parity mode: f32 activations, every contraction on the MFMA kernels over exactly-split operands (any width)
                 if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-                    raise NotImplementedError("DMVAE_PARITY=1 covers the frozen encoder (train_tokenizer.py:295-297); run the ViT under no_grad / freeze_encoder")
+                    from .vit_parity import forward_features_parity        # the trainable encoder of the DMD stage (train_dmd.py:518-520): forward + backward in f32
+                    return forward_features_parity(self, x)
                 from .vit_fast import parity_forward_features
                 return parity_forward_features(self, x)
             if hip_path_supported(self, self.pos_embed.shape[1]):

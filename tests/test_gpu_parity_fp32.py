@@ -376,3 +376,38 @@ def test_patchgan_vs_reference_f32():
             norm = float(g["gn." + n][0])
             assert abs(prm.grad.double().norm().item() - norm) < TOL * norm, n
     assert checked >= 5
+
+
+def test_vit_trainable_fwd_bwd_vs_reference_f32():
+    """The trainable encoder of the DMD stage (train_dmd.py:349,518-520; the ViT reached through models/vae.py:47-53) in the parity mode: forward_features and its
+    whole backward (models/vit_parity.py) against the capture taken from the reference's own models/dinov2.py (oracle/capture_golden_vit.py, embed 256, 2 blocks,
+    257 tokens -- the 272-key padded attention included): tokens, the image gradient (slice + norm), the ten fully captured parameter gradients element by
+    element and the gradient norm of EVERY parameter at 1e-4."""
+    from test_oracle_vit import vit_fixture
+    g, vit, p, x = vit_fixture("vit_w256")
+    vit = vit.to(DEV).train()
+    dy = torch.randn(g["out"].shape, generator=torch.Generator().manual_seed(int(g["dy_seed"])))
+    xg = x.to(DEV).requires_grad_(True)
+    out = vit.forward_features(xg)
+    assert out.dtype == torch.float32
+    (out * dy.to(DEV)).sum().backward()
+    assert rel_err(out.detach().cpu(), g.t("out")) < TOL and elem_err(out.detach().cpu(), g.t("out")) < TOL
+    assert rel_err(xg.grad[:, :, ::16, ::16].cpu(), g.t("dx_slice")) < TOL
+    assert abs(xg.grad.double().norm().item() - float(g["dx_norm"])) < TOL * float(g["dx_norm"])
+    grads = dict(vit.named_parameters())
+    checked = 0
+    for n, gn in zip(g["names"], g["gnorm"]):
+        n, gn = str(n), float(gn)
+        got = grads[n].grad
+        assert got is not None, n
+        if gn < 1e-6:
+            continue
+        assert abs(got.double().norm().item() - gn) < TOL * gn, (n, got.double().norm().item(), gn)
+        checked += 1
+    assert checked >= 30
+    for k in [k for k in g.keys() if k.startswith("g.")]:
+        ref = g.t(k)
+        if ref.abs().max() < 1e-6:
+            continue
+        assert rel_err(grads[k[2:]].grad.cpu(), ref) < TOL, k
+        assert elem_err(grads[k[2:]].grad.cpu(), ref) < TOL, k
