@@ -611,6 +611,9 @@ def main():
     if world == 1:
         out["kl_mmd"] = kl_mmd_roofline(dev)
     del tr, images
+    if world == 1 and not args.no_secondary and os.environ.get("DMVAE_FORCE_DIST", "0") == "0":
+        torch.cuda.empty_cache()
+        out["comm_n1"] = comm_n1_overhead(out["ms_per_step"])
     torch.cuda.empty_cache()
     if world == 1 and not args.no_secondary:
         try:
@@ -631,6 +634,46 @@ def _flush_c_stdio() -> None:
         ctypes.CDLL(None).fflush(None)
     except OSError:
         pass
+
+
+def comm_n1_overhead(headline_ms: float) -> dict:
+    """What the data-parallel machinery costs BEFORE any byte moves between GPUs, measured on this one GPU (no multi-GPU node was available to any round; the first
+    real SCALE line has this term of DESIGN.md 4's budget to be held against): the same C2 step in a fresh process with a real RCCL group of ONE rank
+    (DMVAE_FORCE_DIST=1: post-accumulate hooks, four bucketed all-reduces with ncclAvg, wait() before the optimiser) and dynamic tile claiming in the persistent
+    conv kernels (DMVAE_PP_DYNAMIC=1: what dist.init_distributed_mode switches on under DP, because a collective's resident kernel takes CUs).  Also records which
+    RCCL the box runs and whether NCCL_ALGO / NCCL_PROTO pin the all-reduce's algorithm (unset = RCCL's tuner decides per message size)."""
+    import re
+    import socket
+    import subprocess
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DMVAE_FORCE_DIST="1", DMVAE_PP_DYNAMIC="1",
+               NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,COLL,TUNING")
+    res = {"what": "C2 step with a one-rank RCCL group + dynamic tile claiming, fresh process, 10 steps after 3", "headline_ms": round(headline_ms, 3)}
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-secondary"], env=env,
+                           capture_output=True, text=True, timeout=400)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            res["error"] = (r.stderr or r.stdout)[-300:]
+            return res
+        sub = json.loads(lines[-1])
+        res["forced_ms"] = sub["ms_per_step"]
+        res["overhead_ms"] = round(sub["ms_per_step"] - headline_ms, 3)
+        res["comm"] = sub.get("comm")
+        info = [l for l in (r.stdout + "\n" + r.stderr).splitlines() if "NCCL INFO" in l]
+        pick = [re.sub(r"^.*NCCL INFO ", "", l)[:160] for l in info if re.search(r"(?i)\b(algo|proto|ring|tree|channel|version|AllReduce)", l)]
+        res["rccl_info"] = pick[:6]
+    except Exception as e:      # noqa: BLE001 -- a diagnostic key must not cost the headline line
+        res["error"] = f"{type(e).__name__}: {e}"[:300]
+    try:
+        res["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:            # noqa: BLE001
+        res["rccl_version"] = None
+    res["NCCL_ALGO"], res["NCCL_PROTO"] = os.environ.get("NCCL_ALGO", "unset (tuner)"), os.environ.get("NCCL_PROTO", "unset (tuner)")
+    return res
 
 
 def _emit(line: str, rank0: bool) -> None:

@@ -166,7 +166,8 @@ class FlatGradSync:
     params   : trainable parameters in the order their gradients become ready in backward (first-ready first);
                their .grad are views into `flat_grad` in that same order.
     The hook on each parameter fires after its gradient has been accumulated; when every parameter of a bucket
-    has fired, the bucket's slice is divided by world_size and all-reduced (SUM) with async_op=True.
+    has fired, the bucket's slice is averaged over the ranks with async_op=True: ReduceOp.AVG under RCCL (the division happens inside the collective), divide +
+    SUM under gloo.
     `wait()` must be called before the optimiser reads the gradients.
     """
 
@@ -189,6 +190,9 @@ class FlatGradSync:
         self._pending = [b[2] for b in self.buckets]
         self._works = []
         self._handles = []
+        # the mean over ranks: RCCL / NCCL average INSIDE the collective (ncclAvg) -- no `div_` launch per bucket on the compute stream (42 per student step of the
+        # DMD stage); gloo has no AVG: divide, then SUM (the CPU tests' transport)
+        self.avg_in_collective = bool(self.enabled and tdist.get_backend() == "nccl" and os.environ.get("DMVAE_DIST_AVG", "1") != "0")
         self.hook_launches = 0      # buckets whose all-reduce was started from a gradient hook, i.e. DURING backward, in the last step
         self._in_wait = False
         self.time_wait = False      # bench.py: bracket wait() with events on the compute stream -- what of the collectives backward did NOT cover
@@ -211,6 +215,9 @@ class FlatGradSync:
             self.hook_launches += 1
         s, e, _ = self.buckets[b]
         sl = self.flat_grad[s:e]
+        if self.avg_in_collective:
+            self._works.append(tdist.all_reduce(sl, op=tdist.ReduceOp.AVG, async_op=True))
+            return
         sl.div_(self.world)
         self._works.append(tdist.all_reduce(sl, op=tdist.ReduceOp.SUM, async_op=True))
 
@@ -247,7 +254,8 @@ class FlatGradSync:
             ms = sum(v) / len(v)
             self._wait_events.clear()
         return {"bytes": int(self.buckets[-1][1]) * 4 if self.buckets else 0, "buckets": len(self.buckets),
-                "launched_in_backward": int(self.last_hook_launches), "wait_ms": None if ms is None else round(ms, 4)}
+                "launched_in_backward": int(self.last_hook_launches), "wait_ms": None if ms is None else round(ms, 4),
+                "mean": "ncclAvg inside the all-reduce" if self.avg_in_collective else "div_ per bucket, then SUM"}
 
     def remove(self):
         for h in self._handles:

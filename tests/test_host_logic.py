@@ -371,3 +371,11 @@ def test_reparam_kl_spec_closed_forms():
     klm.backward()
     g = mom.grad
     assert (g[:, :8] - m / 400).abs().max() < 1e-15 and (g[:, 8:] - 0.5 * (s2 - 1) / 400).abs().max() < 1e-15
+
+
+def test_integration_md_fits_a_160_column_view():
+    """tools/wrap_md.py --check: outside code fences no line of INTEGRATION.md is longer than 160 characters (long tables are wrapped bullet lists)."""
+    import subprocess, sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wrap_md.py"), os.path.join(ROOT, "INTEGRATION.md"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
