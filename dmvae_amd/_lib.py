@@ -65,6 +65,7 @@ SIGNATURES = {
     "dmvae_linear_bf16_splitk_supported": (c_int, [c_int] * 4),
     "dmvae_linear_bf16_splitk": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
     "dmvae_splitk_sum_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "dmvae_linear_bf16_swiglu_pre": (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
     "dmvae_linear_bf16_sk_supported": (c_int, [c_int] * 4),
     "dmvae_linear_bf16_sk_counter_bytes": (c_size_t, []),
     "dmvae_linear_bf16_sk_workspace": (c_size_t, [c_int] * 4),

@@ -51,6 +51,10 @@ struct Args {
   float* slabs;              // [2 V][TM x TP] f32 partial tiles, each in its writer's register layout
   unsigned* counters;        // [tiles][8 waves] arrival counts; zero on entry, left zero
   unsigned slab_bytes;
+  // act 6 only (dmvae_linear_bf16_swiglu_pre): the bf16-rounded PRE-activation [x1 | x2] is stored too ([M][ldy2], what the backward of SwiGLU reads) -- the
+  // w12 Linear and swiglu_ffn.py:32-35's product in one launch, no separate pass over the 2 H-wide tensor
+  void* y2;
+  int ldy2;
 };
 
 // Cache policy of the SK instantiation's partial-tile traffic (aux bits of the buffer builtins on gfx940+: 1 = sc0, 16 = sc1): sc0 sc1 = system scope -- the store
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, BATCHED ? a.xbytes : (unsigned)a.M * (unsigned)a.lda * 2u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)a.N * bsz : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, BATCHED ? a.ybytes : (unsigned)a.M * (unsigned)a.ldy * (OUT_F32 ? 4u : 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rY2 = __builtin_amdgcn_make_buffer_rsrc(a.y2, 0, a.y2 ? (unsigned)a.M * (unsigned)a.ldy2 * 2u : 0u, 0x00020000);
 
   // per-lane DMA source offsets of a tile: weight rows in the permuted order, token rows as they are, the bias slice (wave 0; 16 B per lane)
   auto calc = [&](unsigned work, unsigned (&vA)[NPA], unsigned (&vB)[NPB], unsigned& vBias, int& m0, int& n0, int& b0) {
@@ -477,6 +482,24 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
                 asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[i]) : "a"(acc[i][j][r]));
             }
             if constexpr (ACT == 6) {   // SwiGLU (swiglu_ffn.py:32-35): silu(x1) * x2 on the bf16-rounded halves, the product of bf16 values -- dit.hip::swiglu_kernel's bits
+              if constexpr (!OUT_F32 && !BATCHED && (CL == 8 || CL == 4)) {
+                if (a.y2) {   // the pre-activation as the unfused Linear would have stored it: x1 of the lane's CL / 2 hidden units at column hid, x2 at H + hid
+                  const int m2 = row0 + j * 16 + r;
+                  const bool ok2 = c_ok && m2 < a.M;
+                  const unsigned e1 = ((unsigned)m2 * (unsigned)a.ldy2 + (unsigned)col) * 2u, e2 = e1 + (unsigned)a.H * 2u;
+                  if constexpr (CL == 8) {
+                    const u32x2 p1 = {dmvae_pack_bf16x2(v[0], v[1]), dmvae_pack_bf16x2(v[2], v[3])}, p2 = {dmvae_pack_bf16x2(v[4], v[5]), dmvae_pack_bf16x2(v[6], v[7])};
+                    __builtin_amdgcn_raw_buffer_store_b64(p1, rY2, ok2 ? e1 : SENT, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(p2, rY2, ok2 ? e2 : SENT, 0, 0);
+                    asm volatile("s_nop 0" :: "v"(p1), "v"(p2));
+                  } else {
+                    const unsigned p1 = dmvae_pack_bf16x2(v[0], v[1]), p2 = dmvae_pack_bf16x2(v[2], v[3]);
+                    __builtin_amdgcn_raw_buffer_store_b32(p1, rY2, ok2 ? e1 : SENT, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(p2, rY2, ok2 ? e2 : SENT, 0, 0);
+                    asm volatile("s_nop 0" :: "v"(p1), "v"(p2));
+                  }
+                }
+              }
 #pragma unroll
               for (int i = 0; i < CL / 2; i++) {
                 const float x1 = (float)(bf16)v[i], x2 = (float)(bf16)v[CL / 2 + i];
@@ -724,7 +747,7 @@ extern "C" int dmvae_linear_bf16_batched(const void* x, const void* w, void* y, 
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = nullptr; a.y = y;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldy = ldy;
   a.act = 0; a.bias_bf16 = 0; a.H = N / 2; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = nullptr;
-  a.V = a.skS = a.T = 0; a.slabs = nullptr; a.counters = nullptr; a.slab_bytes = 0u;
+  a.V = a.skS = a.T = 0; a.slabs = nullptr; a.counters = nullptr; a.slab_bytes = 0u; a.y2 = nullptr; a.ldy2 = 0;
   a.wbytes = (unsigned)wb; a.xbytes = (unsigned)xb; a.ybytes = (unsigned)yb;
   a.wsRow = (unsigned)ldw * 2u; a.wsK = 64u;
   a.sA = (unsigned)(sw * 2); a.sB = (unsigned)(sx * 2); a.sY = (unsigned)(sy * (out_f32 ? 4 : 2));
@@ -770,7 +793,7 @@ extern "C" int dmvae_linear_bf16_splitk(const void* x, const void* w, void* slab
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = nullptr; a.y = slabs;
   a.M = M; a.N = N; a.K = Ks; a.lda = lda; a.ldw = ldw; a.ldy = N;
   a.act = 0; a.bias_bf16 = 0; a.H = N / 2; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = nullptr;
-  a.V = a.skS = a.T = 0; a.slabs = nullptr; a.counters = nullptr; a.slab_bytes = 0u;
+  a.V = a.skS = a.T = 0; a.slabs = nullptr; a.counters = nullptr; a.slab_bytes = 0u; a.y2 = nullptr; a.ldy2 = 0;
   a.wbytes = (unsigned)wb; a.xbytes = (unsigned)((long long)M * lda * 2); a.ybytes = (unsigned)((long long)splits * M * N * 4);
   a.wsRow = w_layout == 1 ? 64u : (unsigned)ldw * 2u;
   a.wsK = w_layout == 1 ? (unsigned)N * 64u : 64u;
@@ -849,14 +872,29 @@ extern "C" int dmvae_linear_bf16_sk(const void* x, const void* w, const void* bi
   a.wbytes = (unsigned)wb; a.tpb = 0; a.inv_tpb = 0.f; a.sA = a.sB = a.sY = a.xbytes = a.ybytes = 0u;
   a.wsRow = w_layout == 1 ? 64u : (unsigned)ldw * 2u;
   a.wsK = w_layout == 1 ? (unsigned)N * 64u : 64u;
+  a.y2 = nullptr; a.ldy2 = 0;
   a.counters = (unsigned*)workspace;
   a.slabs = (float*)((char*)workspace + SK_COUNTER_BYTES);
   a.slab_bytes = (unsigned)(need - SK_COUNTER_BYTES);
   return launch_sk(a, splits, stream);
 }
 
+static int linear_bf16_impl(const void* x, const void* w, const void* bias, void* y, void* y2, int ldy2, int M, int N, int K, int lda, int ldw, int ldy,
+                            int act, int bias_bf16, int out_f32, int w_layout, hipStream_t stream);
 extern "C" int dmvae_linear_bf16(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int lda, int ldw, int ldy,
                                  int act, int bias_bf16, int out_f32, int w_layout, hipStream_t stream) {
+  return linear_bf16_impl(x, w, bias, y, nullptr, 0, M, N, K, lda, ldw, ldy, act, bias_bf16, out_f32, w_layout, stream);
+}
+// SwiGLU FFN's first half in one launch: x12 [M][ldx12] = bf16(x w^T + bias) over the N = 2 H columns [x1 | x2] AND g [M][ldg] = silu(x1) * x2 over H columns --
+// what dmvae_linear_bf16 (act 0) followed by dmvae_swiglu_bf16 writes, bit for bit (the product is formed from the bf16-rounded halves), without the second pass
+// over the 2 H-wide tensor.  x12 is what the backward of SwiGLU reads.  Reference: swiglu_ffn.py:31-36 (w12, chunk, silu(x1) * x2).
+extern "C" int dmvae_linear_bf16_swiglu_pre(const void* x, const void* w, const void* bias, void* g, void* x12, int M, int N, int K, int lda, int ldw, int ldg,
+                                            int ldx12, int bias_bf16, int w_layout, hipStream_t stream) {
+  DMVAE_CHECK_ARG(x12 && ldx12 >= N && ldx12 % 8 == 0, "linear_bf16_swiglu_pre: x12 must be given with ldx12 >= N, a multiple of 8");
+  return linear_bf16_impl(x, w, bias, g, x12, ldx12, M, N, K, lda, ldw, ldg, 6, bias_bf16, 0, w_layout, stream);
+}
+static int linear_bf16_impl(const void* x, const void* w, const void* bias, void* y, void* y2, int ldy2, int M, int N, int K, int lda, int ldw, int ldy,
+                            int act, int bias_bf16, int out_f32, int w_layout, hipStream_t stream) {
   using namespace dmvae_gemm_pp;
   DMVAE_CHECK_ARG(x && w && y, "linear_bf16: null operand");
   DMVAE_CHECK_ARG(M > 0 && N > 0 && K >= 384 && K % 32 == 0 && N % 8 == 0, "linear_bf16: need K %% 32 == 0, K >= 384 and N %% 8 == 0 (M %d, N %d, K %d)", M, N, K);
@@ -872,7 +910,8 @@ extern "C" int dmvae_linear_bf16(const void* x, const void* w, const void* bias,
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.y = y;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldy = ldy;
   a.act = act; a.bias_bf16 = bias_bf16; a.H = N / 2; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = g_gemm_dbg;
-  a.V = a.skS = a.T = 0; a.slabs = nullptr; a.counters = nullptr; a.slab_bytes = 0u;
+  a.V = a.skS = a.T = 0; a.slabs = nullptr; a.counters = nullptr; a.slab_bytes = 0u; a.y2 = y2; a.ldy2 = ldy2;
+  DMVAE_CHECK_ARG(!y2 || (long long)M * ldy2 * 2 < (1ll << 31), "linear_bf16_swiglu_pre: x12 is addressed through 32-bit buffer offsets (2 GiB)");
   a.wbytes = (unsigned)wb; a.tpb = 0; a.inv_tpb = 0.f; a.sA = a.sB = a.sY = a.xbytes = a.ybytes = 0u;
   a.wsRow = w_layout == 1 ? 64u : (unsigned)ldw * 2u;
   a.wsK = w_layout == 1 ? (unsigned)N * 64u : 64u;

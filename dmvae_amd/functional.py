@@ -882,6 +882,23 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, a
     return y.reshape(*x.shape[:-1], y.shape[-1])
 
 
+SWIGLU_IN_W12 = os.environ.get("DMVAE_SWIGLU_IN_W12", "1") != "0"      # the training route's w12 Linear writes silu(x1) * x2 AND the pre-activation in one launch (0: Linear, then the swiglu pass; tests compare)
+
+
+def linear_swiglu(a2: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]):
+    """SwiGLUFFN's first half on the training route (swiglu_ffn.py:31-36): -> (x12 = bf16(a2 @ w12^T + b), g = silu(x1) * x2), both kept for the backward.  One launch of
+    the Linear GEMM with the gated epilogue that also stores the pre-activation (ops.linear_swiglu_pre) where the large-tile kernel takes the shape -- the bits of
+    the Linear followed by the swiglu pass, which is the fallback."""
+    k, n = a2.shape[-1], w.shape[0]
+    m = a2.numel() // k
+    if SWIGLU_IN_W12 and not parity.on() and a2.dtype == bf16 and n % 16 == 0 and ops.linear_supported(m, n, k) and not _use_splitk(m, n, k):
+        bb = None if b is None else (b if b.dtype == bf16 else _bf(b))
+        g, x12 = ops.linear_swiglu_pre(_c(a2), (w if w.dtype == bf16 else _bf(w)).view(n, k), bb)
+        return x12, g
+    x12 = linear(a2, w, b)
+    return x12, ops.swiglu(x12)
+
+
 WGRAD_GROUPED = True      # DitStackFn / VitBlockFn: the Linear weight gradients of a stack / block as ONE grouped launch (ops.linear_wgrad_grouped) instead of one split-K call each
 
 
@@ -906,6 +923,19 @@ def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Te
         dw, db = ops.conv2d_nhwc_wgrad(dy2.view(1, 1, rows, cout), x2.view(1, 1, rows, cin), 1,
                                        dw_out=None if dst_w is None else dst_w.view(cout, cin, 1, 1), db_out=_dst(b))
         dw = dw.view(cout, cin)
+    elif not parity.on():
+        # widths that are not multiples of 8 (the 2-D toy's embedders: 2 input / output channels, toy_example_2d/dmd.py:436-440): both operands zero-padded to the
+        # weight-gradient kernel's granule -- zero columns contribute zero rows / columns of dW, which are cut off
+        pc, pi = (-cout) % 8, (-cin) % 8
+        dwp, dbp = ops.conv2d_nhwc_wgrad(torch.nn.functional.pad(dy2, (0, pc)).view(1, 1, rows, cout + pc), torch.nn.functional.pad(x2, (0, pi)).view(1, 1, rows, cin + pi), 1)
+        dw, db = dwp.view(cout + pc, cin + pi)[:cout, :cin].contiguous(), (None if dbp is None else dbp[:cout].contiguous())
+        dst_w, dst_b = _dst(w), _dst(b)
+        if dst_w is not None:
+            dst_w.view(cout, cin).copy_(dw)
+            dw = dst_w.view(cout, cin)
+        if dst_b is not None and db is not None:
+            dst_b.copy_(db)
+            db = dst_b
     else:
         # widths that are not multiples of 8: no kernel of this build takes them -- a library GEMM only behind the explicit opt-in (no silent rocBLAS)
         from ._stock import require_opt_in
@@ -930,6 +960,12 @@ def _lin_grads(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: torch.Te
         pad = (-cout) % 32
         wt = torch.nn.functional.pad(_bf(w).t(), (0, pad)).contiguous()                   # [in, out + pad]
         return ops.gemm_nt(torch.nn.functional.pad(_c(dy2), (0, pad)), wt), dw, db
+    if not parity.on():
+        # in features not a multiple of 4 (the 2-D toy's 2-channel patch embedding): W^T zero-padded to the small batched kernel's granules -- output columns to 4,
+        # the reduction to 32 --, the padding columns cut off
+        pad_k, pad_n = (-cout) % 32, (-cin) % 4
+        wt = torch.nn.functional.pad(_bf(w).t(), (0, pad_k, 0, pad_n)).contiguous()          # [in + pad_n, out + pad_k]
+        return ops.gemm_nt(torch.nn.functional.pad(_c(dy2), (0, pad_k)), wt)[:, :cin].contiguous(), dw, db
     from ._stock import require_opt_in
     require_opt_in("functional._lin_grads (input gradient)", f"Linear {cout} x {cin}: the input-gradient GEMM kernels need in features % 4 == 0")
     return dy2 @ _bf(w), dw, db
@@ -1119,8 +1155,7 @@ class DitBlockFn(torch.autograd.Function):
             o = ops.gemm_nt(p, ops.transpose_last2(v)).view(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, c)
         o2 = linear(o, pw, pb)
         h_mid, a2 = ops.gated_residual_out(h, o2, mod, 2 * c, n2w, mod, 3 * c, 4 * c, eps)       # h itself is saved for the backward pass
-        x12 = linear(a2, w12w, w12b)
-        g = ops.swiglu(x12)
+        x12, g = linear_swiglu(a2, w12w, w12b)
         o3 = linear(g, w3w, w3b)
         h_out, _ = ops.gated_residual_out(h_mid, o3, mod, 5 * c)
         ctx.save_for_backward(h, mod, a1, qkv, q, k, v, p, o, o2, h_mid, a2, x12, g, o3, n1w, qkvw, qnw, knw, pw, n2w, w12w, w3w, cos, sin)
@@ -1262,8 +1297,7 @@ class DitStackFn(torch.autograd.Function):
                 o = ops.attention_heads(q, k, v, b, d ** -0.5)
             o2 = linear(o, pw, pb)
             h_mid, a2 = ops.gated_residual_out(h_in, o2, mod, 2 * c, n2w, mod, 3 * c, 4 * c, eps)
-            x12 = linear(a2, w12w, w12b)
-            g = ops.swiglu(x12)
+            x12, g = linear_swiglu(a2, w12w, w12b)
             o3 = linear(g, w3w, w3b)
             saved += [h_in, a1, qkv, q, k, v, o, o2, h_mid, a2, x12, g, o3]
         h_out, _ = ops.gated_residual_out(h_mid, o3, mod_all[nl - 1], 5 * c)
@@ -1351,6 +1385,43 @@ class RmsnormModulateFn(torch.autograd.Function):
         dmod = torch.zeros(mod.shape, dtype=f32, device=h.device)
         dw = ops.rmsnorm_modulate_bwd_(dt, _c(da).to(bf16), h, w, mod, dmod, shift_off, scale_off, eps, dw_out=_dst(w))
         return _own(dt), dw, dmod.to(mod.dtype), None, None, None
+
+
+class GatedResidualFn(torch.autograd.Function):
+    """h + gate * y with gate = mod[:, off : off + C] per sample (lightningdit.py:245,249) on the f32 residual stream; y, mod bf16.  The unfused step of DitBlockFn, for
+    routes that compose a block from single Functions (the one-token route of the 2-D toy, lightningdit_fast.forward_tokens1)."""
+
+    @staticmethod
+    def forward(ctx, h, y, mod, off):
+        out = h.float().clone()
+        y, mod = _c(y), _c(mod)
+        ops.gated_residual_(out, y, mod, off)
+        ctx.save_for_backward(y, mod)
+        ctx.off = off
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, mod = ctx.saved_tensors
+        dout = _c(dout.float())
+        dmod = torch.zeros(mod.shape, dtype=f32, device=mod.device)
+        dy = ops.gated_residual_bwd(dout, y, mod, dmod, ctx.off)
+        return dout, dy, dmod.to(mod.dtype), None
+
+
+class SwigluFn(torch.autograd.Function):
+    """silu(x1) * x2 over [x1 | x2] (swiglu_ffn.py:32-35), bf16, as its own node (csrc/dit.hip::swiglu_kernel / swiglu_bwd_kernel)."""
+
+    @staticmethod
+    def forward(ctx, x12):
+        x12 = _c(x12)
+        ctx.save_for_backward(x12)
+        return ops.swiglu(x12)
+
+    @staticmethod
+    def backward(ctx, dg):
+        (x12,) = ctx.saved_tensors
+        return ops.swiglu_bwd(_c(dg).to(bf16), x12)
 
 
 def to_nhwc_bf16(x: torch.Tensor) -> torch.Tensor:

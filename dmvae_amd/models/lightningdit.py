@@ -290,6 +290,8 @@ class LightningDiT(nn.Module):
                 if lightningdit_parity.structurally_supported(self):
                     return lightningdit_parity.forward_parity(self, x, t, y)
             from . import lightningdit_fast
+            if lightningdit_fast.tokens1_supported(self, x):        # config C1: one token per sample (toy_example_2d/dmd.py:436-454)
+                return lightningdit_fast.forward_tokens1(self, x, t, y)
             if lightningdit_fast.supported(self, x):
                 if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                     return lightningdit_fast.forward_train(self, x, t, y)        # autograd Functions over csrc/dit.hip

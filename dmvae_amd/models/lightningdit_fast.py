@@ -174,6 +174,61 @@ STACK_SEGMENTS_DP = 4     # ... and with more than one rank (gradient buckets be
 STACK_FN = True      # forward_train: all blocks as one functional.DitStackFn node (False: one DitBlockFn per block + LinearFn modulations; tests compare the two)
 
 
+def tokens1_supported(model, x: torch.Tensor) -> bool:
+    """The one-token configuration of the 2-D toy (toy_example_2d/dmd.py:436-454: LightningDiT-Mini/1 with input_size = 1): RoPE + RMSNorm + SwiGLU blocks, any
+    SwiGLU width (682 there), width a multiple of 8, under autocast(bf16) on the GPU."""
+    from .lightningdit import RMSNorm, SwiGLUFFN
+    if not (x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == _BF):
+        return False
+    blk = model.blocks[0]
+    return bool(model.x_embedder.num_patches == 1 and x.shape[-1] * x.shape[-2] == model.patch_size ** 2 and model.use_rmsnorm and isinstance(blk.mlp, SwiGLUFFN)
+                and isinstance(blk.norm1, RMSNorm) and not blk.wo_shift and model.hidden_size % 8 == 0 and model.hidden_size <= 2048)
+
+
+def _swiglu_operands(blk):
+    """w12 / b12 / w3 with the SwiGLU width H padded to a multiple of 32 -- rows [0, H) = x1's, [Hp, Hp + H) = x2's, the rest zero; w3's extra input columns zero --:
+    LightningDiT-Mini's H = int(2/3 * 1024) = 682 is not a multiple of 8, the 16-byte granule of the bf16 kernels.  Padded columns give silu(0) * 0 = 0 and meet zero
+    weights: the same function; torch.cat / pad are layout, their autograd slices the gradients back to the parameters' shapes."""
+    w12, b12, w3 = blk.mlp.w12.weight, blk.mlp.w12.bias, blk.mlp.w3.weight
+    h = w3.shape[1]
+    hp = (h + 31) // 32 * 32
+    if hp == h:
+        return w12, b12, w3
+    zw, zb = w12.new_zeros(hp - h, w12.shape[1]), b12.new_zeros(hp - h)
+    return torch.cat([w12[:h], zw, w12[h:], zw]), torch.cat([b12[:h], zb, b12[h:], zb]), torch.nn.functional.pad(w3, (0, hp - h))
+
+
+def forward_tokens1(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """LightningDiT.forward at ONE token per sample (config C1: every 2-D point is a [2, 1, 1] "image"), with or without gradients, on this build's kernels: with a
+    single key the softmax is 1 and the attention output IS v -- q, k, their RMSNorm weights and RoPE do not reach the output and get exactly zero gradient, as in
+    the reference --, so a block is five Linears (adaLN, qkv, proj, w12, w3) on the Linear GEMM kernels plus RMSNorm + modulate, the gated residuals and SwiGLU on
+    csrc/dit.hip, composed from single autograd Functions (functional.LinearFn / RmsnormModulateFn / GatedResidualFn / SwigluFn).  The samples are the rows."""
+    from ..functional import GatedResidualFn, LinearFn, RmsnormModulateFn, SwigluFn
+    b, cin = x.shape[0], x.shape[1]
+    ps, c = model.patch_size, model.hidden_size
+    w = model.x_embedder.proj.weight
+    train = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
+    h = (LinearFn.apply(x.reshape(b, 1, cin * ps * ps), w.view(w.shape[0], -1), model.x_embedder.proj.bias).float() + model.pos_embed).contiguous()
+    cvec = _t_embed(model, t, train=train).float() + model.y_embedder(y, model.training)
+    sc = F.silu(cvec)
+    for blk in model.blocks:
+        lin = blk.adaLN_modulation[1]
+        mod = LinearFn.apply(sc, lin.weight, lin.bias)                              # [B, 6C] bf16
+        a1 = RmsnormModulateFn.apply(h, blk.norm1.weight, mod, 0, c, blk.norm1.eps)
+        v = LinearFn.apply(a1, blk.attn.qkv.weight, blk.attn.qkv.bias)[..., 2 * c:]   # attention over one key = its value
+        h = GatedResidualFn.apply(h, LinearFn.apply(v.contiguous(), blk.attn.proj.weight, blk.attn.proj.bias), mod, 2 * c)
+        a2 = RmsnormModulateFn.apply(h, blk.norm2.weight, mod, 3 * c, 4 * c, blk.norm2.eps)
+        w12, b12, w3 = _swiglu_operands(blk)
+        g = SwigluFn.apply(LinearFn.apply(a2, w12, b12))
+        h = GatedResidualFn.apply(h, LinearFn.apply(g, w3, blk.mlp.w3.bias), mod, 5 * c)
+    fl = model.final_layer
+    a = RmsnormModulateFn.apply(h, fl.norm_final.weight, LinearFn.apply(sc, fl.adaLN_modulation[1].weight, fl.adaLN_modulation[1].bias), 0, c, fl.norm_final.eps)
+    out = model.unpatchify(LinearFn.apply(a, fl.linear.weight, fl.linear.bias))
+    if model.learn_sigma:
+        out, _ = out.chunk(2, dim=1)
+    return out
+
+
 def forward_train(model, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """`forward` with gradients (the student's flow-matching turn, train_dmd.py:565-575) under the caller's autocast(bf16): timestep / label embedders
     and the per-sample adaLN Linears through stock autograd, the patch embedding and the output Linear as `functional.LinearFn`, every block as one `functional.DitBlockFn`,

@@ -393,6 +393,27 @@ def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     return y
 
 
+def linear_swiglu_pre(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """(g [..., H], x12 [..., 2H]) = (silu(x1) * x2, bf16(x @ w^T + bias)) in ONE launch of the Linear GEMM (include/dmvae_hip.h dmvae_linear_bf16_swiglu_pre): the bits
+    of `linear_bf16(x, w, bias)` followed by `swiglu(.)`; x12 is kept for SwiGLU's backward.  w bf16 [2H, K] row-major or K-tile-major [K / 32, 2H, 32]."""
+    x = _req(x, bf16, "x")
+    w = _req(w, bf16, "w")
+    k = x.shape[-1]
+    kmajor = w.dim() == 3
+    n = w.shape[1] if kmajor else w.shape[0]
+    assert (w.shape[0] * 32 == k and w.shape[2] == 32) if kmajor else (w.shape[1] == k), (x.shape, w.shape)
+    m = x.numel() // k
+    bias_bf16 = 0
+    if bias is not None:
+        bias_bf16 = int(bias.dtype == bf16)
+        _req(bias, bf16 if bias_bf16 else f32, "bias")
+    g = torch.empty(*x.shape[:-1], n // 2, dtype=bf16, device=x.device)
+    x12 = torch.empty(*x.shape[:-1], n, dtype=bf16, device=x.device)
+    check(_lib.lib().dmvae_linear_bf16_swiglu_pre(x.data_ptr(), w.data_ptr(), _ptr(bias), g.data_ptr(), x12.data_ptr(), m, n, k, k, k, n // 2, n, bias_bf16, int(kmajor),
+                                                  _stream()), "linear_bf16_swiglu_pre")
+    return g, x12
+
+
 _SK_WS = {}
 
 

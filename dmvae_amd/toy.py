@@ -9,8 +9,9 @@ current points (transport.training_losses, :702-714).  Each point is a one-token
 Built here: the S-shape sampler (host-side numpy like the reference's: it feeds the teacher's own training, not the device path), the point
 initialiser, and `ToyDMDTrainer`, whose points turn runs on csrc/losses.hip::dmd_pre / dmd_post (through losses.dmd_make_xt / losses.dmd_loss)
 and on the fused clip + AdamW of csrc/optim.hip; the student's turn is the same code path as train.DMDTrainer's.  The velocity models are
-callables f(xt [B,2,1,1], t [B], labels [B]) -> velocity (LightningDiT-Mini/1 in the reference; one token per sample is outside the HIP attention
-kernels' range, so a LightningDiT here runs on the stock modules under DMVAE_ALLOW_STOCK=1 -- the toy is plumbing, its device work is the loss).
+callables f(xt [B,2,1,1], t [B], labels [B]) -> velocity: LightningDiT-Mini/1 in the reference (toy_example_2d/dmd.py:436-454), which this build runs on its
+one-token HIP route (models/lightningdit_fast.forward_tokens1, round 6: with one key the attention output is v, so a block is five Linears on the GEMM kernels
+plus csrc/dit.hip's norm / modulate / gate / SwiGLU steps; pinned by tests/golden/dit_toy_mini1.npz) -- no stock module, no DMVAE_ALLOW_STOCK.
 The other fifteen `dmd_loss_type` variants, plotting and wandb logging are out of scope.
 
 Pinned by tests/golden/dmd_loss_toy.npz (the reference's own compute_distribution_matching_loss on injected velocities) and tests/golden/sshape.npz

@@ -271,6 +271,12 @@ int dmvae_linear_bf16_splitk_supported(int M, int N, int K, int splits);
 int dmvae_linear_bf16_splitk(const void* x, const void* w, void* slabs, int splits, int M, int N, int K, int lda, int ldw, int w_layout, dmvae_stream_t stream);
 int dmvae_splitk_sum_bf16(const void* slabs, int splits, const void* bias, int bias_bf16, void* y, int M, int N, dmvae_stream_t stream);
 
+/* SwiGLU FFN's first half in one launch: x12 [M][ldx12] = bf16(x w^T + bias) over the N = 2 H columns [x1 | x2] AND g [M][ldg] = silu(x1) * x2 (H columns): the
+ * bits of dmvae_linear_bf16 (act 0) followed by dmvae_swiglu_bf16, without the second pass over the 2 H-wide tensor; x12 is what SwiGLU's backward reads.
+ * N % 16 == 0.  Reference: swiglu_ffn.py:31-36 (w12, chunk, silu(x1) * x2). */
+int dmvae_linear_bf16_swiglu_pre(const void* x, const void* w, const void* bias, void* g, void* x12, int M, int N, int K, int lda, int ldw, int ldg,
+                                 int ldx12, int bias_bf16, int w_layout, dmvae_stream_t stream);
+
 /* Stream-K / fused split-K Linear: y bf16 [M][ldy] = act(x [M][lda] w^T + bias), the reduction cut ACROSS workgroups and summed in K order by the last part of a
  * tile to arrive -- one launch, no slab pass (csrc/gemm_pp.hip, SK instantiation; 256 x 256 tiles).  For few-tile deep-K problems (LightningDiT-XL/1 at batch 16:
  * M 4096 x N 1152 is 80 tiles for 256 CUs; K = 3072 .. 6144) and problems of 1.x rounds of tiles.  splits = 0: stream-K -- 256 equal ranges of the flattened

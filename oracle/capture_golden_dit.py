@@ -46,6 +46,25 @@ def main():
                 **{"gn." + n: np.array([v.double().norm().item(), v.double().sum().item()]) for n, v in grads.items()},
                 **{"g." + n: grads[n] for n in ("blocks.0.adaLN_modulation.1.weight", "blocks.0.attn.q_norm.weight", "blocks.0.mlp.w12.bias",
                                                  "final_layer.linear.weight", "x_embedder.proj.weight", "t_embedder.mlp.0.weight")})
+    # ---- config C1's velocity model: LightningDiT-Mini/1 at ONE token per sample (toy_example_2d/dmd.py:436-454: input_size 1, in_channels = z_channels 2,
+    # num_classes 1), its own generator so that the fixtures above keep their streams.  SwiGLU width int(2/3 * 1024) = 682.
+    g2 = torch.Generator().manual_seed(778)
+    m = LightningDiT_models["LightningDiT-Mini/1"](input_size=1, in_channels=2, num_classes=1).eval()
+    fixed = {k: v.clone() for k, v in m.state_dict().items() if k == "pos_embed" or k.startswith("feat_rope")}
+    det_fill_(m, 76, skip=("pos_embed",))
+    b = 48
+    x = (torch.rand(b, 2, 1, 1, generator=g2) * 3.0 - 1.5).requires_grad_(True)
+    t = torch.rand(b, generator=g2)
+    y = (torch.rand(b, generator=g2) < 0.25).long()        # 0 = the toy's single class, 1 = the unconditional row
+    out = m(x, t, y)
+    dy = torch.randn(out.shape, generator=g2)
+    out.backward(dy)
+    grads = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    cg.save("dit_toy_mini1", seed=np.array(76), x=x.detach(), t=t, y=y, out=out.detach(), dy=dy, dx=x.grad,
+            keys=np.array(list(m.state_dict().keys())), **{"fix." + k: v for k, v in fixed.items()},
+            **{"gn." + n: np.array([v.double().norm().item(), v.double().sum().item()]) for n, v in grads.items()},
+            **{"g." + n: grads[n] for n in ("blocks.0.adaLN_modulation.1.bias", "blocks.5.norm2.weight", "blocks.2.mlp.w3.bias", "final_layer.linear.weight",
+                                             "x_embedder.proj.weight", "t_embedder.mlp.2.bias", "blocks.3.attn.q_norm.weight", "blocks.1.attn.proj.bias")})
     xl = LightningDiT_models["LightningDiT-XL/1"](input_size=16, in_channels=32, num_classes=1000)
     sd = xl.state_dict()
     cg.save("dit_xl1_manifest", keys=np.array(list(sd.keys())), shapes=np.array([str(tuple(v.shape)) for v in sd.values()]),

@@ -249,3 +249,24 @@ def test_batched_products_on_the_large_tile_kernel(batch, m, n, k, out_f32, monk
     assert rel_err(c1.double(), c0.double()) < (1e-5 if out_f32 else 2 ** -7)
     monkeypatch.setattr(ops, "GEMM_NT_LARGE_TILES", True)
     assert torch.equal(ops.gemm_nt(a, b, out_f32=out_f32), c1)
+
+
+@pytest.mark.parametrize("shape", [(4096, 6144, 1152), (16384, 6144, 1152), (4112, 1024, 768), (300, 64, 416)], ids=lambda s: "%dx%dx%d" % s)
+def test_swiglu_epilogue_that_also_stores_the_pre_activation(shape):
+    """dmvae_linear_bf16_swiglu_pre (swiglu_ffn.py:31-36 in one launch): x12 and g bit-identical to the Linear followed by the swiglu pass; row-major and
+    K-tile-major weights; f32 and bf16 bias; nothing written past M."""
+    from dmvae_amd import ops
+    m, n, k = shape
+    x, w, b = _operands(m, n, k, seed=5)
+    x12_ref = ops.linear_bf16(x, w, b)
+    g_ref = ops.swiglu(x12_ref)
+    g, x12 = ops.linear_swiglu_pre(x, w, b)
+    assert torch.equal(x12, x12_ref) and torch.equal(g, g_ref)
+    g2, x122 = ops.linear_swiglu_pre(x, w, b.to(BF))
+    assert torch.equal(x122, ops.linear_bf16(x, w, b.to(BF))) and torch.equal(g2, ops.swiglu(x122))
+    if k % 32 == 0:
+        wk = ops.pack_conv_weight(w.float(), kmajor=True)._dmvae_kmajor.view(k // 32, n, 32)
+        g3, x123 = ops.linear_swiglu_pre(x, wk, b)
+        assert torch.equal(g3, g) and torch.equal(x123, x12)
+    g4, x124 = ops.linear_swiglu_pre(x, w, None)
+    assert torch.equal(x124, ops.linear_bf16(x, w, None)) and torch.equal(g4, ops.swiglu(x124))

@@ -97,3 +97,89 @@ def test_toy_rejects_cpu_points():
     from dmvae_amd.toy import ToyDMDTrainer
     with pytest.raises(DmvaeHipError):
         ToyDMDTrainer(lambda *a: None, lambda *a: None, num_points=8, device="cpu")
+
+
+def _rl2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def test_one_token_velocity_model_vs_reference_capture():
+    """Config C1's velocity model -- LightningDiT-Mini/1 at ONE token per sample (toy_example_2d/dmd.py:436-454) -- on the HIP route (lightningdit_fast.forward_tokens1:
+    no stock module, no DMVAE_ALLOW_STOCK) against the capture taken from the reference's own module (oracle/capture_golden_dit.py, `dit_toy_mini1`): output, input
+    gradient, the eight fully captured parameter gradients and every parameter's gradient norm, by the bf16-site criterion (as close to the reference's f32 numbers
+    as the CPU oracle with bf16 rounding at the autocast sites, x 1.15 + a floor).  q / k and their RMSNorm weights get exactly zero gradient (one key: softmax = 1)."""
+    import numpy as np
+    from oracle import ref_cpu as R
+    from test_oracle_dit import CFGS, build
+    tag = "dit_toy_mini1"
+    g = load_golden(tag)
+    m = build(tag, g).to(DEV)
+    x, t, y, dy = g.t("x"), g.t("t"), torch.from_numpy(np.asarray(g["y"])), g.t("dy")
+    xa = x.to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = m(xa, t.to(DEV), y.to(DEV))                     # one token per sample -> forward_tokens1
+    (out.float() * dy.to(DEV)).sum().backward()
+    names = [n for n, _ in m.named_parameters()]
+    po = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for n in names:
+        po[n].requires_grad_(True)
+    xo = x.clone().requires_grad_(True)
+    yo = R.lightningdit_forward(xo, t, y, po, CFGS[tag]["num_heads"], 1, q=R.bf16_round)
+    yo.backward(dy)
+
+    def floor(hip, orc, ref, what, slack=1.15, abs_floor=2e-3):
+        e_hip, e_orc = _rl2(hip, ref), _rl2(orc, ref)
+        print(f"{tag} {what}: rel-L2 to the f32 reference -- HIP {e_hip:.2e}, bf16-site oracle {e_orc:.2e}")
+        assert e_hip < slack * e_orc + abs_floor, (what, e_hip, e_orc)
+    floor(out.float().cpu(), yo.detach(), g.t("out"), "out")
+    floor(xa.grad.cpu(), xo.grad, g.t("dx"), "dx")
+    pa = dict(m.named_parameters())
+    for k in [k[2:] for k in g.keys() if k.startswith("g.")]:
+        ref = g.t("g." + k)
+        if ref.abs().max() < 1e-5:                            # q_norm / k_norm weights: analytically zero (1e-7 of rounding noise in the reference's own backward)
+            assert pa[k].grad is None or pa[k].grad.abs().max() == 0, k
+            continue
+        floor(pa[k].grad.cpu(), po[k].grad, ref, "grad " + k)
+    for n in names:
+        if n == "pos_embed" or "gn." + n not in g:
+            continue
+        want = float(g["gn." + n][0])
+        got = 0.0 if pa[n].grad is None else pa[n].grad.double().norm().item()
+        if want < 1e-6:
+            assert got < 1e-6, n
+            continue
+        e_orc = abs(po[n].grad.double().norm().item() - want) / want
+        assert abs(got - want) / want < 1.15 * e_orc + 2e-2, (n, got, want)
+
+
+def test_toy_trainer_with_the_reference_models_needs_no_stock_opt_in(monkeypatch):
+    """ToyDMDTrainer with the reference's own models -- LightningDiT-Mini/1 teacher and student at one token per point (toy_example_2d/dmd.py:436-454) -- and WITHOUT
+    DMVAE_ALLOW_STOCK: the velocity evaluations of the DMD loss and the student's flow-matching turn run on the HIP one-token route.  40 steps: finite losses, the
+    student's loss falls, the points move, and a second run from the same seeds is bit-identical."""
+    monkeypatch.delenv("DMVAE_ALLOW_STOCK", raising=False)
+    from dmvae_amd.models.lightningdit import LightningDiT_models
+    from dmvae_amd.toy import ToyDMDTrainer
+    from oracle.detweights import det_fill_
+
+    def run():
+        mk = lambda seed: det_fill_(LightningDiT_models["LightningDiT-Mini/1"](input_size=1, in_channels=2, num_classes=1), seed, skip=("pos_embed",)) or None
+        teacher = LightningDiT_models["LightningDiT-Mini/1"](input_size=1, in_channels=2, num_classes=1)
+        student = LightningDiT_models["LightningDiT-Mini/1"](input_size=1, in_channels=2, num_classes=1)
+        det_fill_(teacher, 5, skip=("pos_embed",))
+        det_fill_(student, 6, skip=("pos_embed",))
+        teacher, student = teacher.to(DEV).eval().requires_grad_(False), student.to(DEV)
+        torch.manual_seed(11)
+        tr = ToyDMDTrainer(teacher, student, num_points=1536, lr=1e-3, diff_lr=1e-3, vae_train_every=2, seed=42)
+        p0 = tr.points.detach().clone()
+        logs = []
+        for _ in range(40):
+            tr.step()
+            logs.append(tr.read_log())
+        return p0, tr.points.detach().clone(), logs, tr.sfp.flat.clone()
+    p0, p1, logs, w1 = run()
+    assert all(v == v and abs(v) < 1e6 for lg in logs for v in lg.values()), logs[-1]
+    first, last = sum(lg["sit_loss"] for lg in logs[:5]) / 5, sum(lg["sit_loss"] for lg in logs[-5:]) / 5
+    assert last < first, (first, last)
+    assert (p1 - p0).abs().max() > 1e-3 and logs[-1]["points_grad_norm"] > 0
+    _, p1b, logs_b, w1b = run()
+    assert torch.equal(p1, p1b) and torch.equal(w1, w1b) and logs == logs_b

@@ -16,7 +16,9 @@ CFGS = {"dit_small_hd64": dict(input_size=8, patch_size=1, in_channels=8, hidden
         "dit_small_hd72": dict(input_size=8, patch_size=1, in_channels=8, hidden_size=144, depth=2, num_heads=2, num_classes=10),
         "dit_small_p2": dict(input_size=8, patch_size=2, in_channels=4, hidden_size=128, depth=1, num_heads=2, num_classes=10),
         # head dim 64 at a width whose SwiGLU inner size (512) the HIP kernels take; hidden 128 gives 341 (CPU oracle / stock module only)
-        "dit_small_hd64w": dict(input_size=8, patch_size=1, in_channels=8, hidden_size=192, depth=2, num_heads=3, num_classes=10)}
+        "dit_small_hd64w": dict(input_size=8, patch_size=1, in_channels=8, hidden_size=192, depth=2, num_heads=3, num_classes=10),
+        # config C1's velocity model (toy_example_2d/dmd.py:436-454): LightningDiT-Mini/1 at ONE token per sample, SwiGLU width 682
+        "dit_toy_mini1": dict(input_size=1, patch_size=1, in_channels=2, hidden_size=256, depth=6, num_heads=4, num_classes=1)}
 
 
 def build(tag, g):
