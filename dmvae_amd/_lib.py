@@ -66,10 +66,10 @@ SIGNATURES = {
     "dmvae_linear_bf16_splitk": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
     "dmvae_splitk_sum_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "dmvae_linear_bf16_swiglu_pre": (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
-    "dmvae_linear_bf16_sk_supported": (c_int, [c_int] * 4),
+    "dmvae_linear_bf16_sk_supported": (c_int, [c_int] * 5),
     "dmvae_linear_bf16_sk_counter_bytes": (c_size_t, []),
-    "dmvae_linear_bf16_sk_workspace": (c_size_t, [c_int] * 4),
-    "dmvae_linear_bf16_sk": (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 10 + [c_void_p]),
+    "dmvae_linear_bf16_sk_workspace": (c_size_t, [c_int] * 5),
+    "dmvae_linear_bf16_sk": (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 11 + [c_void_p]),
     "dmvae_linear_bf16_batched_supported": (c_int, [c_int] * 4),
     "dmvae_linear_bf16_batched": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_longlong] * 3 + [c_int, c_void_p]),
     "dmvae_linear_bf16_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),

@@ -621,10 +621,14 @@ int launch(Args a, hipStream_t st, int batch = 1) {
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
-// SK launch: the 256 x 256 tile only (the N = 1152 / 1024 problems this is for are 4.5 / 4 tile columns of it; its ring is 4 deep: parts of >= 8 K steps).
+// SK launch.  Tile 0: 256 x 256 (ring 4 deep: parts of >= 8 K steps; 256 KB of f32 per partial tile).  Tile 1: 256 columns x 128 rows (ring 6 deep: parts of >= 12
+// steps; 128 KB per partial) -- the vendor library's stream-K solutions for these shapes run 128 x 160 macro-tiles (profiles/r6_hipblaslt_kernel_choices_probe.txt):
+// a cut costs a third of the partial bytes of a 256 x 256 tile, and 144 tiles x 96 steps spread over 256 CUs are 54 steps each instead of 96.
 constexpr int SK_GRID = 256, SK_MAX_TILES = 2048, SK_COUNTER_BYTES = SK_MAX_TILES * 8 * 4;
-static int launch_sk(Args a, int splits, hipStream_t st) {
-  constexpr int TM = 256, TP = 256;
+struct SkTile { int tm, tp, minseg; };
+static inline SkTile sk_tile(int tile) { return tile == 1 ? SkTile{256, 128, 12} : SkTile{256, 256, 8}; }   // minseg = 2 * (ring depth - 1) + 2
+template <int TM, int TP, int WM, int WP>
+static int launch_sk_t(Args a, int splits, hipStream_t st) {
   a.ntn = (a.N + TM - 1) / TM;
   a.tpb = ((a.M + TP - 1) / TP) * a.ntn;
   a.total = a.tpb;
@@ -640,22 +644,26 @@ static int launch_sk(Args a, int splits, hipStream_t st) {
   constexpr int lds = nbuf * slot + 3 * 1024;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<TM, TP, 2, 4, false, nbuf, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<TM, TP, WM, WP, false, nbuf, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<TM, TP, 2, 4, false, nbuf, false, true>), dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<TM, TP, WM, WP, false, nbuf, false, true>), dim3(grid), dim3(512), lds, st, a);
   DMVAE_CHECK_LAUNCH();
   return 0;
 }
-// What dmvae_linear_bf16_sk needs of (M, N, K, splits): splits 0 = stream-K (ranges of T / 256 steps, at least 2 MINSEG each so that no cut collapses), else
-// uniform parts of >= MINSEG steps.  MINSEG of the 256 x 256 instantiation = 2 * 3 + 2.
-static bool sk_ok(int M, int N, int K, int splits) {
-  if (!(M >= 64 && N > 0 && N % 8 == 0 && K % 32 == 0 && K >= 384 && splits >= 0 && splits <= 8)) return false;
-  const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+static int launch_sk(Args a, int splits, int tile, hipStream_t st) {
+  return tile == 1 ? launch_sk_t<256, 128, 4, 2>(a, splits, st) : launch_sk_t<256, 256, 2, 4>(a, splits, st);
+}
+// What dmvae_linear_bf16_sk needs of (M, N, K, splits, tile): splits 0 = stream-K (ranges of T / 256 steps, at least 2 MINSEG each so that no cut collapses), else
+// uniform parts of >= MINSEG steps.
+static bool sk_ok(int M, int N, int K, int splits, int tile) {
+  if (!(M >= 64 && N > 0 && N % 8 == 0 && K % 32 == 0 && K >= 384 && splits >= 0 && splits <= 8 && (tile == 0 || tile == 1))) return false;
+  const SkTile t = sk_tile(tile);
+  const long long tiles = (long long)((M + t.tp - 1) / t.tp) * ((N + t.tm - 1) / t.tm);
   const int nK = K >> 5;
   if (tiles > SK_MAX_TILES || tiles * nK >= (1ll << 30)) return false;
-  if (splits == 0) return tiles * nK / SK_GRID >= 16 && nK >= 16;
-  return nK / splits >= 8 && tiles * splits <= 4096;
+  if (splits == 0) return tiles * nK / SK_GRID >= 2 * t.minseg && nK >= 2 * t.minseg;
+  return nK / splits >= t.minseg && tiles * splits <= 4096;
 }
 
 // The tile menu: (columns, rows, cost of one tile relative to a 256 x 256 tile's at the same K with the whole chip busy -- measured on the 16384 x 6144 x 1152
@@ -841,20 +849,21 @@ extern "C" int dmvae_splitk_sum_bf16(const void* slabs, int splits, const void* 
 // last part to arrive -- one launch, no slab pass.  splits = 0: stream-K (256 equal ranges of the (tile, K step) space: the cut depends on M); splits >= 2: that
 // many uniform parts per tile (depends on N, K only: a row's bits do not depend on how many rows the call has).  workspace: dmvae_linear_bf16_sk_workspace bytes,
 // whose FIRST dmvae_linear_bf16_sk_counter_bytes() bytes must be zero on entry (the kernel leaves them zero; zero the buffer once).
-extern "C" int dmvae_linear_bf16_sk_supported(int M, int N, int K, int splits) { return dmvae_gemm_pp::sk_ok(M, N, K, splits) ? 1 : 0; }
+extern "C" int dmvae_linear_bf16_sk_supported(int M, int N, int K, int splits, int tile) { return dmvae_gemm_pp::sk_ok(M, N, K, splits, tile) ? 1 : 0; }
 extern "C" size_t dmvae_linear_bf16_sk_counter_bytes(void) { return (size_t)dmvae_gemm_pp::SK_COUNTER_BYTES; }
-extern "C" size_t dmvae_linear_bf16_sk_workspace(int M, int N, int K, int splits) {
+extern "C" size_t dmvae_linear_bf16_sk_workspace(int M, int N, int K, int splits, int tile) {
   using namespace dmvae_gemm_pp;
-  if (!sk_ok(M, N, K, splits)) return 0;
-  const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  if (!sk_ok(M, N, K, splits, tile)) return 0;
+  const SkTile t = sk_tile(tile);
+  const long long tiles = (long long)((M + t.tp - 1) / t.tp) * ((N + t.tm - 1) / t.tm);
   const long long V = splits > 0 ? tiles * splits : SK_GRID;
-  return (size_t)SK_COUNTER_BYTES + (size_t)(2 * V) * 256 * 256 * 4;
+  return (size_t)SK_COUNTER_BYTES + (size_t)(2 * V) * t.tm * t.tp * 4;
 }
-extern "C" int dmvae_linear_bf16_sk(const void* x, const void* w, const void* bias, void* y, void* workspace, size_t workspace_bytes, int splits, int M, int N, int K,
-                                    int lda, int ldw, int ldy, int act, int bias_bf16, int w_layout, hipStream_t stream) {
+extern "C" int dmvae_linear_bf16_sk(const void* x, const void* w, const void* bias, void* y, void* workspace, size_t workspace_bytes, int splits, int tile, int M, int N,
+                                    int K, int lda, int ldw, int ldy, int act, int bias_bf16, int w_layout, hipStream_t stream) {
   using namespace dmvae_gemm_pp;
   DMVAE_CHECK_ARG(x && w && y && workspace, "linear_bf16_sk: null operand");
-  DMVAE_CHECK_ARG(sk_ok(M, N, K, splits), "linear_bf16_sk: M %d N %d K %d splits %d not taken (dmvae_linear_bf16_sk_supported)", M, N, K, splits);
+  DMVAE_CHECK_ARG(sk_ok(M, N, K, splits, tile), "linear_bf16_sk: M %d N %d K %d splits %d tile %d not taken (dmvae_linear_bf16_sk_supported)", M, N, K, splits, tile);
   DMVAE_CHECK_ARG(w_layout == 0 || w_layout == 1, "linear_bf16_sk: w_layout must be 0 (row-major [N][ldw]) or 1 (K-tile-major [K / 32][N][32])");
   DMVAE_CHECK_ARG(lda >= K && (w_layout == 1 || ldw >= K) && ldy >= (act == 6 ? N / 2 : N) && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0,
                   "linear_bf16_sk: leading dimensions must cover the rows and be multiples of 8");
@@ -863,7 +872,7 @@ extern "C" int dmvae_linear_bf16_sk(const void* x, const void* w, const void* bi
   const long long wb = w_layout == 1 ? (long long)N * K * 2 : (long long)N * ldw * 2;
   DMVAE_CHECK_ARG((long long)M * lda * 2 < (1ll << 31) && wb < (1ll << 31) && (long long)M * ldy * 2 < (1ll << 31),
                   "linear_bf16_sk: operands are addressed through 32-bit buffer offsets (2 GiB each)");
-  const size_t need = dmvae_linear_bf16_sk_workspace(M, N, K, splits);
+  const size_t need = dmvae_linear_bf16_sk_workspace(M, N, K, splits, tile);
   DMVAE_CHECK_ARG(workspace_bytes >= need && need - SK_COUNTER_BYTES < (1ull << 32), "linear_bf16_sk: workspace too small (need %zu bytes, see dmvae_linear_bf16_sk_workspace)", need);
   Args a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.y = y;
@@ -876,7 +885,7 @@ extern "C" int dmvae_linear_bf16_sk(const void* x, const void* w, const void* bi
   a.counters = (unsigned*)workspace;
   a.slabs = (float*)((char*)workspace + SK_COUNTER_BYTES);
   a.slab_bytes = (unsigned)(need - SK_COUNTER_BYTES);
-  return launch_sk(a, splits, stream);
+  return launch_sk(a, splits, tile, stream);
 }
 
 static int linear_bf16_impl(const void* x, const void* w, const void* bias, void* y, void* y2, int ldy2, int M, int N, int K, int lda, int ldw, int ldy,

@@ -428,14 +428,14 @@ def _sk_workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
-def linear_sk_supported(m: int, n: int, k: int, splits: int = 0) -> bool:
-    return bool(_lib.lib().dmvae_linear_bf16_sk_supported(int(m), int(n), int(k), int(splits)))
+def linear_sk_supported(m: int, n: int, k: int, splits: int = 0, tile: int = 0) -> bool:
+    return bool(_lib.lib().dmvae_linear_bf16_sk_supported(int(m), int(n), int(k), int(splits), int(tile)))
 
 
-def linear_sk(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0, splits: int = 0) -> torch.Tensor:
+def linear_sk(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0, splits: int = 0, tile: int = 0) -> torch.Tensor:
     """y bf16 [M, N] = act(x @ w^T + bias) on the stream-K (splits = 0) / fused split-K (splits >= 2 uniform parts per tile) instantiation of the Linear GEMM
     (include/dmvae_hip.h dmvae_linear_bf16_sk): ONE launch, the parts of a tile summed in K order by the last one to arrive.  w bf16 [N, K] row-major or
-    K-tile-major [K / 32, N, 32]."""
+    K-tile-major [K / 32, N, 32].  tile 0: 256 x 256 output tiles, 1: 256 columns x 128 rows."""
     x = _req2d(x, "x")
     m, k = x.shape
     if w.dim() == 3:
@@ -447,10 +447,10 @@ def linear_sk(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
         n, layout, ldw = w.shape[0], 0, w.stride(0)
         assert w.shape[1] == k
     L = _lib.lib()
-    ws = _sk_workspace(L.dmvae_linear_bf16_sk_workspace(m, n, k, int(splits)), x.device)
+    ws = _sk_workspace(L.dmvae_linear_bf16_sk_workspace(m, n, k, int(splits), int(tile)), x.device)
     nout = n // 2 if act == ACT_SWIGLU else n
     y = torch.empty(m, nout, dtype=bf16, device=x.device)
-    check(L.dmvae_linear_bf16_sk(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), ws.data_ptr(), ws.numel(), int(splits), m, n, k, x.stride(0), ldw, nout,
+    check(L.dmvae_linear_bf16_sk(x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), ws.data_ptr(), ws.numel(), int(splits), int(tile), m, n, k, x.stride(0), ldw, nout,
                                  int(act), int(bias is not None and bias.dtype == bf16), layout, _stream()), "linear_bf16_sk")
     return y
 

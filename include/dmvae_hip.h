@@ -282,13 +282,14 @@ int dmvae_linear_bf16_swiglu_pre(const void* x, const void* w, const void* bias,
  * M 4096 x N 1152 is 80 tiles for 256 CUs; K = 3072 .. 6144) and problems of 1.x rounds of tiles.  splits = 0: stream-K -- 256 equal ranges of the flattened
  * (tile, K step) space, the cut depends on M; splits 2 .. 8: that many uniform parts per tile -- the cut depends on N and K only, so a row's bits do not depend
  * on the number of rows in the call (train_dmd.py:212-217 evaluated as one 2B call = two B calls).  Run-to-run identical either way (fixed summation order).
- * act / bias / w_layout as dmvae_linear_bf16.  workspace >= dmvae_linear_bf16_sk_workspace(M, N, K, splits) bytes whose FIRST dmvae_linear_bf16_sk_counter_bytes()
+ * tile 0: 256 x 256 output tiles; tile 1: 256 columns x 128 rows (a third of the partial bytes per cut; what the few-tile shapes take).
+ * act / bias / w_layout as dmvae_linear_bf16.  workspace >= dmvae_linear_bf16_sk_workspace(M, N, K, splits, tile) bytes whose FIRST dmvae_linear_bf16_sk_counter_bytes()
  * bytes are zero on entry (arrival counters; the kernel leaves them zero: zero the buffer once).  Reference: nn.Linear under autocast,
  * diffusion/lightningdit/lightningdit.py:66-75,236-250, swiglu_ffn.py:15-36, train_dmd.py:563-575 (their backward: dX = dY W). */
-int dmvae_linear_bf16_sk_supported(int M, int N, int K, int splits);
+int dmvae_linear_bf16_sk_supported(int M, int N, int K, int splits, int tile);
 size_t dmvae_linear_bf16_sk_counter_bytes(void);
-size_t dmvae_linear_bf16_sk_workspace(int M, int N, int K, int splits);
-int dmvae_linear_bf16_sk(const void* x, const void* w, const void* bias, void* y, void* workspace, size_t workspace_bytes, int splits,
+size_t dmvae_linear_bf16_sk_workspace(int M, int N, int K, int splits, int tile);
+int dmvae_linear_bf16_sk(const void* x, const void* w, const void* bias, void* y, void* workspace, size_t workspace_bytes, int splits, int tile,
                          int M, int N, int K, int lda, int ldw, int ldy, int act, int bias_bf16, int w_layout, dmvae_stream_t stream);
 /* The input-gradient operand of dmvae_linear_bf16 from a Linear weight's bf16 copy: w bf16 [N][K] row-major (nn.Linear.weight: N = out_features, K = in_features)
  * -> out bf16 [N / 32][K][32], out[n >> 5][k][n & 31] = w[n][k], i.e. the K-tile-major layout (w_layout = 1) of W^T [K][N] with the reduction over n:

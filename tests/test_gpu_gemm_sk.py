@@ -39,12 +39,15 @@ def _operands(m, n, k, seed=0):
     return x, w, b
 
 
+@pytest.mark.parametrize("tile", [0, 1], ids=["256x256", "256x128"])
 @pytest.mark.parametrize("case", CASES, ids=IDS)
-def test_linear_sk_vs_fp64_and_one_chain(case):
+def test_linear_sk_vs_fp64_and_one_chain(case, tile):
     from dmvae_amd import ops
+    import functools
     m, n, k, s = case
-    if not ops.linear_sk_supported(m, n, k, s):
+    if not ops.linear_sk_supported(m, n, k, s, tile):
         pytest.skip("shape outside the SK instantiation's range")
+    ops = type("O", (), {**{a: getattr(ops, a) for a in dir(ops) if not a.startswith("__")}, "linear_sk": staticmethod(functools.partial(ops.linear_sk, tile=tile))})
     x, w, b = _operands(m, n, k, seed=m + s)
     ref = torch.addmm(b.double(), x.double(), w.double().t())
     buf = torch.full((m + 8, n), 7.0, dtype=BF, device=DEV)            # the result inside a sentinel-filled buffer? (ldy = N: rows past M only)
@@ -68,14 +71,17 @@ def test_linear_sk_vs_fp64_and_one_chain(case):
 
 @pytest.mark.parametrize("shape", [(4096, 1152, 3072, 3), (4096, 1152, 6144, 3), (4096, 1152, 1152, 3), (2048, 1024, 4096, 2)])
 def test_uniform_parts_do_not_depend_on_the_row_count(shape):
-    """splits >= 2: a 2B-row call equals two B-row calls bit for bit (the DMD loss's cond / uncond pair as one call, train_dmd.py:212-217)."""
+    """splits >= 2: a 2B-row call equals two B-row calls bit for bit (the DMD loss's cond / uncond pair as one call, train_dmd.py:212-217) -- on either tile."""
     from dmvae_amd import ops
     m, n, k, s = shape
     x, w, b = _operands(2 * m, n, k, seed=3)
-    both = ops.linear_sk(x, w, b, splits=s)
-    lo = ops.linear_sk(x[:m].contiguous(), w, b, splits=s)
-    hi = ops.linear_sk(x[m:].contiguous(), w, b, splits=s)
-    assert torch.equal(both[:m], lo) and torch.equal(both[m:], hi)
+    for tile in (0, 1):
+        if not ops.linear_sk_supported(m, n, k, s, tile):
+            continue
+        both = ops.linear_sk(x, w, b, splits=s, tile=tile)
+        lo = ops.linear_sk(x[:m].contiguous(), w, b, splits=s, tile=tile)
+        hi = ops.linear_sk(x[m:].contiguous(), w, b, splits=s, tile=tile)
+        assert torch.equal(both[:m], lo) and torch.equal(both[m:], hi), tile
 
 
 @pytest.mark.parametrize("splits", [0, 3])

@@ -91,9 +91,11 @@ for name, m, n, k in SHAPES:
                 ops.linear_bf16(nx(), wk, bb)
             arms["gemm_pp_kmajor"] = fk
     if args.sk:
-        for sp in (0, 2, 3, 4):
-            if ops.linear_sk_supported(m, n, k, sp):
-                arms["sk%d" % sp] = (lambda sp_: (lambda: ops.linear_sk(nx(), wsw if args.sweep else w, bb, splits=sp_)))(sp)
+        wsk = ops.pack_conv_weight(w.float(), kmajor=True)._dmvae_kmajor.view(k // 32, n, 32) if k % 32 == 0 else w      # K-tile-major, as the training route serves them
+        for tl in (0, 1):
+            for sp in (0, 2, 3):
+                if ops.linear_sk_supported(m, n, k, sp, tl):
+                    arms["sk%d%s" % (sp, "b" if tl else "a")] = (lambda sp_, tl_: (lambda: ops.linear_sk(nx(), wsk, bb, splits=sp_, tile=tl_)))(sp, tl)
     for f in arms.values():
         for _ in range(3):
             f()
