@@ -654,7 +654,7 @@ def comm_n1_overhead(headline_ms: float) -> dict:
     res = {"what": "C2 step with a one-rank RCCL group + dynamic tile claiming, fresh process, 10 steps after 3", "headline_ms": round(headline_ms, 3)}
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-secondary"], env=env,
-                           capture_output=True, text=True, timeout=400)
+                           capture_output=True, text=True, timeout=240)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
             res["error"] = (r.stderr or r.stdout)[-300:]

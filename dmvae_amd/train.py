@@ -475,7 +475,7 @@ class DMDTrainer(_AdversarialBranch):
             p.requires_grad_(False)
         if vae_turn and student_is_module:
             self.student.eval()           # train_dmd.py:534-535: no label dropout in the four no-grad velocity evaluations of the DMD loss
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not parity.on()):      # the reference's autocast (train_dmd.py:516); off in the fp32 parity mode
             if vae_turn:
                 self.fp.begin_step()
                 vae.train()
@@ -484,7 +484,7 @@ class DMDTrainer(_AdversarialBranch):
                 with torch.no_grad():                               # student-only step: the latents are all that is needed (train_dmd.py:520-523)
                     enc = vae.encoder
                     from .models import vit_fast
-                    if vit_fast.hip_path_supported(enc.model, enc.model.pos_embed.shape[1]):
+                    if not parity.on() and vit_fast.hip_path_supported(enc.model, enc.model.pos_embed.shape[1]):
                         tok = vit_fast.trainable_forward_features(enc.model, enc.scale(enc.de_scale(images)))[:, enc.model.num_prefix_tokens:]
                     else:
                         tok = enc(images)
@@ -535,7 +535,7 @@ class DMDTrainer(_AdversarialBranch):
             t, x0 = self._sample(x1)
             te = t.view(-1, *([1] * (x1.dim() - 1)))
             xt, ut = te * x1 + (1 - te) * x0, x1 - x0                    # ICPlan.plan (path.py:114-136)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not parity.on()):
                 out = self.student(xt, t, labels)
                 sloss = ((out.float() - ut) ** 2).flatten(1).mean(1).mean()
             sloss.backward()
@@ -640,7 +640,7 @@ class DiffusionTrainer:
 
     def step(self, images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         self.model.train()                                                  # label dropout for classifier-free guidance (:232)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not parity.on()):
             x = self.latents(images)                                        # frozen encoder: does not touch the model's weights (an overlapped update may still run)
             self.fp.begin_step()                                            # waits for it
             _, terms = self.transport.training_losses(self.model, x, dict(y=labels))

@@ -827,6 +827,74 @@ def diffusion_train_steps(latents: Tensor, labels: Tensor, p: P, trainable: Sequ
     return logs, p, ema
 
 
+def dmd_train_steps(images: Tensor, labels: Tensor, p_vae: P, lpips_p: P, p_teacher: P, p_student: P, vae_trainable: Sequence[str],
+                    student_trainable: Sequence[str], draws: Sequence[dict], *, vit_heads: int, dit_heads: int, num_classes: int, cfg: float, dmd_weight: float,
+                    latent_mean: float, latent_scale: float, vae_train_every: int, lr: float, diff_lr: float, wd: float, warmup_steps: int,
+                    max_norm: float = 1.0, q: Q = None, on_vae_grads=None, on_student_grads=None):
+    """The loop body of train_dmd.py:506-575 (discriminator off), once per entry of `draws` = {"dmd": (t, x0) on VAE turns, "student": (t, x0, dropped)}:
+    VAE turn every `vae_train_every`-th step -- VAE.forward with the encoder TRAINABLE (:518-520), latents_to_spatial((z - mean) * scale) (:525-526),
+    forward_generator = L1 + LPIPS + dmd_weight * compute_distribution_matching_loss (:204-262: the four velocity evaluations under no_grad, so the gradient reaches
+    the latents through the surrogate's mse alone), backward, clip_grad_norm_, AdamW(lr, wd) over every VAE parameter that received a gradient, LambdaLR counted in VAE
+    turns (:541-544) -- else latents from the no-grad encode (:521-523); then the student's turn (:558-575): flow-matching loss on the detached latents with its
+    label drop-out, clip, AdamW(diff_lr, wd), LambdaLR counted in steps.  Parameters are updated functionally; returns (per-step logs, VAE parameters, student
+    parameters).  Pinned by tests/golden/dmd_step_small.npz."""
+    pv, ps = dict(p_vae), dict(p_student)
+    mv = {k: torch.zeros_like(pv[k]) for k in vae_trainable}
+    vv = {k: torch.zeros_like(pv[k]) for k in vae_trainable}
+    ms = {k: torch.zeros_like(ps[k]) for k in student_trainable}
+    vs_ = {k: torch.zeros_like(ps[k]) for k in student_trainable}
+    null = torch.full_like(labels, num_classes)
+    logs, vae_steps = [], 0
+    for step, d in enumerate(draws):
+        log = {}
+        if step % vae_train_every == 0:
+            leaves = {k: pv[k].detach().clone().requires_grad_(True) for k in vae_trainable}
+            pp = {**{k: t_.detach() for k, t_ in pv.items()}, **leaves}
+            rec, z = vae_forward(images, pp, num_heads=vit_heads, q=q, return_latent=True)
+            lat = latents_to_spatial((z - latent_mean) * latent_scale)
+            rec_loss, rlog = forward_generator(images, rec, lpips_p, q=q)
+            t, x0 = d["dmd"]
+            with torch.no_grad():
+                xt, _ = transport_plan(t, x0, lat.detach())
+                vel = lambda prm, y: lightningdit_forward(xt, t, y, prm, dit_heads, 1, q=q)
+                vt, vst = vel(p_teacher, labels), vel(ps, labels)
+                vtu, vsu = (vel(p_teacher, null), vel(ps, null)) if cfg > 1 else (None, None)
+            dl, gnorm, _ = dmd_loss(lat, t, x0, vt, vst, vtu, vsu, cfg=cfg)
+            loss = rec_loss + dl * dmd_weight
+            got = torch.autograd.grad(loss, [leaves[k] for k in vae_trainable], allow_unused=True)
+            grads = {k: g_ for k, g_ in zip(vae_trainable, got) if g_ is not None}
+            if on_vae_grads is not None:
+                on_vae_grads(step, grads)
+            total, clipped = clip_grad_norm(list(grads.values()), max_norm)
+            vae_steps += 1
+            rate = warmup_lr(vae_steps - 1, lr, warmup_steps)
+            for k, g_ in zip(grads, clipped):
+                pv[k], mv[k], vv[k] = adamw_step(pv[k].detach(), g_, mv[k], vv[k], vae_steps, rate, wd=wd)
+            log.update({kk: float(val.detach()) for kk, val in rlog.items()})
+            log.update({"dmd_loss": float(dl.detach()), "dmd_gradient_norm": float(gnorm), "vae_norm": float(total)})
+            lat = lat.detach()
+        else:
+            with torch.no_grad():
+                z = mlp_forward(dino_encoder_forward(images, pv, num_heads=vit_heads, q=q), pv, q=q)
+                lat = latents_to_spatial((z - latent_mean) * latent_scale)
+        t, x0, dropped = d["student"]
+        y = torch.where(dropped, null, labels)
+        sl = {k: ps[k].detach().clone().requires_grad_(True) for k in student_trainable}
+        pps = {**{k: t_.detach() for k, t_ in ps.items()}, **sl}
+        xt, _ = transport_plan(t, x0, lat)
+        sloss = transport_loss(lightningdit_forward(xt, t, y, pps, dit_heads, 1, q=q), t, x0, lat).mean()
+        sg = dict(zip(student_trainable, torch.autograd.grad(sloss, [sl[k] for k in student_trainable])))
+        if on_student_grads is not None:
+            on_student_grads(step, sg)
+        stotal, sclipped = clip_grad_norm([sg[k] for k in student_trainable], max_norm)
+        rate = warmup_lr(step, diff_lr, warmup_steps)
+        for k, g_ in zip(student_trainable, sclipped):
+            ps[k], ms[k], vs_[k] = adamw_step(ps[k].detach(), g_, ms[k], vs_[k], step + 1, rate, wd=wd)
+        log.update({"diffusion_loss": float(sloss.detach()), "sit_norm": float(stotal)})
+        logs.append(log)
+    return logs, pv, ps
+
+
 def dit_output_to_latents(samples: Tensor, latent_mean: float, latent_scale: float) -> Tensor:
     """sample_50k.py:143-148: [B, C, h, w] -> [B, h*w, C] tokens / scale + mean."""
     b, c, h, w = samples.shape

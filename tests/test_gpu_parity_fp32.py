@@ -411,3 +411,42 @@ def test_vit_trainable_fwd_bwd_vs_reference_f32():
             continue
         assert rel_err(grads[k[2:]].grad.cpu(), ref) < TOL, k
         assert elem_err(grads[k[2:]].grad.cpu(), ref) < TOL, k
+
+
+def test_dmd_stage_steps_vs_reference_f32():
+    """Config C3 in the parity mode: DMDTrainer's four steps (trainable ViT encoder through models/vit_parity.py, decoder + LPIPS + DMD loss, teacher / student
+    LightningDiT through models/lightningdit_parity.py, both optimiser tails on the kernels) against the capture of the reference's train_dmd.py loop
+    (oracle/capture_golden_dmd_step.py): every logged scalar of the first two steps at 1e-4 (the gradient norms included: the whole VAE backward with the encoder,
+    the student's backward), of the later steps at the tolerance tests/test_oracle_dmd_step.py grants the CPU oracle there (x 10: the first forward passes over
+    weights moved by an Adam step at full rate); the first step's fifteen fully captured gradients element-wise and every parameter's gradient norm at 1e-4."""
+    from test_gpu_train_step import _dmd_capture_trainer, _run_dmd_capture_steps
+    from test_oracle_dmd_step import REF_NAME, SMALL_SIT, SMALL_VAE
+    g = load_golden("dmd_step_small")
+    tr, pv, lp_w, teacher, student, images, labels, draws = _dmd_capture_trainer(g)
+    vid = {id(p): n for n, p in tr.vae.named_parameters()}
+    sid = {id(p): n for n, p in student.named_parameters()}
+
+    def on_step(step, log):
+        for k in [k for k in ("L1", "L2", "LPIPS", "rec_loss", "dmd_loss", "dmd_gradient_norm", "vae_norm", "diffusion_loss", "sit_norm") if f"log{step}.{k}" in g]:
+            want, got = float(g[f"log{step}.{k}"]), log[k]
+            bar = TOL * (10.0 if step >= 2 else 1.0)
+            assert abs(got - want) < bar * abs(want), (step, k, got, want)
+        if step == 0:
+            vg = {vid[id(p)]: tr.fp.grad[off:off + p.numel()].view(p.shape).float().cpu() for p, off in zip(tr.fp.params, tr.fp.offsets)}
+            sg = {sid[id(p)]: tr.sfp.grad[off:off + p.numel()].view(p.shape).float().cpu() for p, off in zip(tr.sfp.params, tr.sfp.offsets)}
+            for k in SMALL_VAE:
+                assert rel_err(vg[k], g.t("vg0." + REF_NAME(k))) < TOL, k
+            for k in SMALL_SIT:
+                assert rel_err(sg[k], g.t("sg0." + k)) < TOL, k
+            checked = 0
+            for grads, key, ren in ((vg, "vgn0.", REF_NAME), (sg, "sgn0.", lambda k: k)):
+                for k, gr in grads.items():
+                    if key + ren(k) not in g:
+                        continue
+                    want = float(g[key + ren(k)][0])
+                    if want < 1e-6 or k.endswith("attn_1.k.bias"):
+                        continue
+                    assert abs(gr.double().norm().item() - want) < TOL * want, (k, gr.double().norm().item(), want)
+                    checked += 1
+            assert checked >= 150
+    _run_dmd_capture_steps(tr, images, labels, draws, on_step)

@@ -501,3 +501,101 @@ def test_transport_times_on_the_device_equal_the_pageable_copy():
     end = torch.rand(3)
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(ref, got)) and torch.equal(end, end_ref)
+
+
+def _dmd_capture_trainer(g):
+    """DMDTrainer over the capture's models (tests/test_oracle_dmd_step.py::dmd_step_inputs), on the GPU, with the capture's hyper-parameters."""
+    from dmvae_amd.train import DMDTrainer
+    from dmvae_amd.utils.lpips import LPIPS
+    from test_oracle_dmd_step import dmd_step_inputs
+    pv, vae, lp_w, teacher, student, images, labels, draws = dmd_step_inputs(g)
+    vae.load_state_dict(pv, strict=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lp = LPIPS().eval().requires_grad_(False)
+    lp.load_state_dict(lp_w, strict=False)
+    # the capture's VGG trunk: name-seeded (oracle/capture_golden_dmd_step.py), rebuilt the way tests/test_oracle_golden.py::lpips_params does for the oracle
+    from test_oracle_golden import lpips_params
+    full = lpips_params(g, "lp.")
+    lp.load_state_dict({k: v for k, v in full.items() if k in lp.state_dict()}, strict=False)
+    tr = DMDTrainer(vae.cuda(), lp.cuda(), teacher.cuda().eval().requires_grad_(False), student.cuda(), lr=float(g["lr"]), diff_lr=float(g["diff_lr"]), wd=float(g["wd"]),
+                    dmd_weight=float(g["dmd_weight"]), dmd_cfg_scale=float(g["cfg"]), num_classes=10, latent_mean=float(g["latent_mean"]),
+                    latent_scale=float(g["latent_scale"]), vae_train_every=int(g["vae_train_every"]), warmup_steps=int(g["warmup_steps"]))
+    return tr, pv, lp_w, teacher, student, images, labels, draws
+
+
+def _run_dmd_capture_steps(tr, images, labels, draws, on_step):
+    """Four steps with the capture's draws injected: DMDTrainer._sample hands out the recorded (t, x0) in the order the step asks for them (the DMD loss's on VAE
+    turns, then the student's), the student's label drop-out is the recorded mask."""
+    student = tr.student
+    orig_sample, orig_drop = tr._sample, student.y_embedder.token_drop
+    try:
+        for step, d in enumerate(draws):
+            queue = ([d["dmd"]] if "dmd" in d else []) + [d["student"][:2]]
+            tr._sample = lambda x1, q=queue: tuple(v.to(x1) for v in q.pop(0))
+            student.y_embedder.token_drop = lambda lab, force_drop_ids=None, m=d["student"][2]: torch.where(m.to(lab.device), torch.full_like(lab, 10), lab)
+            tr.step(images.cuda(), labels.cuda())
+            tr.wait_optimizers()
+            assert not queue
+            on_step(step, tr.read_log())
+    finally:
+        tr._sample, student.y_embedder.token_drop = orig_sample, orig_drop
+
+
+def test_dmd_trainer_vs_reference_capture_c3():
+    """Config C3's step pinned to the REFERENCE: `DMDTrainer` (trainable ViT encoder, decoder, LPIPS, the DMD loss over teacher / student LightningDiT with CFG as one
+    2B call, then the student's flow-matching turn) replays the four steps oracle/capture_golden_dmd_step.py recorded from train_dmd.py:506-575 run with the
+    reference's own modules and VAELossFunction, with the capture's draws injected.  Bars: the bf16-site criterion -- as close to the reference's f32 numbers as the
+    CPU oracle with bf16 rounding at the autocast sites (oracle.ref_cpu.dmd_train_steps(q=bf16_round)) is, x 1.15 + a floor -- for every logged scalar of the first
+    step, the fifteen fully captured gradients and every parameter's gradient norm (VAE: decoder, bottleneck, the TRAINABLE encoder; student); the later steps'
+    scalars to the bf16 floor of a trajectory (2 % losses, 8 % norms)."""
+    from conftest import load_golden
+    from oracle import ref_cpu as R
+    from test_oracle_dmd_step import DIT_KW as KW, REF_NAME, SMALL_SIT, SMALL_VAE, hyper
+    g = load_golden("dmd_step_small")
+    tr, pv, lp_w, teacher, student, images, labels, draws = _dmd_capture_trainer(g)
+    vnames = [n for n, _ in tr.vae.named_parameters()]
+    snames = [str(n) for n in g["student_names"]]
+    # ---- the bf16-site oracle's first step (CPU): what "as close as bf16 allows" means for each number ----
+    pt = {k: v.detach().cpu().clone() for k, v in teacher.state_dict().items()}
+    ps = {k: v.detach().cpu().clone() for k, v in student.state_dict().items()}
+    ovg, osg = {}, {}
+    ologs, _, _ = R.dmd_train_steps(images, labels, {k: v.clone() for k, v in pv.items()}, lp_w, pt, ps, vnames, snames, draws[:1], **hyper(g), q=R.bf16_round,
+                                    on_vae_grads=lambda s, gr: ovg.update({k: v.clone() for k, v in gr.items()}),
+                                    on_student_grads=lambda s, gr: osg.update({k: v.clone() for k, v in gr.items()}))
+    rl2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    vid = {id(p): n for n, p in tr.vae.named_parameters()}
+    sid = {id(p): n for n, p in student.named_parameters()}
+
+    def on_step(step, log):
+        for k in [k for k in ("L1", "LPIPS", "rec_loss", "dmd_loss", "dmd_gradient_norm", "vae_norm", "diffusion_loss", "sit_norm") if f"log{step}.{k}" in g]:
+            want, got = float(g[f"log{step}.{k}"]), log[k]
+            norm_like = k in ("vae_norm", "sit_norm", "dmd_gradient_norm")
+            if step == 0:
+                e_orc = abs(ologs[0][k] - want) / abs(want)
+                print(f"C3 step 0 {k}: reference {want:.6f}  HIP {got:.6f}  bf16-site oracle {ologs[0][k]:.6f}")
+                assert abs(got - want) / abs(want) < 1.15 * e_orc + (2e-2 if norm_like else 3e-3), (k, got, want, ologs[0][k])
+            else:
+                assert abs(got - want) < (8e-2 if norm_like else 2e-2) * abs(want), (step, k, got, want)
+        if step == 0:
+            vg = {vid[id(p)]: tr.fp.grad[off:off + p.numel()].view(p.shape).float().cpu() for p, off in zip(tr.fp.params, tr.fp.offsets)}
+            sg = {sid[id(p)]: tr.sfp.grad[off:off + p.numel()].view(p.shape).float().cpu() for p, off in zip(tr.sfp.params, tr.sfp.offsets)}
+            for k in SMALL_VAE:
+                e_hip, e_orc = rl2(vg[k], g.t("vg0." + REF_NAME(k))), rl2(ovg[k], g.t("vg0." + REF_NAME(k)))
+                print(f"C3 step 0 VAE grad {k}: rel-L2 to the f32 reference -- HIP {e_hip:.2e}, bf16-site oracle {e_orc:.2e}")
+                assert e_hip < 1.15 * e_orc + 3e-3, (k, e_hip, e_orc)
+            for k in SMALL_SIT:
+                e_hip, e_orc = rl2(sg[k], g.t("sg0." + k)), rl2(osg[k], g.t("sg0." + k))
+                print(f"C3 step 0 student grad {k}: rel-L2 to the f32 reference -- HIP {e_hip:.2e}, bf16-site oracle {e_orc:.2e}")
+                assert e_hip < 1.15 * e_orc + 3e-3, (k, e_hip, e_orc)
+            for grads, ograds, key, ren in ((vg, ovg, "vgn0.", REF_NAME), (sg, osg, "sgn0.", lambda k: k)):
+                for k, gr in grads.items():
+                    if key + ren(k) not in g or k not in ograds:
+                        continue
+                    want = float(g[key + ren(k)][0])
+                    if want < 1e-4 or k.endswith("attn_1.k.bias"):
+                        continue
+                    e_hip = abs(gr.double().norm().item() - want) / want
+                    e_orc = abs(ograds[k].double().norm().item() - want) / want
+                    assert e_hip < 1.15 * e_orc + 3e-2, (k, e_hip, e_orc)
+    _run_dmd_capture_steps(tr, images, labels, draws, on_step)
