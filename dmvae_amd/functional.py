@@ -184,6 +184,11 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _lib_mod():
+    from . import _lib
+    return _lib
+
+
 SHORTCUT_IN_NORM = True      # tests/test_gpu_norm_short.py switches it off to compare with the stored-operand route
 SHORTCUT_IN_NORM_512 = True  # ... the 512 -> 256 block's alone (its kernels differ: csrc/norm_short.hip, namespace coop)
 
@@ -608,11 +613,35 @@ class BatchNormActFn(torch.autograd.Function):
         if parity.on():
             # fp32 parity mode: the f32 GroupNorm backward (one "image", one channel per group) -- batch statistics of ONE rank only (the cross-rank sums and the
             # constant-statistics form of an eval-mode discriminator are not needed by the 1e-4 tests and are refused rather than approximated)
-            if not batch_stats or group is not None:
-                raise NotImplementedError("BatchNormActFn backward in the fp32 parity mode: batch statistics on a single rank only")
-            dx, dg, db = parity.groupnorm_bwd(dy3.float(), x3, stats, gamma, beta, act, groups=c, need_param_grads=need_p, dg_out=_dst(gamma) if need_p else None,
-                                              db_out=_dst(beta) if need_p else None, inv_count=1.0 / count)
-            return (dx.view(x.shape) if ctx.needs_input_grad[0] else None), dg, db, None, None, None, None, None
+            if group is not None:
+                raise NotImplementedError("BatchNormActFn backward in the fp32 parity mode: a single rank only (the cross-rank sums of SyncBatchNorm are not built in f32)")
+            if batch_stats:
+                dx, dg, db = parity.groupnorm_bwd(dy3.float(), x3, stats, gamma, beta, act, groups=c, need_param_grads=need_p, dg_out=_dst(gamma) if need_p else None,
+                                                  db_out=_dst(beta) if need_p else None, inv_count=1.0 / count)
+                return (dx.view(x.shape) if ctx.needs_input_grad[0] else None), dg, db, None, None, None, None, None
+            # running statistics (an eval-mode discriminator: the generator's adversarial term, train_tokenizer.py:190-193): the statistics are constants, so
+            # dx = g * gamma * rstd with g = dy * act'(u); d gamma = sum g * xh, d beta = sum g -- composed from the f32 kernels (no mean-subtraction terms)
+            from .models.lightningdit_parity import colsum_groups
+            rows = x3.shape[1]
+            g = _c(dy3.float())
+            if act == 2:
+                g = parity.eltwise(3, g, parity.groupnorm_apply(x3, stats, gamma, beta, act, groups=c), param=0.2)      # LeakyReLU backward from the activation's output
+            elif act != 0:
+                raise NotImplementedError("BatchNormActFn backward in the fp32 parity mode: LeakyReLU or no activation")
+            L, st = _lib_mod().lib(), torch.cuda.current_stream().cuda_stream
+            scale = (gamma.detach().float() * stats[0, :, 1]).contiguous().view(1, c)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(g)
+                _lib_mod().check(L.dmvae_bcast_rows_f32(1, g.data_ptr(), None, scale.data_ptr(), dx.data_ptr(), rows, c, rows, c, st), "bcast_rows_f32")
+                dx = dx.view(x.shape)
+            dg = db = None
+            if need_p:
+                xh = parity.groupnorm_apply(x3, stats, torch.ones_like(gamma), torch.zeros_like(beta), 0, groups=c)
+                prod = torch.empty_like(g)
+                _lib_mod().check(L.dmvae_bcast_rows_f32(2, g.data_ptr(), xh.data_ptr(), None, prod.data_ptr(), rows, c, rows, 0, st), "bcast_rows_f32")
+                dg, db = colsum_groups(prod.view(rows, c), 1).view(c), colsum_groups(g.view(rows, c), 1).view(c)
+            return dx, dg, db, None, None, None, None, None
         if batch_stats or need_p:
             sums, dg, db = ops.groupnorm_bwd_reduce(dy3, x3, stats, gamma, beta, act, groups=c, need_param_grads=need_p,
                                                     dg_out=_dst(gamma) if need_p else None, db_out=_dst(beta) if need_p else None)

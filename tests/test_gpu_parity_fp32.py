@@ -450,3 +450,69 @@ def test_dmd_stage_steps_vs_reference_f32():
                     checked += 1
             assert checked >= 150
     _run_dmd_capture_steps(tr, images, labels, draws, on_step)
+
+
+def test_gan_loss_terms_vs_reference_f32():
+    """The adversarial branch (train_tokenizer.py:190-227) in the parity mode against the capture of the reference's own forward_generator (discriminator branch on)
+    and forward_discriminator (oracle/capture_golden_gan.py): the reconstruction loss, the ADAPTIVE WEIGHT -- a ratio of two gradient norms at the last layer, one
+    of them through the eval-mode PatchGAN and DiffAug --, the generator's total and its gradient at the last layer; then the discriminator's hinge + BCR terms,
+    its accuracy counters, the BatchNorm running estimates after two training passes and every parameter's gradient norm -- at 1e-4."""
+    import torch.nn.functional as F
+    from dmvae_amd import losses
+    from dmvae_amd.models.patchgan import NLayerDiscriminator
+    from dmvae_amd.utils.diffaug import DiffAug
+    from dmvae_amd.utils.lpips import LPIPS
+    from test_gpu_gan import _RandQueue
+    from test_oracle_gan import patchgan_params
+    from test_oracle_golden import lpips_params
+    g = load_golden("gan_losses")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lp = LPIPS().eval().requires_grad_(False)
+    sd = lp.state_dict()
+    for k, v in lpips_params(g).items():
+        sd[k] = v.reshape(sd[k].shape)
+    lp.load_state_dict(sd)
+    lp = lp.to(DEV)
+    disc_p = patchgan_params(g, int(g["disc_seed"]))
+    disc = NLayerDiscriminator()
+    dsd = disc.state_dict()
+    for k in dsd:
+        if k in disc_p:
+            dsd[k] = disc_p[k].clone()
+    disc.load_state_dict(dsd, strict=True)
+    disc = disc.to(DEV)
+    img, feat = g.t("images").to(DEV), g.t("feat").to(DEV)
+    last = g.t("last").to(DEV).requires_grad_(True)
+    B = img.shape[0]
+    recon = (F.conv2d(feat.double(), last.double(), padding=1) + 0.9 * img.double()).float()      # the capture's stand-in for the decoder's last layer (test plumbing, not the path under test)
+    l1, l2 = losses.l1_mse(recon, img, 1.0, 0.0)
+    rec_loss = l1 + lp(img, recon)
+    with _RandQueue([torch.zeros(3), g.t("gen_rand01").view(7, B, 1, 1)]):
+        total, d_weight = losses.generator_gan_term(rec_loss, recon, disc, DiffAug(prob=1.0, cutout=0.2), last, 0.5)
+    assert abs(rec_loss.item() - float(g["gen_rec_loss"])) < TOL * float(g["gen_rec_loss"])
+    assert abs(d_weight.item() - float(g["d_weight"])) < TOL * float(g["d_weight"])
+    assert abs(total.item() - float(g["gen_loss"])) < TOL * abs(float(g["gen_loss"]))
+    total.backward()
+    assert rel_err(last.grad.cpu(), g.t("g_last")) < TOL
+    draws = [torch.zeros(3), g.t("d_rand01_a").view(7, 2 * B, 1, 1), torch.zeros(3), g.t("d_rand01_b").view(7, 2 * B, 1, 1)]
+    with _RandQueue(draws):
+        d_total, dlog = losses.discriminator_loss(img, g.t("recon").to(DEV), disc, DiffAug(prob=1.0, cutout=0.2), DiffAug(prob=1, cutout=0.5), 4.0)
+    assert abs(d_total.item() - float(g["d_total"])) < TOL * abs(float(g["d_total"]))
+    assert abs(dlog["d_loss"].item() - float(g["dlog.d_loss"])) < TOL * float(g["dlog.d_loss"])
+    assert abs(dlog["bcr_loss"].item() - float(g["dlog.bcr_loss"])) < TOL * float(g["dlog.bcr_loss"])
+    assert abs(dlog["acc_real"].item() - float(g["dlog.acc_real"])) < 1e-3 and abs(dlog["acc_fake"].item() - float(g["dlog.acc_fake"])) < 1e-3      # the same logits' signs (72 per half: one flip = 1.4 points)
+    d_total.backward()
+    sd = disc.state_dict()
+    for k, v in g.sub("buf2.").items():
+        if "num_batches" not in k:
+            assert rel_err(sd[k].cpu(), v) < TOL, k
+    checked = 0
+    for n, prm in disc.named_parameters():
+        gn = float(g["dgn." + n][0])
+        if gn > 1e-5:
+            assert abs(prm.grad.double().norm().item() - gn) < TOL * gn, n
+            checked += 1
+    assert checked >= 8
+    for k, v in g.sub("dg.").items():
+        assert rel_err(dict(disc.named_parameters())[k].grad.cpu(), v) < TOL, k
