@@ -167,6 +167,11 @@ namespace dmvae_vit {
 
 constexpr int ATT_D = 64, ATT_KB = 9, ATT_KEYS = ATT_KB * 32;  // keys padded to 288
 
+template <int N>
+__device__ __forceinline__ void attn_wait_vmcnt() {   // through the builtin: the compiler's wait-count pass has to see the wait (conv_pp.hip)
+  __builtin_amdgcn_s_waitcnt((N & 15) | 0x0F70 | ((N >> 4) << 14));
+  asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ s16x4 tr_read_v(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
@@ -198,7 +203,10 @@ struct AttnArgs {
 // softmax -> MFMA -> store per wave.  
 constexpr int ATTN_THREADS = 512;
 // (Serving the class token's query -- S = 32 k + 1 -- by extra single-query workgroups instead of a ninth 32-query block was built and measured slower: DESIGN_HISTORY.md 9.8-6.)
-template <int DP, bool NR>
+// PIPE (DP = 96 route, more than one (batch, head) per workgroup): the grid is one workgroup per CU and a workgroup walks (batch, head) items blockIdx.x, + gridDim.x, ...;
+// the NEXT item's K / V global loads are issued into registers right behind the current item's Q loads and land under its two sweeps -- the staging phase (a third of an
+// item's time with one 147-KB workgroup per CU and nothing else resident to hide it) then only pays its LDS stores.  Same operations on the same values: same bits.
+template <int DP, bool NR, bool PIPE = false>
 __global__ __launch_bounds__(ATTN_THREADS) void attention_kernel(AttnArgs a) {
   constexpr int NT = ATTN_THREADS;
 #if __HIP_DEVICE_COMPILE__
@@ -221,12 +229,61 @@ __global__ __launch_bounds__(ATTN_THREADS) void attention_kernel(AttnArgs a) {
   const int S = a.S, H = a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Sq = S;      // queries the 32-query blocks cover
-  const int bh = a.xcd ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  static_assert(!(PIPE && NR), "PIPE: the plain staging only");
+  const int vchunks = a.D / 8;           // V rows hold the real head dim
+  // item -> (batch, head): PIPE walks items blockIdx.x + i gridDim.x (gridDim.x a multiple of 8: an item stays on its workgroup's XCD), else one item per workgroup
+  auto item_bh = [&](int item) { return a.xcd ? (int)xcd_remap((unsigned)item, PIPE ? (unsigned)a.BH : gridDim.x) : item; };
+  constexpr int SWEEPS = (ATT_KEYS * (DP / 8) + NT - 1) / NT;
+  [[maybe_unused]] uint4 kv[SWEEPS], vv[SWEEPS];
+  // every global load of the staging is issued before the first LDS store (the loop form waited for each sweep's loads before issuing the next sweep's:
+  // nine to fourteen serial memory round trips, a third of the kernel's time at these sizes)
+  // PIPE: buffer loads -- the per-lane byte offsets are the same for every item (kept in SWEEPS + SWEEPS registers instead of a 64-bit address per load), the item's base
+  // sits in the wave-uniform descriptor, and a masked element is an offset past the descriptor's range (reads zeros: no select behind the load)
+  [[maybe_unused]] unsigned voK[SWEEPS], voV[SWEEPS];
+  if constexpr (PIPE) {
+#pragma unroll
+    for (int it = 0; it < SWEEPS; it++) {
+      const int i = tid + it * NT, key = i / (DP / 8), c = i - key * (DP / 8);
+      const bool ok = i < ATT_KEYS * (DP / 8) && key < S;
+      voK[it] = ok ? (unsigned)key * (unsigned)a.k_rs * 2u + (unsigned)c * 16u : 0x80000000u;
+      voV[it] = ok && c < vchunks ? (unsigned)key * (unsigned)a.v_rs * 2u + (unsigned)c * 16u : 0x80000000u;
+    }
+  }
+  auto load_kv = [&](int bh_) {
+    const int b_ = __builtin_amdgcn_readfirstlane(bh_ / H), h_ = __builtin_amdgcn_readfirstlane(bh_ % H);
+    const bf16* kp = a.k + b_ * a.k_bs + h_ * a.k_hs;
+    const bf16* vp = a.v + b_ * a.v_bs + h_ * a.v_hs;
+    if constexpr (PIPE) {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int it = 0; it < SWEEPS; it++) {
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rK, voK[it], 0, 0), y = __builtin_amdgcn_raw_buffer_load_b128(rV, voV[it], 0, 0);
+        kv[it] = uint4{x[0], x[1], x[2], x[3]}; vv[it] = uint4{y[0], y[1], y[2], y[3]};
+      }
+      return;
+    }
+#pragma unroll
+    for (int it = 0; it < SWEEPS; it++) {
+      const int i = tid + it * NT, key = i / (DP / 8), c = i - key * (DP / 8);
+      kv[it] = uint4{0, 0, 0, 0}; vv[it] = uint4{0, 0, 0, 0};
+      if (i < ATT_KEYS * (DP / 8) && key < S) {
+        kv[it] = *reinterpret_cast<const uint4*>(kp + (size_t)key * a.k_rs + c * 8);
+        if (c < vchunks) vv[it] = *reinterpret_cast<const uint4*>(vp + (size_t)key * a.v_rs + c * 8);
+      }
+    }
+  };
+  int item = (int)blockIdx.x;
+  if constexpr (PIPE) load_kv(item_bh(item));
+  for (;;) {
+  const int bh = item_bh(item);
   const int b = bh / H, h = bh % H;
   const bf16* qb_ = a.q + b * a.q_bs + h * a.q_hs;
-  const bf16* kb_ = a.k + b * a.k_bs + h * a.k_hs;
-  const bf16* vb_ = a.v + b * a.v_bs + h * a.v_hs;
-  const int vchunks = a.D / 8;           // V rows hold the real head dim
+  [[maybe_unused]] const bf16* kb_ = a.k + b * a.k_bs + h * a.k_hs;
+  [[maybe_unused]] const bf16* vb_ = a.v + b * a.v_bs + h * a.v_hs;
+  const int next = item + (int)gridDim.x;
+  [[maybe_unused]] bool pre = PIPE && next < a.BH;     // the next item's K / V loads are still to be issued
   // ---- stage K and V: DP/8 lanes x 16 B per key row ------------------------------------------------------------------------------------
   if constexpr (NR) {  // 16 lanes per key row (the first DP/8 carry data) so that the row's sum of squares is a 16-lane butterfly
     const int c = tid & 15;
@@ -247,19 +304,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attention_kernel(AttnArgs a) {
       }
     }
   } else {
-    // every global load of the staging is issued before the first LDS store (the loop form waited for each sweep's loads before issuing the next sweep's:
-    // nine to fourteen serial memory round trips, a third of the kernel's time at these sizes)
-    constexpr int SWEEPS = (ATT_KEYS * (DP / 8) + NT - 1) / NT;
-    uint4 kv[SWEEPS], vv[SWEEPS];
-#pragma unroll
-    for (int it = 0; it < SWEEPS; it++) {
-      const int i = tid + it * NT, key = i / (DP / 8), c = i - key * (DP / 8);
-      kv[it] = uint4{0, 0, 0, 0}; vv[it] = uint4{0, 0, 0, 0};
-      if (i < ATT_KEYS * (DP / 8) && key < S) {
-        kv[it] = *reinterpret_cast<const uint4*>(kb_ + (size_t)key * a.k_rs + c * 8);
-        if (c < vchunks) vv[it] = *reinterpret_cast<const uint4*>(vb_ + (size_t)key * a.v_rs + c * 8);
-      }
-    }
+    if constexpr (!PIPE) load_kv(bh);
 #pragma unroll
     for (int it = 0; it < SWEEPS; it++) {
       const int i = tid + it * NT, key = i / (DP / 8), c = i - key * (DP / 8);
@@ -289,6 +334,17 @@ __global__ __launch_bounds__(ATTN_THREADS) void attention_kernel(AttnArgs a) {
       uint4 t = {0, 0, 0, 0};
       if (q < Sq && (!NR || kk * 16 + kg * 8 < a.D)) t = *reinterpret_cast<const uint4*>(qb_ + (size_t)q * a.q_rs + kk * 16 + kg * 8);
       qf[kk] = *reinterpret_cast<bf16x8*>(&t);
+    }
+    if constexpr (PIPE) {
+      // behind this block's Q loads in the (in-order) load queue: waiting for Q leaves them in flight.  The waits are spelled out on both paths: left to the compiler's
+      // wait-count pass, the first use of Q -- inside the sweep loop -- got s_waitcnt vmcnt(0), i.e. the prefetch was waited for before the first product
+      // (and the fragments pass through an empty asm right behind the wait: the pass then knows them landed; the explicit wait alone did not change its in-loop wait)
+      auto pin_q = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; kk++) asm volatile("" : "+v"(qf[kk]));
+      };
+      if (pre) { load_kv(item_bh(next)); pre = false; attn_wait_vmcnt<2 * SWEEPS>(); pin_q(); }
+      else { attn_wait_vmcnt<0>(); pin_q(); }
     }
     if constexpr (NR) {  // this lane and lane ^ 32 hold the two halves of query q's row
       float ss = 0.f;
@@ -395,6 +451,12 @@ __global__ __launch_bounds__(ATTN_THREADS) void attention_kernel(AttnArgs a) {
         }
     }
   }
+  if constexpr (!PIPE) break;
+  if (next >= a.BH) break;
+  if (pre) load_kv(item_bh(next));     // a wave without a query block of its own
+  item = next;
+  __syncthreads();                     // every wave is done with this item's K / V image
+  }
 #endif
 }
 
@@ -410,6 +472,24 @@ static int launch_attention(const AttnArgs& a, int batch, hipStream_t stream) {
   b_.BH = batch * a.H;
   static const int xcd = [] { const char* e = getenv("DMVAE_ATTN_XCD"); return !(e && e[0] == '0') ? 1 : 0; }();
   b_.xcd = xcd;
+  if constexpr (DP == 96 && !NR) {   // two or more (batch, head) items per CU: the persistent form that loads the next item's K / V under the current one's sweeps (DMVAE_ATTN_PIPE=0: off)
+    static const int pipe = [] { const char* e = getenv("DMVAE_ATTN_PIPE"); return !(e && e[0] == '0') ? 1 : 0; }();
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+      return n & ~7;
+    }();
+    if (pipe && b_.BH >= 2 * cus) {
+      static bool attr_pipe = false;
+      if (!attr_pipe) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DP, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_pipe = true;
+      }
+      hipLaunchKernelGGL((attention_kernel<DP, false, true>), dim3(cus), dim3(ATTN_THREADS), lds, stream, b_);
+      DMVAE_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((attention_kernel<DP, NR>), dim3(batch * a.H), dim3(ATTN_THREADS), lds, stream, b_);
   DMVAE_CHECK_LAUNCH();
   return 0;

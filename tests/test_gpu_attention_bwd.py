@@ -124,3 +124,10 @@ def test_attention_kernels_give_the_same_bits_in_every_launch_form(n, d):
         outs.append((o, lse, dq, dk, dv))
     for a, c, rows in zip(outs[0], outs[1], (small, small * h, small * h, small * h, small * h)):
         assert torch.equal(a[:rows], c), "launch form changed the bits"
+    # every sample of the large call, forward: at 640 blocks the 96-wide forward is the persistent form (one workgroup per CU walking two or three (sample, head)
+    # items, the next item's K / V loaded under the current one's sweeps -- csrc/vit.hip, PIPE); 128-block calls are the one-item-per-workgroup form
+    o_big, lse_big = outs[0][0], outs[0][1]
+    for s0 in range(0, big, small):
+        sl = slice(s0 * h, (s0 + small) * h)
+        o_c, lse_c = ops.attention_heads(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), small, scale, need_lse=True)
+        assert torch.equal(o_big[s0:s0 + small], o_c) and torch.equal(lse_big[sl], lse_c), f"samples {s0}..{s0 + small - 1}"
