@@ -330,7 +330,7 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
   wait_vmcnt<0>();
 
   int tix = 0;
-  auto stamp = [&](int k) { if (a.dbg && tid == 0 && tix < 4) a.dbg[((size_t)blockIdx.x * 4 + tix) * 4 + k] = __builtin_amdgcn_s_memtime(); };
+  auto stamp = [&](int k) { if (a.dbg && tid == 0 && tix < 4) a.dbg[((size_t)blockIdx.x * 4 + tix) * 8 + k] = __builtin_amdgcn_s_memtime(); };   // [block][tile 0..3][8]: 0-3 the tile's phases, 4-7 inside SK's hand-over
   while (work < (unsigned)a.total) {
     stamp(0);
     __builtin_amdgcn_s_barrier();                  // B_0: everybody's pieces of K tiles 0 .. 2 and of the bias slice have landed (each wave waited for its own)
@@ -408,12 +408,15 @@ __global__ __launch_bounds__(WM * WP * 64) void gemm_pp_kernel(Args a) {
               asm volatile("s_nop 0" :: "v"(k4));
             }
           }
+        stamp(4);
         wait_vmcnt<0>();                           // the part has been written THROUGH to memory (sc0 sc1 stores are acknowledged from there) before the arrival is counted
+        stamp(5);
         unsigned old = 0;
         unsigned* cnt = a.counters + (size_t)uc.tile * 8 + wave;
         if (lane_s == 0) old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
         sk_final = old == (unsigned)(uc.P - 1);
+        stamp(6);
         if (sk_final) {
           if (lane_s == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left zero for the next launch
         }
@@ -877,7 +880,7 @@ extern "C" int dmvae_linear_bf16_sk(const void* x, const void* w, const void* bi
   Args a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.y = y;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldy = ldy;
-  a.act = act; a.bias_bf16 = bias_bf16; a.H = N / 2; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = nullptr;
+  a.act = act; a.bias_bf16 = bias_bf16; a.H = N / 2; a.ntn = 0; a.total = 0; a.inv_ntn = 0.f; a.dbg = g_gemm_dbg;
   a.wbytes = (unsigned)wb; a.tpb = 0; a.inv_tpb = 0.f; a.sA = a.sB = a.sY = a.xbytes = a.ybytes = 0u;
   a.wsRow = w_layout == 1 ? 64u : (unsigned)ldw * 2u;
   a.wsK = w_layout == 1 ? (unsigned)N * 64u : 64u;

@@ -11,12 +11,12 @@ L.dmvae_debug_gemm_cfg.argtypes = [ctypes.c_int]; L.dmvae_debug_gemm_timing.argt
 x = torch.randn(m, k, device="cuda").to(torch.bfloat16); w = (torch.randn(n, k, device="cuda") * 0.02).to(torch.bfloat16); b = torch.randn(n, device="cuda").to(torch.bfloat16)
 L.dmvae_debug_gemm_cfg(cfg)
 for _ in range(5): ops.linear_bf16(x, w, b)
-buf = torch.zeros(256 * 4 * 4, dtype=torch.int64, device="cuda")
+buf = torch.zeros(256 * 4 * 8, dtype=torch.int64, device="cuda")
 L.dmvae_debug_gemm_timing(buf.data_ptr())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); ops.linear_bf16(x, w, b); e1.record(); torch.cuda.synchronize()
 L.dmvae_debug_gemm_timing(None)
-t = buf.view(256, 4, 4).cpu().double()
+t = buf.view(256, 4, 8).cpu().double()
 print(f"{m}x{n}x{k} cfg {cfg} plan {ops.linear_plan(m, n, k)}: call {e0.elapsed_time(e1) * 1e3:.1f} us (phases in k-cycles of s_memtime)")
 live = t[:, 0, 3] > 0
 t = t * 1.0
