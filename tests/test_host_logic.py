@@ -379,3 +379,18 @@ def test_integration_md_fits_a_160_column_view():
     from conftest import ROOT
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wrap_md.py"), os.path.join(ROOT, "INTEGRATION.md"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_every_environment_switch_the_package_reads_is_listed_in_integration_md():
+    """INTEGRATION.md ("Run-time switches") claims to list every environment variable the package reads: every DMVAE_* name that appears in a getenv / os.environ
+    read of dmvae_amd/ (Python and HIP sources) or bench.py must appear in that file."""
+    import glob, re
+    from conftest import ROOT
+    pat = re.compile(r'(?:getenv\(|environ\.get\(|environ\[|_env_int\(|_flag\()\s*"(DMVAE_[A-Z0-9_]+)"')
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "dmvae_amd", "**", "*.py"), recursive=True) + glob.glob(os.path.join(ROOT, "dmvae_amd", "csrc", "*.hip")) + [os.path.join(ROOT, "bench.py")]:
+        names |= set(pat.findall(open(f, encoding="utf-8").read()))
+    assert len(names) >= 20, names
+    doc = open(os.path.join(ROOT, "INTEGRATION.md"), encoding="utf-8").read()
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
