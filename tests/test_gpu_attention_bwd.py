@@ -101,7 +101,7 @@ def test_attention_bwd_heads_layout(b, n, h, d):
     assert all(torch.equal(x, y) for x, y in zip((dq2, dk2, dv2), again))
 
 
-@pytest.mark.parametrize("n,d", [(256, 72), (200, 72), (256, 64)])
+@pytest.mark.parametrize("n,d", [(256, 72), (200, 72), (272, 72), (256, 64)])      # 272 tokens: nine query blocks for eight waves (a second round inside an item)
 def test_attention_kernels_give_the_same_bits_in_every_launch_form(n, d):
     """The launch forms chosen by the NUMBER of (sample, head) blocks -- the three-image backward at <= 512 blocks, the two-image one above; the XCD-aware block order
     at any grid -- compute the same sums in the same order: samples 0..7 of a 40-sample call (640 blocks) must equal the 8-sample call (128 blocks) bit for bit,
