@@ -47,6 +47,31 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
   return *reinterpret_cast<unsigned*>(&t);
 }
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * PITCH + (((chunk & ~3) | ((chunk & 3) ^ ((row >> 2) & 3))) << 4); }
+// LDS operand layouts of the lse kernels' two block functions.  Wide: the 192-B rows above (both head widths).  Tight (72-channel heads, S <= 256 only): 144-B rows
+// holding the 72 real channels, no swizzle -- row reads: sixteen rows 36 banks apart land on sixteen distinct 4-bank slots (9 is odd), conflict-free as they are;
+// transpose reads: the four rows of a 16-lane group are conflict-free, the two groups of a 32-lane pass overlap in two rows (2-way).  Two images are 73.7 KB, so TWO
+// workgroups fit a CU (attention_bwd_lse_tight_kernel).  The channels 72 .. 95 the 96-wide products would read are zeros in the wide image: the tight form skips the
+// sixth K step, zeroes the upper half of the fifth, and leaves the (finite) garbage of output columns >= 72 of the transposed products to be dropped at the store.
+struct LayWide {
+  static constexpr int PITCH_ = PITCH;
+  template <int DP> static constexpr int ksteps() { return DP / 16; }
+  static __device__ __forceinline__ int off(int row, int chunk) { return lds_off(row, chunk); }
+  static __device__ __forceinline__ bf16x8 frag(const char* buf, int row, int kk, int kg) { return *reinterpret_cast<const bf16x8*>(buf + lds_off(row, kk * 2 + kg)); }
+};
+struct LayTight {
+  static constexpr int PITCH_ = 144;
+  template <int DP> static constexpr int ksteps() { return 5; }
+  static __device__ __forceinline__ int off(int row, int chunk) { return row * 144 + chunk * 16; }
+  static __device__ __forceinline__ bf16x8 frag(const char* buf, int row, int kk, int kg) {
+    if (kk < 4) return *reinterpret_cast<const bf16x8*>(buf + row * 144 + (kk * 2 + kg) * 16);
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(buf + row * 144 + 8 * 16);      // kk == 4: channels 64 .. 71 for kg == 0, nothing for kg == 1
+    if (kg) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = (bf16)0.f;
+    }
+    return v;
+  }
+};
 __device__ __forceinline__ float dot8(const uint4& a, const uint4& b) {
   const bf16x8 x = *reinterpret_cast<const bf16x8*>(&a), y = *reinterpret_cast<const bf16x8*>(&b);
   float s = 0.f;
@@ -302,10 +327,10 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Args a) {
   // A key block's LDS reads are issued in two groups ahead of their matrix products (all K / V row fragments; then, behind the S^T / dP^T products, the six K^T
   // fragments of the dQ product, which land under the softmax arithmetic): left to the scheduler, every pair of products sat behind its own LDS round trip --
   // twelve exposed latencies per key block, more than the products and the exponentials together.  Same operations on the same values: same bits.
-template <int DP>
-__device__ __forceinline__ void lse_dq_block(const char* buf0, const char* buf1, const bf16x8 (&qf)[DP / 16], const bf16x8 (&dof)[DP / 16], float Lq, float delta, float scale,
+template <int DP, class L = LayWide>
+__device__ __forceinline__ void lse_dq_block(const char* buf0, const char* buf1, const bf16x8 (&qf)[L::template ksteps<DP>()], const bf16x8 (&dof)[L::template ksteps<DP>()], float Lq, float delta, float scale,
                                              int S, int nblk, int kg, int ql, const int (&toff0)[DP / 32], const int (&toff1)[DP / 32], f32x16 (&dq)[DP / 32]) {
-  constexpr int KSTEPS = DP / 16, DB = DP / 32;
+  constexpr int KSTEPS = L::template ksteps<DP>(), DB = DP / 32;
   for (int kb = 0; kb < nblk; kb++) {
     f32x16 st, dpt;
 #pragma unroll
@@ -314,9 +339,8 @@ __device__ __forceinline__ void lse_dq_block(const char* buf0, const char* buf1,
     bf16x8 kf[KSTEPS], vf[KSTEPS];
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; kk++) {
-      const int off = lds_off(key, kk * 2 + kg);
-      kf[kk] = *reinterpret_cast<const bf16x8*>(buf0 + off);
-      vf[kk] = *reinterpret_cast<const bf16x8*>(buf1 + off);
+      kf[kk] = L::frag(buf0, key, kk, kg);
+      vf[kk] = L::frag(buf1, key, kk, kg);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -327,7 +351,7 @@ __device__ __forceinline__ void lse_dq_block(const char* buf0, const char* buf1,
     union { bf16x8 v; s16x4 hlf[2]; } ktr[2][DB];
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-      const char* base = buf0 + (kb * 2 + half) * 16 * PITCH;
+      const char* base = buf0 + (kb * 2 + half) * 16 * L::PITCH_;
 #pragma unroll
       for (int db = 0; db < DB; db++) {
         ktr[half][db].hlf[0] = tr_read(base + toff0[db]);
@@ -359,11 +383,11 @@ __device__ __forceinline__ void lse_dq_block(const char* buf0, const char* buf1,
 }
 
 // dK / dV of one 32-key block (phase B): Q in bufq, dO in bufd (LDS images), the block's K / V fragments, L and delta of every query in Ls / Ds.
-template <int DP>
-__device__ __forceinline__ void lse_dkdv_block(const char* bufq, const char* bufd, const float* Ls, const float* Ds, const bf16x8 (&kfb)[DP / 16], const bf16x8 (&vfb)[DP / 16],
+template <int DP, class L = LayWide>
+__device__ __forceinline__ void lse_dkdv_block(const char* bufq, const char* bufd, const float* Ls, const float* Ds, const bf16x8 (&kfb)[L::template ksteps<DP>()], const bf16x8 (&vfb)[L::template ksteps<DP>()],
                                                float scale, int S, int nblk, int kb, int kg, int ql, const int (&toff0)[DP / 32], const int (&toff1)[DP / 32],
                                                f32x16 (&dk)[DP / 32], f32x16 (&dv)[DP / 32]) {
-  constexpr int KSTEPS = DP / 16, DB = DP / 32;
+  constexpr int KSTEPS = L::template ksteps<DP>(), DB = DP / 32;
   const int key = kb * 32 + ql;
   const bool live = kb * 32 + 32 <= S;   // every key of the block is a real one (wave-uniform): the common case takes no per-element select
   for (int qb = 0; qb < nblk; qb++) {
@@ -374,9 +398,8 @@ __device__ __forceinline__ void lse_dkdv_block(const char* bufq, const char* buf
     bf16x8 qfr[KSTEPS], dor[KSTEPS];
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; kk++) {
-      const int off = lds_off(qrow, kk * 2 + kg);
-      qfr[kk] = *reinterpret_cast<const bf16x8*>(bufq + off);
-      dor[kk] = *reinterpret_cast<const bf16x8*>(bufd + off);
+      qfr[kk] = L::frag(bufq, qrow, kk, kg);
+      dor[kk] = L::frag(bufd, qrow, kk, kg);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -405,7 +428,7 @@ __device__ __forceinline__ void lse_dkdv_block(const char* bufq, const char* buf
     union { bf16x8 v; s16x4 hlf[2]; } dft[2][DB], qft[2][DB];
 #pragma unroll
     for (int db = 0; db < DB; db++) {
-      const int rbase = (qb * 2) * 16 * PITCH;
+      const int rbase = (qb * 2) * 16 * L::PITCH_;
       dft[0][db].hlf[0] = tr_read(bufd + rbase + toff0[db]);
       dft[0][db].hlf[1] = tr_read(bufd + rbase + toff1[db]);
       qft[0][db].hlf[0] = tr_read(bufq + rbase + toff0[db]);
@@ -417,7 +440,7 @@ __device__ __forceinline__ void lse_dkdv_block(const char* bufq, const char* buf
     to_afrag(dp, dsf);
 #pragma unroll
     for (int db = 0; db < DB; db++) {
-      const int rbase = (qb * 2 + 1) * 16 * PITCH;
+      const int rbase = (qb * 2 + 1) * 16 * L::PITCH_;
       dft[1][db].hlf[0] = tr_read(bufd + rbase + toff0[db]);
       dft[1][db].hlf[1] = tr_read(bufd + rbase + toff1[db]);
       qft[1][db].hlf[0] = tr_read(bufq + rbase + toff0[db]);
@@ -587,6 +610,157 @@ __global__ __launch_bounds__(512) void attention_bwd_lse_kernel(Args a) {
         const int dcol = db * 32 + ql;
         if (ko < S) {
           dkg[(size_t)ko * a.k_rs + dcol] = (bf16)dk[db][r];
+          if (dcol < D) dvg[(size_t)ko * a.v_rs + dcol] = (bf16)dv[db][r];
+        }
+      }
+  }
+#endif
+}
+
+// 72-channel heads, S <= 256, two or more (batch, head) items per CU: the same backward on the TIGHT layout (LayTight: 144-B rows, two images = 73.7 KB) with FOUR waves
+// per workgroup, so that two workgroups are resident per CU (8 waves, two per SIMD, as before) and run out of phase: one's staging, fragment loads and stores fall
+// under the other's loops -- the memory phases were 62 % of attention_bwd_lse_kernel's cycles with nothing resident to hide them.  A wave owns two 32-query blocks in
+// phase A and two 32-key blocks in phase B.  Same products in the same order on the same values (the skipped K steps multiply zeros): same bits.
+__global__ __launch_bounds__(256, 2) void attention_bwd_lse_tight_kernel(Args a) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int DP = 96, KE = 5, DB = DP / 32, CH = 9, NT = 256, NW = NT / 64, ROWS = 256, TB = ROWS * 144, SWEEPS = ROWS * CH / NT;   // KE: K steps of 16 channels that hold data
+  using L = LayTight;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* buf0 = smem;                    // phase A: K, phase B: Q
+  char* buf1 = smem + TB;               // phase A: V, phase B: dO
+  float* Ls = reinterpret_cast<float*>(smem + 2 * TB);   // [256] L_q; +inf for padded queries
+  float* Ds = Ls + ROWS;                                  // [256] delta
+  const int S = a.S, H = a.H, D = a.D, C = H * D;
+  const int bh = a.xcd ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16* qg = a.q + b * a.q_bs + h * a.q_hs;
+  const bf16* kg_ = a.k + b * a.k_bs + h * a.k_hs;
+  const bf16* vg = a.v + b * a.v_bs + h * a.v_hs;
+  const bf16* og = a.o + (size_t)b * S * C + h * D;
+  const bf16* dog = a.dout + (size_t)b * S * C + h * D;
+  const float* lse = a.lse + (size_t)bh * S;
+  const int nblk = (S + 31) >> 5;
+  const int rows_staged = nblk * 32;
+
+  auto stage = [&](const bf16* s0, int rs0, const bf16* s1, int rs1) {      // nine 16-B chunks (72 channels) of every row of both operands
+    uint4 x[SWEEPS], y[SWEEPS];
+#pragma unroll
+    for (int it = 0; it < SWEEPS; it++) {
+      const int i = tid + it * NT, row = i / CH, c = i - row * CH;
+      x[it] = uint4{0, 0, 0, 0}; y[it] = uint4{0, 0, 0, 0};
+      if (row < S) {
+        x[it] = *reinterpret_cast<const uint4*>(s0 + (size_t)row * rs0 + c * 8);
+        y[it] = *reinterpret_cast<const uint4*>(s1 + (size_t)row * rs1 + c * 8);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < SWEEPS; it++) {
+      const int i = tid + it * NT, row = i / CH, c = i - row * CH;
+      if (row < rows_staged) {
+        const int off = L::off(row, c);
+        *reinterpret_cast<uint4*>(buf0 + off) = x[it];
+        *reinterpret_cast<uint4*>(buf1 + off) = y[it];
+      }
+    }
+  };
+  stage(kg_, a.k_rs, vg, a.v_rs);
+  for (int i = tid; i < ROWS; i += NT) Ls[i] = i < S ? lse[i] : INFINITY;
+  __syncthreads();
+
+  const int kg = lane >> 5, ql = lane & 31;
+  const int g16 = (lane >> 4) & 1, rr = (lane & 15) >> 2, qq = lane & 3;
+  int toff0[DB], toff1[DB];
+#pragma unroll
+  for (int db = 0; db < DB; db++) {
+    const int chunk = db * 4 + g16 * 2 + (qq >> 1);
+    toff0[db] = L::off(kg * 8 + rr, chunk) + (qq & 1) * 8;
+    toff1[db] = L::off(kg * 8 + rr + 4, chunk) + (qq & 1) * 8;
+  }
+  const float scale = a.scale;
+  const bf16 zero16 = (bf16)0.f;
+
+  // ================= phase A: per 32-query block -- delta, dQ ========================================================================================
+  for (int qb = wave; qb < nblk; qb += NW) {
+    const int q = qb * 32 + ql;
+    bf16x8 qf[KE], dof[KE];
+    float delta = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KE; kk++) {
+      uint4 tq = {0, 0, 0, 0}, td = {0, 0, 0, 0}, to = {0, 0, 0, 0};
+      const int d0 = kk * 16 + kg * 8;
+      if (q < S) {
+        tq = *reinterpret_cast<const uint4*>(qg + (size_t)q * a.q_rs + d0);
+        if (d0 < D) {
+          td = *reinterpret_cast<const uint4*>(dog + (size_t)q * C + d0);
+          to = *reinterpret_cast<const uint4*>(og + (size_t)q * C + d0);
+        }
+      }
+      qf[kk] = *reinterpret_cast<bf16x8*>(&tq);
+      dof[kk] = *reinterpret_cast<bf16x8*>(&td);
+      delta += dot8(td, to);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    if (kg == 0) Ds[q] = delta;
+    const float Lq = Ls[q];                 // +inf for a padded query: every P of its column is 0
+    f32x16 dq[DB];
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) dq[db][r] = 0.f;
+    lse_dq_block<DP, L>(buf0, buf1, qf, dof, Lq, delta, scale, S, nblk, kg, ql, toff0, toff1, dq);
+    bf16* dqg = a.dq + b * a.q_bs + h * a.q_hs;
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int qo = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        const int dcol = db * 32 + ql;
+        if (qo < S) dqg[(size_t)qo * a.q_rs + dcol] = dcol < D ? (bf16)dq[db][r] : zero16;      // the padded channels: zeros, as the wide products give them
+      }
+  }
+  // ================= phase B: Q and dO resident; per 32-key block -- dK, dV ===========================================================================
+  // The wave's first key block takes its K / V fragments from the LDS image of phase A before Q / dO are staged over it; its second block reads global.
+  bf16x8 kfb[KE], vfb[KE];
+  {
+    const int key = wave * 32 + ql;
+#pragma unroll
+    for (int kk = 0; kk < KE; kk++) { kfb[kk] = L::frag(buf0, key, kk, kg); vfb[kk] = L::frag(buf1, key, kk, kg); }
+  }
+  __syncthreads();
+  stage(qg, a.q_rs, dog, C);
+  __syncthreads();
+  for (int kb = wave; kb < nblk; kb += NW) {
+    const int key = kb * 32 + ql;
+    if (kb != wave) {
+#pragma unroll
+      for (int kk = 0; kk < KE; kk++) {
+        uint4 tk = {0, 0, 0, 0}, tv = {0, 0, 0, 0};
+        const int d0 = kk * 16 + kg * 8;
+        if (key < S) {
+          tk = *reinterpret_cast<const uint4*>(kg_ + (size_t)key * a.k_rs + d0);
+          if (d0 < D) tv = *reinterpret_cast<const uint4*>(vg + (size_t)key * a.v_rs + d0);
+        }
+        kfb[kk] = *reinterpret_cast<bf16x8*>(&tk);
+        vfb[kk] = *reinterpret_cast<bf16x8*>(&tv);
+      }
+    }
+    f32x16 dk[DB], dv[DB];
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    lse_dkdv_block<DP, L>(buf0, buf1, Ls, Ds, kfb, vfb, scale, S, nblk, kb, kg, ql, toff0, toff1, dk, dv);
+    bf16* dkg = a.dk + b * a.k_bs + h * a.k_hs;
+    bf16* dvg = a.dv + b * a.v_bs + h * a.v_hs;
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        const int dcol = db * 32 + ql;
+        if (ko < S) {
+          dkg[(size_t)ko * a.k_rs + dcol] = dcol < D ? (bf16)dk[db][r] : zero16;
           if (dcol < D) dvg[(size_t)ko * a.v_rs + dcol] = (bf16)dv[db][r];
         }
       }
@@ -775,6 +949,20 @@ static int launch(const Args& a, int batch, hipStream_t stream) {
     b_.xcd = xcd;
     // measured (profiles/r5_attention_3buf_ab.txt): 5 % faster at 256 and 512 (batch, head) blocks, 4 % slower at 1 024 -- with four rounds per CU the kernel is in
     // its bandwidth-bound regime and the larger load burst at the head of every block costs more than the hidden latency returns
+    static const int tight = [] { const char* e = getenv("DMVAE_ATTN_BWD_TIGHT"); return !(e && e[0] == '0') ? 1 : 0; }();
+    if constexpr (DP == 96) {
+      if (tight && a.D == 72 && a.S <= 256 && batch * a.H >= 512) {     // two or more items per CU: two out-of-phase 4-wave workgroups per CU on the 144-B layout
+        constexpr int ldst = 2 * 256 * 144 + 2 * 256 * (int)sizeof(float);
+        static bool attrt_done = false;
+        if (!attrt_done) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_lse_tight_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldst);
+          attrt_done = true;
+        }
+        hipLaunchKernelGGL(attention_bwd_lse_tight_kernel, dim3(batch * a.H), dim3(256), ldst, stream, b_);
+        DMVAE_CHECK_LAUNCH();
+        return 0;
+      }
+    }
     if (three && a.S <= ROWS3 && batch * a.H <= 512) {
       constexpr int lds3 = 3 * BUF3 + 2 * ROWS3 * (int)sizeof(float);
       static bool attr3_done = false;
