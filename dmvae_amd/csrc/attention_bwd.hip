@@ -34,6 +34,7 @@ struct Args {
   long long q_bs, q_hs, k_bs, k_hs, v_bs, v_hs;
   int q_rs, k_rs, v_rs;
   int S, H, D;
+  int QD;                        // channels a q / k / dq / dk row holds: DP (zero-padded by the producer) or D itself (rows 2 D bytes apart: chunks past QD are neither loaded nor stored)
   float scale;
   const float* lse;              // attention_bwd_lse_kernel: [B * H][S] f32, scale * max + log(sum) of every query's scaled scores (the forward kernel writes it)
   int xcd;                       // 1: block -> (batch, head) through xcd_remap (vit.hip::AttnArgs::xcd)
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Args a) {
       *reinterpret_cast<uint4*>(buf1 + off) = y;
     }
   };
-  stage(kg_, a.k_rs, CH, vg, a.v_rs, dchunks);
+  stage(kg_, a.k_rs, a.QD / 8, vg, a.v_rs, dchunks);
   __syncthreads();
 
   const int kg = lane >> 5, ql = lane & 31;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Args a) {
       uint4 tq = {0, 0, 0, 0}, td = {0, 0, 0, 0}, to = {0, 0, 0, 0};
       const int d0 = kk * 16 + kg * 8;
       if (q < S) {
-        tq = *reinterpret_cast<const uint4*>(qg + (size_t)q * a.q_rs + d0);
+        if (d0 < a.QD) tq = *reinterpret_cast<const uint4*>(qg + (size_t)q * a.q_rs + d0);
         if (d0 < D) {
           td = *reinterpret_cast<const uint4*>(dog + (size_t)q * C + d0);
           to = *reinterpret_cast<const uint4*>(og + (size_t)q * C + d0);
@@ -237,12 +238,12 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Args a) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int qo = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        if (qo < S) dqg[(size_t)qo * a.q_rs + db * 32 + ql] = (bf16)dq[db][r];
+        if (qo < S && db * 32 + ql < a.QD) dqg[(size_t)qo * a.q_rs + db * 32 + ql] = (bf16)dq[db][r];
       }
   }
   __syncthreads();
   // ================= phase B: Q and dO resident; per 32-key block -- dK, dV ===========================================================================
-  stage(qg, a.q_rs, CH, dog, C, dchunks);
+  stage(qg, a.q_rs, a.QD / 8, dog, C, dchunks);
   __syncthreads();
   for (int kb = wave; kb < nblk; kb += 4) {
     const int key = kb * 32 + ql;
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Args a) {
       uint4 tk = {0, 0, 0, 0}, tv = {0, 0, 0, 0};
       const int d0 = kk * 16 + kg * 8;
       if (key < S) {
-        tk = *reinterpret_cast<const uint4*>(kg_ + (size_t)key * a.k_rs + d0);
+        if (d0 < a.QD) tk = *reinterpret_cast<const uint4*>(kg_ + (size_t)key * a.k_rs + d0);
         if (d0 < D) tv = *reinterpret_cast<const uint4*>(vg + (size_t)key * a.v_rs + d0);
       }
       kfb[kk] = *reinterpret_cast<bf16x8*>(&tk);
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(Args a) {
         const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
         const int dcol = db * 32 + ql;
         if (ko < S) {
-          dkg[(size_t)ko * a.k_rs + dcol] = (bf16)dk[db][r];
+          if (dcol < a.QD) dkg[(size_t)ko * a.k_rs + dcol] = (bf16)dk[db][r];
           if (dcol < D) dvg[(size_t)ko * a.v_rs + dcol] = (bf16)dv[db][r];
         }
       }
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(512) void attention_bwd_lse_kernel(Args a) {
       }
     }
   };
-  stage(kg_, a.k_rs, CH, vg, a.v_rs, dchunks);
+  stage(kg_, a.k_rs, a.QD / 8, vg, a.v_rs, dchunks);
   for (int i = tid; i < KEYS; i += NT) Ls[i] = i < S ? lse[i] : INFINITY;
   __syncthreads();
 
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(512) void attention_bwd_lse_kernel(Args a) {
       uint4 tq = {0, 0, 0, 0}, td = {0, 0, 0, 0}, to = {0, 0, 0, 0};
       const int d0 = kk * 16 + kg * 8;
       if (q < S) {
-        tq = *reinterpret_cast<const uint4*>(qg + (size_t)q * a.q_rs + d0);
+        if (d0 < a.QD) tq = *reinterpret_cast<const uint4*>(qg + (size_t)q * a.q_rs + d0);
         if (d0 < D) {
           td = *reinterpret_cast<const uint4*>(dog + (size_t)q * C + d0);
           to = *reinterpret_cast<const uint4*>(og + (size_t)q * C + d0);
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(512) void attention_bwd_lse_kernel(Args a) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int qo = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        if (qo < S) dqg[(size_t)qo * a.q_rs + db * 32 + ql] = (bf16)dq[db][r];
+        if (qo < S && db * 32 + ql < a.QD) dqg[(size_t)qo * a.q_rs + db * 32 + ql] = (bf16)dq[db][r];
       }
   }
   // ================= phase B: Q and dO resident; per 32-key block -- dK, dV ===========================================================================
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(512) void attention_bwd_lse_kernel(Args a) {
     }
   }
   __syncthreads();
-  stage(qg, a.q_rs, CH, dog, C, dchunks);
+  stage(qg, a.q_rs, a.QD / 8, dog, C, dchunks);
   __syncthreads();
   for (int kb = wave; kb < nblk; kb += NW) {
     const int key = kb * 32 + ql;
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(512) void attention_bwd_lse_kernel(Args a) {
         uint4 tk = {0, 0, 0, 0}, tv = {0, 0, 0, 0};
         const int d0 = kk * 16 + kg * 8;
         if (key < S) {
-          tk = *reinterpret_cast<const uint4*>(kg_ + (size_t)key * a.k_rs + d0);
+          if (d0 < a.QD) tk = *reinterpret_cast<const uint4*>(kg_ + (size_t)key * a.k_rs + d0);
           if (d0 < D) tv = *reinterpret_cast<const uint4*>(vg + (size_t)key * a.v_rs + d0);
         }
         kfb[kk] = *reinterpret_cast<bf16x8*>(&tk);
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(512) void attention_bwd_lse_kernel(Args a) {
         const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
         const int dcol = db * 32 + ql;
         if (ko < S) {
-          dkg[(size_t)ko * a.k_rs + dcol] = (bf16)dk[db][r];
+          if (dcol < a.QD) dkg[(size_t)ko * a.k_rs + dcol] = (bf16)dk[db][r];
           if (dcol < D) dvg[(size_t)ko * a.v_rs + dcol] = (bf16)dv[db][r];
         }
       }
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_lse_tight_kernel(Args a)
       uint4 tq = {0, 0, 0, 0}, td = {0, 0, 0, 0}, to = {0, 0, 0, 0};
       const int d0 = kk * 16 + kg * 8;
       if (q < S) {
-        tq = *reinterpret_cast<const uint4*>(qg + (size_t)q * a.q_rs + d0);
+        if (d0 < a.QD) tq = *reinterpret_cast<const uint4*>(qg + (size_t)q * a.q_rs + d0);
         if (d0 < D) {
           td = *reinterpret_cast<const uint4*>(dog + (size_t)q * C + d0);
           to = *reinterpret_cast<const uint4*>(og + (size_t)q * C + d0);
@@ -716,7 +717,7 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_lse_tight_kernel(Args a)
       for (int r = 0; r < 16; r++) {
         const int qo = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
         const int dcol = db * 32 + ql;
-        if (qo < S) dqg[(size_t)qo * a.q_rs + dcol] = dcol < D ? (bf16)dq[db][r] : zero16;      // the padded channels: zeros, as the wide products give them
+        if (qo < S && dcol < a.QD) dqg[(size_t)qo * a.q_rs + dcol] = dcol < D ? (bf16)dq[db][r] : zero16;      // padded channels a row holds: zeros, as the wide products give them
       }
   }
   // ================= phase B: Q and dO resident; per 32-key block -- dK, dV ===========================================================================
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_lse_tight_kernel(Args a)
         uint4 tk = {0, 0, 0, 0}, tv = {0, 0, 0, 0};
         const int d0 = kk * 16 + kg * 8;
         if (key < S) {
-          tk = *reinterpret_cast<const uint4*>(kg_ + (size_t)key * a.k_rs + d0);
+          if (d0 < a.QD) tk = *reinterpret_cast<const uint4*>(kg_ + (size_t)key * a.k_rs + d0);
           if (d0 < D) tv = *reinterpret_cast<const uint4*>(vg + (size_t)key * a.v_rs + d0);
         }
         kfb[kk] = *reinterpret_cast<bf16x8*>(&tk);
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_lse_tight_kernel(Args a)
         const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
         const int dcol = db * 32 + ql;
         if (ko < S) {
-          dkg[(size_t)ko * a.k_rs + dcol] = dcol < D ? (bf16)dk[db][r] : zero16;
+          if (dcol < a.QD) dkg[(size_t)ko * a.k_rs + dcol] = dcol < D ? (bf16)dk[db][r] : zero16;
           if (dcol < D) dvg[(size_t)ko * a.v_rs + dcol] = (bf16)dv[db][r];
         }
       }
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(512) void attention_bwd_lse3_kernel(Args a) {
     const int i = tid + it * NT, row = i / CH, c = i - row * CH;
     xk[it] = uint4{0, 0, 0, 0}; xv[it] = uint4{0, 0, 0, 0}; xd[it] = uint4{0, 0, 0, 0};
     if (row < S) {
-      xk[it] = *reinterpret_cast<const uint4*>(kg_ + (size_t)row * a.k_rs + c * 8);
+      if (c < a.QD / 8) xk[it] = *reinterpret_cast<const uint4*>(kg_ + (size_t)row * a.k_rs + c * 8);
       if (c < dchunks) {
         xv[it] = *reinterpret_cast<const uint4*>(vg + (size_t)row * a.v_rs + c * 8);
         xd[it] = *reinterpret_cast<const uint4*>(dog + (size_t)row * C + c * 8);
@@ -822,7 +823,7 @@ __global__ __launch_bounds__(512) void attention_bwd_lse3_kernel(Args a) {
     const int d0 = kk * 16 + kg * 8;
     tq[kk] = uint4{0, 0, 0, 0}; to[kk] = uint4{0, 0, 0, 0};
     if (q < S) {
-      tq[kk] = *reinterpret_cast<const uint4*>(qg + (size_t)q * a.q_rs + d0);
+      if (d0 < a.QD) tq[kk] = *reinterpret_cast<const uint4*>(qg + (size_t)q * a.q_rs + d0);
       if (d0 < D) to[kk] = *reinterpret_cast<const uint4*>(og + (size_t)q * C + d0);
     }
   }
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(512) void attention_bwd_lse3_kernel(Args a) {
   for (int it = 0; it < SW; it++) {
     const int i = tid + it * NT, row = i / CH, c = i - row * CH;
     xq[it] = uint4{0, 0, 0, 0};
-    if (row < S) xq[it] = *reinterpret_cast<const uint4*>(qg + (size_t)row * a.q_rs + c * 8);
+    if (row < S && c < a.QD / 8) xq[it] = *reinterpret_cast<const uint4*>(qg + (size_t)row * a.q_rs + c * 8);
   }
 
   const int g16 = (lane >> 4) & 1, rr = (lane & 15) >> 2, qq = lane & 3;
@@ -883,7 +884,7 @@ __global__ __launch_bounds__(512) void attention_bwd_lse3_kernel(Args a) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int qo = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        if (qo < S) dqg[(size_t)qo * a.q_rs + db * 32 + ql] = (bf16)dq[db][r];
+        if (qo < S && db * 32 + ql < a.QD) dqg[(size_t)qo * a.q_rs + db * 32 + ql] = (bf16)dq[db][r];
       }
   }
   // ================= phase B: the wave's 32-key block -- dK, dV; its K / V fragments from the images before Q goes over K ================================
@@ -921,7 +922,7 @@ __global__ __launch_bounds__(512) void attention_bwd_lse3_kernel(Args a) {
         const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
         const int dcol = db * 32 + ql;
         if (ko < S) {
-          dkg[(size_t)ko * a.k_rs + dcol] = (bf16)dk[db][r];
+          if (dcol < a.QD) dkg[(size_t)ko * a.k_rs + dcol] = (bf16)dk[db][r];
           if (dcol < D) dvg[(size_t)ko * a.v_rs + dcol] = (bf16)dv[db][r];
         }
       }
@@ -1001,7 +1002,7 @@ extern "C" int dmvae_attention_bwd_qkv_lse_bf16(const void* qkv, const void* out
   a.o = (const bf16*)out; a.dout = (const bf16*)dout;
   a.q_bs = a.k_bs = a.v_bs = (long long)seq * 3 * C; a.q_hs = a.k_hs = a.v_hs = head_dim;
   a.q_rs = a.k_rs = a.v_rs = (int)(3 * C);
-  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale; a.lse = (const float*)lse;
+  a.S = seq; a.H = heads; a.D = head_dim; a.QD = head_dim; a.scale = scale; a.lse = (const float*)lse;
   return launch<64>(a, batch, stream);
 }
 
@@ -1015,14 +1016,16 @@ extern "C" int dmvae_attention_bwd_heads_lse_bf16(const void* q, const void* k, 
                                                   void* dv, int batch, int seq, int heads, int head_dim, int head_dim_padded, float scale, hipStream_t stream) {
   using namespace dmvae_attn_bwd;
   DMVAE_CHECK_ARG(q && k && v && out && dout && dq && dk && dv && batch > 0 && heads > 0 && seq > 0, "attention_bwd_heads_bf16: bad argument");
-  DMVAE_CHECK_ARG(seq <= KEYS && head_dim % 8 == 0 && head_dim <= head_dim_padded && (head_dim_padded == 64 || head_dim_padded == 96),
-                  "attention_bwd_heads_bf16: needs seq <= 288, head_dim %% 8 == 0, padded head dim 64 or 96 (got %d, %d, %d)", seq, head_dim, head_dim_padded);
+  const int dpc = (head_dim_padded + 31) / 32 * 32;      // q / k / dq / dk rows of 64 / 96 channels (zero-padded) or of head_dim channels (vit.hip: dmvae_attention_heads_lse_bf16)
+  DMVAE_CHECK_ARG(seq <= KEYS && head_dim % 8 == 0 && head_dim <= head_dim_padded && (head_dim_padded == 64 || head_dim_padded == 96 || head_dim_padded == head_dim) &&
+                  (dpc == 64 || dpc == 96),
+                  "attention_bwd_heads_bf16: needs seq <= 288, head_dim %% 8 == 0, q / k rows of 64, 96 or head_dim <= 96 channels (got %d, %d, %d)", seq, head_dim, head_dim_padded);
   Args a = {};
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (const bf16*)out; a.dout = (const bf16*)dout;
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv;
   a.q_hs = a.k_hs = (long long)seq * head_dim_padded; a.q_bs = a.k_bs = a.q_hs * heads;
   a.v_hs = (long long)seq * head_dim; a.v_bs = a.v_hs * heads;
   a.q_rs = a.k_rs = head_dim_padded; a.v_rs = head_dim;
-  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale; a.lse = (const float*)lse;
-  return head_dim_padded == 64 ? launch<64>(a, batch, stream) : launch<96>(a, batch, stream);
+  a.S = seq; a.H = heads; a.D = head_dim; a.QD = head_dim_padded; a.scale = scale; a.lse = (const float*)lse;
+  return dpc == 64 ? launch<64>(a, batch, stream) : launch<96>(a, batch, stream);
 }

@@ -188,6 +188,8 @@ struct AttnArgs {
   long long q_bs, q_hs, k_bs, k_hs, v_bs, v_hs;
   int q_rs, k_rs, v_rs;
   int S, H, D;
+  int QD;          // channels a q / k row HOLDS (non-NR forms): the staged width DP (rows zero-padded by the producer), or D itself -- rows of 72 channels, 144 B apart, whose
+                   // channels D .. DP - 1 are zeros by construction (a chunk past QD is not loaded); NR forms read rows of D channels out of the packed qkv
   float scale;
   int BH;          // batch * heads: blocks past it are the single-query blocks (eight (batch, head) pairs each)
   int xcd;         // 1: block -> (batch, head) through xcd_remap, so that the blocks resident on one XCD are CONSECUTIVE heads of the same samples and the 128-B lines
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attention_kernel(AttnArgs a) {
     for (int it = 0; it < SWEEPS; it++) {
       const int i = tid + it * NT, key = i / (DP / 8), c = i - key * (DP / 8);
       const bool ok = i < ATT_KEYS * (DP / 8) && key < S;
-      voK[it] = ok ? (unsigned)key * (unsigned)a.k_rs * 2u + (unsigned)c * 16u : 0x80000000u;
+      voK[it] = ok && c < a.QD / 8 ? (unsigned)key * (unsigned)a.k_rs * 2u + (unsigned)c * 16u : 0x80000000u;
       voV[it] = ok && c < vchunks ? (unsigned)key * (unsigned)a.v_rs * 2u + (unsigned)c * 16u : 0x80000000u;
     }
   }
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attention_kernel(AttnArgs a) {
       const int i = tid + it * NT, key = i / (DP / 8), c = i - key * (DP / 8);
       kv[it] = uint4{0, 0, 0, 0}; vv[it] = uint4{0, 0, 0, 0};
       if (i < ATT_KEYS * (DP / 8) && key < S) {
-        kv[it] = *reinterpret_cast<const uint4*>(kp + (size_t)key * a.k_rs + c * 8);
+        if (c < a.QD / 8) kv[it] = *reinterpret_cast<const uint4*>(kp + (size_t)key * a.k_rs + c * 8);
         if (c < vchunks) vv[it] = *reinterpret_cast<const uint4*>(vp + (size_t)key * a.v_rs + c * 8);
       }
     }
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attention_kernel(AttnArgs a) {
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; kk++) {
       uint4 t = {0, 0, 0, 0};
-      if (q < Sq && (!NR || kk * 16 + kg * 8 < a.D)) t = *reinterpret_cast<const uint4*>(qb_ + (size_t)q * a.q_rs + kk * 16 + kg * 8);
+      if (q < Sq && kk * 16 + kg * 8 < (NR ? a.D : a.QD)) t = *reinterpret_cast<const uint4*>(qb_ + (size_t)q * a.q_rs + kk * 16 + kg * 8);
       qf[kk] = *reinterpret_cast<bf16x8*>(&t);
     }
     if constexpr (PIPE) {
@@ -511,7 +513,7 @@ extern "C" int dmvae_attention_qkv_lse_bf16(const void* qkv, void* out, void* ls
   a.q = (const bf16*)qkv; a.k = a.q + C; a.v = a.q + 2 * C; a.out = (bf16*)out;
   a.q_bs = a.k_bs = a.v_bs = (long long)seq * 3 * C; a.q_hs = a.k_hs = a.v_hs = head_dim;
   a.q_rs = a.k_rs = a.v_rs = (int)(3 * C);
-  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale; a.lse = (float*)lse;
+  a.S = seq; a.H = heads; a.D = head_dim; a.QD = head_dim; a.scale = scale; a.lse = (float*)lse;
   return launch_attention<64>(a, batch, stream);
 }
 
@@ -526,15 +528,18 @@ extern "C" int dmvae_attention_heads_lse_bf16(const void* q, const void* k, cons
                                               int head_dim_padded, float scale, hipStream_t stream) {
   using namespace dmvae_vit;
   DMVAE_CHECK_ARG(q && k && v && out && batch > 0 && heads > 0 && seq > 0, "attention_heads_bf16: bad argument");
-  DMVAE_CHECK_ARG(seq <= ATT_KEYS && head_dim % 8 == 0 && head_dim <= head_dim_padded && (head_dim_padded == 64 || head_dim_padded == 96),
-                  "attention_heads_bf16: needs seq <= 288, head_dim %% 8 == 0, padded head dim 64 or 96 (got %d, %d, %d)", seq, head_dim, head_dim_padded);
+  // q / k rows: head_dim_padded channels -- 64 / 96 (zero-padded by the producer), or head_dim itself (no padding in memory; the kernels' 96-wide products see zeros)
+  const int dpc = (head_dim_padded + 31) / 32 * 32;
+  DMVAE_CHECK_ARG(seq <= ATT_KEYS && head_dim % 8 == 0 && head_dim <= head_dim_padded && (head_dim_padded == 64 || head_dim_padded == 96 || head_dim_padded == head_dim) &&
+                  (dpc == 64 || dpc == 96),
+                  "attention_heads_bf16: needs seq <= 288, head_dim %% 8 == 0, q / k rows of 64, 96 or head_dim <= 96 channels (got %d, %d, %d)", seq, head_dim, head_dim_padded);
   AttnArgs a = {};
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out;
   a.q_hs = a.k_hs = (long long)seq * head_dim_padded; a.q_bs = a.k_bs = a.q_hs * heads;
   a.v_hs = (long long)seq * head_dim; a.v_bs = a.v_hs * heads;
   a.q_rs = a.k_rs = head_dim_padded; a.v_rs = head_dim;
-  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale; a.lse = (float*)lse;
-  return head_dim_padded == 64 ? launch_attention<64>(a, batch, stream) : launch_attention<96>(a, batch, stream);
+  a.S = seq; a.H = heads; a.D = head_dim; a.QD = head_dim_padded; a.scale = scale; a.lse = (float*)lse;
+  return dpc == 64 ? launch_attention<64>(a, batch, stream) : launch_attention<96>(a, batch, stream);
 }
 
 // LightningDiT's attention straight from the qkv Linear's output [B][N][3][H][D]: QK RMSNorm + weight, 2-D RoPE (what dmvae_qknorm_rope_bf16 does) applied
@@ -550,7 +555,7 @@ extern "C" int dmvae_attention_qknorm_rope_bf16(const void* qkv, const void* q_w
   a.q = (const bf16*)qkv; a.k = a.q + C; a.v = a.q + 2 * C; a.out = (bf16*)out;
   a.q_bs = a.k_bs = a.v_bs = (long long)seq * 3 * C; a.q_hs = a.k_hs = a.v_hs = head_dim;
   a.q_rs = a.k_rs = a.v_rs = (int)(3 * C);
-  a.S = seq; a.H = heads; a.D = head_dim; a.scale = scale;
+  a.S = seq; a.H = heads; a.D = head_dim; a.QD = head_dim; a.scale = scale;
   a.qw = (const float*)q_weight; a.kw = (const float*)k_weight; a.cosb = (const float*)cos_table; a.sinb = (const float*)sin_table; a.eps = eps;
   return head_dim <= 64 ? launch_attention<64, true>(a, batch, stream) : launch_attention<96, true>(a, batch, stream);
 }

@@ -1042,6 +1042,7 @@ class SiluFn(torch.autograd.Function):
 
 
 ATTN_BWD_LSE = True        # the forward attention kernels also write the row statistics and the backward takes the eight-wave form built on them (False: recomputed; tests compare)
+QK_UNPADDED = os.environ.get("DMVAE_QK_UNPADDED", "1") != "0"      # DitStackFn: q / k (and dq / dk) rows of D = 72 channels instead of 96 zero-padded ones between QK-norm + RoPE and the attention kernels (0: padded, for A/B)
 ATTN_BWD_FUSED = True      # False: the GEMM-composed attention backward (probabilities through HBM; the first implementation) -- tests compare the two
 THIN_CIN_BWD_AS_GEMM = True      # ConvFn.backward of a 3x3 conv from 32 / 64 channels: weight and input gradient as GEMMs on the im2col form
 NORM_CONV_OUT_FUSED_FWD = True      # NormConvOutFn.forward: ops.norm_conv_out_fwd where the shape allows
@@ -1318,7 +1319,7 @@ class DitStackFn(torch.autograd.Function):
             else:
                 h_in, a1 = ops.gated_residual_out(h_mid, o3, mod_all[i - 1], 5 * c, n1w, mod, 0, c, eps)
             qkv = linear(a1, qkvw, qkvb)
-            q, k, v = ops.qknorm_rope(qkv, qnw, knw, cos, sin, heads, eps)
+            q, k, v = ops.qknorm_rope(qkv, qnw, knw, cos, sin, heads, eps, padded=not QK_UNPADDED)
             if ATTN_BWD_LSE:
                 o, lse = ops.attention_heads(q, k, v, b, d ** -0.5, need_lse=True)
                 lses.append(lse)

@@ -1248,12 +1248,13 @@ def gated_residual_out(x: torch.Tensor, r: torch.Tensor, gate_mod: torch.Tensor,
     return xo, y
 
 
-def qknorm_rope(qkv: torch.Tensor, qw: torch.Tensor, kw: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, eps: float = 1e-6):
-    """qkv [B,N,3*H*D] bf16 -> (q, k [B*H, N, Dp] with Dp = D rounded up to 32, v [B*H, N, D]): per-head RMSNorm * weight + 2-D RoPE on q and k."""
+def qknorm_rope(qkv: torch.Tensor, qw: torch.Tensor, kw: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, eps: float = 1e-6, padded: bool = True):
+    """qkv [B,N,3*H*D] bf16 -> (q, k [B*H, N, Dp] with Dp = D rounded up to 32, v [B*H, N, D]): per-head RMSNorm * weight + 2-D RoPE on q and k.  padded=False
+    (D a multiple of 8): q, k rows of D channels -- the fused attention kernels then load and store D of their 96 channels (a quarter fewer q / k bytes at D = 72)."""
     qkv = _req(qkv, bf16, "qkv")
     b, n, c3 = qkv.shape
     d = c3 // 3 // heads
-    dp = (d + 31) // 32 * 32
+    dp = (d + 31) // 32 * 32 if (padded or d % 8) else d
     q = torch.empty(b * heads, n, dp, dtype=bf16, device=qkv.device)
     k = torch.empty_like(q)
     v = torch.empty(b * heads, n, d, dtype=bf16, device=qkv.device)

@@ -421,8 +421,8 @@ int dmvae_attention_qkv_bf16(const void* qkv, void* out, int batch, int seq, int
                              dmvae_stream_t stream);
 /* The same fused kernel on head-major operands: q, k [batch*heads][seq][head_dim_padded] (channels >= head_dim zero), v
  * [batch*heads][seq][head_dim] bf16 -- what dmvae_qknorm_rope_bf16 produces -> out [batch][seq][heads*head_dim].  LightningDiT's
- * attention after QK-norm + RoPE (models/lightningdit.py:64-98, F.scaled_dot_product_attention); head_dim % 8 == 0, head_dim_padded 64 or 96,
- * seq <= 288. */
+ * attention after QK-norm + RoPE (models/lightningdit.py:64-98, F.scaled_dot_product_attention); head_dim % 8 == 0, seq <= 288; head_dim_padded = the channels
+ * a q / k row holds: 64 or 96, or head_dim itself (<= 96; rows without padding: the kernel does not touch the chunks past head_dim and computes the same bits). */
 int dmvae_attention_heads_bf16(const void* q, const void* k, const void* v, void* out, int batch, int seq, int heads, int head_dim,
                                int head_dim_padded, float scale, dmvae_stream_t stream);
 /* The two kernels above with the row statistics written out: lse f32 [batch * heads][seq] = scale * max_k(q.k) + log(sum_k exp(scale (q.k - max))) per query -- what
@@ -441,7 +441,7 @@ int dmvae_attention_qknorm_rope_bf16(const void* qkv, const void* q_weight, cons
  * S x S probabilities are recomputed in registers and never reach HBM.  out = the forward result [batch][seq][heads*head_dim], dout = its gradient (bf16).
  * _qkv: qkv [batch][seq][3][heads][64] -> dqkv in the same layout (every element of rows < seq written).  head_dim 64, seq <= 288.
  * _heads: q, k [batch*heads][seq][head_dim_padded], v [batch*heads][seq][head_dim] -> dq, dk, dv in the same layouts (padded channels of dq / dk
- *         come out as the zeros the padded operands imply).  head_dim % 8 == 0, head_dim_padded 64 or 96, seq <= 288. */
+ *         come out as the zeros the padded operands imply).  head_dim % 8 == 0, head_dim_padded 64, 96 or head_dim (rows without padding), seq <= 288. */
 int dmvae_attention_bwd_qkv_bf16(const void* qkv, const void* out, const void* dout, void* dqkv, int batch, int seq, int heads, int head_dim,
                                  float scale, dmvae_stream_t stream);
 int dmvae_attention_bwd_heads_bf16(const void* q, const void* k, const void* v, const void* out, const void* dout, void* dq, void* dk, void* dv,

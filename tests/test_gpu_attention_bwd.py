@@ -131,3 +131,32 @@ def test_attention_kernels_give_the_same_bits_in_every_launch_form(n, d):
         sl = slice(s0 * h, (s0 + small) * h)
         o_c, lse_c = ops.attention_heads(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), small, scale, need_lse=True)
         assert torch.equal(o_big[s0:s0 + small], o_c) and torch.equal(lse_big[sl], lse_c), f"samples {s0}..{s0 + small - 1}"
+
+
+@pytest.mark.parametrize("big,n", [(8, 256), (40, 256), (40, 200), (40, 272)])
+def test_attention_heads_with_unpadded_q_k_rows_gives_the_same_bits(big, n):
+    """q / k rows of D = 72 channels (144 B apart; `ops.qknorm_rope(padded=False)`, what `DitStackFn` hands the kernels) instead of rows zero-padded to 96: the kernels
+    neither load nor store the chunks past D, and every product sees the same zeros -- forward output, row statistics and all three gradients are bit-identical to
+    the padded call, in every launch form (128 blocks: three-image backward; 640 blocks: the pipelined forward and the two-workgroup backward, or the wide 8-wave
+    backward at 272 tokens)."""
+    from dmvae_amd import ops
+    h, d, dp = 16, 72, 96
+    g = torch.Generator().manual_seed(big + n)
+    q = torch.zeros(big * h, n, dp); k = torch.zeros(big * h, n, dp)
+    q[..., :d] = torch.randn(big * h, n, d, generator=g); k[..., :d] = torch.randn(big * h, n, d, generator=g)
+    v = torch.randn(big * h, n, d, generator=g)
+    q, k, v = (t.to(DEV).to(BF) for t in (q, k, v))
+    do = torch.randn(big, n, h * d, generator=g).to(DEV).to(BF)
+    qu, ku = q[..., :d].contiguous(), k[..., :d].contiguous()
+    scale = d ** -0.5
+    o, lse = ops.attention_heads(q, k, v, big, scale, need_lse=True)
+    ou, lseu = ops.attention_heads(qu, ku, v, big, scale, need_lse=True)
+    assert torch.equal(o, ou) and torch.equal(lse, lseu)
+    dq, dk, dv = ops.attention_bwd_heads(q, k, v, o, do, big, scale, lse=lse)
+    dqu, dku, dvu = ops.attention_bwd_heads(qu, ku, v, o, do, big, scale, lse=lse)
+    assert dqu.shape[-1] == d and torch.equal(dq[..., :d], dqu) and torch.equal(dk[..., :d], dku) and torch.equal(dv, dvu)
+    assert dq[..., d:].abs().max() == 0 and dk[..., d:].abs().max() == 0
+    if big == 8:      # the kernel without row statistics (first form), too
+        dq0, dk0, dv0 = ops.attention_bwd_heads(qu, ku, v, o, do, big, scale)
+        dq1, dk1, dv1 = ops.attention_bwd_heads(q, k, v, o, do, big, scale)
+        assert torch.equal(dq1[..., :d], dq0) and torch.equal(dk1[..., :d], dk0) and torch.equal(dv1, dv0)
