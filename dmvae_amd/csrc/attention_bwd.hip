@@ -722,11 +722,12 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_lse_tight_kernel(Args a)
   }
   // ================= phase B: Q and dO resident; per 32-key block -- dK, dV ===========================================================================
   // The wave's first key block takes its K / V fragments from the LDS image of phase A before Q / dO are staged over it; its second block reads global.
-  bf16x8 kfb[KE], vfb[KE];
+  // (the second block's K fragments too -- 20 of the registers the tight layout leaves free; its V fragments come from memory)
+  bf16x8 kfb[KE], vfb[KE], kfb2[KE];
   {
-    const int key = wave * 32 + ql;
+    const int key = wave * 32 + ql, key2 = key + NW * 32;      // key2 <= 255: inside the image whether or not the block is live
 #pragma unroll
-    for (int kk = 0; kk < KE; kk++) { kfb[kk] = L::frag(buf0, key, kk, kg); vfb[kk] = L::frag(buf1, key, kk, kg); }
+    for (int kk = 0; kk < KE; kk++) { kfb[kk] = L::frag(buf0, key, kk, kg); vfb[kk] = L::frag(buf1, key, kk, kg); kfb2[kk] = L::frag(buf0, key2, kk, kg); }
   }
   __syncthreads();
   stage(qg, a.q_rs, dog, C);
@@ -736,13 +737,10 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_lse_tight_kernel(Args a)
     if (kb != wave) {
 #pragma unroll
       for (int kk = 0; kk < KE; kk++) {
-        uint4 tk = {0, 0, 0, 0}, tv = {0, 0, 0, 0};
+        uint4 tv = {0, 0, 0, 0};
         const int d0 = kk * 16 + kg * 8;
-        if (key < S) {
-          if (d0 < a.QD) tk = *reinterpret_cast<const uint4*>(kg_ + (size_t)key * a.k_rs + d0);
-          if (d0 < D) tv = *reinterpret_cast<const uint4*>(vg + (size_t)key * a.v_rs + d0);
-        }
-        kfb[kk] = *reinterpret_cast<bf16x8*>(&tk);
+        if (key < S && d0 < D) tv = *reinterpret_cast<const uint4*>(vg + (size_t)key * a.v_rs + d0);
+        kfb[kk] = kfb2[kk];
         vfb[kk] = *reinterpret_cast<bf16x8*>(&tv);
       }
     }
